@@ -1,0 +1,175 @@
+"""Deterministic synthetic LiDAR-BA problems in the packed format of include/lvba_hip.h.
+
+Follows SURVEY.md §8(d): N poses on a closed 3-D Lissajous loop (~200 x 150 x 5 m, so world
+coordinates reach the 100 m regime where lambda_min is a 1e8:1 cancellation), V plane voxels
+each seen by k ~ 2+Poisson(3) (clipped to [2,16]) poses drawn from a band |i-home| <= W, 5 % of
+voxels also seen from the far side of the loop (home + N/2) so the pose graph is banded plus
+sparse far blocks.  Each observer contributes 15..120 points, generated in the world frame on
+the plane (1 cm thickness noise), moved to the body frame with the ground-truth pose, ROUNDED
+TO fp32 (the reference reads fp32 PCL points and widens them, bavoxel.hpp:806) and accumulated
+in fp64 into (P = sum pp^T, v = sum p, n)  -- exactly what cut_voxel/PointCluster::push produce
+(bavoxel.hpp:819-820, tools.hpp:428-433).
+
+Deviation from the survey's sketch: the initial pose perturbation is N(0,0.02 deg)/N(0,1 cm)
+instead of 0.5 deg / 5 cm, because at 30 m range 0.5 deg smears a 0.3-0.9 m plane patch by
+26 cm and the merged voxel stops being a plane (the reference front-end would never admit it:
+recut's lambda0/lambda2 test, bavoxel.hpp:351-352); the exact second-order Hessian is then
+indefinite and every LM step is rejected.  At 0.02 deg / 1 cm (LiDAR-odometry quality) LM
+converges in ~5 accepted iterations; 0.03 deg / 2 cm exercises the reject branch (tests).
+
+torch is used only as an array library + RNG so the same code runs on CPU (tests, small) and
+on the GPU (bench, 10M factors / ~700M points).  Outputs are numpy arrays.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+
+def _exp_so3(w):
+    th = w.norm(dim=-1, keepdim=True).clamp_min(1e-300)
+    k = w / th
+    K = torch.zeros(w.shape[:-1] + (3, 3), dtype=w.dtype, device=w.device)
+    K[..., 0, 1], K[..., 0, 2] = -k[..., 2], k[..., 1]
+    K[..., 1, 0], K[..., 1, 2] = k[..., 2], -k[..., 0]
+    K[..., 2, 0], K[..., 2, 1] = -k[..., 1], k[..., 0]
+    th = th[..., None]
+    I = torch.eye(3, dtype=w.dtype, device=w.device).expand_as(K)
+    return I + torch.sin(th) * K + (1 - torch.cos(th)) * (K @ K)
+
+
+def trajectory(n_poses, gen, device):
+    """Ground-truth poses T_world<-body on a closed Lissajous loop."""
+    f64 = torch.float64
+    t = torch.arange(n_poses, dtype=f64, device=device) * (2 * math.pi / n_poses)
+    p = torch.stack([100 * torch.sin(t), 75 * torch.sin(2 * t), 2.5 * torch.sin(3 * t)], -1)
+    dx, dy = 100 * torch.cos(t), 150 * torch.cos(2 * t)
+    yaw = torch.atan2(dy, dx)
+    rp = torch.randn(n_poses, 2, generator=gen, dtype=f64, device=device) * math.radians(2.0)
+    zeros = torch.zeros_like(yaw)
+    Rz = _exp_so3(torch.stack([zeros, zeros, yaw], -1))
+    Ry = _exp_so3(torch.stack([zeros, rp[:, 1], zeros], -1))
+    Rx = _exp_so3(torch.stack([rp[:, 0], zeros, zeros], -1))
+    return Rz @ Ry @ Rx, p
+
+
+def make_balm_problem(n_poses, n_voxels, *, seed=20250925, band=50, loop_frac=0.05,
+                      k_extra_mean=3.0, k_max=16, npts=(15, 120), rot_sigma_deg=0.02,
+                      trans_sigma=0.01, thickness=0.01, device="cpu", chunk=None):
+    """Returns dict(poses_gt, poses_init [N,12], voxel_off [V+1] i64, pose_idx [F] i32,
+    clusters [F,10] f64, plane_n [V,3], plane_c [V,3])."""
+    dev = torch.device(device)
+    f64 = torch.float64
+    g_struct = torch.Generator(device=dev).manual_seed(seed)
+    g_noise = torch.Generator(device=dev).manual_seed(seed + 1)
+    g_pose = torch.Generator(device=dev).manual_seed(seed + 2)
+    N, V = int(n_poses), int(n_voxels)
+
+    R_gt, p_gt = trajectory(N, g_struct, dev)
+
+    # ---- structure: home pose, observer count, observer set ---------------------------
+    W = min(band, (N - 1) // 2)
+    band_sz = min(2 * W + 1, N)
+    k_max = max(2, min(k_max, band_sz))
+    home = torch.randint(0, N, (V,), generator=g_struct, device=dev).sort().values
+    lam = torch.full((V,), float(k_extra_mean), dtype=f64, device=dev)
+    k = (2 + torch.poisson(lam, generator=g_struct)).clamp(2, k_max).long()
+    loops_ok = N >= 4 * W + 4
+    is_loop = (torch.rand(V, generator=g_struct, device=dev) < loop_frac) & loops_ok
+    n_far = torch.where(is_loop, (k // 2).clamp_min(1), torch.zeros_like(k))
+
+    def band_members(center):
+        c = center.clamp(W, N - 1 - W) if N > 2 * W else torch.full_like(center, W)
+        r = torch.rand(V, band_sz, generator=g_struct, device=dev)
+        off = r.topk(k_max, dim=1, largest=False).indices  # k_max distinct offsets
+        return (c[:, None] - W + off).clamp(0, N - 1)
+
+    near = band_members(home)
+    far = band_members((home + N // 2) % N)
+    j = torch.arange(k_max, device=dev)[None, :]
+    n_near = (k - n_far)[:, None]
+    obs = torch.where(j < n_near, near, far.gather(1, (j - n_near).clamp(0, k_max - 1)))
+    valid = j < k[:, None]
+    obs = torch.where(valid, obs, torch.full_like(obs, N + 1)).sort(dim=1).values
+    # drop accidental duplicates (only possible when near/far bands overlap)
+    dup = torch.zeros_like(valid)
+    dup[:, 1:] = obs[:, 1:] == obs[:, :-1]
+    valid = (obs <= N - 1) & ~dup
+    k = valid.sum(1)
+    assert int(k.min()) >= 2, "generator produced a voxel with < 2 observers"
+    voxel_off = torch.zeros(V + 1, dtype=torch.int64, device=dev)
+    voxel_off[1:] = k.cumsum(0)
+    F = int(voxel_off[-1])
+    pose_idx = obs[valid]                       # row-major -> ascending inside each voxel
+    vox_of = torch.arange(V, device=dev)[:, None].expand(V, k_max)[valid]
+
+    # ---- planes -------------------------------------------------------------------------
+    center = p_gt[home] + (torch.rand(V, 3, generator=g_struct, dtype=f64, device=dev) - 0.5) * 60.0
+    nrm = torch.randn(V, 3, generator=g_struct, dtype=f64, device=dev)
+    nrm = nrm / nrm.norm(dim=1, keepdim=True)
+    helper = torch.where((nrm[:, 0].abs() < 0.9)[:, None],
+                         torch.tensor([1.0, 0, 0], dtype=f64, device=dev),
+                         torch.tensor([0, 1.0, 0], dtype=f64, device=dev))
+    e1 = torch.linalg.cross(nrm, helper)
+    e1 = e1 / e1.norm(dim=1, keepdim=True)
+    e2 = torch.linalg.cross(nrm, e1)
+    ext = 0.3 + 0.6 * torch.rand(V, generator=g_struct, dtype=f64, device=dev)
+
+    # ---- points -> clusters, chunked over factors -----------------------------------------
+    n_lo, n_hi = npts
+    n_pts = torch.randint(n_lo, n_hi + 1, (F,), generator=g_noise, device=dev)
+    clusters = torch.empty(F, 10, dtype=f64, device=dev)
+    if chunk is None:
+        chunk = 1_000_000 if dev.type == "cuda" else 100_000
+    jj = torch.arange(n_hi, device=dev)[None, :]
+    for s in range(0, F, chunk):
+        e = min(F, s + chunk)
+        vo, pi, npt = vox_of[s:e], pose_idx[s:e], n_pts[s:e]
+        m = e - s
+        ab = (torch.rand(m, n_hi, 2, generator=g_noise, dtype=f64, device=dev) - 0.5) * ext[vo][:, None, None]
+        zz = torch.randn(m, n_hi, generator=g_noise, dtype=f64, device=dev) * thickness
+        pw = (center[vo][:, None, :] + ab[..., 0:1] * e1[vo][:, None, :]
+              + ab[..., 1:2] * e2[vo][:, None, :] + zz[..., None] * nrm[vo][:, None, :])
+        pb = torch.einsum('fji,fnj->fni', R_gt[pi], pw - p_gt[pi][:, None, :])   # R^T (pw - p)
+        pb = pb.to(torch.float32).to(f64)                                          # PCL fp32 points
+        pb = pb * (jj < npt[:, None])[..., None]
+        c = clusters[s:e]
+        c[:, 0] = (pb[..., 0] * pb[..., 0]).sum(1)
+        c[:, 1] = (pb[..., 0] * pb[..., 1]).sum(1)
+        c[:, 2] = (pb[..., 0] * pb[..., 2]).sum(1)
+        c[:, 3] = (pb[..., 1] * pb[..., 1]).sum(1)
+        c[:, 4] = (pb[..., 1] * pb[..., 2]).sum(1)
+        c[:, 5] = (pb[..., 2] * pb[..., 2]).sum(1)
+        c[:, 6:9] = pb.sum(1)
+        c[:, 9] = npt.to(f64)
+        del ab, zz, pw, pb
+
+    # ---- initial poses ----------------------------------------------------------------------
+    dth = torch.randn(N, 3, generator=g_pose, dtype=f64, device=dev) * math.radians(rot_sigma_deg)
+    dp = torch.randn(N, 3, generator=g_pose, dtype=f64, device=dev) * trans_sigma
+    R0 = R_gt @ _exp_so3(dth)
+    p0 = p_gt + dp
+
+    def pack(R, p):
+        return torch.cat([R.reshape(N, 9), p], 1).cpu().numpy()
+
+    return dict(
+        n_poses=N,
+        poses_gt=pack(R_gt, p_gt),
+        poses_init=pack(R0, p0),
+        voxel_off=voxel_off.cpu().numpy(),
+        pose_idx=pose_idx.to(torch.int32).cpu().numpy(),
+        clusters=clusters.cpu().numpy(),
+        plane_n=nrm.cpu().numpy(),
+        plane_c=center.cpu().numpy(),
+    )
+
+
+# BASELINE.json configs: name -> (N poses, V voxels); F ~= 5 V
+CONFIGS = {
+    "C2": (500, 400_000),
+    "C3": (2_000, 2_000_000),
+    "C4": (10_000, 10_000_000),
+}
