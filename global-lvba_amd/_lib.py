@@ -1,0 +1,109 @@
+"""ctypes binding of liblvba_hip.so (include/lvba_hip.h).  No torch types cross this boundary."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liblvba_hip.so")
+
+# every extern "C" symbol include/lvba_hip.h declares (tests check the .so exports all of them)
+SYMBOLS = [
+    "lvba_version", "lvba_last_error", "lvba_device_count", "lvba_balm_default_opts", "lvba_shard_range",
+    "lvba_balm_create", "lvba_balm_destroy", "lvba_balm_configure", "lvba_balm_info", "lvba_balm_cost",
+    "lvba_balm_eval", "lvba_balm_solve", "lvba_balm_refine", "lvba_balm_lm_begin", "lvba_balm_lm_step",
+    "lvba_balm_lm_end", "lvba_balm_set_profiling", "lvba_balm_get_profile", "lvba_balm_get_ordering",
+    "lvba_dist_unique_id", "lvba_balm_dist_init",
+]
+
+OK, ERR_ARG, ERR_DEVICE, ERR_NOMEM, ERR_UNSUPPORTED, ERR_DIST, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
+NUM_FACTORIZATION, NUM_NONFINITE = 1, 2
+
+
+class BalmOpts(C.Structure):
+    _fields_ = [("max_iter", C.c_int32), ("reserved", C.c_int32), ("u0", C.c_double), ("v0", C.c_double),
+                ("rel_tol", C.c_double)]
+
+
+class LmTrace(C.Structure):
+    _fields_ = [("iter", C.c_int32), ("accepted", C.c_int32), ("evaluated", C.c_int32), ("status", C.c_int32),
+                ("residual1", C.c_double), ("residual2", C.c_double), ("u", C.c_double), ("v", C.c_double),
+                ("q", C.c_double), ("q1", C.c_double)]
+
+    def as_dict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_}
+
+
+class BalmInfo(C.Structure):
+    _fields_ = [("n_poses", C.c_int32), ("n_ranks", C.c_int32), ("n_voxels", C.c_int64),
+                ("n_voxels_global", C.c_int64), ("n_factors", C.c_int64), ("n_pairs", C.c_int64),
+                ("n_chunks", C.c_int64), ("band_blocks", C.c_int32), ("use_band", C.c_int32),
+                ("hess_bytes", C.c_int64), ("device_bytes", C.c_int64)]
+
+
+class Prof(C.Structure):
+    _fields_ = [("cost_ms", C.c_double), ("cost_calls", C.c_int64), ("eval_ms", C.c_double),
+                ("eval_calls", C.c_int64), ("solve_ms", C.c_double), ("solve_calls", C.c_int64),
+                ("reduce_ms", C.c_double), ("reduce_calls", C.c_int64), ("cost_kernel_ms", C.c_double),
+                ("eval_kernel_ms", C.c_double)]
+
+
+class LvbaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"lvba status {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP library.  Fails loudly if it has not been built (python __graft_entry__.py)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback for the hot path)")
+    lib = C.CDLL(LIB_PATH)
+    f64p = np.ctypeslib.ndpointer(np.float64, flags="C")
+    i64p = np.ctypeslib.ndpointer(np.int64, flags="C")
+    i32p = np.ctypeslib.ndpointer(np.int32, flags="C")
+    H = C.c_void_p
+    lib.lvba_version.restype = C.c_int32
+    lib.lvba_last_error.restype = C.c_char_p
+    lib.lvba_device_count.restype = C.c_int32
+    lib.lvba_balm_default_opts.argtypes = [C.POINTER(BalmOpts)]
+    lib.lvba_balm_default_opts.restype = None
+    lib.lvba_shard_range.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.lvba_shard_range.restype = None
+    lib.lvba_balm_create.argtypes = [C.c_int32, C.c_int64, i64p, i32p, f64p, C.c_int32, C.POINTER(H)]
+    lib.lvba_balm_destroy.argtypes = [H]
+    lib.lvba_balm_configure.argtypes = [H, C.c_int32, C.c_double]
+    lib.lvba_balm_info.argtypes = [H, C.POINTER(BalmInfo)]
+    lib.lvba_balm_cost.argtypes = [H, f64p, C.c_int32, C.POINTER(C.c_double)]
+    lib.lvba_balm_eval.argtypes = [H, f64p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+    lib.lvba_balm_solve.argtypes = [H, C.c_double, f64p]
+    lib.lvba_balm_refine.argtypes = [H, f64p, C.POINTER(BalmOpts), C.POINTER(LmTrace), C.POINTER(C.c_int32)]
+    lib.lvba_balm_lm_begin.argtypes = [H, f64p, C.POINTER(BalmOpts)]
+    lib.lvba_balm_lm_step.argtypes = [H, C.POINTER(LmTrace), C.POINTER(C.c_int32)]
+    lib.lvba_balm_lm_end.argtypes = [H, C.c_void_p]
+    lib.lvba_balm_set_profiling.argtypes = [H, C.c_int32]
+    lib.lvba_balm_get_profile.argtypes = [H, C.POINTER(Prof), C.c_int32]
+    lib.lvba_balm_get_ordering.argtypes = [H, i32p]
+    lib.lvba_dist_unique_id.argtypes = [C.c_char_p]
+    lib.lvba_balm_dist_init.argtypes = [H, C.c_int32, C.c_int32, C.c_char_p]
+    for name in SYMBOLS:
+        fn = getattr(lib, name)
+        if fn.restype is C.c_int:  # default
+            fn.restype = C.c_int32
+    _lib = lib
+    return lib
+
+
+def check(rc, allow_numeric=False):
+    if rc == OK or (allow_numeric and rc > 0):
+        return rc
+    raise LvbaError(rc, load().lvba_last_error().decode(errors="replace"))

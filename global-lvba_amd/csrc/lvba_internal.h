@@ -1,0 +1,53 @@
+// lvba_internal.h -- shared declarations between the HIP translation units of liblvba_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define LVBA_CF 256   // max factors per chunk == workgroup size of the BALM kernels
+#define LVBA_CV 128   // max voxels per chunk (every voxel has >= 2 factors)
+#define LVBA_NB 64    // LDL^T panel width
+
+namespace lvba {
+
+// Device view of one packed BALM problem (a rank's voxel shard).
+struct BalmDev {
+    int32_t n_poses;
+    int32_t band_blocks;       // pose-block half bandwidth Bb of the Hessian store (solver order)
+    int64_t V, F, n_chunks;
+    const int64_t *voff;       // [V+1] CSR offsets (local, voff[0] == 0)
+    const int32_t *pidx;       // [F] pose of each factor, SOLVER order
+    const double *clu;         // [10][F] SoA cluster statistics
+    const int64_t *chunk_v0;   // [n_chunks+1] first voxel of each chunk
+};
+
+// Working matrix of the damped system, lower triangle, column-major with leading dimension ld:
+// A(r,c) = a[r + c*ld].  Dense: ld = n.  Band: LAPACK lower-band storage with ldab = ld+1, i.e.
+// A(r,c) = ab[(r-c) + c*ldab]; valid offsets 0 <= r-c <= ld.  bw = half bandwidth in scalars.
+struct LdltMat {
+    double *a;
+    int64_t n, ld, bw;
+};
+
+// balm_kernels.hip
+void launch_cost(const BalmDev &d, const double *poses, double *chunk_cost, double *out, hipStream_t s,
+                 hipEvent_t k0, hipEvent_t k1);
+void launch_eval(const BalmDev &d, const double *poses, double *Hblk, int64_t hblk_doubles, double *g,
+                 double *chunk_cost, double *out, hipStream_t s, hipEvent_t k0, hipEvent_t k1);
+void launch_retract(const double *poses, const double *dx, double *out, int n_poses, hipStream_t s);
+void launch_predicted_decrease(const double *Hblk, int band_blocks, const double *g, const double *dx, double u,
+                               int64_t n, double *out, hipStream_t s);
+void launch_export_dense(const double *Hblk, int band_blocks, int n_poses, const int *perm, double *Hd, hipStream_t s);
+void launch_export_vec(const double *v, const int *perm, int n_poses, double *out, hipStream_t s);
+void launch_import_poses(const double *in, const int *perm, int n_poses, double *out, hipStream_t s);
+void launch_export_poses(const double *in, const int *perm, int n_poses, double *out, hipStream_t s);
+
+// ldlt.hip
+// Workspace doubles needed by ldlt_solve for an n x n system.
+int64_t ldlt_workspace_doubles(int64_t n, int64_t bw);
+// A <- H + u*diag(H) from the block-band store, b <- -g; then unpivoted blocked LDL^T of the lower
+// triangle and the two triangular solves.  x (length n) receives the solution; status[0] != 0 on a
+// zero / non-finite pivot.  u is read from device memory (u_dev) so the launch sequence is static.
+void ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_poses, const double *g,
+                const double *u_dev, double *x, double *work, int *status, hipStream_t s);
+
+} // namespace lvba

@@ -1,0 +1,166 @@
+/* lvba_hip.h -- C-ABI of liblvba_hip.so: the MI355X (gfx950) replacement for the LM-refinement
+ * hot path of xuankuzcr/Global-LVBA.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Reference interfaces replaced (paths relative to the reference repo):
+ *   lvba_balm_cost     <- BALM2::only_residual            include/BALM/bavoxel.hpp:641-648
+ *                         (VOX_HESS::evaluate_only_residual  bavoxel.hpp:176-203)
+ *   lvba_balm_eval     <- BALM2::divide_thread            include/BALM/bavoxel.hpp:597-639
+ *                         (VOX_HESS::acc_evaluate2           bavoxel.hpp:68-174)
+ *   lvba_balm_refine   <- BALM2::damping_iter             include/BALM/bavoxel.hpp:662-767
+ *                         call sites src/lvba_system.cpp:264 (window BA) and :386 (global BA)
+ *   lvba_balm_create   <- VOX_HESS::push_voxel / plvec_voxels (bavoxel.hpp:35,45-54): the packed
+ *                         CSR copy of every admitted voxel's non-empty PointCluster slots
+ *   lvba_balm_dist_*   <- the 16-way thread sum of bavoxel.hpp:626-633, as an RCCL all-reduce
+ * The reference has no refine() symbol (SURVEY.md "five facts" #1); refine here is the name
+ * BASELINE.json uses for damping_iter.
+ *
+ * Conventions (kept from the reference):
+ *   pose      = T_world<-body, 12 doubles: R row-major (9) then p (3)          tools.hpp:147-207
+ *   tangent   = [dtheta(3), dp(3)] per pose; retraction R*Exp(dtheta), p+dp   bavoxel.hpp:722-727
+ *   cluster   = 10 doubles: Pxx Pxy Pxz Pyy Pyz Pzz vx vy vz n  (P = sum p p^T, v = sum p, n = #points,
+ *               body frame)                                                     tools.hpp:407-466
+ *   factor    = one non-empty (voxel, pose) cluster slot; a voxel needs >= 2   bavoxel.hpp:45-54
+ *   cost      = sum over voxels of lambda_min(cov of the merged, transformed clusters); the *_avg
+ *               variants divide by the number of voxels (AVG_THR, bavoxel.hpp:11,634-635)
+ *   H, g      = exact Hessian / gradient of the (un-averaged) cost, 6N x 6N / 6N
+ *
+ * Ownership: create() copies and repacks everything it is given onto the device; caller memory is
+ * never referenced after a call returns.  The caller owns pose arrays and output buffers.
+ * Threading: one caller thread per handle; calls are synchronous.  Handles are independent.
+ * Errors: 0 = ok, < 0 = usage/runtime error, > 0 = numerical condition; never throws.
+ * lvba_last_error() returns a thread-local message for the last non-zero status.
+ * All arithmetic is IEEE fp64.  There is no CPU fallback: without a HIP device every entry point
+ * that needs one returns LVBA_ERR_DEVICE.
+ */
+#ifndef LVBA_HIP_H
+#define LVBA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LVBA_OK 0
+#define LVBA_ERR_ARG (-1)          /* bad argument / shape */
+#define LVBA_ERR_DEVICE (-2)       /* HIP runtime error or no device */
+#define LVBA_ERR_NOMEM (-3)
+#define LVBA_ERR_UNSUPPORTED (-4)
+#define LVBA_ERR_DIST (-5)         /* RCCL error */
+#define LVBA_ERR_STATE (-6)        /* call sequence error (e.g. lm_step before lm_begin) */
+#define LVBA_NUM_FACTORIZATION 1   /* zero / non-finite pivot in LDL^T (reference: unchecked, bavoxel.hpp:707) */
+#define LVBA_NUM_NONFINITE 2       /* non-finite cost */
+
+typedef struct lvba_balm_s *lvba_balm_t;
+
+/* LM options; lvba_balm_default_opts fills the reference's hard-coded values. */
+typedef struct {
+    int32_t max_iter;   /* 10   bavoxel.hpp:686 (rejected steps count) */
+    int32_t reserved;
+    double u0;          /* 0.01 bavoxel.hpp:664 */
+    double v0;          /* 2    bavoxel.hpp:664 */
+    double rel_tol;     /* 1e-6 bavoxel.hpp:760 */
+} lvba_balm_opts;
+
+/* One LM iteration, the quantities of the commented printf at bavoxel.hpp:737. */
+typedef struct {
+    int32_t iter;
+    int32_t accepted;    /* q > 0 */
+    int32_t evaluated;   /* H/g recomputed at the start of this iteration (is_calc_hess) */
+    int32_t status;      /* LVBA_OK or LVBA_NUM_* for this iteration */
+    double residual1;    /* averaged cost at the current poses */
+    double residual2;    /* averaged cost at the trial poses */
+    double u, v;         /* damping state used for this solve */
+    double q;            /* residual1 - residual2 */
+    double q1;           /* predicted decrease, averaged */
+} lvba_lm_trace;
+
+typedef struct {
+    int32_t n_poses;
+    int32_t n_ranks;
+    int64_t n_voxels;        /* local shard */
+    int64_t n_voxels_global;
+    int64_t n_factors;       /* local shard */
+    int64_t n_pairs;         /* local pose-pair contributions, sum k(k-1)/2 */
+    int64_t n_chunks;        /* workgroup work items */
+    int32_t band_blocks;     /* pose-block half bandwidth after ordering */
+    int32_t use_band;        /* 1 = band LDL^T, 0 = dense */
+    int64_t hess_bytes;      /* block-band Hessian storage */
+    int64_t device_bytes;    /* total device memory held by the handle */
+} lvba_balm_info_t;
+
+/* Accumulated device times (HIP events on the handle's stream) since the last reset, ms. */
+typedef struct {
+    double cost_ms;     int64_t cost_calls;      /* cost-only kernel (+ reduction) */
+    double eval_ms;     int64_t eval_calls;      /* H/g/cost evaluation kernels */
+    double solve_ms;    int64_t solve_calls;     /* damped LDL^T + triangular solves */
+    double reduce_ms;   int64_t reduce_calls;    /* RCCL all-reduce */
+    double cost_kernel_ms;  /* dominant kernel only: balm_cost_kernel */
+    double eval_kernel_ms;  /* dominant kernel only: balm_eval_kernel */
+} lvba_prof_t;
+
+int32_t lvba_version(void);
+const char *lvba_last_error(void);
+int32_t lvba_device_count(void);
+
+void lvba_balm_default_opts(lvba_balm_opts *opts);
+
+/* Contiguous voxel range of rank r of G: [floor(V*r/G), floor(V*(r+1)/G)), the formula of
+ * bavoxel.hpp:621-624 with thread -> GPU. */
+void lvba_shard_range(int64_t n_voxels, int32_t rank, int32_t n_ranks, int64_t *head, int64_t *end);
+
+/* Pack a problem (or one rank's voxel shard of it) onto HIP device `device`.
+ *   voxel_off [n_voxels+1]  CSR offsets into pose_idx/clusters (voxel_off[0] may be non-zero: the
+ *                           arrays are indexed by voxel_off[v]-voxel_off[0])
+ *   pose_idx  [F]           observing pose of each factor, in [0, n_poses), distinct inside a voxel
+ *   clusters  [F][10]
+ * Every voxel must have >= 2 factors (push_voxel's admission rule). */
+int32_t lvba_balm_create(int32_t n_poses, int64_t n_voxels, const int64_t *voxel_off,
+                         const int32_t *pose_idx, const double *clusters, int32_t device,
+                         lvba_balm_t *out);
+int32_t lvba_balm_destroy(lvba_balm_t h);
+
+/* Optional, before the first cost/eval/refine call: pose ordering for the linear solver
+ * (1 = reverse Cuthill-McKee on the pose co-visibility graph [default], 0 = caller order) and the
+ * band/dense switch: the band LDL^T is used when (half-bandwidth + 128) < band_frac * 6N
+ * (default 0.6), otherwise the dense one.  Results do not depend on either beyond rounding. */
+int32_t lvba_balm_configure(lvba_balm_t h, int32_t ordering, double band_frac);
+int32_t lvba_balm_info(lvba_balm_t h, lvba_balm_info_t *info);
+
+/* only_residual: cost at `poses` [N][12]; is_avg divides by the (global) voxel count. */
+int32_t lvba_balm_cost(lvba_balm_t h, const double *poses, int32_t is_avg, double *cost);
+
+/* divide_thread: H [6N*6N] (symmetric, so row/col-major agree), g [6N], averaged cost.
+ * H and g may be NULL (kept on the device for lvba_balm_solve). */
+int32_t lvba_balm_eval(lvba_balm_t h, const double *poses, double *H, double *g, double *cost_avg);
+
+/* Solve (H + u*diag(H)) dx = -g with the H, g of the last lvba_balm_eval (bavoxel.hpp:692-710). */
+int32_t lvba_balm_solve(lvba_balm_t h, double u, double *dx);
+
+/* damping_iter: refines poses in place.  trace may be NULL; at most opts->max_iter rows. */
+int32_t lvba_balm_refine(lvba_balm_t h, double *poses_inout, const lvba_balm_opts *opts,
+                         lvba_lm_trace *trace, int32_t *n_trace);
+
+/* The same loop, one iteration per call (what bench.py times).  *done is set when the reference
+ * loop would exit (max_iter reached or the bavoxel.hpp:760 test). */
+int32_t lvba_balm_lm_begin(lvba_balm_t h, const double *poses, const lvba_balm_opts *opts);
+int32_t lvba_balm_lm_step(lvba_balm_t h, lvba_lm_trace *row, int32_t *done);
+int32_t lvba_balm_lm_end(lvba_balm_t h, double *poses_out);
+
+/* Profiling (HIP events around the stages, on the stream the kernels are launched on). */
+int32_t lvba_balm_set_profiling(lvba_balm_t h, int32_t enable);
+int32_t lvba_balm_get_profile(lvba_balm_t h, lvba_prof_t *out, int32_t reset);
+
+/* Pose ordering used internally: perm[internal] = caller pose index (n_poses entries). */
+int32_t lvba_balm_get_ordering(lvba_balm_t h, int32_t *perm);
+
+/* Multi-GPU (one process per GPU): factors are sharded by voxel range across ranks; every eval
+ * all-reduces {block-band H, g, cost} and every cost pass all-reduces one double, over RCCL.
+ * uid is an ncclUniqueId (128 bytes) created on rank 0 and distributed by the caller. */
+int32_t lvba_dist_unique_id(char uid[128]);
+int32_t lvba_balm_dist_init(lvba_balm_t h, int32_t n_ranks, int32_t rank, const char uid[128]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LVBA_HIP_H */

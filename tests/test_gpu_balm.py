@@ -1,0 +1,226 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle on identical inputs.
+
+Tolerances: the path is fp64; lambda_min (~1e-4) is a cancellation of second moments (~1e4), so two
+correct fp64 implementations agree to ~1e-9 relative per voxel.  north_star's bar is 1e-5 relative on
+per-iteration cost and final poses; these tests hold 1e-7 or tighter.
+"""
+import numpy as np
+import pytest
+
+from conftest import make_problem, rel
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    dict(n_poses=12, n_voxels=60, band=4, seed=1),
+    dict(n_poses=20, n_voxels=500, band=20, seed=5),            # window-BA shape: every pose sees every voxel region
+    dict(n_poses=40, n_voxels=3000, band=10, seed=2),
+    dict(n_poses=100, n_voxels=20000, seed=3),
+    dict(n_poses=150, n_voxels=8000, band=12, seed=4),          # banded -> band LDL^T path
+]
+
+
+def _mk(pkg, oracle_mod, case, **kw):
+    d = make_problem(**case)
+    prob = pkg.BalmProblem(d["n_poses"], d["voxel_off"], d["pose_idx"], d["clusters"], **kw)
+    co = oracle_mod.COracle(d["n_poses"], d["voxel_off"], d["pose_idx"], d["clusters"])
+    return d, prob, co
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_cost_matches_oracle(pkg, oracle_mod, case):
+    d, prob, co = _mk(pkg, oracle_mod, case)
+    for x in (d["poses_init"], d["poses_gt"]):
+        c_gpu = prob.cost(x)
+        c_ref = co.cost(x)
+        assert abs(c_gpu - c_ref) <= 1e-8 * abs(c_ref)
+        assert abs(prob.cost(x, is_avg=True) - c_ref / prob.n_voxels) <= 1e-8 * abs(c_ref / prob.n_voxels)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_eval_matches_oracle(pkg, oracle_mod, case):
+    d, prob, co = _mk(pkg, oracle_mod, case)
+    x = d["poses_init"]
+    H, g, c = prob.eval(x)
+    Hc, gc, cc = co.eval_dense(x)
+    assert abs(c - cc) <= 1e-8 * abs(cc)
+    assert rel(g, gc) <= 1e-8
+    assert rel(H, Hc) <= 1e-8
+    assert np.array_equal(H, H.T)
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("u", [0.01, 10.0])
+def test_solve_matches_oracle(pkg, oracle_mod, case, u):
+    d, prob, co = _mk(pkg, oracle_mod, case)
+    x = d["poses_init"]
+    prob.eval(x, want_H=False, want_g=False)
+    dx = prob.solve(u)
+    Hc, gc, _ = co.eval_dense(x)
+    A = Hc + u * np.diag(np.diag(Hc))
+    dx_ref, rc = oracle_mod.ldlt_solve_dense(A, -gc)
+    assert rc == 0
+    # residual of the damped system and agreement with the oracle's unpivoted LDL^T
+    assert np.abs(A @ dx + gc).max() <= 1e-8 * np.abs(gc).max()
+    assert rel(dx, dx_ref) <= 1e-6
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("solver", ["auto", "dense", "natural"])
+def test_refine_trace_matches_oracle(pkg, oracle_mod, case, solver):
+    kw = {"auto": {}, "dense": dict(band_frac=0.0), "natural": dict(ordering=0)}[solver]
+    d, prob, co = _mk(pkg, oracle_mod, case, **kw)
+    x_gpu, trace, rc = prob.refine(d["poses_init"])
+    x_ref, tr_ref, rc_ref = co.damping_iter(d["poses_init"])
+    assert rc == 0 and rc_ref == 0
+    assert len(trace) == len(tr_ref)
+    for row, ref in zip(trace, tr_ref):
+        assert row["accepted"] == int(ref[7]) and row["evaluated"] == int(ref[8])
+        assert abs(row["residual1"] - ref[1]) <= 1e-7 * abs(ref[1])
+        assert abs(row["residual2"] - ref[2]) <= 1e-7 * abs(ref[2])
+        assert abs(row["u"] - ref[3]) <= 1e-5 * abs(ref[3])
+    assert np.abs(x_gpu - x_ref).max() <= 1e-7
+
+
+def test_refine_reject_branch(pkg, oracle_mod):
+    """A start far enough from the optimum that the first steps are rejected (u *= v; v *= 2;
+    Hessian reused, bavoxel.hpp:753-758)."""
+    case = dict(n_poses=12, n_voxels=60, band=4, seed=1, rot_sigma_deg=0.03, trans_sigma=0.02)
+    d, prob, co = _mk(pkg, oracle_mod, case)
+    x_gpu, trace, rc = prob.refine(d["poses_init"])
+    x_ref, tr_ref, _ = co.damping_iter(d["poses_init"])
+    assert any(not r["accepted"] for r in trace)
+    assert [r["accepted"] for r in trace] == [int(r[7]) for r in tr_ref]
+    assert [r["evaluated"] for r in trace] == [int(r[8]) for r in tr_ref]
+    for row, ref in zip(trace, tr_ref):
+        assert abs(row["residual2"] - ref[2]) <= 1e-6 * abs(ref[2])
+    assert np.abs(x_gpu - x_ref).max() <= 1e-6
+
+
+def test_step_api_equals_refine(pkg, oracle_mod):
+    d, prob, _ = _mk(pkg, oracle_mod, CASES[2])
+    x1, trace, _ = prob.refine(d["poses_init"])
+    prob.lm_begin(d["poses_init"])
+    rows, done = [], False
+    while not done:
+        row, done, rc = prob.lm_step()
+        rows.append(row)
+    x2 = prob.lm_end()
+    assert len(rows) == len(trace)
+    assert np.array_equal(x1, x2)
+    with pytest.raises(pkg._lib.LvbaError):
+        prob.lm_step()
+
+
+def test_reference_interface_mirror(pkg, oracle_mod):
+    """VOX_HESS.push_voxel / BALM2.divide_thread / only_residual / damping_iter, called the way
+    src/lvba_system.cpp:253-264 calls the reference."""
+    d = make_problem(12, 60, band=4, seed=1)
+    N = d["n_poses"]
+    voxhess = pkg.VOX_HESS(N)
+    off, idx, clu = d["voxel_off"], d["pose_idx"], d["clusters"]
+    for a in range(len(off) - 1):
+        sig = np.zeros((N, 10))
+        sig[idx[off[a]:off[a + 1]]] = clu[off[a]:off[a + 1]]
+        voxhess.push_voxel(sig)
+    lone = np.zeros((N, 10)); lone[3] = clu[0]
+    voxhess.push_voxel(lone)                                   # < 2 observers: not admitted (bavoxel.hpp:52)
+    assert len(voxhess.plvec_voxels) == len(off) - 1
+    x_stats = [pkg.IMUST(row[:9].reshape(3, 3), row[9:]) for row in d["poses_init"]]
+    opt = pkg.BALM2(N)
+    co = oracle_mod.COracle(N, off, idx, clu)
+    r, H, g = opt.divide_thread(x_stats, voxhess)
+    Hc, gc, cc = co.eval_dense(d["poses_init"])
+    assert abs(r - cc) <= 1e-8 * cc and rel(H, Hc) <= 1e-8 and rel(g, gc) <= 1e-8
+    assert abs(opt.only_residual(x_stats, voxhess, is_avg=True) - cc) <= 1e-8 * cc
+    opt.damping_iter(x_stats, voxhess)
+    x_ref, tr_ref, _ = co.damping_iter(d["poses_init"])
+    got = np.stack([np.concatenate([x.R.reshape(9), x.p]) for x in x_stats])
+    assert np.abs(got - x_ref).max() <= 1e-7
+    assert len(opt.last_trace) == len(tr_ref)
+
+
+def test_edge_cases(pkg, oracle_mod):
+    L = pkg._lib
+    d = make_problem(12, 60, band=4, seed=1)
+    # a voxel with a single factor is refused (push_voxel admission rule)
+    with pytest.raises(L.LvbaError) as e:
+        pkg.BalmProblem(12, np.array([0, 1, 3]), d["pose_idx"][:3], d["clusters"][:3])
+    assert e.value.code == L.ERR_ARG
+    # pose index out of range
+    bad = d["pose_idx"].copy(); bad[0] = 99
+    with pytest.raises(L.LvbaError):
+        pkg.BalmProblem(12, d["voxel_off"], bad, d["clusters"])
+    # non-zero CSR base (a shard handed over with global offsets)
+    off = d["voxel_off"]
+    lo = 20
+    sub = pkg.BalmProblem(12, off[lo:], d["pose_idx"][off[lo]:], d["clusters"][off[lo]:])
+    co = oracle_mod.COracle(12, off[lo:] - off[lo], d["pose_idx"][off[lo]:], d["clusters"][off[lo]:])
+    assert abs(sub.cost(d["poses_init"]) - co.cost(d["poses_init"])) <= 1e-8 * co.cost(d["poses_init"])
+    # max_iter = 0 leaves the poses untouched; solve before eval is a state error
+    p = pkg.BalmProblem(12, off, d["pose_idx"], d["clusters"])
+    with pytest.raises(L.LvbaError) as e:
+        p.solve(0.01)
+    assert e.value.code == L.ERR_STATE
+    x, trace, rc = p.refine(d["poses_init"], max_iter=0)
+    assert trace == [] and np.array_equal(x, d["poses_init"])
+    # a pose observed by no voxel: zero pivot -> numerical status, like an unchecked LDLT failure upstream
+    idx2 = d["pose_idx"].copy()
+    d13 = pkg.BalmProblem(13, off, idx2, d["clusters"])
+    x13 = np.concatenate([d["poses_init"], d["poses_init"][-1:]])
+    _, _, rc = d13.refine(x13)
+    assert rc == L.NUM_FACTORIZATION
+
+
+def test_max_observers_per_voxel(pkg, oracle_mod):
+    """One voxel seen by many poses (k = 40) next to ordinary ones: exercises the pair enumeration."""
+    d = make_problem(60, 400, band=29, k_max=40, k_extra_mean=25.0, seed=7)
+    assert np.diff(d["voxel_off"]).max() >= 30
+    prob = pkg.BalmProblem(d["n_poses"], d["voxel_off"], d["pose_idx"], d["clusters"])
+    co = oracle_mod.COracle(d["n_poses"], d["voxel_off"], d["pose_idx"], d["clusters"])
+    H, g, c = prob.eval(d["poses_init"])
+    Hc, gc, cc = co.eval_dense(d["poses_init"])
+    assert rel(H, Hc) <= 1e-8 and rel(g, gc) <= 1e-8 and abs(c - cc) <= 1e-8 * cc
+
+
+def test_properties_at_scale(pkg, synth):
+    """Size-independent properties at a size the dense oracle cannot reach (N=500, ~250k factors):
+    rigid-motion invariance of the cost, gradient = directional derivative of the cost-only kernel,
+    Hessian-vector product = directional derivative of the gradient, linearity over voxel shards."""
+    d = make_problem(500, 50000, seed=11)
+    N = d["n_poses"]
+    prob = pkg.BalmProblem(N, d["voxel_off"], d["pose_idx"], d["clusters"])
+    x = d["poses_init"]
+    c0 = prob.cost(x)
+    # (1) left-multiplying every pose by one rigid motion leaves every lambda_min unchanged
+    th = 0.7
+    Rg = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1.0]])
+    tg = np.array([3.0, -2.0, 0.5])
+    R = x[:, :9].reshape(-1, 3, 3); p = x[:, 9:]
+    xg = np.concatenate([(Rg @ R).reshape(-1, 9), p @ Rg.T + tg], axis=1)
+    assert abs(prob.cost(xg) - c0) <= 1e-7 * c0
+    # (2)/(3) directional derivatives through the retraction, using the oracle-free GPU kernels only
+    import oracle.balm_oracle as bo
+    H, g, _ = prob.eval(x)
+    rng = np.random.default_rng(0)
+    dvec = rng.standard_normal(6 * N)
+    h = 1e-6
+    cp, cm = prob.cost(bo.retract(x, h * dvec)), prob.cost(bo.retract(x, -h * dvec))
+    assert abs((cp - cm) / (2 * h) - g @ dvec) <= 1e-5 * abs(g @ dvec)
+    # (4) shards add up: cost, g and H are sums over voxel ranges (bavoxel.hpp:626-633)
+    off = d["voxel_off"]
+    Hs, gs, cs = 0, 0, 0
+    for r in range(3):
+        a, b = pkg.shard_range(len(off) - 1, r, 3)
+        sh = pkg.BalmProblem(N, off[a:b + 1], d["pose_idx"][off[a]:off[b]], d["clusters"][off[a]:off[b]])
+        Hr, gr, cr = sh.eval(x)
+        Hs, gs, cs = Hs + Hr, gs + gr, cs + cr * (b - a)
+        sh.close()
+    assert rel(Hs, H) <= 1e-10 and rel(gs, g) <= 1e-10
+    assert abs(cs - c0) <= 1e-10 * c0
+    # LM at this size: monotone accepted costs, ends below the ground-truth cost
+    xf, trace, rc = prob.refine(x)
+    assert rc == 0
+    acc = [r for r in trace if r["accepted"]]
+    assert len(acc) >= 2 and all(r["residual2"] < r["residual1"] for r in acc)
+    assert acc[-1]["residual2"] <= prob.cost(d["poses_gt"], is_avg=True) * 1.001
