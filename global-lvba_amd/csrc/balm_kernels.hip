@@ -4,11 +4,17 @@
 // <= LVBA_CV voxels; one 256-thread workgroup (4 wavefronts) owns one chunk.  Inside a chunk
 //   lane = factor   for everything per (voxel,pose) cluster (coalesced SoA loads, 8 B/lane/array),
 //   lane = voxel    for the merged covariance + 3x3 eigen-decomposition (reads the transformed
-//                   statistics of its factors from LDS),
-//   lane = (pair, block column) for the rank-3 pose-pair blocks -Y_i Y_j^T.
-// The pose-block Hessian is accumulated with hardware fp64 atomics (global_atomic_add_f64) into a
-// block-band lower-triangular store: block (I,J), J <= I <= J+Bb, at ((J*(Bb+1) + I-J)*36), 6x6
-// column-major inside, pose indices already in the solver's (RCM) order.
+//                   statistics of its factors from LDS).
+// The pose-block Hessian lives in a block-band lower-triangular store: block (I,J), J <= I <= J+Bb, at
+// ((J*(Bb+1) + I-J)*36), 6x6 column-major inside, pose indices already in the solver's (RCM) order.
+// It is assembled WITHOUT atomics (fp64 global atomics measured 18 G/s on MI355X: 12 ms for C2), in
+// three deterministic passes over data laid out for each:
+//   balm_voxel_kernel   voxel-major  : merged covariance, eigen-decomposition -> cost + voxel records
+//   balm_factor_kernel  pose-major   : per factor Y_i (stored), diagonal block E_i - Y_i Y_i^T and gradient
+//                                      reduced in registers over the pose's factors (one plain store)
+//   balm_pair_kernel    block-major  : every off-diagonal block -sum Y_I Y_J^T over its voxel list; 16 lanes
+//                                      per block, one pair per lane, DPP row reduction, one plain store
+// so run-to-run results are bitwise identical.
 //
 // Replaces VOX_HESS::evaluate_only_residual (bavoxel.hpp:176-203) and VOX_HESS::acc_evaluate2
 // (bavoxel.hpp:68-174) of the reference; math in balm_math.h.
@@ -34,12 +40,6 @@ __device__ __forceinline__ double block_sum_256(double x, double *red)
     if (lane == 0) red[wv] = x;
     __syncthreads();
     return red[0] + red[1] + red[2] + red[3];
-}
-
-__device__ __forceinline__ void atomic_add_f64(double *p, double v)
-{
-    // lowers to global_atomic_add_f64 (no return) with -munsafe-fp-atomics
-    unsafeAtomicAdd(p, v);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -102,134 +102,193 @@ __global__ __launch_bounds__(1024) void reduce_chunks_kernel(const double *__res
 }
 
 // ------------------------------------------------------------------------------------------------
-// full evaluation: cost + gradient + block-band Hessian.
-// LDS (~52 KB -> 3 workgroups/CU): YT = union{ T[10][CF] (phases 1-2), Y[18][CF] (phases 3-4) },
-// VR[13][CV] voxel records, small index arrays.
+// full evaluation, pass 1 (voxel-major): cost + per-voxel records.  Same loads as balm_cost_kernel.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(LVBA_CF) void balm_eval_kernel(BalmDev d, const double *__restrict__ poses,
-                                                           double *__restrict__ Hblk, double *__restrict__ g,
-                                                           double *__restrict__ chunk_cost)
+__global__ __launch_bounds__(LVBA_CF) void balm_voxel_kernel(BalmDev d, const double *__restrict__ poses,
+                                                            double *__restrict__ chunk_cost)
 {
-    __shared__ double YT[18 * LVBA_CF];
-    __shared__ double VR[LVBA_VOXREC_DOUBLES * LVBA_CV];
+    __shared__ double T[10 * LVBA_CF];
     __shared__ int lvoff[LVBA_CV + 1];
-    __shared__ int pair_off[LVBA_CV + 1];
-    __shared__ int hpose[LVBA_CF];
-    __shared__ unsigned char fvox[LVBA_CF];
     __shared__ double red[4];
     const int tid = threadIdx.x;
     const int ch = blockIdx.x;
     const int64_t v0 = d.chunk_v0[ch], v1 = d.chunk_v0[ch + 1];
     const int64_t f0 = d.voff[v0];
     const int nf = (int)(d.voff[v1] - f0), nv = (int)(v1 - v0);
-    const int Bb1 = d.band_blocks + 1;
-
     if (tid <= nv) lvoff[tid] = (int)(d.voff[v0 + tid] - f0);
-    // ---- phase 1: lane = factor: load, transform -------------------------------------------------
-    double c[10], x[12];
-    int myp = 0;
     if (tid < nf) {
         const int64_t f = f0 + tid;
+        double c[10], x[12], t[10];
 #pragma unroll
         for (int e = 0; e < 10; ++e) c[e] = d.clu[(int64_t)e * d.F + f];
-        myp = d.pidx[f];
-        const double *xp = poses + 12 * (int64_t)myp;
+        const double *xp = poses + 12 * (int64_t)d.pidx[f];
 #pragma unroll
         for (int e = 0; e < 12; ++e) x[e] = xp[e];
-        double t[10];
         transform_cluster(c, x, x + 9, t);
 #pragma unroll
-        for (int e = 0; e < 10; ++e) YT[e * LVBA_CF + tid] = t[e];
-        hpose[tid] = myp;
+        for (int e = 0; e < 10; ++e) T[e * LVBA_CF + tid] = t[e];
     }
     __syncthreads();
-    // ---- phase 2: lane = voxel: merge, eigen-decompose, publish the voxel record ---------------
     double lam0 = 0.0;
     if (tid < nv) {
         double S[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        const int b = lvoff[tid], e1 = lvoff[tid + 1];
-        for (int f = b; f < e1; ++f) {
+        for (int f = lvoff[tid]; f < lvoff[tid + 1]; ++f) {
 #pragma unroll
-            for (int e = 0; e < 10; ++e) S[e] += YT[e * LVBA_CF + f];
-            fvox[f] = (unsigned char)tid;
+            for (int e = 0; e < 10; ++e) S[e] += T[e * LVBA_CF + f];
         }
         VoxRec vr;
         lam0 = voxel_finish(S, vr);
-        VR[0 * LVBA_CV + tid] = vr.NN;
+        double *o = d.vrec + 16 * (v0 + tid);
+        o[0] = vr.NN;
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
-            VR[(1 + e) * LVBA_CV + tid] = vr.vb[e];
-            VR[(4 + e) * LVBA_CV + tid] = vr.u0[e];
-            VR[(7 + e) * LVBA_CV + tid] = vr.s1[e];
-            VR[(10 + e) * LVBA_CV + tid] = vr.s2[e];
+            o[1 + e] = vr.vb[e];
+            o[4 + e] = vr.u0[e];
+            o[7 + e] = vr.s1[e];
+            o[10 + e] = vr.s2[e];
         }
-        const int k = e1 - b;
-        pair_off[tid + 1] = (k * (k - 1)) / 2;
     }
-    if (tid == 0) pair_off[0] = 0;
-    const double tot = block_sum_256(lam0, red); // contains a __syncthreads after the LDS writes above
+    const double tot = block_sum_256(lam0, red);
     if (tid == 0) chunk_cost[ch] = tot;
-    __syncthreads();
-    // inclusive scan of the per-voxel pair counts (nv <= 128: serial by one lane is cheap enough)
-    if (tid == 0) {
-        int acc = 0;
-        for (int i = 1; i <= nv; ++i) { acc += pair_off[i]; pair_off[i] = acc; }
-    }
-    // ---- phase 3: lane = factor: Y_i, diagonal block, gradient ------------------------------------
-    if (tid < nf) {
-        const int vx = fvox[tid];
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass 2 (pose-major): workgroup (I, s) handles the s-th slice of pose I's factor segment.  The pose is
+// uniform per workgroup; cluster loads are coalesced (pose-major copy); the voxel record is one 128-byte
+// line per lane.  Y_i goes to global memory for pass 3; (D, g) are summed in registers.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void balm_factor_kernel(BalmDev d, const double *__restrict__ poses)
+{
+    __shared__ double red[4 * 27];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int I = blockIdx.x / d.S, s = blockIdx.x - I * d.S;
+    const int64_t seg0 = d.csc_off[I], len = d.csc_off[I + 1] - seg0;
+    const int64_t a = seg0 + (len * s) / d.S, b = seg0 + (len * (s + 1)) / d.S;
+    double x[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) x[e] = poses[12 * (int64_t)I + e];
+    double acc[27];
+#pragma unroll
+    for (int e = 0; e < 27; ++e) acc[e] = 0.0;
+    for (int64_t t = a + tid; t < b; t += 256) {
+        double c[10];
+#pragma unroll
+        for (int e = 0; e < 10; ++e) c[e] = d.clu_csc[(int64_t)e * d.F + t];
+        const double *vp = d.vrec + 16 * (int64_t)d.vox_of_pos[t];
         VoxRec vr;
-        vr.NN = VR[0 * LVBA_CV + vx];
+        vr.NN = vp[0];
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
-            vr.vb[e] = VR[(1 + e) * LVBA_CV + vx];
-            vr.u0[e] = VR[(4 + e) * LVBA_CV + vx];
-            vr.s1[e] = VR[(7 + e) * LVBA_CV + vx];
-            vr.s2[e] = VR[(10 + e) * LVBA_CV + vx];
+            vr.vb[e] = vp[1 + e];
+            vr.u0[e] = vp[4 + e];
+            vr.s1[e] = vp[7 + e];
+            vr.s2[e] = vp[10 + e];
         }
         double Y[18], D[21], gi[6];
         factor_derivs(c, x, x + 9, vr, Y, D, gi);
+        double *yo = d.Y + 18 * t;
 #pragma unroll
-        for (int e = 0; e < 18; ++e) YT[e * LVBA_CF + tid] = Y[e]; // T is dead after phase 2 (barrier above)
-        double *gp = g + 6 * (int64_t)myp;
+        for (int e = 0; e < 18; ++e) yo[e] = Y[e];
 #pragma unroll
-        for (int e = 0; e < 6; ++e) atomic_add_f64(gp + e, gi[e]);
-        double *hp = Hblk + (int64_t)myp * Bb1 * 36; // diagonal block (I == J)
+        for (int e = 0; e < 21; ++e) acc[e] += D[e];
 #pragma unroll
-        for (int cc = 0; cc < 6; ++cc)
+        for (int e = 0; e < 6; ++e) acc[21 + e] += gi[e];
+    }
 #pragma unroll
-            for (int r = cc; r < 6; ++r) atomic_add_f64(hp + cc * 6 + r, D[dlow(r, cc)]);
+    for (int e = 0; e < 27; ++e) {
+        const double v = wave_sum(acc[e]);
+        if (lane == 0) red[wv * 27 + e] = v;
     }
     __syncthreads();
-    // ---- phase 4: lane = (pair, block column): -Y_I Y_J^T into the lower block (I > J) ------------
-    const int npairs = pair_off[nv];
-    for (int e = tid; e < npairs * 6; e += LVBA_CF) {
-        const int pr = e / 6, col = e - pr * 6;
-        // voxel of this pair: largest vx with pair_off[vx] <= pr
-        int lo = 0, hi = nv;
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (pair_off[mid] <= pr) lo = mid; else hi = mid;
-        }
-        const int fb = lvoff[lo], k = lvoff[lo + 1] - fb;
-        int q = pr - pair_off[lo];
-        // q-th pair (i<j) in row-major order over the strict upper triangle of k x k
-        int i = 0, rowlen = k - 1;
-        while (q >= rowlen) { q -= rowlen; ++i; --rowlen; }
-        const int j = i + 1 + q;
-        int fi = fb + i, fj = fb + j;
-        int I = hpose[fi], J = hpose[fj];
-        if (I < J) { int t = I; I = J; J = t; t = fi; fi = fj; fj = t; } // now I > J, fi <-> I
-        const double b0 = YT[(0 + col) * LVBA_CF + fj], b1 = YT[(6 + col) * LVBA_CF + fj],
-                     b2 = YT[(12 + col) * LVBA_CF + fj];
-        double *hp = Hblk + ((int64_t)J * Bb1 + (I - J)) * 36 + col * 6;
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            const double val = YT[r * LVBA_CF + fi] * b0 + YT[(6 + r) * LVBA_CF + fi] * b1 +
-                               YT[(12 + r) * LVBA_CF + fi] * b2;
-            atomic_add_f64(hp + r, -val);
-        }
+    if (tid < 27) d.part[(int64_t)blockIdx.x * 32 + tid] = red[tid] + red[27 + tid] + red[54 + tid] + red[81 + tid];
+}
+
+// sum the S slice partials of every pose -> diagonal block (lower triangle) and gradient
+__global__ void balm_diag_reduce_kernel(BalmDev d, double *__restrict__ Hblk, double *__restrict__ g)
+{
+    const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t I = gid >> 5;
+    const int e = (int)(gid & 31);
+    if (I >= d.n_poses || e >= 27) return;
+    double s = 0.0;
+    for (int q = 0; q < d.S; ++q) s += d.part[(I * d.S + q) * 32 + e];
+    if (e >= 21) {
+        g[6 * I + (e - 21)] = s;
+    } else {
+        // packed lower index e -> (r, c): columns hold 6,5,4,3,2,1 entries
+        int c = 0, base = 0;
+        while (e >= base + (6 - c)) { base += 6 - c; ++c; }
+        const int r = c + (e - base);
+        Hblk[I * (int64_t)(d.band_blocks + 1) * 36 + c * 6 + r] = s;
     }
+}
+
+// sum over the 16 lanes of a DPP row; every lane of the row gets the total
+__device__ __forceinline__ double row16_sum(double x)
+{
+#define LVBA_ROR_ADD(n)                                                                                \
+    do {                                                                                               \
+        const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x120 + (n), 0xF, 0xF, false); \
+        const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x120 + (n), 0xF, 0xF, false); \
+        x += __hiloint2double(hi_, lo_);                                                               \
+    } while (0)
+    LVBA_ROR_ADD(1);
+    LVBA_ROR_ADD(2);
+    LVBA_ROR_ADD(4);
+    LVBA_ROR_ADD(8);
+#undef LVBA_ROR_ADD
+    return x;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass 3 (block-major): 16 lanes (one DPP row) own one off-diagonal block; each lane takes one
+// contributing voxel (a pair of Y records) per iteration and forms the 6x6 rank-3 product in registers.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void balm_pair_kernel(BalmDev d, double *__restrict__ Hblk)
+{
+    const int64_t blk = blockIdx.x * (int64_t)16 + (threadIdx.x >> 4);
+    const int l16 = threadIdx.x & 15;
+    const bool live = blk < d.nnzb;
+    int64_t o0 = 0, o1 = 0;
+    if (live) { o0 = d.blk_off[blk]; o1 = d.blk_off[blk + 1]; }
+    double acc[36];
+#pragma unroll
+    for (int e = 0; e < 36; ++e) acc[e] = 0.0;
+    for (int64_t q = o0 + l16; q < o1; q += 16) {
+        const int2 pr = d.pairs[q];
+        const double2 *yi = reinterpret_cast<const double2 *>(d.Y + 18 * (int64_t)pr.x);
+        const double2 *yj = reinterpret_cast<const double2 *>(d.Y + 18 * (int64_t)pr.y);
+        double Yi[18], Yj[18];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) {
+            const double2 a = yi[e], b = yj[e];
+            Yi[2 * e] = a.x; Yi[2 * e + 1] = a.y;
+            Yj[2 * e] = b.x; Yj[2 * e + 1] = b.y;
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+                acc[c * 6 + r] += Yi[r] * Yj[c] + Yi[6 + r] * Yj[6 + c] + Yi[12 + r] * Yj[12 + c];
+    }
+#pragma unroll
+    for (int e = 0; e < 36; ++e) acc[e] = row16_sum(acc[e]);
+    if (live && l16 == 0) {
+        double2 *hp = reinterpret_cast<double2 *>(Hblk + d.blk_slot[blk] * 36);
+#pragma unroll
+        for (int e = 0; e < 18; ++e) hp[e] = make_double2(-acc[2 * e], -acc[2 * e + 1]);
+    }
+}
+
+// pose-major copy of the cluster statistics (one-off, at finalize)
+__global__ void gather_csc_kernel(const double *__restrict__ clu, const int32_t *__restrict__ csc_f, int64_t F,
+                                  double *__restrict__ clu_csc)
+{
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= F) return;
+    const int64_t f = csc_f[t];
+#pragma unroll
+    for (int e = 0; e < 10; ++e) clu_csc[(int64_t)e * F + t] = clu[(int64_t)e * F + f];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -339,14 +398,22 @@ void launch_cost(const BalmDev &d, const double *poses, double *chunk_cost, doub
 }
 
 void launch_eval(const BalmDev &d, const double *poses, double *Hblk, int64_t hblk_doubles, double *g,
-                 double *chunk_cost, double *out, hipStream_t s, hipEvent_t k0, hipEvent_t k1)
+                 double *chunk_cost, double *out, bool zero_first, hipStream_t s, hipEvent_t k0, hipEvent_t k1)
 {
-    hipMemsetAsync(Hblk, 0, (size_t)hblk_doubles * sizeof(double), s);
-    hipMemsetAsync(g, 0, (size_t)6 * d.n_poses * sizeof(double), s);
+    if (zero_first) hipMemsetAsync(Hblk, 0, (size_t)hblk_doubles * sizeof(double), s);
     if (k0) hipEventRecord(k0, s);
-    hipLaunchKernelGGL(balm_eval_kernel, dim3((unsigned)d.n_chunks), dim3(LVBA_CF), 0, s, d, poses, Hblk, g, chunk_cost);
+    hipLaunchKernelGGL(balm_voxel_kernel, dim3((unsigned)d.n_chunks), dim3(LVBA_CF), 0, s, d, poses, chunk_cost);
+    hipLaunchKernelGGL(balm_factor_kernel, dim3((unsigned)(d.n_poses * d.S)), dim3(256), 0, s, d, poses);
+    hipLaunchKernelGGL(balm_diag_reduce_kernel, dim3((unsigned)((32 * (int64_t)d.n_poses + 255) / 256)), dim3(256), 0, s, d, Hblk, g);
+    if (d.nnzb > 0)
+        hipLaunchKernelGGL(balm_pair_kernel, dim3((unsigned)((d.nnzb + 15) / 16)), dim3(256), 0, s, d, Hblk);
     if (k1) hipEventRecord(k1, s);
     hipLaunchKernelGGL(reduce_chunks_kernel, dim3(1), dim3(1024), 0, s, chunk_cost, d.n_chunks, out);
+}
+
+void launch_gather_csc(const double *clu, const int32_t *csc_f, int64_t F, double *clu_csc, hipStream_t s)
+{
+    hipLaunchKernelGGL(gather_csc_kernel, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, s, clu, csc_f, F, clu_csc);
 }
 
 void launch_retract(const double *poses, const double *dx, double *out, int n_poses, hipStream_t s)

@@ -8,8 +8,8 @@
 // the band only limits the row window [k+NB, k+NB+bw) each panel touches.
 //
 //   per panel k:
-//     K1 ldlt_diag    1 workgroup: LDL^T of the 64x64 diagonal block in LDS.  The right-hand side and
-//                     an identity are appended as extra ROWS, so the same elimination yields
+//     K1 ldlt_diag    1 workgroup: LDL^T of the 64x64 diagonal block, one register-resident row per
+//                     thread.  The right-hand side and an identity are appended as extra ROWS, so the same elimination yields
 //                     z_k = D^-1 L11^-1 b_k, y_k = L11^-1 b_k and G = L11^-T D^-1 for free.
 //     K2 ldlt_panel   per 64-row tile: L21 = A21 * G (fp64 MFMA 16x16x4), Z = L21*D, b -= L21*y_k.
 //     K3 ldlt_update  per 64x64 lower tile of the window: A22 -= L21 * Z^T (fp64 MFMA 16x16x4).
@@ -51,88 +51,97 @@ __global__ void ldlt_prepare_kernel(LdltMat M, const double *__restrict__ Hblk, 
 }
 
 // ---------------------------------------------------------------------------------------------- K1
-__global__ __launch_bounds__(256) void ldlt_diag_kernel(LdltMat M, int64_t k, int nbe, double *__restrict__ G,
+// One thread per ROW, the row lives in registers (64 doubles, fully unrolled static indexing).  Rows 0..63
+// are the diagonal block, row 64 the right-hand side, rows 65..128 an identity; eliminating column j needs
+// only the (unscaled) column j broadcast through LDS -> ONE barrier per column (double-buffered).
+// Outputs: L11 (strict lower) and D (diagonal) in place, z_k in b, y_k, d_k, and Gt[c][m] = G[m][c] with
+// G = L11^-T D^-1.
+__global__ __launch_bounds__(192) void ldlt_diag_kernel(LdltMat M, int64_t k, int nbe, double *__restrict__ Gt,
                                                         double *__restrict__ dvec, double *__restrict__ yvec,
                                                         double *__restrict__ b, int *__restrict__ status)
 {
-    constexpr int LS = 65;
-    __shared__ double S[129 * LS];
-    __shared__ double wv[132];
+    __shared__ double wv[2][136];
     const int tid = threadIdx.x;
-    for (int e = tid; e < 129 * 64; e += 256) {
-        const int r = e >> 6, c = e & 63;
-        double v = 0.0;
-        if (r < 64) {
-            if (r < nbe && c < nbe) {
-                if (r >= c) v = M.a[(k + r) + (k + c) * M.ld];
-            } else if (r == c)
+    double a[64];
+    if (tid < 64) {
+#pragma unroll
+        for (int c = 0; c < 64; ++c) {
+            double v = 0.0;
+            if (tid < nbe) {
+                if (c <= tid) v = M.a[(k + tid) + (k + c) * M.ld];
+            } else if (c == tid)
                 v = 1.0;
-        } else if (r == 64) {
-            v = (c < nbe) ? b[k + c] : 0.0;
-        } else {
-            v = (r - 65 == c) ? 1.0 : 0.0;
+            a[c] = v;
         }
-        S[r * LS + c] = v;
+    } else if (tid == 64) {
+#pragma unroll
+        for (int c = 0; c < 64; ++c) a[c] = (c < nbe) ? b[k + c] : 0.0;
+    } else {
+#pragma unroll
+        for (int c = 0; c < 64; ++c) a[c] = (c == tid - 65) ? 1.0 : 0.0;
     }
-    __syncthreads();
+#pragma unroll
     for (int j = 0; j < 64; ++j) {
-        double d = S[j * LS + j];
+        double *w = wv[j & 1];
+        if (tid <= 128) w[tid] = a[j];
+        __syncthreads();
+        double d = w[j];
         if (!(d != 0.0) || !isfinite(d)) {
             if (tid == 0) status[0] = 1;
             d = 1.0;
         }
-        const int rlast = 65 + j; // rows j+1..63 (matrix), 64 (rhs), 65..65+j (identity rows with fill)
-        if (tid > j && tid <= rlast) {
-            const double t = S[tid * LS + j];
-            wv[tid] = t;
-            S[tid * LS + j] = t / d;
+        if (tid == j && j < nbe) dvec[k + j] = d;
+        if (tid == 64 && j < nbe) yvec[k + j] = a[j];
+        if (tid > j) {
+            const double l = a[j] / d;
+            a[j] = l;
+#pragma unroll
+            for (int c = j + 1; c < 64; ++c) a[c] -= l * w[c];
         }
-        __syncthreads();
-        if (tid == 0 && j < nbe) {
-            dvec[k + j] = d;
-            yvec[k + j] = wv[64];
-        }
-        const int nc = 63 - j;
-        if (nc > 0) {
-            const int nr = rlast - j;
-            for (int e = tid; e < nr * nc; e += 256) {
-                const int q = e / nc;
-                const int rr = j + 1 + q, c = j + 1 + (e - q * nc);
-                if (rr <= 63 && c > rr) continue;
-                S[rr * LS + c] -= S[rr * LS + j] * wv[c];
-            }
-        }
-        __syncthreads();
     }
-    for (int e = tid; e < 64 * 64; e += 256) {
-        const int c = e >> 6, r = e & 63; // r fastest: column-major global writes
-        if (r < nbe && c < nbe && r >= c) M.a[(k + r) + (k + c) * M.ld] = S[r * LS + c];
-    }
-    if (tid < nbe) b[k + tid] = S[64 * LS + tid];
-    for (int e = tid; e < 64 * 64; e += 256) {
-        const int m = e >> 6, c = e & 63;
-        G[e] = S[(65 + m) * LS + c];
+    if (tid < 64) {
+        if (tid < nbe) {
+#pragma unroll
+            for (int c = 0; c < 64; ++c)
+                if (c <= tid) M.a[(k + tid) + (k + c) * M.ld] = a[c];
+        }
+    } else if (tid == 64) {
+#pragma unroll
+        for (int c = 0; c < 64; ++c)
+            if (c < nbe) b[k + c] = a[c];
+    } else if (tid <= 128) {
+        const int m = tid - 65;
+#pragma unroll
+        for (int c = 0; c < 64; ++c) Gt[c * 64 + m] = a[c];
     }
 }
 
 // ---------------------------------------------------------------------------------------------- K2
+#define LVBA_GS 66 // stride of the [j][m] G tile: 66 = 2 mod 32 -> conflict-free A-operand reads
 __global__ __launch_bounds__(256) void ldlt_panel_kernel(LdltMat M, int64_t k, int nbe, int64_t w0, int64_t rend,
-                                                         const double *__restrict__ G,
+                                                         const double *__restrict__ Gt,
                                                          const double *__restrict__ dvec,
                                                          const double *__restrict__ yvec, double *__restrict__ Zws,
                                                          int64_t ldz, double *__restrict__ b)
 {
     __shared__ double As[64 * LVBA_TS]; // [m][row]; later the L tile as [j][row]
-    __shared__ double Gs[64 * LVBA_TS]; // [m][j]
+    __shared__ double Gs[64 * LVBA_GS]; // [j][m]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int row = tid & 63;
     const int64_t r0 = w0 + 64 * (int64_t)blockIdx.x;
-#pragma unroll 4
+    const int64_t r = r0 + row;
+    double av[16], gv[16];
+#pragma unroll
     for (int it = 0; it < 16; ++it) {
         const int m = w + 4 * it;
-        const int64_t r = r0 + row;
-        As[m * LVBA_TS + row] = (r < rend && m < nbe) ? M.a[r + (k + m) * M.ld] : 0.0;
-        Gs[m * LVBA_TS + row] = G[m * 64 + row];
+        av[it] = (r < rend && m < nbe) ? M.a[r + (k + m) * M.ld] : 0.0;
+        gv[it] = Gt[m * 64 + row]; // Gt[j = m][m' = row]
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int m = w + 4 * it;
+        As[m * LVBA_TS + row] = av[it];
+        Gs[m * LVBA_GS + row] = gv[it];
     }
     __syncthreads();
     d4 acc[4];
@@ -141,7 +150,7 @@ __global__ __launch_bounds__(256) void ldlt_panel_kernel(LdltMat M, int64_t k, i
     const int i = lane & 15, kk = lane >> 4;
 #pragma unroll 4
     for (int k0 = 0; k0 < 64; k0 += 4) {
-        const double a = Gs[(k0 + kk) * LVBA_TS + 16 * w + i]; // G[m][j], j = 16w+i
+        const double a = Gs[(16 * w + i) * LVBA_GS + k0 + kk]; // G[m = k0+kk][j = 16w+i]
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const double bv = As[(k0 + kk) * LVBA_TS + 16 * t + i]; // A21[row=16t+i][m]
@@ -155,10 +164,9 @@ __global__ __launch_bounds__(256) void ldlt_panel_kernel(LdltMat M, int64_t k, i
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) As[(16 * w + kk + 4 * reg) * LVBA_TS + 16 * t + i] = acc[t][reg];
     __syncthreads();
-#pragma unroll 4
+#pragma unroll
     for (int it = 0; it < 16; ++it) {
         const int j = w + 4 * it;
-        const int64_t r = r0 + row;
         if (r < rend && j < nbe) {
             const double v = As[j * LVBA_TS + row];
             M.a[r + (k + j) * M.ld] = v;
@@ -166,11 +174,14 @@ __global__ __launch_bounds__(256) void ldlt_panel_kernel(LdltMat M, int64_t k, i
         }
     }
     if (tid < 64) {
-        const int64_t r = r0 + tid;
         if (r < rend) {
-            double s = 0.0;
-            for (int j = 0; j < nbe; ++j) s += As[j * LVBA_TS + tid] * yvec[k + j];
-            b[r] -= s;
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+            for (int j = 0; j < 64; j += 2) {
+                s0 += As[j * LVBA_TS + tid] * yvec[k + j];       // yvec/As are 0 beyond nbe? (As yes, yvec guarded)
+                s1 += As[(j + 1) * LVBA_TS + tid] * yvec[k + j + 1];
+            }
+            b[r] -= s0 + s1;
         }
     }
 }
@@ -190,18 +201,36 @@ __global__ __launch_bounds__(256) void ldlt_update_kernel(LdltMat M, int64_t k, 
     const int64_t tj = bidx - ti * (ti + 1) / 2;
     const int64_t r0 = w0 + 64 * ti, c0 = w0 + 64 * tj;
     const int row = tid & 63;
-#pragma unroll 4
+    const int i = lane & 15, kk = lane >> 4;
+    double lv[16], zv[16];
+    {
+        const int64_t r = r0 + row, c = c0 + row;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int m = w + 4 * it;
+            lv[it] = (r < rend && m < nbe) ? M.a[r + (k + m) * M.ld] : 0.0;
+            zv[it] = (c < rend && m < nbe) ? Zws[(c - w0) + m * ldz] : 0.0;
+        }
+    }
+    // prefetch the C tile entries this lane updates: c = c0+16w+kk+4reg, r = r0+16t+i
+    double cv[16];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int64_t c = c0 + 16 * w + kk + 4 * reg, r = r0 + 16 * t + i;
+            cv[4 * t + reg] = (r < rend && c < rend && r >= c) ? M.a[r + c * M.ld] : 0.0;
+        }
+#pragma unroll
     for (int it = 0; it < 16; ++it) {
         const int m = w + 4 * it;
-        const int64_t r = r0 + row, c = c0 + row;
-        Ls[m * LVBA_TS + row] = (r < rend && m < nbe) ? M.a[r + (k + m) * M.ld] : 0.0;
-        Zs[m * LVBA_TS + row] = (c < rend && m < nbe) ? Zws[(c - w0) + m * ldz] : 0.0;
+        Ls[m * LVBA_TS + row] = lv[it];
+        Zs[m * LVBA_TS + row] = zv[it];
     }
     __syncthreads();
     d4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
-    const int i = lane & 15, kk = lane >> 4;
 #pragma unroll 4
     for (int k0 = 0; k0 < 64; k0 += 4) {
         const double a = Zs[(k0 + kk) * LVBA_TS + 16 * w + i];
@@ -217,37 +246,54 @@ __global__ __launch_bounds__(256) void ldlt_update_kernel(LdltMat M, int64_t k, 
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int64_t c = c0 + 16 * w + kk + 4 * reg, r = r0 + 16 * t + i;
-            if (r < rend && c < rend && r >= c) M.a[r + c * M.ld] -= acc[t][reg];
+            if (r < rend && c < rend && r >= c) M.a[r + c * M.ld] = cv[4 * t + reg] - acc[t][reg];
         }
 }
 
 // ---------------------------------------------------------------------------------------- backward
-__global__ __launch_bounds__(256) void ldlt_back_kernel(LdltMat M, int64_t k, int nbe, const double *__restrict__ G,
+__global__ __launch_bounds__(256) void ldlt_back_kernel(LdltMat M, int64_t k, int nbe, const double *__restrict__ Gt,
                                                         const double *__restrict__ dvec, double *__restrict__ b,
                                                         double *__restrict__ x, int64_t cmin)
 {
     constexpr int LS = 65;
-    __shared__ double Gs[64 * LS];
+    __shared__ double Gs[64 * LS]; // [i][c] = G[i][c]
     __shared__ double sd[64], xs[64];
     const int tid = threadIdx.x;
-    for (int e = tid; e < 64 * 64; e += 256) Gs[(e >> 6) * LS + (e & 63)] = G[e];
+    const int64_t c = cmin + 256 * (int64_t)blockIdx.x + tid;
+    // this thread's column segment A(k..k+63, c), issued before anything waits
+    double colv[64];
+    int64_t rmax = k + nbe - 1;
+    if (c < k) {
+        if (c + M.bw < rmax) rmax = c + M.bw;
+        const double *col = M.a + c * M.ld + k;
+#pragma unroll
+        for (int q = 0; q < 64; ++q) colv[q] = (k + q <= rmax) ? col[q] : 0.0;
+    }
+    double gl[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) gl[it] = Gt[tid + 256 * it];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int e = tid + 256 * it; // Gt[c'][i]: c' = e>>6, i = e&63
+        Gs[(e & 63) * LS + (e >> 6)] = gl[it];
+    }
     if (tid < 64) sd[tid] = (tid < nbe) ? b[k + tid] * dvec[k + tid] : 0.0;
     __syncthreads();
     if (tid < 64) {
         double acc = 0.0;
-        for (int c = tid; c < 64; ++c) acc += Gs[tid * LS + c] * sd[c]; // x_k = (L11^-T D^-1) (D s)
+        for (int cc = tid; cc < 64; ++cc) acc += Gs[tid * LS + cc] * sd[cc]; // x_k = (L11^-T D^-1) (D s)
         xs[tid] = acc;
         if (blockIdx.x == 0 && tid < nbe) x[k + tid] = acc;
     }
     __syncthreads();
-    const int64_t c = cmin + 256 * (int64_t)blockIdx.x + tid;
     if (c < k) {
-        int64_t rmax = k + nbe - 1;
-        if (c + M.bw < rmax) rmax = c + M.bw;
-        double s = 0.0;
-        const double *col = M.a + c * M.ld;
-        for (int64_t r = k; r <= rmax; ++r) s += col[r] * xs[r - k];
-        b[c] -= s;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 64; q += 2) {
+            s0 += colv[q] * xs[q];
+            s1 += colv[q + 1] * xs[q + 1];
+        }
+        b[c] -= s0 + s1;
     }
 }
 
@@ -286,7 +332,7 @@ void ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_pos
         int64_t rend = k + nbe + bw;
         if (rend > n) rend = n;
         double *G = Gall + st * 4096;
-        hipLaunchKernelGGL(ldlt_diag_kernel, dim3(1), dim3(256), 0, s, A, k, nbe, G, dvec, yvec, b, status);
+        hipLaunchKernelGGL(ldlt_diag_kernel, dim3(1), dim3(192), 0, s, A, k, nbe, G, dvec, yvec, b, status);
         if (w0 < rend) {
             const int64_t T = (rend - w0 + 63) / 64;
             hipLaunchKernelGGL(ldlt_panel_kernel, dim3((unsigned)T), dim3(256), 0, s, A, k, nbe, w0, rend, G, dvec,

@@ -97,6 +97,13 @@ struct lvba_balm_s {
     double *d_hg = nullptr; // [Hblk | g | scal(8)] contiguous: one all-reduce covers all
     int64_t hblk_doubles = 0;
     double *d_chunk_cost = nullptr;
+    // pose-major assembly structures (see BalmDev)
+    int32_t S = 1;
+    int64_t nnzb = 0;
+    int64_t *d_csc_off = nullptr, *d_blk_off = nullptr, *d_blk_slot = nullptr;
+    int32_t *d_vox_of_pos = nullptr;
+    int2 *d_pairs = nullptr;
+    double *d_clu_csc = nullptr, *d_vrec = nullptr, *d_Y = nullptr, *d_part = nullptr;
     double *d_pose_in = nullptr, *d_pose_cur = nullptr, *d_pose_trial = nullptr;
     double *d_dx = nullptr, *d_out = nullptr; // d_out: staging for caller-order exports (>= 12N)
     double *d_scal2 = nullptr;                // [0]=trial cost sum, [1]=q1 numerator, [2]=u
@@ -125,6 +132,8 @@ struct lvba_balm_s {
         BalmDev d;
         d.n_poses = N; d.band_blocks = Bb; d.V = V; d.F = F; d.n_chunks = n_chunks;
         d.voff = d_voff; d.pidx = d_pidx; d.clu = d_clu; d.chunk_v0 = d_chunk_v0;
+        d.S = S; d.csc_off = d_csc_off; d.clu_csc = d_clu_csc; d.vox_of_pos = d_vox_of_pos; d.vrec = d_vrec;
+        d.Y = d_Y; d.part = d_part; d.nnzb = nnzb; d.blk_off = d_blk_off; d.blk_slot = d_blk_slot; d.pairs = d_pairs;
         return d;
     }
     double *Hblk() const { return d_hg; }
@@ -244,7 +253,8 @@ extern "C" int32_t lvba_balm_destroy(lvba_balm_t h)
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
-    void *ptrs[] = {h->d_voff, h->d_chunk_v0, h->d_pidx, h->d_perm, h->d_clu, h->d_hg, h->d_chunk_cost, h->d_pose_in,
+    void *ptrs[] = {h->d_csc_off, h->d_blk_off, h->d_blk_slot, h->d_vox_of_pos, h->d_pairs, h->d_clu_csc, h->d_vrec, h->d_Y,
+                    h->d_part, h->d_voff, h->d_chunk_v0, h->d_pidx, h->d_perm, h->d_clu, h->d_hg, h->d_chunk_cost, h->d_pose_in,
                     h->d_pose_cur, h->d_pose_trial, h->d_dx, h->d_out, h->d_scal2, h->d_A, h->d_work, h->d_status};
     for (void *p : ptrs)
         if (p) hipFree(p);
@@ -394,6 +404,76 @@ static int32_t finalize(lvba_balm_s *h)
         for (int64_t f = 0; f < h->F; ++f) p[f] = h->iperm[h->h_pidx[f]];
         HIPCHK(hipMemcpy(h->d_pidx, p.data(), (size_t)h->F * sizeof(int32_t), hipMemcpyHostToDevice));
     }
+    { // pose-major (CSC) view + per-block voxel lists for the atomic-free Hessian assembly
+        const int64_t F = h->F;
+        std::vector<int64_t> csc_off((size_t)N + 1, 0);
+        for (int64_t f = 0; f < F; ++f) csc_off[(size_t)h->iperm[h->h_pidx[f]] + 1]++;
+        for (int i = 0; i < N; ++i) csc_off[i + 1] += csc_off[i];
+        std::vector<int32_t> csc_f((size_t)F), vox_of_pos((size_t)F), pos_of((size_t)F);
+        {
+            std::vector<int64_t> cur(csc_off.begin(), csc_off.end() - 1);
+            for (int64_t a = 0; a < h->V; ++a)
+                for (int64_t f = h->h_voff[a]; f < h->h_voff[a + 1]; ++f) {
+                    const int64_t t = cur[h->iperm[h->h_pidx[f]]]++;
+                    csc_f[t] = (int32_t)f; vox_of_pos[t] = (int32_t)a; pos_of[f] = (int32_t)t;
+                }
+        }
+        const int64_t nslots = (int64_t)N * Bb1;
+        std::vector<int64_t> start((size_t)nslots + 1, 0);
+        auto slot_of = [&](int64_t fx, int64_t fy, int32_t &px, int32_t &py) {
+            int32_t I = h->iperm[h->h_pidx[fx]], J = h->iperm[h->h_pidx[fy]];
+            px = pos_of[fx]; py = pos_of[fy];
+            if (I < J) { std::swap(I, J); std::swap(px, py); }
+            return (int64_t)J * Bb1 + (I - J);
+        };
+        for (int64_t a = 0; a < h->V; ++a)
+            for (int64_t x = h->h_voff[a]; x < h->h_voff[a + 1]; ++x)
+                for (int64_t y = x + 1; y < h->h_voff[a + 1]; ++y) {
+                    int32_t px, py;
+                    start[slot_of(x, y, px, py) + 1]++;
+                }
+        std::vector<int64_t> blk_off, blk_slot;
+        blk_off.push_back(0);
+        for (int64_t sl = 0; sl < nslots; ++sl) {
+            const int64_t c = start[sl + 1];
+            start[sl + 1] = start[sl] + c; // exclusive prefix in start[sl]
+            if (c > 0) { blk_slot.push_back(sl); blk_off.push_back(start[sl + 1]); }
+        }
+        std::vector<int2> pairs((size_t)h->Q);
+        for (int64_t a = 0; a < h->V; ++a)
+            for (int64_t x = h->h_voff[a]; x < h->h_voff[a + 1]; ++x)
+                for (int64_t y = x + 1; y < h->h_voff[a + 1]; ++y) {
+                    int32_t px, py;
+                    const int64_t sl = slot_of(x, y, px, py);
+                    pairs[(size_t)start[sl]++] = make_int2(px, py);
+                }
+        h->nnzb = (int64_t)blk_slot.size();
+        // slices per pose: enough workgroups to fill the chip, but >= ~256 factors per slice
+        int64_t Ssz = (2048 + N - 1) / N;
+        const int64_t avg = F / N;
+        Ssz = std::min<int64_t>(Ssz, std::max<int64_t>(1, avg / 256));
+        h->S = (int32_t)std::max<int64_t>(1, std::min<int64_t>(Ssz, 64));
+        TRY(dmalloc(h, &h->d_csc_off, N + 1));
+        TRY(dmalloc(h, &h->d_vox_of_pos, F));
+        TRY(dmalloc(h, &h->d_clu_csc, 10 * F));
+        TRY(dmalloc(h, &h->d_vrec, 16 * h->V));
+        TRY(dmalloc(h, &h->d_Y, 18 * F));
+        TRY(dmalloc(h, &h->d_part, (int64_t)N * h->S * 32));
+        TRY(dmalloc(h, &h->d_blk_off, h->nnzb + 1));
+        TRY(dmalloc(h, &h->d_blk_slot, h->nnzb));
+        TRY(dmalloc(h, &h->d_pairs, h->Q));
+        HIPCHK(hipMemcpy(h->d_csc_off, csc_off.data(), (size_t)(N + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_vox_of_pos, vox_of_pos.data(), (size_t)F * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_blk_off, blk_off.data(), (size_t)(h->nnzb + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+        if (h->nnzb) HIPCHK(hipMemcpy(h->d_blk_slot, blk_slot.data(), (size_t)h->nnzb * sizeof(int64_t), hipMemcpyHostToDevice));
+        if (h->Q) HIPCHK(hipMemcpy(h->d_pairs, pairs.data(), (size_t)h->Q * sizeof(int2), hipMemcpyHostToDevice));
+        int32_t *d_csc_f = nullptr;
+        HIPCHK(hipMalloc((void **)&d_csc_f, (size_t)F * sizeof(int32_t)));
+        HIPCHK(hipMemcpy(d_csc_f, csc_f.data(), (size_t)F * sizeof(int32_t), hipMemcpyHostToDevice));
+        launch_gather_csc(h->d_clu, d_csc_f, F, h->d_clu_csc, h->stream);
+        HIPCHK(hipStreamSynchronize(h->stream));
+        hipFree(d_csc_f);
+    }
     TRY(dmalloc(h, &h->d_perm, N));
     HIPCHK(hipMemcpy(h->d_perm, h->perm.data(), (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice));
     TRY(dmalloc(h, &h->d_hg, h->hg_doubles()));
@@ -503,7 +583,7 @@ static int32_t enqueue_cost(lvba_balm_s *h, const double *d_poses, double *dst)
 static int32_t enqueue_eval(lvba_balm_s *h, const double *d_poses)
 {
     ev_begin(h, EV_EVAL);
-    launch_eval(h->dev(), d_poses, h->Hblk(), h->hblk_doubles, h->g(), h->d_chunk_cost, h->scal(), h->stream,
+    launch_eval(h->dev(), d_poses, h->Hblk(), h->hblk_doubles, h->g(), h->d_chunk_cost, h->scal(), h->n_ranks > 1, h->stream,
                 h->prof_on ? h->ev[EV_EVALK][0] : nullptr, h->prof_on ? h->ev[EV_EVALK][1] : nullptr);
     if (h->prof_on) h->ev_used[EV_EVALK] = true;
     ev_end(h, EV_EVAL);

@@ -18,6 +18,18 @@ struct BalmDev {
     const int32_t *pidx;       // [F] pose of each factor, SOLVER order
     const double *clu;         // [10][F] SoA cluster statistics
     const int64_t *chunk_v0;   // [n_chunks+1] first voxel of each chunk
+    // pose-major ("CSC") view used by the deterministic Hessian assembly
+    int32_t S;                 // each pose's factor segment is split over S workgroups
+    const int64_t *csc_off;    // [N+1] factor positions of each pose (solver order), sorted by voxel
+    const double *clu_csc;     // [10][F] cluster statistics in pose-major order
+    const int32_t *vox_of_pos; // [F] voxel of the factor at each pose-major position
+    double *vrec;              // [V][16] per-voxel records (13 used; 128-byte stride)
+    double *Y;                 // [F][18] per-factor Y_i, pose-major positions
+    double *part;              // [N*S][32] per-workgroup partial sums of (D[21], g[6])
+    int64_t nnzb;              // off-diagonal pose blocks with at least one contributing voxel
+    const int64_t *blk_off;    // [nnzb+1] offsets into pairs
+    const int64_t *blk_slot;   // [nnzb] block slot in the block-band store
+    const int2 *pairs;         // [Q] (position of the factor of pose I, position of the factor of pose J), I > J
 };
 
 // Working matrix of the damped system, lower triangle, column-major with leading dimension ld:
@@ -31,8 +43,10 @@ struct LdltMat {
 // balm_kernels.hip
 void launch_cost(const BalmDev &d, const double *poses, double *chunk_cost, double *out, hipStream_t s,
                  hipEvent_t k0, hipEvent_t k1);
+// zero_first: clear the whole store first (needed when other ranks' blocks were reduced into it)
 void launch_eval(const BalmDev &d, const double *poses, double *Hblk, int64_t hblk_doubles, double *g,
-                 double *chunk_cost, double *out, hipStream_t s, hipEvent_t k0, hipEvent_t k1);
+                 double *chunk_cost, double *out, bool zero_first, hipStream_t s, hipEvent_t k0, hipEvent_t k1);
+void launch_gather_csc(const double *clu, const int32_t *csc_f, int64_t F, double *clu_csc, hipStream_t s);
 void launch_retract(const double *poses, const double *dx, double *out, int n_poses, hipStream_t s);
 void launch_predicted_decrease(const double *Hblk, int band_blocks, const double *g, const double *dx, double u,
                                int64_t n, double *out, hipStream_t s);
