@@ -1,0 +1,239 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark: LM iterations/s of the LiDAR bundle-adjustment refinement loop
+(BALM2::damping_iter, reference include/BALM/bavoxel.hpp:662-767) on BASELINE.json's 2k-pose x
+10M-factor synthetic problem (config C3), fp64, on N MI355X.
+
+A "step" is one LM iteration = one trip through bavoxel.hpp:686-766: H/g/cost evaluation (if the last
+step was accepted), damped LDL^T solve, retraction, cost-only evaluation, accept/reject.  When a
+damping_iter run ends (<= 10 iterations or the 1e-6 relative-decrease test) the next one restarts from
+the same perturbed poses, so the timed steps are the iteration mix a real refinement executes.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3|C2|NxV]
+N > 1 is launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`:
+one rank per GPU, voxels sharded by contiguous range (bavoxel.hpp:621-624 with thread -> GPU), the
+pose-block Hessian / gradient / cost all-reduced over RCCL inside liblvba_hip.so; the damped solve is
+replicated.  Total work is fixed as N grows -> "scaling": "strong".
+
+Rank 0 prints ONE JSON line.  `roofline` is the H/g/cost evaluation ("Jacobian") pass against HBM, from
+HIP-event durations recorded on the library's stream around its kernels during the timed steps and the
+algorithmic bytes of SURVEY.md section 8(d); `cpu_baseline` is the C restatement (oracle/balm_oracle.c)
+timed on this host on a bounded sample.  torch is used only for synthetic data generation on the GPU and
+for the control-plane barrier; the product path is the C-ABI library.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured achievable)
+FP64_PEAK_TFLOPS = 78.6    # MI355X fp64 vector == fp64 MFMA peak (256 CU x 128 flop/clk x 2.4 GHz)
+
+
+def parse_config(name, synth):
+    if name in synth.CONFIGS:
+        return synth.CONFIGS[name]
+    n, v = name.lower().split("x")
+    return int(n), int(v)
+
+
+def cpu_baseline(d, info, sample_voxels=400000, solve_cols=4096):
+    """Time the C oracle on a bounded sample and scale to one LM iteration of the full problem."""
+    import oracle
+    N = d["n_poses"]
+    off = d["voxel_off"]
+    V = len(off) - 1
+    Vs = min(V, sample_voxels)
+    sl = slice(0, off[Vs])
+    co = oracle.COracle(N, off[:Vs + 1], d["pose_idx"][sl], d["clusters"][sl])
+    x = d["poses_init"]
+    cores = min(16, os.cpu_count() or 1)               # the reference uses 16 std::threads (bavoxel.hpp:25)
+    co.eval_sparse(x, nthreads=cores, want_blocks=False)
+    t = time.perf_counter(); co.eval_sparse(x, nthreads=cores, want_blocks=False); t_eval = time.perf_counter() - t
+    co.cost(x, nthreads=1)
+    t = time.perf_counter(); co.cost(x, nthreads=1); t_cost = time.perf_counter() - t   # reference: single-threaded
+    # damped solve: unpivoted band LDL^T (what the GPU path does) on a slice of columns, linear in n at fixed bw
+    n = 6 * N
+    bw = min(n - 1, 6 * info["band_blocks"] + 5)
+    ns = min(n, max(solve_cols, bw + 64))
+    rng = np.random.default_rng(0)
+    AB = rng.standard_normal((ns, bw + 1)) * 0.01
+    AB[:, 0] = bw + 1.0
+    t = time.perf_counter(); oracle.ldlt_solve_band(AB, bw, np.ones(ns), nthreads=cores); t_solve = time.perf_counter() - t
+    scale_v = V / Vs
+    # an ns-column slice under-counts the ramp-up at the matrix ends by < bw/n; scale linearly
+    t_iter = t_eval * scale_v + t_cost * scale_v + t_solve * (n / ns)
+    return {
+        "value": 1.0 / t_iter, "unit": "iterations/s", "cores": cores, "kind": "port",
+        "sample": (f"oracle/balm_oracle.c: H/g/cost eval ({cores} threads, sparse block accumulation) and "
+                   f"cost-only (1 thread, as bavoxel.hpp:176-203) on the first {Vs} of {V} voxels, scaled x{scale_v:.1f}; "
+                   f"unpivoted band LDL^T ({cores} threads) on {ns} of {n} columns at half-bandwidth {bw}, scaled x{n/ns:.2f}; "
+                   f"eval {t_eval*scale_v:.2f}s + cost {t_cost*scale_v:.2f}s + solve {t_solve*n/ns:.2f}s per iteration"),
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C3")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)   # control plane only
+
+    pkg = importlib.import_module("global-lvba_amd")
+    synth = importlib.import_module("global-lvba_amd.synth")
+    N, V = parse_config(args.config, synth)
+    d = synth.make_balm_problem(N, V, device=f"cuda:{local_rank}")
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    off = d["voxel_off"]
+    F_total = int(off[-1])
+    head, end = pkg.shard_range(V, rank, world)
+    prob = pkg.BalmProblem(N, off[head:end + 1], d["pose_idx"][off[head]:off[end]], d["clusters"][off[head]:off[end]],
+                           device=local_rank)
+    if world > 1:
+        uid = [pkg.BalmProblem.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        prob.dist_init(world, rank, uid[0])
+    info = prob.info()
+    x0 = d["poses_init"]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    state = {"active": False, "runs": 0, "evals": 0, "accepts": 0}
+
+    def step():
+        if not state["active"]:
+            prob.lm_begin(x0)
+            state["active"] = True
+            state["runs"] += 1
+        row, done, rc = prob.lm_step()
+        state["evals"] += row["evaluated"]
+        state["accepts"] += row["accepted"]
+        if done or rc != 0:
+            prob.lm_end(want_poses=False)
+            state["active"] = False
+        return row
+
+    for _ in range(args.warmup):
+        step()
+    state.update(evals=0, accepts=0)
+    prob.set_profiling(True)
+    prob.profile(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt[0])
+    p = prob.profile()
+    if state["active"]:
+        prob.lm_end(want_poses=False)
+
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        # algorithmic bytes of one H/g/cost evaluation of THIS rank's shard:
+        #   84 B/factor (80 B cluster + 4 B pose index) + 4 B/voxel offsets + 96 B/pose + 8 B cost
+        #   + upper pose blocks written once: 8 * (36 * nnzb + 6 N)
+        Fl, Vl = info["n_factors"], info["n_voxels"]
+        nnzb = prob_nnzb(prob, info)
+        bytes_eval = 84 * Fl + 4 * (Vl + 1) + 96 * N + 8 + 8 * (36 * nnzb + 6 * N)
+        bytes_cost = 84 * Fl + 4 * (Vl + 1) + 96 * N + 8
+        ev_ms = p["eval_kernel_ms"] / max(1, p["eval_calls"])
+        ck_ms = p["cost_kernel_ms"] / max(1, p["cost_calls"])
+        sv_ms = p["solve_ms"] / max(1, p["solve_calls"])
+        n = 6 * N
+        bw = 6 * info["band_blocks"] + 5
+        flops_solve = (n * bw * bw if info["use_band"] else n ** 3 / 3.0)
+        roof = {"bound": "hbm", "kernel": "H/g/cost evaluation: balm_voxel_kernel + balm_factor_kernel + balm_pair_kernel",
+                "achieved": bytes_eval / ev_ms / 1e6 if ev_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (bytes_eval / ev_ms / 1e6) / HBM_PEAK_GBS if ev_ms > 0 else None,
+                "traffic": read_traffic("eval"), "algorithmic_bytes": bytes_eval, "avg_ms": ev_ms}
+        others = [
+            {"kernel": "balm_cost_kernel (cost-only pass)", "bound": "hbm", "achieved": bytes_cost / ck_ms / 1e6,
+             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_cost / ck_ms / 1e6 / HBM_PEAK_GBS,
+             "traffic": read_traffic("cost"), "algorithmic_bytes": bytes_cost, "avg_ms": ck_ms},
+            {"kernel": "damped LDL^T solve (ldlt_diag/panel/update/back)", "bound": "mfma",
+             "achieved": flops_solve / sv_ms / 1e9, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+             "frac": flops_solve / sv_ms / 1e9 / FP64_PEAK_TFLOPS, "traffic": None,
+             "algorithmic_flops": flops_solve, "avg_ms": sv_ms},
+        ]
+        out = {
+            "metric": "LM iterations/sec, 2k poses x 10M LiDAR factors (BALM damping_iter)",
+            "value": args.steps / elapsed, "unit": "iterations/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.config}: BALM LiDAR BA, {N} poses x {V} voxels x {F_total} LiDAR factors "
+                                   f"(plane-eigenvalue factors, exact Hessian, Nielsen LM)",
+                       "n_poses": N, "n_voxels": V, "n_factors": F_total, "n_pairs_local": info["n_pairs"],
+                       "sharding": f"voxel ranges over {world} rank(s), RCCL all-reduce of pose-block H/g/cost" if world > 1 else "single GPU",
+                       "solver": ("band" if info["use_band"] else "dense") + f" LDL^T, half-bandwidth {bw} of n={n}",
+                       "lm_runs": state["runs"], "evals_in_timed_steps": state["evals"],
+                       "accepted_in_timed_steps": state["accepts"], "last_cost": last["residual2"] if last else None},
+            "stage_ms": {"eval": p["eval_ms"] / max(1, p["eval_calls"]), "solve": sv_ms,
+                         "cost": p["cost_ms"] / max(1, p["cost_calls"]),
+                         "allreduce": p["reduce_ms"] / max(1, p["reduce_calls"]) if p["reduce_calls"] else 0.0},
+            "roofline": roof, "roofline_other_kernels": others,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(d, info)
+            except Exception as e:  # the baseline is a reported number, not part of the measured path
+                out["cpu_baseline"] = {"value": None, "unit": "iterations/s", "cores": 0, "kind": "port",
+                                       "sample": f"failed: {e!r}"}
+        print(json.dumps(out), flush=True)
+    prob.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def prob_nnzb(prob, info):
+    """distinct lower pose blocks incl. diagonal (== upper) that the evaluation writes"""
+    return info.get("n_blocks", 0) + info["n_poses"]
+
+
+def read_traffic(which):
+    """HBM bytes per launch from the committed PMC pass (profiles/traffic_r01.json), or null."""
+    path = os.path.join(ROOT, "profiles", "traffic_r01.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(which)
+    except Exception:
+        return None
+
+
+if __name__ == "__main__":
+    main()

@@ -8,6 +8,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <new>
@@ -279,7 +280,63 @@ extern "C" int32_t lvba_balm_configure(lvba_balm_t h, int32_t ordering, double b
 }
 
 // ------------------------------------------------------------------------------------------ ordering
-// Reverse Cuthill-McKee on the pose co-visibility graph (byte adjacency matrix adj[N*N]).
+// Pose ordering for the band solver: reverse Cuthill-McKee on the pose co-visibility graph (byte adjacency
+// matrix adj[N*N]) from two start rules (pseudo-peripheral node, minimum-degree node), then a barycenter
+// refinement: positions are repeatedly replaced by the mean position of the neighbours and re-ranked, which
+// interleaves the two sides of ring-like trajectories (loop closures).  The candidate with the smallest
+// pose-block bandwidth wins.  One-off host work at finalize().
+static int32_t bandwidth_of(const std::vector<std::vector<int32_t>> &nb, const std::vector<int32_t> &perm)
+{
+    const int N = (int)perm.size();
+    std::vector<int32_t> ip(N);
+    for (int i = 0; i < N; ++i) ip[perm[i]] = i;
+    int32_t bw = 0;
+    for (int i = 0; i < N; ++i)
+        for (int j : nb[i]) bw = std::max(bw, std::abs(ip[i] - ip[j]));
+    return bw;
+}
+
+static void rcm_from(const std::vector<std::vector<int32_t>> &nb, const std::vector<int32_t> &deg, bool peripheral,
+                     std::vector<int32_t> &perm)
+{
+    const int N = (int)nb.size();
+    std::vector<char> seen(N, 0), mark(N, 0);
+    std::vector<int32_t> order, level(N);
+    order.reserve(N);
+    auto bfs_far = [&](int start) { // farthest node (minimal degree among the last level) from start
+        std::queue<int> q;
+        std::vector<int> touched;
+        q.push(start); mark[start] = 1; touched.push_back(start); level[start] = 0;
+        int last = start;
+        while (!q.empty()) {
+            int a = q.front(); q.pop();
+            if (level[a] > level[last] || (level[a] == level[last] && deg[a] < deg[last])) last = a;
+            for (int b : nb[a])
+                if (!mark[b] && !seen[b]) { mark[b] = 1; level[b] = level[a] + 1; touched.push_back(b); q.push(b); }
+        }
+        for (int t : touched) mark[t] = 0;
+        return last;
+    };
+    std::vector<int32_t> by_deg(N);
+    for (int i = 0; i < N; ++i) by_deg[i] = i;
+    std::stable_sort(by_deg.begin(), by_deg.end(), [&](int a, int b) { return deg[a] < deg[b]; });
+    for (int root : by_deg) {
+        if (seen[root]) continue;
+        int s = root;
+        if (peripheral)
+            for (int pass = 0; pass < 3; ++pass) s = bfs_far(s);
+        std::queue<int> q;
+        q.push(s); seen[s] = 1;
+        while (!q.empty()) {
+            int a = q.front(); q.pop();
+            order.push_back(a);
+            for (int b : nb[a])
+                if (!seen[b]) { seen[b] = 1; q.push(b); }
+        }
+    }
+    perm.assign(order.rbegin(), order.rend());
+}
+
 static void rcm_order(const std::vector<uint8_t> &adj, int N, std::vector<int32_t> &perm)
 {
     std::vector<std::vector<int32_t>> nb(N);
@@ -292,40 +349,34 @@ static void rcm_order(const std::vector<uint8_t> &adj, int N, std::vector<int32_
     }
     for (int i = 0; i < N; ++i)
         std::sort(nb[i].begin(), nb[i].end(), [&](int a, int b) { return deg[a] != deg[b] ? deg[a] < deg[b] : a < b; });
-    std::vector<char> seen(N, 0);
-    std::vector<int32_t> order;
-    order.reserve(N);
-    std::vector<int32_t> level(N);
-    auto bfs_far = [&](int start, std::vector<char> &mark) { // farthest node of minimal degree from start
-        std::queue<int> q;
-        std::vector<int> touched;
-        q.push(start); mark[start] = 1; touched.push_back(start); level[start] = 0;
-        int last = start;
-        while (!q.empty()) {
-            int a = q.front(); q.pop();
-            if (level[a] > level[last] || (level[a] == level[last] && deg[a] < deg[last])) last = a;
-            for (int b : nb[a])
-                if (!mark[b]) { mark[b] = 1; level[b] = level[a] + 1; touched.push_back(b); q.push(b); }
+    std::vector<int32_t> best, cand;
+    int32_t best_bw = INT32_MAX;
+    for (int variant = 0; variant < 2; ++variant) {
+        rcm_from(nb, deg, variant == 0, cand);
+        const int32_t bw = bandwidth_of(nb, cand);
+        if (bw < best_bw) { best_bw = bw; best = cand; }
+    }
+    // barycenter refinement of the best candidate
+    std::vector<double> x(N), y(N);
+    for (int i = 0; i < N; ++i) x[best[i]] = i;
+    std::vector<int32_t> idx(N);
+    for (int it = 1; it <= 200; ++it) {
+        for (int i = 0; i < N; ++i) {
+            if (nb[i].empty()) { y[i] = x[i]; continue; }
+            double s = 0.0;
+            for (int j : nb[i]) s += x[j];
+            y[i] = s / (double)nb[i].size();
         }
-        for (int t : touched) mark[t] = 0;
-        return last;
-    };
-    std::vector<char> mark(N, 0);
-    for (int root = 0; root < N; ++root) {
-        if (seen[root]) continue;
-        // pseudo-peripheral start inside this component
-        int s = root;
-        for (int pass = 0; pass < 3; ++pass) s = bfs_far(s, mark);
-        std::queue<int> q;
-        q.push(s); seen[s] = 1;
-        while (!q.empty()) {
-            int a = q.front(); q.pop();
-            order.push_back(a);
-            for (int b : nb[a])
-                if (!seen[b]) { seen[b] = 1; q.push(b); }
+        x.swap(y);
+        if (it % 5 == 0) {
+            for (int i = 0; i < N; ++i) idx[i] = i;
+            std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return x[a] < x[b]; });
+            const int32_t bw = bandwidth_of(nb, idx);
+            if (bw < best_bw) { best_bw = bw; best = idx; }
+            for (int i = 0; i < N; ++i) x[idx[i]] = i; // re-rank so the positions do not collapse
         }
     }
-    perm.assign(order.rbegin(), order.rend());
+    perm = best;
 }
 
 static int32_t band_of(const lvba_balm_s *h, const std::vector<int32_t> &iperm)
@@ -352,7 +403,7 @@ static int32_t finalize(lvba_balm_s *h)
     h->iperm.resize(N);
     for (int i = 0; i < N; ++i) h->perm[i] = h->iperm[i] = i;
     int32_t Bb_nat = band_of(h, h->iperm);
-    if (h->n_ranks > 1) { // the Hessian layout must agree on every rank: reduce over the global problem
+    if (h->comm) { // the Hessian layout must agree on every rank: reduce over the global problem
         int32_t *dtmp = nullptr;
         HIPCHK(hipMalloc((void **)&dtmp, sizeof(int32_t)));
         HIPCHK(hipMemcpy(dtmp, &Bb_nat, sizeof(int32_t), hipMemcpyHostToDevice));
@@ -373,7 +424,7 @@ static int32_t finalize(lvba_balm_s *h)
                     adj[(size_t)i * N + j] = 1; adj[(size_t)j * N + i] = 1;
                 }
         }
-        if (h->n_ranks > 1) {
+        if (h->comm) {
             uint8_t *dadj = nullptr;
             HIPCHK(hipMalloc((void **)&dadj, adj.size()));
             HIPCHK(hipMemcpy(dadj, adj.data(), adj.size(), hipMemcpyHostToDevice));
@@ -509,7 +560,7 @@ extern "C" int32_t lvba_balm_info(lvba_balm_t h, lvba_balm_info_t *info)
     if (!h || !info) return fail(LVBA_ERR_ARG, "NULL argument");
     TRY(finalize(h));
     info->n_poses = h->N; info->n_ranks = h->n_ranks; info->n_voxels = h->V; info->n_voxels_global = h->Vglobal;
-    info->n_factors = h->F; info->n_pairs = h->Q; info->n_chunks = h->n_chunks; info->band_blocks = h->Bb;
+    info->n_factors = h->F; info->n_pairs = h->Q; info->n_chunks = h->n_chunks; info->n_blocks = h->nnzb; info->band_blocks = h->Bb;
     info->use_band = h->use_band ? 1 : 0; info->hess_bytes = h->hblk_doubles * 8; info->device_bytes = h->device_bytes;
     return LVBA_OK;
 }
@@ -570,7 +621,7 @@ static int32_t enqueue_cost(lvba_balm_s *h, const double *d_poses, double *dst)
                 h->prof_on ? h->ev[EV_COSTK][1] : nullptr);
     if (h->prof_on) h->ev_used[EV_COSTK] = true;
     ev_end(h, EV_COST);
-    if (h->n_ranks > 1) {
+    if (h->comm) {
         ev_begin(h, EV_REDUCE);
         NCCLCHK(g_rccl.AllReduce(dst, dst, 1, ncclDouble, ncclSum, h->comm, h->stream));
         ev_end(h, EV_REDUCE);
@@ -583,11 +634,11 @@ static int32_t enqueue_cost(lvba_balm_s *h, const double *d_poses, double *dst)
 static int32_t enqueue_eval(lvba_balm_s *h, const double *d_poses)
 {
     ev_begin(h, EV_EVAL);
-    launch_eval(h->dev(), d_poses, h->Hblk(), h->hblk_doubles, h->g(), h->d_chunk_cost, h->scal(), h->n_ranks > 1, h->stream,
+    launch_eval(h->dev(), d_poses, h->Hblk(), h->hblk_doubles, h->g(), h->d_chunk_cost, h->scal(), h->comm != nullptr, h->stream,
                 h->prof_on ? h->ev[EV_EVALK][0] : nullptr, h->prof_on ? h->ev[EV_EVALK][1] : nullptr);
     if (h->prof_on) h->ev_used[EV_EVALK] = true;
     ev_end(h, EV_EVAL);
-    if (h->n_ranks > 1) {
+    if (h->comm) {
         ev_begin(h, EV_REDUCE);
         NCCLCHK(g_rccl.AllReduce(h->d_hg, h->d_hg, (size_t)(h->hblk_doubles + 6 * (int64_t)h->N + 1), ncclDouble, ncclSum,
                                  h->comm, h->stream));
@@ -797,7 +848,9 @@ extern "C" int32_t lvba_balm_dist_init(lvba_balm_t h, int32_t n_ranks, int32_t r
     if (!h || !uid) return fail(LVBA_ERR_ARG, "NULL argument");
     if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(LVBA_ERR_ARG, "bad rank %d of %d", rank, n_ranks);
     if (h->finalized) return fail(LVBA_ERR_STATE, "dist_init must precede the first cost/eval/refine call");
-    if (n_ranks == 1) return LVBA_OK;
+    // a 1-rank job needs no communicator; LVBA_SINGLE_RANK_COMM=1 builds one anyway so that the whole
+    // RCCL path (dlopen, communicator, all-reduces) can be exercised on a 1-GPU box
+    if (n_ranks == 1 && !getenv("LVBA_SINGLE_RANK_COMM")) return LVBA_OK;
     TRY(rccl_load());
     HIPCHK(hipSetDevice(h->device));
     ncclUniqueId id;

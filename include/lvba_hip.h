@@ -83,6 +83,7 @@ typedef struct {
     int64_t n_factors;       /* local shard */
     int64_t n_pairs;         /* local pose-pair contributions, sum k(k-1)/2 */
     int64_t n_chunks;        /* workgroup work items */
+    int64_t n_blocks;        /* off-diagonal pose blocks (I>J) with at least one contributing voxel */
     int32_t band_blocks;     /* pose-block half bandwidth after ordering */
     int32_t use_band;        /* 1 = band LDL^T, 0 = dense */
     int64_t hess_bytes;      /* block-band Hessian storage */

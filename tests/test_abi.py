@@ -1,0 +1,75 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol include/lvba_hip.h
+declares, and refuses to compute without a HIP device (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, make_problem
+
+
+@pytest.fixture(scope="module")
+def lib(pkg):
+    import __graft_entry__ as ge
+    ge.build()
+    return pkg._lib.load()
+
+
+def test_header_symbols_are_exported(lib, pkg):
+    hdr = open(os.path.join(ROOT, "include", "lvba_hip.h")).read()
+    declared = set(re.findall(r"\b(lvba_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(pkg._lib.SYMBOLS), declared ^ set(pkg._lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.lvba_version() >= 100
+
+
+def test_struct_layouts_match_header(pkg):
+    L = pkg._lib
+    assert ctypes.sizeof(L.BalmOpts) == 32 and ctypes.sizeof(L.LmTrace) == 64
+    assert ctypes.sizeof(L.BalmInfo) == 80 and ctypes.sizeof(L.Prof) == 80
+    o = pkg.BalmProblem.default_opts()
+    assert (o.max_iter, o.u0, o.v0, o.rel_tol) == (10, 0.01, 2.0, 1e-6)      # bavoxel.hpp:664,686,760
+
+
+def test_shard_range_matches_reference_slicing(pkg):
+    from oracle import balm_oracle as bo
+    for V in (7, 16, 100, 12345, 2_000_000):
+        ref = bo.thread_slices(V) if V >= 16 else None
+        got = [pkg.shard_range(V, r, 16) for r in range(16)]
+        assert got[0][0] == 0 and got[-1][1] == V and all(a[1] == b[0] for a, b in zip(got, got[1:]))
+        if ref:
+            assert got == ref                                               # bavoxel.hpp:621-624
+
+
+def test_no_cpu_fallback(lib, pkg):
+    if lib.lvba_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    d = make_problem(12, 60, band=4, seed=1)
+    with pytest.raises(pkg._lib.LvbaError) as e:
+        pkg.BalmProblem(d["n_poses"], d["voxel_off"], d["pose_idx"], d["clusters"])
+    assert e.value.code == pkg._lib.ERR_DEVICE and "no CPU fallback" in str(e.value)
+
+
+def test_product_does_not_import_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch oracle/."""
+    pk = os.path.join(ROOT, "global-lvba_amd")
+    for dirpath, _, files in os.walk(pk):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                for pat in (r"^\s*(import|from)\s+oracle", r"libbalm_oracle", r"balm_oracle", r"oracle/", r"import_module\([\"']oracle"):
+                    assert not re.search(pat, src, re.M), (os.path.join(dirpath, f), pat)
+
+
+def test_vox_hess_mirror_packs_like_the_reference(pkg):
+    N = 5
+    vh = pkg.VOX_HESS(N)
+    sig = np.zeros((N, 10)); sig[1, 9] = 20; sig[3, 9] = 15; sig[1, :9] = 1.0; sig[3, :9] = 2.0
+    vh.push_voxel(sig)
+    one = np.zeros((N, 10)); one[2, 9] = 30
+    vh.push_voxel(one)                                   # only one observer: dropped (bavoxel.hpp:52)
+    off, idx, clu = vh.pack()
+    assert off.tolist() == [0, 2] and idx.tolist() == [1, 3] and clu.shape == (2, 10) and clu[1, 9] == 15

@@ -242,3 +242,25 @@ def test_properties_at_scale(pkg, synth):
     acc = [r for r in trace if r["accepted"]]
     assert len(acc) >= 2 and all(r["residual2"] < r["residual1"] for r in acc)
     assert acc[-1]["residual2"] <= prob.cost(d["poses_gt"], is_avg=True) * 1.001
+
+
+def test_rccl_path_single_rank(pkg, oracle_mod, monkeypatch):
+    """The RCCL plumbing (dlopen, unique id, communicator, all-reduce of {H, g, cost} and of the cost
+    scalar) exercised with a 1-rank communicator -- all a 1-GPU box can run; the multi-rank arithmetic is
+    covered by tests/test_dist_cpu.py."""
+    monkeypatch.setenv("LVBA_SINGLE_RANK_COMM", "1")
+    d = make_problem(40, 3000, band=10, seed=2)
+    prob = pkg.BalmProblem(d["n_poses"], d["voxel_off"], d["pose_idx"], d["clusters"])
+    uid = pkg.BalmProblem.unique_id()
+    assert len(uid) == 128
+    prob.dist_init(1, 0, uid)
+    co = oracle_mod.COracle(d["n_poses"], d["voxel_off"], d["pose_idx"], d["clusters"])
+    H, g, c = prob.eval(d["poses_init"])
+    Hc, gc, cc = co.eval_dense(d["poses_init"])
+    assert rel(H, Hc) <= 1e-8 and rel(g, gc) <= 1e-8 and abs(c - cc) <= 1e-8 * cc
+    H2, g2, c2 = prob.eval(d["poses_init"])                 # the store is re-zeroed before every reduce
+    assert np.array_equal(H, H2) and np.array_equal(g, g2)
+    x, trace, rc = prob.refine(d["poses_init"])
+    xr, tr, _ = co.damping_iter(d["poses_init"])
+    assert rc == 0 and np.abs(x - xr).max() <= 1e-7
+    assert prob.info()["n_voxels_global"] == 3000

@@ -1,0 +1,221 @@
+"""CPU tests (no GPU): pin the oracle -- finite differences, numpy vs C restatement, autograd of an
+independent lambda_min formulation, golden fixtures -- and check the device math of balm_math.h
+(compiled for the host, tests/host_emul.cpp) against it."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, make_problem, rel
+from oracle import balm_oracle as bo
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def _prob(d):
+    return bo.Problem(d["n_poses"], d["voxel_off"], d["pose_idx"], d["clusters"])
+
+
+# ---------------------------------------------------------------------------------------------- known answers
+def test_gradient_and_hessian_match_finite_differences():
+    """JacT = grad sum(lambda_min), Hess = exact second derivative (bavoxel.hpp:137-165), through the
+    reference's retraction R*Exp(dtheta), p+dp."""
+    d = make_problem(8, 30, band=3, seed=21)
+    prob = _prob(d)
+    x = d["poses_init"]
+    H, g, _ = bo.acc_evaluate2(prob, x, 0, prob.n_voxels)
+    rng = np.random.default_rng(0)
+    for _ in range(3):
+        dv = rng.standard_normal(6 * 8)
+        # the cost carries ~1e-11 absolute rounding noise (lambda_min ~1e-4 out of moments ~1e4), so the
+        # step is 2e-5 with Richardson extrapolation and the tolerance is relative to |g||dv|
+        def d1(h):
+            return (bo.only_residual(prob, bo.retract(x, h * dv)) - bo.only_residual(prob, bo.retract(x, -h * dv))) / (2 * h)
+
+        h = 2e-5
+        fd1 = (4 * d1(h / 2) - d1(h)) / 3
+        assert abs(fd1 - g @ dv) <= 1e-6 * np.linalg.norm(g) * np.linalg.norm(dv)
+        # t -> x (+) t dv is a one-parameter subgroup, so d2/dt2 f at 0 is dv^T H dv; Richardson-extrapolated
+        c0 = bo.only_residual(prob, x)
+
+        def d2(h):
+            cp, cm = bo.only_residual(prob, bo.retract(x, h * dv)), bo.only_residual(prob, bo.retract(x, -h * dv))
+            return (cp - 2 * c0 + cm) / h ** 2
+
+        h2 = 1e-4
+        fd2 = (4 * d2(h2 / 2) - d2(h2)) / 3
+        assert abs(fd2 - dv @ H @ dv) <= 1e-4 * abs(dv @ H @ dv)
+    assert rel(H, H.T) <= 1e-12
+
+
+def test_autograd_of_independent_formulation():
+    """torch autograd of lambda_min computed straight from the definition (transform -> merge -> eigvalsh)
+    reproduces the oracle's gradient: a structurally different check of bavoxel.hpp:112-138."""
+    torch = pytest.importorskip("torch")
+    d = make_problem(6, 20, band=2, seed=22)
+    prob = _prob(d)
+    x = d["poses_init"]
+    _, g, _ = bo.acc_evaluate2(prob, x, 0, prob.n_voxels)
+    R0 = torch.tensor(x[:, :9].reshape(-1, 3, 3)); p0 = torch.tensor(x[:, 9:])
+    P = torch.tensor(prob.P); v = torch.tensor(prob.v); n = torch.tensor(prob.n)
+    idx = torch.tensor(prob.pose_idx, dtype=torch.long)
+    delta = torch.zeros(6, 6, dtype=torch.float64, requires_grad=True)
+
+    def hat(w):
+        z = torch.zeros_like(w[..., 0])
+        return torch.stack([torch.stack([z, -w[..., 2], w[..., 1]], -1), torch.stack([w[..., 2], z, -w[..., 0]], -1),
+                            torch.stack([-w[..., 1], w[..., 0], z], -1)], -2)
+
+    R = R0 @ torch.matrix_exp(hat(delta[:, :3]))
+    p = p0 + delta[:, 3:]
+    Rf, pf = R[idx], p[idx]
+    Rv = torch.einsum("fij,fj->fi", Rf, v)
+    v2 = Rv + n[:, None] * pf
+    rp = torch.einsum("fi,fj->fij", Rv, pf)
+    P2 = Rf @ P @ Rf.transpose(1, 2) + rp + rp.transpose(1, 2) + n[:, None, None] * torch.einsum("fi,fj->fij", pf, pf)
+    cost = 0
+    for a in range(prob.n_voxels):
+        s = slice(int(prob.voxel_off[a]), int(prob.voxel_off[a + 1]))
+        NN = n[s].sum(); vb = v2[s].sum(0) / NN
+        C = P2[s].sum(0) / NN - torch.outer(vb, vb)
+        cost = cost + torch.linalg.eigvalsh(C)[0]
+    cost.backward()
+    assert rel(delta.grad.reshape(-1).numpy(), g) <= 1e-8
+
+
+def test_c_restatement_agrees_with_numpy(oracle_mod):
+    for case in (dict(n_poses=12, n_voxels=60, band=4, seed=1), dict(n_poses=30, n_voxels=400, band=8, seed=23)):
+        d = make_problem(**case)
+        prob, co = _prob(d), oracle_mod.COracle(d["n_poses"], d["voxel_off"], d["pose_idx"], d["clusters"])
+        x = d["poses_init"]
+        H, g, c = bo.divide_thread(prob, x)
+        Hc, gc, cc = co.eval_dense(x)
+        # two fp64 implementations of a 1e8:1 cancellation: agreement ~1e-10, required 1e-8
+        assert abs(c - cc) <= 1e-8 * c and rel(gc, g) <= 1e-8 and rel(Hc, H) <= 1e-8
+        assert abs(co.cost(x) - bo.only_residual(prob, x)) <= 1e-8 * co.cost(x)
+        lam = co.voxel_lambdas(x)
+        assert rel(lam[:, 0], bo.voxel_lambdas(prob, x)[:, 0]) <= 1e-7
+        bi, bj, bl, gs, cs = co.eval_sparse(x)
+        Hs = np.zeros_like(H)
+        for i, j, b in zip(bi, bj, bl):
+            Hs[6 * i:6 * i + 6, 6 * j:6 * j + 6] += b
+            if i != j:
+                Hs[6 * j:6 * j + 6, 6 * i:6 * i + 6] += b.T
+        assert rel(Hs, Hc) <= 1e-14 and rel(gs, gc) <= 1e-14
+
+
+def test_lm_traces_agree_numpy_vs_c(oracle_mod):
+    for case in (dict(n_poses=12, n_voxels=60, band=4, seed=1),
+                 dict(n_poses=12, n_voxels=60, band=4, seed=1, rot_sigma_deg=0.03, trans_sigma=0.02)):
+        d = make_problem(**case)
+        prob, co = _prob(d), oracle_mod.COracle(d["n_poses"], d["voxel_off"], d["pose_idx"], d["clusters"])
+        xf, tr = bo.damping_iter(prob, d["poses_init"])
+        xc, trc, rc = co.damping_iter(d["poses_init"])
+        assert rc == 0 and len(tr) == len(trc)
+        for a, b in zip(tr, trc):
+            assert a.accepted == bool(b[7]) and a.evaluated == bool(b[8])
+            assert abs(a.residual2 - b[2]) <= 1e-7 * abs(b[2])
+        assert np.abs(xf - xc).max() <= 1e-8
+
+
+def test_slicing_and_admission_rules():
+    # bavoxel.hpp:614-624: 16 slices with double `part`, truncation at the int conversion; 1 slice if < 16
+    assert bo.thread_slices(7) == [(0, 7)]
+    s = bo.thread_slices(100)
+    assert len(s) == 16 and s[0] == (0, 6) and s[-1] == (93, 100) and all(a[1] == b[0] for a, b in zip(s, s[1:]))
+    # bavoxel.hpp:45-54
+    assert bo.push_voxel_admits([0, 3, 0, 9]) and not bo.push_voxel_admits([0, 3, 0, 0])
+
+
+def test_ldlt_solvers(oracle_mod):
+    rng = np.random.default_rng(3)
+    n, bw = 90, 17
+    A = np.zeros((n, n))
+    for i in range(n):
+        for j in range(max(0, i - bw), i + 1):
+            A[i, j] = A[j, i] = rng.standard_normal()
+        A[i, i] += (-1) ** i * 6.0           # indefinite: unpivoted LDL^T must still work (no Cholesky)
+    b = rng.standard_normal(n)
+    x_np = bo.ldlt_solve(A, b)
+    xd, rc = oracle_mod.ldlt_solve_dense(A, b)
+    assert rc == 0 and rel(xd, x_np) <= 1e-10 and np.abs(A @ xd - b).max() <= 1e-10
+    AB = np.zeros((n, bw + 1))
+    for c in range(n):
+        for r in range(c, min(n, c + bw + 1)):
+            AB[c, r - c] = A[r, c]
+    xb, rc = oracle_mod.ldlt_solve_band(AB, bw, b)
+    assert rc == 0 and rel(xb, xd) <= 1e-10
+
+
+# ---------------------------------------------------------------------------------------------- golden fixtures
+@pytest.mark.parametrize("name", ["balm_small", "balm_window", "balm_reject"])
+def test_oracles_reproduce_golden(oracle_mod, name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    prob = bo.Problem(int(z["n_poses"]), z["voxel_off"], z["pose_idx"], z["clusters"])
+    co = oracle_mod.COracle(int(z["n_poses"]), z["voxel_off"], z["pose_idx"], z["clusters"])
+    x0 = z["poses_init"]
+    assert abs(bo.only_residual(prob, x0) - z["cost_sum"]) <= 1e-12 * z["cost_sum"]
+    Hc, gc, cc = co.eval_dense(x0)
+    assert abs(cc - z["cost_avg"]) <= 1e-8 * z["cost_avg"] and rel(Hc, z["H"]) <= 1e-8 and rel(gc, z["g"]) <= 1e-8
+    xc, trc, _ = co.damping_iter(x0)
+    assert len(trc) == len(z["trace"])
+    assert np.array_equal(trc[:, 7], z["trace"][:, 7])
+    assert np.abs(xc - z["poses_final"]).max() <= 1e-8
+
+
+# ---------------------------------------------------------------------------------------------- device math on the host
+@pytest.fixture(scope="module")
+def emul(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("emul") / "libemul.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", os.path.join(ROOT, "tests", "host_emul.cpp"), "-o", so])
+    lib = ctypes.CDLL(so)
+    f64p = np.ctypeslib.ndpointer(np.float64, flags="C")
+    i64p = np.ctypeslib.ndpointer(np.int64, flags="C")
+    i32p = np.ctypeslib.ndpointer(np.int32, flags="C")
+    lib.emul_eval.argtypes = [ctypes.c_int, ctypes.c_int64, i64p, i32p, f64p, f64p, f64p, f64p, ctypes.POINTER(ctypes.c_double)]
+    lib.emul_cost.argtypes = [ctypes.c_int, ctypes.c_int64, i64p, i32p, f64p, f64p, ctypes.POINTER(ctypes.c_double)]
+    lib.emul_retract.argtypes = [ctypes.c_int, f64p, f64p, f64p]
+    lib.emul_eig3.argtypes = [f64p, f64p, f64p]
+    return lib
+
+
+@pytest.mark.parametrize("case", [dict(n_poses=12, n_voxels=60, band=4, seed=1), dict(n_poses=40, n_voxels=3000, band=10, seed=2)])
+def test_device_math_matches_oracle(emul, oracle_mod, case):
+    """The kernels' per-lane math (E_i - Y Y^T formulation, Jacobi eigen-solver) == the reference formulation."""
+    d = make_problem(**case)
+    N, V = d["n_poses"], len(d["voxel_off"]) - 1
+    co = oracle_mod.COracle(N, d["voxel_off"], d["pose_idx"], d["clusters"])
+    x = np.ascontiguousarray(d["poses_init"])
+    Hc, gc, cc = co.eval_dense(x)
+    H, g, c = np.empty((6 * N, 6 * N)), np.empty(6 * N), ctypes.c_double()
+    emul.emul_eval(N, V, d["voxel_off"], d["pose_idx"], d["clusters"], x, H, g, ctypes.byref(c))
+    assert abs(c.value / V - cc) <= 1e-8 * cc and rel(g, gc) <= 1e-8 and rel(H, Hc) <= 1e-8
+    emul.emul_cost(N, V, d["voxel_off"], d["pose_idx"], d["clusters"], x, ctypes.byref(c))
+    assert abs(c.value - co.cost(x)) <= 1e-8 * c.value
+    dx = np.random.default_rng(0).standard_normal(6 * N) * 0.01
+    dx[:6] = 0.0                                            # exercises the |theta| < 1e-11 -> identity branch
+    out = np.empty((N, 12))
+    emul.emul_retract(N, x, dx, out)
+    assert np.abs(out - bo.retract(x, dx)).max() <= 1e-14
+
+
+def test_device_eig3_accuracy(emul):
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        Q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+        lam = np.sort(np.array([10.0 ** rng.uniform(-6, -3), 10.0 ** rng.uniform(-2, 0), 10.0 ** rng.uniform(-2, 0)]))
+        C = Q @ np.diag(lam) @ Q.T + 100.0 * 0  # PSD with a tiny smallest eigenvalue
+        C6 = np.array([C[0, 0], C[0, 1], C[0, 2], C[1, 1], C[1, 2], C[2, 2]])
+        out_l, out_U = np.empty(3), np.empty(9)
+        emul.emul_eig3(C6, out_l, out_U)
+        assert rel(out_l, lam) <= 1e-12
+        assert abs(out_l[0] - lam[0]) <= 1e-10 * lam[0] + 1e-17   # relative accuracy of the SMALL eigenvalue
+        U = out_U.reshape(3, 3)
+        assert np.abs(U.T @ U - np.eye(3)).max() <= 1e-13
+        assert np.abs(C @ U - U * out_l).max() <= 1e-14
+    # already diagonal / repeated eigenvalues
+    out_l, out_U = np.empty(3), np.empty(9)
+    emul.emul_eig3(np.array([3.0, 0, 0, 1.0, 0, 2.0]), out_l, out_U)
+    assert np.array_equal(out_l, [1.0, 2.0, 3.0])
