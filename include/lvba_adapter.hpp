@@ -1,0 +1,79 @@
+// lvba_adapter.hpp -- the reference-side binding: what a Global-LVBA maintainer adds to call liblvba_hip.so
+// instead of BALM2::damping_iter.  Header-only, duck-typed on the reference's own types so it needs neither
+// Eigen nor PCL to compile:
+//   VoxHess : has `win_size` and `plvec_voxels`, a sequence of `const std::vector<PointCluster>*`
+//             (reference include/BALM/bavoxel.hpp:35-36)
+//   PointCluster : `.P(r,c)`, `.v[r]` (or `.v(r)`), `.N`              (include/BALM/tools.hpp:407-412)
+//   IMUST   : `.R(r,c)`, `.p[r]`                                       (include/BALM/tools.hpp:147-151)
+// Usage at src/lvba_system.cpp:264 and :386 --
+//       // opt_lsv->damping_iter(x_win, *voxhess);
+//       lvba::damping_iter_hip(x_win, *voxhess);
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "lvba_hip.h"
+
+namespace lvba {
+
+// Packs VOX_HESS::plvec_voxels (dense win_size slots per voxel, mostly empty) into the CSR arrays of
+// lvba_balm_create: the non-empty slots of every voxel, ascending pose index.
+template <class VoxHess>
+void pack_voxhess(const VoxHess &vh, std::vector<int64_t> &voxel_off, std::vector<int32_t> &pose_idx,
+                  std::vector<double> &clusters)
+{
+    voxel_off.assign(1, 0);
+    pose_idx.clear();
+    clusters.clear();
+    for (const auto *sig_orig : vh.plvec_voxels) {
+        for (int i = 0; i < vh.win_size; ++i) {
+            const auto &c = (*sig_orig)[i];
+            if (c.N == 0) continue;                       // bavoxel.hpp:90-91
+            pose_idx.push_back(i);
+            const double rec[10] = {c.P(0, 0), c.P(0, 1), c.P(0, 2), c.P(1, 1), c.P(1, 2), c.P(2, 2),
+                                    c.v[0], c.v[1], c.v[2], static_cast<double>(c.N)};
+            clusters.insert(clusters.end(), rec, rec + 10);
+        }
+        voxel_off.push_back(static_cast<int64_t>(pose_idx.size()));
+    }
+}
+
+// Drop-in for BALM2::damping_iter(x_stats, voxhess)  (bavoxel.hpp:662).  Refines x_stats in place.
+// Returns the LM trace (the quantities of the commented printf at bavoxel.hpp:737).
+template <class PoseVec, class VoxHess>
+std::vector<lvba_lm_trace> damping_iter_hip(PoseVec &x_stats, const VoxHess &voxhess, int device = 0)
+{
+    std::vector<int64_t> off;
+    std::vector<int32_t> idx;
+    std::vector<double> clu;
+    pack_voxhess(voxhess, off, idx, clu);
+    const int32_t N = voxhess.win_size;
+    std::vector<double> poses(12 * static_cast<size_t>(N));
+    for (int j = 0; j < N; ++j) {
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) poses[12 * j + 3 * r + c] = x_stats[j].R(r, c);
+        for (int r = 0; r < 3; ++r) poses[12 * j + 9 + r] = x_stats[j].p[r];
+    }
+    lvba_balm_t h = nullptr;
+    int32_t rc = lvba_balm_create(N, static_cast<int64_t>(off.size()) - 1, off.data(), idx.data(), clu.data(), device, &h);
+    if (rc != LVBA_OK) throw std::runtime_error(std::string("lvba_balm_create: ") + lvba_last_error());
+    lvba_balm_opts opts;
+    lvba_balm_default_opts(&opts);                       // 10 iterations, u=0.01, v=2 (bavoxel.hpp:664,686)
+    std::vector<lvba_lm_trace> trace(opts.max_iter);
+    int32_t n_trace = 0;
+    rc = lvba_balm_refine(h, poses.data(), &opts, trace.data(), &n_trace);
+    lvba_balm_destroy(h);
+    if (rc < 0) throw std::runtime_error(std::string("lvba_balm_refine: ") + lvba_last_error());
+    // rc > 0 (zero pivot / non-finite cost): the reference leaves LDLT failure unchecked (bavoxel.hpp:707-710);
+    // here the poses of the last accepted step are returned.
+    trace.resize(n_trace);
+    for (int j = 0; j < N; ++j) {
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) x_stats[j].R(r, c) = poses[12 * j + 3 * r + c];
+        for (int r = 0; r < 3; ++r) x_stats[j].p[r] = poses[12 * j + 9 + r];
+    }
+    return trace;
+}
+
+} // namespace lvba

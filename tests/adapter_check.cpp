@@ -1,0 +1,43 @@
+// Compile/link check of include/lvba_adapter.hpp against stand-ins for the reference's Eigen-based types.
+// Returns 0 if packing is right and (without a GPU) the library refuses loudly, or (with one) refines.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "../include/lvba_adapter.hpp"
+
+struct Mat3 { double m[9]; double &operator()(int r, int c) { return m[3 * r + c]; } double operator()(int r, int c) const { return m[3 * r + c]; } };
+struct PointCluster { Mat3 P; double v[3]; int N; };
+struct IMUST { Mat3 R; double p[3]; };
+struct VOX_HESS { int win_size; std::vector<const std::vector<PointCluster> *> plvec_voxels; };
+
+int main()
+{
+    const int N = 3;
+    std::vector<PointCluster> a(N), b(N);
+    for (auto *vv : {&a, &b})
+        for (auto &c : *vv) { std::memset(&c, 0, sizeof c); }
+    const double pts[4][3] = {{1, 0, 0.01}, {0, 1, -0.01}, {-1, 0, 0.0}, {0, -1, 0.02}};
+    auto push = [&](PointCluster &c, double ox) {
+        for (auto &p : pts) {
+            double q[3] = {p[0] + ox, p[1], p[2]};
+            for (int r = 0; r < 3; ++r) { c.v[r] += q[r]; for (int s = 0; s < 3; ++s) c.P(r, s) += q[r] * q[s]; }
+            c.N++;
+        }
+    };
+    push(a[0], 0.0); push(a[2], 0.1); push(b[1], 0.0); push(b[2], 0.2);
+    VOX_HESS vh{N, {&a, &b}};
+    std::vector<int64_t> off; std::vector<int32_t> idx; std::vector<double> clu;
+    lvba::pack_voxhess(vh, off, idx, clu);
+    if (off != std::vector<int64_t>{0, 2, 4} || idx != std::vector<int32_t>{0, 2, 1, 2} || clu.size() != 40 || clu[9] != 4) return 1;
+    std::vector<IMUST> x(N);
+    for (auto &s : x) { std::memset(&s, 0, sizeof s); s.R(0, 0) = s.R(1, 1) = s.R(2, 2) = 1; }
+    try {
+        auto trace = lvba::damping_iter_hip(x, vh);
+        std::printf("refined on the GPU: %zu LM iterations\n", trace.size());
+    } catch (const std::exception &e) {
+        std::printf("refused: %s\n", e.what());
+        return lvba_device_count() == 0 && std::strstr(e.what(), "no CPU fallback") ? 0 : 2;
+    }
+    return 0;
+}

@@ -73,3 +73,13 @@ def test_vox_hess_mirror_packs_like_the_reference(pkg):
     vh.push_voxel(one)                                   # only one observer: dropped (bavoxel.hpp:52)
     off, idx, clu = vh.pack()
     assert off.tolist() == [0, 2] and idx.tolist() == [1, 3] and clu.shape == (2, 10) and clu[1, 9] == 15
+
+
+def test_cpp_adapter_compiles_and_links(lib, tmp_path):
+    """include/lvba_adapter.hpp (the reference-side binding of INTEGRATION.md) against stand-in types."""
+    import subprocess
+    exe = str(tmp_path / "adapter_check")
+    libdir = os.path.join(ROOT, "global-lvba_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "adapter_check.cpp"), "-o", exe,
+                           "-L", libdir, "-llvba_hip", f"-Wl,-rpath,{libdir}"])
+    assert subprocess.call([exe]) == 0
