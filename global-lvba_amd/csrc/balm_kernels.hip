@@ -246,7 +246,11 @@ __device__ __forceinline__ double row16_sum(double x)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void balm_pair_kernel(BalmDev d, double *__restrict__ Hblk)
 {
-    const int64_t blk = blockIdx.x * (int64_t)16 + (threadIdx.x >> 4);
+    // XCD-aware order: workgroup b runs on XCD b % 8 (observed dispatch rule; speed only).  Give every XCD a
+    // contiguous range of blocks (= a range of block columns J) so pose J's Y segment is re-read from ITS L2.
+    const int64_t per_xcd = (gridDim.x + 7) / 8;
+    const int64_t wg = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int64_t blk = wg * 16 + (threadIdx.x >> 4);
     const int l16 = threadIdx.x & 15;
     const bool live = blk < d.nnzb;
     int64_t o0 = 0, o1 = 0;
@@ -406,7 +410,7 @@ void launch_eval(const BalmDev &d, const double *poses, double *Hblk, int64_t hb
     hipLaunchKernelGGL(balm_factor_kernel, dim3((unsigned)(d.n_poses * d.S)), dim3(256), 0, s, d, poses);
     hipLaunchKernelGGL(balm_diag_reduce_kernel, dim3((unsigned)((32 * (int64_t)d.n_poses + 255) / 256)), dim3(256), 0, s, d, Hblk, g);
     if (d.nnzb > 0)
-        hipLaunchKernelGGL(balm_pair_kernel, dim3((unsigned)((d.nnzb + 15) / 16)), dim3(256), 0, s, d, Hblk);
+        hipLaunchKernelGGL(balm_pair_kernel, dim3((unsigned)((((d.nnzb + 15) / 16) + 7) / 8 * 8)), dim3(256), 0, s, d, Hblk);
     if (k1) hipEventRecord(k1, s);
     hipLaunchKernelGGL(reduce_chunks_kernel, dim3(1), dim3(1024), 0, s, chunk_cost, d.n_chunks, out);
 }

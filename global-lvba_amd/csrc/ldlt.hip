@@ -8,13 +8,15 @@
 // the band only limits the row window [k+NB, k+NB+bw) each panel touches.
 //
 //   per panel k:
-//     K1 ldlt_diag    1 workgroup: LDL^T of the 64x64 diagonal block, one register-resident row per
-//                     thread.  The right-hand side and an identity are appended as extra ROWS, so the same elimination yields
-//                     z_k = D^-1 L11^-1 b_k, y_k = L11^-1 b_k and G = L11^-T D^-1 for free.
-//     K2 ldlt_panel   per 64-row tile: L21 = A21 * G (fp64 MFMA 16x16x4), Z = L21*D, b -= L21*y_k.
+//     K1 ldlt_diag    1 workgroup: LDL^T of the 64x64 diagonal block, register-resident (4 threads per row).
+//                     An identity is appended as extra ROWS, so the same elimination yields G = L11^-T D^-1,
+//                     which turns every later triangular solve with this block into a product.
+//     K2 ldlt_panel   per 64-row tile: L21 = A21 * G (fp64 MFMA 16x16x4), Z = L21*D, y_k = D G^T b_k, b -= L21*y_k.
 //     K3 ldlt_update  per 64x64 lower tile of the window: A22 -= L21 * Z^T (fp64 MFMA 16x16x4).
-//   backward, per panel from the last: x_k = G D s_k (s = updated z), then b[c] -= A(k:k+64, c)^T x_k
+//   backward, per panel from the last: x_k = G D (G^T b_k - acc_k), then acc[c] += A(k:k+64, c)^T x_k
 //   for the <= bw columns left of the panel (right-looking, one launch per panel).
+//   Look-ahead: the bulk of K3 (tile columns >= 1) runs on a second stream beside K3(first column), K1, K2 of
+//   the next panel; the whole static launch sequence is captured once into a hipGraph (lvba_api.hip).
 //
 // MFMA operand layout used (v_mfma_f64_16x16x4_f64): lane l supplies A[i=l&15][k=l>>4] and
 // B[k=l>>4][j=l&15]; result register r of lane l is D[(l>>4)+4r][l&15].  Products are arranged so that
@@ -51,68 +53,74 @@ __global__ void ldlt_prepare_kernel(LdltMat M, const double *__restrict__ Hblk, 
 }
 
 // ---------------------------------------------------------------------------------------------- K1
-// One thread per ROW, the row lives in registers (64 doubles, fully unrolled static indexing).  Rows 0..63
-// are the diagonal block, row 64 the right-hand side, rows 65..128 an identity; eliminating column j needs
-// only the (unscaled) column j broadcast through LDS -> ONE barrier per column (double-buffered).
-// Outputs: L11 (strict lower) and D (diagonal) in place, z_k in b, y_k, d_k, and Gt[c][m] = G[m][c] with
-// G = L11^-T D^-1.
-__global__ __launch_bounds__(192) void ldlt_diag_kernel(LdltMat M, int64_t k, int nbe, double *__restrict__ Gt,
-                                                        double *__restrict__ dvec, double *__restrict__ yvec,
-                                                        double *__restrict__ b, int *__restrict__ status)
+// LDL^T of the 64x64 diagonal block together with G = L11^-T D^-1 (an identity appended as 64 extra ROWS is
+// carried through the same elimination).  128 rows x 4 threads per row: thread (row, h) keeps the entries of
+// its row in columns c = 4q+h (q = 0..15) in registers, so eliminating column j costs each thread at most
+// 16-(j>>2) FMAs, and needs only the unscaled column j broadcast through LDS: ONE barrier per column
+// (double-buffered).  The pivot reciprocal is v_rcp_f64 + 2 Newton steps instead of an IEEE division.
+// Outputs: L11 (strict lower) and D (diagonal) in place, d_k, Gt[c][m] = G[m][c].
+__device__ __forceinline__ double fast_rcp(double d)
 {
-    __shared__ double wv[2][136];
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(r, fma(-d, r, 1.0), r);
+    r = fma(r, fma(-d, r, 1.0), r);
+    return r;
+}
+
+__global__ __launch_bounds__(512) void ldlt_diag_kernel(LdltMat M, int64_t k, int nbe, double *__restrict__ Gt,
+                                                        double *__restrict__ dvec, int *__restrict__ status)
+{
+    __shared__ double wv[2][128];
     const int tid = threadIdx.x;
-    double a[64];
-    if (tid < 64) {
+    const int row = tid & 127, h = tid >> 7;
+    double a[16];
+    if (row < 64) {
 #pragma unroll
-        for (int c = 0; c < 64; ++c) {
+        for (int q = 0; q < 16; ++q) {
+            const int c = 4 * q + h;
             double v = 0.0;
-            if (tid < nbe) {
-                if (c <= tid) v = M.a[(k + tid) + (k + c) * M.ld];
-            } else if (c == tid)
+            if (row < nbe) {
+                if (c <= row) v = M.a[(k + row) + (k + c) * M.ld];
+            } else if (c == row)
                 v = 1.0;
-            a[c] = v;
+            a[q] = v;
         }
-    } else if (tid == 64) {
-#pragma unroll
-        for (int c = 0; c < 64; ++c) a[c] = (c < nbe) ? b[k + c] : 0.0;
     } else {
 #pragma unroll
-        for (int c = 0; c < 64; ++c) a[c] = (c == tid - 65) ? 1.0 : 0.0;
+        for (int q = 0; q < 16; ++q) a[q] = (4 * q + h == row - 64) ? 1.0 : 0.0;
     }
 #pragma unroll
     for (int j = 0; j < 64; ++j) {
+        const int qj = j >> 2, hj = j & 3;
         double *w = wv[j & 1];
-        if (tid <= 128) w[tid] = a[j];
+        if (h == hj) w[row] = a[qj];
         __syncthreads();
         double d = w[j];
         if (!(d != 0.0) || !isfinite(d)) {
             if (tid == 0) status[0] = 1;
             d = 1.0;
         }
-        if (tid == j && j < nbe) dvec[k + j] = d;
-        if (tid == 64 && j < nbe) yvec[k + j] = a[j];
-        if (tid > j) {
-            const double l = a[j] / d;
-            a[j] = l;
+        if (row == j && h == hj && j < nbe) dvec[k + j] = d;
+        if (row > j) {
+            const double l = w[row] * fast_rcp(d);
+            if (h == hj) a[qj] = l;
+            if (h > hj) a[qj] -= l * w[4 * qj + h];
 #pragma unroll
-            for (int c = j + 1; c < 64; ++c) a[c] -= l * w[c];
+            for (int q = qj + 1; q < 16; ++q) a[q] -= l * w[4 * q + h];
         }
     }
-    if (tid < 64) {
-        if (tid < nbe) {
+    if (row < 64) {
+        if (row < nbe) {
 #pragma unroll
-            for (int c = 0; c < 64; ++c)
-                if (c <= tid) M.a[(k + tid) + (k + c) * M.ld] = a[c];
+            for (int q = 0; q < 16; ++q) {
+                const int c = 4 * q + h;
+                if (c <= row) M.a[(k + row) + (k + c) * M.ld] = a[q];
+            }
         }
-    } else if (tid == 64) {
+    } else {
+        const int m = row - 64;
 #pragma unroll
-        for (int c = 0; c < 64; ++c)
-            if (c < nbe) b[k + c] = a[c];
-    } else if (tid <= 128) {
-        const int m = tid - 65;
-#pragma unroll
-        for (int c = 0; c < 64; ++c) Gt[c * 64 + m] = a[c];
+        for (int q = 0; q < 16; ++q) Gt[(4 * q + h) * 64 + m] = a[q];
     }
 }
 
@@ -120,12 +128,12 @@ __global__ __launch_bounds__(192) void ldlt_diag_kernel(LdltMat M, int64_t k, in
 #define LVBA_GS 66 // stride of the [j][m] G tile: 66 = 2 mod 32 -> conflict-free A-operand reads
 __global__ __launch_bounds__(256) void ldlt_panel_kernel(LdltMat M, int64_t k, int nbe, int64_t w0, int64_t rend,
                                                          const double *__restrict__ Gt,
-                                                         const double *__restrict__ dvec,
-                                                         const double *__restrict__ yvec, double *__restrict__ Zws,
+                                                         const double *__restrict__ dvec, double *__restrict__ Zws,
                                                          int64_t ldz, double *__restrict__ b)
 {
     __shared__ double As[64 * LVBA_TS]; // [m][row]; later the L tile as [j][row]
     __shared__ double Gs[64 * LVBA_GS]; // [j][m]
+    __shared__ double bks[64], ys[64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int row = tid & 63;
     const int64_t r0 = w0 + 64 * (int64_t)blockIdx.x;
@@ -137,6 +145,7 @@ __global__ __launch_bounds__(256) void ldlt_panel_kernel(LdltMat M, int64_t k, i
         av[it] = (r < rend && m < nbe) ? M.a[r + (k + m) * M.ld] : 0.0;
         gv[it] = Gt[m * 64 + row]; // Gt[j = m][m' = row]
     }
+    if (tid < 64) bks[tid] = (tid < nbe) ? b[k + tid] : 0.0;
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
         const int m = w + 4 * it;
@@ -144,6 +153,15 @@ __global__ __launch_bounds__(256) void ldlt_panel_kernel(LdltMat M, int64_t k, i
         Gs[m * LVBA_GS + row] = gv[it];
     }
     __syncthreads();
+    if (tid < 64) { // y_k = L11^-1 b_k = D G^T b_k   (b_k is final: every earlier panel already updated it)
+        double z0 = 0.0, z1 = 0.0;
+#pragma unroll 8
+        for (int m = 0; m < 64; m += 2) {
+            z0 += Gs[tid * LVBA_GS + m] * bks[m];
+            z1 += Gs[tid * LVBA_GS + m + 1] * bks[m + 1];
+        }
+        ys[tid] = (tid < nbe) ? (z0 + z1) * dvec[k + tid] : 0.0;
+    }
     d4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
@@ -178,8 +196,8 @@ __global__ __launch_bounds__(256) void ldlt_panel_kernel(LdltMat M, int64_t k, i
             double s0 = 0.0, s1 = 0.0;
 #pragma unroll 8
             for (int j = 0; j < 64; j += 2) {
-                s0 += As[j * LVBA_TS + tid] * yvec[k + j];       // yvec/As are 0 beyond nbe? (As yes, yvec guarded)
-                s1 += As[(j + 1) * LVBA_TS + tid] * yvec[k + j + 1];
+                s0 += As[j * LVBA_TS + tid] * ys[j];
+                s1 += As[(j + 1) * LVBA_TS + tid] * ys[j + 1];
             }
             b[r] -= s0 + s1;
         }
@@ -187,18 +205,25 @@ __global__ __launch_bounds__(256) void ldlt_panel_kernel(LdltMat M, int64_t k, i
 }
 
 // ---------------------------------------------------------------------------------------------- K3
+// mode 0: every lower tile (ti >= tj) of the window; mode 1: only the first tile column (tj = 0);
+// mode 2: ti >= tj >= 1.  Modes 1/2 let the driver run the next panel's K1/K2 beside the bulk of this update.
 __global__ __launch_bounds__(256) void ldlt_update_kernel(LdltMat M, int64_t k, int nbe, int64_t w0, int64_t rend,
-                                                          const double *__restrict__ Zws, int64_t ldz)
+                                                          const double *__restrict__ Zws, int64_t ldz, int mode)
 {
     __shared__ double Ls[64 * LVBA_TS]; // [m][row of tile ti]
     __shared__ double Zs[64 * LVBA_TS]; // [m][row of tile tj] (= column of the updated tile)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    // triangular decode blockIdx.x -> (ti >= tj)
     const int64_t bidx = blockIdx.x;
-    int64_t ti = (int64_t)((sqrt(8.0 * (double)bidx + 1.0) - 1.0) * 0.5);
-    while (ti * (ti + 1) / 2 > bidx) --ti;
-    while ((ti + 1) * (ti + 2) / 2 <= bidx) ++ti;
-    const int64_t tj = bidx - ti * (ti + 1) / 2;
+    int64_t ti, tj;
+    if (mode == 1) {
+        ti = bidx; tj = 0;
+    } else { // triangular decode bidx -> (ti >= tj)
+        ti = (int64_t)((sqrt(8.0 * (double)bidx + 1.0) - 1.0) * 0.5);
+        while (ti * (ti + 1) / 2 > bidx) --ti;
+        while ((ti + 1) * (ti + 2) / 2 <= bidx) ++ti;
+        tj = bidx - ti * (ti + 1) / 2;
+        if (mode == 2) { ++ti; ++tj; }
+    }
     const int64_t r0 = w0 + 64 * ti, c0 = w0 + 64 * tj;
     const int row = tid & 63;
     const int i = lane & 15, kk = lane >> 4;
@@ -251,49 +276,78 @@ __global__ __launch_bounds__(256) void ldlt_update_kernel(LdltMat M, int64_t k, 
 }
 
 // ---------------------------------------------------------------------------------------- backward
+// x_k = L11^-T (z_k - sum_{i>k} L_ik^T x_i),  z_k = D^-1 L11^-1 b_k = G^T b_k,  L11^-T = G D.
+// bacc accumulates sum_{i>k} L_ik^T x_i (right-looking: after x_k is known every column c left of the panel
+// inside the band receives A(k:k+64, c)^T x_k).
 __global__ __launch_bounds__(256) void ldlt_back_kernel(LdltMat M, int64_t k, int nbe, const double *__restrict__ Gt,
-                                                        const double *__restrict__ dvec, double *__restrict__ b,
-                                                        double *__restrict__ x, int64_t cmin)
+                                                        const double *__restrict__ dvec, const double *__restrict__ b,
+                                                        double *__restrict__ bacc, double *__restrict__ x, int64_t cmin)
 {
     constexpr int LS = 65;
-    __shared__ double Gs[64 * LS]; // [i][c] = G[i][c]
-    __shared__ double sd[64], xs[64];
+    __shared__ double Gs[64 * LS]; // [c][m] = G[m][c]
+    __shared__ double bs[64], sd[64], xs[64], red[4 * 64];
     const int tid = threadIdx.x;
+    const int i = tid & 63, q = tid >> 6;
     const int64_t c = cmin + 256 * (int64_t)blockIdx.x + tid;
-    // this thread's column segment A(k..k+63, c), issued before anything waits
+    // this thread's column segment A(k..k+63, c), issued before anything waits (16-byte loads: k, ld are even)
     double colv[64];
     int64_t rmax = k + nbe - 1;
     if (c < k) {
         if (c + M.bw < rmax) rmax = c + M.bw;
-        const double *col = M.a + c * M.ld + k;
+        const double2 *col = reinterpret_cast<const double2 *>(M.a + c * M.ld + k);
 #pragma unroll
-        for (int q = 0; q < 64; ++q) colv[q] = (k + q <= rmax) ? col[q] : 0.0;
+        for (int e = 0; e < 32; ++e) {
+            const double2 v = col[e];
+            colv[2 * e] = (k + 2 * e <= rmax) ? v.x : 0.0;
+            colv[2 * e + 1] = (k + 2 * e + 1 <= rmax) ? v.y : 0.0;
+        }
     }
     double gl[16];
 #pragma unroll
     for (int it = 0; it < 16; ++it) gl[it] = Gt[tid + 256 * it];
+    if (tid < 64) {
+        bs[tid] = (tid < nbe) ? b[k + tid] : 0.0;
+        sd[tid] = (tid < nbe) ? bacc[k + tid] : 0.0; // temporarily: the accumulated right-hand side
+    }
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
-        const int e = tid + 256 * it; // Gt[c'][i]: c' = e>>6, i = e&63
-        Gs[(e & 63) * LS + (e >> 6)] = gl[it];
+        const int e = tid + 256 * it; // Gt[c'][m]: c' = e>>6, m = e&63
+        Gs[(e >> 6) * LS + (e & 63)] = gl[it];
     }
-    if (tid < 64) sd[tid] = (tid < nbe) ? b[k + tid] * dvec[k + tid] : 0.0;
+    __syncthreads();
+    { // z_i = sum_m G[m][i] b_m : thread (i, q) sums m in [16q, 16q+16)
+        double z = 0.0;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) z += Gs[i * LS + 16 * q + m] * bs[16 * q + m];
+        red[q * 64 + i] = z;
+    }
     __syncthreads();
     if (tid < 64) {
-        double acc = 0.0;
-        for (int cc = tid; cc < 64; ++cc) acc += Gs[tid * LS + cc] * sd[cc]; // x_k = (L11^-T D^-1) (D s)
-        xs[tid] = acc;
-        if (blockIdx.x == 0 && tid < nbe) x[k + tid] = acc;
+        const double z = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
+        sd[tid] = (tid < nbe) ? (z - sd[tid]) * dvec[k + tid] : 0.0; // D t
+    }
+    __syncthreads();
+    { // x_i = sum_c G[i][c] (D t)_c : thread (i, q) sums c in [16q, 16q+16)
+        double v = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) v += Gs[(16 * q + cc) * LS + i] * sd[16 * q + cc];
+        red[q * 64 + i] = v;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const double v = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
+        xs[tid] = v;
+        if (blockIdx.x == 0 && tid < nbe) x[k + tid] = v;
     }
     __syncthreads();
     if (c < k) {
         double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-        for (int q = 0; q < 64; q += 2) {
-            s0 += colv[q] * xs[q];
-            s1 += colv[q + 1] * xs[q + 1];
+        for (int e = 0; e < 64; e += 2) {
+            s0 += colv[e] * xs[e];
+            s1 += colv[e + 1] * xs[e + 1];
         }
-        b[c] -= s0 + s1;
+        bacc[c] += s0 + s1;
     }
 }
 
@@ -307,24 +361,32 @@ static inline int64_t ldz_for(int64_t n, int64_t bw)
 int64_t ldlt_workspace_doubles(int64_t n, int64_t bw)
 {
     const int64_t nsteps = (n + LVBA_NB - 1) / LVBA_NB;
-    return nsteps * 4096 /*G*/ + 3 * n /*d, y, b*/ + ldz_for(n, bw) * LVBA_NB /*Z*/ + 64;
+    return nsteps * 4096 /*G*/ + 3 * n /*d, b, bacc*/ + 2 * ldz_for(n, bw) * LVBA_NB /*Z, double-buffered*/ + 64;
 }
 
+int64_t ldlt_num_panels(int64_t n) { return (n + LVBA_NB - 1) / LVBA_NB; }
+
+// Launch sequence of one solve.  s2/evA/evB (2 events per panel) enable the look-ahead: the bulk of panel p's
+// trailing update (tile columns >= 1) runs on s2 while s continues with the first tile column, then K1/K2 of
+// panel p+1.  With s2 == nullptr everything is serial on s.
 void ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_poses, const double *g,
-                const double *u_dev, double *x, double *work, int *status, hipStream_t s)
+                const double *u_dev, double *x, double *work, int *status, hipStream_t s, hipStream_t s2,
+                hipEvent_t *evA, hipEvent_t *evB)
 {
     const int64_t n = A.n, bw = A.bw;
     const int64_t nsteps = (n + LVBA_NB - 1) / LVBA_NB;
     double *Gall = work;
     double *dvec = Gall + nsteps * 4096;
-    double *yvec = dvec + n;
-    double *b = yvec + n;
-    double *Zws = b + n;
+    double *b = dvec + n;
+    double *bacc = b + n;
     const int64_t ldz = ldz_for(n, bw);
+    double *Zbuf[2] = {bacc + n, bacc + n + ldz * LVBA_NB};
     const size_t abytes = (size_t)((A.ld == n) ? n * n : (A.ld + 1) * n) * sizeof(double);
     hipMemsetAsync(A.a, 0, abytes, s);
     hipMemsetAsync(status, 0, sizeof(int), s);
+    hipMemsetAsync(bacc, 0, (size_t)n * sizeof(double), s);
     hipLaunchKernelGGL(ldlt_prepare_kernel, dim3(2048), dim3(256), 0, s, A, Hblk, band_blocks, n_poses, g, u_dev, b);
+    int64_t last_b = -1; // last panel whose bulk update was issued on s2
     for (int64_t st = 0; st < nsteps; ++st) {
         const int64_t k = st * LVBA_NB;
         const int nbe = (int)((n - k) < LVBA_NB ? (n - k) : LVBA_NB);
@@ -332,15 +394,27 @@ void ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_pos
         int64_t rend = k + nbe + bw;
         if (rend > n) rend = n;
         double *G = Gall + st * 4096;
-        hipLaunchKernelGGL(ldlt_diag_kernel, dim3(1), dim3(192), 0, s, A, k, nbe, G, dvec, yvec, b, status);
+        double *Zws = Zbuf[st & 1];
+        hipLaunchKernelGGL(ldlt_diag_kernel, dim3(1), dim3(512), 0, s, A, k, nbe, G, dvec, status);
         if (w0 < rend) {
             const int64_t T = (rend - w0 + 63) / 64;
-            hipLaunchKernelGGL(ldlt_panel_kernel, dim3((unsigned)T), dim3(256), 0, s, A, k, nbe, w0, rend, G, dvec,
-                               yvec, Zws, ldz, b);
-            hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)(T * (T + 1) / 2)), dim3(256), 0, s, A, k, nbe, w0,
-                               rend, Zws, ldz);
+            hipLaunchKernelGGL(ldlt_panel_kernel, dim3((unsigned)T), dim3(256), 0, s, A, k, nbe, w0, rend, G, dvec, Zws, ldz, b);
+            if (s2 && T > 1) {
+                hipEventRecord(evA[st], s);
+                hipStreamWaitEvent(s2, evA[st], 0);
+                hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)((T - 1) * T / 2)), dim3(256), 0, s2, A, k, nbe, w0, rend, Zws, ldz, 2);
+                hipEventRecord(evB[st], s2);
+                // the first tile column (block column st+1) is also written by panel st-1's bulk update
+                if (last_b >= 0) hipStreamWaitEvent(s, evB[last_b], 0);
+                hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)T), dim3(256), 0, s, A, k, nbe, w0, rend, Zws, ldz, 1);
+                last_b = st;
+            } else {
+                if (last_b >= 0) { hipStreamWaitEvent(s, evB[last_b], 0); last_b = -1; }
+                hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)(T * (T + 1) / 2)), dim3(256), 0, s, A, k, nbe, w0, rend, Zws, ldz, 0);
+            }
         }
     }
+    if (last_b >= 0) hipStreamWaitEvent(s, evB[last_b], 0);
     for (int64_t st = nsteps - 1; st >= 0; --st) {
         const int64_t k = st * LVBA_NB;
         const int nbe = (int)((n - k) < LVBA_NB ? (n - k) : LVBA_NB);
@@ -348,7 +422,7 @@ void ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_pos
         if (cmin < 0) cmin = 0;
         const int64_t ncols = k - cmin;
         const unsigned nwg = (unsigned)(ncols > 0 ? (ncols + 255) / 256 : 1);
-        hipLaunchKernelGGL(ldlt_back_kernel, dim3(nwg), dim3(256), 0, s, A, k, nbe, Gall + st * 4096, dvec, b, x, cmin);
+        hipLaunchKernelGGL(ldlt_back_kernel, dim3(nwg), dim3(256), 0, s, A, k, nbe, Gall + st * 4096, dvec, b, bacc, x, cmin);
     }
 }
 

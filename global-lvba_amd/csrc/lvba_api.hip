@@ -78,7 +78,11 @@ struct lvba_balm_s {
     int device = 0;
     int32_t N = 0;
     int64_t V = 0, F = 0, Q = 0, n_chunks = 0, Vglobal = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr;
+    std::vector<hipEvent_t> evA, evB;      // look-ahead fork/join events of the solver, one pair per panel
+    hipGraph_t solve_graph = nullptr;      // the captured launch sequence of one damped solve
+    hipGraphExec_t solve_exec = nullptr;
+    bool graph_tried = false;
     // host copies kept until finalize()
     std::vector<int64_t> h_voff;
     std::vector<int32_t> h_pidx;
@@ -254,6 +258,11 @@ extern "C" int32_t lvba_balm_destroy(lvba_balm_t h)
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+    if (h->solve_exec) hipGraphExecDestroy(h->solve_exec);
+    if (h->solve_graph) hipGraphDestroy(h->solve_graph);
+    for (hipEvent_t e : h->evA) hipEventDestroy(e);
+    for (hipEvent_t e : h->evB) hipEventDestroy(e);
+    if (h->stream2) hipStreamDestroy(h->stream2);
     void *ptrs[] = {h->d_csc_off, h->d_blk_off, h->d_blk_slot, h->d_vox_of_pos, h->d_pairs, h->d_clu_csc, h->d_vrec, h->d_Y,
                     h->d_part, h->d_voff, h->d_chunk_v0, h->d_pidx, h->d_perm, h->d_clu, h->d_hg, h->d_chunk_cost, h->d_pose_in,
                     h->d_pose_cur, h->d_pose_trial, h->d_dx, h->d_out, h->d_scal2, h->d_A, h->d_work, h->d_status};
@@ -546,6 +555,15 @@ static int32_t finalize(lvba_balm_s *h)
     }
     h->A.a = h->d_A;
     TRY(dmalloc(h, &h->d_work, ldlt_workspace_doubles(n, h->A.bw)));
+    if (!getenv("LVBA_NO_LOOKAHEAD")) {
+        HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+        const int64_t np = ldlt_num_panels(n);
+        h->evA.resize(np); h->evB.resize(np);
+        for (int64_t i = 0; i < np; ++i) {
+            HIPCHK(hipEventCreateWithFlags(&h->evA[i], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&h->evB[i], hipEventDisableTiming));
+        }
+    }
     HIPCHK(hipMemset(h->d_hg, 0, (size_t)h->hg_doubles() * sizeof(double)));
     // host copies are no longer needed
     std::vector<int64_t>().swap(h->h_voff);
@@ -649,13 +667,39 @@ static int32_t enqueue_eval(lvba_balm_s *h, const double *d_poses)
     return LVBA_OK;
 }
 
-// enqueue: dx = -(H + u diag H)^-1 g  (u taken from d_scal2[2])
+// enqueue: dx = -(H + u diag H)^-1 g  (u taken from d_scal2[2]).  The launch sequence is static per handle
+// (~5 kernels per 64-column panel on two streams), so it is captured once into a hipGraph and replayed.
+static void solve_launches(lvba_balm_s *h)
+{
+    ldlt_solve(h->A, h->Hblk(), h->Bb, h->N, h->g(), h->d_scal2 + 2, h->d_dx, h->d_work, h->d_status, h->stream,
+               h->stream2, h->evA.empty() ? nullptr : h->evA.data(), h->evB.empty() ? nullptr : h->evB.data());
+}
+
 static int32_t enqueue_solve(lvba_balm_s *h, double u)
 {
     h->h_pin[8] = u;
     HIPCHK(hipMemcpyAsync(h->d_scal2 + 2, h->h_pin + 8, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (!h->graph_tried) {
+        h->graph_tried = true;
+        if (!getenv("LVBA_NO_GRAPH")) {
+            (void)hipGetLastError();
+            if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                solve_launches(h);
+                hipGraph_t gph = nullptr;
+                if (hipStreamEndCapture(h->stream, &gph) == hipSuccess && gph &&
+                    hipGraphInstantiate(&h->solve_exec, gph, nullptr, nullptr, 0) == hipSuccess) {
+                    h->solve_graph = gph;
+                } else {
+                    if (gph) hipGraphDestroy(gph);
+                    h->solve_exec = nullptr;
+                }
+            }
+            (void)hipGetLastError(); // a failed capture falls back to eager launches
+        }
+    }
     ev_begin(h, EV_SOLVE);
-    ldlt_solve(h->A, h->Hblk(), h->Bb, h->N, h->g(), h->d_scal2 + 2, h->d_dx, h->d_work, h->d_status, h->stream);
+    if (h->solve_exec) HIPCHK(hipGraphLaunch(h->solve_exec, h->stream));
+    else solve_launches(h);
     ev_end(h, EV_SOLVE);
     HIPCHK(hipGetLastError());
     return LVBA_OK;
