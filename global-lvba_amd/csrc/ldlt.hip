@@ -8,7 +8,7 @@
 // the band only limits the row window [k+NB, k+NB+bw) each panel touches.
 //
 //   per panel k:
-//     K1 ldlt_diag    1 workgroup: LDL^T of the 64x64 diagonal block, register-resident (4 threads per row).
+//     K1 ldlt_diag    1 workgroup, 2 wavefronts, barrier-free: LDL^T of the 64x64 diagonal block, register-resident.
 //                     An identity is appended as extra ROWS, so the same elimination yields G = L11^-T D^-1,
 //                     which turns every later triangular solve with this block into a product.
 //     K2 ldlt_panel   per 64-row tile: L21 = A21 * G (fp64 MFMA 16x16x4), Z = L21*D, y_k = D G^T b_k, b -= L21*y_k.
@@ -23,6 +23,7 @@
 // l&15 indexes ROWS of the column-major target, i.e. 16 lanes touch 128 contiguous bytes.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <utility>
 #include "lvba_internal.h"
 
 namespace lvba {
@@ -53,12 +54,17 @@ __global__ void ldlt_prepare_kernel(LdltMat M, const double *__restrict__ Hblk, 
 }
 
 // ---------------------------------------------------------------------------------------------- K1
-// LDL^T of the 64x64 diagonal block together with G = L11^-T D^-1 (an identity appended as 64 extra ROWS is
-// carried through the same elimination).  128 rows x 4 threads per row: thread (row, h) keeps the entries of
-// its row in columns c = 4q+h (q = 0..15) in registers, so eliminating column j costs each thread at most
-// 16-(j>>2) FMAs, and needs only the unscaled column j broadcast through LDS: ONE barrier per column
-// (double-buffered).  The pivot reciprocal is v_rcp_f64 + 2 Newton steps instead of an IEEE division.
-// Outputs: L11 (strict lower) and D (diagonal) in place, d_k, Gt[c][m] = G[m][c].
+// LDL^T of the 64x64 diagonal block together with G = L11^-T D^-1 (an identity appended as 64 extra ROWS and
+// carried through the same elimination).  TWO wavefronts, NO barriers in the column loop:
+//   wave 0 (lane = matrix row, the row's 64 entries in registers) eliminates column after column; the unscaled
+//          column j is published in an LDS table Wtab[j][*] followed by a progress flag.  Column j+1 is updated
+//          and published FIRST, then the rest of the rank-1 update runs while that LDS round trip is in flight
+//          and the next step's operands are already being read back (software pipelining through one w[] array).
+//   wave 1 (lane = identity row) trails it: waits for the flag, reads the same columns, updates its G row.
+// Measured history on MI355X: barrier-per-column variants cost 610-880 cycles/column (s_barrier ~230, the
+// LDS write->read round trip and the reciprocal chain all serialised); this form is latency-pipelined.
+// The pivot reciprocal is v_rcp_f64 + 2 Newton steps instead of an IEEE division.
+// Outputs: d_k and G[m][c] (row-major 64x64).
 __device__ __forceinline__ double fast_rcp(double d)
 {
     double r = __builtin_amdgcn_rcp(d);
@@ -67,67 +73,195 @@ __device__ __forceinline__ double fast_rcp(double d)
     return r;
 }
 
-__global__ __launch_bounds__(512) void ldlt_diag_kernel(LdltMat M, int64_t k, int nbe, double *__restrict__ Gt,
+#ifdef LVBA_K1_TIMING
+__device__ unsigned long long g_k1_clk[8];
+__device__ unsigned long long g_k1_step[2][64];
+#define LVBA_K1_STAMP(i) do { if (threadIdx.x == 0) g_k1_clk[i] = __builtin_readcyclecounter(); } while (0)
+#define LVBA_K1_STEPSTAMP(role, j) do { if ((threadIdx.x & 63) == 0) g_k1_step[role][j] = __builtin_readcyclecounter(); } while (0)
+#else
+#define LVBA_K1_STAMP(i)
+#define LVBA_K1_STEPSTAMP(role, j)
+#endif
+
+typedef double vdouble; // plain LDS accesses; ordering comes from LVBA_CBAR + the LDS executing a wave's ops in order
+#define LVBA_CBAR() asm volatile("" ::: "memory") // compiler-only barrier (emits nothing)
+#define LVBA_PIN(x) asm volatile("" : "+v"(x))    // keep the value computed HERE (LLVM otherwise sinks it to its first use)
+
+// wave 0, elimination step with compile-time column J (a runtime index would make a[J] dynamic register
+// indexing).  rd enters as 1/pivot_J and leaves as 1/pivot_{J+1}: the reciprocal chain of the NEXT pivot is
+// issued in the middle of this step's FMA stream, off the critical path.
+template <int J>
+__device__ __forceinline__ void k1_core_step(double (&a)[64], double (&w)[64], vdouble *Wtab, volatile int *flag, int lane,
+                                             double &rd)
+{
+    LVBA_K1_STEPSTAMP(0, J);
+    const double l = (lane > J) ? a[J] * rd : 0.0; // finished rows: l = 0 leaves them untouched
+    a[J] = (lane > J) ? l : a[J];
+    if constexpr (J + 1 < 64) {
+        a[J + 1] = fma(-l, w[J + 1], a[J + 1]);
+        Wtab[(J + 1) * 64 + lane] = a[J + 1]; // publish the next column before finishing this step
+        LVBA_CBAR();
+        *flag = J + 1;
+        LVBA_CBAR();
+        w[J + 1] = Wtab[(J + 1) * 64 + J + 1]; // next pivot first
+        // operands of the next step are read back (16 bytes at a time where aligned) while the FMAs run
+        constexpr int C0 = (J + 2) + ((J + 2) & 1); // first even column >= J+2
+        constexpr int CR = (C0 + 12 < 64) ? C0 + 12 : C0; // where the next reciprocal is slotted in
+        if constexpr (C0 > J + 2) {
+            a[J + 2] = fma(-l, w[J + 2], a[J + 2]);
+            LVBA_PIN(a[J + 2]);
+            w[J + 2] = Wtab[(J + 1) * 64 + J + 2];
+        }
+        if constexpr (C0 >= 64) rd = fast_rcp(w[J + 1]);
+#pragma unroll
+        for (int c = C0; c < 64; c += 2) {
+            if (c == CR) { rd = fast_rcp(w[J + 1]); LVBA_PIN(rd); }
+            a[c] = fma(-l, w[c], a[c]);
+            a[c + 1] = fma(-l, w[c + 1], a[c + 1]);
+            LVBA_PIN(a[c]);
+            LVBA_PIN(a[c + 1]);
+            const double2 t = *reinterpret_cast<const double2 *>(&Wtab[(J + 1) * 64 + c]);
+            w[c] = t.x;
+            w[c + 1] = t.y;
+        }
+    }
+}
+
+// wave 1, the same step for the identity rows (G), trailing wave 0 through the flag
+template <int J>
+__device__ __forceinline__ void k1_g_step(double (&g)[64], double (&w)[64], vdouble *Wtab, volatile int *flag, double &rd)
+{
+    LVBA_K1_STEPSTAMP(1, J);
+    const double l = g[J] * rd;
+    g[J] = l;
+    if constexpr (J + 1 < 64) {
+        while (*flag < J + 1) {}
+        LVBA_CBAR();
+        constexpr int C0 = (J + 1) + ((J + 1) & 1); // first even column >= J+1
+        constexpr int CR = (C0 + 12 < 64) ? C0 + 12 : C0;
+        double pn; // next pivot
+        if constexpr (C0 > J + 1) {
+            g[J + 1] = fma(-l, w[J + 1], g[J + 1]);
+            LVBA_PIN(g[J + 1]);
+            w[J + 1] = Wtab[(J + 1) * 64 + J + 1];
+            pn = w[J + 1];
+        } else {
+            pn = Wtab[(J + 1) * 64 + J + 1];
+        }
+        if constexpr (C0 >= 64) rd = fast_rcp(pn);
+#pragma unroll
+        for (int c = C0; c < 64; c += 2) {
+            if (c == CR) { rd = fast_rcp(pn); LVBA_PIN(rd); }
+            g[c] = fma(-l, w[c], g[c]);
+            g[c + 1] = fma(-l, w[c + 1], g[c + 1]);
+            LVBA_PIN(g[c]);
+            LVBA_PIN(g[c + 1]);
+            const double2 t = *reinterpret_cast<const double2 *>(&Wtab[(J + 1) * 64 + c]);
+            w[c] = t.x;
+            w[c + 1] = t.y;
+        }
+    }
+}
+
+template <int... Js>
+__device__ __forceinline__ void k1_core_steps(std::integer_sequence<int, Js...>, double (&a)[64], double (&w)[64],
+                                              vdouble *Wtab, volatile int *flag, int lane, double rd)
+{
+    (k1_core_step<Js>(a, w, Wtab, flag, lane, rd), ...);
+}
+template <int... Js>
+__device__ __forceinline__ void k1_g_steps(std::integer_sequence<int, Js...>, double (&g)[64], double (&w)[64],
+                                           vdouble *Wtab, volatile int *flag, double rd)
+{
+    (k1_g_step<Js>(g, w, Wtab, flag, rd), ...);
+}
+
+__global__ __launch_bounds__(128) void ldlt_diag_kernel(LdltMat M, int64_t k, int nbe, double *__restrict__ G,
                                                         double *__restrict__ dvec, int *__restrict__ status)
 {
-    __shared__ double wv[2][128];
+    LVBA_K1_STAMP(0);
+    __shared__ __attribute__((aligned(16))) double Wtab_s[64 * 64];
+    __shared__ int flag_s;
+    vdouble *Wtab = Wtab_s;
+    volatile int *flag = &flag_s;
     const int tid = threadIdx.x;
-    const int row = tid & 127, h = tid >> 7;
-    double a[16];
-    if (row < 64) {
+    const int lane = tid & 63;
+    const int role = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid == 0) flag_s = -1;
+    double a[64], w[64];
+    // initial load of the block, split over both waves: wave 0 takes columns 0..31 straight into registers,
+    // wave 1 stages columns 32..63 in the (still unused) upper half of Wtab
+    if (role == 0) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int c = 4 * q + h;
+        for (int c = 0; c < 32; ++c) {
             double v = 0.0;
-            if (row < nbe) {
-                if (c <= row) v = M.a[(k + row) + (k + c) * M.ld];
-            } else if (c == row)
+            if (lane < nbe) {
+                if (c <= lane) v = M.a[(k + lane) + (k + c) * M.ld];
+            } else if (c == lane)
                 v = 1.0;
-            a[q] = v;
+            a[c] = v;
         }
     } else {
+        double t[32];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) a[q] = (4 * q + h == row - 64) ? 1.0 : 0.0;
+        for (int c = 32; c < 64; ++c) {
+            double v = 0.0;
+            if (lane < nbe) {
+                if (c <= lane) v = M.a[(k + lane) + (k + c) * M.ld];
+            } else if (c == lane)
+                v = 1.0;
+            t[c - 32] = v;
+        }
+#pragma unroll
+        for (int c = 32; c < 64; ++c) Wtab[c * 64 + lane] = t[c - 32];
+#pragma unroll
+        for (int c = 0; c < 64; ++c) a[c] = (c == lane) ? 1.0 : 0.0;
     }
+    __syncthreads(); // flag initialised, staged half visible
+    if (role == 0) {
 #pragma unroll
-    for (int j = 0; j < 64; ++j) {
-        const int qj = j >> 2, hj = j & 3;
-        double *w = wv[j & 1];
-        if (h == hj) w[row] = a[qj];
-        __syncthreads();
-        double d = w[j];
-        if (!(d != 0.0) || !isfinite(d)) {
-            if (tid == 0) status[0] = 1;
-            d = 1.0;
-        }
-        if (row == j && h == hj && j < nbe) dvec[k + j] = d;
-        if (row > j) {
-            const double l = w[row] * fast_rcp(d);
-            if (h == hj) a[qj] = l;
-            if (h > hj) a[qj] -= l * w[4 * qj + h];
+        for (int c = 32; c < 64; ++c) a[c] = Wtab[c * 64 + lane];
 #pragma unroll
-            for (int q = qj + 1; q < 16; ++q) a[q] -= l * w[4 * q + h];
-        }
+        for (int c = 32; c < 64; ++c) LVBA_PIN(a[c]);
     }
-    if (row < 64) {
-        if (row < nbe) {
+    LVBA_K1_STAMP(1);
+    if (role == 0) {
+        Wtab[lane] = a[0];
+        LVBA_CBAR();
+        *flag = 0;
+        LVBA_CBAR();
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int c = 4 * q + h;
-                if (c <= row) M.a[(k + row) + (k + c) * M.ld] = a[q];
-            }
-        }
+        for (int c = 0; c < 64; ++c) w[c] = Wtab[c];
+        k1_core_steps(std::make_integer_sequence<int, 64>{}, a, w, Wtab, flag, lane, fast_rcp(w[0]));
     } else {
-        const int m = row - 64;
+        while (*flag < 0) {}
+        LVBA_CBAR();
 #pragma unroll
-        for (int q = 0; q < 16; ++q) Gt[(4 * q + h) * 64 + m] = a[q];
+        for (int c = 0; c < 64; ++c) w[c] = Wtab[c];
+        k1_g_steps(std::make_integer_sequence<int, 64>{}, a, w, Wtab, flag, fast_rcp(w[0]));
     }
+    LVBA_K1_STAMP(2);
+    if (role == 0) {
+        // a[lane] is the pivot of row `lane` (updated by every earlier column, never scaled)
+        double dl = 0.0;
+#pragma unroll
+        for (int c = 0; c < 64; ++c) dl = (c == lane) ? a[c] : dl;
+        const bool badp = (lane < nbe) && (!(dl != 0.0) || !isfinite(dl));
+        if (__any(badp) && lane == 0) status[0] = 1;
+        // L11 itself is never read again (every later stage uses G and D), so it is not written back
+        if (lane < nbe) dvec[k + lane] = dl;
+    } else {
+        double2 *go = reinterpret_cast<double2 *>(G + 64 * lane); // G[m][c], row m = lane: 512 contiguous bytes
+#pragma unroll
+        for (int c = 0; c < 64; c += 2) go[c >> 1] = make_double2(a[c], a[c + 1]);
+    }
+    LVBA_K1_STAMP(3);
 }
 
 // ---------------------------------------------------------------------------------------------- K2
 #define LVBA_GS 66 // stride of the [j][m] G tile: 66 = 2 mod 32 -> conflict-free A-operand reads
 __global__ __launch_bounds__(256) void ldlt_panel_kernel(LdltMat M, int64_t k, int nbe, int64_t w0, int64_t rend,
-                                                         const double *__restrict__ Gt,
+                                                         const double *__restrict__ G,
                                                          const double *__restrict__ dvec, double *__restrict__ Zws,
                                                          int64_t ldz, double *__restrict__ b)
 {
@@ -143,14 +277,14 @@ __global__ __launch_bounds__(256) void ldlt_panel_kernel(LdltMat M, int64_t k, i
     for (int it = 0; it < 16; ++it) {
         const int m = w + 4 * it;
         av[it] = (r < rend && m < nbe) ? M.a[r + (k + m) * M.ld] : 0.0;
-        gv[it] = Gt[m * 64 + row]; // Gt[j = m][m' = row]
+        gv[it] = G[m * 64 + row]; // G[m][j = row], lanes along j: coalesced
     }
     if (tid < 64) bks[tid] = (tid < nbe) ? b[k + tid] : 0.0;
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
         const int m = w + 4 * it;
         As[m * LVBA_TS + row] = av[it];
-        Gs[m * LVBA_GS + row] = gv[it];
+        Gs[row * LVBA_GS + m] = gv[it]; // [j][m]
     }
     __syncthreads();
     if (tid < 64) { // y_k = L11^-1 b_k = D G^T b_k   (b_k is final: every earlier panel already updated it)
@@ -279,7 +413,7 @@ __global__ __launch_bounds__(256) void ldlt_update_kernel(LdltMat M, int64_t k, 
 // x_k = L11^-T (z_k - sum_{i>k} L_ik^T x_i),  z_k = D^-1 L11^-1 b_k = G^T b_k,  L11^-T = G D.
 // bacc accumulates sum_{i>k} L_ik^T x_i (right-looking: after x_k is known every column c left of the panel
 // inside the band receives A(k:k+64, c)^T x_k).
-__global__ __launch_bounds__(256) void ldlt_back_kernel(LdltMat M, int64_t k, int nbe, const double *__restrict__ Gt,
+__global__ __launch_bounds__(256) void ldlt_back_kernel(LdltMat M, int64_t k, int nbe, const double *__restrict__ G,
                                                         const double *__restrict__ dvec, const double *__restrict__ b,
                                                         double *__restrict__ bacc, double *__restrict__ x, int64_t cmin)
 {
@@ -304,15 +438,15 @@ __global__ __launch_bounds__(256) void ldlt_back_kernel(LdltMat M, int64_t k, in
     }
     double gl[16];
 #pragma unroll
-    for (int it = 0; it < 16; ++it) gl[it] = Gt[tid + 256 * it];
+    for (int it = 0; it < 16; ++it) gl[it] = G[tid + 256 * it];
     if (tid < 64) {
         bs[tid] = (tid < nbe) ? b[k + tid] : 0.0;
         sd[tid] = (tid < nbe) ? bacc[k + tid] : 0.0; // temporarily: the accumulated right-hand side
     }
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
-        const int e = tid + 256 * it; // Gt[c'][m]: c' = e>>6, m = e&63
-        Gs[(e >> 6) * LS + (e & 63)] = gl[it];
+        const int e = tid + 256 * it; // G[m][c']: m = e>>6, c' = e&63
+        Gs[(e & 63) * LS + (e >> 6)] = gl[it];
     }
     __syncthreads();
     { // z_i = sum_m G[m][i] b_m : thread (i, q) sums m in [16q, 16q+16)
@@ -395,7 +529,7 @@ void ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_pos
         if (rend > n) rend = n;
         double *G = Gall + st * 4096;
         double *Zws = Zbuf[st & 1];
-        hipLaunchKernelGGL(ldlt_diag_kernel, dim3(1), dim3(512), 0, s, A, k, nbe, G, dvec, status);
+        hipLaunchKernelGGL(ldlt_diag_kernel, dim3(1), dim3(128), 0, s, A, k, nbe, G, dvec, status);
         if (w0 < rend) {
             const int64_t T = (rend - w0 + 63) / 64;
             hipLaunchKernelGGL(ldlt_panel_kernel, dim3((unsigned)T), dim3(256), 0, s, A, k, nbe, w0, rend, G, dvec, Zws, ldz, b);

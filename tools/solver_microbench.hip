@@ -1,0 +1,72 @@
+// tools/solver_microbench.hip -- standalone timing of the LDL^T kernels (development tool, not product).
+// Includes ldlt.hip directly.  usage: solver_microbench [n=12000] [bw=2813]
+#define LVBA_K1_TIMING
+#include "../global-lvba_amd/csrc/ldlt.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+using namespace lvba;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+template <class F> static float time_ms(hipStream_t s, int reps, F f)
+{
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    f(); CK(hipStreamSynchronize(s));
+    CK(hipEventRecord(a, s));
+    for (int i = 0; i < reps; ++i) f();
+    CK(hipEventRecord(b, s)); CK(hipEventSynchronize(b));
+    float ms = 0; CK(hipEventElapsedTime(&ms, a, b));
+    return ms / reps;
+}
+
+int main(int argc, char **argv)
+{
+    const int64_t n = argc > 1 ? atoll(argv[1]) : 12000, bw = argc > 2 ? atoll(argv[2]) : 2813;
+    const int64_t ldab = bw + LVBA_NB + 64;
+    LdltMat A; A.n = n; A.ld = ldab - 1; A.bw = bw;
+    std::vector<double> hA((size_t)ldab * n + ldab, 0.0);
+    srand(1);
+    for (int64_t c = 0; c < n; ++c) {
+        for (int64_t o = 1; o <= bw && c + o < n; ++o) hA[o + c * ldab] = 0.02 * (rand() / (double)RAND_MAX - 0.5);
+        hA[c * ldab] = 2.0 + bw * 0.01;
+    }
+    CK(hipMalloc((void **)&A.a, hA.size() * 8)); CK(hipMemcpy(A.a, hA.data(), hA.size() * 8, hipMemcpyHostToDevice));
+    const int64_t nsteps = ldlt_num_panels(n);
+    double *work; CK(hipMalloc((void **)&work, ldlt_workspace_doubles(n, bw) * 8)); CK(hipMemset(work, 0, ldlt_workspace_doubles(n, bw) * 8));
+    double *Gall = work, *dvec = Gall + nsteps * 4096, *b = dvec + n, *bacc = b + n;
+    const int64_t ldz = ldz_for(n, bw);
+    double *Zws = bacc + n;
+    int *status; CK(hipMalloc((void **)&status, 4)); CK(hipMemset(status, 0, 4));
+    double *x; CK(hipMalloc((void **)&x, n * 8));
+    hipStream_t s; CK(hipStreamCreate(&s));
+    const int64_t k = 64 * 10, w0 = k + 64, rend = (k + 64 + bw < n) ? k + 64 + bw : n, T = (rend - w0 + 63) / 64;
+    printf("n=%lld bw=%lld panels=%lld T=%lld\n", (long long)n, (long long)bw, (long long)nsteps, (long long)T);
+    float t;
+    t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_diag_kernel, dim3(1), dim3(128), 0, s, A, k, 64, Gall, dvec, status); });
+    unsigned long long clk[8]; CK(hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_k1_clk), sizeof clk));
+    printf("K1 diag   %8.2f us   cycles: init %llu  loop %llu (%.0f/col)  store %llu\n", t * 1e3, clk[1] - clk[0], clk[2] - clk[1],
+           (clk[2] - clk[1]) / 64.0, clk[3] - clk[2]);
+    {
+        unsigned long long st[2][64]; CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_k1_step), sizeof st));
+        printf("   wave0 per-step cycles:");
+        for (int j = 1; j < 64; ++j) printf(" %llu", st[0][j] - st[0][j - 1]);
+        printf("\n   wave1 lag behind wave0 (cycles) at steps 1,16,32,48,63: %lld %lld %lld %lld %lld\n", (long long)(st[1][1] - st[0][1]),
+               (long long)(st[1][16] - st[0][16]), (long long)(st[1][32] - st[0][32]), (long long)(st[1][48] - st[0][48]), (long long)(st[1][63] - st[0][63]));
+    }
+    t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_panel_kernel, dim3((unsigned)T), dim3(256), 0, s, A, k, 64, w0, rend, Gall, dvec, Zws, ldz, b); });
+    printf("K2 panel  %8.2f us  (%lld tiles)\n", t * 1e3, (long long)T);
+    t = time_ms(s, 100, [&] { hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)(T * (T + 1) / 2)), dim3(256), 0, s, A, k, 64, w0, rend, Zws, ldz, 0); });
+    printf("K3 update %8.2f us  (%lld tiles, %.1f TFLOP/s)\n", t * 1e3, (long long)(T * (T + 1) / 2), T * (T + 1) / 2 * 2.0 * 64 * 64 * 64 / (t * 1e-3) / 1e12);
+    t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)T), dim3(256), 0, s, A, k, 64, w0, rend, Zws, ldz, 1); });
+    printf("K3a col0  %8.2f us\n", t * 1e3);
+    t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_back_kernel, dim3((unsigned)((bw + 255) / 256)), dim3(256), 0, s, A, k + bw, 64, Gall, dvec, b, bacc, x, k); });
+    printf("back      %8.2f us\n", t * 1e3);
+    t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_diag_kernel, dim3(1), dim3(128), 0, s, A, k, 64, Gall, dvec, status);
+                              hipLaunchKernelGGL(ldlt_panel_kernel, dim3((unsigned)T), dim3(256), 0, s, A, k, 64, w0, rend, Gall, dvec, Zws, ldz, b);
+                              hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)T), dim3(256), 0, s, A, k, 64, w0, rend, Zws, ldz, 1); });
+    printf("K1+K2+K3a chain %8.2f us\n", t * 1e3);
+    // empty-kernel launch chain for reference
+    t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_prepare_kernel, dim3(1), dim3(64), 0, s, A, work, 0, 0, work, work, work); });
+    printf("tiny kernel back-to-back %8.2f us\n", t * 1e3);
+    return 0;
+}
