@@ -244,7 +244,7 @@ __device__ __forceinline__ double row16_sum(double x)
 // pass 3 (block-major): 16 lanes (one DPP row) own one off-diagonal block; each lane takes one
 // contributing voxel (a pair of Y records) per iteration and forms the 6x6 rank-3 product in registers.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void balm_pair_kernel(BalmDev d, double *__restrict__ Hblk)
+__global__ __launch_bounds__(256) void balm_pair_kernel(PairDev d, double *__restrict__ Hblk)
 {
     // XCD-aware order: workgroup b runs on XCD b % 8 (observed dispatch rule; speed only).  Give every XCD a
     // contiguous range of blocks (= a range of block columns J) so pose J's Y segment is re-read from ITS L2.
@@ -401,7 +401,13 @@ void launch_cost(const BalmDev &d, const double *poses, double *chunk_cost, doub
     hipLaunchKernelGGL(reduce_chunks_kernel, dim3(1), dim3(1024), 0, s, chunk_cost, d.n_chunks, out);
 }
 
-void launch_eval(const BalmDev &d, const double *poses, double *Hblk, int64_t hblk_doubles, double *g,
+void launch_pairs(const PairDev &pd, double *Hblk, hipStream_t s)
+{
+    if (pd.nnzb > 0)
+        hipLaunchKernelGGL(balm_pair_kernel, dim3((unsigned)((((pd.nnzb + 15) / 16) + 7) / 8 * 8)), dim3(256), 0, s, pd, Hblk);
+}
+
+void launch_eval(const BalmDev &d, const PairDev &pd, const double *poses, double *Hblk, int64_t hblk_doubles, double *g,
                  double *chunk_cost, double *out, bool zero_first, hipStream_t s, hipEvent_t k0, hipEvent_t k1)
 {
     if (zero_first) hipMemsetAsync(Hblk, 0, (size_t)hblk_doubles * sizeof(double), s);
@@ -409,8 +415,7 @@ void launch_eval(const BalmDev &d, const double *poses, double *Hblk, int64_t hb
     hipLaunchKernelGGL(balm_voxel_kernel, dim3((unsigned)d.n_chunks), dim3(LVBA_CF), 0, s, d, poses, chunk_cost);
     hipLaunchKernelGGL(balm_factor_kernel, dim3((unsigned)(d.n_poses * d.S)), dim3(256), 0, s, d, poses);
     hipLaunchKernelGGL(balm_diag_reduce_kernel, dim3((unsigned)((32 * (int64_t)d.n_poses + 255) / 256)), dim3(256), 0, s, d, Hblk, g);
-    if (d.nnzb > 0)
-        hipLaunchKernelGGL(balm_pair_kernel, dim3((unsigned)((((d.nnzb + 15) / 16) + 7) / 8 * 8)), dim3(256), 0, s, d, Hblk);
+    launch_pairs(pd, Hblk, s);
     if (k1) hipEventRecord(k1, s);
     hipLaunchKernelGGL(reduce_chunks_kernel, dim3(1), dim3(1024), 0, s, chunk_cost, d.n_chunks, out);
 }

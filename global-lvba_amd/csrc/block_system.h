@@ -1,0 +1,81 @@
+// block_system.h -- the part of the solver that both stages share: a set of N 6-dof blocks (LiDAR poses or
+// cameras), F factors each attached to one block and grouped into G groups (voxels / landmark tracks), and the
+// symmetric block system   H = blockdiag(.) - sum_groups Y Y^T   that couples the blocks of a group.
+// BlockSys owns: the fill-reducing block ordering, the pose-major ("CSC") factor order, the per-block pair lists
+// of the atomic-free assembly, the block-band store [H | g | scalars], the LDL^T workspace + captured hipGraph,
+// and the RCCL communicator.  The factor payload (clusters, observations) stays with the caller.
+#pragma once
+#include <vector>
+#include "lvba_common.h"
+#include "lvba_internal.h"
+
+namespace lvba {
+
+struct BlockSys {
+    int device = 0;
+    hipStream_t stream = nullptr, stream2 = nullptr;
+    int32_t N = 0;
+    int64_t G = 0, F = 0, Q = 0;
+    // configuration
+    int ordering = 1;
+    double band_frac = 0.6;
+    // ordering / layout
+    std::vector<int32_t> perm, iperm; // perm[internal] = caller, iperm[caller] = internal
+    int32_t Bb = 0;
+    bool use_band = false, built = false;
+    int32_t *d_perm = nullptr;
+    // pose-major order + pair lists
+    int32_t S = 1;        // slices per block for the per-factor reduction
+    int64_t nnzb = 0;
+    int64_t *d_csc_off = nullptr, *d_blk_off = nullptr, *d_blk_slot = nullptr;
+    int32_t *d_group_of_pos = nullptr, *d_csc_f = nullptr, *d_pos_of = nullptr;
+    int2 *d_pairs = nullptr;
+    double *d_Y = nullptr; // [F][18]
+    // block-band store
+    double *d_hg = nullptr; // [Hblk | g | scal(8)] contiguous: one all-reduce covers all
+    int64_t hblk_doubles = 0;
+    // solver
+    LdltMat A{};
+    double *d_A = nullptr, *d_work = nullptr, *d_dx = nullptr, *d_u = nullptr, *h_pin_u = nullptr;
+    int *d_status = nullptr;
+    std::vector<hipEvent_t> evA, evB;
+    hipGraph_t solve_graph = nullptr;
+    hipGraphExec_t solve_exec = nullptr;
+    bool graph_tried = false;
+    // distributed
+    int n_ranks = 1, rank = 0;
+    ncclComm_t comm = nullptr;
+    int64_t device_bytes = 0;
+
+    double *Hblk() const { return d_hg; }
+    double *g() const { return d_hg + hblk_doubles; }
+    double *scal() const { return d_hg + hblk_doubles + 6 * (int64_t)N; }
+    int64_t hg_doubles() const { return hblk_doubles + 6 * (int64_t)N + 8; }
+    PairDev pair_dev() const
+    {
+        PairDev p;
+        p.nnzb = nnzb; p.blk_off = d_blk_off; p.blk_slot = d_blk_slot; p.pairs = d_pairs; p.Y = d_Y;
+        return p;
+    }
+};
+
+template <typename T>
+int32_t bs_dmalloc(BlockSys &bs, T **p, int64_t count)
+{
+    HIPCHK(hipMalloc((void **)p, (size_t)(count > 0 ? count : 1) * sizeof(T)));
+    bs.device_bytes += count * (int64_t)sizeof(T);
+    return LVBA_OK;
+}
+
+// Creates the stream(s).  Call once, before bs_dist_init / bs_build.
+int32_t bs_init(BlockSys &bs, int device);
+// voff [G+1] (0-based) and pidx [F] (caller block indices) are host arrays; groups may have any size >= 0.
+int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const int32_t *pidx);
+// enqueue: dx = -(H + u diag H)^-1 g on bs.stream (u = 0: H is used as assembled)
+int32_t bs_enqueue_solve(BlockSys &bs, double u);
+// all-reduce `count` doubles in place over the ranks (no-op without a communicator)
+int32_t bs_allreduce(BlockSys &bs, double *buf, size_t count);
+int32_t bs_dist_init(BlockSys &bs, int32_t n_ranks, int32_t rank, const char uid[128], int64_t *group_count_inout);
+void bs_destroy(BlockSys &bs);
+
+} // namespace lvba

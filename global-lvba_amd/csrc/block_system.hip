@@ -1,0 +1,427 @@
+// block_system.hip -- shared host logic of both stages (see block_system.h): error message storage, lazy RCCL
+// binding, block ordering (RCM + barycenter refinement), pose-major factor order and per-block pair lists of the
+// atomic-free assembly, block-band store, LDL^T solve (captured into a hipGraph), all-reduce.
+#include <dlfcn.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <queue>
+#include <vector>
+#include "block_system.h"
+
+// ------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+int32_t lvba_fail(int32_t code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+extern "C" const char *lvba_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------ RCCL (lazy)
+RcclApi g_rccl;
+int32_t rccl_load()
+{
+    if (g_rccl.lib) return LVBA_OK;
+    void *lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return lvba_fail(LVBA_ERR_DIST, "dlopen(librccl.so) failed: %s", dlerror());
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(lib, "ncclCommInitRank");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(lib, "ncclAllReduce");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(lib, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
+        return lvba_fail(LVBA_ERR_DIST, "librccl.so lacks a required symbol");
+    g_rccl.lib = lib;
+    return LVBA_OK;
+}
+
+extern "C" int32_t lvba_dist_unique_id(char uid[128])
+{
+    if (!uid) return lvba_fail(LVBA_ERR_ARG, "uid is NULL");
+    TRY(rccl_load());
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+    ncclUniqueId id;
+    NCCLCHK(g_rccl.GetUniqueId(&id));
+    memcpy(uid, &id, 128);
+    return LVBA_OK;
+}
+
+namespace lvba {
+
+// Pose ordering for the band solver: reverse Cuthill-McKee on the pose co-visibility graph (byte adjacency
+// matrix adj[N*N]) from two start rules (pseudo-peripheral node, minimum-degree node), then a barycenter
+// refinement: positions are repeatedly replaced by the mean position of the neighbours and re-ranked, which
+// interleaves the two sides of ring-like trajectories (loop closures).  The candidate with the smallest
+// pose-block bandwidth wins.  One-off host work at finalize().
+static int32_t bandwidth_of(const std::vector<std::vector<int32_t>> &nb, const std::vector<int32_t> &perm)
+{
+    const int N = (int)perm.size();
+    std::vector<int32_t> ip(N);
+    for (int i = 0; i < N; ++i) ip[perm[i]] = i;
+    int32_t bw = 0;
+    for (int i = 0; i < N; ++i)
+        for (int j : nb[i]) bw = std::max(bw, std::abs(ip[i] - ip[j]));
+    return bw;
+}
+
+static void rcm_from(const std::vector<std::vector<int32_t>> &nb, const std::vector<int32_t> &deg, bool peripheral,
+                     std::vector<int32_t> &perm)
+{
+    const int N = (int)nb.size();
+    std::vector<char> seen(N, 0), mark(N, 0);
+    std::vector<int32_t> order, level(N);
+    order.reserve(N);
+    auto bfs_far = [&](int start) { // farthest node (minimal degree among the last level) from start
+        std::queue<int> q;
+        std::vector<int> touched;
+        q.push(start); mark[start] = 1; touched.push_back(start); level[start] = 0;
+        int last = start;
+        while (!q.empty()) {
+            int a = q.front(); q.pop();
+            if (level[a] > level[last] || (level[a] == level[last] && deg[a] < deg[last])) last = a;
+            for (int b : nb[a])
+                if (!mark[b] && !seen[b]) { mark[b] = 1; level[b] = level[a] + 1; touched.push_back(b); q.push(b); }
+        }
+        for (int t : touched) mark[t] = 0;
+        return last;
+    };
+    std::vector<int32_t> by_deg(N);
+    for (int i = 0; i < N; ++i) by_deg[i] = i;
+    std::stable_sort(by_deg.begin(), by_deg.end(), [&](int a, int b) { return deg[a] < deg[b]; });
+    for (int root : by_deg) {
+        if (seen[root]) continue;
+        int s = root;
+        if (peripheral)
+            for (int pass = 0; pass < 3; ++pass) s = bfs_far(s);
+        std::queue<int> q;
+        q.push(s); seen[s] = 1;
+        while (!q.empty()) {
+            int a = q.front(); q.pop();
+            order.push_back(a);
+            for (int b : nb[a])
+                if (!seen[b]) { seen[b] = 1; q.push(b); }
+        }
+    }
+    perm.assign(order.rbegin(), order.rend());
+}
+
+static void rcm_order(const std::vector<uint8_t> &adj, int N, std::vector<int32_t> &perm)
+{
+    std::vector<std::vector<int32_t>> nb(N);
+    std::vector<int32_t> deg(N, 0);
+    for (int i = 0; i < N; ++i) {
+        const uint8_t *row = adj.data() + (size_t)i * N;
+        for (int j = 0; j < N; ++j)
+            if (row[j] && j != i) nb[i].push_back(j);
+        deg[i] = (int32_t)nb[i].size();
+    }
+    for (int i = 0; i < N; ++i)
+        std::sort(nb[i].begin(), nb[i].end(), [&](int a, int b) { return deg[a] != deg[b] ? deg[a] < deg[b] : a < b; });
+    std::vector<int32_t> best, cand;
+    int32_t best_bw = INT32_MAX;
+    for (int variant = 0; variant < 2; ++variant) {
+        rcm_from(nb, deg, variant == 0, cand);
+        const int32_t bw = bandwidth_of(nb, cand);
+        if (bw < best_bw) { best_bw = bw; best = cand; }
+    }
+    // barycenter refinement of the best candidate
+    std::vector<double> x(N), y(N);
+    for (int i = 0; i < N; ++i) x[best[i]] = i;
+    std::vector<int32_t> idx(N);
+    for (int it = 1; it <= 200; ++it) {
+        for (int i = 0; i < N; ++i) {
+            if (nb[i].empty()) { y[i] = x[i]; continue; }
+            double s = 0.0;
+            for (int j : nb[i]) s += x[j];
+            y[i] = s / (double)nb[i].size();
+        }
+        x.swap(y);
+        if (it % 5 == 0) {
+            for (int i = 0; i < N; ++i) idx[i] = i;
+            std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return x[a] < x[b]; });
+            const int32_t bw = bandwidth_of(nb, idx);
+            if (bw < best_bw) { best_bw = bw; best = idx; }
+            for (int i = 0; i < N; ++i) x[idx[i]] = i; // re-rank so the positions do not collapse
+        }
+    }
+    perm = best;
+}
+
+
+int32_t bs_init(BlockSys &bs, int device)
+{
+    bs.device = device;
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamCreateWithFlags(&bs.stream, hipStreamNonBlocking));
+    HIPCHK(hipHostMalloc((void **)&bs.h_pin_u, 2 * sizeof(double), hipHostMallocDefault));
+    return LVBA_OK;
+}
+
+int32_t bs_dist_init(BlockSys &bs, int32_t n_ranks, int32_t rank, const char uid[128], int64_t *group_count_inout)
+{
+    if (!uid) return lvba_fail(LVBA_ERR_ARG, "uid is NULL");
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return lvba_fail(LVBA_ERR_ARG, "bad rank %d of %d", rank, n_ranks);
+    if (bs.built) return lvba_fail(LVBA_ERR_STATE, "dist_init must precede the first cost/eval/refine call");
+    // a 1-rank job needs no communicator; LVBA_SINGLE_RANK_COMM=1 builds one anyway so that the whole
+    // RCCL path (dlopen, communicator, all-reduces) can be exercised on a 1-GPU box
+    if (n_ranks == 1 && !getenv("LVBA_SINGLE_RANK_COMM")) return LVBA_OK;
+    TRY(rccl_load());
+    HIPCHK(hipSetDevice(bs.device));
+    ncclUniqueId id;
+    memcpy(&id, uid, 128);
+    NCCLCHK(g_rccl.CommInitRank(&bs.comm, n_ranks, id, rank));
+    bs.n_ranks = n_ranks; bs.rank = rank;
+    if (group_count_inout) { // global group count (the AVG_THR averages of the BALM stage)
+        int64_t *dv = nullptr;
+        HIPCHK(hipMalloc((void **)&dv, sizeof(int64_t)));
+        HIPCHK(hipMemcpy(dv, group_count_inout, sizeof(int64_t), hipMemcpyHostToDevice));
+        NCCLCHK(g_rccl.AllReduce(dv, dv, 1, ncclInt64, ncclSum, bs.comm, bs.stream));
+        HIPCHK(hipStreamSynchronize(bs.stream));
+        HIPCHK(hipMemcpy(group_count_inout, dv, sizeof(int64_t), hipMemcpyDeviceToHost));
+        hipFree(dv);
+    }
+    return LVBA_OK;
+}
+
+int32_t bs_allreduce(BlockSys &bs, double *buf, size_t count)
+{
+    if (!bs.comm) return LVBA_OK;
+    NCCLCHK(g_rccl.AllReduce(buf, buf, count, ncclDouble, ncclSum, bs.comm, bs.stream));
+    return LVBA_OK;
+}
+
+int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const int32_t *pidx)
+{
+    if (bs.built) return LVBA_OK;
+    HIPCHK(hipSetDevice(bs.device));
+    bs.N = N; bs.G = G; bs.F = voff[G];
+    const int64_t F = bs.F;
+    const int64_t n = 6 * (int64_t)N;
+    bs.perm.resize(N);
+    bs.iperm.resize(N);
+    for (int i = 0; i < N; ++i) bs.perm[i] = bs.iperm[i] = i;
+    auto band_of = [&](const std::vector<int32_t> &iperm) {
+        int32_t Bb = 0;
+        for (int64_t a = 0; a < G; ++a) {
+            int32_t lo = INT32_MAX, hi = -1;
+            for (int64_t f = voff[a]; f < voff[a + 1]; ++f) {
+                const int32_t p = iperm[pidx[f]];
+                lo = std::min(lo, p); hi = std::max(hi, p);
+            }
+            if (hi >= 0) Bb = std::max(Bb, hi - lo);
+        }
+        return Bb;
+    };
+    int32_t Bb_nat = band_of(bs.iperm);
+    if (bs.comm) { // the store layout must agree on every rank: reduce over the global problem
+        int32_t *dtmp = nullptr;
+        HIPCHK(hipMalloc((void **)&dtmp, sizeof(int32_t)));
+        HIPCHK(hipMemcpy(dtmp, &Bb_nat, sizeof(int32_t), hipMemcpyHostToDevice));
+        NCCLCHK(g_rccl.AllReduce(dtmp, dtmp, 1, ncclInt32, ncclMax, bs.comm, bs.stream));
+        HIPCHK(hipStreamSynchronize(bs.stream));
+        HIPCHK(hipMemcpy(&Bb_nat, dtmp, sizeof(int32_t), hipMemcpyDeviceToHost));
+        hipFree(dtmp);
+    }
+    bs.Bb = Bb_nat;
+    int64_t Q = 0;
+    for (int64_t a = 0; a < G; ++a) { const int64_t k = voff[a + 1] - voff[a]; Q += k * (k - 1) / 2; }
+    bs.Q = Q;
+    const bool small = (int64_t)N * N <= ((int64_t)1 << 29); // byte adjacency <= 512 MiB
+    if (bs.ordering == 1 && N > 2 && small) {
+        std::vector<uint8_t> adj((size_t)N * N, 0);
+        for (int64_t a = 0; a < G; ++a) {
+            const int64_t f0 = voff[a], f1 = voff[a + 1];
+            for (int64_t x = f0; x < f1; ++x)
+                for (int64_t y = x + 1; y < f1; ++y) {
+                    const int32_t i = pidx[x], j = pidx[y];
+                    adj[(size_t)i * N + j] = 1; adj[(size_t)j * N + i] = 1;
+                }
+        }
+        if (bs.comm) {
+            uint8_t *dadj = nullptr;
+            HIPCHK(hipMalloc((void **)&dadj, adj.size()));
+            HIPCHK(hipMemcpy(dadj, adj.data(), adj.size(), hipMemcpyHostToDevice));
+            NCCLCHK(g_rccl.AllReduce(dadj, dadj, adj.size(), ncclUint8, ncclMax, bs.comm, bs.stream));
+            HIPCHK(hipStreamSynchronize(bs.stream));
+            HIPCHK(hipMemcpy(adj.data(), dadj, adj.size(), hipMemcpyDeviceToHost));
+            hipFree(dadj);
+        }
+        std::vector<int32_t> perm, iperm(N);
+        rcm_order(adj, N, perm);
+        for (int i = 0; i < N; ++i) iperm[perm[i]] = i;
+        int32_t Bb_rcm = 0; // from the (global) adjacency so that all ranks agree
+        for (int i = 0; i < N; ++i) {
+            const uint8_t *row = adj.data() + (size_t)i * N;
+            for (int j = 0; j < N; ++j)
+                if (row[j]) Bb_rcm = std::max(Bb_rcm, std::abs(iperm[i] - iperm[j]));
+        }
+        if (Bb_rcm < Bb_nat) { bs.perm = perm; bs.iperm = iperm; bs.Bb = Bb_rcm; }
+    }
+    const int64_t bw = 6 * (int64_t)bs.Bb + 5;
+    bs.use_band = (double)(bw + LVBA_NB + 64) < bs.band_frac * (double)n;
+    if (!bs.use_band) bs.Bb = N - 1; // full lower block triangle
+    const int64_t Bb1 = (int64_t)bs.Bb + 1;
+    bs.hblk_doubles = (int64_t)N * Bb1 * 36;
+
+    { // pose-major (CSC) view + per-block group lists for the atomic-free assembly
+        std::vector<int64_t> csc_off((size_t)N + 1, 0);
+        for (int64_t f = 0; f < F; ++f) csc_off[(size_t)bs.iperm[pidx[f]] + 1]++;
+        for (int i = 0; i < N; ++i) csc_off[i + 1] += csc_off[i];
+        std::vector<int32_t> csc_f((size_t)F), group_of_pos((size_t)F), pos_of((size_t)F);
+        {
+            std::vector<int64_t> cur(csc_off.begin(), csc_off.end() - 1);
+            for (int64_t a = 0; a < G; ++a)
+                for (int64_t f = voff[a]; f < voff[a + 1]; ++f) {
+                    const int64_t t = cur[bs.iperm[pidx[f]]]++;
+                    csc_f[t] = (int32_t)f; group_of_pos[t] = (int32_t)a; pos_of[f] = (int32_t)t;
+                }
+        }
+        const int64_t nslots = (int64_t)N * Bb1;
+        std::vector<int64_t> start((size_t)nslots + 1, 0);
+        auto slot_of = [&](int64_t fx, int64_t fy, int32_t &px, int32_t &py) {
+            int32_t I = bs.iperm[pidx[fx]], J = bs.iperm[pidx[fy]];
+            px = pos_of[fx]; py = pos_of[fy];
+            if (I < J) { std::swap(I, J); std::swap(px, py); }
+            return (int64_t)J * Bb1 + (I - J);
+        };
+        for (int64_t a = 0; a < G; ++a)
+            for (int64_t x = voff[a]; x < voff[a + 1]; ++x)
+                for (int64_t y = x + 1; y < voff[a + 1]; ++y) {
+                    int32_t px, py;
+                    start[slot_of(x, y, px, py) + 1]++;
+                }
+        std::vector<int64_t> blk_off, blk_slot;
+        blk_off.push_back(0);
+        for (int64_t sl = 0; sl < nslots; ++sl) {
+            const int64_t c = start[sl + 1];
+            start[sl + 1] = start[sl] + c; // exclusive prefix in start[sl]
+            if (c > 0) { blk_slot.push_back(sl); blk_off.push_back(start[sl + 1]); }
+        }
+        std::vector<int2> pairs((size_t)Q);
+        for (int64_t a = 0; a < G; ++a)
+            for (int64_t x = voff[a]; x < voff[a + 1]; ++x)
+                for (int64_t y = x + 1; y < voff[a + 1]; ++y) {
+                    int32_t px, py;
+                    const int64_t sl = slot_of(x, y, px, py);
+                    pairs[(size_t)start[sl]++] = make_int2(px, py);
+                }
+        bs.nnzb = (int64_t)blk_slot.size();
+        // slices per block: enough workgroups to fill the chip, but >= ~256 factors per slice
+        int64_t Ssz = (2048 + N - 1) / N;
+        const int64_t avg = F / N;
+        Ssz = std::min<int64_t>(Ssz, std::max<int64_t>(1, avg / 256));
+        bs.S = (int32_t)std::max<int64_t>(1, std::min<int64_t>(Ssz, 64));
+        TRY(bs_dmalloc(bs, &bs.d_csc_off, N + 1));
+        TRY(bs_dmalloc(bs, &bs.d_group_of_pos, F));
+        TRY(bs_dmalloc(bs, &bs.d_csc_f, F));
+        TRY(bs_dmalloc(bs, &bs.d_pos_of, F));
+        TRY(bs_dmalloc(bs, &bs.d_Y, 18 * F));
+        TRY(bs_dmalloc(bs, &bs.d_blk_off, bs.nnzb + 1));
+        TRY(bs_dmalloc(bs, &bs.d_blk_slot, bs.nnzb));
+        TRY(bs_dmalloc(bs, &bs.d_pairs, Q));
+        HIPCHK(hipMemcpy(bs.d_csc_off, csc_off.data(), (size_t)(N + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+        if (F) {
+            HIPCHK(hipMemcpy(bs.d_group_of_pos, group_of_pos.data(), (size_t)F * sizeof(int32_t), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(bs.d_csc_f, csc_f.data(), (size_t)F * sizeof(int32_t), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(bs.d_pos_of, pos_of.data(), (size_t)F * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+        HIPCHK(hipMemcpy(bs.d_blk_off, blk_off.data(), (size_t)(bs.nnzb + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+        if (bs.nnzb) HIPCHK(hipMemcpy(bs.d_blk_slot, blk_slot.data(), (size_t)bs.nnzb * sizeof(int64_t), hipMemcpyHostToDevice));
+        if (Q) HIPCHK(hipMemcpy(bs.d_pairs, pairs.data(), (size_t)Q * sizeof(int2), hipMemcpyHostToDevice));
+    }
+    TRY(bs_dmalloc(bs, &bs.d_perm, N));
+    HIPCHK(hipMemcpy(bs.d_perm, bs.perm.data(), (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice));
+    TRY(bs_dmalloc(bs, &bs.d_hg, bs.hg_doubles()));
+    TRY(bs_dmalloc(bs, &bs.d_dx, n));
+    TRY(bs_dmalloc(bs, &bs.d_u, 8));
+    TRY(bs_dmalloc(bs, &bs.d_status, 4));
+    bs.A.n = n;
+    if (bs.use_band) {
+        const int64_t ldab = bw + LVBA_NB + 64;
+        bs.A.ld = ldab - 1; bs.A.bw = bw;
+        TRY(bs_dmalloc(bs, &bs.d_A, ldab * n + ldab));
+    } else {
+        bs.A.ld = n; bs.A.bw = n - 1;
+        TRY(bs_dmalloc(bs, &bs.d_A, n * n));
+    }
+    bs.A.a = bs.d_A;
+    TRY(bs_dmalloc(bs, &bs.d_work, ldlt_workspace_doubles(n, bs.A.bw)));
+    if (!getenv("LVBA_NO_LOOKAHEAD")) {
+        HIPCHK(hipStreamCreateWithFlags(&bs.stream2, hipStreamNonBlocking));
+        const int64_t np = ldlt_num_panels(n);
+        bs.evA.resize(np); bs.evB.resize(np);
+        for (int64_t i = 0; i < np; ++i) {
+            HIPCHK(hipEventCreateWithFlags(&bs.evA[i], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&bs.evB[i], hipEventDisableTiming));
+        }
+    }
+    HIPCHK(hipMemset(bs.d_hg, 0, (size_t)bs.hg_doubles() * sizeof(double)));
+    bs.built = true;
+    return LVBA_OK;
+}
+
+// The launch sequence of one solve is static per BlockSys (~5 kernels per 64-column panel on two streams), so it
+// is captured once into a hipGraph and replayed; u is read from device memory.
+static void solve_launches(BlockSys &bs)
+{
+    ldlt_solve(bs.A, bs.Hblk(), bs.Bb, bs.N, bs.g(), bs.d_u, bs.d_dx, bs.d_work, bs.d_status, bs.stream, bs.stream2,
+               bs.evA.empty() ? nullptr : bs.evA.data(), bs.evB.empty() ? nullptr : bs.evB.data());
+}
+
+int32_t bs_enqueue_solve(BlockSys &bs, double u)
+{
+    bs.h_pin_u[0] = u;
+    HIPCHK(hipMemcpyAsync(bs.d_u, bs.h_pin_u, sizeof(double), hipMemcpyHostToDevice, bs.stream));
+    if (!bs.graph_tried) {
+        bs.graph_tried = true;
+        if (!getenv("LVBA_NO_GRAPH")) {
+            (void)hipGetLastError();
+            if (hipStreamBeginCapture(bs.stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                solve_launches(bs);
+                hipGraph_t gph = nullptr;
+                if (hipStreamEndCapture(bs.stream, &gph) == hipSuccess && gph &&
+                    hipGraphInstantiate(&bs.solve_exec, gph, nullptr, nullptr, 0) == hipSuccess) {
+                    bs.solve_graph = gph;
+                } else {
+                    if (gph) hipGraphDestroy(gph);
+                    bs.solve_exec = nullptr;
+                }
+            }
+            (void)hipGetLastError(); // a failed capture falls back to eager launches
+        }
+    }
+    if (bs.solve_exec) HIPCHK(hipGraphLaunch(bs.solve_exec, bs.stream));
+    else solve_launches(bs);
+    HIPCHK(hipGetLastError());
+    return LVBA_OK;
+}
+
+void bs_destroy(BlockSys &bs)
+{
+    hipSetDevice(bs.device);
+    if (bs.stream) hipStreamSynchronize(bs.stream);
+    if (bs.stream2) hipStreamSynchronize(bs.stream2);
+    if (bs.comm && g_rccl.CommDestroy) g_rccl.CommDestroy(bs.comm);
+    if (bs.solve_exec) hipGraphExecDestroy(bs.solve_exec);
+    if (bs.solve_graph) hipGraphDestroy(bs.solve_graph);
+    for (hipEvent_t e : bs.evA) hipEventDestroy(e);
+    for (hipEvent_t e : bs.evB) hipEventDestroy(e);
+    void *ptrs[] = {bs.d_perm, bs.d_csc_off, bs.d_blk_off, bs.d_blk_slot, bs.d_group_of_pos, bs.d_csc_f, bs.d_pos_of,
+                    bs.d_pairs, bs.d_Y, bs.d_hg, bs.d_A, bs.d_work, bs.d_dx, bs.d_u, bs.d_status};
+    for (void *p : ptrs)
+        if (p) hipFree(p);
+    if (bs.h_pin_u) hipHostFree(bs.h_pin_u);
+    if (bs.stream2) hipStreamDestroy(bs.stream2);
+    if (bs.stream) hipStreamDestroy(bs.stream);
+    bs = BlockSys();
+}
+
+} // namespace lvba

@@ -26,10 +26,15 @@ struct BalmDev {
     double *vrec;              // [V][16] per-voxel records (13 used; 128-byte stride)
     double *Y;                 // [F][18] per-factor Y_i, pose-major positions
     double *part;              // [N*S][32] per-workgroup partial sums of (D[21], g[6])
-    int64_t nnzb;              // off-diagonal pose blocks with at least one contributing voxel
+};
+
+// Per-block contributor lists of the atomic-free assembly of  -sum Y_I Y_J^T  (shared by both stages).
+struct PairDev {
+    int64_t nnzb;              // off-diagonal blocks with at least one contributing group
     const int64_t *blk_off;    // [nnzb+1] offsets into pairs
     const int64_t *blk_slot;   // [nnzb] block slot in the block-band store
-    const int2 *pairs;         // [Q] (position of the factor of pose I, position of the factor of pose J), I > J
+    const int2 *pairs;         // [Q] (position of block I's factor, position of block J's factor), I > J
+    const double *Y;           // [F][18] per-factor Y, pose-major positions
 };
 
 // Working matrix of the damped system, lower triangle, column-major with leading dimension ld:
@@ -44,8 +49,9 @@ struct LdltMat {
 void launch_cost(const BalmDev &d, const double *poses, double *chunk_cost, double *out, hipStream_t s,
                  hipEvent_t k0, hipEvent_t k1);
 // zero_first: clear the whole store first (needed when other ranks' blocks were reduced into it)
-void launch_eval(const BalmDev &d, const double *poses, double *Hblk, int64_t hblk_doubles, double *g,
+void launch_eval(const BalmDev &d, const PairDev &pd, const double *poses, double *Hblk, int64_t hblk_doubles, double *g,
                  double *chunk_cost, double *out, bool zero_first, hipStream_t s, hipEvent_t k0, hipEvent_t k1);
+void launch_pairs(const PairDev &pd, double *Hblk, hipStream_t s);
 void launch_gather_csc(const double *clu, const int32_t *csc_f, int64_t F, double *clu_csc, hipStream_t s);
 void launch_retract(const double *poses, const double *dx, double *out, int n_poses, hipStream_t s);
 void launch_predicted_decrease(const double *Hblk, int band_blocks, const double *g, const double *dx, double u,

@@ -173,3 +173,99 @@ CONFIGS = {
     "C3": (2_000, 2_000_000),
     "C4": (10_000, 10_000_000),
 }
+
+
+# =====================================================================================================
+# Visual stage (SURVEY.md section 8(d) "Visual"): cameras ride on the same trajectory through the reference's
+# extrinsics (config/config.yaml:15-20), intrinsics of config.yaml:2-12 at scale 0.5, tracks of 4 consecutive
+# cameras, 0.5 px pixel noise, every landmark on a plane (the (n, d) prior of src/lvba_system.cpp:1531-1565).
+# =====================================================================================================
+REF_INTRINSICS = np.array([1293.56944 * 0.5, 1293.3155 * 0.5, 626.91359 * 0.5, 522.799224 * 0.5,
+                           -0.076160, 0.123001, -0.00113, 0.000251])
+REF_IMAGE_WH = (640, 512)
+_RCL = np.array([[0.00610193, -0.999863, -0.0154172], [-0.00615449, 0.0153796, -0.999863],
+                 [0.999962, 0.00619598, -0.0060598]])
+_PCL = np.array([0.0194384, 0.104689, -0.0251952])
+_TLI = np.array([0.04165, 0.02326, -0.0284])
+
+
+def _rotmat_to_quat_wxyz(R):
+    """Batched rotation matrix -> unit quaternion [w,x,y,z] (w >= 0), torch."""
+    m00, m11, m22 = R[:, 0, 0], R[:, 1, 1], R[:, 2, 2]
+    w = torch.sqrt(torch.clamp(1 + m00 + m11 + m22, min=1e-30)) / 2
+    x = torch.sqrt(torch.clamp(1 + m00 - m11 - m22, min=1e-30)) / 2
+    y = torch.sqrt(torch.clamp(1 - m00 + m11 - m22, min=1e-30)) / 2
+    z = torch.sqrt(torch.clamp(1 - m00 - m11 + m22, min=1e-30)) / 2
+    x = torch.copysign(x, R[:, 2, 1] - R[:, 1, 2])
+    y = torch.copysign(y, R[:, 0, 2] - R[:, 2, 0])
+    z = torch.copysign(z, R[:, 1, 0] - R[:, 0, 1])
+    q = torch.stack([w, x, y, z], 1)
+    return q / q.norm(dim=1, keepdim=True)
+
+
+def project_distorted(Xc, intr):
+    """Pixel of camera-frame points, Brown-Conrady model of include/utils.hpp:86-105 (torch, batched)."""
+    fx, fy, cx, cy, k1, k2, p1, p2 = [float(v) for v in intr]
+    xn, yn = Xc[..., 0] / Xc[..., 2], Xc[..., 1] / Xc[..., 2]
+    r2 = xn * xn + yn * yn
+    radial = 1 + k1 * r2 + k2 * r2 * r2
+    xd = xn * radial + 2 * p1 * xn * yn + p2 * (r2 + 2 * xn * xn)
+    yd = yn * radial + p1 * (r2 + 2 * yn * yn) + 2 * p2 * xn * yn
+    return torch.stack([fx * xd + cx, fy * yd + cy], -1)
+
+
+def make_visual_problem(n_cams, n_tracks, *, seed=20250925, track_len=4, pixel_sigma=0.5, rot_sigma_deg=0.05,
+                        trans_sigma=0.02, point_sigma=0.05, invalid_frac=0.05, loop_poses=None, device="cpu"):
+    """Returns dict(q [M,4] wxyz, t [M,3], X [T,3], obs_off [T+1] i64, obs_cam [O] i32, obs_uv [O,2], plane [T,4],
+    valid [T] u8, intr [8], q_gt, t_gt, X_gt).  Camera 0 starts at its ground truth (it is held constant)."""
+    dev = torch.device(device)
+    f64 = torch.float64
+    g = torch.Generator(device=dev).manual_seed(seed + 10)
+    M, T = int(n_cams), int(n_tracks)
+    # the cameras are the first M poses of a loop sampled with >= 2000 poses (~0.6 m apart), so that small test
+    # problems still have consecutive cameras that share landmarks
+    R_wi, p_wi = trajectory(max(M, 2000) if loop_poses is None else int(loop_poses), g, dev)
+    R_wi, p_wi = R_wi[:M], p_wi[:M]
+    Rcl = torch.tensor(_RCL, dtype=f64, device=dev)
+    tci = Rcl @ torch.tensor(_TLI, dtype=f64, device=dev) + torch.tensor(_PCL, dtype=f64, device=dev)
+    Rcw = Rcl @ R_wi.transpose(1, 2)                      # src/lvba_system.cpp:860-861
+    tcw = -(Rcw @ p_wi[..., None])[..., 0] + tci
+    W, H = REF_IMAGE_WH
+    intr = REF_INTRINSICS
+    L = max(1, min(track_len, M))
+    # landmark seen from cameras c0 .. c0+L-1: back-project a pixel of the MIDDLE camera at a random depth
+    c0 = torch.randint(0, M - L + 1, (T,), generator=g, device=dev)
+    cm = c0 + L // 2
+    depth = 3.0 + 22.0 * torch.rand(T, generator=g, dtype=f64, device=dev)
+    u = (0.2 + 0.6 * torch.rand(T, generator=g, dtype=f64, device=dev)) * W
+    v = (0.2 + 0.6 * torch.rand(T, generator=g, dtype=f64, device=dev)) * H
+    Xc = torch.stack([(u - intr[2]) / intr[0] * depth, (v - intr[3]) / intr[1] * depth, depth], 1)
+    X_gt = (Rcw[cm].transpose(1, 2) @ (Xc - tcw[cm])[..., None])[..., 0]
+    cams = c0[:, None] + torch.arange(L, device=dev)[None, :]
+    Xc_all = (Rcw[cams] @ X_gt[:, None, :, None])[..., 0] + tcw[cams]
+    px = project_distorted(Xc_all, intr)
+    vis = (Xc_all[..., 2] > 0.5) & (px[..., 0] > 0) & (px[..., 0] < W) & (px[..., 1] > 0) & (px[..., 1] < H)
+    px = px + torch.randn(T, L, 2, generator=g, dtype=f64, device=dev) * pixel_sigma
+    px = px.to(torch.float32).to(f64)                     # keypoints are float (include/utils.hpp:37-38)
+    k = vis.sum(1)
+    obs_off = torch.zeros(T + 1, dtype=torch.int64, device=dev)
+    obs_off[1:] = k.cumsum(0)
+    obs_cam = cams[vis].to(torch.int32)
+    obs_uv = px[vis]
+    n = torch.randn(T, 3, generator=g, dtype=f64, device=dev)
+    n = n / n.norm(dim=1, keepdim=True)
+    plane = torch.cat([n, -(n * X_gt).sum(1, keepdim=True)], 1)
+    valid = (torch.rand(T, generator=g, device=dev) >= invalid_frac).to(torch.uint8)
+    plane = plane * valid[:, None].to(f64)                # landmarks without a plane carry n = 0, d = 0 (:1549-1551)
+    # initial values
+    dth = torch.randn(M, 3, generator=g, dtype=f64, device=dev) * math.radians(rot_sigma_deg)
+    dtr = torch.randn(M, 3, generator=g, dtype=f64, device=dev) * trans_sigma
+    dth[0] = 0
+    dtr[0] = 0
+    R0 = _exp_so3(dth) @ Rcw
+    t0 = tcw + dtr
+    X0 = X_gt + torch.randn(T, 3, generator=g, dtype=f64, device=dev) * point_sigma
+    return dict(q=_rotmat_to_quat_wxyz(R0).cpu().numpy(), t=t0.cpu().numpy(), X=X0.cpu().numpy(),
+                obs_off=obs_off.cpu().numpy(), obs_cam=obs_cam.cpu().numpy(), obs_uv=obs_uv.cpu().numpy(),
+                plane=plane.cpu().numpy(), valid=valid.cpu().numpy(), intr=intr.copy(),
+                q_gt=_rotmat_to_quat_wxyz(Rcw).cpu().numpy(), t_gt=tcw.cpu().numpy(), X_gt=X_gt.cpu().numpy())
