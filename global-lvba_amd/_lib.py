@@ -16,6 +16,8 @@ SYMBOLS = [
     "lvba_balm_eval", "lvba_balm_solve", "lvba_balm_refine", "lvba_balm_lm_begin", "lvba_balm_lm_step",
     "lvba_balm_lm_end", "lvba_balm_set_profiling", "lvba_balm_get_profile", "lvba_balm_get_ordering",
     "lvba_dist_unique_id", "lvba_balm_dist_init",
+    "lvba_visual_default_opts", "lvba_visual_create", "lvba_visual_destroy", "lvba_visual_cost", "lvba_visual_linearize",
+    "lvba_visual_refine",
 ]
 
 OK, ERR_ARG, ERR_DEVICE, ERR_NOMEM, ERR_UNSUPPORTED, ERR_DIST, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
@@ -48,6 +50,26 @@ class Prof(C.Structure):
                 ("eval_calls", C.c_int64), ("solve_ms", C.c_double), ("solve_calls", C.c_int64),
                 ("reduce_ms", C.c_double), ("reduce_calls", C.c_int64), ("cost_kernel_ms", C.c_double),
                 ("eval_kernel_ms", C.c_double)]
+
+
+class VisualOpts(C.Structure):
+    _fields_ = [("max_iter", C.c_int32), ("reserved", C.c_int32), ("initial_radius", C.c_double), ("max_radius", C.c_double),
+                ("min_radius", C.c_double), ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double),
+                ("max_lm_diagonal", C.c_double), ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
+                ("parameter_tolerance", C.c_double)]
+
+
+class VisualTrace(C.Structure):
+    _fields_ = [("iter", C.c_int32), ("accepted", C.c_int32), ("valid", C.c_int32), ("reserved", C.c_int32),
+                ("cost", C.c_double), ("cost_change", C.c_double), ("step_norm", C.c_double), ("radius", C.c_double),
+                ("rho", C.c_double), ("gradient_max_norm", C.c_double)]
+
+    def as_dict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_ if f != "reserved"}
+
+
+TERMINATION = {0: "NO_CONVERGENCE", 1: "CONVERGENCE(function)", 2: "CONVERGENCE(parameter)", 3: "CONVERGENCE(gradient)",
+               4: "CONVERGENCE(radius)", 5: "FAILURE"}
 
 
 class LvbaError(RuntimeError):
@@ -95,6 +117,16 @@ def load():
     lib.lvba_balm_get_ordering.argtypes = [H, i32p]
     lib.lvba_dist_unique_id.argtypes = [C.c_char_p]
     lib.lvba_balm_dist_init.argtypes = [H, C.c_int32, C.c_int32, C.c_char_p]
+    u8p = np.ctypeslib.ndpointer(np.uint8, flags="C")
+    lib.lvba_visual_default_opts.argtypes = [C.POINTER(VisualOpts)]
+    lib.lvba_visual_default_opts.restype = None
+    lib.lvba_visual_create.argtypes = [C.c_int32, C.c_int64, i64p, C.c_void_p, C.c_void_p, f64p, u8p, f64p, C.c_double,
+                                       C.c_double, C.c_int32, C.POINTER(H)]
+    lib.lvba_visual_destroy.argtypes = [H]
+    lib.lvba_visual_cost.argtypes = [H, f64p, f64p, f64p, C.POINTER(C.c_double)]
+    lib.lvba_visual_linearize.argtypes = [H, f64p, f64p, f64p, C.c_double, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+    lib.lvba_visual_refine.argtypes = [H, f64p, f64p, f64p, C.POINTER(VisualOpts), C.POINTER(VisualTrace), C.c_int32,
+                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int:  # default

@@ -37,6 +37,28 @@ struct PairDev {
     const double *Y;           // [F][18] per-factor Y, pose-major positions
 };
 
+// Device view of one packed visual problem (cameras in solver order; only landmarks with a valid plane).
+struct VisDev {
+    int32_t M, S, band_blocks, fixed_cam;
+    int64_t Ta, O;
+    const int64_t *off;            // [Ta+1] CSR offsets of each landmark's observations
+    const int32_t *cam;            // [O] camera (solver order) of each observation
+    const int32_t *track_of_obs;   // [O]
+    const double *uv;              // [O][2]
+    const double *plane;           // [Ta][4]
+    double intr[8];
+    double inv_sig_px, inv_sig_pl;
+    // linearisation at the current point
+    double *Jc, *Jp, *r;           // [O][12], [O][6], [O][2]
+    double *rpl, *Jpl;             // [Ta], [Ta][3]
+    double *sc_cam, *sc_pt;        // [M][6], [Ta][3] Jacobi column scales
+    double *Lp, *zp, *step_p;      // [Ta][6], [Ta][3], [Ta][3]
+    // camera-major order (BlockSys)
+    const int64_t *csc_off;
+    const int32_t *csc_f, *group_of_pos, *pos_of;
+    double *Y, *part;              // [O][18], [M*S][40]
+};
+
 // Working matrix of the damped system, lower triangle, column-major with leading dimension ld:
 // A(r,c) = a[r + c*ld].  Dense: ld = n.  Band: LAPACK lower-band storage with ldab = ld+1, i.e.
 // A(r,c) = ab[(r-c) + c*ldab]; valid offsets 0 <= r-c <= ld.  bw = half bandwidth in scalars.
@@ -60,6 +82,16 @@ void launch_export_dense(const double *Hblk, int band_blocks, int n_poses, const
 void launch_export_vec(const double *v, const int *perm, int n_poses, double *out, hipStream_t s);
 void launch_import_poses(const double *in, const int *perm, int n_poses, double *out, hipStream_t s);
 void launch_export_poses(const double *in, const int *perm, int n_poses, double *out, hipStream_t s);
+
+// visual_kernels.hip
+void vis_launch_residuals(const VisDev &d, bool jac, const double *qc, const double *tc, const double *Xp, double *part,
+                          double *cost_out, hipStream_t s);
+void vis_launch_colnorms(const VisDev &d, hipStream_t s);
+void vis_launch_reduced_system(const VisDev &d, const PairDev &pd, double radius, double min_diag, double max_diag, double *Hblk,
+                               int64_t hblk_doubles, double *g, unsigned long long *gmax, bool zero_first, hipStream_t s);
+void vis_launch_back(const VisDev &d, const double *step_c, double *part, double *model_out, hipStream_t s);
+void vis_launch_apply(const VisDev &d, const double *step_c, const double *qc, const double *tc, const double *Xp, double *qc2,
+                      double *tc2, double *Xp2, double *part, double *norms_out, hipStream_t s);
 
 // ldlt.hip
 // Workspace doubles needed by ldlt_solve for an n x n system.

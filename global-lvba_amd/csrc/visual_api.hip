@@ -1,0 +1,353 @@
+// visual_api.hip -- visual half of the C-ABI (include/lvba_hip.h): packing of the landmark/observation problem and
+// the trust-region Levenberg-Marquardt driver that replaces ceres::Solve in LvbaSystem::optimizeCameraPoses
+// (reference src/lvba_system.cpp:1571-1665).  The control flow restates Ceres 2.1.0's TrustRegionMinimizer +
+// LevenbergMarquardtStrategy (not in /root/reference; restated from its published sources):
+// Jacobi scaling fixed at iteration 0, LM diagonal sqrt(clamp(diag J^T J)/radius),
+// parameter/function tolerance checks before the accept test, radius /= max(1/3, 1-(2 rho-1)^3) on success and
+// /= 2,4,8.. on failure.  Host logic only; arithmetic runs in visual_kernels.hip, balm_pair_kernel and ldlt.hip.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "block_system.h"
+
+using namespace lvba;
+#define fail lvba_fail
+
+struct lvba_visual_s {
+    BlockSys bs;
+    int32_t M = 0;
+    int64_t T = 0, Ta = 0, O = 0;
+    std::vector<int64_t> act;      // active landmark -> caller track index
+    std::vector<int64_t> h_off;    // CSR of the active landmarks (host, kept until finalize)
+    std::vector<int32_t> h_cam;    // caller camera index per kept observation
+    bool finalized = false;
+    double intr[8] = {}, sig_px = 0.5, sig_pl = 0.01;
+    // device
+    int64_t *d_off = nullptr;
+    int32_t *d_cam = nullptr, *d_track_of_obs = nullptr;
+    double *d_uv = nullptr, *d_plane = nullptr;
+    double *d_Jc = nullptr, *d_Jp = nullptr, *d_r = nullptr, *d_rpl = nullptr, *d_Jpl = nullptr;
+    double *d_sc_cam = nullptr, *d_sc_pt = nullptr, *d_Lp = nullptr, *d_zp = nullptr, *d_step_p = nullptr, *d_part = nullptr;
+    double *d_q = nullptr, *d_t = nullptr, *d_X = nullptr, *d_q2 = nullptr, *d_t2 = nullptr, *d_X2 = nullptr;
+    double *d_blkpart = nullptr;   // per-workgroup partials of the scalar reductions
+    double *d_scal = nullptr;      // [0]=cost(x) [1]=cost(cand) [2]=model change [3]=|step|^2 [4]=|x|^2
+    unsigned long long *d_gmax = nullptr;
+    double *d_out = nullptr;       // export staging
+    double *h_pin = nullptr;
+    std::vector<double> hq, ht, hX; // host staging in solver order
+
+    VisDev dev() const
+    {
+        VisDev d;
+        d.M = M; d.S = bs.S; d.band_blocks = bs.Bb; d.fixed_cam = bs.iperm.empty() ? 0 : bs.iperm[0];
+        d.Ta = Ta; d.O = O; d.off = d_off; d.cam = d_cam; d.track_of_obs = d_track_of_obs; d.uv = d_uv; d.plane = d_plane;
+        for (int e = 0; e < 8; ++e) d.intr[e] = intr[e];
+        d.inv_sig_px = 1.0 / sig_px; d.inv_sig_pl = 1.0 / std::max(1e-9, sig_pl); // utils.hpp:131
+        d.Jc = d_Jc; d.Jp = d_Jp; d.r = d_r; d.rpl = d_rpl; d.Jpl = d_Jpl; d.sc_cam = d_sc_cam; d.sc_pt = d_sc_pt;
+        d.Lp = d_Lp; d.zp = d_zp; d.step_p = d_step_p;
+        d.csc_off = bs.d_csc_off; d.csc_f = bs.d_csc_f; d.group_of_pos = bs.d_group_of_pos; d.pos_of = bs.d_pos_of;
+        d.Y = bs.d_Y; d.part = d_part;
+        return d;
+    }
+};
+
+extern "C" void lvba_visual_default_opts(lvba_visual_opts *o)
+{
+    if (!o) return;
+    o->max_iter = 50; o->reserved = 0; o->initial_radius = 1e4; o->max_radius = 1e16; o->min_radius = 1e-32;
+    o->min_relative_decrease = 1e-3; o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32;
+    o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-8;
+}
+
+extern "C" int32_t lvba_visual_destroy(lvba_visual_t h)
+{
+    if (!h) return LVBA_OK;
+    hipSetDevice(h->bs.device);
+    if (h->bs.stream) hipStreamSynchronize(h->bs.stream);
+    void *ptrs[] = {h->d_off, h->d_cam, h->d_track_of_obs, h->d_uv, h->d_plane, h->d_Jc, h->d_Jp, h->d_r, h->d_rpl, h->d_Jpl,
+                    h->d_sc_cam, h->d_sc_pt, h->d_Lp, h->d_zp, h->d_step_p, h->d_part, h->d_q, h->d_t, h->d_X, h->d_q2,
+                    h->d_t2, h->d_X2, h->d_blkpart, h->d_scal, h->d_gmax, h->d_out};
+    for (void *p : ptrs)
+        if (p) hipFree(p);
+    if (h->h_pin) hipHostFree(h->h_pin);
+    bs_destroy(h->bs);
+    delete h;
+    return LVBA_OK;
+}
+
+extern "C" int32_t lvba_visual_create(int32_t n_cams, int64_t n_tracks, const int64_t *obs_off, const int32_t *obs_cam,
+                                      const double *obs_uv, const double *plane, const uint8_t *valid, const double intr[8],
+                                      double sigma_px, double sigma_plane, int32_t device, lvba_visual_t *out)
+{
+    if (!out) return fail(LVBA_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (n_cams < 1 || n_tracks < 0 || !obs_off || !plane || !valid || !intr) return fail(LVBA_ERR_ARG, "bad sizes or NULL arrays");
+    if (!(sigma_px > 0.0)) return fail(LVBA_ERR_ARG, "sigma_px must be > 0");
+    const int64_t base = obs_off[0];
+    const int64_t Oall = obs_off[n_tracks] - base;
+    if (Oall > 0 && (!obs_cam || !obs_uv)) return fail(LVBA_ERR_ARG, "observation arrays are NULL");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(LVBA_ERR_DEVICE, "no HIP device available (liblvba_hip has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(LVBA_ERR_ARG, "device %d out of range [0,%d)", device, ndev);
+    lvba_visual_s *h = new (std::nothrow) lvba_visual_s();
+    if (!h) return fail(LVBA_ERR_NOMEM, "host allocation failed");
+    h->M = n_cams; h->T = n_tracks; h->sig_px = sigma_px; h->sig_pl = sigma_plane;
+    memcpy(h->intr, intr, 8 * sizeof(double));
+    // keep only landmarks with a valid plane, together with their observations (src/lvba_system.cpp:1598-1603)
+    std::vector<double> uv, pl;
+    h->h_off.push_back(0);
+    for (int64_t i = 0; i < n_tracks; ++i) {
+        if (obs_off[i + 1] < obs_off[i]) { delete h; return fail(LVBA_ERR_ARG, "obs_off is not monotone at %lld", (long long)i); }
+        if (!valid[i]) continue;
+        for (int64_t o = obs_off[i] - base; o < obs_off[i + 1] - base; ++o) {
+            if (obs_cam[o] < 0 || obs_cam[o] >= n_cams) { delete h; return fail(LVBA_ERR_ARG, "obs_cam[%lld] = %d out of range", (long long)o, obs_cam[o]); }
+            h->h_cam.push_back(obs_cam[o]);
+            uv.push_back(obs_uv[2 * o]);
+            uv.push_back(obs_uv[2 * o + 1]);
+        }
+        h->act.push_back(i);
+        h->h_off.push_back((int64_t)h->h_cam.size());
+        for (int e = 0; e < 4; ++e) pl.push_back(plane[4 * i + e]);
+    }
+    h->Ta = (int64_t)h->act.size();
+    h->O = (int64_t)h->h_cam.size();
+    auto bail = [&](int32_t rc) { lvba_visual_destroy(h); return rc; };
+#define CTRY(expr) do { int32_t rc_ = (expr); if (rc_ != LVBA_OK) return bail(rc_); } while (0)
+#define CHIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(fail(e_ == hipErrorOutOfMemory ? LVBA_ERR_NOMEM : LVBA_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_))); } while (0)
+    CTRY(bs_init(h->bs, device));
+    BlockSys &bs = h->bs;
+    const int64_t Ta = h->Ta, O = h->O, M = n_cams;
+    CTRY(bs_dmalloc(bs, &h->d_off, Ta + 1));
+    CTRY(bs_dmalloc(bs, &h->d_cam, O));
+    CTRY(bs_dmalloc(bs, &h->d_track_of_obs, O));
+    CTRY(bs_dmalloc(bs, &h->d_uv, 2 * O));
+    CTRY(bs_dmalloc(bs, &h->d_plane, 4 * Ta));
+    CHIP(hipMemcpy(h->d_off, h->h_off.data(), (size_t)(Ta + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    if (O) CHIP(hipMemcpy(h->d_uv, uv.data(), (size_t)(2 * O) * sizeof(double), hipMemcpyHostToDevice));
+    if (Ta) CHIP(hipMemcpy(h->d_plane, pl.data(), (size_t)(4 * Ta) * sizeof(double), hipMemcpyHostToDevice));
+    {
+        std::vector<int32_t> too((size_t)O);
+        for (int64_t i = 0; i < Ta; ++i)
+            for (int64_t o = h->h_off[i]; o < h->h_off[i + 1]; ++o) too[o] = (int32_t)i;
+        if (O) CHIP(hipMemcpy(h->d_track_of_obs, too.data(), (size_t)O * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    CTRY(bs_dmalloc(bs, &h->d_Jc, 12 * O)); CTRY(bs_dmalloc(bs, &h->d_Jp, 6 * O)); CTRY(bs_dmalloc(bs, &h->d_r, 2 * O));
+    CTRY(bs_dmalloc(bs, &h->d_rpl, Ta)); CTRY(bs_dmalloc(bs, &h->d_Jpl, 3 * Ta));
+    CTRY(bs_dmalloc(bs, &h->d_sc_cam, 6 * M)); CTRY(bs_dmalloc(bs, &h->d_sc_pt, 3 * Ta));
+    CTRY(bs_dmalloc(bs, &h->d_Lp, 6 * Ta)); CTRY(bs_dmalloc(bs, &h->d_zp, 3 * Ta)); CTRY(bs_dmalloc(bs, &h->d_step_p, 3 * Ta));
+    CTRY(bs_dmalloc(bs, &h->d_q, 4 * M)); CTRY(bs_dmalloc(bs, &h->d_t, 3 * M)); CTRY(bs_dmalloc(bs, &h->d_X, 3 * Ta));
+    CTRY(bs_dmalloc(bs, &h->d_q2, 4 * M)); CTRY(bs_dmalloc(bs, &h->d_t2, 3 * M)); CTRY(bs_dmalloc(bs, &h->d_X2, 3 * Ta));
+    CTRY(bs_dmalloc(bs, &h->d_blkpart, 2 * ((O + Ta + M) / 256 + 4)));
+    CTRY(bs_dmalloc(bs, &h->d_scal, 16));
+    CTRY(bs_dmalloc(bs, &h->d_gmax, 2));
+    CTRY(bs_dmalloc(bs, &h->d_out, 36 * (int64_t)M + 16));
+    CHIP(hipHostMalloc((void **)&h->h_pin, 16 * sizeof(double), hipHostMallocDefault));
+#undef CTRY
+#undef CHIP
+    *out = h;
+    return LVBA_OK;
+}
+
+static int32_t finalize(lvba_visual_s *h)
+{
+    if (h->finalized) return LVBA_OK;
+    BlockSys &bs = h->bs;
+    HIPCHK(hipSetDevice(bs.device));
+    TRY(bs_build(bs, h->M, h->Ta, h->h_off.data(), h->h_cam.data()));
+    {
+        std::vector<int32_t> cam((size_t)h->O);
+        for (int64_t o = 0; o < h->O; ++o) cam[o] = bs.iperm[h->h_cam[o]];
+        if (h->O) HIPCHK(hipMemcpy(h->d_cam, cam.data(), (size_t)h->O * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    TRY(bs_dmalloc(bs, &h->d_part, (int64_t)h->M * bs.S * 40));
+    std::vector<int32_t>().swap(h->h_cam);
+    h->finalized = true;
+    return LVBA_OK;
+}
+
+// caller arrays -> device state in solver order
+static int32_t import_state(lvba_visual_s *h, const double *q, const double *t, const double *X)
+{
+    BlockSys &bs = h->bs;
+    h->hq.resize(4 * (size_t)h->M); h->ht.resize(3 * (size_t)h->M); h->hX.resize(3 * (size_t)h->Ta);
+    for (int c = 0; c < h->M; ++c) {
+        const int I = bs.iperm[c];
+        for (int e = 0; e < 4; ++e) h->hq[4 * I + e] = q[4 * c + e];
+        for (int e = 0; e < 3; ++e) h->ht[3 * I + e] = t[3 * c + e];
+    }
+    for (int64_t i = 0; i < h->Ta; ++i)
+        for (int e = 0; e < 3; ++e) h->hX[3 * i + e] = X[3 * h->act[i] + e];
+    HIPCHK(hipMemcpyAsync(h->d_q, h->hq.data(), h->hq.size() * sizeof(double), hipMemcpyHostToDevice, bs.stream));
+    HIPCHK(hipMemcpyAsync(h->d_t, h->ht.data(), h->ht.size() * sizeof(double), hipMemcpyHostToDevice, bs.stream));
+    if (h->Ta) HIPCHK(hipMemcpyAsync(h->d_X, h->hX.data(), h->hX.size() * sizeof(double), hipMemcpyHostToDevice, bs.stream));
+    HIPCHK(hipStreamSynchronize(bs.stream)); // the host staging vectors may be reused
+    return LVBA_OK;
+}
+
+static int32_t export_state(lvba_visual_s *h, double *q, double *t, double *X)
+{
+    BlockSys &bs = h->bs;
+    HIPCHK(hipMemcpyAsync(h->hq.data(), h->d_q, h->hq.size() * sizeof(double), hipMemcpyDeviceToHost, bs.stream));
+    HIPCHK(hipMemcpyAsync(h->ht.data(), h->d_t, h->ht.size() * sizeof(double), hipMemcpyDeviceToHost, bs.stream));
+    if (h->Ta) HIPCHK(hipMemcpyAsync(h->hX.data(), h->d_X, h->hX.size() * sizeof(double), hipMemcpyDeviceToHost, bs.stream));
+    HIPCHK(hipStreamSynchronize(bs.stream));
+    for (int c = 0; c < h->M; ++c) {
+        const int I = bs.iperm[c];
+        const double *s = &h->hq[4 * I];
+        const double nq = sqrt(s[0] * s[0] + s[1] * s[1] + s[2] * s[2] + s[3] * s[3]); // q_eig.normalize(), :1653
+        for (int e = 0; e < 4; ++e) q[4 * c + e] = s[e] / nq;
+        for (int e = 0; e < 3; ++e) t[3 * c + e] = h->ht[3 * I + e];
+    }
+    for (int64_t i = 0; i < h->Ta; ++i)
+        for (int e = 0; e < 3; ++e) X[3 * h->act[i] + e] = h->hX[3 * i + e];
+    return LVBA_OK;
+}
+
+extern "C" int32_t lvba_visual_cost(lvba_visual_t h, const double *q, const double *t, const double *X, double *cost)
+{
+    if (!h || !q || !t || !X || !cost) return fail(LVBA_ERR_ARG, "NULL argument");
+    TRY(finalize(h));
+    BlockSys &bs = h->bs;
+    HIPCHK(hipSetDevice(bs.device));
+    TRY(import_state(h, q, t, X));
+    vis_launch_residuals(h->dev(), false, h->d_q, h->d_t, h->d_X, h->d_blkpart, h->d_scal, bs.stream);
+    HIPCHK(hipMemcpyAsync(h->h_pin, h->d_scal, sizeof(double), hipMemcpyDeviceToHost, bs.stream));
+    HIPCHK(hipStreamSynchronize(bs.stream));
+    HIPCHK(hipGetLastError());
+    *cost = 0.5 * h->h_pin[0];
+    return LVBA_OK;
+}
+
+extern "C" int32_t lvba_visual_linearize(lvba_visual_t h, const double *q, const double *t, const double *X, double radius,
+                                         double *S, double *rhs, double *cost)
+{
+    if (!h || !q || !t || !X) return fail(LVBA_ERR_ARG, "NULL argument");
+    if (!(radius > 0.0)) return fail(LVBA_ERR_ARG, "radius must be > 0");
+    TRY(finalize(h));
+    BlockSys &bs = h->bs;
+    HIPCHK(hipSetDevice(bs.device));
+    TRY(import_state(h, q, t, X));
+    lvba_visual_opts o;
+    lvba_visual_default_opts(&o);
+    const VisDev d = h->dev();
+    vis_launch_residuals(d, true, h->d_q, h->d_t, h->d_X, h->d_blkpart, h->d_scal, bs.stream);
+    vis_launch_colnorms(d, bs.stream);
+    vis_launch_reduced_system(d, bs.pair_dev(), radius, o.min_lm_diagonal, o.max_lm_diagonal, bs.Hblk(), bs.hblk_doubles, bs.g(),
+                              h->d_gmax, false, bs.stream);
+    const int64_t n = 6 * (int64_t)h->M;
+    double *dS = nullptr;
+    if (S) {
+        HIPCHK(hipMalloc((void **)&dS, (size_t)(n * n) * sizeof(double)));
+        launch_export_dense(bs.Hblk(), bs.Bb, h->M, bs.d_perm, dS, bs.stream);
+        HIPCHK(hipMemcpyAsync(S, dS, (size_t)(n * n) * sizeof(double), hipMemcpyDeviceToHost, bs.stream));
+    }
+    if (rhs) {
+        launch_export_vec(bs.g(), bs.d_perm, h->M, h->d_out, bs.stream);
+        HIPCHK(hipMemcpyAsync(rhs, h->d_out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, bs.stream));
+    }
+    HIPCHK(hipMemcpyAsync(h->h_pin, h->d_scal, sizeof(double), hipMemcpyDeviceToHost, bs.stream));
+    HIPCHK(hipStreamSynchronize(bs.stream));
+    if (dS) hipFree(dS);
+    HIPCHK(hipGetLastError());
+    if (cost) *cost = 0.5 * h->h_pin[0];
+    return LVBA_OK;
+}
+
+extern "C" int32_t lvba_visual_refine(lvba_visual_t h, double *q, double *t, double *X, const lvba_visual_opts *opts,
+                                      lvba_visual_trace *trace, int32_t trace_cap, int32_t *n_trace, int32_t *termination)
+{
+    if (!h || !q || !t || !X) return fail(LVBA_ERR_ARG, "NULL argument");
+    if (n_trace) *n_trace = 0;
+    TRY(finalize(h));
+    BlockSys &bs = h->bs;
+    HIPCHK(hipSetDevice(bs.device));
+    lvba_visual_opts o;
+    if (opts) o = *opts; else lvba_visual_default_opts(&o);
+    TRY(import_state(h, q, t, X));
+    int32_t rows = 0, term = LVBA_TERM_NO_CONVERGENCE, rc = LVBA_OK;
+    auto push = [&](int it, int acc, int valid, double cost, double dc, double sn, double rad, double rho, double gm) {
+        if (trace && rows < trace_cap) {
+            lvba_visual_trace &r = trace[rows];
+            r.iter = it; r.accepted = acc; r.valid = valid; r.reserved = 0; r.cost = cost; r.cost_change = dc; r.step_norm = sn;
+            r.radius = rad; r.rho = rho; r.gradient_max_norm = gm;
+        }
+        rows++;
+    };
+    VisDev d = h->dev();
+    // iteration 0: evaluate, fix the Jacobi scaling
+    vis_launch_residuals(d, true, h->d_q, h->d_t, h->d_X, h->d_blkpart, h->d_scal, bs.stream);
+    vis_launch_colnorms(d, bs.stream);
+    HIPCHK(hipMemcpyAsync(h->h_pin, h->d_scal, sizeof(double), hipMemcpyDeviceToHost, bs.stream));
+    HIPCHK(hipStreamSynchronize(bs.stream));
+    double cost = 0.5 * h->h_pin[0];
+    double radius = o.initial_radius, decrease_factor = 2.0;
+    bool first = true;
+    int invalid_run = 0;
+    if (!isfinite(cost)) { term = LVBA_TERM_FAILURE; rc = fail(LVBA_NUM_NONFINITE, "non-finite initial cost"); }
+    for (int it = 1; rc == LVBA_OK; ++it) {
+        // linearised system at the current point (its gradient norm belongs to the row of the previous iteration)
+        vis_launch_reduced_system(d, bs.pair_dev(), radius, o.min_lm_diagonal, o.max_lm_diagonal, bs.Hblk(), bs.hblk_doubles,
+                                  bs.g(), h->d_gmax, false, bs.stream);
+        TRY(bs_enqueue_solve(bs, 0.0));
+        vis_launch_back(d, bs.d_dx, h->d_blkpart, h->d_scal + 2, bs.stream);
+        vis_launch_apply(d, bs.d_dx, h->d_q, h->d_t, h->d_X, h->d_q2, h->d_t2, h->d_X2, h->d_blkpart, h->d_scal + 3, bs.stream);
+        vis_launch_residuals(d, false, h->d_q2, h->d_t2, h->d_X2, h->d_blkpart, h->d_scal + 1, bs.stream);
+        HIPCHK(hipMemcpyAsync(h->h_pin, h->d_scal, 5 * sizeof(double), hipMemcpyDeviceToHost, bs.stream));
+        HIPCHK(hipMemcpyAsync(h->h_pin + 8, h->d_gmax, sizeof(unsigned long long), hipMemcpyDeviceToHost, bs.stream));
+        HIPCHK(hipMemcpyAsync(h->h_pin + 9, bs.d_status, sizeof(int), hipMemcpyDeviceToHost, bs.stream));
+        HIPCHK(hipStreamSynchronize(bs.stream));
+        HIPCHK(hipGetLastError());
+        double gmax;
+        memcpy(&gmax, h->h_pin + 8, sizeof(double));
+        int st = 0;
+        memcpy(&st, h->h_pin + 9, sizeof(int));
+        if (first) { push(0, 1, 1, cost, 0.0, 0.0, radius, 0.0, gmax); first = false; }
+        if (gmax <= o.gradient_tolerance) { term = LVBA_TERM_GRADIENT; break; }
+        if (it > o.max_iter) { term = LVBA_TERM_NO_CONVERGENCE; break; }
+        const double cand = 0.5 * h->h_pin[1], model = h->h_pin[2];
+        const double step_norm = sqrt(h->h_pin[3]), x_norm = sqrt(h->h_pin[4]);
+        const bool finite_step = st == 0 && isfinite(model) && isfinite(step_norm);
+        if (!finite_step || !(model > 0.0)) { // LevenbergMarquardtStrategy::StepIsInvalid
+            radius *= 0.5;
+            push(it, 0, 0, cost, 0.0, 0.0, radius, 0.0, gmax);
+            if (++invalid_run >= 5) { term = LVBA_TERM_FAILURE; rc = fail(LVBA_NUM_FACTORIZATION, "5 consecutive invalid steps"); }
+            if (radius < o.min_radius) { term = LVBA_TERM_RADIUS; break; }
+            continue;
+        }
+        invalid_run = 0;
+        if (step_norm <= o.parameter_tolerance * (x_norm + o.parameter_tolerance)) {
+            push(it, 0, 1, cost, cost - cand, step_norm, radius, 0.0, gmax);
+            term = LVBA_TERM_PARAMETER;
+            break;
+        }
+        const double cost_change = cost - cand;
+        if (fabs(cost_change) <= o.function_tolerance * cost) {
+            push(it, 0, 1, cost, cost_change, step_norm, radius, 0.0, gmax);
+            term = LVBA_TERM_FUNCTION;
+            break;
+        }
+        const double rho = cost_change / model;
+        if (isfinite(cand) && rho > o.min_relative_decrease) {
+            std::swap(h->d_q, h->d_q2); std::swap(h->d_t, h->d_t2); std::swap(h->d_X, h->d_X2);
+            vis_launch_residuals(d, true, h->d_q, h->d_t, h->d_X, h->d_blkpart, h->d_scal, bs.stream); // new J, r at x
+            cost = cand;
+            radius = std::min(o.max_radius, radius / std::max(1.0 / 3.0, 1.0 - pow(2.0 * rho - 1.0, 3.0)));
+            decrease_factor = 2.0;
+            push(it, 1, 1, cost, cost_change, step_norm, radius, rho, gmax);
+        } else {
+            radius = radius / decrease_factor;
+            decrease_factor *= 2.0;
+            push(it, 0, 1, cand, cost_change, step_norm, radius, rho, gmax);
+            if (radius < o.min_radius) { term = LVBA_TERM_RADIUS; break; }
+        }
+    }
+    if (n_trace) *n_trace = std::min(rows, trace_cap > 0 ? trace_cap : 0);
+    if (termination) *termination = term;
+    const int32_t rc2 = export_state(h, q, t, X);
+    return rc != LVBA_OK ? rc : rc2;
+}

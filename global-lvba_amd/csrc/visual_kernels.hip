@@ -1,0 +1,406 @@
+// visual_kernels.hip -- gfx950 kernels of the visual bundle-adjustment stage (reference
+// LvbaSystem::optimizeCameraPoses, src/lvba_system.cpp:1571-1665, solved there by Ceres DENSE_SCHUR).
+//
+// One LM iteration = linearise (residuals + hand-derived Jacobians per observation), eliminate the 3x3 landmark
+// blocks, assemble the reduced camera system, solve it, back-substitute.  With C_i = L_i L_i^T the Cholesky factor
+// of a landmark's (damped) block and E = Jc^T Jp, every camera-pair block of the Schur complement is
+//        S_ab = [a==b] (Jc^T Jc + D^2)  -  sum_landmarks Y_a Y_b^T ,   Y = E L^-T   (6x3 per observation)
+// the same rank-3 structure as the LiDAR Hessian, so the per-block pair pass (balm_pair_kernel), the camera
+// ordering and the LDL^T solver are shared with the BALM stage (block_system.hip).
+//   vis_residual_kernel   lane = observation / landmark : residuals (+ Jacobians), cost partials
+//   vis_colnorm_*         Jacobi column scaling 1/(1+||col||), fixed at iteration 0 (Ceres jacobi_scaling)
+//   vis_point_kernel      lane = landmark : C_i, LM diagonal, Cholesky, z = L^-1 g
+//   vis_cam_kernel        workgroup = (camera, slice) of the camera-major order: Y per observation, diagonal block
+//                         and reduced right-hand side summed in registers
+//   vis_back_kernel       lane = landmark : landmark step by back-substitution + model cost change
+//   vis_apply_kernel      candidate point x (+) step on the manifold, step / parameter norms
+// Camera order everywhere is the solver's (RCM) order; camera `fixed_cam` is constant (zero Jacobian columns).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "lvba_internal.h"
+#include "visual_math.h"
+
+namespace lvba {
+
+__device__ __forceinline__ double v_wave_sum(double x)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    return x;
+}
+__device__ __forceinline__ double v_block_sum(double x, double *red) // 256 threads; valid in every thread
+{
+    x = v_wave_sum(x);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+    __syncthreads();
+    const double t = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    return t;
+}
+
+// residuals at (qc, tc, Xp); threads [0,O) observations, [O, O+Ta) plane priors.  part[blockIdx] = sum r^2.
+template <bool JAC>
+__global__ __launch_bounds__(256) void vis_residual_kernel(VisDev d, const double *__restrict__ qc, const double *__restrict__ tc,
+                                                           const double *__restrict__ Xp, double *__restrict__ part)
+{
+    __shared__ double red[4];
+    const int64_t gid = blockIdx.x * (int64_t)256 + threadIdx.x;
+    double ss = 0.0;
+    if (gid < d.O) {
+        const int cam = d.cam[gid];
+        const int64_t i = d.track_of_obs[gid];
+        double q[4], t[3], X[3], r[2], Jc[12], Jp[6];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q[e] = qc[4 * (int64_t)cam + e];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) { t[e] = tc[3 * (int64_t)cam + e]; X[e] = Xp[3 * i + e]; }
+        reproj_eval<JAC>(q, t, X, d.uv[2 * gid], d.uv[2 * gid + 1], d.intr, d.inv_sig_px, r, Jc, Jp);
+        d.r[2 * gid] = r[0];
+        d.r[2 * gid + 1] = r[1];
+        if (JAC) {
+            const bool fixed = cam == d.fixed_cam;
+#pragma unroll
+            for (int e = 0; e < 12; ++e) d.Jc[12 * gid + e] = fixed ? 0.0 : Jc[e];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) d.Jp[6 * gid + e] = Jp[e];
+        }
+        ss = r[0] * r[0] + r[1] * r[1];
+    } else if (gid < d.O + d.Ta) {
+        const int64_t i = gid - d.O;
+        double X[3], pl[4], J[3];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) X[e] = Xp[3 * i + e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pl[e] = d.plane[4 * i + e];
+        const double rp = plane_eval(X, pl, d.inv_sig_pl, JAC ? J : nullptr);
+        d.rpl[i] = rp;
+        if (JAC) {
+#pragma unroll
+            for (int e = 0; e < 3; ++e) d.Jpl[3 * i + e] = J[e];
+        }
+        ss = rp * rp;
+    }
+    const double tot = v_block_sum(ss, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+// Jacobi scaling of the landmark columns: sc = 1 / (1 + sqrt(sum of squares of the column))
+__global__ void vis_colnorm_pt_kernel(VisDev d)
+{
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= d.Ta) return;
+    double s[3] = {d.Jpl[3 * i] * d.Jpl[3 * i], d.Jpl[3 * i + 1] * d.Jpl[3 * i + 1], d.Jpl[3 * i + 2] * d.Jpl[3 * i + 2]};
+    for (int64_t o = d.off[i]; o < d.off[i + 1]; ++o)
+#pragma unroll
+        for (int e = 0; e < 3; ++e) s[e] += d.Jp[6 * o + e] * d.Jp[6 * o + e] + d.Jp[6 * o + 3 + e] * d.Jp[6 * o + 3 + e];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) d.sc_pt[3 * i + e] = 1.0 / (1.0 + sqrt(s[e]));
+}
+
+// ... and of the camera columns (one thread per camera over its camera-major observation list)
+__global__ void vis_colnorm_cam_kernel(VisDev d)
+{
+    const int64_t I = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (I >= d.M) return;
+    double s[6] = {0, 0, 0, 0, 0, 0};
+    for (int64_t t = d.csc_off[I]; t < d.csc_off[I + 1]; ++t) {
+        const int64_t o = d.csc_f[t];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) s[e] += d.Jc[12 * o + e] * d.Jc[12 * o + e] + d.Jc[12 * o + 6 + e] * d.Jc[12 * o + 6 + e];
+    }
+#pragma unroll
+    for (int e = 0; e < 6; ++e) d.sc_cam[6 * I + e] = 1.0 / (1.0 + sqrt(s[e]));
+}
+
+// lane = landmark: C = sum Jp^T Jp (+ plane) in the scaled variables, LM diagonal D^2 = clamp(diag C)/radius,
+// Cholesky of C + D^2, z = L^-1 g.  gmax: max |unscaled gradient entry| (bit pattern of a non-negative double).
+__global__ void vis_point_kernel(VisDev d, double radius, double min_diag, double max_diag, unsigned long long *gmax)
+{
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= d.Ta) return;
+    const double sp[3] = {d.sc_pt[3 * i], d.sc_pt[3 * i + 1], d.sc_pt[3 * i + 2]};
+    double C[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+    {
+        const double j[3] = {d.Jpl[3 * i] * sp[0], d.Jpl[3 * i + 1] * sp[1], d.Jpl[3 * i + 2] * sp[2]};
+        const double rp = d.rpl[i];
+        C[0] += j[0] * j[0]; C[1] += j[1] * j[0]; C[2] += j[1] * j[1]; C[3] += j[2] * j[0]; C[4] += j[2] * j[1]; C[5] += j[2] * j[2];
+        g[0] += j[0] * rp; g[1] += j[1] * rp; g[2] += j[2] * rp;
+    }
+    for (int64_t o = d.off[i]; o < d.off[i + 1]; ++o) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const double j[3] = {d.Jp[6 * o + 3 * k] * sp[0], d.Jp[6 * o + 3 * k + 1] * sp[1], d.Jp[6 * o + 3 * k + 2] * sp[2]};
+            const double rk = d.r[2 * o + k];
+            C[0] += j[0] * j[0]; C[1] += j[1] * j[0]; C[2] += j[1] * j[1]; C[3] += j[2] * j[0]; C[4] += j[2] * j[1]; C[5] += j[2] * j[2];
+            g[0] += j[0] * rk; g[1] += j[1] * rk; g[2] += j[2] * rk;
+        }
+    }
+    double gm = fmax(fabs(g[0] / sp[0]), fmax(fabs(g[1] / sp[1]), fabs(g[2] / sp[2])));
+    atomicMax(gmax, (unsigned long long)__double_as_longlong(gm));
+    C[0] += fmin(fmax(C[0], min_diag), max_diag) / radius;
+    C[2] += fmin(fmax(C[2], min_diag), max_diag) / radius;
+    C[5] += fmin(fmax(C[5], min_diag), max_diag) / radius;
+    double L[6], z[3];
+    chol3(C, L);
+    chol3_fwd(L, g, z);
+#pragma unroll
+    for (int e = 0; e < 6; ++e) d.Lp[6 * i + e] = L[e];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) d.zp[3 * i + e] = z[e];
+}
+
+// workgroup (I, s): slice s of camera I's observations in camera-major order.  Per observation Y = (Jc^T Jp) L^-T
+// (stored for the pair pass and the back-substitution); per camera the sums of
+//   D = Jc^T Jc - Y Y^T (lower 21) | reduced rhs Jc^T r - Y z (6) | diag(Jc^T Jc) (6) | Jc^T r (6)   -> part[.][40]
+__global__ __launch_bounds__(256) void vis_cam_kernel(VisDev d)
+{
+    __shared__ double red[4 * 39];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int I = blockIdx.x / d.S, s = blockIdx.x - I * d.S;
+    const int64_t seg0 = d.csc_off[I], len = d.csc_off[I + 1] - seg0;
+    const int64_t a = seg0 + (len * s) / d.S, b = seg0 + (len * (s + 1)) / d.S;
+    double sc[6];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) sc[e] = d.sc_cam[6 * (int64_t)I + e];
+    double acc[39];
+#pragma unroll
+    for (int e = 0; e < 39; ++e) acc[e] = 0.0;
+    for (int64_t t = a + tid; t < b; t += 256) {
+        const int64_t o = d.csc_f[t], i = d.group_of_pos[t];
+        double J[12], P[6], L[6], z[3];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) J[e] = d.Jc[12 * o + e] * sc[e % 6];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) P[e] = d.Jp[6 * o + e] * d.sc_pt[3 * i + (e % 3)];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) L[e] = d.Lp[6 * i + e];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) z[e] = d.zp[3 * i + e];
+        const double r0 = d.r[2 * o], r1 = d.r[2 * o + 1];
+        double Y[18];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+            // row e of E = Jc^T Jp, then row e of Y: Y L^T = E
+            const double E0 = J[e] * P[0] + J[6 + e] * P[3], E1 = J[e] * P[1] + J[6 + e] * P[4], E2 = J[e] * P[2] + J[6 + e] * P[5];
+            const double y0 = E0 / L[0];
+            const double y1 = (E1 - y0 * L[1]) / L[2];
+            const double y2 = (E2 - y0 * L[3] - y1 * L[4]) / L[5];
+            Y[e] = y0; Y[6 + e] = y1; Y[12 + e] = y2;
+        }
+        double *yo = d.Y + 18 * t;
+#pragma unroll
+        for (int e = 0; e < 18; ++e) yo[e] = Y[e];
+        int p = 0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+#pragma unroll
+            for (int rr = c; rr < 6; ++rr) {
+                acc[p] += J[rr] * J[c] + J[6 + rr] * J[6 + c] - (Y[rr] * Y[c] + Y[6 + rr] * Y[6 + c] + Y[12 + rr] * Y[12 + c]);
+                ++p;
+            }
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+            const double jr = J[e] * r0 + J[6 + e] * r1;
+            acc[21 + e] += jr - (Y[e] * z[0] + Y[6 + e] * z[1] + Y[12 + e] * z[2]);
+            acc[27 + e] += J[e] * J[e] + J[6 + e] * J[6 + e];
+            acc[33 + e] += jr;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 39; ++e) {
+        const double v = v_wave_sum(acc[e]);
+        if (lane == 0) red[wv * 39 + e] = v;
+    }
+    __syncthreads();
+    if (tid < 39) d.part[(int64_t)blockIdx.x * 40 + tid] = red[tid] + red[39 + tid] + red[78 + tid] + red[117 + tid];
+}
+
+// one thread per camera: slice sums -> diagonal block (lower) + LM diagonal, reduced right-hand side, gradient max
+__global__ void vis_cam_reduce_kernel(VisDev d, double radius, double min_diag, double max_diag, double *__restrict__ Hblk,
+                                      double *__restrict__ g, unsigned long long *gmax)
+{
+    const int64_t I = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (I >= d.M) return;
+    double acc[39];
+#pragma unroll
+    for (int e = 0; e < 39; ++e) acc[e] = 0.0;
+    for (int q = 0; q < d.S; ++q)
+#pragma unroll
+        for (int e = 0; e < 39; ++e) acc[e] += d.part[(I * d.S + q) * 40 + e];
+    double *hp = Hblk + I * (int64_t)(d.band_blocks + 1) * 36;
+    int p = 0;
+    double gm = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+#pragma unroll
+        for (int rr = c; rr < 6; ++rr) {
+            double v = acc[p++];
+            if (rr == c) v += fmin(fmax(acc[27 + c], min_diag), max_diag) / radius;
+            hp[c * 6 + rr] = v;
+        }
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+        g[6 * I + e] = acc[21 + e];
+        gm = fmax(gm, fabs(acc[33 + e] / d.sc_cam[6 * I + e]));
+    }
+    atomicMax(gmax, (unsigned long long)__double_as_longlong(gm));
+}
+
+// lane = landmark: step_p = -L^-T (z + sum_obs Y^T step_c), and the model cost change
+// -sum_rows m (r + m/2), m = J step (scaled variables).  part[blockIdx] = partial of the model cost change.
+__global__ __launch_bounds__(256) void vis_back_kernel(VisDev d, const double *__restrict__ step_c, double *__restrict__ part)
+{
+    __shared__ double red[4];
+    const int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x;
+    double mc = 0.0;
+    if (i < d.Ta) {
+        double s[3] = {d.zp[3 * i], d.zp[3 * i + 1], d.zp[3 * i + 2]};
+        for (int64_t o = d.off[i]; o < d.off[i + 1]; ++o) {
+            const double *y = d.Y + 18 * (int64_t)d.pos_of[o];
+            const double *sc = step_c + 6 * (int64_t)d.cam[o];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                double v = 0.0;
+#pragma unroll
+                for (int e = 0; e < 6; ++e) v += y[6 * m + e] * sc[e];
+                s[m] += v;
+            }
+        }
+        double L[6], sp[3], st[3];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) L[e] = d.Lp[6 * i + e];
+        chol3_bwd(L, s, st);
+#pragma unroll
+        for (int e = 0; e < 3; ++e) { st[e] = -st[e]; sp[e] = d.sc_pt[3 * i + e]; d.step_p[3 * i + e] = st[e]; }
+        {
+            const double m = d.Jpl[3 * i] * sp[0] * st[0] + d.Jpl[3 * i + 1] * sp[1] * st[1] + d.Jpl[3 * i + 2] * sp[2] * st[2];
+            mc -= m * (d.rpl[i] + 0.5 * m);
+        }
+        for (int64_t o = d.off[i]; o < d.off[i + 1]; ++o) {
+            const int cam = d.cam[o];
+            const double *sc = step_c + 6 * (int64_t)cam;
+            const double *scl = d.sc_cam + 6 * (int64_t)cam;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                double m = 0.0;
+#pragma unroll
+                for (int e = 0; e < 6; ++e) m += d.Jc[12 * o + 6 * k + e] * scl[e] * sc[e];
+#pragma unroll
+                for (int e = 0; e < 3; ++e) m += d.Jp[6 * o + 3 * k + e] * sp[e] * st[e];
+                mc -= m * (d.r[2 * o + k] + 0.5 * m);
+            }
+        }
+    }
+    const double tot = v_block_sum(mc, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+// candidate = x (+) step (unscaled): threads [0,M) cameras, [M, M+Ta) landmarks.  part[2*blk] = |cand - x|^2,
+// part[2*blk+1] = |x|^2 over the free parameters (ambient, as Ceres' step_norm / x_norm).
+__global__ __launch_bounds__(256) void vis_apply_kernel(VisDev d, const double *__restrict__ step_c, const double *__restrict__ qc,
+                                                        const double *__restrict__ tc, const double *__restrict__ Xp,
+                                                        double *__restrict__ qc2, double *__restrict__ tc2,
+                                                        double *__restrict__ Xp2, double *__restrict__ part)
+{
+    __shared__ double red[4];
+    const int64_t gid = blockIdx.x * (int64_t)256 + threadIdx.x;
+    double dn = 0.0, xn = 0.0;
+    if (gid < d.M) {
+        double q[4], t[3], dl[6], q2[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q[e] = qc[4 * gid + e];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) t[e] = tc[3 * gid + e];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) dl[e] = step_c[6 * gid + e] * d.sc_cam[6 * gid + e];
+        if (gid == d.fixed_cam) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) qc2[4 * gid + e] = q[e];
+#pragma unroll
+            for (int e = 0; e < 3; ++e) tc2[3 * gid + e] = t[e];
+        } else {
+            quat_plus(q, dl, q2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { qc2[4 * gid + e] = q2[e]; dn += (q2[e] - q[e]) * (q2[e] - q[e]); xn += q[e] * q[e]; }
+#pragma unroll
+            for (int e = 0; e < 3; ++e) { tc2[3 * gid + e] = t[e] + dl[3 + e]; dn += dl[3 + e] * dl[3 + e]; xn += t[e] * t[e]; }
+        }
+    } else if (gid < d.M + d.Ta) {
+        const int64_t i = gid - d.M;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const double x = Xp[3 * i + e], dl = d.step_p[3 * i + e] * d.sc_pt[3 * i + e];
+            Xp2[3 * i + e] = x + dl;
+            dn += dl * dl;
+            xn += x * x;
+        }
+    }
+    const double t0 = v_block_sum(dn, red);
+    const double t1 = v_block_sum(xn, red);
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = t0; part[2 * blockIdx.x + 1] = t1; }
+}
+
+// out[0] = sum part[0..n), out[1] = sum of odd entries if stride 2 (deterministic, single workgroup)
+__global__ __launch_bounds__(1024) void vis_reduce_kernel(const double *__restrict__ part, int64_t n, int stride, double *__restrict__ out)
+{
+    __shared__ double red[16];
+    for (int k = 0; k < stride; ++k) {
+        double s = 0.0;
+        for (int64_t i = threadIdx.x; i < n; i += 1024) s += part[stride * i + k];
+        s = v_wave_sum(s);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int i = 0; i < 16; ++i) t += red[i];
+            out[k] = t;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- launchers
+static inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b > 0 ? (n + b - 1) / b : 1); }
+
+void vis_launch_residuals(const VisDev &d, bool jac, const double *qc, const double *tc, const double *Xp, double *part,
+                          double *cost_out, hipStream_t s)
+{
+    const unsigned nb = nblk(d.O + d.Ta, 256);
+    if (jac) hipLaunchKernelGGL(vis_residual_kernel<true>, dim3(nb), dim3(256), 0, s, d, qc, tc, Xp, part);
+    else hipLaunchKernelGGL(vis_residual_kernel<false>, dim3(nb), dim3(256), 0, s, d, qc, tc, Xp, part);
+    hipLaunchKernelGGL(vis_reduce_kernel, dim3(1), dim3(1024), 0, s, part, (int64_t)nb, 1, cost_out);
+}
+
+void vis_launch_colnorms(const VisDev &d, hipStream_t s)
+{
+    hipLaunchKernelGGL(vis_colnorm_pt_kernel, dim3(nblk(d.Ta, 256)), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(vis_colnorm_cam_kernel, dim3(nblk(d.M, 64)), dim3(64), 0, s, d);
+}
+
+void vis_launch_reduced_system(const VisDev &d, const PairDev &pd, double radius, double min_diag, double max_diag, double *Hblk,
+                               int64_t hblk_doubles, double *g, unsigned long long *gmax, bool zero_first, hipStream_t s)
+{
+    if (zero_first) hipMemsetAsync(Hblk, 0, (size_t)hblk_doubles * sizeof(double), s);
+    hipMemsetAsync(gmax, 0, sizeof(unsigned long long), s);
+    hipLaunchKernelGGL(vis_point_kernel, dim3(nblk(d.Ta, 256)), dim3(256), 0, s, d, radius, min_diag, max_diag, gmax);
+    hipLaunchKernelGGL(vis_cam_kernel, dim3((unsigned)(d.M * d.S)), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(vis_cam_reduce_kernel, dim3(nblk(d.M, 64)), dim3(64), 0, s, d, radius, min_diag, max_diag, Hblk, g, gmax);
+    launch_pairs(pd, Hblk, s);
+}
+
+void vis_launch_back(const VisDev &d, const double *step_c, double *part, double *model_out, hipStream_t s)
+{
+    const unsigned nb = nblk(d.Ta, 256);
+    hipLaunchKernelGGL(vis_back_kernel, dim3(nb), dim3(256), 0, s, d, step_c, part);
+    hipLaunchKernelGGL(vis_reduce_kernel, dim3(1), dim3(1024), 0, s, part, (int64_t)nb, 1, model_out);
+}
+
+void vis_launch_apply(const VisDev &d, const double *step_c, const double *qc, const double *tc, const double *Xp, double *qc2,
+                      double *tc2, double *Xp2, double *part, double *norms_out, hipStream_t s)
+{
+    const unsigned nb = nblk(d.M + d.Ta, 256);
+    hipLaunchKernelGGL(vis_apply_kernel, dim3(nb), dim3(256), 0, s, d, step_c, qc, tc, Xp, qc2, tc2, Xp2, part);
+    hipLaunchKernelGGL(vis_reduce_kernel, dim3(1), dim3(1024), 0, s, part, (int64_t)nb, 2, norms_out);
+}
+
+} // namespace lvba

@@ -161,6 +161,80 @@ int32_t lvba_balm_get_ordering(lvba_balm_t h, int32_t *perm);
 int32_t lvba_dist_unique_id(char uid[128]);
 int32_t lvba_balm_dist_init(lvba_balm_t h, int32_t n_ranks, int32_t rank, const char uid[128]);
 
+/* ===================================================================================================
+ * Visual stage: replaces the ceres::Problem ... ceres::Solve region of LvbaSystem::optimizeCameraPoses
+ * (src/lvba_system.cpp:1571-1665) with the cost functors of include/utils.hpp:51-147.
+ *   camera   = T_cam<-world: q [w,x,y,z] (memory order of src/lvba_system.cpp:1516) + t; camera 0 is held
+ *              constant (:1582-1583); quaternions move on ceres::EigenQuaternionManifold applied to that memory
+ *              as the reference does (:1579) -- see DESIGN.md
+ *   landmark = X_w [3]; a landmark whose `valid` flag is 0 (no plane found, :1598-1603) is dropped together with
+ *              its reprojection observations and is returned unchanged
+ *   residuals: per observation the whitened Brown-Conrady reprojection error (2), per landmark the whitened
+ *              point-to-plane distance sqrt(s^2+1e-12)/sigma (1); no loss function (:1630,1639)
+ *   solver:    Levenberg-Marquardt trust region with Ceres 2.1 defaults restated (Jacobi scaling, LM diagonal
+ *              clamp(diag)/radius, radius schedule, tolerances), landmark blocks eliminated (Schur), reduced
+ *              camera system solved by the same LDL^T as the LiDAR stage.
+ * =================================================================================================== */
+typedef struct lvba_visual_s *lvba_visual_t;
+
+typedef struct {
+    int32_t max_iter;               /* 50     src/lvba_system.cpp:1573 */
+    int32_t reserved;
+    double initial_radius;          /* 1e4    Ceres default initial_trust_region_radius */
+    double max_radius;              /* 1e16 */
+    double min_radius;              /* 1e-32 */
+    double min_relative_decrease;   /* 1e-3 */
+    double min_lm_diagonal;         /* 1e-6 */
+    double max_lm_diagonal;         /* 1e32 */
+    double function_tolerance;      /* 1e-6 */
+    double gradient_tolerance;      /* 1e-10 */
+    double parameter_tolerance;     /* 1e-8 */
+} lvba_visual_opts;
+
+#define LVBA_TERM_NO_CONVERGENCE 0  /* max_iter reached */
+#define LVBA_TERM_FUNCTION 1
+#define LVBA_TERM_PARAMETER 2
+#define LVBA_TERM_GRADIENT 3
+#define LVBA_TERM_RADIUS 4
+#define LVBA_TERM_FAILURE 5         /* linear solver failed repeatedly / non-finite cost */
+
+/* one row per iteration, iteration 0 = the initial evaluation (like Ceres' progress table) */
+typedef struct {
+    int32_t iter;
+    int32_t accepted;     /* step successful (always 1 for iteration 0) */
+    int32_t valid;        /* linear solve produced a finite step with positive model decrease */
+    int32_t reserved;
+    double cost;          /* 1/2 sum r^2: the new cost if accepted, the rejected candidate's cost otherwise */
+    double cost_change;
+    double step_norm;
+    double radius;        /* trust-region radius after this iteration's update */
+    double rho;           /* relative decrease (step quality) */
+    double gradient_max_norm;
+} lvba_visual_trace;
+
+void lvba_visual_default_opts(lvba_visual_opts *opts);
+
+/* obs_off [n_tracks+1] CSR offsets of each landmark's (de-duplicated, inlier) observations; obs_cam [O] in
+ * [0,n_cams); obs_uv [O][2] pixels; plane [n_tracks][4] = (n, d); valid [n_tracks]; intr = fx fy cx cy k1 k2 p1 p2
+ * (already scaled, src/dataset_io.cpp:59-62); sigma_px = 0.5, sigma_plane = 0.01 upstream (:1590-1591). */
+int32_t lvba_visual_create(int32_t n_cams, int64_t n_tracks, const int64_t *obs_off, const int32_t *obs_cam,
+                           const double *obs_uv, const double *plane, const uint8_t *valid, const double intr[8],
+                           double sigma_px, double sigma_plane, int32_t device, lvba_visual_t *out);
+int32_t lvba_visual_destroy(lvba_visual_t h);
+
+/* 1/2 sum r^2 over the residuals of the active landmarks at (q [M][4], t [M][3], X [n_tracks][3]). */
+int32_t lvba_visual_cost(lvba_visual_t h, const double *q, const double *t, const double *X, double *cost);
+
+/* Linearise at the given point with trust-region radius `radius` (Jacobi scaling taken from THIS Jacobian, as at
+ * Ceres' iteration 0): the reduced camera system S [6M x 6M] (symmetric; camera 0's block is decoupled) and its
+ * right-hand side rhs [6M] in the scaled tangent variables, caller camera order.  For tests / inspection. */
+int32_t lvba_visual_linearize(lvba_visual_t h, const double *q, const double *t, const double *X, double radius,
+                              double *S, double *rhs, double *cost);
+
+/* The solve: refines q, t, X in place (quaternions re-normalised on write-back, :1651-1657). */
+int32_t lvba_visual_refine(lvba_visual_t h, double *q, double *t, double *X, const lvba_visual_opts *opts,
+                           lvba_visual_trace *trace, int32_t trace_cap, int32_t *n_trace, int32_t *termination);
+
 #ifdef __cplusplus
 }
 #endif

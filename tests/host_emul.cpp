@@ -88,3 +88,13 @@ extern "C" int emul_eig3(const double *C6, double *lam, double *U)
     eig3<true>(C6, lam, U);
     return 0;
 }
+
+// ---- visual stage: hand-derived Jacobians of global-lvba_amd/csrc/visual_math.h --------------------------------
+#include "../global-lvba_amd/csrc/visual_math.h"
+extern "C" int emul_reproj(const double *q, const double *t, const double *X, const double *uv, const double *intr,
+                           double sigma, double *r, double *Jc, double *Jp)
+{
+    return reproj_eval<true>(q, t, X, uv[0], uv[1], intr, 1.0 / sigma, r, Jc, Jp) ? 1 : 0;
+}
+extern "C" double emul_plane(const double *X, const double *pl, double sigma, double *J) { return plane_eval(X, pl, 1.0 / sigma, J); }
+extern "C" void emul_quat_plus(const double *a, const double *d, double *out) { quat_plus(a, d, out); }
