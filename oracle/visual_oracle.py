@@ -71,7 +71,7 @@ def reproj_residual(q, t, X, uv, intr, sigma):
     fx, fy, cx, cy, k1, k2, p1, p2 = intr
     Xc = _rotate_wxyz(q, X) + t
     z = Xc[2]
-    if float(z) <= 1e-8:
+    if float(z.detach()) <= 1e-8:
         return torch.zeros(2, dtype=F64) * (q.sum() + t.sum() + X.sum()) * 0.0
     xn, yn = Xc[0] / z, Xc[1] / z
     r2 = xn * xn + yn * yn
