@@ -264,3 +264,40 @@ def test_rccl_path_single_rank(pkg, oracle_mod, monkeypatch):
     xr, tr, _ = co.damping_iter(d["poses_init"])
     assert rc == 0 and np.abs(x - xr).max() <= 1e-7
     assert prob.info()["n_voxels_global"] == 3000
+
+
+def test_properties_at_baseline_size_c2(pkg, synth):
+    """BASELINE.json config C2 (500 poses x 400k voxels x 2M factors), generated on the GPU: size-independent
+    properties -- rigid-motion invariance, shard additivity of the cost, bitwise run-to-run reproducibility of the
+    atomic-free assembly, gradient = directional derivative of the cost kernel, and a full refine that ends at the
+    ground-truth cost level."""
+    import torch
+    N, V = synth.CONFIGS["C2"]
+    d = synth.make_balm_problem(N, V, device="cuda")
+    torch.cuda.empty_cache()
+    prob = pkg.BalmProblem(N, d["voxel_off"], d["pose_idx"], d["clusters"])
+    x = d["poses_init"]
+    c0 = prob.cost(x)
+    th = -0.4
+    Rg = np.array([[1, 0, 0], [0, np.cos(th), -np.sin(th)], [0, np.sin(th), np.cos(th)]])
+    tg = np.array([-7.0, 2.0, 1.5])
+    xg = np.concatenate([(Rg @ x[:, :9].reshape(-1, 3, 3)).reshape(-1, 9), x[:, 9:] @ Rg.T + tg], axis=1)
+    assert abs(prob.cost(xg) - c0) <= 1e-7 * c0
+    _, g, _ = prob.eval(x, want_H=False)
+    _, g2, _ = prob.eval(x, want_H=False)
+    assert np.array_equal(g, g2)                                        # deterministic assembly
+    import oracle.balm_oracle as bo
+    dv = np.random.default_rng(1).standard_normal(6 * N)
+    h = 2e-6
+    fd = (prob.cost(bo.retract(x, h * dv)) - prob.cost(bo.retract(x, -h * dv))) / (2 * h)
+    assert abs(fd - g @ dv) <= 1e-5 * np.linalg.norm(g) * np.linalg.norm(dv)
+    off = d["voxel_off"]
+    cs = 0.0
+    for r in range(2):
+        a, b = pkg.shard_range(V, r, 2)
+        sh = pkg.BalmProblem(N, off[a:b + 1], d["pose_idx"][off[a]:off[b]], d["clusters"][off[a]:off[b]])
+        cs += sh.cost(x)
+        sh.close()
+    assert abs(cs - c0) <= 1e-12 * c0
+    xf, trace, rc = prob.refine(x)
+    assert rc == 0 and trace[-1]["residual2"] <= prob.cost(d["poses_gt"], is_avg=True) * 1.001
