@@ -18,6 +18,8 @@ SYMBOLS = [
     "lvba_dist_unique_id", "lvba_balm_dist_init",
     "lvba_visual_default_opts", "lvba_visual_create", "lvba_visual_destroy", "lvba_visual_cost", "lvba_visual_linearize",
     "lvba_visual_refine",
+    "lvba_voxel_default_opts", "lvba_voxmap_build", "lvba_voxmap_destroy", "lvba_voxmap_info", "lvba_voxmap_export",
+    "lvba_voxmap_to_balm", "lvba_voxmap_find_planes",
 ]
 
 OK, ERR_ARG, ERR_DEVICE, ERR_NOMEM, ERR_UNSUPPORTED, ERR_DIST, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
@@ -66,6 +68,16 @@ class VisualTrace(C.Structure):
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_ if f != "reserved"}
+
+
+class VoxelOpts(C.Structure):
+    _fields_ = [("voxel_size", C.c_double), ("eigen_ratio", C.c_float * 4), ("min_points", C.c_int32),
+                ("layer_limit", C.c_int32)]
+
+
+class VoxmapInfo(C.Structure):
+    _fields_ = [("n_points", C.c_int64), ("n_roots", C.c_int64), ("n_planes", C.c_int64), ("n_voxels", C.c_int64),
+                ("n_factors", C.c_int64)]
 
 
 TERMINATION = {0: "NO_CONVERGENCE", 1: "CONVERGENCE(function)", 2: "CONVERGENCE(parameter)", 3: "CONVERGENCE(gradient)",
@@ -127,6 +139,15 @@ def load():
     lib.lvba_visual_linearize.argtypes = [H, f64p, f64p, f64p, C.c_double, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
     lib.lvba_visual_refine.argtypes = [H, f64p, f64p, f64p, C.POINTER(VisualOpts), C.POINTER(VisualTrace), C.c_int32,
                                        C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.lvba_voxel_default_opts.argtypes = [C.POINTER(VoxelOpts)]
+    lib.lvba_voxel_default_opts.restype = None
+    lib.lvba_voxmap_build.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_void_p), i64p, C.c_int32, f64p,
+                                      C.POINTER(VoxelOpts), C.POINTER(H)]
+    lib.lvba_voxmap_destroy.argtypes = [H]
+    lib.lvba_voxmap_info.argtypes = [H, C.POINTER(VoxmapInfo)]
+    lib.lvba_voxmap_export.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.lvba_voxmap_to_balm.argtypes = [H, C.POINTER(H)]
+    lib.lvba_voxmap_find_planes.argtypes = [H, C.c_int64, f64p, f64p, u8p]
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int:  # default

@@ -43,6 +43,17 @@ class BalmProblem:
             L.check(self.lib.lvba_balm_configure(self._h, 1 if ordering is None else int(ordering),
                                                  0.6 if band_frac is None else float(band_frac)))
 
+    @classmethod
+    def _from_handle(cls, handle, n_poses, n_voxels, ordering=None, band_frac=None):
+        """Wrap an lvba_balm_t made by another entry point (lvba_voxmap_to_balm)."""
+        self = cls.__new__(cls)
+        self.lib = L.load()
+        self.n_poses, self.n_voxels, self._h = int(n_poses), int(n_voxels), handle
+        if ordering is not None or band_frac is not None:
+            L.check(self.lib.lvba_balm_configure(self._h, 1 if ordering is None else int(ordering),
+                                                 0.6 if band_frac is None else float(band_frac)))
+        return self
+
     # -- lifetime ---------------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

@@ -269,3 +269,77 @@ def make_visual_problem(n_cams, n_tracks, *, seed=20250925, track_len=4, pixel_s
                 obs_off=obs_off.cpu().numpy(), obs_cam=obs_cam.cpu().numpy(), obs_uv=obs_uv.cpu().numpy(),
                 plane=plane.cpu().numpy(), valid=valid.cpu().numpy(), intr=intr.copy(),
                 q_gt=_rotmat_to_quat_wxyz(Rcw).cpu().numpy(), t_gt=tcw.cpu().numpy(), X_gt=X_gt.cpu().numpy())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Raw scans for the voxel front-end (lvba_voxmap_build): a box room with slanted panels and non-planar clutter.
+# ------------------------------------------------------------------------------------------------------------------
+
+def _rot_zyx(yaw, pitch, roll):
+    cy, sy, cp, sp, cr, sr = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch), np.cos(roll), np.sin(roll)
+    Rz = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1.0]])
+    Ry = np.array([[cp, 0, sp], [0, 1.0, 0], [-sp, 0, cp]])
+    Rx = np.array([[1.0, 0, 0], [0, cr, -sr], [0, sr, cr]])
+    return Rz @ Ry @ Rx
+
+
+def make_scans(n_frames, pts_per_frame, *, seed=20250925, room=(30.0, 20.0, 6.0), n_panels=6, n_blobs=12,
+               clutter_frac=0.15, noise=0.01, rot_sigma_deg=0.02, trans_sigma=0.01, origin=(0.0, 0.0, 0.0),
+               point_floats=3):
+    """Synthetic window of LiDAR scans.  Returns dict(clouds=[n_i, point_floats] float32 body-frame arrays,
+    poses=[N,12] (ground truth + odometry-grade noise), poses_gt=[N,12]).  The sensor flies a loop inside a
+    room[0] x room[1] x room[2] box centred at `origin` (a non-zero origin exercises negative / large voxel keys);
+    every ray hits the nearest of the 6 room faces and n_panels slanted rectangles; clutter_frac of the points are
+    replaced by samples of Gaussian blobs (non-planar -> voxels that split or drop)."""
+    rng = np.random.default_rng(seed)
+    L = np.asarray(room, np.float64)
+    org = np.asarray(origin, np.float64)
+    # planes: (point c, unit normal n, in-plane axes a,b, half extents)
+    quads = []
+    for ax in range(3):
+        for sgn in (-1.0, 1.0):
+            n = np.zeros(3); n[ax] = sgn
+            c = np.zeros(3); c[ax] = sgn * L[ax] / 2
+            a = np.zeros(3); a[(ax + 1) % 3] = 1.0
+            b = np.zeros(3); b[(ax + 2) % 3] = 1.0
+            quads.append((c, n, a, b, L[(ax + 1) % 3] / 2, L[(ax + 2) % 3] / 2))
+    for _ in range(n_panels):
+        R = _rot_zyx(*rng.uniform(-np.pi, np.pi, 3))
+        c = rng.uniform(-0.35, 0.35, 3) * L
+        quads.append((c, R[:, 2], R[:, 0], R[:, 1], rng.uniform(0.8, 2.5), rng.uniform(0.8, 2.5)))
+    blobs = rng.uniform(-0.4, 0.4, (max(n_blobs, 1), 3)) * L
+    blob_sig = rng.uniform(0.15, 0.5, max(n_blobs, 1))
+
+    t = np.arange(n_frames) * (2 * np.pi / max(n_frames, 1))
+    pos = np.stack([0.3 * L[0] * np.cos(t), 0.3 * L[1] * np.sin(t), 0.1 * L[2] * np.sin(2 * t)], -1)
+    clouds, poses, poses_gt = [], [], []
+    for f in range(n_frames):
+        R = _rot_zyx(t[f] + np.pi / 2, *np.radians(rng.normal(0, 2.0, 2)))
+        p = pos[f]
+        d = rng.normal(size=(pts_per_frame, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        best = np.full(pts_per_frame, np.inf)
+        for c, n, a, b, ha, hb in quads:
+            den = d @ n
+            s = np.where(np.abs(den) > 1e-9, ((c - p) @ n) / np.where(den == 0, 1, den), np.inf)
+            hit = p + s[:, None] * d
+            ok = (s > 0.3) & (np.abs((hit - c) @ a) <= ha) & (np.abs((hit - c) @ b) <= hb)
+            best = np.where(ok & (s < best), s, best)
+        pw = p + best[:, None] * d + rng.normal(0, noise, (pts_per_frame, 3))
+        nb = int(clutter_frac * pts_per_frame)
+        if n_blobs > 0 and nb > 0:
+            which = rng.integers(0, len(blobs), nb)
+            pw[:nb] = blobs[which] + rng.normal(size=(nb, 3)) * blob_sig[which, None]
+        pw = pw[np.isfinite(pw).all(1)]
+        pw = pw[rng.permutation(len(pw))]
+        body = ((pw - p) @ R).astype(np.float32)                   # R^T (pw - p)
+        cloud = np.zeros((len(body), point_floats), np.float32)
+        cloud[:, :3] = body
+        if point_floats > 3:
+            cloud[:, 3:] = rng.random((len(body), point_floats - 3), dtype=np.float32)   # payload the library must skip
+        clouds.append(cloud)
+        p_world = p + org
+        poses_gt.append(np.concatenate([R.reshape(-1), p_world]))
+        dR = _rot_zyx(*np.radians(rng.normal(0, rot_sigma_deg, 3)))
+        poses.append(np.concatenate([(R @ dR).reshape(-1), p_world + rng.normal(0, trans_sigma, 3)]))
+    return dict(clouds=clouds, poses=np.asarray(poses), poses_gt=np.asarray(poses_gt))

@@ -1,0 +1,113 @@
+"""Host-side mirror of the reference's voxel front-end over the C-ABI.
+
+    surf_map = VoxelMap(clouds, x_buf, voxel_size, eigen_ratio_array)   # cut_voxel per frame + recut per root
+    voxhess  = surf_map.tras_opt()                                      # -> the VOX_HESS damping_iter takes
+    n, d, ok = surf_map.find_planes(X)                                  # recompute_local_planes
+
+mirrors include/BALM/bavoxel.hpp:799-836 (cut_voxel), :391-464 (recut), :466-474 (tras_opt) and
+src/lvba_system.cpp:1531-1565.  Everything runs in liblvba_hip.so on the GPU; this file packs arrays.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .balm import BalmProblem
+
+
+def default_opts():
+    o = L.VoxelOpts()
+    L.load().lvba_voxel_default_opts(C.byref(o))
+    return o
+
+
+class VoxelMap:
+    """Adaptive-voxel plane map of a window of scans, resident on a GPU."""
+
+    def __init__(self, clouds, poses, voxel_size=1.0, eigen_ratio_array=None, min_points=None, device=0):
+        """clouds: sequence of [n_i, >=3] float32 arrays (x, y, z first; row stride = the array's, so PCL-style
+        padded points can be passed as they are); poses [N, 12]."""
+        self.lib = L.load()
+        self._keep = []
+        n = len(clouds)
+        ptrs = (C.c_void_p * max(n, 1))()
+        counts = np.zeros(max(n, 1), np.int64)
+        stride = None
+        for f, c in enumerate(clouds):
+            c = np.asarray(c)
+            if c.dtype != np.float32:
+                c = c.astype(np.float32)
+            if c.ndim != 2 or c.shape[1] < 3:
+                raise ValueError("each cloud must be [n, >=3] float32")
+            if not c.flags["C_CONTIGUOUS"]:
+                c = np.ascontiguousarray(c)
+            if stride is None:
+                stride = 4 * c.shape[1]
+            elif stride != 4 * c.shape[1]:
+                raise ValueError("all clouds must share one point stride")
+            self._keep.append(c)
+            ptrs[f] = c.ctypes.data if c.shape[0] else None
+            counts[f] = c.shape[0]
+        poses = np.ascontiguousarray(poses, np.float64).reshape(-1)
+        if poses.size != 12 * n:
+            raise ValueError(f"poses must hold {n} x 12 doubles")
+        o = default_opts()
+        o.voxel_size = float(voxel_size)
+        if eigen_ratio_array is not None:
+            er = np.asarray(eigen_ratio_array, np.float32)
+            for i in range(min(4, len(er))):
+                o.eigen_ratio[i] = float(er[i])
+        if min_points is not None:
+            o.min_points = int(min_points)
+        self.n_frames = n
+        self.voxel_size = float(voxel_size)
+        self._h = C.c_void_p()
+        L.check(self.lib.lvba_voxmap_build(int(device), n, ptrs, counts, int(stride or 12), poses, C.byref(o),
+                                           C.byref(self._h)))
+        self._keep = []
+        info = L.VoxmapInfo()
+        L.check(self.lib.lvba_voxmap_info(self._h, C.byref(info)))
+        self.info = {f: getattr(info, f) for f, _ in info._fields_}
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.lib.lvba_voxmap_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def export(self):
+        """(voxel_off [V+1], pose_idx [F], clusters [F,10], voxel_key [V,4]) of the admitted voxels."""
+        V, F = self.info["n_voxels"], self.info["n_factors"]
+        off = np.zeros(V + 1, np.int64)
+        idx = np.zeros(F, np.int32)
+        cl = np.zeros((F, 10))
+        key = np.zeros((V, 4), np.int64)
+        L.check(self.lib.lvba_voxmap_export(self._h, off.ctypes.data, idx.ctypes.data, cl.ctypes.data, key.ctypes.data))
+        return off, idx, cl, key
+
+    def tras_opt(self, ordering=None, band_frac=None):
+        """The packed problem of all admitted plane voxels (every root's tras_opt, bavoxel.hpp:466-474)."""
+        h = C.c_void_p()
+        L.check(self.lib.lvba_voxmap_to_balm(self._h, C.byref(h)))
+        return BalmProblem._from_handle(h, self.n_frames, self.info["n_voxels"], ordering, band_frac)
+
+    def find_planes(self, X):
+        """(plane [n,4] = unit normal and d, valid [n]) for world points X [n,3] (src/lvba_system.cpp:1531-1565)."""
+        X = np.ascontiguousarray(X, np.float64).reshape(-1, 3)
+        plane = np.zeros((len(X), 4))
+        valid = np.zeros(len(X), np.uint8)
+        L.check(self.lib.lvba_voxmap_find_planes(self._h, len(X), X.reshape(-1), plane.reshape(-1), valid))
+        return plane, valid

@@ -235,6 +235,48 @@ int32_t lvba_visual_linearize(lvba_visual_t h, const double *q, const double *t,
 int32_t lvba_visual_refine(lvba_visual_t h, double *q, double *t, double *X, const lvba_visual_opts *opts,
                            lvba_visual_trace *trace, int32_t trace_cap, int32_t *n_trace, int32_t *termination);
 
+/* ---- voxel front-end: raw scans -> the packed LiDAR-BA problem, on the device ---------------------------------------
+ * Replaces the construction that precedes every damping_iter call (src/lvba_system.cpp:247-258, :365-377, :1498-1506):
+ *   lvba_voxmap_build       <- cut_voxel (include/BALM/bavoxel.hpp:799-836) for every frame, then, for every root,
+ *                              OCTO_TREE_NODE::recut (:391-464, judge_eigen :335-352)
+ *   lvba_voxmap_to_balm     <- OCTO_TREE_NODE::tras_opt (:466-474) into VOX_HESS::push_voxel (:45-54)
+ *   lvba_voxmap_find_planes <- recompute_local_planes (src/lvba_system.cpp:1531-1565) +
+ *                              OCTO_TREE_NODE::findCorrespondPoint (bavoxel.hpp:320-333)
+ * Kept from the reference: fp32 points promoted to double; root key = C truncation of a FLOAT quotient that had 1
+ * subtracted when negative; float voxel centres / quarter lengths; octant test `double > float`; a node with fewer
+ * than min_points points is dropped, one whose lambda_min/lambda_max exceeds eigen_ratio[layer] is split (dropped at
+ * layer 2); PointCluster sums accumulate in cloud order (results are bit-identical to PointCluster::push).
+ * Voxels come out sorted by (root key x,y,z, octant path); the reference's unordered_map order is unspecified. */
+typedef struct lvba_voxmap_s *lvba_voxmap_t;
+typedef struct {
+    double voxel_size;      /* root voxel edge (stage1_root_voxel_size_ / stage2_root_voxel_size_) */
+    float eigen_ratio[4];   /* eigen_ratio_array (bavoxel.hpp:17, include/dataset_io.h:77,80); [3] unused as upstream */
+    int32_t min_points;     /* min_ps = 15 (bavoxel.hpp:24) */
+    int32_t layer_limit;    /* must be 2 (bavoxel.hpp:13) */
+} lvba_voxel_opts;
+typedef struct {
+    int64_t n_points, n_roots, n_planes; /* points hashed; root voxels; PLANE nodes (admitted or not) */
+    int64_t n_voxels, n_factors;         /* admitted voxels (>= 2 observing frames) and their cluster slots */
+} lvba_voxmap_info_t;
+void lvba_voxel_default_opts(lvba_voxel_opts *opts);
+
+/* frame_points[f] -> host memory of frame f's cloud: frame_count[f] points, x,y,z as the first three floats of every
+ * point_stride_bytes (12 for packed xyz, sizeof(pcl::PointXYZINormal) = 48 for the reference's PointType);
+ * poses [n_frames][12].  Fails with LVBA_ERR_ARG on a non-finite point. */
+int32_t lvba_voxmap_build(int32_t device, int32_t n_frames, const void *const *frame_points,
+                          const int64_t *frame_count, int32_t point_stride_bytes, const double *poses,
+                          const lvba_voxel_opts *opts, lvba_voxmap_t *out);
+int32_t lvba_voxmap_destroy(lvba_voxmap_t h);
+int32_t lvba_voxmap_info(lvba_voxmap_t h, lvba_voxmap_info_t *info);
+/* Host copies of the admitted voxels in lvba_balm_create's layout (any pointer may be NULL): voxel_off [V+1],
+ * pose_idx [F], clusters [F][10], voxel_key [V][4] = root key x, y, z and layer | o1 << 4 | o2 << 8. */
+int32_t lvba_voxmap_export(lvba_voxmap_t h, int64_t *voxel_off, int32_t *pose_idx, double *clusters,
+                           int64_t *voxel_key);
+/* The VOX_HESS of this map (poses = the n_frames of the build), ready for lvba_balm_refine. */
+int32_t lvba_voxmap_to_balm(lvba_voxmap_t h, lvba_balm_t *out);
+/* plane [n][4] = (unit normal, d = -n.centre) and valid [n] for n world points X [n][3]; invalid -> zeros. */
+int32_t lvba_voxmap_find_planes(lvba_voxmap_t h, int64_t n, const double *X, double *plane, uint8_t *valid);
+
 #ifdef __cplusplus
 }
 #endif

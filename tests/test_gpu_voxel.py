@@ -1,0 +1,134 @@
+"""GPU parity tests of the voxel front-end (lvba_voxmap_*) against oracle/voxel_oracle.py on identical scans.
+
+Index work (root keys, octant paths, observing frames, admission) must agree exactly; the PointCluster sums are
+accumulated in the reference's cloud order and must be BIT-identical; plane parameters (an eigen-decomposition) agree
+to 1e-8 up to the sign of the normal."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    dict(n_frames=5, pts_per_frame=12000, room=(10, 8, 4), origin=(-3.3, 7.1, 0.4), n_panels=8, seed=11),
+    dict(n_frames=3, pts_per_frame=9000, room=(6, 5, 3), origin=(40.2, -55.7, 3.0), n_panels=5, seed=12, voxel_size=0.5),
+    dict(n_frames=8, pts_per_frame=5000, room=(10, 8, 4), origin=(0.0, 0.0, 0.0), n_panels=8, seed=13, voxel_size=2.0,
+         point_floats=12),                                    # padded points (PCL PointXYZINormal stride)
+]
+STAGE2_RATIO = np.float32([0.08, 0.08, 0.08, 0.08])           # include/dataset_io.h:80
+
+
+def _build(pkg, synth, case, ratio=None):
+    from oracle import voxel_oracle as vo
+    case = dict(case)
+    vs = case.pop("voxel_size", 1.0)
+    s = synth.make_scans(**case)
+    ratio = vo.DEFAULT_EIGEN_RATIO if ratio is None else ratio
+    surf_map, vox = vo.build([c[:, :3] for c in s["clouds"]], s["poses"], vs, ratio)
+    m = pkg.VoxelMap(s["clouds"], s["poses"], vs, ratio)
+    return s, vs, surf_map, vox, m
+
+
+def _path_code(path):
+    return len(path) | ((path[0] if len(path) >= 1 else 0) << 4) | ((path[1] if len(path) == 2 else 0) << 8)
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("ratio", [None, STAGE2_RATIO])
+def test_voxels_match_oracle_bit_for_bit(pkg, synth, case, ratio):
+    from oracle import voxel_oracle as vo
+    s, vs, surf_map, vox, m = _build(pkg, synth, case, ratio)
+    off_ref, idx_ref, cl_ref = vo.pack(vox)
+    assert len(vox) > 20, "case too small to mean anything"
+    assert m.info["n_points"] == sum(len(c) for c in s["clouds"])
+    assert m.info["n_roots"] == len(surf_map)
+    n_planes = 0
+
+    def count(n):
+        nonlocal n_planes
+        n_planes += n.state == "PLANE"
+        for l in n.leaves:
+            if l is not None:
+                count(l)
+    for r in surf_map.values():
+        count(r)
+    assert m.info["n_planes"] == n_planes
+    assert m.info["n_voxels"] == len(vox) and m.info["n_factors"] == off_ref[-1]
+    off, idx, cl, key = m.export()
+    key_ref = np.array([list(k) + [_path_code(p)] for k, p, _ in vox], np.int64)
+    np.testing.assert_array_equal(key, key_ref)
+    np.testing.assert_array_equal(off, off_ref)
+    np.testing.assert_array_equal(idx, idx_ref)
+    np.testing.assert_array_equal(cl, cl_ref)             # same products, same order of sums
+    # the split branches were exercised
+    layers = set(len(p) for _, p, _ in vox)
+    assert layers >= {0, 1}
+
+
+@pytest.mark.parametrize("case", CASES[:2])
+def test_find_planes_matches_oracle(pkg, synth, case):
+    from oracle import voxel_oracle as vo
+    s, vs, surf_map, vox, m = _build(pkg, synth, case, STAGE2_RATIO)
+    rng = np.random.default_rng(5)
+    # queries: scan points moved to the world frame (mostly hits) + uniform points (mostly misses) + non-finite
+    q = []
+    for c, T in zip(s["clouds"], s["poses"]):
+        sel = rng.choice(len(c), 300, replace=False)
+        q.append(c[sel, :3].astype(np.float64) @ T[:9].reshape(3, 3).T + T[9:])
+    org = np.asarray(case["origin"])
+    q.append(org + rng.uniform(-6, 6, (500, 3)))
+    q.append(np.array([[np.nan, 0, 0], [0, np.inf, 0]]))
+    X = np.concatenate(q)
+    plane, valid = m.find_planes(X)
+    n_hit = 0
+    for i, x in enumerate(X):
+        ref = vo.find_plane(surf_map, x, vs)
+        assert bool(valid[i]) == (ref is not None), i
+        if ref is None:
+            assert not plane[i].any()
+            continue
+        n_hit += 1
+        n, d = ref
+        sgn = np.sign(n @ plane[i, :3])
+        # eigenvector of a (nearly) planar covariance: conditioning ~ eps * lambda_max / gap; d inherits it times |centre|
+        assert np.abs(sgn * plane[i, :3] - n).max() < 1e-8
+        assert abs(sgn * plane[i, 3] - d) < 1e-8 * (1 + np.abs(x).max())
+    assert 200 < n_hit < len(X) - 200
+
+
+def test_map_feeds_the_lm_refinement(pkg, synth):
+    """scans -> lvba_voxmap_to_balm -> damping_iter: the cost seen through the map equals the cost of the oracle's
+    packed voxels, and refinement from odometry-grade poses reduces it."""
+    from oracle import voxel_oracle as vo
+    from oracle import balm_oracle as bo
+    s, vs, surf_map, vox, m = _build(pkg, synth, CASES[0])
+    off, idx, cl = vo.pack(vox)
+    prob = m.tras_opt()
+    c_gpu = prob.cost(s["poses"])
+    c_ref = bo.only_residual(bo.Problem(len(s["poses"]), off, idx, cl), s["poses"])
+    assert abs(c_gpu - c_ref) <= 1e-9 * c_ref
+    poses, trace, rc = prob.refine(s["poses"])
+    assert rc == 0
+    assert trace[-1]["residual1"] <= trace[0]["residual1"]
+    assert any(t["accepted"] for t in trace)
+
+
+def test_argument_errors(pkg):
+    from importlib import import_module
+    L = import_module("global-lvba_amd._lib")
+    T = np.concatenate([np.eye(3).reshape(-1), np.zeros(3)])[None]
+    bad = np.array([[0.1, 0.2, np.nan]], np.float32)
+    with pytest.raises(L.LvbaError) as e:
+        pkg.VoxelMap([bad], T)
+    assert e.value.code == L.ERR_ARG
+    with pytest.raises(L.LvbaError):
+        pkg.VoxelMap([np.zeros((4, 3), np.float32)], T, voxel_size=0.0)
+    # a map without admitted voxels builds, answers lookups with "no plane", and refuses to become a problem
+    m = pkg.VoxelMap([np.zeros((4, 3), np.float32)], T)
+    assert m.info["n_voxels"] == 0 and m.info["n_roots"] == 1
+    plane, valid = m.find_planes(np.zeros((3, 3)))
+    assert not valid.any()
+    with pytest.raises(L.LvbaError):
+        m.tras_opt()
+    empty = pkg.VoxelMap([np.zeros((0, 3), np.float32)], T)
+    assert empty.info["n_points"] == 0
+    assert not empty.find_planes(np.zeros((2, 3)))[1].any()
