@@ -8,6 +8,10 @@
 // Usage at src/lvba_system.cpp:264 and :386 --
 //       // opt_lsv->damping_iter(x_win, *voxhess);
 //       lvba::damping_iter_hip(x_win, *voxhess);
+// or, replacing the whole block src/lvba_system.cpp:247-264 / :365-386 (cut_voxel loop, recut, tras_opt, damping_iter)
+// so that the octree is never built on the CPU --
+//       lvba::VoxelMap surf_map(pl_win, x_win, stage1_root_voxel_size_, stage1_eigen_ratio_array_.data());
+//       if (surf_map.info().n_voxels >= 3 * x_win.size()) surf_map.damping_iter(x_win);
 #pragma once
 #include <cstdint>
 #include <stdexcept>
@@ -75,5 +79,95 @@ std::vector<lvba_lm_trace> damping_iter_hip(PoseVec &x_stats, const VoxHess &vox
     }
     return trace;
 }
+
+// RAII wrapper of the device-resident voxel map.  CloudPtrVec: sequence of (smart) pointers to clouds with
+// `.points` (contiguous PointT whose first three floats are x, y, z -- pcl::PointXYZINormal and friends).
+class VoxelMap {
+  public:
+    template <class CloudPtrVec, class PoseVec>
+    VoxelMap(const CloudPtrVec &clouds, const PoseVec &x_buf, double voxel_size, const float *eigen_ratio_array,
+             int device = 0)
+    {
+        const int32_t n = static_cast<int32_t>(x_buf.size());
+        std::vector<const void *> ptr(n);
+        std::vector<int64_t> cnt(n);
+        int32_t stride = 12;
+        for (int32_t j = 0; j < n; ++j) {
+            const auto &pts = clouds[j]->points;
+            ptr[j] = pts.data();
+            cnt[j] = static_cast<int64_t>(pts.size());
+            stride = static_cast<int32_t>(sizeof(pts[0]));
+        }
+        std::vector<double> poses;
+        pack_poses(x_buf, poses);
+        lvba_voxel_opts o;
+        lvba_voxel_default_opts(&o);
+        o.voxel_size = voxel_size;
+        if (eigen_ratio_array)
+            for (int k = 0; k < 4; ++k) o.eigen_ratio[k] = eigen_ratio_array[k];
+        if (lvba_voxmap_build(device, n, ptr.data(), cnt.data(), stride, poses.data(), &o, &h_) != LVBA_OK)
+            throw std::runtime_error(std::string("lvba_voxmap_build: ") + lvba_last_error());
+    }
+    ~VoxelMap() { lvba_voxmap_destroy(h_); }
+    VoxelMap(const VoxelMap &) = delete;
+    VoxelMap &operator=(const VoxelMap &) = delete;
+
+    lvba_voxmap_info_t info() const
+    {
+        lvba_voxmap_info_t i;
+        lvba_voxmap_info(h_, &i);
+        return i;
+    }
+    // tras_opt + BALM2::damping_iter on the map's admitted voxels; refines x_stats in place.
+    template <class PoseVec>
+    std::vector<lvba_lm_trace> damping_iter(PoseVec &x_stats) const
+    {
+        lvba_balm_t b = nullptr;
+        if (lvba_voxmap_to_balm(h_, &b) != LVBA_OK)
+            throw std::runtime_error(std::string("lvba_voxmap_to_balm: ") + lvba_last_error());
+        std::vector<double> poses;
+        pack_poses(x_stats, poses);
+        lvba_balm_opts opts;
+        lvba_balm_default_opts(&opts);
+        std::vector<lvba_lm_trace> trace(opts.max_iter);
+        int32_t n_trace = 0;
+        const int32_t rc = lvba_balm_refine(b, poses.data(), &opts, trace.data(), &n_trace);
+        lvba_balm_destroy(b);
+        if (rc < 0) throw std::runtime_error(std::string("lvba_balm_refine: ") + lvba_last_error());
+        trace.resize(n_trace);
+        for (size_t j = 0; j < x_stats.size(); ++j) {
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) x_stats[j].R(r, c) = poses[12 * j + 3 * r + c];
+            for (int r = 0; r < 3; ++r) x_stats[j].p[r] = poses[12 * j + 9 + r];
+        }
+        return trace;
+    }
+    // recompute_local_planes (src/lvba_system.cpp:1531-1565): Xs = sequence of 3-element arrays.
+    template <class PointVec>
+    void find_planes(const PointVec &Xs, std::vector<double> &plane_nd, std::vector<uint8_t> &valid) const
+    {
+        std::vector<double> X(3 * Xs.size());
+        for (size_t i = 0; i < Xs.size(); ++i)
+            for (int r = 0; r < 3; ++r) X[3 * i + r] = Xs[i][r];
+        plane_nd.assign(4 * Xs.size(), 0.0);
+        valid.assign(Xs.size(), 0);
+        if (lvba_voxmap_find_planes(h_, static_cast<int64_t>(Xs.size()), X.data(), plane_nd.data(), valid.data()) != LVBA_OK)
+            throw std::runtime_error(std::string("lvba_voxmap_find_planes: ") + lvba_last_error());
+    }
+    lvba_voxmap_t handle() const { return h_; }
+
+  private:
+    template <class PoseVec>
+    static void pack_poses(const PoseVec &x, std::vector<double> &poses)
+    {
+        poses.resize(12 * x.size());
+        for (size_t j = 0; j < x.size(); ++j) {
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) poses[12 * j + 3 * r + c] = x[j].R(r, c);
+            for (int r = 0; r < 3; ++r) poses[12 * j + 9 + r] = x[j].p[r];
+        }
+    }
+    lvba_voxmap_t h_ = nullptr;
+};
 
 } // namespace lvba

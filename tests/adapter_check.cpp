@@ -9,6 +9,8 @@
 struct Mat3 { double m[9]; double &operator()(int r, int c) { return m[3 * r + c]; } double operator()(int r, int c) const { return m[3 * r + c]; } };
 struct PointCluster { Mat3 P; double v[3]; int N; };
 struct IMUST { Mat3 R; double p[3]; };
+struct PointXYZINormal { float x, y, z, pad0, nx, ny, nz, pad1, intensity, curvature, pad2, pad3; };   // 48 B, as PCL
+struct Cloud { std::vector<PointXYZINormal> points; };
 struct VOX_HESS { int win_size; std::vector<const std::vector<PointCluster> *> plvec_voxels; };
 
 int main()
@@ -32,6 +34,33 @@ int main()
     if (off != std::vector<int64_t>{0, 2, 4} || idx != std::vector<int32_t>{0, 2, 1, 2} || clu.size() != 40 || clu[9] != 4) return 1;
     std::vector<IMUST> x(N);
     for (auto &s : x) { std::memset(&s, 0, sizeof s); s.R(0, 0) = s.R(1, 1) = s.R(2, 2) = 1; }
+    // front-end adapter: two frames looking at one plane patch inside a single root voxel
+    static_assert(sizeof(PointXYZINormal) == 48, "stand-in must have PCL's stride");
+    Cloud c0, c1;
+    for (int i = 0; i < 40; ++i) {
+        PointXYZINormal p{};
+        p.x = 0.1f + 0.02f * (i % 8); p.y = 0.1f + 0.1f * (i / 8); p.z = 0.5f + 0.001f * ((i * 7) % 3);
+        p.intensity = 100.f;
+        (i % 2 ? c1 : c0).points.push_back(p);
+    }
+    std::vector<const Cloud *> clouds{&c0, &c1};
+    std::vector<IMUST> xw(2);
+    for (auto &s : xw) { std::memset(&s, 0, sizeof s); s.R(0, 0) = s.R(1, 1) = s.R(2, 2) = 1; }
+    const float ratio[4] = {0.3f, 0.1f, 0.06f, 0.03f};
+    try {
+        lvba::VoxelMap surf_map(clouds, xw, 1.0, ratio);
+        const auto info = surf_map.info();
+        std::printf("voxel map on the GPU: %lld points, %lld roots, %lld voxels\n", (long long)info.n_points,
+                    (long long)info.n_roots, (long long)info.n_voxels);
+        if (info.n_points != 40 || info.n_roots != 1 || info.n_voxels != 1 || info.n_factors != 2) return 3;
+        std::vector<std::vector<double>> Xs{{0.2, 0.3, 0.9}, {5.0, 5.0, 5.0}};
+        std::vector<double> nd; std::vector<uint8_t> ok;
+        surf_map.find_planes(Xs, nd, ok);
+        if (!ok[0] || ok[1] || std::fabs(std::fabs(nd[2]) - 1.0) > 1e-3 || std::fabs(std::fabs(nd[3]) - 0.5) > 5e-3) return 4;
+    } catch (const std::exception &e) {
+        std::printf("refused: %s\n", e.what());
+        if (!(lvba_device_count() == 0 && std::strstr(e.what(), "no CPU fallback"))) return 5;
+    }
     try {
         auto trace = lvba::damping_iter_hip(x, vh);
         std::printf("refined on the GPU: %zu LM iterations\n", trace.size());

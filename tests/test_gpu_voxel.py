@@ -132,3 +132,18 @@ def test_argument_errors(pkg):
     empty = pkg.VoxelMap([np.zeros((0, 3), np.float32)], T)
     assert empty.info["n_points"] == 0
     assert not empty.find_planes(np.zeros((2, 3)))[1].any()
+
+
+def test_cpp_adapter_runs_on_the_gpu(tmp_path):
+    """include/lvba_adapter.hpp end to end from C++ (stand-in PCL/Eigen types): VoxelMap build, plane lookup,
+    damping_iter -- the binding INTEGRATION.md shows, executed on the device."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "global-lvba_amd")
+    exe = str(tmp_path / "adapter_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(root, "tests", "adapter_check.cpp"), "-o", exe,
+                           "-L", libdir, "-llvba_hip", f"-Wl,-rpath,{libdir}"])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "voxel map on the GPU" in out.stdout and "refined on the GPU" in out.stdout
