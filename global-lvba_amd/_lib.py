@@ -19,7 +19,7 @@ SYMBOLS = [
     "lvba_visual_default_opts", "lvba_visual_create", "lvba_visual_destroy", "lvba_visual_cost", "lvba_visual_linearize",
     "lvba_visual_refine",
     "lvba_voxel_default_opts", "lvba_voxmap_build", "lvba_voxmap_destroy", "lvba_voxmap_info", "lvba_voxmap_export",
-    "lvba_voxmap_to_balm", "lvba_voxmap_find_planes",
+    "lvba_voxmap_to_balm", "lvba_voxmap_find_planes", "lvba_scans_create", "lvba_scans_destroy", "lvba_voxmap_build_scans",
 ]
 
 OK, ERR_ARG, ERR_DEVICE, ERR_NOMEM, ERR_UNSUPPORTED, ERR_DIST, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
@@ -77,7 +77,8 @@ class VoxelOpts(C.Structure):
 
 class VoxmapInfo(C.Structure):
     _fields_ = [("n_points", C.c_int64), ("n_roots", C.c_int64), ("n_planes", C.c_int64), ("n_voxels", C.c_int64),
-                ("n_factors", C.c_int64)]
+                ("n_factors", C.c_int64), ("upload_ms", C.c_double), ("key_ms", C.c_double), ("sort_ms", C.c_double),
+                ("count_ms", C.c_double), ("write_ms", C.c_double)]
 
 
 TERMINATION = {0: "NO_CONVERGENCE", 1: "CONVERGENCE(function)", 2: "CONVERGENCE(parameter)", 3: "CONVERGENCE(gradient)",
@@ -144,6 +145,9 @@ def load():
     lib.lvba_voxmap_build.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_void_p), i64p, C.c_int32, f64p,
                                       C.POINTER(VoxelOpts), C.POINTER(H)]
     lib.lvba_voxmap_destroy.argtypes = [H]
+    lib.lvba_scans_create.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_void_p), i64p, C.c_int32, C.POINTER(H)]
+    lib.lvba_scans_destroy.argtypes = [H]
+    lib.lvba_voxmap_build_scans.argtypes = [H, C.c_int32, C.c_int32, f64p, C.POINTER(VoxelOpts), C.POINTER(H)]
     lib.lvba_voxmap_info.argtypes = [H, C.POINTER(VoxmapInfo)]
     lib.lvba_voxmap_export.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.lvba_voxmap_to_balm.argtypes = [H, C.POINTER(H)]

@@ -7,19 +7,26 @@
 //   findCorrespondPoint + plane lookup  include/BALM/bavoxel.hpp:320-333, src/lvba_system.cpp:1531-1565
 // by a sort-based formulation (no pointers, no hash map):
 //   1. one lane per point: world transform, root voxel key (with the reference's fp32 quotient / "-1 if negative" /
-//      truncation) and the two octant codes the point WOULD take if its root and child were split (the fp32 centre
-//      arithmetic of cut_func is closed-form given the key, so no tree needs to exist yet);
-//   2. three stable radix sorts (rocPRIM) on (root | frame | octant prefix) make every (node, frame) PointCluster of
-//      every layer a contiguous run IN CLOUD ORDER, so one lane summing its run reproduces PointCluster::push
-//      bit for bit (products of fp32 values are exact in fp64; the order of the sums is the reference's);
-//   3. one wave per root voxel walks the (at most 1 + 8 + 64) nodes: merged world-frame covariance, eigen test,
-//      PLANE / split / drop, admission (>= 2 observing frames) and the CSR emission that lvba_balm_create takes.
+//      truncation) and the two octant codes the point WOULD take if its root and then its child were split (the fp32
+//      centre arithmetic of cut_func is closed-form given the key, so no tree has to exist yet); the point becomes a
+//      16-byte record (x, y, z, frame << 6 | o1 << 3 | o2);
+//   2. ONE stable radix sort (rocPRIM) by root key; records are gathered into that order, so every root's points are
+//      contiguous, frame-major and in cloud order inside a frame;
+//   3. one wave per root voxel streams its records (coalesced 16-byte loads, broadcast lane by lane with v_readlane).
+//      Lane t owns grandchild t = (o1, o2) and carries three PointCluster accumulators -- the root's, child o1's and
+//      grandchild t's -- each advanced in cloud order, so every (node, frame) cluster reproduces PointCluster::push
+//      bit for bit (products of fp32 values are exact in fp64; the order of the sums is the reference's).  At each
+//      frame boundary the clusters are moved to the world frame and merged (judge_eigen's covMat); the root is decided
+//      first and only a root that splits is swept again for its children and grandchildren (min_ps, eigen ratio, layer
+//      limit); ballots give the emission order, and after three scans a last sweep writes the admitted nodes' clusters
+//      as the CSR that lvba_balm_create takes.
 // The octree states stay on the device as two words per root for the landmark -> plane lookup of the visual stage.
 #include <cstring>
 #include <cstdint>
 #include <rocprim/rocprim.hpp>
 #include <vector>
 #include <new>
+#include <chrono>
 #include "lvba_common.h"
 #include "balm_math.h"
 
@@ -70,21 +77,24 @@ __device__ __forceinline__ uint64_t pack_key(const int64_t k[3])
     return ((uint64_t)(k[0] + KEY_BIAS) << 42) | ((uint64_t)(k[1] + KEY_BIAS) << 21) | (uint64_t)(k[2] + KEY_BIAS);
 }
 
-// ---- 1. keys ----------------------------------------------------------------------------------------------------
+// ---- 1. keys + records --------------------------------------------------------------------------------------------
+// frame_off: the window's slice of the scan set's frame offsets; pts already points at the window's first point
 __global__ void vox_key_kernel(int64_t P, const float *__restrict__ pts, const int64_t *__restrict__ frame_off,
                                int n_frames, const double *__restrict__ poses, double vs,
-                               uint64_t *__restrict__ key, uint32_t *__restrict__ sec, uint32_t *__restrict__ idx,
+                               uint64_t *__restrict__ key, float4 *__restrict__ rec, uint32_t *__restrict__ idx,
                                int *__restrict__ err)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
-    int lo = 0, hi = n_frames; // frame f with frame_off[f] <= i < frame_off[f+1]
+    const int64_t base = frame_off[0];
+    int lo = 0, hi = n_frames; // frame f with frame_off[f] <= base + i < frame_off[f+1]
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
-        if (frame_off[mid] <= i) lo = mid; else hi = mid;
+        if (frame_off[mid] - base <= i) lo = mid; else hi = mid;
     }
     const double *T = poses + 12 * (int64_t)lo;
-    const double p0 = pts[3 * i], p1 = pts[3 * i + 1], p2 = pts[3 * i + 2];
+    const float fx = pts[3 * i], fy = pts[3 * i + 1], fz = pts[3 * i + 2];
+    const double p0 = fx, p1 = fy, p2 = fz;
     double pw[3];
     pw[0] = T[0] * p0 + T[1] * p1 + T[2] * p2 + T[9];
     pw[1] = T[3] * p0 + T[4] * p1 + T[5] * p2 + T[10];
@@ -94,10 +104,15 @@ __global__ void vox_key_kernel(int64_t P, const float *__restrict__ pts, const i
     int o1, o2;
     octants_of(pw, k, vs, o1, o2);
     key[i] = pack_key(k);
-    sec[i] = ((uint32_t)lo << 6) | (uint32_t)(o1 << 3) | (uint32_t)o2;
+    rec[i] = make_float4(fx, fy, fz, __int_as_float((int)(((uint32_t)lo << 6) | (uint32_t)(o1 << 3) | (uint32_t)o2)));
     idx[i] = (uint32_t)i;
 }
-
+__global__ void vox_gather_kernel(int64_t n, const float4 *__restrict__ rec, const uint32_t *__restrict__ order,
+                                  float4 *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = rec[order[i]];
+}
 // head[i] = 1 where the sorted key changes
 __global__ void vox_heads_kernel(int64_t n, const uint64_t *__restrict__ key, uint32_t *__restrict__ head)
 {
@@ -105,7 +120,7 @@ __global__ void vox_heads_kernel(int64_t n, const uint64_t *__restrict__ key, ui
     if (i >= n) return;
     head[i] = (i == 0 || key[i] != key[i - 1]) ? 1u : 0u;
 }
-// segment tables from heads + their inclusive scan
+// root table from heads + their inclusive scan
 __global__ void vox_segs_kernel(int64_t n, const uint64_t *__restrict__ key, const uint32_t *__restrict__ head,
                                 const uint32_t *__restrict__ incl, uint64_t *__restrict__ seg_key,
                                 uint32_t *__restrict__ seg_start)
@@ -118,74 +133,24 @@ __global__ void vox_segs_kernel(int64_t n, const uint64_t *__restrict__ key, con
     }
     if (i == n - 1) seg_start[incl[i]] = (uint32_t)n;
 }
-// root id of every ORIGINAL point
-__global__ void vox_rid_kernel(int64_t n, const uint32_t *__restrict__ incl, const uint32_t *__restrict__ idx0,
-                               uint32_t *__restrict__ rid)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) rid[idx0[i]] = incl[i] - 1;
-}
-// composite key (root id | frame | octant prefix of `level`): sorted==1 takes points in root-sorted order
-__global__ void vox_comp_kernel(int64_t n, const uint32_t *__restrict__ rid, const uint32_t *__restrict__ sec,
-                                const uint32_t *__restrict__ order, int shift, uint32_t mask,
-                                uint64_t *__restrict__ comp, uint32_t *__restrict__ idx_out)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t src = order ? order[i] : (uint32_t)i;
-    comp[i] = ((uint64_t)rid[src] << shift) | (uint64_t)(sec[src] & mask);
-    if (idx_out) idx_out[i] = (uint32_t)i;
-}
 
-// ---- 2. PointCluster of every (node, frame) run, summed in cloud order (tools.hpp:428-433) ---------------------------
-__global__ void vox_cluster_kernel(int64_t nseg, const uint32_t *__restrict__ seg_start,
-                                   const uint32_t *__restrict__ order, const float *__restrict__ pts,
-                                   double *__restrict__ cl)
-{
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= nseg) return;
-    double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, v0 = 0, v1 = 0, v2 = 0;
-    const uint32_t b = seg_start[s], e = seg_start[s + 1];
-    for (uint32_t i = b; i < e; ++i) {
-        const float *q = pts + 3 * (int64_t)order[i];
-        const double x = q[0], y = q[1], z = q[2];
-        c0 += x * x; c1 += x * y; c2 += x * z; c3 += y * y; c4 += y * z; c5 += z * z;
-        v0 += x; v1 += y; v2 += z;
-    }
-    double *o = cl + 10 * s;
-    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3; o[4] = c4; o[5] = c5; o[6] = v0; o[7] = v1; o[8] = v2;
-    o[9] = (double)(e - b);
-}
-
-// first segment of every root in a level's table (tables are sorted by root id first)
-__global__ void vox_rootrange_kernel(int64_t R, int64_t nseg, const uint64_t *__restrict__ seg_key, int shift,
-                                     uint32_t *__restrict__ rs)
-{
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r > R) return;
-    int64_t lo = 0, hi = nseg; // first s with (seg_key[s] >> shift) >= r
-    while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if ((int64_t)(seg_key[mid] >> shift) < r) lo = mid + 1; else hi = mid;
-    }
-    rs[r] = (uint32_t)lo;
-}
-
-// ---- 3. per-root octree decisions and emission ---------------------------------------------------------------------
+// ---- 3. per-root octree walk -------------------------------------------------------------------------------------
 struct NodeArgs {
     int64_t R;
-    const uint64_t *seg_key[3];
-    const double *seg_cl[3];
-    const uint32_t *rs[3];
+    const float4 *rec;          // records in root-sorted order
+    const uint32_t *root_start; // [R+1]
     const double *poses;
     float ratio[3];
     int min_ps;
-    uint32_t fmask; // frame field of a segment key: (key >> 6) & fmask
     // count mode outputs
     int32_t *n_plane, *n_vox;
     int64_t *n_fac;
-    uint64_t *mask;
+    uint64_t *mask;     // lanes that hold a PLANE node
     uint32_t *rootinfo; // state0 | split1 << 8
+    unsigned *tmp_count; // PLANE nodes parked so far
+    int32_t *tmp_base;   // [R] first parked slot of the root
+    double *tmp_plane;   // [<= P / min_ps][6]
+    int32_t *tmp_nf;     // [<= P / min_ps] observing frames
     // write mode inputs (exclusive scans of the above) and outputs
     const int32_t *plane_first, *vox_first;
     const int64_t *fac_first;
@@ -196,24 +161,30 @@ struct NodeArgs {
     int32_t *vox_label; // [V][2] root id, layer | o1 << 4 | o2 << 8
 };
 
-// merged world-frame statistics of node (level, code) of root r, frames in ascending order (judge_eigen :337-344)
-__device__ __forceinline__ int node_stats(const NodeArgs &a, int level, uint32_t code, int64_t r, double *S)
-{
-#pragma unroll
-    for (int k = 0; k < 10; ++k) S[k] = 0.0;
-    int nf = 0;
-    const uint64_t *sk = a.seg_key[level];
-    for (uint32_t s = a.rs[level][r], e = a.rs[level][r + 1]; s < e; ++s) {
-        const uint64_t key = sk[s];
-        if ((uint32_t)(key & 63u) != code) continue;
-        const uint32_t f = (uint32_t)(key >> 6) & a.fmask;
-        double T[10];
-        transform_cluster(a.seg_cl[level] + 10 * (int64_t)s, a.poses + 12 * (int64_t)f, a.poses + 12 * (int64_t)f + 9, T);
-#pragma unroll
-        for (int k = 0; k < 10; ++k) S[k] += T[k];
-        ++nf;
+struct Acc { // one PointCluster in the making (tools.hpp:407-433)
+    double c0, c1, c2, c3, c4, c5, v0, v1, v2;
+    int n;
+    __device__ __forceinline__ void clear() { c0 = c1 = c2 = c3 = c4 = c5 = v0 = v1 = v2 = 0.0; n = 0; }
+    __device__ __forceinline__ void push(double x, double y, double z)
+    {
+        c0 += x * x; c1 += x * y; c2 += x * z; c3 += y * y; c4 += y * z; c5 += z * z;
+        v0 += x; v1 += y; v2 += z;
+        ++n;
     }
-    return nf;
+    __device__ __forceinline__ void store(double *o) const
+    {
+        o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3; o[4] = c4; o[5] = c5; o[6] = v0; o[7] = v1; o[8] = v2; o[9] = (double)n;
+    }
+};
+// covMat += tmp.transform(sig_orig[f], x_buf[f])  (judge_eigen :337-344)
+__device__ __forceinline__ void merge_world(const Acc &a, const double *T, double *S, int &nf)
+{
+    double c[10], W[10];
+    a.store(c);
+    transform_cluster(c, T, T + 9, W);
+#pragma unroll
+    for (int k = 0; k < 10; ++k) S[k] += W[k];
+    ++nf;
 }
 // recut's decision for one node (:396-427); also returns the plane (centre, direct) of judge_eigen
 __device__ __forceinline__ int node_decide(const double *S, int nf, int min_ps, float ratio, bool last_layer,
@@ -224,94 +195,169 @@ __device__ __forceinline__ int node_decide(const double *S, int nf, int min_ps, 
     double C[6], vb[3], lam[3], U[9];
     voxel_cov(S, C, vb);
     eig3<true>(C, lam, U);
-    if (plane) {
-        plane[0] = vb[0]; plane[1] = vb[1]; plane[2] = vb[2];
-        plane[3] = U[0]; plane[4] = U[3]; plane[5] = U[6];
-    }
+    plane[0] = vb[0]; plane[1] = vb[1]; plane[2] = vb[2];
+    plane[3] = U[0]; plane[4] = U[3]; plane[5] = U[6];
     if (lam[0] / lam[2] > (double)ratio) return last_layer ? ST_DROP : ST_SPLIT;
     return ST_PLANE;
 }
+__device__ __forceinline__ float lane_bcast(float v, int j)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
+}
 
-template <bool WRITE>
-__global__ __launch_bounds__(64) void vox_node_kernel(NodeArgs a)
+// Sweep over one root's records; calls on_point(frame, code, j) per point with uniform frame/code and, at every frame
+// boundary, on_frame(frame).  q holds the staged 64 records, j the staged lane to broadcast from.
+#define LVBA_VOX_SWEEP(ON_FRAME, ON_POINT)                                                              \
+    {                                                                                                   \
+        int cur_f = -1;                                                                                 \
+        for (uint32_t base = b; base < e; base += 64) {                                                 \
+            const int cnt = (int)min(64u, e - base);                                                    \
+            const float4 q = t < cnt ? a.rec[base + t] : make_float4(0.f, 0.f, 0.f, 0.f);               \
+            for (int j = 0; j < cnt; ++j) {                                                             \
+                const int sec = __builtin_amdgcn_readlane(__float_as_int(q.w), j);                      \
+                const int f = sec >> 6, c = sec & 63;                                                   \
+                if (f != cur_f) {                                                                       \
+                    if (cur_f >= 0) { ON_FRAME }                                                        \
+                    cur_f = f;                                                                          \
+                }                                                                                       \
+                const double x = lane_bcast(q.x, j), y = lane_bcast(q.y, j), z = lane_bcast(q.z, j);    \
+                (void)c;                                                                                \
+                ON_POINT                                                                                \
+            }                                                                                           \
+        }                                                                                               \
+        if (cur_f >= 0) { ON_FRAME }                                                                    \
+    }
+
+// Decisions for one root (recut :391-464): the root first; only if it splits, its children and grandchildren.
+__global__ __launch_bounds__(64) void vox_decide_kernel(NodeArgs a)
 {
     const int64_t r = blockIdx.x;
     const int t = threadIdx.x, o1 = t >> 3, o2 = t & 7;
-    __shared__ int s_state0, s_state1[8], s_nf[64];
-    double S[10], plane[6];
-    if (t == 0) {
-        const int nf = node_stats(a, 0, 0u, r, S);
-        s_state0 = node_decide(S, nf, a.min_ps, a.ratio[0], false, nullptr);
+    const uint32_t b = a.root_start[r], e = a.root_start[r + 1];
+    __shared__ int s_nf[64];
+    __shared__ int s_base;
+    double pl[6];
+    int level = -1, nf = 0, st0, st1 = ST_NONE;
+    {
+        double S0[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) S0[k] = 0.0;
+        int nf0 = 0;
+        Acc A0;
+        A0.clear();
+        LVBA_VOX_SWEEP({ merge_world(A0, a.poses + 12 * (int64_t)cur_f, S0, nf0); A0.clear(); }, { A0.push(x, y, z); })
+        st0 = node_decide(S0, nf0, a.min_ps, a.ratio[0], false, pl);
+        if (st0 == ST_PLANE && t == 0) { level = 0; nf = nf0; }
     }
-    __syncthreads();
-    const int st0 = s_state0;
-    if (t < 8) {
-        int st1 = ST_NONE;
-        if (st0 == ST_SPLIT) {
-            const int nf = node_stats(a, 1, (uint32_t)(t << 3), r, S);
-            st1 = node_decide(S, nf, a.min_ps, a.ratio[1], false, nullptr);
+    if (st0 == ST_SPLIT) { // uniform
+        double S1[10], S2[10], pl1[6];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) S1[k] = S2[k] = 0.0;
+        int nf1 = 0, nf2 = 0;
+        Acc A1, A2;
+        A1.clear(); A2.clear();
+        LVBA_VOX_SWEEP(
+            {
+                const double *T = a.poses + 12 * (int64_t)cur_f;
+                if (A1.n > 0) merge_world(A1, T, S1, nf1);
+                if (A2.n > 0) merge_world(A2, T, S2, nf2);
+                A1.clear(); A2.clear();
+            },
+            {
+                if ((c >> 3) == o1) A1.push(x, y, z);
+                if (c == t) A2.push(x, y, z);
+            })
+        st1 = node_decide(S1, nf1, a.min_ps, a.ratio[1], false, pl1);
+        if (st1 == ST_PLANE) {
+            if (o2 == 0) {
+                level = 1; nf = nf1;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) pl[k] = pl1[k];
+            }
+        } else if (st1 == ST_SPLIT) {
+            if (node_decide(S2, nf2, a.min_ps, a.ratio[2], true, pl) == ST_PLANE) { level = 2; nf = nf2; }
         }
-        s_state1[t] = st1;
     }
-    __syncthreads();
-    const int st1 = s_state1[o1];
-    // the node this lane emits (lanes in path order: root -> lane 0, child o1 -> lane 8*o1, grandchild -> its own lane)
-    int level = -1;
-    uint32_t code = 0;
-    if (st0 == ST_PLANE) { if (t == 0) level = 0; }
-    else if (st0 == ST_SPLIT) {
-        if (st1 == ST_PLANE) { if (o2 == 0) { level = 1; code = (uint32_t)(o1 << 3); } }
-        else if (st1 == ST_SPLIT) { level = 2; code = (uint32_t)t; }
-    }
-    int nf = 0, st = ST_NONE;
-    if (level >= 0) {
-        nf = node_stats(a, level, code, r, S);
-        st = node_decide(S, nf, a.min_ps, a.ratio[level], level == 2, plane);
-    }
-    const bool is_plane = st == ST_PLANE;
+    // lanes in path order: root -> lane 0, child o1 -> lane 8*o1, grandchild -> its own lane
+    const bool is_plane = level >= 0;
     const bool admitted = is_plane && nf >= 2;
     const uint64_t pmask = __ballot(is_plane);
     const uint64_t amask = __ballot(admitted);
+    const uint64_t smask = __ballot(st1 == ST_SPLIT && o2 == 0); // bit 8*o1
     const uint64_t lt = t == 0 ? 0ull : (~0ull >> (64 - t));
     s_nf[t] = admitted ? nf : 0;
+    if (t == 0) s_base = pmask ? (int)atomicAdd(a.tmp_count, (unsigned)__popcll(pmask)) : 0;
     __syncthreads();
-    if (!WRITE) {
-        if (t == 0) {
-            int64_t fsum = 0;
-            for (int k = 0; k < 64; ++k) fsum += s_nf[k];
-            uint32_t split1 = 0;
-            for (int k = 0; k < 8; ++k) split1 |= (s_state1[k] == ST_SPLIT ? 1u : 0u) << k;
-            a.n_plane[r] = __popcll(pmask);
-            a.n_vox[r] = __popcll(amask);
-            a.n_fac[r] = fsum;
-            a.mask[r] = pmask;
-            a.rootinfo[r] = (uint32_t)st0 | (split1 << 8);
-        }
-        return;
+    if (is_plane) { // parked until the scans have fixed the final order
+        const int64_t slot = (int64_t)s_base + __popcll(pmask & lt);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) a.tmp_plane[6 * slot + k] = pl[k];
+        a.tmp_nf[slot] = nf;
     }
+    if (t == 0) {
+        int64_t fsum = 0;
+        for (int k = 0; k < 64; ++k) fsum += s_nf[k];
+        uint32_t split1 = 0;
+        for (int k = 0; k < 8; ++k) split1 |= (uint32_t)((smask >> (8 * k)) & 1ull) << k;
+        a.n_plane[r] = __popcll(pmask);
+        a.n_vox[r] = __popcll(amask);
+        a.n_fac[r] = fsum;
+        a.mask[r] = pmask;
+        a.rootinfo[r] = (uint32_t)st0 | (split1 << 8);
+        a.tmp_base[r] = s_base;
+    }
+}
+
+// Emission for one root (tras_opt :466-474 -> push_voxel :45-54): planes into their final slots, and one more sweep
+// that writes the admitted nodes' per-frame clusters in frame order.
+__global__ __launch_bounds__(64) void vox_emit_kernel(NodeArgs a)
+{
+    const int64_t r = blockIdx.x;
+    const uint64_t pmask = a.mask[r];
+    if (pmask == 0ull) return;
+    const int t = threadIdx.x, o1 = t >> 3, o2 = t & 7;
+    const uint32_t b = a.root_start[r], e = a.root_start[r + 1];
+    __shared__ int s_nf[64];
+    const uint32_t info = a.rootinfo[r];
+    const uint64_t lt = t == 0 ? 0ull : (~0ull >> (64 - t));
+    const bool is_plane = (pmask >> t) & 1ull;
+    const int level = (info & 0xff) == ST_PLANE ? 0 : (((info >> (8 + o1)) & 1u) ? 2 : 1);
+    int nf = 0;
     if (is_plane) {
+        const int64_t slot = (int64_t)a.tmp_base[r] + __popcll(pmask & lt);
+        nf = a.tmp_nf[slot];
         double *o = a.plane + 6 * ((int64_t)a.plane_first[r] + __popcll(pmask & lt));
 #pragma unroll
-        for (int k = 0; k < 6; ++k) o[k] = plane[k];
+        for (int k = 0; k < 6; ++k) o[k] = a.tmp_plane[6 * slot + k];
     }
+    const bool admitted = is_plane && nf >= 2;
+    const uint64_t amask = __ballot(admitted);
+    if (amask == 0ull) return;
+    s_nf[t] = admitted ? nf : 0;
+    __syncthreads();
+    int64_t foff = a.fac_first[r];
+    for (int k = 0; k < t; ++k) foff += s_nf[k];
     if (admitted) {
-        int64_t foff = a.fac_first[r];
-        for (int k = 0; k < t; ++k) foff += s_nf[k];
         const int64_t v = (int64_t)a.vox_first[r] + __popcll(amask & lt);
         a.vox_off[v] = foff;
         a.vox_label[2 * v] = (int32_t)r;
         a.vox_label[2 * v + 1] = level | ((level >= 1 ? o1 : 0) << 4) | ((level == 2 ? o2 : 0) << 8);
-        const uint64_t *sk = a.seg_key[level];
-        for (uint32_t s = a.rs[level][r], e = a.rs[level][r + 1]; s < e; ++s) {
-            const uint64_t key = sk[s];
-            if ((uint32_t)(key & 63u) != code) continue;
-            a.pose_idx[foff] = (int32_t)((uint32_t)(key >> 6) & a.fmask);
-            const double *c = a.seg_cl[level] + 10 * (int64_t)s;
-#pragma unroll
-            for (int k = 0; k < 10; ++k) a.clusters[10 * foff + k] = c[k];
-            ++foff;
-        }
     }
+    Acc A;
+    A.clear();
+    LVBA_VOX_SWEEP(
+        {
+            if (A.n > 0) {
+                a.pose_idx[foff] = cur_f;
+                A.store(a.clusters + 10 * foff);
+                ++foff;
+                A.clear();
+            }
+        },
+        {
+            const bool mine = admitted && (level == 0 || (level == 1 ? (c >> 3) == o1 : c == t));
+            if (mine) A.push(x, y, z);
+        })
 }
 
 // ---- landmark -> plane lookup (src/lvba_system.cpp:1531-1565) ------------------------------------------------------
@@ -355,10 +401,21 @@ __global__ void vox_lookup_kernel(int64_t n, const double *__restrict__ X, doubl
     valid[i] = 1;
 }
 
+inline double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 inline unsigned grid_for(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
-inline int bits_for(uint64_t n) { int b = 1; while ((n >> b) != 0) ++b; return b; } // bits to hold values < n (n >= 1)
 
 } // namespace
+
+struct lvba_scans_s {
+    int device = 0;
+    int n_frames = 0;
+    std::vector<int64_t> frame_off; // [n_frames+1]
+    float *d_pts = nullptr;         // [P][3]
+    int64_t *d_frame_off = nullptr;
+};
 
 struct lvba_voxmap_s {
     int device = 0;
@@ -387,6 +444,65 @@ extern "C" void lvba_voxel_default_opts(lvba_voxel_opts *o)
     o->layer_limit = 2;                                    // bavoxel.hpp:13
 }
 
+extern "C" int32_t lvba_scans_destroy(lvba_scans_t sc)
+{
+    if (!sc) return LVBA_OK;
+    (void)hipSetDevice(sc->device);
+    if (sc->d_pts) (void)hipFree(sc->d_pts);
+    if (sc->d_frame_off) (void)hipFree(sc->d_frame_off);
+    delete sc;
+    return LVBA_OK;
+}
+
+extern "C" int32_t lvba_scans_create(int32_t device, int32_t n_frames, const void *const *frame_points,
+                                     const int64_t *frame_count, int32_t point_stride_bytes, lvba_scans_t *out)
+{
+    if (!out) return lvba_fail(LVBA_ERR_ARG, "out is null");
+    *out = nullptr;
+    if (n_frames < 1 || !frame_points || !frame_count) return lvba_fail(LVBA_ERR_ARG, "n_frames < 1 or a null argument");
+    if (point_stride_bytes < 12 || point_stride_bytes % 4)
+        return lvba_fail(LVBA_ERR_ARG, "point_stride_bytes must be a multiple of 4 and >= 12 (got %d)", point_stride_bytes);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return lvba_fail(LVBA_ERR_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return lvba_fail(LVBA_ERR_ARG, "device %d out of range [0,%d)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    lvba_scans_s *sc = new (std::nothrow) lvba_scans_s();
+    if (!sc) return lvba_fail(LVBA_ERR_NOMEM, "host allocation failed");
+    sc->device = device;
+    sc->n_frames = n_frames;
+    sc->frame_off.assign(n_frames + 1, 0);
+    for (int f = 0; f < n_frames; ++f) {
+        if (frame_count[f] < 0 || (frame_count[f] > 0 && !frame_points[f])) {
+            delete sc;
+            return lvba_fail(LVBA_ERR_ARG, "frame %d: bad point count / null cloud", f);
+        }
+        sc->frame_off[f + 1] = sc->frame_off[f] + frame_count[f];
+    }
+    const int64_t P = sc->frame_off[n_frames];
+    auto fail = [&](hipError_t e, const char *what) {
+        lvba_scans_destroy(sc);
+        return lvba_fail(e == hipErrorOutOfMemory ? LVBA_ERR_NOMEM : LVBA_ERR_DEVICE, "%s: %s", what, hipGetErrorString(e));
+    };
+    hipError_t e;
+    if ((e = hipMalloc((void **)&sc->d_pts, P ? 12 * (size_t)P : 8)) != hipSuccess) return fail(e, "hipMalloc(points)");
+    if ((e = hipMalloc((void **)&sc->d_frame_off, 8 * ((size_t)n_frames + 1))) != hipSuccess) return fail(e, "hipMalloc(frame_off)");
+    // xyz packed out of the caller's point stride (e.g. sizeof(pcl::PointXYZINormal) = 48)
+    for (int f = 0; f < n_frames; ++f)
+        if (frame_count[f] > 0) {
+            float *dst = sc->d_pts + 3 * sc->frame_off[f];
+            e = point_stride_bytes == 12
+                    ? hipMemcpy(dst, frame_points[f], 12 * (size_t)frame_count[f], hipMemcpyHostToDevice)
+                    : hipMemcpy2D(dst, 12, frame_points[f], (size_t)point_stride_bytes, 12, (size_t)frame_count[f],
+                                  hipMemcpyHostToDevice);
+            if (e != hipSuccess) return fail(e, "hipMemcpy(points)");
+        }
+    if ((e = hipMemcpy(sc->d_frame_off, sc->frame_off.data(), 8 * ((size_t)n_frames + 1), hipMemcpyHostToDevice)) != hipSuccess)
+        return fail(e, "hipMemcpy(frame_off)");
+    *out = sc;
+    return LVBA_OK;
+}
+
 extern "C" int32_t lvba_voxmap_destroy(lvba_voxmap_t h)
 {
     if (!h) return LVBA_OK;
@@ -401,8 +517,8 @@ extern "C" int32_t lvba_voxmap_destroy(lvba_voxmap_t h)
 
 namespace {
 
-template <class K>
-int32_t sort_pairs(hipStream_t s, const K *kin, K *kout, const uint32_t *vin, uint32_t *vout, size_t n, unsigned end_bit)
+int32_t sort_pairs(hipStream_t s, const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout, size_t n,
+                   unsigned end_bit)
 {
     size_t bytes = 0;
     HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, 0u, end_bit, s));
@@ -435,117 +551,61 @@ int32_t scan_excl(hipStream_t s, const T *in, T *out, size_t n)
     return LVBA_OK;
 }
 
-// heads -> scan -> segment table of a sorted key array; returns the number of segments
-int32_t segment(hipStream_t s, int64_t n, const uint64_t *key_sorted, DevBuf &incl, DevBuf &seg_key, DevBuf &seg_start,
-                int64_t *nseg)
-{
-    DevBuf head;
-    HIPCHK(head.alloc(4 * n));
-    HIPCHK(incl.alloc(4 * n));
-    vox_heads_kernel<<<grid_for(n, 256), 256, 0, s>>>(n, key_sorted, head.as<uint32_t>());
-    TRY(scan_incl<uint32_t>(s, head.as<uint32_t>(), incl.as<uint32_t>(), (size_t)n));
-    uint32_t last = 0;
-    HIPCHK(hipMemcpy(&last, incl.as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost));
-    *nseg = last;
-    HIPCHK(seg_key.alloc(8 * (size_t)last));
-    HIPCHK(seg_start.alloc(4 * ((size_t)last + 1)));
-    vox_segs_kernel<<<grid_for(n, 256), 256, 0, s>>>(n, key_sorted, head.as<uint32_t>(), incl.as<uint32_t>(),
-                                                     seg_key.as<uint64_t>(), seg_start.as<uint32_t>());
-    HIPCHK(hipGetLastError());
-    return LVBA_OK;
-}
-
-int32_t voxmap_build_impl(lvba_voxmap_s *h, const void *const *frame_points, const int64_t *frame_count,
-                          int32_t stride_bytes, const double *poses)
+int32_t voxmap_build_impl(lvba_voxmap_s *h, const lvba_scans_s *sc, int frame_begin, const double *poses)
 {
     const int nfr = h->n_frames;
     hipStream_t s = h->stream;
-    std::vector<int64_t> foff(nfr + 1, 0);
-    for (int f = 0; f < nfr; ++f) {
-        if (frame_count[f] < 0 || (frame_count[f] > 0 && !frame_points[f]))
-            return lvba_fail(LVBA_ERR_ARG, "frame %d: bad point count / null cloud", f);
-        foff[f + 1] = foff[f] + frame_count[f];
-    }
-    const int64_t P = foff[nfr];
+    const int64_t p_begin = sc->frame_off[frame_begin];
+    const int64_t P = sc->frame_off[frame_begin + nfr] - p_begin;
     if (P >= (int64_t)1 << 31) return lvba_fail(LVBA_ERR_UNSUPPORTED, "more than 2^31 points in one map (%lld)", (long long)P);
+    if (nfr >= (1 << 25)) return lvba_fail(LVBA_ERR_UNSUPPORTED, "more than 2^25 frames in one map");
     h->info.n_points = P;
     if (P == 0) return LVBA_OK;
+    const float *pts = sc->d_pts + 3 * p_begin;
+    double t0 = now_ms();
 
-    // -- upload (xyz packed out of the caller's point stride, e.g. sizeof(pcl::PointXYZINormal))
-    DevBuf pts, d_foff, d_poses;
-    HIPCHK(pts.alloc(12 * (size_t)P));
-    HIPCHK(d_foff.alloc(8 * (nfr + 1)));
+    DevBuf d_poses;
     HIPCHK(d_poses.alloc(96 * (size_t)nfr));
-    for (int f = 0; f < nfr; ++f)
-        if (frame_count[f] > 0)
-            HIPCHK(hipMemcpy2DAsync(pts.as<float>() + 3 * foff[f], 12, frame_points[f], (size_t)stride_bytes, 12,
-                                    (size_t)frame_count[f], hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(d_foff.p, foff.data(), 8 * (nfr + 1), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_poses.p, poses, 96 * (size_t)nfr, hipMemcpyHostToDevice, s));
 
-    // -- 1. keys, root sort (stable: cloud order inside a root == (frame, index) order)
-    DevBuf key, sec, idx, key_s, idx0, d_err;
-    HIPCHK(key.alloc(8 * P)); HIPCHK(sec.alloc(4 * P)); HIPCHK(idx.alloc(4 * P));
-    HIPCHK(key_s.alloc(8 * P)); HIPCHK(idx0.alloc(4 * P)); HIPCHK(d_err.alloc(4));
+    // -- 1. keys + records, root sort (stable: inside a root the records stay frame-major, cloud order inside a frame)
+    DevBuf key, rec, idx, key_s, idx0, rec_s, d_err;
+    HIPCHK(key.alloc(8 * P)); HIPCHK(rec.alloc(16 * P)); HIPCHK(idx.alloc(4 * P));
+    HIPCHK(key_s.alloc(8 * P)); HIPCHK(idx0.alloc(4 * P)); HIPCHK(rec_s.alloc(16 * P)); HIPCHK(d_err.alloc(4));
     HIPCHK(hipMemsetAsync(d_err.p, 0, 4, s));
-    vox_key_kernel<<<grid_for(P, 256), 256, 0, s>>>(P, pts.as<float>(), d_foff.as<int64_t>(), nfr, d_poses.as<double>(),
-                                                    h->opts.voxel_size, key.as<uint64_t>(), sec.as<uint32_t>(),
+    vox_key_kernel<<<grid_for(P, 256), 256, 0, s>>>(P, pts, sc->d_frame_off + frame_begin, nfr, d_poses.as<double>(),
+                                                    h->opts.voxel_size, key.as<uint64_t>(), rec.as<float4>(),
                                                     idx.as<uint32_t>(), d_err.as<int>());
     HIPCHK(hipGetLastError());
     int err = 0;
     HIPCHK(hipMemcpyAsync(&err, d_err.p, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (err) return lvba_fail(LVBA_ERR_ARG, "a point is non-finite or its voxel key exceeds +-2^20 after the pose transform");
-    TRY(sort_pairs<uint64_t>(s, key.as<uint64_t>(), key_s.as<uint64_t>(), idx.as<uint32_t>(), idx0.as<uint32_t>(), (size_t)P, 63));
+    h->info.key_ms = now_ms() - t0; t0 = now_ms();
+    TRY(sort_pairs(s, key.as<uint64_t>(), key_s.as<uint64_t>(), idx.as<uint32_t>(), idx0.as<uint32_t>(), (size_t)P, 63));
+    vox_gather_kernel<<<grid_for(P, 256), 256, 0, s>>>(P, rec.as<float4>(), idx0.as<uint32_t>(), rec_s.as<float4>());
+    HIPCHK(hipGetLastError());
 
     int64_t R = 0;
-    DevBuf incl0, root_key, root_start, rid;
-    TRY(segment(s, P, key_s.as<uint64_t>(), incl0, root_key, root_start, &R));
-    HIPCHK(rid.alloc(4 * P));
-    vox_rid_kernel<<<grid_for(P, 256), 256, 0, s>>>(P, incl0.as<uint32_t>(), idx0.as<uint32_t>(), rid.as<uint32_t>());
-    HIPCHK(hipGetLastError());
-    h->info.n_roots = R;
-
-    // -- 2. per-level (node, frame) cluster tables
-    const int fbits = bits_for((uint64_t)nfr), rbits = bits_for((uint64_t)R);
-    const int shift = fbits + 6;
-    if (fbits > 26 || shift + rbits > 64) return lvba_fail(LVBA_ERR_UNSUPPORTED, "frames x roots exceed the 64-bit sort key");
-    DevBuf seg_key[3], seg_start[3], seg_cl[3], rs[3];
-    int64_t nseg[3] = {0, 0, 0};
+    DevBuf root_key, root_start;
     {
-        DevBuf comp, comp_s, idxL, iota;
-        HIPCHK(comp.alloc(8 * P)); HIPCHK(comp_s.alloc(8 * P)); HIPCHK(idxL.alloc(4 * P)); HIPCHK(iota.alloc(4 * P));
-        for (int L = 0; L < 3; ++L) {
-            const uint32_t mask = L == 0 ? ~63u : (L == 1 ? ~7u : ~0u);
-            const uint64_t *sorted_keys;
-            const uint32_t *order;
-            if (L == 0) { // the root sort already is the (root, frame, index) order
-                vox_comp_kernel<<<grid_for(P, 256), 256, 0, s>>>(P, rid.as<uint32_t>(), sec.as<uint32_t>(), idx0.as<uint32_t>(),
-                                                                 shift, mask, comp_s.as<uint64_t>(), nullptr);
-                sorted_keys = comp_s.as<uint64_t>();
-                order = idx0.as<uint32_t>();
-            } else {
-                vox_comp_kernel<<<grid_for(P, 256), 256, 0, s>>>(P, rid.as<uint32_t>(), sec.as<uint32_t>(), nullptr, shift, mask,
-                                                                 comp.as<uint64_t>(), iota.as<uint32_t>());
-                TRY(sort_pairs<uint64_t>(s, comp.as<uint64_t>(), comp_s.as<uint64_t>(), iota.as<uint32_t>(), idxL.as<uint32_t>(),
-                                         (size_t)P, (unsigned)(shift + rbits)));
-                sorted_keys = comp_s.as<uint64_t>();
-                order = idxL.as<uint32_t>();
-            }
-            HIPCHK(hipGetLastError());
-            DevBuf incl;
-            TRY(segment(s, P, sorted_keys, incl, seg_key[L], seg_start[L], &nseg[L]));
-            HIPCHK(seg_cl[L].alloc(80 * (size_t)nseg[L]));
-            vox_cluster_kernel<<<grid_for(nseg[L], 64), 64, 0, s>>>(nseg[L], seg_start[L].as<uint32_t>(), order, pts.as<float>(),
-                                                                    seg_cl[L].as<double>());
-            HIPCHK(rs[L].alloc(4 * ((size_t)R + 1)));
-            vox_rootrange_kernel<<<grid_for(R + 1, 256), 256, 0, s>>>(R, nseg[L], seg_key[L].as<uint64_t>(), shift, rs[L].as<uint32_t>());
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipStreamSynchronize(s));
-        }
+        DevBuf head, incl;
+        HIPCHK(head.alloc(4 * P)); HIPCHK(incl.alloc(4 * P));
+        vox_heads_kernel<<<grid_for(P, 256), 256, 0, s>>>(P, key_s.as<uint64_t>(), head.as<uint32_t>());
+        TRY(scan_incl<uint32_t>(s, head.as<uint32_t>(), incl.as<uint32_t>(), (size_t)P));
+        uint32_t last = 0;
+        HIPCHK(hipMemcpy(&last, incl.as<uint32_t>() + (P - 1), 4, hipMemcpyDeviceToHost));
+        R = last;
+        HIPCHK(root_key.alloc(8 * (size_t)R)); HIPCHK(root_start.alloc(4 * ((size_t)R + 1)));
+        vox_segs_kernel<<<grid_for(P, 256), 256, 0, s>>>(P, key_s.as<uint64_t>(), head.as<uint32_t>(), incl.as<uint32_t>(),
+                                                         root_key.as<uint64_t>(), root_start.as<uint32_t>());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s));
     }
+    h->info.n_roots = R;
+    h->info.sort_ms = now_ms() - t0; t0 = now_ms();
 
-    // -- 3. octree decisions: count, scan, write
+    // -- 3. octree walk: count, scan, write
     DevBuf n_plane, n_vox, n_fac, mask, rootinfo, plane_first, vox_first, fac_first;
     HIPCHK(n_plane.alloc(4 * (R + 1))); HIPCHK(n_vox.alloc(4 * (R + 1))); HIPCHK(n_fac.alloc(8 * (R + 1)));
     HIPCHK(mask.alloc(8 * R)); HIPCHK(rootinfo.alloc(4 * R));
@@ -555,18 +615,20 @@ int32_t voxmap_build_impl(lvba_voxmap_s *h, const void *const *frame_points, con
     HIPCHK(hipMemsetAsync(n_fac.p, 0, 8 * (R + 1), s));
     NodeArgs a{};
     a.R = R;
-    for (int L = 0; L < 3; ++L) {
-        a.seg_key[L] = seg_key[L].as<uint64_t>();
-        a.seg_cl[L] = seg_cl[L].as<double>();
-        a.rs[L] = rs[L].as<uint32_t>();
-        a.ratio[L] = h->opts.eigen_ratio[L];
-    }
+    a.rec = rec_s.as<float4>();
+    a.root_start = root_start.as<uint32_t>();
     a.poses = d_poses.as<double>();
+    for (int L = 0; L < 3; ++L) a.ratio[L] = h->opts.eigen_ratio[L];
     a.min_ps = h->opts.min_points;
-    a.fmask = (1u << fbits) - 1u;
     a.n_plane = n_plane.as<int32_t>(); a.n_vox = n_vox.as<int32_t>(); a.n_fac = n_fac.as<int64_t>();
     a.mask = mask.as<uint64_t>(); a.rootinfo = rootinfo.as<uint32_t>();
-    vox_node_kernel<false><<<(unsigned)R, 64, 0, s>>>(a);
+    const size_t tmp_cap = (size_t)(P / h->opts.min_points) + 1; // a PLANE node holds >= min_points points, nodes of
+    DevBuf tmp_count, tmp_base, tmp_plane, tmp_nf;              // one root are disjoint or nested under a non-PLANE one
+    HIPCHK(tmp_count.alloc(4)); HIPCHK(tmp_base.alloc(4 * R)); HIPCHK(tmp_plane.alloc(48 * tmp_cap)); HIPCHK(tmp_nf.alloc(4 * tmp_cap));
+    HIPCHK(hipMemsetAsync(tmp_count.p, 0, 4, s));
+    a.tmp_count = tmp_count.as<unsigned>(); a.tmp_base = tmp_base.as<int32_t>();
+    a.tmp_plane = tmp_plane.as<double>(); a.tmp_nf = tmp_nf.as<int32_t>();
+    vox_decide_kernel<<<(unsigned)R, 64, 0, s>>>(a);
     HIPCHK(hipGetLastError());
     TRY(scan_excl<int32_t>(s, n_plane.as<int32_t>(), plane_first.as<int32_t>(), (size_t)R + 1));
     TRY(scan_excl<int32_t>(s, n_vox.as<int32_t>(), vox_first.as<int32_t>(), (size_t)R + 1));
@@ -577,6 +639,7 @@ int32_t voxmap_build_impl(lvba_voxmap_s *h, const void *const *frame_points, con
     HIPCHK(hipMemcpy(&V, vox_first.as<int32_t>() + R, 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(&F, fac_first.as<int64_t>() + R, 8, hipMemcpyDeviceToHost));
     h->info.n_planes = n_planes; h->info.n_voxels = V; h->info.n_factors = F;
+    h->info.count_ms = now_ms() - t0; t0 = now_ms();
 
     DevBuf plane, vox_off, pose_idx, clusters, vox_label;
     HIPCHK(plane.alloc(48 * (size_t)n_planes)); HIPCHK(vox_off.alloc(8 * ((size_t)V + 1)));
@@ -584,10 +647,11 @@ int32_t voxmap_build_impl(lvba_voxmap_s *h, const void *const *frame_points, con
     a.plane_first = plane_first.as<int32_t>(); a.vox_first = vox_first.as<int32_t>(); a.fac_first = fac_first.as<int64_t>();
     a.plane = plane.as<double>(); a.vox_off = vox_off.as<int64_t>(); a.pose_idx = pose_idx.as<int32_t>();
     a.clusters = clusters.as<double>(); a.vox_label = vox_label.as<int32_t>();
-    vox_node_kernel<true><<<(unsigned)R, 64, 0, s>>>(a);
+    vox_emit_kernel<<<(unsigned)R, 64, 0, s>>>(a);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(vox_off.as<int64_t>() + V, &F, 8, hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));
+    h->info.write_ms = now_ms() - t0;
 
     h->d_root_key = (uint64_t *)root_key.release();
     h->d_mask = (uint64_t *)mask.release();
@@ -603,39 +667,51 @@ int32_t voxmap_build_impl(lvba_voxmap_s *h, const void *const *frame_points, con
 
 } // namespace
 
-extern "C" int32_t lvba_voxmap_build(int32_t device, int32_t n_frames, const void *const *frame_points,
-                                     const int64_t *frame_count, int32_t point_stride_bytes, const double *poses,
-                                     const lvba_voxel_opts *opts, lvba_voxmap_t *out)
+extern "C" int32_t lvba_voxmap_build_scans(lvba_scans_t sc, int32_t frame_begin, int32_t n_frames, const double *poses,
+                                           const lvba_voxel_opts *opts, lvba_voxmap_t *out)
 {
     if (!out) return lvba_fail(LVBA_ERR_ARG, "out is null");
     *out = nullptr;
-    if (n_frames < 1 || !frame_points || !frame_count || !poses)
-        return lvba_fail(LVBA_ERR_ARG, "n_frames < 1 or a null argument");
-    if (point_stride_bytes < 12 || point_stride_bytes % 4)
-        return lvba_fail(LVBA_ERR_ARG, "point_stride_bytes must be a multiple of 4 and >= 12 (got %d)", point_stride_bytes);
+    if (!sc || !poses) return lvba_fail(LVBA_ERR_ARG, "null argument");
+    if (frame_begin < 0 || n_frames < 1 || frame_begin + n_frames > sc->n_frames)
+        return lvba_fail(LVBA_ERR_ARG, "frame range [%d, %d) outside the %d uploaded frames", frame_begin,
+                         frame_begin + n_frames, sc->n_frames);
     lvba_voxel_opts o;
     lvba_voxel_default_opts(&o);
     if (opts) o = *opts;
     if (!(o.voxel_size > 0.0) || o.min_points < 1) return lvba_fail(LVBA_ERR_ARG, "voxel_size must be > 0 and min_points >= 1");
     if (o.layer_limit != 2) return lvba_fail(LVBA_ERR_UNSUPPORTED, "layer_limit is fixed at 2 (bavoxel.hpp:13), got %d", o.layer_limit);
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
-        return lvba_fail(LVBA_ERR_DEVICE, "no HIP device available (this library has no CPU fallback)");
-    if (device < 0 || device >= ndev) return lvba_fail(LVBA_ERR_ARG, "device %d out of range [0,%d)", device, ndev);
-    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipSetDevice(sc->device));
     lvba_voxmap_s *h = new (std::nothrow) lvba_voxmap_s();
     if (!h) return lvba_fail(LVBA_ERR_NOMEM, "host allocation failed");
-    h->device = device;
+    h->device = sc->device;
     h->n_frames = n_frames;
     h->opts = o;
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
         return lvba_fail(LVBA_ERR_DEVICE, "hipStreamCreate failed");
     }
-    const int32_t rc = voxmap_build_impl(h, frame_points, frame_count, point_stride_bytes, poses);
+    const int32_t rc = voxmap_build_impl(h, sc, frame_begin, poses);
     if (rc != LVBA_OK) { lvba_voxmap_destroy(h); return rc; }
     *out = h;
     return LVBA_OK;
+}
+
+extern "C" int32_t lvba_voxmap_build(int32_t device, int32_t n_frames, const void *const *frame_points,
+                                     const int64_t *frame_count, int32_t point_stride_bytes, const double *poses,
+                                     const lvba_voxel_opts *opts, lvba_voxmap_t *out)
+{
+    if (!out) return lvba_fail(LVBA_ERR_ARG, "out is null");
+    *out = nullptr;
+    if (!poses) return lvba_fail(LVBA_ERR_ARG, "poses is null");
+    const double t0 = now_ms();
+    lvba_scans_t sc = nullptr;
+    TRY(lvba_scans_create(device, n_frames, frame_points, frame_count, point_stride_bytes, &sc));
+    const double up = now_ms() - t0;
+    const int32_t rc = lvba_voxmap_build_scans(sc, 0, n_frames, poses, opts, out);
+    lvba_scans_destroy(sc);
+    if (rc == LVBA_OK) (*out)->info.upload_ms = up;
+    return rc;
 }
 
 extern "C" int32_t lvba_voxmap_info(lvba_voxmap_t h, lvba_voxmap_info_t *info)

@@ -2,10 +2,11 @@
 
     surf_map = VoxelMap(clouds, x_buf, voxel_size, eigen_ratio_array)   # cut_voxel per frame + recut per root
     voxhess  = surf_map.tras_opt()                                      # -> the VOX_HESS damping_iter takes
-    n, d, ok = surf_map.find_planes(X)                                  # recompute_local_planes
+    plane, ok = surf_map.find_planes(X)                                 # recompute_local_planes
 
 mirrors include/BALM/bavoxel.hpp:799-836 (cut_voxel), :391-464 (recut), :466-474 (tras_opt) and
-src/lvba_system.cpp:1531-1565.  Everything runs in liblvba_hip.so on the GPU; this file packs arrays.
+src/lvba_system.cpp:1531-1565.  `Scans` keeps the clouds on the device between maps (window BA, stage 1, stage 2 and the
+visual stage all re-cut the same clouds).  Everything runs in liblvba_hip.so on the GPU; this file packs arrays.
 """
 from __future__ import annotations
 
@@ -23,15 +24,27 @@ def default_opts():
     return o
 
 
-class VoxelMap:
-    """Adaptive-voxel plane map of a window of scans, resident on a GPU."""
+def _opts(voxel_size, eigen_ratio_array, min_points):
+    o = default_opts()
+    o.voxel_size = float(voxel_size)
+    if eigen_ratio_array is not None:
+        er = np.asarray(eigen_ratio_array, np.float32)
+        for i in range(min(4, len(er))):
+            o.eigen_ratio[i] = float(er[i])
+    if min_points is not None:
+        o.min_points = int(min_points)
+    return o
 
-    def __init__(self, clouds, poses, voxel_size=1.0, eigen_ratio_array=None, min_points=None, device=0):
-        """clouds: sequence of [n_i, >=3] float32 arrays (x, y, z first; row stride = the array's, so PCL-style
-        padded points can be passed as they are); poses [N, 12]."""
+
+class Scans:
+    """A set of LiDAR clouds resident on a GPU (fp32 x, y, z per point)."""
+
+    def __init__(self, clouds, device=0):
+        """clouds: sequence of [n_i, >=3] float32 arrays (x, y, z first; row stride = the array's, so PCL-style padded
+        points can be passed as they are)."""
         self.lib = L.load()
-        self._keep = []
         n = len(clouds)
+        keep = []
         ptrs = (C.c_void_p * max(n, 1))()
         counts = np.zeros(max(n, 1), np.int64)
         stride = None
@@ -47,26 +60,75 @@ class VoxelMap:
                 stride = 4 * c.shape[1]
             elif stride != 4 * c.shape[1]:
                 raise ValueError("all clouds must share one point stride")
-            self._keep.append(c)
+            keep.append(c)
             ptrs[f] = c.ctypes.data if c.shape[0] else None
             counts[f] = c.shape[0]
-        poses = np.ascontiguousarray(poses, np.float64).reshape(-1)
-        if poses.size != 12 * n:
-            raise ValueError(f"poses must hold {n} x 12 doubles")
-        o = default_opts()
-        o.voxel_size = float(voxel_size)
-        if eigen_ratio_array is not None:
-            er = np.asarray(eigen_ratio_array, np.float32)
-            for i in range(min(4, len(er))):
-                o.eigen_ratio[i] = float(er[i])
-        if min_points is not None:
-            o.min_points = int(min_points)
         self.n_frames = n
+        self.counts = counts[:n].copy()
+        self._h = C.c_void_p()
+        L.check(self.lib.lvba_scans_create(int(device), n, ptrs, counts, int(stride or 12), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.lib.lvba_scans_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def voxel_map(self, poses, voxel_size=1.0, eigen_ratio_array=None, min_points=None, frame_begin=0, n_frames=None):
+        """Map of frames [frame_begin, frame_begin + n_frames) at `poses` [n_frames, 12]."""
+        n = self.n_frames - frame_begin if n_frames is None else int(n_frames)
+        return VoxelMap(None, poses, voxel_size, eigen_ratio_array, min_points, _scans=(self, int(frame_begin), n))
+
+
+class VoxelMap:
+    """Adaptive-voxel plane map of a window of scans, resident on a GPU."""
+
+    def __init__(self, clouds, poses, voxel_size=1.0, eigen_ratio_array=None, min_points=None, device=0, _scans=None):
+        self.lib = L.load()
+        o = _opts(voxel_size, eigen_ratio_array, min_points)
         self.voxel_size = float(voxel_size)
         self._h = C.c_void_p()
-        L.check(self.lib.lvba_voxmap_build(int(device), n, ptrs, counts, int(stride or 12), poses, C.byref(o),
-                                           C.byref(self._h)))
-        self._keep = []
+        if _scans is not None:
+            sc, begin, n = _scans
+            poses = np.ascontiguousarray(poses, np.float64).reshape(-1)
+            if poses.size != 12 * n:
+                raise ValueError(f"poses must hold {n} x 12 doubles")
+            L.check(self.lib.lvba_voxmap_build_scans(sc._h, begin, n, poses, C.byref(o), C.byref(self._h)))
+        else:
+            n = len(clouds)
+            poses = np.ascontiguousarray(poses, np.float64).reshape(-1)
+            if poses.size != 12 * n:
+                raise ValueError(f"poses must hold {n} x 12 doubles")
+            keep, ptrs, counts, stride = [], (C.c_void_p * max(n, 1))(), np.zeros(max(n, 1), np.int64), None
+            for f, c in enumerate(clouds):
+                c = np.asarray(c)
+                if c.dtype != np.float32:
+                    c = c.astype(np.float32)
+                if c.ndim != 2 or c.shape[1] < 3:
+                    raise ValueError("each cloud must be [n, >=3] float32")
+                if not c.flags["C_CONTIGUOUS"]:
+                    c = np.ascontiguousarray(c)
+                if stride is None:
+                    stride = 4 * c.shape[1]
+                elif stride != 4 * c.shape[1]:
+                    raise ValueError("all clouds must share one point stride")
+                keep.append(c)
+                ptrs[f] = c.ctypes.data if c.shape[0] else None
+                counts[f] = c.shape[0]
+            L.check(self.lib.lvba_voxmap_build(int(device), n, ptrs, counts, int(stride or 12), poses, C.byref(o),
+                                               C.byref(self._h)))
+        self.n_frames = n
         info = L.VoxmapInfo()
         L.check(self.lib.lvba_voxmap_info(self._h, C.byref(info)))
         self.info = {f: getattr(info, f) for f, _ in info._fields_}

@@ -257,6 +257,9 @@ typedef struct {
 typedef struct {
     int64_t n_points, n_roots, n_planes; /* points hashed; root voxels; PLANE nodes (admitted or not) */
     int64_t n_voxels, n_factors;         /* admitted voxels (>= 2 observing frames) and their cluster slots */
+    /* host wall clock of the build phases, ms (each ends on a stream synchronise): host->device copy of the clouds
+     * (lvba_voxmap_build only), key kernel, root sort + gather + root table, octree walk (count), octree walk (write) */
+    double upload_ms, key_ms, sort_ms, count_ms, write_ms;
 } lvba_voxmap_info_t;
 void lvba_voxel_default_opts(lvba_voxel_opts *opts);
 
@@ -267,6 +270,19 @@ int32_t lvba_voxmap_build(int32_t device, int32_t n_frames, const void *const *f
                           const int64_t *frame_count, int32_t point_stride_bytes, const double *poses,
                           const lvba_voxel_opts *opts, lvba_voxmap_t *out);
 int32_t lvba_voxmap_destroy(lvba_voxmap_t h);
+
+/* The same, in two steps, for callers that voxelise the same clouds more than once (the reference re-cuts the anchor
+ * clouds for stage 1, stage 2 and the visual stage, src/lvba_system.cpp:365-377,1498-1506, and the raw scans window by
+ * window, :232-258): lvba_scans_create copies the clouds to the device once; lvba_voxmap_build_scans builds the map of
+ * frames [frame_begin, frame_begin + n_frames) at poses [n_frames][12] (pose / frame indices in the outputs are
+ * relative to frame_begin, as cut_voxel's fnum is relative to the window). */
+typedef struct lvba_scans_s *lvba_scans_t;
+int32_t lvba_scans_create(int32_t device, int32_t n_frames, const void *const *frame_points,
+                          const int64_t *frame_count, int32_t point_stride_bytes, lvba_scans_t *out);
+int32_t lvba_scans_destroy(lvba_scans_t scans);
+int32_t lvba_voxmap_build_scans(lvba_scans_t scans, int32_t frame_begin, int32_t n_frames, const double *poses,
+                                const lvba_voxel_opts *opts, lvba_voxmap_t *out);
+
 int32_t lvba_voxmap_info(lvba_voxmap_t h, lvba_voxmap_info_t *info);
 /* Host copies of the admitted voxels in lvba_balm_create's layout (any pointer may be NULL): voxel_off [V+1],
  * pose_idx [F], clusters [F][10], voxel_key [V][4] = root key x, y, z and layer | o1 << 4 | o2 << 8. */

@@ -95,6 +95,28 @@ def test_find_planes_matches_oracle(pkg, synth, case):
     assert 200 < n_hit < len(X) - 200
 
 
+def test_resident_scans_and_frame_windows(pkg, synth):
+    """lvba_scans_create + lvba_voxmap_build_scans: clouds uploaded once, maps cut per window (the reference's
+    runWindowBA loop, src/lvba_system.cpp:232-258) -- each must equal the oracle run on that window alone."""
+    from oracle import voxel_oracle as vo
+    s = synth.make_scans(9, 6000, room=(8, 6, 3), origin=(2.5, -1.5, 0.2), n_panels=6, seed=21, point_floats=5)
+    with pkg.Scans(s["clouds"]) as scans:
+        for begin, n in ((0, 9), (0, 4), (4, 5), (8, 1)):
+            poses = s["poses"][begin:begin + n]
+            surf_map, vox = vo.build([c[:, :3] for c in s["clouds"][begin:begin + n]], poses, 1.0)
+            off_ref, idx_ref, cl_ref = vo.pack(vox)
+            with scans.voxel_map(poses, 1.0, frame_begin=begin, n_frames=n) as m:
+                assert m.info["n_points"] == sum(len(c) for c in s["clouds"][begin:begin + n])
+                assert m.info["n_roots"] == len(surf_map) and m.info["n_voxels"] == len(vox)
+                off, idx, cl, key = m.export()
+                np.testing.assert_array_equal(off, off_ref)
+                np.testing.assert_array_equal(idx, idx_ref)          # frame indices relative to the window
+                np.testing.assert_array_equal(cl, cl_ref)
+        L = __import__("importlib").import_module("global-lvba_amd._lib")
+        with pytest.raises(L.LvbaError):
+            scans.voxel_map(s["poses"][:3], 1.0, frame_begin=7, n_frames=3)
+
+
 def test_map_feeds_the_lm_refinement(pkg, synth):
     """scans -> lvba_voxmap_to_balm -> damping_iter: the cost seen through the map equals the cost of the oracle's
     packed voxels, and refinement from odometry-grade poses reduces it."""
