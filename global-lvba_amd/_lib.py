@@ -20,6 +20,7 @@ SYMBOLS = [
     "lvba_visual_refine",
     "lvba_voxel_default_opts", "lvba_voxmap_build", "lvba_voxmap_destroy", "lvba_voxmap_info", "lvba_voxmap_export",
     "lvba_voxmap_to_balm", "lvba_voxmap_find_planes", "lvba_scans_create", "lvba_scans_destroy", "lvba_voxmap_build_scans",
+    "lvba_release_cached_memory",
 ]
 
 OK, ERR_ARG, ERR_DEVICE, ERR_NOMEM, ERR_UNSUPPORTED, ERR_DIST, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
@@ -152,6 +153,7 @@ def load():
     lib.lvba_voxmap_export.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.lvba_voxmap_to_balm.argtypes = [H, C.POINTER(H)]
     lib.lvba_voxmap_find_planes.argtypes = [H, C.c_int64, f64p, f64p, u8p]
+    lib.lvba_release_cached_memory.restype = C.c_int64
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int:  # default

@@ -11,24 +11,27 @@
 //      centre arithmetic of cut_func is closed-form given the key, so no tree has to exist yet); the point becomes a
 //      16-byte record (x, y, z, frame << 6 | o1 << 3 | o2);
 //   2. ONE stable radix sort (rocPRIM) by root key; records are gathered into that order, so every root's points are
-//      contiguous, frame-major and in cloud order inside a frame;
-//   3. one wave per root voxel streams its records (coalesced 16-byte loads, broadcast lane by lane with v_readlane).
-//      Lane t owns grandchild t = (o1, o2) and carries three PointCluster accumulators -- the root's, child o1's and
-//      grandchild t's -- each advanced in cloud order, so every (node, frame) cluster reproduces PointCluster::push
-//      bit for bit (products of fp32 values are exact in fp64; the order of the sums is the reference's).  At each
-//      frame boundary the clusters are moved to the world frame and merged (judge_eigen's covMat); the root is decided
-//      first and only a root that splits is swept again for its children and grandchildren (min_ps, eigen ratio, layer
-//      limit); ballots give the emission order, and after three scans a last sweep writes the admitted nodes' clusters
-//      as the CSR that lvba_balm_create takes.
+//      contiguous, frame-major and in cloud order inside a frame; heads + scans give the root table and the table of
+//      (root, frame) segments;
+//   3. root layer: one lane per segment sums its records (PointCluster::push in cloud order -- products of fp32 values
+//      are exact in fp64 and the order of the sums is the reference's, so the cluster is bit-identical); one lane per
+//      root merges its segments in the world frame (judge_eigen's covMat) and decides PLANE / split / drop;
+//   4. only for roots that split: one wave per segment, lane t = grandchild t = (o1, o2): every lane sees every record
+//      (coalesced 16-byte loads, v_readlane broadcast) and advances its child's and grandchild's cluster in cloud
+//      order; one wave per split root then merges and decides the 8 + 64 nodes (min_ps, eigen ratio, layer limit);
+//   5. ballots / scans fix the emission order (root key, then octant path); the admitted nodes' clusters are copied
+//      out as the CSR that lvba_balm_create takes.
 // The octree states stay on the device as two words per root for the landmark -> plane lookup of the visual stage.
 #include <cstring>
 #include <cstdint>
+#include <cstdlib>
 #include <rocprim/rocprim.hpp>
 #include <vector>
 #include <new>
 #include <chrono>
 #include "lvba_common.h"
 #include "balm_math.h"
+#include "mempool.h"
 
 using namespace lvba;
 
@@ -36,14 +39,6 @@ namespace {
 
 constexpr int KEY_BIAS = 1 << 20; // root key components must lie in [-2^20, 2^20)
 enum : int { ST_NONE = 0, ST_DROP = 1, ST_PLANE = 2, ST_SPLIT = 3 };
-
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
-    template <class T> T *as() const { return (T *)p; }
-    void *release() { void *q = p; p = nullptr; return q; }
-};
 
 // ---- shared per-point arithmetic (cut_voxel :809-815, root centre :826-829, cut_func :368-381) ------------------
 __device__ __forceinline__ bool root_key_of(const double pw[3], double vs, int64_t k[3])
@@ -113,54 +108,44 @@ __global__ void vox_gather_kernel(int64_t n, const float4 *__restrict__ rec, con
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = rec[order[i]];
 }
-// head[i] = 1 where the sorted key changes
-__global__ void vox_heads_kernel(int64_t n, const uint64_t *__restrict__ key, uint32_t *__restrict__ head)
+// head flags of the sorted records: bit 0 = first record of a root, bit 1 = first record of a (root, frame) segment
+__global__ void vox_heads_kernel(int64_t n, const uint64_t *__restrict__ key, const float4 *__restrict__ rec,
+                                 uint32_t *__restrict__ head_root, uint32_t *__restrict__ head_seg)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    head[i] = (i == 0 || key[i] != key[i - 1]) ? 1u : 0u;
+    const bool hr = i == 0 || key[i] != key[i - 1];
+    const bool hs = hr || (__float_as_int(rec[i].w) >> 6) != (__float_as_int(rec[i - 1].w) >> 6);
+    head_root[i] = hr ? 1u : 0u;
+    head_seg[i] = hs ? 1u : 0u;
 }
-// root table from heads + their inclusive scan
-__global__ void vox_segs_kernel(int64_t n, const uint64_t *__restrict__ key, const uint32_t *__restrict__ head,
-                                const uint32_t *__restrict__ incl, uint64_t *__restrict__ seg_key,
-                                uint32_t *__restrict__ seg_start)
+// root table and (root, frame) segment table from the heads and their inclusive scans
+__global__ void vox_tables_kernel(int64_t n, const uint64_t *__restrict__ key, const float4 *__restrict__ rec,
+                                  const uint32_t *__restrict__ head_root, const uint32_t *__restrict__ incl_root,
+                                  const uint32_t *__restrict__ head_seg, const uint32_t *__restrict__ incl_seg,
+                                  uint64_t *__restrict__ root_key, uint32_t *__restrict__ root_seg,
+                                  uint32_t *__restrict__ seg_start, uint32_t *__restrict__ seg_root,
+                                  int32_t *__restrict__ seg_frame)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (head[i]) {
-        seg_key[incl[i] - 1] = key[i];
-        seg_start[incl[i] - 1] = (uint32_t)i;
+    if (head_seg[i]) {
+        const uint32_t sg = incl_seg[i] - 1;
+        seg_start[sg] = (uint32_t)i;
+        seg_root[sg] = incl_root[i] - 1;
+        seg_frame[sg] = __float_as_int(rec[i].w) >> 6;
+        if (head_root[i]) {
+            root_key[incl_root[i] - 1] = key[i];
+            root_seg[incl_root[i] - 1] = sg;
+        }
     }
-    if (i == n - 1) seg_start[incl[i]] = (uint32_t)n;
+    if (i == n - 1) {
+        seg_start[incl_seg[i]] = (uint32_t)n;
+        root_seg[incl_root[i]] = incl_seg[i];
+    }
 }
 
-// ---- 3. per-root octree walk -------------------------------------------------------------------------------------
-struct NodeArgs {
-    int64_t R;
-    const float4 *rec;          // records in root-sorted order
-    const uint32_t *root_start; // [R+1]
-    const double *poses;
-    float ratio[3];
-    int min_ps;
-    // count mode outputs
-    int32_t *n_plane, *n_vox;
-    int64_t *n_fac;
-    uint64_t *mask;     // lanes that hold a PLANE node
-    uint32_t *rootinfo; // state0 | split1 << 8
-    unsigned *tmp_count; // PLANE nodes parked so far
-    int32_t *tmp_base;   // [R] first parked slot of the root
-    double *tmp_plane;   // [<= P / min_ps][6]
-    int32_t *tmp_nf;     // [<= P / min_ps] observing frames
-    // write mode inputs (exclusive scans of the above) and outputs
-    const int32_t *plane_first, *vox_first;
-    const int64_t *fac_first;
-    double *plane;      // [n_planes][6] centre, direct
-    int64_t *vox_off;   // [V+1]
-    int32_t *pose_idx;  // [F]
-    double *clusters;   // [F][10]
-    int32_t *vox_label; // [V][2] root id, layer | o1 << 4 | o2 << 8
-};
-
+// ---- 3. octree -------------------------------------------------------------------------------------------------
 struct Acc { // one PointCluster in the making (tools.hpp:407-433)
     double c0, c1, c2, c3, c4, c5, v0, v1, v2;
     int n;
@@ -177,14 +162,12 @@ struct Acc { // one PointCluster in the making (tools.hpp:407-433)
     }
 };
 // covMat += tmp.transform(sig_orig[f], x_buf[f])  (judge_eigen :337-344)
-__device__ __forceinline__ void merge_world(const Acc &a, const double *T, double *S, int &nf)
+__device__ __forceinline__ void merge_world(const double *c, const double *T, double *S)
 {
-    double c[10], W[10];
-    a.store(c);
+    double W[10];
     transform_cluster(c, T, T + 9, W);
 #pragma unroll
     for (int k = 0; k < 10; ++k) S[k] += W[k];
-    ++nf;
 }
 // recut's decision for one node (:396-427); also returns the plane (centre, direct) of judge_eigen
 __device__ __forceinline__ int node_decide(const double *S, int nf, int min_ps, float ratio, bool last_layer,
@@ -205,159 +188,346 @@ __device__ __forceinline__ float lane_bcast(float v, int j)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
 }
 
-// Sweep over one root's records; calls on_point(frame, code, j) per point with uniform frame/code and, at every frame
-// boundary, on_frame(frame).  q holds the staged 64 records, j the staged lane to broadcast from.
-#define LVBA_VOX_SWEEP(ON_FRAME, ON_POINT)                                                              \
-    {                                                                                                   \
-        int cur_f = -1;                                                                                 \
-        for (uint32_t base = b; base < e; base += 64) {                                                 \
-            const int cnt = (int)min(64u, e - base);                                                    \
-            const float4 q = t < cnt ? a.rec[base + t] : make_float4(0.f, 0.f, 0.f, 0.f);               \
-            for (int j = 0; j < cnt; ++j) {                                                             \
-                const int sec = __builtin_amdgcn_readlane(__float_as_int(q.w), j);                      \
-                const int f = sec >> 6, c = sec & 63;                                                   \
-                if (f != cur_f) {                                                                       \
-                    if (cur_f >= 0) { ON_FRAME }                                                        \
-                    cur_f = f;                                                                          \
-                }                                                                                       \
-                const double x = lane_bcast(q.x, j), y = lane_bcast(q.y, j), z = lane_bcast(q.z, j);    \
-                (void)c;                                                                                \
-                ON_POINT                                                                                \
-            }                                                                                           \
-        }                                                                                               \
-        if (cur_f >= 0) { ON_FRAME }                                                                    \
-    }
-
-// Decisions for one root (recut :391-464): the root first; only if it splits, its children and grandchildren.
-__global__ __launch_bounds__(64) void vox_decide_kernel(NodeArgs a)
+// 3a. root-level PointCluster of every (root, frame) segment, records in cloud order.  The sum is a serial chain by
+// definition (that is what makes it bit-identical to PointCluster::push), so the work is arranged to keep the chain as
+// short as the hardware allows:
+//   segments below SEG_BIG records: one lane per segment (a wave's loop is bounded by SEG_BIG iterations);
+//   larger segments: one wave per segment -- the 64 lanes form the nine terms (xx, xy, xz, yy, yz, zz, x, y, z) of 64
+//   records in parallel and park them in LDS, then lanes 0..8 each run ONE of the nine chains over the 64 parked
+//   values (an LDS read and one dependent v_add_f64 per record instead of ~25 instructions).
+// Both also note which children / grandchildren the segment touches (m1: 8 bits by o1, m2: 64 bits by code) for the
+// roots that will split.
+constexpr uint32_t SEG_BIG = 48;
+__global__ void vox_seg_small_kernel(int64_t NS, const uint32_t *__restrict__ seg_start, const float4 *__restrict__ rec,
+                                     double *__restrict__ segcl, uint32_t *__restrict__ segm1, uint64_t *__restrict__ segm2)
 {
-    const int64_t r = blockIdx.x;
-    const int t = threadIdx.x, o1 = t >> 3, o2 = t & 7;
-    const uint32_t b = a.root_start[r], e = a.root_start[r + 1];
-    __shared__ int s_nf[64];
-    __shared__ int s_base;
-    double pl[6];
-    int level = -1, nf = 0, st0, st1 = ST_NONE;
-    {
-        double S0[10];
-#pragma unroll
-        for (int k = 0; k < 10; ++k) S0[k] = 0.0;
-        int nf0 = 0;
-        Acc A0;
-        A0.clear();
-        LVBA_VOX_SWEEP({ merge_world(A0, a.poses + 12 * (int64_t)cur_f, S0, nf0); A0.clear(); }, { A0.push(x, y, z); })
-        st0 = node_decide(S0, nf0, a.min_ps, a.ratio[0], false, pl);
-        if (st0 == ST_PLANE && t == 0) { level = 0; nf = nf0; }
+    const int64_t sg = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (sg >= NS) return;
+    const uint32_t b = seg_start[sg], e = seg_start[sg + 1];
+    if (e - b >= SEG_BIG) return;
+    Acc A;
+    A.clear();
+    uint32_t a1 = 0;
+    uint64_t a2 = 0;
+    for (uint32_t i = b; i < e; ++i) {
+        const float4 q = rec[i];
+        A.push((double)q.x, (double)q.y, (double)q.z);
+        const int c = __float_as_int(q.w) & 63;
+        a1 |= 1u << (c >> 3);
+        a2 |= 1ull << c;
     }
-    if (st0 == ST_SPLIT) { // uniform
-        double S1[10], S2[10], pl1[6];
+    A.store(segcl + 10 * sg);
+    segm1[sg] = a1;
+    segm2[sg] = a2;
+}
+__global__ __launch_bounds__(64) void vox_seg_big_kernel(const uint32_t *__restrict__ seg_start, const float4 *__restrict__ rec,
+                                                         double *__restrict__ segcl, uint32_t *__restrict__ segm1,
+                                                         uint64_t *__restrict__ segm2)
+{
+    const int64_t sg = blockIdx.x;
+    const uint32_t b = seg_start[sg], e = seg_start[sg + 1];
+    if (e - b < SEG_BIG) return;
+    __shared__ double terms[64 * 9];
+    __shared__ unsigned long long s_m2;
+    __shared__ unsigned s_m1;
+    const int t = threadIdx.x;
+    if (t == 0) { s_m1 = 0u; s_m2 = 0ull; }
+    double acc = 0.0;
+    uint32_t a1 = 0;
+    uint64_t a2 = 0;
+    for (uint32_t base = b; base < e; base += 64) {
+        const int cnt = (int)min(64u, e - base);
+        if (t < cnt) {
+            const float4 q = rec[base + t];
+            const double x = q.x, y = q.y, z = q.z;
+            double *o = terms + 9 * t;
+            o[0] = x * x; o[1] = x * y; o[2] = x * z; o[3] = y * y; o[4] = y * z; o[5] = z * z; o[6] = x; o[7] = y; o[8] = z;
+            const int c = __float_as_int(q.w) & 63;
+            a1 |= 1u << (c >> 3);
+            a2 |= 1ull << c;
+        }
+        __syncthreads();
+        if (t < 9)
+            for (int j = 0; j < cnt; ++j) acc += terms[9 * j + t];
+        __syncthreads();
+    }
+    if (a1) atomicOr(&s_m1, a1);
+    if (a2) atomicOr(&s_m2, (unsigned long long)a2);
+    __syncthreads();
+    if (t < 9) segcl[10 * sg + t] = acc;
+    if (t == 9) {
+        segcl[10 * sg + 9] = (double)(e - b);
+        segm1[sg] = s_m1;
+        segm2[sg] = s_m2;
+    }
+}
+
+struct RootArgs {
+    int64_t R;
+    const uint32_t *root_seg; // [R+1]
+    const int32_t *seg_frame;
+    const double *segcl;
+    const double *poses;
+    float ratio[3];
+    int min_ps;
+    // per-root results shared by all later stages
+    int32_t *n_plane, *n_vox;
+    int64_t *n_fac;
+    uint64_t *mask;      // lanes that hold a PLANE node
+    uint32_t *rootinfo;  // state0 | split1 << 8
+    double *plane0;      // [R][6] plane of the root node
+    uint32_t *is_split;  // [R+1] 1 if the root splits (scanned into the split list)
+    uint32_t *seg_split; // [NS+1] 1 for every segment of a splitting root
+};
+// 3b. root decision (recut at layer 0): one lane per root, its segments merged in frame order.
+__global__ void vox_root_kernel(RootArgs a)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.R) return;
+    const uint32_t s0 = a.root_seg[r], s1 = a.root_seg[r + 1];
+    double S[10];
 #pragma unroll
-        for (int k = 0; k < 10; ++k) S1[k] = S2[k] = 0.0;
-        int nf1 = 0, nf2 = 0;
-        Acc A1, A2;
-        A1.clear(); A2.clear();
-        LVBA_VOX_SWEEP(
-            {
-                const double *T = a.poses + 12 * (int64_t)cur_f;
-                if (A1.n > 0) merge_world(A1, T, S1, nf1);
-                if (A2.n > 0) merge_world(A2, T, S2, nf2);
-                A1.clear(); A2.clear();
-            },
-            {
-                if ((c >> 3) == o1) A1.push(x, y, z);
-                if (c == t) A2.push(x, y, z);
-            })
-        st1 = node_decide(S1, nf1, a.min_ps, a.ratio[1], false, pl1);
-        if (st1 == ST_PLANE) {
-            if (o2 == 0) {
-                level = 1; nf = nf1;
+    for (int k = 0; k < 10; ++k) S[k] = 0.0;
+    for (uint32_t sg = s0; sg < s1; ++sg) merge_world(a.segcl + 10 * (int64_t)sg, a.poses + 12 * (int64_t)a.seg_frame[sg], S);
+    double pl[6] = {0, 0, 0, 0, 0, 0};
+    const int nf = (int)(s1 - s0);
+    const int st = node_decide(S, nf, a.min_ps, a.ratio[0], false, pl);
+    const bool plane = st == ST_PLANE, adm = plane && nf >= 2, split = st == ST_SPLIT;
+    a.n_plane[r] = plane ? 1 : 0;
+    a.n_vox[r] = adm ? 1 : 0;
+    a.n_fac[r] = adm ? nf : 0;
+    a.mask[r] = plane ? 1ull : 0ull;
+    a.rootinfo[r] = (uint32_t)st;
 #pragma unroll
-                for (int k = 0; k < 6; ++k) pl[k] = pl1[k];
-            }
-        } else if (st1 == ST_SPLIT) {
-            if (node_decide(S2, nf2, a.min_ps, a.ratio[2], true, pl) == ST_PLANE) { level = 2; nf = nf2; }
+    for (int k = 0; k < 6; ++k) a.plane0[6 * r + k] = pl[k];
+    a.is_split[r] = split ? 1u : 0u;
+    for (uint32_t sg = s0; sg < s1; ++sg) a.seg_split[sg] = split ? 1u : 0u;
+}
+
+// compaction of the split roots / their segments (flag + exclusive scan -> list)
+__global__ void vox_compact_kernel(int64_t n, const uint32_t *__restrict__ flag, const uint32_t *__restrict__ excl,
+                                   uint32_t *__restrict__ list)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flag[i]) list[excl[i]] = (uint32_t)i;
+}
+
+// 3c. masks and node counts of the split segments, in split-list order
+__global__ void vox_split_masks_kernel(int64_t NSS, const uint32_t *__restrict__ split_segs,
+                                       const uint32_t *__restrict__ segm1, const uint64_t *__restrict__ segm2,
+                                       uint32_t *__restrict__ m1, uint64_t *__restrict__ m2, uint32_t *__restrict__ cnt)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= NSS) { if (k == NSS) cnt[k] = 0; return; }
+    const uint32_t sg = split_segs[k];
+    const uint32_t a1 = segm1[sg];
+    const uint64_t a2 = segm2[sg];
+    m1[k] = a1;
+    m2[k] = a2;
+    cnt[k] = (uint32_t)(__popc(a1) + __popcll(a2));
+}
+
+// 3d. child and grandchild PointClusters of a split segment: one wave per segment, lane t = grandchild t = (o1, o2);
+// every lane sees every record (v_readlane broadcast) and advances its two accumulators in cloud order.
+// Stored at nodecl[base ..]: the children present (ascending o1), then the grandchildren present (ascending code).
+__global__ __launch_bounds__(64) void vox_split_cluster_kernel(const uint32_t *__restrict__ split_segs,
+                                                               const uint32_t *__restrict__ seg_start,
+                                                               const float4 *__restrict__ rec,
+                                                               const uint32_t *__restrict__ m1v,
+                                                               const uint64_t *__restrict__ m2v,
+                                                               const uint32_t *__restrict__ basev,
+                                                               double *__restrict__ nodecl)
+{
+    const int64_t k = blockIdx.x;
+    const int t = threadIdx.x, o1 = t >> 3, o2 = t & 7;
+    const uint32_t sg = split_segs[k];
+    const uint32_t b = seg_start[sg], e = seg_start[sg + 1];
+    Acc A1, A2;
+    A1.clear(); A2.clear();
+    for (uint32_t base = b; base < e; base += 64) {
+        const int cnt = (int)min(64u, e - base);
+        const float4 q = t < cnt ? rec[base + t] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < cnt; ++j) {
+            const int c = __builtin_amdgcn_readlane(__float_as_int(q.w), j) & 63;
+            const double x = lane_bcast(q.x, j), y = lane_bcast(q.y, j), z = lane_bcast(q.z, j);
+            if ((c >> 3) == o1) A1.push(x, y, z);
+            if (c == t) A2.push(x, y, z);
         }
     }
-    // lanes in path order: root -> lane 0, child o1 -> lane 8*o1, grandchild -> its own lane
+    const uint32_t m1 = m1v[k];
+    const uint64_t m2 = m2v[k];
+    const int64_t base = basev[k];
+    if (o2 == 0 && ((m1 >> o1) & 1u)) A1.store(nodecl + 10 * (base + __popc(m1 & ((1u << o1) - 1u))));
+    if ((m2 >> t) & 1ull) A2.store(nodecl + 10 * (base + __popc(m1) + __popcll(t ? (m2 & (~0ull >> (64 - t))) : 0ull)));
+}
+
+struct SplitArgs {
+    const uint32_t *split_roots; // [NRS]
+    const uint32_t *root_seg;    // [R+1]
+    const uint32_t *seg_excl;    // [NS+1] exclusive scan of seg_split: position of a segment in the split list
+    const int32_t *seg_frame;
+    const uint32_t *m1;
+    const uint64_t *m2;
+    const uint32_t *base;
+    const double *nodecl;
+    const double *poses;
+    float ratio[3];
+    int min_ps;
+    int32_t *n_plane, *n_vox;
+    int64_t *n_fac;
+    uint64_t *mask;
+    uint32_t *rootinfo;
+    unsigned *tmp_count; // PLANE nodes of split roots parked so far
+    int32_t *tmp_base;   // [NRS] first parked slot of the split root
+    double *tmp_plane;   // [][6]
+    int32_t *tmp_nf;     // [] observing frames
+    // emission (after the scans)
+    const int32_t *plane_first, *vox_first;
+    const int64_t *fac_first;
+    double *plane;
+    int64_t *vox_off;
+    int32_t *pose_idx;
+    double *clusters;
+    int32_t *vox_label;
+};
+// 3e. children / grandchildren of a split root (recut at layers 1 and 2): one wave per split root, lane t = grandchild t.
+__global__ __launch_bounds__(64) void vox_split_decide_kernel(SplitArgs a)
+{
+    const int64_t k = blockIdx.x;
+    const int64_t r = a.split_roots[k];
+    const int t = threadIdx.x, o1 = t >> 3, o2 = t & 7;
+    const uint64_t lt = t == 0 ? 0ull : (~0ull >> (64 - t));
+    __shared__ int s_nf[64];
+    __shared__ int s_base;
+    double S1[10], S2[10], pl[6], pl1[6];
+#pragma unroll
+    for (int q = 0; q < 10; ++q) S1[q] = S2[q] = 0.0;
+    int nf1 = 0, nf2 = 0;
+    for (uint32_t sg = a.root_seg[r], s1 = a.root_seg[r + 1]; sg < s1; ++sg) {
+        const uint32_t j = a.seg_excl[sg];
+        const uint32_t m1 = a.m1[j];
+        const uint64_t m2 = a.m2[j];
+        const int64_t base = a.base[j];
+        const double *T = a.poses + 12 * (int64_t)a.seg_frame[sg];
+        if ((m1 >> o1) & 1u) { merge_world(a.nodecl + 10 * (base + __popc(m1 & ((1u << o1) - 1u))), T, S1); ++nf1; }
+        if ((m2 >> t) & 1ull) { merge_world(a.nodecl + 10 * (base + __popc(m1) + __popcll(m2 & lt)), T, S2); ++nf2; }
+    }
+    int level = -1, nf = 0;
+    const int st1 = node_decide(S1, nf1, a.min_ps, a.ratio[1], false, pl1);
+    if (st1 == ST_PLANE) {
+        if (o2 == 0) {
+            level = 1; nf = nf1;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) pl[q] = pl1[q];
+        }
+    } else if (st1 == ST_SPLIT) {
+        if (node_decide(S2, nf2, a.min_ps, a.ratio[2], true, pl) == ST_PLANE) { level = 2; nf = nf2; }
+    }
+    // lanes in path order: child o1 -> lane 8*o1, grandchild -> its own lane
     const bool is_plane = level >= 0;
     const bool admitted = is_plane && nf >= 2;
     const uint64_t pmask = __ballot(is_plane);
     const uint64_t amask = __ballot(admitted);
     const uint64_t smask = __ballot(st1 == ST_SPLIT && o2 == 0); // bit 8*o1
-    const uint64_t lt = t == 0 ? 0ull : (~0ull >> (64 - t));
     s_nf[t] = admitted ? nf : 0;
     if (t == 0) s_base = pmask ? (int)atomicAdd(a.tmp_count, (unsigned)__popcll(pmask)) : 0;
     __syncthreads();
     if (is_plane) { // parked until the scans have fixed the final order
         const int64_t slot = (int64_t)s_base + __popcll(pmask & lt);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) a.tmp_plane[6 * slot + k] = pl[k];
+        for (int q = 0; q < 6; ++q) a.tmp_plane[6 * slot + q] = pl[q];
         a.tmp_nf[slot] = nf;
     }
     if (t == 0) {
         int64_t fsum = 0;
-        for (int k = 0; k < 64; ++k) fsum += s_nf[k];
+        for (int q = 0; q < 64; ++q) fsum += s_nf[q];
         uint32_t split1 = 0;
-        for (int k = 0; k < 8; ++k) split1 |= (uint32_t)((smask >> (8 * k)) & 1ull) << k;
+        for (int q = 0; q < 8; ++q) split1 |= (uint32_t)((smask >> (8 * q)) & 1ull) << q;
         a.n_plane[r] = __popcll(pmask);
         a.n_vox[r] = __popcll(amask);
         a.n_fac[r] = fsum;
         a.mask[r] = pmask;
-        a.rootinfo[r] = (uint32_t)st0 | (split1 << 8);
-        a.tmp_base[r] = s_base;
+        a.rootinfo[r] = (uint32_t)ST_SPLIT | (split1 << 8);
+        a.tmp_base[k] = s_base;
     }
 }
-
-// Emission for one root (tras_opt :466-474 -> push_voxel :45-54): planes into their final slots, and one more sweep
-// that writes the admitted nodes' per-frame clusters in frame order.
-__global__ __launch_bounds__(64) void vox_emit_kernel(NodeArgs a)
+// 3f. emission for a split root (tras_opt :466-474 -> push_voxel :45-54): planes into their final slots, admitted
+// nodes' per-frame clusters copied in frame order.
+__global__ __launch_bounds__(64) void vox_split_emit_kernel(SplitArgs a)
 {
-    const int64_t r = blockIdx.x;
+    const int64_t k = blockIdx.x;
+    const int64_t r = a.split_roots[k];
     const uint64_t pmask = a.mask[r];
     if (pmask == 0ull) return;
     const int t = threadIdx.x, o1 = t >> 3, o2 = t & 7;
-    const uint32_t b = a.root_start[r], e = a.root_start[r + 1];
     __shared__ int s_nf[64];
     const uint32_t info = a.rootinfo[r];
     const uint64_t lt = t == 0 ? 0ull : (~0ull >> (64 - t));
     const bool is_plane = (pmask >> t) & 1ull;
-    const int level = (info & 0xff) == ST_PLANE ? 0 : (((info >> (8 + o1)) & 1u) ? 2 : 1);
+    const int level = ((info >> (8 + o1)) & 1u) ? 2 : 1;
     int nf = 0;
     if (is_plane) {
-        const int64_t slot = (int64_t)a.tmp_base[r] + __popcll(pmask & lt);
+        const int64_t slot = (int64_t)a.tmp_base[k] + __popcll(pmask & lt);
         nf = a.tmp_nf[slot];
         double *o = a.plane + 6 * ((int64_t)a.plane_first[r] + __popcll(pmask & lt));
 #pragma unroll
-        for (int k = 0; k < 6; ++k) o[k] = a.tmp_plane[6 * slot + k];
+        for (int q = 0; q < 6; ++q) o[q] = a.tmp_plane[6 * slot + q];
     }
     const bool admitted = is_plane && nf >= 2;
     const uint64_t amask = __ballot(admitted);
     if (amask == 0ull) return;
     s_nf[t] = admitted ? nf : 0;
     __syncthreads();
+    if (!admitted) return;
     int64_t foff = a.fac_first[r];
-    for (int k = 0; k < t; ++k) foff += s_nf[k];
-    if (admitted) {
-        const int64_t v = (int64_t)a.vox_first[r] + __popcll(amask & lt);
-        a.vox_off[v] = foff;
-        a.vox_label[2 * v] = (int32_t)r;
-        a.vox_label[2 * v + 1] = level | ((level >= 1 ? o1 : 0) << 4) | ((level == 2 ? o2 : 0) << 8);
+    for (int q = 0; q < t; ++q) foff += s_nf[q];
+    const int64_t v = (int64_t)a.vox_first[r] + __popcll(amask & lt);
+    a.vox_off[v] = foff;
+    a.vox_label[2 * v] = (int32_t)r;
+    a.vox_label[2 * v + 1] = level | (o1 << 4) | ((level == 2 ? o2 : 0) << 8);
+    for (uint32_t sg = a.root_seg[r], s1 = a.root_seg[r + 1]; sg < s1; ++sg) {
+        const uint32_t j = a.seg_excl[sg];
+        const uint32_t m1 = a.m1[j];
+        const uint64_t m2 = a.m2[j];
+        int64_t src = -1;
+        if (level == 1) { if ((m1 >> o1) & 1u) src = (int64_t)a.base[j] + __popc(m1 & ((1u << o1) - 1u)); }
+        else if ((m2 >> t) & 1ull) src = (int64_t)a.base[j] + __popc(m1) + __popcll(m2 & lt);
+        if (src < 0) continue;
+        a.pose_idx[foff] = a.seg_frame[sg];
+#pragma unroll
+        for (int q = 0; q < 10; ++q) a.clusters[10 * foff + q] = a.nodecl[10 * src + q];
+        ++foff;
     }
-    Acc A;
-    A.clear();
-    LVBA_VOX_SWEEP(
-        {
-            if (A.n > 0) {
-                a.pose_idx[foff] = cur_f;
-                A.store(a.clusters + 10 * foff);
-                ++foff;
-                A.clear();
-            }
-        },
-        {
-            const bool mine = admitted && (level == 0 || (level == 1 ? (c >> 3) == o1 : c == t));
-            if (mine) A.push(x, y, z);
-        })
+}
+// 3g. emission for roots that are planes themselves: one lane per segment.
+__global__ void vox_root_emit_kernel(int64_t NS, const uint32_t *__restrict__ seg_root, const uint32_t *__restrict__ root_seg,
+                                     const int32_t *__restrict__ seg_frame, const double *__restrict__ segcl,
+                                     const uint32_t *__restrict__ rootinfo, const int32_t *__restrict__ n_vox,
+                                     const double *__restrict__ plane0, const int32_t *__restrict__ plane_first,
+                                     const int32_t *__restrict__ vox_first, const int64_t *__restrict__ fac_first,
+                                     double *__restrict__ plane, int64_t *__restrict__ vox_off, int32_t *__restrict__ pose_idx,
+                                     double *__restrict__ clusters, int32_t *__restrict__ vox_label)
+{
+    const int64_t sg = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (sg >= NS) return;
+    const uint32_t r = seg_root[sg];
+    if ((rootinfo[r] & 0xff) != ST_PLANE) return;
+    const uint32_t first = root_seg[r];
+    if (sg == first) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) plane[6 * (int64_t)plane_first[r] + q] = plane0[6 * (int64_t)r + q];
+    }
+    if (!n_vox[r]) return;
+    const int64_t foff = fac_first[r] + (sg - first);
+    if (sg == first) {
+        const int64_t v = vox_first[r];
+        vox_off[v] = foff;
+        vox_label[2 * v] = (int32_t)r;
+        vox_label[2 * v + 1] = 0;
+    }
+    pose_idx[foff] = seg_frame[sg];
+#pragma unroll
+    for (int q = 0; q < 10; ++q) clusters[10 * foff + q] = segcl[10 * sg + q];
 }
 
 // ---- landmark -> plane lookup (src/lvba_system.cpp:1531-1565) ------------------------------------------------------
@@ -434,6 +604,8 @@ struct lvba_voxmap_s {
     double *d_clusters = nullptr;
 };
 
+extern "C" int64_t lvba_release_cached_memory(void) { return (int64_t)DevicePool::get().release(); }
+
 extern "C" void lvba_voxel_default_opts(lvba_voxel_opts *o)
 {
     if (!o) return;
@@ -509,7 +681,7 @@ extern "C" int32_t lvba_voxmap_destroy(lvba_voxmap_t h)
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_root_key, h->d_mask, h->d_rootinfo, h->d_plane_first, h->d_plane,
                     h->d_vox_off, h->d_pose_idx, h->d_vox_label, h->d_clusters};
-    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (void *p : ptrs) DevicePool::get().free(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return LVBA_OK;
@@ -522,7 +694,7 @@ int32_t sort_pairs(hipStream_t s, const uint64_t *kin, uint64_t *kout, const uin
 {
     size_t bytes = 0;
     HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, 0u, end_bit, s));
-    DevBuf tmp;
+    DevBuf tmp(s);
     HIPCHK(tmp.alloc(bytes));
     HIPCHK(rocprim::radix_sort_pairs(tmp.p, bytes, kin, kout, vin, vout, n, 0u, end_bit, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -533,7 +705,7 @@ int32_t scan_incl(hipStream_t s, const T *in, T *out, size_t n)
 {
     size_t bytes = 0;
     HIPCHK(rocprim::inclusive_scan(nullptr, bytes, in, out, n, rocprim::plus<T>(), s));
-    DevBuf tmp;
+    DevBuf tmp(s);
     HIPCHK(tmp.alloc(bytes));
     HIPCHK(rocprim::inclusive_scan(tmp.p, bytes, in, out, n, rocprim::plus<T>(), s));
     HIPCHK(hipStreamSynchronize(s));
@@ -544,7 +716,7 @@ int32_t scan_excl(hipStream_t s, const T *in, T *out, size_t n)
 {
     size_t bytes = 0;
     HIPCHK(rocprim::exclusive_scan(nullptr, bytes, in, out, T(0), n, rocprim::plus<T>(), s));
-    DevBuf tmp;
+    DevBuf tmp(s);
     HIPCHK(tmp.alloc(bytes));
     HIPCHK(rocprim::exclusive_scan(tmp.p, bytes, in, out, T(0), n, rocprim::plus<T>(), s));
     HIPCHK(hipStreamSynchronize(s));
@@ -564,72 +736,128 @@ int32_t voxmap_build_impl(lvba_voxmap_s *h, const lvba_scans_s *sc, int frame_be
     const float *pts = sc->d_pts + 3 * p_begin;
     double t0 = now_ms();
 
-    DevBuf d_poses;
+    DevBuf d_poses(s);
     HIPCHK(d_poses.alloc(96 * (size_t)nfr));
     HIPCHK(hipMemcpyAsync(d_poses.p, poses, 96 * (size_t)nfr, hipMemcpyHostToDevice, s));
 
-    // -- 1. keys + records, root sort (stable: inside a root the records stay frame-major, cloud order inside a frame)
-    DevBuf key, rec, idx, key_s, idx0, rec_s, d_err;
-    HIPCHK(key.alloc(8 * P)); HIPCHK(rec.alloc(16 * P)); HIPCHK(idx.alloc(4 * P));
-    HIPCHK(key_s.alloc(8 * P)); HIPCHK(idx0.alloc(4 * P)); HIPCHK(rec_s.alloc(16 * P)); HIPCHK(d_err.alloc(4));
-    HIPCHK(hipMemsetAsync(d_err.p, 0, 4, s));
-    vox_key_kernel<<<grid_for(P, 256), 256, 0, s>>>(P, pts, sc->d_frame_off + frame_begin, nfr, d_poses.as<double>(),
-                                                    h->opts.voxel_size, key.as<uint64_t>(), rec.as<float4>(),
-                                                    idx.as<uint32_t>(), d_err.as<int>());
-    HIPCHK(hipGetLastError());
-    int err = 0;
-    HIPCHK(hipMemcpyAsync(&err, d_err.p, 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    if (err) return lvba_fail(LVBA_ERR_ARG, "a point is non-finite or its voxel key exceeds +-2^20 after the pose transform");
-    h->info.key_ms = now_ms() - t0; t0 = now_ms();
-    TRY(sort_pairs(s, key.as<uint64_t>(), key_s.as<uint64_t>(), idx.as<uint32_t>(), idx0.as<uint32_t>(), (size_t)P, 63));
-    vox_gather_kernel<<<grid_for(P, 256), 256, 0, s>>>(P, rec.as<float4>(), idx0.as<uint32_t>(), rec_s.as<float4>());
-    HIPCHK(hipGetLastError());
-
-    int64_t R = 0;
-    DevBuf root_key, root_start;
+    // -- 1./2. keys + records, root sort (stable: inside a root the records stay frame-major, cloud order inside a frame),
+    //          root table and (root, frame) segment table
+    int64_t R = 0, NS = 0;
+    DevBuf rec_s(s), root_key(s), root_seg(s), seg_start(s), seg_root(s), seg_frame(s);
     {
-        DevBuf head, incl;
-        HIPCHK(head.alloc(4 * P)); HIPCHK(incl.alloc(4 * P));
-        vox_heads_kernel<<<grid_for(P, 256), 256, 0, s>>>(P, key_s.as<uint64_t>(), head.as<uint32_t>());
-        TRY(scan_incl<uint32_t>(s, head.as<uint32_t>(), incl.as<uint32_t>(), (size_t)P));
-        uint32_t last = 0;
-        HIPCHK(hipMemcpy(&last, incl.as<uint32_t>() + (P - 1), 4, hipMemcpyDeviceToHost));
-        R = last;
-        HIPCHK(root_key.alloc(8 * (size_t)R)); HIPCHK(root_start.alloc(4 * ((size_t)R + 1)));
-        vox_segs_kernel<<<grid_for(P, 256), 256, 0, s>>>(P, key_s.as<uint64_t>(), head.as<uint32_t>(), incl.as<uint32_t>(),
-                                                         root_key.as<uint64_t>(), root_start.as<uint32_t>());
+        DevBuf key(s), rec(s), idx(s), key_s(s), idx0(s), d_err(s);
+        HIPCHK(key.alloc(8 * P)); HIPCHK(rec.alloc(16 * P)); HIPCHK(idx.alloc(4 * P));
+        HIPCHK(key_s.alloc(8 * P)); HIPCHK(idx0.alloc(4 * P)); HIPCHK(rec_s.alloc(16 * P)); HIPCHK(d_err.alloc(4));
+        HIPCHK(hipMemsetAsync(d_err.p, 0, 4, s));
+        vox_key_kernel<<<grid_for(P, 256), 256, 0, s>>>(P, pts, sc->d_frame_off + frame_begin, nfr, d_poses.as<double>(),
+                                                        h->opts.voxel_size, key.as<uint64_t>(), rec.as<float4>(),
+                                                        idx.as<uint32_t>(), d_err.as<int>());
+        HIPCHK(hipGetLastError());
+        int err = 0;
+        HIPCHK(hipMemcpyAsync(&err, d_err.p, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (err) return lvba_fail(LVBA_ERR_ARG, "a point is non-finite or its voxel key exceeds +-2^20 after the pose transform");
+        h->info.key_ms = now_ms() - t0; t0 = now_ms();
+        TRY(sort_pairs(s, key.as<uint64_t>(), key_s.as<uint64_t>(), idx.as<uint32_t>(), idx0.as<uint32_t>(), (size_t)P, 63));
+        vox_gather_kernel<<<grid_for(P, 256), 256, 0, s>>>(P, rec.as<float4>(), idx0.as<uint32_t>(), rec_s.as<float4>());
+        HIPCHK(hipGetLastError());
+
+        DevBuf head_root(s), head_seg(s), incl_root(s), incl_seg(s);
+        HIPCHK(head_root.alloc(4 * P)); HIPCHK(head_seg.alloc(4 * P)); HIPCHK(incl_root.alloc(4 * P)); HIPCHK(incl_seg.alloc(4 * P));
+        vox_heads_kernel<<<grid_for(P, 256), 256, 0, s>>>(P, key_s.as<uint64_t>(), rec_s.as<float4>(), head_root.as<uint32_t>(),
+                                                          head_seg.as<uint32_t>());
+        HIPCHK(hipGetLastError());
+        TRY(scan_incl<uint32_t>(s, head_root.as<uint32_t>(), incl_root.as<uint32_t>(), (size_t)P));
+        TRY(scan_incl<uint32_t>(s, head_seg.as<uint32_t>(), incl_seg.as<uint32_t>(), (size_t)P));
+        uint32_t last[2] = {0, 0};
+        HIPCHK(hipMemcpy(&last[0], incl_root.as<uint32_t>() + (P - 1), 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&last[1], incl_seg.as<uint32_t>() + (P - 1), 4, hipMemcpyDeviceToHost));
+        R = last[0]; NS = last[1];
+        HIPCHK(root_key.alloc(8 * (size_t)R)); HIPCHK(root_seg.alloc(4 * ((size_t)R + 1)));
+        HIPCHK(seg_start.alloc(4 * ((size_t)NS + 1))); HIPCHK(seg_root.alloc(4 * (size_t)NS)); HIPCHK(seg_frame.alloc(4 * (size_t)NS));
+        vox_tables_kernel<<<grid_for(P, 256), 256, 0, s>>>(P, key_s.as<uint64_t>(), rec_s.as<float4>(), head_root.as<uint32_t>(),
+                                                           incl_root.as<uint32_t>(), head_seg.as<uint32_t>(),
+                                                           incl_seg.as<uint32_t>(), root_key.as<uint64_t>(),
+                                                           root_seg.as<uint32_t>(), seg_start.as<uint32_t>(),
+                                                           seg_root.as<uint32_t>(), seg_frame.as<int32_t>());
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(s));
     }
     h->info.n_roots = R;
     h->info.sort_ms = now_ms() - t0; t0 = now_ms();
 
-    // -- 3. octree walk: count, scan, write
-    DevBuf n_plane, n_vox, n_fac, mask, rootinfo, plane_first, vox_first, fac_first;
+    // -- 3. octree: root clusters and decisions for every root, children / grandchildren for the roots that split
+    DevBuf segm1(s), segm2(s);
+    HIPCHK(segm1.alloc(4 * (size_t)NS)); HIPCHK(segm2.alloc(8 * (size_t)NS));
+    DevBuf segcl(s), n_plane(s), n_vox(s), n_fac(s), mask(s), rootinfo(s), plane0(s), is_split(s), seg_split(s), split_excl(s), seg_excl(s);
+    HIPCHK(segcl.alloc(80 * (size_t)NS));
     HIPCHK(n_plane.alloc(4 * (R + 1))); HIPCHK(n_vox.alloc(4 * (R + 1))); HIPCHK(n_fac.alloc(8 * (R + 1)));
-    HIPCHK(mask.alloc(8 * R)); HIPCHK(rootinfo.alloc(4 * R));
-    HIPCHK(plane_first.alloc(4 * (R + 1))); HIPCHK(vox_first.alloc(4 * (R + 1))); HIPCHK(fac_first.alloc(8 * (R + 1)));
-    HIPCHK(hipMemsetAsync(n_plane.p, 0, 4 * (R + 1), s));
-    HIPCHK(hipMemsetAsync(n_vox.p, 0, 4 * (R + 1), s));
-    HIPCHK(hipMemsetAsync(n_fac.p, 0, 8 * (R + 1), s));
-    NodeArgs a{};
-    a.R = R;
-    a.rec = rec_s.as<float4>();
-    a.root_start = root_start.as<uint32_t>();
-    a.poses = d_poses.as<double>();
-    for (int L = 0; L < 3; ++L) a.ratio[L] = h->opts.eigen_ratio[L];
-    a.min_ps = h->opts.min_points;
-    a.n_plane = n_plane.as<int32_t>(); a.n_vox = n_vox.as<int32_t>(); a.n_fac = n_fac.as<int64_t>();
-    a.mask = mask.as<uint64_t>(); a.rootinfo = rootinfo.as<uint32_t>();
-    const size_t tmp_cap = (size_t)(P / h->opts.min_points) + 1; // a PLANE node holds >= min_points points, nodes of
-    DevBuf tmp_count, tmp_base, tmp_plane, tmp_nf;              // one root are disjoint or nested under a non-PLANE one
-    HIPCHK(tmp_count.alloc(4)); HIPCHK(tmp_base.alloc(4 * R)); HIPCHK(tmp_plane.alloc(48 * tmp_cap)); HIPCHK(tmp_nf.alloc(4 * tmp_cap));
-    HIPCHK(hipMemsetAsync(tmp_count.p, 0, 4, s));
-    a.tmp_count = tmp_count.as<unsigned>(); a.tmp_base = tmp_base.as<int32_t>();
-    a.tmp_plane = tmp_plane.as<double>(); a.tmp_nf = tmp_nf.as<int32_t>();
-    vox_decide_kernel<<<(unsigned)R, 64, 0, s>>>(a);
+    HIPCHK(mask.alloc(8 * R)); HIPCHK(rootinfo.alloc(4 * R)); HIPCHK(plane0.alloc(48 * R));
+    HIPCHK(is_split.alloc(4 * (R + 1))); HIPCHK(seg_split.alloc(4 * (NS + 1)));
+    HIPCHK(split_excl.alloc(4 * (R + 1))); HIPCHK(seg_excl.alloc(4 * (NS + 1)));
+    HIPCHK(hipMemsetAsync(n_plane.as<int32_t>() + R, 0, 4, s));
+    HIPCHK(hipMemsetAsync(n_vox.as<int32_t>() + R, 0, 4, s));
+    HIPCHK(hipMemsetAsync(n_fac.as<int64_t>() + R, 0, 8, s));
+    HIPCHK(hipMemsetAsync(is_split.as<uint32_t>() + R, 0, 4, s));
+    HIPCHK(hipMemsetAsync(seg_split.as<uint32_t>() + NS, 0, 4, s));
+    vox_seg_small_kernel<<<grid_for(NS, 64), 64, 0, s>>>(NS, seg_start.as<uint32_t>(), rec_s.as<float4>(), segcl.as<double>(),
+                                                         segm1.as<uint32_t>(), segm2.as<uint64_t>());
+    vox_seg_big_kernel<<<(unsigned)NS, 64, 0, s>>>(seg_start.as<uint32_t>(), rec_s.as<float4>(), segcl.as<double>(),
+                                                   segm1.as<uint32_t>(), segm2.as<uint64_t>());
     HIPCHK(hipGetLastError());
+    RootArgs ra{};
+    ra.R = R; ra.root_seg = root_seg.as<uint32_t>(); ra.seg_frame = seg_frame.as<int32_t>(); ra.segcl = segcl.as<double>();
+    ra.poses = d_poses.as<double>();
+    for (int L = 0; L < 3; ++L) ra.ratio[L] = h->opts.eigen_ratio[L];
+    ra.min_ps = h->opts.min_points;
+    ra.n_plane = n_plane.as<int32_t>(); ra.n_vox = n_vox.as<int32_t>(); ra.n_fac = n_fac.as<int64_t>();
+    ra.mask = mask.as<uint64_t>(); ra.rootinfo = rootinfo.as<uint32_t>(); ra.plane0 = plane0.as<double>();
+    ra.is_split = is_split.as<uint32_t>(); ra.seg_split = seg_split.as<uint32_t>();
+    vox_root_kernel<<<grid_for(R, 64), 64, 0, s>>>(ra);
+    HIPCHK(hipGetLastError());
+    TRY(scan_excl<uint32_t>(s, is_split.as<uint32_t>(), split_excl.as<uint32_t>(), (size_t)R + 1));
+    TRY(scan_excl<uint32_t>(s, seg_split.as<uint32_t>(), seg_excl.as<uint32_t>(), (size_t)NS + 1));
+    uint32_t NRS = 0, NSS = 0;
+    HIPCHK(hipMemcpy(&NRS, split_excl.as<uint32_t>() + R, 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&NSS, seg_excl.as<uint32_t>() + NS, 4, hipMemcpyDeviceToHost));
+
+    DevBuf split_roots(s), split_segs(s), m1(s), m2(s), cnt(s), base(s), nodecl(s), tmp_count(s), tmp_base(s), tmp_plane(s), tmp_nf(s);
+    SplitArgs sa{};
+    if (NRS > 0) {
+        HIPCHK(split_roots.alloc(4 * (size_t)NRS)); HIPCHK(split_segs.alloc(4 * (size_t)NSS));
+        vox_compact_kernel<<<grid_for(R, 256), 256, 0, s>>>(R, is_split.as<uint32_t>(), split_excl.as<uint32_t>(), split_roots.as<uint32_t>());
+        vox_compact_kernel<<<grid_for(NS, 256), 256, 0, s>>>(NS, seg_split.as<uint32_t>(), seg_excl.as<uint32_t>(), split_segs.as<uint32_t>());
+        HIPCHK(m1.alloc(4 * (size_t)NSS)); HIPCHK(m2.alloc(8 * (size_t)NSS)); HIPCHK(cnt.alloc(4 * ((size_t)NSS + 1)));
+        HIPCHK(base.alloc(4 * ((size_t)NSS + 1)));
+        vox_split_masks_kernel<<<grid_for((int64_t)NSS + 1, 256), 256, 0, s>>>(NSS, split_segs.as<uint32_t>(), segm1.as<uint32_t>(),
+                                                                               segm2.as<uint64_t>(), m1.as<uint32_t>(), m2.as<uint64_t>(),
+                                                                               cnt.as<uint32_t>());
+        HIPCHK(hipGetLastError());
+        TRY(scan_excl<uint32_t>(s, cnt.as<uint32_t>(), base.as<uint32_t>(), (size_t)NSS + 1));
+        uint32_t NN = 0;
+        HIPCHK(hipMemcpy(&NN, base.as<uint32_t>() + NSS, 4, hipMemcpyDeviceToHost));
+        HIPCHK(nodecl.alloc(80 * (size_t)NN));
+        vox_split_cluster_kernel<<<NSS, 64, 0, s>>>(split_segs.as<uint32_t>(), seg_start.as<uint32_t>(), rec_s.as<float4>(),
+                                                    m1.as<uint32_t>(), m2.as<uint64_t>(), base.as<uint32_t>(), nodecl.as<double>());
+        HIPCHK(hipGetLastError());
+        const size_t tmp_cap = (size_t)(P / h->opts.min_points) + 1; // a PLANE node holds >= min_points points of its own
+        HIPCHK(tmp_count.alloc(4)); HIPCHK(tmp_base.alloc(4 * (size_t)NRS));
+        HIPCHK(tmp_plane.alloc(48 * tmp_cap)); HIPCHK(tmp_nf.alloc(4 * tmp_cap));
+        HIPCHK(hipMemsetAsync(tmp_count.p, 0, 4, s));
+        sa.split_roots = split_roots.as<uint32_t>(); sa.root_seg = root_seg.as<uint32_t>(); sa.seg_excl = seg_excl.as<uint32_t>();
+        sa.seg_frame = seg_frame.as<int32_t>(); sa.m1 = m1.as<uint32_t>(); sa.m2 = m2.as<uint64_t>(); sa.base = base.as<uint32_t>();
+        sa.nodecl = nodecl.as<double>(); sa.poses = d_poses.as<double>();
+        for (int L = 0; L < 3; ++L) sa.ratio[L] = h->opts.eigen_ratio[L];
+        sa.min_ps = h->opts.min_points;
+        sa.n_plane = n_plane.as<int32_t>(); sa.n_vox = n_vox.as<int32_t>(); sa.n_fac = n_fac.as<int64_t>();
+        sa.mask = mask.as<uint64_t>(); sa.rootinfo = rootinfo.as<uint32_t>();
+        sa.tmp_count = tmp_count.as<unsigned>(); sa.tmp_base = tmp_base.as<int32_t>();
+        sa.tmp_plane = tmp_plane.as<double>(); sa.tmp_nf = tmp_nf.as<int32_t>();
+        vox_split_decide_kernel<<<NRS, 64, 0, s>>>(sa);
+        HIPCHK(hipGetLastError());
+    }
+    DevBuf plane_first(s), vox_first(s), fac_first(s);
+    HIPCHK(plane_first.alloc(4 * (R + 1))); HIPCHK(vox_first.alloc(4 * (R + 1))); HIPCHK(fac_first.alloc(8 * (R + 1)));
     TRY(scan_excl<int32_t>(s, n_plane.as<int32_t>(), plane_first.as<int32_t>(), (size_t)R + 1));
     TRY(scan_excl<int32_t>(s, n_vox.as<int32_t>(), vox_first.as<int32_t>(), (size_t)R + 1));
     TRY(scan_excl<int64_t>(s, n_fac.as<int64_t>(), fac_first.as<int64_t>(), (size_t)R + 1));
@@ -641,14 +869,23 @@ int32_t voxmap_build_impl(lvba_voxmap_s *h, const lvba_scans_s *sc, int frame_be
     h->info.n_planes = n_planes; h->info.n_voxels = V; h->info.n_factors = F;
     h->info.count_ms = now_ms() - t0; t0 = now_ms();
 
-    DevBuf plane, vox_off, pose_idx, clusters, vox_label;
+    // -- emission
+    DevBuf plane(s), vox_off(s), pose_idx(s), clusters(s), vox_label(s);
     HIPCHK(plane.alloc(48 * (size_t)n_planes)); HIPCHK(vox_off.alloc(8 * ((size_t)V + 1)));
     HIPCHK(pose_idx.alloc(4 * (size_t)F)); HIPCHK(clusters.alloc(80 * (size_t)F)); HIPCHK(vox_label.alloc(8 * (size_t)V));
-    a.plane_first = plane_first.as<int32_t>(); a.vox_first = vox_first.as<int32_t>(); a.fac_first = fac_first.as<int64_t>();
-    a.plane = plane.as<double>(); a.vox_off = vox_off.as<int64_t>(); a.pose_idx = pose_idx.as<int32_t>();
-    a.clusters = clusters.as<double>(); a.vox_label = vox_label.as<int32_t>();
-    vox_emit_kernel<<<(unsigned)R, 64, 0, s>>>(a);
+    vox_root_emit_kernel<<<grid_for(NS, 256), 256, 0, s>>>(NS, seg_root.as<uint32_t>(), root_seg.as<uint32_t>(), seg_frame.as<int32_t>(),
+                                                           segcl.as<double>(), rootinfo.as<uint32_t>(), n_vox.as<int32_t>(),
+                                                           plane0.as<double>(), plane_first.as<int32_t>(), vox_first.as<int32_t>(),
+                                                           fac_first.as<int64_t>(), plane.as<double>(), vox_off.as<int64_t>(),
+                                                           pose_idx.as<int32_t>(), clusters.as<double>(), vox_label.as<int32_t>());
     HIPCHK(hipGetLastError());
+    if (NRS > 0) {
+        sa.plane_first = plane_first.as<int32_t>(); sa.vox_first = vox_first.as<int32_t>(); sa.fac_first = fac_first.as<int64_t>();
+        sa.plane = plane.as<double>(); sa.vox_off = vox_off.as<int64_t>(); sa.pose_idx = pose_idx.as<int32_t>();
+        sa.clusters = clusters.as<double>(); sa.vox_label = vox_label.as<int32_t>();
+        vox_split_emit_kernel<<<NRS, 64, 0, s>>>(sa);
+        HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipMemcpyAsync(vox_off.as<int64_t>() + V, &F, 8, hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));
     h->info.write_ms = now_ms() - t0;
@@ -772,7 +1009,7 @@ extern "C" int32_t lvba_voxmap_find_planes(lvba_voxmap_t h, int64_t n, const dou
         return LVBA_OK;
     }
     HIPCHK(hipSetDevice(h->device));
-    DevBuf dX, dpl, dval;
+    DevBuf dX(h->stream), dpl(h->stream), dval(h->stream);
     HIPCHK(dX.alloc(24 * (size_t)n)); HIPCHK(dpl.alloc(32 * (size_t)n)); HIPCHK(dval.alloc((size_t)n));
     HIPCHK(hipMemcpyAsync(dX.p, X, 24 * (size_t)n, hipMemcpyHostToDevice, h->stream));
     vox_lookup_kernel<<<grid_for(n, 256), 256, 0, h->stream>>>(n, dX.as<double>(), h->opts.voxel_size, h->info.n_roots,

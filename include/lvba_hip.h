@@ -284,6 +284,9 @@ int32_t lvba_voxmap_build_scans(lvba_scans_t scans, int32_t frame_begin, int32_t
                                 const lvba_voxel_opts *opts, lvba_voxmap_t *out);
 
 int32_t lvba_voxmap_info(lvba_voxmap_t h, lvba_voxmap_info_t *info);
+/* The front-end keeps its device workspaces in a per-process cache between maps (hipMalloc/hipFree of 100 MB-class
+ * buffers would otherwise dominate small maps); this returns the cached bytes to the driver.  Returns bytes freed. */
+int64_t lvba_release_cached_memory(void);
 /* Host copies of the admitted voxels in lvba_balm_create's layout (any pointer may be NULL): voxel_off [V+1],
  * pose_idx [F], clusters [F][10], voxel_key [V][4] = root key x, y, z and layer | o1 << 4 | o2 << 8. */
 int32_t lvba_voxmap_export(lvba_voxmap_t h, int64_t *voxel_off, int32_t *pose_idx, double *clusters,
