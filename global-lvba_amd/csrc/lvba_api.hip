@@ -82,13 +82,28 @@ extern "C" void lvba_shard_range(int64_t V, int32_t rank, int32_t G, int64_t *he
 }
 
 // ------------------------------------------------------------------------------------------ create
+static int32_t balm_create_impl(int32_t n_poses, int64_t n_voxels, const int64_t *voxel_off, const int32_t *pose_idx,
+                                const double *clusters, const double *d_clusters, int32_t device, lvba_balm_t *out);
+
 extern "C" int32_t lvba_balm_create(int32_t n_poses, int64_t n_voxels, const int64_t *voxel_off,
                                     const int32_t *pose_idx, const double *clusters, int32_t device,
                                     lvba_balm_t *out)
 {
+    return balm_create_impl(n_poses, n_voxels, voxel_off, pose_idx, clusters, nullptr, device, out);
+}
+
+extern "C" int32_t lvba_balm_create_dev(int32_t n_poses, int64_t n_voxels, const int64_t *voxel_off, const int32_t *pose_idx,
+                                        const double *d_clusters, int32_t device, lvba_balm_t *out)
+{
+    return balm_create_impl(n_poses, n_voxels, voxel_off, pose_idx, nullptr, d_clusters, device, out);
+}
+
+static int32_t balm_create_impl(int32_t n_poses, int64_t n_voxels, const int64_t *voxel_off, const int32_t *pose_idx,
+                                const double *clusters, const double *d_clusters, int32_t device, lvba_balm_t *out)
+{
     if (!out) return fail(LVBA_ERR_ARG, "out is NULL");
     *out = nullptr;
-    if (n_poses < 1 || n_voxels < 1 || !voxel_off || !pose_idx || !clusters)
+    if (n_poses < 1 || n_voxels < 1 || !voxel_off || !pose_idx || (!clusters && !d_clusters))
         return fail(LVBA_ERR_ARG, "n_poses/n_voxels must be >= 1 and arrays non-NULL");
     const int64_t base = voxel_off[0];
     const int64_t F = voxel_off[n_voxels] - base;
@@ -136,15 +151,18 @@ extern "C" int32_t lvba_balm_create(int32_t n_poses, int64_t n_voxels, const int
     CTRY(bs_dmalloc(bs, &h->d_chunk_cost, h->n_chunks));
     CHIP(hipMemcpy(h->d_voff, h->h_voff.data(), (size_t)(n_voxels + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
     CHIP(hipMemcpy(h->d_chunk_v0, chunk_v0.data(), (size_t)(h->n_chunks + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
-    { // AoS [F][10] -> SoA [10][F], staged through a bounded host buffer
-        const int64_t CH = 1 << 20;
-        std::vector<double> tmp((size_t)std::min(F, CH));
-        for (int e = 0; e < 10; ++e)
-            for (int64_t s = 0; s < F; s += CH) {
-                const int64_t m = std::min(CH, F - s);
-                for (int64_t f = 0; f < m; ++f) tmp[f] = clusters[10 * (s + f) + e];
-                CHIP(hipMemcpy(h->d_clu + (int64_t)e * F + s, tmp.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice));
-            }
+    { // AoS [F][10] -> SoA [10][F] on the device (a host array is staged in a temporary device buffer)
+        const double *src = d_clusters; // like the host array: indexed relative to voxel_off[0]
+        double *d_stage = nullptr;
+        if (!d_clusters) {
+            CTRY(bs_dmalloc(bs, &d_stage, 10 * F));
+            CHIP(hipMemcpy(d_stage, clusters, (size_t)(10 * F) * sizeof(double), hipMemcpyHostToDevice));
+            src = d_stage;
+        }
+        launch_aos_to_soa(src, F, h->d_clu, bs.stream);
+        CHIP(hipGetLastError());
+        CHIP(hipStreamSynchronize(bs.stream));
+        if (d_stage) { hipFree(d_stage); bs.device_bytes -= (int64_t)(10 * F) * (int64_t)sizeof(double); }
     }
     CHIP(hipHostMalloc((void **)&h->h_pin, 16 * sizeof(double), hipHostMallocDefault));
     for (int e = 0; e < EV_N; ++e)

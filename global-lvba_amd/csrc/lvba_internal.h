@@ -74,6 +74,7 @@ void launch_cost(const BalmDev &d, const double *poses, double *chunk_cost, doub
 void launch_eval(const BalmDev &d, const PairDev &pd, const double *poses, double *Hblk, int64_t hblk_doubles, double *g,
                  double *chunk_cost, double *out, bool zero_first, hipStream_t s, hipEvent_t k0, hipEvent_t k1);
 void launch_pairs(const PairDev &pd, double *Hblk, hipStream_t s);
+void launch_aos_to_soa(const double *aos, int64_t F, double *soa, hipStream_t s);
 void launch_gather_csc(const double *clu, const int32_t *csc_f, int64_t F, double *clu_csc, hipStream_t s);
 void launch_retract(const double *poses, const double *dx, double *out, int n_poses, hipStream_t s);
 void launch_predicted_decrease(const double *Hblk, int band_blocks, const double *g, const double *dx, double u,
@@ -106,3 +107,9 @@ void ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_pos
                 hipEvent_t *evA, hipEvent_t *evB);
 
 } // namespace lvba
+
+// lvba_balm_create with the clusters [F][10] already on `device` (the voxel front-end hands them over without a host
+// round trip); voxel_off / pose_idx are host arrays as in lvba_balm_create.
+struct lvba_balm_s;
+extern "C" int32_t lvba_balm_create_dev(int32_t n_poses, int64_t n_voxels, const int64_t *voxel_off, const int32_t *pose_idx,
+                                        const double *d_clusters, int32_t device, struct lvba_balm_s **out);

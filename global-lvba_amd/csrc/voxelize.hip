@@ -32,6 +32,7 @@
 #include "lvba_common.h"
 #include "balm_math.h"
 #include "mempool.h"
+#include "lvba_internal.h"
 
 using namespace lvba;
 
@@ -994,9 +995,8 @@ extern "C" int32_t lvba_voxmap_to_balm(lvba_voxmap_t h, lvba_balm_t *out)
     if (V == 0) return lvba_fail(LVBA_ERR_ARG, "the map holds no admitted plane voxel (nothing to optimise)");
     std::vector<int64_t> off(V + 1);
     std::vector<int32_t> idx(F);
-    std::vector<double> cl(10 * F);
-    TRY(lvba_voxmap_export(h, off.data(), idx.data(), cl.data(), nullptr));
-    return lvba_balm_create(h->n_frames, V, off.data(), idx.data(), cl.data(), h->device, out);
+    TRY(lvba_voxmap_export(h, off.data(), idx.data(), nullptr, nullptr)); // CSR structure to the host, clusters stay in HBM
+    return lvba_balm_create_dev(h->n_frames, V, off.data(), idx.data(), h->d_clusters, h->device, out);
 }
 
 extern "C" int32_t lvba_voxmap_find_planes(lvba_voxmap_t h, int64_t n, const double *X, double *plane, uint8_t *valid)
