@@ -17,6 +17,50 @@ def build_c(force=False):
     return so
 
 
+def build_voxel(force=False):
+    so = os.path.join(_HERE, "libvoxel_oracle.so")
+    src = os.path.join(_HERE, "voxel_oracle.cpp")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s", "libvoxel_oracle.so"])
+    return so
+
+
+_VLIB = None
+
+
+def voxel_build_cpp(clouds, poses, voxel_size, eigen_ratio=(0.3, 0.1, 0.06, 0.03), min_ps=15):
+    """The C++ restatement of cut_voxel / recut / tras_opt (oracle/voxel_oracle.cpp) on a list of [n,>=3] fp32 clouds.
+    Returns dict(off, idx, clu, key, n_roots, n_planes, seconds) -- `seconds` is the wall time of the build alone."""
+    import time
+    global _VLIB
+    if _VLIB is None:
+        lib = ctypes.CDLL(build_voxel())
+        lib.vo_build.restype = ctypes.c_void_p
+        lib.vo_build.argtypes = [ctypes.c_int, np.ctypeslib.ndpointer(np.int64, flags="C"),
+                                 np.ctypeslib.ndpointer(np.float32, flags="C"), np.ctypeslib.ndpointer(np.float64, flags="C"),
+                                 ctypes.c_double, np.ctypeslib.ndpointer(np.float32, flags="C"), ctypes.c_int]
+        lib.vo_sizes.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_int64)] * 4
+        lib.vo_export.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 4
+        lib.vo_free.argtypes = [ctypes.c_void_p]
+        _VLIB = lib
+    lib = _VLIB
+    off = np.zeros(len(clouds) + 1, np.int64)
+    off[1:] = np.cumsum([len(c) for c in clouds])
+    pts = np.ascontiguousarray(np.concatenate([np.asarray(c, np.float32)[:, :3] for c in clouds]), np.float32)
+    poses = np.ascontiguousarray(poses, np.float64).reshape(-1)
+    ratio = np.ascontiguousarray(eigen_ratio, np.float32)
+    t0 = time.perf_counter()
+    h = lib.vo_build(len(clouds), off, pts.reshape(-1), poses, float(voxel_size), ratio, int(min_ps))
+    dt = time.perf_counter() - t0
+    n = [ctypes.c_int64() for _ in range(4)]
+    lib.vo_sizes(h, *[ctypes.byref(x) for x in n])
+    R, NP, V, F = (x.value for x in n)
+    o, i, c, k = np.zeros(V + 1, np.int64), np.zeros(F, np.int32), np.zeros((F, 10)), np.zeros((V, 4), np.int64)
+    lib.vo_export(h, o.ctypes.data, i.ctypes.data, c.ctypes.data, k.ctypes.data)
+    lib.vo_free(h)
+    return dict(off=o, idx=i, clu=c, key=k, n_roots=R, n_planes=NP, seconds=dt)
+
+
 def load_c():
     """ctypes handle to oracle/libbalm_oracle.so (built on demand)."""
     global _LIB

@@ -103,3 +103,24 @@ def test_pose_is_applied_before_hashing():
     np.testing.assert_array_equal(vox[0][2].center, np.float32([-6.5, 3.5, 12.5]))
     # clusters stay in the BODY frame
     assert abs(vox[0][2].sig[0][6] / 30 - 0.5) < 0.05
+
+
+@pytest.mark.parametrize("ratio", [vo.DEFAULT_EIGEN_RATIO, np.float32([0.08, 0.08, 0.08, 0.08])])
+def test_cpp_twin_matches_bit_for_bit(ratio):
+    """oracle/voxel_oracle.cpp (unordered_map + recursive octree, the reference's data structures) against the Python
+    restatement on a synthetic window: keys, paths, frames and cluster sums identical."""
+    import importlib
+    import oracle
+    synth = importlib.import_module("global-lvba_amd.synth")
+    s = synth.make_scans(5, 12000, room=(10, 8, 4), origin=(-3.3, 7.1, 0.4), n_panels=8, seed=11)
+    surf_map, vox = vo.build(s["clouds"], s["poses"], 1.0, ratio)
+    off, idx, cl = vo.pack(vox)
+    got = oracle.voxel_build_cpp(s["clouds"], s["poses"], 1.0, ratio)
+    assert got["n_roots"] == len(surf_map) and len(vox) > 50
+    key_ref = np.array([list(k) + [len(p) | ((p[0] if len(p) >= 1 else 0) << 4) | ((p[1] if len(p) == 2 else 0) << 8)]
+                        for k, p, _ in vox], np.int64)
+    np.testing.assert_array_equal(got["key"], key_ref)
+    np.testing.assert_array_equal(got["off"], off)
+    np.testing.assert_array_equal(got["idx"], idx)
+    np.testing.assert_array_equal(got["clu"], cl)
+    assert {len(p) for _, p, _ in vox} >= {0, 1}
