@@ -20,7 +20,7 @@ SYMBOLS = [
     "lvba_visual_refine",
     "lvba_voxel_default_opts", "lvba_voxmap_build", "lvba_voxmap_destroy", "lvba_voxmap_info", "lvba_voxmap_export",
     "lvba_voxmap_to_balm", "lvba_voxmap_find_planes", "lvba_scans_create", "lvba_scans_destroy", "lvba_voxmap_build_scans",
-    "lvba_release_cached_memory",
+    "lvba_release_cached_memory", "lvba_window_default_opts", "lvba_window_ba", "lvba_scans_info", "lvba_scans_download",
 ]
 
 OK, ERR_ARG, ERR_DEVICE, ERR_NOMEM, ERR_UNSUPPORTED, ERR_DIST, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
@@ -80,6 +80,20 @@ class VoxmapInfo(C.Structure):
     _fields_ = [("n_points", C.c_int64), ("n_roots", C.c_int64), ("n_planes", C.c_int64), ("n_voxels", C.c_int64),
                 ("n_factors", C.c_int64), ("upload_ms", C.c_double), ("key_ms", C.c_double), ("sort_ms", C.c_double),
                 ("count_ms", C.c_double), ("write_ms", C.c_double)]
+
+
+class WindowOpts(C.Structure):
+    _fields_ = [("window_size", C.c_int32), ("use_rel", C.c_int32), ("anchor_leaf", C.c_double), ("voxel", VoxelOpts),
+                ("lm", BalmOpts)]
+
+
+class WindowInfo(C.Structure):
+    _fields_ = [("start", C.c_int32), ("n_frames", C.c_int32), ("skipped", C.c_int32), ("anchor", C.c_int32),
+                ("n_iter", C.c_int32), ("lm_status", C.c_int32), ("n_voxels", C.c_int64), ("n_factors", C.c_int64),
+                ("n_anchor_points", C.c_int64), ("cost_first", C.c_double), ("cost_last", C.c_double)]
+
+    def as_dict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_}
 
 
 TERMINATION = {0: "NO_CONVERGENCE", 1: "CONVERGENCE(function)", 2: "CONVERGENCE(parameter)", 3: "CONVERGENCE(gradient)",
@@ -154,6 +168,12 @@ def load():
     lib.lvba_voxmap_to_balm.argtypes = [H, C.POINTER(H)]
     lib.lvba_voxmap_find_planes.argtypes = [H, C.c_int64, f64p, f64p, u8p]
     lib.lvba_release_cached_memory.restype = C.c_int64
+    lib.lvba_window_default_opts.argtypes = [C.POINTER(WindowOpts)]
+    lib.lvba_window_default_opts.restype = None
+    lib.lvba_window_ba.argtypes = [H, f64p, C.POINTER(WindowOpts), C.c_void_p, f64p, i32p, f64p, C.POINTER(C.c_int32),
+                                   C.POINTER(H), C.POINTER(WindowInfo)]
+    lib.lvba_scans_info.argtypes = [H, C.POINTER(C.c_int32), C.c_void_p]
+    lib.lvba_scans_download.argtypes = [H, C.c_int32, np.ctypeslib.ndpointer(np.float32, flags="C")]
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int:  # default

@@ -1,0 +1,62 @@
+// voxel_internal.h -- pieces shared by the voxel front-end (voxelize.hip) and the window-BA driver (window_ba.hip):
+// the device-resident scan set, rocPRIM wrappers on the caching pool, small utilities.
+#pragma once
+#include <cstring>
+#include <cstdint>
+#include <rocprim/rocprim.hpp>
+#include <chrono>
+#include <vector>
+#include "lvba_common.h"
+#include "mempool.h"
+
+struct lvba_scans_s {
+    int device = 0;
+    int n_frames = 0;
+    std::vector<int64_t> frame_off; // [n_frames+1]
+    float *d_pts = nullptr;         // [P][3]
+    int64_t *d_frame_off = nullptr;
+};
+
+namespace lvba {
+
+inline double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+inline unsigned grid_for(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+inline int32_t sort_pairs(hipStream_t s, const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout, size_t n,
+                   unsigned end_bit)
+{
+    size_t bytes = 0;
+    HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, 0u, end_bit, s));
+    DevBuf tmp(s);
+    HIPCHK(tmp.alloc(bytes));
+    HIPCHK(rocprim::radix_sort_pairs(tmp.p, bytes, kin, kout, vin, vout, n, 0u, end_bit, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return LVBA_OK;
+}
+template <class T>
+inline int32_t scan_incl(hipStream_t s, const T *in, T *out, size_t n)
+{
+    size_t bytes = 0;
+    HIPCHK(rocprim::inclusive_scan(nullptr, bytes, in, out, n, rocprim::plus<T>(), s));
+    DevBuf tmp(s);
+    HIPCHK(tmp.alloc(bytes));
+    HIPCHK(rocprim::inclusive_scan(tmp.p, bytes, in, out, n, rocprim::plus<T>(), s));
+    HIPCHK(hipStreamSynchronize(s));
+    return LVBA_OK;
+}
+template <class T>
+inline int32_t scan_excl(hipStream_t s, const T *in, T *out, size_t n)
+{
+    size_t bytes = 0;
+    HIPCHK(rocprim::exclusive_scan(nullptr, bytes, in, out, T(0), n, rocprim::plus<T>(), s));
+    DevBuf tmp(s);
+    HIPCHK(tmp.alloc(bytes));
+    HIPCHK(rocprim::exclusive_scan(tmp.p, bytes, in, out, T(0), n, rocprim::plus<T>(), s));
+    HIPCHK(hipStreamSynchronize(s));
+    return LVBA_OK;
+}
+
+} // namespace lvba

@@ -1,0 +1,304 @@
+// window_ba.hip -- the window-BA stage that turns raw scans + odometry into anchor frames, on the device.
+//
+// Replaces LvbaSystem::runWindowBA (reference src/lvba_system.cpp:204-310): per window of `window_size` frames
+//   cut_voxel / recut / tras_opt at the odometry poses   :247-257   -> lvba_voxmap_build_scans + lvba_voxmap_to_balm
+//   skip if fewer than 3 plane voxels per frame           :258-262
+//   BALM2::damping_iter                                   :264       -> lvba_balm_refine
+//   re-alignment to the odometry pose of the first frame  :268-279   (12-double algebra, host)
+//   relative poses to the anchor, merge of the clouds     :284-299   -> wba_merge_kernel (fp32 write-back as pl_transform,
+//                                                                       include/BALM/tools.hpp:385-395)
+//   down_sampling_voxel2                                  tools.hpp:300-359 -> key + stable sort + first-minimum per voxel
+// The raw clouds never leave HBM between the stages; the anchor clouds are born there (a new lvba_scans_t) and feed the
+// global stages' lvba_voxmap_build_scans directly.
+// down_sampling_voxel2 emits survivors in unordered_map order (unspecified); here: sorted by voxel key (x, y, z).
+#include "voxel_internal.h"
+#include "lvba_internal.h"
+
+using namespace lvba;
+
+namespace {
+
+constexpr int KEY_BIAS = 1 << 20;
+
+// merged cloud of one window: every point moved into the anchor frame with its frame's relative pose and rounded to fp32
+// (pl_transform); plus the leaf-voxel key and squared distance to the voxel centre of down_sampling_voxel2.
+__global__ void wba_merge_kernel(int64_t P, const float *__restrict__ pts, const int64_t *__restrict__ frame_off, int n_frames,
+                                 const double *__restrict__ rel, double leaf, float *__restrict__ out,
+                                 uint64_t *__restrict__ key, double *__restrict__ d2, uint32_t *__restrict__ idx,
+                                 int *__restrict__ err)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const int64_t base = frame_off[0];
+    int lo = 0, hi = n_frames;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (frame_off[mid] - base <= i) lo = mid; else hi = mid;
+    }
+    const double *T = rel + 12 * (int64_t)lo;
+    const double p0 = pts[3 * i], p1 = pts[3 * i + 1], p2 = pts[3 * i + 2];
+    const float q[3] = {(float)(T[0] * p0 + T[1] * p1 + T[2] * p2 + T[9]), (float)(T[3] * p0 + T[4] * p1 + T[5] * p2 + T[10]),
+                        (float)(T[6] * p0 + T[7] * p1 + T[8] * p2 + T[11])};
+    out[3 * i] = q[0]; out[3 * i + 1] = q[1]; out[3 * i + 2] = q[2];
+    if (!key) return;
+    int64_t k[3];
+    double dd = 0.0;
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        float loc = (float)((double)q[j] / leaf);
+        if (loc < 0.f) loc -= 1.f;
+        ok = ok && (fabsf(loc) < (float)KEY_BIAS);
+        k[j] = ok ? (int64_t)loc : 0;
+        const double c = ((double)k[j] + 0.5) * leaf;
+        const double d = (double)q[j] - c;
+        dd = __dadd_rn(dd, __dmul_rn(d, d)); // dx*dx + dy*dy + dz*dz, left to right, no contraction
+    }
+    if (!ok) *err = 1;
+    key[i] = ((uint64_t)(k[0] + KEY_BIAS) << 42) | ((uint64_t)(k[1] + KEY_BIAS) << 21) | (uint64_t)(k[2] + KEY_BIAS);
+    d2[i] = dd;
+    idx[i] = (uint32_t)i;
+}
+// after the stable sort by key: the run leader picks the first minimum of d2 in merged order
+__global__ void wba_pick_kernel(int64_t P, const uint64_t *__restrict__ key_s, const uint32_t *__restrict__ order,
+                                const double *__restrict__ d2, uint32_t *__restrict__ flag, uint32_t *__restrict__ pick)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const bool head = i == 0 || key_s[i] != key_s[i - 1];
+    flag[i] = head ? 1u : 0u;
+    if (!head) return;
+    const uint64_t k = key_s[i];
+    uint32_t best = order[i];
+    double bd = d2[best];
+    for (int64_t j = i + 1; j < P && key_s[j] == k; ++j) {
+        const uint32_t c = order[j];
+        const double d = d2[c];
+        if (d < bd) { bd = d; best = c; }
+    }
+    pick[i] = best;
+}
+__global__ void wba_compact_kernel(int64_t P, const uint32_t *__restrict__ flag, const uint32_t *__restrict__ excl,
+                                   const uint32_t *__restrict__ pick, const float *__restrict__ merged, float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P || !flag[i]) return;
+    const uint32_t s = pick[i], o = excl[i];
+    out[3 * (int64_t)o] = merged[3 * (int64_t)s];
+    out[3 * (int64_t)o + 1] = merged[3 * (int64_t)s + 1];
+    out[3 * (int64_t)o + 2] = merged[3 * (int64_t)s + 2];
+}
+
+inline void mat3_mul(const double *A, const double *B, double *C)
+{
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) C[3 * r + c] = A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c] + A[3 * r + 2] * B[6 + c];
+}
+inline void mat3_mulT(const double *A, const double *B, double *C) // A * B^T
+{
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) C[3 * r + c] = A[3 * r] * B[3 * c] + A[3 * r + 1] * B[3 * c + 1] + A[3 * r + 2] * B[3 * c + 2];
+}
+inline void mat3T_mul(const double *A, const double *B, double *C) // A^T * B
+{
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) C[3 * r + c] = A[r] * B[c] + A[3 + r] * B[3 + c] + A[6 + r] * B[6 + c];
+}
+
+} // namespace
+
+extern "C" void lvba_window_default_opts(lvba_window_opts *o)
+{
+    if (!o) return;
+    o->window_size = 10;     // include/dataset_io.h:71
+    o->use_rel = 1;          // config.yaml window_ba.use_window_ba_rel
+    o->anchor_leaf = 0.1;    // include/dataset_io.h:72
+    lvba_voxel_default_opts(&o->voxel);
+    o->voxel.voxel_size = 0.5; // stage1_root_voxel_size_, include/dataset_io.h:76
+    lvba_balm_default_opts(&o->lm);
+}
+
+extern "C" int32_t lvba_scans_info(lvba_scans_t sc, int32_t *n_frames, int64_t *frame_count)
+{
+    if (!sc) return lvba_fail(LVBA_ERR_ARG, "null handle");
+    if (n_frames) *n_frames = sc->n_frames;
+    if (frame_count)
+        for (int f = 0; f < sc->n_frames; ++f) frame_count[f] = sc->frame_off[f + 1] - sc->frame_off[f];
+    return LVBA_OK;
+}
+
+extern "C" int32_t lvba_scans_download(lvba_scans_t sc, int32_t frame, float *xyz)
+{
+    if (!sc || !xyz) return lvba_fail(LVBA_ERR_ARG, "null argument");
+    if (frame < 0 || frame >= sc->n_frames) return lvba_fail(LVBA_ERR_ARG, "frame %d out of range [0,%d)", frame, sc->n_frames);
+    HIPCHK(hipSetDevice(sc->device));
+    const int64_t n = sc->frame_off[frame + 1] - sc->frame_off[frame];
+    if (n > 0) HIPCHK(hipMemcpy(xyz, sc->d_pts + 3 * sc->frame_off[frame], 12 * (size_t)n, hipMemcpyDeviceToHost));
+    return LVBA_OK;
+}
+
+extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lvba_window_opts *opts, double *window_poses,
+                                  double *rel_poses, int32_t *anchor_index, double *anchor_poses, int32_t *n_anchors,
+                                  lvba_scans_t *anchor_scans, lvba_window_info *win_info)
+{
+    if (anchor_scans) *anchor_scans = nullptr;
+    if (!sc || !poses || !rel_poses || !anchor_index || !anchor_poses || !n_anchors || !anchor_scans)
+        return lvba_fail(LVBA_ERR_ARG, "null argument");
+    lvba_window_opts o;
+    lvba_window_default_opts(&o);
+    if (opts) o = *opts;
+    if (o.window_size < 1) return lvba_fail(LVBA_ERR_ARG, "window_size must be >= 1");
+    HIPCHK(hipSetDevice(sc->device));
+    const int n = sc->n_frames, w = o.window_size;
+    hipStream_t s = nullptr;
+    HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sguard{s};
+
+    static const double I12[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+    for (int i = 0; i < n; ++i) { // rel_poses_to_anchor_.assign(total, IMUST()), anchor_index -1 (:338-339)
+        memcpy(rel_poses + 12 * i, I12, sizeof I12);
+        anchor_index[i] = -1;
+    }
+    if (window_poses) memcpy(window_poses, poses, 96 * (size_t)n);
+
+    struct AnchorCloud { float *d; int64_t n; };
+    std::vector<AnchorCloud> clouds;
+    auto free_clouds = [&]() { for (auto &c : clouds) DevicePool::get().free(c.d); clouds.clear(); };
+    int wi = 0;
+    for (int start = 0; start < n; start += w, ++wi) {
+        const int cw = std::min(w, n - start);
+        lvba_window_info info{};
+        info.start = start; info.n_frames = cw; info.anchor = -1;
+        const double *x_odom = poses + 12 * (int64_t)start;
+        lvba_voxmap_t map = nullptr;
+        int32_t rc = lvba_voxmap_build_scans(sc, start, cw, x_odom, &o.voxel, &map);
+        if (rc != LVBA_OK) { free_clouds(); return rc; }
+        lvba_voxmap_info_t mi;
+        lvba_voxmap_info(map, &mi);
+        info.n_voxels = mi.n_voxels; info.n_factors = mi.n_factors;
+        if (mi.n_voxels < 3 * (int64_t)cw) { // :258-262
+            info.skipped = 1;
+            lvba_voxmap_destroy(map);
+            if (win_info) win_info[wi] = info;
+            continue;
+        }
+        std::vector<double> x(x_odom, x_odom + 12 * (size_t)cw);
+        {
+            lvba_balm_t b = nullptr;
+            rc = lvba_voxmap_to_balm(map, &b);
+            lvba_voxmap_destroy(map);
+            if (rc != LVBA_OK) { free_clouds(); return rc; }
+            std::vector<lvba_lm_trace> trace((size_t)std::max(1, o.lm.max_iter));
+            int32_t nt = 0;
+            rc = lvba_balm_refine(b, x.data(), &o.lm, trace.data(), &nt);
+            lvba_balm_destroy(b);
+            if (rc < 0) { free_clouds(); return rc; }
+            info.lm_status = rc; info.n_iter = nt;
+            if (nt > 0) {
+                info.cost_first = trace[0].residual1;
+                info.cost_last = trace[nt - 1].accepted ? trace[nt - 1].residual2 : trace[nt - 1].residual1;
+            }
+        }
+        if (window_poses) memcpy(window_poses + 12 * (int64_t)start, x.data(), 96 * (size_t)cw);
+        // alignment (:268-279) and relative poses (:284-299)
+        std::vector<double> rel(12 * (size_t)cw);
+        const double *Ro0 = x_odom, *po0 = x_odom + 9;
+        double R_align[9], p_align[3] = {0, 0, 0};
+        if (o.use_rel) {
+            mat3_mulT(Ro0, x.data(), R_align);
+            for (int r = 0; r < 3; ++r)
+                p_align[r] = po0[r] - (R_align[3 * r] * x[9] + R_align[3 * r + 1] * x[10] + R_align[3 * r + 2] * x[11]);
+        }
+        for (int j = 0; j < cw; ++j) {
+            double Ra[9], pa[3];
+            if (o.use_rel) {
+                const double *Rj = x.data() + 12 * j, *pj = Rj + 9;
+                mat3_mul(R_align, Rj, Ra);
+                for (int r = 0; r < 3; ++r)
+                    pa[r] = R_align[3 * r] * pj[0] + R_align[3 * r + 1] * pj[1] + R_align[3 * r + 2] * pj[2] + p_align[r];
+            } else {
+                memcpy(Ra, x_odom + 12 * j, 72);
+                memcpy(pa, x_odom + 12 * j + 9, 24);
+            }
+            double *rj = rel.data() + 12 * j;
+            mat3T_mul(Ro0, Ra, rj);
+            const double d[3] = {pa[0] - po0[0], pa[1] - po0[1], pa[2] - po0[2]};
+            for (int r = 0; r < 3; ++r) rj[9 + r] = Ro0[r] * d[0] + Ro0[3 + r] * d[1] + Ro0[6 + r] * d[2];
+            memcpy(rel_poses + 12 * (int64_t)(start + j), rj, 96);
+            anchor_index[start + j] = (int32_t)clouds.size();
+        }
+        // merge + down_sampling_voxel2 on the device
+        const int64_t p_begin = sc->frame_off[start], P = sc->frame_off[start + cw] - p_begin;
+        const bool down = o.anchor_leaf >= 0.001 && P > 0; // tools.hpp:303
+        float *d_out = nullptr;
+        int64_t n_out = P;
+        if (P > 0) {
+            DevBuf d_rel(s), merged(s), key(s), d2(s), idx(s), d_err(s);
+            HIPCHK(d_rel.alloc(96 * (size_t)cw)); HIPCHK(merged.alloc(12 * (size_t)P)); HIPCHK(d_err.alloc(4));
+            HIPCHK(hipMemcpyAsync(d_rel.p, rel.data(), 96 * (size_t)cw, hipMemcpyHostToDevice, s));
+            HIPCHK(hipMemsetAsync(d_err.p, 0, 4, s));
+            if (down) { HIPCHK(key.alloc(8 * (size_t)P)); HIPCHK(d2.alloc(8 * (size_t)P)); HIPCHK(idx.alloc(4 * (size_t)P)); }
+            wba_merge_kernel<<<grid_for(P, 256), 256, 0, s>>>(P, sc->d_pts + 3 * p_begin, sc->d_frame_off + start, cw, d_rel.as<double>(),
+                                                              o.anchor_leaf, merged.as<float>(), down ? key.as<uint64_t>() : nullptr,
+                                                              d2.as<double>(), idx.as<uint32_t>(), d_err.as<int>());
+            HIPCHK(hipGetLastError());
+            if (!down) {
+                HIPCHK(hipStreamSynchronize(s));
+                d_out = (float *)merged.release();
+            } else {
+                int err = 0;
+                HIPCHK(hipMemcpyAsync(&err, d_err.p, 4, hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+                if (err) { free_clouds(); return lvba_fail(LVBA_ERR_ARG, "window %d: a merged point is non-finite or outside +-2^20 anchor leaves", wi); }
+                DevBuf key_s(s), order(s), flag(s), excl(s), pick(s);
+                HIPCHK(key_s.alloc(8 * (size_t)P)); HIPCHK(order.alloc(4 * (size_t)P)); HIPCHK(flag.alloc(4 * ((size_t)P + 1)));
+                HIPCHK(excl.alloc(4 * ((size_t)P + 1))); HIPCHK(pick.alloc(4 * (size_t)P));
+                TRY(sort_pairs(s, key.as<uint64_t>(), key_s.as<uint64_t>(), idx.as<uint32_t>(), order.as<uint32_t>(), (size_t)P, 63));
+                wba_pick_kernel<<<grid_for(P, 256), 256, 0, s>>>(P, key_s.as<uint64_t>(), order.as<uint32_t>(), d2.as<double>(),
+                                                                 flag.as<uint32_t>(), pick.as<uint32_t>());
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipMemsetAsync(flag.as<uint32_t>() + P, 0, 4, s));
+                TRY(scan_excl<uint32_t>(s, flag.as<uint32_t>(), excl.as<uint32_t>(), (size_t)P + 1));
+                uint32_t cnt = 0;
+                HIPCHK(hipMemcpy(&cnt, excl.as<uint32_t>() + P, 4, hipMemcpyDeviceToHost));
+                n_out = cnt;
+                void *raw = nullptr;
+                HIPCHK(DevicePool::get().alloc(&raw, 12 * (size_t)std::max<int64_t>(n_out, 1)));
+                d_out = (float *)raw;
+                wba_compact_kernel<<<grid_for(P, 256), 256, 0, s>>>(P, flag.as<uint32_t>(), excl.as<uint32_t>(), pick.as<uint32_t>(),
+                                                                    merged.as<float>(), d_out);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipStreamSynchronize(s));
+            }
+        }
+        info.anchor = (int32_t)clouds.size();
+        info.n_anchor_points = n_out;
+        memcpy(anchor_poses + 12 * clouds.size(), x_odom, 96);
+        clouds.push_back({d_out, n_out});
+        if (win_info) win_info[wi] = info;
+    }
+
+    // the anchor clouds as a scan set of their own
+    lvba_scans_s *out = new (std::nothrow) lvba_scans_s();
+    if (!out) { free_clouds(); return lvba_fail(LVBA_ERR_NOMEM, "host allocation failed"); }
+    out->device = sc->device;
+    out->n_frames = (int)clouds.size();
+    out->frame_off.assign(clouds.size() + 1, 0);
+    for (size_t a = 0; a < clouds.size(); ++a) out->frame_off[a + 1] = out->frame_off[a] + clouds[a].n;
+    const int64_t PT = out->frame_off.back();
+    hipError_t e = hipMalloc((void **)&out->d_pts, PT ? 12 * (size_t)PT : 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&out->d_frame_off, 8 * (clouds.size() + 1));
+    for (size_t a = 0; a < clouds.size() && e == hipSuccess; ++a)
+        if (clouds[a].n > 0)
+            e = hipMemcpy(out->d_pts + 3 * out->frame_off[a], clouds[a].d, 12 * (size_t)clouds[a].n, hipMemcpyDeviceToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy(out->d_frame_off, out->frame_off.data(), 8 * (clouds.size() + 1), hipMemcpyHostToDevice);
+    free_clouds();
+    if (e != hipSuccess) {
+        lvba_scans_destroy(out);
+        return lvba_fail(e == hipErrorOutOfMemory ? LVBA_ERR_NOMEM : LVBA_ERR_DEVICE, "anchor scan set: %s", hipGetErrorString(e));
+    }
+    *n_anchors = out->n_frames;
+    *anchor_scans = out;
+    return LVBA_OK;
+}

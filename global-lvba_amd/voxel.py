@@ -85,6 +85,52 @@ class Scans:
     def __exit__(self, *a):
         self.close()
 
+    @classmethod
+    def _from_handle(cls, handle):
+        self = cls.__new__(cls)
+        self.lib = L.load()
+        self._h = handle
+        n = C.c_int32()
+        L.check(self.lib.lvba_scans_info(self._h, C.byref(n), None))
+        self.n_frames = n.value
+        self.counts = np.zeros(max(self.n_frames, 1), np.int64)
+        L.check(self.lib.lvba_scans_info(self._h, None, self.counts.ctypes.data))
+        self.counts = self.counts[:self.n_frames]
+        return self
+
+    def download(self, frame):
+        """Host copy [count, 3] fp32 of one frame."""
+        out = np.zeros((int(self.counts[frame]), 3), np.float32)
+        L.check(self.lib.lvba_scans_download(self._h, int(frame), out.reshape(-1) if out.size else np.zeros(1, np.float32)))
+        return out
+
+    def window_ba(self, poses, window_size=10, voxel_size=0.5, eigen_ratio_array=None, anchor_leaf=0.1, use_rel=True,
+                  min_points=None, **lm):
+        """LvbaSystem::runWindowBA (src/lvba_system.cpp:204-310) on the resident scans.  Returns dict(anchor_poses,
+        anchor_scans (a Scans), anchor_index, rel_poses, window_poses, windows)."""
+        n = self.n_frames
+        poses = np.ascontiguousarray(poses, np.float64).reshape(-1)
+        if poses.size != 12 * n:
+            raise ValueError(f"poses must hold {n} x 12 doubles")
+        o = L.WindowOpts()
+        self.lib.lvba_window_default_opts(C.byref(o))
+        o.window_size, o.use_rel, o.anchor_leaf = int(window_size), 1 if use_rel else 0, float(anchor_leaf)
+        o.voxel = _opts(voxel_size, eigen_ratio_array, min_points)
+        for k, v in lm.items():
+            setattr(o.lm, k, v)
+        nw = (n + o.window_size - 1) // o.window_size
+        window_poses = np.zeros((n, 12))
+        rel = np.zeros((n, 12))
+        aidx = np.zeros(n, np.int32)
+        aposes = np.zeros((max(nw, 1), 12))
+        na = C.c_int32()
+        h = C.c_void_p()
+        info = (L.WindowInfo * max(nw, 1))()
+        L.check(self.lib.lvba_window_ba(self._h, poses, C.byref(o), window_poses.ctypes.data, rel.reshape(-1), aidx,
+                                        aposes.reshape(-1), C.byref(na), C.byref(h), info))
+        return dict(anchor_poses=aposes[:na.value].copy(), anchor_scans=Scans._from_handle(h), anchor_index=aidx,
+                    rel_poses=rel, window_poses=window_poses, windows=[info[i].as_dict() for i in range(nw)])
+
     def voxel_map(self, poses, voxel_size=1.0, eigen_ratio_array=None, min_points=None, frame_begin=0, n_frames=None):
         """Map of frames [frame_begin, frame_begin + n_frames) at `poses` [n_frames, 12]."""
         n = self.n_frames - frame_begin if n_frames is None else int(n_frames)

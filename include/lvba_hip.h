@@ -296,6 +296,38 @@ int32_t lvba_voxmap_to_balm(lvba_voxmap_t h, lvba_balm_t *out);
 /* plane [n][4] = (unit normal, d = -n.centre) and valid [n] for n world points X [n][3]; invalid -> zeros. */
 int32_t lvba_voxmap_find_planes(lvba_voxmap_t h, int64_t n, const double *X, double *plane, uint8_t *valid);
 
+/* ---- window BA: raw scans + odometry -> anchor frames --------------------------------------------------------------
+ *   lvba_window_ba <- LvbaSystem::runWindowBA  src/lvba_system.cpp:204-310 : for every window of window_size frames the voxel
+ *   map at the odometry poses (:247-257), the "fewer than 3 plane voxels per frame -> skip" rule (:258-262), damping_iter
+ *   (:264), re-alignment of the optimised window to its first odometry pose (:268-279), relative poses to the anchor and the
+ *   merged cloud in the anchor frame with fp32 write-back (:284-299, pl_transform include/BALM/tools.hpp:385-395) and
+ *   down_sampling_voxel2 (tools.hpp:300-359; survivors come out sorted by voxel key, upstream order is unspecified).
+ * Outputs follow the reference's members: rel_poses [n][12] = rel_poses_to_anchor_ (identity for frames of skipped windows),
+ * anchor_index [n] = anchor_index_per_frame_ (-1 when skipped), anchor_poses [<= ceil(n/w)][12] = odometry pose of each
+ * window's first frame, anchor_scans = the merged, down-sampled clouds as a device-resident scan set (destroy with
+ * lvba_scans_destroy), window_poses [n][12] (may be NULL) = the optimised poses before re-alignment, win_info
+ * [ceil(n/w)] (may be NULL). */
+typedef struct {
+    int32_t window_size;    /* window_ba_size_ (10; config.yaml 20) */
+    int32_t use_rel;        /* use_window_ba_rel_ */
+    double anchor_leaf;     /* anchor_leaf_size_ (0.1; config.yaml 0.01); < 0.001 disables the down-sampling */
+    lvba_voxel_opts voxel;  /* stage1_root_voxel_size_ and the eigen_ratio_array in effect (bavoxel.hpp:17 until a stage sets it) */
+    lvba_balm_opts lm;
+} lvba_window_opts;
+typedef struct {
+    int32_t start, n_frames, skipped, anchor; /* anchor = index into anchor_poses / anchor_scans, -1 if skipped */
+    int32_t n_iter, lm_status;
+    int64_t n_voxels, n_factors, n_anchor_points;
+    double cost_first, cost_last;             /* averaged LiDAR cost before / after the window's damping_iter */
+} lvba_window_info;
+void lvba_window_default_opts(lvba_window_opts *opts);
+int32_t lvba_window_ba(lvba_scans_t scans, const double *poses, const lvba_window_opts *opts, double *window_poses,
+                       double *rel_poses, int32_t *anchor_index, double *anchor_poses, int32_t *n_anchors,
+                       lvba_scans_t *anchor_scans, lvba_window_info *win_info);
+/* Frame count and per-frame point counts of a scan set; host copy of one frame's xyz [count][3]. */
+int32_t lvba_scans_info(lvba_scans_t scans, int32_t *n_frames, int64_t *frame_count);
+int32_t lvba_scans_download(lvba_scans_t scans, int32_t frame, float *xyz);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,69 @@
+"""GPU parity test of the window-BA stage (lvba_window_ba) against oracle/window_oracle.py: same scans, same odometry.
+
+Per window: voxel counts and skip decisions exact; optimised poses / relative poses to 1e-7 (they inherit the LM parity
+of tests/test_gpu_balm.py); anchor clouds: the fp32 points that survive down_sampling_voxel2.  A relative pose that differs
+by 1e-9 can move a transformed coordinate across an fp32 rounding boundary, so clouds are compared as point sets with a
+1e-5 m tolerance and a 0.2 % budget for flipped survivors."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare_clouds(a, b):
+    assert abs(len(a) - len(b)) <= max(2, 0.002 * len(b))
+    # both are sorted by voxel key; match greedily through a KD-free trick: sort rows lexicographically after rounding
+    from scipy.spatial import cKDTree
+    d, _ = cKDTree(b).query(a, k=1)
+    assert np.mean(d > 1e-5) <= 0.002, float(np.mean(d > 1e-5))
+
+
+@pytest.mark.parametrize("use_rel", [True, False])
+@pytest.mark.parametrize("leaf", [0.05, 0.0])
+def test_window_ba_matches_oracle(pkg, synth, use_rel, leaf):
+    from oracle import window_oracle as wo
+    s = synth.make_scans(10, 8000, room=(10, 8, 4), origin=(-3.3, 7.1, 0.4), n_panels=8, seed=31, rot_sigma_deg=0.1,
+                         trans_sigma=0.03)
+    ratio = np.float32([0.3, 0.1, 0.06, 0.03])
+    ref = wo.run_window_ba(s["clouds"], s["poses"], 4, 1.0, ratio, leaf, use_rel)
+    with pkg.Scans(s["clouds"]) as scans:
+        got = scans.window_ba(s["poses"], window_size=4, voxel_size=1.0, eigen_ratio_array=ratio, anchor_leaf=leaf,
+                              use_rel=use_rel)
+    assert len(got["windows"]) == len(ref["windows"]) == 3
+    for g, r in zip(got["windows"], ref["windows"]):
+        assert (g["start"], g["n_frames"], g["n_voxels"], bool(g["skipped"])) == (r["start"], r["n"], r["n_voxels"], r["skipped"])
+        assert g["n_iter"] == len(r["trace"])
+        assert abs(g["cost_first"] - r["trace"][0][1]) <= 1e-9 * r["trace"][0][1]
+    np.testing.assert_array_equal(got["anchor_index"], ref["anchor_index"])
+    assert np.abs(got["window_poses"] - ref["window_poses"]).max() < 1e-7
+    assert np.abs(got["rel_poses"] - ref["rel_poses"]).max() < 1e-7
+    np.testing.assert_array_equal(got["anchor_poses"], ref["anchor_poses"])
+    asc = got["anchor_scans"]
+    assert asc.n_frames == len(ref["anchor_clouds"])
+    for a in range(asc.n_frames):
+        _compare_clouds(asc.download(a), ref["anchor_clouds"][a])
+    # the LM did something: the optimised windows moved away from the odometry
+    assert np.abs(got["window_poses"] - s["poses"]).max() > 1e-4
+    # the anchors feed the global stage directly: a map over the anchor clouds builds and refines
+    with asc.voxel_map(got["anchor_poses"], 1.0) as m:
+        assert m.info["n_voxels"] > 50
+    asc.close()
+
+
+def test_window_skip_rule_and_identity_rel(pkg, synth):
+    """A window with fewer than 3 plane voxels per frame is skipped: no anchor, index -1, identity relative pose."""
+    s = synth.make_scans(4, 4000, room=(8, 6, 3), n_panels=4, seed=5)
+    rng = np.random.default_rng(0)
+    clouds = list(s["clouds"])
+    clouds[2] = rng.uniform(-1, 1, (300, 3)).astype(np.float32)        # window 1 = frames 2,3: volume noise only
+    clouds[3] = rng.uniform(-1, 1, (300, 3)).astype(np.float32)
+    with pkg.Scans(clouds) as scans:
+        got = scans.window_ba(s["poses"], window_size=2, voxel_size=1.0, anchor_leaf=0.05)
+    w = got["windows"]
+    assert not w[0]["skipped"] and w[1]["skipped"] and w[1]["anchor"] == -1
+    assert got["anchor_index"].tolist() == [0, 0, -1, -1]
+    I12 = np.concatenate([np.eye(3).reshape(-1), np.zeros(3)])
+    np.testing.assert_array_equal(got["rel_poses"][2:], np.tile(I12, (2, 1)))
+    np.testing.assert_array_equal(got["window_poses"][2:], s["poses"][2:])
+    assert got["anchor_scans"].n_frames == 1
+    got["anchor_scans"].close()
