@@ -21,6 +21,7 @@ SYMBOLS = [
     "lvba_voxel_default_opts", "lvba_voxmap_build", "lvba_voxmap_destroy", "lvba_voxmap_info", "lvba_voxmap_export",
     "lvba_voxmap_to_balm", "lvba_voxmap_find_planes", "lvba_scans_create", "lvba_scans_destroy", "lvba_voxmap_build_scans",
     "lvba_release_cached_memory", "lvba_window_default_opts", "lvba_window_ba", "lvba_scans_info", "lvba_scans_download",
+    "lvba_lidar_ba_default_opts", "lvba_lidar_ba",
 ]
 
 OK, ERR_ARG, ERR_DEVICE, ERR_NOMEM, ERR_UNSUPPORTED, ERR_DIST, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
@@ -94,6 +95,26 @@ class WindowInfo(C.Structure):
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}
+
+
+class LidarBaOpts(C.Structure):
+    _fields_ = [("window", WindowOpts), ("window_enable", C.c_int32), ("stage1_enable", C.c_int32),
+                ("stage_voxel_size", C.c_double * 2), ("stage_eigen_ratio", (C.c_float * 4) * 2), ("lm", BalmOpts)]
+
+
+class LidarBaReport(C.Structure):
+    _fields_ = [("n_frames", C.c_int32), ("n_windows", C.c_int32), ("n_windows_skipped", C.c_int32), ("n_anchors", C.c_int32),
+                ("stage_ran", C.c_int32 * 2), ("stage_iters", C.c_int32 * 2), ("stage_status", C.c_int32 * 2),
+                ("reserved", C.c_int32), ("stage_voxels", C.c_int64 * 2), ("stage_factors", C.c_int64 * 2),
+                ("stage_cost_first", C.c_double * 2), ("stage_cost_last", C.c_double * 2), ("window_ms", C.c_double),
+                ("stage_ms", C.c_double * 2)]
+
+    def as_dict(self):
+        out = {}
+        for f, t in self._fields_:
+            v = getattr(self, f)
+            out[f] = list(v) if hasattr(v, "__len__") else v
+        return out
 
 
 TERMINATION = {0: "NO_CONVERGENCE", 1: "CONVERGENCE(function)", 2: "CONVERGENCE(parameter)", 3: "CONVERGENCE(gradient)",
@@ -172,6 +193,9 @@ def load():
     lib.lvba_window_default_opts.restype = None
     lib.lvba_window_ba.argtypes = [H, f64p, C.POINTER(WindowOpts), C.c_void_p, f64p, i32p, f64p, C.POINTER(C.c_int32),
                                    C.POINTER(H), C.POINTER(WindowInfo)]
+    lib.lvba_lidar_ba_default_opts.argtypes = [C.POINTER(LidarBaOpts)]
+    lib.lvba_lidar_ba_default_opts.restype = None
+    lib.lvba_lidar_ba.argtypes = [H, f64p, C.POINTER(LidarBaOpts), f64p, C.POINTER(LidarBaReport)]
     lib.lvba_scans_info.argtypes = [H, C.POINTER(C.c_int32), C.c_void_p]
     lib.lvba_scans_download.argtypes = [H, C.c_int32, np.ctypeslib.ndpointer(np.float32, flags="C")]
     for name in SYMBOLS:

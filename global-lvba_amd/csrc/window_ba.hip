@@ -302,3 +302,91 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
     *anchor_scans = out;
     return LVBA_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LvbaSystem::runLidarBA (src/lvba_system.cpp:312-410) without the ROS/visualisation calls: window BA -> anchors, then the
+// global stages (stage 1 optional, stage 2) each re-cutting the anchor clouds at the current anchor poses with that stage's
+// voxel size / eigen ratios and running damping_iter over all anchors, then every frame's pose = anchor o rel (:393-404).
+extern "C" void lvba_lidar_ba_default_opts(lvba_lidar_ba_opts *o)
+{
+    if (!o) return;
+    lvba_window_default_opts(&o->window);
+    o->window_enable = 1;                                        // include/dataset_io.h:70
+    o->stage1_enable = 1;                                        // include/dataset_io.h:75
+    o->stage_voxel_size[0] = 0.5; o->stage_voxel_size[1] = 0.5;  // include/dataset_io.h:76,79
+    const float r1[4] = {0.3f, 0.1f, 0.06f, 0.03f}, r2[4] = {0.08f, 0.08f, 0.08f, 0.08f}; // :77,:80
+    for (int k = 0; k < 4; ++k) { o->stage_eigen_ratio[0][k] = r1[k]; o->stage_eigen_ratio[1][k] = r2[k]; }
+    lvba_balm_default_opts(&o->lm);
+}
+
+extern "C" int32_t lvba_lidar_ba(lvba_scans_t sc, const double *poses_in, const lvba_lidar_ba_opts *opts, double *poses_out,
+                                 lvba_lidar_ba_report *rep)
+{
+    if (!sc || !poses_in || !poses_out) return lvba_fail(LVBA_ERR_ARG, "null argument");
+    lvba_lidar_ba_opts o;
+    lvba_lidar_ba_default_opts(&o);
+    if (opts) o = *opts;
+    const int n = sc->n_frames;
+    lvba_lidar_ba_report r{};
+    r.n_frames = n;
+    std::vector<double> rel(12 * (size_t)n), anchor_poses;
+    std::vector<int32_t> aidx((size_t)n);
+    lvba_scans_t anchors = nullptr;
+    int32_t na = 0;
+    double t0 = now_ms();
+    if (o.window_enable) {
+        const int nw = (n + o.window.window_size - 1) / std::max(1, o.window.window_size);
+        anchor_poses.resize(12 * (size_t)std::max(nw, 1));
+        std::vector<lvba_window_info> wi((size_t)std::max(nw, 1));
+        TRY(lvba_window_ba(sc, poses_in, &o.window, nullptr, rel.data(), aidx.data(), anchor_poses.data(), &na, &anchors, wi.data()));
+        r.n_windows = nw;
+        for (int k = 0; k < nw; ++k) r.n_windows_skipped += wi[k].skipped;
+    } else { // :221-229: every frame is its own anchor
+        static const double I12[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+        anchor_poses.assign(poses_in, poses_in + 12 * (size_t)n);
+        for (int i = 0; i < n; ++i) { memcpy(rel.data() + 12 * i, I12, sizeof I12); aidx[i] = i; }
+        na = n;
+    }
+    r.n_anchors = na;
+    r.window_ms = now_ms() - t0;
+    struct AnchorGuard { lvba_scans_t a; ~AnchorGuard() { lvba_scans_destroy(a); } } guard{anchors};
+    lvba_scans_t cut = o.window_enable ? anchors : sc;
+    if (na > 0)
+        for (int idx = o.stage1_enable ? 0 : 1; idx < 2; ++idx) {
+            t0 = now_ms();
+            lvba_voxel_opts vo = o.window.voxel;
+            vo.voxel_size = o.stage_voxel_size[idx];
+            for (int k = 0; k < 4; ++k) vo.eigen_ratio[k] = o.stage_eigen_ratio[idx][k];
+            lvba_voxmap_t map = nullptr;
+            TRY(lvba_voxmap_build_scans(cut, 0, na, anchor_poses.data(), &vo, &map));
+            lvba_voxmap_info_t mi;
+            lvba_voxmap_info(map, &mi);
+            r.stage_voxels[idx] = mi.n_voxels; r.stage_factors[idx] = mi.n_factors; r.stage_ran[idx] = 1;
+            lvba_balm_t b = nullptr;
+            int32_t rc = lvba_voxmap_to_balm(map, &b);
+            lvba_voxmap_destroy(map);
+            if (rc != LVBA_OK) return rc;
+            std::vector<lvba_lm_trace> trace((size_t)std::max(1, o.lm.max_iter));
+            int32_t nt = 0;
+            rc = lvba_balm_refine(b, anchor_poses.data(), &o.lm, trace.data(), &nt);
+            lvba_balm_destroy(b);
+            if (rc < 0) return rc;
+            r.stage_status[idx] = rc; r.stage_iters[idx] = nt;
+            if (nt > 0) {
+                r.stage_cost_first[idx] = trace[0].residual1;
+                r.stage_cost_last[idx] = trace[nt - 1].accepted ? trace[nt - 1].residual2 : trace[nt - 1].residual1;
+            }
+            r.stage_ms[idx] = now_ms() - t0;
+        }
+    memcpy(poses_out, poses_in, 96 * (size_t)n); // optimized_x_buf_ = x_buf_full (:393)
+    for (int i = 0; i < n; ++i) {
+        const int a = aidx[i];
+        if (a < 0 || a >= na) continue;
+        const double *A = anchor_poses.data() + 12 * (size_t)a, *L = rel.data() + 12 * (size_t)i;
+        double *O = poses_out + 12 * (size_t)i;
+        mat3_mul(A, L, O);
+        for (int q = 0; q < 3; ++q) O[9 + q] = A[3 * q] * L[9] + A[3 * q + 1] * L[10] + A[3 * q + 2] * L[11] + A[9 + q];
+    }
+    if (rep) *rep = r;
+    return LVBA_OK;
+}

@@ -131,6 +131,29 @@ class Scans:
         return dict(anchor_poses=aposes[:na.value].copy(), anchor_scans=Scans._from_handle(h), anchor_index=aidx,
                     rel_poses=rel, window_poses=window_poses, windows=[info[i].as_dict() for i in range(nw)])
 
+    def lidar_ba(self, poses, window_enable=True, window_size=10, anchor_leaf=0.1, use_rel=True, stage1_enable=True,
+                 stage_voxel_size=(0.5, 0.5), stage_eigen_ratio=((0.3, 0.1, 0.06, 0.03), (0.08, 0.08, 0.08, 0.08)),
+                 window_eigen_ratio=None):
+        """LvbaSystem::runLidarBA (src/lvba_system.cpp:312-410): window BA, global stage 1 / stage 2, pose composition.
+        Returns (poses [n,12], report dict)."""
+        n = self.n_frames
+        poses = np.ascontiguousarray(poses, np.float64).reshape(-1)
+        if poses.size != 12 * n:
+            raise ValueError(f"poses must hold {n} x 12 doubles")
+        o = L.LidarBaOpts()
+        self.lib.lvba_lidar_ba_default_opts(C.byref(o))
+        o.window_enable, o.stage1_enable = int(bool(window_enable)), int(bool(stage1_enable))
+        o.window.window_size, o.window.use_rel, o.window.anchor_leaf = int(window_size), int(bool(use_rel)), float(anchor_leaf)
+        o.window.voxel = _opts(stage_voxel_size[0], window_eigen_ratio, None)   # stage1_root_voxel_size_, ratios in effect
+        for i in range(2):
+            o.stage_voxel_size[i] = float(stage_voxel_size[i])
+            for k in range(4):
+                o.stage_eigen_ratio[i][k] = float(stage_eigen_ratio[i][k])
+        out = np.zeros(12 * n)
+        rep = L.LidarBaReport()
+        L.check(self.lib.lvba_lidar_ba(self._h, poses, C.byref(o), out, C.byref(rep)))
+        return out.reshape(n, 12), rep.as_dict()
+
     def voxel_map(self, poses, voxel_size=1.0, eigen_ratio_array=None, min_points=None, frame_begin=0, n_frames=None):
         """Map of frames [frame_begin, frame_begin + n_frames) at `poses` [n_frames, 12]."""
         n = self.n_frames - frame_begin if n_frames is None else int(n_frames)

@@ -170,4 +170,42 @@ class VoxelMap {
     lvba_voxmap_t h_ = nullptr;
 };
 
+// Drop-in for the compute of LvbaSystem::runLidarBA (src/lvba_system.cpp:312-410): window BA -> anchors -> global stage 1 /
+// stage 2 -> composed frame poses.  x_buf is refined in place (what the reference stores into dataset_io_->x_buf_, :406).
+//       lvba_lidar_ba_opts o; lvba_lidar_ba_default_opts(&o);   // then copy window_ba_size_, anchor_leaf_size_, stage sizes ...
+//       lvba::lidar_ba(dataset_io_->pl_fulls_, dataset_io_->x_buf_, o);
+template <class CloudPtrVec, class PoseVec>
+lvba_lidar_ba_report lidar_ba(const CloudPtrVec &clouds, PoseVec &x_buf, const lvba_lidar_ba_opts &opts, int device = 0)
+{
+    const int32_t n = static_cast<int32_t>(x_buf.size());
+    std::vector<const void *> ptr(n);
+    std::vector<int64_t> cnt(n);
+    int32_t stride = 12;
+    for (int32_t j = 0; j < n; ++j) {
+        const auto &pts = clouds[j]->points;
+        ptr[j] = pts.data();
+        cnt[j] = static_cast<int64_t>(pts.size());
+        stride = static_cast<int32_t>(sizeof(pts[0]));
+    }
+    std::vector<double> poses(12 * static_cast<size_t>(n));
+    for (int32_t j = 0; j < n; ++j) {
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) poses[12 * j + 3 * r + c] = x_buf[j].R(r, c);
+        for (int r = 0; r < 3; ++r) poses[12 * j + 9 + r] = x_buf[j].p[r];
+    }
+    lvba_scans_t scans = nullptr;
+    if (lvba_scans_create(device, n, ptr.data(), cnt.data(), stride, &scans) != LVBA_OK)
+        throw std::runtime_error(std::string("lvba_scans_create: ") + lvba_last_error());
+    lvba_lidar_ba_report rep;
+    const int32_t rc = lvba_lidar_ba(scans, poses.data(), &opts, poses.data(), &rep);
+    lvba_scans_destroy(scans);
+    if (rc != LVBA_OK) throw std::runtime_error(std::string("lvba_lidar_ba: ") + lvba_last_error());
+    for (int32_t j = 0; j < n; ++j) {
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) x_buf[j].R(r, c) = poses[12 * j + 3 * r + c];
+        for (int r = 0; r < 3; ++r) x_buf[j].p[r] = poses[12 * j + 9 + r];
+    }
+    return rep;
+}
+
 } // namespace lvba

@@ -324,6 +324,30 @@ void lvba_window_default_opts(lvba_window_opts *opts);
 int32_t lvba_window_ba(lvba_scans_t scans, const double *poses, const lvba_window_opts *opts, double *window_poses,
                        double *rel_poses, int32_t *anchor_index, double *anchor_poses, int32_t *n_anchors,
                        lvba_scans_t *anchor_scans, lvba_window_info *win_info);
+/* ---- the whole LiDAR stage -------------------------------------------------------------------------------------------
+ *   lvba_lidar_ba <- LvbaSystem::runLidarBA  src/lvba_system.cpp:312-410 (compute only): window BA (or, with
+ *   window_enable = 0, every frame its own anchor, :221-229), then for stage 1 (optional) and stage 2 the voxel map of the
+ *   anchor clouds at the current anchor poses with that stage's root voxel size and eigen_ratio_array (:356-377) and
+ *   damping_iter over all anchors (:386), finally pose_i = anchor(anchor_index_i) o rel_i for every frame (:393-404; frames of
+ *   skipped windows keep their input pose).  poses_in / poses_out [n][12] may alias. */
+typedef struct {
+    lvba_window_opts window;
+    int32_t window_enable, stage1_enable;
+    double stage_voxel_size[2];
+    float stage_eigen_ratio[2][4];
+    lvba_balm_opts lm;           /* damping_iter options of the global stages */
+} lvba_lidar_ba_opts;
+typedef struct {
+    int32_t n_frames, n_windows, n_windows_skipped, n_anchors;
+    int32_t stage_ran[2], stage_iters[2], stage_status[2], reserved;
+    int64_t stage_voxels[2], stage_factors[2];
+    double stage_cost_first[2], stage_cost_last[2];
+    double window_ms, stage_ms[2];  /* host wall clock */
+} lvba_lidar_ba_report;
+void lvba_lidar_ba_default_opts(lvba_lidar_ba_opts *opts);
+int32_t lvba_lidar_ba(lvba_scans_t scans, const double *poses_in, const lvba_lidar_ba_opts *opts, double *poses_out,
+                      lvba_lidar_ba_report *report);
+
 /* Frame count and per-frame point counts of a scan set; host copy of one frame's xyz [count][3]. */
 int32_t lvba_scans_info(lvba_scans_t scans, int32_t *n_frames, int64_t *frame_count);
 int32_t lvba_scans_download(lvba_scans_t scans, int32_t frame, float *xyz);

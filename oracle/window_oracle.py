@@ -84,3 +84,34 @@ def run_window_ba(clouds, poses, window_size, voxel_size, eigen_ratio, anchor_le
         anchor_clouds.append(merged[keep])
     return dict(anchor_poses=np.asarray(anchor_poses).reshape(-1, 12), anchor_clouds=anchor_clouds,
                 anchor_index=anchor_index, rel_poses=rel_poses, window_poses=window_poses, windows=windows)
+
+
+def run_lidar_ba(clouds, poses, *, window_enable=True, window_size=10, anchor_leaf=0.1, use_rel=True, stage1_enable=True,
+                 stage_voxel_size=(0.5, 0.5), stage_eigen_ratio=((0.3, 0.1, 0.06, 0.03), (0.08, 0.08, 0.08, 0.08)),
+                 window_eigen_ratio=(0.3, 0.1, 0.06, 0.03)):
+    """LvbaSystem::runLidarBA (src/lvba_system.cpp:312-410), compute only.  Returns (poses [n,12], report dict)."""
+    import oracle
+    n = len(clouds)
+    poses = np.asarray(poses, np.float64).reshape(n, 12)
+    if window_enable:
+        w = run_window_ba(clouds, poses, window_size, stage_voxel_size[0], np.float32(window_eigen_ratio), anchor_leaf, use_rel)
+        anchor_poses, anchor_clouds, aidx, rel = w["anchor_poses"].copy(), w["anchor_clouds"], w["anchor_index"], w["rel_poses"]
+    else:                                                                  # :221-229
+        I12 = np.concatenate([np.eye(3).reshape(-1), np.zeros(3)])
+        anchor_poses, anchor_clouds = poses.copy(), [np.asarray(c, f32)[:, :3] for c in clouds]
+        aidx, rel = np.arange(n, dtype=np.int32), np.tile(I12, (n, 1))
+    report = dict(n_anchors=len(anchor_clouds), stages=[])
+    for idx in range(0 if stage1_enable else 1, 2):                        # :356-389
+        vm = oracle.voxel_build_cpp(anchor_clouds, anchor_poses, stage_voxel_size[idx], np.float32(stage_eigen_ratio[idx]))
+        co = oracle.COracle(len(anchor_clouds), vm["off"], vm["idx"], vm["clu"])
+        anchor_poses, trace, rc = co.damping_iter(anchor_poses)
+        report["stages"].append(dict(stage=idx, n_voxels=len(vm["off"]) - 1, trace=trace))
+    out = poses.copy()                                                     # :393-404
+    for i in range(n):
+        a = aidx[i]
+        if a < 0:
+            continue
+        A, Lr = anchor_poses[a], rel[i]
+        R = A[:9].reshape(3, 3) @ Lr[:9].reshape(3, 3)
+        out[i] = np.concatenate([R.reshape(-1), A[:9].reshape(3, 3) @ Lr[9:] + A[9:]])
+    return out, report

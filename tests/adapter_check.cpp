@@ -61,6 +61,21 @@ int main()
         std::printf("refused: %s\n", e.what());
         if (!(lvba_device_count() == 0 && std::strstr(e.what(), "no CPU fallback"))) return 5;
     }
+    try { // whole LiDAR stage through the adapter: two windows of one frame pair each
+        std::vector<const Cloud *> four{&c0, &c1, &c0, &c1};
+        std::vector<IMUST> x4(4);
+        for (auto &s : x4) { std::memset(&s, 0, sizeof s); s.R(0, 0) = s.R(1, 1) = s.R(2, 2) = 1; }
+        lvba_lidar_ba_opts lo;
+        lvba_lidar_ba_default_opts(&lo);
+        lo.window.window_size = 2;
+        lo.window.voxel.voxel_size = 1.0; lo.stage_voxel_size[0] = lo.stage_voxel_size[1] = 1.0;
+        const auto rep = lvba::lidar_ba(four, x4, lo);
+        std::printf("lidar_ba on the GPU: %d windows, %d skipped, %d anchors\n", rep.n_windows, rep.n_windows_skipped, rep.n_anchors);
+        if (rep.n_windows != 2 || rep.n_frames != 4) return 6;
+    } catch (const std::exception &e) {
+        std::printf("refused: %s\n", e.what());
+        if (!(lvba_device_count() == 0 && std::strstr(e.what(), "no CPU fallback"))) return 7;
+    }
     try {
         auto trace = lvba::damping_iter_hip(x, vh);
         std::printf("refined on the GPU: %zu LM iterations\n", trace.size());

@@ -67,3 +67,32 @@ def test_window_skip_rule_and_identity_rel(pkg, synth):
     np.testing.assert_array_equal(got["window_poses"][2:], s["poses"][2:])
     assert got["anchor_scans"].n_frames == 1
     got["anchor_scans"].close()
+
+
+@pytest.mark.parametrize("window_enable", [True, False])
+def test_lidar_ba_pipeline_matches_oracle(pkg, synth, window_enable):
+    """lvba_lidar_ba = runLidarBA's compute: window BA -> anchors -> stage 1 -> stage 2 -> composed frame poses."""
+    from oracle import window_oracle as wo
+    s = synth.make_scans(12, 8000, room=(10, 8, 4), origin=(-3.3, 7.1, 0.4), n_panels=8, seed=41, rot_sigma_deg=0.1,
+                         trans_sigma=0.03)
+    kw = dict(window_enable=window_enable, window_size=4, anchor_leaf=0.05, stage_voxel_size=(1.0, 0.5))
+    ref, rrep = wo.run_lidar_ba(s["clouds"], s["poses"], **kw)
+    with pkg.Scans(s["clouds"]) as scans:
+        got, rep = scans.lidar_ba(s["poses"], **kw)
+    assert rep["n_anchors"] == rrep["n_anchors"] == (3 if window_enable else 12)
+    for st in rrep["stages"]:
+        i = st["stage"]
+        assert rep["stage_ran"][i] == 1
+        if window_enable:
+            # anchor clouds may differ by a few fp32 survivors (see above): voxel counts agree to a fraction of a percent
+            assert abs(rep["stage_voxels"][i] - st["n_voxels"]) <= max(3, 0.01 * st["n_voxels"])
+        else:
+            assert rep["stage_voxels"][i] == st["n_voxels"]
+            assert rep["stage_iters"][i] == len(st["trace"])
+            assert abs(rep["stage_cost_first"][i] - st["trace"][0][1]) <= 1e-9 * st["trace"][0][1]
+    tol = 1e-7 if not window_enable else 2e-4      # with windows, the stages see slightly different anchor clouds
+    assert np.abs(got - ref).max() < tol
+    # and the pipeline improved the trajectory: closer to ground truth than the odometry it started from
+    def err(x):
+        return np.abs(x[:, 9:] - s["poses_gt"][:, 9:]).mean()
+    assert err(got) < err(s["poses"])
