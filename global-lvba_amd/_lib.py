@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "liblvba_hip.so")
+LIB_PATH = os.environ.get("LVBA_HIP_LIB") or os.path.join(HERE, "liblvba_hip.so")  # override: A/B runs of two builds
 
 # every extern "C" symbol include/lvba_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
