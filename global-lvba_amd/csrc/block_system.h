@@ -13,7 +13,7 @@ namespace lvba {
 
 struct BlockSys {
     int device = 0;
-    hipStream_t stream = nullptr, stream2 = nullptr;
+    hipStream_t stream = nullptr;
     int32_t N = 0;
     int64_t G = 0, F = 0, Q = 0;
     // configuration
@@ -38,7 +38,6 @@ struct BlockSys {
     LdltMat A{};
     double *d_A = nullptr, *d_work = nullptr, *d_dx = nullptr, *d_u = nullptr, *h_pin_u = nullptr;
     int *d_status = nullptr;
-    std::vector<hipEvent_t> evA, evB;
     hipGraph_t solve_graph = nullptr;
     hipGraphExec_t solve_exec = nullptr;
     bool graph_tried = false;

@@ -370,26 +370,16 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
     }
     bs.A.a = bs.d_A;
     TRY(bs_dmalloc(bs, &bs.d_work, ldlt_workspace_doubles(n, bs.A.bw)));
-    if (!getenv("LVBA_NO_LOOKAHEAD")) {
-        HIPCHK(hipStreamCreateWithFlags(&bs.stream2, hipStreamNonBlocking));
-        const int64_t np = ldlt_num_panels(n);
-        bs.evA.resize(np); bs.evB.resize(np);
-        for (int64_t i = 0; i < np; ++i) {
-            HIPCHK(hipEventCreateWithFlags(&bs.evA[i], hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&bs.evB[i], hipEventDisableTiming));
-        }
-    }
     HIPCHK(hipMemset(bs.d_hg, 0, (size_t)bs.hg_doubles() * sizeof(double)));
     bs.built = true;
     return LVBA_OK;
 }
 
-// The launch sequence of one solve is static per BlockSys (~5 kernels per 64-column panel on two streams), so it
+// The launch sequence of one solve is static per BlockSys (3 kernels per 64-column panel + 1 for the backward pass), so it
 // is captured once into a hipGraph and replayed; u is read from device memory.
 static void solve_launches(BlockSys &bs)
 {
-    ldlt_solve(bs.A, bs.Hblk(), bs.Bb, bs.N, bs.g(), bs.d_u, bs.d_dx, bs.d_work, bs.d_status, bs.stream, bs.stream2,
-               bs.evA.empty() ? nullptr : bs.evA.data(), bs.evB.empty() ? nullptr : bs.evB.data());
+    ldlt_solve(bs.A, bs.Hblk(), bs.Bb, bs.N, bs.g(), bs.d_u, bs.d_dx, bs.d_work, bs.d_status, bs.stream);
 }
 
 int32_t bs_enqueue_solve(BlockSys &bs, double u)
@@ -424,18 +414,14 @@ void bs_destroy(BlockSys &bs)
 {
     hipSetDevice(bs.device);
     if (bs.stream) hipStreamSynchronize(bs.stream);
-    if (bs.stream2) hipStreamSynchronize(bs.stream2);
     if (bs.comm && g_rccl.CommDestroy) g_rccl.CommDestroy(bs.comm);
     if (bs.solve_exec) hipGraphExecDestroy(bs.solve_exec);
     if (bs.solve_graph) hipGraphDestroy(bs.solve_graph);
-    for (hipEvent_t e : bs.evA) hipEventDestroy(e);
-    for (hipEvent_t e : bs.evB) hipEventDestroy(e);
     void *ptrs[] = {bs.d_perm, bs.d_csc_off, bs.d_blk_off, bs.d_blk_slot, bs.d_group_of_pos, bs.d_csc_f, bs.d_pos_of,
                     bs.d_pairs, bs.d_Y, bs.d_hg, bs.d_A, bs.d_work, bs.d_dx, bs.d_u, bs.d_status};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (bs.h_pin_u) hipHostFree(bs.h_pin_u);
-    if (bs.stream2) hipStreamDestroy(bs.stream2);
     if (bs.stream) hipStreamDestroy(bs.stream);
     bs = BlockSys();
 }

@@ -8,15 +8,15 @@
 // the band only limits the row window [k+NB, k+NB+bw) each panel touches.
 //
 //   per panel k:
-//     K1 ldlt_diag    1 workgroup, 2 wavefronts, barrier-free: LDL^T of the 64x64 diagonal block, register-resident.
-//                     An identity is appended as extra ROWS, so the same elimination yields G = L11^-T D^-1,
-//                     which turns every later triangular solve with this block into a product.
+//     K1 ldlt_diag    1 workgroup: LDL^T of the 64x64 diagonal block.  An identity is appended as extra ROWS, so the
+//                     same elimination yields G = L11^-T D^-1, which turns every later triangular solve with this block
+//                     into a product.  Default: 16-column blocked form (serial chain inside one wavefront's registers,
+//                     panel / trailing steps on fp64 MFMA); LVBA_K1=rowwise selects the earlier row-per-lane form.
 //     K2 ldlt_panel   per 64-row tile: L21 = A21 * G (fp64 MFMA 16x16x4), Z = L21*D, y_k = D G^T b_k, b -= L21*y_k.
 //     K3 ldlt_update  per 64x64 lower tile of the window: A22 -= L21 * Z^T (fp64 MFMA 16x16x4).
 //   backward, per panel from the last: x_k = G D (G^T b_k - acc_k), then acc[c] += A(k:k+64, c)^T x_k
 //   for the <= bw columns left of the panel (right-looking, one launch per panel).
-//   Look-ahead: the bulk of K3 (tile columns >= 1) runs on a second stream beside K3(first column), K1, K2 of
-//   the next panel; the whole static launch sequence is captured once into a hipGraph (lvba_api.hip).
+//   The whole static launch sequence is captured once into a hipGraph (block_system.hip).
 //
 // MFMA operand layout used (v_mfma_f64_16x16x4_f64): lane l supplies A[i=l&15][k=l>>4] and
 // B[k=l>>4][j=l&15]; result register r of lane l is D[(l>>4)+4r][l&15].  Products are arranged so that
@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <utility>
+#include <stdlib.h>
+#include <string.h>
 #include "lvba_internal.h"
 
 namespace lvba {
@@ -74,11 +76,14 @@ __device__ __forceinline__ double fast_rcp(double d)
 }
 
 #ifdef LVBA_K1_TIMING
+__device__ unsigned long long g_k1b_clk[16];
+#define LVBA_K1B_STAMP(i) do { if (threadIdx.x == 0) g_k1b_clk[i] = __builtin_readcyclecounter(); } while (0)
 __device__ unsigned long long g_k1_clk[8];
 __device__ unsigned long long g_k1_step[2][64];
 #define LVBA_K1_STAMP(i) do { if (threadIdx.x == 0) g_k1_clk[i] = __builtin_readcyclecounter(); } while (0)
 #define LVBA_K1_STEPSTAMP(role, j) do { if ((threadIdx.x & 63) == 0) g_k1_step[role][j] = __builtin_readcyclecounter(); } while (0)
 #else
+#define LVBA_K1B_STAMP(i)
 #define LVBA_K1_STAMP(i)
 #define LVBA_K1_STEPSTAMP(role, j)
 #endif
@@ -258,6 +263,147 @@ __global__ __launch_bounds__(128) void ldlt_diag_kernel(LdltMat M, int64_t k, in
     LVBA_K1_STAMP(3);
 }
 
+// ------------------------------------------------------------------------------------------ K1, blocked
+// The same factorisation (d, G = L11^-T D^-1) as ldlt_diag_kernel, organised so that the serial chain only ever spans a
+// 16x16 block held in ONE wavefront's registers: the 64x64 block and the 64 appended identity rows live in LDS
+// (W[128][64]); per 16-column block step
+//   diag   wave 0: lanes 0..15 hold the block's rows, lanes 16..31 the matching identity rows; 16 compile-time steps, the
+//          pivot row reaches the other lanes through v_readlane (no LDS round trip, no barrier); yields d, the block's
+//          G rows and G11 = L11^-T D11^-1;
+//   panel  3 waves: the 48 rows below / left over (block rows still to come + identity rows of finished blocks) times G11,
+//          fp64 MFMA 16x16x4 -- a triangular solve turned into a product, as everywhere else in this file;
+//   update 4 waves: trailing 64 x (48 - 16 s) block -= X (X D)^T, fp64 MFMA.
+// 64 pivots still follow one another, but each costs ~(16 - j) readlane+FMA pairs instead of an LDS publish / flag /
+// read-back of a 64-entry column.
+#define LVBA_W1S 130 // column stride of W (doubles)
+#define LVBA_Z1S 50  // column stride of the Z^T tile (doubles)
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+template <int J>
+__device__ __forceinline__ void k1b_step(double (&a)[16], int lane, double &rd)
+{
+    const bool done = lane < 16 && lane <= J; // finished block rows: l = 0 leaves them untouched
+    const double u = a[J];
+    const double l = done ? 0.0 : u * rd;
+    a[J] = done ? u : l;
+    if constexpr (J + 1 < 16) {
+        a[J + 1] = fma(-l, readlane_f64(u, J + 1), a[J + 1]);
+        // next pivot: start its reciprocal now, refine it after the rest of the row (the FMAs below do not depend on it
+        // and fill the latency of v_rcp_f64 and of the readlanes)
+        const double pn = readlane_f64(a[J + 1], J + 1);
+        double r = __builtin_amdgcn_rcp(pn);
+        LVBA_PIN(r);
+#pragma unroll
+        for (int c = J + 2; c < 16; ++c) {
+            a[c] = fma(-l, readlane_f64(u, c), a[c]);
+            LVBA_PIN(a[c]);
+        }
+        r = fma(r, fma(-pn, r, 1.0), r);
+        r = fma(r, fma(-pn, r, 1.0), r);
+        rd = r;
+    }
+}
+template <int... Js>
+__device__ __forceinline__ void k1b_steps(std::integer_sequence<int, Js...>, double (&a)[16], int lane, double rd)
+{
+    (k1b_step<Js>(a, lane, rd), ...);
+}
+
+__global__ __launch_bounds__(256) void ldlt_diag_blocked_kernel(LdltMat M, int64_t k, int nbe, double *__restrict__ G,
+                                                               double *__restrict__ dvec, int *__restrict__ status)
+{
+    __shared__ double W[64 * LVBA_W1S]; // (row, col) at col * LVBA_W1S + row; rows 64..127 = the appended identity
+    __shared__ double G11s[16 * 16];    // [m][c]
+    __shared__ double Zt[16 * LVBA_Z1S]; // [j][block row relative to c0 + 16] = X * d
+    __shared__ double dvs[64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    LVBA_K1B_STAMP(0);
+    for (int e = tid; e < 4096; e += 256) {
+        const int row = e & 63, col = e >> 6;
+        double v = 0.0;
+        if (row < nbe) {
+            if (col <= row) v = M.a[(k + row) + (k + col) * M.ld];
+        } else if (col == row)
+            v = 1.0;
+        W[col * LVBA_W1S + row] = v;
+        W[col * LVBA_W1S + 64 + row] = (row == col) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    LVBA_K1B_STAMP(1);
+    const int i15 = lane & 15, kk = lane >> 4;
+    for (int s = 0; s < 4; ++s) {
+        const int c0 = 16 * s;
+        const int nb_rows = 48 - c0; // block rows still to come
+        if (w == 0) { // ---- diag
+            const int r = lane < 16 ? c0 + lane : 64 + c0 + (lane & 15);
+            double a[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) a[c] = (lane < 32) ? W[(c0 + c) * LVBA_W1S + r] : 0.0;
+            k1b_steps(std::make_integer_sequence<int, 16>{}, a, lane, fast_rcp(readlane_f64(a[0], 0)));
+            if (lane < 16) {
+                double dl = 0.0;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) dl = (c == lane) ? a[c] : dl;
+                dvs[c0 + lane] = dl;
+                if (c0 + lane < nbe && (!(dl != 0.0) || !isfinite(dl))) status[0] = 1;
+            } else if (lane < 32) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    W[(c0 + c) * LVBA_W1S + r] = a[c];
+                    G11s[(lane - 16) * 16 + c] = a[c];
+                }
+            }
+        }
+        __syncthreads();
+        LVBA_K1B_STAMP(2 + 3 * s);
+        // row tile of this wave in the panel / update steps: waves 0..2 -> the 48 panel rows, wave 3 -> the identity
+        // rows of this block (their X is what the diag step just wrote)
+        const int base = (w < 3) ? ((16 * w < nb_rows) ? c0 + 16 + 16 * w : 64 + 16 * w - nb_rows) : 64 + c0;
+        if (w < 3) { // ---- panel: X = A * G11
+            d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double av = W[(c0 + 4 * q + kk) * LVBA_W1S + base + i15];
+                const double bv = G11s[(4 * q + kk) * 16 + i15];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+            // acc[r] = X[base + kk + 4r][c0 + i15]
+            const double dj = dvs[c0 + i15];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                W[(c0 + i15) * LVBA_W1S + base + kk + 4 * r] = acc[r];
+                if (16 * w < nb_rows) Zt[i15 * LVBA_Z1S + 16 * w + kk + 4 * r] = acc[r] * dj;
+            }
+        }
+        __syncthreads();
+        LVBA_K1B_STAMP(3 + 3 * s);
+        // ---- update: C[base + i][c0 + 16 + 16 ct + n] -= sum_j X[base + i][c0 + j] * Z[16 ct + n][j]
+        for (int ct = 0; 16 * ct < nb_rows; ++ct) {
+            d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double av = W[(c0 + 4 * q + kk) * LVBA_W1S + base + i15];
+                const double bv = Zt[(4 * q + kk) * LVBA_Z1S + 16 * ct + i15];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) W[(c0 + 16 + 16 * ct + i15) * LVBA_W1S + base + kk + 4 * r] -= acc[r];
+        }
+        __syncthreads();
+        LVBA_K1B_STAMP(4 + 3 * s);
+    }
+    if (tid < nbe) dvec[k + tid] = dvs[tid];
+    for (int e = tid; e < 4096; e += 256) { // G[m][c], row-major
+        const int c = e & 63, m = e >> 6;
+        G[e] = W[c * LVBA_W1S + 64 + m];
+    }
+    LVBA_K1B_STAMP(14);
+}
+
 // ---------------------------------------------------------------------------------------------- K2
 #define LVBA_GS 66 // stride of the [j][m] G tile: 66 = 2 mod 32 -> conflict-free A-operand reads
 __global__ __launch_bounds__(256) void ldlt_panel_kernel(LdltMat M, int64_t k, int nbe, int64_t w0, int64_t rend,
@@ -339,25 +485,20 @@ __global__ __launch_bounds__(256) void ldlt_panel_kernel(LdltMat M, int64_t k, i
 }
 
 // ---------------------------------------------------------------------------------------------- K3
-// mode 0: every lower tile (ti >= tj) of the window; mode 1: only the first tile column (tj = 0);
-// mode 2: ti >= tj >= 1.  Modes 1/2 let the driver run the next panel's K1/K2 beside the bulk of this update.
+// every lower tile (ti >= tj) of the window.  At one 64x64 tile per workgroup the kernel moves 128 KB (C in and out, L, Z)
+// per 0.52 MFLOP = 4 flop/B: it runs at the HBM bound (~5 TB/s -> ~20 TFLOP/s), not at the MFMA bound.
 __global__ __launch_bounds__(256) void ldlt_update_kernel(LdltMat M, int64_t k, int nbe, int64_t w0, int64_t rend,
-                                                          const double *__restrict__ Zws, int64_t ldz, int mode)
+                                                          const double *__restrict__ Zws, int64_t ldz)
 {
     __shared__ double Ls[64 * LVBA_TS]; // [m][row of tile ti]
     __shared__ double Zs[64 * LVBA_TS]; // [m][row of tile tj] (= column of the updated tile)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t bidx = blockIdx.x;
-    int64_t ti, tj;
-    if (mode == 1) {
-        ti = bidx; tj = 0;
-    } else { // triangular decode bidx -> (ti >= tj)
-        ti = (int64_t)((sqrt(8.0 * (double)bidx + 1.0) - 1.0) * 0.5);
-        while (ti * (ti + 1) / 2 > bidx) --ti;
-        while ((ti + 1) * (ti + 2) / 2 <= bidx) ++ti;
-        tj = bidx - ti * (ti + 1) / 2;
-        if (mode == 2) { ++ti; ++tj; }
-    }
+    // triangular decode bidx -> (ti >= tj)
+    int64_t ti = (int64_t)((sqrt(8.0 * (double)bidx + 1.0) - 1.0) * 0.5);
+    while (ti * (ti + 1) / 2 > bidx) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= bidx) ++ti;
+    const int64_t tj = bidx - ti * (ti + 1) / 2;
     const int64_t r0 = w0 + 64 * ti, c0 = w0 + 64 * tj;
     const int row = tid & 63;
     const int i = lane & 15, kk = lane >> 4;
@@ -495,18 +636,19 @@ static inline int64_t ldz_for(int64_t n, int64_t bw)
 int64_t ldlt_workspace_doubles(int64_t n, int64_t bw)
 {
     const int64_t nsteps = (n + LVBA_NB - 1) / LVBA_NB;
-    return nsteps * 4096 /*G*/ + 3 * n /*d, b, bacc*/ + 2 * ldz_for(n, bw) * LVBA_NB /*Z, double-buffered*/ + 64;
+    return nsteps * 4096 /*G*/ + 3 * n /*d, b, bacc*/ + ldz_for(n, bw) * LVBA_NB /*Z*/ + 64;
 }
 
 int64_t ldlt_num_panels(int64_t n) { return (n + LVBA_NB - 1) / LVBA_NB; }
 
-// Launch sequence of one solve.  s2/evA/evB (2 events per panel) enable the look-ahead: the bulk of panel p's
-// trailing update (tile columns >= 1) runs on s2 while s continues with the first tile column, then K1/K2 of
-// panel p+1.  With s2 == nullptr everything is serial on s.
+// Launch sequence of one solve: per panel K1 -> K2 -> K3, serial on one stream (captured once into a hipGraph by the
+// caller).  A two-stream look-ahead (K3's bulk beside the next panel's K1/K2) was measured slower than this on MI355X:
+// K3 is HBM-bound and already fills the machine, so the overlapped K1/K2 only wait for slots and every cross-stream edge
+// costs ~10 us.
 void ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_poses, const double *g,
-                const double *u_dev, double *x, double *work, int *status, hipStream_t s, hipStream_t s2,
-                hipEvent_t *evA, hipEvent_t *evB)
+                const double *u_dev, double *x, double *work, int *status, hipStream_t s)
 {
+    static const bool k1_blocked = [] { const char *e = getenv("LVBA_K1"); return !(e && !strcmp(e, "rowwise")); }();
     const int64_t n = A.n, bw = A.bw;
     const int64_t nsteps = (n + LVBA_NB - 1) / LVBA_NB;
     double *Gall = work;
@@ -514,13 +656,12 @@ void ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_pos
     double *b = dvec + n;
     double *bacc = b + n;
     const int64_t ldz = ldz_for(n, bw);
-    double *Zbuf[2] = {bacc + n, bacc + n + ldz * LVBA_NB};
+    double *Zws = bacc + n;
     const size_t abytes = (size_t)((A.ld == n) ? n * n : (A.ld + 1) * n) * sizeof(double);
     hipMemsetAsync(A.a, 0, abytes, s);
     hipMemsetAsync(status, 0, sizeof(int), s);
     hipMemsetAsync(bacc, 0, (size_t)n * sizeof(double), s);
     hipLaunchKernelGGL(ldlt_prepare_kernel, dim3(2048), dim3(256), 0, s, A, Hblk, band_blocks, n_poses, g, u_dev, b);
-    int64_t last_b = -1; // last panel whose bulk update was issued on s2
     for (int64_t st = 0; st < nsteps; ++st) {
         const int64_t k = st * LVBA_NB;
         const int nbe = (int)((n - k) < LVBA_NB ? (n - k) : LVBA_NB);
@@ -528,27 +669,14 @@ void ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_pos
         int64_t rend = k + nbe + bw;
         if (rend > n) rend = n;
         double *G = Gall + st * 4096;
-        double *Zws = Zbuf[st & 1];
-        hipLaunchKernelGGL(ldlt_diag_kernel, dim3(1), dim3(128), 0, s, A, k, nbe, G, dvec, status);
+        if (k1_blocked) hipLaunchKernelGGL(ldlt_diag_blocked_kernel, dim3(1), dim3(256), 0, s, A, k, nbe, G, dvec, status);
+        else hipLaunchKernelGGL(ldlt_diag_kernel, dim3(1), dim3(128), 0, s, A, k, nbe, G, dvec, status);
         if (w0 < rend) {
             const int64_t T = (rend - w0 + 63) / 64;
             hipLaunchKernelGGL(ldlt_panel_kernel, dim3((unsigned)T), dim3(256), 0, s, A, k, nbe, w0, rend, G, dvec, Zws, ldz, b);
-            if (s2 && T > 1) {
-                hipEventRecord(evA[st], s);
-                hipStreamWaitEvent(s2, evA[st], 0);
-                hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)((T - 1) * T / 2)), dim3(256), 0, s2, A, k, nbe, w0, rend, Zws, ldz, 2);
-                hipEventRecord(evB[st], s2);
-                // the first tile column (block column st+1) is also written by panel st-1's bulk update
-                if (last_b >= 0) hipStreamWaitEvent(s, evB[last_b], 0);
-                hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)T), dim3(256), 0, s, A, k, nbe, w0, rend, Zws, ldz, 1);
-                last_b = st;
-            } else {
-                if (last_b >= 0) { hipStreamWaitEvent(s, evB[last_b], 0); last_b = -1; }
-                hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)(T * (T + 1) / 2)), dim3(256), 0, s, A, k, nbe, w0, rend, Zws, ldz, 0);
-            }
+            hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)(T * (T + 1) / 2)), dim3(256), 0, s, A, k, nbe, w0, rend, Zws, ldz);
         }
     }
-    if (last_b >= 0) hipStreamWaitEvent(s, evB[last_b], 0);
     for (int64_t st = nsteps - 1; st >= 0; --st) {
         const int64_t k = st * LVBA_NB;
         const int nbe = (int)((n - k) < LVBA_NB ? (n - k) : LVBA_NB);

@@ -101,10 +101,9 @@ int64_t ldlt_num_panels(int64_t n);
 // A <- H + u*diag(H) from the block-band store, b <- -g; then unpivoted blocked LDL^T of the lower
 // triangle and the two triangular solves.  x (length n) receives the solution; status[0] != 0 on a
 // zero / non-finite pivot.  u is read from device memory (u_dev) so the launch sequence is static and
-// can be captured into a hipGraph.  s2 + evA/evB (ldlt_num_panels events each) enable the look-ahead.
+// can be captured into a hipGraph.
 void ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_poses, const double *g,
-                const double *u_dev, double *x, double *work, int *status, hipStream_t s, hipStream_t s2,
-                hipEvent_t *evA, hipEvent_t *evB);
+                const double *u_dev, double *x, double *work, int *status, hipStream_t s);
 
 } // namespace lvba
 
