@@ -313,13 +313,14 @@ __device__ __forceinline__ void k1b_steps(std::integer_sequence<int, Js...>, dou
     (k1b_step<Js>(a, lane, rd), ...);
 }
 
-__global__ __launch_bounds__(256) void ldlt_diag_blocked_kernel(LdltMat M, int64_t k, int nbe, double *__restrict__ G,
-                                                               double *__restrict__ dvec, int *__restrict__ status)
+#define LVBA_K1B_LDS (64 * LVBA_W1S + 256 + 16 * LVBA_Z1S + 64) // doubles
+// Leaves d in dvs[64] and G[m][c] in W[c * LVBA_W1S + 64 + m]; ends on a __syncthreads().
+__device__ __forceinline__ void diag_blocked_body(double *lds, LdltMat M, int64_t k, int nbe, int *__restrict__ status)
 {
-    __shared__ double W[64 * LVBA_W1S]; // (row, col) at col * LVBA_W1S + row; rows 64..127 = the appended identity
-    __shared__ double G11s[16 * 16];    // [m][c]
-    __shared__ double Zt[16 * LVBA_Z1S]; // [j][block row relative to c0 + 16] = X * d
-    __shared__ double dvs[64];
+    double *W = lds;                      // (row, col) at col * LVBA_W1S + row; rows 64..127 = the appended identity
+    double *G11s = W + 64 * LVBA_W1S;     // [m][c]
+    double *Zt = G11s + 256;              // [j][block row relative to c0 + 16] = X * d
+    double *dvs = Zt + 16 * LVBA_Z1S;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     LVBA_K1B_STAMP(0);
     for (int e = tid; e < 4096; e += 256) {
@@ -396,6 +397,15 @@ __global__ __launch_bounds__(256) void ldlt_diag_blocked_kernel(LdltMat M, int64
         __syncthreads();
         LVBA_K1B_STAMP(4 + 3 * s);
     }
+}
+
+__global__ __launch_bounds__(256) void ldlt_diag_blocked_kernel(LdltMat M, int64_t k, int nbe, double *__restrict__ G,
+                                                               double *__restrict__ dvec, int *__restrict__ status)
+{
+    __shared__ double lds[LVBA_K1B_LDS];
+    diag_blocked_body(lds, M, k, nbe, status);
+    const double *W = lds, *dvs = lds + 64 * LVBA_W1S + 256 + 16 * LVBA_Z1S;
+    const int tid = threadIdx.x;
     if (tid < nbe) dvec[k + tid] = dvs[tid];
     for (int e = tid; e < 4096; e += 256) { // G[m][c], row-major
         const int c = e & 63, m = e >> 6;
@@ -481,6 +491,88 @@ __global__ __launch_bounds__(256) void ldlt_panel_kernel(LdltMat M, int64_t k, i
             }
             b[r] -= s0 + s1;
         }
+    }
+}
+
+// K1 + K2 in one launch: every panel workgroup repeats the (cheap, 1-workgroup) diagonal factorisation itself instead of
+// waiting for a separate kernel to publish G -- one kernel boundary and the G / d round trip through global memory less per
+// panel, and the workgroup's A21 tile is already in registers when the factorisation ends.  Workgroup 0 also writes G and d
+// (the backward pass needs them).
+__global__ __launch_bounds__(256) void ldlt_diagpanel_kernel(LdltMat M, int64_t k, int nbe, int64_t w0, int64_t rend,
+                                                             double *__restrict__ G, double *__restrict__ dvec,
+                                                             double *__restrict__ Zws, int64_t ldz, double *__restrict__ b,
+                                                             int *__restrict__ status)
+{
+    __shared__ double lds[LVBA_K1B_LDS];
+    __shared__ double As[64 * LVBA_TS]; // [m][row]; later the L tile as [j][row]
+    __shared__ double bks[64], ys[64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int row = tid & 63;
+    const int64_t r0 = w0 + 64 * (int64_t)blockIdx.x;
+    const int64_t r = r0 + row;
+    double av[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int m = w + 4 * it;
+        av[it] = (r < rend && m < nbe) ? M.a[r + (k + m) * M.ld] : 0.0;
+    }
+    const double bk = (tid < nbe) ? b[k + tid] : 0.0;
+    diag_blocked_body(lds, M, k, nbe, status);
+    const double *W = lds, *dvs = lds + 64 * LVBA_W1S + 256 + 16 * LVBA_Z1S;
+    if (blockIdx.x == 0) {
+        if (tid < nbe) dvec[k + tid] = dvs[tid];
+        for (int e = tid; e < 4096; e += 256) G[e] = W[(e & 63) * LVBA_W1S + 64 + (e >> 6)];
+    }
+    if (tid < 64) bks[tid] = bk;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) As[(w + 4 * it) * LVBA_TS + row] = av[it];
+    __syncthreads();
+    // G[m][j] sits at W[j * LVBA_W1S + 64 + m]: the [j][m] layout the products below want, stride 130 = 2 mod 32
+    if (tid < 64) { // y_k = L11^-1 b_k = D G^T b_k
+        double z0 = 0.0, z1 = 0.0;
+#pragma unroll 8
+        for (int m = 0; m < 64; m += 2) {
+            z0 += W[tid * LVBA_W1S + 64 + m] * bks[m];
+            z1 += W[tid * LVBA_W1S + 64 + m + 1] * bks[m + 1];
+        }
+        ys[tid] = (tid < nbe) ? (z0 + z1) * dvs[tid] : 0.0;
+    }
+    d4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+    const int i = lane & 15, kk = lane >> 4;
+#pragma unroll 4
+    for (int k0 = 0; k0 < 64; k0 += 4) {
+        const double a = W[(16 * w + i) * LVBA_W1S + 64 + k0 + kk]; // G[m = k0+kk][j = 16w+i]
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const double bv = As[(k0 + kk) * LVBA_TS + 16 * t + i]; // A21[row=16t+i][m]
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc[t], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) As[(16 * w + kk + 4 * reg) * LVBA_TS + 16 * t + i] = acc[t][reg];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int j = w + 4 * it;
+        if (r < rend && j < nbe) {
+            const double v = As[j * LVBA_TS + row];
+            M.a[r + (k + j) * M.ld] = v;
+            Zws[(r - w0) + j * ldz] = v * dvs[j];
+        }
+    }
+    if (tid < 64 && r < rend) {
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+        for (int j = 0; j < 64; j += 2) {
+            s0 += As[j * LVBA_TS + tid] * ys[j];
+            s1 += As[(j + 1) * LVBA_TS + tid] * ys[j + 1];
+        }
+        b[r] -= s0 + s1;
     }
 }
 
@@ -648,7 +740,9 @@ int64_t ldlt_num_panels(int64_t n) { return (n + LVBA_NB - 1) / LVBA_NB; }
 void ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_poses, const double *g,
                 const double *u_dev, double *x, double *work, int *status, hipStream_t s)
 {
-    static const bool k1_blocked = [] { const char *e = getenv("LVBA_K1"); return !(e && !strcmp(e, "rowwise")); }();
+    // LVBA_K1 = fused (default: diag + panel in one launch) | blocked (separate 16-column blocked diag kernel) | rowwise
+    static const int k1_mode = [] { const char *e = getenv("LVBA_K1"); return !e ? 2 : !strcmp(e, "rowwise") ? 0 : !strcmp(e, "blocked") ? 1 : 2; }();
+    const bool k1_blocked = k1_mode >= 1, k1_fused = k1_mode == 2;
     const int64_t n = A.n, bw = A.bw;
     const int64_t nsteps = (n + LVBA_NB - 1) / LVBA_NB;
     double *Gall = work;
@@ -669,14 +763,21 @@ void ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_pos
         int64_t rend = k + nbe + bw;
         if (rend > n) rend = n;
         double *G = Gall + st * 4096;
-        if (k1_blocked) hipLaunchKernelGGL(ldlt_diag_blocked_kernel, dim3(1), dim3(256), 0, s, A, k, nbe, G, dvec, status);
-        else hipLaunchKernelGGL(ldlt_diag_kernel, dim3(1), dim3(128), 0, s, A, k, nbe, G, dvec, status);
-        if (w0 < rend) {
-            const int64_t T = (rend - w0 + 63) / 64;
-            hipLaunchKernelGGL(ldlt_panel_kernel, dim3((unsigned)T), dim3(256), 0, s, A, k, nbe, w0, rend, G, dvec, Zws, ldz, b);
+        const int64_t T = w0 < rend ? (rend - w0 + 63) / 64 : 0;
+        if (k1_fused && T > 0) {
+            hipLaunchKernelGGL(ldlt_diagpanel_kernel, dim3((unsigned)T), dim3(256), 0, s, A, k, nbe, w0, rend, G, dvec, Zws, ldz, b, status);
+        } else {
+            if (k1_blocked) hipLaunchKernelGGL(ldlt_diag_blocked_kernel, dim3(1), dim3(256), 0, s, A, k, nbe, G, dvec, status);
+            else hipLaunchKernelGGL(ldlt_diag_kernel, dim3(1), dim3(128), 0, s, A, k, nbe, G, dvec, status);
+            if (T > 0) hipLaunchKernelGGL(ldlt_panel_kernel, dim3((unsigned)T), dim3(256), 0, s, A, k, nbe, w0, rend, G, dvec, Zws, ldz, b);
+        }
+        if (T > 0) {
             hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)(T * (T + 1) / 2)), dim3(256), 0, s, A, k, nbe, w0, rend, Zws, ldz);
         }
     }
+    // backward: one launch per panel.  (A 4-panels-per-launch form, every workgroup walking the group's serial part
+    // redundantly, measured 10.9 ms per C3 solve against 10.45 ms: its in-kernel chain of loads and barriers is longer than
+    // four kernel boundaries.)
     for (int64_t st = nsteps - 1; st >= 0; --st) {
         const int64_t k = st * LVBA_NB;
         const int nbe = (int)((n - k) < LVBA_NB ? (n - k) : LVBA_NB);
