@@ -21,7 +21,7 @@ SYMBOLS = [
     "lvba_voxel_default_opts", "lvba_voxmap_build", "lvba_voxmap_destroy", "lvba_voxmap_info", "lvba_voxmap_export",
     "lvba_voxmap_to_balm", "lvba_voxmap_find_planes", "lvba_scans_create", "lvba_scans_destroy", "lvba_voxmap_build_scans",
     "lvba_release_cached_memory", "lvba_window_default_opts", "lvba_window_ba", "lvba_scans_info", "lvba_scans_download",
-    "lvba_lidar_ba_default_opts", "lvba_lidar_ba",
+    "lvba_lidar_ba_default_opts", "lvba_lidar_ba", "lvba_triangulate_tracks",
 ]
 
 OK, ERR_ARG, ERR_DEVICE, ERR_NOMEM, ERR_UNSUPPORTED, ERR_DIST, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
@@ -196,6 +196,8 @@ def load():
     lib.lvba_lidar_ba_default_opts.argtypes = [C.POINTER(LidarBaOpts)]
     lib.lvba_lidar_ba_default_opts.restype = None
     lib.lvba_lidar_ba.argtypes = [H, f64p, C.POINTER(LidarBaOpts), f64p, C.POINTER(LidarBaReport)]
+    lib.lvba_triangulate_tracks.argtypes = [C.c_int32, C.c_int32, C.c_int64, i64p, C.c_void_p, C.c_void_p, f64p, f64p, f64p, f64p,
+                                            f64p, i32p, u8p]
     lib.lvba_scans_info.argtypes = [H, C.POINTER(C.c_int32), C.c_void_p]
     lib.lvba_scans_download.argtypes = [H, C.c_int32, np.ctypeslib.ndpointer(np.float32, flags="C")]
     for name in SYMBOLS:

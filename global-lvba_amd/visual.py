@@ -98,3 +98,23 @@ def optimize_camera_poses(qs, ts, Xs, obs_off, obs_cam, obs_uv, plane_n, plane_d
         return prob.refine(qs, ts, Xs) + (valid,)
     finally:
         prob.close()
+
+
+def triangulate_tracks(Rcw, tcw, obs_off, obs_cam, obs_uv, intr, device=0):
+    """TriangulateTrackDLT + ComputeMeanReproj for every track (src/lvba_system.cpp:8-111).
+    Returns (ok [n] uint8, X [n,3], mean_reproj [n], count [n])."""
+    lib = L.load()
+    Rcw = np.ascontiguousarray(Rcw, np.float64).reshape(-1, 9)
+    tcw = np.ascontiguousarray(tcw, np.float64).reshape(-1, 3)
+    obs_off = np.ascontiguousarray(obs_off, np.int64)
+    obs_cam = np.ascontiguousarray(obs_cam, np.int32)
+    obs_uv = np.ascontiguousarray(obs_uv, np.float64).reshape(-1, 2)
+    n = len(obs_off) - 1
+    X = np.zeros((max(n, 1), 3))
+    err = np.zeros(max(n, 1))
+    cnt = np.zeros(max(n, 1), np.int32)
+    ok = np.zeros(max(n, 1), np.uint8)
+    L.check(lib.lvba_triangulate_tracks(int(device), len(Rcw), n, obs_off, obs_cam.ctypes.data, obs_uv.ctypes.data,
+                                        Rcw.reshape(-1), tcw.reshape(-1), np.ascontiguousarray(intr, np.float64), X.reshape(-1),
+                                        err, cnt, ok))
+    return ok[:n], X[:n], err[:n], cnt[:n]

