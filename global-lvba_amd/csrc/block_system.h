@@ -8,12 +8,14 @@
 #include <vector>
 #include "lvba_common.h"
 #include "lvba_internal.h"
+#include "mempool.h"
 
 namespace lvba {
 
 struct BlockSys {
     int device = 0;
     hipStream_t stream = nullptr;
+    int solve_calls = 0;
     int32_t N = 0;
     int64_t G = 0, F = 0, Q = 0;
     // configuration
@@ -61,7 +63,9 @@ struct BlockSys {
 template <typename T>
 int32_t bs_dmalloc(BlockSys &bs, T **p, int64_t count)
 {
-    HIPCHK(hipMalloc((void **)p, (size_t)(count > 0 ? count : 1) * sizeof(T)));
+    // through the caching pool: short-lived handles (one per window in the window-BA stage) would otherwise spend more
+    // time in hipMalloc / hipFree than in kernels
+    HIPCHK(DevicePool::get().alloc((void **)p, (size_t)(count > 0 ? count : 1) * sizeof(T)));
     bs.device_bytes += count * (int64_t)sizeof(T);
     return LVBA_OK;
 }

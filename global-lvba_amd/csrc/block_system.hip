@@ -386,7 +386,9 @@ int32_t bs_enqueue_solve(BlockSys &bs, double u)
 {
     bs.h_pin_u[0] = u;
     HIPCHK(hipMemcpyAsync(bs.d_u, bs.h_pin_u, sizeof(double), hipMemcpyHostToDevice, bs.stream));
-    if (!bs.graph_tried) {
+    // capture + instantiate costs about as much as a few eager solves of a small system: wait for the third solve, so
+    // handles that live for one short refinement (window BA) never pay for it
+    if (!bs.graph_tried && ++bs.solve_calls >= 3) {
         bs.graph_tried = true;
         if (!getenv("LVBA_NO_GRAPH")) {
             (void)hipGetLastError();
@@ -420,7 +422,7 @@ void bs_destroy(BlockSys &bs)
     void *ptrs[] = {bs.d_perm, bs.d_csc_off, bs.d_blk_off, bs.d_blk_slot, bs.d_group_of_pos, bs.d_csc_f, bs.d_pos_of,
                     bs.d_pairs, bs.d_Y, bs.d_hg, bs.d_A, bs.d_work, bs.d_dx, bs.d_u, bs.d_status};
     for (void *p : ptrs)
-        if (p) hipFree(p);
+        if (p) DevicePool::get().free(p);
     if (bs.h_pin_u) hipHostFree(bs.h_pin_u);
     if (bs.stream) hipStreamDestroy(bs.stream);
     bs = BlockSys();

@@ -162,7 +162,7 @@ static int32_t balm_create_impl(int32_t n_poses, int64_t n_voxels, const int64_t
         launch_aos_to_soa(src, F, h->d_clu, bs.stream);
         CHIP(hipGetLastError());
         CHIP(hipStreamSynchronize(bs.stream));
-        if (d_stage) { hipFree(d_stage); bs.device_bytes -= (int64_t)(10 * F) * (int64_t)sizeof(double); }
+        if (d_stage) { lvba::DevicePool::get().free(d_stage); bs.device_bytes -= (int64_t)(10 * F) * (int64_t)sizeof(double); }
     }
     CHIP(hipHostMalloc((void **)&h->h_pin, 16 * sizeof(double), hipHostMallocDefault));
     for (int e = 0; e < EV_N; ++e)
@@ -181,7 +181,7 @@ extern "C" int32_t lvba_balm_destroy(lvba_balm_t h)
     void *ptrs[] = {h->d_voff, h->d_chunk_v0, h->d_pidx, h->d_clu, h->d_chunk_cost, h->d_clu_csc, h->d_vrec, h->d_part,
                     h->d_pose_in, h->d_pose_cur, h->d_pose_trial, h->d_out, h->d_scal2};
     for (void *p : ptrs)
-        if (p) hipFree(p);
+        if (p) lvba::DevicePool::get().free(p);
     if (h->h_pin) hipHostFree(h->h_pin);
     for (int e = 0; e < EV_N; ++e)
         for (int s = 0; s < 2; ++s)

@@ -72,7 +72,7 @@ extern "C" int32_t lvba_visual_destroy(lvba_visual_t h)
                     h->d_sc_cam, h->d_sc_pt, h->d_Lp, h->d_zp, h->d_step_p, h->d_part, h->d_q, h->d_t, h->d_X, h->d_q2,
                     h->d_t2, h->d_X2, h->d_blkpart, h->d_scal, h->d_gmax, h->d_out};
     for (void *p : ptrs)
-        if (p) hipFree(p);
+        if (p) lvba::DevicePool::get().free(p);
     if (h->h_pin) hipHostFree(h->h_pin);
     bs_destroy(h->bs);
     delete h;

@@ -171,11 +171,13 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
         info.start = start; info.n_frames = cw; info.anchor = -1;
         const double *x_odom = poses + 12 * (int64_t)start;
         lvba_voxmap_t map = nullptr;
+        double tw = now_ms();
         int32_t rc = lvba_voxmap_build_scans(sc, start, cw, x_odom, &o.voxel, &map);
         if (rc != LVBA_OK) { free_clouds(); return rc; }
         lvba_voxmap_info_t mi;
         lvba_voxmap_info(map, &mi);
         info.n_voxels = mi.n_voxels; info.n_factors = mi.n_factors;
+        info.map_ms = now_ms() - tw; tw = now_ms();
         if (mi.n_voxels < 3 * (int64_t)cw) { // :258-262
             info.skipped = 1;
             lvba_voxmap_destroy(map);
@@ -199,6 +201,7 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
                 info.cost_last = trace[nt - 1].accepted ? trace[nt - 1].residual2 : trace[nt - 1].residual1;
             }
         }
+        info.solve_ms = now_ms() - tw; tw = now_ms();
         if (window_poses) memcpy(window_poses + 12 * (int64_t)start, x.data(), 96 * (size_t)cw);
         // alignment (:268-279) and relative poses (:284-299)
         std::vector<double> rel(12 * (size_t)cw);
@@ -271,6 +274,7 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
                 HIPCHK(hipStreamSynchronize(s));
             }
         }
+        info.merge_ms = now_ms() - tw;
         info.anchor = (int32_t)clouds.size();
         info.n_anchor_points = n_out;
         memcpy(anchor_poses + 12 * clouds.size(), x_odom, 96);
