@@ -34,6 +34,24 @@ def test_struct_layouts_match_header(pkg):
     assert (o.max_iter, o.u0, o.v0, o.rel_tol) == (10, 0.01, 2.0, 1e-6)      # bavoxel.hpp:664,686,760
 
 
+def test_every_struct_has_the_size_the_c_compiler_gives_it(pkg, tmp_path):
+    """ctypes mirrors vs `sizeof` from the header itself (compiled as C: the header must stay plain C)."""
+    import subprocess
+    L = pkg._lib
+    pairs = [("lvba_balm_opts", L.BalmOpts), ("lvba_lm_trace", L.LmTrace), ("lvba_balm_info_t", L.BalmInfo),
+             ("lvba_prof_t", L.Prof), ("lvba_visual_opts", L.VisualOpts), ("lvba_visual_trace", L.VisualTrace),
+             ("lvba_voxel_opts", L.VoxelOpts), ("lvba_voxmap_info_t", L.VoxmapInfo), ("lvba_window_opts", L.WindowOpts),
+             ("lvba_window_info", L.WindowInfo), ("lvba_lidar_ba_opts", L.LidarBaOpts), ("lvba_lidar_ba_report", L.LidarBaReport)]
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "lvba_hip.h"\nint main(void){' +
+                   "".join(f'printf("%zu\\n", sizeof({n}));' for n, _ in pairs) + "return 0;}\n")
+    exe = str(tmp_path / "sizes")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe])
+    sizes = [int(v) for v in subprocess.check_output([exe]).split()]
+    for (name, cls), sz in zip(pairs, sizes):
+        assert ctypes.sizeof(cls) == sz, (name, ctypes.sizeof(cls), sz)
+
+
 def test_shard_range_matches_reference_slicing(pkg):
     from oracle import balm_oracle as bo
     for V in (7, 16, 100, 12345, 2_000_000):
