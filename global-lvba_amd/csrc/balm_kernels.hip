@@ -42,6 +42,41 @@ __device__ __forceinline__ double block_sum_256(double x, double *red)
     return red[0] + red[1] + red[2] + red[3];
 }
 
+// A voxel observed by more poses than a workgroup has lanes sits alone in its chunk and is merged in tiles of LVBA_CF
+// factors: per-lane partial sums of the transformed statistics, then lane e < 10 adds up column e of the LDS table in lane
+// order (deterministic).  Returns the merged statistics in S on every lane.
+__device__ __forceinline__ void merge_big_voxel(const BalmDev &d, const double *__restrict__ poses, int64_t f0, int nf,
+                                                double *T, double *S)
+{
+    const int tid = threadIdx.x;
+    double p[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int t0 = 0; t0 < nf; t0 += LVBA_CF) {
+        if (t0 + tid < nf) {
+            const int64_t f = f0 + t0 + tid;
+            double c[10], x[12], t[10];
+#pragma unroll
+            for (int e = 0; e < 10; ++e) c[e] = d.clu[(int64_t)e * d.F + f];
+            const double *xp = poses + 12 * (int64_t)d.pidx[f];
+#pragma unroll
+            for (int e = 0; e < 12; ++e) x[e] = xp[e];
+            transform_cluster(c, x, x + 9, t);
+#pragma unroll
+            for (int e = 0; e < 10; ++e) p[e] += t[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 10; ++e) T[e * LVBA_CF + tid] = p[e];
+    __syncthreads();
+    if (tid < 10) {
+        double s = 0.0;
+        for (int j = 0; j < LVBA_CF; ++j) s += T[tid * LVBA_CF + j];
+        T[tid * LVBA_CF] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 10; ++e) S[e] = T[e * LVBA_CF];
+}
+
 // ------------------------------------------------------------------------------------------------
 // cost only: sum of lambda_min per chunk.  Algorithmic traffic 84 B/factor (80 B cluster + 4 B pose
 // index) -> HBM-bound.  LDS: transformed statistics SoA T[10][CF].
@@ -57,6 +92,12 @@ __global__ __launch_bounds__(LVBA_CF) void balm_cost_kernel(BalmDev d, const dou
     const int64_t v0 = d.chunk_v0[ch], v1 = d.chunk_v0[ch + 1];
     const int64_t f0 = d.voff[v0];
     const int nf = (int)(d.voff[v1] - f0), nv = (int)(v1 - v0);
+    if (nf > LVBA_CF) { // one voxel with more observers than lanes (uniform branch)
+        double S[10];
+        merge_big_voxel(d, poses, f0, nf, T, S);
+        if (tid == 0) chunk_cost[ch] = voxel_lambda_min(S);
+        return;
+    }
     if (tid <= nv) lvoff[tid] = (int)(d.voff[v0 + tid] - f0);
     if (tid < nf) {
         const int64_t f = f0 + tid;
@@ -115,6 +156,23 @@ __global__ __launch_bounds__(LVBA_CF) void balm_voxel_kernel(BalmDev d, const do
     const int64_t v0 = d.chunk_v0[ch], v1 = d.chunk_v0[ch + 1];
     const int64_t f0 = d.voff[v0];
     const int nf = (int)(d.voff[v1] - f0), nv = (int)(v1 - v0);
+    if (nf > LVBA_CF) { // one voxel with more observers than lanes (uniform branch)
+        double S[10];
+        merge_big_voxel(d, poses, f0, nf, T, S);
+        if (tid == 0) {
+            VoxRec vr;
+            chunk_cost[ch] = voxel_finish(S, vr);
+            double *o = d.vrec + 16 * v0;
+            o[0] = vr.NN;
+            for (int e = 0; e < 3; ++e) {
+                o[1 + e] = vr.vb[e];
+                o[4 + e] = vr.u0[e];
+                o[7 + e] = vr.s1[e];
+                o[10 + e] = vr.s2[e];
+            }
+        }
+        return;
+    }
     if (tid <= nv) lvoff[tid] = (int)(d.voff[v0 + tid] - f0);
     if (tid < nf) {
         const int64_t f = f0 + tid;

@@ -126,7 +126,13 @@ static int32_t balm_create_impl(int32_t n_poses, int64_t n_voxels, const int64_t
         const int64_t k = voxel_off[a + 1] - voxel_off[a];
         h->h_voff[a] = voxel_off[a] - base;
         if (k < 2) { delete h; return fail(LVBA_ERR_ARG, "voxel %lld has %lld factors (< 2)", (long long)a, (long long)k); }
-        if (k > LVBA_CF) { delete h; return fail(LVBA_ERR_UNSUPPORTED, "voxel %lld has %lld observers (> %d per voxel not supported yet)", (long long)a, (long long)k, LVBA_CF); }
+        if (k > LVBA_CF) { // more observers than lanes: a chunk of its own, merged in tiles by the kernels
+            if (nv > 0) chunk_v0.push_back(a);
+            chunk_v0.push_back(a + 1);
+            nf = 0; nv = 0;
+            Q += k * (k - 1) / 2;
+            continue;
+        }
         if (nf + k > LVBA_CF || nv == LVBA_CV) { chunk_v0.push_back(a); nf = 0; nv = 0; }
         nf += k; nv += 1;
         Q += k * (k - 1) / 2;

@@ -301,3 +301,50 @@ def test_properties_at_baseline_size_c2(pkg, synth):
     assert abs(cs - c0) <= 1e-12 * c0
     xf, trace, rc = prob.refine(x)
     assert rc == 0 and trace[-1]["residual2"] <= prob.cost(d["poses_gt"], is_avg=True) * 1.001
+
+
+def test_voxels_with_more_observers_than_lanes(pkg, oracle_mod):
+    """Voxels seen by more poses than a workgroup has lanes (> 256): merged in tiles by a workgroup of their own.  Cost, H
+    and g against the C oracle on a problem that mixes them with ordinary voxels (first, middle and last position)."""
+    rng = np.random.default_rng(7)
+    N = 320
+    d = make_problem(N, 500, band=12, seed=5)
+    off, idx, clu = d["voxel_off"], d["pose_idx"], d["clusters"].reshape(-1, 10)
+    t = np.arange(N) * (2 * np.pi / N)
+
+    def big_voxel(k):
+        # a horizontal plane patch far below the trajectory, seen by k poses: points in the world frame, moved to each body
+        poses = rng.choice(N, k, replace=False)
+        poses.sort()
+        out = []
+        for p in poses:
+            T = d["poses_gt"][p]
+            R, tr = T[:9].reshape(3, 3), T[9:]
+            pw = np.column_stack([rng.uniform(-0.4, 0.4, (20, 2)) + [3.0, -2.0], np.full(20, -30.0) + rng.normal(0, 0.01, 20)])
+            pb = ((pw - tr) @ R).astype(np.float32).astype(np.float64)
+            out.append(np.concatenate([[np.sum(pb[:, 0] * pb[:, 0]), np.sum(pb[:, 0] * pb[:, 1]), np.sum(pb[:, 0] * pb[:, 2]),
+                                        np.sum(pb[:, 1] * pb[:, 1]), np.sum(pb[:, 1] * pb[:, 2]), np.sum(pb[:, 2] * pb[:, 2])],
+                                       pb.sum(0), [20.0]]))
+        return poses.astype(np.int32), np.asarray(out)
+    bigs = [big_voxel(k) for k in (300, 257, 320)]
+    V = len(off) - 1
+    pieces = [(bigs[0][0], bigs[0][1])]
+    for v in range(V):
+        pieces.append((idx[off[v]:off[v + 1]], clu[off[v]:off[v + 1]]))
+        if v == V // 2:
+            pieces.append(bigs[1])
+    pieces.append(bigs[2])
+    new_off = np.concatenate([[0], np.cumsum([len(p[0]) for p in pieces])]).astype(np.int64)
+    new_idx = np.concatenate([p[0] for p in pieces]).astype(np.int32)
+    new_clu = np.concatenate([p[1] for p in pieces])
+    prob = pkg.BalmProblem(N, new_off, new_idx, new_clu)
+    co = oracle_mod.COracle(N, new_off, new_idx, new_clu)
+    x0 = d["poses_init"]
+    assert abs(prob.cost(x0) - co.cost(x0)) <= 1e-9 * co.cost(x0)
+    H, g, c = prob.eval(x0)
+    Hc, gc, cc = co.eval_dense(x0)
+    assert abs(c - cc) <= 1e-9 * cc
+    assert rel(g, gc) <= 1e-8 and rel(H, Hc) <= 1e-8
+    x, trace, rc = prob.refine(x0)
+    xr, tr, _ = co.damping_iter(x0)
+    assert rc == 0 and len(trace) == len(tr) and np.abs(x - xr).max() <= 1e-7
