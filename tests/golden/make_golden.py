@@ -54,6 +54,45 @@ def main_visual():
     print("visual_small", status, len(trace), trace[-1]["cost"])
 
 
+def main_voxel():
+    """Voxel front-end / window stage / track triangulation: inputs + what the oracles answer (frozen)."""
+    synth = importlib.import_module("global-lvba_amd.synth")
+    from oracle import voxel_oracle as vx, window_oracle as wo, track_oracle as to
+    s = synth.make_scans(6, 2500, room=(8, 6, 3), origin=(-2.5, 4.0, 0.3), n_panels=6, seed=17, rot_sigma_deg=0.1, trans_sigma=0.03)
+    flat = np.concatenate(s["clouds"]).astype(np.float32)
+    counts = np.array([len(c) for c in s["clouds"]], np.int64)
+    surf_map, vox = vx.build(s["clouds"], s["poses"], 1.0)
+    off, idx, clu = vx.pack(vox)
+    key = np.array([list(k) + [len(p) | ((p[0] if len(p) >= 1 else 0) << 4) | ((p[1] if len(p) == 2 else 0) << 8)]
+                    for k, p, _ in vox], np.int64)
+    rng = np.random.default_rng(1)
+    Xq = np.concatenate([c[rng.choice(len(c), 40, replace=False), :3].astype(np.float64) @ T[:9].reshape(3, 3).T + T[9:]
+                         for c, T in zip(s["clouds"], s["poses"])])
+    planes = np.zeros((len(Xq), 4)); valid = np.zeros(len(Xq), np.uint8)
+    for i, x in enumerate(Xq):
+        r = vx.find_plane(surf_map, x, 1.0)
+        if r is not None:
+            planes[i, :3], planes[i, 3], valid[i] = r[0], r[1], 1
+    w = wo.run_window_ba(s["clouds"], s["poses"], 3, 1.0, np.float32([0.3, 0.1, 0.06, 0.03]), 0.05)
+    np.savez_compressed(os.path.join(HERE, "voxel_small.npz"), points=flat, counts=counts, poses=s["poses"], voxel_off=off,
+                        pose_idx=idx, clusters=clu, voxel_key=key, query=Xq, planes=planes, valid=valid,
+                        win_anchor_index=w["anchor_index"], win_rel_poses=w["rel_poses"], win_window_poses=w["window_poses"],
+                        win_anchor_poses=w["anchor_poses"], win_anchor_counts=np.array([len(c) for c in w["anchor_clouds"]]))
+    print("voxel_small", len(flat), "points ->", len(off) - 1, "voxels,", int(valid.sum()), "of", len(Xq), "queries on planes,",
+          len(w["anchor_clouds"]), "anchors")
+    d = synth.make_visual_problem(8, 60, seed=3, track_len=5)
+    q = d["q_gt"]
+    qw, qx, qy, qz = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    Rcw = np.stack([1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy),
+                    2 * (qx * qy + qw * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qw * qx),
+                    2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 1 - 2 * (qx * qx + qy * qy)], 1).reshape(-1, 3, 3)
+    ok, X, err, cnt = to.triangulate_tracks(d["intr"], Rcw, d["t_gt"], d["obs_off"], d["obs_cam"], d["obs_uv"])
+    np.savez_compressed(os.path.join(HERE, "tracks_small.npz"), Rcw=Rcw, tcw=d["t_gt"], obs_off=d["obs_off"], obs_cam=d["obs_cam"],
+                        obs_uv=d["obs_uv"], intr=d["intr"], ok=ok, X=X, mean_reproj=err, count=cnt)
+    print("tracks_small", int(ok.sum()), "of", len(ok), "tracks triangulated")
+
+
 if __name__ == "__main__":
     main()
     main_visual()
+    main_voxel()

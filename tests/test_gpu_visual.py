@@ -135,3 +135,15 @@ def test_triangulate_tracks_matches_oracle(pkg, synth, seed, track_len):
     assert rel.max() < 1e-7
     assert np.abs(err[good] - err_r[good]).max() < 1e-6
     assert np.isinf(err[~good]).all() or (cnt[~good] >= 0).all()
+
+
+def test_triangulation_golden_fixture(pkg):
+    import os
+    from importlib import import_module
+    vis = import_module("global-lvba_amd.visual")
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tracks_small.npz"))
+    ok, X, err, cnt = vis.triangulate_tracks(z["Rcw"], z["tcw"], z["obs_off"], z["obs_cam"], z["obs_uv"], z["intr"])
+    np.testing.assert_array_equal(ok, z["ok"])
+    np.testing.assert_array_equal(cnt, z["count"])
+    assert (np.linalg.norm(X - z["X"], axis=1) / np.linalg.norm(z["X"], axis=1)).max() < 1e-7
+    assert np.abs(err - z["mean_reproj"]).max() < 1e-6

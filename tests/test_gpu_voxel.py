@@ -200,3 +200,30 @@ def test_four_million_points_bit_identical_and_deterministic(pkg, synth):
     np.testing.assert_array_equal(cl, ref["clu"])
     assert cl[:, 9].sum() <= info["n_points"] and (cl[:, 9] >= 1).all() and (np.diff(off) >= 2).all()
     assert len(off) - 1 > 50_000
+
+
+def test_golden_fixture(pkg):
+    """The HIP path against the committed fixture tests/golden/voxel_small.npz (inputs + frozen oracle answers): voxels and
+    clusters bit for bit, plane lookups to 1e-8, the window stage's anchors and relative poses."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "voxel_small.npz"))
+    clouds = np.split(z["points"], np.cumsum(z["counts"])[:-1])
+    with pkg.Scans(clouds) as scans:
+        with scans.voxel_map(z["poses"], 1.0) as m:
+            off, idx, cl, key = m.export()
+            plane, valid = m.find_planes(z["query"])
+        w = scans.window_ba(z["poses"], window_size=3, voxel_size=1.0, eigen_ratio_array=np.float32([0.3, 0.1, 0.06, 0.03]),
+                            anchor_leaf=0.05)
+    np.testing.assert_array_equal(off, z["voxel_off"])
+    np.testing.assert_array_equal(idx, z["pose_idx"])
+    np.testing.assert_array_equal(key, z["voxel_key"])
+    np.testing.assert_array_equal(cl, z["clusters"])
+    np.testing.assert_array_equal(valid, z["valid"])
+    sgn = np.sign(np.sum(plane[:, :3] * z["planes"][:, :3], axis=1))[:, None]
+    assert np.abs(sgn * plane - z["planes"])[z["valid"] > 0].max() < 1e-8
+    np.testing.assert_array_equal(w["anchor_index"], z["win_anchor_index"])
+    assert np.abs(w["rel_poses"] - z["win_rel_poses"]).max() < 1e-7
+    np.testing.assert_array_equal(w["anchor_poses"], z["win_anchor_poses"])
+    got = w["anchor_scans"].counts.tolist()
+    assert all(abs(a - b) <= max(2, 0.002 * b) for a, b in zip(got, z["win_anchor_counts"].tolist()))
+    w["anchor_scans"].close()

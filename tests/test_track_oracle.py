@@ -48,3 +48,12 @@ def test_tracks_from_the_visual_generator():
     # 0.5 px noise with the short baselines of consecutive cameras: depth along the ray is loose, the pixel fit is not
     assert np.median(np.linalg.norm(X[good] - d["X_gt"][good], axis=1)) < 0.5
     assert np.median(err[good]) < 2.0
+
+
+def test_oracle_reproduces_golden_fixture():
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tracks_small.npz"))
+    ok, X, err, cnt = to.triangulate_tracks(z["intr"], z["Rcw"], z["tcw"], z["obs_off"], z["obs_cam"], z["obs_uv"])
+    np.testing.assert_array_equal(ok, z["ok"])
+    np.testing.assert_array_equal(cnt, z["count"])
+    assert np.abs(X - z["X"]).max() < 1e-9 and np.abs(err - z["mean_reproj"]).max() < 1e-9

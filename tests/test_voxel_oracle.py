@@ -124,3 +124,34 @@ def test_cpp_twin_matches_bit_for_bit(ratio):
     np.testing.assert_array_equal(got["idx"], idx)
     np.testing.assert_array_equal(got["clu"], cl)
     assert {len(p) for _, p, _ in vox} >= {0, 1}
+
+
+def _golden():
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "voxel_small.npz"))
+    clouds = np.split(z["points"], np.cumsum(z["counts"])[:-1])
+    return z, clouds
+
+
+def test_oracles_reproduce_golden_fixture():
+    """tests/golden/voxel_small.npz freezes both restatements (and the window oracle built on them)."""
+    import oracle
+    from oracle import window_oracle as wo
+    z, clouds = _golden()
+    surf_map, vox = vo.build(clouds, z["poses"], 1.0)
+    off, idx, cl = vo.pack(vox)
+    np.testing.assert_array_equal(off, z["voxel_off"])
+    np.testing.assert_array_equal(idx, z["pose_idx"])
+    np.testing.assert_array_equal(cl, z["clusters"])
+    cpp = oracle.voxel_build_cpp(clouds, z["poses"], 1.0)
+    np.testing.assert_array_equal(cpp["clu"], z["clusters"])
+    np.testing.assert_array_equal(cpp["key"], z["voxel_key"])
+    for i, x in enumerate(z["query"]):
+        r = vo.find_plane(surf_map, x, 1.0)
+        assert (r is not None) == bool(z["valid"][i])
+        if r is not None:
+            assert np.abs(np.r_[r[0], r[1]] - z["planes"][i]).max() < 1e-12
+    w = wo.run_window_ba(clouds, z["poses"], 3, 1.0, np.float32([0.3, 0.1, 0.06, 0.03]), 0.05)
+    np.testing.assert_array_equal(w["anchor_index"], z["win_anchor_index"])
+    assert np.abs(w["rel_poses"] - z["win_rel_poses"]).max() < 1e-10
+    assert [len(c) for c in w["anchor_clouds"]] == z["win_anchor_counts"].tolist()
