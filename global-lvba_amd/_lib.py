@@ -92,7 +92,7 @@ class WindowInfo(C.Structure):
     _fields_ = [("start", C.c_int32), ("n_frames", C.c_int32), ("skipped", C.c_int32), ("anchor", C.c_int32),
                 ("n_iter", C.c_int32), ("lm_status", C.c_int32), ("n_voxels", C.c_int64), ("n_factors", C.c_int64),
                 ("n_anchor_points", C.c_int64), ("cost_first", C.c_double), ("cost_last", C.c_double), ("map_ms", C.c_double),
-                ("solve_ms", C.c_double), ("merge_ms", C.c_double)]
+                ("solve_ms", C.c_double), ("merge_ms", C.c_double), ("setup_ms", C.c_double)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}

@@ -192,6 +192,9 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
             if (rc != LVBA_OK) { free_clouds(); return rc; }
             std::vector<lvba_lm_trace> trace((size_t)std::max(1, o.lm.max_iter));
             int32_t nt = 0;
+            lvba_balm_info_t bi;
+            lvba_balm_info(b, &bi); // forces the one-off problem set-up (ordering, pair lists) so that it is timed apart
+            info.setup_ms = now_ms() - tw;
             rc = lvba_balm_refine(b, x.data(), &o.lm, trace.data(), &nt);
             lvba_balm_destroy(b);
             if (rc < 0) { free_clouds(); return rc; }

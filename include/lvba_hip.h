@@ -332,6 +332,7 @@ typedef struct {
     int64_t n_voxels, n_factors, n_anchor_points;
     double cost_first, cost_last;             /* averaged LiDAR cost before / after the window's damping_iter */
     double map_ms, solve_ms, merge_ms;        /* host wall clock: voxel map, problem set-up + LM, anchor merge + down-sampling */
+    double setup_ms;                          /* the part of solve_ms before the first LM iteration */
 } lvba_window_info;
 void lvba_window_default_opts(lvba_window_opts *opts);
 int32_t lvba_window_ba(lvba_scans_t scans, const double *poses, const lvba_window_opts *opts, double *window_poses,
