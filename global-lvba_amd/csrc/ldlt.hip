@@ -498,17 +498,15 @@ __global__ __launch_bounds__(256) void ldlt_panel_kernel(LdltMat M, int64_t k, i
 // waiting for a separate kernel to publish G -- one kernel boundary and the G / d round trip through global memory less per
 // panel, and the workgroup's A21 tile is already in registers when the factorisation ends.  Workgroup 0 also writes G and d
 // (the backward pass needs them).
-__global__ __launch_bounds__(256) void ldlt_diagpanel_kernel(LdltMat M, int64_t k, int nbe, int64_t w0, int64_t rend,
-                                                             double *__restrict__ G, double *__restrict__ dvec,
-                                                             double *__restrict__ Zws, int64_t ldz, double *__restrict__ b,
-                                                             int *__restrict__ status)
+#define LVBA_K12_LDS (LVBA_K1B_LDS + 128) // doubles: the blocked factorisation's tables + b_k, y_k
+__device__ __forceinline__ void diagpanel_tile(double *lds, LdltMat M, int64_t k, int nbe, int64_t w0, int64_t rend,
+                                               double *__restrict__ G, double *__restrict__ dvec, double *__restrict__ Zws,
+                                               int64_t ldz, double *__restrict__ b, int *__restrict__ status, int64_t tile)
 {
-    __shared__ double lds[LVBA_K1B_LDS];
-    __shared__ double As[64 * LVBA_TS]; // [m][row]; later the L tile as [j][row]
-    __shared__ double bks[64], ys[64];
+    double *bks = lds + LVBA_K1B_LDS, *ys = bks + 64;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int row = tid & 63;
-    const int64_t r0 = w0 + 64 * (int64_t)blockIdx.x;
+    const int64_t r0 = w0 + 64 * tile;
     const int64_t r = r0 + row;
     double av[16];
 #pragma unroll
@@ -518,16 +516,19 @@ __global__ __launch_bounds__(256) void ldlt_diagpanel_kernel(LdltMat M, int64_t 
     }
     const double bk = (tid < nbe) ? b[k + tid] : 0.0;
     diag_blocked_body(lds, M, k, nbe, status);
-    const double *W = lds, *dvs = lds + 64 * LVBA_W1S + 256 + 16 * LVBA_Z1S;
-    if (blockIdx.x == 0) {
+    double *W = lds;
+    const double *dvs = lds + 64 * LVBA_W1S + 256 + 16 * LVBA_Z1S;
+    if (tile == 0) {
         if (tid < nbe) dvec[k + tid] = dvs[tid];
         for (int e = tid; e < 4096; e += 256) G[e] = W[(e & 63) * LVBA_W1S + 64 + (e >> 6)];
     }
+    // rows 0..63 of W (the factored block itself) are dead now: the A21 tile is staged there as As[m][row] = W[m][row],
+    // next to G[m][j] = W[j * LVBA_W1S + 64 + m] in rows 64..127
+    double *As = W;
     if (tid < 64) bks[tid] = bk;
 #pragma unroll
-    for (int it = 0; it < 16; ++it) As[(w + 4 * it) * LVBA_TS + row] = av[it];
+    for (int it = 0; it < 16; ++it) As[(w + 4 * it) * LVBA_W1S + row] = av[it];
     __syncthreads();
-    // G[m][j] sits at W[j * LVBA_W1S + 64 + m]: the [j][m] layout the products below want, stride 130 = 2 mod 32
     if (tid < 64) { // y_k = L11^-1 b_k = D G^T b_k
         double z0 = 0.0, z1 = 0.0;
 #pragma unroll 8
@@ -546,7 +547,7 @@ __global__ __launch_bounds__(256) void ldlt_diagpanel_kernel(LdltMat M, int64_t 
         const double a = W[(16 * w + i) * LVBA_W1S + 64 + k0 + kk]; // G[m = k0+kk][j = 16w+i]
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const double bv = As[(k0 + kk) * LVBA_TS + 16 * t + i]; // A21[row=16t+i][m]
+            const double bv = As[(k0 + kk) * LVBA_W1S + 16 * t + i]; // A21[row=16t+i][m]
             acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc[t], 0, 0, 0);
         }
     }
@@ -554,13 +555,13 @@ __global__ __launch_bounds__(256) void ldlt_diagpanel_kernel(LdltMat M, int64_t 
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) As[(16 * w + kk + 4 * reg) * LVBA_TS + 16 * t + i] = acc[t][reg];
+        for (int reg = 0; reg < 4; ++reg) As[(16 * w + kk + 4 * reg) * LVBA_W1S + 16 * t + i] = acc[t][reg];
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
         const int j = w + 4 * it;
         if (r < rend && j < nbe) {
-            const double v = As[j * LVBA_TS + row];
+            const double v = As[j * LVBA_W1S + row];
             M.a[r + (k + j) * M.ld] = v;
             Zws[(r - w0) + j * ldz] = v * dvs[j];
         }
@@ -569,28 +570,38 @@ __global__ __launch_bounds__(256) void ldlt_diagpanel_kernel(LdltMat M, int64_t 
         double s0 = 0.0, s1 = 0.0;
 #pragma unroll 8
         for (int j = 0; j < 64; j += 2) {
-            s0 += As[j * LVBA_TS + tid] * ys[j];
-            s1 += As[(j + 1) * LVBA_TS + tid] * ys[j + 1];
+            s0 += As[j * LVBA_W1S + tid] * ys[j];
+            s1 += As[(j + 1) * LVBA_W1S + tid] * ys[j + 1];
         }
         b[r] -= s0 + s1;
     }
+}
+__global__ __launch_bounds__(256) void ldlt_diagpanel_kernel(LdltMat M, int64_t k, int nbe, int64_t w0, int64_t rend,
+                                                             double *__restrict__ G, double *__restrict__ dvec,
+                                                             double *__restrict__ Zws, int64_t ldz, double *__restrict__ b,
+                                                             int *__restrict__ status)
+{
+    __shared__ double lds[LVBA_K12_LDS];
+    diagpanel_tile(lds, M, k, nbe, w0, rend, G, dvec, Zws, ldz, b, status, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------- K3
 // every lower tile (ti >= tj) of the window.  At one 64x64 tile per workgroup the kernel moves 128 KB (C in and out, L, Z)
 // per 0.52 MFLOP = 4 flop/B: it runs at the HBM bound (~5 TB/s -> ~20 TFLOP/s), not at the MFMA bound.
-__global__ __launch_bounds__(256) void ldlt_update_kernel(LdltMat M, int64_t k, int nbe, int64_t w0, int64_t rend,
-                                                          const double *__restrict__ Zws, int64_t ldz)
+#define LVBA_K3_LDS (2 * 64 * LVBA_TS) // doubles
+__device__ __forceinline__ void tri_decode(int64_t bidx, int64_t &ti, int64_t &tj) // bidx -> (ti >= tj)
 {
-    __shared__ double Ls[64 * LVBA_TS]; // [m][row of tile ti]
-    __shared__ double Zs[64 * LVBA_TS]; // [m][row of tile tj] (= column of the updated tile)
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int64_t bidx = blockIdx.x;
-    // triangular decode bidx -> (ti >= tj)
-    int64_t ti = (int64_t)((sqrt(8.0 * (double)bidx + 1.0) - 1.0) * 0.5);
+    ti = (int64_t)((sqrt(8.0 * (double)bidx + 1.0) - 1.0) * 0.5);
     while (ti * (ti + 1) / 2 > bidx) --ti;
     while ((ti + 1) * (ti + 2) / 2 <= bidx) ++ti;
-    const int64_t tj = bidx - ti * (ti + 1) / 2;
+    tj = bidx - ti * (ti + 1) / 2;
+}
+__device__ __forceinline__ void update_tile(double *lds, LdltMat M, int64_t k, int nbe, int64_t w0, int64_t rend,
+                                            const double *__restrict__ Zws, int64_t ldz, int64_t ti, int64_t tj)
+{
+    double *Ls = lds;                // [m][row of tile ti]
+    double *Zs = lds + 64 * LVBA_TS; // [m][row of tile tj] (= column of the updated tile)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t r0 = w0 + 64 * ti, c0 = w0 + 64 * tj;
     const int row = tid & 63;
     const int i = lane & 15, kk = lane >> 4;
@@ -640,6 +651,38 @@ __global__ __launch_bounds__(256) void ldlt_update_kernel(LdltMat M, int64_t k, 
             const int64_t c = c0 + 16 * w + kk + 4 * reg, r = r0 + 16 * t + i;
             if (r < rend && c < rend && r >= c) M.a[r + c * M.ld] = cv[4 * t + reg] - acc[t][reg];
         }
+}
+// mode 0: every lower tile (ti >= tj) of the window; mode 1: only the first tile column (tj = 0)
+__global__ __launch_bounds__(256) void ldlt_update_kernel(LdltMat M, int64_t k, int nbe, int64_t w0, int64_t rend,
+                                                          const double *__restrict__ Zws, int64_t ldz, int mode)
+{
+    __shared__ double lds[LVBA_K3_LDS];
+    int64_t ti, tj;
+    if (mode == 1) { ti = blockIdx.x; tj = 0; }
+    else tri_decode(blockIdx.x, ti, tj);
+    update_tile(lds, M, k, nbe, w0, rend, Zws, ldz, ti, tj);
+}
+
+// One launch for two independent pieces of work: the factorisation of panel p+1 (diag + panel tiles, blocks [0, T2)) and the
+// bulk of the trailing update of panel p (tiles ti >= tj >= 1, the remaining blocks).  The former touches block column
+// p+1 only, the latter block columns >= p+2, and neither waits for the other inside the launch -- the only ordering is
+// between launches: update(first column of p) -> this -> update(first column of p+1).  The 20 us serial factorisation is
+// thereby hidden behind the HBM-bound update instead of preceding it.
+__global__ __launch_bounds__(256) void ldlt_step_kernel(LdltMat M, int64_t k2, int nbe2, int64_t w02, int64_t rend2, int T2,
+                                                        double *__restrict__ G2, double *__restrict__ dvec,
+                                                        double *__restrict__ Zws2, double *__restrict__ b,
+                                                        int *__restrict__ status, int64_t k, int nbe, int64_t w0, int64_t rend,
+                                                        const double *__restrict__ Zws, int64_t ldz)
+{
+    __shared__ double lds[LVBA_K3_LDS];
+    static_assert(LVBA_K12_LDS <= LVBA_K3_LDS, "factorisation tables must fit the update's LDS");
+    if ((int)blockIdx.x < T2) {
+        diagpanel_tile(lds, M, k2, nbe2, w02, rend2, G2, dvec, Zws2, ldz, b, status, blockIdx.x);
+    } else {
+        int64_t ti, tj;
+        tri_decode((int64_t)blockIdx.x - T2, ti, tj);
+        update_tile(lds, M, k, nbe, w0, rend, Zws, ldz, ti + 1, tj + 1);
+    }
 }
 
 // ---------------------------------------------------------------------------------------- backward
@@ -728,21 +771,24 @@ static inline int64_t ldz_for(int64_t n, int64_t bw)
 int64_t ldlt_workspace_doubles(int64_t n, int64_t bw)
 {
     const int64_t nsteps = (n + LVBA_NB - 1) / LVBA_NB;
-    return nsteps * 4096 /*G*/ + 3 * n /*d, b, bacc*/ + ldz_for(n, bw) * LVBA_NB /*Z*/ + 64;
+    return nsteps * 4096 /*G*/ + 3 * n /*d, b, bacc*/ + 2 * ldz_for(n, bw) * LVBA_NB /*Z, double-buffered*/ + 64;
 }
 
 int64_t ldlt_num_panels(int64_t n) { return (n + LVBA_NB - 1) / LVBA_NB; }
 
-// Launch sequence of one solve: per panel K1 -> K2 -> K3, serial on one stream (captured once into a hipGraph by the
-// caller).  A two-stream look-ahead (K3's bulk beside the next panel's K1/K2) was measured slower than this on MI355X:
-// K3 is HBM-bound and already fills the machine, so the overlapped K1/K2 only wait for slots and every cross-stream edge
-// costs ~10 us.
+// Launch sequence of one solve on one stream (captured once into a hipGraph by the caller).
+//   LVBA_K1 = overlap (default): per panel  [factorise panel p+1 || bulk update of panel p]  ->  first-column update of p+1
+//             fused | blocked | rowwise : the plain K1 (-> K2) -> K3 sequence with the respective diagonal kernel.
+// A two-STREAM look-ahead was measured slower than the serial sequence (every cross-stream edge costs ~10 us); the
+// overlap form gets the same concurrency from one heterogeneous launch.
 void ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_poses, const double *g,
                 const double *u_dev, double *x, double *work, int *status, hipStream_t s)
 {
-    // LVBA_K1 = fused (default: diag + panel in one launch) | blocked (separate 16-column blocked diag kernel) | rowwise
-    static const int k1_mode = [] { const char *e = getenv("LVBA_K1"); return !e ? 2 : !strcmp(e, "rowwise") ? 0 : !strcmp(e, "blocked") ? 1 : 2; }();
-    const bool k1_blocked = k1_mode >= 1, k1_fused = k1_mode == 2;
+    static const int k1_mode = [] {
+        const char *e = getenv("LVBA_K1");
+        return !e ? 3 : !strcmp(e, "rowwise") ? 0 : !strcmp(e, "blocked") ? 1 : !strcmp(e, "fused") ? 2 : 3;
+    }();
+    const bool k1_blocked = k1_mode >= 1, k1_fused = k1_mode >= 2, overlap = k1_mode == 3;
     const int64_t n = A.n, bw = A.bw;
     const int64_t nsteps = (n + LVBA_NB - 1) / LVBA_NB;
     double *Gall = work;
@@ -750,29 +796,60 @@ void ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_pos
     double *b = dvec + n;
     double *bacc = b + n;
     const int64_t ldz = ldz_for(n, bw);
-    double *Zws = bacc + n;
+    double *Zbuf[2] = {bacc + n, bacc + n + ldz * LVBA_NB};
     const size_t abytes = (size_t)((A.ld == n) ? n * n : (A.ld + 1) * n) * sizeof(double);
     hipMemsetAsync(A.a, 0, abytes, s);
     hipMemsetAsync(status, 0, sizeof(int), s);
     hipMemsetAsync(bacc, 0, (size_t)n * sizeof(double), s);
     hipLaunchKernelGGL(ldlt_prepare_kernel, dim3(2048), dim3(256), 0, s, A, Hblk, band_blocks, n_poses, g, u_dev, b);
-    for (int64_t st = 0; st < nsteps; ++st) {
-        const int64_t k = st * LVBA_NB;
-        const int nbe = (int)((n - k) < LVBA_NB ? (n - k) : LVBA_NB);
-        const int64_t w0 = k + nbe;
-        int64_t rend = k + nbe + bw;
-        if (rend > n) rend = n;
-        double *G = Gall + st * 4096;
-        const int64_t T = w0 < rend ? (rend - w0 + 63) / 64 : 0;
-        if (k1_fused && T > 0) {
-            hipLaunchKernelGGL(ldlt_diagpanel_kernel, dim3((unsigned)T), dim3(256), 0, s, A, k, nbe, w0, rend, G, dvec, Zws, ldz, b, status);
+    struct Geo { int64_t k, w0, rend, T; int nbe; };
+    auto geom = [&](int64_t st) {
+        Geo q;
+        q.k = st * LVBA_NB;
+        q.nbe = (int)((n - q.k) < LVBA_NB ? (n - q.k) : LVBA_NB);
+        q.w0 = q.k + q.nbe;
+        q.rend = q.k + q.nbe + bw;
+        if (q.rend > n) q.rend = n;
+        q.T = q.w0 < q.rend ? (q.rend - q.w0 + 63) / 64 : 0;
+        return q;
+    };
+    auto factor_panel = [&](int64_t st, const Geo &q) { // K1 (+ K2) of one panel as launches of their own
+        double *G = Gall + st * 4096, *Zws = Zbuf[st & 1];
+        if (k1_fused && q.T > 0) {
+            hipLaunchKernelGGL(ldlt_diagpanel_kernel, dim3((unsigned)q.T), dim3(256), 0, s, A, q.k, q.nbe, q.w0, q.rend, G, dvec, Zws, ldz, b, status);
         } else {
-            if (k1_blocked) hipLaunchKernelGGL(ldlt_diag_blocked_kernel, dim3(1), dim3(256), 0, s, A, k, nbe, G, dvec, status);
-            else hipLaunchKernelGGL(ldlt_diag_kernel, dim3(1), dim3(128), 0, s, A, k, nbe, G, dvec, status);
-            if (T > 0) hipLaunchKernelGGL(ldlt_panel_kernel, dim3((unsigned)T), dim3(256), 0, s, A, k, nbe, w0, rend, G, dvec, Zws, ldz, b);
+            if (k1_blocked) hipLaunchKernelGGL(ldlt_diag_blocked_kernel, dim3(1), dim3(256), 0, s, A, q.k, q.nbe, G, dvec, status);
+            else hipLaunchKernelGGL(ldlt_diag_kernel, dim3(1), dim3(128), 0, s, A, q.k, q.nbe, G, dvec, status);
+            if (q.T > 0) hipLaunchKernelGGL(ldlt_panel_kernel, dim3((unsigned)q.T), dim3(256), 0, s, A, q.k, q.nbe, q.w0, q.rend, G, dvec, Zws, ldz, b);
         }
-        if (T > 0) {
-            hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)(T * (T + 1) / 2)), dim3(256), 0, s, A, k, nbe, w0, rend, Zws, ldz);
+    };
+    if (!overlap) {
+        for (int64_t st = 0; st < nsteps; ++st) {
+            const Geo q = geom(st);
+            factor_panel(st, q);
+            if (q.T > 0)
+                hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)(q.T * (q.T + 1) / 2)), dim3(256), 0, s, A, q.k, q.nbe, q.w0, q.rend, Zbuf[st & 1], ldz, 0);
+        }
+    } else {
+        Geo q = geom(0);
+        factor_panel(0, q);
+        if (q.T > 0) hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)q.T), dim3(256), 0, s, A, q.k, q.nbe, q.w0, q.rend, Zbuf[0], ldz, 1);
+        for (int64_t st = 0; st + 1 < nsteps; ++st) {
+            const Geo q2 = geom(st + 1);
+            const int64_t nb3 = q.T > 1 ? (q.T - 1) * q.T / 2 : 0; // bulk tiles of panel st
+            if (q2.T > 0) {
+                hipLaunchKernelGGL(ldlt_step_kernel, dim3((unsigned)(q2.T + nb3)), dim3(256), 0, s, A, q2.k, q2.nbe, q2.w0, q2.rend, (int)q2.T,
+                                   Gall + (st + 1) * 4096, dvec, Zbuf[(st + 1) & 1], b, status, q.k, q.nbe, q.w0, q.rend,
+                                   (const double *)Zbuf[st & 1], ldz);
+                hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)q2.T), dim3(256), 0, s, A, q2.k, q2.nbe, q2.w0, q2.rend, Zbuf[(st + 1) & 1], ldz, 1);
+            } else { // the last panel has no rows below it: nothing to overlap with
+                if (nb3 > 0)
+                    hipLaunchKernelGGL(ldlt_step_kernel, dim3((unsigned)nb3), dim3(256), 0, s, A, q2.k, q2.nbe, q2.w0, q2.rend, 0,
+                                       Gall + (st + 1) * 4096, dvec, Zbuf[(st + 1) & 1], b, status, q.k, q.nbe, q.w0, q.rend,
+                                       (const double *)Zbuf[st & 1], ldz);
+                factor_panel(st + 1, q2);
+            }
+            q = q2;
         }
     }
     // backward: one launch per panel.  (A 4-panels-per-launch form, every workgroup walking the group's serial part

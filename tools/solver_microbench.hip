@@ -62,13 +62,13 @@ int main(int argc, char **argv)
     }
     t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_panel_kernel, dim3((unsigned)T), dim3(256), 0, s, A, k, 64, w0, rend, Gall, dvec, Zws, ldz, b); });
     printf("K2 panel  %8.2f us  (%lld tiles)\n", t * 1e3, (long long)T);
-    t = time_ms(s, 100, [&] { hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)(T * (T + 1) / 2)), dim3(256), 0, s, A, k, 64, w0, rend, Zws, ldz); });
+    t = time_ms(s, 100, [&] { hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)(T * (T + 1) / 2)), dim3(256), 0, s, A, k, 64, w0, rend, Zws, ldz, 0); });
     printf("K3 update %8.2f us  (%lld tiles, %.1f TFLOP/s)\n", t * 1e3, (long long)(T * (T + 1) / 2), T * (T + 1) / 2 * 2.0 * 64 * 64 * 64 / (t * 1e-3) / 1e12);
     t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_back_kernel, dim3((unsigned)((bw + 255) / 256)), dim3(256), 0, s, A, k + bw, 64, Gall, dvec, b, bacc, x, k); });
     printf("back      %8.2f us\n", t * 1e3);
     t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_diag_blocked_kernel, dim3(1), dim3(256), 0, s, A, k, 64, Gall, dvec, status);
                               hipLaunchKernelGGL(ldlt_panel_kernel, dim3((unsigned)T), dim3(256), 0, s, A, k, 64, w0, rend, Gall, dvec, Zws, ldz, b);
-                              hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)(T * (T + 1) / 2)), dim3(256), 0, s, A, k, 64, w0, rend, Zws, ldz); });
+                              hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)(T * (T + 1) / 2)), dim3(256), 0, s, A, k, 64, w0, rend, Zws, ldz, 0); });
     printf("K1+K2+K3 chain %8.2f us\n", t * 1e3);
     // empty-kernel launch chain for reference
     t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_prepare_kernel, dim3(1), dim3(64), 0, s, A, work, 0, 0, work, work, work); });
