@@ -498,7 +498,7 @@ __global__ __launch_bounds__(256) void ldlt_panel_kernel(LdltMat M, int64_t k, i
 // waiting for a separate kernel to publish G -- one kernel boundary and the G / d round trip through global memory less per
 // panel, and the workgroup's A21 tile is already in registers when the factorisation ends.  Workgroup 0 also writes G and d
 // (the backward pass needs them).
-#define LVBA_K12_LDS (LVBA_K1B_LDS + 128) // doubles: the blocked factorisation's tables + b_k, y_k
+#define LVBA_K12_LDS (LVBA_K1B_LDS + 128 + 256) // doubles: the blocked factorisation's tables + b_k, y_k + partial sums
 __device__ __forceinline__ void diagpanel_tile(double *lds, LdltMat M, int64_t k, int nbe, int64_t w0, int64_t rend,
                                                double *__restrict__ G, double *__restrict__ dvec, double *__restrict__ Zws,
                                                int64_t ldz, double *__restrict__ b, int *__restrict__ status, int64_t tile)
@@ -529,14 +529,13 @@ __device__ __forceinline__ void diagpanel_tile(double *lds, LdltMat M, int64_t k
 #pragma unroll
     for (int it = 0; it < 16; ++it) As[(w + 4 * it) * LVBA_W1S + row] = av[it];
     __syncthreads();
-    if (tid < 64) { // y_k = L11^-1 b_k = D G^T b_k
-        double z0 = 0.0, z1 = 0.0;
-#pragma unroll 8
-        for (int m = 0; m < 64; m += 2) {
-            z0 += W[tid * LVBA_W1S + 64 + m] * bks[m];
-            z1 += W[tid * LVBA_W1S + 64 + m + 1] * bks[m + 1];
-        }
-        ys[tid] = (tid < nbe) ? (z0 + z1) * dvs[tid] : 0.0;
+    double *red = bks + 128; // [4][64] partial sums (inside the b_k / y_k scratch area)
+    { // y_k = L11^-1 b_k = D G^T b_k: lane (j, q) sums m in [16q, 16q+16), combined after the MFMA loop
+        const int q = tid >> 6;
+        double z = 0.0;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) z += W[row * LVBA_W1S + 64 + 16 * q + m] * bks[16 * q + m];
+        red[q * 64 + row] = z;
     }
     d4 acc[4];
 #pragma unroll
@@ -556,6 +555,7 @@ __device__ __forceinline__ void diagpanel_tile(double *lds, LdltMat M, int64_t k
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) As[(16 * w + kk + 4 * reg) * LVBA_W1S + 16 * t + i] = acc[t][reg];
+    if (tid < 64) ys[tid] = (tid < nbe) ? (red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid]) * dvs[tid] : 0.0;
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
@@ -566,15 +566,16 @@ __device__ __forceinline__ void diagpanel_tile(double *lds, LdltMat M, int64_t k
             Zws[(r - w0) + j * ldz] = v * dvs[j];
         }
     }
-    if (tid < 64 && r < rend) {
-        double s0 = 0.0, s1 = 0.0;
-#pragma unroll 8
-        for (int j = 0; j < 64; j += 2) {
-            s0 += As[j * LVBA_W1S + tid] * ys[j];
-            s1 += As[(j + 1) * LVBA_W1S + tid] * ys[j + 1];
-        }
-        b[r] -= s0 + s1;
+    { // b[r] -= L21[row] . y_k, again four lanes per row
+        const int q = tid >> 6;
+        double sacc = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sacc += As[(16 * q + j) * LVBA_W1S + row] * ys[16 * q + j];
+        __syncthreads(); // red is being reused
+        red[q * 64 + row] = sacc;
     }
+    __syncthreads();
+    if (tid < 64 && r < rend) b[r] -= red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
 }
 __global__ __launch_bounds__(256) void ldlt_diagpanel_kernel(LdltMat M, int64_t k, int nbe, int64_t w0, int64_t rend,
                                                              double *__restrict__ G, double *__restrict__ dvec,
