@@ -336,33 +336,35 @@ __device__ __forceinline__ void diag_blocked_body(double *lds, LdltMat M, int64_
     __syncthreads();
     LVBA_K1B_STAMP(1);
     const int i15 = lane & 15, kk = lane >> 4;
+    // ---- diag step of the 16 columns at c0: wavefront 0 only, no barrier inside
+    auto diag_step = [&](int c0) {
+        const int r = lane < 16 ? c0 + lane : 64 + c0 + (lane & 15);
+        double a[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) a[c] = (lane < 32) ? W[(c0 + c) * LVBA_W1S + r] : 0.0;
+        k1b_steps(std::make_integer_sequence<int, 16>{}, a, lane, fast_rcp(readlane_f64(a[0], 0)));
+        if (lane < 16) {
+            double dl = 0.0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) dl = (c == lane) ? a[c] : dl;
+            dvs[c0 + lane] = dl;
+            if (c0 + lane < nbe && (!(dl != 0.0) || !isfinite(dl))) status[0] = 1;
+        } else if (lane < 32) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                W[(c0 + c) * LVBA_W1S + r] = a[c];
+                G11s[(lane - 16) * 16 + c] = a[c];
+            }
+        }
+    };
+    if (w == 0) diag_step(0);
+    __syncthreads();
     for (int s = 0; s < 4; ++s) {
         const int c0 = 16 * s;
         const int nb_rows = 48 - c0; // block rows still to come
-        if (w == 0) { // ---- diag
-            const int r = lane < 16 ? c0 + lane : 64 + c0 + (lane & 15);
-            double a[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) a[c] = (lane < 32) ? W[(c0 + c) * LVBA_W1S + r] : 0.0;
-            k1b_steps(std::make_integer_sequence<int, 16>{}, a, lane, fast_rcp(readlane_f64(a[0], 0)));
-            if (lane < 16) {
-                double dl = 0.0;
-#pragma unroll
-                for (int c = 0; c < 16; ++c) dl = (c == lane) ? a[c] : dl;
-                dvs[c0 + lane] = dl;
-                if (c0 + lane < nbe && (!(dl != 0.0) || !isfinite(dl))) status[0] = 1;
-            } else if (lane < 32) {
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    W[(c0 + c) * LVBA_W1S + r] = a[c];
-                    G11s[(lane - 16) * 16 + c] = a[c];
-                }
-            }
-        }
-        __syncthreads();
         LVBA_K1B_STAMP(2 + 3 * s);
         // row tile of this wave in the panel / update steps: waves 0..2 -> the 48 panel rows, wave 3 -> the identity
-        // rows of this block (their X is what the diag step just wrote)
+        // rows of this block (their X is what the diag step wrote)
         const int base = (w < 3) ? ((16 * w < nb_rows) ? c0 + 16 + 16 * w : 64 + 16 * w - nb_rows) : 64 + c0;
         if (w < 3) { // ---- panel: X = A * G11
             d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
@@ -382,8 +384,10 @@ __device__ __forceinline__ void diag_blocked_body(double *lds, LdltMat M, int64_
         }
         __syncthreads();
         LVBA_K1B_STAMP(3 + 3 * s);
-        // ---- update: C[base + i][c0 + 16 + 16 ct + n] -= sum_j X[base + i][c0 + j] * Z[16 ct + n][j]
-        for (int ct = 0; 16 * ct < nb_rows; ++ct) {
+        // ---- update: C[base + i][c0 + 16 + 16 ct + n] -= sum_j X[base + i][c0 + j] * Z[16 ct + n][j].  A block-row tile
+        // only needs its lower part (ct <= its own index); identity-row tiles need every column tile.
+        const int ct_end = (w < 3 && 16 * w < nb_rows) ? w + 1 : nb_rows / 16;
+        for (int ct = 0; ct < ct_end; ++ct) {
             d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -394,6 +398,9 @@ __device__ __forceinline__ void diag_blocked_body(double *lds, LdltMat M, int64_
 #pragma unroll
             for (int r = 0; r < 4; ++r) W[(c0 + 16 + 16 * ct + i15) * LVBA_W1S + base + kk + 4 * r] -= acc[r];
         }
+        // look-ahead: wavefront 0's tile was the next diagonal block (rows c0+16.., column tile 0), which nobody else
+        // touches -- its pivot chain runs while the other wavefronts finish their update tiles
+        if (w == 0 && nb_rows > 0) diag_step(c0 + 16);
         __syncthreads();
         LVBA_K1B_STAMP(4 + 3 * s);
     }
