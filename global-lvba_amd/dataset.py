@@ -8,6 +8,7 @@ Mirrors (reference paths):
                              binary_compressed (LZF, fields stored one after the other)
   write_images_txt           src/lvba_system.cpp:2018-2024    COLMAP images.txt rows "id qw qx qy qz tx ty tz 1 id.jpg" + "0.0 0.0 -1"
   write_points3d_txt         src/lvba_system.cpp:2126-2137    COLMAP points3D.txt rows "i x y z r g b 0"
+  load_colmap_db             src/lvba_system.cpp:510-685      keypoints + inlier matches from a COLMAP sqlite database
 Host-side I/O only: nothing here touches the GPU; the arrays go straight into Scans / lidar_ba.
 """
 from __future__ import annotations
@@ -230,3 +231,52 @@ def write_points3d_txt(path, xyz, rgb):
     with open(path, "w") as f:
         for i, (p, c) in enumerate(zip(np.asarray(xyz).reshape(-1, 3), np.asarray(rgb).reshape(-1, 3))):
             f.write(f"{i} {p[0]:.6f} {p[1]:.6f} {p[2]:.6f} {int(c[0])} {int(c[1])} {int(c[2])} 0\n")
+
+
+# ------------------------------------------------------------------------------------------------------------- COLMAP database
+COLMAP_MAX_NUM_IMAGES = (1 << 31) - 1
+
+
+def image_ids_to_pair_id(id1, id2):
+    """src/lvba_system.cpp:512-519 (COLMAP's own formula): ids ordered, id_small * (2^31 - 1) + id_large."""
+    if id1 > id2:
+        id1, id2 = id2, id1
+    return int(id1) * COLMAP_MAX_NUM_IMAGES + int(id2)
+
+
+def load_colmap_db(path, image_names, pairs):
+    """LvbaSystem::loadFromColmapDB (src/lvba_system.cpp:510-685) without OpenCV/SiftGPU types.
+    image_names: file names in the caller's image order (matched against images.name, as name2id upstream);
+    pairs: [(i, j)] index pairs into that order.  Returns (keypoints, matches): keypoints[i] = float32 [n_i, cols] (x, y,
+    then sigma / extremum if present) or an empty array when the image or its blob is missing; matches[k] = int32 [m, 2]
+    inlier matches of two_view_geometries for pairs[k], columns in the order (i, j) of the pair (swapped back when the
+    database stored the pair the other way round), out-of-range indices dropped."""
+    import sqlite3
+    con = sqlite3.connect(path)
+    try:
+        name2id = {name: int(iid) for iid, name in con.execute("SELECT image_id, name FROM images")}
+        ids = [name2id.get(n, -1) for n in image_names]
+        kps = []
+        for iid in ids:
+            row = con.execute("SELECT rows, cols, data FROM keypoints WHERE image_id=?", (iid,)).fetchone() if iid >= 0 else None
+            if row is None or row[2] is None or len(row[2]) != row[0] * row[1] * 4:
+                kps.append(np.zeros((0, 4), np.float32))
+            else:
+                kps.append(np.frombuffer(row[2], np.float32).reshape(row[0], row[1]).copy())
+        out = []
+        for i, j in pairs:
+            m = np.zeros((0, 2), np.int32)
+            a, b = ids[i], ids[j]
+            if a >= 0 and b >= 0 and len(kps[i]) and len(kps[j]):
+                row = con.execute("SELECT rows, cols, data FROM two_view_geometries WHERE pair_id=?",
+                                  (image_ids_to_pair_id(a, b),)).fetchone()
+                if row is not None and row[1] == 2 and row[2] is not None and row[0] > 0 and len(row[2]) == row[0] * 8:
+                    m = np.frombuffer(row[2], np.uint32).reshape(-1, 2).astype(np.int64)
+                    if a > b:                                   # stored as (smaller id, larger id)
+                        m = m[:, ::-1]
+                    ok = (m[:, 0] >= 0) & (m[:, 0] < len(kps[i])) & (m[:, 1] >= 0) & (m[:, 1] < len(kps[j]))
+                    m = m[ok].astype(np.int32)
+            out.append(m)
+        return kps, out
+    finally:
+        con.close()

@@ -103,3 +103,32 @@ def test_colmap_text_writers(tmp_path):
     assert lines[1] == "0.0 0.0 -1" and lines[2].endswith("1 1.jpg")
     ds.write_points3d_txt(str(tmp_path / "points3D.txt"), [[1, 2, 3.5]], [[255, 0, 7]])
     assert (tmp_path / "points3D.txt").read_text() == "0 1.000000 2.000000 3.500000 255 0 7 0\n"
+
+
+def test_colmap_database(tmp_path):
+    """A three-image COLMAP database written by hand: blobs as COLMAP stores them (float32 keypoints [rows, cols],
+    uint32 match pairs keyed by pair_id = id_small * (2^31 - 1) + id_large)."""
+    import sqlite3
+    p = str(tmp_path / "db.db")
+    con = sqlite3.connect(p)
+    con.execute("CREATE TABLE images (image_id INTEGER PRIMARY KEY, name TEXT)")
+    con.execute("CREATE TABLE keypoints (image_id INTEGER PRIMARY KEY, rows INTEGER, cols INTEGER, data BLOB)")
+    con.execute("CREATE TABLE two_view_geometries (pair_id INTEGER PRIMARY KEY, rows INTEGER, cols INTEGER, data BLOB)")
+    names = {7: "0.5.jpg", 3: "1.5.jpg", 9: "2.5.jpg"}
+    rng = np.random.default_rng(0)
+    kp = {iid: rng.uniform(0, 600, (5 + iid, 6 if iid == 9 else 4)).astype(np.float32) for iid in names}
+    for iid, n in names.items():
+        con.execute("INSERT INTO images VALUES (?, ?)", (iid, n))
+        con.execute("INSERT INTO keypoints VALUES (?, ?, ?, ?)", (iid, kp[iid].shape[0], kp[iid].shape[1], kp[iid].tobytes()))
+    m37 = np.array([[0, 1], [2, 3], [7, 11], [99, 0]], np.uint32)          # (image 3, image 7); last row out of range
+    con.execute("INSERT INTO two_view_geometries VALUES (?, ?, ?, ?)", (ds.image_ids_to_pair_id(7, 3), 4, 2, m37.tobytes()))
+    con.commit(); con.close()
+    assert ds.image_ids_to_pair_id(7, 3) == 3 * 2147483647 + 7 == ds.image_ids_to_pair_id(3, 7)
+    order = ["0.5.jpg", "1.5.jpg", "2.5.jpg", "missing.jpg"]              # caller order: ids 7, 3, 9, none
+    kps, matches = ds.load_colmap_db(p, order, [(0, 1), (1, 0), (0, 2), (0, 3)])
+    np.testing.assert_array_equal(kps[0], kp[7]); np.testing.assert_array_equal(kps[2], kp[9])
+    assert kps[3].shape[0] == 0
+    # pair (0, 1) = ids (7, 3): stored as (3, 7) -> columns swapped back to (image 7, image 3)
+    np.testing.assert_array_equal(matches[0], [[1, 0], [3, 2], [11, 7]])
+    np.testing.assert_array_equal(matches[1], [[0, 1], [2, 3], [7, 11]])
+    assert len(matches[2]) == 0 and len(matches[3]) == 0
