@@ -118,3 +118,90 @@ def triangulate_tracks(Rcw, tcw, obs_off, obs_cam, obs_uv, intr, device=0):
                                         Rcw.reshape(-1), tcw.reshape(-1), np.ascontiguousarray(intr, np.float64), X.reshape(-1),
                                         err, cnt, ok))
     return ok[:n], X[:n], err[:n], cnt[:n]
+
+
+def build_tracks(n_keypoints, pairs, matches, obser_thr=3):
+    """Feature tracks = connected components of the match graph, as LvbaSystem::BuildTracksAndFuse3D builds them
+    (src/lvba_system.cpp:923-1003): adjacency filled pair by pair (i < j) in the given order, BFS from every unvisited
+    (image, keypoint) in image-major order, components smaller than obser_thr or seen by fewer than obser_thr images
+    dropped, then one observation per image (the first the BFS met).  Host-side graph walk (this is control flow, not a
+    kernel).  n_keypoints[i] = number of keypoints of image i; pairs = [(i, j)], matches[k] = [m, 2] indices for pairs[k].
+    Returns (obs_off [T+1], obs_img [O], obs_kp [O]) of the de-duplicated tracks."""
+    from collections import deque
+    N = len(n_keypoints)
+    adj = [dict() for _ in range(N)]                    # image -> {kp: [(image, kp), ...]}
+    for (i, j), m in zip(pairs, matches):
+        if i > j:
+            i, j, m = j, i, np.asarray(m)[:, ::-1]
+        for ki, kj in np.asarray(m, np.int64).reshape(-1, 2):
+            if ki < 0 or kj < 0 or ki >= n_keypoints[i] or kj >= n_keypoints[j]:
+                continue
+            adj[i].setdefault(int(ki), []).append((j, int(kj)))
+            adj[j].setdefault(int(kj), []).append((i, int(ki)))
+    seen = [set() for _ in range(N)]
+    off, img, kp = [0], [], []
+    for i in range(N):
+        for ki in sorted(adj[i]):                       # keypoints without matches are singletons: dropped anyway
+            if ki in seen[i]:
+                continue
+            comp, q = [], deque([(i, ki)])
+            seen[i].add(ki)
+            while q:
+                ci, ck = q.popleft()
+                comp.append((ci, ck))
+                for ni, nk in adj[ci].get(ck, ()):
+                    if nk not in seen[ni]:
+                        seen[ni].add(nk)
+                        q.append((ni, nk))
+            if len(comp) < obser_thr:
+                for ci, ck in comp:
+                    seen[ci].discard(ck)                # upstream resets obs_to_track to -1 (:980)
+                continue
+            uniq = {}
+            for ci, ck in comp:
+                uniq.setdefault(ci, ck)
+            if len(uniq) < obser_thr:
+                for ci, ck in comp:
+                    seen[ci].discard(ck)
+                continue
+            for ci, ck in uniq.items():
+                img.append(ci); kp.append(ck)
+            off.append(len(img))
+    return np.asarray(off, np.int64), np.asarray(img, np.int32), np.asarray(kp, np.int32)
+
+
+def triangulate_and_filter(Rcw, tcw, keypoints, obs_off, obs_img, obs_kp, intr, min_view_angle_deg=8.0,
+                           reproj_mean_thr_px=3.0, device=0):
+    """The triangulation candidate of BuildTracksAndFuse3D (src/lvba_system.cpp:1108-1160): seed DLT over all images of the
+    track, greedy view-angle filter against the seed (an observation is kept if its ray makes at least min_view_angle with
+    one already kept ray -- upstream walks an unordered_map, here: track order), DLT again over the kept observations,
+    accepted if its mean reprojection error <= reproj_mean_thr_px.  Both DLT passes run on the GPU
+    (lvba_triangulate_tracks); the depth-fusion candidate (:1016-1106) needs the projected depth images and is not built.
+    Returns (ok [T], X [T,3], mean_reproj [T], kept_off [T+1], kept_img, kept_kp)."""
+    Rcw = np.ascontiguousarray(Rcw, np.float64).reshape(-1, 3, 3)
+    tcw = np.ascontiguousarray(tcw, np.float64).reshape(-1, 3)
+    uv = np.array([keypoints[i][k][:2] for i, k in zip(obs_img, obs_kp)], np.float64).reshape(-1, 2)
+    ok0, X0, _, _ = triangulate_tracks(Rcw, tcw, obs_off, obs_img, uv, intr, device)
+    Cw = -np.einsum("nji,nj->ni", Rcw, tcw)
+    cos_min = np.cos(np.radians(min_view_angle_deg))
+    koff, kimg, kkp, kuv = [0], [], [], []
+    for t in range(len(obs_off) - 1):
+        a, b = obs_off[t], obs_off[t + 1]
+        if ok0[t] and b - a >= 4:
+            dirs = []
+            for o in range(a, b):
+                d = X0[t] - Cw[obs_img[o]]
+                n = np.linalg.norm(d)
+                if n < 1e-6:
+                    continue
+                d = d / n
+                if not dirs or min(float(d @ e) for e in dirs) <= cos_min:
+                    dirs.append(d)
+                    kimg.append(obs_img[o]); kkp.append(obs_kp[o]); kuv.append(uv[o])
+        koff.append(len(kimg))
+    koff = np.asarray(koff, np.int64)
+    kimg = np.asarray(kimg, np.int32); kkp = np.asarray(kkp, np.int32)
+    kuv = np.asarray(kuv, np.float64).reshape(-1, 2)
+    ok1, X1, err1, _ = triangulate_tracks(Rcw, tcw, koff, kimg, kuv, intr, device)
+    ok = (ok1 > 0) & (np.diff(koff) >= 4) & (err1 <= reproj_mean_thr_px)
+    return ok, X1, err1, koff, kimg, kkp

@@ -147,3 +147,57 @@ def test_triangulation_golden_fixture(pkg):
     np.testing.assert_array_equal(cnt, z["count"])
     assert (np.linalg.norm(X - z["X"], axis=1) / np.linalg.norm(z["X"], axis=1)).max() < 1e-7
     assert np.abs(err - z["mean_reproj"]).max() < 1e-6
+
+
+def test_matches_to_landmarks_pipeline(pkg, synth):
+    """keypoints + pairwise matches -> build_tracks (host BFS) -> seed DLT, view-angle filter, final DLT (GPU): the tracks
+    of the synthetic problem come back, and the accepted landmarks sit on the planted ones."""
+    from importlib import import_module
+    vis = import_module("global-lvba_amd.visual")
+    d = synth.make_visual_problem(12, 150, seed=9, track_len=6)
+    M = 12
+    off, cam, uv = d["obs_off"], d["obs_cam"], d["obs_uv"]
+    # keypoint lists per image (shuffled so that keypoint ids are not track ids) and the matches between consecutive
+    # observations of every track
+    rng = np.random.default_rng(1)
+    per_img = [[] for _ in range(M)]
+    for o, c in enumerate(cam):
+        per_img[c].append(o)
+    kp_of_obs = np.zeros(len(cam), np.int64)
+    keypoints = []
+    for c in range(M):
+        order = rng.permutation(len(per_img[c]))
+        ids = np.asarray(per_img[c], np.int64)[order]
+        kp_of_obs[ids] = np.arange(len(ids))
+        keypoints.append(uv[ids])
+    pair_m = {}
+    for t in range(len(off) - 1):
+        obs = list(range(off[t], off[t + 1]))
+        for a, b in zip(obs[:-1], obs[1:]):
+            i, j = int(cam[a]), int(cam[b])
+            ka, kb = int(kp_of_obs[a]), int(kp_of_obs[b])
+            if i == j:
+                continue
+            if i > j:
+                i, j, ka, kb = j, i, kb, ka
+            pair_m.setdefault((i, j), []).append((ka, kb))
+    pairs = sorted(pair_m)
+    matches = [np.asarray(pair_m[p]) for p in pairs]
+    toff, timg, tkp = vis.build_tracks([len(k) for k in keypoints], pairs, matches, obser_thr=3)
+    assert len(toff) - 1 == len(off) - 1                       # every planted track is one component
+    q = d["q_gt"]
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    Rcw = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                    2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                    2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], 1).reshape(-1, 3, 3)
+    ok, X, err, koff, kimg, kkp = vis.triangulate_and_filter(Rcw, d["t_gt"], keypoints, toff, timg, tkp, d["intr"],
+                                                             min_view_angle_deg=0.5)
+    assert ok.mean() > 0.5 and (err[ok] <= 3.0).all()
+    # match recovered tracks to planted landmarks through their first observation
+    first_obs = {(int(cam[off[t]]), int(kp_of_obs[off[t]])): t for t in range(len(off) - 1)}
+    dists = []
+    for t in np.nonzero(ok)[0]:
+        key = (int(timg[toff[t]]), int(tkp[toff[t]]))
+        if key in first_obs:
+            dists.append(np.linalg.norm(X[t] - d["X_gt"][first_obs[key]]))
+    assert len(dists) > 50 and np.median(dists) < 0.5

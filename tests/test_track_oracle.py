@@ -57,3 +57,20 @@ def test_oracle_reproduces_golden_fixture():
     np.testing.assert_array_equal(ok, z["ok"])
     np.testing.assert_array_equal(cnt, z["count"])
     assert np.abs(X - z["X"]).max() < 1e-9 and np.abs(err - z["mean_reproj"]).max() < 1e-9
+
+
+def test_build_tracks_recovers_components():
+    """Host mirror of the BFS track builder (src/lvba_system.cpp:923-1003): components of the match graph, small ones
+    dropped, one observation per image in BFS order."""
+    vis = importlib.import_module("global-lvba_amd.visual")
+    # 4 images; track A: (0,0)-(1,0)-(2,0)-(3,0) chained; track B: (0,1)-(1,1) only (too small);
+    # track C: (0,2)-(1,2)-(2,2) plus a second keypoint of image 1, (1,5), matched to (2,2) -> image 1 seen twice
+    nk = [3, 6, 3, 1]
+    pairs = [(0, 1), (1, 2), (2, 3), (0, 2)]
+    matches = [np.array([[0, 0], [1, 1], [2, 2]]), np.array([[0, 0], [2, 2], [5, 2]]), np.array([[0, 0]]), np.array([[2, 2]])]
+    off, img, kp = vis.build_tracks(nk, pairs, matches, obser_thr=3)
+    tracks = [list(zip(img[a:b].tolist(), kp[a:b].tolist())) for a, b in zip(off[:-1], off[1:])]
+    assert tracks == [[(0, 0), (1, 0), (2, 0), (3, 0)], [(0, 2), (1, 2), (2, 2)]]     # (1,5) is the duplicate of image 1: dropped
+    # out-of-range match indices are ignored (as the bounds checks at :945-947)
+    off2, *_ = vis.build_tracks(nk, [(0, 1)], [np.array([[0, 99], [-1, 0]])], obser_thr=2)
+    assert off2.tolist() == [0]
