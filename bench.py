@@ -123,6 +123,8 @@ def main():
         prob.dist_init(world, rank, uid[0])
     info = prob.info()
     x0 = d["poses_init"]
+    prob.refine(x0)   # set-up, untimed: first-touch allocations and the solve hipGraph (captured lazily at the third solve),
+                      # so that --warmup 0/1 does not put the one-off capture inside the timed steps
 
     def barrier():
         if dist is not None:
