@@ -336,10 +336,24 @@ __global__ __launch_bounds__(256) void balm_pair_kernel(PairDev d, double *__res
 #pragma unroll
     for (int e = 0; e < 36; ++e) acc[e] = row16_sum(acc[e]);
     if (live && l16 == 0) {
-        double2 *hp = reinterpret_cast<double2 *>(Hblk + d.blk_slot[blk] * 36);
+        const int64_t dst = d.blk_slot[blk];
+        double2 *hp = reinterpret_cast<double2 *>(dst >= 0 ? Hblk + dst * 36 : d.partial + (-dst - 1) * 36);
 #pragma unroll
         for (int e = 0; e < 18; ++e) hp[e] = make_double2(-acc[2 * e], -acc[2 * e + 1]);
     }
+}
+
+// blocks whose pair list was cut into several work items (few blocks, many pairs each: window BA): the partial blocks are
+// added up in item order -- still no atomics, still bitwise reproducible
+__global__ void balm_pair_reduce_kernel(PairDev d, double *__restrict__ Hblk)
+{
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t m = t / 36;
+    const int e = (int)(t - 36 * m);
+    if (m >= d.n_multi) return;
+    double s = 0.0;
+    for (int64_t q = d.multi_off[m]; q < d.multi_off[m + 1]; ++q) s += d.partial[36 * q + e];
+    Hblk[d.multi_slot[m] * 36 + e] = s;
 }
 
 // pose-major copy of the cluster statistics (one-off, at finalize)
@@ -473,6 +487,8 @@ void launch_pairs(const PairDev &pd, double *Hblk, hipStream_t s)
 {
     if (pd.nnzb > 0)
         hipLaunchKernelGGL(balm_pair_kernel, dim3((unsigned)((((pd.nnzb + 15) / 16) + 7) / 8 * 8)), dim3(256), 0, s, pd, Hblk);
+    if (pd.n_multi > 0)
+        hipLaunchKernelGGL(balm_pair_reduce_kernel, dim3((unsigned)((pd.n_multi * 36 + 255) / 256)), dim3(256), 0, s, pd, Hblk);
 }
 
 void launch_eval(const BalmDev &d, const PairDev &pd, const double *poses, double *Hblk, int64_t hblk_doubles, double *g,

@@ -30,6 +30,9 @@ struct BlockSys {
     int32_t S = 1;        // slices per block for the per-factor reduction
     int64_t nnzb = 0;
     int64_t *d_csc_off = nullptr, *d_blk_off = nullptr, *d_blk_slot = nullptr;
+    int64_t n_items = 0, n_multi = 0; // work items of the pair pass (>= nnzb), blocks cut into several items
+    int64_t *d_multi_off = nullptr, *d_multi_slot = nullptr;
+    double *d_partial = nullptr;
     int32_t *d_group_of_pos = nullptr, *d_csc_f = nullptr, *d_pos_of = nullptr;
     int2 *d_pairs = nullptr;
     double *d_Y = nullptr; // [F][18]
@@ -55,7 +58,8 @@ struct BlockSys {
     PairDev pair_dev() const
     {
         PairDev p;
-        p.nnzb = nnzb; p.blk_off = d_blk_off; p.blk_slot = d_blk_slot; p.pairs = d_pairs; p.Y = d_Y;
+        p.nnzb = n_items; p.blk_off = d_blk_off; p.blk_slot = d_blk_slot; p.pairs = d_pairs; p.Y = d_Y;
+        p.partial = d_partial; p.n_multi = n_multi; p.multi_off = d_multi_off; p.multi_slot = d_multi_slot;
         return p;
     }
 };

@@ -416,6 +416,38 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
                     }
         }
         bs.nnzb = (int64_t)blk_slot.size();
+        // work items of the pair pass.  One 16-lane group per block is right when there are many blocks (C3: 4e5 blocks of
+        // ~60 pairs); with few blocks and long lists (window BA: 190 blocks x 2000 pairs) it leaves the chip empty, so lists
+        // longer than `cut` pairs become several items whose partial blocks are summed afterwards.
+        std::vector<int64_t> item_off(1, 0), item_dst, multi_off(1, 0), multi_slot;
+        {
+            int64_t cut = (Q / 4096 + 15) / 16 * 16;
+            cut = std::max<int64_t>(64, std::min<int64_t>(cut, 512));
+            int64_t n_partial = 0;
+            for (size_t bi = 0; bi < blk_slot.size(); ++bi) {
+                const int64_t q0 = blk_off[bi], q1 = blk_off[bi + 1];
+                if (q1 - q0 <= cut) {
+                    item_off.push_back(q1);
+                    item_dst.push_back(blk_slot[bi]);
+                } else {
+                    for (int64_t q = q0; q < q1; q += cut) {
+                        item_off.push_back(std::min(q + cut, q1));
+                        item_dst.push_back(-(1 + n_partial++));
+                    }
+                    multi_off.push_back(n_partial);
+                    multi_slot.push_back(blk_slot[bi]);
+                }
+            }
+            bs.n_items = (int64_t)item_dst.size();
+            bs.n_multi = (int64_t)multi_slot.size();
+            if (n_partial) TRY(bs_dmalloc(bs, &bs.d_partial, 36 * n_partial));
+            if (bs.n_multi) {
+                TRY(bs_dmalloc(bs, &bs.d_multi_off, bs.n_multi + 1));
+                TRY(bs_dmalloc(bs, &bs.d_multi_slot, bs.n_multi));
+                HIPCHK(hipMemcpy(bs.d_multi_off, multi_off.data(), (size_t)(bs.n_multi + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(bs.d_multi_slot, multi_slot.data(), (size_t)bs.n_multi * sizeof(int64_t), hipMemcpyHostToDevice));
+            }
+        }
         // slices per block: enough workgroups to fill the chip, but >= ~256 factors per slice
         int64_t Ssz = (2048 + N - 1) / N;
         const int64_t avg = F / N;
@@ -426,8 +458,8 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
         TRY(bs_dmalloc(bs, &bs.d_csc_f, F));
         TRY(bs_dmalloc(bs, &bs.d_pos_of, F));
         TRY(bs_dmalloc(bs, &bs.d_Y, 18 * F));
-        TRY(bs_dmalloc(bs, &bs.d_blk_off, bs.nnzb + 1));
-        TRY(bs_dmalloc(bs, &bs.d_blk_slot, bs.nnzb));
+        TRY(bs_dmalloc(bs, &bs.d_blk_off, bs.n_items + 1));
+        TRY(bs_dmalloc(bs, &bs.d_blk_slot, bs.n_items));
         TRY(bs_dmalloc(bs, &bs.d_pairs, Q));
         HIPCHK(hipMemcpy(bs.d_csc_off, csc_off.data(), (size_t)(N + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
         if (F) {
@@ -435,8 +467,8 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
             HIPCHK(hipMemcpy(bs.d_csc_f, csc_f.data(), (size_t)F * sizeof(int32_t), hipMemcpyHostToDevice));
             HIPCHK(hipMemcpy(bs.d_pos_of, pos_of.data(), (size_t)F * sizeof(int32_t), hipMemcpyHostToDevice));
         }
-        HIPCHK(hipMemcpy(bs.d_blk_off, blk_off.data(), (size_t)(bs.nnzb + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
-        if (bs.nnzb) HIPCHK(hipMemcpy(bs.d_blk_slot, blk_slot.data(), (size_t)bs.nnzb * sizeof(int64_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(bs.d_blk_off, item_off.data(), (size_t)(bs.n_items + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+        if (bs.n_items) HIPCHK(hipMemcpy(bs.d_blk_slot, item_dst.data(), (size_t)bs.n_items * sizeof(int64_t), hipMemcpyHostToDevice));
         if (Q) HIPCHK(hipMemcpy(bs.d_pairs, pairs.data(), (size_t)Q * sizeof(int2), hipMemcpyHostToDevice));
     }
     TRY(bs_dmalloc(bs, &bs.d_perm, N));
@@ -505,7 +537,7 @@ void bs_destroy(BlockSys &bs)
     if (bs.comm && g_rccl.CommDestroy) g_rccl.CommDestroy(bs.comm);
     if (bs.solve_exec) hipGraphExecDestroy(bs.solve_exec);
     if (bs.solve_graph) hipGraphDestroy(bs.solve_graph);
-    void *ptrs[] = {bs.d_perm, bs.d_csc_off, bs.d_blk_off, bs.d_blk_slot, bs.d_group_of_pos, bs.d_csc_f, bs.d_pos_of,
+    void *ptrs[] = {bs.d_multi_off, bs.d_multi_slot, bs.d_partial, bs.d_perm, bs.d_csc_off, bs.d_blk_off, bs.d_blk_slot, bs.d_group_of_pos, bs.d_csc_f, bs.d_pos_of,
                     bs.d_pairs, bs.d_Y, bs.d_hg, bs.d_A, bs.d_work, bs.d_dx, bs.d_u, bs.d_status};
     for (void *p : ptrs)
         if (p) DevicePool::get().free(p);

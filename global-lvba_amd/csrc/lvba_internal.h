@@ -30,11 +30,16 @@ struct BalmDev {
 
 // Per-block contributor lists of the atomic-free assembly of  -sum Y_I Y_J^T  (shared by both stages).
 struct PairDev {
-    int64_t nnzb;              // off-diagonal blocks with at least one contributing group
+    int64_t nnzb;              // work items of the pair pass: off-diagonal blocks, long pair lists cut into several items
     const int64_t *blk_off;    // [nnzb+1] offsets into pairs
-    const int64_t *blk_slot;   // [nnzb] block slot in the block-band store
+    const int64_t *blk_slot;   // [nnzb] >= 0: block slot in the block-band store (the item is the whole block);
+                               //        < 0: -(1 + index into `partial`) (the block is summed from several items)
     const int2 *pairs;         // [Q] (position of block I's factor, position of block J's factor), I > J
     const double *Y;           // [F][18] per-factor Y, pose-major positions
+    double *partial;           // [n_partial][36] partial blocks of the cut lists
+    int64_t n_multi;           // blocks assembled from several items
+    const int64_t *multi_off;  // [n_multi+1] their ranges in `partial`
+    const int64_t *multi_slot; // [n_multi] their slots in the store
 };
 
 // Device view of one packed visual problem (cameras in solver order; only landmarks with a valid plane).
