@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <algorithm>
 #include <queue>
 #include <vector>
@@ -117,8 +118,9 @@ static void rcm_from(const std::vector<std::vector<int32_t>> &nb, const std::vec
 // the other (the nodes in between shift by one), keep the move if (bandwidth, number of edges within 8 of it) did not get
 // worse.  Edge lengths live in a histogram, so a move costs O(degree x nodes moved).  Deterministic (own LCG): every rank
 // of a multi-GPU job derives the same order from the same (all-reduced) graph.  On the C3 co-visibility graph (ring
-// trajectory, +-50 pose band, antipodal loop closures) this takes the half-bandwidth from ~470 to ~420 pose blocks, i.e.
-// ~20 % fewer factorisation flops, for ~3 s of one-off host time; it stops after 5000 moves without progress.
+// trajectory, +-50 pose band, antipodal loop closures) 10 N moves take the half-bandwidth from ~470 to ~435 pose blocks
+// (~15 % fewer factorisation flops) for ~0.1 s of one-off host time; 8x more moves reach ~420 but cost 2.5 s, more than
+// a whole refinement saves.
 static void hill_climb(const std::vector<std::vector<int32_t>> &nb, std::vector<int32_t> &perm, int32_t &bw_io)
 {
     const int N = (int)perm.size();
@@ -131,7 +133,7 @@ static void hill_climb(const std::vector<std::vector<int32_t>> &nb, std::vector<
             if (j > i) hist[std::abs(pos[i] - pos[j])]++;
     int32_t cur = N;
     while (cur > 0 && hist[cur] == 0) --cur;
-    constexpr int32_t SLACK = 8, SMAX = 32;
+    constexpr int32_t SLACK = 8, SMAX = 8;
     auto near_max = [&](int32_t m) { int64_t c = 0; for (int32_t l = std::max(1, m - SLACK); l <= m; ++l) c += hist[l]; return c; };
     uint64_t rng = 0x9e3779b97f4a7c15ull;
     auto next = [&]() { rng = rng * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(rng >> 33); };
@@ -144,7 +146,7 @@ static void hill_climb(const std::vector<std::vector<int32_t>> &nb, std::vector<
                 if (j > i && std::abs(pos[i] - pos[j]) >= cur - SLACK) longe.emplace_back(i, j);
     };
     rebuild();
-    const int64_t iters = std::min<int64_t>(400000, 150 * (int64_t)N);
+    const int64_t iters = std::min<int64_t>(100000, 10 * (int64_t)N); // fixed budget: every rank must derive the same order
     std::vector<int32_t> seg, old;
     int64_t since_rebuild = 0;
     int64_t stale = 0;
@@ -221,7 +223,7 @@ static void rcm_order(const std::vector<uint8_t> &adj, int N, std::vector<int32_
     std::vector<double> x(N), y(N);
     for (int i = 0; i < N; ++i) x[best[i]] = i;
     std::vector<int32_t> idx(N);
-    for (int it = 1; it <= 200; ++it) {
+    for (int it = 1; it <= 40; ++it) {
         for (int i = 0; i < N; ++i) {
             if (nb[i].empty()) { y[i] = x[i]; continue; }
             double s = 0.0;
@@ -284,9 +286,19 @@ int32_t bs_allreduce(BlockSys &bs, double *buf, size_t count)
     return LVBA_OK;
 }
 
+static double bs_now_ms()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return 1e3 * ts.tv_sec + 1e-6 * ts.tv_nsec;
+}
+#define BS_MARK(tag) do { if (timing) { const double t_ = bs_now_ms(); fprintf(stderr, "[bs_build] %-12s %.3f ms\n", tag, t_ - tmark); tmark = t_; } } while (0)
+
 int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const int32_t *pidx)
 {
     if (bs.built) return LVBA_OK;
+    const bool timing = getenv("LVBA_TIMING") != nullptr;
+    double tmark = bs_now_ms();
     HIPCHK(hipSetDevice(bs.device));
     bs.N = N; bs.G = G; bs.F = voff[G];
     const int64_t F = bs.F;
@@ -321,7 +333,8 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
     for (int64_t a = 0; a < G; ++a) { const int64_t k = voff[a + 1] - voff[a]; Q += k * (k - 1) / 2; }
     bs.Q = Q;
     const bool small = (int64_t)N * N <= ((int64_t)1 << 29); // byte adjacency <= 512 MiB
-    if (bs.ordering == 1 && N > 2 && small) {
+    // systems of <= 1024 unknowns (window BA: 20 poses) are solved dense whatever the order: skip the graph work
+    if (bs.ordering == 1 && N > 2 && small && n > 1024) {
         std::vector<uint8_t> adj((size_t)N * N, 0);
         for (int64_t a = 0; a < G; ++a) {
             const int64_t f0 = voff[a], f1 = voff[a + 1];
@@ -351,6 +364,7 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
         }
         if (Bb_rcm < Bb_nat) { bs.perm = perm; bs.iperm = iperm; bs.Bb = Bb_rcm; }
     }
+    BS_MARK("ordering");
     const int64_t bw = 6 * (int64_t)bs.Bb + 5;
     bs.use_band = (double)(bw + LVBA_NB + 64) < bs.band_frac * (double)n;
     if (!bs.use_band) bs.Bb = N - 1; // full lower block triangle
@@ -403,6 +417,7 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
             const int64_t sl = blk_slot[bi];
             blk_off[bi + 1] = blk_off[bi] + start[sl + 1]; // start[sl+1] = number of pairs of slot sl
         }
+        BS_MARK("slots");
         std::vector<int2> pairs((size_t)Q);
         {
             std::vector<int64_t> cur((size_t)nslots, -1); // fill cursor of every non-empty slot
@@ -415,6 +430,7 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
                         pairs[(size_t)cur[sl]++] = make_int2(px, py);
                     }
         }
+        BS_MARK("pairs");
         bs.nnzb = (int64_t)blk_slot.size();
         // work items of the pair pass.  One 16-lane group per block is right when there are many blocks (C3: 4e5 blocks of
         // ~60 pairs); with few blocks and long lists (window BA: 190 blocks x 2000 pairs) it leaves the chip empty, so lists
@@ -471,6 +487,7 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
         if (bs.n_items) HIPCHK(hipMemcpy(bs.d_blk_slot, item_dst.data(), (size_t)bs.n_items * sizeof(int64_t), hipMemcpyHostToDevice));
         if (Q) HIPCHK(hipMemcpy(bs.d_pairs, pairs.data(), (size_t)Q * sizeof(int2), hipMemcpyHostToDevice));
     }
+    BS_MARK("upload");
     TRY(bs_dmalloc(bs, &bs.d_perm, N));
     HIPCHK(hipMemcpy(bs.d_perm, bs.perm.data(), (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice));
     TRY(bs_dmalloc(bs, &bs.d_hg, bs.hg_doubles()));
@@ -489,6 +506,7 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
     bs.A.a = bs.d_A;
     TRY(bs_dmalloc(bs, &bs.d_work, ldlt_workspace_doubles(n, bs.A.bw)));
     HIPCHK(hipMemset(bs.d_hg, 0, (size_t)bs.hg_doubles() * sizeof(double)));
+    BS_MARK("solver");
     bs.built = true;
     return LVBA_OK;
 }
