@@ -8,12 +8,12 @@
 // the band only limits the row window [k+NB, k+NB+bw) each panel touches.
 //
 //   per panel k:
-//     K1 ldlt_diag    1 workgroup: LDL^T of the 64x64 diagonal block.  An identity is appended as extra ROWS, so the
-//                     same elimination yields G = L11^-T D^-1, which turns every later triangular solve with this block
-//                     into a product.  Default: 16-column blocked form (serial chain inside one wavefront's registers,
-//                     panel / trailing steps on fp64 MFMA); LVBA_K1=rowwise selects the earlier row-per-lane form.
-//     K2 ldlt_panel   per 64-row tile: L21 = A21 * G (fp64 MFMA 16x16x4), Z = L21*D, y_k = D G^T b_k, b -= L21*y_k.
-//     K3 ldlt_update  per 64x64 lower tile of the window: A22 -= L21 * Z^T (fp64 MFMA 16x16x4).
+//     diag + panel    every one of the panel's T workgroups factorises the 64x64 diagonal block itself (16-column blocked
+//                     LDL^T with an identity appended as extra ROWS, so the same elimination yields G = L11^-T D^-1, which
+//                     turns every later triangular solve with this block into a product), then forms its 64-row tile of
+//                     L21 = A21 * G (fp64 MFMA 16x16x4), Z = L21*D, y_k = D G^T b_k, b -= L21*y_k.
+//     update          per 64x64 lower tile of the window: A22 -= L21 * Z^T (fp64 MFMA 16x16x4); the first tile column as a
+//                     launch of its own, the rest in the same launch as the NEXT panel's diag + panel work.
 //   backward, per panel from the last: x_k = G D (G^T b_k - acc_k), then acc[c] += A(k:k+64, c)^T x_k
 //   for the <= bw columns left of the panel (right-looking, one launch per panel).
 //   The whole static launch sequence is captured once into a hipGraph (block_system.hip).
@@ -56,17 +56,7 @@ __global__ void ldlt_prepare_kernel(LdltMat M, const double *__restrict__ Hblk, 
 }
 
 // ---------------------------------------------------------------------------------------------- K1
-// LDL^T of the 64x64 diagonal block together with G = L11^-T D^-1 (an identity appended as 64 extra ROWS and
-// carried through the same elimination).  TWO wavefronts, NO barriers in the column loop:
-//   wave 0 (lane = matrix row, the row's 64 entries in registers) eliminates column after column; the unscaled
-//          column j is published in an LDS table Wtab[j][*] followed by a progress flag.  Column j+1 is updated
-//          and published FIRST, then the rest of the rank-1 update runs while that LDS round trip is in flight
-//          and the next step's operands are already being read back (software pipelining through one w[] array).
-//   wave 1 (lane = identity row) trails it: waits for the flag, reads the same columns, updates its G row.
-// Measured history on MI355X: barrier-per-column variants cost 610-880 cycles/column (s_barrier ~230, the
-// LDS write->read round trip and the reciprocal chain all serialised); this form is latency-pipelined.
 // The pivot reciprocal is v_rcp_f64 + 2 Newton steps instead of an IEEE division.
-// Outputs: d_k and G[m][c] (row-major 64x64).
 __device__ __forceinline__ double fast_rcp(double d)
 {
     double r = __builtin_amdgcn_rcp(d);
@@ -78,194 +68,15 @@ __device__ __forceinline__ double fast_rcp(double d)
 #ifdef LVBA_K1_TIMING
 __device__ unsigned long long g_k1b_clk[16];
 #define LVBA_K1B_STAMP(i) do { if (threadIdx.x == 0) g_k1b_clk[i] = __builtin_readcyclecounter(); } while (0)
-__device__ unsigned long long g_k1_clk[8];
-__device__ unsigned long long g_k1_step[2][64];
-#define LVBA_K1_STAMP(i) do { if (threadIdx.x == 0) g_k1_clk[i] = __builtin_readcyclecounter(); } while (0)
-#define LVBA_K1_STEPSTAMP(role, j) do { if ((threadIdx.x & 63) == 0) g_k1_step[role][j] = __builtin_readcyclecounter(); } while (0)
 #else
 #define LVBA_K1B_STAMP(i)
-#define LVBA_K1_STAMP(i)
-#define LVBA_K1_STEPSTAMP(role, j)
 #endif
-
-typedef double vdouble; // plain LDS accesses; ordering comes from LVBA_CBAR + the LDS executing a wave's ops in order
-#define LVBA_CBAR() asm volatile("" ::: "memory") // compiler-only barrier (emits nothing)
-#define LVBA_PIN(x) asm volatile("" : "+v"(x))    // keep the value computed HERE (LLVM otherwise sinks it to its first use)
-
-// wave 0, elimination step with compile-time column J (a runtime index would make a[J] dynamic register
-// indexing).  rd enters as 1/pivot_J and leaves as 1/pivot_{J+1}: the reciprocal chain of the NEXT pivot is
-// issued in the middle of this step's FMA stream, off the critical path.
-template <int J>
-__device__ __forceinline__ void k1_core_step(double (&a)[64], double (&w)[64], vdouble *Wtab, volatile int *flag, int lane,
-                                             double &rd)
-{
-    LVBA_K1_STEPSTAMP(0, J);
-    const double l = (lane > J) ? a[J] * rd : 0.0; // finished rows: l = 0 leaves them untouched
-    a[J] = (lane > J) ? l : a[J];
-    if constexpr (J + 1 < 64) {
-        a[J + 1] = fma(-l, w[J + 1], a[J + 1]);
-        Wtab[(J + 1) * 64 + lane] = a[J + 1]; // publish the next column before finishing this step
-        LVBA_CBAR();
-        *flag = J + 1;
-        LVBA_CBAR();
-        w[J + 1] = Wtab[(J + 1) * 64 + J + 1]; // next pivot first
-        // operands of the next step are read back (16 bytes at a time where aligned) while the FMAs run
-        constexpr int C0 = (J + 2) + ((J + 2) & 1); // first even column >= J+2
-        constexpr int CR = (C0 + 12 < 64) ? C0 + 12 : C0; // where the next reciprocal is slotted in
-        if constexpr (C0 > J + 2) {
-            a[J + 2] = fma(-l, w[J + 2], a[J + 2]);
-            LVBA_PIN(a[J + 2]);
-            w[J + 2] = Wtab[(J + 1) * 64 + J + 2];
-        }
-        if constexpr (C0 >= 64) rd = fast_rcp(w[J + 1]);
-#pragma unroll
-        for (int c = C0; c < 64; c += 2) {
-            if (c == CR) { rd = fast_rcp(w[J + 1]); LVBA_PIN(rd); }
-            a[c] = fma(-l, w[c], a[c]);
-            a[c + 1] = fma(-l, w[c + 1], a[c + 1]);
-            LVBA_PIN(a[c]);
-            LVBA_PIN(a[c + 1]);
-            const double2 t = *reinterpret_cast<const double2 *>(&Wtab[(J + 1) * 64 + c]);
-            w[c] = t.x;
-            w[c + 1] = t.y;
-        }
-    }
-}
-
-// wave 1, the same step for the identity rows (G), trailing wave 0 through the flag
-template <int J>
-__device__ __forceinline__ void k1_g_step(double (&g)[64], double (&w)[64], vdouble *Wtab, volatile int *flag, double &rd)
-{
-    LVBA_K1_STEPSTAMP(1, J);
-    const double l = g[J] * rd;
-    g[J] = l;
-    if constexpr (J + 1 < 64) {
-        while (*flag < J + 1) {}
-        LVBA_CBAR();
-        constexpr int C0 = (J + 1) + ((J + 1) & 1); // first even column >= J+1
-        constexpr int CR = (C0 + 12 < 64) ? C0 + 12 : C0;
-        double pn; // next pivot
-        if constexpr (C0 > J + 1) {
-            g[J + 1] = fma(-l, w[J + 1], g[J + 1]);
-            LVBA_PIN(g[J + 1]);
-            w[J + 1] = Wtab[(J + 1) * 64 + J + 1];
-            pn = w[J + 1];
-        } else {
-            pn = Wtab[(J + 1) * 64 + J + 1];
-        }
-        if constexpr (C0 >= 64) rd = fast_rcp(pn);
-#pragma unroll
-        for (int c = C0; c < 64; c += 2) {
-            if (c == CR) { rd = fast_rcp(pn); LVBA_PIN(rd); }
-            g[c] = fma(-l, w[c], g[c]);
-            g[c + 1] = fma(-l, w[c + 1], g[c + 1]);
-            LVBA_PIN(g[c]);
-            LVBA_PIN(g[c + 1]);
-            const double2 t = *reinterpret_cast<const double2 *>(&Wtab[(J + 1) * 64 + c]);
-            w[c] = t.x;
-            w[c + 1] = t.y;
-        }
-    }
-}
-
-template <int... Js>
-__device__ __forceinline__ void k1_core_steps(std::integer_sequence<int, Js...>, double (&a)[64], double (&w)[64],
-                                              vdouble *Wtab, volatile int *flag, int lane, double rd)
-{
-    (k1_core_step<Js>(a, w, Wtab, flag, lane, rd), ...);
-}
-template <int... Js>
-__device__ __forceinline__ void k1_g_steps(std::integer_sequence<int, Js...>, double (&g)[64], double (&w)[64],
-                                           vdouble *Wtab, volatile int *flag, double rd)
-{
-    (k1_g_step<Js>(g, w, Wtab, flag, rd), ...);
-}
-
-__global__ __launch_bounds__(128) void ldlt_diag_kernel(LdltMat M, int64_t k, int nbe, double *__restrict__ G,
-                                                        double *__restrict__ dvec, int *__restrict__ status)
-{
-    LVBA_K1_STAMP(0);
-    __shared__ __attribute__((aligned(16))) double Wtab_s[64 * 64];
-    __shared__ int flag_s;
-    vdouble *Wtab = Wtab_s;
-    volatile int *flag = &flag_s;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int role = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (tid == 0) flag_s = -1;
-    double a[64], w[64];
-    // initial load of the block, split over both waves: wave 0 takes columns 0..31 straight into registers,
-    // wave 1 stages columns 32..63 in the (still unused) upper half of Wtab
-    if (role == 0) {
-#pragma unroll
-        for (int c = 0; c < 32; ++c) {
-            double v = 0.0;
-            if (lane < nbe) {
-                if (c <= lane) v = M.a[(k + lane) + (k + c) * M.ld];
-            } else if (c == lane)
-                v = 1.0;
-            a[c] = v;
-        }
-    } else {
-        double t[32];
-#pragma unroll
-        for (int c = 32; c < 64; ++c) {
-            double v = 0.0;
-            if (lane < nbe) {
-                if (c <= lane) v = M.a[(k + lane) + (k + c) * M.ld];
-            } else if (c == lane)
-                v = 1.0;
-            t[c - 32] = v;
-        }
-#pragma unroll
-        for (int c = 32; c < 64; ++c) Wtab[c * 64 + lane] = t[c - 32];
-#pragma unroll
-        for (int c = 0; c < 64; ++c) a[c] = (c == lane) ? 1.0 : 0.0;
-    }
-    __syncthreads(); // flag initialised, staged half visible
-    if (role == 0) {
-#pragma unroll
-        for (int c = 32; c < 64; ++c) a[c] = Wtab[c * 64 + lane];
-#pragma unroll
-        for (int c = 32; c < 64; ++c) LVBA_PIN(a[c]);
-    }
-    LVBA_K1_STAMP(1);
-    if (role == 0) {
-        Wtab[lane] = a[0];
-        LVBA_CBAR();
-        *flag = 0;
-        LVBA_CBAR();
-#pragma unroll
-        for (int c = 0; c < 64; ++c) w[c] = Wtab[c];
-        k1_core_steps(std::make_integer_sequence<int, 64>{}, a, w, Wtab, flag, lane, fast_rcp(w[0]));
-    } else {
-        while (*flag < 0) {}
-        LVBA_CBAR();
-#pragma unroll
-        for (int c = 0; c < 64; ++c) w[c] = Wtab[c];
-        k1_g_steps(std::make_integer_sequence<int, 64>{}, a, w, Wtab, flag, fast_rcp(w[0]));
-    }
-    LVBA_K1_STAMP(2);
-    if (role == 0) {
-        // a[lane] is the pivot of row `lane` (updated by every earlier column, never scaled)
-        double dl = 0.0;
-#pragma unroll
-        for (int c = 0; c < 64; ++c) dl = (c == lane) ? a[c] : dl;
-        const bool badp = (lane < nbe) && (!(dl != 0.0) || !isfinite(dl));
-        if (__any(badp) && lane == 0) status[0] = 1;
-        // L11 itself is never read again (every later stage uses G and D), so it is not written back
-        if (lane < nbe) dvec[k + lane] = dl;
-    } else {
-        double2 *go = reinterpret_cast<double2 *>(G + 64 * lane); // G[m][c], row m = lane: 512 contiguous bytes
-#pragma unroll
-        for (int c = 0; c < 64; c += 2) go[c >> 1] = make_double2(a[c], a[c + 1]);
-    }
-    LVBA_K1_STAMP(3);
-}
+#define LVBA_PIN(x) asm volatile("" : "+v"(x)) // keep the value computed HERE (LLVM otherwise sinks it to its first use)
 
 // ------------------------------------------------------------------------------------------ K1, blocked
-// The same factorisation (d, G = L11^-T D^-1) as ldlt_diag_kernel, organised so that the serial chain only ever spans a
-// 16x16 block held in ONE wavefront's registers: the 64x64 block and the 64 appended identity rows live in LDS
+// LDL^T of the 64x64 diagonal block together with G = L11^-T D^-1 (an identity appended as 64 extra ROWS and carried
+// through the same elimination), organised so that the serial chain only ever spans a 16x16 block held in ONE wavefront's
+// registers (an earlier row-per-lane form published every column through LDS and cost 22 us per block; this one 14 us): the 64x64 block and the 64 appended identity rows live in LDS
 // (W[128][64]); per 16-column block step
 //   diag   wave 0: lanes 0..15 hold the block's rows, lanes 16..31 the matching identity rows; 16 compile-time steps, the
 //          pivot row reaches the other lanes through v_readlane (no LDS round trip, no barrier); yields d, the block's
@@ -421,86 +232,7 @@ __global__ __launch_bounds__(256) void ldlt_diag_blocked_kernel(LdltMat M, int64
     LVBA_K1B_STAMP(14);
 }
 
-// ---------------------------------------------------------------------------------------------- K2
-#define LVBA_GS 66 // stride of the [j][m] G tile: 66 = 2 mod 32 -> conflict-free A-operand reads
-__global__ __launch_bounds__(256) void ldlt_panel_kernel(LdltMat M, int64_t k, int nbe, int64_t w0, int64_t rend,
-                                                         const double *__restrict__ G,
-                                                         const double *__restrict__ dvec, double *__restrict__ Zws,
-                                                         int64_t ldz, double *__restrict__ b)
-{
-    __shared__ double As[64 * LVBA_TS]; // [m][row]; later the L tile as [j][row]
-    __shared__ double Gs[64 * LVBA_GS]; // [j][m]
-    __shared__ double bks[64], ys[64];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int row = tid & 63;
-    const int64_t r0 = w0 + 64 * (int64_t)blockIdx.x;
-    const int64_t r = r0 + row;
-    double av[16], gv[16];
-#pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        const int m = w + 4 * it;
-        av[it] = (r < rend && m < nbe) ? M.a[r + (k + m) * M.ld] : 0.0;
-        gv[it] = G[m * 64 + row]; // G[m][j = row], lanes along j: coalesced
-    }
-    if (tid < 64) bks[tid] = (tid < nbe) ? b[k + tid] : 0.0;
-#pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        const int m = w + 4 * it;
-        As[m * LVBA_TS + row] = av[it];
-        Gs[row * LVBA_GS + m] = gv[it]; // [j][m]
-    }
-    __syncthreads();
-    if (tid < 64) { // y_k = L11^-1 b_k = D G^T b_k   (b_k is final: every earlier panel already updated it)
-        double z0 = 0.0, z1 = 0.0;
-#pragma unroll 8
-        for (int m = 0; m < 64; m += 2) {
-            z0 += Gs[tid * LVBA_GS + m] * bks[m];
-            z1 += Gs[tid * LVBA_GS + m + 1] * bks[m + 1];
-        }
-        ys[tid] = (tid < nbe) ? (z0 + z1) * dvec[k + tid] : 0.0;
-    }
-    d4 acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
-    const int i = lane & 15, kk = lane >> 4;
-#pragma unroll 4
-    for (int k0 = 0; k0 < 64; k0 += 4) {
-        const double a = Gs[(16 * w + i) * LVBA_GS + k0 + kk]; // G[m = k0+kk][j = 16w+i]
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const double bv = As[(k0 + kk) * LVBA_TS + 16 * t + i]; // A21[row=16t+i][m]
-            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc[t], 0, 0, 0);
-        }
-    }
-    __syncthreads();
-    // acc[t][reg] = L[row = 16t + i][j = 16w + kk + 4reg]
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) As[(16 * w + kk + 4 * reg) * LVBA_TS + 16 * t + i] = acc[t][reg];
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        const int j = w + 4 * it;
-        if (r < rend && j < nbe) {
-            const double v = As[j * LVBA_TS + row];
-            M.a[r + (k + j) * M.ld] = v;
-            Zws[(r - w0) + j * ldz] = v * dvec[k + j];
-        }
-    }
-    if (tid < 64) {
-        if (r < rend) {
-            double s0 = 0.0, s1 = 0.0;
-#pragma unroll 8
-            for (int j = 0; j < 64; j += 2) {
-                s0 += As[j * LVBA_TS + tid] * ys[j];
-                s1 += As[(j + 1) * LVBA_TS + tid] * ys[j + 1];
-            }
-            b[r] -= s0 + s1;
-        }
-    }
-}
-
+// ---------------------------------------------------------------------------------------------- K1 + K2
 // K1 + K2 in one launch: every panel workgroup repeats the (cheap, 1-workgroup) diagonal factorisation itself instead of
 // waiting for a separate kernel to publish G -- one kernel boundary and the G / d round trip through global memory less per
 // panel, and the workgroup's A21 tile is already in registers when the factorisation ends.  Workgroup 0 also writes G and d
@@ -785,18 +517,14 @@ int64_t ldlt_workspace_doubles(int64_t n, int64_t bw)
 int64_t ldlt_num_panels(int64_t n) { return (n + LVBA_NB - 1) / LVBA_NB; }
 
 // Launch sequence of one solve on one stream (captured once into a hipGraph by the caller).
-//   LVBA_K1 = overlap (default): per panel  [factorise panel p+1 || bulk update of panel p]  ->  first-column update of p+1
-//             fused | blocked | rowwise : the plain K1 (-> K2) -> K3 sequence with the respective diagonal kernel.
+//   LVBA_SCHEDULE = overlap (default): per panel  [factorise panel p+1 || bulk update of panel p]  ->  first-column update of p+1
+//                   serial            : factorise -> update, one after the other (A/B reference).
 // A two-STREAM look-ahead was measured slower than the serial sequence (every cross-stream edge costs ~10 us); the
 // overlap form gets the same concurrency from one heterogeneous launch.
 void ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_poses, const double *g,
                 const double *u_dev, double *x, double *work, int *status, hipStream_t s)
 {
-    static const int k1_mode = [] {
-        const char *e = getenv("LVBA_K1");
-        return !e ? 3 : !strcmp(e, "rowwise") ? 0 : !strcmp(e, "blocked") ? 1 : !strcmp(e, "fused") ? 2 : 3;
-    }();
-    const bool k1_blocked = k1_mode >= 1, k1_fused = k1_mode >= 2, overlap = k1_mode == 3;
+    static const bool overlap = [] { const char *e = getenv("LVBA_SCHEDULE"); return !(e && !strcmp(e, "serial")); }();
     const int64_t n = A.n, bw = A.bw;
     const int64_t nsteps = (n + LVBA_NB - 1) / LVBA_NB;
     double *Gall = work;
@@ -821,15 +549,12 @@ void ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_pos
         q.T = q.w0 < q.rend ? (q.rend - q.w0 + 63) / 64 : 0;
         return q;
     };
-    auto factor_panel = [&](int64_t st, const Geo &q) { // K1 (+ K2) of one panel as launches of their own
+    auto factor_panel = [&](int64_t st, const Geo &q) { // diag (+ panel) of one panel as a launch of its own
         double *G = Gall + st * 4096, *Zws = Zbuf[st & 1];
-        if (k1_fused && q.T > 0) {
+        if (q.T > 0)
             hipLaunchKernelGGL(ldlt_diagpanel_kernel, dim3((unsigned)q.T), dim3(256), 0, s, A, q.k, q.nbe, q.w0, q.rend, G, dvec, Zws, ldz, b, status);
-        } else {
-            if (k1_blocked) hipLaunchKernelGGL(ldlt_diag_blocked_kernel, dim3(1), dim3(256), 0, s, A, q.k, q.nbe, G, dvec, status);
-            else hipLaunchKernelGGL(ldlt_diag_kernel, dim3(1), dim3(128), 0, s, A, q.k, q.nbe, G, dvec, status);
-            if (q.T > 0) hipLaunchKernelGGL(ldlt_panel_kernel, dim3((unsigned)q.T), dim3(256), 0, s, A, q.k, q.nbe, q.w0, q.rend, G, dvec, Zws, ldz, b);
-        }
+        else
+            hipLaunchKernelGGL(ldlt_diag_blocked_kernel, dim3(1), dim3(256), 0, s, A, q.k, q.nbe, G, dvec, status);
     };
     if (!overlap) {
         for (int64_t st = 0; st < nsteps; ++st) {

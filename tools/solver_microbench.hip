@@ -42,17 +42,6 @@ int main(int argc, char **argv)
     const int64_t k = 64 * 10, w0 = k + 64, rend = (k + 64 + bw < n) ? k + 64 + bw : n, T = (rend - w0 + 63) / 64;
     printf("n=%lld bw=%lld panels=%lld T=%lld\n", (long long)n, (long long)bw, (long long)nsteps, (long long)T);
     float t;
-    t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_diag_kernel, dim3(1), dim3(128), 0, s, A, k, 64, Gall, dvec, status); });
-    unsigned long long clk[8]; CK(hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_k1_clk), sizeof clk));
-    printf("K1 diag   %8.2f us   cycles: init %llu  loop %llu (%.0f/col)  store %llu\n", t * 1e3, clk[1] - clk[0], clk[2] - clk[1],
-           (clk[2] - clk[1]) / 64.0, clk[3] - clk[2]);
-    {
-        unsigned long long st[2][64]; CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_k1_step), sizeof st));
-        printf("   wave0 per-step cycles:");
-        for (int j = 1; j < 64; ++j) printf(" %llu", st[0][j] - st[0][j - 1]);
-        printf("\n   wave1 lag behind wave0 (cycles) at steps 1,16,32,48,63: %lld %lld %lld %lld %lld\n", (long long)(st[1][1] - st[0][1]),
-               (long long)(st[1][16] - st[0][16]), (long long)(st[1][32] - st[0][32]), (long long)(st[1][48] - st[0][48]), (long long)(st[1][63] - st[0][63]));
-    }
     t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_diag_blocked_kernel, dim3(1), dim3(256), 0, s, A, k, 64, Gall, dvec, status); });
     {
         unsigned long long c[16]; CK(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_k1b_clk), sizeof c));
@@ -60,16 +49,15 @@ int main(int argc, char **argv)
         for (int q = 0; q < 4; ++q) printf(" diag %llu panel %llu update %llu |", c[2 + 3 * q] - c[1 + 3 * q], c[3 + 3 * q] - c[2 + 3 * q], c[4 + 3 * q] - c[3 + 3 * q]);
         printf(" store %llu  total %llu\n", c[14] - c[13], c[14] - c[0]);
     }
-    t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_panel_kernel, dim3((unsigned)T), dim3(256), 0, s, A, k, 64, w0, rend, Gall, dvec, Zws, ldz, b); });
-    printf("K2 panel  %8.2f us  (%lld tiles)\n", t * 1e3, (long long)T);
+    t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_diagpanel_kernel, dim3((unsigned)T), dim3(256), 0, s, A, k, 64, w0, rend, Gall, dvec, Zws, ldz, b, status); });
+    printf("diag+panel %7.2f us  (%lld tiles)\n", t * 1e3, (long long)T);
     t = time_ms(s, 100, [&] { hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)(T * (T + 1) / 2)), dim3(256), 0, s, A, k, 64, w0, rend, Zws, ldz, 0); });
     printf("K3 update %8.2f us  (%lld tiles, %.1f TFLOP/s)\n", t * 1e3, (long long)(T * (T + 1) / 2), T * (T + 1) / 2 * 2.0 * 64 * 64 * 64 / (t * 1e-3) / 1e12);
     t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_back_kernel, dim3((unsigned)((bw + 255) / 256)), dim3(256), 0, s, A, k + bw, 64, Gall, dvec, b, bacc, x, k); });
     printf("back      %8.2f us\n", t * 1e3);
-    t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_diag_blocked_kernel, dim3(1), dim3(256), 0, s, A, k, 64, Gall, dvec, status);
-                              hipLaunchKernelGGL(ldlt_panel_kernel, dim3((unsigned)T), dim3(256), 0, s, A, k, 64, w0, rend, Gall, dvec, Zws, ldz, b);
+    t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_diagpanel_kernel, dim3((unsigned)T), dim3(256), 0, s, A, k, 64, w0, rend, Gall, dvec, Zws, ldz, b, status);
                               hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)(T * (T + 1) / 2)), dim3(256), 0, s, A, k, 64, w0, rend, Zws, ldz, 0); });
-    printf("K1+K2+K3 chain %8.2f us\n", t * 1e3);
+    printf("diag+panel, update chain %8.2f us\n", t * 1e3);
     // empty-kernel launch chain for reference
     t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_prepare_kernel, dim3(1), dim3(64), 0, s, A, work, 0, 0, work, work, work); });
     printf("tiny kernel back-to-back %8.2f us\n", t * 1e3);
