@@ -12,6 +12,7 @@
 #include <queue>
 #include <vector>
 #include "block_system.h"
+#include "pair_lists.h"
 
 // ------------------------------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
@@ -384,51 +385,20 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
                     csc_f[t] = (int32_t)f; group_of_pos[t] = (int32_t)a; pos_of[f] = (int32_t)t;
                 }
         }
-        const int64_t nslots = (int64_t)N * Bb1;
-        std::vector<int64_t> start((size_t)nslots + 1, 0);
-        auto slot_of = [&](int64_t fx, int64_t fy, int32_t &px, int32_t &py) {
-            int32_t I = bs.iperm[pidx[fx]], J = bs.iperm[pidx[fy]];
-            px = pos_of[fx]; py = pos_of[fy];
-            if (I < J) { std::swap(I, J); std::swap(px, py); }
-            return (int64_t)J * Bb1 + (I - J);
-        };
-        for (int64_t a = 0; a < G; ++a)
-            for (int64_t x = voff[a]; x < voff[a + 1]; ++x)
-                for (int64_t y = x + 1; y < voff[a + 1]; ++y) {
-                    int32_t px, py;
-                    start[slot_of(x, y, px, py) + 1]++;
-                }
+        BS_MARK("csc");
+        TRY(bs_dmalloc(bs, &bs.d_pos_of, F));
+        TRY(bs_dmalloc(bs, &bs.d_pairs, Q));
+        if (F) HIPCHK(hipMemcpy(bs.d_pos_of, pos_of.data(), (size_t)F * sizeof(int32_t), hipMemcpyHostToDevice));
         // Non-empty blocks, visited in 2-D TILES of the block matrix (8 x 8 poses): a tile's pairs touch only a slice of
         // 8 + 8 poses' Y segments (factors are sorted by voxel inside a segment), which stays L2-resident, whereas a
         // column-by-column sweep re-fetches every Y record ~k-1 times from HBM (measured 5.5 GB per pass at C3).
-        std::vector<int64_t> blk_slot;
-        for (int64_t sl = 0; sl < nslots; ++sl)
-            if (start[sl + 1] > 0) blk_slot.push_back(sl);
+        // The Q-sized grouping itself is a device sort (pair_lists.hip).
+        std::vector<int64_t> blk_slot, blk_off;
         {
-            const int64_t TSZ = 8;
-            auto key = [&](int64_t sl) {
-                const int64_t J = sl / Bb1, I = J + (sl - J * Bb1);
-                return std::make_pair((J / TSZ) * ((int64_t)N / TSZ + 1) + I / TSZ, sl);
-            };
-            std::sort(blk_slot.begin(), blk_slot.end(), [&](int64_t a, int64_t b) { return key(a) < key(b); });
-        }
-        std::vector<int64_t> blk_off(blk_slot.size() + 1, 0);
-        for (size_t bi = 0; bi < blk_slot.size(); ++bi) {
-            const int64_t sl = blk_slot[bi];
-            blk_off[bi + 1] = blk_off[bi] + start[sl + 1]; // start[sl+1] = number of pairs of slot sl
-        }
-        BS_MARK("slots");
-        std::vector<int2> pairs((size_t)Q);
-        {
-            std::vector<int64_t> cur((size_t)nslots, -1); // fill cursor of every non-empty slot
-            for (size_t bi = 0; bi < blk_slot.size(); ++bi) cur[blk_slot[bi]] = blk_off[bi];
-            for (int64_t a = 0; a < G; ++a)
-                for (int64_t x = voff[a]; x < voff[a + 1]; ++x)
-                    for (int64_t y = x + 1; y < voff[a + 1]; ++y) {
-                        int32_t px, py;
-                        const int64_t sl = slot_of(x, y, px, py);
-                        pairs[(size_t)cur[sl]++] = make_int2(px, py);
-                    }
+            std::vector<int32_t> blk_of((size_t)F);
+            for (int64_t f = 0; f < F; ++f) blk_of[f] = bs.iperm[pidx[f]];
+            TRY(pair_lists_build(bs.stream, G, voff, F, blk_of.data(), bs.d_pos_of, N, (int32_t)Bb1, Q, bs.d_pairs, blk_slot,
+                                 blk_off));
         }
         BS_MARK("pairs");
         bs.nnzb = (int64_t)blk_slot.size();
@@ -472,20 +442,16 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
         TRY(bs_dmalloc(bs, &bs.d_csc_off, N + 1));
         TRY(bs_dmalloc(bs, &bs.d_group_of_pos, F));
         TRY(bs_dmalloc(bs, &bs.d_csc_f, F));
-        TRY(bs_dmalloc(bs, &bs.d_pos_of, F));
         TRY(bs_dmalloc(bs, &bs.d_Y, 18 * F));
         TRY(bs_dmalloc(bs, &bs.d_blk_off, bs.n_items + 1));
         TRY(bs_dmalloc(bs, &bs.d_blk_slot, bs.n_items));
-        TRY(bs_dmalloc(bs, &bs.d_pairs, Q));
         HIPCHK(hipMemcpy(bs.d_csc_off, csc_off.data(), (size_t)(N + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
         if (F) {
             HIPCHK(hipMemcpy(bs.d_group_of_pos, group_of_pos.data(), (size_t)F * sizeof(int32_t), hipMemcpyHostToDevice));
             HIPCHK(hipMemcpy(bs.d_csc_f, csc_f.data(), (size_t)F * sizeof(int32_t), hipMemcpyHostToDevice));
-            HIPCHK(hipMemcpy(bs.d_pos_of, pos_of.data(), (size_t)F * sizeof(int32_t), hipMemcpyHostToDevice));
         }
         HIPCHK(hipMemcpy(bs.d_blk_off, item_off.data(), (size_t)(bs.n_items + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
         if (bs.n_items) HIPCHK(hipMemcpy(bs.d_blk_slot, item_dst.data(), (size_t)bs.n_items * sizeof(int64_t), hipMemcpyHostToDevice));
-        if (Q) HIPCHK(hipMemcpy(bs.d_pairs, pairs.data(), (size_t)Q * sizeof(int2), hipMemcpyHostToDevice));
     }
     BS_MARK("upload");
     TRY(bs_dmalloc(bs, &bs.d_perm, N));

@@ -1,0 +1,17 @@
+// pair_lists.h -- device construction of the block-major pair lists (pair_lists.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <vector>
+
+namespace lvba {
+
+// voff [G+1]: factor ranges of the voxels; blk_of [F]: solver-order pose block of every factor (host); d_pos_of [F]:
+// position of every factor in the pose-major Y array (device).  Writes the Q sorted (pos_x, pos_y) records to d_pairs
+// (device, caller-allocated) and returns the non-empty block slots J * Bb1 + (I - J) in tile order with their list
+// offsets.  Synchronises the stream.
+int32_t pair_lists_build(hipStream_t s, int64_t G, const int64_t *h_voff, int64_t F, const int32_t *h_blk_of,
+                         const int32_t *d_pos_of, int32_t N, int32_t Bb1, int64_t Q, int2 *d_pairs,
+                         std::vector<int64_t> &blk_slot, std::vector<int64_t> &blk_off);
+
+} // namespace lvba
