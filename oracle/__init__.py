@@ -171,3 +171,159 @@ def ldlt_solve_band(AB, bw, b, nthreads=8):
     x = np.empty(n)
     rc = lib.bo_ldlt_solve_band(n, bw, AB.reshape(-1), ldab, np.ascontiguousarray(b, np.float64), x, nthreads)
     return x, rc
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# oracle/_ref: the reference's own BALM headers compiled against the Eigen / PCL stand-ins of oracle/shim (Makefile
+# target `ref`, sources read from /root/reference where they lie).  Used by tests/test_ref_pin.py and
+# tests/golden/make_golden.py to pin the restatements above; never by the product.
+# ---------------------------------------------------------------------------------------------------------------------
+REFERENCE_ROOT = os.environ.get("LVBA_REFERENCE_ROOT", "/root/reference")
+_RLIB = None
+
+
+def build_ref(force=False):
+    """Builds oracle/_ref/libbalm_ref.so when the reference sources are present; returns its path, or None when neither
+    the sources nor a prebuilt library exist (e.g. a checkout without /root/reference)."""
+    so = os.path.join(_HERE, "_ref", "libbalm_ref.so")
+    hdr = os.path.join(REFERENCE_ROOT, "include", "BALM", "bavoxel.hpp")
+    if os.path.exists(hdr):
+        deps = [os.path.join(_HERE, "ref_glue.cpp"), os.path.join(_HERE, "shim", "lvba_eigen_standin.h"), hdr,
+                os.path.join(REFERENCE_ROOT, "include", "BALM", "tools.hpp")]
+        if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
+            subprocess.check_call(["make", "-C", _HERE, "-B", "-s", "ref", "REF=" + REFERENCE_ROOT])
+    return so if os.path.exists(so) else None
+
+
+def load_ref():
+    """ctypes handle to oracle/_ref/libbalm_ref.so, or None when it cannot be had."""
+    global _RLIB
+    if _RLIB is None:
+        so = build_ref()
+        if so is None:
+            return None
+        lib = ctypes.CDLL(so)
+        f64p = np.ctypeslib.ndpointer(np.float64, flags="C")
+        f32p = np.ctypeslib.ndpointer(np.float32, flags="C")
+        i64p = np.ctypeslib.ndpointer(np.int64, flags="C")
+        c_i64, c_int, c_dbl, vp = ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_void_p
+        lib.ref_acc_evaluate2.restype = c_i64
+        lib.ref_acc_evaluate2.argtypes = [c_int, c_i64, f64p, f64p, f64p, f64p, ctypes.POINTER(c_dbl)]
+        lib.ref_divide_thread.restype = c_dbl
+        lib.ref_divide_thread.argtypes = [c_int, c_i64, f64p, f64p, f64p, f64p]
+        lib.ref_only_residual.restype = c_dbl
+        lib.ref_only_residual.argtypes = [c_int, c_i64, f64p, f64p, c_int]
+        lib.ref_damping_iter.restype = c_i64
+        lib.ref_damping_iter.argtypes = [c_int, c_i64, f64p, f64p]
+        lib.ref_exp.argtypes = [f64p, f64p]
+        lib.ref_transform_cluster.argtypes = [f64p, f64p, f64p]
+        lib.ref_map_build.restype = vp
+        lib.ref_map_build.argtypes = [c_int, i64p, f32p, f64p, c_dbl, f32p]
+        lib.ref_map_sizes.argtypes = [vp] + [ctypes.POINTER(c_i64)] * 3
+        lib.ref_map_export.argtypes = [vp, i64p, f64p, f64p]
+        lib.ref_map_find_planes.argtypes = [vp, c_i64, f64p, c_dbl, f64p]
+        lib.ref_map_free.argtypes = [vp]
+        lib.ref_down_sampling_voxel2.restype = c_i64
+        lib.ref_down_sampling_voxel2.argtypes = [c_i64, f32p, c_dbl, f32p]
+        lib.ref_pl_transform.argtypes = [c_i64, f32p, f64p]
+        _RLIB = lib
+    return _RLIB
+
+
+def csr_to_slots(n_poses, voxel_off, pose_idx, clusters):
+    """CSR problem (lvba_balm_create layout) -> the reference's dense layout [V][win_size][10] with empty slots zero."""
+    voxel_off = np.asarray(voxel_off, np.int64)
+    V = len(voxel_off) - 1
+    out = np.zeros((V, int(n_poses), 10))
+    clusters = np.asarray(clusters, np.float64).reshape(-1, 10)
+    for a in range(V):
+        for f in range(voxel_off[a], voxel_off[a + 1]):
+            out[a, int(pose_idx[f])] = clusters[f]
+    return out
+
+
+class Reference:
+    """numpy front of oracle/_ref/libbalm_ref.so (the reference's BALM code).  Reference.available() first."""
+
+    @staticmethod
+    def available():
+        return load_ref() is not None
+
+    def __init__(self):
+        self.lib = load_ref()
+        if self.lib is None:
+            raise RuntimeError("oracle/_ref/libbalm_ref.so is absent and /root/reference is not there to build it from")
+
+    @staticmethod
+    def _c(a, dt=np.float64):
+        return np.ascontiguousarray(a, dt)
+
+    def exp(self, w):
+        R = np.empty(9)
+        self.lib.ref_exp(self._c(w).reshape(3), R)
+        return R.reshape(3, 3)
+
+    def transform_cluster(self, cluster, pose):
+        out = np.empty(10)
+        self.lib.ref_transform_cluster(self._c(cluster).reshape(10), self._c(pose).reshape(12), out)
+        return out
+
+    def acc_evaluate2(self, slots, poses):
+        V, win = slots.shape[:2]
+        H, g, r = np.empty((6 * win, 6 * win)), np.empty(6 * win), ctypes.c_double()
+        n = self.lib.ref_acc_evaluate2(win, V, self._c(slots).reshape(-1), self._c(poses).reshape(-1), H, g, ctypes.byref(r))
+        return H, g, r.value, int(n)
+
+    def divide_thread(self, slots, poses):
+        V, win = slots.shape[:2]
+        H, g = np.empty((6 * win, 6 * win)), np.empty(6 * win)
+        r = self.lib.ref_divide_thread(win, V, self._c(slots).reshape(-1), self._c(poses).reshape(-1), H, g)
+        return H, g, float(r)
+
+    def only_residual(self, slots, poses, is_avg=False):
+        V, win = slots.shape[:2]
+        return float(self.lib.ref_only_residual(win, V, self._c(slots).reshape(-1), self._c(poses).reshape(-1), int(is_avg)))
+
+    def damping_iter(self, slots, poses):
+        V, win = slots.shape[:2]
+        x = np.array(poses, np.float64).reshape(-1).copy()
+        self.lib.ref_damping_iter(win, V, self._c(slots).reshape(-1), x)
+        return x.reshape(-1, 12)
+
+    def map_build(self, clouds, poses, voxel_size, eigen_ratio=(0.3, 0.1, 0.06, 0.03)):
+        """cut_voxel + recut + tras_opt as the reference's call sites run them.  Returns dict(keys [P,4] (x, y, z,
+        layer<<6|o1<<3|o2), clusters [P,win,10], geo [P,9] (center, direct, eigenvalues), n_roots, n_admitted, handle),
+        planes sorted by key; close with map_free(handle)."""
+        win = len(clouds)
+        off = np.zeros(win + 1, np.int64)
+        off[1:] = np.cumsum([len(c) for c in clouds])
+        pts = np.ascontiguousarray(np.concatenate([np.asarray(c, np.float32)[:, :3] for c in clouds]), np.float32)
+        h = self.lib.ref_map_build(win, off, pts.reshape(-1), self._c(poses).reshape(-1), float(voxel_size),
+                                   self._c(eigen_ratio, np.float32))
+        n = [ctypes.c_int64() for _ in range(3)]
+        self.lib.ref_map_sizes(h, *[ctypes.byref(x) for x in n])
+        R, P, A = (x.value for x in n)
+        keys, clu, geo = np.zeros((P, 4), np.int64), np.zeros((P, win, 10)), np.zeros((P, 9))
+        self.lib.ref_map_export(h, keys.reshape(-1), clu.reshape(-1), geo.reshape(-1))
+        order = np.lexsort((keys[:, 3], keys[:, 2], keys[:, 1], keys[:, 0]))
+        return dict(keys=keys[order], clusters=clu[order], geo=geo[order], n_roots=R, n_admitted=A, handle=h)
+
+    def map_find_planes(self, handle, X, voxel_size):
+        X = self._c(X).reshape(-1, 3)
+        out = np.zeros((len(X), 4))
+        self.lib.ref_map_find_planes(handle, len(X), X.reshape(-1), float(voxel_size), out.reshape(-1))
+        return out
+
+    def map_free(self, handle):
+        self.lib.ref_map_free(handle)
+
+    def down_sampling_voxel2(self, pts, leaf):
+        pts = self._c(pts, np.float32).reshape(-1, 3)
+        out = np.empty_like(pts)
+        n = self.lib.ref_down_sampling_voxel2(len(pts), pts.reshape(-1), float(leaf), out.reshape(-1))
+        return out[:n]
+
+    def pl_transform(self, pts, pose):
+        p = np.array(pts, np.float32).reshape(-1, 3).copy()
+        self.lib.ref_pl_transform(len(p), p.reshape(-1), self._c(pose).reshape(12))
+        return p

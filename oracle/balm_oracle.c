@@ -3,9 +3,9 @@
  * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and
  * bench.py's cpu_baseline leg may load it.  The product path (liblvba_hip.so) never links it.
  *
- * PARITY UNPINNED: the reference ships no tests / golden vectors for this path and cannot be
- * compiled here (needs Eigen + PCL); see oracle/balm_oracle.py's header for how the two
- * restatements are pinned instead (finite differences, each other, autograd).
+ * Pinned against the reference's own BALM headers compiled with the Eigen / PCL stand-ins of oracle/shim
+ * (oracle/_ref/libbalm_ref.so; tests/test_ref_pin.py, tests/golden/ref_balm.npz) -- see oracle/balm_oracle.py's
+ * header -- and by finite differences, the numpy twin and autograd.
  *
  * Restates, with the reference's own formulation (Auk / umumT / per-block corrections):
  *   PointCluster::transform            include/BALM/tools.hpp:450-456

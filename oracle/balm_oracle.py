@@ -4,11 +4,15 @@ THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smo
 bench.py's cpu_baseline leg may import it.  The product path is the HIP library behind
 include/lvba_hip.h and must never route through this file.
 
-PARITY UNPINNED: the reference (xuankuzcr/Global-LVBA) ships no tests, golden vectors or
-fixtures for this path and cannot be compiled here (needs Eigen + PCL).
-This restatement is instead pinned by (1) central finite differences of its own cost
-(tests/test_oracle_fd.py), (2) an independent C restatement (oracle/balm_oracle.c) and
-(3) a structurally different autograd formulation (tests/test_oracle_autograd.py).
+PINNED AGAINST THE REFERENCE'S OWN CODE: the reference (xuankuzcr/Global-LVBA) ships no tests, golden vectors or
+fixtures for this path, and Eigen / PCL are not installed here -- but its BALM headers
+(include/BALM/tools.hpp, bavoxel.hpp) compile unmodified against the small Eigen / PCL stand-ins of oracle/shim
+(`make -C oracle ref` -> oracle/_ref/libbalm_ref.so).  tests/test_ref_pin.py holds every function below against that
+library (H, g to 1e-9; costs to 1e-9; LM-refined poses to 1e-5, the last LM decisions being taken at rounding-noise
+level), and tests/golden/ref_balm.npz carries its answers to the GPU box.  What the stand-in supplies in Eigen's place
+(3x3 symmetric eigen-solver, LDL^T, products) is the only part not the reference's own.  Additionally pinned by
+(1) central finite differences of its own cost, (2) an independent C restatement (oracle/balm_oracle.c) and
+(3) a structurally different autograd formulation (tests/test_oracle.py).
 
 Each function cites the reference lines it restates (paths relative to /root/reference).
 

@@ -5,8 +5,9 @@
 //   OCTO_TREE_NODE::cut_func/recut   include/BALM/bavoxel.hpp:357-464 (judge_eigen :335-352)
 //   OCTO_TREE_NODE::tras_opt         include/BALM/bavoxel.hpp:466-474 -> VOX_HESS::push_voxel :45-54
 //   VOXEL_LOC + its std::hash        include/BALM/tools.hpp:29-60
-// PARITY UNPINNED (the reference ships no tests and cannot be compiled here: Eigen/PCL absent); pinned by the hand-built
-// cases of tests/test_voxel_oracle.py through the Python twin, which this file must match bit for bit.
+// Pinned against the reference's own headers compiled with the Eigen / PCL stand-ins of oracle/shim (tests/test_ref_pin.py:
+// bit-identical clusters) and by the hand-built cases of tests/test_voxel_oracle.py through the Python twin, which this
+// file must match bit for bit.
 // Eigen::SelfAdjointEigenSolver is replaced by a cyclic Jacobi iteration (results differ at rounding level only).
 #include <algorithm>
 #include <cmath>

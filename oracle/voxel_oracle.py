@@ -8,7 +8,10 @@ Literal restatement (paths relative to /root/reference) of
   OCTO_TREE_NODE::findCorrespondPoint include/BALM/bavoxel.hpp:320-333 (landmark -> plane lookup, src/lvba_system.cpp:1531-1565)
 including its fp32 quirks: voxel keys from a FLOAT quotient with "-1 if negative" then C
 truncation; voxel centres and quarter lengths stored as float; octant test `double > float`.
-PARITY UNPINNED (the reference ships no tests); pinned by tests/test_voxel_oracle.py (hand-built cases).
+PINNED against the reference's own bavoxel.hpp / tools.hpp compiled with the Eigen / PCL stand-ins of oracle/shim
+(oracle/_ref/libbalm_ref.so): tests/test_ref_pin.py finds the same roots, the same plane nodes at the same octant paths and
+bit-identical per-frame clusters, and the same plane for every looked-up landmark; tests/golden/ref_voxel.npz carries the
+reference's answers to the GPU box.  Also pinned by the hand-built cases of tests/test_voxel_oracle.py.
 Traversal order of the reference's unordered_map is unspecified; voxels are reported sorted by (root key, path).
 """
 from __future__ import annotations

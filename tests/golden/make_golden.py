@@ -1,9 +1,13 @@
 """Generates tests/golden/*.npz: small packed problems + the oracle's outputs on them.
 
-PARITY UNPINNED: the reference has no tests / golden vectors and cannot be built or imported here
-(C++ needing Eigen, PCL, Ceres), so these fixtures come from OUR restatement (oracle/balm_oracle.py,
-cross-checked against oracle/balm_oracle.c and finite differences), not from the reference itself.
-They freeze the oracle: any later change to oracle/ or to the generator that alters results is caught.
+The reference has no tests / golden vectors of its own.  Two kinds of fixtures are written here:
+  * balm_*.npz, visual_small.npz, voxel_small.npz, tracks_small.npz -- inputs + the answers of OUR restatement
+    (oracle/*.py): they freeze the oracle, any later change to oracle/ or to the generator that alters results is caught;
+  * ref_balm.npz, ref_voxel.npz (main_ref) -- the answers of THE REFERENCE'S OWN CODE on the same inputs:
+    include/BALM/{tools,bavoxel}.hpp compiled from /root/reference against the Eigen / PCL stand-ins of oracle/shim
+    (oracle/_ref/libbalm_ref.so, `make -C oracle ref`).  These are what the -m gpu tests on the GPU box (where
+    /root/reference does not exist) hold the HIP path against.  The visual stage (Ceres) and src/lvba_system.cpp (ROS,
+    OpenCV, SiftGPU) cannot be built here; their fixtures stay restatement-only (PARITY UNPINNED for those pieces).
 
     python tests/golden/make_golden.py
 """
@@ -92,7 +96,37 @@ def main_voxel():
     print("tracks_small", int(ok.sum()), "of", len(ok), "tracks triangulated")
 
 
+def main_ref():
+    """Reference-generated golden vectors: needs /root/reference (or a prebuilt oracle/_ref/libbalm_ref.so)."""
+    import oracle
+    ref = oracle.Reference()
+    out = {}
+    for name in CASES:
+        z = np.load(os.path.join(HERE, name + ".npz"))
+        slots = oracle.csr_to_slots(int(z["n_poses"]), z["voxel_off"], z["pose_idx"], z["clusters"])
+        H, g, c_avg = ref.divide_thread(slots, z["poses_init"])             # BALM2::divide_thread
+        out[name + "__H"], out[name + "__g"], out[name + "__cost_avg"] = H, g, c_avg
+        out[name + "__cost_sum"] = ref.only_residual(slots, z["poses_init"], False)
+        xf = ref.damping_iter(slots, z["poses_init"])                       # BALM2::damping_iter
+        out[name + "__poses_final"] = xf
+        out[name + "__cost_final_avg"] = ref.only_residual(slots, xf, True)
+        print("ref", name, "cost", c_avg, "->", out[name + "__cost_final_avg"])
+    np.savez_compressed(os.path.join(HERE, "ref_balm.npz"), **out)
+    z = np.load(os.path.join(HERE, "voxel_small.npz"))
+    clouds = np.split(z["points"], np.cumsum(z["counts"])[:-1])
+    m = ref.map_build(clouds, z["poses"], 1.0)                              # cut_voxel + recut + tras_opt
+    adm = np.array([np.count_nonzero(c[:, 9] != 0) >= 2 for c in m["clusters"]])
+    planes = ref.map_find_planes(m["handle"], z["query"], 1.0)              # findCorrespondPoint at the call site
+    ref.map_free(m["handle"])
+    # anchor cloud of the first window of 3 frames merged with the (odometry) poses, then down_sampling_voxel2
+    np.savez_compressed(os.path.join(HERE, "ref_voxel.npz"), keys=m["keys"][adm], slots=m["clusters"][adm], geo=m["geo"][adm],
+                        n_roots=m["n_roots"], n_plane_nodes=len(adm), n_admitted=m["n_admitted"], planes=planes)
+    print("ref voxel_small", m["n_roots"], "roots,", len(adm), "plane nodes,", int(adm.sum()), "admitted,",
+          int(np.any(planes != 0, axis=1).sum()), "queries on planes")
+
+
 if __name__ == "__main__":
     main()
     main_visual()
     main_voxel()
+    main_ref()

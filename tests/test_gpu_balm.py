@@ -100,6 +100,27 @@ def _compare_traces(trace, tr_ref, x_gpu, x_ref, tol=1e-7):
         assert np.abs(x_gpu - x_ref).max() <= 1e-5   # north_star's bar; the coin-flip step itself is ~1e-6
 
 
+@pytest.mark.parametrize("name", ["balm_small", "balm_window", "balm_reject"])
+def test_hip_matches_reference_golden(pkg, name):
+    """The HIP path against what the REFERENCE'S OWN CODE answers on the committed fixtures (tests/golden/ref_balm.npz:
+    BALM2::divide_thread and BALM2::damping_iter of include/BALM/bavoxel.hpp, compiled from the reference's sources against
+    the stand-ins of oracle/shim by tests/golden/make_golden.py:main_ref).  No oracle in between."""
+    import os
+    gd = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    z, r = np.load(os.path.join(gd, name + ".npz")), np.load(os.path.join(gd, "ref_balm.npz"))
+    prob = pkg.BalmProblem(int(z["n_poses"]), z["voxel_off"], z["pose_idx"], z["clusters"])
+    x0 = z["poses_init"]
+    H, g, c = prob.eval(x0)
+    assert abs(c - r[name + "__cost_avg"]) <= 1e-8 * r[name + "__cost_avg"]
+    assert rel(g, r[name + "__g"]) <= 1e-8 and rel(H, r[name + "__H"]) <= 1e-8
+    assert abs(prob.cost(x0) - r[name + "__cost_sum"]) <= 1e-8 * r[name + "__cost_sum"]
+    xf, trace, rc = prob.refine(x0)
+    assert rc == 0
+    assert np.abs(xf - r[name + "__poses_final"]).max() <= 1e-5              # BASELINE.json: refined poses within 1e-5
+    cf = prob.cost(xf, is_avg=True)
+    assert abs(cf - r[name + "__cost_final_avg"]) <= 1e-5 * r[name + "__cost_final_avg"]   # and the converged cost
+
+
 def test_refine_reject_branch(pkg, oracle_mod):
     """A start far enough from the optimum that the first steps are rejected (u *= v; v *= 2;
     Hessian reused, bavoxel.hpp:753-758)."""

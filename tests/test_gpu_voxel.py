@@ -227,3 +227,35 @@ def test_golden_fixture(pkg):
     got = w["anchor_scans"].counts.tolist()
     assert all(abs(a - b) <= max(2, 0.002 * b) for a, b in zip(got, z["win_anchor_counts"].tolist()))
     w["anchor_scans"].close()
+
+
+def test_hip_matches_reference_voxel_golden(pkg):
+    """The HIP voxel front-end against what the REFERENCE'S OWN cut_voxel / recut / tras_opt and findCorrespondPoint answer
+    on tests/golden/voxel_small.npz's scans (tests/golden/ref_voxel.npz, generated by make_golden.py:main_ref from
+    include/BALM/bavoxel.hpp compiled against the stand-ins of oracle/shim): same admitted voxels at the same octant paths,
+    per-frame clusters bit for bit, plane lookups to 1e-8 up to the normal's sign."""
+    import os
+    gd = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    z, r = np.load(os.path.join(gd, "voxel_small.npz")), np.load(os.path.join(gd, "ref_voxel.npz"))
+    clouds = np.split(z["points"], np.cumsum(z["counts"])[:-1])
+    with pkg.Scans(clouds) as scans:
+        with scans.voxel_map(z["poses"], 1.0) as m:
+            off, idx, cl, key = m.export()
+            plane, valid = m.find_planes(z["query"])
+            info = dict(m.info)
+    assert len(off) - 1 == int(r["n_admitted"]) == len(r["keys"])
+    assert info["n_roots"] == int(r["n_roots"]) and info["n_planes"] == int(r["n_plane_nodes"])
+    # our key column 3 is len | o1 << 4 | o2 << 8; the reference fixture's is layer << 6 | o1 << 3 | o2
+    k3 = key[:, 3]
+    ours = np.stack([key[:, 0], key[:, 1], key[:, 2], ((k3 & 15) << 6) | (((k3 >> 4) & 15) << 3) | ((k3 >> 8) & 15)], 1)
+    order = np.lexsort((ours[:, 3], ours[:, 2], ours[:, 1], ours[:, 0]))
+    np.testing.assert_array_equal(ours[order], r["keys"])
+    slots = np.zeros_like(r["slots"])
+    for a in range(len(off) - 1):
+        for f in range(off[a], off[a + 1]):
+            slots[a, idx[f]] = cl[f]
+    np.testing.assert_array_equal(slots[order], r["slots"])
+    want_valid = np.any(r["planes"] != 0, axis=1)
+    np.testing.assert_array_equal(valid.astype(bool), want_valid)
+    sgn = np.sign(np.sum(plane[:, :3] * r["planes"][:, :3], axis=1))[:, None]
+    assert np.abs(sgn * plane - r["planes"])[want_valid].max() < 1e-8

@@ -165,6 +165,28 @@ def test_oracles_reproduce_golden(oracle_mod, name):
     assert np.abs(xc - z["poses_final"]).max() <= 1e-8
 
 
+@pytest.mark.parametrize("name", ["balm_small", "balm_window", "balm_reject"])
+def test_oracles_reproduce_reference_golden(oracle_mod, name):
+    """tests/golden/ref_balm.npz holds what THE REFERENCE'S OWN divide_thread / damping_iter (include/BALM/bavoxel.hpp
+    compiled against the stand-ins of oracle/shim, see make_golden.py:main_ref) answers on the fixtures' inputs."""
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    r = np.load(os.path.join(GOLDEN, "ref_balm.npz"))
+    prob = bo.Problem(int(z["n_poses"]), z["voxel_off"], z["pose_idx"], z["clusters"])
+    co = oracle_mod.COracle(int(z["n_poses"]), z["voxel_off"], z["pose_idx"], z["clusters"])
+    x0 = z["poses_init"]
+    H, g, c = bo.divide_thread(prob, x0)
+    Hc, gc, cc = co.eval_dense(x0)
+    for HH, gg, c_ in ((H, g, c), (Hc, gc, cc)):
+        assert abs(c_ - r[name + "__cost_avg"]) <= 1e-9 * r[name + "__cost_avg"]
+        assert rel(HH, r[name + "__H"]) <= 1e-9 and rel(gg, r[name + "__g"]) <= 1e-9
+    assert abs(bo.only_residual(prob, x0) - r[name + "__cost_sum"]) <= 1e-9 * r[name + "__cost_sum"]
+    xr = r[name + "__poses_final"]
+    for xf in (bo.damping_iter(prob, x0)[0], co.damping_iter(x0)[0]):
+        assert np.abs(xf - xr).max() <= 1e-5                                 # BASELINE.json's bar for refined poses
+        cf = bo.only_residual(prob, xf, True)
+        assert abs(cf - r[name + "__cost_final_avg"]) <= 1e-7 * r[name + "__cost_final_avg"]
+
+
 # ---------------------------------------------------------------------------------------------- device math on the host
 @pytest.fixture(scope="module")
 def emul(tmp_path_factory):
