@@ -247,6 +247,8 @@ def visual_leg(pkg, synth, n_cams, local_rank):
     iters = max(1, len(trace) - 1)
     prob.close()
     n_obs = int(d["obs_off"][-1])
+    vmask = np.asarray(d["valid"]) != 0                                   # landmarks without a plane are left out entirely
+    n_res = 2 * int(np.diff(d["obs_off"])[vmask].sum()) + int(vmask.sum())  # reprojection (2 / observation) + plane priors
     return {"workload": f"{n_cams} cameras x 125000 landmarks x {n_obs} reprojection observations + plane priors",
             "lm_iterations": iters, "iterations_per_s": iters / dt, "ms_per_iteration": 1e3 * dt / iters, "termination": term,
             "cost_initial": trace[0]["cost"], "cost_final": trace[-1]["cost"],
@@ -255,7 +257,12 @@ def visual_leg(pkg, synth, n_cams, local_rank):
                                          "initial_max": float(np.abs(d["t"] - d["t_gt"]).max()),
                                          "final_max": float(np.abs(t - d["t_gt"]).max())},
             "landmark_err_m": {"initial_rms": float(np.sqrt(((d["X"] - d["X_gt"]) ** 2).sum(1).mean())),
-                               "final_rms": float(np.sqrt(((X - d["X_gt"]) ** 2).sum(1).mean()))}}
+                               "final_rms": float(np.sqrt(((X - d["X_gt"]) ** 2).sum(1).mean()))},
+            "residual_rms_whitened": {"initial": float(np.sqrt(2 * trace[0]["cost"] / n_res)),
+                                      "final": float(np.sqrt(2 * trace[-1]["cost"] / n_res))},
+            "note": "the synthetic initial values are closer to ground truth than 0.5 px observations over a 4-camera, 1.8 m "
+                    "baseline can resolve (depth sigma ~ z^2 sigma_px / (f b)), so errors against ground truth grow while the "
+                    "whitened residual falls to the injected noise level; a fit check, not an accuracy claim"}
 
 
 def front_end_leg(pkg, synth, with_cpu):
