@@ -188,8 +188,10 @@ def build_ref(force=False):
     so = os.path.join(_HERE, "_ref", "libbalm_ref.so")
     hdr = os.path.join(REFERENCE_ROOT, "include", "BALM", "bavoxel.hpp")
     if os.path.exists(hdr):
-        deps = [os.path.join(_HERE, "ref_glue.cpp"), os.path.join(_HERE, "shim", "lvba_eigen_standin.h"), hdr,
-                os.path.join(REFERENCE_ROOT, "include", "BALM", "tools.hpp")]
+        deps = [os.path.join(_HERE, "ref_glue.cpp"), os.path.join(_HERE, "ref_glue_visual.cpp"),
+                os.path.join(_HERE, "shim", "lvba_eigen_standin.h"), os.path.join(_HERE, "shim", "ceres", "ceres.h"),
+                os.path.join(_HERE, "shim", "ceres", "rotation.h"), hdr, os.path.join(REFERENCE_ROOT, "include", "BALM", "tools.hpp"),
+                os.path.join(REFERENCE_ROOT, "include", "utils.hpp")]
         if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
             subprocess.check_call(["make", "-C", _HERE, "-B", "-s", "ref", "REF=" + REFERENCE_ROOT])
     return so if os.path.exists(so) else None
@@ -226,6 +228,20 @@ def load_ref():
         lib.ref_down_sampling_voxel2.restype = c_i64
         lib.ref_down_sampling_voxel2.argtypes = [c_i64, f32p, c_dbl, f32p]
         lib.ref_pl_transform.argtypes = [c_i64, f32p, f64p]
+        i32p = np.ctypeslib.ndpointer(np.int32, flags="C")
+        lib.ref_reproj.argtypes = [f64p, f64p, f64p, f64p, f64p, c_dbl, c_dbl, f64p, f64p]
+        lib.ref_plane.argtypes = [f64p, c_dbl, c_dbl, f64p, f64p, f64p]
+        for fn in (lib.ref_distort, lib.ref_undistort):
+            fn.restype, fn.argtypes = c_int, [f64p, c_dbl, c_dbl, f64p]
+        lib.ref_project_world.restype, lib.ref_project_world.argtypes = c_int, [f64p, f64p, f64p, f64p, f64p]
+        lib.ref_backproject.restype, lib.ref_backproject.argtypes = c_int, [f64p, c_dbl, c_dbl, c_dbl, f64p]
+        lib.ref_cam_to_world.argtypes = [f64p, f64p, f64p, f64p]
+        lib.ref_pair_index.restype, lib.ref_pair_index.argtypes = c_i64, [c_int, c_int, c_int]
+        lib.ref_compute_mad.restype, lib.ref_compute_mad.argtypes = c_dbl, [c_i64, f64p]
+        lib.ref_pick_largest_cluster.restype = c_i64
+        lib.ref_pick_largest_cluster.argtypes = [c_i64, f64p, c_i64, i32p, i32p]
+        lib.ref_euler_to_rot.argtypes = [c_dbl, c_dbl, c_dbl, f64p]
+        lib.ref_parse_timestamp.restype, lib.ref_parse_timestamp.argtypes = c_int, [ctypes.c_char_p, ctypes.POINTER(c_dbl)]
         _RLIB = lib
     return _RLIB
 
@@ -327,3 +343,63 @@ class Reference:
         p = np.array(pts, np.float32).reshape(-1, 3).copy()
         self.lib.ref_pl_transform(len(p), p.reshape(-1), self._c(pose).reshape(12))
         return p
+
+    # ---- include/utils.hpp (oracle/ref_glue_visual.cpp)
+    def reproj(self, q, t, X, uv, intr, su=1.0, sv=1.0):
+        """ReprojErrorWhitenedDistorted: (r [2], J [2,10] = d r / d (q[4] as stored [w,x,y,z], t[3], X[3]))."""
+        r, J = np.empty(2), np.empty(20)
+        self.lib.ref_reproj(self._c(q).reshape(4), self._c(t).reshape(3), self._c(X).reshape(3), self._c(uv).reshape(2),
+                            self._c(intr).reshape(8), float(su), float(sv), r, J)
+        return r, J.reshape(2, 10)
+
+    def plane(self, n, d, sigma, X):
+        r, J = np.empty(1), np.empty(3)
+        self.lib.ref_plane(self._c(n).reshape(3), float(d), float(sigma), self._c(X).reshape(3), r, J)
+        return r[0], J
+
+    def distort(self, intr, x, y):
+        out = np.zeros(2)
+        return bool(self.lib.ref_distort(self._c(intr).reshape(8), float(x), float(y), out)), out
+
+    def undistort(self, intr, u, v):
+        out = np.zeros(2)
+        return bool(self.lib.ref_undistort(self._c(intr).reshape(8), float(u), float(v), out)), out
+
+    def project_world(self, intr, Rcw, tcw, Xw):
+        out = np.zeros(3)
+        ok = self.lib.ref_project_world(self._c(intr).reshape(8), self._c(Rcw).reshape(9), self._c(tcw).reshape(3),
+                                        self._c(Xw).reshape(3), out)
+        return bool(ok), out
+
+    def backproject(self, intr, u, v, depth):
+        out = np.zeros(3)
+        return bool(self.lib.ref_backproject(self._c(intr).reshape(8), float(u), float(v), float(depth), out)), out
+
+    def cam_to_world(self, Xc, Rcw, tcw):
+        out = np.zeros(3)
+        self.lib.ref_cam_to_world(self._c(Xc).reshape(3), self._c(Rcw).reshape(9), self._c(tcw).reshape(3), out)
+        return out
+
+    def pair_index(self, i, j, N):
+        return int(self.lib.ref_pair_index(int(i), int(j), int(N)))
+
+    def compute_mad(self, resid):
+        resid = self._c(resid).reshape(-1)
+        return float(self.lib.ref_compute_mad(len(resid), resid))
+
+    def pick_largest_cluster(self, pts, idx_valid):
+        pts = self._c(pts).reshape(-1, 3)
+        iv = np.ascontiguousarray(idx_valid, np.int32)
+        out = np.zeros(max(1, len(iv)), np.int32)
+        n = self.lib.ref_pick_largest_cluster(len(pts), pts.reshape(-1), len(iv), iv, out)
+        return out[:n].copy()
+
+    def euler_to_rot(self, roll, pitch, yaw):
+        R = np.empty(9)
+        self.lib.ref_euler_to_rot(float(roll), float(pitch), float(yaw), R)
+        return R.reshape(3, 3)
+
+    def parse_timestamp(self, name):
+        ts = ctypes.c_double()
+        ok = self.lib.ref_parse_timestamp(name.encode(), ctypes.byref(ts))
+        return (ts.value if ok else None)

@@ -162,6 +162,12 @@ class Matrix {
     void normalize() { *this /= norm(); }
     S trace() const { S s = 0; for (int i = 0; i < std::min(rows(), cols()); ++i) s += (*this)(i, i); return s; }
     S sum() const { S s = 0; for (auto v : st.d) s += v; return s; }
+    Matrix cwiseMin(const Matrix &o) const { Matrix m(*this); for (int i = 0; i < size(); ++i) m.st.d[i] = std::min(st.d[i], o.st.d[i]); return m; }
+    Matrix cwiseMax(const Matrix &o) const { Matrix m(*this); for (int i = 0; i < size(); ++i) m.st.d[i] = std::max(st.d[i], o.st.d[i]); return m; }
+    bool allFinite() const { for (auto v : st.d) if (!std::isfinite(v)) return false; return true; }
+    static Matrix UnitX() { Matrix m; m.st.d[0] = S(1); return m; }
+    static Matrix UnitY() { Matrix m; m.st.d[1] = S(1); return m; }
+    static Matrix UnitZ() { Matrix m; m.st.d[2] = S(1); return m; }
     template <int R2, int C2>
     S dot(const Matrix<S, R2, C2> &o) const
     {
@@ -424,24 +430,38 @@ class SelfAdjointEigenSolver {
     M vec_;
 };
 
-// rotation matrix -> axis / angle (jr_inv in tools.hpp is the only user)
-class AngleAxisd {
+// Axis-angle rotation: from a rotation matrix (jr_inv in tools.hpp) or from (angle, axis) (EulerToRot in utils.hpp);
+// products compose rotations.
+template <class S>
+class AngleAxis {
   public:
-    explicit AngleAxisd(const Matrix3d &Rm)
+    typedef Matrix<S, 3, 3> Mat3;
+    typedef Matrix<S, 3, 1> Vec3;
+    explicit AngleAxis(const Mat3 &Rm) : R_(Rm)
     {
-        const double c = std::min(1.0, std::max(-1.0, 0.5 * (Rm.trace() - 1.0)));
+        const S c = std::min(S(1), std::max(S(-1), S(0.5) * (Rm.trace() - S(1))));
         angle_ = std::acos(c);
-        Vector3d k(Rm(2, 1) - Rm(1, 2), Rm(0, 2) - Rm(2, 0), Rm(1, 0) - Rm(0, 1));
-        const double n = k.norm();
-        axis_ = n > 0 ? Vector3d(k / n) : Vector3d(1, 0, 0);
+        Vec3 k(Rm(2, 1) - Rm(1, 2), Rm(0, 2) - Rm(2, 0), Rm(1, 0) - Rm(0, 1));
+        const S n = k.norm();
+        axis_ = n > 0 ? Vec3(k / n) : Vec3(S(1), S(0), S(0));
     }
-    const Vector3d &axis() const { return axis_; }
-    double angle() const { return angle_; }
+    AngleAxis(S angle, const Vec3 &axis) : axis_(axis), angle_(angle)
+    {
+        Mat3 K;
+        K << S(0), -axis[2], axis[1], axis[2], S(0), -axis[0], -axis[1], axis[0], S(0);
+        R_ = Mat3::Identity() + std::sin(angle) * K + (S(1) - std::cos(angle)) * (K * K);
+    }
+    const Vec3 &axis() const { return axis_; }
+    S angle() const { return angle_; }
+    Mat3 toRotationMatrix() const { return R_; }
+    AngleAxis operator*(const AngleAxis &o) const { return AngleAxis(Mat3(R_ * o.R_)); }
 
   private:
-    Vector3d axis_;
-    double angle_;
+    Mat3 R_;
+    Vec3 axis_;
+    S angle_;
 };
+typedef AngleAxis<double> AngleAxisd;
 
 template <class S>
 class Triplet {

@@ -3,12 +3,15 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <memory>
 #include <utility>
 #include <vector>
 namespace pcl {
 template <class PointT>
 class PointCloud {
   public:
+    typedef std::shared_ptr<PointCloud<PointT>> Ptr;
+    typedef std::shared_ptr<const PointCloud<PointT>> ConstPtr;
     std::vector<PointT> points;
     uint32_t width = 0, height = 0;
     bool is_dense = true;

@@ -8,4 +8,6 @@ struct PointXYZINormal {
     float normal_x = 0, normal_y = 0, normal_z = 0, pad2_ = 0;
     float intensity = 0, curvature = 0, pad3_[2] = {0, 0};
 };
+struct PointXYZRGB { float x = 0, y = 0, z = 0, pad_ = 1; unsigned char b = 0, g = 0, r = 0, a = 255; float pad2_[3] = {0, 0, 0}; };
+struct PointXYZRGBA { float x = 0, y = 0, z = 0, pad_ = 1; unsigned char b = 0, g = 0, r = 0, a = 255; float pad2_[3] = {0, 0, 0}; };
 } // namespace pcl

@@ -5,7 +5,9 @@ Restates (paths relative to /root/reference)
   TriangulateTrackDLT                                                     src/lvba_system.cpp:50-111
   ComputeMeanReproj                                                       src/lvba_system.cpp:8-48
 The reference walks an unordered_map<image, observation>; the order only changes the rounding of the sums.  Each track here
-is the already de-duplicated list (one observation per image).  PARITY UNPINNED (no tests upstream).
+is the already de-duplicated list (one observation per image).  The camera model (undistort / distort / project) is PINNED
+against the reference's own include/utils.hpp compiled with the stand-ins of oracle/shim (tests/test_ref_pin.py); the DLT and
+the mean reprojection error live in src/lvba_system.cpp (ROS / OpenCV / Ceres: cannot be built here) -> PARITY UNPINNED.
 """
 from __future__ import annotations
 

@@ -8,7 +8,10 @@ Restates the reference's visual problem (paths relative to /root/reference):
   solver options                             src/lvba_system.cpp:1572-1576 (DENSE_SCHUR, 50 iterations, Ceres defaults)
   write-back                                 src/lvba_system.cpp:1651-1665
 
-PARITY UNPINNED.  The arithmetic of the solve lives in Ceres Solver 2.1.0 (README.md:20, find_package in
+THE TWO COST FUNCTORS ARE PINNED against the reference's own include/utils.hpp, compiled from /root/reference with the
+stand-ins of oracle/shim and differentiated with forward-mode Jets as ceres::AutoDiffCostFunction would
+(tests/test_ref_pin.py: residuals and ambient Jacobians to 1e-11, also against csrc/visual_math.h directly) -- except
+ceres::QuaternionRotatePoint, which the stand-in restates from memory.  THE SOLVE IS PARITY UNPINNED: its arithmetic lives in Ceres Solver 2.1.0 (README.md:20, find_package in
 CMakeLists.txt:33), which is not in /root/reference and not installed here.  Its published algorithm is restated
 FROM MEMORY of ceres-solver 2.1.0 (internal/ceres/trust_region_minimizer.cc, levenberg_marquardt_strategy.cc,
 manifold.cc, rotation.h):
@@ -21,7 +24,7 @@ manifold.cc, rotation.h):
     initial radius 1e4; accept if relative decrease > 1e-3; radius /= max(1/3, 1-(2 rho-1)^3) on success,
     radius /= decrease_factor (2,4,8,...) on failure; parameter tolerance 1e-8, function tolerance 1e-6, gradient
     tolerance 1e-10, checked in Ceres' order (parameter, function, then accept/reject).
-It is pinned only by self-consistency tests (tests/test_visual_oracle.py): autograd Jacobians vs finite differences,
+The solver restatement is pinned only by self-consistency tests (tests/test_visual_oracle.py): autograd Jacobians vs finite differences,
 Schur-complement solve vs the full normal equations, manifold Plus/PlusJacobian consistency.
 """
 from __future__ import annotations

@@ -1,7 +1,8 @@
 """CPU tests (no GPU): pin the oracle against THE REFERENCE'S OWN CODE.
 
-oracle/_ref/libbalm_ref.so is include/BALM/{tools,bavoxel}.hpp of the reference, compiled unmodified from /root/reference
-against the Eigen / PCL stand-ins of oracle/shim (oracle/Makefile target `ref`; oracle/ref_glue.cpp moves data in and out).
+oracle/_ref/libbalm_ref.so is include/BALM/{tools,bavoxel}.hpp and include/utils.hpp of the reference, compiled unmodified
+from /root/reference against the Eigen / PCL / OpenCV / Sophus / Ceres stand-ins of oracle/shim (oracle/Makefile target `ref`;
+oracle/ref_glue.cpp and ref_glue_visual.cpp move data in and out).
 Every statement of the reference on this path -- cluster transforms, acc_evaluate2's Hessian assembly, the thread split,
 damping_iter's control flow, voxel keys, the octree recursion, plane lookup, down-sampling -- runs as written; only Eigen's
 own kernels (3x3 symmetric eigen-solver, sparse LDL^T, products) are the stand-in's, hence tolerances of 1e-9..1e-7 where an
@@ -215,3 +216,137 @@ def test_down_sampling_voxel2_and_pl_transform(ref):
     got = ref.pl_transform(pts[:1000], pose)
     want = (pts[:1000].astype(np.float64) @ pose[:9].reshape(3, 3).T + pose[9:]).astype(np.float32)
     assert np.abs(got.astype(np.float64) - want).max() <= 1e-6              # fp32 write-back (tools.hpp:333-343)
+
+
+# ------------------------------------------------------------------------------------------------ a9, a10: include/utils.hpp
+def _visual(seed=3):
+    import importlib
+    synth = importlib.import_module("global-lvba_amd.synth")
+    return synth.make_visual_problem(8, 60, seed=seed)
+
+
+def test_cost_functors_match_reference(ref):
+    """ReprojErrorWhitenedDistorted / PointPlaneErrorWhitened of include/utils.hpp, evaluated and differentiated (forward-mode
+    Jets, as ceres::AutoDiffCostFunction does) from the reference's own source, against oracle/visual_oracle.py's torch
+    restatement + autograd.  ceres::QuaternionRotatePoint itself is the stand-in's (from memory of Ceres 2.1.0)."""
+    torch = pytest.importorskip("torch")
+    from oracle import visual_oracle as vis
+    d = _visual()
+    intr = [float(v) for v in d["intr"]]
+    F64 = torch.float64
+    rng = np.random.default_rng(2)
+    n = 0
+    for o in range(0, len(d["obs_cam"]), 3):
+        c = int(d["obs_cam"][o]); ti = int(np.searchsorted(d["obs_off"], o, side="right") - 1)
+        q = d["q"][c] * (1.0 + 0.1 * rng.standard_normal())              # un-normalised on purpose: the functor rescales
+        t, X, uv = d["t"][c], d["X"][ti], d["obs_uv"][o]
+        r_ref, J_ref = ref.reproj(q, t, X, uv, intr, 0.5, 0.5)
+        qt, tt, Xt = (torch.tensor(v, dtype=F64, requires_grad=True) for v in (q, t, X))
+        rr = vis.reproj_residual(qt, tt, Xt, torch.tensor(uv, dtype=F64), intr, 0.5)
+        assert np.abs(rr.detach().numpy() - r_ref).max() <= 1e-11 * max(1.0, np.abs(r_ref).max())
+        for k in range(2):
+            g = np.concatenate([v.numpy() for v in torch.autograd.grad(rr[k], (qt, tt, Xt), retain_graph=True)])
+            assert rel(g, J_ref[k]) <= 1e-11
+        n += 1
+    assert n > 50
+    # the z <= 1e-8 guard: zero residual, zero Jacobian (utils.hpp:78)
+    r0, J0 = ref.reproj([1.0, 0, 0, 0], [0, 0, 0], [0.3, 0.1, -2.0], [10, 10], intr, 0.5, 0.5)
+    assert not r0.any() and not J0.any()
+    for ti in range(0, 60, 7):
+        pl, X = d["plane"][ti], d["X"][ti] + 0.01 * rng.standard_normal(3)
+        for sigma in (0.01, 1e-12):                                         # s_ = max(1e-9, sigma) (utils.hpp:131)
+            r_ref, J_ref = ref.plane(pl[:3], pl[3], sigma, X)
+            Xt = torch.tensor(X, dtype=F64, requires_grad=True)
+            rr = vis.plane_residual(Xt, torch.tensor(pl, dtype=F64), max(1e-9, sigma))
+            (g,) = torch.autograd.grad(rr, (Xt,))
+            assert abs(float(rr.detach()) - r_ref) <= 1e-12 * max(1.0, abs(r_ref)) and rel(g.numpy(), J_ref) <= 1e-11
+
+
+def test_device_visual_math_matches_reference_functors(ref, tmp_path):
+    """csrc/visual_math.h (the kernels' hand-derived residuals and Jacobians, compiled for the host by tests/host_emul.cpp)
+    against the Jet derivatives of the reference's functors: J_cam = [dr/dq . PlusJacobian(q) | dr/dt], J_point = dr/dX."""
+    import ctypes
+    import subprocess
+    from oracle import visual_oracle as vis
+    so = str(tmp_path / "libemul.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", os.path.join(ROOT, "tests", "host_emul.cpp"), "-o", so])
+    lib = ctypes.CDLL(so)
+    f64p = np.ctypeslib.ndpointer(np.float64, flags="C")
+    lib.emul_reproj.argtypes = [f64p] * 5 + [ctypes.c_double] + [f64p] * 3
+    lib.emul_plane.argtypes = [f64p, f64p, ctypes.c_double, f64p]
+    lib.emul_plane.restype = ctypes.c_double
+    d = _visual(seed=4)
+    intr = np.ascontiguousarray(d["intr"], np.float64)
+    for o in range(0, len(d["obs_cam"]), 4):
+        c = int(d["obs_cam"][o]); ti = int(np.searchsorted(d["obs_off"], o, side="right") - 1)
+        q, t, X, uv = (np.ascontiguousarray(v, np.float64).copy() for v in (d["q"][c], d["t"][c], d["X"][ti], d["obs_uv"][o]))
+        r, Jc, Jp = np.zeros(2), np.zeros(12), np.zeros(6)
+        assert lib.emul_reproj(q, t, X, uv, intr, 0.5, r, Jc, Jp) == 1
+        r_ref, J_ref = ref.reproj(q, t, X, uv, intr, 0.5, 0.5)
+        assert np.abs(r - r_ref).max() <= 1e-10 * max(1.0, np.abs(r_ref).max())
+        Jc_ref = np.concatenate([J_ref[:, :4] @ vis.eigen_quat_plus_jacobian(q), J_ref[:, 4:7]], axis=1)
+        assert rel(Jc.reshape(2, 6), Jc_ref) <= 1e-11 and rel(Jp.reshape(2, 3), J_ref[:, 7:]) <= 1e-11
+    J = np.zeros(3)
+    for ti in range(0, 60, 5):
+        X, pl = np.ascontiguousarray(d["X"][ti]), np.ascontiguousarray(d["plane"][ti])
+        rp = lib.emul_plane(X, pl, 0.01, J)
+        r_ref, J_ref = ref.plane(pl[:3], pl[3], 0.01, X)
+        assert abs(rp - r_ref) <= 1e-12 * max(1.0, abs(r_ref)) and np.abs(J - J_ref).max() <= 1e-12 * max(1.0, np.abs(J_ref).max())
+
+
+def test_camera_model_helpers_match_reference(ref):
+    """distortNormalized / undistortPixelToNormalized (8 fixed-point iterations) / projectWorldToPixel /
+    backProjectPixelDepthDistorted / camToWorld (utils.hpp:169-284) against oracle/track_oracle.py; EulerToRot, pairIndex,
+    computeMAD, parseTimestampFromName against their restatements."""
+    from oracle import track_oracle as to
+    import importlib
+    ds = importlib.import_module("global-lvba_amd.dataset")
+    d = _visual()
+    intr = np.asarray(d["intr"], np.float64)
+    rng = np.random.default_rng(9)
+    for _ in range(200):
+        u, v = rng.uniform(0, 1280), rng.uniform(0, 1024)
+        ok, xy = ref.undistort(intr, u, v)
+        want = to.undistort(intr, u, v)
+        assert ok == (want is not None)
+        if ok:
+            assert np.abs(xy - np.array(want)).max() <= 1e-15 * max(1.0, np.abs(xy).max())
+            okd, xyd = ref.distort(intr, xy[0], xy[1])                      # round trip back to the pixel
+            assert okd
+            if abs(u - intr[2]) < 150 and abs(v - intr[3]) < 150:           # 8 iterations only converge near the centre
+                assert abs(intr[0] * xyd[0] + intr[2] - u) < 1e-6 and abs(intr[1] * xyd[1] + intr[3] - v) < 1e-6
+            okb, Xc = ref.backproject(intr, u, v, 7.5)
+            assert okb and np.abs(Xc - np.array([xy[0] * 7.5, xy[1] * 7.5, 7.5])).max() == 0
+    assert not ref.undistort(intr, np.nan, 1.0)[0] and not ref.backproject(intr, 10, 10, -1.0)[0]
+    q = d["q_gt"]
+    for c in range(len(q)):
+        R = ds.quat_to_rot(*q[c])
+        for ti in range(0, 60, 9):
+            X = d["X_gt"][ti]
+            ok, uvz = ref.project_world(intr, R, d["t_gt"][c], X)
+            want = to.project(intr, R, d["t_gt"][c], X)
+            assert ok == (want is not None)
+            if ok:
+                assert np.abs(uvz[:2] - np.array(want)).max() <= 1e-12 * max(1.0, np.abs(uvz[:2]).max())
+        Xc = rng.standard_normal(3)
+        assert np.abs(ref.cam_to_world(Xc, R, d["t_gt"][c]) - R.T @ (Xc - d["t_gt"][c])).max() <= 1e-14 * 100
+    # EulerToRot = Rz(yaw) Ry(pitch) Rx(roll) (utils.hpp:448-459)
+    def rot(axis, a):
+        c, s = np.cos(a), np.sin(a)
+        return {0: np.array([[1, 0, 0], [0, c, -s], [0, s, c]]), 1: np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]]),
+                2: np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])}[axis]
+    for rpy in rng.uniform(-3, 3, (10, 3)):
+        assert np.abs(ref.euler_to_rot(*rpy) - rot(2, rpy[2]) @ rot(1, rpy[1]) @ rot(0, rpy[0])).max() <= 1e-15 * 10
+    N = 7
+    idx = 0
+    for i in range(N):
+        for j in range(i + 1, N):
+            assert ref.pair_index(i, j, N) == idx                           # 0-1, 0-2, ..., 1-2, ... (utils.hpp:286-291)
+            idx += 1
+    for n in (1, 2, 5, 8, 101):
+        x = rng.standard_normal(n)
+        med = np.sort(x)[n // 2]                                            # nth_element at size/2: the UPPER median
+        assert abs(ref.compute_mad(x) - 1.4826 * np.sort(np.abs(x - med))[n // 2]) <= 1e-15
+    assert ref.compute_mad([]) == -1.0
+    for name in ["0.423131.png", "/data/seq/12.5.pcd", "frame_000123.jpg", "img.png", "1700000000.250000_left.png", "a7b.9"]:
+        assert ref.parse_timestamp(name) == ds.parse_timestamp_from_name(name)
