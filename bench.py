@@ -202,7 +202,8 @@ def main():
             "config": {"workload": f"{args.config}: BALM LiDAR BA, {N} poses x {V} voxels x {F_total} LiDAR factors "
                                    f"(plane-eigenvalue factors, exact Hessian, Nielsen LM)",
                        "n_poses": N, "n_voxels": V, "n_factors": F_total, "n_pairs_local": info["n_pairs"],
-                       "sharding": f"voxel ranges over {world} rank(s), RCCL all-reduce of pose-block H/g/cost" if world > 1 else "single GPU",
+                       "sharding": (f"voxel ranges over {world} rank(s), RCCL all-reduce of pose-block H/g/cost, "
+                                    f"{info['allreduce_bytes'] / 1e6:.0f} MB per evaluation") if world > 1 else "single GPU",
                        "solver": ("band" if info["use_band"] else "dense") + f" LDL^T, half-bandwidth {bw} of n={n}",
                        "lm_runs": state["runs"], "evals_in_timed_steps": state["evals"],
                        "accepted_in_timed_steps": state["accepts"], "last_cost": last["residual2"] if last else None},

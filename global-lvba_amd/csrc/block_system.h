@@ -49,6 +49,9 @@ struct BlockSys {
     // distributed
     int n_ranks = 1, rank = 0;
     ncclComm_t comm = nullptr;
+    // packed all-reduce: slots of the blocks that are non-zero on ANY rank (+ the diagonal), and the staging buffer
+    int64_t n_ar = 0, *d_ar_slot = nullptr;
+    double *d_arbuf = nullptr;
     int64_t device_bytes = 0;
 
     double *Hblk() const { return d_hg; }
@@ -82,6 +85,8 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
 int32_t bs_enqueue_solve(BlockSys &bs, double u);
 // all-reduce `count` doubles in place over the ranks (no-op without a communicator)
 int32_t bs_allreduce(BlockSys &bs, double *buf, size_t count);
+// all-reduce [Hblk | g | cost] over the ranks: only the blocks of the union sparsity pattern travel when that is known
+int32_t bs_allreduce_hg(BlockSys &bs);
 int32_t bs_dist_init(BlockSys &bs, int32_t n_ranks, int32_t rank, const char uid[128], int64_t *group_count_inout);
 void bs_destroy(BlockSys &bs);
 

@@ -287,6 +287,45 @@ int32_t bs_allreduce(BlockSys &bs, double *buf, size_t count)
     return LVBA_OK;
 }
 
+// [Hblk | g | cost] <-> [blocks of the union pattern | g | cost]
+__global__ void hg_pack_kernel(const double *__restrict__ hg, const int64_t *__restrict__ slot, int64_t n_ar, int64_t hblk_doubles,
+                               int64_t tail, double *__restrict__ buf)
+{
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t < 36 * n_ar) {
+        const int64_t b = t / 36;
+        buf[t] = hg[slot[b] * 36 + (t - 36 * b)];
+    } else if (t < 36 * n_ar + tail)
+        buf[t] = hg[hblk_doubles + (t - 36 * n_ar)];
+}
+__global__ void hg_unpack_kernel(double *__restrict__ hg, const int64_t *__restrict__ slot, int64_t n_ar, int64_t hblk_doubles,
+                                 int64_t tail, const double *__restrict__ buf)
+{
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t < 36 * n_ar) {
+        const int64_t b = t / 36;
+        hg[slot[b] * 36 + (t - 36 * b)] = buf[t];
+    } else if (t < 36 * n_ar + tail)
+        hg[hblk_doubles + (t - 36 * n_ar)] = buf[t];
+}
+
+// The block-band store is mostly structural zeros (C3: 4e5 non-zero blocks of 8.7e5 slots, 270 MB): when the union sparsity
+// pattern is known (it is whenever the ordering was computed from the all-reduced adjacency) only its blocks travel --
+// xGMI all-reduce time is proportional to bytes, and slots outside the union are zero on every rank.
+int32_t bs_allreduce_hg(BlockSys &bs)
+{
+    if (!bs.comm) return LVBA_OK;
+    const int64_t tail = 6 * (int64_t)bs.N + 1;
+    if (!bs.d_ar_slot) return bs_allreduce(bs, bs.d_hg, (size_t)(bs.hblk_doubles + tail));
+    const int64_t total = 36 * bs.n_ar + tail;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(hg_pack_kernel, dim3(grid), dim3(256), 0, bs.stream, bs.d_hg, bs.d_ar_slot, bs.n_ar, bs.hblk_doubles, tail, bs.d_arbuf);
+    TRY(bs_allreduce(bs, bs.d_arbuf, (size_t)total));
+    hipLaunchKernelGGL(hg_unpack_kernel, dim3(grid), dim3(256), 0, bs.stream, bs.d_hg, bs.d_ar_slot, bs.n_ar, bs.hblk_doubles, tail, bs.d_arbuf);
+    HIPCHK(hipGetLastError());
+    return LVBA_OK;
+}
+
 static double bs_now_ms()
 {
     struct timespec ts;
@@ -335,8 +374,9 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
     bs.Q = Q;
     const bool small = (int64_t)N * N <= ((int64_t)1 << 29); // byte adjacency <= 512 MiB
     // systems of <= 1024 unknowns (window BA: 20 poses) are solved dense whatever the order: skip the graph work
+    std::vector<uint8_t> adj; // co-visibility of the GLOBAL problem (all-reduced), when it is computed at all
     if (bs.ordering == 1 && N > 2 && small && n > 1024) {
-        std::vector<uint8_t> adj((size_t)N * N, 0);
+        adj.assign((size_t)N * N, 0);
         for (int64_t a = 0; a < G; ++a) {
             const int64_t f0 = voff[a], f1 = voff[a + 1];
             for (int64_t x = f0; x < f1; ++x)
@@ -371,6 +411,27 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
     if (!bs.use_band) bs.Bb = N - 1; // full lower block triangle
     const int64_t Bb1 = (int64_t)bs.Bb + 1;
     bs.hblk_doubles = (int64_t)N * Bb1 * 36;
+    {
+        const char *e = getenv("LVBA_PACKED_ALLREDUCE");
+        if (bs.comm && !adj.empty() && !(e && !strcmp(e, "0"))) {
+            std::vector<int64_t> slots;
+            for (int32_t J = 0; J < N; ++J) slots.push_back((int64_t)J * Bb1);
+            for (int32_t i = 0; i < N; ++i)
+                for (int32_t j = 0; j < i; ++j)
+                    if (adj[(size_t)i * N + j]) {
+                        int32_t I = bs.iperm[i], J = bs.iperm[j];
+                        if (I < J) std::swap(I, J);
+                        slots.push_back((int64_t)J * Bb1 + (I - J));
+                    }
+            std::sort(slots.begin(), slots.end());
+            if (36 * (int64_t)slots.size() < (bs.hblk_doubles / 4) * 3) {
+                bs.n_ar = (int64_t)slots.size();
+                TRY(bs_dmalloc(bs, &bs.d_ar_slot, bs.n_ar));
+                TRY(bs_dmalloc(bs, &bs.d_arbuf, 36 * bs.n_ar + 6 * (int64_t)N + 8));
+                HIPCHK(hipMemcpy(bs.d_ar_slot, slots.data(), (size_t)bs.n_ar * sizeof(int64_t), hipMemcpyHostToDevice));
+            }
+        }
+    }
 
     { // pose-major (CSC) view + per-block group lists for the atomic-free assembly
         std::vector<int64_t> csc_off((size_t)N + 1, 0);
@@ -521,7 +582,7 @@ void bs_destroy(BlockSys &bs)
     if (bs.comm && g_rccl.CommDestroy) g_rccl.CommDestroy(bs.comm);
     if (bs.solve_exec) hipGraphExecDestroy(bs.solve_exec);
     if (bs.solve_graph) hipGraphDestroy(bs.solve_graph);
-    void *ptrs[] = {bs.d_multi_off, bs.d_multi_slot, bs.d_partial, bs.d_perm, bs.d_csc_off, bs.d_blk_off, bs.d_blk_slot, bs.d_group_of_pos, bs.d_csc_f, bs.d_pos_of,
+    void *ptrs[] = {bs.d_ar_slot, bs.d_arbuf, bs.d_multi_off, bs.d_multi_slot, bs.d_partial, bs.d_perm, bs.d_csc_off, bs.d_blk_off, bs.d_blk_slot, bs.d_group_of_pos, bs.d_csc_f, bs.d_pos_of,
                     bs.d_pairs, bs.d_Y, bs.d_hg, bs.d_A, bs.d_work, bs.d_dx, bs.d_u, bs.d_status};
     for (void *p : ptrs)
         if (p) DevicePool::get().free(p);

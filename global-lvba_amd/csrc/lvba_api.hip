@@ -244,6 +244,7 @@ extern "C" int32_t lvba_balm_info(lvba_balm_t h, lvba_balm_info_t *info)
     info->n_factors = h->F; info->n_pairs = h->Q; info->n_chunks = h->n_chunks; info->n_blocks = h->bs.nnzb;
     info->band_blocks = h->bs.Bb; info->use_band = h->bs.use_band ? 1 : 0; info->hess_bytes = h->bs.hblk_doubles * 8;
     info->device_bytes = h->bs.device_bytes;
+    info->allreduce_bytes = !h->bs.comm ? 0 : 8 * ((h->bs.d_ar_slot ? 36 * h->bs.n_ar : h->bs.hblk_doubles) + 6 * (int64_t)h->N + 1);
     return LVBA_OK;
 }
 
@@ -324,7 +325,7 @@ static int32_t enqueue_eval(lvba_balm_s *h, const double *d_poses)
     ev_end(h, EV_EVAL);
     if (bs.comm) {
         ev_begin(h, EV_REDUCE);
-        TRY(bs_allreduce(bs, bs.d_hg, (size_t)(bs.hblk_doubles + 6 * (int64_t)h->N + 1)));
+        TRY(bs_allreduce_hg(bs));
         ev_end(h, EV_REDUCE);
     }
     HIPCHK(hipGetLastError());

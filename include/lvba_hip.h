@@ -88,6 +88,7 @@ typedef struct {
     int32_t use_band;        /* 1 = band LDL^T, 0 = dense */
     int64_t hess_bytes;      /* block-band Hessian storage */
     int64_t device_bytes;    /* total device memory held by the handle */
+    int64_t allreduce_bytes; /* bytes all-reduced per evaluation (0 without a communicator): the union-pattern blocks + g + cost */
 } lvba_balm_info_t;
 
 /* Accumulated device times (HIP events on the handle's stream) since the last reset, ms. */

@@ -287,6 +287,35 @@ def test_rccl_path_single_rank(pkg, oracle_mod, monkeypatch):
     assert prob.info()["n_voxels_global"] == 3000
 
 
+def test_packed_allreduce_single_rank(pkg, oracle_mod, monkeypatch):
+    """With a communicator and a system large enough for the ordering to be computed (n > 1024), only the blocks of the union
+    sparsity pattern are all-reduced (bs_allreduce_hg: pack -> RCCL -> unpack).  1-rank communicator: the result must be
+    bitwise what the dense all-reduce gives, and match the oracle."""
+    monkeypatch.setenv("LVBA_SINGLE_RANK_COMM", "1")
+    d = make_problem(200, 6000, band=10, seed=7)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LVBA_PACKED_ALLREDUCE", mode)
+        prob = pkg.BalmProblem(d["n_poses"], d["voxel_off"], d["pose_idx"], d["clusters"])
+        prob.dist_init(1, 0, pkg.BalmProblem.unique_id())
+        H, g, c = prob.eval(d["poses_init"])
+        H2, g2, c2 = prob.eval(d["poses_gt"])
+        x, trace, rc = prob.refine(d["poses_init"])
+        assert rc == 0
+        info = prob.info()
+        if mode == "1":   # the packed buffer really is smaller than the block-band store
+            assert 0 < info["allreduce_bytes"] < 0.75 * info["hess_bytes"]
+        else:
+            assert info["allreduce_bytes"] >= info["hess_bytes"]
+        out[mode] = (H, g, c, H2, g2, c2, x)
+        prob.close()
+    for a, b in zip(out["1"], out["0"]):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+    co = oracle_mod.COracle(d["n_poses"], d["voxel_off"], d["pose_idx"], d["clusters"])
+    Hc, gc, cc = co.eval_dense(d["poses_init"])
+    assert rel(out["1"][0], Hc) <= 1e-8 and rel(out["1"][1], gc) <= 1e-8 and abs(out["1"][2] - cc) <= 1e-8 * cc
+
+
 def test_properties_at_baseline_size_c2(pkg, synth):
     """BASELINE.json config C2 (500 poses x 400k voxels x 2M factors), generated on the GPU: size-independent
     properties -- rigid-motion invariance, shard additivity of the cost, bitwise run-to-run reproducibility of the
