@@ -218,6 +218,7 @@ __global__ __launch_bounds__(LVBA_CF) void balm_voxel_kernel(BalmDev d, const do
 __global__ __launch_bounds__(256) void balm_factor_kernel(BalmDev d, const double *__restrict__ poses)
 {
     __shared__ double red[4 * 27];
+    __shared__ double Ys[4 * 64 * 19];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int I = blockIdx.x / d.S, s = blockIdx.x - I * d.S;
     const int64_t seg0 = d.csc_off[I], len = d.csc_off[I + 1] - seg0;
@@ -228,29 +229,45 @@ __global__ __launch_bounds__(256) void balm_factor_kernel(BalmDev d, const doubl
     double acc[27];
 #pragma unroll
     for (int e = 0; e < 27; ++e) acc[e] = 0.0;
-    for (int64_t t = a + tid; t < b; t += 256) {
-        double c[10];
+    for (int64_t t0 = a + 64 * wv; t0 < b; t0 += 256) { // wavefront-uniform trip count: every lane takes part in the stores
+        const int64_t t = t0 + lane;
+        double Y[18];
+        if (t < b) {
+            double c[10];
 #pragma unroll
-        for (int e = 0; e < 10; ++e) c[e] = d.clu_csc[(int64_t)e * d.F + t];
-        const double *vp = d.vrec + 16 * (int64_t)d.vox_of_pos[t];
-        VoxRec vr;
-        vr.NN = vp[0];
+            for (int e = 0; e < 10; ++e) c[e] = d.clu_csc[(int64_t)e * d.F + t];
+            const double *vp = d.vrec + 16 * (int64_t)d.vox_of_pos[t];
+            VoxRec vr;
+            vr.NN = vp[0];
 #pragma unroll
-        for (int e = 0; e < 3; ++e) {
-            vr.vb[e] = vp[1 + e];
-            vr.u0[e] = vp[4 + e];
-            vr.s1[e] = vp[7 + e];
-            vr.s2[e] = vp[10 + e];
+            for (int e = 0; e < 3; ++e) {
+                vr.vb[e] = vp[1 + e];
+                vr.u0[e] = vp[4 + e];
+                vr.s1[e] = vp[7 + e];
+                vr.s2[e] = vp[10 + e];
+            }
+            double D[21], gi[6];
+            factor_derivs(c, x, x + 9, vr, Y, D, gi);
+#pragma unroll
+            for (int e = 0; e < 21; ++e) acc[e] += D[e];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) acc[21 + e] += gi[e];
         }
-        double Y[18], D[21], gi[6];
-        factor_derivs(c, x, x + 9, vr, Y, D, gi);
-        double *yo = d.Y + 18 * t;
+        // Y records leave through LDS: a lane-per-record store puts 16 bytes into each of 72 cache lines per instruction
+        // (stride 144 B); transposed, the wavefront's 64 records go out as 9 contiguous 1-KB stores
+        double *ys = Ys + wv * (64 * 19);
+        if (t < b) {
 #pragma unroll
-        for (int e = 0; e < 18; ++e) yo[e] = Y[e];
+            for (int e = 0; e < 18; ++e) ys[lane * 19 + e] = Y[e];
+        }
+        const int nrec = (int)((b - t0) < 64 ? (b - t0) : 64);
+        double2 *yo = reinterpret_cast<double2 *>(d.Y + 18 * t0);
 #pragma unroll
-        for (int e = 0; e < 21; ++e) acc[e] += D[e];
-#pragma unroll
-        for (int e = 0; e < 6; ++e) acc[21 + e] += gi[e];
+        for (int r = 0; r < 9; ++r) {
+            const int f = 2 * (lane + 64 * r); // flat double index inside the batch
+            const int rec = f / 18, el = f - 18 * rec;
+            if (rec < nrec) yo[lane + 64 * r] = make_double2(ys[rec * 19 + el], ys[rec * 19 + el + 1]);
+        }
     }
 #pragma unroll
     for (int e = 0; e < 27; ++e) {
