@@ -188,15 +188,20 @@ __global__ __launch_bounds__(LVBA_CF) void balm_voxel_kernel(BalmDev d, const do
     }
     __syncthreads();
     double lam0 = 0.0;
+    VoxRec vr;
     if (tid < nv) {
         double S[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (int f = lvoff[tid]; f < lvoff[tid + 1]; ++f) {
 #pragma unroll
             for (int e = 0; e < 10; ++e) S[e] += T[e * LVBA_CF + f];
         }
-        VoxRec vr;
         lam0 = voxel_finish(S, vr);
-        double *o = d.vrec + 16 * (v0 + tid);
+    }
+    // the records leave through LDS (T is dead once every lane has its sums): lane-per-record stores would put 8 bytes into
+    // each of up to 128 cache lines per instruction; staged, the chunk's records go out as contiguous 2-KB stores
+    __syncthreads();
+    if (tid < nv) {
+        double *o = T + 17 * tid;
         o[0] = vr.NN;
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
@@ -205,6 +210,12 @@ __global__ __launch_bounds__(LVBA_CF) void balm_voxel_kernel(BalmDev d, const do
             o[7 + e] = vr.s1[e];
             o[10 + e] = vr.s2[e];
         }
+        o[13] = o[14] = o[15] = 0.0;
+    }
+    __syncthreads();
+    {
+        double *o = d.vrec + 16 * v0;
+        for (int f = tid; f < 16 * nv; f += LVBA_CF) o[f] = T[17 * (f >> 4) + (f & 15)];
     }
     const double tot = block_sum_256(lam0, red);
     if (tid == 0) chunk_cost[ch] = tot;
@@ -236,7 +247,13 @@ __global__ __launch_bounds__(256) void balm_factor_kernel(BalmDev d, const doubl
             double c[10];
 #pragma unroll
             for (int e = 0; e < 10; ++e) c[e] = d.clu_csc[(int64_t)e * d.F + t];
-            const double *vp = d.vrec + 16 * (int64_t)d.vox_of_pos[t];
+            const double2 *vq = reinterpret_cast<const double2 *>(d.vrec + 16 * (int64_t)d.vox_of_pos[t]); // one 128-B line
+            double vp[14];
+#pragma unroll
+            for (int e = 0; e < 7; ++e) {
+                const double2 v2 = vq[e];
+                vp[2 * e] = v2.x; vp[2 * e + 1] = v2.y;
+            }
             VoxRec vr;
             vr.NN = vp[0];
 #pragma unroll
