@@ -20,6 +20,8 @@
 // (bavoxel.hpp:68-174) of the reference; math in balm_math.h.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 #include "balm_math.h"
 #include "lvba_internal.h"
 
@@ -377,6 +379,79 @@ __global__ __launch_bounds__(256) void balm_pair_kernel(PairDev d, double *__res
     }
 }
 
+// Same work items, records fetched COOPERATIVELY: in the kernel above every lane gathers its own two 144-byte records, so
+// each of the 18 load instructions of an iteration touches 64+ different cache lines per wavefront (the texture-address
+// path serialises on lines, not bytes).  Here the 16 lanes of a group fetch the group's 32 records of an iteration as 288
+// consecutive 16-byte chunks (a lane run of 9 covers one record), x side then y side, park them in LDS and each lane reads
+// its own records back.
+#define LVBA_PAIR_GROUP_DOUBLES (16 * 18)
+__global__ __launch_bounds__(256) void balm_pair_staged_kernel(PairDev d, double *__restrict__ Hblk)
+{
+    __shared__ double stage[16 * LVBA_PAIR_GROUP_DOUBLES]; // 36.9 KB: 16 groups x 16 records x 18 doubles (x side, then y side)
+    __shared__ int2 prs[16 * 16];
+    const int64_t per_xcd = (gridDim.x + 7) / 8;
+    const int64_t wg = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int grp = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+    const int64_t blk = wg * 16 + grp;
+    const bool live = blk < d.nnzb;
+    int64_t o0 = 0, o1 = 0;
+    if (live) { o0 = d.blk_off[blk]; o1 = d.blk_off[blk + 1]; }
+    double *st = stage + grp * LVBA_PAIR_GROUP_DOUBLES;
+    int2 *pg = prs + grp * 16;
+    double acc[36];
+#pragma unroll
+    for (int e = 0; e < 36; ++e) acc[e] = 0.0;
+    for (int64_t q = o0; q < o1; q += 16) {
+        const int64_t qi = q + l16;
+        const int npair = (int)((o1 - q) < 16 ? (o1 - q) : 16);
+        pg[l16] = (qi < o1) ? d.pairs[qi] : make_int2(0, 0);
+        double2 vx[9], vy[9];
+#pragma unroll
+        for (int s2 = 0; s2 < 9; ++s2) {
+            const int ci = s2 * 16 + l16;       // chunk of the group's 16 x 9
+            const int rc = ci / 9, cc = ci - 9 * rc;
+            const int2 pp = pg[rc];
+            const bool ok = rc < npair;
+            vx[s2] = ok ? reinterpret_cast<const double2 *>(d.Y + 18 * (int64_t)pp.x)[cc] : make_double2(0.0, 0.0);
+            vy[s2] = ok ? reinterpret_cast<const double2 *>(d.Y + 18 * (int64_t)pp.y)[cc] : make_double2(0.0, 0.0);
+        }
+        double Yi[18], Yj[18];
+#pragma unroll
+        for (int s2 = 0; s2 < 9; ++s2) reinterpret_cast<double2 *>(st)[s2 * 16 + l16] = vx[s2]; // record rc at st + 18 rc
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int e = 0; e < 9; ++e) {
+            const double2 a = reinterpret_cast<const double2 *>(st + 18 * l16)[e];
+            Yi[2 * e] = a.x; Yi[2 * e + 1] = a.y;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s2 = 0; s2 < 9; ++s2) reinterpret_cast<double2 *>(st)[s2 * 16 + l16] = vy[s2];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int e = 0; e < 9; ++e) {
+            const double2 a = reinterpret_cast<const double2 *>(st + 18 * l16)[e];
+            Yj[2 * e] = a.x; Yj[2 * e + 1] = a.y;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (qi < o1) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+                    acc[c * 6 + r] += Yi[r] * Yj[c] + Yi[6 + r] * Yj[6 + c] + Yi[12 + r] * Yj[12 + c];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 36; ++e) acc[e] = row16_sum(acc[e]);
+    if (live && l16 == 0) {
+        const int64_t dst = d.blk_slot[blk];
+        double2 *hp = reinterpret_cast<double2 *>(dst >= 0 ? Hblk + dst * 36 : d.partial + (-dst - 1) * 36);
+#pragma unroll
+        for (int e = 0; e < 18; ++e) hp[e] = make_double2(-acc[2 * e], -acc[2 * e + 1]);
+    }
+}
+
 // blocks whose pair list was cut into several work items (few blocks, many pairs each: window BA): the partial blocks are
 // added up in item order -- still no atomics, still bitwise reproducible
 __global__ void balm_pair_reduce_kernel(PairDev d, double *__restrict__ Hblk)
@@ -519,8 +594,12 @@ void launch_cost(const BalmDev &d, const double *poses, double *chunk_cost, doub
 
 void launch_pairs(const PairDev &pd, double *Hblk, hipStream_t s)
 {
-    if (pd.nnzb > 0)
-        hipLaunchKernelGGL(balm_pair_kernel, dim3((unsigned)((((pd.nnzb + 15) / 16) + 7) / 8 * 8)), dim3(256), 0, s, pd, Hblk);
+    static const bool gather = [] { const char *e = getenv("LVBA_PAIR"); return e && !strcmp(e, "gather"); }();
+    if (pd.nnzb > 0) {
+        const dim3 grid((unsigned)((((pd.nnzb + 15) / 16) + 7) / 8 * 8));
+        if (gather) hipLaunchKernelGGL(balm_pair_kernel, grid, dim3(256), 0, s, pd, Hblk);
+        else hipLaunchKernelGGL(balm_pair_staged_kernel, grid, dim3(256), 0, s, pd, Hblk);
+    }
     if (pd.n_multi > 0)
         hipLaunchKernelGGL(balm_pair_reduce_kernel, dim3((unsigned)((pd.n_multi * 36 + 255) / 256)), dim3(256), 0, s, pd, Hblk);
 }
