@@ -89,5 +89,7 @@ int32_t bs_allreduce(BlockSys &bs, double *buf, size_t count);
 int32_t bs_allreduce_hg(BlockSys &bs);
 int32_t bs_dist_init(BlockSys &bs, int32_t n_ranks, int32_t rank, const char uid[128], int64_t *group_count_inout);
 void bs_destroy(BlockSys &bs);
+// +1 / -1 around sections in which several host threads use the library concurrently: solve graphs are not captured then
+void bs_graph_inhibit(int delta);
 
 } // namespace lvba

@@ -9,10 +9,14 @@
 #include <string.h>
 #include <time.h>
 #include <algorithm>
+#include <atomic>
 #include <queue>
 #include <vector>
 #include "block_system.h"
 #include "pair_lists.h"
+
+static std::atomic<int> g_graph_inhibit{0};
+namespace lvba { void bs_graph_inhibit(int delta) { g_graph_inhibit.fetch_add(delta); } }
 
 // ------------------------------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
@@ -551,7 +555,9 @@ int32_t bs_enqueue_solve(BlockSys &bs, double u)
     HIPCHK(hipMemcpyAsync(bs.d_u, bs.h_pin_u, sizeof(double), hipMemcpyHostToDevice, bs.stream));
     // capture + instantiate costs about as much as a few eager solves of a small system: wait for the third solve, so
     // handles that live for one short refinement (window BA) never pay for it
-    if (!bs.graph_tried && ++bs.solve_calls >= 3) {
+    // no capture while several host threads drive the device (bs_graph_inhibit): with HIP 7.0 a capture in one thread is
+    // invalidated by allocations / synchronous copies in another even in hipStreamCaptureModeThreadLocal
+    if (!bs.graph_tried && g_graph_inhibit.load() == 0 && ++bs.solve_calls >= 3) {
         bs.graph_tried = true;
         if (!getenv("LVBA_NO_GRAPH")) {
             (void)hipGetLastError();

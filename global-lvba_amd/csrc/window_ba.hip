@@ -11,8 +11,12 @@
 // The raw clouds never leave HBM between the stages; the anchor clouds are born there (a new lvba_scans_t) and feed the
 // global stages' lvba_voxmap_build_scans directly.
 // down_sampling_voxel2 emits survivors in unordered_map order (unspecified); here: sorted by voxel key (x, y, z).
+#include <atomic>
+#include <string>
+#include <thread>
 #include "voxel_internal.h"
 #include "lvba_internal.h"
+#include "block_system.h"
 
 using namespace lvba;
 
@@ -164,16 +168,24 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
     struct AnchorCloud { float *d; int64_t n; };
     std::vector<AnchorCloud> clouds;
     auto free_clouds = [&]() { for (auto &c : clouds) DevicePool::get().free(c.d); clouds.clear(); };
-    int wi = 0;
-    for (int start = 0; start < n; start += w, ++wi) {
+    // One window = map -> problem -> LM -> anchor cloud; windows are independent (src/lvba_system.cpp:232-302 runs them one
+    // after the other), and a single window leaves the GPU idle most of the time (its 5.6 ms are mostly host-side set-up and
+    // launch / synchronisation latency), so a few host threads, each with its own stream and handles, work through them
+    // concurrently (LVBA_WINDOW_THREADS, default 4; 1 = in the calling thread).  Results are assembled in window order below.
+    struct WinResult { int32_t rc = LVBA_OK; std::string err; lvba_window_info info{}; std::vector<double> x, rel; float *d_out = nullptr; int64_t n_out = 0; };
+    const int n_win = (n + w - 1) / w;
+    std::vector<WinResult> results((size_t)n_win);
+    auto process = [&](int wi, hipStream_t s, WinResult &R) -> int32_t {
+        const int start = wi * w;
         const int cw = std::min(w, n - start);
-        lvba_window_info info{};
+        lvba_window_info &info = R.info;
+        info = lvba_window_info{};
         info.start = start; info.n_frames = cw; info.anchor = -1;
         const double *x_odom = poses + 12 * (int64_t)start;
         lvba_voxmap_t map = nullptr;
         double tw = now_ms();
         int32_t rc = lvba_voxmap_build_scans(sc, start, cw, x_odom, &o.voxel, &map);
-        if (rc != LVBA_OK) { free_clouds(); return rc; }
+        if (rc != LVBA_OK) return rc;
         lvba_voxmap_info_t mi;
         lvba_voxmap_info(map, &mi);
         info.n_voxels = mi.n_voxels; info.n_factors = mi.n_factors;
@@ -181,15 +193,15 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
         if (mi.n_voxels < 3 * (int64_t)cw) { // :258-262
             info.skipped = 1;
             lvba_voxmap_destroy(map);
-            if (win_info) win_info[wi] = info;
-            continue;
+            return LVBA_OK;
         }
-        std::vector<double> x(x_odom, x_odom + 12 * (size_t)cw);
+        std::vector<double> &x = R.x;
+        x.assign(x_odom, x_odom + 12 * (size_t)cw);
         {
             lvba_balm_t b = nullptr;
             rc = lvba_voxmap_to_balm(map, &b);
             lvba_voxmap_destroy(map);
-            if (rc != LVBA_OK) { free_clouds(); return rc; }
+            if (rc != LVBA_OK) return rc;
             std::vector<lvba_lm_trace> trace((size_t)std::max(1, o.lm.max_iter));
             int32_t nt = 0;
             lvba_balm_info_t bi;
@@ -197,7 +209,7 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
             info.setup_ms = now_ms() - tw;
             rc = lvba_balm_refine(b, x.data(), &o.lm, trace.data(), &nt);
             lvba_balm_destroy(b);
-            if (rc < 0) { free_clouds(); return rc; }
+            if (rc < 0) return rc;
             info.lm_status = rc; info.n_iter = nt;
             if (nt > 0) {
                 info.cost_first = trace[0].residual1;
@@ -205,9 +217,9 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
             }
         }
         info.solve_ms = now_ms() - tw; tw = now_ms();
-        if (window_poses) memcpy(window_poses + 12 * (int64_t)start, x.data(), 96 * (size_t)cw);
         // alignment (:268-279) and relative poses (:284-299)
-        std::vector<double> rel(12 * (size_t)cw);
+        std::vector<double> &rel = R.rel;
+        rel.assign(12 * (size_t)cw, 0.0);
         const double *Ro0 = x_odom, *po0 = x_odom + 9;
         double R_align[9], p_align[3] = {0, 0, 0};
         if (o.use_rel) {
@@ -230,8 +242,6 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
             mat3T_mul(Ro0, Ra, rj);
             const double d[3] = {pa[0] - po0[0], pa[1] - po0[1], pa[2] - po0[2]};
             for (int r = 0; r < 3; ++r) rj[9 + r] = Ro0[r] * d[0] + Ro0[3 + r] * d[1] + Ro0[6 + r] * d[2];
-            memcpy(rel_poses + 12 * (int64_t)(start + j), rj, 96);
-            anchor_index[start + j] = (int32_t)clouds.size();
         }
         // merge + down_sampling_voxel2 on the device
         const int64_t p_begin = sc->frame_off[start], P = sc->frame_off[start + cw] - p_begin;
@@ -255,7 +265,7 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
                 int err = 0;
                 HIPCHK(hipMemcpyAsync(&err, d_err.p, 4, hipMemcpyDeviceToHost, s));
                 HIPCHK(hipStreamSynchronize(s));
-                if (err) { free_clouds(); return lvba_fail(LVBA_ERR_ARG, "window %d: a merged point is non-finite or outside +-2^20 anchor leaves", wi); }
+                if (err) { return lvba_fail(LVBA_ERR_ARG, "window %d: a merged point is non-finite or outside +-2^20 anchor leaves", wi); }
                 DevBuf key_s(s), order(s), flag(s), excl(s), pick(s);
                 HIPCHK(key_s.alloc(8 * (size_t)P)); HIPCHK(order.alloc(4 * (size_t)P)); HIPCHK(flag.alloc(4 * ((size_t)P + 1)));
                 HIPCHK(excl.alloc(4 * ((size_t)P + 1))); HIPCHK(pick.alloc(4 * (size_t)P));
@@ -278,13 +288,67 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
             }
         }
         info.merge_ms = now_ms() - tw;
-        info.anchor = (int32_t)clouds.size();
         info.n_anchor_points = n_out;
-        memcpy(anchor_poses + 12 * clouds.size(), x_odom, 96);
-        clouds.push_back({d_out, n_out});
-        if (win_info) win_info[wi] = info;
+        R.d_out = d_out; R.n_out = n_out;
+        return LVBA_OK;
+    };
+    {
+        int n_thr = 4;
+        if (const char *e = getenv("LVBA_WINDOW_THREADS")) n_thr = atoi(e);
+        n_thr = std::max(1, std::min(n_thr, n_win));
+        std::atomic<int> next{0};
+        auto worker = [&](hipStream_t ws) {
+            for (int wi = next.fetch_add(1); wi < n_win; wi = next.fetch_add(1)) {
+                WinResult &R = results[(size_t)wi];
+                R.rc = process(wi, ws, R);
+                if (R.rc < 0) R.err = lvba_last_error();
+            }
+        };
+        if (n_thr == 1) {
+            worker(s);
+        } else {
+            struct Inhibit { Inhibit() { bs_graph_inhibit(+1); } ~Inhibit() { bs_graph_inhibit(-1); } } inhibit;
+            std::vector<std::thread> pool;
+            for (int t = 0; t < n_thr; ++t)
+                pool.emplace_back([&, t]() {
+                    (void)t;
+                    if (hipSetDevice(sc->device) != hipSuccess) return;
+                    hipStream_t ws = nullptr;
+                    if (hipStreamCreateWithFlags(&ws, hipStreamNonBlocking) != hipSuccess) return;
+                    worker(ws);
+                    (void)hipStreamSynchronize(ws);
+                    (void)hipStreamDestroy(ws);
+                });
+            for (auto &th : pool) th.join();
+            for (int wi = 0; wi < n_win; ++wi) // a thread that could not get a stream leaves its windows untouched
+                if (results[(size_t)wi].rc == LVBA_OK && results[(size_t)wi].info.n_frames == 0) {
+                    WinResult &R = results[(size_t)wi];
+                    R.rc = process(wi, s, R);
+                    if (R.rc < 0) R.err = lvba_last_error();
+                }
+        }
     }
-
+    for (int wi = 0; wi < n_win; ++wi) { // assemble in window order
+        WinResult &R = results[(size_t)wi];
+        if (R.rc < 0) {
+            for (auto &q : results) if (q.d_out) DevicePool::get().free(q.d_out);
+            clouds.clear();
+            return lvba_fail(R.rc, "%s", R.err.c_str());
+        }
+    }
+    for (int wi = 0; wi < n_win; ++wi) {
+        WinResult &R = results[(size_t)wi];
+        const int start = wi * w, cw = std::min(w, n - start);
+        if (!R.info.skipped) {
+            if (window_poses) memcpy(window_poses + 12 * (int64_t)start, R.x.data(), 96 * (size_t)cw);
+            memcpy(rel_poses + 12 * (int64_t)start, R.rel.data(), 96 * (size_t)cw);
+            for (int j = 0; j < cw; ++j) anchor_index[start + j] = (int32_t)clouds.size();
+            R.info.anchor = (int32_t)clouds.size();
+            memcpy(anchor_poses + 12 * clouds.size(), poses + 12 * (int64_t)start, 96);
+            clouds.push_back({R.d_out, R.n_out});
+        }
+        if (win_info) win_info[wi] = R.info;
+    }
     // the anchor clouds as a scan set of their own
     lvba_scans_s *out = new (std::nothrow) lvba_scans_s();
     if (!out) { free_clouds(); return lvba_fail(LVBA_ERR_NOMEM, "host allocation failed"); }

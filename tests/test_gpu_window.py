@@ -96,3 +96,30 @@ def test_lidar_ba_pipeline_matches_oracle(pkg, synth, window_enable):
     def err(x):
         return np.abs(x[:, 9:] - s["poses_gt"][:, 9:]).mean()
     assert err(got) < err(s["poses"])
+
+
+def test_window_threads_give_identical_results(pkg, synth, monkeypatch):
+    """Windows are worked through by several host threads (LVBA_WINDOW_THREADS, default 4); every window's arithmetic is
+    independent of the others, so the outputs must be bitwise those of the single-threaded run -- poses, relative poses,
+    anchor numbering (with a skipped window in between) and the anchor clouds."""
+    s = synth.make_scans(22, 6000, room=(10, 8, 4), origin=(2.0, -1.0, 0.4), n_panels=8, seed=41, rot_sigma_deg=0.1,
+                         trans_sigma=0.03)
+    clouds = [c.copy() for c in s["clouds"]]
+    for f in range(8, 12):
+        clouds[f] = clouds[f][:40]                                          # window 2 (frames 8..11) has too few planes: skipped
+    outs = {}
+    for thr in ("1", "4"):
+        monkeypatch.setenv("LVBA_WINDOW_THREADS", thr)
+        with pkg.Scans(clouds) as scans:
+            got = scans.window_ba(s["poses"], window_size=4, voxel_size=1.0, anchor_leaf=0.05)
+        pts = [got["anchor_scans"].download(a) for a in range(len(got["anchor_poses"]))]
+        got["anchor_scans"].close()
+        outs[thr] = (got, pts)
+    a, b = outs["1"], outs["4"]
+    assert [w["skipped"] for w in a[0]["windows"]] == [0, 0, 1, 0, 0, 0]
+    for k in ("window_poses", "rel_poses", "anchor_index", "anchor_poses"):
+        np.testing.assert_array_equal(a[0][k], b[0][k])
+    assert [w["anchor"] for w in a[0]["windows"]] == [w["anchor"] for w in b[0]["windows"]] == [0, 1, -1, 2, 3, 4]
+    assert len(a[1]) == len(b[1]) == 5
+    for p, q in zip(a[1], b[1]):
+        np.testing.assert_array_equal(p, q)
