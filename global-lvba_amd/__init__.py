@@ -5,7 +5,7 @@ The directory name (with a hyphen) is fixed by the build contract; import it wit
 """
 from . import _lib
 from .balm import BALM2, IMUST, VOX_HESS, BalmProblem, shard_range
-from .visual import VisualProblem, optimize_camera_poses
+from .visual import DepthImages, VisualProblem, fuse_tracks, optimize_camera_poses
 from .voxel import Scans, VoxelMap
 
 __all__ = ["BALM2", "IMUST", "VOX_HESS", "BalmProblem", "shard_range", "VisualProblem", "optimize_camera_poses", "VoxelMap", "Scans", "_lib"]

@@ -22,6 +22,8 @@ SYMBOLS = [
     "lvba_voxmap_to_balm", "lvba_voxmap_find_planes", "lvba_scans_create", "lvba_scans_destroy", "lvba_voxmap_build_scans",
     "lvba_release_cached_memory", "lvba_window_default_opts", "lvba_window_ba", "lvba_scans_info", "lvba_scans_download",
     "lvba_lidar_ba_default_opts", "lvba_lidar_ba", "lvba_triangulate_tracks",
+    "lvba_depth_render", "lvba_depth_upload", "lvba_depth_info", "lvba_depth_download", "lvba_depth_destroy",
+    "lvba_fuse_default_opts", "lvba_fuse_tracks",
 ]
 
 OK, ERR_ARG, ERR_DEVICE, ERR_NOMEM, ERR_UNSUPPORTED, ERR_DIST, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
@@ -70,6 +72,11 @@ class VisualTrace(C.Structure):
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_ if f != "reserved"}
+
+
+class FuseOpts(C.Structure):
+    _fields_ = [("obser_thr", C.c_int32), ("reserved", C.c_int32), ("min_view_angle_deg", C.c_double),
+                ("reproj_mean_thr_px", C.c_double)]
 
 
 class VoxelOpts(C.Structure):
@@ -199,6 +206,18 @@ def load():
     lib.lvba_lidar_ba.argtypes = [H, f64p, C.POINTER(LidarBaOpts), f64p, C.POINTER(LidarBaReport)]
     lib.lvba_triangulate_tracks.argtypes = [C.c_int32, C.c_int32, C.c_int64, i64p, C.c_void_p, C.c_void_p, f64p, f64p, f64p, f64p,
                                             f64p, i32p, u8p]
+    lib.lvba_depth_render.argtypes = [C.c_void_p, f64p, f64p, C.c_int32, f64p, f64p, f64p, f64p, C.c_int32, C.c_int32, C.c_double,
+                                      C.c_double, C.POINTER(C.c_void_p)]
+    lib.lvba_depth_upload.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, np.ctypeslib.ndpointer(np.float32, flags="C"),
+                                      C.POINTER(C.c_void_p)]
+    lib.lvba_depth_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.lvba_depth_download.argtypes = [C.c_void_p, C.c_int32, np.ctypeslib.ndpointer(np.float32, flags="C")]
+    lib.lvba_depth_destroy.argtypes = [C.c_void_p]
+    lib.lvba_depth_destroy.restype = None
+    lib.lvba_fuse_default_opts.argtypes = [C.POINTER(FuseOpts)]
+    lib.lvba_fuse_default_opts.restype = None
+    lib.lvba_fuse_tracks.argtypes = [C.c_int32, C.c_void_p, C.c_int32, f64p, f64p, f64p, C.c_int64, i64p, C.c_void_p, C.c_void_p,
+                                     C.POINTER(FuseOpts), C.c_void_p, f64p, f64p, C.c_void_p]
     lib.lvba_scans_info.argtypes = [H, C.POINTER(C.c_int32), C.c_void_p]
     lib.lvba_scans_download.argtypes = [H, C.c_int32, np.ctypeslib.ndpointer(np.float32, flags="C")]
     for name in SYMBOLS:

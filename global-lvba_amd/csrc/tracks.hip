@@ -13,74 +13,13 @@
 #include <stdint.h>
 #include "lvba_common.h"
 #include "mempool.h"
+#include "tracks_device.h"
 
 using namespace lvba;
 
 namespace {
 
-struct Intr { double fx, fy, cx, cy, k1, k2, p1, p2; };
-
-__device__ __forceinline__ bool undistort(const Intr &c, double u, double v, double &x, double &y)
-{
-    if (!(isfinite(u) && isfinite(v)) || fabs(c.fx) < 1e-12 || fabs(c.fy) < 1e-12) return false;
-    const double xd = (u - c.cx) / c.fx, yd = (v - c.cy) / c.fy;
-    double xu = xd, yu = yd;
-    for (int it = 0; it < 8; ++it) {
-        const double r2 = xu * xu + yu * yu, r4 = r2 * r2;
-        const double radial = 1.0 + c.k1 * r2 + c.k2 * r4;
-        if (fabs(radial) < 1e-12 || !isfinite(radial)) return false;
-        const double xt = 2.0 * c.p1 * xu * yu + c.p2 * (r2 + 2.0 * xu * xu);
-        const double yt = c.p1 * (r2 + 2.0 * yu * yu) + 2.0 * c.p2 * xu * yu;
-        xu = (xd - xt) / radial;
-        yu = (yd - yt) / radial;
-        if (!(isfinite(xu) && isfinite(yu))) return false;
-    }
-    x = xu; y = yu;
-    return true;
-}
-__device__ __forceinline__ bool project(const Intr &c, const double *R, const double *t, const double *X, double &u, double &v)
-{
-    const double X0 = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + t[0];
-    const double X1 = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + t[1];
-    const double Z = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + t[2];
-    if (!(isfinite(X0) && isfinite(X1) && isfinite(Z)) || Z <= 1e-12) return false;
-    const double x = X0 / Z, y = X1 / Z;
-    const double r2 = x * x + y * y, r4 = r2 * r2;
-    const double radial = 1.0 + c.k1 * r2 + c.k2 * r4;
-    const double xd = x * radial + 2.0 * c.p1 * x * y + c.p2 * (r2 + 2.0 * x * x);
-    const double yd = y * radial + c.p1 * (r2 + 2.0 * y * y) + 2.0 * c.p2 * x * y;
-    if (!(isfinite(xd) && isfinite(yd))) return false;
-    u = c.fx * xd + c.cx;
-    v = c.fy * yd + c.cy;
-    return isfinite(u) && isfinite(v);
-}
-
-// one Jacobi rotation in the (p, q) plane of the symmetric 4x4 A (full storage) with eigenvector accumulation in V
-#define JROT4(p, q)                                                                                      \
-    do {                                                                                                 \
-        const double apq = A[p][q];                                                                      \
-        if (apq != 0.0) {                                                                                \
-            const double th = (A[q][q] - A[p][p]) / (2.0 * apq);                                         \
-            const double tt = (th >= 0.0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));               \
-            const double cs = 1.0 / sqrt(tt * tt + 1.0), sn = tt * cs;                                   \
-            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                              \
-                const double arp = A[r][p], arq = A[r][q];                                               \
-                A[r][p] = cs * arp - sn * arq;                                                           \
-                A[r][q] = sn * arp + cs * arq;                                                           \
-            }                                                                                            \
-            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                              \
-                const double apr = A[p][r], aqr = A[q][r];                                               \
-                A[p][r] = cs * apr - sn * aqr;                                                           \
-                A[q][r] = sn * apr + cs * aqr;                                                           \
-            }                                                                                            \
-            A[p][q] = 0.0; A[q][p] = 0.0;                                                                \
-            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                              \
-                const double vrp = V[r][p], vrq = V[r][q];                                               \
-                V[r][p] = cs * vrp - sn * vrq;                                                           \
-                V[r][q] = sn * vrp + cs * vrq;                                                           \
-            }                                                                                            \
-        }                                                                                                \
-    } while (0)
+typedef TrkIntr Intr;
 
 __global__ void tri_kernel(int64_t n, const int64_t *__restrict__ obs_off, const int32_t *__restrict__ obs_cam,
                            const double *__restrict__ obs_uv, const double *__restrict__ Rcw, const double *__restrict__ tcw,
@@ -95,63 +34,13 @@ __global__ void tri_kernel(int64_t n, const int64_t *__restrict__ obs_off, const
     cnt_out[i] = 0;
     ok_out[i] = 0;
     const int64_t a = obs_off[i], b = obs_off[i + 1];
-    if (b - a < 4) return; // selected_ids.size() < 4
-    double A[4][4], V[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { A[r][c] = 0.0; V[r][c] = r == c ? 1.0 : 0.0; }
-    int rows = 0;
-    for (int64_t o = a; o < b; ++o) {
-        const int32_t cm = obs_cam[o];
-        if (cm < 0 || cm >= n_cams) continue;
-        double x, y;
-        if (!undistort(cam, obs_uv[2 * o], obs_uv[2 * o + 1], x, y)) continue;
-        const double *R = Rcw + 9 * (int64_t)cm, *t = tcw + 3 * (int64_t)cm;
-        const double P0[4] = {R[0], R[1], R[2], t[0]}, P1[4] = {R[3], R[4], R[5], t[1]}, P2[4] = {R[6], R[7], R[8], t[2]};
-        double ru[4], rv[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { ru[c] = x * P2[c] - P0[c]; rv[c] = y * P2[c] - P1[c]; }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) A[r][c] += ru[r] * ru[c] + rv[r] * rv[c];
-        rows += 2;
-    }
-    if (rows < 8) return;
-    for (int sweep = 0; sweep < 40; ++sweep) {
-        const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[0][3]) + fabs(A[1][2]) + fabs(A[1][3]) + fabs(A[2][3]);
-        if (off == 0.0) break;
-        JROT4(0, 1); JROT4(0, 2); JROT4(0, 3); JROT4(1, 2); JROT4(1, 3); JROT4(2, 3);
-    }
-    int m = 0; // column of the smallest eigenvalue
-    double lm = A[0][0];
-#pragma unroll
-    for (int c = 1; c < 4; ++c)
-        if (A[c][c] < lm) { lm = A[c][c]; m = c; }
-    double Xh[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Xh[r] = m == 0 ? V[r][0] : (m == 1 ? V[r][1] : (m == 2 ? V[r][2] : V[r][3]));
-    if (fabs(Xh[3]) < 1e-12) return;
-    const double X[3] = {Xh[0] / Xh[3], Xh[1] / Xh[3], Xh[2] / Xh[3]};
-    if (!(isfinite(X[0]) && isfinite(X[1]) && isfinite(X[2]))) return;
+    double X[3] = {0.0, 0.0, 0.0}, mean;
+    int cnt;
+    const bool ok = trk_dlt(cam, Rcw, tcw, n_cams, a, b, obs_cam, obs_uv, nullptr, 0, X, mean, cnt);
     Xo[0] = X[0]; Xo[1] = X[1]; Xo[2] = X[2];
-    double sum = 0.0;
-    int cnt = 0;
-    for (int64_t o = a; o < b; ++o) {
-        const int32_t cm = obs_cam[o];
-        if (cm < 0 || cm >= n_cams) continue;
-        double u, v;
-        if (!project(cam, Rcw + 9 * (int64_t)cm, tcw + 3 * (int64_t)cm, X, u, v)) continue;
-        const double du = u - obs_uv[2 * o], dv = v - obs_uv[2 * o + 1];
-        sum += sqrt(du * du + dv * dv);
-        ++cnt;
-    }
     cnt_out[i] = cnt;
-    if (cnt < 4) return;
-    const double mean = sum / (double)cnt;
     err_out[i] = mean;
-    ok_out[i] = isfinite(mean) ? 1 : 0;
+    ok_out[i] = ok ? 1 : 0;
 }
 
 } // namespace

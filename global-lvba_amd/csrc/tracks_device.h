@@ -1,0 +1,163 @@
+// tracks_device.h -- device functions shared by tracks.hip (stand-alone DLT) and fusion.hip (per-track fusion):
+//   undistortPixelToNormalized / distortNormalized / projectCameraToPixel   include/utils.hpp:169-233
+//   TriangulateTrackDLT                                                     src/lvba_system.cpp:50-111
+//   ComputeMeanReproj                                                       src/lvba_system.cpp:8-48
+// Observations are visited in the caller's order (the reference walks an unordered_map: the sums differ at rounding level).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+namespace lvba {
+
+struct TrkIntr { double fx, fy, cx, cy, k1, k2, p1, p2; };
+
+__device__ __forceinline__ bool trk_undistort(const TrkIntr &c, double u, double v, double &x, double &y)
+{
+    if (!(isfinite(u) && isfinite(v)) || fabs(c.fx) < 1e-12 || fabs(c.fy) < 1e-12) return false;
+    const double xd = (u - c.cx) / c.fx, yd = (v - c.cy) / c.fy;
+    double xu = xd, yu = yd;
+    for (int it = 0; it < 8; ++it) {
+        const double r2 = xu * xu + yu * yu, r4 = r2 * r2;
+        const double radial = 1.0 + c.k1 * r2 + c.k2 * r4;
+        if (fabs(radial) < 1e-12 || !isfinite(radial)) return false;
+        const double xt = 2.0 * c.p1 * xu * yu + c.p2 * (r2 + 2.0 * xu * xu);
+        const double yt = c.p1 * (r2 + 2.0 * yu * yu) + 2.0 * c.p2 * xu * yu;
+        xu = (xd - xt) / radial;
+        yu = (yd - yt) / radial;
+        if (!(isfinite(xu) && isfinite(yu))) return false;
+    }
+    x = xu; y = yu;
+    return true;
+}
+// projectCameraToPixel: camera-frame point -> distorted pixel
+__device__ __forceinline__ bool trk_project_cam(const TrkIntr &c, double X0, double X1, double Z, double &u, double &v)
+{
+    if (!(isfinite(X0) && isfinite(X1) && isfinite(Z)) || Z <= 1e-12) return false;
+    const double x = X0 / Z, y = X1 / Z;
+    const double r2 = x * x + y * y, r4 = r2 * r2;
+    const double radial = 1.0 + c.k1 * r2 + c.k2 * r4;
+    const double xd = x * radial + (2.0 * c.p1 * x * y + c.p2 * (r2 + 2.0 * x * x));
+    const double yd = y * radial + (c.p1 * (r2 + 2.0 * y * y) + 2.0 * c.p2 * x * y);
+    if (!(isfinite(xd) && isfinite(yd))) return false;
+    u = c.fx * xd + c.cx;
+    v = c.fy * yd + c.cy;
+    return isfinite(u) && isfinite(v);
+}
+__device__ __forceinline__ bool trk_project(const TrkIntr &c, const double *R, const double *t, const double *X, double &u, double &v)
+{
+    const double X0 = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + t[0];
+    const double X1 = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + t[1];
+    const double Z = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + t[2];
+    return trk_project_cam(c, X0, X1, Z, u, v);
+}
+
+// one Jacobi rotation in the (p, q) plane of the symmetric 4x4 A (full storage) with eigenvector accumulation in V
+#define LVBA_JROT4(p, q)                                                                                 \
+    do {                                                                                                 \
+        const double apq = A[p][q];                                                                      \
+        if (apq != 0.0) {                                                                                \
+            const double th = (A[q][q] - A[p][p]) / (2.0 * apq);                                         \
+            const double tt = (th >= 0.0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));               \
+            const double cs = 1.0 / sqrt(tt * tt + 1.0), sn = tt * cs;                                   \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                              \
+                const double arp = A[r][p], arq = A[r][q];                                               \
+                A[r][p] = cs * arp - sn * arq;                                                           \
+                A[r][q] = sn * arp + cs * arq;                                                           \
+            }                                                                                            \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                              \
+                const double apr = A[p][r], aqr = A[q][r];                                               \
+                A[p][r] = cs * apr - sn * aqr;                                                           \
+                A[q][r] = sn * apr + cs * aqr;                                                           \
+            }                                                                                            \
+            A[p][q] = 0.0; A[q][p] = 0.0;                                                                \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                              \
+                const double vrp = V[r][p], vrq = V[r][q];                                               \
+                V[r][p] = cs * vrp - sn * vrq;                                                           \
+                V[r][q] = sn * vrp + cs * vrq;                                                           \
+            }                                                                                            \
+        }                                                                                                \
+    } while (0)
+
+// ComputeMeanReproj over the observations o in [a, b) with (sel == nullptr || sel[o] & bit).  false: fewer than min_count
+// projectable observations or a non-finite mean.
+template <class UV>
+__device__ __forceinline__ bool trk_mean_reproj(const TrkIntr &cam, const double *__restrict__ Rcw, const double *__restrict__ tcw,
+                                                int32_t n_cams, int64_t a, int64_t b, const int32_t *__restrict__ obs_cam,
+                                                const UV *__restrict__ obs_uv, const uint8_t *sel, uint8_t bit, const double *X,
+                                                int min_count, double &mean, int &cnt)
+{
+    double sum = 0.0;
+    cnt = 0;
+    for (int64_t o = a; o < b; ++o) {
+        if (sel && !(sel[o] & bit)) continue;
+        const int32_t cm = obs_cam[o];
+        if (cm < 0 || cm >= n_cams) continue;
+        double u, v;
+        if (!trk_project(cam, Rcw + 9 * (int64_t)cm, tcw + 3 * (int64_t)cm, X, u, v)) continue;
+        const double du = u - (double)obs_uv[2 * o], dv = v - (double)obs_uv[2 * o + 1];
+        sum += sqrt(du * du + dv * dv);
+        ++cnt;
+    }
+    if (cnt < min_count) return false;
+    mean = sum / (double)cnt;
+    return isfinite(mean);
+}
+
+// TriangulateTrackDLT over the selected observations.  X, mean, cnt are written only as far as the reference gets.
+template <class UV>
+__device__ __forceinline__ bool trk_dlt(const TrkIntr &cam, const double *__restrict__ Rcw, const double *__restrict__ tcw,
+                                        int32_t n_cams, int64_t a, int64_t b, const int32_t *__restrict__ obs_cam,
+                                        const UV *__restrict__ obs_uv, const uint8_t *sel, uint8_t bit, double *X, double &mean,
+                                        int &cnt)
+{
+    mean = INFINITY;
+    cnt = 0;
+    int n_sel = 0;
+    for (int64_t o = a; o < b; ++o) n_sel += (!sel || (sel[o] & bit)) ? 1 : 0;
+    if (n_sel < 4) return false; // selected_ids.size() < 4
+    double A[4][4], V[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { A[r][c] = 0.0; V[r][c] = r == c ? 1.0 : 0.0; }
+    int rows = 0;
+    for (int64_t o = a; o < b; ++o) {
+        if (sel && !(sel[o] & bit)) continue;
+        const int32_t cm = obs_cam[o];
+        if (cm < 0 || cm >= n_cams) continue;
+        double x, y;
+        if (!trk_undistort(cam, (double)obs_uv[2 * o], (double)obs_uv[2 * o + 1], x, y)) continue;
+        const double *R = Rcw + 9 * (int64_t)cm, *t = tcw + 3 * (int64_t)cm;
+        const double P0[4] = {R[0], R[1], R[2], t[0]}, P1[4] = {R[3], R[4], R[5], t[1]}, P2[4] = {R[6], R[7], R[8], t[2]};
+        double ru[4], rv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { ru[c] = x * P2[c] - P0[c]; rv[c] = y * P2[c] - P1[c]; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) A[r][c] += ru[r] * ru[c] + rv[r] * rv[c];
+        rows += 2;
+    }
+    if (rows < 8) return false;
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[0][3]) + fabs(A[1][2]) + fabs(A[1][3]) + fabs(A[2][3]);
+        if (off == 0.0) break;
+        LVBA_JROT4(0, 1); LVBA_JROT4(0, 2); LVBA_JROT4(0, 3); LVBA_JROT4(1, 2); LVBA_JROT4(1, 3); LVBA_JROT4(2, 3);
+    }
+    int m = 0; // column of the smallest eigenvalue
+    double lm = A[0][0];
+#pragma unroll
+    for (int c = 1; c < 4; ++c)
+        if (A[c][c] < lm) { lm = A[c][c]; m = c; }
+    double Xh[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Xh[r] = m == 0 ? V[r][0] : (m == 1 ? V[r][1] : (m == 2 ? V[r][2] : V[r][3]));
+    if (fabs(Xh[3]) < 1e-12) return false;
+    const double Xc[3] = {Xh[0] / Xh[3], Xh[1] / Xh[3], Xh[2] / Xh[3]};
+    if (!(isfinite(Xc[0]) && isfinite(Xc[1]) && isfinite(Xc[2]))) return false;
+    X[0] = Xc[0]; X[1] = Xc[1]; X[2] = Xc[2];
+    return trk_mean_reproj(cam, Rcw, tcw, n_cams, a, b, obs_cam, obs_uv, sel, bit, Xc, 4, mean, cnt);
+}
+
+} // namespace lvba

@@ -59,4 +59,26 @@ inline int32_t scan_excl(hipStream_t s, const T *in, T *out, size_t n)
     return LVBA_OK;
 }
 
+
+// ---- voxel keys shared by the plane map (voxelize.hip) and the depth grid map (fusion.hip) --------------------------
+constexpr int KEY_BIAS = 1 << 20; // key components must lie in [-2^20, 2^20)
+// (int64)(float)(p / vs), minus one for negatives (cut_voxel, bavoxel.hpp:809-815; the same rule at src/lvba_system.cpp:1289-1293
+// and :1539-1544)
+__device__ __forceinline__ bool root_key_of(const double pw[3], double vs, int64_t k[3])
+{
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        float loc = (float)(pw[j] / vs);
+        if (loc < 0) loc = (float)((double)loc - 1.0);
+        ok = ok && (fabsf(loc) < (float)KEY_BIAS); // also false for NaN / inf
+        k[j] = ok ? (int64_t)loc : 0;
+    }
+    return ok;
+}
+__device__ __forceinline__ uint64_t pack_key(const int64_t k[3])
+{
+    return ((uint64_t)(k[0] + KEY_BIAS) << 42) | ((uint64_t)(k[1] + KEY_BIAS) << 21) | (uint64_t)(k[2] + KEY_BIAS);
+}
+
 } // namespace lvba

@@ -38,22 +38,9 @@ using namespace lvba;
 
 namespace {
 
-constexpr int KEY_BIAS = 1 << 20; // root key components must lie in [-2^20, 2^20)
 enum : int { ST_NONE = 0, ST_DROP = 1, ST_PLANE = 2, ST_SPLIT = 3 };
 
 // ---- shared per-point arithmetic (cut_voxel :809-815, root centre :826-829, cut_func :368-381) ------------------
-__device__ __forceinline__ bool root_key_of(const double pw[3], double vs, int64_t k[3])
-{
-    bool ok = true;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        float loc = (float)(pw[j] / vs);
-        if (loc < 0) loc = (float)((double)loc - 1.0);
-        ok = ok && (fabsf(loc) < (float)KEY_BIAS); // also false for NaN / inf
-        k[j] = ok ? (int64_t)loc : 0;
-    }
-    return ok;
-}
 __device__ __forceinline__ void octants_of(const double pw[3], const int64_t k[3], double vs, int &o1, int &o2)
 {
     const float quater = (float)(vs / 4.0);
@@ -67,10 +54,6 @@ __device__ __forceinline__ void octants_of(const double pw[3], const int64_t k[3
         o1 |= b1 << (2 - j);
         o2 |= b2 << (2 - j);
     }
-}
-__device__ __forceinline__ uint64_t pack_key(const int64_t k[3])
-{
-    return ((uint64_t)(k[0] + KEY_BIAS) << 42) | ((uint64_t)(k[1] + KEY_BIAS) << 21) | (uint64_t)(k[2] + KEY_BIAS);
 }
 
 // ---- 1. keys + records --------------------------------------------------------------------------------------------

@@ -176,7 +176,8 @@ def triangulate_and_filter(Rcw, tcw, keypoints, obs_off, obs_img, obs_kp, intr, 
     track, greedy view-angle filter against the seed (an observation is kept if its ray makes at least min_view_angle with
     one already kept ray -- upstream walks an unordered_map, here: track order), DLT again over the kept observations,
     accepted if its mean reprojection error <= reproj_mean_thr_px.  Both DLT passes run on the GPU
-    (lvba_triangulate_tracks); the depth-fusion candidate (:1016-1106) needs the projected depth images and is not built.
+    (lvba_triangulate_tracks).  fuse_tracks() below runs both candidates (depth-fused and triangulated) and the selection in
+    one kernel; this function remains as the two-pass host-driven form of the triangulation candidate.
     Returns (ok [T], X [T,3], mean_reproj [T], kept_off [T+1], kept_img, kept_kp)."""
     Rcw = np.ascontiguousarray(Rcw, np.float64).reshape(-1, 3, 3)
     tcw = np.ascontiguousarray(tcw, np.float64).reshape(-1, 3)
@@ -205,3 +206,86 @@ def triangulate_and_filter(Rcw, tcw, keypoints, obs_off, obs_img, obs_kp, intr, 
     ok1, X1, err1, _ = triangulate_tracks(Rcw, tcw, koff, kimg, kuv, intr, device)
     ok = (ok1 > 0) & (np.diff(koff) >= 4) & (err1 <= reproj_mean_thr_px)
     return ok, X1, err1, koff, kimg, kkp
+
+
+class DepthImages:
+    """Device-resident depth images (lvba_depth_t): rendered from the refined LiDAR map
+    (LvbaSystem::buildGridMapFromOptimized + generateDepthWithVoxel, src/lvba_system.cpp:835-919, 1266-1338) or uploaded."""
+
+    def __init__(self, handle):
+        self._h = handle
+        self.lib = L.load()
+        n, w, h = C.c_int32(), C.c_int32(), C.c_int32()
+        L.check(self.lib.lvba_depth_info(self._h, C.byref(n), C.byref(w), C.byref(h)))
+        self.n_images, self.width, self.height = n.value, w.value, h.value
+
+    @classmethod
+    def render(cls, scans, scan_poses, scan_times, image_times, Rcw, tcw, intr, width, height, half_window_s=0.5,
+               voxel_size=0.5):
+        """scans: a voxel.Scans; scan_poses [n,12] (refined, T_world<-body); scan_times ascending; image_times are rounded
+        to 1e-6 s as the reference's std::to_string round trip does (src/lvba_system.cpp:1311-1318)."""
+        lib = L.load()
+        img_t = np.array([float(f"{t:.6f}") for t in np.asarray(image_times, np.float64)], np.float64)
+        h = C.c_void_p()
+        L.check(lib.lvba_depth_render(scans._h, np.ascontiguousarray(scan_poses, np.float64).reshape(-1),
+                                      np.ascontiguousarray(scan_times, np.float64), len(img_t), img_t,
+                                      np.ascontiguousarray(Rcw, np.float64).reshape(-1), np.ascontiguousarray(tcw, np.float64).reshape(-1),
+                                      np.ascontiguousarray(intr, np.float64), int(width), int(height), float(half_window_s),
+                                      float(voxel_size), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def upload(cls, depth, device=0):
+        depth = np.ascontiguousarray(depth, np.float32)
+        n, hh, ww = depth.shape
+        h = C.c_void_p()
+        L.check(L.load().lvba_depth_upload(int(device), n, ww, hh, depth.reshape(-1), C.byref(h)))
+        return cls(h)
+
+    def download(self, image):
+        out = np.zeros(self.width * self.height, np.float32)
+        L.check(self.lib.lvba_depth_download(self._h, int(image), out))
+        return out.reshape(self.height, self.width)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.lvba_depth_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+def fuse_tracks(obs_off, obs_img, obs_uv, Rcw, tcw, intr, depth=None, obser_thr=3, min_view_angle_deg=8.0,
+                reproj_mean_thr_px=3.0, device=0):
+    """The per-component part of LvbaSystem::BuildTracksAndFuse3D (src/lvba_system.cpp:1000-1225) on the GPU: depth-fused and
+    triangulated candidates + selection for every track (BFS component, observations in BFS order, float keypoints).
+    depth: a DepthImages or None.  Returns (status [n] 0 dropped / 1 triangulated / 2 depth-fused, X [n,3], mean_reproj [n],
+    kept [O] mask of the inlier observations)."""
+    lib = L.load()
+    Rcw = np.ascontiguousarray(Rcw, np.float64).reshape(-1, 9)
+    tcw = np.ascontiguousarray(tcw, np.float64).reshape(-1, 3)
+    obs_off = np.ascontiguousarray(obs_off, np.int64)
+    obs_img = np.ascontiguousarray(obs_img, np.int32)
+    obs_uv = np.ascontiguousarray(obs_uv, np.float32).reshape(-1, 2)
+    n, O = len(obs_off) - 1, len(obs_img)
+    status = np.zeros(max(n, 1), np.uint8)
+    X = np.zeros((max(n, 1), 3))
+    err = np.zeros(max(n, 1))
+    kept = np.zeros(max(O, 1), np.uint8)
+    o = L.FuseOpts()
+    lib.lvba_fuse_default_opts(C.byref(o))
+    o.obser_thr, o.min_view_angle_deg, o.reproj_mean_thr_px = int(obser_thr), float(min_view_angle_deg), float(reproj_mean_thr_px)
+    L.check(lib.lvba_fuse_tracks(int(device), depth._h if depth is not None else None, len(Rcw), Rcw.reshape(-1), tcw.reshape(-1),
+                                 np.ascontiguousarray(intr, np.float64), n, obs_off, obs_img.ctypes.data, obs_uv.ctypes.data,
+                                 C.byref(o), status.ctypes.data, X.reshape(-1), err, kept.ctypes.data))
+    return status[:n], X[:n], err[:n], kept[:O]

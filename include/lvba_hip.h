@@ -309,6 +309,46 @@ int32_t lvba_triangulate_tracks(int32_t device, int32_t n_cams, int64_t n_tracks
                                 const int32_t *obs_cam, const double *obs_uv, const double *Rcw, const double *tcw,
                                 const double intr[8], double *X, double *mean_reproj, int32_t *count, uint8_t *ok);
 
+/* ---- LiDAR-assisted landmark initialisation: depth images + per-track fusion ---------------------------------------------
+ *   lvba_depth_render <- LvbaSystem::buildGridMapFromOptimized (src/lvba_system.cpp:1266-1338) + generateDepthWithVoxel
+ *   (:835-919): every scan point in the world frame (scan_poses [n_frames][12], T_world<-body of the REFINED trajectory) is
+ *   hashed into voxel_size (reference: 0.5 m) voxels; image m sees the voxels touched by the scans with
+ *   |scan_time - image_time| <= half_window_s (reference: 0.5 s; scan_times ascending; the reference passes the image id
+ *   through std::to_string, i.e. rounds it to 1e-6 s -- the caller does that) and ALL map points of those voxels are
+ *   z-buffered through camera m (Rcw [n][9], tcw [n][3], intr = fx fy cx cy k1 k2 p1 p2): pixel (int)u, (int)v, Z < 1e-3
+ *   skipped, smallest (float)Z wins, 0 = no return.  Images stay on the device.
+ *   lvba_depth_upload makes a handle from host images [n][height][width] (depth from another source).
+ *   lvba_fuse_tracks <- the per-component part of LvbaSystem::BuildTracksAndFuse3D (:1000-1225): tracks are the BFS
+ *   components in CSR form (obs_off [n+1] from 0, obs_img [O], obs_uv [O][2] float keypoint coordinates, observations in BFS
+ *   order, several per image allowed).  Per track: the depth-fused candidate (fetchDepthBilinear, back-projection through the
+ *   distortion model, 0.12 m consistency with the first valid observation, first observation per image, greedy view-angle
+ *   filter, mean reprojection error), the triangulation candidate (DLT over the first observation of every image, the same
+ *   filter around the seed, DLT again over >= 4 kept observations), then the reference's selection.  depth may be NULL
+ *   (triangulation candidate only).  status[t] = 0 dropped / 1 triangulated / 2 depth-fused; X [n][3]; mean_reproj [n]
+ *   (+inf when dropped); kept [O] = the track's inlier_indices as a mask.  Where the reference iterates an unordered_map
+ *   of images, images are visited in the order of their first occurrence in the component. */
+typedef struct lvba_depth_s *lvba_depth_t;
+int32_t lvba_depth_render(lvba_scans_t scans, const double *scan_poses, const double *scan_times, int32_t n_images,
+                          const double *image_times, const double *Rcw, const double *tcw, const double intr[8],
+                          int32_t width, int32_t height, double half_window_s, double voxel_size, lvba_depth_t *out);
+int32_t lvba_depth_upload(int32_t device, int32_t n_images, int32_t width, int32_t height, const float *depth,
+                          lvba_depth_t *out);
+int32_t lvba_depth_info(lvba_depth_t depth, int32_t *n_images, int32_t *width, int32_t *height);
+int32_t lvba_depth_download(lvba_depth_t depth, int32_t image, float *out);
+void lvba_depth_destroy(lvba_depth_t depth);
+
+typedef struct lvba_fuse_opts {
+    int32_t obser_thr;          /* minimum observations / images per track (config obser_thr, default 3) */
+    int32_t reserved;
+    double min_view_angle_deg;  /* greedy view-angle filter (config min_view_angle_deg, default 8) */
+    double reproj_mean_thr_px;  /* acceptance threshold of a candidate's mean reprojection error (default 3) */
+} lvba_fuse_opts;
+void lvba_fuse_default_opts(lvba_fuse_opts *opts);
+int32_t lvba_fuse_tracks(int32_t device, lvba_depth_t depth, int32_t n_images, const double *Rcw, const double *tcw,
+                         const double intr[8], int64_t n_tracks, const int64_t *obs_off, const int32_t *obs_img,
+                         const float *obs_uv, const lvba_fuse_opts *opts, uint8_t *status, double *X, double *mean_reproj,
+                         uint8_t *kept);
+
 /* ---- window BA: raw scans + odometry -> anchor frames --------------------------------------------------------------
  *   lvba_window_ba <- LvbaSystem::runWindowBA  src/lvba_system.cpp:204-310 : for every window of window_size frames the voxel
  *   map at the odometry poses (:247-257), the "fewer than 3 plane voxels per frame -> skip" rule (:258-262), damping_iter

@@ -242,6 +242,8 @@ def load_ref():
         lib.ref_pick_largest_cluster.argtypes = [c_i64, f64p, c_i64, i32p, i32p]
         lib.ref_euler_to_rot.argtypes = [c_dbl, c_dbl, c_dbl, f64p]
         lib.ref_parse_timestamp.restype, lib.ref_parse_timestamp.argtypes = c_int, [ctypes.c_char_p, ctypes.POINTER(c_dbl)]
+        lib.ref_fetch_depth_bilinear.restype = c_int
+        lib.ref_fetch_depth_bilinear.argtypes = [c_int, c_int, f32p, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.POINTER(ctypes.c_float)]
         _RLIB = lib
     return _RLIB
 
@@ -403,3 +405,10 @@ class Reference:
         ts = ctypes.c_double()
         ok = self.lib.ref_parse_timestamp(name.encode(), ctypes.byref(ts))
         return (ts.value if ok else None)
+
+    def fetch_depth_bilinear(self, depth, u, v, depth_scale=0.001):
+        depth = self._c(depth, np.float32)
+        out = ctypes.c_float()
+        ok = self.lib.ref_fetch_depth_bilinear(depth.shape[0], depth.shape[1], depth.reshape(-1), float(u), float(v),
+                                               float(depth_scale), ctypes.byref(out))
+        return out.value if ok else None

@@ -41,8 +41,8 @@ def project(intr, R, t, X):
     x, y = Xc[0] / Xc[2], Xc[1] / Xc[2]
     r2 = x * x + y * y
     radial = 1.0 + k1 * r2 + k2 * r2 * r2
-    xd = x * radial + 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x)
-    yd = y * radial + p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y
+    xd = x * radial + (2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x))          # x * radial + x_tan (utils.hpp:176-179)
+    yd = y * radial + (p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y)
     u, v = fx * xd + cx, fy * yd + cy
     return (u, v) if np.isfinite(u) and np.isfinite(v) else None
 

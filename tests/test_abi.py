@@ -41,7 +41,8 @@ def test_every_struct_has_the_size_the_c_compiler_gives_it(pkg, tmp_path):
     pairs = [("lvba_balm_opts", L.BalmOpts), ("lvba_lm_trace", L.LmTrace), ("lvba_balm_info_t", L.BalmInfo),
              ("lvba_prof_t", L.Prof), ("lvba_visual_opts", L.VisualOpts), ("lvba_visual_trace", L.VisualTrace),
              ("lvba_voxel_opts", L.VoxelOpts), ("lvba_voxmap_info_t", L.VoxmapInfo), ("lvba_window_opts", L.WindowOpts),
-             ("lvba_window_info", L.WindowInfo), ("lvba_lidar_ba_opts", L.LidarBaOpts), ("lvba_lidar_ba_report", L.LidarBaReport)]
+             ("lvba_window_info", L.WindowInfo), ("lvba_lidar_ba_opts", L.LidarBaOpts), ("lvba_lidar_ba_report", L.LidarBaReport),
+             ("lvba_fuse_opts", L.FuseOpts)]
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include "lvba_hip.h"\nint main(void){' +
                    "".join(f'printf("%zu\\n", sizeof({n}));' for n, _ in pairs) + "return 0;}\n")
