@@ -137,15 +137,27 @@ __device__ __forceinline__ void diag_blocked_body(double *lds, LdltMat M, int64_
     double *dvs = Zt + 16 * LVBA_Z1S;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     LVBA_K1B_STAMP(0);
-    for (int e = tid; e < 4096; e += 256) {
-        const int row = e & 63, col = e >> 6;
-        double v = 0.0;
-        if (row < nbe) {
-            if (col <= row) v = M.a[(k + row) + (k + col) * M.ld];
-        } else if (col == row)
-            v = 1.0;
-        W[col * LVBA_W1S + row] = v;
-        W[col * LVBA_W1S + 64 + row] = (row == col) ? 1.0 : 0.0;
+    {
+        // all 16 loads of a lane are issued before the first one is waited for (one memory latency instead of a chain of
+        // load -> LDS store pairs)
+        double vv[16];
+        const int row = tid & 63;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int col = (tid >> 6) + 4 * it;
+            double v = 0.0;
+            if (row < nbe) {
+                if (col <= row) v = M.a[(k + row) + (k + col) * M.ld];
+            } else if (col == row)
+                v = 1.0;
+            vv[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int col = (tid >> 6) + 4 * it;
+            W[col * LVBA_W1S + row] = vv[it];
+            W[col * LVBA_W1S + 64 + row] = (row == col) ? 1.0 : 0.0;
+        }
     }
     __syncthreads();
     LVBA_K1B_STAMP(1);
