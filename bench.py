@@ -181,7 +181,7 @@ def main():
         n = 6 * N
         bw = 6 * info["band_blocks"] + 5
         flops_solve = (n * bw * bw if info["use_band"] else n ** 3 / 3.0)
-        roof = {"bound": "hbm", "kernel": "H/g/cost evaluation: balm_voxel_kernel + balm_factor_kernel + balm_pair_kernel",
+        roof = {"bound": "hbm", "kernel": "H/g/cost evaluation: balm_voxel_kernel + balm_factor_kernel + balm_pair_staged_kernel",
                 "achieved": bytes_eval / ev_ms / 1e6 if ev_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (bytes_eval / ev_ms / 1e6) / HBM_PEAK_GBS if ev_ms > 0 else None,
                 "traffic": read_traffic("eval"), "algorithmic_bytes": bytes_eval, "avg_ms": ev_ms}
