@@ -58,9 +58,13 @@ __device__ __forceinline__ void merge_big_voxel(const BalmDev &d, const double *
             double c[10], x[12], t[10];
 #pragma unroll
             for (int e = 0; e < 10; ++e) c[e] = d.clu[(int64_t)e * d.F + f];
-            const double *xp = poses + 12 * (int64_t)d.pidx[f];
+            // the pose is a gather (one 96-byte record per lane): six 16-byte loads, not twelve 8-byte ones
+            const double2 *xp = reinterpret_cast<const double2 *>(poses + 12 * (int64_t)d.pidx[f]);
 #pragma unroll
-            for (int e = 0; e < 12; ++e) x[e] = xp[e];
+            for (int e = 0; e < 6; ++e) {
+                const double2 v2 = xp[e];
+                x[2 * e] = v2.x; x[2 * e + 1] = v2.y;
+            }
             transform_cluster(c, x, x + 9, t);
 #pragma unroll
             for (int e = 0; e < 10; ++e) p[e] += t[e];
@@ -106,9 +110,13 @@ __global__ __launch_bounds__(LVBA_CF) void balm_cost_kernel(BalmDev d, const dou
         double c[10], x[12], t[10];
 #pragma unroll
         for (int e = 0; e < 10; ++e) c[e] = d.clu[(int64_t)e * d.F + f];
-        const double *xp = poses + 12 * (int64_t)d.pidx[f];
+        // the pose is a gather (one 96-byte record per lane): six 16-byte loads, not twelve 8-byte ones
+        const double2 *xp = reinterpret_cast<const double2 *>(poses + 12 * (int64_t)d.pidx[f]);
 #pragma unroll
-        for (int e = 0; e < 12; ++e) x[e] = xp[e];
+        for (int e = 0; e < 6; ++e) {
+            const double2 v2 = xp[e];
+            x[2 * e] = v2.x; x[2 * e + 1] = v2.y;
+        }
         transform_cluster(c, x, x + 9, t);
 #pragma unroll
         for (int e = 0; e < 10; ++e) T[e * LVBA_CF + tid] = t[e];
@@ -181,9 +189,13 @@ __global__ __launch_bounds__(LVBA_CF) void balm_voxel_kernel(BalmDev d, const do
         double c[10], x[12], t[10];
 #pragma unroll
         for (int e = 0; e < 10; ++e) c[e] = d.clu[(int64_t)e * d.F + f];
-        const double *xp = poses + 12 * (int64_t)d.pidx[f];
+        // the pose is a gather (one 96-byte record per lane): six 16-byte loads, not twelve 8-byte ones
+        const double2 *xp = reinterpret_cast<const double2 *>(poses + 12 * (int64_t)d.pidx[f]);
 #pragma unroll
-        for (int e = 0; e < 12; ++e) x[e] = xp[e];
+        for (int e = 0; e < 6; ++e) {
+            const double2 v2 = xp[e];
+            x[2 * e] = v2.x; x[2 * e + 1] = v2.y;
+        }
         transform_cluster(c, x, x + 9, t);
 #pragma unroll
         for (int e = 0; e < 10; ++e) T[e * LVBA_CF + tid] = t[e];
