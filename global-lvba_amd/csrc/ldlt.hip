@@ -407,14 +407,68 @@ __device__ __forceinline__ void update_tile(double *lds, LdltMat M, int64_t k, i
             if (r < rend && c < rend && r >= c) M.a[r + c * M.ld] = cv[4 * t + reg] - acc[t][reg];
         }
 }
-// mode 0: every lower tile (ti >= tj) of the window; mode 1: only the first tile column (tj = 0)
+// A quarter of update_tile: the 16 columns [16 qc, 16 qc + 16) of tile (ti, tj), one 16 x 16 output per wavefront.  Used for
+// the first tile column, which is a latency chain on ~40 workgroups with the rest of the chip idle: four workgroups per
+// tile cut the MFMA part of the chain from 64 to 16 instructions per wavefront.
+__device__ __forceinline__ void update_tile_quarter(double *lds, LdltMat M, int64_t k, int nbe, int64_t w0, int64_t rend,
+                                                    const double *__restrict__ Zws, int64_t ldz, int64_t ti, int64_t tj, int qc)
+{
+    double *Ls = lds;                // [m][row of tile ti]
+    double *Zs = lds + 64 * LVBA_TS; // [m][16 columns of tile tj]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t r0 = w0 + 64 * ti, c0 = w0 + 64 * tj + 16 * qc;
+    const int row = tid & 63;
+    const int i = lane & 15, kk = lane >> 4;
+    double lv[16], zv[4];
+    {
+        const int64_t r = r0 + row;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int m = w + 4 * it;
+            lv[it] = (r < rend && m < nbe) ? M.a[r + (k + m) * M.ld] : 0.0;
+        }
+        const int64_t c = c0 + (tid & 15);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int m = (tid >> 4) + 16 * it;
+            zv[it] = (c < rend && m < nbe) ? Zws[(c - w0) + m * ldz] : 0.0;
+        }
+    }
+    double cv[4]; // c = c0 + kk + 4 reg, r = r0 + 16 w + i
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int64_t c = c0 + kk + 4 * reg, r = r0 + 16 * w + i;
+        cv[reg] = (r < rend && c < rend && r >= c) ? M.a[r + c * M.ld] : 0.0;
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) Ls[(w + 4 * it) * LVBA_TS + row] = lv[it];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) Zs[((tid >> 4) + 16 * it) * LVBA_TS + (tid & 15)] = zv[it];
+    __syncthreads();
+    d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int k0 = 0; k0 < 64; k0 += 4) {
+        const double a = Zs[(k0 + kk) * LVBA_TS + i];
+        const double bv = Ls[(k0 + kk) * LVBA_TS + 16 * w + i];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int64_t c = c0 + kk + 4 * reg, r = r0 + 16 * w + i;
+        if (r < rend && c < rend && r >= c) M.a[r + c * M.ld] = cv[reg] - acc[reg];
+    }
+}
+// mode 0: every lower tile (ti >= tj) of the window; mode 1: only the first tile column (tj = 0), four workgroups per tile
 __global__ __launch_bounds__(256) void ldlt_update_kernel(LdltMat M, int64_t k, int nbe, int64_t w0, int64_t rend,
                                                           const double *__restrict__ Zws, int64_t ldz, int mode)
 {
     __shared__ double lds[LVBA_K3_LDS];
     int64_t ti, tj;
-    if (mode == 1) { ti = blockIdx.x; tj = 0; }
-    else tri_decode(blockIdx.x, ti, tj);
+    if (mode == 1) {
+        update_tile_quarter(lds, M, k, nbe, w0, rend, Zws, ldz, blockIdx.x >> 2, 0, blockIdx.x & 3);
+        return;
+    }
+    tri_decode(blockIdx.x, ti, tj);
     update_tile(lds, M, k, nbe, w0, rend, Zws, ldz, ti, tj);
 }
 
@@ -686,7 +740,7 @@ void ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_pos
     } else {
         Geo q = geom(0);
         factor_panel(0, q);
-        if (q.T > 0) hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)q.T), dim3(256), 0, s, A, q.k, q.nbe, q.w0, q.rend, Zbuf[0], ldz, 1);
+        if (q.T > 0) hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)(4 * q.T)), dim3(256), 0, s, A, q.k, q.nbe, q.w0, q.rend, Zbuf[0], ldz, 1);
         for (int64_t st = 0; st + 1 < nsteps; ++st) {
             const Geo q2 = geom(st + 1);
             const int64_t nb3 = q.T > 1 ? (q.T - 1) * q.T / 2 : 0; // bulk tiles of panel st
@@ -694,7 +748,7 @@ void ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_pos
                 hipLaunchKernelGGL(ldlt_step_kernel, dim3((unsigned)(q2.T + nb3)), dim3(256), 0, s, A, q2.k, q2.nbe, q2.w0, q2.rend, (int)q2.T,
                                    Gall + (st + 1) * 4096, dvec, Zbuf[(st + 1) & 1], b, status, q.k, q.nbe, q.w0, q.rend,
                                    (const double *)Zbuf[st & 1], ldz);
-                hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)q2.T), dim3(256), 0, s, A, q2.k, q2.nbe, q2.w0, q2.rend, Zbuf[(st + 1) & 1], ldz, 1);
+                hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)(4 * q2.T)), dim3(256), 0, s, A, q2.k, q2.nbe, q2.w0, q2.rend, Zbuf[(st + 1) & 1], ldz, 1);
             } else { // the last panel has no rows below it: nothing to overlap with
                 if (nb3 > 0)
                     hipLaunchKernelGGL(ldlt_step_kernel, dim3((unsigned)nb3), dim3(256), 0, s, A, q2.k, q2.nbe, q2.w0, q2.rend, 0,
