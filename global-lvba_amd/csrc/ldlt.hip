@@ -22,6 +22,7 @@
 // B[k=l>>4][j=l&15]; result register r of lane l is D[(l>>4)+4r][l&15].  Products are arranged so that
 // l&15 indexes ROWS of the column-major target, i.e. 16 lanes touch 128 contiguous bytes.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <math.h>
 #include <utility>
 #include <stdlib.h>
@@ -575,11 +576,11 @@ __global__ __launch_bounds__(256) void ldlt_back_kernel(LdltMat M, int64_t k, in
 //   x_j   = G D (G^T b_j - acc_j)
 // The x vector is the only inter-workgroup channel: it is pre-filled with a NaN sentinel (ldlt_prepare_kernel), written
 // with agent-scope atomic stores and polled with agent-scope atomic loads, 8 bytes carrying data and flag at once -- no
-// fences, no L2 write-back.  A workgroup waits only for workgroups with a smaller blockIdx (dispatched earlier), so the
-// kernel cannot deadlock whatever the residency.  Critical path per panel: poll round trip + one 64x64 tile-vector
+// fences, no L2 write-back.  A workgroup waits only for workgroups with a smaller blockIdx (dispatched earlier) or of an
+// earlier launch, and a launch holds at most 256 workgroups (one per CU), so the chain cannot starve.  Critical path per panel: poll round trip + one 64x64 tile-vector
 // product + two 64x64 mat-vecs out of LDS, ~3 us, against ~9 us for a kernel boundary per panel.
 #define LVBA_X_SENTINEL 0x7ff4dead5eed0001ULL
-__global__ __launch_bounds__(256) void ldlt_back_chain_kernel(LdltMat M, int P, const double *__restrict__ Gall,
+__global__ __launch_bounds__(256) void ldlt_back_chain_kernel(LdltMat M, int j_top, const double *__restrict__ Gall,
                                                               const double *__restrict__ dvec, const double *__restrict__ b,
                                                               double *__restrict__ x)
 {
@@ -587,7 +588,7 @@ __global__ __launch_bounds__(256) void ldlt_back_chain_kernel(LdltMat M, int P, 
     __shared__ double Gs[64 * LS]; // [c][m] = G[m][c]
     __shared__ double bs[64], sd[64], red[4 * 64];
     const int tid = threadIdx.x, c = tid & 63, q = tid >> 6;
-    const int j = P - 1 - (int)blockIdx.x;
+    const int j = j_top - (int)blockIdx.x; // this launch covers the panels j_top, j_top - 1, ...
     const int64_t n = M.n, k = (int64_t)j * 64;
     const int nbe = (int)((n - k) < 64 ? (n - k) : 64);
     const double *G = Gall + (int64_t)j * 4096;
@@ -763,7 +764,12 @@ void ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_pos
     // the former one-launch-per-panel form for A/B (1.7 ms of a C3 solve, ~9 us per kernel boundary).
     static const bool back_panel = [] { const char *e = getenv("LVBA_BACK"); return e && !strcmp(e, "panel"); }();
     if (!back_panel) {
-        hipLaunchKernelGGL(ldlt_back_chain_kernel, dim3((unsigned)nsteps), dim3(256), 0, s, A, (int)nsteps, Gall, dvec, b, x);
+        // at most 256 panels per launch: one workgroup per CU is then resident whatever else shares the device, so the
+        // chain cannot starve even if workgroups were not dispatched in index order; later launches only read finished x
+        for (int64_t top = nsteps - 1; top >= 0; top -= 256) {
+            const int64_t cnt = std::min<int64_t>(256, top + 1);
+            hipLaunchKernelGGL(ldlt_back_chain_kernel, dim3((unsigned)cnt), dim3(256), 0, s, A, (int)top, Gall, dvec, b, x);
+        }
         return;
     }
     for (int64_t st = nsteps - 1; st >= 0; --st) {
