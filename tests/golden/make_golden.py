@@ -125,8 +125,28 @@ def main_ref():
           int(np.any(planes != 0, axis=1).sum()), "queries on planes")
 
 
+def main_fusion():
+    """LiDAR-assisted landmark initialisation: scans + camera rig + tracks and what oracle/fusion_oracle.py answers (frozen)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_fusion as T
+    from oracle import fusion_oracle as fo
+    clouds, poses, times, img_t, Rcw, tcw = T._scene(n_frames=4, pts=14000, n_cams=6)
+    rng = np.random.default_rng(12)
+    off, img, uv, X = T._tracks(clouds, poses, Rcw, tcw, rng, n_tracks=90)
+    depth = fo.render_depth(clouds, poses, times, img_t, Rcw, tcw, T.INTR, T.W, T.H, half_w=100.0)
+    depth_win = fo.render_depth(clouds, poses, times, img_t, Rcw, tcw, T.INTR, T.W, T.H)       # the reference's +-0.5 s windows
+    st, Xf, err, kept = fo.fuse_tracks(off, img, uv, depth, Rcw, tcw, T.INTR)
+    np.savez_compressed(os.path.join(HERE, "fusion_small.npz"), points=np.concatenate(clouds).astype(np.float32)[:, :3],
+                        counts=np.array([len(c) for c in clouds], np.int64), scan_poses=poses, scan_times=times, image_times=img_t,
+                        Rcw=Rcw, tcw=tcw, intr=T.INTR, width=T.W, height=T.H, obs_off=off, obs_img=img, obs_uv=uv,
+                        depth_filled=(depth > 0).sum(axis=(1, 2)), depth_sum=depth.astype(np.float64).sum(axis=(1, 2)),
+                        depth_win_filled=(depth_win > 0).sum(axis=(1, 2)), status=st, X=Xf, mean_reproj=err, kept=kept)
+    print("fusion_small", np.bincount(st, minlength=3).tolist(), "dropped / triangulated / depth-fused")
+
+
 if __name__ == "__main__":
     main()
     main_visual()
     main_voxel()
     main_ref()
+    main_fusion()
