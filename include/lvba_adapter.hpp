@@ -208,4 +208,55 @@ lvba_lidar_ba_report lidar_ba(const CloudPtrVec &clouds, PoseVec &x_buf, const l
     return rep;
 }
 
+// Drop-in for the per-component body of LvbaSystem::BuildTracksAndFuse3D (src/lvba_system.cpp:1000-1225).  The caller keeps
+// its BFS over the match graph (:936-998) but, instead of processing every component in the loop, collects the components
+// that pass the two size checks and hands them over in one call:
+//       std::vector<std::vector<std::pair<int,int>>> comps;           // (image, keypoint) in BFS order
+//       ... BFS ...  comps.push_back(component);
+//       lvba::fuse_components<Track>(comps, all_keypoints_, Rcw_all_optimized_, tcw_all_optimized_, intr, depth /*or nullptr*/,
+//                                    opts, tracks_, comp_track);       // comp_track[c] = index into tracks_ or -1
+// Track needs the reference's members Xw_fused, observations, inlier_indices (include/utils.hpp:150-156); keypoints .x / .y.
+template <class Track, class Component, class KeypointTable, class RotVec, class TransVec>
+void fuse_components(const std::vector<Component> &comps, const KeypointTable &all_keypoints, const RotVec &Rcw_all,
+                     const TransVec &tcw_all, const double intr[8], lvba_depth_t depth, const lvba_fuse_opts *opts,
+                     std::vector<Track> &tracks, std::vector<int> &comp_track, int device = 0)
+{
+    const int32_t n_img = static_cast<int32_t>(Rcw_all.size());
+    std::vector<double> R(9 * static_cast<size_t>(n_img)), t(3 * static_cast<size_t>(n_img));
+    for (int32_t m = 0; m < n_img; ++m) {
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) R[9 * m + 3 * r + c] = Rcw_all[m](r, c);
+            t[3 * m + r] = tcw_all[m][r];
+        }
+    }
+    std::vector<int64_t> off(comps.size() + 1, 0);
+    for (size_t c = 0; c < comps.size(); ++c) off[c + 1] = off[c] + static_cast<int64_t>(comps[c].size());
+    std::vector<int32_t> img(static_cast<size_t>(off.back()));
+    std::vector<float> uv(2 * static_cast<size_t>(off.back()));
+    for (size_t c = 0; c < comps.size(); ++c)
+        for (size_t i = 0; i < comps[c].size(); ++i) {
+            const size_t o = static_cast<size_t>(off[c]) + i;
+            const int im = comps[c][i].first, kp = comps[c][i].second;
+            img[o] = im;
+            uv[2 * o] = all_keypoints[im][kp].x;
+            uv[2 * o + 1] = all_keypoints[im][kp].y;
+        }
+    std::vector<uint8_t> status(comps.size() + 1), kept(img.size() + 1);
+    std::vector<double> X(3 * (comps.size() + 1)), err(comps.size() + 1);
+    if (lvba_fuse_tracks(device, depth, n_img, R.data(), t.data(), intr, static_cast<int64_t>(comps.size()), off.data(), img.data(),
+                         uv.data(), opts, status.data(), X.data(), err.data(), kept.data()) != LVBA_OK)
+        throw std::runtime_error(std::string("lvba_fuse_tracks: ") + lvba_last_error());
+    comp_track.assign(comps.size(), -1);
+    for (size_t c = 0; c < comps.size(); ++c) {
+        if (!status[c]) continue;
+        Track tr;
+        tr.Xw_fused[0] = X[3 * c]; tr.Xw_fused[1] = X[3 * c + 1]; tr.Xw_fused[2] = X[3 * c + 2];
+        tr.observations.assign(comps[c].begin(), comps[c].end());
+        for (size_t i = 0; i < comps[c].size(); ++i)
+            if (kept[static_cast<size_t>(off[c]) + i]) tr.inlier_indices.push_back(static_cast<int>(i));
+        comp_track[c] = static_cast<int>(tracks.size());
+        tracks.push_back(std::move(tr));
+    }
+}
+
 } // namespace lvba

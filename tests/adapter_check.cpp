@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <utility>
 #include <vector>
 #include "../include/lvba_adapter.hpp"
 
@@ -75,6 +76,33 @@ int main()
     } catch (const std::exception &e) {
         std::printf("refused: %s\n", e.what());
         if (!(lvba_device_count() == 0 && std::strstr(e.what(), "no CPU fallback"))) return 7;
+    }
+    try { // track fusion through the adapter: one landmark seen by five cameras on a line (triangulation candidate)
+        struct Vec3 { double v[3]; double &operator[](int i) { return v[i]; } double operator[](int i) const { return v[i]; } };
+        struct Kp { float x, y; };
+        struct Track { Vec3 Xw_fused{}; std::vector<std::pair<int, int>> observations; std::vector<int> inlier_indices; };
+        const double intr[8] = {120, 120, 80, 60, 0, 0, 0, 0};
+        const double Xw[3] = {0.3, -0.2, 6.0};
+        std::vector<Mat3> Rcw(5); std::vector<Vec3> tcw(5);
+        std::vector<std::vector<Kp>> kps(5);
+        std::vector<std::pair<int, int>> comp;
+        for (int m = 0; m < 5; ++m) {
+            std::memset(&Rcw[m], 0, sizeof(Mat3)); Rcw[m](0, 0) = Rcw[m](1, 1) = Rcw[m](2, 2) = 1;
+            tcw[m] = Vec3{{-0.5 * m, 0.0, 0.0}};                                 // camera centre at x = 0.5 m
+            const double xc = Xw[0] + tcw[m][0], yc = Xw[1], zc = Xw[2];
+            kps[m].push_back(Kp{(float)(intr[0] * xc / zc + intr[2]), (float)(intr[1] * yc / zc + intr[3])});
+            comp.push_back({m, 0});
+        }
+        std::vector<std::vector<std::pair<int, int>>> comps{comp, {{0, 0}, {1, 0}}};  // the second one is too short
+        std::vector<Track> tracks; std::vector<int> comp_track;
+        lvba::fuse_components<Track>(comps, kps, Rcw, tcw, intr, nullptr, nullptr, tracks, comp_track);
+        std::printf("fuse_components on the GPU: %zu track(s)\n", tracks.size());
+        if (tracks.size() != 1 || comp_track[0] != 0 || comp_track[1] != -1 || tracks[0].observations.size() != 5 ||
+            tracks[0].inlier_indices.size() < 4 || std::fabs(tracks[0].Xw_fused[2] - 6.0) > 1e-3)
+            return 8;
+    } catch (const std::exception &e) {
+        std::printf("refused: %s\n", e.what());
+        if (!(lvba_device_count() == 0 && std::strstr(e.what(), "no CPU fallback"))) return 9;
     }
     try {
         auto trace = lvba::damping_iter_hip(x, vh);
