@@ -92,7 +92,7 @@ class VoxmapInfo(C.Structure):
 
 class WindowOpts(C.Structure):
     _fields_ = [("window_size", C.c_int32), ("use_rel", C.c_int32), ("anchor_leaf", C.c_double), ("voxel", VoxelOpts),
-                ("lm", BalmOpts)]
+                ("lm", BalmOpts), ("merge_only", C.c_int32), ("reserved", C.c_int32)]
 
 
 class WindowInfo(C.Structure):

@@ -116,6 +116,8 @@ extern "C" void lvba_window_default_opts(lvba_window_opts *o)
     if (!o) return;
     o->window_size = 10;     // include/dataset_io.h:71
     o->use_rel = 1;          // config.yaml window_ba.use_window_ba_rel
+    o->merge_only = 0;
+    o->reserved = 0;
     o->anchor_leaf = 0.1;    // include/dataset_io.h:72
     lvba_voxel_default_opts(&o->voxel);
     o->voxel.voxel_size = 0.5; // stage1_root_voxel_size_, include/dataset_io.h:76
@@ -182,8 +184,11 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
         info = lvba_window_info{};
         info.start = start; info.n_frames = cw; info.anchor = -1;
         const double *x_odom = poses + 12 * (int64_t)start;
-        lvba_voxmap_t map = nullptr;
+        std::vector<double> &x = R.x;
+        x.assign(x_odom, x_odom + 12 * (size_t)cw);
         double tw = now_ms();
+        if (!o.merge_only) {
+        lvba_voxmap_t map = nullptr;
         int32_t rc = lvba_voxmap_build_scans(sc, start, cw, x_odom, &o.voxel, &map);
         if (rc != LVBA_OK) return rc;
         lvba_voxmap_info_t mi;
@@ -195,8 +200,6 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
             lvba_voxmap_destroy(map);
             return LVBA_OK;
         }
-        std::vector<double> &x = R.x;
-        x.assign(x_odom, x_odom + 12 * (size_t)cw);
         {
             lvba_balm_t b = nullptr;
             rc = lvba_voxmap_to_balm(map, &b);
@@ -216,6 +219,7 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
                 info.cost_last = trace[nt - 1].accepted ? trace[nt - 1].residual2 : trace[nt - 1].residual1;
             }
         }
+        } // !merge_only
         info.solve_ms = now_ms() - tw; tw = now_ms();
         // alignment (:268-279) and relative poses (:284-299)
         std::vector<double> &rel = R.rel;

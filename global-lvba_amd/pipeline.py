@@ -1,0 +1,190 @@
+"""Host-side mirror of the reference's top-level flow over the C-ABI: everything between "a dataset in memory" and "refined
+LiDAR poses, camera poses and landmarks", with every compute step in liblvba_hip.so on the GPU.
+
+    LvbaSystem::runFullPipeline               src/lvba_system.cpp:136-142   initFromDatasetIO -> runLidarBA -> visual stage
+    LvbaSystem::runVisualBAWithLidarAssist    src/lvba_system.cpp:144-154   grid map, camera poses from the refined LiDAR
+                                                                            poses, depth images, (features), tracks + fusion,
+                                                                            optimizeCameraPoses
+    LvbaSystem::updateCameraPosesFromLidar    src/lvba_system.cpp:412-446   T_cam_new = (T_opt T_orig^-1) cam_orig of the
+                                                                            nearest scan in time
+    camera extrinsics                         src/lvba_system.cpp:860-869   Rcw = Rci Rwi^T, tcw = -Rcw Pwi + tci
+    anchor clouds + plane map of the visual stage  src/lvba_system.cpp:1453-1507
+
+Out of scope, as in DESIGN.md: SIFT extraction / matching (SiftGPU, `extractAndMatchFeaturesGPU`) -- keypoints and inlier
+matches are inputs here, e.g. from a COLMAP database through dataset.load_colmap_db, which is the reference's own alternative
+(`loadFromColmapDB`); ROS publishing and the OpenCV visualisations.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import visual as V
+from .voxel import Scans
+
+DEFAULTS = dict(                                   # config/config.yaml of the reference
+    window_enable=True, window_size=20, anchor_leaf=0.01, use_rel=True,
+    stage1_enable=True, stage_voxel_size=(1.0, 0.5), stage_eigen_ratio=((0.2,) * 4, (0.08,) * 4),
+    obser_thr=3, min_view_angle_deg=8.0, reproj_mean_thr_px=3.0, depth_half_window_s=0.5, depth_voxel=0.5,
+    sigma_px=0.5, sigma_plane=0.01)
+
+
+def _mat(T):
+    T = np.asarray(T, np.float64).reshape(-1, 12)
+    return T[:, :9].reshape(-1, 3, 3), T[:, 9:]
+
+
+def update_camera_poses_from_lidar(x_opt, x_orig, scan_times, image_times, cam_orig):
+    """src/lvba_system.cpp:412-446.  Poses are [n,12] (R row-major, p), T_world<-imu.  For every image the scan nearest in
+    time (std::lower_bound, the previous one if it is strictly closer) gives T_delta = T_opt T_orig^-1; the image pose
+    becomes T_delta o cam_orig."""
+    Ro, po = _mat(x_opt)
+    Rb, pb = _mat(x_orig)
+    Rc, pc = _mat(cam_orig)
+    ts = np.asarray(scan_times, np.float64)
+    out = np.zeros((len(Rc), 12))
+    for i, t in enumerate(np.asarray(image_times, np.float64)):
+        it = int(np.searchsorted(ts, t, side="left"))
+        idx = len(ts) - 1 if it == len(ts) else it
+        if 0 < it < len(ts) and abs(ts[idx - 1] - t) < abs(ts[idx] - t):
+            idx -= 1
+        if idx >= len(Ro) or idx >= len(Rb):
+            out[i, :9], out[i, 9:] = Rc[i].reshape(-1), pc[i]
+            continue
+        Rd = Ro[idx] @ Rb[idx].T                                            # T_opt * T_orig.inverse()
+        pd = po[idx] - Rd @ pb[idx]
+        out[i, :9] = (Rd @ Rc[i]).reshape(-1)
+        out[i, 9:] = Rd @ pc[i] + pd
+    return out
+
+
+def camera_from_imu(T_wi, Rci, tci):
+    """Rcw = Rci Rwi^T, tcw = -Rcw Pwi + tci (src/lvba_system.cpp:860-861)."""
+    R, p = _mat(T_wi)
+    Rci, tci = np.asarray(Rci, np.float64).reshape(3, 3), np.asarray(tci, np.float64).reshape(3)
+    Rcw = np.einsum("ij,nkj->nik", Rci, R)
+    tcw = -np.einsum("nij,nj->ni", Rcw, p) + tci
+    return Rcw, tcw
+
+
+def rot_to_quat_wxyz(R):
+    """Eigen::Quaterniond(R).normalize() as [w, x, y, z] (src/lvba_system.cpp:1514-1517)."""
+    from .dataset import rot_to_quat
+    return np.array([rot_to_quat(r) for r in np.asarray(R).reshape(-1, 3, 3)])
+
+
+def quat_wxyz_to_rot(q):
+    from .dataset import quat_to_rot
+    return np.array([quat_to_rot(*qq) for qq in np.asarray(q).reshape(-1, 4)])
+
+
+def build_components(n_keypoints, pairs, matches, obser_thr=3):
+    """The BFS of BuildTracksAndFuse3D (src/lvba_system.cpp:923-1003) WITHOUT the per-image de-duplication: every component
+    that passes the two size checks, observations in BFS order.  Returns (obs_off, obs_img, obs_kp)."""
+    from collections import deque
+    N = len(n_keypoints)
+    adj = [dict() for _ in range(N)]
+    for (i, j), m in zip(pairs, matches):
+        m = np.asarray(m, np.int64).reshape(-1, 2)
+        if i > j:
+            i, j, m = j, i, m[:, ::-1]
+        for ki, kj in m:
+            if ki < 0 or kj < 0 or ki >= n_keypoints[i] or kj >= n_keypoints[j]:
+                continue
+            adj[i].setdefault(int(ki), []).append((j, int(kj)))
+            adj[j].setdefault(int(kj), []).append((i, int(ki)))
+    seen = [set() for _ in range(N)]
+    off, img, kp = [0], [], []
+    for i in range(N):
+        for ki in sorted(adj[i]):
+            if ki in seen[i]:
+                continue
+            comp, q = [], deque([(i, ki)])
+            seen[i].add(ki)
+            while q:
+                ci, ck = q.popleft()
+                comp.append((ci, ck))
+                for ni, nk in adj[ci].get(ck, ()):
+                    if nk not in seen[ni]:
+                        seen[ni].add(nk)
+                        q.append((ni, nk))
+            if len(comp) < obser_thr or len({c for c, _ in comp}) < obser_thr:
+                for ci, ck in comp:
+                    seen[ci].discard(ck)
+                continue
+            for ci, ck in comp:
+                img.append(ci); kp.append(ck)
+            off.append(len(img))
+    return np.asarray(off, np.int64), np.asarray(img, np.int32), np.asarray(kp, np.int32)
+
+
+def run_visual_ba_with_lidar_assist(scans, x_opt, x_orig, scan_times, image_times, image_poses, Rci, tci, intr, width, height,
+                                    keypoints, pairs, matches, **cfg):
+    """LvbaSystem::runVisualBAWithLidarAssist (src/lvba_system.cpp:144-154) from the refined LiDAR poses to the refined
+    cameras.  scans: a voxel.Scans holding the raw clouds; keypoints[i] = [n_i, 2] float pixel coordinates; pairs / matches as
+    build_tracks takes them.  Returns a dict (cameras before / after, tracks, landmarks, planes, traces)."""
+    c = dict(DEFAULTS); c.update(cfg)
+    cam_new = update_camera_poses_from_lidar(x_opt, x_orig, scan_times, image_times, image_poses)      # poses_
+    Rcw, tcw = camera_from_imu(cam_new, Rci, tci)                                                      # Rcw_all_optimized_
+    Rcw0, tcw0 = camera_from_imu(image_poses, Rci, tci)                                                # Rcw_all_ (before)
+    # generateDepthWithVoxel (+ buildGridMapFromOptimized)
+    depth = V.DepthImages.render(scans, x_opt, scan_times, image_times, Rcw, tcw, intr, width, height,
+                                 half_window_s=c["depth_half_window_s"], voxel_size=c["depth_voxel"])
+    try:
+        # BuildTracksAndFuse3D
+        nk = [len(k) for k in keypoints]
+        off, img, kp = build_components(nk, pairs, matches, c["obser_thr"])
+        uv = (np.array([keypoints[i][k][:2] for i, k in zip(img, kp)], np.float32).reshape(-1, 2)
+              if len(img) else np.zeros((0, 2), np.float32))
+        status, X, err, kept = V.fuse_tracks(off, img, uv, Rcw, tcw, intr, depth=depth, obser_thr=c["obser_thr"],
+                                             min_view_angle_deg=c["min_view_angle_deg"], reproj_mean_thr_px=c["reproj_mean_thr_px"])
+    finally:
+        depth.close()
+    tr = np.nonzero(status)[0]                                               # tracks_ (usable: >= obser_thr observations, finite, non-zero)
+    out = dict(cam_poses=cam_new, Rcw_before=Rcw0, tcw_before=tcw0, Rcw_lidar=Rcw, tcw_lidar=tcw, track_status=status,
+               n_components=len(status))
+    if len(tr) == 0:
+        out.update(Rcw=Rcw, tcw=tcw, landmarks=np.zeros((0, 3)), landmark_valid=np.zeros(0, np.uint8), trace=[], termination="NO_TRACKS")
+        return out
+    # anchor clouds from the refined poses and the plane map of the visual stage (:1453-1507)
+    m = scans.window_ba(x_opt, window_size=c["window_size"], anchor_leaf=c["anchor_leaf"], merge_only=True)
+    try:
+        with m["anchor_scans"].voxel_map(m["anchor_poses"], c["stage_voxel_size"][1], np.float32(c["stage_eigen_ratio"][1])) as vmap:
+            plane, pvalid = vmap.find_planes(X[tr])
+    finally:
+        m["anchor_scans"].close()
+    # inlier observations of the usable tracks, one residual per distinct observation (:1612-1634)
+    o_off, o_cam, o_uv = [0], [], []
+    for t in tr:
+        a, b = int(off[t]), int(off[t + 1])
+        sel = np.nonzero(kept[a:b])[0] + a
+        o_cam.extend(img[sel].tolist()); o_uv.extend(uv[sel].astype(np.float64).tolist())
+        o_off.append(len(o_cam))
+    q0 = rot_to_quat_wxyz(Rcw)
+    (q, t, Xn), trace, term, rc, valid = V.optimize_camera_poses(
+        q0, tcw, X[tr], np.asarray(o_off, np.int64), np.asarray(o_cam, np.int32), np.asarray(o_uv, np.float64).reshape(-1, 2),
+        plane[:, :3], plane[:, 3], intr, c["sigma_px"], c["sigma_plane"])
+    out.update(Rcw=quat_wxyz_to_rot(q), tcw=np.asarray(t), q=q, landmarks=np.asarray(Xn), landmarks_before=X[tr],
+               landmark_valid=valid, track_ids=tr, plane=plane, plane_valid=pvalid, obs_off=np.asarray(o_off), obs_cam=np.asarray(o_cam),
+               obs_uv=np.asarray(o_uv).reshape(-1, 2), trace=trace, termination=term, status=rc, mean_reproj=err[tr])
+    return out
+
+
+def run_full_pipeline(clouds, poses, scan_times, image_times, image_poses, Rci, tci, intr, width, height, keypoints, pairs,
+                      matches, enable_lidar_ba=True, enable_visual_ba=True, device=0, **cfg):
+    """LvbaSystem::runFullPipeline (src/lvba_system.cpp:136-142) on in-memory data: clouds = body-frame [n_i, >=3] float32
+    arrays, poses [n,12] = x_buf_ (T_world<-imu), image_poses [m,12] the image poses from the odometry."""
+    c = dict(DEFAULTS); c.update(cfg)
+    x_orig = np.asarray(poses, np.float64).reshape(-1, 12).copy()
+    out = dict(poses_before=x_orig)
+    with Scans(clouds, device=device) as scans:
+        x_opt = x_orig
+        if enable_lidar_ba:
+            x_opt, report = scans.lidar_ba(x_orig, window_enable=c["window_enable"], window_size=c["window_size"],
+                                           anchor_leaf=c["anchor_leaf"], use_rel=c["use_rel"], stage1_enable=c["stage1_enable"],
+                                           stage_voxel_size=c["stage_voxel_size"], stage_eigen_ratio=c["stage_eigen_ratio"])
+            out["lidar_report"] = report
+        out["poses"] = np.asarray(x_opt).reshape(-1, 12)
+        if enable_visual_ba:
+            out["visual"] = run_visual_ba_with_lidar_assist(scans, out["poses"], x_orig, scan_times, image_times, image_poses, Rci,
+                                                            tci, intr, width, height, keypoints, pairs, matches, **c)
+    return out

@@ -366,6 +366,9 @@ typedef struct {
     double anchor_leaf;     /* anchor_leaf_size_ (0.1; config.yaml 0.01); < 0.001 disables the down-sampling */
     lvba_voxel_opts voxel;  /* stage1_root_voxel_size_ and the eigen_ratio_array in effect (bavoxel.hpp:17 until a stage sets it) */
     lvba_balm_opts lm;
+    int32_t merge_only;     /* 1: no map, no LM, no skip rule -- every window is merged at the given poses (rel = anchor^-1 o pose) and
+                               down-sampled: the anchor clouds optimizeCameraPoses rebuilds from the refined poses (:1464-1487) */
+    int32_t reserved;
 } lvba_window_opts;
 typedef struct {
     int32_t start, n_frames, skipped, anchor; /* anchor = index into anchor_poses / anchor_scans, -1 if skipped */

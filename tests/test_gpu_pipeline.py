@@ -1,0 +1,121 @@
+"""End-to-end GPU test of the host-side pipeline mirror (global-lvba_amd/pipeline.py = LvbaSystem::runFullPipeline,
+src/lvba_system.cpp:136-154) on a synthetic dataset in memory: noisy odometry + raw scans + keypoints / matches in, refined
+LiDAR poses, cameras and landmarks out -- every compute step through the C-ABI on the GPU."""
+import importlib
+
+import numpy as np
+import pytest
+
+from oracle import track_oracle as to
+
+pytestmark = pytest.mark.gpu
+
+RCB = np.array([[1.0, 0.0, 0.0], [0.0, 0.0, -1.0], [0.0, 1.0, 0.0]])      # camera z = body y: looking sideways, so that
+# the motion along the trajectory gives the tracks parallax (the view-angle filter wants >= 8 degrees between kept rays)
+TCI = np.array([0.02, 0.05, -0.03])
+INTR = np.array([300.0, 298.0, 240.0, 180.0, -0.076160, 0.123001, -0.00113, 0.000251])   # the reference camera's distortion (a
+# negative k2 would fold rays far outside the field of view back into the image and pollute the z-buffer)
+W, H = 480, 360
+
+
+def _dataset(n_frames=24, pts=80000, n_land=900, seed=61):
+    synth = importlib.import_module("global-lvba_amd.synth")
+    pipe = importlib.import_module("global-lvba_amd.pipeline")
+    s = synth.make_scans(n_frames, pts, room=(14, 10, 4), n_panels=0, n_blobs=0, clutter_frac=0.0, seed=seed, rot_sigma_deg=0.15,
+                         trans_sigma=0.04)
+    gt = np.asarray(s["poses_gt"], np.float64).reshape(-1, 12)
+    odo = np.asarray(s["poses"], np.float64).reshape(-1, 12)
+    times = 50.0 + 0.1 * np.arange(n_frames)
+    img_t = times + 0.004
+    rng = np.random.default_rng(seed)
+    world = np.concatenate([c[:, :3].astype(np.float64) @ T[:9].reshape(3, 3).T + T[9:] for c, T in zip(s["clouds"], gt)])
+    X = world[rng.choice(len(world), n_land, replace=False)]
+    Rcw_gt, tcw_gt = pipe.camera_from_imu(gt, RCB, TCI)
+    kps, lm_of = [], []
+    for m in range(n_frames):
+        k, ids = [], []
+        for li, x in enumerate(X):
+            p = to.project(INTR, Rcw_gt[m], tcw_gt[m], x)
+            if p is not None and 3 < p[0] < W - 4 and 3 < p[1] < H - 4 and (Rcw_gt[m] @ x + tcw_gt[m])[2] < 12.0:
+                k.append(np.float32(p) + np.float32(0.4 * rng.standard_normal(2))); ids.append(li)
+        kps.append(np.array(k, np.float32).reshape(-1, 2)); lm_of.append(ids)
+    pairs, matches = [], []
+    for i in range(n_frames):
+        for j in range(i + 1, min(n_frames, i + 7)):
+            pos_j = {li: kj for kj, li in enumerate(lm_of[j])}
+            m = [(ki, pos_j[li]) for ki, li in enumerate(lm_of[i]) if li in pos_j]
+            if m:
+                pairs.append((i, j)); matches.append(np.array(m, np.int64))
+    return dict(clouds=s["clouds"], gt=gt, odo=odo, times=times, img_t=img_t, X=X, kps=kps, lm_of=lm_of, pairs=pairs,
+                matches=matches, Rcw_gt=Rcw_gt, tcw_gt=tcw_gt)
+
+
+def _rel_err(a, b):
+    """Largest error of the positions relative to frame 0 (gauge-free)."""
+    pa = (a[:, 9:] - a[0, 9:]) @ a[0, :9].reshape(3, 3)
+    pb = (b[:, 9:] - b[0, 9:]) @ b[0, :9].reshape(3, 3)
+    return np.abs(pa - pb).max()
+
+
+def test_full_pipeline_on_a_synthetic_dataset(pkg):
+    pipe = importlib.import_module("global-lvba_amd.pipeline")
+    d = _dataset()
+    out = pipe.run_full_pipeline(d["clouds"], d["odo"], d["times"], d["img_t"], d["odo"], RCB, TCI, INTR, W, H, d["kps"],
+                                 d["pairs"], d["matches"], window_size=6, anchor_leaf=0.02, stage_voxel_size=(1.0, 0.5),
+                                 stage_eigen_ratio=((0.2,) * 4, (0.08,) * 4))
+    # LiDAR stage: the refined trajectory is closer to the ground truth than the odometry
+    rep = out["lidar_report"]
+    assert rep["n_windows"] == 4 and rep["n_anchors"] >= 3 and rep["stage_ran"][1] == 1
+    e0, e1 = _rel_err(d["odo"], d["gt"]), _rel_err(out["poses"], d["gt"])
+    assert e1 < 0.5 * e0, (e0, e1)
+    v = out["visual"]
+    # tracks: a good part of the components is fused, by both candidates
+    st = v["track_status"]
+    assert v["n_components"] > 300 and (st > 0).mean() > 0.5 and (st == 1).sum() > 20 and (st == 2).sum() > 20
+    # landmarks land on the scene and most of them find a plane of the refined map
+    assert v["landmark_valid"].mean() > 0.6
+    # every fused landmark is close to some true scene point (the landmark set it was generated from)
+    from scipy.spatial import cKDTree
+    dist, _ = cKDTree(d["X"]).query(v["landmarks"][v["landmark_valid"] > 0])
+    assert np.median(dist) < 0.08
+    # visual stage: the solve converged and reduced its cost; the cameras stay consistent with the refined LiDAR poses
+    tr = v["trace"]
+    assert v["termination"].startswith("CONVERGENCE") and tr[-1]["cost"] < 0.7 * tr[0]["cost"]
+    Rcw_l, tcw_l = v["Rcw_lidar"], v["tcw_lidar"]
+    Cw_l = -np.einsum("nji,nj->ni", Rcw_l, tcw_l)
+    Cw_v = -np.einsum("nji,nj->ni", v["Rcw"], v["tcw"])
+    assert np.abs(Cw_v - Cw_l).max() < 0.1
+    # and both are closer to the true camera centres than the odometry was (relative to camera 0)
+    Cw_gt = -np.einsum("nji,nj->ni", d["Rcw_gt"], d["tcw_gt"])
+    Cw_0 = -np.einsum("nji,nj->ni", v["Rcw_before"], v["tcw_before"])
+    rel = lambda C: C - C[0]
+    assert np.abs(rel(Cw_v) - rel(Cw_gt)).max() < np.abs(rel(Cw_0) - rel(Cw_gt)).max()
+
+
+def test_update_camera_poses_from_lidar_and_components(pkg):
+    pipe = importlib.import_module("global-lvba_amd.pipeline")
+    rng = np.random.default_rng(2)
+    n = 6
+    def rnd():
+        from oracle import balm_oracle as bo
+        return np.concatenate([bo.exp_so3(0.2 * rng.standard_normal(3)).reshape(-1), rng.standard_normal(3)])
+    x_orig = np.array([rnd() for _ in range(n)]); x_opt = np.array([rnd() for _ in range(n)])
+    cams = np.array([rnd() for _ in range(4)])
+    ts = np.arange(n) * 1.0
+    img_t = np.array([-3.0, 1.4, 1.6, 9.0])                                # before the first, nearer 1, nearer 2, after the last
+    got = pipe.update_camera_poses_from_lidar(x_opt, x_orig, ts, img_t, cams)
+    for i, idx in enumerate([0, 1, 2, 5]):
+        Ro, po = x_opt[idx, :9].reshape(3, 3), x_opt[idx, 9:]
+        Rb, pb = x_orig[idx, :9].reshape(3, 3), x_orig[idx, 9:]
+        Rc, pc = cams[i, :9].reshape(3, 3), cams[i, 9:]
+        Rd = Ro @ Rb.T
+        assert np.abs(got[i, :9].reshape(3, 3) - Rd @ Rc).max() < 1e-14
+        assert np.abs(got[i, 9:] - (Rd @ pc + po - Rd @ pb)).max() < 1e-13
+    # identical trajectories leave the cameras untouched
+    same = pipe.update_camera_poses_from_lidar(x_orig, x_orig, ts, img_t, cams)
+    assert np.abs(same - cams).max() < 1e-13
+    # components keep duplicates of an image and drop what is too small
+    off, img, kp = pipe.build_components([3, 3, 3], [(0, 1), (1, 2), (0, 2)],
+                                         [np.array([[0, 0], [1, 1], [2, 0]]), np.array([[0, 0]]), np.array([[1, 2]])])
+    comps = [list(zip(img[a:b].tolist(), kp[a:b].tolist())) for a, b in zip(off[:-1], off[1:])]
+    assert comps == [[(0, 0), (1, 0), (0, 2), (2, 0)], [(0, 1), (1, 1), (2, 2)]]
