@@ -188,3 +188,66 @@ def run_full_pipeline(clouds, poses, scan_times, image_times, image_poses, Rci, 
             out["visual"] = run_visual_ba_with_lidar_assist(scans, out["poses"], x_orig, scan_times, image_times, image_poses, Rci,
                                                             tci, intr, width, height, keypoints, pairs, matches, **c)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The same flow from a dataset directory in the reference's on-disk layout (README.md "Dataset", src/dataset_io.cpp):
+#     <data_path>/all_pcd_body/lidar_poses.txt + <timestamp>.pcd      TUM poses (T_world<-imu) + body-frame scans
+#     <data_path>/all_image/image_poses.txt + <timestamp>.png         TUM poses of the images + the images (only their names are read)
+#     <data_path>/<colmap_db_path>                                    keypoints + inlier matches (loadFromColmapDB)
+# ---------------------------------------------------------------------------------------------------------------------
+def list_image_ids(image_dir, stride=1):
+    """DatasetIO::handleImages (src/dataset_io.cpp:77-131): numeric ids of *.png/.jpg/.jpeg/.bmp, sorted, every stride-th."""
+    import os
+    from .dataset import parse_timestamp_from_name
+    ids = []
+    for name in os.listdir(image_dir):
+        if os.path.splitext(name)[1] not in (".png", ".jpg", ".jpeg", ".bmp"):
+            continue
+        t = parse_timestamp_from_name(name)
+        if t is not None:
+            ids.append(t)
+    ids.sort()
+    return np.asarray(ids[::max(1, int(stride))], np.float64)
+
+
+def extrinsics_from_config(Rcl, Pcl, extrinsic_R, extrinsic_T):
+    """Rci = Rcl Rli, tci = Rcl tli + tcl with (Rli, tli) the inverse of the lidar->imu extrinsic (src/lvba_system.cpp:484-504)."""
+    Rcl, tcl = np.asarray(Rcl, np.float64).reshape(3, 3), np.asarray(Pcl, np.float64).reshape(3)
+    Ril, til = np.asarray(extrinsic_R, np.float64).reshape(3, 3), np.asarray(extrinsic_T, np.float64).reshape(3)
+    Rli = Ril.T
+    tli = -Rli @ til
+    return Rcl @ Rli, Rcl @ tli + tcl
+
+
+def run_dataset(data_path, colmap_db_path, intr, width, height, Rcl, Pcl, extrinsic_R=np.eye(3), extrinsic_T=np.zeros(3),
+                image_sample_step=1, out_dir=None, device=0, **cfg):
+    """initFromDatasetIO + runFullPipeline on a dataset directory; with out_dir, the refined LiDAR poses (TUM) and the COLMAP
+    text files images.txt / points3D.txt the reference writes (src/lvba_system.cpp:2018-2137) are saved there."""
+    import os
+    from . import dataset as D
+    ds = D.load_dataset(data_path)
+    img_dir = os.path.join(data_path, "all_image")
+    image_ids = list_image_ids(img_dir, image_sample_step)
+    _, image_poses = D.load_poses_tum(os.path.join(img_dir, "image_poses.txt"), image_sample_step)
+    if len(image_poses) != len(image_ids):
+        raise ValueError(f"{len(image_ids)} images but {len(image_poses)} image poses")          # :457-460
+    names = [f"{t:.6f}.png" for t in image_ids]                                                   # getImagePath: std::to_string
+    pairs = [(i, j) for i in range(len(image_ids)) for j in range(i + 1, len(image_ids))]        # image_pairs_, :462-466
+    kps, matches = D.load_colmap_db(colmap_db_path if os.path.isabs(colmap_db_path) else os.path.join(data_path, colmap_db_path),
+                                    names, pairs)
+    keep = [k for k, m in enumerate(matches) if len(m)]
+    Rci, tci = extrinsics_from_config(Rcl, Pcl, extrinsic_R, extrinsic_T)
+    out = run_full_pipeline([c[:, :3] for c in ds["clouds"]], ds["poses"], ds["timestamps"], image_ids, image_poses, Rci, tci, intr,
+                            width, height, [k[:, :2] for k in kps], [pairs[k] for k in keep], [matches[k] for k in keep],
+                            device=device, **cfg)
+    out.update(image_ids=image_ids, scan_times=ds["timestamps"])
+    if out_dir is not None:
+        os.makedirs(out_dir, exist_ok=True)
+        D.write_poses_tum(os.path.join(out_dir, "lidar_poses_refined.txt"), ds["timestamps"], out["poses"])
+        v = out.get("visual")
+        if v is not None and len(v.get("landmarks", [])):
+            D.write_images_txt(os.path.join(out_dir, "images.txt"), rot_to_quat_wxyz(v["Rcw"]), v["tcw"])
+            ok = v["landmark_valid"] > 0
+            D.write_points3d_txt(os.path.join(out_dir, "points3D.txt"), v["landmarks"][ok], np.full((int(ok.sum()), 3), 255))
+    return out

@@ -119,3 +119,49 @@ def test_update_camera_poses_from_lidar_and_components(pkg):
                                          [np.array([[0, 0], [1, 1], [2, 0]]), np.array([[0, 0]]), np.array([[1, 2]])])
     comps = [list(zip(img[a:b].tolist(), kp[a:b].tolist())) for a, b in zip(off[:-1], off[1:])]
     assert comps == [[(0, 0), (1, 0), (0, 2), (2, 0)], [(0, 1), (1, 1), (2, 2)]]
+
+
+def test_pipeline_from_a_dataset_directory(pkg, tmp_path):
+    """The same flow through the reference's on-disk formats (src/dataset_io.cpp, loadFromColmapDB): TUM pose files, binary
+    PCDs named by time stamp, image files named by time stamp (only the names are read), a COLMAP database with keypoints and
+    two_view_geometries.  The result must agree with the in-memory run up to the precision of the text pose files."""
+    import sqlite3
+    pipe = importlib.import_module("global-lvba_amd.pipeline")
+    ds = importlib.import_module("global-lvba_amd.dataset")
+    d = _dataset(n_frames=12, pts=40000, n_land=400, seed=62)
+    root = tmp_path / "seq"
+    (root / "all_pcd_body").mkdir(parents=True); (root / "all_image").mkdir()
+    for t, c in zip(d["times"], d["clouds"]):
+        ds.save_pcd(str(root / "all_pcd_body" / f"{t:.6f}.pcd"), np.concatenate([c[:, :3], np.zeros((len(c), 1), np.float32)], 1))
+    ds.write_poses_tum(str(root / "all_pcd_body" / "lidar_poses.txt"), d["times"], d["odo"])
+    for t in d["img_t"]:
+        (root / "all_image" / f"{t:.6f}.png").write_bytes(b"")
+    ds.write_poses_tum(str(root / "all_image" / "image_poses.txt"), d["img_t"], d["odo"])
+    con = sqlite3.connect(str(root / "colmap.db"))
+    con.execute("CREATE TABLE images (image_id INTEGER PRIMARY KEY, name TEXT)")
+    con.execute("CREATE TABLE keypoints (image_id INTEGER PRIMARY KEY, rows INTEGER, cols INTEGER, data BLOB)")
+    con.execute("CREATE TABLE two_view_geometries (pair_id INTEGER PRIMARY KEY, rows INTEGER, cols INTEGER, data BLOB)")
+    for i, t in enumerate(d["img_t"]):
+        kp4 = np.concatenate([d["kps"][i], np.ones((len(d["kps"][i]), 2), np.float32)], 1).astype(np.float32)
+        con.execute("INSERT INTO images VALUES (?, ?)", (i + 1, f"{t:.6f}.png"))
+        con.execute("INSERT INTO keypoints VALUES (?, ?, ?, ?)", (i + 1, kp4.shape[0], 4, kp4.tobytes()))
+    for (i, j), m in zip(d["pairs"], d["matches"]):
+        con.execute("INSERT INTO two_view_geometries VALUES (?, ?, ?, ?)",
+                    (ds.image_ids_to_pair_id(i + 1, j + 1), len(m), 2, np.asarray(m, np.uint32).tobytes()))
+    con.commit(); con.close()
+    cfg = dict(window_size=6, anchor_leaf=0.02, stage_voxel_size=(1.0, 0.5), stage_eigen_ratio=((0.2,) * 4, (0.08,) * 4))
+    # Rcl / Pcl with an identity lidar->imu extrinsic give Rci = RCB, tci = TCI
+    got = pipe.run_dataset(str(root), "colmap.db", INTR, W, H, RCB, TCI, out_dir=str(tmp_path / "out"), **cfg)
+    ref = pipe.run_full_pipeline(d["clouds"], d["odo"], d["times"], d["img_t"], d["odo"], RCB, TCI, INTR, W, H, d["kps"], d["pairs"],
+                                 d["matches"], **cfg)
+    assert np.abs(got["poses"] - ref["poses"]).max() < 1e-5
+    gv, rv = got["visual"], ref["visual"]
+    assert gv["n_components"] == rv["n_components"] and (gv["track_status"] == rv["track_status"]).mean() > 0.97
+    assert np.abs(gv["tcw"] - rv["tcw"]).max() < 1e-3
+    out = tmp_path / "out"
+    assert (out / "lidar_poses_refined.txt").exists() and (out / "images.txt").exists() and (out / "points3D.txt").exists()
+    assert len((out / "images.txt").read_text().splitlines()) == 2 * len(d["img_t"])
+    back_t, back = ds.load_poses_tum(str(out / "lidar_poses_refined.txt"), 1)
+    assert np.abs(back - got["poses"]).max() < 1e-5
+    Rci, tci = pipe.extrinsics_from_config(RCB, TCI, np.eye(3), np.zeros(3))
+    assert np.array_equal(Rci, RCB) and np.array_equal(tci, TCI)
