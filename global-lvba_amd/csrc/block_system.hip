@@ -437,34 +437,24 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
         }
     }
 
-    { // pose-major (CSC) view + per-block group lists for the atomic-free assembly
-        std::vector<int64_t> csc_off((size_t)N + 1, 0);
-        for (int64_t f = 0; f < F; ++f) csc_off[(size_t)bs.iperm[pidx[f]] + 1]++;
-        for (int i = 0; i < N; ++i) csc_off[i + 1] += csc_off[i];
-        std::vector<int32_t> csc_f((size_t)F), group_of_pos((size_t)F), pos_of((size_t)F);
-        {
-            std::vector<int64_t> cur(csc_off.begin(), csc_off.end() - 1);
-            for (int64_t a = 0; a < G; ++a)
-                for (int64_t f = voff[a]; f < voff[a + 1]; ++f) {
-                    const int64_t t = cur[bs.iperm[pidx[f]]]++;
-                    csc_f[t] = (int32_t)f; group_of_pos[t] = (int32_t)a; pos_of[f] = (int32_t)t;
-                }
-        }
-        BS_MARK("csc");
+    { // pose-major (CSC) view + per-block group lists for the atomic-free assembly: built on the device (pair_lists.hip)
+        TRY(bs_dmalloc(bs, &bs.d_csc_off, N + 1));
+        TRY(bs_dmalloc(bs, &bs.d_group_of_pos, F));
+        TRY(bs_dmalloc(bs, &bs.d_csc_f, F));
         TRY(bs_dmalloc(bs, &bs.d_pos_of, F));
         TRY(bs_dmalloc(bs, &bs.d_pairs, Q));
-        if (F) HIPCHK(hipMemcpy(bs.d_pos_of, pos_of.data(), (size_t)F * sizeof(int32_t), hipMemcpyHostToDevice));
+        DevBuf d_blk_of(bs.stream);
+        HIPCHK(d_blk_of.alloc(4 * (size_t)std::max<int64_t>(F, 1)));
+        TRY(csc_build(bs.stream, G, voff, F, pidx, N, bs.iperm.data(), bs.d_csc_f, bs.d_group_of_pos, bs.d_pos_of, bs.d_csc_off,
+                      d_blk_of.as<int32_t>()));
+        BS_MARK("csc");
         // Non-empty blocks, visited in 2-D TILES of the block matrix (8 x 8 poses): a tile's pairs touch only a slice of
         // 8 + 8 poses' Y segments (factors are sorted by voxel inside a segment), which stays L2-resident, whereas a
         // column-by-column sweep re-fetches every Y record ~k-1 times from HBM (measured 5.5 GB per pass at C3).
         // The Q-sized grouping itself is a device sort (pair_lists.hip).
         std::vector<int64_t> blk_slot, blk_off;
-        {
-            std::vector<int32_t> blk_of((size_t)F);
-            for (int64_t f = 0; f < F; ++f) blk_of[f] = bs.iperm[pidx[f]];
-            TRY(pair_lists_build(bs.stream, G, voff, F, blk_of.data(), bs.d_pos_of, N, (int32_t)Bb1, Q, bs.d_pairs, blk_slot,
-                                 blk_off));
-        }
+        TRY(pair_lists_build(bs.stream, G, voff, F, d_blk_of.as<int32_t>(), bs.d_pos_of, N, (int32_t)Bb1, Q, bs.d_pairs, blk_slot,
+                             blk_off));
         BS_MARK("pairs");
         bs.nnzb = (int64_t)blk_slot.size();
         // work items of the pair pass.  One 16-lane group per block is right when there are many blocks (C3: 4e5 blocks of
@@ -504,17 +494,9 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
         const int64_t avg = F / N;
         Ssz = std::min<int64_t>(Ssz, std::max<int64_t>(1, avg / 256));
         bs.S = (int32_t)std::max<int64_t>(1, std::min<int64_t>(Ssz, 64));
-        TRY(bs_dmalloc(bs, &bs.d_csc_off, N + 1));
-        TRY(bs_dmalloc(bs, &bs.d_group_of_pos, F));
-        TRY(bs_dmalloc(bs, &bs.d_csc_f, F));
         TRY(bs_dmalloc(bs, &bs.d_Y, 18 * F));
         TRY(bs_dmalloc(bs, &bs.d_blk_off, bs.n_items + 1));
         TRY(bs_dmalloc(bs, &bs.d_blk_slot, bs.n_items));
-        HIPCHK(hipMemcpy(bs.d_csc_off, csc_off.data(), (size_t)(N + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
-        if (F) {
-            HIPCHK(hipMemcpy(bs.d_group_of_pos, group_of_pos.data(), (size_t)F * sizeof(int32_t), hipMemcpyHostToDevice));
-            HIPCHK(hipMemcpy(bs.d_csc_f, csc_f.data(), (size_t)F * sizeof(int32_t), hipMemcpyHostToDevice));
-        }
         HIPCHK(hipMemcpy(bs.d_blk_off, item_off.data(), (size_t)(bs.n_items + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
         if (bs.n_items) HIPCHK(hipMemcpy(bs.d_blk_slot, item_dst.data(), (size_t)bs.n_items * sizeof(int64_t), hipMemcpyHostToDevice));
     }

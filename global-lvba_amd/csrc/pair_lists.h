@@ -6,11 +6,15 @@
 
 namespace lvba {
 
-// voff [G+1]: factor ranges of the voxels; blk_of [F]: solver-order pose block of every factor (host); d_pos_of [F]:
+// voff [G+1]: factor ranges of the voxels; blk_of [F]: solver-order pose block of every factor (device); d_pos_of [F]:
 // position of every factor in the pose-major Y array (device).  Writes the Q sorted (pos_x, pos_y) records to d_pairs
 // (device, caller-allocated) and returns the non-empty block slots J * Bb1 + (I - J) in tile order with their list
 // offsets.  Synchronises the stream.
-int32_t pair_lists_build(hipStream_t s, int64_t G, const int64_t *h_voff, int64_t F, const int32_t *h_blk_of,
+// Pose-major tables (pair_lists.hip): csc_f, group_of_pos, pos_of [F], csc_off [N+1] and blk_of [F], all device arrays.
+int32_t csc_build(hipStream_t s, int64_t G, const int64_t *h_voff, int64_t F, const int32_t *h_pidx, int32_t N,
+                  const int32_t *h_iperm, int32_t *d_csc_f, int32_t *d_group_of_pos, int32_t *d_pos_of, int64_t *d_csc_off,
+                  int32_t *d_blk_of);
+int32_t pair_lists_build(hipStream_t s, int64_t G, const int64_t *h_voff, int64_t F, const int32_t *d_blk_of,
                          const int32_t *d_pos_of, int32_t N, int32_t Bb1, int64_t Q, int2 *d_pairs,
                          std::vector<int64_t> &blk_slot, std::vector<int64_t> &blk_off);
 

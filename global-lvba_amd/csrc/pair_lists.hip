@@ -52,9 +52,83 @@ __global__ __launch_bounds__(256) void pair_gen_kernel(const int64_t *__restrict
     vals[q] = (uint64_t)px | (uint64_t)py << 32;
 }
 
+__global__ void csc_key_kernel(int64_t F, const int32_t *__restrict__ pidx, const int32_t *__restrict__ iperm,
+                               uint32_t *__restrict__ key, uint32_t *__restrict__ val, int32_t *__restrict__ blk_of)
+{
+    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const int32_t b = iperm[pidx[f]];
+    key[f] = (uint32_t)b;
+    val[f] = (uint32_t)f;
+    blk_of[f] = b;
+}
+__global__ void csc_tables_kernel(int64_t F, int64_t G, const uint32_t *__restrict__ val_s, const int64_t *__restrict__ voff,
+                                  int32_t *__restrict__ csc_f, int32_t *__restrict__ group_of_pos, int32_t *__restrict__ pos_of)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= F) return;
+    const int64_t f = val_s[t];
+    csc_f[t] = (int32_t)f;
+    pos_of[f] = (int32_t)t;
+    int64_t lo = 0, hi = G; // group of factor f: last a with voff[a] <= f (empty groups are never the last)
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (voff[mid] <= f) lo = mid; else hi = mid;
+    }
+    group_of_pos[t] = (int32_t)lo;
+}
+__global__ void csc_off_kernel(int32_t N, int64_t F, const uint32_t *__restrict__ key_s, int64_t *__restrict__ csc_off)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > N) return;
+    int64_t lo = 0, hi = F; // first sorted position whose key is >= i
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)key_s[mid] < i) lo = mid + 1; else hi = mid;
+    }
+    csc_off[i] = lo;
+}
+
 } // namespace
 
-int32_t pair_lists_build(hipStream_t s, int64_t G, const int64_t *h_voff, int64_t F, const int32_t *h_blk_of,
+// Pose-major (CSC) view of the factors: position t of the pose-major order holds factor csc_f[t] of group
+// group_of_pos[t]; pos_of is its inverse; csc_off [N+1] the pose segments.  One stable sort of (pose block, factor) --
+// factors of a pose stay in voxel order, exactly what the former host loop over the groups produced.  d_blk_of [F] receives
+// the solver-order pose block of every factor (input of pair_lists_build).
+int32_t csc_build(hipStream_t s, int64_t G, const int64_t *h_voff, int64_t F, const int32_t *h_pidx, int32_t N,
+                  const int32_t *h_iperm, int32_t *d_csc_f, int32_t *d_group_of_pos, int32_t *d_pos_of, int64_t *d_csc_off,
+                  int32_t *d_blk_of)
+{
+    DevBuf d_pidx(s), d_iperm(s), d_voff(s), key(s), val(s), key_s(s), val_s(s), tmp(s);
+    HIPCHK(d_iperm.alloc(4 * (size_t)std::max(N, 1)));
+    HIPCHK(hipMemcpyAsync(d_iperm.p, h_iperm, 4 * (size_t)N, hipMemcpyHostToDevice, s));
+    if (F > 0) {
+        HIPCHK(d_pidx.alloc(4 * (size_t)F)); HIPCHK(d_voff.alloc(8 * ((size_t)G + 1)));
+        HIPCHK(key.alloc(4 * (size_t)F)); HIPCHK(val.alloc(4 * (size_t)F)); HIPCHK(key_s.alloc(4 * (size_t)F)); HIPCHK(val_s.alloc(4 * (size_t)F));
+        HIPCHK(hipMemcpyAsync(d_pidx.p, h_pidx, 4 * (size_t)F, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(d_voff.p, h_voff, 8 * ((size_t)G + 1), hipMemcpyHostToDevice, s));
+        csc_key_kernel<<<(unsigned)((F + 255) / 256), 256, 0, s>>>(F, (const int32_t *)d_pidx.p, (const int32_t *)d_iperm.p,
+                                                                   (uint32_t *)key.p, (uint32_t *)val.p, d_blk_of);
+        HIPCHK(hipGetLastError());
+        unsigned end_bit = 1;
+        while (end_bit < 32 && ((uint32_t)N >> end_bit) != 0) ++end_bit;
+        size_t bytes = 0;
+        HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t *)key.p, (uint32_t *)key_s.p, (const uint32_t *)val.p,
+                                         (uint32_t *)val_s.p, (size_t)F, 0u, end_bit, s));
+        HIPCHK(tmp.alloc(bytes));
+        HIPCHK(rocprim::radix_sort_pairs(tmp.p, bytes, (const uint32_t *)key.p, (uint32_t *)key_s.p, (const uint32_t *)val.p,
+                                         (uint32_t *)val_s.p, (size_t)F, 0u, end_bit, s));
+        csc_tables_kernel<<<(unsigned)((F + 255) / 256), 256, 0, s>>>(F, G, (const uint32_t *)val_s.p, (const int64_t *)d_voff.p, d_csc_f,
+                                                                      d_group_of_pos, d_pos_of);
+        HIPCHK(hipGetLastError());
+    }
+    csc_off_kernel<<<(unsigned)((N + 1 + 255) / 256), 256, 0, s>>>(N, F, (const uint32_t *)key_s.p, d_csc_off);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    return LVBA_OK;
+}
+
+int32_t pair_lists_build(hipStream_t s, int64_t G, const int64_t *h_voff, int64_t F, const int32_t *d_blk_of,
                          const int32_t *d_pos_of, int32_t N, int32_t Bb1, int64_t Q, int2 *d_pairs,
                          std::vector<int64_t> &blk_slot, std::vector<int64_t> &blk_off)
 {
@@ -72,18 +146,16 @@ int32_t pair_lists_build(hipStream_t s, int64_t G, const int64_t *h_voff, int64_
     unsigned end_bit = 1;
     while (end_bit < 64 && (max_key >> end_bit) != 0) ++end_bit;
 
-    DevBuf d_voff(s), d_poff(s), d_blk(s), k_in(s), k_out(s), v_in(s), uniq(s), cnt(s), nruns(s), tmp(s);
+    DevBuf d_voff(s), d_poff(s), k_in(s), k_out(s), v_in(s), uniq(s), cnt(s), nruns(s), tmp(s);
     HIPCHK(d_voff.alloc((size_t)(G + 1) * 8));
     HIPCHK(d_poff.alloc((size_t)(G + 1) * 8));
-    HIPCHK(d_blk.alloc((size_t)F * 4));
     HIPCHK(k_in.alloc((size_t)Q * 8));
     HIPCHK(k_out.alloc((size_t)Q * 8));
     HIPCHK(v_in.alloc((size_t)Q * 8));
     HIPCHK(hipMemcpyAsync(d_voff.p, h_voff, (size_t)(G + 1) * 8, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_poff.p, poff.data(), (size_t)(G + 1) * 8, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(d_blk.p, h_blk_of, (size_t)F * 4, hipMemcpyHostToDevice, s));
     pair_gen_kernel<<<(unsigned)((Q + 255) / 256), 256, 0, s>>>((const int64_t *)d_voff.p, (const int64_t *)d_poff.p,
-                                                                (const int32_t *)d_blk.p, d_pos_of, G, Q, tiles_per_row,
+                                                                d_blk_of, d_pos_of, G, Q, tiles_per_row,
                                                                 (uint64_t *)k_in.p, (uint64_t *)v_in.p);
     HIPCHK(hipGetLastError());
     {
