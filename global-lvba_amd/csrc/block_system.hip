@@ -381,14 +381,8 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
     std::vector<uint8_t> adj; // co-visibility of the GLOBAL problem (all-reduced), when it is computed at all
     if (bs.ordering == 1 && N > 2 && small && n > 1024) {
         adj.assign((size_t)N * N, 0);
-        for (int64_t a = 0; a < G; ++a) {
-            const int64_t f0 = voff[a], f1 = voff[a + 1];
-            for (int64_t x = f0; x < f1; ++x)
-                for (int64_t y = x + 1; y < f1; ++y) {
-                    const int32_t i = pidx[x], j = pidx[y];
-                    adj[(size_t)i * N + j] = 1; adj[(size_t)j * N + i] = 1;
-                }
-        }
+        TRY(adjacency_build(bs.stream, G, voff, F, pidx, N, Q, adj.data())); // one thread per observer pair (pair_lists.hip)
+        BS_MARK("adjacency");
         if (bs.comm) {
             uint8_t *dadj = nullptr;
             HIPCHK(hipMalloc((void **)&dadj, adj.size()));

@@ -10,6 +10,9 @@ namespace lvba {
 // position of every factor in the pose-major Y array (device).  Writes the Q sorted (pos_x, pos_y) records to d_pairs
 // (device, caller-allocated) and returns the non-empty block slots J * Bb1 + (I - J) in tile order with their list
 // offsets.  Synchronises the stream.
+// Byte co-visibility matrix [N*N] of the local factors (caller pose indices), written to the host array h_adj.
+int32_t adjacency_build(hipStream_t s, int64_t G, const int64_t *h_voff, int64_t F, const int32_t *h_pidx, int32_t N, int64_t Q,
+                        uint8_t *h_adj);
 // Pose-major tables (pair_lists.hip): csc_f, group_of_pos, pos_of [F], csc_off [N+1] and blk_of [F], all device arrays.
 int32_t csc_build(hipStream_t s, int64_t G, const int64_t *h_voff, int64_t F, const int32_t *h_pidx, int32_t N,
                   const int32_t *h_iperm, int32_t *d_csc_f, int32_t *d_group_of_pos, int32_t *d_pos_of, int64_t *d_csc_off,

@@ -89,7 +89,59 @@ __global__ void csc_off_kernel(int32_t N, int64_t F, const uint32_t *__restrict_
     csc_off[i] = lo;
 }
 
+__global__ void adj_kernel(const int64_t *__restrict__ voff, const int64_t *__restrict__ poff, const int32_t *__restrict__ pidx,
+                           int64_t G, int64_t Q, int32_t N, uint8_t *__restrict__ adj)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    int64_t lo = 0, hi = G;
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (poff[mid] <= q) lo = mid; else hi = mid;
+    }
+    const int64_t f0 = voff[lo], k = voff[lo + 1] - f0, t = q - poff[lo];
+    const double b = (double)(2 * k - 1);
+    int64_t x = (int64_t)((b - sqrt(b * b - 8.0 * (double)t)) * 0.5);
+    if (x < 0) x = 0;
+    while (x > 0 && x * (2 * k - x - 1) / 2 > t) --x;
+    while ((x + 1) * (2 * k - x - 2) / 2 <= t) ++x;
+    const int64_t y = x + 1 + (t - x * (2 * k - x - 1) / 2);
+    const int32_t i = pidx[f0 + x], j = pidx[f0 + y];
+    adj[(size_t)i * N + j] = 1; // every writer stores the same value: no atomics needed
+    adj[(size_t)j * N + i] = 1;
+}
+
 } // namespace
+
+// Co-visibility (byte adjacency, N x N, caller pose indices) of the local factors: one thread per pair of observers of a
+// voxel.  h_adj [N*N] is overwritten.
+int32_t adjacency_build(hipStream_t s, int64_t G, const int64_t *h_voff, int64_t F, const int32_t *h_pidx, int32_t N, int64_t Q,
+                        uint8_t *h_adj)
+{
+    const size_t nn = (size_t)N * N;
+    DevBuf d_adj(s), d_voff(s), d_poff(s), d_pidx(s);
+    HIPCHK(d_adj.alloc(nn));
+    HIPCHK(hipMemsetAsync(d_adj.p, 0, nn, s));
+    if (Q > 0) {
+        std::vector<int64_t> poff((size_t)G + 1, 0);
+        for (int64_t a = 0; a < G; ++a) {
+            const int64_t k = h_voff[a + 1] - h_voff[a];
+            poff[a + 1] = poff[a] + k * (k - 1) / 2;
+        }
+        if (poff[G] != Q) return LVBA_ERR_STATE;
+        HIPCHK(d_voff.alloc(8 * ((size_t)G + 1))); HIPCHK(d_poff.alloc(8 * ((size_t)G + 1))); HIPCHK(d_pidx.alloc(4 * (size_t)F));
+        HIPCHK(hipMemcpyAsync(d_voff.p, h_voff, 8 * ((size_t)G + 1), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(d_poff.p, poff.data(), 8 * ((size_t)G + 1), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(d_pidx.p, h_pidx, 4 * (size_t)F, hipMemcpyHostToDevice, s));
+        adj_kernel<<<(unsigned)((Q + 255) / 256), 256, 0, s>>>((const int64_t *)d_voff.p, (const int64_t *)d_poff.p,
+                                                               (const int32_t *)d_pidx.p, G, Q, N, (uint8_t *)d_adj.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s)); // poff is a local
+    }
+    HIPCHK(hipMemcpyAsync(h_adj, d_adj.p, nn, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return LVBA_OK;
+}
 
 // Pose-major (CSC) view of the factors: position t of the pose-major order holds factor csc_f[t] of group
 // group_of_pos[t]; pos_of is its inverse; csc_off [N+1] the pose segments.  One stable sort of (pose block, factor) --
