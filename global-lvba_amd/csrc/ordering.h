@@ -5,6 +5,7 @@
 #include <climits>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
 #include <queue>
 #include <utility>
 #include <vector>
@@ -158,9 +159,17 @@ inline void rcm_order(const std::vector<uint8_t> &adj, int N, std::vector<int32_
 {
     std::vector<std::vector<int32_t>> nb(N);
     std::vector<int32_t> deg(N, 0);
-    for (int i = 0; i < N; ++i) {
+    for (int i = 0; i < N; ++i) { // the matrix is sparse (C3: 13 % non-zero): skip it eight bytes at a time
         const uint8_t *row = adj.data() + (size_t)i * N;
-        for (int j = 0; j < N; ++j)
+        int j = 0;
+        for (; j + 8 <= N; j += 8) {
+            uint64_t w;
+            std::memcpy(&w, row + j, 8);
+            if (!w) continue;
+            for (int e = 0; e < 8; ++e)
+                if (row[j + e] && j + e != i) nb[i].push_back(j + e);
+        }
+        for (; j < N; ++j)
             if (row[j] && j != i) nb[i].push_back(j);
         deg[i] = (int32_t)nb[i].size();
     }
