@@ -92,35 +92,6 @@ def test_full_pipeline_on_a_synthetic_dataset(pkg):
     assert np.abs(rel(Cw_v) - rel(Cw_gt)).max() < np.abs(rel(Cw_0) - rel(Cw_gt)).max()
 
 
-def test_update_camera_poses_from_lidar_and_components(pkg):
-    pipe = importlib.import_module("global-lvba_amd.pipeline")
-    rng = np.random.default_rng(2)
-    n = 6
-    def rnd():
-        from oracle import balm_oracle as bo
-        return np.concatenate([bo.exp_so3(0.2 * rng.standard_normal(3)).reshape(-1), rng.standard_normal(3)])
-    x_orig = np.array([rnd() for _ in range(n)]); x_opt = np.array([rnd() for _ in range(n)])
-    cams = np.array([rnd() for _ in range(4)])
-    ts = np.arange(n) * 1.0
-    img_t = np.array([-3.0, 1.4, 1.6, 9.0])                                # before the first, nearer 1, nearer 2, after the last
-    got = pipe.update_camera_poses_from_lidar(x_opt, x_orig, ts, img_t, cams)
-    for i, idx in enumerate([0, 1, 2, 5]):
-        Ro, po = x_opt[idx, :9].reshape(3, 3), x_opt[idx, 9:]
-        Rb, pb = x_orig[idx, :9].reshape(3, 3), x_orig[idx, 9:]
-        Rc, pc = cams[i, :9].reshape(3, 3), cams[i, 9:]
-        Rd = Ro @ Rb.T
-        assert np.abs(got[i, :9].reshape(3, 3) - Rd @ Rc).max() < 1e-14
-        assert np.abs(got[i, 9:] - (Rd @ pc + po - Rd @ pb)).max() < 1e-13
-    # identical trajectories leave the cameras untouched
-    same = pipe.update_camera_poses_from_lidar(x_orig, x_orig, ts, img_t, cams)
-    assert np.abs(same - cams).max() < 1e-13
-    # components keep duplicates of an image and drop what is too small
-    off, img, kp = pipe.build_components([3, 3, 3], [(0, 1), (1, 2), (0, 2)],
-                                         [np.array([[0, 0], [1, 1], [2, 0]]), np.array([[0, 0]]), np.array([[1, 2]])])
-    comps = [list(zip(img[a:b].tolist(), kp[a:b].tolist())) for a, b in zip(off[:-1], off[1:])]
-    assert comps == [[(0, 0), (1, 0), (0, 2), (2, 0)], [(0, 1), (1, 1), (2, 2)]]
-
-
 def test_pipeline_from_a_dataset_directory(pkg, tmp_path):
     """The same flow through the reference's on-disk formats (src/dataset_io.cpp, loadFromColmapDB): TUM pose files, binary
     PCDs named by time stamp, image files named by time stamp (only the names are read), a COLMAP database with keypoints and
