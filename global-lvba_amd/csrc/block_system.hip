@@ -15,6 +15,7 @@
 #include "block_system.h"
 #include "pair_lists.h"
 #include "ordering.h"
+#include "host_tables.h"
 
 static std::atomic<int> g_graph_inhibit{0};
 namespace lvba { void bs_graph_inhibit(int delta) { g_graph_inhibit.fetch_add(delta); } }
@@ -268,25 +269,10 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
         // work items of the pair pass.  One 16-lane group per block is right when there are many blocks (C3: 4e5 blocks of
         // ~60 pairs); with few blocks and long lists (window BA: 190 blocks x 2000 pairs) it leaves the chip empty, so lists
         // longer than `cut` pairs become several items whose partial blocks are summed afterwards.
-        std::vector<int64_t> item_off(1, 0), item_dst, multi_off(1, 0), multi_slot;
+        std::vector<int64_t> item_off, item_dst, multi_off, multi_slot;
         {
-            int64_t cut = (Q / 4096 + 15) / 16 * 16;
-            cut = std::max<int64_t>(64, std::min<int64_t>(cut, 512));
             int64_t n_partial = 0;
-            for (size_t bi = 0; bi < blk_slot.size(); ++bi) {
-                const int64_t q0 = blk_off[bi], q1 = blk_off[bi + 1];
-                if (q1 - q0 <= cut) {
-                    item_off.push_back(q1);
-                    item_dst.push_back(blk_slot[bi]);
-                } else {
-                    for (int64_t q = q0; q < q1; q += cut) {
-                        item_off.push_back(std::min(q + cut, q1));
-                        item_dst.push_back(-(1 + n_partial++));
-                    }
-                    multi_off.push_back(n_partial);
-                    multi_slot.push_back(blk_slot[bi]);
-                }
-            }
+            cut_pair_items(blk_slot, blk_off, Q, item_off, item_dst, multi_off, multi_slot, n_partial); // host_tables.h
             bs.n_items = (int64_t)item_dst.size();
             bs.n_multi = (int64_t)multi_slot.size();
             if (n_partial) TRY(bs_dmalloc(bs, &bs.d_partial, 36 * n_partial));

@@ -1,0 +1,74 @@
+// host_tables.h -- host-side work partitioning of the evaluation kernels (header-only, no HIP: unit-tested on the CPU by
+// tests/host_tables_check.cpp).
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <vector>
+
+namespace lvba {
+
+// Chunks of the voxel-major kernels: consecutive voxels with at most max_factors factors and max_voxels voxels per chunk (one
+// workgroup each: lane = factor, then lane = voxel).  A voxel with more than max_factors observers sits alone in its chunk
+// and is merged in tiles by the kernels.  voxel_off [n_voxels + 1]; chunk_v0 receives the first voxel of every chunk plus
+// n_voxels; Q = sum k (k - 1) / 2.  Returns -1, or the index of the first voxel with fewer than two factors.
+inline int64_t chunk_voxels(int64_t n_voxels, const int64_t *voxel_off, int max_factors, int max_voxels,
+                            std::vector<int64_t> &chunk_v0, int64_t &Q)
+{
+    chunk_v0.assign(1, 0);
+    int64_t nf = 0, nv = 0;
+    Q = 0;
+    for (int64_t a = 0; a < n_voxels; ++a) {
+        const int64_t k = voxel_off[a + 1] - voxel_off[a];
+        if (k < 2) return a;
+        Q += k * (k - 1) / 2;
+        if (k > max_factors) {
+            if (nv > 0) chunk_v0.push_back(a);
+            chunk_v0.push_back(a + 1);
+            nf = 0; nv = 0;
+            continue;
+        }
+        if (nf + k > max_factors || nv == max_voxels) { chunk_v0.push_back(a); nf = 0; nv = 0; }
+        nf += k; nv += 1;
+    }
+    if (chunk_v0.back() != n_voxels || chunk_v0.size() == 1) chunk_v0.push_back(n_voxels); // (an empty problem keeps one empty chunk)
+    return -1;
+}
+
+// Work items of the pair pass.  One 16-lane group per block is right when there are many blocks (C3: 4e5 blocks of ~60
+// pairs); with few blocks and long lists (window BA: 190 blocks x 2000 pairs) it leaves the chip empty, so lists longer
+// than `cut` pairs become several items whose partial blocks are summed afterwards (balm_pair_reduce_kernel).
+//   item i covers pairs [item_off[i], item_off[i+1]); item_dst[i] >= 0: the block slot it writes;
+//   item_dst[i] < 0: partial block -(1 + item_dst[i]); block m of the cut ones sums partials [multi_off[m], multi_off[m+1])
+//   into slot multi_slot[m].
+inline int64_t pair_cut_length(int64_t Q)
+{
+    const int64_t cut = (Q / 4096 + 15) / 16 * 16;
+    return std::max<int64_t>(64, std::min<int64_t>(cut, 512));
+}
+inline void cut_pair_items(const std::vector<int64_t> &blk_slot, const std::vector<int64_t> &blk_off, int64_t Q,
+                           std::vector<int64_t> &item_off, std::vector<int64_t> &item_dst, std::vector<int64_t> &multi_off,
+                           std::vector<int64_t> &multi_slot, int64_t &n_partial)
+{
+    item_off.assign(1, 0);
+    item_dst.clear();
+    multi_off.assign(1, 0);
+    multi_slot.clear();
+    n_partial = 0;
+    const int64_t cut = pair_cut_length(Q);
+    for (size_t bi = 0; bi < blk_slot.size(); ++bi) {
+        const int64_t q0 = blk_off[bi], q1 = blk_off[bi + 1];
+        if (q1 - q0 <= cut) {
+            item_off.push_back(q1);
+            item_dst.push_back(blk_slot[bi]);
+        } else {
+            for (int64_t q = q0; q < q1; q += cut) {
+                item_off.push_back(std::min(q + cut, q1));
+                item_dst.push_back(-(1 + n_partial++));
+            }
+            multi_off.push_back(n_partial);
+            multi_slot.push_back(blk_slot[bi]);
+        }
+    }
+}
+
+} // namespace lvba

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "block_system.h"
+#include "host_tables.h"
 
 using namespace lvba;
 
@@ -120,25 +121,16 @@ static int32_t balm_create_impl(int32_t n_poses, int64_t n_voxels, const int64_t
     // validate + chunk
     h->h_voff.resize(n_voxels + 1);
     std::vector<int64_t> chunk_v0;
-    chunk_v0.push_back(0);
-    int64_t nf = 0, nv = 0, Q = 0;
-    for (int64_t a = 0; a < n_voxels; ++a) {
-        const int64_t k = voxel_off[a + 1] - voxel_off[a];
-        h->h_voff[a] = voxel_off[a] - base;
-        if (k < 2) { delete h; return fail(LVBA_ERR_ARG, "voxel %lld has %lld factors (< 2)", (long long)a, (long long)k); }
-        if (k > LVBA_CF) { // more observers than lanes: a chunk of its own, merged in tiles by the kernels
-            if (nv > 0) chunk_v0.push_back(a);
-            chunk_v0.push_back(a + 1);
-            nf = 0; nv = 0;
-            Q += k * (k - 1) / 2;
-            continue;
+    int64_t Q = 0;
+    for (int64_t a = 0; a <= n_voxels; ++a) h->h_voff[a] = voxel_off[a] - base;
+    {
+        const int64_t bad = lvba::chunk_voxels(n_voxels, voxel_off, LVBA_CF, LVBA_CV, chunk_v0, Q); // host_tables.h
+        if (bad >= 0) {
+            const long long k = (long long)(voxel_off[bad + 1] - voxel_off[bad]);
+            delete h;
+            return fail(LVBA_ERR_ARG, "voxel %lld has %lld factors (< 2)", (long long)bad, k);
         }
-        if (nf + k > LVBA_CF || nv == LVBA_CV) { chunk_v0.push_back(a); nf = 0; nv = 0; }
-        nf += k; nv += 1;
-        Q += k * (k - 1) / 2;
     }
-    h->h_voff[n_voxels] = F;
-    chunk_v0.push_back(n_voxels);
     h->n_chunks = (int64_t)chunk_v0.size() - 1;
     h->Q = Q;
     h->h_pidx.assign(pose_idx, pose_idx + F);

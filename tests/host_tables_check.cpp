@@ -1,0 +1,78 @@
+// CPU check of global-lvba_amd/csrc/host_tables.h: chunking of the voxel-major kernels and work items of the pair pass.
+#include <cstdio>
+#include <cstdlib>
+#include "../global-lvba_amd/csrc/host_tables.h"
+
+#define CHECK(c) do { if (!(c)) { std::printf("FAILED %s (line %d)\n", #c, __LINE__); return 1; } } while (0)
+
+static int check_chunks(const std::vector<int64_t> &k, int CF, int CV)
+{
+    std::vector<int64_t> off(k.size() + 1, 0), chunk;
+    for (size_t a = 0; a < k.size(); ++a) off[a + 1] = off[a] + k[a];
+    int64_t Q = -1, Qw = 0;
+    for (auto v : k) Qw += v * (v - 1) / 2;
+    CHECK(lvba::chunk_voxels((int64_t)k.size(), off.data(), CF, CV, chunk, Q) == -1);
+    CHECK(Q == Qw && chunk.front() == 0 && chunk.back() == (int64_t)k.size());
+    for (size_t c = 0; c + 1 < chunk.size(); ++c) {
+        const int64_t v0 = chunk[c], v1 = chunk[c + 1];
+        CHECK(v1 > v0 || k.empty());
+        const int64_t nf = off[v1] - off[v0];
+        if (v1 - v0 == 1 && k[v0] > CF) continue;                    // a big voxel alone
+        CHECK(nf <= CF && v1 - v0 <= CV);
+        for (int64_t a = v0; a < v1; ++a) CHECK(k[a] <= CF);
+        // greedy: the next voxel would not have fitted
+        if (v1 < (int64_t)k.size() && k[v1] <= CF) CHECK(nf + k[v1] > CF || v1 - v0 == CV);
+    }
+    return 0;
+}
+
+int main()
+{
+    uint64_t rng = 99;
+    auto next = [&]() { rng = rng * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(rng >> 33); };
+    for (int rep = 0; rep < 200; ++rep) {
+        std::vector<int64_t> k(1 + next() % 400);
+        for (auto &v : k) v = 2 + next() % 7;
+        if (rep % 3 == 0) k[next() % k.size()] = 257 + next() % 900;   // a voxel with more observers than lanes
+        if (rep % 5 == 0) k[0] = 256;
+        if (rep % 7 == 0) k.back() = 300;
+        if (check_chunks(k, 256, 128)) return 1;
+    }
+    if (check_chunks({}, 256, 128)) return 1;
+    if (check_chunks(std::vector<int64_t>(1000, 2), 256, 128)) return 1;  // the voxel limit binds (128 voxels x 2 factors)
+    if (check_chunks(std::vector<int64_t>(10, 256), 256, 128)) return 1;
+    { // a voxel with a single factor is rejected, and reported
+        std::vector<int64_t> off{0, 3, 4, 8}, chunk; int64_t Q;
+        CHECK(lvba::chunk_voxels(3, off.data(), 256, 128, chunk, Q) == 1);
+    }
+    for (int rep = 0; rep < 200; ++rep) { // pair work items
+        const int nb = 1 + next() % 300;
+        std::vector<int64_t> slot(nb), off(nb + 1, 0);
+        for (int b = 0; b < nb; ++b) { slot[b] = 10 * b + 3; off[b + 1] = off[b] + 1 + (rep % 2 ? next() % 90 : next() % 5000); }
+        const int64_t Q = off.back(), cut = lvba::pair_cut_length(Q);
+        CHECK(cut >= 64 && cut <= 512 && cut % 16 == 0);
+        std::vector<int64_t> io, id, mo, ms; int64_t np;
+        lvba::cut_pair_items(slot, off, Q, io, id, mo, ms, np);
+        CHECK(io.front() == 0 && io.back() == Q && io.size() == id.size() + 1 && mo.size() == ms.size() + 1 && mo.back() == np);
+        size_t it = 0, m = 0;
+        for (int b = 0; b < nb; ++b) {
+            const int64_t len = off[b + 1] - off[b];
+            if (len <= cut) {
+                CHECK(id[it] == slot[b] && io[it] == off[b] && io[it + 1] == off[b + 1]);
+                ++it;
+            } else {
+                CHECK(ms[m] == slot[b]);
+                int64_t q = off[b];
+                for (int64_t pi = mo[m]; pi < mo[m + 1]; ++pi, ++it) {
+                    CHECK(id[it] == -(1 + pi) && io[it] == q && io[it + 1] - io[it] <= cut && io[it + 1] > io[it]);
+                    q = io[it + 1];
+                }
+                CHECK(q == off[b + 1]);
+                ++m;
+            }
+        }
+        CHECK(it == id.size() && m == ms.size());
+    }
+    std::printf("host tables ok\n");
+    return 0;
+}

@@ -27,3 +27,13 @@ def test_ordering_properties(exe, n, band, loop):
     assert got <= rcm and got <= nat
     if loop and n >= 600:            # ring trajectories with loop closures: the refinement beats plain RCM clearly
         assert got <= 0.8 * rcm
+
+
+def test_host_tables(tmp_path):
+    """global-lvba_amd/csrc/host_tables.h: chunks of the voxel-major kernels (<= 256 factors, <= 128 voxels, big voxels alone,
+    greedy) and work items of the pair pass (lists longer than the cut become partial-block items), through
+    tests/host_tables_check.cpp."""
+    exe = str(tmp_path / "host_tables_check")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(ROOT, "tests", "host_tables_check.cpp"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "host tables ok" in r.stdout, r.stdout + r.stderr
