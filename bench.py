@@ -311,6 +311,17 @@ def front_end_leg(pkg, synth, with_cpu):
         out["cpu_baseline"] = {"value": n / ref["seconds"], "unit": "points/s", "cores": 1, "kind": "port",
                                "sample": f"oracle/voxel_oracle.cpp on the {len(base['clouds'])} ray-cast base scans ({n} points), "
                                          f"{ref['seconds']:.2f} s"}
+        try:   # the reference's own cut_voxel / recut / tras_opt (oracle/_ref: bavoxel.hpp compiled against the stand-ins of
+               # oracle/shim; the hash-map / octree work that dominates here is the reference's own code), when it is available
+            if oracle.Reference.available():
+                m = oracle.Reference().map_build([c[:, :3] for c in base["clouds"]], base["poses"], 1.0)
+                oracle.Reference().map_free(m["handle"])
+                out["cpu_baseline_reference"] = {
+                    "value": n / m["seconds"], "unit": "points/s", "cores": 1, "kind": "reference",
+                    "sample": f"oracle/_ref/libbalm_ref.so (the reference's include/BALM/bavoxel.hpp: cut_voxel + recut + tras_opt) on "
+                              f"the same {len(base['clouds'])} scans ({n} points), {m['seconds']:.2f} s"}
+        except Exception as e:  # the baseline is reporting only: never let it take the bench down
+            out["cpu_baseline_reference"] = {"value": None, "kind": "reference", "sample": f"failed: {e!r}"}
     return out
 
 

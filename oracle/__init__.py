@@ -316,15 +316,18 @@ class Reference:
         off = np.zeros(win + 1, np.int64)
         off[1:] = np.cumsum([len(c) for c in clouds])
         pts = np.ascontiguousarray(np.concatenate([np.asarray(c, np.float32)[:, :3] for c in clouds]), np.float32)
-        h = self.lib.ref_map_build(win, off, pts.reshape(-1), self._c(poses).reshape(-1), float(voxel_size),
-                                   self._c(eigen_ratio, np.float32))
+        import time
+        poses_c, ratio_c = self._c(poses).reshape(-1), self._c(eigen_ratio, np.float32)
+        t0 = time.perf_counter()
+        h = self.lib.ref_map_build(win, off, pts.reshape(-1), poses_c, float(voxel_size), ratio_c)
+        seconds = time.perf_counter() - t0                                   # cut_voxel + recut + tras_opt (+ the export walk)
         n = [ctypes.c_int64() for _ in range(3)]
         self.lib.ref_map_sizes(h, *[ctypes.byref(x) for x in n])
         R, P, A = (x.value for x in n)
         keys, clu, geo = np.zeros((P, 4), np.int64), np.zeros((P, win, 10)), np.zeros((P, 9))
         self.lib.ref_map_export(h, keys.reshape(-1), clu.reshape(-1), geo.reshape(-1))
         order = np.lexsort((keys[:, 3], keys[:, 2], keys[:, 1], keys[:, 0]))
-        return dict(keys=keys[order], clusters=clu[order], geo=geo[order], n_roots=R, n_admitted=A, handle=h)
+        return dict(keys=keys[order], clusters=clu[order], geo=geo[order], n_roots=R, n_admitted=A, handle=h, seconds=seconds)
 
     def map_find_planes(self, handle, X, voxel_size):
         X = self._c(X).reshape(-1, 3)
