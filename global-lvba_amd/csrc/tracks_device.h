@@ -2,17 +2,26 @@
 //   undistortPixelToNormalized / distortNormalized / projectCameraToPixel   include/utils.hpp:169-233
 //   TriangulateTrackDLT                                                     src/lvba_system.cpp:50-111
 //   ComputeMeanReproj                                                       src/lvba_system.cpp:8-48
+// The functions are host/device-neutral so that tests/host_emul_tracks.cpp can run them on the CPU.
 // Observations are visited in the caller's order (the reference walks an unordered_map: the sums differ at rounding level).
 #pragma once
-#include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define LVBA_TRK_FN __host__ __device__ __forceinline__
+#else // plain C++: tests/host_emul_tracks.cpp runs the same code on the CPU
+#define LVBA_TRK_FN inline
+#ifndef __restrict__
+#define __restrict__
+#endif
+#endif
 
 namespace lvba {
 
 struct TrkIntr { double fx, fy, cx, cy, k1, k2, p1, p2; };
 
-__device__ __forceinline__ bool trk_undistort(const TrkIntr &c, double u, double v, double &x, double &y)
+LVBA_TRK_FN bool trk_undistort(const TrkIntr &c, double u, double v, double &x, double &y)
 {
     if (!(isfinite(u) && isfinite(v)) || fabs(c.fx) < 1e-12 || fabs(c.fy) < 1e-12) return false;
     const double xd = (u - c.cx) / c.fx, yd = (v - c.cy) / c.fy;
@@ -31,7 +40,7 @@ __device__ __forceinline__ bool trk_undistort(const TrkIntr &c, double u, double
     return true;
 }
 // projectCameraToPixel: camera-frame point -> distorted pixel
-__device__ __forceinline__ bool trk_project_cam(const TrkIntr &c, double X0, double X1, double Z, double &u, double &v)
+LVBA_TRK_FN bool trk_project_cam(const TrkIntr &c, double X0, double X1, double Z, double &u, double &v)
 {
     if (!(isfinite(X0) && isfinite(X1) && isfinite(Z)) || Z <= 1e-12) return false;
     const double x = X0 / Z, y = X1 / Z;
@@ -44,7 +53,7 @@ __device__ __forceinline__ bool trk_project_cam(const TrkIntr &c, double X0, dou
     v = c.fy * yd + c.cy;
     return isfinite(u) && isfinite(v);
 }
-__device__ __forceinline__ bool trk_project(const TrkIntr &c, const double *R, const double *t, const double *X, double &u, double &v)
+LVBA_TRK_FN bool trk_project(const TrkIntr &c, const double *R, const double *t, const double *X, double &u, double &v)
 {
     const double X0 = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + t[0];
     const double X1 = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + t[1];
@@ -82,7 +91,7 @@ __device__ __forceinline__ bool trk_project(const TrkIntr &c, const double *R, c
 // ComputeMeanReproj over the observations o in [a, b) with (sel == nullptr || sel[o] & bit).  false: fewer than min_count
 // projectable observations or a non-finite mean.
 template <class UV>
-__device__ __forceinline__ bool trk_mean_reproj(const TrkIntr &cam, const double *__restrict__ Rcw, const double *__restrict__ tcw,
+LVBA_TRK_FN bool trk_mean_reproj(const TrkIntr &cam, const double *__restrict__ Rcw, const double *__restrict__ tcw,
                                                 int32_t n_cams, int64_t a, int64_t b, const int32_t *__restrict__ obs_cam,
                                                 const UV *__restrict__ obs_uv, const uint8_t *sel, uint8_t bit, const double *X,
                                                 int min_count, double &mean, int &cnt)
@@ -106,7 +115,7 @@ __device__ __forceinline__ bool trk_mean_reproj(const TrkIntr &cam, const double
 
 // TriangulateTrackDLT over the selected observations.  X, mean, cnt are written only as far as the reference gets.
 template <class UV>
-__device__ __forceinline__ bool trk_dlt(const TrkIntr &cam, const double *__restrict__ Rcw, const double *__restrict__ tcw,
+LVBA_TRK_FN bool trk_dlt(const TrkIntr &cam, const double *__restrict__ Rcw, const double *__restrict__ tcw,
                                         int32_t n_cams, int64_t a, int64_t b, const int32_t *__restrict__ obs_cam,
                                         const UV *__restrict__ obs_uv, const uint8_t *sel, uint8_t bit, double *X, double &mean,
                                         int &cnt)
