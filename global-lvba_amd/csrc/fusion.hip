@@ -131,13 +131,13 @@ __global__ void fuse_kernel(int64_t n_tracks, const int64_t *__restrict__ obs_of
                             const double *__restrict__ Rcw, const double *__restrict__ tcw, int32_t n_images, TrkIntr cam,
                             int obser_thr, double cos_min, double reproj_thr, double *__restrict__ pts /*[O][3] scratch*/,
                             double *__restrict__ dirs /*[O][3] scratch*/, uint8_t *__restrict__ flag /*[O] scratch*/,
-                            uint8_t *__restrict__ status, double *__restrict__ Xout, double *__restrict__ err_out,
+                            int32_t *__restrict__ idx /*[O][2] scratch*/, uint8_t *__restrict__ status, double *__restrict__ Xout, double *__restrict__ err_out,
                             uint8_t *__restrict__ kept_out)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tracks) return;
     fuse_track(t, obs_off, obs_img, obs_uv, depth, width, height, Rcw, tcw, n_images, cam, obser_thr, cos_min, reproj_thr, pts, dirs,
-               flag, status, Xout, err_out, kept_out);
+               flag, idx, status, Xout, err_out, kept_out);
 }
 
 int32_t check_device(int32_t device)
@@ -319,11 +319,11 @@ extern "C" int32_t lvba_fuse_tracks(int32_t device, lvba_depth_t depth, int32_t 
     hipStream_t s = nullptr;
     HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     struct SG { hipStream_t s; ~SG() { (void)hipStreamDestroy(s); } } sg{s};
-    DevBuf d_off(s), d_img(s), d_uv(s), d_R(s), d_t(s), d_pts(s), d_dirs(s), d_flag(s), d_st(s), d_X(s), d_err(s), d_kept(s);
+    DevBuf d_off(s), d_img(s), d_uv(s), d_R(s), d_t(s), d_pts(s), d_dirs(s), d_flag(s), d_idx(s), d_st(s), d_X(s), d_err(s), d_kept(s);
     const size_t O1 = (size_t)std::max<int64_t>(O, 1);
     HIPCHK(d_off.alloc(8 * ((size_t)n_tracks + 1))); HIPCHK(d_img.alloc(4 * O1)); HIPCHK(d_uv.alloc(8 * O1));
     HIPCHK(d_R.alloc(72 * (size_t)n_images)); HIPCHK(d_t.alloc(24 * (size_t)n_images));
-    HIPCHK(d_pts.alloc(24 * O1)); HIPCHK(d_dirs.alloc(24 * O1)); HIPCHK(d_flag.alloc(O1));
+    HIPCHK(d_pts.alloc(24 * O1)); HIPCHK(d_dirs.alloc(24 * O1)); HIPCHK(d_flag.alloc(O1)); HIPCHK(d_idx.alloc(8 * O1));
     HIPCHK(d_st.alloc((size_t)n_tracks)); HIPCHK(d_X.alloc(24 * (size_t)n_tracks)); HIPCHK(d_err.alloc(8 * (size_t)n_tracks));
     HIPCHK(d_kept.alloc(O1));
     HIPCHK(hipMemcpyAsync(d_off.p, obs_off, 8 * ((size_t)n_tracks + 1), hipMemcpyHostToDevice, s));
@@ -338,7 +338,7 @@ extern "C" int32_t lvba_fuse_tracks(int32_t device, lvba_depth_t depth, int32_t 
     fuse_kernel<<<(unsigned)((n_tracks + 63) / 64), 64, 0, s>>>(
         n_tracks, d_off.as<int64_t>(), d_img.as<int32_t>(), d_uv.as<float>(), depth ? depth->d_depth : nullptr,
         depth ? depth->width : 0, depth ? depth->height : 0, d_R.as<double>(), d_t.as<double>(), n_images, cam, o.obser_thr, cos_min,
-        o.reproj_mean_thr_px, d_pts.as<double>(), d_dirs.as<double>(), d_flag.as<uint8_t>(), d_st.as<uint8_t>(), d_X.as<double>(),
+        o.reproj_mean_thr_px, d_pts.as<double>(), d_dirs.as<double>(), d_flag.as<uint8_t>(), d_idx.as<int32_t>(), d_st.as<uint8_t>(), d_X.as<double>(),
         d_err.as<double>(), d_kept.as<uint8_t>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(status, d_st.p, (size_t)n_tracks, hipMemcpyDeviceToHost, s));

@@ -36,7 +36,7 @@ __global__ void tri_kernel(int64_t n, const int64_t *__restrict__ obs_off, const
     const int64_t a = obs_off[i], b = obs_off[i + 1];
     double X[3] = {0.0, 0.0, 0.0}, mean;
     int cnt;
-    const bool ok = trk_dlt(cam, Rcw, tcw, n_cams, a, b, obs_cam, obs_uv, nullptr, 0, X, mean, cnt);
+    const bool ok = trk_dlt(cam, Rcw, tcw, n_cams, a, (const int32_t *)nullptr, (int)(b - a), obs_cam, obs_uv, X, mean, cnt);
     Xo[0] = X[0]; Xo[1] = X[1]; Xo[2] = X[2];
     cnt_out[i] = cnt;
     err_out[i] = mean;

@@ -3,7 +3,8 @@
 //   TriangulateTrackDLT                                                     src/lvba_system.cpp:50-111
 //   ComputeMeanReproj                                                       src/lvba_system.cpp:8-48
 // The functions are host/device-neutral so that tests/host_emul_tracks.cpp can run them on the CPU.
-// Observations are visited in the caller's order (the reference walks an unordered_map: the sums differ at rounding level).
+// Observations are visited in the order the caller's index list gives (fusion.hip passes the iteration order the reference's
+// std::unordered_map would have, see umap_order below); with no list, in storage order.
 #pragma once
 #include <math.h>
 #include <stdint.h>
@@ -88,18 +89,56 @@ LVBA_TRK_FN bool trk_project(const TrkIntr &c, const double *R, const double *t,
         }                                                                                                \
     } while (0)
 
-// ComputeMeanReproj over the observations o in [a, b) with (sel == nullptr || sel[o] & bit).  false: fewer than min_count
+// ---- iteration order of the reference's std::unordered_map<int,int> containers (image -> observation) ------------------------
+// unique_id / best_id / kept_id_* of BuildTracksAndFuse3D are walked by range-for, and the greedy view-angle filter depends on
+// that order.  With libstdc++ it is a function of reserve() and of the insertion sequence: bucket = key % bucket_count, a new
+// node goes to the front of its bucket, a bucket that becomes non-empty goes to the front of the list.  bucket_count after
+// reserve(n) is the first entry >= n of the rehash policy's prime table (tests/test_ref_system.py re-derives both from the
+// real container; tests/test_tracks_host.py runs these functions against it).
+LVBA_TRK_FN int umap_bucket_count(int reserve_n)
+{
+    const int primes[] = {2,     3,     5,     7,     11,    13,    17,    19,    23,    29,    31,    37,    41,    43,    47,    53,
+                          59,    61,    67,    71,    73,    79,    83,    89,    97,    103,   109,   113,   127,   137,   139,   149,
+                          157,   167,   179,   193,   199,   211,   227,   241,   257,   277,   293,   313,   337,   359,   383,   409,
+                          439,   467,   503,   541,   577,   619,   661,   709,   761,   823,   887,   953,   1031,  1109,  1193,  1289,
+                          1381,  1493,  1613,  1741,  1879,  2029,  2179,  2357,  2549,  2753,  2971,  3209,  3469,  3739,  4027,  4349,
+                          4703,  5087,  5503,  5953,  6427,  6949,  7517,  8123,  8783,  9497,  10273, 11113, 12011, 12983, 14033, 15173,
+                          16411, 17749, 19183, 20753, 22447, 24281, 26267, 28411, 30727, 33223, 35933, 38873, 42043, 45481, 49201, 53201,
+                          57557, 62233, 67307, 72817, 78779, 85229, 92203, 99733, 107897, 116731, 126271, 136607, 147793, 159871, 172933,
+                          187091, 202409};
+    const int n = (int)(sizeof(primes) / sizeof(primes[0]));
+    for (int i = 0; i < n; ++i)
+        if (primes[i] >= reserve_n) return primes[i];
+    return primes[n - 1];
+}
+// ins[0..m): observation offsets in insertion order (distinct images); key(e) = obs_img[base + ins[e]] (>= 0).  Writes the
+// iteration order to ord[0..m).  O(m^2), m = images of one track.
+LVBA_TRK_FN void umap_order(const int32_t *__restrict__ obs_img, int64_t base, const int32_t *__restrict__ ins, int m, int reserve_n,
+                            int32_t *__restrict__ ord)
+{
+    const int B = umap_bucket_count(reserve_n);
+    int k = 0;
+    for (int e = m - 1; e >= 0; --e) { // buckets by the time they became non-empty, latest first
+        const int be = obs_img[base + ins[e]] % B;
+        bool creator = true;
+        for (int f = 0; f < e && creator; ++f) creator = (obs_img[base + ins[f]] % B) != be;
+        if (!creator) continue;
+        for (int f = m - 1; f >= e; --f) // inside a bucket: latest insertion first
+            if ((obs_img[base + ins[f]] % B) == be) ord[k++] = ins[f];
+    }
+}
+
+// ComputeMeanReproj over the observations base + list[i], i < m (list == nullptr: base + i).  false: fewer than min_count
 // projectable observations or a non-finite mean.
 template <class UV>
-LVBA_TRK_FN bool trk_mean_reproj(const TrkIntr &cam, const double *__restrict__ Rcw, const double *__restrict__ tcw,
-                                                int32_t n_cams, int64_t a, int64_t b, const int32_t *__restrict__ obs_cam,
-                                                const UV *__restrict__ obs_uv, const uint8_t *sel, uint8_t bit, const double *X,
-                                                int min_count, double &mean, int &cnt)
+LVBA_TRK_FN bool trk_mean_reproj(const TrkIntr &cam, const double *__restrict__ Rcw, const double *__restrict__ tcw, int32_t n_cams,
+                                 int64_t base, const int32_t *list, int m, const int32_t *__restrict__ obs_cam,
+                                 const UV *__restrict__ obs_uv, const double *X, int min_count, double &mean, int &cnt)
 {
     double sum = 0.0;
     cnt = 0;
-    for (int64_t o = a; o < b; ++o) {
-        if (sel && !(sel[o] & bit)) continue;
+    for (int i = 0; i < m; ++i) {
+        const int64_t o = base + (list ? list[i] : i);
         const int32_t cm = obs_cam[o];
         if (cm < 0 || cm >= n_cams) continue;
         double u, v;
@@ -113,26 +152,24 @@ LVBA_TRK_FN bool trk_mean_reproj(const TrkIntr &cam, const double *__restrict__ 
     return isfinite(mean);
 }
 
-// TriangulateTrackDLT over the selected observations.  X, mean, cnt are written only as far as the reference gets.
+// TriangulateTrackDLT over the observations base + list[i], i < m (list == nullptr: base + i).  X, mean, cnt are written only
+// as far as the reference gets.
 template <class UV>
-LVBA_TRK_FN bool trk_dlt(const TrkIntr &cam, const double *__restrict__ Rcw, const double *__restrict__ tcw,
-                                        int32_t n_cams, int64_t a, int64_t b, const int32_t *__restrict__ obs_cam,
-                                        const UV *__restrict__ obs_uv, const uint8_t *sel, uint8_t bit, double *X, double &mean,
-                                        int &cnt)
+LVBA_TRK_FN bool trk_dlt(const TrkIntr &cam, const double *__restrict__ Rcw, const double *__restrict__ tcw, int32_t n_cams,
+                         int64_t base, const int32_t *list, int m, const int32_t *__restrict__ obs_cam, const UV *__restrict__ obs_uv,
+                         double *X, double &mean, int &cnt)
 {
     mean = INFINITY;
     cnt = 0;
-    int n_sel = 0;
-    for (int64_t o = a; o < b; ++o) n_sel += (!sel || (sel[o] & bit)) ? 1 : 0;
-    if (n_sel < 4) return false; // selected_ids.size() < 4
+    if (m < 4) return false; // selected_ids.size() < 4
     double A[4][4], V[4][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int c = 0; c < 4; ++c) { A[r][c] = 0.0; V[r][c] = r == c ? 1.0 : 0.0; }
     int rows = 0;
-    for (int64_t o = a; o < b; ++o) {
-        if (sel && !(sel[o] & bit)) continue;
+    for (int i = 0; i < m; ++i) {
+        const int64_t o = base + (list ? list[i] : i);
         const int32_t cm = obs_cam[o];
         if (cm < 0 || cm >= n_cams) continue;
         double x, y;
@@ -154,19 +191,19 @@ LVBA_TRK_FN bool trk_dlt(const TrkIntr &cam, const double *__restrict__ Rcw, con
         if (off == 0.0) break;
         LVBA_JROT4(0, 1); LVBA_JROT4(0, 2); LVBA_JROT4(0, 3); LVBA_JROT4(1, 2); LVBA_JROT4(1, 3); LVBA_JROT4(2, 3);
     }
-    int m = 0; // column of the smallest eigenvalue
+    int mn = 0; // column of the smallest eigenvalue
     double lm = A[0][0];
 #pragma unroll
     for (int c = 1; c < 4; ++c)
-        if (A[c][c] < lm) { lm = A[c][c]; m = c; }
+        if (A[c][c] < lm) { lm = A[c][c]; mn = c; }
     double Xh[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Xh[r] = m == 0 ? V[r][0] : (m == 1 ? V[r][1] : (m == 2 ? V[r][2] : V[r][3]));
+    for (int r = 0; r < 4; ++r) Xh[r] = mn == 0 ? V[r][0] : (mn == 1 ? V[r][1] : (mn == 2 ? V[r][2] : V[r][3]));
     if (fabs(Xh[3]) < 1e-12) return false;
     const double Xc[3] = {Xh[0] / Xh[3], Xh[1] / Xh[3], Xh[2] / Xh[3]};
     if (!(isfinite(Xc[0]) && isfinite(Xc[1]) && isfinite(Xc[2]))) return false;
     X[0] = Xc[0]; X[1] = Xc[1]; X[2] = Xc[2];
-    return trk_mean_reproj(cam, Rcw, tcw, n_cams, a, b, obs_cam, obs_uv, sel, bit, Xc, 4, mean, cnt);
+    return trk_mean_reproj(cam, Rcw, tcw, n_cams, base, list, m, obs_cam, obs_uv, Xc, 4, mean, cnt);
 }
 
 } // namespace lvba

@@ -183,17 +183,29 @@ _RLIB = None
 
 
 def build_ref(force=False):
-    """Builds oracle/_ref/libbalm_ref.so when the reference sources are present; returns its path, or None when neither
-    the sources nor a prebuilt library exist (e.g. a checkout without /root/reference)."""
+    """Builds oracle/_ref/libbalm_ref.so and oracle/_ref/liblvba_system_ref.so when the reference sources are present; returns
+    the path of the former, or None when neither the sources nor a prebuilt library exist (e.g. a checkout without
+    /root/reference)."""
     so = os.path.join(_HERE, "_ref", "libbalm_ref.so")
+    so_sys = os.path.join(_HERE, "_ref", "liblvba_system_ref.so")
     hdr = os.path.join(REFERENCE_ROOT, "include", "BALM", "bavoxel.hpp")
     if os.path.exists(hdr):
-        deps = [os.path.join(_HERE, "ref_glue.cpp"), os.path.join(_HERE, "ref_glue_visual.cpp"),
-                os.path.join(_HERE, "shim", "lvba_eigen_standin.h"), os.path.join(_HERE, "shim", "ceres", "ceres.h"),
-                os.path.join(_HERE, "shim", "ceres", "rotation.h"), hdr, os.path.join(REFERENCE_ROOT, "include", "BALM", "tools.hpp"),
-                os.path.join(REFERENCE_ROOT, "include", "utils.hpp")]
-        if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
+        deps = [os.path.join(_HERE, f) for f in ("ref_glue.cpp", "ref_glue_visual.cpp", "ref_glue_system.cpp", "Makefile")]
+        for root, _, files in os.walk(os.path.join(_HERE, "shim")):
+            deps += [os.path.join(root, f) for f in files]
+        deps += [hdr] + [os.path.join(REFERENCE_ROOT, *q) for q in (("include", "BALM", "tools.hpp"), ("include", "utils.hpp"),
+                                                                    ("include", "lvba_system.h"), ("include", "dataset_io.h"),
+                                                                    ("src", "lvba_system.cpp"), ("src", "dataset_io.cpp"))]
+        newest = max(os.path.getmtime(d) for d in deps)
+        if force or any(not os.path.exists(f) or os.path.getmtime(f) < newest for f in (so, so_sys)):
             subprocess.check_call(["make", "-C", _HERE, "-B", "-s", "ref", "REF=" + REFERENCE_ROOT])
+    return so if os.path.exists(so) else None
+
+
+def ref_system_path():
+    """Path of oracle/_ref/liblvba_system_ref.so (built by build_ref), or None."""
+    build_ref()
+    so = os.path.join(_HERE, "_ref", "liblvba_system_ref.so")
     return so if os.path.exists(so) else None
 
 

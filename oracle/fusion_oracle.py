@@ -9,12 +9,18 @@ Restates (paths relative to /root/reference)
   LvbaSystem::BuildTracksAndFuse3D          src/lvba_system.cpp:1016-1225  per track: depth-fused candidate, triangulation
                                                                            candidate, selection by mean reprojection error
   fetchDepthBilinear / backProjectPixelDepthDistorted / camToWorld          include/utils.hpp:235-284
-The helper functions of include/utils.hpp are pinned against the reference's own code (tests/test_ref_pin.py); the three
-member functions live in src/lvba_system.cpp (ROS / OpenCV / Ceres: cannot be built here) -> PARITY UNPINNED for their loops.
+PINNED: the helper functions of include/utils.hpp against the reference's own code (tests/test_ref_pin.py), and the three
+member functions against src/lvba_system.cpp itself, compiled unmodified against the stand-ins of oracle/shim
+(oracle/ref_glue_system.cpp, tests/test_ref_system.py): depth images bit-identical, tracks identical in membership, kept
+observations and order, landmarks to rounding.
 
-Where the reference walks a std::unordered_map<int,int> (image -> observation) the order is unspecified; here, as in the HIP
-path, images are visited in the order of their first occurrence in the track's BFS component.  It changes which observations
-the greedy view-angle filter keeps only when two candidates tie, and the rounding of sums otherwise.
+Two accidents of the reference are part of its results and are restated as they are:
+  * it walks std::unordered_map<int,int> containers (image -> observation: unique_id, best_id, kept_id_*), and the greedy
+    view-angle filter depends on that order.  With libstdc++ (GCC 11, the toolchain of this image and of the reference's
+    Ubuntu targets) the order is a function of the insertion sequence and of reserve(): `umap_order` below restates it
+    (bucket = key % bucket_count; a node goes to the front of its bucket, a new bucket to the front of the list);
+  * a component that fails the fusion is released (obs_to_track = -1, :1197) and found again from its next member in scan
+    order, i.e. fused again with a different BFS order -- `fuse_components_with_retries`.
 """
 from __future__ import annotations
 
@@ -71,6 +77,9 @@ def render_depth(clouds, scan_poses, scan_times, image_times, Rcw, tcw, intr, wi
         yd = y * radial + (p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y)
         uu, vv = fx * xd + cx, fy * yd + cy
         fin = np.isfinite(pc).all(1) & np.isfinite(xd) & np.isfinite(yd) & np.isfinite(uu) & np.isfinite(vv)
+        big = np.abs(uu) < 1e9
+        big &= np.abs(vv) < 1e9                                              # keeps the int cast defined; such pixels are outside anyway
+        fin &= big
         ui = np.trunc(np.where(fin, uu, -1.0)).astype(np.int64)
         vi = np.trunc(np.where(fin, vv, -1.0)).astype(np.int64)
         ins = fin & (ui >= 0) & (ui < width) & (vi >= 0) & (vi < height)
@@ -98,6 +107,39 @@ def fetch_depth_bilinear(depth, u, v):
             f32(f32((one - du) * dv) * d01)) + f32(f32(du * dv) * d11)
     d = f32(d)
     return d if d > 0 else None
+
+
+# bucket counts libstdc++'s _Prime_rehash_policy hands out (reserve(n) -> the first entry >= n), read off this image's
+# libstdc++ (tests/test_fusion_oracle.py re-derives them from the real container)
+UMAP_BUCKETS = (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37, 41, 43, 47, 53, 59, 61, 67, 71, 73, 79, 83, 89, 97, 103, 109, 113, 127,
+                137, 139, 149, 157, 167, 179, 193, 199, 211, 227, 241, 257, 277, 293, 313, 337, 359, 383, 409, 439, 467, 503, 541,
+                577, 619, 661, 709, 761, 823, 887, 953, 1031, 1109, 1193, 1289, 1381, 1493, 1613, 1741, 1879, 2029, 2179, 2357,
+                2549, 2753, 2971, 3209, 3469, 3739, 4027, 4349, 4703, 5087, 5503, 5953, 6427, 6949, 7517, 8123, 8783, 9497, 10273,
+                11113, 12011, 12983, 14033, 15173, 16411, 17749, 19183, 20753, 22447, 24281, 26267, 28411, 30727, 33223, 35933,
+                38873, 42043, 45481, 49201, 53201, 57557, 62233, 67307, 72817, 78779, 85229, 92203, 99733, 107897, 116731, 126271,
+                136607, 147793, 159871, 172933, 187091, 202409)
+
+
+def umap_bucket_count(reserve_n):
+    for b in UMAP_BUCKETS:
+        if b >= reserve_n:
+            return b
+    return UMAP_BUCKETS[-1]
+
+
+def umap_order(keys, reserve_n):
+    """Iteration order (positions into `keys`) of a libstdc++ std::unordered_map<int, ...> that was reserve(reserve_n)'d and then
+    received the distinct non-negative `keys` in this order (no rehash: len(keys) <= reserve_n)."""
+    B = umap_bucket_count(reserve_n)
+    order, first_of_bucket = [], {}                       # order: list of positions; bucket -> its current first position
+    for pos, k in enumerate(keys):
+        b = int(k) % B
+        if b in first_of_bucket:
+            order.insert(order.index(first_of_bucket[b]), pos)
+        else:
+            order.insert(0, pos)
+        first_of_bucket[b] = pos
+    return order
 
 
 def _view_filter(ids, points, Cw, cos_min):
@@ -129,7 +171,8 @@ def fuse_track(component_img, component_uv, depth, Rcw, tcw, intr, obser_thr=3, 
         first.setdefault(int(im), ci)
     if len(first) < obser_thr:
         return none
-    unique = list(first.items())                                             # (img, comp_idx), first-occurrence order
+    unique = list(first.items())                                             # (img, comp_idx), insertion order
+    unique = [unique[i] for i in umap_order([im for im, _ in unique], n)]    # unique_id.reserve(component.size()), :1005
     cos_min = np.cos(min_view_angle_deg * np.pi / 180.0)
     Cw = {im: -np.asarray(Rcw[im]).reshape(3, 3).T @ np.asarray(tcw[im]) for im in first}
     uv64 = np.asarray(component_uv, f32).astype(np.float64)
@@ -161,10 +204,16 @@ def fuse_track(component_img, component_uv, depth, Rcw, tcw, intr, obser_thr=3, 
             for ci in inl:
                 best.setdefault(int(component_img[ci]), ci)
             if len(best) >= obser_thr:
-                X_depth = sum(pts[ci] for ci in best.values()) / float(len(best))
-                kd = _view_filter(list(best.items()), pts, Cw, cos_min)
+                best = list(best.items())
+                best = [best[i] for i in umap_order([im for im, _ in best], len(inl))]   # best_id.reserve(inliers.size())
+                X_depth = np.zeros(3)
+                for _, ci in best:
+                    X_depth = X_depth + pts[ci]
+                X_depth = X_depth / float(len(best))
+                kd = _view_filter(best, pts, Cw, cos_min)
                 if len(kd) >= obser_thr:
-                    m, cnt = to.mean_reproj(intr, R3, t3, X_depth, [im for im, _ in kd], [uv64[ci] for _, ci in kd], obser_thr)
+                    kdo = [kd[i] for i in umap_order([im for im, _ in kd], len(best))]   # kept_id_depth.reserve(best_id.size())
+                    m, cnt = to.mean_reproj(intr, R3, t3, X_depth, [im for im, _ in kdo], [uv64[ci] for _, ci in kdo], obser_thr)
                     if m is not None:
                         m_depth, kept_depth = m, [ci for _, ci in kd]
                         depth_ok = m <= reproj_thr
@@ -176,7 +225,8 @@ def fuse_track(component_img, component_uv, depth, Rcw, tcw, intr, obser_thr=3, 
             kt = _view_filter(unique, Xs, Cw, cos_min)
             kept_tri = [ci for _, ci in kt]
             if len(kt) >= 4:
-                ok2, X2, m2, _ = to.triangulate_track(intr, R3, t3, [im for im, _ in kt], [uv64[ci] for _, ci in kt])
+                kto = [kt[i] for i in umap_order([im for im, _ in kt], len(unique))]     # kept_id_tri.reserve(unique_id.size())
+                ok2, X2, m2, _ = to.triangulate_track(intr, R3, t3, [im for im, _ in kto], [uv64[ci] for _, ci in kto])
                 if ok2:
                     X_tri, m_tri = X2, m2
                     tri_ok = m2 <= reproj_thr
@@ -208,3 +258,54 @@ def fuse_tracks(obs_off, obs_img, obs_uv, depth, Rcw, tcw, intr, **kw):
         status[t], X[t], err[t] = s, x, m
         kept[a:b] = k
     return status, X, err, kept
+
+
+def build_tracks_and_fuse(keypoints, pairs, matches, depth, Rcw, tcw, intr, obser_thr=3, **kw):
+    """The whole loop of BuildTracksAndFuse3D (src/lvba_system.cpp:921-1263): adjacency from the pairwise matches (pairs in
+    pairIndex order), BFS components from every still-free key point in (image, key point) scan order, fusion; a component that
+    is dropped releases its key points, so it is found again -- in another BFS order -- from its next member (:1000-1014,
+    :1197, :1203).  keypoints: list of [n_i, >=2] arrays.  Returns a list of dict(obs [n,2], X, status, err, kept [n])."""
+    from collections import deque
+    N = len(keypoints)
+    nk = [len(k) for k in keypoints]
+    adj = [[[] for _ in range(n)] for n in nk]
+    order = sorted(range(len(pairs)), key=lambda q: (min(pairs[q]), max(pairs[q])))
+    for q in order:
+        (i, j), m = pairs[q], np.asarray(matches[q], np.int64).reshape(-1, 2)
+        if i > j:
+            i, j, m = j, i, m[:, ::-1]
+        for ki, kj in m:
+            if ki < 0 or kj < 0 or ki >= nk[i] or kj >= nk[j]:
+                continue
+            adj[i][ki].append((j, int(kj)))
+            adj[j][kj].append((i, int(ki)))
+    state = [np.full(n, -1, np.int64) for n in nk]
+    tracks = []
+    for i in range(N):
+        for ki in range(nk[i]):
+            if state[i][ki] != -1:
+                continue
+            comp, q = [], deque([(i, ki)])
+            state[i][ki] = -2
+            while q:
+                ci, ck = q.popleft()
+                comp.append((ci, ck))
+                for ni, nkk in adj[ci][ck]:
+                    if state[ni][nkk] == -1:
+                        state[ni][nkk] = -2
+                        q.append((ni, nkk))
+            res = None
+            if len(comp) >= obser_thr and len({c for c, _ in comp}) >= obser_thr:
+                img = np.array([c for c, _ in comp], np.int32)
+                uv = np.array([keypoints[c][k][:2] for c, k in comp], f32).reshape(-1, 2)
+                s, X, e, kept = fuse_track(img, uv, depth, Rcw, tcw, intr, obser_thr=obser_thr, **kw)
+                if s:
+                    res = dict(obs=np.array(comp, np.int32), X=X, status=s, err=e, kept=kept)
+            if res is None:
+                for ci, ck in comp:
+                    state[ci][ck] = -1
+                continue
+            for ci, ck in comp:
+                state[ci][ck] = len(tracks)
+            tracks.append(res)
+    return tracks

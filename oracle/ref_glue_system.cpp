@@ -1,0 +1,292 @@
+// ref_glue_system.cpp -- TEST INFRASTRUCTURE ONLY: C entry points around the REFERENCE'S OWN src/lvba_system.cpp and
+// src/dataset_io.cpp, compiled as they lie under /root/reference (both files are #included below, nothing is copied) against
+// the stand-ins of oracle/shim:
+//   ROS            ros/ros.h: NodeHandle::param() served from a table the test fills, publishers that drop their messages
+//   OpenCV         a real cv::Mat (depth images); codecs / drawing throw (never reached), previews are no-ops
+//   PCL            PointCloud = vector of points, a PCD reader for the encodings the tests write
+//   Eigen, Sophus  lvba_eigen_standin.h, sophus/se3.h
+//   SiftGPU, sqlite3, GL   every call throws: the SIFT front end and the COLMAP import are outside the scope contract
+//   Ceres          cost functors differentiated with Jets exactly as AutoDiffCostFunction would, and a ceres::Problem that
+//                  RECORDS what optimizeCameraPoses adds to it; ceres::Solve hands the recorded problem to the hook below,
+//                  which evaluates it at the initial point and (optionally) installs a solution computed elsewhere.
+//                  There is no Ceres solver: the trust-region iterations themselves stay UNPINNED.
+// Third translation unit of oracle/_ref/libbalm_ref.so.  tests/test_ref_system.py drives it to pin, against the reference's
+// own statements: global-lvba_amd/dataset.py (DatasetIO), oracle/window_oracle.py (runWindowBA / runLidarBA),
+// global-lvba_amd/pipeline.py (updateCameraPosesFromLidar, camera_from_imu, build_components, the visual problem set-up),
+// oracle/fusion_oracle.py (buildGridMapFromOptimized + generateDepthWithVoxel, BuildTracksAndFuse3D) and
+// oracle/track_oracle.py (ComputeMeanReproj / TriangulateTrackDLT).
+#include <deque>
+#include <fstream>
+#include <set>
+#include <unordered_set>
+#ifndef ROOT_DIR
+#define ROOT_DIR "" // CMakeLists.txt of the reference defines it as the source directory; the tests pass absolute paths
+#endif
+#include "dataset_io.cpp"
+#include "lvba_system.cpp"
+
+namespace {
+
+struct RecordedResidual { int kind; int cam; int point; double r[2]; double loss_a; };
+struct RecordedProblem {
+    bool valid = false;
+    int n_cams = 0, n_points = 0, max_iter = 0, linear_solver = -1;
+    std::vector<double *> cam_q, cam_t, pts;       // parameter block addresses in order of first appearance
+    std::vector<int> q_const, t_const, q_manifold; // per camera
+    std::vector<double> q0, t0, X0;                // values when Solve was called
+    std::vector<RecordedResidual> res;
+    std::vector<double> plane;                     // per point: n[3], d  (read back from the functor)
+    double cost0 = 0;                              // 0.5 sum rho(|r|^2), Huber where a loss was given
+    std::vector<double> sol_q, sol_t, sol_X;       // optional solution to install (same order as q0 / t0 / X0)
+};
+RecordedProblem g_rec;
+
+int index_of(const std::vector<double *> &v, const double *p)
+{
+    for (size_t i = 0; i < v.size(); ++i) if (v[i] == p) return (int)i;
+    return -1;
+}
+
+void solve_hook(const ceres::Solver::Options &opt, ceres::Problem *prob, ceres::Solver::Summary *sum)
+{
+    RecordedProblem &R = g_rec;
+    std::vector<double> sq = R.sol_q, st = R.sol_t, sX = R.sol_X;
+    R = RecordedProblem();
+    R.valid = true;
+    R.max_iter = opt.max_num_iterations;
+    R.linear_solver = (int)opt.linear_solver_type;
+    // parameter blocks: the reference adds (q, t) per camera first, then one block per landmark it keeps
+    for (size_t i = 0; i < prob->parameter_blocks.size(); ++i) {
+        const auto &pb = prob->parameter_blocks[i];
+        if (pb.size == 4) { R.cam_q.push_back(pb.values); R.q_const.push_back(pb.constant); R.q_manifold.push_back(pb.manifold ? pb.manifold->TangentSize() : 0); }
+    }
+    for (size_t i = 0; i < prob->parameter_blocks.size(); ++i) {
+        const auto &pb = prob->parameter_blocks[i];
+        if (pb.size != 3) continue;
+        // a 3-block directly following a 4-block in the list is that camera's translation
+        if (i > 0 && prob->parameter_blocks[i - 1].size == 4) { R.cam_t.push_back(pb.values); R.t_const.push_back(pb.constant); }
+        else R.pts.push_back(pb.values);
+    }
+    R.n_cams = (int)R.cam_q.size();
+    R.n_points = (int)R.pts.size();
+    for (double *q : R.cam_q) R.q0.insert(R.q0.end(), q, q + 4);
+    for (double *t : R.cam_t) R.t0.insert(R.t0.end(), t, t + 3);
+    for (double *X : R.pts) R.X0.insert(R.X0.end(), X, X + 3);
+    R.plane.assign((size_t)4 * R.n_points, 0.0);
+    for (const auto &rb : prob->residual_blocks) {
+        RecordedResidual rr{};
+        rr.loss_a = rb.loss ? rb.loss->scale() : 0.0;
+        rr.r[0] = rr.r[1] = 0.0;
+        if (rb.parameters.size() == 3) {
+            rr.kind = 2;
+            rr.cam = index_of(R.cam_q, rb.parameters[0]);
+            if (index_of(R.cam_t, rb.parameters[1]) != rr.cam) rr.cam = -1;
+            rr.point = index_of(R.pts, rb.parameters[2]);
+        } else {
+            rr.kind = 1;
+            rr.cam = -1;
+            rr.point = index_of(R.pts, rb.parameters[0]);
+            // r = (n.X + d) / sigma  ->  n / sigma = gradient, d / sigma = r(0)
+            const double zero[3] = {0, 0, 0};
+            const double *pz[1] = {zero};
+            double r0, J[3];
+            double *Jp[1] = {J};
+            rb.cost->Evaluate(pz, &r0, Jp);
+            const double inv_sigma = std::sqrt(J[0] * J[0] + J[1] * J[1] + J[2] * J[2]); // |n| = 1
+            if (rr.point >= 0)
+                for (int k = 0; k < 4; ++k) R.plane[4 * rr.point + k] = (k < 3 ? J[k] : r0) / inv_sigma;
+        }
+        std::vector<const double *> pp(rb.parameters.begin(), rb.parameters.end());
+        rb.cost->Evaluate(pp.data(), rr.r, nullptr);
+        const double s = rr.r[0] * rr.r[0] + rr.r[1] * rr.r[1];
+        if (rb.loss && s > rr.loss_a * rr.loss_a) R.cost0 += 0.5 * (2.0 * rr.loss_a * std::sqrt(s) - rr.loss_a * rr.loss_a);
+        else R.cost0 += 0.5 * s;
+        R.res.push_back(rr);
+    }
+    sum->termination_type = ceres::NO_CONVERGENCE;
+    if ((int)sq.size() == 4 * R.n_cams && (int)st.size() == 3 * R.n_cams && (int)sX.size() == 3 * R.n_points) {
+        for (int k = 0; k < R.n_cams; ++k) {
+            std::copy(sq.begin() + 4 * k, sq.begin() + 4 * k + 4, R.cam_q[k]);
+            std::copy(st.begin() + 3 * k, st.begin() + 3 * k + 3, R.cam_t[k]);
+        }
+        for (int p = 0; p < R.n_points; ++p) std::copy(sX.begin() + 3 * p, sX.begin() + 3 * p + 3, R.pts[p]);
+        sum->termination_type = ceres::CONVERGENCE;
+    }
+}
+
+ros::NodeHandle g_nh;
+
+template <class F> int guarded(F f)
+{
+    try { f(); return 0; }
+    catch (const std::exception &e) { std::fprintf(stderr, "[ref_sys] %s\n", e.what()); return -1; }
+}
+void put_R(const Eigen::Matrix3d &R, double *o) { for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) o[3 * i + j] = R(i, j); }
+void put_v(const Eigen::Vector3d &v, double *o) { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; }
+
+} // namespace
+
+extern "C" {
+
+void ref_sys_clear_params() { ros::lvba_param_table().clear(); }
+void ref_sys_set_param(const char *key, const char *value) { ros::lvba_param_table()[key] = value; }
+
+// LvbaSystem::LvbaSystem (:113-134): reads the parameters, DatasetIO loads the dataset directory named by data_config/data_path
+void *ref_sys_create()
+{
+    lvba::LvbaSystem *s = nullptr;
+    if (guarded([&] { s = new lvba::LvbaSystem(g_nh); }) != 0) return nullptr;
+    return s;
+}
+void ref_sys_destroy(void *h) { delete static_cast<lvba::LvbaSystem *>(h); }
+#define SYS(h) (*static_cast<lvba::LvbaSystem *>(h))
+
+// ---- DatasetIO (src/dataset_io.cpp) -------------------------------------------------------------------------------------
+int ref_sys_n_scans(void *h) { return (int)SYS(h).dataset_io_->x_buf_.size(); }
+int ref_sys_n_clouds(void *h) { return (int)SYS(h).dataset_io_->pl_fulls_.size(); }
+int ref_sys_n_images(void *h) { return (int)SYS(h).dataset_io_->images_ids_.size(); }
+// which: 0 = x_buf_ (current), 1 = x_buf_before_.  R [n][9] row-major, p [n][3], t [n]
+void ref_sys_scan_poses(void *h, int which, double *R, double *p, double *t)
+{
+    const std::vector<IMUST> &x = which ? SYS(h).dataset_io_->x_buf_before_ : SYS(h).dataset_io_->x_buf_;
+    for (size_t i = 0; i < x.size(); ++i) { put_R(x[i].R, R + 9 * i); put_v(x[i].p, p + 3 * i); t[i] = x[i].t; }
+}
+void ref_sys_set_scan_poses(void *h, const double *R, const double *p)
+{
+    std::vector<IMUST> &x = SYS(h).dataset_io_->x_buf_;
+    for (size_t i = 0; i < x.size(); ++i) {
+        for (int a = 0; a < 3; ++a) { for (int b = 0; b < 3; ++b) x[i].R(a, b) = R[9 * i + 3 * a + b]; x[i].p[a] = p[3 * i + a]; }
+    }
+}
+int ref_sys_cloud_size(void *h, int i) { return (int)SYS(h).dataset_io_->pl_fulls_[i]->size(); }
+void ref_sys_cloud(void *h, int i, float *xyzi)
+{
+    const auto &pl = *SYS(h).dataset_io_->pl_fulls_[i];
+    for (size_t k = 0; k < pl.size(); ++k) { xyzi[4 * k] = pl[k].x; xyzi[4 * k + 1] = pl[k].y; xyzi[4 * k + 2] = pl[k].z; xyzi[4 * k + 3] = pl[k].intensity; }
+}
+void ref_sys_image_ids(void *h, double *ids) { const auto &v = SYS(h).dataset_io_->images_ids_; std::copy(v.begin(), v.end(), ids); }
+// which: 0 = DatasetIO::image_poses_ (as loaded), 1 = LvbaSystem::poses_ (after updateCameraPosesFromLidar)
+void ref_sys_image_poses(void *h, int which, double *R, double *t)
+{
+    const std::vector<Sophus::SE3> &v = which ? SYS(h).poses_ : SYS(h).dataset_io_->image_poses_;
+    for (size_t i = 0; i < v.size(); ++i) { put_R(v[i].rotation_matrix(), R + 9 * i); put_v(v[i].translation(), t + 3 * i); }
+}
+// out: width height fx fy cx cy k1 k2 p1 p2 scale  (after the resize scaling of readParameters)
+void ref_sys_camera(void *h, double *out)
+{
+    const lvba::DatasetIO &d = *SYS(h).dataset_io_;
+    const double v[11] = {(double)d.width_, (double)d.height_, d.fx_, d.fy_, d.cx_, d.cy_, d.k1_, d.k2_, d.p1_, d.p2_, d.resize_scale_};
+    std::copy(v, v + 11, out);
+}
+
+// ---- LiDAR stage -------------------------------------------------------------------------------------------------------
+int ref_sys_init(void *h) { return guarded([&] { SYS(h).initFromDatasetIO(); }); } // :448-505
+// Rci [9], tci [3]: the IMU -> camera extrinsics initFromDatasetIO derives
+void ref_sys_extrinsics(void *h, double *Rci, double *tci) { put_R(SYS(h).Rci_, Rci); put_v(SYS(h).tci_, tci); }
+// runLidarBA (:312-410).  The reference waits for a '1' on stdin after its preview; the glue answers it.
+int ref_sys_run_lidar_ba(void *h)
+{
+    std::istringstream yes("1\n");
+    std::streambuf *old = std::cin.rdbuf(yes.rdbuf());
+    const int rc = guarded([&] { SYS(h).runLidarBA(); });
+    std::cin.rdbuf(old);
+    return rc;
+}
+void ref_sys_anchor_index(void *h, int *idx) { const auto &v = SYS(h).anchor_index_per_frame_; std::copy(v.begin(), v.end(), idx); }
+void ref_sys_rel_poses(void *h, double *R, double *p)
+{
+    const auto &v = SYS(h).rel_poses_to_anchor_;
+    for (size_t i = 0; i < v.size(); ++i) { put_R(v[i].R, R + 9 * i); put_v(v[i].p, p + 3 * i); }
+}
+
+// ---- visual stage, step by step (runVisualBAWithLidarAssist :144-154) -------------------------------------------------------
+int ref_sys_build_grid_map(void *h) { return guarded([&] { SYS(h).buildGridMapFromOptimized(); }); }      // :1266-1338
+int ref_sys_update_camera_poses(void *h) { return guarded([&] { SYS(h).updateCameraPosesFromLidar(); }); } // :412-446
+int ref_sys_generate_depth(void *h) { return guarded([&] { SYS(h).generateDepthWithVoxel(); }); }         // :835-919
+int64_t ref_sys_grid_points(void *h) { int64_t n = 0; for (const auto &kv : SYS(h).grid_map_) n += (int64_t)kv.second.size(); return n; }
+int ref_sys_n_voxel_ids(void *h, int img) { return (int)SYS(h).all_voxel_ids_[img].size(); }
+void ref_sys_depth(void *h, int img, float *out)
+{
+    const cv::Mat &d = SYS(h).all_depths_[img];
+    std::memcpy(out, d.data, sizeof(float) * (size_t)d.rows * d.cols);
+}
+// which: 0 = Rcw_all_ (from the poses as loaded), 1 = Rcw_all_optimized_
+void ref_sys_cam_poses(void *h, int which, double *R, double *t)
+{
+    const auto &Rs = which ? SYS(h).Rcw_all_optimized_ : SYS(h).Rcw_all_;
+    const auto &ts = which ? SYS(h).tcw_all_optimized_ : SYS(h).tcw_all_;
+    for (size_t i = 0; i < Rs.size(); ++i) { put_R(Rs[i], R + 9 * i); put_v(ts[i], t + 3 * i); }
+}
+// the SIFT front end is replaced by the test's own key points and matches (all_keypoints_, all_matches_ in pairIndex order)
+void ref_sys_set_keypoints(void *h, int img, int n, const float *xy)
+{
+    auto &all = SYS(h).all_keypoints_;
+    if ((int)all.size() <= img) all.resize(img + 1);
+    all[img].assign(n, sift::Keypoint{});
+    for (int k = 0; k < n; ++k) { all[img][k].x = xy[2 * k]; all[img][k].y = xy[2 * k + 1]; }
+}
+void ref_sys_set_matches(void *h, int i, int j, int n, const int32_t *pairs)
+{
+    lvba::LvbaSystem &s = SYS(h);
+    const int N = (int)s.all_keypoints_.size();
+    s.all_matches_.resize((size_t)N * (N - 1) / 2);
+    auto &m = s.all_matches_[lvba::pairIndex(i, j, N)];
+    m.clear();
+    for (int k = 0; k < n; ++k) m.emplace_back(pairs[2 * k], pairs[2 * k + 1]);
+}
+void ref_sys_set_fusion_params(void *h, int obser_thr, double min_view_angle_deg, double reproj_mean_thr_px)
+{
+    SYS(h).obser_thr_ = obser_thr; SYS(h).min_view_angle_deg_ = min_view_angle_deg; SYS(h).reproj_mean_thr_px_ = reproj_mean_thr_px;
+}
+int ref_sys_build_tracks(void *h) { return guarded([&] { SYS(h).BuildTracksAndFuse3D(); }); } // :921-1263
+int ref_sys_n_tracks(void *h) { return (int)SYS(h).tracks_.size(); }
+int ref_sys_track_sizes(void *h, int t, int *n_inl) { *n_inl = (int)SYS(h).tracks_[t].inlier_indices.size(); return (int)SYS(h).tracks_[t].observations.size(); }
+void ref_sys_track(void *h, int t, double *X, int32_t *obs /*[n][2]*/, int32_t *inl)
+{
+    const lvba::Track &tr = SYS(h).tracks_[t];
+    put_v(tr.Xw_fused, X);
+    for (size_t k = 0; k < tr.observations.size(); ++k) { obs[2 * k] = tr.observations[k].first; obs[2 * k + 1] = tr.observations[k].second; }
+    std::copy(tr.inlier_indices.begin(), tr.inlier_indices.end(), inl);
+}
+
+// optimizeCameraPoses (:1423-1670) with the recording ceres::Problem.  sol_* (may be null): a solution to install in place of
+// the Ceres solve, in the order of the recorded blocks (needs a previous call to learn that order).
+int ref_sys_optimize(void *h, const double *sol_q, const double *sol_t, const double *sol_X, int n_cams, int n_points)
+{
+    g_rec.sol_q.clear(); g_rec.sol_t.clear(); g_rec.sol_X.clear();
+    if (sol_q && sol_t && sol_X) {
+        g_rec.sol_q.assign(sol_q, sol_q + 4 * (size_t)n_cams);
+        g_rec.sol_t.assign(sol_t, sol_t + 3 * (size_t)n_cams);
+        g_rec.sol_X.assign(sol_X, sol_X + 3 * (size_t)n_points);
+    }
+    ceres::lvba_solve_hook() = solve_hook;
+    const int rc = guarded([&] { SYS(h).optimizeCameraPoses(); });
+    ceres::lvba_solve_hook() = nullptr;
+    return rc == 0 && !g_rec.valid ? 1 : rc; // 1: the reference returned before building a problem
+}
+// out: n_cams n_points n_residual_blocks max_num_iterations linear_solver_type(3 = DENSE_SCHUR)
+void ref_sys_problem_info(int *out)
+{
+    out[0] = g_rec.n_cams; out[1] = g_rec.n_points; out[2] = (int)g_rec.res.size(); out[3] = g_rec.max_iter; out[4] = g_rec.linear_solver;
+}
+double ref_sys_problem_cost() { return g_rec.cost0; }
+void ref_sys_problem_blocks(double *q0, double *t0, double *X0, double *plane, int32_t *q_const, int32_t *t_const, int32_t *q_tangent)
+{
+    std::copy(g_rec.q0.begin(), g_rec.q0.end(), q0);
+    std::copy(g_rec.t0.begin(), g_rec.t0.end(), t0);
+    std::copy(g_rec.X0.begin(), g_rec.X0.end(), X0);
+    std::copy(g_rec.plane.begin(), g_rec.plane.end(), plane);
+    std::copy(g_rec.q_const.begin(), g_rec.q_const.end(), q_const);
+    std::copy(g_rec.t_const.begin(), g_rec.t_const.end(), t_const);
+    std::copy(g_rec.q_manifold.begin(), g_rec.q_manifold.end(), q_tangent);
+}
+// per residual block: kind (2 = reprojection, 1 = plane), camera, point, r[2], Huber scale (0 = none)
+void ref_sys_problem_residuals(int32_t *kind, int32_t *cam, int32_t *point, double *r, double *loss_a)
+{
+    for (size_t i = 0; i < g_rec.res.size(); ++i) {
+        kind[i] = g_rec.res[i].kind; cam[i] = g_rec.res[i].cam; point[i] = g_rec.res[i].point;
+        r[2 * i] = g_rec.res[i].r[0]; r[2 * i + 1] = g_rec.res[i].r[1]; loss_a[i] = g_rec.res[i].loss_a;
+    }
+}
+
+} // extern "C"

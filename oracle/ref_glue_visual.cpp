@@ -89,9 +89,8 @@ void ref_euler_to_rot(double roll, double pitch, double yaw, double *R)
 // fetchDepthBilinear (utils.hpp:246-275) on a CV_32FC1 image [h][w]
 int ref_fetch_depth_bilinear(int h, int w, const float *depth, float u, float v, float depth_scale, float *out)
 {
-    cv::Mat m;
-    m.rows = h; m.cols = w; m.type_ = CV_32FC1;
-    m.data_.assign(reinterpret_cast<const unsigned char *>(depth), reinterpret_cast<const unsigned char *>(depth) + (size_t)h * w * 4);
+    cv::Mat m(h, w, CV_32FC1);
+    std::memcpy(m.data, depth, sizeof(float) * (size_t)h * w);
     return lvba::fetchDepthBilinear(m, u, v, *out, depth_scale);
 }
 int ref_parse_timestamp(const char *name, double *ts) { return parseTimestampFromName(std::string(name), *ts); }

@@ -131,6 +131,8 @@ class Matrix {
     const S &x() const { return st.d[0]; }
     const S &y() const { return st.d[1]; }
     const S &z() const { return st.d[2]; }
+    S &w() { return st.d[3]; }
+    const S &w() const { return st.d[3]; }
     S *data() { return st.d.data(); }
     const S *data() const { return st.d.data(); }
 
@@ -164,6 +166,7 @@ class Matrix {
     S sum() const { S s = 0; for (auto v : st.d) s += v; return s; }
     Matrix cwiseMin(const Matrix &o) const { Matrix m(*this); for (int i = 0; i < size(); ++i) m.st.d[i] = std::min(st.d[i], o.st.d[i]); return m; }
     Matrix cwiseMax(const Matrix &o) const { Matrix m(*this); for (int i = 0; i < size(); ++i) m.st.d[i] = std::max(st.d[i], o.st.d[i]); return m; }
+    bool isZero(S prec = S(1e-12)) const { for (auto v : st.d) if (!(std::abs(v) <= prec)) return false; return true; }
     bool allFinite() const { for (auto v : st.d) if (!std::isfinite(v)) return false; return true; }
     static Matrix UnitX() { Matrix m; m.st.d[0] = S(1); return m; }
     static Matrix UnitY() { Matrix m; m.st.d[1] = S(1); return m; }
@@ -424,6 +427,7 @@ class SelfAdjointEigenSolver {
     }
     const Matrix<S, M::RowsAtCompileTimeStandin, 1> &eigenvalues() const { return val_; }
     const M &eigenvectors() const { return vec_; }
+    int info() const { return 0; } // Eigen::Success: the Jacobi sweeps below always terminate
 
   private:
     Matrix<S, M::RowsAtCompileTimeStandin, 1> val_;
@@ -462,6 +466,71 @@ class AngleAxis {
     S angle_;
 };
 typedef AngleAxis<double> AngleAxisd;
+enum ComputationInfo { Success = 0, NumericalIssue = 1, NoConvergence = 2, InvalidInput = 3 };
+
+// Eigen::Quaternion<S>: (w, x, y, z) constructor, construction from a rotation matrix by the branch on the trace / the
+// largest diagonal entry (Eigen's published quaternion-from-matrix rule), toRotationMatrix.
+template <class S>
+class Quaternion {
+  public:
+    typedef Matrix<S, 3, 3> Mat3;
+    Quaternion() : w_(1), x_(0), y_(0), z_(0) {}
+    Quaternion(S w, S x, S y, S z) : w_(w), x_(x), y_(y), z_(z) {}
+    explicit Quaternion(const Mat3 &m)
+    {
+        S t = m.trace();
+        if (t > S(0)) {
+            t = std::sqrt(t + S(1));
+            w_ = S(0.5) * t;
+            t = S(0.5) / t;
+            x_ = (m(2, 1) - m(1, 2)) * t;
+            y_ = (m(0, 2) - m(2, 0)) * t;
+            z_ = (m(1, 0) - m(0, 1)) * t;
+        } else {
+            int i = 0;
+            if (m(1, 1) > m(0, 0)) i = 1;
+            if (m(2, 2) > m(i, i)) i = 2;
+            const int j = (i + 1) % 3, k = (j + 1) % 3;
+            S v[3];
+            t = std::sqrt(m(i, i) - m(j, j) - m(k, k) + S(1));
+            v[i] = S(0.5) * t;
+            t = S(0.5) / t;
+            w_ = (m(k, j) - m(j, k)) * t;
+            v[j] = (m(j, i) + m(i, j)) * t;
+            v[k] = (m(k, i) + m(i, k)) * t;
+            x_ = v[0]; y_ = v[1]; z_ = v[2];
+        }
+    }
+    S w() const { return w_; }
+    S x() const { return x_; }
+    S y() const { return y_; }
+    S z() const { return z_; }
+    S norm() const { return std::sqrt(w_ * w_ + x_ * x_ + y_ * y_ + z_ * z_); }
+    void normalize() { const S n = norm(); w_ /= n; x_ /= n; y_ /= n; z_ /= n; }
+    Quaternion normalized() const { Quaternion q(*this); q.normalize(); return q; }
+    Quaternion conjugate() const { return Quaternion(w_, -x_, -y_, -z_); }
+    Quaternion operator*(const Quaternion &b) const
+    {
+        return Quaternion(w_ * b.w_ - x_ * b.x_ - y_ * b.y_ - z_ * b.z_, w_ * b.x_ + x_ * b.w_ + y_ * b.z_ - z_ * b.y_,
+                          w_ * b.y_ + y_ * b.w_ + z_ * b.x_ - x_ * b.z_, w_ * b.z_ + z_ * b.w_ + x_ * b.y_ - y_ * b.x_);
+    }
+    Mat3 toRotationMatrix() const
+    {
+        const S tx = S(2) * x_, ty = S(2) * y_, tz = S(2) * z_;
+        const S twx = tx * w_, twy = ty * w_, twz = tz * w_, txx = tx * x_, txy = ty * x_, txz = tz * x_, tyy = ty * y_, tyz = tz * y_,
+                tzz = tz * z_;
+        Mat3 r;
+        r(0, 0) = S(1) - (tyy + tzz); r(0, 1) = txy - twz; r(0, 2) = txz + twy;
+        r(1, 0) = txy + twz; r(1, 1) = S(1) - (txx + tzz); r(1, 2) = tyz - twx;
+        r(2, 0) = txz - twy; r(2, 1) = tyz + twx; r(2, 2) = S(1) - (txx + tyy);
+        return r;
+    }
+    Matrix<S, 3, 1> operator*(const Matrix<S, 3, 1> &v) const { return toRotationMatrix() * v; }
+
+  private:
+    S w_, x_, y_, z_;
+};
+typedef Quaternion<double> Quaterniond;
 
 template <class S>
 class Triplet {
@@ -496,7 +565,6 @@ class SparseMatrix {
     Matrix<S, Dynamic, Dynamic> dense;
 };
 
-enum ComputationInfo { Success = 0, NumericalIssue = 1 };
 
 // Unpivoted LDL^T of the lower triangle (Eigen's default UpLo = Lower), D may be indefinite -- like SimplicialLDLT.
 template <class SpMat>

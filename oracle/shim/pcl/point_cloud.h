@@ -20,6 +20,13 @@ class PointCloud {
     void reserve(size_t n) { points.reserve(n); }
     void resize(size_t n) { points.resize(n); width = (uint32_t)n; height = 1; }
     void clear() { points.clear(); width = height = 0; }
+    template <class... A> void emplace_back(A &&...a) { points.emplace_back(std::forward<A>(a)...); width = (uint32_t)points.size(); height = 1; }
+    PointCloud &operator+=(const PointCloud &o)
+    {
+        points.insert(points.end(), o.points.begin(), o.points.end());
+        width = (uint32_t)points.size(); height = 1;
+        return *this;
+    }
     void push_back(const PointT &p) { points.push_back(p); width = (uint32_t)points.size(); height = 1; }
     void swap(PointCloud &o) { points.swap(o.points); std::swap(width, o.width); std::swap(height, o.height); std::swap(is_dense, o.is_dense); }
     PointT &operator[](size_t i) { return points[i]; }

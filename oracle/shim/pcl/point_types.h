@@ -1,7 +1,7 @@
 // stand-in for <pcl/point_types.h>: only the point layouts the reference's BALM headers name (test infrastructure only)
 #pragma once
 namespace pcl {
-struct PointXYZ { float x = 0, y = 0, z = 0, pad_ = 1; };
+struct PointXYZ { float x = 0, y = 0, z = 0, pad_ = 1; PointXYZ() {} PointXYZ(float a, float b, float c) : x(a), y(b), z(c) {} };
 struct PointXYZI { float x = 0, y = 0, z = 0, pad_ = 1, intensity = 0, pad2_[3] = {0, 0, 0}; };
 struct PointXYZINormal {
     float x = 0, y = 0, z = 0, pad_ = 1;

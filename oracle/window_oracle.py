@@ -117,3 +117,26 @@ def run_lidar_ba(clouds, poses, *, window_enable=True, window_size=10, anchor_le
         R = A[:9].reshape(3, 3) @ Lr[:9].reshape(3, 3)
         out[i] = np.concatenate([R.reshape(-1), A[:9].reshape(3, 3) @ Lr[9:] + A[9:]])
     return out, report
+
+
+def merge_anchors(clouds, poses, window_size, anchor_leaf):
+    """The anchor clouds of LvbaSystem::optimizeCameraPoses (src/lvba_system.cpp:1466-1489): per window of `window_size`
+    scans, every scan moved into the frame of the window's first scan with the CURRENT poses (pl_transform: fp32 write-back),
+    concatenated and thinned by down_sampling_voxel2.  Returns (anchor_poses [A,12], anchor_clouds [A] of [m,3] fp32; the
+    survivors ordered by voxel key, where the reference emits them in unordered_map order)."""
+    n = len(clouds)
+    poses = np.asarray(poses, np.float64).reshape(n, 12)
+    anchor_poses, anchor_clouds = [], []
+    for start in range(0, n, window_size):
+        end = min(start + window_size, n)
+        R0, p0 = poses[start, :9].reshape(3, 3), poses[start, 9:]
+        merged = []
+        for j in range(start, end):
+            rel_R = R0.T @ poses[j, :9].reshape(3, 3)
+            rel_p = R0.T @ (poses[j, 9:] - p0)
+            c = np.asarray(clouds[j], f32)[:, :3].astype(np.float64)
+            merged.append((c @ rel_R.T + rel_p).astype(f32))
+        merged = np.concatenate(merged)
+        anchor_poses.append(poses[start].copy())
+        anchor_clouds.append(merged[down_sampling_voxel2(merged, anchor_leaf)])
+    return np.asarray(anchor_poses).reshape(-1, 12), anchor_clouds

@@ -16,8 +16,8 @@ void emul_triangulate(int64_t n_tracks, const int64_t *obs_off, const int32_t *o
     for (int64_t i = 0; i < n_tracks; ++i) {
         double x[3] = {0, 0, 0}, mean;
         int c;
-        const bool good = trk_dlt(cam, Rcw, tcw, n_cams, obs_off[i], obs_off[i + 1], obs_cam, obs_uv, (const uint8_t *)nullptr, (uint8_t)0,
-                                  x, mean, c);
+        const bool good = trk_dlt(cam, Rcw, tcw, n_cams, obs_off[i], (const int32_t *)nullptr, (int)(obs_off[i + 1] - obs_off[i]), obs_cam,
+                                  obs_uv, x, mean, c);
         X[3 * i] = x[0]; X[3 * i + 1] = x[1]; X[3 * i + 2] = x[2];
         err[i] = mean; cnt[i] = c; ok[i] = good ? 1 : 0;
     }
@@ -32,9 +32,19 @@ void emul_fuse_tracks(int64_t n_tracks, const int64_t *obs_off, const int32_t *o
     const int64_t O = obs_off[n_tracks];
     std::vector<double> pts(3 * (size_t)(O + 1)), dirs(3 * (size_t)(O + 1));
     std::vector<uint8_t> flag((size_t)O + 1);
+    std::vector<int32_t> idx(2 * (size_t)(O + 1));
     for (int64_t t = 0; t < n_tracks; ++t)
         fuse_track(t, obs_off, obs_img, obs_uv, depth, width, height, Rcw, tcw, n_images, cam, obser_thr, cos_min, reproj_thr,
-                   pts.data(), dirs.data(), flag.data(), status, X, err, kept);
+                   pts.data(), dirs.data(), flag.data(), idx.data(), status, X, err, kept);
+}
+
+// umap_order of tracks_device.h: keys in insertion order -> positions in iteration order; returns the bucket count
+int emul_umap_order(int reserve_n, int m, const int32_t *keys, int32_t *order)
+{
+    std::vector<int32_t> ins((size_t)m);
+    for (int i = 0; i < m; ++i) ins[i] = i;
+    umap_order(keys, 0, ins.data(), m, reserve_n, order);
+    return umap_bucket_count(reserve_n);
 }
 
 float emul_fetch_depth(const float *depth, int w, int h, float u, float v, int *ok)

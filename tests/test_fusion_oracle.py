@@ -122,12 +122,15 @@ def test_depth_candidate_and_selection():
     ok = st > 0
     assert np.abs(Xf[ok] - X[ok]).max() < 0.25
     # with depth only for THREE images a track can still be depth-fused (obser_thr = 3) where triangulation needs 4
-    # (images 0, 3, 5: an observation is kept when its ray differs by >= 8 degrees from at least one ray already kept;
-    # at 8 m that needs > 1.1 m of baseline to the first camera)
-    sel = [o for o in range(off[0], off[1]) if img[o] in (0, 3, 5)]
+    # (images 0, 2, 5: an observation is kept when its ray differs by >= 8 degrees from at least one ray already kept -- at 8 m
+    # that needs > 1.1 m of baseline to a kept camera; the rays are visited in the order of the reference's unordered_map, for
+    # these keys 5, 2, 0.  Images 0, 3, 5 are visited 5, 3, 0 (3 and 0 share a bucket) and lose image 3 to image 5.)
+    sel = [o for o in range(off[0], off[1]) if img[o] in (0, 2, 5)]
     assert len(sel) == 3
     s3, X3, e3, k3 = fo.fuse_tracks(np.array([0, 3]), img[sel], uv[sel], depth, Rs, ts, INTR)
     assert s3[0] == 2 and k3.sum() == 3 and np.abs(X3[0] - X[0]).max() < 0.25
+    sel_b = [o for o in range(off[0], off[1]) if img[o] in (0, 3, 5)]
+    assert fo.fuse_tracks(np.array([0, 3]), img[sel_b], uv[sel_b], depth, Rs, ts, INTR)[0][0] == 0
     sel2 = [o for o in range(off[0], off[1]) if img[o] in (0, 1, 2)]         # all within 1 m of camera 0: only one ray survives
     s3b, _, _, _ = fo.fuse_tracks(np.array([0, 3]), img[sel2], uv[sel2], depth, Rs, ts, INTR)
     assert s3b[0] == 0

@@ -18,7 +18,7 @@ INTR = np.array([300.0, 298.0, 240.0, 180.0, -0.076160, 0.123001, -0.00113, 0.00
 W, H = 480, 360
 
 
-def _dataset(n_frames=24, pts=80000, n_land=900, seed=61):
+def _dataset(n_frames=24, pts=80000, n_land=900, seed=61, INTR=INTR, W=W, H=H):
     synth = importlib.import_module("global-lvba_amd.synth")
     pipe = importlib.import_module("global-lvba_amd.pipeline")
     s = synth.make_scans(n_frames, pts, room=(14, 10, 4), n_panels=0, n_blobs=0, clutter_frac=0.0, seed=seed, rot_sigma_deg=0.15,

@@ -1,0 +1,244 @@
+"""Pins the restatements of the pipeline AROUND the two LM loops against the reference's own src/lvba_system.cpp and
+src/dataset_io.cpp, compiled unmodified against the stand-ins of oracle/shim (oracle/ref_glue_system.cpp ->
+oracle/_ref/liblvba_system_ref.so).  A small synthetic sequence is written in the reference's on-disk layout, the
+reference's LvbaSystem loads it and runs its stages one at a time; after every stage the restatement that the GPU tests use as
+their oracle (oracle/*.py), and the product's host mirror (global-lvba_amd/pipeline.py, dataset.py), are held against it:
+
+    DatasetIO                                -> dataset.load_dataset / load_poses_tum / pipeline.list_image_ids
+    initFromDatasetIO                        -> pipeline.extrinsics_from_config
+    runLidarBA (runWindowBA + two stages)    -> oracle.window_oracle.run_lidar_ba                     (poses to 1e-9)
+    updateCameraPosesFromLidar               -> pipeline.update_camera_poses_from_lidar, camera_from_imu
+    buildGridMapFromOptimized + generateDepthWithVoxel -> oracle.fusion_oracle.render_depth            (bit-identical images)
+    BuildTracksAndFuse3D                     -> oracle.fusion_oracle.build_tracks_and_fuse             (same tracks, same order)
+    optimizeCameraPoses up to ceres::Solve   -> window_oracle.merge_anchors + voxel_oracle.find_plane + visual_oracle cost
+                                                (the problem Ceres would receive: blocks, constancy, manifold, residuals)
+
+What stays unpinned: the iterations of ceres::Solve (no Ceres here) and the SIFT / COLMAP front end (out of scope)."""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from oracle import fusion_oracle as fo, ref_system as rs, visual_oracle as vis, voxel_oracle as vo, window_oracle as wo
+
+pytestmark = pytest.mark.skipif(not rs.available(), reason="no reference sources and no prebuilt oracle/_ref/liblvba_system_ref.so")
+
+INTR = np.array([150.0, 149.0, 120.0, 90.0, -0.076160, 0.123001, -0.00113, 0.000251])   # a small image, so that a modest cloud
+W, H = 240, 180                                                                          # gives dense depth images
+CFG = dict(window_size=6, anchor_leaf=0.02, stage_voxel_size=(1.0, 0.5), stage_eigen_ratio=((0.2,) * 4, (0.08,) * 4))
+
+
+def write_sequence(root, d, ds):
+    """The reference's dataset layout (README "Dataset", src/dataset_io.cpp) for the synthetic sequence d."""
+    os.makedirs(os.path.join(root, "all_pcd_body")); os.makedirs(os.path.join(root, "all_image"))
+    for t, c in zip(d["times"], d["clouds"]):
+        ds.save_pcd(os.path.join(root, "all_pcd_body", f"{t:.6f}.pcd"), np.concatenate([c[:, :3], np.zeros((len(c), 1), np.float32)], 1))
+    ds.write_poses_tum(os.path.join(root, "all_pcd_body", "lidar_poses.txt"), d["times"], d["odo"])
+    for t in d["img_t"]:
+        open(os.path.join(root, "all_image", f"{t:.6f}.png"), "wb").close()
+    ds.write_poses_tum(os.path.join(root, "all_image", "image_poses.txt"), d["img_t"], d["odo"])
+
+
+def reference_params(tp, cfg=CFG):
+    """The ROS parameters (config/*.yaml names of the reference) for the synthetic camera / extrinsics / BALM settings."""
+    I = INTR
+    p = {"data_config/image_sample_step": 1, "cam_model/cam_width": W, "cam_model/cam_height": H, "cam_model/scale": 1.0,
+         "extrin_calib/extrinsic_T": [0, 0, 0], "extrin_calib/extrinsic_R": np.eye(3), "extrin_calib/Pcl": tp.TCI, "extrin_calib/Rcl": tp.RCB,
+         "window_ba/enable": True, "window_ba/size": cfg["window_size"], "window_ba/anchor_leaf_size": cfg["anchor_leaf"],
+         "window_ba/use_window_ba_rel": True, "BALM_stage1/root_voxel_size": cfg["stage_voxel_size"][0],
+         "BALM_stage1/eigen_ratio_array": cfg["stage_eigen_ratio"][0], "BALM_stage2/root_voxel_size": cfg["stage_voxel_size"][1],
+         "BALM_stage2/eigen_ratio_array": cfg["stage_eigen_ratio"][1]}
+    for k, v in zip(("fx", "fy", "cx", "cy", "d0", "d1", "d2", "d3"), I):
+        p["cam_model/cam_" + k] = float(v)
+    return p
+
+
+@pytest.fixture(scope="module")
+def run(tmp_path_factory):
+    import test_gpu_pipeline as tp
+    ds = importlib.import_module("global-lvba_amd.dataset")
+    pipe = importlib.import_module("global-lvba_amd.pipeline")
+    d = tp._dataset(n_frames=12, pts=16000, n_land=260, seed=63, INTR=INTR, W=W, H=H)
+    root = str(tmp_path_factory.mktemp("refsys") / "seq")
+    write_sequence(root, d, ds)
+    S = rs.ReferenceSystem(root, reference_params(tp))
+    r = types.SimpleNamespace(tp=tp, ds=ds, pipe=pipe, d=d, root=root, S=S)
+    r.loaded = ds.load_dataset(root)
+    r.R0, r.p0, r.ts = S.scan_poses()
+    r.clouds_ref = [S.cloud(i) for i in range(S.n_clouds)]
+    r.image_ids = S.image_ids()
+    r.img_R0, r.img_t0 = S.image_poses()
+    r.camera = S.camera()
+    r.Rci, r.tci = S.init()
+    r.anchor_idx, r.rel_R, r.rel_p = S.run_lidar_ba()
+    r.R1, r.p1, _ = S.scan_poses()
+    r.x_opt = np.concatenate([r.R1.reshape(-1, 9), r.p1], 1)
+    r.grid_points, r.n_voxel_ids = S.build_grid_map()
+    r.cam_R, r.cam_t = S.update_camera_poses()
+    r.depth = S.generate_depth(W, H)
+    r.Rcw, r.tcw = S.cam_poses(True)
+    r.Rcw_before, r.tcw_before = S.cam_poses(False)
+    S.set_features(d["kps"], {pr: m for pr, m in zip(d["pairs"], d["matches"])})
+    r.tracks = S.build_tracks()
+    r.problem = S.optimize()
+    yield r
+    S.close()
+
+
+def test_dataset_io(run):
+    r = run
+    assert r.S.n_scans == r.S.n_clouds == r.S.n_images == 12
+    L = r.loaded
+    assert np.abs(L["poses"][:, :9].reshape(-1, 3, 3) - r.R0).max() < 1e-15 and np.array_equal(L["poses"][:, 9:], r.p0)
+    assert np.array_equal(L["timestamps"], r.ts)                                   # parseTimestampFromName of the file names
+    for a, b in zip(L["clouds"], r.clouds_ref):
+        assert np.array_equal(np.asarray(a)[:, :3], b[:, :3])
+    assert np.array_equal(r.pipe.list_image_ids(os.path.join(r.root, "all_image")), r.image_ids)
+    _, img = r.ds.load_poses_tum(os.path.join(r.root, "all_image", "image_poses.txt"), 1)
+    assert np.abs(img[:, :9].reshape(-1, 3, 3) - r.img_R0).max() < 1e-15 and np.array_equal(img[:, 9:], r.img_t0)
+    assert r.camera["width"] == W and r.camera["height"] == H and np.array_equal(r.camera["intr"], INTR)
+    Rci, tci = r.pipe.extrinsics_from_config(r.tp.RCB, r.tp.TCI, np.eye(3), np.zeros(3))
+    assert np.abs(Rci - r.Rci).max() < 1e-15 and np.abs(tci - r.tci).max() < 1e-15
+
+
+def test_run_lidar_ba(run):
+    """runLidarBA = runWindowBA + stage 1 + stage 2 + the anchor -> scan composition, against the restatement the GPU tests of
+    lvba_lidar_ba / lvba_window_ba use."""
+    r = run
+    L = r.loaded
+    out, rep = wo.run_lidar_ba(L["clouds"], L["poses"], window_size=CFG["window_size"], anchor_leaf=CFG["anchor_leaf"], use_rel=True,
+                               stage_voxel_size=CFG["stage_voxel_size"], stage_eigen_ratio=CFG["stage_eigen_ratio"])
+    assert np.abs(r.p1 - r.p0).max() > 0.02                                        # the reference did move the trajectory
+    assert np.abs(out[:, :9].reshape(-1, 3, 3) - r.R1).max() < 1e-9 and np.abs(out[:, 9:] - r.p1).max() < 1e-9
+    w = wo.run_window_ba(L["clouds"], L["poses"], CFG["window_size"], CFG["stage_voxel_size"][0], np.float32((0.3, 0.1, 0.06, 0.03)),
+                         CFG["anchor_leaf"], True)
+    assert np.array_equal(w["anchor_index"], r.anchor_idx)
+    assert np.abs(w["rel_poses"][:, :9].reshape(-1, 3, 3) - r.rel_R).max() < 1e-9 and np.abs(w["rel_poses"][:, 9:] - r.rel_p).max() < 1e-9
+
+
+def test_camera_poses_and_depth_images(run):
+    r = run
+    L = r.loaded
+    _, img = r.ds.load_poses_tum(os.path.join(r.root, "all_image", "image_poses.txt"), 1)
+    cam_new = r.pipe.update_camera_poses_from_lidar(r.x_opt, L["poses"], r.ts, r.image_ids, img)
+    assert np.abs(cam_new[:, :9].reshape(-1, 3, 3) - r.cam_R).max() < 1e-13 and np.abs(cam_new[:, 9:] - r.cam_t).max() < 1e-13
+    Rcw, tcw = r.pipe.camera_from_imu(cam_new, r.Rci, r.tci)
+    assert np.abs(Rcw - r.Rcw).max() < 1e-13 and np.abs(tcw - r.tcw).max() < 1e-12
+    Rb, tb = r.pipe.camera_from_imu(img, r.Rci, r.tci)
+    assert np.abs(Rb - r.Rcw_before).max() < 1e-14 and np.abs(tb - r.tcw_before).max() < 1e-13
+    assert r.grid_points == sum(len(c) for c in L["clouds"]) and min(r.n_voxel_ids) > 100
+    depth = fo.render_depth(L["clouds"], r.x_opt, r.ts, r.image_ids, r.Rcw, r.tcw, INTR, W, H)
+    assert (r.depth > 0).mean() > 0.1
+    assert np.array_equal(depth, r.depth)                                          # every pixel of every image, bit for bit
+
+
+def test_unordered_map_order_is_the_real_one(tmp_path):
+    """fusion_oracle.umap_order / UMAP_BUCKETS against std::unordered_map<int,int> of this toolchain."""
+    import ctypes
+    import subprocess
+    src = tmp_path / "umap.cpp"
+    src.write_text('#include <cstddef>\n#include <unordered_map>\nextern "C" int real_order(int res, int m, const int *k, int *out) {\n'
+                   "  std::unordered_map<int, int> u; u.reserve((std::size_t)res);\n  for (int i = 0; i < m; ++i) u[k[i]] = i;\n"
+                   "  int n = 0; for (const auto &kv : u) out[n++] = kv.second; return (int)u.bucket_count(); }\n")
+    so = str(tmp_path / "umap.so")
+    subprocess.check_call(["g++", "-O1", "-shared", "-fPIC", "-o", so, str(src)])
+    lib = ctypes.CDLL(so)
+    ip = ctypes.POINTER(ctypes.c_int)
+    rng = np.random.default_rng(5)
+    for _ in range(600):
+        m = int(rng.integers(1, 48))
+        res = m + int(rng.integers(0, 40))
+        keys = rng.choice(int(rng.integers(m, 4000)), m, replace=False).astype(np.int32)
+        out = np.zeros(m, np.int32)
+        B = lib.real_order(res, m, keys.ctypes.data_as(ip), out.ctypes.data_as(ip))
+        assert B == fo.umap_bucket_count(res) and fo.umap_order(keys.tolist(), res) == out.tolist()
+    for res in (3, 200, 5000, 150000):
+        out = np.zeros(1, np.int32)
+        assert lib.real_order(res, 1, out.ctypes.data_as(ip), out.ctypes.data_as(ip)) == fo.umap_bucket_count(res)
+
+
+def test_build_tracks_and_fuse(run):
+    """Same tracks in the same order, the same observations in the same BFS order, the same inlier sets, landmarks to rounding --
+    including the components the reference only fuses on a retry from a later member."""
+    r = run
+    mine = fo.build_tracks_and_fuse(r.d["kps"], r.d["pairs"], r.d["matches"], r.depth, r.Rcw, r.tcw, INTR)
+    assert len(mine) == len(r.tracks) > 100
+    n_tri = n_depth = 0
+    for a, b in zip(r.tracks, mine):
+        assert np.array_equal(a["obs"], b["obs"])
+        assert np.abs(a["X"] - b["X"]).max() < 1e-10
+        assert sorted(a["inliers"].tolist()) == np.nonzero(b["kept"])[0].tolist()
+        n_tri += b["status"] == 1; n_depth += b["status"] == 2
+    assert n_tri > 10 and n_depth > 10
+    # the retry quirk is exercised: some track does not start at the smallest member of its component
+    assert any(tuple(t["obs"][0]) != min(map(tuple, t["obs"].tolist())) for t in r.tracks)
+
+
+def test_device_fusion_code_reproduces_the_reference_tracks(run, tmp_path_factory):
+    """The per-track code the fuse kernel runs (global-lvba_amd/csrc/fusion_device.h, compiled for the host by
+    tests/host_emul_tracks.cpp) on the components of the reference's tracks, in the reference's BFS order: same candidate
+    selected, same kept observations, same landmark."""
+    import test_tracks_host as th
+    lib = th.build_emul(tmp_path_factory.mktemp("emul_tracks_ref"))
+    r = run
+    off = np.concatenate([[0], np.cumsum([len(t["obs"]) for t in r.tracks])]).astype(np.int64)
+    obs = np.concatenate([t["obs"] for t in r.tracks])
+    uv = np.array([r.d["kps"][i][k][:2] for i, k in obs], np.float32)
+    st, X, err, kept = th._fuse(lib, off, obs[:, 0], uv, r.depth, r.Rcw, r.tcw, INTR)
+    assert np.all(st > 0)
+    for n, t in enumerate(r.tracks):
+        assert np.abs(X[n] - t["X"]).max() < 1e-10
+        assert np.nonzero(kept[off[n]:off[n + 1]])[0].tolist() == sorted(t["inliers"].tolist())
+
+
+def test_problem_handed_to_ceres(run):
+    r = run
+    P = r.problem
+    assert P is not None and P["n_cams"] == 12 and P["max_iter"] == 50 and P["linear_solver"] == 3          # DENSE_SCHUR
+    assert P["q_const"].tolist() == [1] + [0] * 11 and P["t_const"].tolist() == [1] + [0] * 11              # camera 0 fixed
+    assert np.all(P["q_tangent"] == 3) and np.all(P["loss_a"] == 0)                                         # manifold; loss = nullptr
+    assert np.abs(P["q0"] - r.pipe.rot_to_quat_wxyz(r.Rcw)).max() < 1e-15 and np.array_equal(P["t0"], r.tcw)
+    # landmarks: the usable tracks that find a plane in the map of the anchor clouds rebuilt from the refined poses
+    L = r.loaded
+    ap, ac = wo.merge_anchors(L["clouds"], r.x_opt, CFG["window_size"], CFG["anchor_leaf"])
+    smap, _ = vo.build(ac, ap, CFG["stage_voxel_size"][1], np.float32(CFG["stage_eigen_ratio"][1]))
+    mine = fo.build_tracks_and_fuse(r.d["kps"], r.d["pairs"], r.d["matches"], r.depth, r.Rcw, r.tcw, INTR)
+    planes = [vo.find_plane(smap, t["X"], CFG["stage_voxel_size"][1]) for t in mine]
+    keep = [i for i, p in enumerate(planes) if p is not None]
+    assert len(keep) == P["n_points"] and 50 < len(keep) < len(mine)
+    X = np.array([mine[i]["X"] for i in keep])
+    assert np.abs(X - P["X0"]).max() < 1e-10
+    pl = np.array([np.concatenate([planes[i][0], [planes[i][1]]]) for i in keep])
+    sgn = np.sign(np.einsum("ij,ij->i", pl[:, :3], P["plane"][:, :3]))                                     # eigenvector sign is free
+    assert np.abs(pl * sgn[:, None] - P["plane"]).max() < 1e-9
+    # residual blocks: per landmark its distinct inlier observations, then its plane
+    obs_off, obs_cam, obs_uv, k = [0], [], [], 0
+    for li, i in enumerate(keep):
+        t = mine[i]
+        ref_inl = r.tracks[i]["inliers"]
+        for idx in ref_inl:
+            assert P["kind"][k] == 2 and P["point"][k] == li and P["cam"][k] == t["obs"][idx, 0]
+            obs_cam.append(int(t["obs"][idx, 0])); obs_uv.append(r.d["kps"][t["obs"][idx, 0]][t["obs"][idx, 1]][:2].astype(np.float64))
+            k += 1
+        assert P["kind"][k] == 1 and P["point"][k] == li
+        k += 1
+        obs_off.append(len(obs_cam))
+    assert k == len(P["kind"])
+    prob = vis.VisualProblem(q=P["q0"], t=P["t0"], X=X, obs_off=np.array(obs_off), obs_cam=np.array(obs_cam, np.int32),
+                             obs_uv=np.array(obs_uv).reshape(-1, 2), plane=pl, valid=np.ones(len(X), np.uint8), intr=INTR)
+    O = vis.VisualOracle(prob)
+    c0 = O.cost(*O.state())
+    assert abs(c0 - P["cost0"]) < 1e-10 * P["cost0"]                               # sigma_px 0.5, sigma_plane 0.01, no robust loss
+    # the write-back after the solve (:1651-1667): a solution installed in place of Ceres' is what the members hold afterwards
+    rng = np.random.default_rng(3)
+    q = P["q0"] + 1e-3 * rng.standard_normal(P["q0"].shape)
+    t = P["t0"] + 1e-2 * rng.standard_normal(P["t0"].shape)
+    Xs = P["X0"] + 1e-2 * rng.standard_normal(P["X0"].shape)
+    assert r.S.optimize(solution=(q, t, Xs)) is not None
+    Rn, tn = r.S.cam_poses(True)
+    qn = q / np.linalg.norm(q, axis=1, keepdims=True)
+    assert np.abs(r.pipe.quat_wxyz_to_rot(qn) - Rn).max() < 1e-14 and np.array_equal(tn, t)

@@ -17,9 +17,9 @@ from oracle import track_oracle as to
 import test_gpu_fusion as G   # scene / track generators (pure numpy; its tests are GPU-marked, the helpers are not)
 
 
-@pytest.fixture(scope="module")
-def emul(tmp_path_factory):
-    so = str(tmp_path_factory.mktemp("emul_tracks") / "libemul_tracks.so")
+def build_emul(directory):
+    """Compiles tests/host_emul_tracks.cpp (the device headers, for the host) into `directory` and binds it."""
+    so = os.path.join(str(directory), "libemul_tracks.so")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                            os.path.join(ROOT, "tests", "host_emul_tracks.cpp"), "-o", so])
     lib = ctypes.CDLL(so)
@@ -31,9 +31,16 @@ def emul(tmp_path_factory):
     lib.emul_triangulate.argtypes = [ctypes.c_int64, i64, i32, f64, f64, f64, ctypes.c_int32, f64, f64, f64, i32, u8]
     lib.emul_fuse_tracks.argtypes = [ctypes.c_int64, i64, i32, f32, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, f64, f64,
                                      ctypes.c_int32, f64, ctypes.c_int, ctypes.c_double, ctypes.c_double, u8, f64, f64, u8]
+    lib.emul_umap_order.restype = ctypes.c_int
+    lib.emul_umap_order.argtypes = [ctypes.c_int, ctypes.c_int, i32, i32]
     lib.emul_fetch_depth.restype = ctypes.c_float
     lib.emul_fetch_depth.argtypes = [f32, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.POINTER(ctypes.c_int)]
     return lib
+
+
+@pytest.fixture(scope="module")
+def emul(tmp_path_factory):
+    return build_emul(tmp_path_factory.mktemp("emul_tracks"))
 
 
 def _fuse(lib, off, img, uv, depth, Rcw, tcw, intr, obser_thr=3, angle=8.0, thr=3.0):
@@ -105,3 +112,25 @@ def test_device_dlt_and_depth_sampling_match_oracle(emul):
         assert bool(okc.value) == (want is not None)
         if want is not None:
             assert np.float32(d) == np.float32(want)
+
+
+def test_device_umap_order_is_the_real_container_order(emul, tmp_path):
+    """umap_order / umap_bucket_count of tracks_device.h (what the kernel walks) against std::unordered_map<int,int> itself."""
+    src = tmp_path / "umap.cpp"
+    src.write_text('#include <cstddef>\n#include <unordered_map>\nextern "C" int real_order(int res, int m, const int *k, int *out) {\n'
+                   "  std::unordered_map<int, int> u; u.reserve((std::size_t)res);\n  for (int i = 0; i < m; ++i) u[k[i]] = i;\n"
+                   "  int n = 0; for (const auto &kv : u) out[n++] = kv.second; return (int)u.bucket_count(); }\n")
+    so = str(tmp_path / "umap.so")
+    subprocess.check_call(["g++", "-O1", "-shared", "-fPIC", "-o", so, str(src)])
+    real = ctypes.CDLL(so)
+    ip = ctypes.POINTER(ctypes.c_int)
+    rng = np.random.default_rng(11)
+    for _ in range(800):
+        m = int(rng.integers(1, 60))
+        res = m + int(rng.integers(0, 50))
+        keys = rng.choice(int(rng.integers(m, 5000)), m, replace=False).astype(np.int32)
+        want, got = np.zeros(m, np.int32), np.zeros(m, np.int32)
+        B = real.real_order(res, m, keys.ctypes.data_as(ip), want.ctypes.data_as(ip))
+        assert emul.emul_umap_order(res, m, keys, got) == B
+        np.testing.assert_array_equal(got, want)
+        assert fo.umap_order(keys.tolist(), res) == want.tolist()
