@@ -77,44 +77,111 @@ def quat_wxyz_to_rot(q):
     return np.array([quat_to_rot(*qq) for qq in np.asarray(q).reshape(-1, 4)])
 
 
-def build_components(n_keypoints, pairs, matches, obser_thr=3):
-    """The BFS of BuildTracksAndFuse3D (src/lvba_system.cpp:923-1003) WITHOUT the per-image de-duplication: every component
-    that passes the two size checks, observations in BFS order.  Returns (obs_off, obs_img, obs_kp)."""
-    from collections import deque
+def match_graph(n_keypoints, pairs, matches):
+    """Adjacency of the key point match graph as BuildTracksAndFuse3D builds it (src/lvba_system.cpp:932-952): pairs visited in
+    pairIndex order (i < j, i-major), every match appended to both ends' lists.  adj[i] = {key point: [(image, key point), ..]}."""
     N = len(n_keypoints)
     adj = [dict() for _ in range(N)]
+    todo = []
     for (i, j), m in zip(pairs, matches):
         m = np.asarray(m, np.int64).reshape(-1, 2)
         if i > j:
             i, j, m = j, i, m[:, ::-1]
+        todo.append((i, j, m))
+    todo.sort(key=lambda q: (q[0], q[1]))
+    for i, j, m in todo:
         for ki, kj in m:
             if ki < 0 or kj < 0 or ki >= n_keypoints[i] or kj >= n_keypoints[j]:
                 continue
             adj[i].setdefault(int(ki), []).append((j, int(kj)))
             adj[j].setdefault(int(kj), []).append((i, int(ki)))
-    seen = [set() for _ in range(N)]
-    off, img, kp = [0], [], []
-    for i in range(N):
+    return adj
+
+
+def bfs_order(adj, start):
+    """The BFS of :962-981 from `start` = (image, key point) over a whole connected component."""
+    from collections import deque
+    seen, comp, q = {start}, [], deque([start])
+    while q:
+        ci, ck = q.popleft()
+        comp.append((ci, ck))
+        for nb in adj[ci].get(ck, ()):
+            if nb not in seen:
+                seen.add(nb)
+                q.append(nb)
+    return comp
+
+
+def match_components(n_keypoints, pairs, matches, obser_thr=3):
+    """Connected components of the match graph that pass the two size checks (:983-1014: >= obser_thr observations from >=
+    obser_thr images).  Returns (adj, comps); comps[c] = members sorted in scan order (image, key point): the reference starts
+    its BFS at comps[c][0] and, if the fusion drops the component, again at comps[c][1], comps[c][2], ..."""
+    adj = match_graph(n_keypoints, pairs, matches)
+    seen = [set() for _ in adj]
+    comps = []
+    for i in range(len(adj)):
         for ki in sorted(adj[i]):
             if ki in seen[i]:
                 continue
-            comp, q = [], deque([(i, ki)])
-            seen[i].add(ki)
-            while q:
-                ci, ck = q.popleft()
-                comp.append((ci, ck))
-                for ni, nk in adj[ci].get(ck, ()):
-                    if nk not in seen[ni]:
-                        seen[ni].add(nk)
-                        q.append((ni, nk))
-            if len(comp) < obser_thr or len({c for c, _ in comp}) < obser_thr:
-                for ci, ck in comp:
-                    seen[ci].discard(ck)
-                continue
+            comp = bfs_order(adj, (i, ki))
             for ci, ck in comp:
-                img.append(ci); kp.append(ck)
-            off.append(len(img))
+                seen[ci].add(ck)
+            if len(comp) >= obser_thr and len({c for c, _ in comp}) >= obser_thr:
+                comps.append(sorted(comp))
+    return adj, comps
+
+
+def build_components(n_keypoints, pairs, matches, obser_thr=3):
+    """First-attempt BFS order of every component of match_components as CSR arrays (obs_off, obs_img, obs_kp)."""
+    adj, comps = match_components(n_keypoints, pairs, matches, obser_thr)
+    off, img, kp = [0], [], []
+    for members in comps:
+        for ci, ck in bfs_order(adj, members[0]):
+            img.append(ci); kp.append(ck)
+        off.append(len(img))
     return np.asarray(off, np.int64), np.asarray(img, np.int32), np.asarray(kp, np.int32)
+
+
+def build_tracks_and_fuse(keypoints, pairs, matches, fuse_fn, obser_thr=3):
+    """The track loop of BuildTracksAndFuse3D (src/lvba_system.cpp:954-1246) with the per-component fusion batched:
+    fuse_fn(obs_off, obs_img, obs_uv) -> (status, X, err, kept) is lvba_fuse_tracks on the GPU.  A component the fusion drops is
+    released by the reference (:1197, :1203) and met again at its next member in scan order, i.e. fused again in another BFS
+    order; round r of the loop below fuses, in one batch, the r-th attempt of every component that is still dropped.  Tracks
+    come out in the reference's order (by the key point their successful BFS started from).
+    Returns dict(obs_off, obs_img, obs_kp, obs_uv, kept: CSR arrays of the tracks; X, err, status: per track; component_status:
+    per component (0 = dropped after all attempts), attempts: per track, 0-based)."""
+    nk = [len(k) for k in keypoints]
+    adj, comps = match_components(nk, pairs, matches, obser_thr)
+    comp_status = np.zeros(len(comps), np.uint8)
+    done = []                                                               # (start, order, X, err, status, kept, attempt)
+    pending, attempt = list(range(len(comps))), 0
+    while pending:
+        orders = [bfs_order(adj, comps[c][attempt]) for c in pending]
+        off = np.concatenate([[0], np.cumsum([len(o) for o in orders])]).astype(np.int64)
+        flat = [ob for o in orders for ob in o]
+        img = np.array([i for i, _ in flat], np.int32)
+        uv = np.array([keypoints[i][k][:2] for i, k in flat], np.float32).reshape(-1, 2)
+        status, X, err, kept = fuse_fn(off, img, uv)
+        nxt = []
+        for n, c in enumerate(pending):
+            if status[n]:
+                comp_status[c] = status[n]
+                done.append((comps[c][attempt], orders[n], X[n].copy(), float(err[n]), int(status[n]),
+                             np.asarray(kept[off[n]:off[n + 1]]).copy(), attempt))
+            elif attempt + 1 < len(comps[c]):
+                nxt.append(c)
+        pending, attempt = nxt, attempt + 1
+    done.sort(key=lambda d: d[0])
+    off = np.concatenate([[0], np.cumsum([len(d[1]) for d in done])]).astype(np.int64)
+    flat = [ob for d in done for ob in d[1]]
+    img = np.array([i for i, _ in flat], np.int32)
+    kp = np.array([k for _, k in flat], np.int32)
+    uv = np.array([keypoints[i][k][:2] for i, k in flat], np.float32).reshape(-1, 2)
+    return dict(obs_off=off, obs_img=img, obs_kp=kp, obs_uv=uv,
+                kept=np.concatenate([d[5] for d in done]).astype(np.uint8) if done else np.zeros(0, np.uint8),
+                X=np.array([d[2] for d in done]).reshape(-1, 3), err=np.array([d[3] for d in done]),
+                status=np.array([d[4] for d in done], np.uint8), attempts=np.array([d[6] for d in done], np.int32),
+                component_status=comp_status)
 
 
 def run_visual_ba_with_lidar_assist(scans, x_opt, x_orig, scan_times, image_times, image_poses, Rci, tci, intr, width, height,
@@ -131,17 +198,17 @@ def run_visual_ba_with_lidar_assist(scans, x_opt, x_orig, scan_times, image_time
                                  half_window_s=c["depth_half_window_s"], voxel_size=c["depth_voxel"])
     try:
         # BuildTracksAndFuse3D
-        nk = [len(k) for k in keypoints]
-        off, img, kp = build_components(nk, pairs, matches, c["obser_thr"])
-        uv = (np.array([keypoints[i][k][:2] for i, k in zip(img, kp)], np.float32).reshape(-1, 2)
-              if len(img) else np.zeros((0, 2), np.float32))
-        status, X, err, kept = V.fuse_tracks(off, img, uv, Rcw, tcw, intr, depth=depth, obser_thr=c["obser_thr"],
-                                             min_view_angle_deg=c["min_view_angle_deg"], reproj_mean_thr_px=c["reproj_mean_thr_px"])
+        T = build_tracks_and_fuse(keypoints, pairs, matches,
+                                  lambda o, i, u: V.fuse_tracks(o, i, u, Rcw, tcw, intr, depth=depth, obser_thr=c["obser_thr"],
+                                                                min_view_angle_deg=c["min_view_angle_deg"],
+                                                                reproj_mean_thr_px=c["reproj_mean_thr_px"]), c["obser_thr"])
     finally:
         depth.close()
-    tr = np.nonzero(status)[0]                                               # tracks_ (usable: >= obser_thr observations, finite, non-zero)
+    off, img, uv, kept, X, err = T["obs_off"], T["obs_img"], T["obs_uv"], T["kept"], T["X"], T["err"]
+    status = T["component_status"]
+    tr = np.arange(len(X))                                                   # tracks_: every one is usable (:1436-1441)
     out = dict(cam_poses=cam_new, Rcw_before=Rcw0, tcw_before=tcw0, Rcw_lidar=Rcw, tcw_lidar=tcw, track_status=status,
-               n_components=len(status))
+               n_components=len(status), tracks=T)
     if len(tr) == 0:
         out.update(Rcw=Rcw, tcw=tcw, landmarks=np.zeros((0, 3)), landmark_valid=np.zeros(0, np.uint8), trace=[], termination="NO_TRACKS")
         return out

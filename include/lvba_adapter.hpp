@@ -13,9 +13,11 @@
 //       lvba::VoxelMap surf_map(pl_win, x_win, stage1_root_voxel_size_, stage1_eigen_ratio_array_.data());
 //       if (surf_map.info().n_voxels >= 3 * x_win.size()) surf_map.damping_iter(x_win);
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 #include "lvba_hip.h"
 
@@ -208,31 +210,22 @@ lvba_lidar_ba_report lidar_ba(const CloudPtrVec &clouds, PoseVec &x_buf, const l
     return rep;
 }
 
-// Drop-in for the per-component body of LvbaSystem::BuildTracksAndFuse3D (src/lvba_system.cpp:1000-1225).  The caller keeps
-// its BFS over the match graph (:936-998) but, instead of processing every component in the loop, collects the components
-// that pass the two size checks and hands them over in one call:
-//       std::vector<std::vector<std::pair<int,int>>> comps;           // (image, keypoint) in BFS order
-//       ... BFS ...  comps.push_back(component);
-//       lvba::fuse_components<Track>(comps, all_keypoints_, Rcw_all_optimized_, tcw_all_optimized_, intr, depth /*or nullptr*/,
-//                                    opts, tracks_, comp_track);       // comp_track[c] = index into tracks_ or -1
-// Track needs the reference's members Xw_fused, observations, inlier_indices (include/utils.hpp:150-156); keypoints .x / .y.
-template <class Track, class Component, class KeypointTable, class RotVec, class TransVec>
-void fuse_components(const std::vector<Component> &comps, const KeypointTable &all_keypoints, const RotVec &Rcw_all,
-                     const TransVec &tcw_all, const double intr[8], lvba_depth_t depth, const lvba_fuse_opts *opts,
-                     std::vector<Track> &tracks, std::vector<int> &comp_track, int device = 0)
+// ---- LvbaSystem::BuildTracksAndFuse3D (src/lvba_system.cpp:921-1263) ---------------------------------------------------------
+// One batch of components (observations = (image, key point) in BFS order) through lvba_fuse_tracks.  status[c] 0 = dropped,
+// 1 = triangulated, 2 = depth-fused; X [C][3]; kept: one flag per observation, components back to back.
+struct FusedBatch {
+    std::vector<uint8_t> status, kept;
+    std::vector<double> X;
+    std::vector<int64_t> off;
+};
+template <class Component, class KeypointTable>
+void pack_components(const std::vector<Component> &comps, const KeypointTable &all_keypoints, std::vector<int64_t> &off,
+                     std::vector<int32_t> &img, std::vector<float> &uv)
 {
-    const int32_t n_img = static_cast<int32_t>(Rcw_all.size());
-    std::vector<double> R(9 * static_cast<size_t>(n_img)), t(3 * static_cast<size_t>(n_img));
-    for (int32_t m = 0; m < n_img; ++m) {
-        for (int r = 0; r < 3; ++r) {
-            for (int c = 0; c < 3; ++c) R[9 * m + 3 * r + c] = Rcw_all[m](r, c);
-            t[3 * m + r] = tcw_all[m][r];
-        }
-    }
-    std::vector<int64_t> off(comps.size() + 1, 0);
+    off.assign(comps.size() + 1, 0);
     for (size_t c = 0; c < comps.size(); ++c) off[c + 1] = off[c] + static_cast<int64_t>(comps[c].size());
-    std::vector<int32_t> img(static_cast<size_t>(off.back()));
-    std::vector<float> uv(2 * static_cast<size_t>(off.back()));
+    img.resize(static_cast<size_t>(off.back()));
+    uv.resize(2 * static_cast<size_t>(off.back()));
     for (size_t c = 0; c < comps.size(); ++c)
         for (size_t i = 0; i < comps[c].size(); ++i) {
             const size_t o = static_cast<size_t>(off[c]) + i;
@@ -241,22 +234,184 @@ void fuse_components(const std::vector<Component> &comps, const KeypointTable &a
             uv[2 * o] = all_keypoints[im][kp].x;
             uv[2 * o + 1] = all_keypoints[im][kp].y;
         }
-    std::vector<uint8_t> status(comps.size() + 1), kept(img.size() + 1);
-    std::vector<double> X(3 * (comps.size() + 1)), err(comps.size() + 1);
-    if (lvba_fuse_tracks(device, depth, n_img, R.data(), t.data(), intr, static_cast<int64_t>(comps.size()), off.data(), img.data(),
-                         uv.data(), opts, status.data(), X.data(), err.data(), kept.data()) != LVBA_OK)
-        throw std::runtime_error(std::string("lvba_fuse_tracks: ") + lvba_last_error());
+}
+// The GPU batch: a callable (comps) -> FusedBatch bound to the cameras, the depth images and the thresholds.
+template <class KeypointTable, class RotVec, class TransVec>
+struct GpuFuse {
+    const KeypointTable &all_keypoints;
+    std::vector<double> R, t;
+    int32_t n_img;
+    const double *intr;
+    lvba_depth_t depth;
+    const lvba_fuse_opts *opts;
+    int device;
+    GpuFuse(const KeypointTable &kps, const RotVec &Rcw_all, const TransVec &tcw_all, const double intr_[8], lvba_depth_t depth_,
+            const lvba_fuse_opts *opts_, int device_)
+        : all_keypoints(kps), n_img(static_cast<int32_t>(Rcw_all.size())), intr(intr_), depth(depth_), opts(opts_), device(device_)
+    {
+        R.resize(9 * static_cast<size_t>(n_img));
+        t.resize(3 * static_cast<size_t>(n_img));
+        for (int32_t m = 0; m < n_img; ++m)
+            for (int r = 0; r < 3; ++r) {
+                for (int c = 0; c < 3; ++c) R[9 * m + 3 * r + c] = Rcw_all[m](r, c);
+                t[3 * m + r] = tcw_all[m][r];
+            }
+    }
+    template <class Component>
+    FusedBatch operator()(const std::vector<Component> &comps) const
+    {
+        FusedBatch out;
+        std::vector<int32_t> img;
+        std::vector<float> uv;
+        pack_components(comps, all_keypoints, out.off, img, uv);
+        out.status.assign(comps.size() + 1, 0);
+        out.kept.assign(img.size() + 1, 0);
+        out.X.assign(3 * (comps.size() + 1), 0.0);
+        std::vector<double> err(comps.size() + 1);
+        if (lvba_fuse_tracks(device, depth, n_img, R.data(), t.data(), intr, static_cast<int64_t>(comps.size()), out.off.data(),
+                             img.data(), uv.data(), opts, out.status.data(), out.X.data(), err.data(), out.kept.data()) != LVBA_OK)
+            throw std::runtime_error(std::string("lvba_fuse_tracks: ") + lvba_last_error());
+        return out;
+    }
+};
+template <class Track, class Component>
+Track make_track(const Component &comp, const FusedBatch &fb, size_t c)
+{
+    Track tr;
+    tr.Xw_fused[0] = fb.X[3 * c]; tr.Xw_fused[1] = fb.X[3 * c + 1]; tr.Xw_fused[2] = fb.X[3 * c + 2];
+    tr.observations.assign(comp.begin(), comp.end());
+    for (size_t i = 0; i < comp.size(); ++i)
+        if (fb.kept[static_cast<size_t>(fb.off[c]) + i]) tr.inlier_indices.push_back(static_cast<int>(i));
+    return tr;
+}
+
+// Drop-in for the per-component body of LvbaSystem::BuildTracksAndFuse3D (src/lvba_system.cpp:1000-1225) for a caller that
+// keeps its own BFS: the components that pass the two size checks, each in ONE BFS order, in one call:
+//       lvba::fuse_components<Track>(comps, all_keypoints_, Rcw_all_optimized_, tcw_all_optimized_, intr, depth /*or nullptr*/,
+//                                    opts, tracks_, comp_track);       // comp_track[c] = index into tracks_ or -1
+// (The reference meets a dropped component again from its next member -- build_tracks_and_fuse below does that too.)
+// Track needs the reference's members Xw_fused, observations, inlier_indices (include/utils.hpp:150-156); keypoints .x / .y.
+template <class Track, class Component, class KeypointTable, class RotVec, class TransVec>
+void fuse_components(const std::vector<Component> &comps, const KeypointTable &all_keypoints, const RotVec &Rcw_all,
+                     const TransVec &tcw_all, const double intr[8], lvba_depth_t depth, const lvba_fuse_opts *opts,
+                     std::vector<Track> &tracks, std::vector<int> &comp_track, int device = 0)
+{
+    const GpuFuse<KeypointTable, RotVec, TransVec> fuse(all_keypoints, Rcw_all, tcw_all, intr, depth, opts, device);
+    const FusedBatch fb = fuse(comps);
     comp_track.assign(comps.size(), -1);
     for (size_t c = 0; c < comps.size(); ++c) {
-        if (!status[c]) continue;
-        Track tr;
-        tr.Xw_fused[0] = X[3 * c]; tr.Xw_fused[1] = X[3 * c + 1]; tr.Xw_fused[2] = X[3 * c + 2];
-        tr.observations.assign(comps[c].begin(), comps[c].end());
-        for (size_t i = 0; i < comps[c].size(); ++i)
-            if (kept[static_cast<size_t>(off[c]) + i]) tr.inlier_indices.push_back(static_cast<int>(i));
+        if (!fb.status[c]) continue;
         comp_track[c] = static_cast<int>(tracks.size());
-        tracks.push_back(std::move(tr));
+        tracks.push_back(make_track<Track>(comps[c], fb, c));
     }
+}
+
+// The whole track loop (:921-1263) with the fusion batched.  all_matches: the reference's table in pairIndex order
+// (include/utils.hpp:286-291), entries (key point in image i, key point in image j), i < j.  `fuse` is a callable
+// (std::vector<std::vector<std::pair<int,int>>>) -> FusedBatch; see build_tracks_and_fuse for the GPU one.
+// What the reference does one component at a time is done in rounds: round r fuses, in one batch, the r-th attempt of every
+// component that is still dropped -- the reference releases a dropped component (:1197, :1203) and meets it again at its next
+// member in scan order, i.e. in another BFS order.  tracks come out in the reference's order (by the key point the successful
+// BFS started from); obs_to_track (optional) as the reference leaves it: track index, or -1.
+template <class Track, class KeypointTable, class MatchTable, class Fuse>
+void build_tracks_and_fuse_with(const KeypointTable &all_keypoints, const MatchTable &all_matches, int obser_thr, Fuse &&fuse,
+                                std::vector<Track> &tracks, std::vector<std::vector<int>> *obs_to_track = nullptr)
+{
+    typedef std::pair<int, int> Obs;
+    typedef std::vector<Obs> Comp;
+    const int N = static_cast<int>(all_keypoints.size());
+    std::vector<std::vector<std::vector<Obs>>> adj(N);
+    for (int i = 0; i < N; ++i) adj[i].resize(all_keypoints[i].size());
+    for (int i = 0; i < N - 1; ++i)
+        for (int j = i + 1; j < N; ++j) {
+            const size_t idx = static_cast<size_t>(i * (2 * N - i - 1) / 2 + (j - i - 1)); // pairIndex
+            if (idx >= all_matches.size()) continue;
+            for (const auto &m : all_matches[idx]) {
+                const int ki = m.first, kj = m.second;
+                if (ki < 0 || kj < 0 || ki >= static_cast<int>(adj[i].size()) || kj >= static_cast<int>(adj[j].size())) continue;
+                adj[i][ki].push_back(Obs(j, kj));
+                adj[j][kj].push_back(Obs(i, ki));
+            }
+        }
+    std::vector<std::vector<int>> stamp(N);
+    for (int i = 0; i < N; ++i) stamp[i].assign(all_keypoints[i].size(), 0);
+    int epoch = 0;
+    auto bfs = [&](const Obs &start) {
+        ++epoch;
+        Comp comp;
+        comp.push_back(start);
+        stamp[start.first][start.second] = epoch;
+        for (size_t head = 0; head < comp.size(); ++head) {
+            const Obs cur = comp[head];
+            for (const Obs &nb : adj[cur.first][cur.second])
+                if (stamp[nb.first][nb.second] != epoch) {
+                    stamp[nb.first][nb.second] = epoch;
+                    comp.push_back(nb);
+                }
+        }
+        return comp;
+    };
+    // components that pass the size checks (:1000, :1012), members in scan order
+    std::vector<Comp> members;
+    {
+        std::vector<std::vector<char>> seen(N);
+        for (int i = 0; i < N; ++i) seen[i].assign(all_keypoints[i].size(), 0);
+        for (int i = 0; i < N; ++i)
+            for (int ki = 0; ki < static_cast<int>(adj[i].size()); ++ki) {
+                if (seen[i][ki] || adj[i][ki].empty()) continue;
+                Comp comp = bfs(Obs(i, ki));
+                std::vector<char> has(N, 0);
+                int n_img = 0;
+                for (const Obs &o : comp) {
+                    seen[o.first][o.second] = 1;
+                    if (!has[o.first]) { has[o.first] = 1; ++n_img; }
+                }
+                if (static_cast<int>(comp.size()) < obser_thr || n_img < obser_thr) continue;
+                std::sort(comp.begin(), comp.end());
+                members.push_back(std::move(comp));
+            }
+    }
+    struct Done { Obs start; Track track; };
+    std::vector<Done> done;
+    std::vector<size_t> pending(members.size());
+    for (size_t c = 0; c < members.size(); ++c) pending[c] = c;
+    for (size_t attempt = 0; !pending.empty(); ++attempt) {
+        std::vector<Comp> orders;
+        orders.reserve(pending.size());
+        for (size_t c : pending) orders.push_back(bfs(members[c][attempt]));
+        const FusedBatch fb = fuse(orders);
+        std::vector<size_t> next;
+        for (size_t n = 0; n < pending.size(); ++n) {
+            const size_t c = pending[n];
+            if (fb.status[n]) done.push_back(Done{members[c][attempt], make_track<Track>(orders[n], fb, n)});
+            else if (attempt + 1 < members[c].size()) next.push_back(c);
+        }
+        pending.swap(next);
+    }
+    std::sort(done.begin(), done.end(), [](const Done &x, const Done &y) { return x.start < y.start; });
+    if (obs_to_track) {
+        obs_to_track->assign(N, std::vector<int>());
+        for (int i = 0; i < N; ++i) (*obs_to_track)[i].assign(all_keypoints[i].size(), -1);
+    }
+    for (Done &d : done) {
+        if (obs_to_track)
+            for (const Obs &o : d.track.observations) (*obs_to_track)[o.first][o.second] = static_cast<int>(tracks.size());
+        tracks.push_back(std::move(d.track));
+    }
+}
+// Replaces the body of LvbaSystem::BuildTracksAndFuse3D from :923 to :1246:
+//       tracks_.clear();
+//       lvba::build_tracks_and_fuse<Track>(all_keypoints_, all_matches_, Rcw_all_optimized_, tcw_all_optimized_, intr, depth, &opts, tracks_);
+//       tracks_before_ = tracks_;
+template <class Track, class KeypointTable, class MatchTable, class RotVec, class TransVec>
+void build_tracks_and_fuse(const KeypointTable &all_keypoints, const MatchTable &all_matches, const RotVec &Rcw_all,
+                           const TransVec &tcw_all, const double intr[8], lvba_depth_t depth, const lvba_fuse_opts *opts,
+                           std::vector<Track> &tracks, std::vector<std::vector<int>> *obs_to_track = nullptr, int device = 0)
+{
+    lvba_fuse_opts o;
+    if (opts) o = *opts; else lvba_fuse_default_opts(&o);
+    const GpuFuse<KeypointTable, RotVec, TransVec> fuse(all_keypoints, Rcw_all, tcw_all, intr, depth, &o, device);
+    build_tracks_and_fuse_with<Track>(all_keypoints, all_matches, o.obser_thr, fuse, tracks, obs_to_track);
 }
 
 } // namespace lvba

@@ -144,9 +144,50 @@ def main_fusion():
     print("fusion_small", np.bincount(st, minlength=3).tolist(), "dropped / triangulated / depth-fused")
 
 
+def main_ref_system():
+    """The whole pipeline of the reference (src/lvba_system.cpp + src/dataset_io.cpp compiled against oracle/shim, see
+    oracle/ref_glue_system.cpp) on the synthetic sequence of tests/test_gpu_pipeline.py: what ITS stages answer, frozen for the
+    GPU test (needs /root/reference)."""
+    import importlib
+    import shutil
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_pipeline as tp
+    import test_ref_system as trs
+    from oracle import ref_system as rs
+    ds = importlib.import_module("global-lvba_amd.dataset")
+    d = tp._dataset()
+    root = os.path.join(tempfile.mkdtemp(), "seq")
+    trs.write_sequence(root, d, ds)
+    trs.INTR, trs.W, trs.H = tp.INTR, tp.W, tp.H
+    S = rs.ReferenceSystem(root, trs.reference_params(tp))
+    L = ds.load_dataset(root)
+    _, img_poses = ds.load_poses_tum(os.path.join(root, "all_image", "image_poses.txt"), 1)
+    S.init()
+    S.run_lidar_ba()
+    R1, p1, ts = S.scan_poses()
+    S.build_grid_map(); S.update_camera_poses()
+    depth = S.generate_depth(tp.W, tp.H)
+    Rcw, tcw = S.cam_poses(True)
+    S.set_features(d["kps"], {pr: m for pr, m in zip(d["pairs"], d["matches"])})
+    tracks = S.build_tracks()
+    P = S.optimize()
+    np.savez_compressed(os.path.join(HERE, "ref_system.npz"), cloud_digest=np.array([float(np.asarray(c, np.float64).sum()) for c in d["clouds"]]),
+                        scan_poses_in=L["poses"], image_poses_in=img_poses, scan_times=ts, image_times=S.image_ids(),
+                        scan_poses_out=np.concatenate([R1.reshape(-1, 9), p1], 1), Rcw=Rcw, tcw=tcw,
+                        depth_filled=(depth > 0).sum(axis=(1, 2)), depth_sum=depth.astype(np.float64).sum(axis=(1, 2)),
+                        track_start=np.array([t["obs"][0] for t in tracks], np.int32), track_len=np.array([len(t["obs"]) for t in tracks]),
+                        track_X=np.array([t["X"] for t in tracks]), track_inliers=np.array([len(t["inliers"]) for t in tracks]),
+                        n_points=P["n_points"], n_residuals=len(P["kind"]), cost0=P["cost0"])
+    print("ref_system", len(tracks), "tracks,", P["n_points"], "with a plane, cost0", P["cost0"])
+    S.close()
+    shutil.rmtree(os.path.dirname(root), ignore_errors=True)
+
+
 if __name__ == "__main__":
     main()
     main_visual()
     main_voxel()
     main_ref()
     main_fusion()
+    main_ref_system()

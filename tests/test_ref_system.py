@@ -195,6 +195,59 @@ def test_device_fusion_code_reproduces_the_reference_tracks(run, tmp_path_factor
         assert np.nonzero(kept[off[n]:off[n + 1]])[0].tolist() == sorted(t["inliers"].tolist())
 
 
+def _same_tracks(ref_tracks, off, obs_img, obs_kp, kept, X):
+    assert len(off) - 1 == len(ref_tracks)
+    for n, t in enumerate(ref_tracks):
+        a, b = int(off[n]), int(off[n + 1])
+        assert np.array_equal(t["obs"][:, 0], obs_img[a:b]) and np.array_equal(t["obs"][:, 1], obs_kp[a:b])
+        assert np.abs(X[n] - t["X"]).max() < 1e-10
+        assert np.nonzero(kept[a:b])[0].tolist() == sorted(t["inliers"].tolist())
+
+
+def test_product_host_loops_reproduce_the_reference_tracks(run, tmp_path_factory):
+    """The product's two host-side track loops -- global-lvba_amd/pipeline.py:build_tracks_and_fuse (Python mirror) and
+    include/lvba_adapter.hpp:build_tracks_and_fuse_with (the C++ binding) -- with the device code of fusion_device.h compiled for
+    the host in the place of the GPU call: the reference's tracks, in its order, retries included."""
+    import ctypes
+    import subprocess
+    import test_tracks_host as th
+    from conftest import ROOT
+    r = run
+    lib = th.build_emul(tmp_path_factory.mktemp("emul_tracks_loop"))
+    T = r.pipe.build_tracks_and_fuse(r.d["kps"], r.d["pairs"], r.d["matches"],
+                                     lambda o, i, u: th._fuse(lib, o, i, u, r.depth, r.Rcw, r.tcw, INTR))
+    _same_tracks(r.tracks, T["obs_off"], T["obs_img"], T["obs_kp"], T["kept"], T["X"])
+    assert (T["attempts"] > 0).sum() >= 1 and (T["component_status"] > 0).sum() == len(r.tracks)
+    # the C++ adapter
+    so = str(tmp_path_factory.mktemp("adapter_emul") / "libadapter_emul.so")
+    libdir = os.path.join(ROOT, "global-lvba_amd")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", os.path.join(ROOT, "tests", "adapter_tracks_emul.cpp"),
+                           "-o", so, "-L", libdir, "-llvba_hip", f"-Wl,-rpath,{libdir}"])
+    ad = ctypes.CDLL(so)
+    nk = np.array([len(k) for k in r.d["kps"]], np.int32)
+    kp_xy = np.concatenate([np.asarray(k, np.float32)[:, :2] for k in r.d["kps"]]).astype(np.float32)
+    pairs = np.array(r.d["pairs"], np.int32)
+    moff = np.concatenate([[0], np.cumsum([len(m) for m in r.d["matches"]])]).astype(np.int64)
+    matches = np.concatenate(r.d["matches"]).astype(np.int32)
+    K = int(nk.sum())
+    tl, X, obs, inl, o2t = np.zeros(K, np.int32), np.zeros((K, 3)), np.zeros((K, 2), np.int32), np.zeros(K, np.uint8), np.zeros(K, np.int32)
+    depth = np.ascontiguousarray(r.depth, np.float32)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    ad.adapter_build_tracks.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_int] * 2 + \
+        [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_double, ctypes.c_double] + [ctypes.c_void_p] * 5
+    Rcw, tcw, intr = np.ascontiguousarray(r.Rcw), np.ascontiguousarray(r.tcw), np.ascontiguousarray(INTR)
+    n = ad.adapter_build_tracks(len(nk), P(nk), P(kp_xy), len(pairs), P(pairs), P(moff), P(matches), P(depth), W, H, P(Rcw), P(tcw), P(intr),
+                                3, 8.0, 3.0, P(tl), P(X), P(obs), P(inl), P(o2t))
+    off = np.concatenate([[0], np.cumsum(tl[:n])])
+    _same_tracks(r.tracks, off, obs[:, 0], obs[:, 1], inl, X)
+    # obs_to_track as the reference leaves it: the track of every member, -1 elsewhere
+    want = -np.ones(K, np.int32)
+    base = np.concatenate([[0], np.cumsum(nk)])
+    for ti, t in enumerate(r.tracks):
+        want[base[t["obs"][:, 0]] + t["obs"][:, 1]] = ti
+    assert np.array_equal(o2t, want)
+
+
 def test_problem_handed_to_ceres(run):
     r = run
     P = r.problem
