@@ -4,10 +4,11 @@ Restates (paths relative to /root/reference)
   undistortPixelToNormalized / distortNormalized / projectWorldToPixel   include/utils.hpp:168-233
   TriangulateTrackDLT                                                     src/lvba_system.cpp:50-111
   ComputeMeanReproj                                                       src/lvba_system.cpp:8-48
-The reference walks an unordered_map<image, observation>; the order only changes the rounding of the sums.  Each track here
-is the already de-duplicated list (one observation per image).  The camera model (undistort / distort / project) is PINNED
-against the reference's own include/utils.hpp compiled with the stand-ins of oracle/shim (tests/test_ref_pin.py); the DLT and
-the mean reprojection error live in src/lvba_system.cpp (ROS / OpenCV / Ceres: cannot be built here) -> PARITY UNPINNED.
+The reference walks an unordered_map<image, observation>; the caller passes the observations in that order
+(fusion_oracle.umap_order), here it only changes the rounding of the sums.  Each track is the already de-duplicated list (one
+observation per image).  PINNED: the camera model (undistort / distort / project) against the reference's own
+include/utils.hpp (tests/test_ref_pin.py); the DLT and the mean reprojection error against src/lvba_system.cpp itself, through
+BuildTracksAndFuse3D (oracle/ref_glue_system.cpp, tests/test_ref_system.py: landmarks to 1e-14).
 """
 from __future__ import annotations
 

@@ -11,7 +11,9 @@ Restates the reference's visual problem (paths relative to /root/reference):
 THE TWO COST FUNCTORS ARE PINNED against the reference's own include/utils.hpp, compiled from /root/reference with the
 stand-ins of oracle/shim and differentiated with forward-mode Jets as ceres::AutoDiffCostFunction would
 (tests/test_ref_pin.py: residuals and ambient Jacobians to 1e-11, also against csrc/visual_math.h directly) -- except
-ceres::QuaternionRotatePoint, which the stand-in restates from memory.  THE SOLVE IS PARITY UNPINNED: its arithmetic lives in Ceres Solver 2.1.0 (README.md:20, find_package in
+ceres::QuaternionRotatePoint, which the stand-in restates from memory.  The problem construction (blocks, constancy,
+manifold, residual set, sigmas, no robust loss) and its cost at the initial point are pinned against src/lvba_system.cpp:1571-1640 itself through a recording ceres::Problem (tests/test_ref_system.py).
+THE SOLVER ITERATIONS ARE PARITY UNPINNED: its arithmetic lives in Ceres Solver 2.1.0 (README.md:20, find_package in
 CMakeLists.txt:33), which is not in /root/reference and not installed here.  Its published algorithm is restated
 FROM MEMORY of ceres-solver 2.1.0 (internal/ceres/trust_region_minimizer.cc, levenberg_marquardt_strategy.cc,
 manifold.cc, rotation.h):

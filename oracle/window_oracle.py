@@ -6,9 +6,10 @@ BALM2::damping_iter (:264), re-alignment of the optimised window to the odometry
 relative poses to the anchor (:284-299), merge of the transformed clouds with fp32 write-back (pl_transform,
 include/BALM/tools.hpp:385-395) and down_sampling_voxel2 (tools.hpp:300-359).
 down_sampling_voxel2 emits its survivors in unordered_map order (unspecified); here: sorted by voxel key (x, y, z).
-The window LOOP itself lives in src/lvba_system.cpp (ROS / OpenCV / Ceres / SiftGPU: cannot be built here) and is PARITY
-UNPINNED; its pieces are pinned against the reference's own code (tests/test_ref_pin.py): map build, damping_iter,
-pl_transform and down_sampling_voxel2 (bit-identical survivors).
+PINNED: the pieces (map build, damping_iter, pl_transform, down_sampling_voxel2 with bit-identical survivors) against the
+reference's BALM headers (tests/test_ref_pin.py), and the loops themselves -- runWindowBA, runLidarBA, the anchor merge of
+optimizeCameraPoses -- against src/lvba_system.cpp compiled as it lies (oracle/ref_glue_system.cpp, tests/test_ref_system.py:
+refined poses to 1e-12, anchor indices and relative poses equal).
 """
 from __future__ import annotations
 

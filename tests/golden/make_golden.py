@@ -3,11 +3,11 @@
 The reference has no tests / golden vectors of its own.  Two kinds of fixtures are written here:
   * balm_*.npz, visual_small.npz, voxel_small.npz, tracks_small.npz -- inputs + the answers of OUR restatement
     (oracle/*.py): they freeze the oracle, any later change to oracle/ or to the generator that alters results is caught;
-  * ref_balm.npz, ref_voxel.npz (main_ref) -- the answers of THE REFERENCE'S OWN CODE on the same inputs:
-    include/BALM/{tools,bavoxel}.hpp compiled from /root/reference against the Eigen / PCL stand-ins of oracle/shim
-    (oracle/_ref/libbalm_ref.so, `make -C oracle ref`).  These are what the -m gpu tests on the GPU box (where
-    /root/reference does not exist) hold the HIP path against.  The visual stage (Ceres) and src/lvba_system.cpp (ROS,
-    OpenCV, SiftGPU) cannot be built here; their fixtures stay restatement-only (PARITY UNPINNED for those pieces).
+  * ref_balm.npz, ref_voxel.npz (main_ref), ref_system.npz (main_ref_system) -- the answers of THE REFERENCE'S OWN CODE on
+    the same inputs: include/BALM/{tools,bavoxel}.hpp, and src/lvba_system.cpp + src/dataset_io.cpp (the whole pipeline up
+    to ceres::Solve), compiled from /root/reference against the stand-ins of oracle/shim (oracle/_ref/*.so, `make -C oracle
+    ref`).  These are what the -m gpu tests on the GPU box (where /root/reference does not exist) hold the HIP path
+    against.  The iterations of the visual stage's solver live in Ceres (absent): visual_small.npz stays restatement-only.
 
     python tests/golden/make_golden.py
 """
