@@ -172,40 +172,21 @@ def build_tracks(n_keypoints, pairs, matches, obser_thr=3):
 
 def triangulate_and_filter(Rcw, tcw, keypoints, obs_off, obs_img, obs_kp, intr, min_view_angle_deg=8.0,
                            reproj_mean_thr_px=3.0, device=0):
-    """The triangulation candidate of BuildTracksAndFuse3D (src/lvba_system.cpp:1108-1160): seed DLT over all images of the
-    track, greedy view-angle filter against the seed (an observation is kept if its ray makes at least min_view_angle with
-    one already kept ray -- upstream walks an unordered_map, here: track order), DLT again over the kept observations,
-    accepted if its mean reprojection error <= reproj_mean_thr_px.  Both DLT passes run on the GPU
-    (lvba_triangulate_tracks).  fuse_tracks() below runs both candidates (depth-fused and triangulated) and the selection in
-    one kernel; this function remains as the two-pass host-driven form of the triangulation candidate.
+    """The triangulation candidate of BuildTracksAndFuse3D alone (src/lvba_system.cpp:1108-1160): seed DLT over all images of
+    the track, greedy view-angle filter against the seed, DLT again over the kept observations, accepted if its mean
+    reprojection error <= reproj_mean_thr_px -- i.e. fuse_tracks() without depth images (one kernel; the images are visited in
+    the order of the reference's unordered_map, see csrc/tracks_device.h).  Tracks as build_tracks returns them.
     Returns (ok [T], X [T,3], mean_reproj [T], kept_off [T+1], kept_img, kept_kp)."""
-    Rcw = np.ascontiguousarray(Rcw, np.float64).reshape(-1, 3, 3)
-    tcw = np.ascontiguousarray(tcw, np.float64).reshape(-1, 3)
-    uv = np.array([keypoints[i][k][:2] for i, k in zip(obs_img, obs_kp)], np.float64).reshape(-1, 2)
-    ok0, X0, _, _ = triangulate_tracks(Rcw, tcw, obs_off, obs_img, uv, intr, device)
-    Cw = -np.einsum("nji,nj->ni", Rcw, tcw)
-    cos_min = np.cos(np.radians(min_view_angle_deg))
-    koff, kimg, kkp, kuv = [0], [], [], []
-    for t in range(len(obs_off) - 1):
-        a, b = obs_off[t], obs_off[t + 1]
-        if ok0[t] and b - a >= 4:
-            dirs = []
-            for o in range(a, b):
-                d = X0[t] - Cw[obs_img[o]]
-                n = np.linalg.norm(d)
-                if n < 1e-6:
-                    continue
-                d = d / n
-                if not dirs or min(float(d @ e) for e in dirs) <= cos_min:
-                    dirs.append(d)
-                    kimg.append(obs_img[o]); kkp.append(obs_kp[o]); kuv.append(uv[o])
-        koff.append(len(kimg))
-    koff = np.asarray(koff, np.int64)
-    kimg = np.asarray(kimg, np.int32); kkp = np.asarray(kkp, np.int32)
-    kuv = np.asarray(kuv, np.float64).reshape(-1, 2)
-    ok1, X1, err1, _ = triangulate_tracks(Rcw, tcw, koff, kimg, kuv, intr, device)
-    ok = (ok1 > 0) & (np.diff(koff) >= 4) & (err1 <= reproj_mean_thr_px)
-    return ok, X1, err1, koff, kimg, kkp
+    obs_off = np.asarray(obs_off, np.int64)
+    obs_img = np.asarray(obs_img, np.int32)
+    obs_kp = np.asarray(obs_kp, np.int32)
+    uv = np.array([keypoints[i][k][:2] for i, k in zip(obs_img, obs_kp)], np.float32).reshape(-1, 2)
+    status, X, err, kept = fuse_tracks(obs_off, obs_img, uv, Rcw, tcw, intr, depth=None, obser_thr=3,
+                                       min_view_angle_deg=min_view_angle_deg, reproj_mean_thr_px=reproj_mean_thr_px, device=device)
+    sel = np.nonzero(kept)[0]
+    track_of = np.repeat(np.arange(len(obs_off) - 1), np.diff(obs_off))
+    koff = np.concatenate([[0], np.cumsum(np.bincount(track_of[sel], minlength=len(obs_off) - 1))]).astype(np.int64)
+    return status == 1, X, err, koff, obs_img[sel], obs_kp[sel]
 
 
 class DepthImages:
