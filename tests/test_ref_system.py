@@ -295,3 +295,49 @@ def test_problem_handed_to_ceres(run):
     Rn, tn = r.S.cam_poses(True)
     qn = q / np.linalg.norm(q, axis=1, keepdims=True)
     assert np.abs(r.pipe.quat_wxyz_to_rot(qn) - Rn).max() < 1e-14 and np.array_equal(tn, t)
+
+
+@pytest.mark.parametrize("variant", ["no_window", "odometry_anchors", "stage2_only", "ragged_windows", "image_stride"])
+def test_run_lidar_ba_variants(run, variant):
+    """The switches of runLidarBA / runWindowBA / DatasetIO (config keys window_ba/*, BALM_stage1/enable,
+    data_config/image_sample_step) against the same switches of the restatements."""
+    r = run
+    L = r.loaded
+    p = reference_params(r.tp)
+    kw = dict(window_enable=True, window_size=CFG["window_size"], anchor_leaf=CFG["anchor_leaf"], use_rel=True, stage1_enable=True,
+              stage_voxel_size=CFG["stage_voxel_size"], stage_eigen_ratio=CFG["stage_eigen_ratio"],
+              # the plane thresholds recut() uses are a process-wide global of the reference (eigen_value_array, set per stage by
+              # set_eigen_ratio_array, bavoxel.hpp): the window BA of a second LvbaSystem in the same process sees what the last
+              # stage of the first one (the `run` fixture) left there, not the built-in defaults a fresh process starts with
+              window_eigen_ratio=CFG["stage_eigen_ratio"][1])
+    if variant == "no_window":                       # :221-229: every scan is its own anchor
+        p["window_ba/enable"] = False; kw["window_enable"] = False
+    elif variant == "odometry_anchors":              # :268-279: window BA only thins the clouds, poses stay the odometry's
+        p["window_ba/use_window_ba_rel"] = False; kw["use_rel"] = False
+    elif variant == "stage2_only":
+        p["BALM_stage1/enable"] = False; kw["stage1_enable"] = False
+    elif variant == "ragged_windows":                # 12 scans in windows of 5, 5, 2
+        p["window_ba/size"] = 5; kw["window_size"] = 5
+    elif variant == "image_stride":
+        p["data_config/image_sample_step"] = 5
+    S = rs.ReferenceSystem(r.root, p)
+    try:
+        if variant == "image_stride":                # handleImages / handleCamPoses: every 5th image and every 5th pose line
+            ids = r.pipe.list_image_ids(os.path.join(r.root, "all_image"), 5)
+            assert S.n_images == 3 and np.array_equal(S.image_ids(), ids)
+            _, img = r.ds.load_poses_tum(os.path.join(r.root, "all_image", "image_poses.txt"), 5)
+            Ri, ti = S.image_poses()
+            assert np.abs(img[:, :9].reshape(-1, 3, 3) - Ri).max() < 1e-15 and np.array_equal(img[:, 9:], ti)
+            return
+        S.init()
+        aidx, relR, relp = S.run_lidar_ba()
+        R1, p1, _ = S.scan_poses()
+    finally:
+        S.close()
+    out, rep = wo.run_lidar_ba(L["clouds"], L["poses"], **kw)
+    assert np.abs(out[:, :9].reshape(-1, 3, 3) - R1).max() < 1e-9 and np.abs(out[:, 9:] - p1).max() < 1e-9
+    assert np.abs(p1 - r.p0).max() > 0.01
+    if variant == "no_window":
+        assert aidx.tolist() == list(range(12)) and rep["n_anchors"] == 12
+    if variant == "ragged_windows":
+        assert aidx.tolist() == [0] * 5 + [1] * 5 + [2] * 2
