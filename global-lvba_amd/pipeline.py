@@ -290,7 +290,10 @@ def extrinsics_from_config(Rcl, Pcl, extrinsic_R, extrinsic_T):
 def run_dataset(data_path, colmap_db_path, intr, width, height, Rcl, Pcl, extrinsic_R=np.eye(3), extrinsic_T=np.zeros(3),
                 image_sample_step=1, out_dir=None, device=0, **cfg):
     """initFromDatasetIO + runFullPipeline on a dataset directory; with out_dir, the refined LiDAR poses (TUM) and the COLMAP
-    text files images.txt / points3D.txt the reference writes (src/lvba_system.cpp:2018-2137) are saved there."""
+    text files images.txt / points3D.txt the reference writes (src/lvba_system.cpp:2018-2137) are saved there.  images.txt is
+    the reference's, character for character (tests/test_ref_system.py); points3D.txt has the reference's format but holds
+    the refined visual landmarks in white -- the reference fills it with its LiDAR map coloured from the images
+    (VisualizeOptComparison), which needs an image codec and is visualisation, outside the scope contract."""
     import os
     from . import dataset as D
     ds = D.load_dataset(data_path)

@@ -289,4 +289,19 @@ void ref_sys_problem_residuals(int32_t *kind, int32_t *cam, int32_t *point, doub
     }
 }
 
+// VisualizeOptComparison (:1932-2144) = the COLMAP text export (<data_path>/Colmap/sparse/images.txt, points3D.txt) after
+// colourising the LiDAR map from the images.  No image codec here: cv::imread hands out a synthetic w x h pattern (see
+// oracle/shim/opencv2/opencv.hpp).  Empties DatasetIO::pl_fulls_ as the reference does (:2143): call it last.
+int ref_sys_export_colmap(void *h, int w, int hgt)
+{
+    cv::lvba_synthetic_image_size()[0] = w; cv::lvba_synthetic_image_size()[1] = hgt;
+    const int rc = guarded([&] {
+        SYS(h).VisualizeOptComparison(SYS(h).images_ids_, true);
+        SYS(h).fout_poses_after.close();
+        SYS(h).fout_points_after.close();
+    });
+    cv::lvba_synthetic_image_size()[0] = cv::lvba_synthetic_image_size()[1] = 0;
+    return rc;
+}
+
 } // extern "C"

@@ -50,6 +50,7 @@ def load():
         lib.ref_sys_set_fusion_params.argtypes = [vp, c_int, c_dbl, c_dbl]
         lib.ref_sys_track_sizes.restype, lib.ref_sys_track_sizes.argtypes = c_int, [vp, c_int, ctypes.POINTER(c_int)]
         lib.ref_sys_track.argtypes = [vp, c_int, f64p, i32p, i32p]
+        lib.ref_sys_export_colmap.restype, lib.ref_sys_export_colmap.argtypes = c_int, [vp, c_int, c_int]
         lib.ref_sys_optimize.restype = c_int
         lib.ref_sys_optimize.argtypes = [vp, vp, vp, vp, c_int, c_int]
         lib.ref_sys_problem_info.argtypes = [i32p]
@@ -196,6 +197,12 @@ class ReferenceSystem:
             self.lib.ref_sys_track(self.h, t, X, obs.reshape(-1), inl)
             out.append(dict(X=X, obs=obs, inliers=inl))
         return out
+
+    def export_colmap(self, width, height):
+        """VisualizeOptComparison: writes <dataset>/Colmap/sparse/{images,points3D}.txt (images are a synthetic pattern: b = x,
+        g = y, r = x + y mod 256).  Empties the reference's clouds: call it last."""
+        if self.lib.ref_sys_export_colmap(self.h, int(width), int(height)) != 0:
+            raise RuntimeError("reference VisualizeOptComparison threw")
 
     def optimize(self, solution=None):
         """optimizeCameraPoses with the recording ceres::Problem.  Returns the recorded problem, or None when the reference

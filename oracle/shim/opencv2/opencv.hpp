@@ -118,8 +118,23 @@ enum { INTER_LINEAR = 1, INTER_CUBIC = 2, COLOR_BGR2Lab = 44, COLOR_Lab2BGR = 56
 inline void initUndistortRectifyMap(const Mat &, const Mat &, const Mat &, const Mat &, Size, int, Mat &, Mat &) {}
 inline bool imwrite(const std::string &, const Mat &) { return true; }
 // unreachable on the tested paths: every call throws
-inline Mat imread(const std::string &, int = IMREAD_COLOR) { lvba_unavailable("cv::imread"); }
-inline void remap(const Mat &, Mat &, const Mat &, const Mat &, int) { lvba_unavailable("cv::remap"); }
+// no image codec: when the test glue has set a synthetic image size, imread hands out a deterministic BGR pattern of that size
+// (b, g, r) = (x mod 256, y mod 256, (x + y) mod 256) whatever the path -- enough for the reference's colourising export to
+// run; otherwise it throws
+inline int (&lvba_synthetic_image_size())[2] { static int wh[2] = {0, 0}; return wh; }
+inline Mat imread(const std::string &, int = IMREAD_COLOR)
+{
+    const int w = lvba_synthetic_image_size()[0], h = lvba_synthetic_image_size()[1];
+    if (w <= 0 || h <= 0) lvba_unavailable("cv::imread");
+    Mat m(h, w, CV_8UC3);
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            unsigned char *p = m.data + 3 * ((size_t)y * w + x);
+            p[0] = (unsigned char)(x % 256); p[1] = (unsigned char)(y % 256); p[2] = (unsigned char)((x + y) % 256);
+        }
+    return m;
+}
+inline void remap(const Mat &src, Mat &dst, const Mat &, const Mat &, int) { dst = src; } // undistorted previews are never read back
 inline void resize(const Mat &, Mat &, Size, double = 0, double = 0, int = 1) { lvba_unavailable("cv::resize"); }
 inline void cvtColor(const Mat &, Mat &, int) { lvba_unavailable("cv::cvtColor"); }
 inline void split(const Mat &, std::vector<Mat> &) { lvba_unavailable("cv::split"); }

@@ -341,3 +341,42 @@ def test_run_lidar_ba_variants(run, variant):
         assert aidx.tolist() == list(range(12)) and rep["n_anchors"] == 12
     if variant == "ragged_windows":
         assert aidx.tolist() == [0] * 5 + [1] * 5 + [2] * 2
+
+
+def test_colmap_text_export(run, tmp_path):
+    """The result writers (SURVEY 8(f) row 3): Colmap/sparse/images.txt and points3D.txt as LvbaSystem::VisualizeOptComparison
+    writes them (src/lvba_system.cpp:2018-2024, :2126-2137) against dataset.write_images_txt / write_points3d_txt.  The
+    reference colours its LiDAR map from the images; with no image codec the stand-in's imread hands out the pattern
+    (b, g, r) = (x, y, x + y) mod 256, so a point's colour tells the pixel it was drawn from."""
+    r = run
+    S = rs.ReferenceSystem(r.root, reference_params(r.tp))
+    try:
+        S.init()
+        S.build_grid_map(); S.update_camera_poses(); S.generate_depth(W, H)     # fills Rcw_all_optimized_ (no LiDAR BA: = odometry)
+        Rcw, tcw = S.cam_poses(True)
+        S.export_colmap(W, H)
+    finally:
+        S.close()
+    sparse = os.path.join(r.root, "Colmap", "sparse")
+    mine = tmp_path / "images.txt"
+    r.ds.write_images_txt(str(mine), r.pipe.rot_to_quat_wxyz(Rcw), tcw)
+    assert open(os.path.join(sparse, "images.txt")).read() == mine.read_text()
+    lines = open(os.path.join(sparse, "points3D.txt")).read().splitlines()
+    assert len(lines) > 1000
+    rows = np.array([[float(v) for v in ln.split()] for ln in lines])
+    assert np.array_equal(rows[:, 0], np.arange(len(rows))) and np.all(rows[:, 7] == 0)
+    mine_p = tmp_path / "points3D.txt"
+    r.ds.write_points3d_txt(str(mine_p), rows[:, 1:4], rows[:, 4:7])
+    assert mine_p.read_text().splitlines() == lines                                # same number formatting
+    # colours: r = (b + g) mod 256 for every point, and b, g are the pixel some camera sees the point at
+    rr, gg, bb = rows[:, 4].astype(int), rows[:, 5].astype(int), rows[:, 6].astype(int)
+    assert np.array_equal(rr, (bb + gg) % 256)
+    from oracle import track_oracle as to
+    hits = 0
+    for p, g, b in zip(rows[:200, 1:4], gg[:200], bb[:200]):
+        for m in range(len(Rcw)):
+            uv = to.project(INTR, Rcw[m], tcw[m], p)
+            if uv is not None and int(round(uv[0])) % 256 == b and int(round(uv[1])) % 256 == g:
+                hits += 1
+                break
+    assert hits >= 190                                                             # 6-decimal text coordinates: a few sit on a pixel edge
