@@ -118,8 +118,11 @@ ros::NodeHandle g_nh;
 
 template <class F> int guarded(F f)
 {
-    try { f(); return 0; }
-    catch (const std::exception &e) { std::fprintf(stderr, "[ref_sys] %s\n", e.what()); return -1; }
+    int rc = 0;
+    try { f(); }
+    catch (const std::exception &e) { std::fprintf(stderr, "[ref_sys] %s\n", e.what()); rc = -1; }
+    std::cout.flush(); std::fflush(stdout); // the reference narrates on stdout: hand it to the test runner's capture now, not at exit
+    return rc;
 }
 void put_R(const Eigen::Matrix3d &R, double *o) { for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) o[3 * i + j] = R(i, j); }
 void put_v(const Eigen::Vector3d &v, double *o) { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; }
