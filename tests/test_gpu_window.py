@@ -123,3 +123,25 @@ def test_window_threads_give_identical_results(pkg, synth, monkeypatch):
     assert len(a[1]) == len(b[1]) == 5
     for p, q in zip(a[1], b[1]):
         np.testing.assert_array_equal(p, q)
+
+
+def test_merge_only_matches_the_anchor_merge_of_the_visual_stage(pkg, synth):
+    """lvba_window_opts.merge_only = the anchor clouds optimizeCameraPoses rebuilds from the refined poses
+    (src/lvba_system.cpp:1466-1489: no window BA, every scan moved into the frame of its window's first scan with the poses
+    given, down_sampling_voxel2) against oracle/window_oracle.merge_anchors -- itself held against the reference's own function
+    through the planes it yields (tests/test_ref_system.py)."""
+    from oracle import window_oracle as wo
+    s = synth.make_scans(10, 8000, room=(10, 8, 4), origin=(-3.3, 7.1, 0.4), n_panels=8, seed=33, rot_sigma_deg=0.1,
+                         trans_sigma=0.03)
+    ap, ac = wo.merge_anchors(s["clouds"], s["poses"], 4, 0.05)
+    with pkg.Scans(s["clouds"]) as scans:
+        got = scans.window_ba(s["poses"], window_size=4, anchor_leaf=0.05, merge_only=True)
+    asc = got["anchor_scans"]
+    try:
+        np.testing.assert_array_equal(got["anchor_poses"], ap)
+        assert got["anchor_index"].tolist() == [0] * 4 + [1] * 4 + [2] * 2
+        assert asc.n_frames == len(ac) == 3
+        for a in range(3):
+            _compare_clouds(asc.download(a), ac[a])
+    finally:
+        asc.close()
