@@ -380,3 +380,31 @@ def test_colmap_text_export(run, tmp_path):
                 hits += 1
                 break
     assert hits >= 190                                                             # 6-decimal text coordinates: a few sit on a pixel edge
+
+
+@pytest.mark.parametrize("obser_thr,angle,thr", [(4, 5.0, 2.0), (3, 15.0, 1.0), (5, 2.0, 6.0)])
+def test_track_fusion_thresholds(run, tmp_path_factory, obser_thr, angle, thr):
+    """obser_thr_ / track_fusion/min_view_angle / track_fusion/reproj_mean_thr away from their defaults, on the unrefined
+    (odometry) cameras: the reference's tracks against the oracle and against the product's loop + device code on the host."""
+    import test_tracks_host as th
+    r = run
+    S = rs.ReferenceSystem(r.root, reference_params(r.tp))
+    try:
+        S.init()
+        S.build_grid_map(); S.update_camera_poses()
+        depth = S.generate_depth(W, H)
+        Rcw, tcw = S.cam_poses(True)
+        S.set_features(r.d["kps"], {pr: m for pr, m in zip(r.d["pairs"], r.d["matches"])})
+        tracks = S.build_tracks(obser_thr, angle, thr)
+    finally:
+        S.close()
+    mine = fo.build_tracks_and_fuse(r.d["kps"], r.d["pairs"], r.d["matches"], depth, Rcw, tcw, INTR, obser_thr=obser_thr,
+                                    min_view_angle_deg=angle, reproj_thr=thr)
+    assert len(mine) == len(tracks) > 20
+    for a, b in zip(tracks, mine):
+        assert np.array_equal(a["obs"], b["obs"]) and np.abs(a["X"] - b["X"]).max() < 1e-10
+        assert sorted(a["inliers"].tolist()) == np.nonzero(b["kept"])[0].tolist()
+    lib = th.build_emul(tmp_path_factory.mktemp("emul_thr"))
+    T = r.pipe.build_tracks_and_fuse(r.d["kps"], r.d["pairs"], r.d["matches"],
+                                     lambda o, i, u: th._fuse(lib, o, i, u, depth, Rcw, tcw, INTR, obser_thr, angle, thr), obser_thr)
+    _same_tracks(tracks, T["obs_off"], T["obs_img"], T["obs_kp"], T["kept"], T["X"])
