@@ -195,6 +195,34 @@ def test_device_fusion_code_reproduces_the_reference_tracks(run, tmp_path_factor
         assert np.nonzero(kept[off[n]:off[n + 1]])[0].tolist() == sorted(t["inliers"].tolist())
 
 
+def _adapter_tracks(r, matches, depth, Rcw, tcw, directory):
+    """include/lvba_adapter.hpp:build_tracks_and_fuse_with on the CPU (tests/adapter_tracks_emul.cpp).  Returns (off, obs, inlier
+    flags, X, obs_to_track)."""
+    import ctypes
+    import subprocess
+    from conftest import ROOT
+    so = os.path.join(str(directory), "libadapter_emul.so")
+    libdir = os.path.join(ROOT, "global-lvba_amd")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", os.path.join(ROOT, "tests", "adapter_tracks_emul.cpp"),
+                           "-o", so, "-L", libdir, "-llvba_hip", f"-Wl,-rpath,{libdir}"])
+    ad = ctypes.CDLL(so)
+    nk = np.array([len(k) for k in r.d["kps"]], np.int32)
+    kp_xy = np.concatenate([np.asarray(k, np.float32)[:, :2] for k in r.d["kps"]]).astype(np.float32)
+    pairs = np.array(r.d["pairs"], np.int32)
+    moff = np.concatenate([[0], np.cumsum([len(m) for m in matches])]).astype(np.int64)
+    mm = np.concatenate(matches).astype(np.int32)
+    K = int(nk.sum())
+    tl, X, obs, inl, o2t = np.zeros(K, np.int32), np.zeros((K, 3)), np.zeros((K, 2), np.int32), np.zeros(K, np.uint8), np.zeros(K, np.int32)
+    depth = np.ascontiguousarray(depth, np.float32)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    ad.adapter_build_tracks.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_int] * 2 + \
+        [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_double, ctypes.c_double] + [ctypes.c_void_p] * 5
+    Rcw, tcw, intr = np.ascontiguousarray(Rcw), np.ascontiguousarray(tcw), np.ascontiguousarray(INTR)
+    n = ad.adapter_build_tracks(len(nk), P(nk), P(kp_xy), len(pairs), P(pairs), P(moff), P(mm), P(depth), W, H, P(Rcw), P(tcw), P(intr),
+                                3, 8.0, 3.0, P(tl), P(X), P(obs), P(inl), P(o2t))
+    return np.concatenate([[0], np.cumsum(tl[:n])]), obs, inl, X, o2t, nk
+
+
 def _same_tracks(ref_tracks, off, obs_img, obs_kp, kept, X):
     assert len(off) - 1 == len(ref_tracks)
     for n, t in enumerate(ref_tracks):
@@ -219,26 +247,8 @@ def test_product_host_loops_reproduce_the_reference_tracks(run, tmp_path_factory
     _same_tracks(r.tracks, T["obs_off"], T["obs_img"], T["obs_kp"], T["kept"], T["X"])
     assert (T["attempts"] > 0).sum() >= 1 and (T["component_status"] > 0).sum() == len(r.tracks)
     # the C++ adapter
-    so = str(tmp_path_factory.mktemp("adapter_emul") / "libadapter_emul.so")
-    libdir = os.path.join(ROOT, "global-lvba_amd")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", os.path.join(ROOT, "tests", "adapter_tracks_emul.cpp"),
-                           "-o", so, "-L", libdir, "-llvba_hip", f"-Wl,-rpath,{libdir}"])
-    ad = ctypes.CDLL(so)
-    nk = np.array([len(k) for k in r.d["kps"]], np.int32)
-    kp_xy = np.concatenate([np.asarray(k, np.float32)[:, :2] for k in r.d["kps"]]).astype(np.float32)
-    pairs = np.array(r.d["pairs"], np.int32)
-    moff = np.concatenate([[0], np.cumsum([len(m) for m in r.d["matches"]])]).astype(np.int64)
-    matches = np.concatenate(r.d["matches"]).astype(np.int32)
+    off, obs, inl, X, o2t, nk = _adapter_tracks(r, r.d["matches"], r.depth, r.Rcw, r.tcw, tmp_path_factory.mktemp("adapter_emul"))
     K = int(nk.sum())
-    tl, X, obs, inl, o2t = np.zeros(K, np.int32), np.zeros((K, 3)), np.zeros((K, 2), np.int32), np.zeros(K, np.uint8), np.zeros(K, np.int32)
-    depth = np.ascontiguousarray(r.depth, np.float32)
-    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-    ad.adapter_build_tracks.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_int] * 2 + \
-        [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_double, ctypes.c_double] + [ctypes.c_void_p] * 5
-    Rcw, tcw, intr = np.ascontiguousarray(r.Rcw), np.ascontiguousarray(r.tcw), np.ascontiguousarray(INTR)
-    n = ad.adapter_build_tracks(len(nk), P(nk), P(kp_xy), len(pairs), P(pairs), P(moff), P(matches), P(depth), W, H, P(Rcw), P(tcw), P(intr),
-                                3, 8.0, 3.0, P(tl), P(X), P(obs), P(inl), P(o2t))
-    off = np.concatenate([[0], np.cumsum(tl[:n])])
     _same_tracks(r.tracks, off, obs[:, 0], obs[:, 1], inl, X)
     # obs_to_track as the reference leaves it: the track of every member, -1 elsewhere
     want = -np.ones(K, np.int32)
@@ -408,3 +418,37 @@ def test_track_fusion_thresholds(run, tmp_path_factory, obser_thr, angle, thr):
     T = r.pipe.build_tracks_and_fuse(r.d["kps"], r.d["pairs"], r.d["matches"],
                                      lambda o, i, u: th._fuse(lib, o, i, u, depth, Rcw, tcw, INTR, obser_thr, angle, thr), obser_thr)
     _same_tracks(tracks, T["obs_off"], T["obs_img"], T["obs_kp"], T["kept"], T["X"])
+
+
+def test_tracks_with_false_matches(run, tmp_path_factory):
+    """Wrong matches chain tracks together: components with several key points of one image, depth points far apart, many
+    fusion failures and therefore many retries from later members -- reference against oracle and product loop."""
+    import test_tracks_host as th
+    r = run
+    rng = np.random.default_rng(17)
+    matches = []
+    for (i, j), m in zip(r.d["pairs"], r.d["matches"]):
+        extra = np.stack([rng.integers(0, len(r.d["kps"][i]), 6), rng.integers(0, len(r.d["kps"][j]), 6)], 1)
+        matches.append(np.concatenate([np.asarray(m, np.int64), extra]))
+    S = rs.ReferenceSystem(r.root, reference_params(r.tp))
+    try:
+        S.init()
+        S.build_grid_map(); S.update_camera_poses()
+        depth = S.generate_depth(W, H)
+        Rcw, tcw = S.cam_poses(True)
+        S.set_features(r.d["kps"], {pr: m for pr, m in zip(r.d["pairs"], matches)})
+        tracks = S.build_tracks()
+    finally:
+        S.close()
+    assert any(len(set(t["obs"][:, 0].tolist())) < len(t["obs"]) for t in tracks)      # some track sees an image twice
+    mine = fo.build_tracks_and_fuse(r.d["kps"], r.d["pairs"], matches, depth, Rcw, tcw, INTR)
+    assert len(mine) == len(tracks) > 20
+    for a, b in zip(tracks, mine):
+        assert np.array_equal(a["obs"], b["obs"]) and np.abs(a["X"] - b["X"]).max() < 1e-10
+        assert sorted(a["inliers"].tolist()) == np.nonzero(b["kept"])[0].tolist()
+    lib = th.build_emul(tmp_path_factory.mktemp("emul_noise"))
+    T = r.pipe.build_tracks_and_fuse(r.d["kps"], r.d["pairs"], matches, lambda o, i, u: th._fuse(lib, o, i, u, depth, Rcw, tcw, INTR))
+    _same_tracks(tracks, T["obs_off"], T["obs_img"], T["obs_kp"], T["kept"], T["X"])
+    assert (T["attempts"] > 0).sum() >= 3 and T["attempts"].max() >= 2
+    off, obs, inl, X, _, _ = _adapter_tracks(r, matches, depth, Rcw, tcw, tmp_path_factory.mktemp("adapter_noise"))
+    _same_tracks(tracks, off, obs[:, 0], obs[:, 1], inl, X)
