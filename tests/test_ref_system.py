@@ -452,3 +452,48 @@ def test_tracks_with_false_matches(run, tmp_path_factory):
     assert (T["attempts"] > 0).sum() >= 3 and T["attempts"].max() >= 2
     off, obs, inl, X, _, _ = _adapter_tracks(r, matches, depth, Rcw, tcw, tmp_path_factory.mktemp("adapter_noise"))
     _same_tracks(tracks, off, obs[:, 0], obs[:, 1], inl, X)
+
+
+def test_camera_update_edge_cases(tmp_path):
+    """updateCameraPosesFromLidar (:412-446) where the nearest-scan search leaves the scan range: images before the first scan,
+    after the last one, exactly between two scans (lower_bound, the earlier scan only if STRICTLY closer), and more images than
+    a 1:1 pairing would need."""
+    ds = importlib.import_module("global-lvba_amd.dataset")
+    pipe = importlib.import_module("global-lvba_amd.pipeline")
+    import test_gpu_pipeline as tp
+    rng = np.random.default_rng(4)
+    n = 5
+    times = 100.0 + 0.5 * np.arange(n)
+    img_t = np.array([99.2, 100.0, 100.25, 100.26, 100.74, 101.5, 102.0, 103.7])
+    def rand_pose():
+        q = rng.standard_normal(4); q /= np.linalg.norm(q)
+        return np.concatenate([np.asarray(ds.quat_to_rot(*q)).reshape(-1), rng.standard_normal(3)])
+    d = dict(times=times, img_t=img_t, clouds=[rng.standard_normal((50, 3)).astype(np.float32) for _ in range(n)],
+             odo=np.array([rand_pose() for _ in range(n)]))
+    root = str(tmp_path / "seq")
+    os.makedirs(os.path.join(root, "all_pcd_body")); os.makedirs(os.path.join(root, "all_image"))
+    for t, c in zip(times, d["clouds"]):
+        ds.save_pcd(os.path.join(root, "all_pcd_body", f"{t:.6f}.pcd"), np.concatenate([c, np.zeros((len(c), 1), np.float32)], 1), mode="ascii")
+    ds.write_poses_tum(os.path.join(root, "all_pcd_body", "lidar_poses.txt"), times, d["odo"])
+    for t in img_t:
+        open(os.path.join(root, "all_image", f"{t:.6f}.jpg"), "wb").close()
+    cam = np.array([rand_pose() for _ in img_t])
+    ds.write_poses_tum(os.path.join(root, "all_image", "image_poses.txt"), img_t, cam)
+    S = rs.ReferenceSystem(root, reference_params(tp))
+    try:
+        assert S.n_scans == n and S.n_images == len(img_t)
+        for i in range(n):                                                         # the ascii PCD branch of the stand-in reader
+            assert np.array_equal(S.cloud(i)[:, :3], d["clouds"][i])
+        S.init()
+        R0, p0, ts = S.scan_poses()
+        x_orig = np.concatenate([R0.reshape(-1, 9), p0], 1)
+        x_opt = np.array([rand_pose() for _ in range(n)])                          # "refined" poses: anything
+        S.set_scan_poses(x_opt[:, :9].reshape(-1, 3, 3), x_opt[:, 9:])
+        Rn, tn = S.update_camera_poses()
+        _, cam_in = ds.load_poses_tum(os.path.join(root, "all_image", "image_poses.txt"), 1)
+        ids = S.image_ids()
+    finally:
+        S.close()
+    assert np.array_equal(ids, img_t)
+    got = pipe.update_camera_poses_from_lidar(x_opt, x_orig, ts, ids, cam_in)
+    assert np.abs(got[:, :9].reshape(-1, 3, 3) - Rn).max() < 1e-13 and np.abs(got[:, 9:] - tn).max() < 1e-12
