@@ -5,7 +5,8 @@
 //   OpenCV         a real cv::Mat (depth images); codecs / drawing throw (never reached), previews are no-ops
 //   PCL            PointCloud = vector of points, a PCD reader for the encodings the tests write
 //   Eigen, Sophus  lvba_eigen_standin.h, sophus/se3.h
-//   SiftGPU, sqlite3, GL   every call throws: the SIFT front end and the COLMAP import are outside the scope contract
+//   SiftGPU, GL    every call throws: the SIFT front end is outside the scope contract
+//   sqlite3        declarations only; the system's libsqlite3.so.0 is linked, so loadFromColmapDB runs for real
 //   Ceres          cost functors differentiated with Jets exactly as AutoDiffCostFunction would, and a ceres::Problem that
 //                  RECORDS what optimizeCameraPoses adds to it; ceres::Solve hands the recorded problem to the hook below,
 //                  which evaluates it at the initial point and (optionally) installs a solution computed elsewhere.
@@ -290,6 +291,32 @@ void ref_sys_problem_residuals(int32_t *kind, int32_t *cam, int32_t *point, doub
         kind[i] = g_rec.res[i].kind; cam[i] = g_rec.res[i].cam; point[i] = g_rec.res[i].point;
         r[2 * i] = g_rec.res[i].r[0]; r[2 * i + 1] = g_rec.res[i].r[1]; loss_a[i] = g_rec.res[i].loss_a;
     }
+}
+
+// loadFromColmapDB (:510-685) on <data_path>/<data_config/colmap_db_path>: key points and inlier matches into all_keypoints_ /
+// all_matches_ (image_pairs_ = all i < j in pairIndex order, :460-464).  Returns 1 when the reference accepted the database.
+int ref_sys_load_colmap_db(void *h)
+{
+    bool ok = false;
+    if (guarded([&] { ok = SYS(h).loadFromColmapDB(); }) != 0) return -1;
+    return ok ? 1 : 0;
+}
+int ref_sys_n_keypoints(void *h, int img) { return (int)SYS(h).all_keypoints_[img].size(); }
+void ref_sys_keypoints(void *h, int img, float *xyse /*[n][4]: x y sigma extremum*/)
+{
+    const auto &v = SYS(h).all_keypoints_[img];
+    for (size_t k = 0; k < v.size(); ++k) { xyse[4 * k] = v[k].x; xyse[4 * k + 1] = v[k].y; xyse[4 * k + 2] = v[k].sigma; xyse[4 * k + 3] = v[k].extremum_val; }
+}
+int ref_sys_n_matches(void *h, int i, int j)
+{
+    const int N = (int)SYS(h).images_ids_.size();
+    return (int)SYS(h).all_matches_[lvba::pairIndex(i, j, N)].size();
+}
+void ref_sys_matches(void *h, int i, int j, int32_t *out)
+{
+    const int N = (int)SYS(h).images_ids_.size();
+    const auto &m = SYS(h).all_matches_[lvba::pairIndex(i, j, N)];
+    for (size_t k = 0; k < m.size(); ++k) { out[2 * k] = m[k].first; out[2 * k + 1] = m[k].second; }
 }
 
 // VisualizeOptComparison (:1932-2144) = the COLMAP text export (<data_path>/Colmap/sparse/images.txt, points3D.txt) after

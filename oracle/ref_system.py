@@ -50,6 +50,11 @@ def load():
         lib.ref_sys_set_fusion_params.argtypes = [vp, c_int, c_dbl, c_dbl]
         lib.ref_sys_track_sizes.restype, lib.ref_sys_track_sizes.argtypes = c_int, [vp, c_int, ctypes.POINTER(c_int)]
         lib.ref_sys_track.argtypes = [vp, c_int, f64p, i32p, i32p]
+        lib.ref_sys_load_colmap_db.restype, lib.ref_sys_load_colmap_db.argtypes = c_int, [vp]
+        lib.ref_sys_n_keypoints.restype, lib.ref_sys_n_keypoints.argtypes = c_int, [vp, c_int]
+        lib.ref_sys_keypoints.argtypes = [vp, c_int, f32p]
+        lib.ref_sys_n_matches.restype, lib.ref_sys_n_matches.argtypes = c_int, [vp, c_int, c_int]
+        lib.ref_sys_matches.argtypes = [vp, c_int, c_int, i32p]
         lib.ref_sys_export_colmap.restype, lib.ref_sys_export_colmap.argtypes = c_int, [vp, c_int, c_int]
         lib.ref_sys_optimize.restype = c_int
         lib.ref_sys_optimize.argtypes = [vp, vp, vp, vp, c_int, c_int]
@@ -197,6 +202,26 @@ class ReferenceSystem:
             self.lib.ref_sys_track(self.h, t, X, obs.reshape(-1), inl)
             out.append(dict(X=X, obs=obs, inliers=inl))
         return out
+
+    def load_colmap_db(self):
+        """loadFromColmapDB: (accepted, key points per image [n,4] = x y sigma extremum, {(i, j): matches [m,2]} for all i < j)."""
+        rc = self.lib.ref_sys_load_colmap_db(self.h)
+        if rc < 0:
+            raise RuntimeError("reference loadFromColmapDB threw")
+        if rc == 0:
+            return False, [], {}
+        kps = []
+        for i in range(self.n_images):
+            k = np.zeros((self.lib.ref_sys_n_keypoints(self.h, i), 4), np.float32)
+            self.lib.ref_sys_keypoints(self.h, i, k.reshape(-1))
+            kps.append(k)
+        matches = {}
+        for i in range(self.n_images):
+            for j in range(i + 1, self.n_images):
+                m = np.zeros((self.lib.ref_sys_n_matches(self.h, i, j), 2), np.int32)
+                self.lib.ref_sys_matches(self.h, i, j, m.reshape(-1))
+                matches[(i, j)] = m
+        return True, kps, matches
 
     def export_colmap(self, width, height):
         """VisualizeOptComparison: writes <dataset>/Colmap/sparse/{images,points3D}.txt (images are a synthetic pattern: b = x,

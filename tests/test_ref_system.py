@@ -13,7 +13,10 @@ their oracle (oracle/*.py), and the product's host mirror (global-lvba_amd/pipel
     optimizeCameraPoses up to ceres::Solve   -> window_oracle.merge_anchors + voxel_oracle.find_plane + visual_oracle cost
                                                 (the problem Ceres would receive: blocks, constancy, manifold, residuals)
 
-What stays unpinned: the iterations of ceres::Solve (no Ceres here) and the SIFT / COLMAP front end (out of scope)."""
+    loadFromColmapDB                         -> dataset.load_colmap_db                                 (system libsqlite3 linked)
+    VisualizeOptComparison (COLMAP text)     -> dataset.write_images_txt / write_points3d_txt
+
+What stays unpinned: the iterations of ceres::Solve (no Ceres here); SIFT extraction / matching is out of scope."""
 import importlib
 import os
 import sys
@@ -497,3 +500,79 @@ def test_camera_update_edge_cases(tmp_path):
     assert np.array_equal(ids, img_t)
     got = pipe.update_camera_poses_from_lidar(x_opt, x_orig, ts, ids, cam_in)
     assert np.abs(got[:, :9].reshape(-1, 3, 3) - Rn).max() < 1e-13 and np.abs(got[:, 9:] - tn).max() < 1e-12
+
+
+def test_colmap_database_import(tmp_path):
+    """LvbaSystem::loadFromColmapDB (:510-685, the system's libsqlite3 linked) against dataset.load_colmap_db on a database with
+    the cases the reader has branches for: image ids that do not follow the time order (pairs stored the other way round),
+    4- and 6-column key points, a missing key point blob, a blob of the wrong size, out-of-range match indices, a pair with
+    cols != 2, a pair that is absent."""
+    import sqlite3
+    import test_gpu_pipeline as tp
+    ds = importlib.import_module("global-lvba_amd.dataset")
+    rng = np.random.default_rng(9)
+    n = 5
+    times = 10.0 + 0.5 * np.arange(n)
+    img_t = times + 0.01
+    root = str(tmp_path / "seq")
+    os.makedirs(os.path.join(root, "all_pcd_body")); os.makedirs(os.path.join(root, "all_image"))
+    I12 = np.concatenate([np.eye(3).reshape(-1), np.zeros(3)])
+    for t in times:
+        ds.save_pcd(os.path.join(root, "all_pcd_body", f"{t:.6f}.pcd"), rng.standard_normal((20, 4)).astype(np.float32))
+    ds.write_poses_tum(os.path.join(root, "all_pcd_body", "lidar_poses.txt"), times, np.tile(I12, (n, 1)))
+    for t in img_t:
+        open(os.path.join(root, "all_image", f"{t:.6f}.png"), "wb").close()
+    ds.write_poses_tum(os.path.join(root, "all_image", "image_poses.txt"), img_t, np.tile(I12, (n, 1)))
+    db_id = [4, 2, 9, 1, 7]                                                     # database image ids, not in time order
+    nk = [30, 25, 0, 40, 35]
+    con = sqlite3.connect(os.path.join(root, "colmap.db"))
+    con.execute("CREATE TABLE images (image_id INTEGER PRIMARY KEY, name TEXT)")
+    con.execute("CREATE TABLE keypoints (image_id INTEGER PRIMARY KEY, rows INTEGER, cols INTEGER, data BLOB)")
+    con.execute("CREATE TABLE two_view_geometries (pair_id INTEGER PRIMARY KEY, rows INTEGER, cols INTEGER, data BLOB)")
+    for i, t in enumerate(img_t):
+        con.execute("INSERT INTO images VALUES (?, ?)", (db_id[i], f"{t:.6f}.png"))
+        cols = 6 if i == 1 else 4
+        kp = rng.uniform(0, 400, (nk[i], cols)).astype(np.float32)
+        if i == 2:
+            continue                                                            # image 2: no key point row at all
+        blob = kp.tobytes()[:-4] if i == 4 else kp.tobytes()                    # image 4: blob one float short -> ignored
+        con.execute("INSERT INTO keypoints VALUES (?, ?, ?, ?)", (db_id[i], nk[i], cols, blob))
+    def put(i, j, m, cols=2):
+        a, b = db_id[i], db_id[j]
+        m = np.asarray(m, np.uint32)
+        if a > b:                                                               # COLMAP stores (smaller id, larger id)
+            m = m[:, ::-1]
+        con.execute("INSERT INTO two_view_geometries VALUES (?, ?, ?, ?)", (ds.image_ids_to_pair_id(a, b), len(m), cols, np.ascontiguousarray(m).tobytes()))
+    put(0, 1, [[0, 1], [5, 6], [29, 24], [30, 3], [2, 25]])                     # two out-of-range rows
+    put(0, 3, [[1, 2], [3, 39], [7, 7]])                                        # ids 4 > 1: stored swapped
+    put(1, 3, [[4, 4], [24, 0]])
+    put(0, 2, [[0, 0]])                                                         # image 2 has no key points
+    put(3, 4, [[0, 0]])                                                         # image 4's blob was rejected
+    con.execute("INSERT INTO two_view_geometries VALUES (?, ?, ?, ?)", (ds.image_ids_to_pair_id(db_id[1], db_id[4]) + 10**6, 1, 3, b"\\0" * 12))
+    con.commit(); con.close()
+    p = reference_params(tp); p["data_config/colmap_db_path"] = "colmap.db"
+    S = rs.ReferenceSystem(root, p)
+    try:
+        S.init()
+        ok, kps, matches = S.load_colmap_db()
+    finally:
+        S.close()
+    assert ok
+    pairs = [(i, j) for i in range(n) for j in range(i + 1, n)]
+    names = [f"{t:.6f}.png" for t in img_t]
+    mk, mm = ds.load_colmap_db(os.path.join(root, "colmap.db"), names, pairs)
+    for i in range(n):
+        assert len(kps[i]) == len(mk[i]) == (0 if i in (2, 4) else nk[i])
+        if len(mk[i]):
+            assert np.array_equal(kps[i], mk[i][:, :4])                         # x y sigma extremum (cols 5, 6 of a 6-column blob unused)
+    for pr, m in zip(pairs, mm):
+        assert np.array_equal(matches[pr], m), pr
+    assert len(matches[(0, 1)]) == 3 and matches[(0, 3)].tolist() == [[1, 2], [3, 39], [7, 7]] and len(matches[(0, 2)]) == 0
+    # a database whose image count differs is refused (:545-552)
+    con = sqlite3.connect(os.path.join(root, "colmap.db")); con.execute("DELETE FROM images WHERE image_id=9"); con.commit(); con.close()
+    S = rs.ReferenceSystem(root, p)
+    try:
+        S.init()
+        assert S.load_colmap_db()[0] is False
+    finally:
+        S.close()
