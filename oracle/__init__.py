@@ -198,7 +198,11 @@ def build_ref(force=False):
                                                                     ("src", "lvba_system.cpp"), ("src", "dataset_io.cpp"))]
         newest = max(os.path.getmtime(d) for d in deps)
         if force or any(not os.path.exists(f) or os.path.getmtime(f) < newest for f in (so, so_sys)):
-            subprocess.check_call(["make", "-C", _HERE, "-B", "-s", "ref", "REF=" + REFERENCE_ROOT])
+            try:
+                subprocess.check_call(["make", "-C", _HERE, "-B", "-s", "ref", "REF=" + REFERENCE_ROOT])
+            except subprocess.CalledProcessError:
+                # the system library (links the host's libsqlite3.so.0) is optional: tests/test_ref_system.py skips without it
+                subprocess.check_call(["make", "-C", _HERE, "-B", "-s", "_ref/libbalm_ref.so", "REF=" + REFERENCE_ROOT])
     return so if os.path.exists(so) else None
 
 
