@@ -145,3 +145,37 @@ def test_device_reprojection_jacobians_match_autograd(emul, synth):
         a = rng.standard_normal(4); a /= np.linalg.norm(a); dd = rng.standard_normal(3) * 0.1; out = np.zeros(4)
         emul.emul_quat_plus(a, dd, out)
         assert np.abs(out - vo.eigen_quat_plus(a, dd)).max() <= 1e-15
+
+
+def test_converged_answer_does_not_depend_on_the_solver(synth):
+    """The iterations of ceres::Solve are restated from memory (unpinned).  What they converge TO is not a matter of the
+    solver: an independent method -- undamped Gauss-Newton on the full normal equations (numpy lstsq) with step halving, no
+    Jacobi scaling, no trust region, no Schur complement -- reaches the same minimum of the same pinned cost, and the
+    Ceres-style LM of the oracle stops within its function tolerance (1e-6 relative) of it."""
+    d, o = _problem(synth, n_cams=6, n_tracks=40, seed=5)
+    (q, t, X), trace, status = o.solve()
+    assert status.startswith("CONVERGENCE")
+    q2, t2, X2 = o.state()
+    cost = o.cost(q2, t2, X2)
+    for _ in range(40):
+        r, J = o.residuals_and_jacobian(q2, t2, X2)
+        dx = np.linalg.lstsq(J, -r, rcond=None)[0]
+        step = 1.0
+        while True:
+            cand = o.plus(q2, t2, X2, step * dx)
+            c = o.cost(*cand)
+            if c < cost or step < 1e-6:
+                break
+            step *= 0.5
+        if c >= cost:
+            break
+        done = (cost - c) < 1e-14 * cost
+        (q2, t2, X2), cost = cand, c
+        if done:
+            break
+    lm_cost = trace[-1]["cost"]
+    assert cost <= lm_cost * (1 + 1e-12) and (lm_cost - cost) < 1e-5 * cost
+    act = o.act
+    # the LM stops on its function tolerance, a little before the minimum: poses agree to what that leaves
+    assert np.abs(t - t2).max() < 2e-3 * max(1.0, np.abs(t2).max()) and np.abs(X[act] - X2[act]).max() < 5e-3
+    assert np.abs(np.abs(np.einsum("ij,ij->i", q, q2)) - 1).max() < 1e-6
