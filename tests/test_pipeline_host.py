@@ -61,3 +61,29 @@ def test_extrinsics_camera_from_imu_and_image_listing(tmp_path):
         (tmp_path / name).write_bytes(b"")
     assert pipe.list_image_ids(str(tmp_path)).tolist() == [0.75, 1.25, 2.0, 3.5]
     assert pipe.list_image_ids(str(tmp_path), 2).tolist() == [0.75, 2.0]
+
+
+def test_track_loop_edge_cases():
+    """build_tracks_and_fuse with nothing to do, with a fusion that always fails (every member of every component is tried
+    once, in scan order) and with one that succeeds on the second attempt (the track starts at the second member)."""
+    pipe = importlib.import_module("global-lvba_amd.pipeline")
+    kps = [np.zeros((3, 2), np.float32) for _ in range(4)]
+    T = pipe.build_tracks_and_fuse(kps, [], [], lambda o, i, u: (_ for _ in ()).throw(AssertionError("no batch expected")))
+    assert len(T["X"]) == 0 and T["obs_off"].tolist() == [0] and len(T["component_status"]) == 0
+    pairs = [(0, 1), (1, 2), (2, 3)]
+    matches = [np.array([[0, 0]]), np.array([[0, 0]]), np.array([[0, 0]])]           # one chain (0,0)-(1,0)-(2,0)-(3,0)
+    starts = []
+
+    def never(off, img, uv):
+        starts.append(int(img[0]))
+        n = len(off) - 1
+        return np.zeros(n, np.uint8), np.zeros((n, 3)), np.full(n, np.inf), np.zeros(len(img), np.uint8)
+    T = pipe.build_tracks_and_fuse(kps, pairs, matches, never)
+    assert starts == [0, 1, 2, 3] and len(T["X"]) == 0 and T["component_status"].tolist() == [0]
+
+    def second(off, img, uv):
+        n = len(off) - 1
+        ok = np.array([1 if img[off[k]] == 1 else 0 for k in range(n)], np.uint8)
+        return ok, np.ones((n, 3)), np.zeros(n), np.ones(len(img), np.uint8)
+    T = pipe.build_tracks_and_fuse(kps, pairs, matches, second)
+    assert T["attempts"].tolist() == [1] and T["obs_img"].tolist() == [1, 0, 2, 3] and T["component_status"].tolist() == [1]
