@@ -1,8 +1,9 @@
 // lvba_eigen_standin.h -- TEST INFRASTRUCTURE ONLY.
 //
 // A small, eagerly evaluated stand-in for the subset of the Eigen 3 API that the reference's BALM headers
-// (include/BALM/tools.hpp, include/BALM/bavoxel.hpp) use, so that those two files can be compiled UNMODIFIED, from where
-// they lie under /root/reference, into oracle/_ref/libbalm_ref.so (oracle/Makefile, target `ref`).  Eigen itself is not
+// (include/BALM/tools.hpp, include/BALM/bavoxel.hpp), include/utils.hpp and src/lvba_system.cpp / src/dataset_io.cpp use, so
+// that those files can be compiled UNMODIFIED, from where they lie under /root/reference, into oracle/_ref/libbalm_ref.so and
+// oracle/_ref/liblvba_system_ref.so (oracle/Makefile, target `ref`).  Eigen itself is not
 // installed in this image and cannot be fetched.  Everything the reference computes with its own statements -- cluster
 // transforms, the Hessian / gradient assembly of acc_evaluate2, the LM control flow of damping_iter, voxel keys, the
 // octree recursion, the down-sampling rules -- therefore runs as the reference wrote it.  What this file supplies in
@@ -12,7 +13,9 @@
 //   * SelfAdjointEigenSolver<Matrix3d>: cyclic Jacobi, eigenvalues ascending (Eigen: tridiagonalisation + implicit QL);
 //     eigenvector signs may differ -- the reference only uses sign-invariant products u u^T and the plane normal;
 //   * SimplicialLDLT: unpivoted dense LDL^T of the lower triangle, no fill-reducing permutation (Eigen: AMD ordering);
-//   * colPivHouseholderQr().solve: normal equations (only esti_plane uses it; not on the tested path).
+//   * colPivHouseholderQr().solve: normal equations (only esti_plane uses it; not on the tested path);
+//   * SelfAdjointEigenSolver<Matrix4d> (TriangulateTrackDLT): the same cyclic Jacobi;
+//   * Quaterniond: construction from a rotation matrix by Eigen's published branch rule, toRotationMatrix, product.
 #pragma once
 #include <algorithm>
 #include <array>
