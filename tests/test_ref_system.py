@@ -576,3 +576,11 @@ def test_colmap_database_import(tmp_path):
         assert S.load_colmap_db()[0] is False
     finally:
         S.close()
+
+
+def test_adapter_track_loop_without_matches(run, tmp_path_factory):
+    """lvba::build_tracks_and_fuse_with on an empty match table: no batch, no tracks, obs_to_track all -1."""
+    r = run
+    empty = [np.zeros((0, 2), np.int64) for _ in r.d["pairs"]]
+    off, obs, inl, X, o2t, nk = _adapter_tracks(r, empty, r.depth, r.Rcw, r.tcw, tmp_path_factory.mktemp("adapter_empty"))
+    assert off.tolist() == [0] and np.all(o2t == -1)
