@@ -17,7 +17,8 @@ replicated.  Total work is fixed as N grows -> "scaling": "strong".
 Rank 0 prints ONE JSON line.  `roofline` is the H/g/cost evaluation ("Jacobian") pass against HBM, from
 HIP-event durations recorded on the library's stream around its kernels during the timed steps and the
 algorithmic bytes of SURVEY.md section 8(d); `cpu_baseline` is the C restatement (oracle/balm_oracle.c)
-timed on this host on a bounded sample.  torch is used only for synthetic data generation on the GPU and
+timed on this host on ONE full LM iteration of the same problem, and `parity` holds the HIP path against it at that
+size (the run fails when they disagree beyond 1e-7).  torch is used only for synthetic data generation on the GPU and
 for the control-plane barrier; the product path is the C-ABI library.
 """
 import argparse
@@ -43,40 +44,65 @@ def parse_config(name, synth):
     return int(n), int(v)
 
 
-def cpu_baseline(d, info, sample_voxels=400000, solve_cols=4096):
-    """Time the C oracle on a bounded sample and scale to one LM iteration of the full problem."""
+def cpu_baseline_and_parity(prob, d, info):
+    """The C oracle (oracle/balm_oracle.c) on the FULL problem the bench just timed -- no sampling, no scaling -- serving
+    twice: (1) `cpu_baseline`: one LM iteration of the reference's loop (bavoxel.hpp:686-766) with the reference's
+    threading (16-way sliced evaluation :597-639, single-threaded cost pass :176-203,731; the damped solve is the oracle's
+    unpivoted band LDL^T of the REAL damped Hessian in the GPU path's pose order, where the reference runs Eigen's
+    SimplicialLDLT); (2) `parity`: the HIP path against it at this size -- cost, gradient, every non-zero pose block of the
+    Hessian at the initial poses, and the first LM iteration (cost before / after the step, i.e. through the solve and
+    the retraction).  Returns (cpu_baseline, parity)."""
     import oracle
     N = d["n_poses"]
-    off = d["voxel_off"]
-    V = len(off) - 1
-    Vs = min(V, sample_voxels)
-    sl = slice(0, off[Vs])
-    co = oracle.COracle(N, off[:Vs + 1], d["pose_idx"][sl], d["clusters"][sl])
-    x = d["poses_init"]
+    co = oracle.COracle(N, d["voxel_off"], d["pose_idx"], d["clusters"])
+    x0 = d["poses_init"]
     cores = min(16, os.cpu_count() or 1)               # the reference uses 16 std::threads (bavoxel.hpp:25)
-    co.eval_sparse(x, nthreads=cores, want_blocks=False)
-    t = time.perf_counter(); co.eval_sparse(x, nthreads=cores, want_blocks=False); t_eval = time.perf_counter() - t
-    co.cost(x, nthreads=1)
-    t = time.perf_counter(); co.cost(x, nthreads=1); t_cost = time.perf_counter() - t   # reference: single-threaded
-    # damped solve: unpivoted band LDL^T (what the GPU path does) on a slice of columns, linear in n at fixed bw
+    solve_threads = min(32, os.cpu_count() or 1)
+    # --- HIP path
+    xg, trace, rc = prob.refine(x0, max_iter=1)
+    H, g, c = prob.eval(x0)
+    # --- oracle: evaluation with the block list (two passes inside: count, fill)
+    t = time.perf_counter()
+    bi, bj, blocks, gc, cc = co.eval_sparse(x0, nthreads=cores)
+    t_eval_list = 0.5 * (time.perf_counter() - t)
+    h_block_rel, h_outside = oracle.block_parity(H, bi, bj, blocks)
+    del H, blocks
+    g_rel = float(np.abs(g - gc).max() / np.abs(gc).max())
+    cost_rel = abs(c - cc) / abs(cc)
+    # --- oracle: one LM iteration, timed per stage
+    xr, tr, rcr, sec = co.damping_iter_band(x0, perm=prob.ordering(), max_iter=1, eval_threads=cores,
+                                            solve_threads=solve_threads)
+    lm_rel = max(abs(trace[0]["residual1"] - tr[0][1]) / tr[0][1], abs(trace[0]["residual2"] - tr[0][2]) / tr[0][2])
+    pose_abs = float(np.abs(xg - xr).max())
+    parity = {"against": "oracle/balm_oracle.c on the full problem", "cost_rel": cost_rel, "g_rel": g_rel,
+              "H_block_rel": h_block_rel, "H_outside_pattern": h_outside, "lm_iteration_cost_rel": lm_rel,
+              "poses_after_step_abs": pose_abs, "blocks_compared": int(len(bi)), "tolerance": 1e-7,
+              "ok": bool(rc == 0 and rcr == 0 and max(cost_rel, g_rel, h_block_rel, lm_rel) <= 1e-7 and h_outside <= 1e-12
+                         and pose_abs <= 1e-7)}
+    t_iter = sec["eval"] + sec["solve"] + sec["cost"]
     n = 6 * N
-    bw = min(n - 1, 6 * info["band_blocks"] + 5)
-    ns = min(n, max(solve_cols, bw + 64))
-    rng = np.random.default_rng(0)
-    AB = rng.standard_normal((ns, bw + 1)) * 0.01
-    AB[:, 0] = bw + 1.0
-    t = time.perf_counter(); oracle.ldlt_solve_band(AB, bw, np.ones(ns), nthreads=cores); t_solve = time.perf_counter() - t
-    scale_v = V / Vs
-    # an ns-column slice under-counts the ramp-up at the matrix ends by < bw/n; scale linearly
-    t_iter = t_eval * scale_v + t_cost * scale_v + t_solve * (n / ns)
-    return {
+    base = {
         "value": 1.0 / t_iter, "unit": "iterations/s", "cores": cores, "kind": "port",
-        "sample": (f"oracle/balm_oracle.c: H/g/cost eval ({cores} threads, sparse block accumulation) and "
-                   f"cost-only (1 thread, as bavoxel.hpp:176-203) on the first {Vs} of {V} voxels, scaled x{scale_v:.1f}; "
-                   f"unpivoted band LDL^T ({cores} threads) on {ns} of {n} columns at half-bandwidth {bw}, scaled x{n/ns:.2f}; "
-                   f"eval {t_eval*scale_v:.2f}s + cost {t_cost*scale_v:.2f}s + solve {t_solve*n/ns:.2f}s per iteration"),
-        "host_cpus": os.cpu_count(),
+        "sample": (f"oracle/balm_oracle.c, ONE full LM iteration of the whole problem (no sampling): H/g/cost evaluation "
+                   f"{sec['eval']:.2f} s ({cores} threads, sparse block accumulation), damped solve {sec['solve']:.2f} s "
+                   f"(unpivoted band LDL^T of the real damped Hessian, n = {n}, half-bandwidth {6 * sec['band_blocks'] + 5}, "
+                   f"{solve_threads} threads; the reference calls Eigen::SimplicialLDLT here, single-threaded), cost-only pass "
+                   f"{sec['cost']:.2f} s (1 thread, as bavoxel.hpp:176-203)"),
+        "stage_s": {"eval": sec["eval"], "solve": sec["solve"], "cost": sec["cost"], "eval_with_block_list": t_eval_list},
+        "host_cpus": os.cpu_count(), "host_cpu_model": cpu_model(),
     }
+    return base, parity
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return None
 
 
 def main():
@@ -166,6 +192,7 @@ def main():
     if state["active"]:
         prob.lm_end(want_poses=False)
 
+    parity_ok = True
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
         # algorithmic bytes of one H/g/cost evaluation of THIS rank's shard:
@@ -224,7 +251,8 @@ def main():
                 out["front_end"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(d, info)
+                out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(prob, d, info)
+                parity_ok = out["parity"]["ok"]
             except Exception as e:  # the baseline is a reported number, not part of the measured path
                 out["cpu_baseline"] = {"value": None, "unit": "iterations/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {e!r}"}
@@ -233,6 +261,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if not parity_ok:
+        raise SystemExit("bench.py: the HIP path disagrees with the oracle beyond 1e-7 at the benchmark size (see \"parity\")")
 
 
 def visual_leg(pkg, synth, n_cams, local_rank):

@@ -82,6 +82,8 @@ def load_c():
         lib.bo_retract.argtypes = [c_int, f64p, f64p, f64p]
         lib.bo_damping_iter.argtypes = [c_int, c_i64, i64p, i32p, f64p, f64p, c_int, c_dbl, c_dbl,
                                         c_dbl, f64p, intp]
+        lib.bo_damping_iter_band.argtypes = [c_int, c_i64, i64p, i32p, f64p, f64p, i32p, c_int, c_int, c_dbl, c_dbl,
+                                             c_dbl, c_int, c_int, f64p, intp, f64p]
         _LIB = lib
     return _LIB
 
@@ -151,6 +153,49 @@ class COracle:
         rc = self.lib.bo_damping_iter(self.N, self.V, self.voff, self.pidx, self.clu, x, max_iter, u0, v0,
                                       rel_tol, trace, ctypes.byref(nt))
         return x, trace[:nt.value], rc
+
+
+    def damping_iter_band(self, poses, perm=None, max_iter=10, u0=0.01, v0=2.0, rel_tol=1e-6, eval_threads=16,
+                          solve_threads=None):
+        """damping_iter at sizes where the dense (6N)^2 Hessian is out of reach: sparse block evaluation + unpivoted band
+        LDL^T under the pose order `perm` (perm[position] = caller pose; None = natural order).  Returns (poses, trace, rc,
+        seconds) with seconds = dict(eval, solve, cost) summed over the iterations."""
+        x = self._p(poses).copy()
+        perm = np.arange(self.N, dtype=np.int32) if perm is None else np.ascontiguousarray(perm, np.int32)
+        iperm = np.empty(self.N, np.int32)
+        iperm[perm] = np.arange(self.N, dtype=np.int32)
+        # block half-bandwidth of the co-visibility pattern under that order
+        pos = iperm[self.pidx].astype(np.int64)
+        k = np.diff(self.voff)
+        nz = k > 0
+        starts = self.voff[:-1][nz]
+        bwb = int((np.maximum.reduceat(pos, starts) - np.minimum.reduceat(pos, starts)).max()) if len(pos) else 0
+        trace = np.zeros((max_iter, 9))
+        nt = ctypes.c_int()
+        times = np.zeros(3)
+        if solve_threads is None:
+            solve_threads = min(32, os.cpu_count() or 1)
+        rc = self.lib.bo_damping_iter_band(self.N, self.V, self.voff, self.pidx, self.clu, x, iperm, bwb, max_iter, u0, v0,
+                                           rel_tol, int(eval_threads), int(solve_threads), trace, ctypes.byref(nt), times)
+        return x, trace[:nt.value], rc, dict(eval=times[0], solve=times[1], cost=times[2], band_blocks=bwb)
+
+
+def block_parity(H, bi, bj, blocks):
+    """Checker for a dense symmetric Hessian H [6N,6N] (from the path under test) against the block list of
+    COracle.eval_sparse (6x6 row-major, each unordered pose pair once).  Returns (worst per-block relative error, relative
+    weight of everything in H outside the listed blocks)."""
+    n = H.shape[0]
+    N = n // 6
+    Hv = H.reshape(N, 6, N, 6)
+    got = Hv[bi, :, bj, :]                                   # [nb, 6, 6]: got[b, r, c] = H[6 bi + r, 6 bj + c]
+    scale = np.abs(blocks).reshape(len(bi), -1).max(1)
+    err = np.abs(got - blocks).reshape(len(bi), -1).max(1)
+    floor = 1e-6 * np.abs(blocks).max()                      # blocks 1e6 x smaller than the largest: absolute bar
+    worst = float((err / np.maximum(scale, floor)).max())
+    w = np.where(bi == bj, 1.0, 2.0)                         # ||H||_F^2 = sum over listed blocks (off-diagonal ones twice)
+    listed = float((w * (got.reshape(len(bi), -1) ** 2).sum(1)).sum())
+    total = float((H ** 2).sum())
+    return worst, abs(total - listed) / total
 
 
 def ldlt_solve_dense(A, b, nthreads=8):

@@ -586,3 +586,100 @@ int bo_damping_iter(int n_poses, int64_t V, const int64_t *voff, const int32_t *
     free(Hess); free(HuD); free(JacT); free(rhs); free(dxi); free(xt);
     return rc;
 }
+
+/* ------------------------------------------------------------------ a8 at the BASELINE.json sizes
+ * BALM2::damping_iter (bavoxel.hpp:662-767) for systems whose dense (6N)^2 Hessian is out of reach (C3: 12 000^2):
+ * the same loop as bo_damping_iter with the "sparse-honest" evaluation (bo_eval_sparse: thread-local hash maps of pose
+ * blocks merged in thread order) and the unpivoted LDL^T in lower BAND storage under a caller-given pose order
+ * (iperm[caller pose] = position; any permutation is valid -- it only changes the rounding of the factorisation).
+ * The hash maps see the blocks at (pidx[x], pidx[y]) for x < y inside a voxel, whichever is larger.
+ * times[3] (may be NULL) accumulates wall seconds of {evaluation, damped solve, cost-only pass}; eval_threads is passed to
+ * bo_eval_sparse (the reference runs 16 std::threads), the cost pass is single-threaded as in the reference (:176-203,731),
+ * the band solve uses solve_threads.
+ * Returns 0, 1 (zero / non-finite pivot) or -1 (the permutation's bandwidth exceeds bw_blocks). */
+int bo_damping_iter_band(int n_poses, int64_t V, const int64_t *voff, const int32_t *pidx,
+                         const double *clusters, double *poses, const int32_t *iperm, int bw_blocks,
+                         int max_iter, double u, double v, double rel_tol, int eval_threads,
+                         int solve_threads, double *trace, int *n_trace, double *times)
+{
+    int64_t n = 6 * (int64_t)n_poses;
+    int64_t bw = 6 * (int64_t)bw_blocks + 5;
+    if (bw > n - 1) bw = n - 1;
+    int64_t ldab = bw + 1;
+    double *Hb = malloc((size_t)(ldab * n) * sizeof(double)), *HuD = malloc((size_t)(ldab * n) * sizeof(double));
+    double *JacT = malloc(n * sizeof(double)), *gperm = malloc(n * sizeof(double)), *rhs = malloc(n * sizeof(double));
+    double *dxp = malloc(n * sizeof(double)), *dxi = malloc(n * sizeof(double));
+    double *xt = malloc((size_t)n_poses * 12 * sizeof(double));
+    double residual1 = 0, residual2 = 0, q;
+    int is_calc_hess = 1, rows = 0, rc = 0;
+    int64_t cap = 0;
+    int32_t *bi = NULL, *bj = NULL;
+    double *blocks = NULL;
+    if (times) times[0] = times[1] = times[2] = 0.0;
+    for (int it = 0; it < max_iter && rc == 0; it++) {
+        int evaluated = is_calc_hess;
+        if (is_calc_hess) {
+            double t0 = omp_get_wtime();
+            int64_t nb = 0;
+            bo_eval_sparse(n_poses, V, voff, pidx, clusters, poses, eval_threads, 0, NULL, NULL, NULL, &nb, JacT, &residual1);
+            if (nb > cap) {
+                cap = nb + nb / 8;
+                bi = realloc(bi, cap * sizeof(int32_t)); bj = realloc(bj, cap * sizeof(int32_t));
+                blocks = realloc(blocks, (size_t)cap * 36 * sizeof(double));
+            }
+            bo_eval_sparse(n_poses, V, voff, pidx, clusters, poses, eval_threads, cap, bi, bj, blocks, &nb, JacT, &residual1);
+            memset(Hb, 0, (size_t)(ldab * n) * sizeof(double));
+            for (int64_t b = 0; b < nb && rc == 0; b++) {
+                const int64_t I = iperm[bi[b]], J = iperm[bj[b]];
+                const double *B = blocks + 36 * b;
+                if ((I > J ? I - J : J - I) > bw_blocks) { rc = -1; break; }
+                for (int r = 0; r < 6; r++)
+                    for (int c = 0; c < 6; c++) {
+                        const int64_t R = 6 * I + r, C = 6 * J + c;
+                        if (I == J) { if (r >= c) Hb[(R - C) + C * ldab] += B[6 * r + c]; }
+                        else if (R > C) Hb[(R - C) + C * ldab] += B[6 * r + c];
+                        else Hb[(C - R) + R * ldab] += B[6 * r + c];
+                    }
+            }
+            for (int64_t a = 0; a < n; a++) gperm[6 * (int64_t)iperm[a / 6] + a % 6] = JacT[a];
+            if (times) times[0] += 0.5 * (omp_get_wtime() - t0); /* the list is produced twice (count, then fill): one pass counted */
+            if (rc) break;
+        }
+        double t1 = omp_get_wtime();
+        memcpy(HuD, Hb, (size_t)(ldab * n) * sizeof(double));
+        for (int64_t a = 0; a < n; a++) { HuD[a * ldab] += u * Hb[a * ldab]; rhs[a] = -gperm[a]; }
+        if (bo_ldlt_solve_band(n, bw, HuD, ldab, rhs, dxp, solve_threads)) { rc = 1; break; }
+        if (times) times[1] += omp_get_wtime() - t1;
+        for (int64_t a = 0; a < n; a++) dxi[a] = dxp[6 * (int64_t)iperm[a / 6] + a % 6];
+        bo_retract(n_poses, poses, dxi, xt);
+        double q1 = 0;
+        for (int64_t a = 0; a < n; a++) q1 += dxp[a] * (u * Hb[a * ldab] * dxp[a] - gperm[a]);
+        q1 *= 0.5;
+        double c2, t2 = omp_get_wtime();
+        bo_cost(n_poses, V, voff, pidx, clusters, xt, 1, &c2);
+        if (times) times[2] += omp_get_wtime() - t2;
+        residual2 = c2 / (double)V;
+        q1 /= (double)V;
+        q = residual1 - residual2;
+        double *row = trace + 9 * rows++;
+        row[0] = it; row[1] = residual1; row[2] = residual2; row[3] = u; row[4] = v; row[5] = q; row[6] = q1;
+        row[7] = q > 0; row[8] = evaluated;
+        if (q > 0) {
+            memcpy(poses, xt, (size_t)n_poses * 12 * sizeof(double));
+            q = q / q1;
+            v = 2;
+            q = 1 - pow(2 * q - 1, 3);
+            u *= (q < (1.0 / 3.0) ? (1.0 / 3.0) : q);
+            is_calc_hess = 1;
+        } else {
+            u = u * v;
+            v = 2 * v;
+            is_calc_hess = 0;
+        }
+        if (fabs(residual1 - residual2) / residual1 < rel_tol) break;
+    }
+    *n_trace = rows;
+    free(Hb); free(HuD); free(JacT); free(gperm); free(rhs); free(dxp); free(dxi); free(xt);
+    free(bi); free(bj); free(blocks);
+    return rc;
+}

@@ -241,3 +241,40 @@ def test_device_eig3_accuracy(emul):
     out_l, out_U = np.empty(3), np.empty(9)
     emul.emul_eig3(np.array([3.0, 0, 0, 1.0, 0, 2.0]), out_l, out_U)
     assert np.array_equal(out_l, [1.0, 2.0, 3.0])
+
+
+def test_band_lm_twin_equals_dense_lm(oracle_mod):
+    """bo_damping_iter_band (sparse block evaluation + band LDL^T; what the config-size GPU tests and bench.py compare
+    against) == bo_damping_iter (dense, the pinned one): bitwise in the natural pose order, to rounding under a permutation."""
+    d = make_problem(150, 8000, band=12, seed=4)
+    co = oracle_mod.COracle(d["n_poses"], d["voxel_off"], d["pose_idx"], d["clusters"])
+    x1, tr1, rc1 = co.damping_iter(d["poses_init"])
+    x2, tr2, rc2, sec = co.damping_iter_band(d["poses_init"])
+    assert rc1 == 0 and rc2 == 0 and np.array_equal(x1, x2) and np.array_equal(tr1, tr2)
+    assert sec["eval"] > 0 and sec["solve"] > 0 and sec["cost"] > 0
+    perm = np.random.default_rng(0).permutation(150).astype(np.int32)
+    x3, tr3, rc3, _ = co.damping_iter_band(d["poses_init"], perm=perm)
+    assert rc3 == 0 and len(tr3) == len(tr1) and np.abs(x3 - x1).max() <= 1e-9
+    assert np.abs(tr3[:, 1:3] - tr1[:, 1:3]).max() <= 1e-8 * tr1[-1, 2]   # the permutation changes the rounding of the solve
+    # a reject branch as well
+    d = make_problem(12, 60, band=4, seed=1, rot_sigma_deg=0.03, trans_sigma=0.02)
+    co = oracle_mod.COracle(d["n_poses"], d["voxel_off"], d["pose_idx"], d["clusters"])
+    x1, tr1, _ = co.damping_iter(d["poses_init"])
+    x2, tr2, _, _ = co.damping_iter_band(d["poses_init"])
+    assert (tr1[:, 7] == 0).any() and np.array_equal(tr1, tr2) and np.array_equal(x1, x2)
+
+
+def test_block_parity_checker(oracle_mod):
+    d = make_problem(40, 3000, band=10, seed=2)
+    co = oracle_mod.COracle(d["n_poses"], d["voxel_off"], d["pose_idx"], d["clusters"])
+    H, g, c = co.eval_dense(d["poses_init"])
+    bi, bj, blocks, g2, c2 = co.eval_sparse(d["poses_init"])
+    worst, outside = oracle_mod.block_parity(np.ascontiguousarray(H), bi, bj, blocks)
+    assert worst <= 1e-12 and outside <= 1e-14 and np.array_equal(g, g2)
+    Hbad = np.ascontiguousarray(H).copy()
+    i, j = int(bi[5]), int(bj[5])
+    Hbad[6 * i + 1, 6 * j + 2] *= 1.0 + 1e-6
+    assert oracle_mod.block_parity(Hbad, bi, bj, blocks)[0] > 1e-8      # a perturbed entry of one block is seen
+    Hbad = np.ascontiguousarray(H).copy()
+    Hbad[0, 6 * 39 + 3] = Hbad[6 * 39 + 3, 0] = 1e-3 * np.abs(H).max()     # an entry outside the pattern is seen
+    assert oracle_mod.block_parity(Hbad, bi, bj, blocks)[1] > 1e-12
