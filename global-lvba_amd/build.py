@@ -14,7 +14,16 @@ SOURCES = ["lvba_api.hip", "block_system.hip", "balm_kernels.hip", "ldlt.hip", "
            "voxelize.hip", "window_ba.hip", "tracks.hip", "pair_lists.hip", "fusion.hip"]
 HEADERS = ["balm_math.h", "lvba_internal.h", "lvba_common.h", "block_system.h", "visual_math.h", "mempool.h", "voxel_internal.h", "pair_lists.h", "tracks_device.h", "ordering.h", "host_tables.h", "fusion_device.h", os.path.join("..", "..", "include", "lvba_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
-         "-Wall", "-Wno-unused-result", "-Wno-unused-value", "-ffp-contract=fast"]
+         "-Wall", "-Wno-unused-result", "-Wno-unused-value"]
+# Kernels that take DISCRETE decisions on floating-point values (voxel keys, pixel indices, depth / angle / reprojection
+# thresholds, fp32 write-backs: the depth renderer, the track fusion, the triangulation, the anchor merge and down-sampling)
+# must round like the reference's plain x86-64 build, expression by expression: no contraction of a*b+c into FMAs there.
+# The LM kernels (smooth arithmetic, compared at 1e-8) keep the FMAs.
+NO_CONTRACT = {"fusion.hip", "tracks.hip", "window_ba.hip"}
+
+
+def flags_for(src):
+    return FLAGS + ["-ffp-contract=off" if src in NO_CONTRACT else "-ffp-contract=fast"]
 
 
 def hipcc():
@@ -39,7 +48,7 @@ def build(force=False, verbose=False):
     procs = []
     for s in SOURCES:
         o = os.path.join(CSRC, s.replace(".hip", ".o"))
-        cmd = [hipcc(), *FLAGS, "-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [hipcc(), *flags_for(s), "-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -370,14 +370,13 @@ extern "C" int32_t lvba_balm_eval(lvba_balm_t h, const double *poses, double *H,
         launch_export_vec(bs.g(), bs.d_perm, h->N, h->d_out, bs.stream);
         HIPCHK(hipMemcpyAsync(g, h->d_out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, bs.stream));
     }
-    double *dH = nullptr;
+    DevBuf dH(bs.stream); // freed on every path, error returns included
     if (H) {
-        HIPCHK(hipMalloc((void **)&dH, (size_t)(n * n) * sizeof(double)));
-        launch_export_dense(bs.Hblk(), bs.Bb, h->N, bs.d_perm, dH, bs.stream);
-        HIPCHK(hipMemcpyAsync(H, dH, (size_t)(n * n) * sizeof(double), hipMemcpyDeviceToHost, bs.stream));
+        HIPCHK(dH.alloc((size_t)(n * n) * sizeof(double)));
+        launch_export_dense(bs.Hblk(), bs.Bb, h->N, bs.d_perm, dH.as<double>(), bs.stream);
+        HIPCHK(hipMemcpyAsync(H, dH.as<double>(), (size_t)(n * n) * sizeof(double), hipMemcpyDeviceToHost, bs.stream));
     }
     HIPCHK(hipStreamSynchronize(bs.stream));
-    if (dH) hipFree(dH);
     ev_collect(h);
     if (cost_avg) *cost_avg = h->h_pin[0] / (double)h->Vglobal;
     return LVBA_OK;
@@ -446,6 +445,10 @@ extern "C" int32_t lvba_balm_lm_step(lvba_balm_t h, lvba_lm_trace *row, int32_t 
     int32_t status = LVBA_OK;
     if (st) status = LVBA_NUM_FACTORIZATION;
     else if (!isfinite(residual2) || !isfinite(residual1)) status = LVBA_NUM_NONFINITE;
+    // The reference checks neither the LDLT's info() nor the cost (:706-710, :731): a broken factorisation yields a non-finite
+    // step, hence a NaN residual2, `q > 0` is false, the step is rejected, u *= v, and the loop goes on with more damping
+    // (it can recover).  Same here: a flagged solve counts as a rejected step whatever the kernels left in dx.
+    if (st) q = NAN;
     if (row) {
         row->iter = h->iter; row->accepted = q > 0; row->evaluated = evaluated; row->status = status;
         row->residual1 = residual1; row->residual2 = residual2; row->u = h->u; row->v = h->v; row->q = q; row->q1 = q1;
@@ -466,6 +469,7 @@ extern "C" int32_t lvba_balm_lm_step(lvba_balm_t h, lvba_lm_trace *row, int32_t 
     if (fabs(residual1 - residual2) / residual1 < h->lm_opts.rel_tol) h->lm_done = true;   // :760
     if (h->iter >= h->lm_opts.max_iter) h->lm_done = true;                                 // :686
     if (done) *done = h->lm_done ? 1 : 0;
+    // numerical statuses (> 0) are reported, not fatal: the caller may keep stepping, as BALM2::damping_iter does
     if (status == LVBA_NUM_FACTORIZATION) return fail(status, "zero or non-finite pivot in LDL^T (iteration %d)", h->iter - 1);
     if (status == LVBA_NUM_NONFINITE) return fail(status, "non-finite cost (iteration %d)", h->iter - 1);
     return LVBA_OK;
@@ -491,18 +495,25 @@ extern "C" int32_t lvba_balm_refine(lvba_balm_t h, double *poses_inout, const lv
     if (!h || !poses_inout) return fail(LVBA_ERR_ARG, "NULL argument");
     if (n_trace) *n_trace = 0;
     TRY(lvba_balm_lm_begin(h, poses_inout, opts));
-    int32_t rows = 0, done = h->lm_done ? 1 : 0, rc = LVBA_OK;
+    int32_t rows = 0, done = h->lm_done ? 1 : 0, rc = LVBA_OK, worst = LVBA_OK;
+    char worst_msg[512] = "";
     while (!done) {
         lvba_lm_trace row;
         rc = lvba_balm_lm_step(h, &row, &done);
         if (rc < 0) break;
         if (trace) trace[rows] = row;
         rows++;
-        if (rc > 0) break; // numerical failure: stop like the reference's FAILURE early-return (lvba_system.cpp:1646)
+        // a numerical failure (zero pivot, non-finite cost) does NOT end the loop: BALM2::damping_iter (bavoxel.hpp:686-766)
+        // has no such exit -- the step is rejected, u *= v, and up to 10 iterations run.  The status is kept in the trace row
+        // and the worst one is returned at the end.
+        if (rc > worst) { worst = rc; snprintf(worst_msg, sizeof worst_msg, "%s", lvba_last_error()); }
     }
     if (n_trace) *n_trace = rows;
     const int32_t rc2 = lvba_balm_lm_end(h, poses_inout);
-    return rc != LVBA_OK ? rc : rc2;
+    if (rc < 0) return rc;
+    if (rc2 != LVBA_OK) return rc2;
+    if (worst != LVBA_OK) return fail(worst, "%s", worst_msg);
+    return LVBA_OK;
 }
 
 // ------------------------------------------------------------------------------------------ multi-GPU

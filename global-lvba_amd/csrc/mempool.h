@@ -44,6 +44,8 @@ class DevicePool {
         }
         hipError_t e = hipMalloc(p, cls);
         if (e == hipErrorOutOfMemory) { // give the cache back and retry once
+            (void)hipGetLastError(); // the failed hipMalloc stays latched in the thread's last-error slot: a later
+                                     // HIPCHK(hipGetLastError()) would report NOMEM although the retry succeeded
             release();
             e = hipMalloc(p, cls);
         }

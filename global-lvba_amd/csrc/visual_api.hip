@@ -240,11 +240,11 @@ extern "C" int32_t lvba_visual_linearize(lvba_visual_t h, const double *q, const
     vis_launch_reduced_system(d, bs.pair_dev(), radius, o.min_lm_diagonal, o.max_lm_diagonal, bs.Hblk(), bs.hblk_doubles, bs.g(),
                               h->d_gmax, false, bs.stream);
     const int64_t n = 6 * (int64_t)h->M;
-    double *dS = nullptr;
+    DevBuf dS(bs.stream); // freed on every path, error returns included
     if (S) {
-        HIPCHK(hipMalloc((void **)&dS, (size_t)(n * n) * sizeof(double)));
-        launch_export_dense(bs.Hblk(), bs.Bb, h->M, bs.d_perm, dS, bs.stream);
-        HIPCHK(hipMemcpyAsync(S, dS, (size_t)(n * n) * sizeof(double), hipMemcpyDeviceToHost, bs.stream));
+        HIPCHK(dS.alloc((size_t)(n * n) * sizeof(double)));
+        launch_export_dense(bs.Hblk(), bs.Bb, h->M, bs.d_perm, dS.as<double>(), bs.stream);
+        HIPCHK(hipMemcpyAsync(S, dS.as<double>(), (size_t)(n * n) * sizeof(double), hipMemcpyDeviceToHost, bs.stream));
     }
     if (rhs) {
         launch_export_vec(bs.g(), bs.d_perm, h->M, h->d_out, bs.stream);
@@ -252,7 +252,6 @@ extern "C" int32_t lvba_visual_linearize(lvba_visual_t h, const double *q, const
     }
     HIPCHK(hipMemcpyAsync(h->h_pin, h->d_scal, sizeof(double), hipMemcpyDeviceToHost, bs.stream));
     HIPCHK(hipStreamSynchronize(bs.stream));
-    if (dS) hipFree(dS);
     HIPCHK(hipGetLastError());
     if (cost) *cost = 0.5 * h->h_pin[0];
     return LVBA_OK;
@@ -307,13 +306,15 @@ extern "C" int32_t lvba_visual_refine(lvba_visual_t h, double *q, double *t, dou
         int st = 0;
         memcpy(&st, h->h_pin + 9, sizeof(int));
         if (first) { push(0, 1, 1, cost, 0.0, 0.0, radius, 0.0, gmax); first = false; }
-        if (gmax <= o.gradient_tolerance) { term = LVBA_TERM_GRADIENT; break; }
+        // TrustRegionMinimizer::FinalizeIterationAndCheckIfMinimizerCanContinue: iterations, then gradient, then radius
         if (it > o.max_iter) { term = LVBA_TERM_NO_CONVERGENCE; break; }
+        if (gmax <= o.gradient_tolerance) { term = LVBA_TERM_GRADIENT; break; }
         const double cand = 0.5 * h->h_pin[1], model = h->h_pin[2];
         const double step_norm = sqrt(h->h_pin[3]), x_norm = sqrt(h->h_pin[4]);
         const bool finite_step = st == 0 && isfinite(model) && isfinite(step_norm);
-        if (!finite_step || !(model > 0.0)) { // LevenbergMarquardtStrategy::StepIsInvalid
-            radius *= 0.5;
+        if (!finite_step || !(model > 0.0)) { // LevenbergMarquardtStrategy::StepIsInvalid = StepRejected(0): /2, /4, /8 ...
+            radius = radius / decrease_factor;
+            decrease_factor *= 2.0;
             push(it, 0, 0, cost, 0.0, 0.0, radius, 0.0, gmax);
             if (++invalid_run >= 5) { term = LVBA_TERM_FAILURE; rc = fail(LVBA_NUM_FACTORIZATION, "5 consecutive invalid steps"); }
             if (radius < o.min_radius) { term = LVBA_TERM_RADIUS; break; }

@@ -437,6 +437,15 @@ extern "C" int32_t lvba_lidar_ba(lvba_scans_t sc, const double *poses_in, const 
             lvba_voxmap_info_t mi;
             lvba_voxmap_info(map, &mi);
             r.stage_voxels[idx] = mi.n_voxels; r.stage_factors[idx] = mi.n_factors; r.stage_ran[idx] = 1;
+            if (mi.n_voxels == 0) {
+                // nothing admitted at this stage's voxel size: upstream, damping_iter over an empty VOX_HESS averages 0 / 0
+                // (bavoxel.hpp:634-635), every step is rejected on the NaN cost and the poses come out as they went in
+                // (src/lvba_system.cpp:386) -- the stage is a no-op, the next stage and the anchor / rel composition still run
+                lvba_voxmap_destroy(map);
+                r.stage_ran[idx] = 0;
+                r.stage_ms[idx] = now_ms() - t0;
+                continue;
+            }
             lvba_balm_t b = nullptr;
             int32_t rc = lvba_voxmap_to_balm(map, &b);
             lvba_voxmap_destroy(map);

@@ -325,8 +325,11 @@ int32_t lvba_triangulate_tracks(int32_t device, int32_t n_cams, int64_t n_tracks
  *   filter, mean reprojection error), the triangulation candidate (DLT over the first observation of every image, the same
  *   filter around the seed, DLT again over >= 4 kept observations), then the reference's selection.  depth may be NULL
  *   (triangulation candidate only).  status[t] = 0 dropped / 1 triangulated / 2 depth-fused; X [n][3]; mean_reproj [n]
- *   (+inf when dropped); kept [O] = the track's inlier_indices as a mask.  Where the reference iterates an unordered_map
- *   of images, images are visited in the order of their first occurrence in the component. */
+ *   (+inf when dropped); kept [O] = the track's inlier_indices as a mask.  Where the reference iterates a
+ *   std::unordered_map<int,int> of images (unique_id :994, best_id :1051, kept_id_depth :1064), images are visited in the order libstdc++ gives that
+ *   container for the reference's reserve() and insertion sequence (bucket = key mod the rehash policy's prime, a new node
+ *   goes to the front of its bucket and a new bucket to the front of the list: csrc/tracks_device.h umap_order), because
+ *   the greedy view-angle filter's survivors depend on it. */
 typedef struct lvba_depth_s *lvba_depth_t;
 int32_t lvba_depth_render(lvba_scans_t scans, const double *scan_poses, const double *scan_times, int32_t n_images,
                           const double *image_times, const double *Rcw, const double *tcw, const double intr[8],

@@ -24,8 +24,10 @@ manifold.cc, rotation.h):
   * ceres::QuaternionRotatePoint normalises q before rotating (utils.hpp:72);
   * Jacobi scaling 1/(1+sqrt(colnorm^2)) fixed at iteration 0; LM diagonal sqrt(clamp(colnorm^2,1e-6,1e32)/radius);
     initial radius 1e4; accept if relative decrease > 1e-3; radius /= max(1/3, 1-(2 rho-1)^3) on success,
-    radius /= decrease_factor (2,4,8,...) on failure; parameter tolerance 1e-8, function tolerance 1e-6, gradient
-    tolerance 1e-10, checked in Ceres' order (parameter, function, then accept/reject).
+    radius /= decrease_factor (2,4,8,...) on failure AND on an invalid step (LevenbergMarquardtStrategy::StepIsInvalid is
+    StepRejected(0); five invalid steps in a row are a FAILURE); parameter tolerance 1e-8, function tolerance 1e-6,
+    checked in Ceres' order (parameter, function, then accept/reject); at the end of every iteration
+    FinalizeIterationAndCheckIfMinimizerCanContinue tests max iterations, then gradient tolerance 1e-10, then min radius.
 The solver restatement is pinned only by self-consistency tests (tests/test_visual_oracle.py): autograd Jacobians vs finite differences,
 Schur-complement solve vs the full normal equations, manifold Plus/PlusJacobian consistency.
 """
@@ -215,8 +217,12 @@ class VisualOracle:
         trace = [dict(iter=0, cost=cost, cost_change=0.0, step_norm=0.0, radius=radius, accepted=1, rho=0.0)]
         status = "NO_CONVERGENCE"
         g = J.T @ r
+        # FinalizeIterationAndCheckIfMinimizerCanContinue checks iterations, then gradient, then radius
+        if max_iter <= 0:
+            return (q, t, X), trace, "NO_CONVERGENCE"
         if np.abs(g / scale).max(initial=0.0) <= 1e-10:
             return (q, t, X), trace, "CONVERGENCE(gradient)"
+        invalid_run = 0
         x_norm = float(np.sqrt((q[1:] ** 2).sum() + (t[1:] ** 2).sum() + (X[self.act] ** 2).sum()))
         it = 0
         while True:
@@ -228,15 +234,34 @@ class VisualOracle:
             x = self.solve_schur(J, r, D)
             step = -x
             if not np.all(np.isfinite(step)):
-                radius *= 0.5
+                # LevenbergMarquardtStrategy::StepIsInvalid = StepRejected(0): radius / 2, / 4, / 8 ... ; five in a row fail
+                radius = radius / decrease_factor
+                decrease_factor *= 2.0
                 trace.append(dict(iter=it, cost=cost, cost_change=0.0, step_norm=0.0, radius=radius, accepted=0, rho=0.0))
+                invalid_run += 1
+                if invalid_run >= 5:
+                    status = "FAILURE"
+                    break
+                if radius < 1e-32:
+                    status = "CONVERGENCE(radius)"
+                    break
                 continue
             mr = J @ step
             model_cost_change = -float(mr @ (r + mr / 2.0))
             if model_cost_change <= 0.0:
-                radius *= 0.5
+                # LevenbergMarquardtStrategy::StepIsInvalid = StepRejected(0): radius / 2, / 4, / 8 ... ; five in a row fail
+                radius = radius / decrease_factor
+                decrease_factor *= 2.0
                 trace.append(dict(iter=it, cost=cost, cost_change=0.0, step_norm=0.0, radius=radius, accepted=0, rho=0.0))
+                invalid_run += 1
+                if invalid_run >= 5:
+                    status = "FAILURE"
+                    break
+                if radius < 1e-32:
+                    status = "CONVERGENCE(radius)"
+                    break
                 continue
+            invalid_run = 0
             delta = step * scale
             q2, t2, X2 = self.plus(q, t, X, delta)
             cand = self.cost(q2, t2, X2)
@@ -261,6 +286,8 @@ class VisualOracle:
                 decrease_factor = 2.0
                 trace.append(dict(iter=it, cost=cost, cost_change=cost_change, step_norm=step_norm, radius=radius, accepted=1, rho=rho))
                 g = J.T @ r
+                if it >= max_iter:                      # MaxSolverIterationsReached comes before GradientToleranceReached
+                    break
                 if np.abs(g / scale).max(initial=0.0) <= 1e-10:
                     status = "CONVERGENCE(gradient)"
                     break

@@ -127,7 +127,7 @@ def test_pipeline_from_a_dataset_directory(pkg, tmp_path):
                                  d["matches"], **cfg)
     assert np.abs(got["poses"] - ref["poses"]).max() < 1e-5
     gv, rv = got["visual"], ref["visual"]
-    assert gv["n_components"] == rv["n_components"] and (gv["track_status"] == rv["track_status"]).mean() > 0.97
+    assert gv["n_components"] == rv["n_components"] and np.array_equal(gv["track_status"], rv["track_status"])
     assert np.abs(gv["tcw"] - rv["tcw"]).max() < 1e-3
     out = tmp_path / "out"
     assert (out / "lidar_poses_refined.txt").exists() and (out / "images.txt").exists() and (out / "points3D.txt").exists()
@@ -155,22 +155,19 @@ def test_pipeline_matches_the_reference_system_golden(pkg):
     assert np.abs(out["poses"] - z["scan_poses_out"]).max() < 1e-5
     v = out["visual"]
     assert np.abs(v["Rcw_lidar"] - z["Rcw"]).max() < 1e-5 and np.abs(v["tcw_lidar"] - z["tcw"]).max() < 1e-5
-    # tracks (BuildTracksAndFuse3D): the GPU depth images differ from the reference's in a few boundary pixels, which can flip a
-    # track whose depth candidate sits at a threshold -- 97 % of the reference's tracks must be there with the same start and
-    # the same landmark, and no more than 3 % may be extra
+    # tracks (BuildTracksAndFuse3D): index work -- the bar is exact.  The depth renderer, the fusion and the triangulation are
+    # compiled without FMA contraction (build.py: NO_CONTRACT), like the plain x86-64 build the golden file came from, so every
+    # depth pixel, every threshold decision and hence every track agrees: the same tracks in the same order.
     T = v["tracks"]
-    mine = {(int(T["obs_img"][a]), int(T["obs_kp"][a])): n for n, a in enumerate(T["obs_off"][:-1])}
-    hit = [mine.get((int(i), int(k)), -1) for i, k in z["track_start"]]
-    found = np.array([h >= 0 for h in hit])
-    assert found.mean() >= 0.97 and len(T["X"]) <= 1.03 * len(z["track_X"])
-    idx = np.array([h for h in hit if h >= 0])
-    dX = np.abs(T["X"][idx] - z["track_X"][found]).max(axis=1)
-    assert (dX < 1e-5).mean() >= 0.97
-    same = dX < 1e-5
-    assert np.array_equal(np.diff(T["obs_off"])[idx][same], z["track_len"][found][same])
-    assert (np.array([T["kept"][T["obs_off"][h]:T["obs_off"][h + 1]].sum() for h in idx])[same] == z["track_inliers"][found][same]).mean() > 0.99
+    starts = np.stack([T["obs_img"][T["obs_off"][:-1]], T["obs_kp"][T["obs_off"][:-1]]], 1)
+    assert len(T["X"]) == len(z["track_X"]), (len(T["X"]), len(z["track_X"]))
+    assert np.array_equal(starts, z["track_start"])
+    assert np.abs(T["X"] - z["track_X"]).max() < 1e-5, float(np.abs(T["X"] - z["track_X"]).max())   # the scan poses agree to 1e-5 only
+    assert np.array_equal(np.diff(T["obs_off"]), z["track_len"])
+    inl = np.add.reduceat(T["kept"].astype(np.int64), T["obs_off"][:-1])
+    assert np.array_equal(inl, z["track_inliers"])
     assert (T["attempts"] > 0).sum() >= 10                                   # the reference's retries are exercised
-    # the problem handed to the solver: landmarks with a plane, residual count, cost at the initial point (3 %: a flipped track
-    # moves it)
-    assert abs(int(v["landmark_valid"].sum()) - int(z["n_points"])) <= 0.03 * int(z["n_points"])
-    assert abs(v["trace"][0]["cost"] - float(z["cost0"])) <= 0.03 * float(z["cost0"])
+    # the problem handed to the solver: landmarks with a plane, and the cost at the initial point (it is a smooth function of
+    # the refined scan poses, which agree to 1e-5 m over two LM loops; whitened residuals are O(1/0.01 m) per metre)
+    assert int(v["landmark_valid"].sum()) == int(z["n_points"])
+    assert abs(v["trace"][0]["cost"] - float(z["cost0"])) <= 1e-3 * float(z["cost0"]), (v["trace"][0]["cost"], float(z["cost0"]))
