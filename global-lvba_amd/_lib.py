@@ -15,7 +15,7 @@ SYMBOLS = [
     "lvba_balm_create", "lvba_balm_destroy", "lvba_balm_configure", "lvba_balm_info", "lvba_balm_cost",
     "lvba_balm_eval", "lvba_balm_solve", "lvba_balm_refine", "lvba_balm_lm_begin", "lvba_balm_lm_step",
     "lvba_balm_lm_end", "lvba_balm_set_profiling", "lvba_balm_get_profile", "lvba_balm_get_ordering",
-    "lvba_dist_unique_id", "lvba_balm_dist_init",
+    "lvba_dist_unique_id", "lvba_balm_dist_init", "lvba_dist_host_unique_id",
     "lvba_visual_default_opts", "lvba_visual_create", "lvba_visual_destroy", "lvba_visual_cost", "lvba_visual_linearize",
     "lvba_visual_refine",
     "lvba_voxel_default_opts", "lvba_voxmap_build", "lvba_voxmap_destroy", "lvba_voxmap_info", "lvba_voxmap_export",
@@ -173,6 +173,7 @@ def load():
     lib.lvba_balm_get_profile.argtypes = [H, C.POINTER(Prof), C.c_int32]
     lib.lvba_balm_get_ordering.argtypes = [H, i32p]
     lib.lvba_dist_unique_id.argtypes = [C.c_char_p]
+    lib.lvba_dist_host_unique_id.argtypes = [C.c_char_p]
     lib.lvba_balm_dist_init.argtypes = [H, C.c_int32, C.c_int32, C.c_char_p]
     u8p = np.ctypeslib.ndpointer(np.uint8, flags="C")
     lib.lvba_visual_default_opts.argtypes = [C.POINTER(VisualOpts)]

@@ -85,6 +85,13 @@ class BalmProblem:
         L.check(L.load().lvba_dist_unique_id(buf))
         return buf.raw
 
+    @staticmethod
+    def host_unique_id():
+        """Id of the single-box test transport (ranks = host threads of this process; lvba_dist_host_unique_id)."""
+        buf = C.create_string_buffer(128)
+        L.check(L.load().lvba_dist_host_unique_id(buf))
+        return buf.raw
+
     def dist_init(self, n_ranks, rank, uid):
         L.check(self.lib.lvba_balm_dist_init(self._h, int(n_ranks), int(rank), bytes(uid)))
 

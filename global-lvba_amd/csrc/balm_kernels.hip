@@ -464,8 +464,90 @@ __global__ __launch_bounds__(256) void balm_pair_staged_kernel(PairDev d, double
     }
 }
 
-// blocks whose pair list was cut into several work items (few blocks, many pairs each: window BA): the partial blocks are
-// added up in item order -- still no atomics, still bitwise reproducible
+// ------------------------------------------------------------------------------------------------
+// pass 3, column-per-lane form (the default).  The pair lists are grouped by (voxel window, block): the pairs the chip is
+// working on at any moment then draw on one window's Y records -- an L2-sized slice of every pose's segment -- instead of
+// the whole 1.4 GB array (PMC at C3: L2 misses 64 M -> 29 M per pass).  That makes the items short (C3: ~9 pairs per
+// (window, block)), and the 16-lane forms above then spend their time on per-item overhead (36 DPP row reductions and a
+// half-empty gather round per item).  Here SIX LANES own one item, lane c holding column c of the 6 x 6 block: per pair a
+// lane needs Y_I (18 doubles, the same for the six lanes: an LDS broadcast) and the three entries Y_J[c], Y_J[6+c],
+// Y_J[12+c], and does 18 FMAs -- no cross-lane reduction at all, 80 VGPRs, 6 waves per SIMD to hide the gathers.  A
+// wavefront walks 10 items in lock-step, one pair of each per round: the 20 records of a round are fetched cooperatively
+// (180 consecutive 16-byte chunks, a lane run of nine covers one 144-byte record), parked in LDS, and the next round's pair
+// indices are already on their way.  Every lane ends with one 48-byte store; a group's 288 bytes are contiguous (a block
+// with a single item goes straight into the store, the others into partial blocks in item order).
+// ------------------------------------------------------------------------------------------------
+#define LVBA_PC_ITEMS 10 // items per wavefront (6 lanes each; lanes 60..63 only help fetching)
+__global__ __launch_bounds__(256) void balm_pair_col_kernel(PairDev d, double *__restrict__ Hblk)
+{
+    __shared__ double2 recs[4][LVBA_PC_ITEMS * 18]; // per wavefront: 10 pairs x (x record, y record) x 9 chunks of 16 bytes
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t per_xcd = (gridDim.x + 7) / 8; // XCD x sweeps a contiguous eighth of the items = a range of voxel windows
+    const int64_t wg = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int64_t i0 = (wg * 4 + wv) * LVBA_PC_ITEMS;
+    if (i0 >= d.nnzb) return; // wavefront-uniform; no workgroup barrier below
+    const int g = lane / 6, cc = lane - 6 * g; // item of the wavefront, column of its block (g = 10: idle lanes 60..63)
+    // lane l < 10 also keeps the pair-list range of item l (the fetch side asks for it through shuffles)
+    int64_t fa = 0, fb = 0;
+    if (lane < LVBA_PC_ITEMS && i0 + lane < d.nnzb) { fa = d.blk_off[i0 + lane]; fb = d.blk_off[i0 + lane + 1]; }
+    const int flen = (int)(fb - fa);
+    int rounds = flen;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) { const int t = __shfl_xor(rounds, o, 16); rounds = t > rounds ? t : rounds; }
+    rounds = __shfl(rounds, 0, 64); // max over lanes 0..15
+    const int mylen = __shfl(flen, g < LVBA_PC_ITEMS ? g : 0, 64);
+    const bool owner = g < LVBA_PC_ITEMS && i0 + g < d.nnzb;
+    double2 *rw = recs[wv];
+    double acc[6];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) acc[e] = 0.0;
+    int2 pr = (lane < LVBA_PC_ITEMS && 0 < flen) ? d.pairs[fa] : make_int2(0, 0);
+    for (int r = 0; r < rounds; ++r) {
+        double2 v[3];
+#pragma unroll
+        for (int s2 = 0; s2 < 3; ++s2) {
+            const int c = lane + 64 * s2; // chunk c of the round: record c / 9 (item rc >> 1, side rc & 1), piece c % 9
+            const int rc = c / 9, piece = c - 9 * rc, gi = rc >> 1;
+            const int px = __shfl(pr.x, gi < LVBA_PC_ITEMS ? gi : 0, 64), py = __shfl(pr.y, gi < LVBA_PC_ITEMS ? gi : 0, 64);
+            const int ln = __shfl(flen, gi < LVBA_PC_ITEMS ? gi : 0, 64);
+            const int pos = (rc & 1) ? py : px;
+            v[s2] = (c < LVBA_PC_ITEMS * 18 && r < ln) ? reinterpret_cast<const double2 *>(d.Y + 18 * (int64_t)pos)[piece]
+                                                      : make_double2(0.0, 0.0);
+        }
+        // next round's pair indices: issued before this round's records are waited for
+        const int2 prn = (lane < LVBA_PC_ITEMS && r + 1 < flen) ? d.pairs[fa + r + 1] : make_int2(0, 0);
+#pragma unroll
+        for (int s2 = 0; s2 < 3; ++s2) {
+            const int c = lane + 64 * s2;
+            if (c < LVBA_PC_ITEMS * 18) rw[c] = v[s2];
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (owner && r < mylen) {
+            const double2 *ri = rw + 18 * g;
+            const double *yj = reinterpret_cast<const double *>(ri + 9);
+            double Yi[18];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) {
+                const double2 x = ri[e];
+                Yi[2 * e] = x.x; Yi[2 * e + 1] = x.y;
+            }
+            const double j0 = yj[cc], j1 = yj[6 + cc], j2 = yj[12 + cc];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) acc[e] += Yi[e] * j0 + Yi[6 + e] * j1 + Yi[12 + e] * j2;
+        }
+        __builtin_amdgcn_wave_barrier();
+        pr = prn;
+    }
+    if (owner) {
+        const int64_t dst = d.blk_slot[i0 + g];
+        double2 *hp = reinterpret_cast<double2 *>((dst >= 0 ? Hblk + dst * 36 : d.partial + (-dst - 1) * 36) + 6 * cc);
+#pragma unroll
+        for (int e = 0; e < 3; ++e) hp[e] = make_double2(-acc[2 * e], -acc[2 * e + 1]);
+    }
+}
+
+// blocks assembled from several work items (one per voxel window, and lists cut at LVBA_PAIR_CUT pairs): the partial blocks
+// are added up in item order -- still no atomics, still bitwise reproducible
 __global__ void balm_pair_reduce_kernel(PairDev d, double *__restrict__ Hblk)
 {
     const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -473,7 +555,7 @@ __global__ void balm_pair_reduce_kernel(PairDev d, double *__restrict__ Hblk)
     const int e = (int)(t - 36 * m);
     if (m >= d.n_multi) return;
     double s = 0.0;
-    for (int64_t q = d.multi_off[m]; q < d.multi_off[m + 1]; ++q) s += d.partial[36 * q + e];
+    for (int64_t q = d.multi_off[m]; q < d.multi_off[m + 1]; ++q) s += d.partial[36 * d.multi_idx[q] + e];
     Hblk[d.multi_slot[m] * 36 + e] = s;
 }
 
@@ -606,11 +688,18 @@ void launch_cost(const BalmDev &d, const double *poses, double *chunk_cost, doub
 
 void launch_pairs(const PairDev &pd, double *Hblk, hipStream_t s)
 {
+    // LVBA_PAIR = gather: the lane-per-record form of the 16-lane kernel, kept for A/B runs
     static const bool gather = [] { const char *e = getenv("LVBA_PAIR"); return e && !strcmp(e, "gather"); }();
+    const int mode = pd.col_form ? 0 : gather ? 1 : 2;
     if (pd.nnzb > 0) {
-        const dim3 grid((unsigned)((((pd.nnzb + 15) / 16) + 7) / 8 * 8));
-        if (gather) hipLaunchKernelGGL(balm_pair_kernel, grid, dim3(256), 0, s, pd, Hblk);
-        else hipLaunchKernelGGL(balm_pair_staged_kernel, grid, dim3(256), 0, s, pd, Hblk);
+        if (mode == 0) {
+            const dim3 grid((unsigned)((((pd.nnzb + 4 * LVBA_PC_ITEMS - 1) / (4 * LVBA_PC_ITEMS)) + 7) / 8 * 8));
+            hipLaunchKernelGGL(balm_pair_col_kernel, grid, dim3(256), 0, s, pd, Hblk);
+        } else {
+            const dim3 grid((unsigned)((((pd.nnzb + 15) / 16) + 7) / 8 * 8));
+            if (mode == 1) hipLaunchKernelGGL(balm_pair_kernel, grid, dim3(256), 0, s, pd, Hblk);
+            else hipLaunchKernelGGL(balm_pair_staged_kernel, grid, dim3(256), 0, s, pd, Hblk);
+        }
     }
     if (pd.n_multi > 0)
         hipLaunchKernelGGL(balm_pair_reduce_kernel, dim3((unsigned)((pd.n_multi * 36 + 255) / 256)), dim3(256), 0, s, pd, Hblk);

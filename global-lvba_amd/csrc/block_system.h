@@ -5,6 +5,7 @@
 // of the atomic-free assembly, the block-band store [H | g | scalars], the LDL^T workspace + captured hipGraph,
 // and the RCCL communicator.  The factor payload (clusters, observations) stays with the caller.
 #pragma once
+#include <memory>
 #include <vector>
 #include "lvba_common.h"
 #include "lvba_internal.h"
@@ -30,8 +31,9 @@ struct BlockSys {
     int32_t S = 1;        // slices per block for the per-factor reduction
     int64_t nnzb = 0;
     int64_t *d_csc_off = nullptr, *d_blk_off = nullptr, *d_blk_slot = nullptr;
+    bool pair_col = false;            // which pair kernel the item lists were cut for
     int64_t n_items = 0, n_multi = 0; // work items of the pair pass (>= nnzb), blocks cut into several items
-    int64_t *d_multi_off = nullptr, *d_multi_slot = nullptr;
+    int64_t *d_multi_off = nullptr, *d_multi_slot = nullptr, *d_multi_idx = nullptr;
     double *d_partial = nullptr;
     int32_t *d_group_of_pos = nullptr, *d_csc_f = nullptr, *d_pos_of = nullptr;
     int2 *d_pairs = nullptr;
@@ -49,6 +51,8 @@ struct BlockSys {
     // distributed
     int n_ranks = 1, rank = 0;
     ncclComm_t comm = nullptr;
+    std::shared_ptr<struct HostComm> hostcomm; // single-box test transport (see bs_dist_init): ranks = host threads
+    bool distributed() const { return comm != nullptr || hostcomm != nullptr; }
     // packed all-reduce: slots of the blocks that are non-zero on ANY rank (+ the diagonal), and the staging buffer
     int64_t n_ar = 0, *d_ar_slot = nullptr;
     double *d_arbuf = nullptr;
@@ -62,7 +66,7 @@ struct BlockSys {
     {
         PairDev p;
         p.nnzb = n_items; p.blk_off = d_blk_off; p.blk_slot = d_blk_slot; p.pairs = d_pairs; p.Y = d_Y;
-        p.partial = d_partial; p.n_multi = n_multi; p.multi_off = d_multi_off; p.multi_slot = d_multi_slot;
+        p.partial = d_partial; p.n_multi = n_multi; p.multi_off = d_multi_off; p.multi_slot = d_multi_slot; p.multi_idx = d_multi_idx; p.col_form = pair_col ? 1 : 0;
         return p;
     }
 };
@@ -87,6 +91,8 @@ int32_t bs_enqueue_solve(BlockSys &bs, double u);
 int32_t bs_allreduce(BlockSys &bs, double *buf, size_t count);
 // all-reduce [Hblk | g | cost] over the ranks: only the blocks of the union sparsity pattern travel when that is known
 int32_t bs_allreduce_hg(BlockSys &bs);
+// all-reduce `count` elements of a device buffer in place (sum or max; double / int64 / int32 / uint8) over the ranks
+int32_t bs_comm_allreduce(BlockSys &bs, void *dbuf, size_t count, ncclDataType_t dt, ncclRedOp_t op);
 int32_t bs_dist_init(BlockSys &bs, int32_t n_ranks, int32_t rank, const char uid[128], int64_t *group_count_inout);
 void bs_destroy(BlockSys &bs);
 // +1 / -1 around sections in which several host threads use the library concurrently: solve graphs are not captured then

@@ -10,7 +10,11 @@
 #include <time.h>
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <map>
+#include <mutex>
 #include <queue>
+#include <string>
 #include <vector>
 #include "block_system.h"
 #include "pair_lists.h"
@@ -62,7 +66,86 @@ extern "C" int32_t lvba_dist_unique_id(char uid[128])
     return LVBA_OK;
 }
 
+// ------------------------------------------------------------------------------------------ host-staged transport
+// A second transport behind the same all-reduce calls, for ONE purpose: running the multi-rank code paths (the max-reduced
+// band width, the all-reduced adjacency and the common pose order it yields, the packed [H | g | cost] all-reduce, the
+// global voxel count) with N > 1 ranks on a box with ONE GPU, where RCCL refuses two ranks on the same device.  Ranks are
+// host threads of one process, each with its own handle and stream on the same device; an all-reduce copies every rank's
+// buffer to the host, meets the others at a barrier, sums in RANK ORDER (so every rank computes bitwise the same result, as
+// RCCL guarantees for its own reductions) and copies the result back.  Selected by a unique id that starts with
+// "LVBAHOST:" (lvba_dist_host_unique_id); never used when a real multi-GPU job passes an RCCL id.  It moves data only:
+// every arithmetic operation on problem data still runs in the kernels.
 namespace lvba {
+struct HostComm {
+    int n = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t gen = 0;
+    std::vector<std::vector<unsigned char>> stage;
+    void barrier()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        const uint64_t g = gen;
+        if (++arrived == n) { arrived = 0; ++gen; cv.notify_all(); }
+        else cv.wait(lk, [&] { return gen != g; });
+    }
+};
+} // namespace lvba
+static std::mutex g_hostcomm_mu;
+static std::map<std::string, std::weak_ptr<lvba::HostComm>> g_hostcomms;
+static std::atomic<uint64_t> g_hostcomm_serial{0};
+
+extern "C" int32_t lvba_dist_host_unique_id(char uid[128])
+{
+    if (!uid) return lvba_fail(LVBA_ERR_ARG, "uid is NULL");
+    memset(uid, 0, 128);
+    snprintf(uid, 128, "LVBAHOST:%llu:%p", (unsigned long long)g_hostcomm_serial.fetch_add(1), (void *)&g_hostcomms);
+    return LVBA_OK;
+}
+
+template <typename T>
+static void host_reduce(std::vector<std::vector<unsigned char>> &stage, size_t count, bool is_max, T *out)
+{
+    const int n = (int)stage.size();
+    const T *r0 = reinterpret_cast<const T *>(stage[0].data());
+    for (size_t e = 0; e < count; ++e) out[e] = r0[e];
+    for (int r = 1; r < n; ++r) {
+        const T *p = reinterpret_cast<const T *>(stage[(size_t)r].data());
+        if (is_max) { for (size_t e = 0; e < count; ++e) out[e] = p[e] > out[e] ? p[e] : out[e]; }
+        else { for (size_t e = 0; e < count; ++e) out[e] = (T)(out[e] + p[e]); }
+    }
+}
+
+namespace lvba {
+
+int32_t bs_comm_allreduce(BlockSys &bs, void *dbuf, size_t count, ncclDataType_t dt, ncclRedOp_t op)
+{
+    if (bs.comm) {
+        NCCLCHK(g_rccl.AllReduce(dbuf, dbuf, count, dt, op, bs.comm, bs.stream));
+        return LVBA_OK;
+    }
+    if (!bs.hostcomm) return LVBA_OK;
+    HostComm &hc = *bs.hostcomm;
+    const size_t esz = dt == ncclDouble || dt == ncclInt64 ? 8 : dt == ncclInt32 ? 4 : 1;
+    if (!(op == ncclSum || op == ncclMax) || !(dt == ncclDouble || dt == ncclInt64 || dt == ncclInt32 || dt == ncclUint8))
+        return lvba_fail(LVBA_ERR_UNSUPPORTED, "host transport: unsupported all-reduce type");
+    std::vector<unsigned char> &mine = hc.stage[(size_t)bs.rank];
+    mine.resize(count * esz);
+    HIPCHK(hipMemcpyAsync(mine.data(), dbuf, count * esz, hipMemcpyDeviceToHost, bs.stream));
+    HIPCHK(hipStreamSynchronize(bs.stream));
+    hc.barrier();
+    std::vector<unsigned char> res(count * esz);
+    const bool is_max = op == ncclMax;
+    if (dt == ncclDouble) host_reduce<double>(hc.stage, count, is_max, reinterpret_cast<double *>(res.data()));
+    else if (dt == ncclInt64) host_reduce<int64_t>(hc.stage, count, is_max, reinterpret_cast<int64_t *>(res.data()));
+    else if (dt == ncclInt32) host_reduce<int32_t>(hc.stage, count, is_max, reinterpret_cast<int32_t *>(res.data()));
+    else host_reduce<uint8_t>(hc.stage, count, is_max, res.data());
+    hc.barrier(); // nobody refills its stage before everybody has read it
+    HIPCHK(hipMemcpyAsync(dbuf, res.data(), count * esz, hipMemcpyHostToDevice, bs.stream));
+    HIPCHK(hipStreamSynchronize(bs.stream)); // res is a local
+    return LVBA_OK;
+}
 
 int32_t bs_init(BlockSys &bs, int device)
 {
@@ -80,30 +163,46 @@ int32_t bs_dist_init(BlockSys &bs, int32_t n_ranks, int32_t rank, const char uid
     if (bs.built) return lvba_fail(LVBA_ERR_STATE, "dist_init must precede the first cost/eval/refine call");
     // a 1-rank job needs no communicator; LVBA_SINGLE_RANK_COMM=1 builds one anyway so that the whole
     // RCCL path (dlopen, communicator, all-reduces) can be exercised on a 1-GPU box
-    if (n_ranks == 1 && !getenv("LVBA_SINGLE_RANK_COMM")) return LVBA_OK;
-    TRY(rccl_load());
     HIPCHK(hipSetDevice(bs.device));
-    ncclUniqueId id;
-    memcpy(&id, uid, 128);
-    NCCLCHK(g_rccl.CommInitRank(&bs.comm, n_ranks, id, rank));
+    if (!strncmp(uid, "LVBAHOST:", 9)) { // the single-box test transport: ranks are host threads of this process
+        const std::string key(uid, strnlen(uid, 127));
+        std::lock_guard<std::mutex> g(g_hostcomm_mu);
+        std::shared_ptr<HostComm> hc = g_hostcomms[key].lock();
+        if (!hc) {
+            hc = std::make_shared<HostComm>();
+            hc->n = n_ranks;
+            hc->stage.resize((size_t)n_ranks);
+            g_hostcomms[key] = hc;
+        }
+        if (hc->n != n_ranks) return lvba_fail(LVBA_ERR_DIST, "host transport: rank counts disagree (%d vs %d)", hc->n, n_ranks);
+        bs.hostcomm = hc;
+        bs.graph_tried = true; // several host threads drive the device: no stream capture (see bs_enqueue_solve)
+    } else {
+        if (n_ranks == 1 && !getenv("LVBA_SINGLE_RANK_COMM")) return LVBA_OK;
+        TRY(rccl_load());
+        ncclUniqueId id;
+        memcpy(&id, uid, 128);
+        NCCLCHK(g_rccl.CommInitRank(&bs.comm, n_ranks, id, rank));
+    }
     bs.n_ranks = n_ranks; bs.rank = rank;
     if (group_count_inout) { // global group count (the AVG_THR averages of the BALM stage)
         int64_t *dv = nullptr;
         HIPCHK(hipMalloc((void **)&dv, sizeof(int64_t)));
         HIPCHK(hipMemcpy(dv, group_count_inout, sizeof(int64_t), hipMemcpyHostToDevice));
-        NCCLCHK(g_rccl.AllReduce(dv, dv, 1, ncclInt64, ncclSum, bs.comm, bs.stream));
-        HIPCHK(hipStreamSynchronize(bs.stream));
-        HIPCHK(hipMemcpy(group_count_inout, dv, sizeof(int64_t), hipMemcpyDeviceToHost));
+        const int32_t rc = bs_comm_allreduce(bs, dv, 1, ncclInt64, ncclSum);
+        if (rc == LVBA_OK) {
+            HIPCHK(hipStreamSynchronize(bs.stream));
+            HIPCHK(hipMemcpy(group_count_inout, dv, sizeof(int64_t), hipMemcpyDeviceToHost));
+        }
         hipFree(dv);
+        TRY(rc);
     }
     return LVBA_OK;
 }
 
 int32_t bs_allreduce(BlockSys &bs, double *buf, size_t count)
 {
-    if (!bs.comm) return LVBA_OK;
-    NCCLCHK(g_rccl.AllReduce(buf, buf, count, ncclDouble, ncclSum, bs.comm, bs.stream));
-    return LVBA_OK;
+    return bs_comm_allreduce(bs, buf, count, ncclDouble, ncclSum);
 }
 
 // [Hblk | g | cost] <-> [blocks of the union pattern | g | cost]
@@ -133,7 +232,7 @@ __global__ void hg_unpack_kernel(double *__restrict__ hg, const int64_t *__restr
 // xGMI all-reduce time is proportional to bytes, and slots outside the union are zero on every rank.
 int32_t bs_allreduce_hg(BlockSys &bs)
 {
-    if (!bs.comm) return LVBA_OK;
+    if (!bs.distributed()) return LVBA_OK;
     const int64_t tail = 6 * (int64_t)bs.N + 1;
     if (!bs.d_ar_slot) return bs_allreduce(bs, bs.d_hg, (size_t)(bs.hblk_doubles + tail));
     const int64_t total = 36 * bs.n_ar + tail;
@@ -178,11 +277,11 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
         return Bb;
     };
     int32_t Bb_nat = band_of(bs.iperm);
-    if (bs.comm) { // the store layout must agree on every rank: reduce over the global problem
+    if (bs.distributed()) { // the store layout must agree on every rank: reduce over the global problem
         int32_t *dtmp = nullptr;
         HIPCHK(hipMalloc((void **)&dtmp, sizeof(int32_t)));
         HIPCHK(hipMemcpy(dtmp, &Bb_nat, sizeof(int32_t), hipMemcpyHostToDevice));
-        NCCLCHK(g_rccl.AllReduce(dtmp, dtmp, 1, ncclInt32, ncclMax, bs.comm, bs.stream));
+        TRY(bs_comm_allreduce(bs, dtmp, 1, ncclInt32, ncclMax));
         HIPCHK(hipStreamSynchronize(bs.stream));
         HIPCHK(hipMemcpy(&Bb_nat, dtmp, sizeof(int32_t), hipMemcpyDeviceToHost));
         hipFree(dtmp);
@@ -198,11 +297,11 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
         adj.assign((size_t)N * N, 0);
         TRY(adjacency_build(bs.stream, G, voff, F, pidx, N, Q, adj.data())); // one thread per observer pair (pair_lists.hip)
         BS_MARK("adjacency");
-        if (bs.comm) {
+        if (bs.distributed()) {
             uint8_t *dadj = nullptr;
             HIPCHK(hipMalloc((void **)&dadj, adj.size()));
             HIPCHK(hipMemcpy(dadj, adj.data(), adj.size(), hipMemcpyHostToDevice));
-            NCCLCHK(g_rccl.AllReduce(dadj, dadj, adj.size(), ncclUint8, ncclMax, bs.comm, bs.stream));
+            TRY(bs_comm_allreduce(bs, dadj, adj.size(), ncclUint8, ncclMax));
             HIPCHK(hipStreamSynchronize(bs.stream));
             HIPCHK(hipMemcpy(adj.data(), dadj, adj.size(), hipMemcpyDeviceToHost));
             hipFree(dadj);
@@ -226,7 +325,7 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
     bs.hblk_doubles = (int64_t)N * Bb1 * 36;
     {
         const char *e = getenv("LVBA_PACKED_ALLREDUCE");
-        if (bs.comm && !adj.empty() && !(e && !strcmp(e, "0"))) {
+        if (bs.distributed() && !adj.empty() && !(e && !strcmp(e, "0"))) {
             std::vector<int64_t> slots;
             for (int32_t J = 0; J < N; ++J) slots.push_back((int64_t)J * Bb1);
             for (int32_t i = 0; i < N; ++i)
@@ -262,23 +361,45 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
         // column-by-column sweep re-fetches every Y record ~k-1 times from HBM (measured 5.5 GB per pass at C3).
         // The Q-sized grouping itself is a device sort (pair_lists.hip).
         std::vector<int64_t> blk_slot, blk_off;
-        TRY(pair_lists_build(bs.stream, G, voff, F, d_blk_of.as<int32_t>(), bs.d_pos_of, N, (int32_t)Bb1, Q, bs.d_pairs, blk_slot,
-                             blk_off));
+        // Voxel windows of the pair lists: the pairs processed at about the same time should draw on a slice of Y that the
+        // L2s can hold (8 x 4 MB; XCD x sweeps its own eighth of the windows).  A window of w consecutive voxels holds
+        // w * F / G records of 144 bytes.  Measured at C3 (PMC, profiles/): 6 MB windows cut the L2 misses of the pair pass from
+        // 88 M to 36 M per evaluation; smaller windows miss less still, but every (window, block) item costs a partial block
+        // and the pass is latency-bound, not bandwidth-bound, by then.  Problems whose whole Y is small are not windowed.
+        // LVBA_PAIR_WINDOW overrides (voxels per window, 0 = none).
+        int64_t window_groups = 0;
+        if (18 * 8 * F > ((int64_t)24 << 20)) window_groups = std::max<int64_t>(256, (((int64_t)6 << 20) / 144) * G / std::max<int64_t>(F, 1));
+        if (const char *e = getenv("LVBA_PAIR_WINDOW")) window_groups = atoll(e);
+        TRY(pair_lists_build(bs.stream, G, voff, F, d_blk_of.as<int32_t>(), bs.d_pos_of, N, (int32_t)Bb1, Q, window_groups, bs.d_pairs,
+                             blk_slot, blk_off));
         BS_MARK("pairs");
         bs.nnzb = (int64_t)blk_slot.size();
+        { // distinct blocks, not runs
+            std::vector<int64_t> u(blk_slot);
+            std::sort(u.begin(), u.end());
+            bs.nnzb = (int64_t)(std::unique(u.begin(), u.end()) - u.begin());
+        }
         // work items of the pair pass.  One 16-lane group per block is right when there are many blocks (C3: 4e5 blocks of
         // ~60 pairs); with few blocks and long lists (window BA: 190 blocks x 2000 pairs) it leaves the chip empty, so lists
         // longer than `cut` pairs become several items whose partial blocks are summed afterwards.
-        std::vector<int64_t> item_off, item_dst, multi_off, multi_slot;
+        std::vector<int64_t> item_off, item_dst, multi_off, multi_slot, multi_idx;
         {
             int64_t n_partial = 0;
-            cut_pair_items(blk_slot, blk_off, Q, item_off, item_dst, multi_off, multi_slot, n_partial); // host_tables.h
+            // windowed lists (large problems: many short (window, block) items) go to the column-per-lane kernel, cut at
+            // LVBA_PAIR_CUT pairs; few blocks with long lists (window BA: 190 blocks x 2000 pairs) to the 16-lane kernel, cut so
+            // that the chip is filled.  LVBA_PAIR = col | staged | gather overrides the kernel.
+            bs.pair_col = window_groups > 0;
+            if (const char *e = getenv("LVBA_PAIR")) bs.pair_col = !strcmp(e, "col");
+            group_pair_items(blk_slot, blk_off, bs.pair_col ? LVBA_PAIR_CUT : pair_cut_length(Q), (int64_t)N * Bb1, item_off, item_dst,
+                             multi_off, multi_slot, multi_idx, n_partial); // host_tables.h
             bs.n_items = (int64_t)item_dst.size();
             bs.n_multi = (int64_t)multi_slot.size();
             if (n_partial) TRY(bs_dmalloc(bs, &bs.d_partial, 36 * n_partial));
             if (bs.n_multi) {
                 TRY(bs_dmalloc(bs, &bs.d_multi_off, bs.n_multi + 1));
                 TRY(bs_dmalloc(bs, &bs.d_multi_slot, bs.n_multi));
+                TRY(bs_dmalloc(bs, &bs.d_multi_idx, (int64_t)multi_idx.size()));
+                HIPCHK(hipMemcpy(bs.d_multi_idx, multi_idx.data(), multi_idx.size() * sizeof(int64_t), hipMemcpyHostToDevice));
                 HIPCHK(hipMemcpy(bs.d_multi_off, multi_off.data(), (size_t)(bs.n_multi + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
                 HIPCHK(hipMemcpy(bs.d_multi_slot, multi_slot.data(), (size_t)bs.n_multi * sizeof(int64_t), hipMemcpyHostToDevice));
             }
@@ -364,7 +485,7 @@ void bs_destroy(BlockSys &bs)
     if (bs.comm && g_rccl.CommDestroy) g_rccl.CommDestroy(bs.comm);
     if (bs.solve_exec) hipGraphExecDestroy(bs.solve_exec);
     if (bs.solve_graph) hipGraphDestroy(bs.solve_graph);
-    void *ptrs[] = {bs.d_ar_slot, bs.d_arbuf, bs.d_multi_off, bs.d_multi_slot, bs.d_partial, bs.d_perm, bs.d_csc_off, bs.d_blk_off, bs.d_blk_slot, bs.d_group_of_pos, bs.d_csc_f, bs.d_pos_of,
+    void *ptrs[] = {bs.d_ar_slot, bs.d_arbuf, bs.d_multi_off, bs.d_multi_slot, bs.d_multi_idx, bs.d_partial, bs.d_perm, bs.d_csc_off, bs.d_blk_off, bs.d_blk_slot, bs.d_group_of_pos, bs.d_csc_f, bs.d_pos_of,
                     bs.d_pairs, bs.d_Y, bs.d_hg, bs.d_A, bs.d_work, bs.d_dx, bs.d_u, bs.d_status};
     for (void *p : ptrs)
         if (p) DevicePool::get().free(p);

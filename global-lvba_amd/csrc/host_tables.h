@@ -71,4 +71,48 @@ inline void cut_pair_items(const std::vector<int64_t> &blk_slot, const std::vect
     }
 }
 
+// Work items of the lane-per-item pair kernel (balm_pair_lane_kernel): runs whose block slots may REPEAT (pair lists grouped by
+// (voxel window, block): a block then appears in one run per window) and runs longer than `cut` pairs are cut; every piece is
+// one item.  A block with a single item is written straight into the store; a block with several is summed from partial
+// blocks in item order (= voxel window order: deterministic).  Partial indices follow the ITEM order, so that consecutive
+// items store to consecutive partial blocks; the lists of a summed block's partials are multi_idx[multi_off[m] ..
+// multi_off[m+1]).  run_slot [R], run_off [R+1]; n_slots bounds the slot values.
+inline void group_pair_items(const std::vector<int64_t> &run_slot, const std::vector<int64_t> &run_off, int64_t cut, int64_t n_slots,
+                             std::vector<int64_t> &item_off, std::vector<int64_t> &item_dst, std::vector<int64_t> &multi_off,
+                             std::vector<int64_t> &multi_slot, std::vector<int64_t> &multi_idx, int64_t &n_partial)
+{
+    item_off.assign(1, 0);
+    item_dst.clear();
+    multi_off.assign(1, 0);
+    multi_slot.clear();
+    multi_idx.clear();
+    n_partial = 0;
+    if (cut < 1) cut = 1;
+    std::vector<int32_t> cnt((size_t)n_slots, 0);
+    std::vector<int64_t> item_slot;
+    for (size_t r = 0; r < run_slot.size(); ++r)
+        for (int64_t q = run_off[r]; q < run_off[r + 1]; q += cut) {
+            item_off.push_back(std::min(q + cut, run_off[r + 1]));
+            item_slot.push_back(run_slot[r]);
+            cnt[(size_t)run_slot[r]]++;
+        }
+    std::vector<int64_t> base((size_t)n_slots, -1);
+    int64_t tot = 0;
+    for (int64_t sl = 0; sl < n_slots; ++sl)
+        if (cnt[(size_t)sl] > 1) {
+            base[(size_t)sl] = tot;
+            tot += cnt[(size_t)sl];
+            multi_slot.push_back(sl);
+            multi_off.push_back(tot);
+        }
+    multi_idx.resize((size_t)tot);
+    item_dst.resize(item_slot.size());
+    for (size_t i = 0; i < item_slot.size(); ++i) {
+        const int64_t sl = item_slot[i];
+        if (base[(size_t)sl] < 0) { item_dst[i] = sl; continue; }
+        multi_idx[(size_t)base[(size_t)sl]++] = n_partial;
+        item_dst[i] = -(1 + n_partial++);
+    }
+}
+
 } // namespace lvba

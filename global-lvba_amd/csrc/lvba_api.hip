@@ -236,7 +236,7 @@ extern "C" int32_t lvba_balm_info(lvba_balm_t h, lvba_balm_info_t *info)
     info->n_factors = h->F; info->n_pairs = h->Q; info->n_chunks = h->n_chunks; info->n_blocks = h->bs.nnzb;
     info->band_blocks = h->bs.Bb; info->use_band = h->bs.use_band ? 1 : 0; info->hess_bytes = h->bs.hblk_doubles * 8;
     info->device_bytes = h->bs.device_bytes;
-    info->allreduce_bytes = !h->bs.comm ? 0 : 8 * ((h->bs.d_ar_slot ? 36 * h->bs.n_ar : h->bs.hblk_doubles) + 6 * (int64_t)h->N + 1);
+    info->allreduce_bytes = !h->bs.distributed() ? 0 : 8 * ((h->bs.d_ar_slot ? 36 * h->bs.n_ar : h->bs.hblk_doubles) + 6 * (int64_t)h->N + 1);
     return LVBA_OK;
 }
 
@@ -296,7 +296,7 @@ static int32_t enqueue_cost(lvba_balm_s *h, const double *d_poses, double *dst)
                 h->prof_on ? h->ev[EV_COSTK][1] : nullptr);
     if (h->prof_on) h->ev_used[EV_COSTK] = true;
     ev_end(h, EV_COST);
-    if (h->bs.comm) {
+    if (h->bs.distributed()) {
         ev_begin(h, EV_REDUCE);
         TRY(bs_allreduce(h->bs, dst, 1));
         ev_end(h, EV_REDUCE);
@@ -311,11 +311,11 @@ static int32_t enqueue_eval(lvba_balm_s *h, const double *d_poses)
     BlockSys &bs = h->bs;
     ev_begin(h, EV_EVAL);
     launch_eval(h->dev(), bs.pair_dev(), d_poses, bs.Hblk(), bs.hblk_doubles, bs.g(), h->d_chunk_cost, bs.scal(),
-                bs.comm != nullptr, bs.stream, h->prof_on ? h->ev[EV_EVALK][0] : nullptr,
+                bs.distributed(), bs.stream, h->prof_on ? h->ev[EV_EVALK][0] : nullptr,
                 h->prof_on ? h->ev[EV_EVALK][1] : nullptr);
     if (h->prof_on) h->ev_used[EV_EVALK] = true;
     ev_end(h, EV_EVAL);
-    if (bs.comm) {
+    if (bs.distributed()) {
         ev_begin(h, EV_REDUCE);
         TRY(bs_allreduce_hg(bs));
         ev_end(h, EV_REDUCE);

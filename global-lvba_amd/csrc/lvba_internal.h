@@ -6,6 +6,7 @@
 #define LVBA_CF 256   // max factors per chunk == workgroup size of the BALM kernels
 #define LVBA_CV 128   // max voxels per chunk (every voxel has >= 2 factors)
 #define LVBA_NB 64    // LDL^T panel width
+#define LVBA_PAIR_CUT 32 // longest pair list one lane of balm_pair_lane_kernel walks
 
 namespace lvba {
 
@@ -38,8 +39,10 @@ struct PairDev {
     const double *Y;           // [F][18] per-factor Y, pose-major positions
     double *partial;           // [n_partial][36] partial blocks of the cut lists
     int64_t n_multi;           // blocks assembled from several items
-    const int64_t *multi_off;  // [n_multi+1] their ranges in `partial`
+    const int64_t *multi_off;  // [n_multi+1] their ranges in multi_idx
     const int64_t *multi_slot; // [n_multi] their slots in the store
+    const int64_t *multi_idx;  // indices into `partial`, in summation order
+    int32_t col_form;          // 1: balm_pair_col_kernel (short items of windowed lists), 0: balm_pair_staged_kernel
 };
 
 // Device view of one packed visual problem (cameras in solver order; only landmarks with a valid plane).

@@ -22,8 +22,9 @@ namespace {
 
 __global__ __launch_bounds__(256) void pair_gen_kernel(const int64_t *__restrict__ voff, const int64_t *__restrict__ poff,
                                                        const int32_t *__restrict__ blk_of, const int32_t *__restrict__ pos_of,
-                                                       int64_t G, int64_t Q, int64_t tiles_per_row,
-                                                       uint64_t *__restrict__ keys, uint64_t *__restrict__ vals)
+                                                       int64_t G, int64_t Q, int64_t tiles_per_row, int64_t window_groups,
+                                                       unsigned block_bits, uint64_t *__restrict__ keys,
+                                                       uint64_t *__restrict__ vals)
 {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= Q) return;
@@ -48,7 +49,9 @@ __global__ __launch_bounds__(256) void pair_gen_kernel(const int64_t *__restrict
         const uint32_t tp = px; px = py; py = tp;
     }
     const uint64_t tile = (uint64_t)(J >> 3) * (uint64_t)tiles_per_row + (uint64_t)(I >> 3);
-    keys[q] = tile << 6 | (uint64_t)(J & 7) << 3 | (uint64_t)(I & 7);
+    uint64_t key = tile << 6 | (uint64_t)(J & 7) << 3 | (uint64_t)(I & 7);
+    if (window_groups > 0) key |= (uint64_t)(lo / window_groups) << block_bits;
+    keys[q] = key;
     vals[q] = (uint64_t)px | (uint64_t)py << 32;
 }
 
@@ -181,7 +184,7 @@ int32_t csc_build(hipStream_t s, int64_t G, const int64_t *h_voff, int64_t F, co
 }
 
 int32_t pair_lists_build(hipStream_t s, int64_t G, const int64_t *h_voff, int64_t F, const int32_t *d_blk_of,
-                         const int32_t *d_pos_of, int32_t N, int32_t Bb1, int64_t Q, int2 *d_pairs,
+                         const int32_t *d_pos_of, int32_t N, int32_t Bb1, int64_t Q, int64_t window_groups, int2 *d_pairs,
                          std::vector<int64_t> &blk_slot, std::vector<int64_t> &blk_off)
 {
     blk_slot.clear();
@@ -197,6 +200,15 @@ int32_t pair_lists_build(hipStream_t s, int64_t G, const int64_t *h_voff, int64_
     const uint64_t max_key = ((uint64_t)tiles_per_row * (uint64_t)tiles_per_row) << 6;
     unsigned end_bit = 1;
     while (end_bit < 64 && (max_key >> end_bit) != 0) ++end_bit;
+    const unsigned block_bits = end_bit;
+    if (window_groups > 0) {
+        const uint64_t n_win = (uint64_t)((G + window_groups - 1) / window_groups);
+        unsigned wb = 1;
+        while (wb < 40 && (n_win >> wb) != 0) ++wb;
+        end_bit += wb;
+        if (end_bit > 64) return LVBA_ERR_UNSUPPORTED;
+    }
+    const uint64_t block_mask = (block_bits >= 64) ? ~0ull : (((uint64_t)1 << block_bits) - 1);
 
     DevBuf d_voff(s), d_poff(s), k_in(s), k_out(s), v_in(s), uniq(s), cnt(s), nruns(s), tmp(s);
     HIPCHK(d_voff.alloc((size_t)(G + 1) * 8));
@@ -207,8 +219,8 @@ int32_t pair_lists_build(hipStream_t s, int64_t G, const int64_t *h_voff, int64_
     HIPCHK(hipMemcpyAsync(d_voff.p, h_voff, (size_t)(G + 1) * 8, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_poff.p, poff.data(), (size_t)(G + 1) * 8, hipMemcpyHostToDevice, s));
     pair_gen_kernel<<<(unsigned)((Q + 255) / 256), 256, 0, s>>>((const int64_t *)d_voff.p, (const int64_t *)d_poff.p,
-                                                                d_blk_of, d_pos_of, G, Q, tiles_per_row,
-                                                                (uint64_t *)k_in.p, (uint64_t *)v_in.p);
+                                                                d_blk_of, d_pos_of, G, Q, tiles_per_row, window_groups,
+                                                                block_bits, (uint64_t *)k_in.p, (uint64_t *)v_in.p);
     HIPCHK(hipGetLastError());
     {
         size_t bytes = 0;
@@ -219,7 +231,7 @@ int32_t pair_lists_build(hipStream_t s, int64_t G, const int64_t *h_voff, int64_
                                          (uint64_t *)d_pairs, (size_t)Q, 0u, end_bit, s));
     }
     // non-empty blocks and their list lengths; the number of runs is bounded by the band profile N * Bb1 and by Q
-    const int64_t max_runs = std::min<int64_t>(Q, (int64_t)N * Bb1);
+    const int64_t max_runs = window_groups > 0 ? Q : std::min<int64_t>(Q, (int64_t)N * Bb1);
     HIPCHK(uniq.alloc((size_t)max_runs * 8));
     HIPCHK(cnt.alloc((size_t)max_runs * 4));
     HIPCHK(nruns.alloc(8));
@@ -244,7 +256,7 @@ int32_t pair_lists_build(hipStream_t s, int64_t G, const int64_t *h_voff, int64_
     blk_slot.resize((size_t)n_runs);
     blk_off.resize((size_t)n_runs + 1);
     for (size_t r = 0; r < (size_t)n_runs; ++r) {
-        const uint64_t key = h_uniq[r], tile = key >> 6;
+        const uint64_t key = h_uniq[r] & block_mask, tile = key >> 6;
         const int64_t J = (int64_t)(tile / (uint64_t)tiles_per_row) * 8 + (int64_t)((key >> 3) & 7);
         const int64_t I = (int64_t)(tile % (uint64_t)tiles_per_row) * 8 + (int64_t)(key & 7);
         blk_slot[r] = J * Bb1 + (I - J);

@@ -161,6 +161,11 @@ int32_t lvba_balm_get_ordering(lvba_balm_t h, int32_t *perm);
  * uid is an ncclUniqueId (128 bytes) created on rank 0 and distributed by the caller. */
 int32_t lvba_dist_unique_id(char uid[128]);
 int32_t lvba_balm_dist_init(lvba_balm_t h, int32_t n_ranks, int32_t rank, const char uid[128]);
+/* A second transport behind the same entry points, for testing the multi-rank code on a box with ONE GPU (RCCL refuses two
+ * ranks on one device): an id made by lvba_dist_host_unique_id selects ranks that are HOST THREADS of one process, each with
+ * its own handle on the same device; every all-reduce is staged through the host and summed in rank order.  It moves data
+ * only -- all arithmetic on problem data stays in the kernels -- and is not meant for production runs. */
+int32_t lvba_dist_host_unique_id(char uid[128]);
 
 /* ===================================================================================================
  * Visual stage: replaces the ceres::Problem ... ceres::Solve region of LvbaSystem::optimizeCameraPoses

@@ -73,6 +73,44 @@ int main()
         }
         CHECK(it == id.size() && m == ms.size());
     }
+    for (int rep = 0; rep < 200; ++rep) { // grouped items: repeating slots (one run per voxel window) and a small cut
+        const int nslots = 1 + next() % 60, nruns = 1 + next() % 400;
+        const int64_t cut = 1 + next() % 40;
+        std::vector<int64_t> slot(nruns), off(nruns + 1, 0);
+        for (int r = 0; r < nruns; ++r) { slot[r] = next() % nslots; off[r + 1] = off[r] + 1 + next() % 100; }
+        std::vector<int64_t> io, id, mo, ms, mi; int64_t np;
+        lvba::group_pair_items(slot, off, cut, nslots, io, id, mo, ms, mi, np);
+        CHECK(io.front() == 0 && io.back() == off.back() && io.size() == id.size() + 1 && mo.size() == ms.size() + 1);
+        CHECK((int64_t)mi.size() == mo.back() && (int64_t)mi.size() == np);
+        // every item lies inside one run, is at most `cut` long, and the items tile the pair array
+        std::vector<int64_t> item_slot(id.size());
+        size_t r = 0;
+        for (size_t i = 0; i < id.size(); ++i) {
+            CHECK(io[i + 1] > io[i] && io[i + 1] - io[i] <= cut);
+            while (io[i] >= off[r + 1]) ++r;
+            CHECK(io[i + 1] <= off[r + 1]);
+            item_slot[i] = slot[r];
+        }
+        // direct items: their slot occurs once; partial indices follow the item order; every summed block lists exactly its
+        // items' partials, in item order
+        std::vector<int> cnt(nslots, 0);
+        for (auto sl : item_slot) cnt[sl]++;
+        int64_t next_partial = 0;
+        std::vector<std::vector<int64_t>> want(nslots);
+        for (size_t i = 0; i < id.size(); ++i) {
+            if (cnt[item_slot[i]] == 1) CHECK(id[i] == item_slot[i]);
+            else { CHECK(id[i] == -(1 + next_partial)); want[item_slot[i]].push_back(next_partial++); }
+        }
+        CHECK(next_partial == np);
+        size_t m = 0;
+        for (int sl = 0; sl < nslots; ++sl) {
+            if (cnt[sl] <= 1) continue;
+            CHECK(m < ms.size() && ms[m] == sl && mo[m + 1] - mo[m] == (int64_t)want[sl].size());
+            for (size_t q = 0; q < want[sl].size(); ++q) CHECK(mi[mo[m] + q] == want[sl][q]);
+            ++m;
+        }
+        CHECK(m == ms.size());
+    }
     std::printf("host tables ok\n");
     return 0;
 }

@@ -1,0 +1,107 @@
+"""The product's MULTI-RANK code with N = 2 and 3 ranks on a one-GPU box.
+
+RCCL refuses two ranks on one device, so the ranks are host threads of this process, each with its own handle (its own
+voxel shard, its own stream) on the same GPU, joined by the library's host-staged test transport
+(lvba_dist_host_unique_id: every all-reduce goes device -> host -> sum in rank order -> device).  Everything above the
+transport is the code a real multi-GPU job runs (csrc/block_system.hip): the global voxel count, the max-reduced band
+width, the all-reduced co-visibility matrix and the common pose order computed from it, the packed [H | g | cost]
+all-reduce over the union sparsity pattern, the all-reduced cost scalar of the trial poses, the replicated damped solve.
+Required: every rank ends with bitwise the same answer, and that answer equals the single-rank one to rounding
+(partial sums are grouped differently) and the C oracle to 1e-8.  bavoxel.hpp:614-633 with thread -> rank."""
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import make_problem, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_ranks(pkg, d, world, packed=True):
+    N, off, idx, clu = d["n_poses"], d["voxel_off"], d["pose_idx"], d["clusters"]
+    V = len(off) - 1
+    uid = pkg.BalmProblem.host_unique_id()
+    out, err = [None] * world, [None] * world
+
+    def rank_main(r):
+        try:
+            a, b = pkg.shard_range(V, r, world)
+            prob = pkg.BalmProblem(N, off[a:b + 1], idx[off[a]:off[b]], clu[off[a]:off[b]])
+            prob.dist_init(world, r, uid)
+            info = prob.info()
+            H, g, c = prob.eval(d["poses_init"])
+            c_gt = prob.cost(d["poses_gt"])
+            x, trace, rc = prob.refine(d["poses_init"])
+            out[r] = dict(info=info, H=H, g=g, c=c, c_gt=c_gt, x=x, trace=trace, rc=rc, perm=prob.ordering())
+            prob.close()
+        except Exception as e:   # a rank that dies would leave the others in the barrier: report, do not hang silently
+            err[r] = e
+            raise
+
+    th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert all(e is None for e in err), err
+    assert all(o is not None for o in out), "a rank did not finish (collective mismatch?)"
+    return out
+
+
+@pytest.mark.parametrize("world,case", [(2, dict(n_poses=200, n_voxels=6000, band=10, seed=7)),     # packed all-reduce, band solver
+                                        (3, dict(n_poses=40, n_voxels=3000, band=10, seed=2)),      # dense store, ragged shards
+                                        (2, dict(n_poses=150, n_voxels=8000, band=12, seed=4))])
+def test_ranks_agree_with_single_rank_and_oracle(pkg, oracle_mod, world, case, monkeypatch):
+    d = make_problem(**case)
+    N = d["n_poses"]
+    single = pkg.BalmProblem(N, d["voxel_off"], d["pose_idx"], d["clusters"])
+    H1, g1, c1 = single.eval(d["poses_init"])
+    cgt1 = single.cost(d["poses_gt"])
+    x1, tr1, rc1 = single.refine(d["poses_init"])
+    out = _run_ranks(pkg, d, world)
+    r0 = out[0]
+    assert r0["info"]["n_ranks"] == world and r0["info"]["n_voxels_global"] == len(d["voxel_off"]) - 1
+    assert sum(o["info"]["n_voxels"] for o in out) == len(d["voxel_off"]) - 1
+    if N >= 200:
+        assert 0 < r0["info"]["allreduce_bytes"] < 0.75 * r0["info"]["hess_bytes"]     # the packed form was used
+    for o in out[1:]:                                                                    # replicas: bitwise
+        assert np.array_equal(o["perm"], r0["perm"])
+        assert np.array_equal(o["H"], r0["H"]) and np.array_equal(o["g"], r0["g"]) and o["c"] == r0["c"] and o["c_gt"] == r0["c_gt"]
+        assert np.array_equal(o["x"], r0["x"]) and o["trace"] == r0["trace"]
+    # against the single-rank run: same sums, grouped per shard
+    assert rel(r0["H"], H1) <= 1e-12 and rel(r0["g"], g1) <= 1e-12 and abs(r0["c"] - c1) <= 1e-12 * c1
+    assert abs(r0["c_gt"] - cgt1) <= 1e-12 * cgt1
+    assert r0["rc"] == rc1 == 0 and len(r0["trace"]) == len(tr1)
+    for a, b in zip(r0["trace"], tr1):
+        assert a["accepted"] == b["accepted"] and a["evaluated"] == b["evaluated"]
+        # (rounding differences of the first evaluation grow from iteration to iteration of an LM run)
+        assert abs(a["residual1"] - b["residual1"]) <= 1e-7 * b["residual1"] and abs(a["residual2"] - b["residual2"]) <= 1e-7 * b["residual2"]
+    assert np.abs(r0["x"] - x1).max() <= 1e-8
+    # and the oracle
+    co = oracle_mod.COracle(N, d["voxel_off"], d["pose_idx"], d["clusters"])
+    Hc, gc, cc = co.eval_dense(d["poses_init"])
+    assert rel(r0["H"], Hc) <= 1e-8 and rel(r0["g"], gc) <= 1e-8 and abs(r0["c"] - cc) <= 1e-8 * cc
+    xr, tr, _ = co.damping_iter(d["poses_init"])
+    assert np.abs(r0["x"] - xr).max() <= 1e-7
+    single.close()
+
+
+def test_rank_with_a_different_band(pkg):
+    """Shards whose LOCAL co-visibility differs (one rank holds only narrow-band voxels, the other the loop closures): the
+    store layout, the pose order and the packed slot table must come from the GLOBAL pattern on both ranks."""
+    d = make_problem(200, 6000, band=10, seed=7, loop_frac=0.3)
+    off, idx = d["voxel_off"], d["pose_idx"]
+    span = np.maximum.reduceat(idx, off[:-1]) - np.minimum.reduceat(idx, off[:-1])
+    order = np.argsort(span, kind="stable")                       # narrow voxels first -> rank 0 sees no loop closure
+    k = np.diff(off)
+    new_off = np.concatenate([[0], np.cumsum(k[order])])
+    gather = np.concatenate([np.arange(off[v], off[v + 1]) for v in order])
+    dd = dict(d, voxel_off=new_off, pose_idx=idx[gather], clusters=d["clusters"][gather])
+    single = pkg.BalmProblem(d["n_poses"], dd["voxel_off"], dd["pose_idx"], dd["clusters"])
+    H1, g1, c1 = single.eval(d["poses_init"])
+    out = _run_ranks(pkg, dd, 2)
+    assert out[0]["info"]["band_blocks"] == out[1]["info"]["band_blocks"]
+    assert np.array_equal(out[0]["H"], out[1]["H"])
+    assert rel(out[0]["H"], H1) <= 1e-12 and rel(out[0]["g"], g1) <= 1e-12
+    single.close()
