@@ -426,7 +426,7 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
     if (bs.use_band) {
         const int64_t ldab = bw + LVBA_NB + 64;
         bs.A.ld = ldab - 1; bs.A.bw = bw;
-        TRY(bs_dmalloc(bs, &bs.d_A, ldab * n + ldab));
+        TRY(bs_dmalloc(bs, &bs.d_A, 2 * (ldab * (n + 1)) + ldab)); // room for the second matrix of the twisted factorisation
     } else {
         bs.A.ld = n; bs.A.bw = n - 1;
         TRY(bs_dmalloc(bs, &bs.d_A, n * n));

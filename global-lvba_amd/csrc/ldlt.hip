@@ -34,14 +34,25 @@ namespace lvba {
 typedef double d4 __attribute__((ext_vector_type(4)));
 #define LVBA_TS 80 // LDS tile stride (doubles): 80 = 16 mod 32 -> MFMA operand reads are bank-conflict free
 
+// Twisted ("burn at both ends") form, tw.m > 0: the band matrix is split into T = [0, m), S = [m, n - m), B = [n - m, n) with
+// |S| >= bw, so that T and B are not coupled.  Matrix 1 is the leading block [0, n - m) in natural order, matrix 2 the
+// trailing block [m, n) in REVERSED order (index i' = n - 1 - i), both of size n1 = n - m in their own band storage (a,
+// a + sA; workspace, workspace + sW).  The S x S entries go to matrix 1 only: matrix 2 collects the Schur complement of B
+// there, starting from zero.
+struct LdltTwist {
+    int64_t m, n1, sA, sW; // m = 0: plain top-down factorisation
+    unsigned long long *x2;
+};
 __global__ void ldlt_prepare_kernel(LdltMat M, const double *__restrict__ Hblk, int band_blocks, int n_poses,
                                     const double *__restrict__ g, const double *__restrict__ u_dev,
-                                    double *__restrict__ b, unsigned long long *__restrict__ x, unsigned long long x_fill)
+                                    double *__restrict__ b, unsigned long long *__restrict__ x, unsigned long long x_fill,
+                                    LdltTwist tw)
 {
     const double u = u_dev[0];
     const int64_t Bb1 = band_blocks + 1;
     const int64_t total = (int64_t)n_poses * Bb1 * 36;
     const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n = M.n, n1 = tw.m > 0 ? tw.n1 : n;
     for (int64_t e = gid; e < total; e += gsz) {
         const int64_t slot = e / 36;
         const int el = (int)(e - slot * 36);
@@ -51,12 +62,48 @@ __global__ void ldlt_prepare_kernel(LdltMat M, const double *__restrict__ Hblk, 
         if (dI == 0 && r < c) continue;
         double v = Hblk[e];
         if (dI == 0 && r == c) v += u * v;
-        M.a[(6 * I + r) + (6 * J + c) * M.ld] = v;
+        const int64_t R = 6 * I + r, C = 6 * J + c;
+        if (R < n1) M.a[R + C * M.ld] = v;
+        else M.a[tw.sA + (n - 1 - C) + (n - 1 - R) * M.ld] = v; // row in B: reversed and transposed into the lower triangle
     }
-    for (int64_t a = gid; a < M.n; a += gsz) {
-        b[a] = -g[a];
+    for (int64_t a = gid; a < n; a += gsz) {
+        if (a < n1) b[a] = -g[a];
         x[a] = x_fill; // the backward chain kernel's "not yet written" mark
     }
+    if (tw.m > 0)
+        for (int64_t a = gid; a < n1; a += gsz) {
+            const int64_t i = n - 1 - a;
+            b[tw.sW + a] = (i >= n1) ? -g[i] : 0.0; // the S part of matrix 2's right-hand side only collects updates
+            tw.x2[a] = x_fill;
+        }
+}
+
+// After both ends have been eliminated: the Schur complement that matrix 2 (reversed) collected on S is added to matrix 1's
+// S block, likewise the right-hand side.
+__global__ void ldlt_twist_merge_kernel(LdltMat M, LdltTwist tw, double *__restrict__ b)
+{
+    const int64_t n = M.n, s0 = tw.m, s1 = tw.n1, ns = s1 - s0, bw1 = M.bw + 1;
+    const int64_t total = ns * bw1;
+    const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = gid; e < total; e += gsz) {
+        const int64_t cc = e / bw1, d = e - cc * bw1;
+        const int64_t C = s0 + cc, R = C + d;
+        if (R >= s1) continue;
+        M.a[R + C * M.ld] += M.a[tw.sA + (n - 1 - C) + (n - 1 - R) * M.ld];
+    }
+    for (int64_t a = s0 + gid; a < s1; a += gsz) b[a] += b[tw.sW + (n - 1 - a)];
+}
+// x of the S part, reversed, into matrix 2's solution vector (its backward chain starts from there)
+__global__ void ldlt_twist_xs_kernel(LdltTwist tw, int64_t n, const double *__restrict__ x)
+{
+    const int64_t a = tw.m + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; // index in matrix 2
+    if (a < tw.n1) tw.x2[a] = (unsigned long long)__double_as_longlong(x[n - 1 - a]);
+}
+// matrix 2's B part back into the caller's order
+__global__ void ldlt_twist_xb_kernel(LdltTwist tw, int64_t n, double *__restrict__ x)
+{
+    const int64_t a = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (a < tw.m) x[n - 1 - a] = __longlong_as_double((long long)tw.x2[a]);
 }
 
 // ---------------------------------------------------------------------------------------------- K1
@@ -332,12 +379,14 @@ __device__ __forceinline__ void diagpanel_tile(double *lds, LdltMat M, int64_t k
     __syncthreads();
     if (tid < 64 && r < rend) b[r] -= red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
 }
+// blockIdx.y selects the problem of a twisted factorisation (0: matrix 1, 1: matrix 2 at a + sA / workspace + sW)
 __global__ __launch_bounds__(256) void ldlt_diagpanel_kernel(LdltMat M, int64_t k, int nbe, int64_t w0, int64_t rend,
                                                              double *__restrict__ G, double *__restrict__ dvec,
                                                              double *__restrict__ Zws, int64_t ldz, double *__restrict__ b,
-                                                             int *__restrict__ status)
+                                                             int *__restrict__ status, int64_t sA, int64_t sW)
 {
     __shared__ double lds[LVBA_K12_LDS];
+    if (blockIdx.y) { M.a += sA; G += sW; dvec += sW; Zws += sW; b += sW; }
     diagpanel_tile(lds, M, k, nbe, w0, rend, G, dvec, Zws, ldz, b, status, blockIdx.x);
 }
 
@@ -461,9 +510,11 @@ __device__ __forceinline__ void update_tile_quarter(double *lds, LdltMat M, int6
 }
 // mode 0: every lower tile (ti >= tj) of the window; mode 1: only the first tile column (tj = 0), four workgroups per tile
 __global__ __launch_bounds__(256) void ldlt_update_kernel(LdltMat M, int64_t k, int nbe, int64_t w0, int64_t rend,
-                                                          const double *__restrict__ Zws, int64_t ldz, int mode)
+                                                          const double *__restrict__ Zws, int64_t ldz, int mode, int64_t sA,
+                                                          int64_t sW)
 {
     __shared__ double lds[LVBA_K3_LDS];
+    if (blockIdx.y) { M.a += sA; Zws += sW; }
     int64_t ti, tj;
     if (mode == 1) {
         update_tile_quarter(lds, M, k, nbe, w0, rend, Zws, ldz, blockIdx.x >> 2, 0, blockIdx.x & 3);
@@ -482,10 +533,11 @@ __global__ __launch_bounds__(256) void ldlt_step_kernel(LdltMat M, int64_t k2, i
                                                         double *__restrict__ G2, double *__restrict__ dvec,
                                                         double *__restrict__ Zws2, double *__restrict__ b,
                                                         int *__restrict__ status, int64_t k, int nbe, int64_t w0, int64_t rend,
-                                                        const double *__restrict__ Zws, int64_t ldz)
+                                                        const double *__restrict__ Zws, int64_t ldz, int64_t sA, int64_t sW)
 {
     __shared__ double lds[LVBA_K3_LDS];
     static_assert(LVBA_K12_LDS <= LVBA_K3_LDS, "factorisation tables must fit the update's LDS");
+    if (blockIdx.y) { M.a += sA; G2 += sW; dvec += sW; Zws2 += sW; b += sW; Zws += sW; }
     if ((int)blockIdx.x < T2) {
         diagpanel_tile(lds, M, k2, nbe2, w02, rend2, G2, dvec, Zws2, ldz, b, status, blockIdx.x);
     } else {
@@ -682,80 +734,124 @@ static inline int64_t ldz_for(int64_t n, int64_t bw)
     return w < n ? w : n;
 }
 
-int64_t ldlt_workspace_doubles(int64_t n, int64_t bw)
+static inline int64_t ldlt_ws_one(int64_t n, int64_t bw)
 {
     const int64_t nsteps = (n + LVBA_NB - 1) / LVBA_NB;
     return nsteps * 4096 /*G*/ + 3 * n /*d, b, bacc*/ + 2 * ldz_for(n, bw) * LVBA_NB /*Z, double-buffered*/ + 64;
 }
+// two problems' workspaces + matrix 2's solution vector (twisted factorisation)
+int64_t ldlt_workspace_doubles(int64_t n, int64_t bw) { return 2 * ldlt_ws_one(n, bw) + n + 64; }
 
 int64_t ldlt_num_panels(int64_t n) { return (n + LVBA_NB - 1) / LVBA_NB; }
+
+// Panels each end eliminates in the twisted form (0: plain top-down).  Both ends run the same number of panels, so the two
+// problems have identical geometry and share every launch (blockIdx.y); the middle block S = n - 128 P keeps >= bw columns.
+int64_t ldlt_twist_panels(int64_t n, int64_t ld, int64_t bw)
+{
+    static const bool off = [] { const char *e = getenv("LVBA_TWIST"); return e && !strcmp(e, "0"); }();
+    if (off || ld == n) return 0; // dense storage: every column is coupled to every other
+    const int64_t P = (n - bw) / (2 * LVBA_NB);
+    return P >= 4 ? P : 0;
+}
 
 // Launch sequence of one solve on one stream (captured once into a hipGraph by the caller).
 //   LVBA_SCHEDULE = overlap (default): per panel  [factorise panel p+1 || bulk update of panel p]  ->  first-column update of p+1
 //                   serial            : factorise -> update, one after the other (A/B reference).
 // A two-STREAM look-ahead was measured slower than the serial sequence (every cross-stream edge costs ~10 us); the
 // overlap form gets the same concurrency from one heterogeneous launch.
+// Band systems are factorised from BOTH ENDS at once (LdltTwist above; LVBA_TWIST=0 turns it off): the serial chain of
+// panels -- the latency that bounds this solver -- is P + |S| / 64 long instead of n / 64, with the same flops and no fill.
 void ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_poses, const double *g,
                 const double *u_dev, double *x, double *work, int *status, hipStream_t s)
 {
     static const bool overlap = [] { const char *e = getenv("LVBA_SCHEDULE"); return !(e && !strcmp(e, "serial")); }();
     const int64_t n = A.n, bw = A.bw;
-    const int64_t nsteps = (n + LVBA_NB - 1) / LVBA_NB;
+    const int64_t P1 = overlap ? ldlt_twist_panels(n, A.ld, bw) : 0;
+    LdltTwist tw;
+    tw.m = P1 * LVBA_NB; tw.n1 = n - tw.m;
+    tw.sA = (A.ld + 1) * (n + 1); tw.sW = ldlt_ws_one(n, bw);
+    tw.x2 = reinterpret_cast<unsigned long long *>(work + 2 * tw.sW);
+    const int64_t nf = tw.n1; // columns the top-down problem factorises (all of them without the twist)
+    const int64_t nsteps = (nf + LVBA_NB - 1) / LVBA_NB;
     double *Gall = work;
-    double *dvec = Gall + nsteps * 4096;
+    double *dvec = Gall + ((n + LVBA_NB - 1) / LVBA_NB) * 4096;
     double *b = dvec + n;
     double *bacc = b + n;
     const int64_t ldz = ldz_for(n, bw);
     double *Zbuf[2] = {bacc + n, bacc + n + ldz * LVBA_NB};
+    LdltMat M = A; // the problem the launches see: matrix 1 (and matrix 2 through blockIdx.y)
+    M.n = nf;
     const size_t abytes = (size_t)((A.ld == n) ? n * n : (A.ld + 1) * n) * sizeof(double);
-    hipMemsetAsync(A.a, 0, abytes, s);
+    hipMemsetAsync(A.a, 0, P1 > 0 ? (size_t)tw.sA * sizeof(double) + abytes : abytes, s);
     hipMemsetAsync(status, 0, sizeof(int), s);
     hipMemsetAsync(bacc, 0, (size_t)n * sizeof(double), s);
     hipLaunchKernelGGL(ldlt_prepare_kernel, dim3(2048), dim3(256), 0, s, A, Hblk, band_blocks, n_poses, g, u_dev, b,
-                       reinterpret_cast<unsigned long long *>(x), (unsigned long long)LVBA_X_SENTINEL);
+                       reinterpret_cast<unsigned long long *>(x), (unsigned long long)LVBA_X_SENTINEL, tw);
     struct Geo { int64_t k, w0, rend, T; int nbe; };
     auto geom = [&](int64_t st) {
         Geo q;
         q.k = st * LVBA_NB;
-        q.nbe = (int)((n - q.k) < LVBA_NB ? (n - q.k) : LVBA_NB);
+        q.nbe = (int)((nf - q.k) < LVBA_NB ? (nf - q.k) : LVBA_NB);
         q.w0 = q.k + q.nbe;
         q.rend = q.k + q.nbe + bw;
-        if (q.rend > n) q.rend = n;
+        if (q.rend > nf) q.rend = nf;
         q.T = q.w0 < q.rend ? (q.rend - q.w0 + 63) / 64 : 0;
         return q;
     };
-    auto factor_panel = [&](int64_t st, const Geo &q) { // diag (+ panel) of one panel as a launch of its own
+    auto factor_panel = [&](int64_t st, const Geo &q, unsigned ny) { // diag (+ panel) of one panel as a launch of its own
         double *G = Gall + st * 4096, *Zws = Zbuf[st & 1];
         if (q.T > 0)
-            hipLaunchKernelGGL(ldlt_diagpanel_kernel, dim3((unsigned)q.T), dim3(256), 0, s, A, q.k, q.nbe, q.w0, q.rend, G, dvec, Zws, ldz, b, status);
+            hipLaunchKernelGGL(ldlt_diagpanel_kernel, dim3((unsigned)q.T, ny), dim3(256), 0, s, M, q.k, q.nbe, q.w0, q.rend, G, dvec, Zws, ldz, b, status, tw.sA, tw.sW);
         else
-            hipLaunchKernelGGL(ldlt_diag_blocked_kernel, dim3(1), dim3(256), 0, s, A, q.k, q.nbe, G, dvec, status);
+            hipLaunchKernelGGL(ldlt_diag_blocked_kernel, dim3(1), dim3(256), 0, s, M, q.k, q.nbe, G, dvec, status);
+    };
+    auto first_column = [&](int64_t st, const Geo &q, unsigned ny) {
+        if (q.T > 0)
+            hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)(4 * q.T), ny), dim3(256), 0, s, M, q.k, q.nbe, q.w0, q.rend, Zbuf[st & 1], ldz, 1, tw.sA, tw.sW);
+    };
+    // [factorise panel st+1 || bulk update of panel st]; fac = false: the bulk update alone
+    auto step = [&](int64_t st, const Geo &q, const Geo &q2, bool fac, unsigned ny) {
+        const int64_t nb3 = q.T > 1 ? (q.T - 1) * q.T / 2 : 0; // bulk tiles of panel st
+        const int64_t T2 = fac ? q2.T : 0;
+        if (T2 + nb3 > 0)
+            hipLaunchKernelGGL(ldlt_step_kernel, dim3((unsigned)(T2 + nb3), ny), dim3(256), 0, s, M, q2.k, q2.nbe, q2.w0, q2.rend, (int)T2,
+                               Gall + (st + 1) * 4096, dvec, Zbuf[(st + 1) & 1], b, status, q.k, q.nbe, q.w0, q.rend,
+                               (const double *)Zbuf[st & 1], ldz, tw.sA, tw.sW);
     };
     if (!overlap) {
         for (int64_t st = 0; st < nsteps; ++st) {
             const Geo q = geom(st);
-            factor_panel(st, q);
+            factor_panel(st, q, 1);
             if (q.T > 0)
-                hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)(q.T * (q.T + 1) / 2)), dim3(256), 0, s, A, q.k, q.nbe, q.w0, q.rend, Zbuf[st & 1], ldz, 0);
+                hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)(q.T * (q.T + 1) / 2)), dim3(256), 0, s, M, q.k, q.nbe, q.w0, q.rend, Zbuf[st & 1], ldz, 0, tw.sA, tw.sW);
         }
     } else {
-        Geo q = geom(0);
-        factor_panel(0, q);
-        if (q.T > 0) hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)(4 * q.T)), dim3(256), 0, s, A, q.k, q.nbe, q.w0, q.rend, Zbuf[0], ldz, 1);
-        for (int64_t st = 0; st + 1 < nsteps; ++st) {
+        int64_t st0 = 0;
+        if (P1 > 0) { // both ends, panels 0 .. P1-1 of the two problems in the same launches
+            Geo q = geom(0);
+            factor_panel(0, q, 2);
+            first_column(0, q, 2);
+            for (int64_t st = 0; st + 1 < P1; ++st) {
+                const Geo q2 = geom(st + 1);
+                step(st, q, q2, true, 2);
+                first_column(st + 1, q2, 2);
+                q = q2;
+            }
+            step(P1 - 1, q, geom(P1), false, 2); // the bulk update of the last end panel
+            hipLaunchKernelGGL(ldlt_twist_merge_kernel, dim3(1024), dim3(256), 0, s, A, tw, b); // A: the reversal needs the full n
+            st0 = P1;
+        }
+        Geo q = geom(st0);
+        factor_panel(st0, q, 1);
+        first_column(st0, q, 1);
+        for (int64_t st = st0; st + 1 < nsteps; ++st) {
             const Geo q2 = geom(st + 1);
-            const int64_t nb3 = q.T > 1 ? (q.T - 1) * q.T / 2 : 0; // bulk tiles of panel st
             if (q2.T > 0) {
-                hipLaunchKernelGGL(ldlt_step_kernel, dim3((unsigned)(q2.T + nb3)), dim3(256), 0, s, A, q2.k, q2.nbe, q2.w0, q2.rend, (int)q2.T,
-                                   Gall + (st + 1) * 4096, dvec, Zbuf[(st + 1) & 1], b, status, q.k, q.nbe, q.w0, q.rend,
-                                   (const double *)Zbuf[st & 1], ldz);
-                hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)(4 * q2.T)), dim3(256), 0, s, A, q2.k, q2.nbe, q2.w0, q2.rend, Zbuf[(st + 1) & 1], ldz, 1);
+                step(st, q, q2, true, 1);
+                first_column(st + 1, q2, 1);
             } else { // the last panel has no rows below it: nothing to overlap with
-                if (nb3 > 0)
-                    hipLaunchKernelGGL(ldlt_step_kernel, dim3((unsigned)nb3), dim3(256), 0, s, A, q2.k, q2.nbe, q2.w0, q2.rend, 0,
-                                       Gall + (st + 1) * 4096, dvec, Zbuf[(st + 1) & 1], b, status, q.k, q.nbe, q.w0, q.rend,
-                                       (const double *)Zbuf[st & 1], ldz);
-                factor_panel(st + 1, q2);
+                step(st, q, q2, false, 1);
+                factor_panel(st + 1, q2, 1);
             }
             q = q2;
         }
@@ -763,12 +859,24 @@ void ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_pos
     // backward.  Default: the whole substitution as one chained launch (ldlt_back_chain_kernel).  LVBA_BACK=panel keeps
     // the former one-launch-per-panel form for A/B (1.7 ms of a C3 solve, ~9 us per kernel boundary).
     static const bool back_panel = [] { const char *e = getenv("LVBA_BACK"); return e && !strcmp(e, "panel"); }();
-    if (!back_panel) {
+    if (!back_panel || P1 > 0) {
         // at most 256 panels per launch: one workgroup per CU is then resident whatever else shares the device, so the
         // chain cannot starve even if workgroups were not dispatched in index order; later launches only read finished x
         for (int64_t top = nsteps - 1; top >= 0; top -= 256) {
             const int64_t cnt = std::min<int64_t>(256, top + 1);
-            hipLaunchKernelGGL(ldlt_back_chain_kernel, dim3((unsigned)cnt), dim3(256), 0, s, A, (int)top, Gall, dvec, b, x);
+            hipLaunchKernelGGL(ldlt_back_chain_kernel, dim3((unsigned)cnt), dim3(256), 0, s, M, (int)top, Gall, dvec, b, x);
+        }
+        if (P1 > 0) { // matrix 2's B part: its chain starts from x of S (reversed)
+            LdltMat M2 = M;
+            M2.a += tw.sA;
+            const int64_t ns = tw.n1 - tw.m;
+            hipLaunchKernelGGL(ldlt_twist_xs_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, s, tw, n, (const double *)x);
+            for (int64_t top = P1 - 1; top >= 0; top -= 256) {
+                const int64_t cnt = std::min<int64_t>(256, top + 1);
+                hipLaunchKernelGGL(ldlt_back_chain_kernel, dim3((unsigned)cnt), dim3(256), 0, s, M2, (int)top, Gall + tw.sW, dvec + tw.sW,
+                                   b + tw.sW, reinterpret_cast<double *>(tw.x2));
+            }
+            hipLaunchKernelGGL(ldlt_twist_xb_kernel, dim3((unsigned)((tw.m + 255) / 256)), dim3(256), 0, s, tw, n, x);
         }
         return;
     }

@@ -49,17 +49,17 @@ int main(int argc, char **argv)
         for (int q = 0; q < 4; ++q) printf(" diag %llu panel %llu update %llu |", c[2 + 3 * q] - c[1 + 3 * q], c[3 + 3 * q] - c[2 + 3 * q], c[4 + 3 * q] - c[3 + 3 * q]);
         printf(" store %llu  total %llu\n", c[14] - c[13], c[14] - c[0]);
     }
-    t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_diagpanel_kernel, dim3((unsigned)T), dim3(256), 0, s, A, k, 64, w0, rend, Gall, dvec, Zws, ldz, b, status); });
+    t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_diagpanel_kernel, dim3((unsigned)T), dim3(256), 0, s, A, k, 64, w0, rend, Gall, dvec, Zws, ldz, b, status, 0, 0); });
     printf("diag+panel %7.2f us  (%lld tiles)\n", t * 1e3, (long long)T);
-    t = time_ms(s, 100, [&] { hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)(T * (T + 1) / 2)), dim3(256), 0, s, A, k, 64, w0, rend, Zws, ldz, 0); });
+    t = time_ms(s, 100, [&] { hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)(T * (T + 1) / 2)), dim3(256), 0, s, A, k, 64, w0, rend, Zws, ldz, 0, 0, 0); });
     printf("K3 update %8.2f us  (%lld tiles, %.1f TFLOP/s)\n", t * 1e3, (long long)(T * (T + 1) / 2), T * (T + 1) / 2 * 2.0 * 64 * 64 * 64 / (t * 1e-3) / 1e12);
     t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_back_kernel, dim3((unsigned)((bw + 255) / 256)), dim3(256), 0, s, A, k + bw, 64, Gall, dvec, b, bacc, x, k); });
     printf("back      %8.2f us\n", t * 1e3);
-    t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_diagpanel_kernel, dim3((unsigned)T), dim3(256), 0, s, A, k, 64, w0, rend, Gall, dvec, Zws, ldz, b, status);
-                              hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)(T * (T + 1) / 2)), dim3(256), 0, s, A, k, 64, w0, rend, Zws, ldz, 0); });
+    t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_diagpanel_kernel, dim3((unsigned)T), dim3(256), 0, s, A, k, 64, w0, rend, Gall, dvec, Zws, ldz, b, status, 0, 0);
+                              hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)(T * (T + 1) / 2)), dim3(256), 0, s, A, k, 64, w0, rend, Zws, ldz, 0, 0, 0); });
     printf("diag+panel, update chain %8.2f us\n", t * 1e3);
     // empty-kernel launch chain for reference
-    t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_prepare_kernel, dim3(1), dim3(64), 0, s, A, work, 0, 0, work, work, work, (unsigned long long *)x, 0ULL); });
+    t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_prepare_kernel, dim3(1), dim3(64), 0, s, A, work, 0, 0, work, work, work, (unsigned long long *)x, 0ULL, LdltTwist{0, 0, 0, 0, nullptr}); });
     printf("tiny kernel back-to-back %8.2f us\n", t * 1e3);
     return 0;
 }
