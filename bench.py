@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reference-baseline", action="store_true", help="skip the reference's own divide_thread on C2 (16 GB of host memory)")
     ap.add_argument("--no-visual", action="store_true", help="skip the (untimed-for-the-metric) visual-stage leg")
     ap.add_argument("--no-front-end", action="store_true", help="skip the (untimed-for-the-metric) voxel front-end / window-BA leg")
     args = ap.parse_args()
@@ -208,10 +209,10 @@ def main():
         n = 6 * N
         bw = 6 * info["band_blocks"] + 5
         flops_solve = (n * bw * bw if info["use_band"] else n ** 3 / 3.0)
-        roof = {"bound": "hbm", "kernel": "H/g/cost evaluation: balm_voxel_kernel + balm_factor_kernel + balm_pair_staged_kernel",
+        roof = {"bound": "hbm", "kernel": "H/g/cost evaluation: " + " + ".join(EVAL_KERNELS),
                 "achieved": bytes_eval / ev_ms / 1e6 if ev_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (bytes_eval / ev_ms / 1e6) / HBM_PEAK_GBS if ev_ms > 0 else None,
-                "traffic": read_traffic("eval"), "algorithmic_bytes": bytes_eval, "avg_ms": ev_ms}
+                "traffic": read_traffic("eval"), "traffic_source": TRAFFIC_FILE, "algorithmic_bytes": bytes_eval, "avg_ms": ev_ms}
         others = [
             {"kernel": "balm_cost_kernel (cost-only pass)", "bound": "hbm", "achieved": bytes_cost / ck_ms / 1e6,
              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_cost / ck_ms / 1e6 / HBM_PEAK_GBS,
@@ -241,7 +242,7 @@ def main():
         }
         if world == 1 and not args.no_visual:
             try:
-                out["visual_stage"] = visual_leg(pkg, synth, N, local_rank)
+                out["visual_stage"] = visual_leg(pkg, synth, N, local_rank, not args.no_cpu_baseline)
             except Exception as e:
                 out["visual_stage"] = {"error": repr(e)}
         if world == 1 and not args.no_front_end:
@@ -249,6 +250,11 @@ def main():
                 out["front_end"] = front_end_leg(pkg, synth, not args.no_cpu_baseline)
             except Exception as e:
                 out["front_end"] = {"error": repr(e)}
+        if world == 1 and not args.no_cpu_baseline and not args.no_reference_baseline:
+            try:
+                out["cpu_baseline_reference_c2"] = lidar_reference_baseline_c2(pkg, synth, local_rank)
+            except Exception as e:
+                out["cpu_baseline_reference_c2"] = {"value": None, "kind": "reference", "sample": f"failed: {e!r}"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(prob, d, info)
@@ -265,10 +271,16 @@ def main():
         raise SystemExit("bench.py: the HIP path disagrees with the oracle beyond 1e-7 at the benchmark size (see \"parity\")")
 
 
-def visual_leg(pkg, synth, n_cams, local_rank):
+def visual_leg(pkg, synth, n_cams, local_rank, with_cpu=True):
     """The second, separate problem of config C3: the visual stage (500k reprojection observations on 125k landmarks,
     cameras = the 2k poses), solved after the LiDAR stage as the reference does (src/lvba_system.cpp:139-140).  Reported
-    beside the headline metric, never inside `value`."""
+    beside the headline metric, never inside `value`.  `roofline`: the factor kernels (residual / Jacobian / Schur products)
+    against HBM on their algorithmic bytes (24 B/observation + 56 B/landmark + 56 B/camera + the reduced
+    system written once), and the reduced-camera-system solve against its own bound (a 143-wide band: the serial panel chain,
+    not flops).  `cpu_baseline`: the reference's own cost functors, differentiated with Jets as ceres::AutoDiffCostFunction
+    does, over all observations on all host cores (oracle/_ref, kind "reference"), plus a multi-threaded LAPACK Cholesky of a
+    dense SPD matrix of the reduced system's size -- what Ceres' DENSE_SCHUR factorises every iteration; the Schur elimination
+    itself is left out, so the figure is an UPPER bound of the CPU's iteration rate (restatement, not Ceres)."""
     d = synth.make_visual_problem(n_cams, 125_000, device=f"cuda:{local_rank}")
     prob = pkg.VisualProblem(n_cams, d["obs_off"], d["obs_cam"], d["obs_uv"], d["plane"], d["valid"], d["intr"], device=local_rank)
     prob.refine(d["q"], d["t"], d["X"], max_iter=2)                      # warm-up (graph capture, allocations)
@@ -276,24 +288,140 @@ def visual_leg(pkg, synth, n_cams, local_rank):
     (q, t, X), trace, term, rc = prob.refine(d["q"], d["t"], d["X"])
     dt = time.perf_counter() - t0
     iters = max(1, len(trace) - 1)
-    prob.close()
+    # the factor kernels alone: residuals + Jacobians + column norms + Schur products -> reduced system (no solve, no download)
+    lin = []
+    for _ in range(5):
+        t1 = time.perf_counter()
+        prob.linearize_only(d["q"], d["t"], d["X"])
+        lin.append(time.perf_counter() - t1)
+    lin_ms = 1e3 * min(lin)
     n_obs = int(d["obs_off"][-1])
     vmask = np.asarray(d["valid"]) != 0                                   # landmarks without a plane are left out entirely
-    n_res = 2 * int(np.diff(d["obs_off"])[vmask].sum()) + int(vmask.sum())  # reprojection (2 / observation) + plane priors
-    return {"workload": f"{n_cams} cameras x 125000 landmarks x {n_obs} reprojection observations + plane priors",
-            "lm_iterations": iters, "iterations_per_s": iters / dt, "ms_per_iteration": 1e3 * dt / iters, "termination": term,
-            "cost_initial": trace[0]["cost"], "cost_final": trace[-1]["cost"],
-            "camera_translation_err_m": {"initial_rms": float(np.sqrt(((d["t"] - d["t_gt"]) ** 2).sum(1).mean())),
-                                         "final_rms": float(np.sqrt(((t - d["t_gt"]) ** 2).sum(1).mean())),
-                                         "initial_max": float(np.abs(d["t"] - d["t_gt"]).max()),
-                                         "final_max": float(np.abs(t - d["t_gt"]).max())},
-            "landmark_err_m": {"initial_rms": float(np.sqrt(((d["X"] - d["X_gt"]) ** 2).sum(1).mean())),
-                               "final_rms": float(np.sqrt(((X - d["X_gt"]) ** 2).sum(1).mean()))},
-            "residual_rms_whitened": {"initial": float(np.sqrt(2 * trace[0]["cost"] / n_res)),
-                                      "final": float(np.sqrt(2 * trace[-1]["cost"] / n_res))},
-            "note": "the synthetic initial values are closer to ground truth than 0.5 px observations over a 4-camera, 1.8 m "
-                    "baseline can resolve (depth sigma ~ z^2 sigma_px / (f b)), so errors against ground truth grow while the "
-                    "whitened residual falls to the injected noise level; a fit check, not an accuracy claim"}
+    n_obs_act = int(np.diff(d["obs_off"])[vmask].sum())
+    n_res = 2 * n_obs_act + int(vmask.sum())                               # reprojection (2 / observation) + plane priors
+    n = 6 * n_cams
+    info = prob.info()
+    bw = 6 * info["band_blocks"] + 5
+    bytes_factor = 24 * n_obs_act + 56 * int(vmask.sum()) + 56 * n_cams + 8 * (36 * (info["n_blocks"] + n_cams) + n)
+    iter_ms = 1e3 * dt / iters
+    solve_ms = max(iter_ms - lin_ms, 1e-6)     # the rest of an iteration: band solve, back-substitution, step, cost at the trial point
+    flops_solve = n * bw * bw
+    out = {"workload": f"{n_cams} cameras x 125000 landmarks x {n_obs} reprojection observations + plane priors",
+           "lm_iterations": iters, "iterations_per_s": iters / dt, "ms_per_iteration": iter_ms, "termination": term,
+           "observations_per_s": n_obs_act * iters / dt,
+           "stage_ms": {"linearize (factor kernels)": lin_ms, "solve + step + trial cost": solve_ms},
+           "roofline": {"bound": "hbm", "kernel": "vis_residual / vis_colnorm / vis_point / vis_cam / pair pass (one linearisation)",
+                        "achieved": bytes_factor / lin_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": bytes_factor / lin_ms / 1e6 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": bytes_factor,
+                        "avg_ms": lin_ms,
+                        "note": "19 MB per linearisation: launch- and latency-bound, not bandwidth-bound (SURVEY.md 8(d))"},
+           "roofline_solve": {"bound": "mfma", "kernel": "reduced camera system: band LDL^T from both ends (ldlt_* kernels)",
+                              "achieved": flops_solve / solve_ms / 1e9, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": flops_solve / solve_ms / 1e9 / FP64_PEAK_TFLOPS, "algorithmic_flops": flops_solve,
+                              "avg_ms": solve_ms, "half_bandwidth": bw, "n": n,
+                              "note": f"a {bw}-wide band has {flops_solve / 1e9:.2f} GFLOP: the bound is the serial chain of "
+                                      f"{ldlt_chain(n, bw)} 64-column panels (~25 us each), not the matrix pipe"},
+           "cost_initial": trace[0]["cost"], "cost_final": trace[-1]["cost"],
+           "camera_translation_err_m": {"initial_rms": float(np.sqrt(((d["t"] - d["t_gt"]) ** 2).sum(1).mean())),
+                                        "final_rms": float(np.sqrt(((t - d["t_gt"]) ** 2).sum(1).mean())),
+                                        "initial_max": float(np.abs(d["t"] - d["t_gt"]).max()),
+                                        "final_max": float(np.abs(t - d["t_gt"]).max())},
+           "landmark_err_m": {"initial_rms": float(np.sqrt(((d["X"] - d["X_gt"]) ** 2).sum(1).mean())),
+                              "final_rms": float(np.sqrt(((X - d["X_gt"]) ** 2).sum(1).mean()))},
+           "residual_rms_whitened": {"initial": float(np.sqrt(2 * trace[0]["cost"] / n_res)),
+                                     "final": float(np.sqrt(2 * trace[-1]["cost"] / n_res))},
+           "note": "the synthetic initial values are closer to ground truth than 0.5 px observations over a 4-camera, 1.8 m "
+                   "baseline can resolve (depth sigma ~ z^2 sigma_px / (f b)), so errors against ground truth grow while the "
+                   "whitened residual falls to the injected noise level; a fit check, not an accuracy claim"}
+    prob.close()
+    if with_cpu:
+        try:
+            out["cpu_baseline"] = visual_cpu_baseline(d, n, trace[0]["cost"])
+        except Exception as e:
+            out["cpu_baseline"] = {"value": None, "kind": "reference", "sample": f"failed: {e!r}"}
+    return out
+
+
+def ldlt_chain(n, bw):
+    """serial panels of the two-ended band factorisation (csrc/ldlt.hip: P + |S| / 64)"""
+    P = max(0, (n - bw) // 128)
+    if P < 4:
+        return -(-n // 64)
+    return P + -(-(n - 128 * P) // 64)
+
+
+def visual_cpu_baseline(d, n, gpu_cost0):
+    import oracle
+    cores = os.cpu_count() or 1
+    if not oracle.Reference.available():
+        raise RuntimeError("oracle/_ref/libbalm_ref.so is absent")
+    ref = oracle.Reference()
+    ref.visual_jacobian_pass(d["q"], d["t"], d["X"], d["obs_off"], d["obs_cam"], d["obs_uv"], d["plane"], d["valid"], d["intr"],
+                             nthreads=cores)
+    t_jac, cost = ref.visual_jacobian_pass(d["q"], d["t"], d["X"], d["obs_off"], d["obs_cam"], d["obs_uv"], d["plane"], d["valid"],
+                                           d["intr"], nthreads=cores)
+    # dense Cholesky of an SPD matrix of the reduced camera system's size (what DENSE_SCHUR factorises each iteration)
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((n, 64))
+    S = A @ A.T
+    S[np.diag_indices(n)] += n
+    t0 = time.perf_counter()
+    np.linalg.cholesky(S)
+    t_chol = time.perf_counter() - t0
+    return {"value": 1.0 / (t_jac + t_chol), "unit": "iterations/s", "cores": cores, "kind": "reference",
+            "sample": (f"one LM iteration's two largest stages on the whole problem: residual + Jet-Jacobian evaluation with the "
+                       f"reference's own functors (include/utils.hpp, oracle/_ref/libbalm_ref.so, OpenMP x{cores}) {t_jac:.3f} s; "
+                       f"dense Cholesky of a {n} x {n} SPD matrix (numpy / LAPACK, multi-threaded; Ceres' DENSE_SCHUR does this with "
+                       f"Eigen, single-threaded) {t_chol:.3f} s; the Schur elimination between them is not timed, so this is an upper "
+                       f"bound of the CPU rate (restatement, not Ceres)"),
+            "stage_s": {"jacobian": t_jac, "dense_cholesky": t_chol},
+            "parity_cost_rel": abs(cost - gpu_cost0) / abs(cost), "host_cpus": cores, "host_cpu_model": cpu_model()}
+
+
+def lidar_reference_baseline_c2(pkg, synth, local_rank):
+    """kind "reference": the reference's OWN BALM2::divide_thread and only_residual (include/BALM/bavoxel.hpp compiled against
+    the stand-ins of oracle/shim, oracle/_ref/libbalm_ref.so) on config C2 in the reference's literal layout -- a dense
+    win_size-slot PointCluster array per voxel (400k x 500 x 80 B = 16 GB) and 16 thread-local dense (6N)^2 Hessians.  C3 cannot
+    be represented in that layout (416 GB of slots), which is why the headline's cpu_baseline is the sparse port.  The damped
+    solve is not timed here: the reference calls Eigen::SimplicialLDLT, of which oracle/shim holds only a stand-in."""
+    import oracle
+    if not oracle.Reference.available():
+        return {"value": None, "kind": "reference", "sample": "oracle/_ref/libbalm_ref.so is absent"}
+    try:
+        with open("/proc/meminfo") as f:
+            avail_gb = [int(l.split()[1]) for l in f if l.startswith("MemAvailable")][0] / 1e6
+    except Exception:
+        avail_gb = 0.0
+    N, V = synth.CONFIGS["C2"]
+    if avail_gb < 40.0:
+        return {"value": None, "kind": "reference", "sample": f"skipped: {avail_gb:.0f} GB of host memory available, 40 GB needed"}
+    import torch
+    d = synth.make_balm_problem(N, V, device=f"cuda:{local_rank}")
+    torch.cuda.empty_cache()
+    off, idx = d["voxel_off"], d["pose_idx"]
+    slots = np.zeros((V, N, 10))
+    slots[np.repeat(np.arange(V), np.diff(off)), idx] = d["clusters"]
+    ref = oracle.Reference()
+    x = d["poses_init"]
+    t0 = time.perf_counter(); H, g, r = ref.divide_thread(slots, x); t_eval = time.perf_counter() - t0
+    t0 = time.perf_counter(); c = ref.only_residual(slots, x, is_avg=True); t_cost = time.perf_counter() - t0
+    del slots
+    prob = pkg.BalmProblem(N, off, idx, d["clusters"], device=local_rank)
+    Hg, gg, cg = prob.eval(x)
+    prob.set_profiling(True); prob.profile(reset=True)
+    for _ in range(5):
+        prob.eval(x, want_H=False, want_g=False); prob.cost(x)
+    p = prob.profile()
+    prob.close()
+    return {"workload": f"C2: {N} poses x {V} voxels x {int(off[-1])} factors", "kind": "reference", "cores": 16,
+            "unit": "s per call",
+            "divide_thread_s": t_eval, "only_residual_s": t_cost,
+            "hip_eval_ms": p["eval_ms"] / max(1, p["eval_calls"]), "hip_cost_ms": p["cost_ms"] / max(1, p["cost_calls"]),
+            "parity_vs_reference": {"cost_rel": abs(cg - r) / abs(r), "g_rel": float(np.abs(gg - g).max() / np.abs(g).max()),
+                                    "H_rel": float(np.abs(Hg - H).max() / np.abs(H).max())},
+            "sample": "oracle/_ref/libbalm_ref.so: BALM2::divide_thread (16 std::threads, dense slots, dense per-thread Hessians, "
+                      "bavoxel.hpp:597-639) and BALM2::only_residual (1 thread, :641-648) on the whole C2 problem",
+            "host_cpus": os.cpu_count(), "host_cpu_model": cpu_model()}
 
 
 def front_end_leg(pkg, synth, with_cpu):
@@ -360,12 +488,23 @@ def prob_nnzb(prob, info):
     return info.get("n_blocks", 0) + info["n_poses"]
 
 
+# the kernels the `roofline` entries cover; a committed PMC summary is only quoted when it was taken from these very kernels
+EVAL_KERNELS = ["balm_voxel_kernel", "balm_factor_kernel", "balm_diag_reduce_kernel", "balm_pair_col_kernel", "balm_pair_reduce_kernel"]
+COST_KERNELS = ["balm_cost_kernel"]
+TRAFFIC_FILE = os.path.join("profiles", "traffic_r02.json")
+
+
 def read_traffic(which):
-    """HBM bytes per launch from the committed PMC pass (profiles/traffic_r01.json), or null."""
-    path = os.path.join(ROOT, "profiles", "traffic_r01.json")
+    """HBM bytes per launch from the committed PMC passes (tools/gpu_pmc2.sh -> tools/make_traffic.py -> profiles/), or null.
+    PMC counters cannot be collected inside a timed run (rocprofv3 wraps the process), so the figure comes from a separate
+    profiled run of the same command; it is REFUSED (null) when that run profiled other kernels than the ones timed here."""
     try:
-        with open(path) as f:
-            return json.load(f).get(which)
+        with open(os.path.join(ROOT, TRAFFIC_FILE)) as f:
+            t = json.load(f)
+        want = EVAL_KERNELS if which == "eval" else COST_KERNELS
+        if t.get(which + "_kernels") != want:
+            return None
+        return t.get(which)
     except Exception:
         return None
 

@@ -478,65 +478,86 @@ __global__ __launch_bounds__(256) void balm_pair_staged_kernel(PairDev d, double
 // with a single item goes straight into the store, the others into partial blocks in item order).
 // ------------------------------------------------------------------------------------------------
 #define LVBA_PC_ITEMS 10 // items per wavefront (6 lanes each; lanes 60..63 only help fetching)
+#define LVBA_PC_DEPTH 2  // pairs of every item per round: the gathers of a round are what hides the memory latency
 __global__ __launch_bounds__(256) void balm_pair_col_kernel(PairDev d, double *__restrict__ Hblk)
 {
-    __shared__ double2 recs[4][LVBA_PC_ITEMS * 18]; // per wavefront: 10 pairs x (x record, y record) x 9 chunks of 16 bytes
+    constexpr int NCH = LVBA_PC_ITEMS * LVBA_PC_DEPTH * 18; // 16-byte chunks per round
+    constexpr int NLD = (NCH + 63) / 64;                    // loads per lane per round
+    __shared__ double2 recs[4][NCH]; // per wavefront: DEPTH x 10 pairs x (x record, y record) x 9 chunks of 16 bytes
+    __shared__ int2 plist[4][LVBA_PC_ITEMS * LVBA_PAIR_CUT]; // the pair indices of the wavefront's items, fetched once
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t per_xcd = (gridDim.x + 7) / 8; // XCD x sweeps a contiguous eighth of the items = a range of voxel windows
     const int64_t wg = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     const int64_t i0 = (wg * 4 + wv) * LVBA_PC_ITEMS;
     if (i0 >= d.nnzb) return; // wavefront-uniform; no workgroup barrier below
     const int g = lane / 6, cc = lane - 6 * g; // item of the wavefront, column of its block (g = 10: idle lanes 60..63)
-    // lane l < 10 also keeps the pair-list range of item l (the fetch side asks for it through shuffles)
-    int64_t fa = 0, fb = 0;
-    if (lane < LVBA_PC_ITEMS && i0 + lane < d.nnzb) { fa = d.blk_off[i0 + lane]; fb = d.blk_off[i0 + lane + 1]; }
-    const int flen = (int)(fb - fa);
+    const int64_t iend = (i0 + LVBA_PC_ITEMS < d.nnzb) ? i0 + LVBA_PC_ITEMS : d.nnzb;
+    const int64_t q0 = d.blk_off[i0], q1 = d.blk_off[iend];
+    // the items' pair lists are one contiguous range of the sorted pair array: coalesced copy into LDS
+    int2 *pl = plist[wv];
+    for (int64_t q = q0 + lane; q < q1; q += 64) pl[q - q0] = d.pairs[q];
+    // lane l < 10 keeps the range of item l (relative to q0); everybody learns the ranges it needs through shuffles
+    int fa = 0, flen = 0;
+    if (lane < LVBA_PC_ITEMS && i0 + lane < d.nnzb) {
+        const int64_t a = d.blk_off[i0 + lane];
+        fa = (int)(a - q0); flen = (int)(d.blk_off[i0 + lane + 1] - a);
+    }
     int rounds = flen;
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) { const int t = __shfl_xor(rounds, o, 16); rounds = t > rounds ? t : rounds; }
-    rounds = __shfl(rounds, 0, 64); // max over lanes 0..15
+    rounds = (__shfl(rounds, 0, 64) + LVBA_PC_DEPTH - 1) / LVBA_PC_DEPTH; // max over lanes 0..15
     const int mylen = __shfl(flen, g < LVBA_PC_ITEMS ? g : 0, 64);
     const bool owner = g < LVBA_PC_ITEMS && i0 + g < d.nnzb;
+    // per-lane constants of the cooperative fetch: chunk c = lane + 64 s of a round is piece (c % 9) of record (c / 9);
+    // record rc belongs to slot rc >> 1 = depth * 10 + item, side rc & 1
+    int c_piece[NLD], c_side[NLD], c_dep[NLD], c_fa[NLD], c_len[NLD];
+#pragma unroll
+    for (int s2 = 0; s2 < NLD; ++s2) {
+        const int c = lane + 64 * s2, rc = c / 9, slot = rc >> 1;
+        const int dep = slot / LVBA_PC_ITEMS, gi = slot - dep * LVBA_PC_ITEMS;
+        c_piece[s2] = c - 9 * rc; c_side[s2] = rc & 1; c_dep[s2] = dep;
+        c_fa[s2] = __shfl(fa, gi, 64);
+        c_len[s2] = (c < NCH) ? __shfl(flen, gi, 64) : 0;
+    }
+    __builtin_amdgcn_wave_barrier(); // pl is complete
     double2 *rw = recs[wv];
     double acc[6];
 #pragma unroll
     for (int e = 0; e < 6; ++e) acc[e] = 0.0;
-    int2 pr = (lane < LVBA_PC_ITEMS && 0 < flen) ? d.pairs[fa] : make_int2(0, 0);
     for (int r = 0; r < rounds; ++r) {
-        double2 v[3];
+        double2 v[NLD];
 #pragma unroll
-        for (int s2 = 0; s2 < 3; ++s2) {
-            const int c = lane + 64 * s2; // chunk c of the round: record c / 9 (item rc >> 1, side rc & 1), piece c % 9
-            const int rc = c / 9, piece = c - 9 * rc, gi = rc >> 1;
-            const int px = __shfl(pr.x, gi < LVBA_PC_ITEMS ? gi : 0, 64), py = __shfl(pr.y, gi < LVBA_PC_ITEMS ? gi : 0, 64);
-            const int ln = __shfl(flen, gi < LVBA_PC_ITEMS ? gi : 0, 64);
-            const int pos = (rc & 1) ? py : px;
-            v[s2] = (c < LVBA_PC_ITEMS * 18 && r < ln) ? reinterpret_cast<const double2 *>(d.Y + 18 * (int64_t)pos)[piece]
-                                                      : make_double2(0.0, 0.0);
-        }
-        // next round's pair indices: issued before this round's records are waited for
-        const int2 prn = (lane < LVBA_PC_ITEMS && r + 1 < flen) ? d.pairs[fa + r + 1] : make_int2(0, 0);
-#pragma unroll
-        for (int s2 = 0; s2 < 3; ++s2) {
-            const int c = lane + 64 * s2;
-            if (c < LVBA_PC_ITEMS * 18) rw[c] = v[s2];
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (owner && r < mylen) {
-            const double2 *ri = rw + 18 * g;
-            const double *yj = reinterpret_cast<const double *>(ri + 9);
-            double Yi[18];
-#pragma unroll
-            for (int e = 0; e < 9; ++e) {
-                const double2 x = ri[e];
-                Yi[2 * e] = x.x; Yi[2 * e + 1] = x.y;
+        for (int s2 = 0; s2 < NLD; ++s2) {
+            const int pi = LVBA_PC_DEPTH * r + c_dep[s2]; // this chunk's pair of its item
+            v[s2] = make_double2(0.0, 0.0);
+            if (pi < c_len[s2]) {
+                const int2 pr = pl[c_fa[s2] + pi];
+                v[s2] = reinterpret_cast<const double2 *>(d.Y + 18 * (int64_t)(c_side[s2] ? pr.y : pr.x))[c_piece[s2]];
             }
-            const double j0 = yj[cc], j1 = yj[6 + cc], j2 = yj[12 + cc];
+        }
 #pragma unroll
-            for (int e = 0; e < 6; ++e) acc[e] += Yi[e] * j0 + Yi[6 + e] * j1 + Yi[12 + e] * j2;
+        for (int s2 = 0; s2 < NLD; ++s2) {
+            const int c = lane + 64 * s2;
+            if (c < NCH) rw[c] = v[s2];
         }
         __builtin_amdgcn_wave_barrier();
-        pr = prn;
+#pragma unroll
+        for (int dep = 0; dep < LVBA_PC_DEPTH; ++dep) {
+            if (owner && LVBA_PC_DEPTH * r + dep < mylen) {
+                const double2 *ri = rw + 18 * (dep * LVBA_PC_ITEMS + g);
+                const double *yj = reinterpret_cast<const double *>(ri + 9);
+                double Yi[18];
+#pragma unroll
+                for (int e = 0; e < 9; ++e) {
+                    const double2 x = ri[e];
+                    Yi[2 * e] = x.x; Yi[2 * e + 1] = x.y;
+                }
+                const double j0 = yj[cc], j1 = yj[6 + cc], j2 = yj[12 + cc];
+#pragma unroll
+                for (int e = 0; e < 6; ++e) acc[e] = fma(Yi[12 + e], j2, fma(Yi[6 + e], j1, fma(Yi[e], j0, acc[e])));
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
     if (owner) {
         const int64_t dst = d.blk_slot[i0 + g];
@@ -551,12 +572,25 @@ __global__ __launch_bounds__(256) void balm_pair_col_kernel(PairDev d, double *_
 __global__ void balm_pair_reduce_kernel(PairDev d, double *__restrict__ Hblk)
 {
     const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    const int64_t m = t / 36;
-    const int e = (int)(t - 36 * m);
+    const int64_t m = t / 18;
+    const int e = (int)(t - 18 * m); // 16-byte piece of the 288-byte block
     if (m >= d.n_multi) return;
-    double s = 0.0;
-    for (int64_t q = d.multi_off[m]; q < d.multi_off[m + 1]; ++q) s += d.partial[36 * d.multi_idx[q] + e];
-    Hblk[d.multi_slot[m] * 36 + e] = s;
+    const int64_t q0 = d.multi_off[m], q1 = d.multi_off[m + 1];
+    double2 s = make_double2(0.0, 0.0);
+    int64_t q = q0;
+    for (; q + 4 <= q1; q += 4) { // four independent loads in flight; summed in list order
+        const double2 a0 = reinterpret_cast<const double2 *>(d.partial + 36 * d.multi_idx[q])[e];
+        const double2 a1 = reinterpret_cast<const double2 *>(d.partial + 36 * d.multi_idx[q + 1])[e];
+        const double2 a2 = reinterpret_cast<const double2 *>(d.partial + 36 * d.multi_idx[q + 2])[e];
+        const double2 a3 = reinterpret_cast<const double2 *>(d.partial + 36 * d.multi_idx[q + 3])[e];
+        s.x = (((s.x + a0.x) + a1.x) + a2.x) + a3.x;
+        s.y = (((s.y + a0.y) + a1.y) + a2.y) + a3.y;
+    }
+    for (; q < q1; ++q) {
+        const double2 a0 = reinterpret_cast<const double2 *>(d.partial + 36 * d.multi_idx[q])[e];
+        s.x += a0.x; s.y += a0.y;
+    }
+    reinterpret_cast<double2 *>(Hblk + d.multi_slot[m] * 36)[e] = s;
 }
 
 // pose-major copy of the cluster statistics (one-off, at finalize)
@@ -702,7 +736,7 @@ void launch_pairs(const PairDev &pd, double *Hblk, hipStream_t s)
         }
     }
     if (pd.n_multi > 0)
-        hipLaunchKernelGGL(balm_pair_reduce_kernel, dim3((unsigned)((pd.n_multi * 36 + 255) / 256)), dim3(256), 0, s, pd, Hblk);
+        hipLaunchKernelGGL(balm_pair_reduce_kernel, dim3((unsigned)((pd.n_multi * 18 + 255) / 256)), dim3(256), 0, s, pd, Hblk);
 }
 
 void launch_eval(const BalmDev &d, const PairDev &pd, const double *poses, double *Hblk, int64_t hblk_doubles, double *g,

@@ -223,6 +223,17 @@ extern "C" int32_t lvba_visual_cost(lvba_visual_t h, const double *q, const doub
     return LVBA_OK;
 }
 
+extern "C" int32_t lvba_visual_info(lvba_visual_t h, lvba_balm_info_t *info)
+{
+    if (!h || !info) return fail(LVBA_ERR_ARG, "NULL argument");
+    TRY(finalize(h));
+    memset(info, 0, sizeof *info);
+    info->n_poses = h->M; info->n_ranks = h->bs.n_ranks; info->n_voxels = h->Ta; info->n_voxels_global = h->Ta;
+    info->n_factors = h->O; info->n_pairs = h->bs.Q; info->n_blocks = h->bs.nnzb; info->band_blocks = h->bs.Bb;
+    info->use_band = h->bs.use_band ? 1 : 0; info->hess_bytes = h->bs.hblk_doubles * 8; info->device_bytes = h->bs.device_bytes;
+    return LVBA_OK;
+}
+
 extern "C" int32_t lvba_visual_linearize(lvba_visual_t h, const double *q, const double *t, const double *X, double radius,
                                          double *S, double *rhs, double *cost)
 {

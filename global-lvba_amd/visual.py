@@ -65,6 +65,18 @@ class VisualProblem:
                                                C.byref(c)))
         return S, rhs, c.value
 
+    def linearize_only(self, q, t, X, radius=1e4):
+        """The factor kernels of one linearisation (residuals, Jacobians, column norms, Schur products -> reduced system on
+        the device) without exporting S / rhs; returns the cost."""
+        c = C.c_double()
+        L.check(self.lib.lvba_visual_linearize(self._h, *self._state(q, t, X), float(radius), None, None, C.byref(c)))
+        return c.value
+
+    def info(self):
+        i = L.BalmInfo()
+        L.check(self.lib.lvba_visual_info(self._h, C.byref(i)))
+        return {f: getattr(i, f) for f, _ in i._fields_}
+
     @staticmethod
     def default_opts(**kw):
         o = L.VisualOpts()

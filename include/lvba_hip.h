@@ -228,6 +228,11 @@ int32_t lvba_visual_create(int32_t n_cams, int64_t n_tracks, const int64_t *obs_
                            double sigma_px, double sigma_plane, int32_t device, lvba_visual_t *out);
 int32_t lvba_visual_destroy(lvba_visual_t h);
 
+/* Sizes of the packed problem in the fields of lvba_balm_info_t that apply: n_poses = cameras, n_voxels = landmarks with a
+ * plane (the active ones), n_factors = their observations, n_pairs, n_blocks (off-diagonal camera blocks of the reduced
+ * system), band_blocks, use_band, hess_bytes, device_bytes. */
+int32_t lvba_visual_info(lvba_visual_t h, lvba_balm_info_t *info);
+
 /* 1/2 sum r^2 over the residuals of the active landmarks at (q [M][4], t [M][3], X [n_tracks][3]). */
 int32_t lvba_visual_cost(lvba_visual_t h, const double *q, const double *t, const double *X, double *cost);
 

@@ -291,6 +291,11 @@ def load_ref():
         lib.ref_pl_transform.argtypes = [c_i64, f32p, f64p]
         i32p = np.ctypeslib.ndpointer(np.int32, flags="C")
         lib.ref_reproj.argtypes = [f64p, f64p, f64p, f64p, f64p, c_dbl, c_dbl, f64p, f64p]
+        u8p = np.ctypeslib.ndpointer(np.uint8, flags="C")
+        if hasattr(lib, "ref_visual_jacobian_pass"):
+            lib.ref_visual_jacobian_pass.restype = c_dbl
+            lib.ref_visual_jacobian_pass.argtypes = [c_i64, i64p, i32p, f64p, f64p, f64p, f64p, f64p, u8p, f64p, c_dbl, c_dbl, c_int,
+                                                     ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl)]
         lib.ref_plane.argtypes = [f64p, c_dbl, c_dbl, f64p, f64p, f64p]
         for fn in (lib.ref_distort, lib.ref_undistort):
             fn.restype, fn.argtypes = c_int, [f64p, c_dbl, c_dbl, f64p]
@@ -368,6 +373,20 @@ class Reference:
         x = np.array(poses, np.float64).reshape(-1).copy()
         self.lib.ref_damping_iter(win, V, self._c(slots).reshape(-1), x)
         return x.reshape(-1, 12)
+
+    def visual_jacobian_pass(self, q, t, X, obs_off, obs_cam, obs_uv, plane, valid, intr, sigma_px=0.5, sigma_plane=0.01,
+                             nthreads=None):
+        """One residual + Jet-Jacobian pass of the reference's own cost functors over a visual problem (ref_glue_visual.cpp).
+        Returns (seconds, cost)."""
+        if nthreads is None:
+            nthreads = os.cpu_count() or 1
+        c, js = ctypes.c_double(), ctypes.c_double()
+        sec = self.lib.ref_visual_jacobian_pass(len(obs_off) - 1, self._c(obs_off, np.int64), self._c(obs_cam, np.int32),
+                                                self._c(obs_uv).reshape(-1), self._c(q).reshape(-1), self._c(t).reshape(-1),
+                                                self._c(X).reshape(-1), self._c(plane).reshape(-1), self._c(valid, np.uint8),
+                                                self._c(intr), float(sigma_px), float(max(1e-9, sigma_plane)), int(nthreads),
+                                                ctypes.byref(c), ctypes.byref(js))
+        return float(sec), c.value
 
     def map_build(self, clouds, poses, voxel_size, eigen_ratio=(0.3, 0.1, 0.06, 0.03)):
         """cut_voxel + recut + tras_opt as the reference's call sites run them.  Returns dict(keys [P,4] (x, y, z,

@@ -6,8 +6,53 @@
 // translation unit of oracle/_ref/libbalm_ref.so; tests/test_ref_pin.py uses it to pin oracle/visual_oracle.py's functors,
 // oracle/track_oracle.py's camera model and global-lvba_amd/dataset.py's timestamp parser.
 #include "utils.hpp"
+#include <omp.h>
 
 extern "C" {
+
+// One residual + Jacobian evaluation pass over a whole visual problem with the reference's own functors, differentiated with
+// Jets as ceres::AutoDiffCostFunction does (src/lvba_system.cpp:1615-1639: one ReprojErrorWhitenedDistorted per observation of
+// every landmark that has a plane, one PointPlaneErrorWhitened per such landmark), OpenMP over the landmarks like Ceres'
+// threaded evaluation (:1575 num_threads).  bench.py times it as the CPU baseline of the visual leg's factor kernels.
+// Returns the wall seconds; *cost = 1/2 sum r^2, *jac_sum a checksum of all Jacobian entries (keeps the work alive).
+double ref_visual_jacobian_pass(int64_t n_tracks, const int64_t *obs_off, const int32_t *obs_cam, const double *obs_uv,
+                                const double *q, const double *t, const double *X, const double *plane, const uint8_t *valid,
+                                const double *intr, double sigma_px, double sigma_plane, int nthreads, double *cost, double *jac_sum)
+{
+    typedef ceres::Jet<double, 10> J10;
+    typedef ceres::Jet<double, 3> J3;
+    double c = 0.0, js = 0.0;
+    const double t0 = omp_get_wtime();
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 256) reduction(+ : c, js)
+    for (int64_t a = 0; a < n_tracks; ++a) {
+        if (!valid[a]) continue; // landmarks without a plane are left out with their observations (:1598-1603)
+        const double *Xa = X + 3 * a;
+        for (int64_t o = obs_off[a]; o < obs_off[a + 1]; ++o) {
+            const int m = obs_cam[o];
+            lvba::ReprojErrorWhitenedDistorted f(obs_uv[2 * o], obs_uv[2 * o + 1], intr[0], intr[1], intr[2], intr[3], intr[4], intr[5],
+                                                 intr[6], intr[7], sigma_px, sigma_px);
+            J10 jq[4], jt[3], jX[3], jr[2];
+            for (int i = 0; i < 4; ++i) jq[i] = J10(q[4 * m + i], i);
+            for (int i = 0; i < 3; ++i) jt[i] = J10(t[3 * m + i], 4 + i);
+            for (int i = 0; i < 3; ++i) jX[i] = J10(Xa[i], 7 + i);
+            f(jq, jt, jX, jr);
+            for (int r = 0; r < 2; ++r) {
+                c += jr[r].a * jr[r].a;
+                for (int i = 0; i < 10; ++i) js += jr[r].v[i];
+            }
+        }
+        lvba::PointPlaneErrorWhitened fp(Eigen::Vector3d(plane[4 * a], plane[4 * a + 1], plane[4 * a + 2]), plane[4 * a + 3], sigma_plane);
+        J3 jX[3], jr[1];
+        for (int i = 0; i < 3; ++i) jX[i] = J3(Xa[i], i);
+        fp(jX, jr);
+        c += jr[0].a * jr[0].a;
+        for (int i = 0; i < 3; ++i) js += jr[0].v[i];
+    }
+    const double dt = omp_get_wtime() - t0;
+    *cost = 0.5 * c;
+    *jac_sum = js;
+    return dt;
+}
 
 // ReprojErrorWhitenedDistorted (utils.hpp:51-127).  intr = fx fy cx cy k1 k2 p1 p2.  r[2]; J [2][10] = d r / d (q[4], t[3], X[3])
 // in the ambient parameters, as the AutoDiffCostFunction<.., 2, 4, 3, 3> of :117 would hand to the solver.
