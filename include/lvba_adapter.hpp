@@ -414,4 +414,55 @@ void build_tracks_and_fuse(const KeypointTable &all_keypoints, const MatchTable 
     build_tracks_and_fuse_with<Track>(all_keypoints, all_matches, o.obser_thr, fuse, tracks, obs_to_track);
 }
 
+// ---- the ceres::Problem ... ceres::Solve region of LvbaSystem::optimizeCameraPoses (src/lvba_system.cpp:1571-1649) -------------
+// qs [M] (w, x, y, z), ts [M], Xs [P]: the reference's own std::vector<std::array<double, N>> (any contiguous container of
+// N-double records works), refined in place like the parameter blocks Ceres is handed; the landmarks are the ones the loop at
+// :1593-1640 adds (those with a plane -- `valid` marks them, the others are left untouched with their observations, :1598-1603).
+// obs_off [P+1], obs_cam [O], obs_uv [O][2]: the de-duplicated inlier observations per landmark (:1615-1632); plane_nd [P][4].
+// Camera 0 is held constant (:1582-1583).  Returns the termination code (LVBA_TERM_*; LVBA_TERM_FAILURE is what the
+// reference's `summary.termination_type == ceres::FAILURE` early return at :1646-1649 tests).  Usage:
+//       const int term = lvba::optimize_camera_poses_hip(qs, ts, Xs, obs_off, obs_cam, obs_uv, plane_nd, valid, intr, 0.5, 0.01);
+//       if (term == LVBA_TERM_FAILURE) { std::cerr << "[optimizeCamPoses] Solver failed!\n"; return; }
+// and the write-back block at :1651-1665 runs unchanged afterwards.
+template <class QVec, class TVec, class XVec>
+int32_t optimize_camera_poses_hip(QVec &qs, TVec &ts, XVec &Xs, const std::vector<int64_t> &obs_off,
+                                  const std::vector<int32_t> &obs_cam, const std::vector<double> &obs_uv,
+                                  const std::vector<double> &plane_nd, const std::vector<uint8_t> &valid, const double intr[8],
+                                  double sigma_px, double sigma_plane, std::vector<lvba_visual_trace> *trace = nullptr,
+                                  int device = 0)
+{
+    const int32_t M = static_cast<int32_t>(qs.size());
+    const int64_t P = static_cast<int64_t>(Xs.size());
+    if (static_cast<int64_t>(obs_off.size()) != P + 1 || static_cast<int64_t>(valid.size()) != P ||
+        static_cast<int64_t>(plane_nd.size()) != 4 * P || ts.size() != qs.size())
+        throw std::runtime_error("optimize_camera_poses_hip: array sizes disagree");
+    std::vector<double> q(4 * static_cast<size_t>(M)), t(3 * static_cast<size_t>(M)), X(3 * static_cast<size_t>(P));
+    for (int32_t m = 0; m < M; ++m) {
+        for (int e = 0; e < 4; ++e) q[4 * m + e] = qs[m][e];
+        for (int e = 0; e < 3; ++e) t[3 * m + e] = ts[m][e];
+    }
+    for (int64_t a = 0; a < P; ++a)
+        for (int e = 0; e < 3; ++e) X[3 * a + e] = Xs[a][e];
+    lvba_visual_t vh = nullptr;
+    if (lvba_visual_create(M, P, obs_off.data(), obs_cam.data(), obs_uv.data(), plane_nd.data(), valid.data(), intr, sigma_px,
+                           sigma_plane, device, &vh) != LVBA_OK)
+        throw std::runtime_error(std::string("lvba_visual_create: ") + lvba_last_error());
+    lvba_visual_opts o;
+    lvba_visual_default_opts(&o);                        // 50 iterations, Ceres 2.1 defaults (:1572-1576)
+    std::vector<lvba_visual_trace> tr(static_cast<size_t>(o.max_iter) + 2);
+    int32_t n_trace = 0, term = LVBA_TERM_NO_CONVERGENCE;
+    const int32_t rc = lvba_visual_refine(vh, q.data(), t.data(), X.data(), &o, tr.data(), static_cast<int32_t>(tr.size()), &n_trace, &term);
+    lvba_visual_destroy(vh);
+    if (rc < 0) throw std::runtime_error(std::string("lvba_visual_refine: ") + lvba_last_error());
+    if (trace) trace->assign(tr.begin(), tr.begin() + n_trace);
+    for (int32_t m = 0; m < M; ++m) {
+        for (int e = 0; e < 4; ++e) qs[m][e] = q[4 * m + e];
+        for (int e = 0; e < 3; ++e) ts[m][e] = t[3 * m + e];
+    }
+    for (int64_t a = 0; a < P; ++a)
+        if (valid[a])
+            for (int e = 0; e < 3; ++e) Xs[a][e] = X[3 * a + e];
+    return term;
+}
+
 } // namespace lvba

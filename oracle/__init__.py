@@ -258,6 +258,28 @@ def ref_system_path():
     return so if os.path.exists(so) else None
 
 
+def build_dropin(force=False):
+    """oracle/_ref/liblvba_system_dropin.so: the reference's own src/lvba_system.cpp + src/dataset_io.cpp compiled like
+    liblvba_system_ref.so, but with BALM2::damping_iter and ceres::Solve going to the product's liblvba_hip.so through
+    include/lvba_adapter.hpp (ref_glue_system.cpp, LVBA_DROPIN).  Built when the reference sources and the product library
+    are present; returns the path, or None."""
+    so = os.path.join(_HERE, "_ref", "liblvba_system_dropin.so")
+    src = os.path.join(REFERENCE_ROOT, "src", "lvba_system.cpp")
+    hip = os.path.join(os.path.dirname(_HERE), "global-lvba_amd", "liblvba_hip.so")
+    if os.path.exists(src) and os.path.exists(hip):
+        deps = [os.path.join(_HERE, "ref_glue_system.cpp"), os.path.join(_HERE, "Makefile"), src,
+                os.path.join(os.path.dirname(_HERE), "include", "lvba_adapter.hpp"),
+                os.path.join(os.path.dirname(_HERE), "include", "lvba_hip.h")]
+        for root, _, files in os.walk(os.path.join(_HERE, "shim")):
+            deps += [os.path.join(root, f) for f in files]
+        if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
+            try:
+                subprocess.check_call(["make", "-C", _HERE, "-B", "-s", "dropin", "REF=" + REFERENCE_ROOT])
+            except subprocess.CalledProcessError:
+                return so if os.path.exists(so) else None
+    return so if os.path.exists(so) else None
+
+
 def load_ref():
     """ctypes handle to oracle/_ref/libbalm_ref.so, or None when it cannot be had."""
     global _RLIB

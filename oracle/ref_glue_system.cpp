@@ -16,6 +16,7 @@
 // global-lvba_amd/pipeline.py (updateCameraPosesFromLidar, camera_from_imu, build_components, the visual problem set-up),
 // oracle/fusion_oracle.py (buildGridMapFromOptimized + generateDepthWithVoxel, BuildTracksAndFuse3D) and
 // oracle/track_oracle.py (ComputeMeanReproj / TriangulateTrackDLT).
+#include <cstring>
 #include <deque>
 #include <fstream>
 #include <set>
@@ -23,12 +24,55 @@
 #ifndef ROOT_DIR
 #define ROOT_DIR "" // CMakeLists.txt of the reference defines it as the source directory; the tests pass absolute paths
 #endif
+#ifdef LVBA_DROPIN
+// The DROP-IN build (oracle/_ref/liblvba_system_dropin.so, linked against the product's liblvba_hip.so): the reference's own
+// pipeline code with the two hot-path calls going to the GPU library through include/lvba_adapter.hpp -- what a maintainer
+// gets after the two-line patch of INTEGRATION.md section 2.  The reference's sources are compiled from where they lie and
+// cannot be edited here, so the patch is made by the preprocessor: src/lvba_system.cpp:264 and :386 read
+//     opt_lsv->damping_iter(x, *voxhess);
+// which becomes   opt_lsv->win_size, lvba_dropin::damping_iter(x, *voxhess);   (a member read, then the adapter call).
+// BALM2's own definition is seen first, untouched.  The ceres::Solve of optimizeCameraPoses (:1643) reaches the hook below,
+// which hands the problem the reference assembled to lvba::optimize_camera_poses_hip.
+#include "BALM/bavoxel.hpp"
+#include "../include/lvba_adapter.hpp"
+namespace lvba_dropin {
+static int n_lidar_calls = 0, n_lidar_iterations = 0, n_visual_calls = 0, visual_termination = -1, visual_iterations = 0;
+static double visual_cost0 = 0.0, visual_cost1 = 0.0, lidar_call_diff[16] = {0};
+template <class PoseVec, class VoxHess> void damping_iter(PoseVec &x, const VoxHess &vh)
+{
+    // LVBA_DROPIN_CHECK: the reference's own BALM2::damping_iter (CPU) on a copy of the same inputs, call by call
+    PoseVec x_cpu = x;
+    const bool check = std::getenv("LVBA_DROPIN_CHECK") != nullptr;
+    if (check) { BALM2 ref(vh.win_size); ref.damping_iter(x_cpu, const_cast<VoxHess &>(vh)); }
+    const std::vector<lvba_lm_trace> tr = lvba::damping_iter_hip(x, vh);
+    if (check && n_lidar_calls < 16) {
+        double d = 0.0;
+        for (size_t j = 0; j < x.size(); ++j) {
+            for (int r = 0; r < 3; ++r) {
+                d = std::max(d, std::fabs(x[j].p[r] - x_cpu[j].p[r]));
+                for (int c = 0; c < 3; ++c) d = std::max(d, std::fabs(x[j].R(r, c) - x_cpu[j].R(r, c)));
+            }
+        }
+        lidar_call_diff[n_lidar_calls] = d;
+        std::fprintf(stderr, "[dropin] damping_iter call %d: %d voxels, %d poses, %d LM iterations, cost %.6e -> %.6e, max |GPU - CPU| = %.3e\n",
+                     n_lidar_calls, (int)vh.plvec_voxels.size(), (int)vh.win_size, (int)tr.size(), tr.empty() ? 0.0 : tr.front().residual1,
+                     tr.empty() ? 0.0 : (tr.back().accepted ? tr.back().residual2 : tr.back().residual1), d);
+    }
+    ++n_lidar_calls;
+    n_lidar_iterations += (int)tr.size();
+}
+} // namespace lvba_dropin
+#define damping_iter(X, V) win_size, lvba_dropin::damping_iter(X, V)
+#endif
 #include "dataset_io.cpp"
 #include "lvba_system.cpp"
+#ifdef LVBA_DROPIN
+#undef damping_iter
+#endif
 
 namespace {
 
-struct RecordedResidual { int kind; int cam; int point; double r[2]; double loss_a; };
+struct RecordedResidual { int kind; int cam; int point; double r[2]; double loss_a; double uv[2]; };
 struct RecordedProblem {
     bool valid = false;
     int n_cams = 0, n_points = 0, max_iter = 0, linear_solver = -1;
@@ -80,6 +124,9 @@ void solve_hook(const ceres::Solver::Options &opt, ceres::Problem *prob, ceres::
         rr.r[0] = rr.r[1] = 0.0;
         if (rb.parameters.size() == 3) {
             rr.kind = 2;
+            if (auto *rc = dynamic_cast<const ceres::AutoDiffCostFunction<lvba::ReprojErrorWhitenedDistorted, 2, 4, 3, 3> *>(rb.cost)) {
+                rr.uv[0] = rc->functor_->u_; rr.uv[1] = rc->functor_->v_; // the observation the functor was created with (:1624-1628)
+            }
             rr.cam = index_of(R.cam_q, rb.parameters[0]);
             if (index_of(R.cam_t, rb.parameters[1]) != rr.cam) rr.cam = -1;
             rr.point = index_of(R.pts, rb.parameters[2]);
@@ -114,6 +161,70 @@ void solve_hook(const ceres::Solver::Options &opt, ceres::Problem *prob, ceres::
         sum->termination_type = ceres::CONVERGENCE;
     }
 }
+
+#ifdef LVBA_DROPIN
+// ceres::Solve of the drop-in build: the recorded problem -> the arrays of lvba_visual_create (in the order the reference
+// added the blocks), solved on the GPU, written back into the parameter blocks as Ceres would.
+void dropin_solve_hook(const ceres::Solver::Options &opt, ceres::Problem *prob, ceres::Solver::Summary *sum)
+{
+    typedef ceres::AutoDiffCostFunction<lvba::ReprojErrorWhitenedDistorted, 2, 4, 3, 3> ReprojCost;
+    typedef ceres::AutoDiffCostFunction<lvba::PointPlaneErrorWhitened, 1, 3> PlaneCost;
+    std::vector<double *> cam_q, cam_t, pts;
+    for (size_t i = 0; i < prob->parameter_blocks.size(); ++i) {
+        const auto &pb = prob->parameter_blocks[i];
+        if (pb.size == 4) cam_q.push_back(pb.values);
+        else if (i > 0 && prob->parameter_blocks[i - 1].size == 4) cam_t.push_back(pb.values);
+        else pts.push_back(pb.values);
+    }
+    const int M = (int)cam_q.size(), P = (int)pts.size();
+    std::vector<std::vector<std::pair<int, std::pair<double, double>>>> obs((size_t)P);
+    std::vector<double> plane(4 * (size_t)P, 0.0);
+    std::vector<uint8_t> valid((size_t)P, 0);
+    double intr[8] = {0}, sig_px = 0.5, sig_pl = 0.01;
+    for (const auto &rb : prob->residual_blocks) {
+        if (rb.loss) throw std::runtime_error("drop-in: a loss function was attached (the reference passes nullptr, :1630,1639)");
+        if (const ReprojCost *rc = dynamic_cast<const ReprojCost *>(rb.cost)) {
+            const auto &f = *rc->functor_;
+            const int cam = index_of(cam_q, rb.parameters[0]), pt = index_of(pts, rb.parameters[2]);
+            if (cam < 0 || pt < 0 || index_of(cam_t, rb.parameters[1]) != cam) throw std::runtime_error("drop-in: unexpected block wiring");
+            obs[(size_t)pt].push_back({cam, {f.u_, f.v_}});
+            const double in[8] = {f.fx_, f.fy_, f.cx_, f.cy_, f.k1_, f.k2_, f.p1_, f.p2_};
+            std::copy(in, in + 8, intr);
+            sig_px = f.su_;
+        } else if (const PlaneCost *pc = dynamic_cast<const PlaneCost *>(rb.cost)) {
+            const auto &f = *pc->functor_;
+            const int pt = index_of(pts, rb.parameters[0]);
+            if (pt < 0) throw std::runtime_error("drop-in: plane residual on an unknown block");
+            plane[4 * (size_t)pt] = f.nx_; plane[4 * (size_t)pt + 1] = f.ny_; plane[4 * (size_t)pt + 2] = f.nz_; plane[4 * (size_t)pt + 3] = f.d_;
+            valid[(size_t)pt] = 1;
+            sig_pl = f.s_;
+        } else
+            throw std::runtime_error("drop-in: unknown cost function");
+    }
+    std::vector<int64_t> off(1, 0);
+    std::vector<int32_t> ocam;
+    std::vector<double> ouv;
+    for (int p = 0; p < P; ++p) {
+        for (const auto &o : obs[(size_t)p]) { ocam.push_back(o.first); ouv.push_back(o.second.first); ouv.push_back(o.second.second); }
+        off.push_back((int64_t)ocam.size());
+    }
+    std::vector<std::array<double, 4>> qs((size_t)M);
+    std::vector<std::array<double, 3>> ts((size_t)M), Xs((size_t)P);
+    for (int m = 0; m < M; ++m) { std::copy(cam_q[m], cam_q[m] + 4, qs[m].begin()); std::copy(cam_t[m], cam_t[m] + 3, ts[m].begin()); }
+    for (int p = 0; p < P; ++p) std::copy(pts[p], pts[p] + 3, Xs[p].begin());
+    std::vector<lvba_visual_trace> trace;
+    const int term = lvba::optimize_camera_poses_hip(qs, ts, Xs, off, ocam, ouv, plane, valid, intr, sig_px, sig_pl, &trace);
+    for (int m = 0; m < M; ++m) { std::copy(qs[m].begin(), qs[m].end(), cam_q[m]); std::copy(ts[m].begin(), ts[m].end(), cam_t[m]); }
+    for (int p = 0; p < P; ++p) std::copy(Xs[p].begin(), Xs[p].end(), pts[p]);
+    ++lvba_dropin::n_visual_calls;
+    lvba_dropin::visual_termination = term;
+    lvba_dropin::visual_iterations = trace.empty() ? 0 : (int)trace.size() - 1;
+    lvba_dropin::visual_cost0 = trace.empty() ? 0.0 : trace.front().cost;
+    lvba_dropin::visual_cost1 = trace.empty() ? 0.0 : trace.back().cost;
+    sum->termination_type = term == LVBA_TERM_FAILURE ? ceres::FAILURE : ceres::CONVERGENCE;
+    (void)opt;
+}
+#endif
 
 ros::NodeHandle g_nh;
 
@@ -268,6 +379,24 @@ int ref_sys_optimize(void *h, const double *sol_q, const double *sol_t, const do
     ceres::lvba_solve_hook() = nullptr;
     return rc == 0 && !g_rec.valid ? 1 : rc; // 1: the reference returned before building a problem
 }
+#ifdef LVBA_DROPIN
+// optimizeCameraPoses of the drop-in build: ceres::Solve runs lvba_visual_refine on the GPU (dropin_solve_hook)
+int ref_sys_optimize_dropin(void *h)
+{
+    ceres::lvba_solve_hook() = dropin_solve_hook;
+    const int rc = guarded([&] { SYS(h).optimizeCameraPoses(); });
+    ceres::lvba_solve_hook() = nullptr;
+    return rc;
+}
+// out: GPU damping_iter calls, their LM iterations, GPU visual solves, termination of the last, its LM iterations
+void ref_sys_dropin_call_diffs(double *out) { std::copy(lvba_dropin::lidar_call_diff, lvba_dropin::lidar_call_diff + 16, out); }
+void ref_sys_dropin_stats(int *out, double *cost)
+{
+    out[0] = lvba_dropin::n_lidar_calls; out[1] = lvba_dropin::n_lidar_iterations; out[2] = lvba_dropin::n_visual_calls;
+    out[3] = lvba_dropin::visual_termination; out[4] = lvba_dropin::visual_iterations;
+    cost[0] = lvba_dropin::visual_cost0; cost[1] = lvba_dropin::visual_cost1;
+}
+#endif
 // out: n_cams n_points n_residual_blocks max_num_iterations linear_solver_type(3 = DENSE_SCHUR)
 void ref_sys_problem_info(int *out)
 {
@@ -291,6 +420,12 @@ void ref_sys_problem_residuals(int32_t *kind, int32_t *cam, int32_t *point, doub
         kind[i] = g_rec.res[i].kind; cam[i] = g_rec.res[i].cam; point[i] = g_rec.res[i].point;
         r[2 * i] = g_rec.res[i].r[0]; r[2 * i + 1] = g_rec.res[i].r[1]; loss_a[i] = g_rec.res[i].loss_a;
     }
+}
+
+// per residual block: the pixel observation of a reprojection residual (0, 0 for plane residuals)
+void ref_sys_problem_uv(double *uv)
+{
+    for (size_t i = 0; i < g_rec.res.size(); ++i) { uv[2 * i] = g_rec.res[i].uv[0]; uv[2 * i + 1] = g_rec.res[i].uv[1]; }
 }
 
 // loadFromColmapDB (:510-685) on <data_path>/<data_config/colmap_db_path>: key points and inlier matches into all_keypoints_ /

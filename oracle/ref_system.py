@@ -8,16 +8,20 @@ import ctypes
 
 import numpy as np
 
-from . import ref_system_path
+from . import build_dropin, ref_system_path
 
 _LIB = None
+_LIBS = {}
 
 
-def load():
+def load(dropin=False):
+    """dropin=True: oracle/_ref/liblvba_system_dropin.so -- the same reference sources with BALM2::damping_iter and ceres::Solve
+    going to the product's liblvba_hip.so (GPU) through include/lvba_adapter.hpp."""
     global _LIB
-    if _LIB is None:
-        so = ref_system_path()
+    if dropin not in _LIBS:
+        so = build_dropin() if dropin else ref_system_path()
         if so is None:
+            _LIBS[dropin] = None
             return None
         lib = ctypes.CDLL(so)
         vp, c_int, c_dbl = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
@@ -62,12 +66,17 @@ def load():
         lib.ref_sys_problem_cost.restype = c_dbl
         lib.ref_sys_problem_blocks.argtypes = [f64p, f64p, f64p, f64p, i32p, i32p, i32p]
         lib.ref_sys_problem_residuals.argtypes = [i32p, i32p, i32p, f64p, f64p]
-        _LIB = lib
-    return _LIB
+        lib.ref_sys_problem_uv.argtypes = [f64p]
+        if dropin:
+            lib.ref_sys_optimize_dropin.restype, lib.ref_sys_optimize_dropin.argtypes = c_int, [vp]
+            lib.ref_sys_dropin_stats.argtypes = [i32p, f64p]
+            lib.ref_sys_dropin_call_diffs.argtypes = [f64p]
+        _LIBS[dropin] = lib
+    return _LIBS[dropin]
 
 
-def available():
-    return load() is not None
+def available(dropin=False):
+    return load(dropin) is not None
 
 
 def _fmt(v):
@@ -82,10 +91,12 @@ class ReferenceSystem:
     """One lvba::LvbaSystem.  `params`: the ROS parameter names of the reference's launch/config files (e.g.
     "cam_model/cam_fx", "window_ba/size", "extrin_calib/Rcl") -> values; "data_config/data_path" is set from `dataset_dir`."""
 
-    def __init__(self, dataset_dir, params=None):
-        self.lib = load()
+    def __init__(self, dataset_dir, params=None, dropin=False):
+        self.lib = load(dropin)
+        self.dropin = dropin
         if self.lib is None:
-            raise RuntimeError("oracle/_ref/liblvba_system_ref.so is not available (no reference sources, no prebuilt library)")
+            raise RuntimeError("oracle/_ref/liblvba_system_%s.so is not available (no reference sources, no prebuilt library)"
+                               % ("dropin" if dropin else "ref"))
         self.lib.ref_sys_clear_params()
         p = dict(params or {})
         d = str(dataset_dir)
@@ -229,6 +240,22 @@ class ReferenceSystem:
         if self.lib.ref_sys_export_colmap(self.h, int(width), int(height)) != 0:
             raise RuntimeError("reference VisualizeOptComparison threw")
 
+    def optimize_dropin(self):
+        """optimizeCameraPoses of the drop-in build: the reference assembles its ceres::Problem, ceres::Solve runs
+        lvba_visual_refine on the GPU, the reference writes the result back."""
+        if self.lib.ref_sys_optimize_dropin(self.h) != 0:
+            raise RuntimeError("reference optimizeCameraPoses (drop-in) threw")
+        return self.dropin_stats()
+
+    def dropin_stats(self):
+        out, cost = np.zeros(5, np.int32), np.zeros(2)
+        self.lib.ref_sys_dropin_stats(out, cost)
+        diffs = np.zeros(16)
+        self.lib.ref_sys_dropin_call_diffs(diffs)
+        return dict(lidar_calls=int(out[0]), lidar_iterations=int(out[1]), visual_calls=int(out[2]), visual_termination=int(out[3]),
+                    visual_iterations=int(out[4]), visual_cost0=float(cost[0]), visual_cost1=float(cost[1]),
+                    lidar_call_diffs=diffs[:max(0, min(16, int(out[0])))].copy())
+
     def optimize(self, solution=None):
         """optimizeCameraPoses with the recording ceres::Problem.  Returns the recorded problem, or None when the reference
         returned before building one.  `solution` = (q [M,4] wxyz memory order, t [M,3], X [P,3]) is installed in place of
@@ -251,6 +278,8 @@ class ReferenceSystem:
         kind, cam, point = np.zeros(nr, np.int32), np.zeros(nr, np.int32), np.zeros(nr, np.int32)
         r, loss = np.zeros((nr, 2)), np.zeros(nr)
         self.lib.ref_sys_problem_residuals(kind, cam, point, r.reshape(-1), loss)
-        return dict(n_cams=M, n_points=P, max_iter=int(info[3]), linear_solver=int(info[4]), q0=q0, t0=t0, X0=X0, plane=plane,
+        uv = np.zeros((nr, 2))
+        self.lib.ref_sys_problem_uv(uv.reshape(-1))
+        return dict(uv=uv, n_cams=M, n_points=P, max_iter=int(info[3]), linear_solver=int(info[4]), q0=q0, t0=t0, X0=X0, plane=plane,
                     q_const=qc, t_const=tc, q_tangent=qt, kind=kind, cam=cam, point=point, r=r, loss_a=loss,
                     cost0=float(self.lib.ref_sys_problem_cost()))

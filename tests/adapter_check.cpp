@@ -2,6 +2,7 @@
 // Returns 0 if packing is right and (without a GPU) the library refuses loudly, or (with one) refines.
 #include <cmath>
 #include <cstdio>
+#include <array>
 #include <cstring>
 #include <utility>
 #include <vector>
@@ -103,6 +104,41 @@ int main()
     } catch (const std::exception &e) {
         std::printf("refused: %s\n", e.what());
         if (!(lvba_device_count() == 0 && std::strstr(e.what(), "no CPU fallback"))) return 9;
+    }
+    try { // the visual solve through the adapter (src/lvba_system.cpp:1571-1649): 4 cameras on a line, 40 landmarks on z-planes
+        std::vector<std::array<double, 4>> qs(4, std::array<double, 4>{1.0, 0.0, 0.0, 0.0});
+        std::vector<std::array<double, 3>> ts(4), Xs(40);
+        const double intr[8] = {300, 300, 160, 120, 0, 0, 0, 0};
+        std::vector<int64_t> obs_off{0};
+        std::vector<int32_t> obs_cam;
+        std::vector<double> obs_uv, plane;
+        std::vector<uint8_t> valid;
+        unsigned rs = 12345u;
+        auto rnd = [&]() { rs = rs * 1664525u + 1013904223u; return (double)(rs >> 8) / (double)(1u << 24) - 0.5; };
+        for (int m = 0; m < 4; ++m) ts[m] = {-0.4 * m, 0.0, 0.0};
+        for (int p = 0; p < 40; ++p) {
+            const double X[3] = {2.0 * rnd(), 1.5 * rnd(), 6.0 + 2.0 * rnd()};
+            for (int m = 0; m < 4; ++m) {
+                obs_cam.push_back(m);
+                obs_uv.push_back(intr[0] * (X[0] + ts[m][0]) / X[2] + intr[2] + 0.3 * rnd());
+                obs_uv.push_back(intr[1] * X[1] / X[2] + intr[3] + 0.3 * rnd());
+            }
+            obs_off.push_back((int64_t)obs_cam.size());
+            plane.insert(plane.end(), {0.0, 0.0, 1.0, -X[2]});
+            valid.push_back(p % 7 != 0);                                   // a few landmarks without a plane: left untouched
+            Xs[p] = {X[0] + 0.05 * rnd(), X[1] + 0.05 * rnd(), X[2] + 0.05 * rnd()};
+        }
+        for (int m = 1; m < 4; ++m) ts[m][1] += 0.01 * m;                  // perturbed cameras (camera 0 is held constant)
+        const std::array<double, 3> X0 = Xs[0], X1 = Xs[1];
+        std::vector<lvba_visual_trace> trace;
+        const int32_t term = lvba::optimize_camera_poses_hip(qs, ts, Xs, obs_off, obs_cam, obs_uv, plane, valid, intr, 0.5, 0.01, &trace);
+        std::printf("cameras refined on the GPU: %zu rows, cost %.4e -> %.4e, termination %d\n", trace.size(),
+                    trace.empty() ? 0.0 : trace.front().cost, trace.empty() ? 0.0 : trace.back().cost, (int)term);
+        if (trace.size() < 2 || !(trace.back().cost < 0.2 * trace.front().cost) || term == LVBA_TERM_FAILURE) return 10;
+        if (Xs[0] != X0 || Xs[1] == X1) return 11;                        // landmark 0 has no plane; landmark 1 moved
+    } catch (const std::exception &e) {
+        std::printf("refused: %s\n", e.what());
+        if (!(lvba_device_count() == 0 && std::strstr(e.what(), "no CPU fallback"))) return 12;
     }
     try {
         auto trace = lvba::damping_iter_hip(x, vh);

@@ -168,7 +168,7 @@ def test_cpp_adapter_runs_on_the_gpu(tmp_path):
                            "-L", libdir, "-llvba_hip", f"-Wl,-rpath,{libdir}"])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "voxel map on the GPU" in out.stdout and "refined on the GPU" in out.stdout
+    assert "voxel map on the GPU" in out.stdout and "refined on the GPU" in out.stdout and "cameras refined on the GPU" in out.stdout
 
 
 def test_four_million_points_bit_identical_and_deterministic(pkg, synth):

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Round-2 evidence run: (1) default bench.py, (2) rocprofv3 --kernel-trace --stats of the headline leg alone and of the full
+# default command, (3) the two PMC passes (FETCH_SIZE / WRITE_SIZE) of the headline leg -> traffic json.  Only summaries return.
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_r02; rm -rf $O; mkdir -p $O
+export TMPDIR=/tmp
+cd $R
+python bench.py > $O/bench_default.json 2> $O/bench_default.err
+cd /tmp
+rocprofv3 --kernel-trace --stats -d /tmp/pb1 -o stats -- python $R/bench.py --no-cpu-baseline --no-visual --no-front-end > $O/bench_headline_under_rocprof.json 2>&1
+python $R/tools/rocpd_stats.py /tmp/pb1/stats_results.db $O/headline_kernel_stats.csv > /dev/null
+rocprofv3 --kernel-trace --stats -d /tmp/pb2 -o stats -- python $R/bench.py --no-cpu-baseline > $O/bench_full_under_rocprof.json 2>&1
+python $R/tools/rocpd_stats.py /tmp/pb2/stats_results.db $O/full_kernel_stats.csv > /dev/null
+bash $R/tools/gpu_pmc2.sh > $O/pmc.log 2>&1
+cp $R/gpurun_out/pmc/pmc_FETCH_SIZE.csv $R/gpurun_out/pmc/pmc_WRITE_SIZE.csv $R/gpurun_out/pmc/traffic.json $O/ 2>/dev/null
+head -30 $O/headline_kernel_stats.csv | cut -c1-150
+cat $O/traffic.json | head -5
