@@ -16,7 +16,7 @@ SYMBOLS = [
     "lvba_balm_eval", "lvba_balm_solve", "lvba_balm_refine", "lvba_balm_lm_begin", "lvba_balm_lm_step",
     "lvba_balm_lm_end", "lvba_balm_set_profiling", "lvba_balm_get_profile", "lvba_balm_get_ordering",
     "lvba_dist_unique_id", "lvba_balm_dist_init", "lvba_dist_host_unique_id",
-    "lvba_visual_default_opts", "lvba_visual_create", "lvba_visual_destroy", "lvba_visual_cost", "lvba_visual_linearize", "lvba_visual_info",
+    "lvba_visual_default_opts", "lvba_visual_create", "lvba_visual_destroy", "lvba_visual_cost", "lvba_visual_linearize", "lvba_visual_info", "lvba_visual_dist_init",
     "lvba_visual_refine",
     "lvba_voxel_default_opts", "lvba_voxmap_build", "lvba_voxmap_destroy", "lvba_voxmap_info", "lvba_voxmap_export",
     "lvba_voxmap_to_balm", "lvba_voxmap_find_planes", "lvba_scans_create", "lvba_scans_destroy", "lvba_voxmap_build_scans",
@@ -183,6 +183,7 @@ def load():
     lib.lvba_visual_destroy.argtypes = [H]
     lib.lvba_visual_cost.argtypes = [H, f64p, f64p, f64p, C.POINTER(C.c_double)]
     lib.lvba_visual_info.argtypes = [H, C.POINTER(BalmInfo)]
+    lib.lvba_visual_dist_init.argtypes = [H, C.c_int32, C.c_int32, C.c_char_p]
     lib.lvba_visual_linearize.argtypes = [H, f64p, f64p, f64p, C.c_double, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
     lib.lvba_visual_refine.argtypes = [H, f64p, f64p, f64p, C.POINTER(VisualOpts), C.POINTER(VisualTrace), C.c_int32,
                                        C.POINTER(C.c_int32), C.POINTER(C.c_int32)]

@@ -65,6 +65,10 @@ struct VisDev {
     const int64_t *csc_off;
     const int32_t *csc_f, *group_of_pos, *pos_of;
     double *Y, *part;              // [O][18], [M*S][40]
+    // track shards over several ranks (cameras replicated): per-camera sums that need the other ranks' tracks before they are
+    // used -- camsum [12 M] = diag(Jc^T Jc) | Jc^T r (LM diagonal, gradient max), colsum [6 M] (Jacobi scaling)
+    int32_t dist, count_cams;      // dist: 1 when sharded; count_cams: this rank counts the (replicated) cameras in the step norms
+    double *camsum, *colsum;
 };
 
 // Working matrix of the damped system, lower triangle, column-major with leading dimension ld:
@@ -95,7 +99,11 @@ void launch_export_poses(const double *in, const int *perm, int n_poses, double 
 // visual_kernels.hip
 void vis_launch_residuals(const VisDev &d, bool jac, const double *qc, const double *tc, const double *Xp, double *part,
                           double *cost_out, hipStream_t s);
-void vis_launch_colnorms(const VisDev &d, hipStream_t s);
+void vis_launch_colnorms(const VisDev &d, hipStream_t s);          // single rank: sums + scaling in one go
+void vis_launch_colsums(const VisDev &d, hipStream_t s);           // sharded: landmark scaling + per-camera column sums -> colsum
+void vis_launch_colnorm_finish(const VisDev &d, hipStream_t s);    //          (after the all-reduce of colsum) camera scaling
+void vis_launch_cam_finish(const VisDev &d, double radius, double min_diag, double max_diag, double *Hblk, unsigned long long *gmax,
+                           hipStream_t s);                         // sharded, after the all-reduces: LM diagonal, gradient max
 void vis_launch_reduced_system(const VisDev &d, const PairDev &pd, double radius, double min_diag, double max_diag, double *Hblk,
                                int64_t hblk_doubles, double *g, unsigned long long *gmax, bool zero_first, hipStream_t s);
 void vis_launch_back(const VisDev &d, const double *step_c, double *part, double *model_out, hipStream_t s);

@@ -36,6 +36,7 @@ struct lvba_visual_s {
     double *d_blkpart = nullptr;   // per-workgroup partials of the scalar reductions
     double *d_scal = nullptr;      // [0]=cost(x) [1]=cost(cand) [2]=model change [3]=|step|^2 [4]=|x|^2
     unsigned long long *d_gmax = nullptr;
+    double *d_camsum = nullptr, *d_colsum = nullptr; // sharded runs: per-camera sums awaiting the other ranks' tracks
     double *d_out = nullptr;       // export staging
     double *h_pin = nullptr;
     std::vector<double> hq, ht, hX; // host staging in solver order
@@ -51,6 +52,7 @@ struct lvba_visual_s {
         d.Lp = d_Lp; d.zp = d_zp; d.step_p = d_step_p;
         d.csc_off = bs.d_csc_off; d.csc_f = bs.d_csc_f; d.group_of_pos = bs.d_group_of_pos; d.pos_of = bs.d_pos_of;
         d.Y = bs.d_Y; d.part = d_part;
+        d.dist = bs.distributed() ? 1 : 0; d.count_cams = bs.rank == 0 ? 1 : 0; d.camsum = d_camsum; d.colsum = d_colsum;
         return d;
     }
 };
@@ -70,7 +72,7 @@ extern "C" int32_t lvba_visual_destroy(lvba_visual_t h)
     if (h->bs.stream) hipStreamSynchronize(h->bs.stream);
     void *ptrs[] = {h->d_off, h->d_cam, h->d_track_of_obs, h->d_uv, h->d_plane, h->d_Jc, h->d_Jp, h->d_r, h->d_rpl, h->d_Jpl,
                     h->d_sc_cam, h->d_sc_pt, h->d_Lp, h->d_zp, h->d_step_p, h->d_part, h->d_q, h->d_t, h->d_X, h->d_q2,
-                    h->d_t2, h->d_X2, h->d_blkpart, h->d_scal, h->d_gmax, h->d_out};
+                    h->d_t2, h->d_X2, h->d_blkpart, h->d_scal, h->d_gmax, h->d_out, h->d_camsum, h->d_colsum};
     for (void *p : ptrs)
         if (p) lvba::DevicePool::get().free(p);
     if (h->h_pin) hipHostFree(h->h_pin);
@@ -146,6 +148,8 @@ extern "C" int32_t lvba_visual_create(int32_t n_cams, int64_t n_tracks, const in
     CTRY(bs_dmalloc(bs, &h->d_scal, 16));
     CTRY(bs_dmalloc(bs, &h->d_gmax, 2));
     CTRY(bs_dmalloc(bs, &h->d_out, 36 * (int64_t)M + 16));
+    CTRY(bs_dmalloc(bs, &h->d_camsum, 12 * (int64_t)M));
+    CTRY(bs_dmalloc(bs, &h->d_colsum, 6 * (int64_t)M));
     CHIP(hipHostMalloc((void **)&h->h_pin, 16 * sizeof(double), hipHostMallocDefault));
 #undef CTRY
 #undef CHIP
@@ -208,6 +212,43 @@ static int32_t export_state(lvba_visual_s *h, double *q, double *t, double *X)
     return LVBA_OK;
 }
 
+// ---- the steps of a linearisation / an iteration that need the other ranks' track shards (no-ops on one rank) -------------
+static int32_t enqueue_colnorms(lvba_visual_s *h)
+{
+    BlockSys &bs = h->bs;
+    const VisDev d = h->dev();
+    if (!bs.distributed()) { vis_launch_colnorms(d, bs.stream); return LVBA_OK; }
+    vis_launch_colsums(d, bs.stream);
+    TRY(bs_allreduce(bs, h->d_colsum, 6 * (size_t)h->M));
+    vis_launch_colnorm_finish(d, bs.stream);
+    return LVBA_OK;
+}
+static int32_t enqueue_reduced_system(lvba_visual_s *h, double radius, const lvba_visual_opts &o)
+{
+    BlockSys &bs = h->bs;
+    const VisDev d = h->dev();
+    vis_launch_reduced_system(d, bs.pair_dev(), radius, o.min_lm_diagonal, o.max_lm_diagonal, bs.Hblk(), bs.hblk_doubles, bs.g(),
+                              h->d_gmax, bs.distributed(), bs.stream);
+    if (!bs.distributed()) return LVBA_OK;
+    TRY(bs_allreduce_hg(bs));                                   // [S blocks | reduced rhs]: sums over the track shards
+    TRY(bs_allreduce(bs, h->d_camsum, 12 * (size_t)h->M));      // diag(Jc^T Jc), Jc^T r
+    vis_launch_cam_finish(d, radius, o.min_lm_diagonal, o.max_lm_diagonal, bs.Hblk(), h->d_gmax, bs.stream);
+    TRY(bs_comm_allreduce(bs, h->d_gmax, 1, ncclInt64, ncclMax)); // bit patterns of non-negative doubles order like integers
+    return LVBA_OK;
+}
+static int32_t allreduce_scalars(lvba_visual_s *h, int first, int count)
+{
+    if (!h->bs.distributed()) return LVBA_OK;
+    return bs_allreduce(h->bs, h->d_scal + first, (size_t)count);
+}
+
+extern "C" int32_t lvba_visual_dist_init(lvba_visual_t h, int32_t n_ranks, int32_t rank, const char uid[128])
+{
+    if (!h || !uid) return fail(LVBA_ERR_ARG, "NULL argument");
+    if (h->finalized) return fail(LVBA_ERR_STATE, "dist_init must precede the first cost/linearize/refine call");
+    return bs_dist_init(h->bs, n_ranks, rank, uid, nullptr);
+}
+
 extern "C" int32_t lvba_visual_cost(lvba_visual_t h, const double *q, const double *t, const double *X, double *cost)
 {
     if (!h || !q || !t || !X || !cost) return fail(LVBA_ERR_ARG, "NULL argument");
@@ -216,6 +257,7 @@ extern "C" int32_t lvba_visual_cost(lvba_visual_t h, const double *q, const doub
     HIPCHK(hipSetDevice(bs.device));
     TRY(import_state(h, q, t, X));
     vis_launch_residuals(h->dev(), false, h->d_q, h->d_t, h->d_X, h->d_blkpart, h->d_scal, bs.stream);
+    TRY(allreduce_scalars(h, 0, 1));
     HIPCHK(hipMemcpyAsync(h->h_pin, h->d_scal, sizeof(double), hipMemcpyDeviceToHost, bs.stream));
     HIPCHK(hipStreamSynchronize(bs.stream));
     HIPCHK(hipGetLastError());
@@ -247,9 +289,9 @@ extern "C" int32_t lvba_visual_linearize(lvba_visual_t h, const double *q, const
     lvba_visual_default_opts(&o);
     const VisDev d = h->dev();
     vis_launch_residuals(d, true, h->d_q, h->d_t, h->d_X, h->d_blkpart, h->d_scal, bs.stream);
-    vis_launch_colnorms(d, bs.stream);
-    vis_launch_reduced_system(d, bs.pair_dev(), radius, o.min_lm_diagonal, o.max_lm_diagonal, bs.Hblk(), bs.hblk_doubles, bs.g(),
-                              h->d_gmax, false, bs.stream);
+    TRY(allreduce_scalars(h, 0, 1));
+    TRY(enqueue_colnorms(h));
+    TRY(enqueue_reduced_system(h, radius, o));
     const int64_t n = 6 * (int64_t)h->M;
     DevBuf dS(bs.stream); // freed on every path, error returns included
     if (S) {
@@ -291,7 +333,8 @@ extern "C" int32_t lvba_visual_refine(lvba_visual_t h, double *q, double *t, dou
     VisDev d = h->dev();
     // iteration 0: evaluate, fix the Jacobi scaling
     vis_launch_residuals(d, true, h->d_q, h->d_t, h->d_X, h->d_blkpart, h->d_scal, bs.stream);
-    vis_launch_colnorms(d, bs.stream);
+    TRY(allreduce_scalars(h, 0, 1));
+    TRY(enqueue_colnorms(h));
     HIPCHK(hipMemcpyAsync(h->h_pin, h->d_scal, sizeof(double), hipMemcpyDeviceToHost, bs.stream));
     HIPCHK(hipStreamSynchronize(bs.stream));
     double cost = 0.5 * h->h_pin[0];
@@ -301,12 +344,12 @@ extern "C" int32_t lvba_visual_refine(lvba_visual_t h, double *q, double *t, dou
     if (!isfinite(cost)) { term = LVBA_TERM_FAILURE; rc = fail(LVBA_NUM_NONFINITE, "non-finite initial cost"); }
     for (int it = 1; rc == LVBA_OK; ++it) {
         // linearised system at the current point (its gradient norm belongs to the row of the previous iteration)
-        vis_launch_reduced_system(d, bs.pair_dev(), radius, o.min_lm_diagonal, o.max_lm_diagonal, bs.Hblk(), bs.hblk_doubles,
-                                  bs.g(), h->d_gmax, false, bs.stream);
+        TRY(enqueue_reduced_system(h, radius, o));
         TRY(bs_enqueue_solve(bs, 0.0));
         vis_launch_back(d, bs.d_dx, h->d_blkpart, h->d_scal + 2, bs.stream);
         vis_launch_apply(d, bs.d_dx, h->d_q, h->d_t, h->d_X, h->d_q2, h->d_t2, h->d_X2, h->d_blkpart, h->d_scal + 3, bs.stream);
         vis_launch_residuals(d, false, h->d_q2, h->d_t2, h->d_X2, h->d_blkpart, h->d_scal + 1, bs.stream);
+        TRY(allreduce_scalars(h, 1, 4)); // candidate cost, model cost change, |step|^2, |x|^2: sums over the track shards
         HIPCHK(hipMemcpyAsync(h->h_pin, h->d_scal, 5 * sizeof(double), hipMemcpyDeviceToHost, bs.stream));
         HIPCHK(hipMemcpyAsync(h->h_pin + 8, h->d_gmax, sizeof(unsigned long long), hipMemcpyDeviceToHost, bs.stream));
         HIPCHK(hipMemcpyAsync(h->h_pin + 9, bs.d_status, sizeof(int), hipMemcpyDeviceToHost, bs.stream));

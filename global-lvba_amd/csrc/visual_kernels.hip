@@ -112,6 +112,26 @@ __global__ void vis_colnorm_cam_kernel(VisDev d)
     for (int e = 0; e < 6; ++e) d.sc_cam[6 * I + e] = 1.0 / (1.0 + sqrt(s[e]));
 }
 
+// sharded form: the sums of squares alone (all-reduced over the ranks' track shards before the scaling is taken)
+__global__ void vis_colsum_cam_kernel(VisDev d)
+{
+    const int64_t I = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (I >= d.M) return;
+    double s[6] = {0, 0, 0, 0, 0, 0};
+    for (int64_t t = d.csc_off[I]; t < d.csc_off[I + 1]; ++t) {
+        const int64_t o = d.csc_f[t];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) s[e] += d.Jc[12 * o + e] * d.Jc[12 * o + e] + d.Jc[12 * o + 6 + e] * d.Jc[12 * o + 6 + e];
+    }
+#pragma unroll
+    for (int e = 0; e < 6; ++e) d.colsum[6 * I + e] = s[e];
+}
+__global__ void vis_colnorm_cam_finish_kernel(VisDev d)
+{
+    const int64_t a = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (a < 6 * (int64_t)d.M) d.sc_cam[a] = 1.0 / (1.0 + sqrt(d.colsum[a]));
+}
+
 // lane = landmark: C = sum Jp^T Jp (+ plane) in the scaled variables, LM diagonal D^2 = clamp(diag C)/radius,
 // Cholesky of C + D^2, z = L^-1 g.  gmax: max |unscaled gradient entry| (bit pattern of a non-negative double).
 __global__ void vis_point_kernel(VisDev d, double radius, double min_diag, double max_diag, unsigned long long *gmax)
@@ -235,13 +255,39 @@ __global__ void vis_cam_reduce_kernel(VisDev d, double radius, double min_diag, 
 #pragma unroll
         for (int rr = c; rr < 6; ++rr) {
             double v = acc[p++];
-            if (rr == c) v += fmin(fmax(acc[27 + c], min_diag), max_diag) / radius;
+            // sharded: diag(Jc^T Jc) is only this rank's part -- the LM diagonal is added after the all-reduce (vis_cam_finish_kernel)
+            if (rr == c && !d.dist) v += fmin(fmax(acc[27 + c], min_diag), max_diag) / radius;
             hp[c * 6 + rr] = v;
         }
 #pragma unroll
     for (int e = 0; e < 6; ++e) {
         g[6 * I + e] = acc[21 + e];
         gm = fmax(gm, fabs(acc[33 + e] / d.sc_cam[6 * I + e]));
+    }
+    if (d.dist) {
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+            d.camsum[6 * I + e] = acc[27 + e];
+            d.camsum[6 * (int64_t)d.M + 6 * I + e] = acc[33 + e];
+        }
+        return;
+    }
+    atomicMax(gmax, (unsigned long long)__double_as_longlong(gm));
+}
+
+// sharded, after [H | g] and camsum have been all-reduced: the LM diagonal on the diagonal blocks and the cameras' part of
+// the gradient max (the landmarks' part is local to their rank; gmax itself is max-reduced afterwards)
+__global__ void vis_cam_finish_kernel(VisDev d, double radius, double min_diag, double max_diag, double *__restrict__ Hblk,
+                                      unsigned long long *gmax)
+{
+    const int64_t I = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (I >= d.M) return;
+    double *hp = Hblk + I * (int64_t)(d.band_blocks + 1) * 36;
+    double gm = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        hp[c * 6 + c] += fmin(fmax(d.camsum[6 * I + c], min_diag), max_diag) / radius;
+        gm = fmax(gm, fabs(d.camsum[6 * (int64_t)d.M + 6 * I + c] / d.sc_cam[6 * I + c]));
     }
     atomicMax(gmax, (unsigned long long)__double_as_longlong(gm));
 }
@@ -320,10 +366,12 @@ __global__ __launch_bounds__(256) void vis_apply_kernel(VisDev d, const double *
             for (int e = 0; e < 3; ++e) tc2[3 * gid + e] = t[e];
         } else {
             quat_plus(q, dl, q2);
+            double dc = 0.0, xc = 0.0;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { qc2[4 * gid + e] = q2[e]; dn += (q2[e] - q[e]) * (q2[e] - q[e]); xn += q[e] * q[e]; }
+            for (int e = 0; e < 4; ++e) { qc2[4 * gid + e] = q2[e]; dc += (q2[e] - q[e]) * (q2[e] - q[e]); xc += q[e] * q[e]; }
 #pragma unroll
-            for (int e = 0; e < 3; ++e) { tc2[3 * gid + e] = t[e] + dl[3 + e]; dn += dl[3 + e] * dl[3 + e]; xn += t[e] * t[e]; }
+            for (int e = 0; e < 3; ++e) { tc2[3 * gid + e] = t[e] + dl[3 + e]; dc += dl[3 + e] * dl[3 + e]; xc += t[e] * t[e]; }
+            if (d.count_cams) { dn = dc; xn = xc; } // the cameras are replicated over the ranks: one of them counts their norms
         }
     } else if (gid < d.M + d.Ta) {
         const int64_t i = gid - d.M;
@@ -375,6 +423,21 @@ void vis_launch_colnorms(const VisDev &d, hipStream_t s)
 {
     hipLaunchKernelGGL(vis_colnorm_pt_kernel, dim3(nblk(d.Ta, 256)), dim3(256), 0, s, d);
     hipLaunchKernelGGL(vis_colnorm_cam_kernel, dim3(nblk(d.M, 64)), dim3(64), 0, s, d);
+}
+
+void vis_launch_colsums(const VisDev &d, hipStream_t s)
+{
+    hipLaunchKernelGGL(vis_colnorm_pt_kernel, dim3(nblk(d.Ta, 256)), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(vis_colsum_cam_kernel, dim3(nblk(d.M, 64)), dim3(64), 0, s, d);
+}
+void vis_launch_colnorm_finish(const VisDev &d, hipStream_t s)
+{
+    hipLaunchKernelGGL(vis_colnorm_cam_finish_kernel, dim3(nblk(6 * (int64_t)d.M, 256)), dim3(256), 0, s, d);
+}
+void vis_launch_cam_finish(const VisDev &d, double radius, double min_diag, double max_diag, double *Hblk, unsigned long long *gmax,
+                           hipStream_t s)
+{
+    hipLaunchKernelGGL(vis_cam_finish_kernel, dim3(nblk(d.M, 64)), dim3(64), 0, s, d, radius, min_diag, max_diag, Hblk, gmax);
 }
 
 void vis_launch_reduced_system(const VisDev &d, const PairDev &pd, double radius, double min_diag, double max_diag, double *Hblk,

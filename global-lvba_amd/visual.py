@@ -65,6 +65,10 @@ class VisualProblem:
                                                C.byref(c)))
         return S, rhs, c.value
 
+    def dist_init(self, n_ranks, rank, uid):
+        """Track shards over several ranks (lvba_visual_dist_init): this handle holds the rank's own tracks."""
+        L.check(self.lib.lvba_visual_dist_init(self._h, int(n_ranks), int(rank), bytes(uid)))
+
     def linearize_only(self, q, t, X, radius=1e4):
         """The factor kernels of one linearisation (residuals, Jacobians, column norms, Schur products -> reduced system on
         the device) without exporting S / rhs; returns the cost."""

@@ -233,6 +233,14 @@ int32_t lvba_visual_destroy(lvba_visual_t h);
  * system), band_blocks, use_band, hess_bytes, device_bytes. */
 int32_t lvba_visual_info(lvba_visual_t h, lvba_balm_info_t *info);
 
+/* Multi-GPU: landmark tracks are sharded over the ranks (any partition; contiguous ranges as for the voxels), the cameras are
+ * replicated.  Every rank creates its handle from ITS tracks (X, plane, valid and the observation arrays of that shard) and
+ * calls this before the first cost / linearize / refine call.  Per LM iteration the ranks all-reduce the reduced camera system
+ * [S | rhs] (only the blocks of the union pattern), 12 M per-camera sums (the LM diagonal and the gradient test need the
+ * whole diag(Jc^T Jc), Jc^T r) and five scalars; the reduced system is solved on every rank.  All ranks return bitwise the same
+ * cameras and trace; X holds the rank's own landmarks.  uid as for lvba_balm_dist_init. */
+int32_t lvba_visual_dist_init(lvba_visual_t h, int32_t n_ranks, int32_t rank, const char uid[128]);
+
 /* 1/2 sum r^2 over the residuals of the active landmarks at (q [M][4], t [M][3], X [n_tracks][3]). */
 int32_t lvba_visual_cost(lvba_visual_t h, const double *q, const double *t, const double *X, double *cost);
 

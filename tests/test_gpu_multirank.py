@@ -18,6 +18,12 @@ from conftest import make_problem, rel
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture
+def synth():
+    import importlib
+    return importlib.import_module("global-lvba_amd.synth")
+
+
 def _run_ranks(pkg, d, world, packed=True):
     N, off, idx, clu = d["n_poses"], d["voxel_off"], d["pose_idx"], d["clusters"]
     V = len(off) - 1
@@ -105,3 +111,54 @@ def test_rank_with_a_different_band(pkg):
     assert np.array_equal(out[0]["H"], out[1]["H"])
     assert rel(out[0]["H"], H1) <= 1e-12 and rel(out[0]["g"], g1) <= 1e-12
     single.close()
+
+
+@pytest.mark.parametrize("world,n_cams,n_tracks", [(2, 40, 1500), (3, 12, 300)])
+def test_visual_track_shards_agree_with_single_rank(pkg, synth, world, n_cams, n_tracks):
+    """The visual stage with its landmark tracks sharded over ranks (cameras replicated; lvba_visual_dist_init): the reduced
+    camera system, the per-camera sums behind the LM diagonal and the Jacobi scaling, and the scalars of the trust-region loop are
+    all-reduced; every rank must take the same decisions and return bitwise the same cameras, equal to the single-rank solve."""
+    d = synth.make_visual_problem(n_cams, n_tracks, seed=11)
+    off, cam, uv = d["obs_off"], d["obs_cam"], d["obs_uv"]
+    one = pkg.VisualProblem(n_cams, off, cam, uv, d["plane"], d["valid"], d["intr"])
+    c1 = one.cost(d["q"], d["t"], d["X"])
+    S1, rhs1, _ = one.linearize(d["q"], d["t"], d["X"], radius=3.0)
+    (q1, t1, X1), tr1, term1, rc1 = one.refine(d["q"], d["t"], d["X"])
+    one.close()
+    uid = pkg.BalmProblem.host_unique_id()
+    out, err = [None] * world, [None] * world
+
+    def rank_main(r):
+        try:
+            a, b = pkg.shard_range(n_tracks, r, world)
+            vp = pkg.VisualProblem(n_cams, off[a:b + 1], cam[off[a]:off[b]], uv[off[a]:off[b]], d["plane"][a:b], d["valid"][a:b], d["intr"])
+            vp.dist_init(world, r, uid)
+            c = vp.cost(d["q"], d["t"], d["X"][a:b])
+            S, rhs, _ = vp.linearize(d["q"], d["t"], d["X"][a:b], radius=3.0)
+            (q, t, X), tr, term, rc = vp.refine(d["q"], d["t"], d["X"][a:b])
+            out[r] = dict(c=c, S=S, rhs=rhs, q=q, t=t, X=X, tr=tr, term=term, rc=rc, a=a, b=b)
+            vp.close()
+        except Exception as e:
+            err[r] = e
+            raise
+
+    th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join(timeout=300)
+    assert all(e is None for e in err), err
+    assert all(o is not None for o in out), "a rank did not finish (collective mismatch?)"
+    r0 = out[0]
+    for o in out[1:]:
+        assert o["c"] == r0["c"] and np.array_equal(o["S"], r0["S"]) and np.array_equal(o["rhs"], r0["rhs"])
+        assert np.array_equal(o["q"], r0["q"]) and np.array_equal(o["t"], r0["t"]) and o["term"] == r0["term"]
+        assert [row["cost"] for row in o["tr"]] == [row["cost"] for row in r0["tr"]]
+    assert abs(r0["c"] - c1) <= 1e-12 * c1
+    assert rel(r0["S"], S1) <= 1e-11 and rel(r0["rhs"], rhs1) <= 1e-11
+    assert r0["rc"] == rc1 == 0 and r0["term"] == term1 and len(r0["tr"]) == len(tr1)
+    for a_, b_ in zip(r0["tr"], tr1):
+        assert a_["accepted"] == b_["accepted"] and abs(a_["cost"] - b_["cost"]) <= 1e-8 * b_["cost"]
+    assert np.abs(r0["q"] - q1).max() <= 1e-8 and np.abs(r0["t"] - t1).max() <= 1e-8
+    X = np.concatenate([o["X"] for o in out])
+    assert np.abs(X - X1).max() <= 1e-7
