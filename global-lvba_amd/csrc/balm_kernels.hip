@@ -309,6 +309,168 @@ __global__ __launch_bounds__(256) void balm_factor_kernel(BalmDev d, const doubl
     if (tid < 27) d.part[(int64_t)blockIdx.x * 32 + tid] = red[tid] + red[27 + tid] + red[54 + tid] + red[81 + tid];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused form of passes 1 + 2 (round 2): ONE voxel-major pass.  The workgroup that has just merged a chunk's clusters and
+// eigen-decomposed its voxels holds everything factor_derivs needs -- the factors' clusters and poses in registers, the voxel
+// records in LDS -- so the clusters are read once (not once voxel-major and once pose-major), the voxel records never go to
+// memory (the pose-major pass gathered one 128-byte line per factor) and Y is written at the factors' voxel-major positions
+// (the pair lists only need positions; a voxel window's records are then one contiguous range).  What needed the pose-major
+// pass was the sum over a pose's factors without atomics.  Here a workgroup walks a run of consecutive chunks whose factors
+// touch <= 256 poses and keeps a 27-double accumulator per pose in LDS; a chunk's factors add theirs in ROUNDS -- a factor's
+// round is the number of earlier factors of its chunk with the same pose, so within a round every lane owns its accumulator
+// and a plain read-add-write is safe and its order fixed.  The per-super-chunk sums are added up per pose by
+// balm_fused_reduce_kernel in super-chunk order: bitwise reproducible like the rest.
+// LDS: T 20 KB + accumulators 54 KB + Y staging 39 KB + voxel records 13 KB: one workgroup per CU; the arithmetic of a chunk
+// (~2 400 cycles per wavefront) is what is left to hide latency behind, so the next chunk's clusters are already in flight.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void balm_fused_kernel(BalmDev d, FusedDev fd, const double *__restrict__ poses,
+                                                         double *__restrict__ chunk_cost)
+{
+    __shared__ double T[10 * LVBA_CF];
+    __shared__ double acc[27 * 256];
+    __shared__ double Ys[4 * 64 * 19];
+    __shared__ double vrs[13 * LVBA_CV];
+    __shared__ int lvoff[LVBA_CV + 1];
+    __shared__ unsigned char lvox[LVBA_CF];
+    __shared__ double red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t sc = blockIdx.x;
+    const int64_t c0 = fd.super_c0[sc], c1 = fd.super_c0[sc + 1];
+#pragma unroll
+    for (int e = 0; e < 27; ++e) acc[e * 256 + tid] = 0.0;
+    // this lane's factor of the first chunk: cluster + pose loads issued before anything waits
+    double c[10], x[12];
+    auto load_factor = [&](int64_t ch, double (&cc)[10], double (&xx)[12]) {
+        const int64_t v0 = d.chunk_v0[ch], v1 = d.chunk_v0[ch + 1];
+        const int64_t f0 = d.voff[v0];
+        const int nf = (int)(d.voff[v1] - f0);
+        if (tid < nf) {
+            const int64_t f = f0 + tid;
+#pragma unroll
+            for (int e = 0; e < 10; ++e) cc[e] = d.clu[(int64_t)e * d.F + f];
+            const double2 *xp = reinterpret_cast<const double2 *>(poses + 12 * (int64_t)d.pidx[f]);
+#pragma unroll
+            for (int e = 0; e < 6; ++e) {
+                const double2 v2 = xp[e];
+                xx[2 * e] = v2.x; xx[2 * e + 1] = v2.y;
+            }
+        }
+    };
+    load_factor(c0, c, x);
+    for (int64_t ch = c0; ch < c1; ++ch) {
+        const int64_t v0 = d.chunk_v0[ch], v1 = d.chunk_v0[ch + 1];
+        const int64_t f0 = d.voff[v0];
+        const int nf = (int)(d.voff[v1] - f0), nv = (int)(v1 - v0);
+        __syncthreads(); // the previous chunk is done with T, lvoff, lvox, vrs, Ys
+        if (tid <= nv) lvoff[tid] = (int)(d.voff[v0 + tid] - f0);
+        if (tid < nf) {
+            double t[10];
+            transform_cluster(c, x, x + 9, t);
+#pragma unroll
+            for (int e = 0; e < 10; ++e) T[e * LVBA_CF + tid] = t[e];
+        }
+        // the next chunk's loads go out now (their registers are only read after this chunk's arithmetic)
+        double cn[10], xn[12];
+        if (ch + 1 < c1) load_factor(ch + 1, cn, xn);
+        __syncthreads();
+        double lam0 = 0.0;
+        if (tid < nv) {
+            double S[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int f = lvoff[tid]; f < lvoff[tid + 1]; ++f) {
+                lvox[f] = (unsigned char)tid;
+#pragma unroll
+                for (int e = 0; e < 10; ++e) S[e] += T[e * LVBA_CF + f];
+            }
+            VoxRec vr;
+            lam0 = voxel_finish(S, vr);
+            double *o = vrs + 13 * tid;
+            o[0] = vr.NN;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                o[1 + e] = vr.vb[e];
+                o[4 + e] = vr.u0[e];
+                o[7 + e] = vr.s1[e];
+                o[10 + e] = vr.s2[e];
+            }
+        }
+        __syncthreads();
+        double Y[18], D[21], gi[6];
+        if (tid < nf) {
+            const double *o = vrs + 13 * (int)lvox[tid];
+            VoxRec vr;
+            vr.NN = o[0];
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                vr.vb[e] = o[1 + e];
+                vr.u0[e] = o[4 + e];
+                vr.s1[e] = o[7 + e];
+                vr.s2[e] = o[10 + e];
+            }
+            factor_derivs(c, x, x + 9, vr, Y, D, gi);
+        }
+        // Y leaves through LDS as in balm_factor_kernel: the wavefront's 64 records go out as 9 contiguous 1-KB stores
+        {
+            double *ys = Ys + wv * (64 * 19);
+            if (tid < nf) {
+#pragma unroll
+                for (int e = 0; e < 18; ++e) ys[lane * 19 + e] = Y[e];
+            }
+            const int nrec = nf - 64 * wv < 64 ? nf - 64 * wv : 64; // may be <= 0
+            double2 *yo = reinterpret_cast<double2 *>(d.Y + 18 * (f0 + 64 * wv));
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                const int fl = 2 * (lane + 64 * r); // flat double index inside the wavefront's batch
+                const int rec = fl / 18, el = fl - 18 * rec;
+                if (rec < nrec) yo[lane + 64 * r] = make_double2(ys[rec * 19 + el], ys[rec * 19 + el + 1]);
+            }
+        }
+        // per-pose sums, round by round (a wavefront's LDS accesses are in order: the store above reads ys of its own lanes only)
+        const int nr = fd.n_rounds[ch];
+        int my_round = -1, my_slot = 0;
+        if (tid < nf) { my_round = fd.round[f0 + tid]; my_slot = fd.slot[f0 + tid]; }
+        for (int r = 0; r < nr; ++r) {
+            if (my_round == r) {
+#pragma unroll
+                for (int e = 0; e < 21; ++e) acc[e * 256 + my_slot] += D[e];
+#pragma unroll
+                for (int e = 0; e < 6; ++e) acc[(21 + e) * 256 + my_slot] += gi[e];
+            }
+            __syncthreads();
+        }
+        const double tot = block_sum_256(lam0, red);
+        if (tid == 0) chunk_cost[ch] = tot;
+#pragma unroll
+        for (int e = 0; e < 10; ++e) c[e] = cn[e];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) x[e] = xn[e];
+    }
+    __syncthreads();
+    if (tid < fd.n_slots[sc]) {
+        double *o = fd.part + (sc * 256 + tid) * 32;
+#pragma unroll
+        for (int e = 0; e < 27; ++e) o[e] = acc[e * 256 + tid];
+    }
+}
+
+// per pose: the super-chunks' partial sums in super-chunk order -> diagonal block (lower triangle) and gradient
+__global__ void balm_fused_reduce_kernel(BalmDev d, FusedDev fd, double *__restrict__ Hblk, double *__restrict__ g)
+{
+    const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t I = gid >> 5;
+    const int e = (int)(gid & 31);
+    if (I >= d.n_poses || e >= 27) return;
+    double s = 0.0;
+    for (int64_t q = fd.pp_off[I]; q < fd.pp_off[I + 1]; ++q) s += fd.part[fd.pp_idx[q] * 32 + e];
+    if (e >= 21) {
+        g[6 * I + (e - 21)] = s;
+    } else {
+        int c = 0, base = 0;
+        while (e >= base + (6 - c)) { base += 6 - c; ++c; }
+        const int r = c + (e - base);
+        Hblk[I * (int64_t)(d.band_blocks + 1) * 36 + c * 6 + r] = s;
+    }
+}
+
 // sum the S slice partials of every pose -> diagonal block (lower triangle) and gradient
 __global__ void balm_diag_reduce_kernel(BalmDev d, double *__restrict__ Hblk, double *__restrict__ g)
 {
@@ -747,6 +909,18 @@ void launch_eval(const BalmDev &d, const PairDev &pd, const double *poses, doubl
     hipLaunchKernelGGL(balm_voxel_kernel, dim3((unsigned)d.n_chunks), dim3(LVBA_CF), 0, s, d, poses, chunk_cost);
     hipLaunchKernelGGL(balm_factor_kernel, dim3((unsigned)(d.n_poses * d.S)), dim3(256), 0, s, d, poses);
     hipLaunchKernelGGL(balm_diag_reduce_kernel, dim3((unsigned)((32 * (int64_t)d.n_poses + 255) / 256)), dim3(256), 0, s, d, Hblk, g);
+    launch_pairs(pd, Hblk, s);
+    if (k1) hipEventRecord(k1, s);
+    hipLaunchKernelGGL(reduce_chunks_kernel, dim3(1), dim3(1024), 0, s, chunk_cost, d.n_chunks, out);
+}
+
+void launch_eval_fused(const BalmDev &d, const FusedDev &fd, const PairDev &pd, const double *poses, double *Hblk, int64_t hblk_doubles,
+                       double *g, double *chunk_cost, double *out, bool zero_first, hipStream_t s, hipEvent_t k0, hipEvent_t k1)
+{
+    if (zero_first) hipMemsetAsync(Hblk, 0, (size_t)hblk_doubles * sizeof(double), s);
+    if (k0) hipEventRecord(k0, s);
+    hipLaunchKernelGGL(balm_fused_kernel, dim3((unsigned)fd.n_super), dim3(256), 0, s, d, fd, poses, chunk_cost);
+    hipLaunchKernelGGL(balm_fused_reduce_kernel, dim3((unsigned)((32 * (int64_t)d.n_poses + 255) / 256)), dim3(256), 0, s, d, fd, Hblk, g);
     launch_pairs(pd, Hblk, s);
     if (k1) hipEventRecord(k1, s);
     hipLaunchKernelGGL(reduce_chunks_kernel, dim3(1), dim3(1024), 0, s, chunk_cost, d.n_chunks, out);

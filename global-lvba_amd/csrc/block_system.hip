@@ -370,10 +370,23 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
         int64_t window_groups = 0;
         if (18 * 8 * F > ((int64_t)24 << 20)) window_groups = std::max<int64_t>(256, (((int64_t)6 << 20) / 144) * G / std::max<int64_t>(F, 1));
         if (const char *e = getenv("LVBA_PAIR_WINDOW")) window_groups = atoll(e);
-        TRY(pair_lists_build(bs.stream, G, voff, F, d_blk_of.as<int32_t>(), bs.d_pos_of, N, (int32_t)Bb1, Q, window_groups, bs.d_pairs,
+        TRY(pair_lists_build(bs.stream, G, voff, F, d_blk_of.as<int32_t>(), bs.y_voxel_major ? nullptr : bs.d_pos_of, N, (int32_t)Bb1, Q, window_groups, bs.d_pairs,
                              blk_slot, blk_off));
         BS_MARK("pairs");
         bs.nnzb = (int64_t)blk_slot.size();
+        if (window_groups > 0) {
+            // windows only pay when consecutive voxels are seen from neighbouring poses (a window then touches a band of the block
+            // matrix).  With the voxels in an order unrelated to the poses every window touches every block: one partial block per
+            // pair in the limit.  Then the plain block-major lists are the better ones.
+            std::vector<int64_t> u(blk_slot);
+            std::sort(u.begin(), u.end());
+            const int64_t distinct = (int64_t)(std::unique(u.begin(), u.end()) - u.begin());
+            if ((int64_t)blk_slot.size() > 24 * std::max<int64_t>(distinct, 1)) {
+                window_groups = 0;
+                TRY(pair_lists_build(bs.stream, G, voff, F, d_blk_of.as<int32_t>(), bs.y_voxel_major ? nullptr : bs.d_pos_of, N, (int32_t)Bb1, Q, 0,
+                                     bs.d_pairs, blk_slot, blk_off));
+            }
+        }
         { // distinct blocks, not runs
             std::vector<int64_t> u(blk_slot);
             std::sort(u.begin(), u.end());

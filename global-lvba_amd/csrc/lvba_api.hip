@@ -25,9 +25,16 @@ struct lvba_balm_s {
     int32_t N = 0;
     int64_t V = 0, F = 0, Q = 0, n_chunks = 0, Vglobal = 0;
     // host copies kept until finalize()
-    std::vector<int64_t> h_voff;
+    std::vector<int64_t> h_voff, h_chunk_v0;
     std::vector<int32_t> h_pidx;
     bool finalized = false;
+    // fused voxel-major evaluation (balm_fused_kernel): tables built at finalize
+    bool fused = false;
+    int64_t n_super = 0;
+    int64_t *d_super_c0 = nullptr, *d_pp_off = nullptr, *d_pp_idx = nullptr;
+    int32_t *d_n_slots = nullptr;
+    uint8_t *d_slot = nullptr, *d_round = nullptr, *d_n_rounds = nullptr;
+    double *d_fpart = nullptr;
     // device data (voxel-major)
     int64_t *d_voff = nullptr, *d_chunk_v0 = nullptr;
     int32_t *d_pidx = nullptr;
@@ -58,6 +65,13 @@ struct lvba_balm_s {
         d.S = bs.S; d.csc_off = bs.d_csc_off; d.clu_csc = d_clu_csc; d.vox_of_pos = bs.d_group_of_pos; d.vrec = d_vrec;
         d.Y = bs.d_Y; d.part = d_part;
         return d;
+    }
+    FusedDev fdev() const
+    {
+        FusedDev f;
+        f.n_super = n_super; f.super_c0 = d_super_c0; f.n_slots = d_n_slots; f.slot = d_slot; f.round = d_round;
+        f.n_rounds = d_n_rounds; f.part = d_fpart; f.pp_off = d_pp_off; f.pp_idx = d_pp_idx;
+        return f;
     }
 };
 
@@ -133,6 +147,14 @@ static int32_t balm_create_impl(int32_t n_poses, int64_t n_voxels, const int64_t
     }
     h->n_chunks = (int64_t)chunk_v0.size() - 1;
     h->Q = Q;
+    { // the fused evaluation (opt-in, LVBA_FUSED=1: measured slower than the two passes) needs every chunk to
+      // fit a workgroup's lanes (no voxel with more than LVBA_CF observers)
+        const char *e = getenv("LVBA_FUSED");
+        bool ok = e && !strcmp(e, "1");
+        for (int64_t a = 0; a < n_voxels && ok; ++a) ok = voxel_off[a + 1] - voxel_off[a] <= LVBA_CF;
+        h->fused = ok;
+        h->h_chunk_v0 = chunk_v0;
+    }
     h->h_pidx.assign(pose_idx, pose_idx + F);
     for (int64_t f = 0; f < F; ++f)
         if (pose_idx[f] < 0 || pose_idx[f] >= n_poses) { delete h; return fail(LVBA_ERR_ARG, "pose_idx[%lld] = %d out of range", (long long)f, pose_idx[f]); }
@@ -177,7 +199,8 @@ extern "C" int32_t lvba_balm_destroy(lvba_balm_t h)
     hipSetDevice(h->bs.device);
     if (h->bs.stream) hipStreamSynchronize(h->bs.stream);
     void *ptrs[] = {h->d_voff, h->d_chunk_v0, h->d_pidx, h->d_clu, h->d_chunk_cost, h->d_clu_csc, h->d_vrec, h->d_part,
-                    h->d_pose_in, h->d_pose_cur, h->d_pose_trial, h->d_out, h->d_scal2};
+                    h->d_pose_in, h->d_pose_cur, h->d_pose_trial, h->d_out, h->d_scal2, h->d_super_c0, h->d_pp_off, h->d_pp_idx,
+                    h->d_n_slots, h->d_slot, h->d_round, h->d_n_rounds, h->d_fpart};
     for (void *p : ptrs)
         if (p) lvba::DevicePool::get().free(p);
     if (h->h_pin) hipHostFree(h->h_pin);
@@ -200,22 +223,93 @@ extern "C" int32_t lvba_balm_configure(lvba_balm_t h, int32_t ordering, double b
     return LVBA_OK;
 }
 
+// Super-chunks, pose slots and add rounds of the fused evaluation (balm_fused_kernel).  p [F]: solver-order pose per factor.
+static int32_t build_fused_tables(lvba_balm_s *h, const std::vector<int32_t> &p)
+{
+    BlockSys &bs = h->bs;
+    const int32_t N = h->N;
+    const int64_t F = h->F, nch = h->n_chunks;
+    const std::vector<int64_t> &cv = h->h_chunk_v0, &voff = h->h_voff;
+    // enough super-chunks to fill the chip a few times over (one workgroup per CU is resident), few enough to amortise the flush
+    const int64_t cap = std::max<int64_t>(1, (nch + 1023) / 1024);
+    std::vector<int64_t> super_c0(1, 0), pp_cnt((size_t)N + 1, 0);
+    std::vector<int32_t> n_slots, stamp((size_t)N, -1), slot_of((size_t)N, 0), seen((size_t)N, -1);
+    std::vector<uint8_t> slot((size_t)F), round((size_t)F), n_rounds((size_t)nch);
+    std::vector<std::pair<int32_t, int64_t>> rows; // (pose, row of `part`)
+    int32_t cur_slots = 0;
+    int64_t cur_chunks = 0, epoch = 0;
+    for (int64_t ch = 0; ch < nch; ++ch) {
+        const int64_t f0 = voff[cv[ch]], f1 = voff[cv[ch + 1]];
+        int32_t fresh = 0; // poses of this chunk the open super-chunk has not seen
+        for (int64_t f = f0; f < f1; ++f)
+            if (stamp[p[f]] != (int32_t)epoch && seen[p[f]] != (int32_t)ch) { seen[p[f]] = (int32_t)ch; ++fresh; }
+        if (cur_chunks > 0 && (cur_slots + fresh > 256 || cur_chunks == cap)) { // close the open super-chunk
+            super_c0.push_back(ch);
+            n_slots.push_back(cur_slots);
+            ++epoch; cur_slots = 0; cur_chunks = 0;
+        }
+        uint8_t cnt[256] = {0};
+        int maxr = 0;
+        for (int64_t f = f0; f < f1; ++f) {
+            const int32_t P = p[f];
+            if (stamp[P] != (int32_t)epoch) {
+                stamp[P] = (int32_t)epoch;
+                slot_of[P] = cur_slots++;
+                rows.push_back({P, epoch * 256 + slot_of[P]});
+                pp_cnt[(size_t)P + 1]++;
+            }
+            const int sl = slot_of[P];
+            slot[f] = (uint8_t)sl;
+            round[f] = cnt[sl]++;
+            maxr = std::max(maxr, (int)round[f] + 1);
+        }
+        if (cur_slots > 256) return lvba_fail(LVBA_ERR_STATE, "fused tables: a chunk touches more than 256 poses");
+        n_rounds[ch] = (uint8_t)maxr;
+        ++cur_chunks;
+    }
+    super_c0.push_back(nch);
+    n_slots.push_back(cur_slots);
+    h->n_super = (int64_t)n_slots.size();
+    for (int32_t i = 0; i < N; ++i) pp_cnt[(size_t)i + 1] += pp_cnt[i];
+    std::vector<int64_t> pp_idx(rows.size()), fill(pp_cnt.begin(), pp_cnt.end() - 1);
+    for (const auto &r : rows) pp_idx[(size_t)fill[r.first]++] = r.second; // rows arrive in super-chunk order: so do the sums
+    TRY(bs_dmalloc(bs, &h->d_super_c0, h->n_super + 1));
+    TRY(bs_dmalloc(bs, &h->d_n_slots, h->n_super));
+    TRY(bs_dmalloc(bs, &h->d_slot, F));
+    TRY(bs_dmalloc(bs, &h->d_round, F));
+    TRY(bs_dmalloc(bs, &h->d_n_rounds, nch));
+    TRY(bs_dmalloc(bs, &h->d_fpart, h->n_super * 256 * 32));
+    TRY(bs_dmalloc(bs, &h->d_pp_off, (int64_t)N + 1));
+    TRY(bs_dmalloc(bs, &h->d_pp_idx, (int64_t)pp_idx.size()));
+    HIPCHK(hipMemcpy(h->d_super_c0, super_c0.data(), super_c0.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_n_slots, n_slots.data(), n_slots.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_slot, slot.data(), (size_t)F, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_round, round.data(), (size_t)F, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_n_rounds, n_rounds.data(), (size_t)nch, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_pp_off, pp_cnt.data(), pp_cnt.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    if (!pp_idx.empty()) HIPCHK(hipMemcpy(h->d_pp_idx, pp_idx.data(), pp_idx.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    return LVBA_OK;
+}
+
 static int32_t finalize(lvba_balm_s *h)
 {
     if (h->finalized) return LVBA_OK;
     BlockSys &bs = h->bs;
     HIPCHK(hipSetDevice(bs.device));
     const int N = h->N;
+    bs.y_voxel_major = h->fused;
     TRY(bs_build(bs, N, h->V, h->h_voff.data(), h->h_pidx.data()));
-    { // pose indices of the factors in solver order
-        std::vector<int32_t> p((size_t)h->F);
-        for (int64_t f = 0; f < h->F; ++f) p[f] = bs.iperm[h->h_pidx[f]];
-        HIPCHK(hipMemcpy(h->d_pidx, p.data(), (size_t)h->F * sizeof(int32_t), hipMemcpyHostToDevice));
+    std::vector<int32_t> p((size_t)h->F); // pose indices of the factors in solver order
+    for (int64_t f = 0; f < h->F; ++f) p[f] = bs.iperm[h->h_pidx[f]];
+    HIPCHK(hipMemcpy(h->d_pidx, p.data(), (size_t)h->F * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (h->fused) {
+        TRY(build_fused_tables(h, p));
+    } else {
+        TRY(bs_dmalloc(bs, &h->d_clu_csc, 10 * h->F));
+        TRY(bs_dmalloc(bs, &h->d_vrec, 16 * h->V));
+        TRY(bs_dmalloc(bs, &h->d_part, (int64_t)N * bs.S * 32));
+        launch_gather_csc(h->d_clu, bs.d_csc_f, h->F, h->d_clu_csc, bs.stream);
     }
-    TRY(bs_dmalloc(bs, &h->d_clu_csc, 10 * h->F));
-    TRY(bs_dmalloc(bs, &h->d_vrec, 16 * h->V));
-    TRY(bs_dmalloc(bs, &h->d_part, (int64_t)N * bs.S * 32));
-    launch_gather_csc(h->d_clu, bs.d_csc_f, h->F, h->d_clu_csc, bs.stream);
     TRY(bs_dmalloc(bs, &h->d_pose_in, 12 * (int64_t)N));
     TRY(bs_dmalloc(bs, &h->d_pose_cur, 12 * (int64_t)N));
     TRY(bs_dmalloc(bs, &h->d_pose_trial, 12 * (int64_t)N));
@@ -223,6 +317,7 @@ static int32_t finalize(lvba_balm_s *h)
     TRY(bs_dmalloc(bs, &h->d_scal2, 8));
     HIPCHK(hipStreamSynchronize(bs.stream));
     std::vector<int64_t>().swap(h->h_voff);
+    std::vector<int64_t>().swap(h->h_chunk_v0);
     std::vector<int32_t>().swap(h->h_pidx);
     h->finalized = true;
     return LVBA_OK;
@@ -310,9 +405,14 @@ static int32_t enqueue_eval(lvba_balm_s *h, const double *d_poses)
 {
     BlockSys &bs = h->bs;
     ev_begin(h, EV_EVAL);
-    launch_eval(h->dev(), bs.pair_dev(), d_poses, bs.Hblk(), bs.hblk_doubles, bs.g(), h->d_chunk_cost, bs.scal(),
-                bs.distributed(), bs.stream, h->prof_on ? h->ev[EV_EVALK][0] : nullptr,
-                h->prof_on ? h->ev[EV_EVALK][1] : nullptr);
+    if (h->fused)
+        launch_eval_fused(h->dev(), h->fdev(), bs.pair_dev(), d_poses, bs.Hblk(), bs.hblk_doubles, bs.g(), h->d_chunk_cost, bs.scal(),
+                          bs.distributed(), bs.stream, h->prof_on ? h->ev[EV_EVALK][0] : nullptr,
+                          h->prof_on ? h->ev[EV_EVALK][1] : nullptr);
+    else
+        launch_eval(h->dev(), bs.pair_dev(), d_poses, bs.Hblk(), bs.hblk_doubles, bs.g(), h->d_chunk_cost, bs.scal(),
+                    bs.distributed(), bs.stream, h->prof_on ? h->ev[EV_EVALK][0] : nullptr,
+                    h->prof_on ? h->ev[EV_EVALK][1] : nullptr);
     if (h->prof_on) h->ev_used[EV_EVALK] = true;
     ev_end(h, EV_EVAL);
     if (bs.distributed()) {

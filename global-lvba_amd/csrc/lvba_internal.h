@@ -29,6 +29,20 @@ struct BalmDev {
     double *part;              // [N*S][32] per-workgroup partial sums of (D[21], g[6])
 };
 
+// Tables of the fused voxel-major evaluation (balm_fused_kernel): a workgroup owns a run of consecutive chunks ("super-chunk")
+// whose factors touch at most 256 distinct poses, and keeps one 27-double accumulator (diagonal block + gradient) per pose.
+struct FusedDev {
+    int64_t n_super;
+    const int64_t *super_c0;   // [n_super+1] first chunk of each super-chunk
+    const int32_t *n_slots;    // [n_super] distinct poses of the super-chunk
+    const uint8_t *slot;       // [F] pose slot of every factor inside its super-chunk
+    const uint8_t *round;      // [F] number of earlier factors of the same chunk with the same pose (conflict-free add rounds)
+    const uint8_t *n_rounds;   // [n_chunks] rounds of every chunk
+    double *part;              // [n_super*256][32] per-super-chunk partial sums (27 used)
+    const int64_t *pp_off;     // [N+1] per pose: its (super-chunk, slot) rows in `part`
+    const int64_t *pp_idx;     // rows of `part`
+};
+
 // Per-block contributor lists of the atomic-free assembly of  -sum Y_I Y_J^T  (shared by both stages).
 struct PairDev {
     int64_t nnzb;              // work items of the pair pass: off-diagonal blocks, long pair lists cut into several items
@@ -86,6 +100,9 @@ void launch_cost(const BalmDev &d, const double *poses, double *chunk_cost, doub
 void launch_eval(const BalmDev &d, const PairDev &pd, const double *poses, double *Hblk, int64_t hblk_doubles, double *g,
                  double *chunk_cost, double *out, bool zero_first, hipStream_t s, hipEvent_t k0, hipEvent_t k1);
 void launch_pairs(const PairDev &pd, double *Hblk, hipStream_t s);
+// the same evaluation with voxel + factor pass fused (Y at voxel-major positions)
+void launch_eval_fused(const BalmDev &d, const FusedDev &fd, const PairDev &pd, const double *poses, double *Hblk, int64_t hblk_doubles,
+                       double *g, double *chunk_cost, double *out, bool zero_first, hipStream_t s, hipEvent_t k0, hipEvent_t k1);
 void launch_aos_to_soa(const double *aos, int64_t F, double *soa, hipStream_t s);
 void launch_gather_csc(const double *clu, const int32_t *csc_f, int64_t F, double *clu_csc, hipStream_t s);
 void launch_retract(const double *poses, const double *dx, double *out, int n_poses, hipStream_t s);
