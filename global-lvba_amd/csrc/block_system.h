@@ -22,6 +22,7 @@ struct BlockSys {
     // configuration
     int ordering = 1;
     double band_frac = 0.6;
+    bool spd = false; // the caller promises a symmetric POSITIVE DEFINITE system (visual stage): narrow bands go to bcr.hip
     // ordering / layout
     std::vector<int32_t> perm, iperm; // perm[internal] = caller, iperm[caller] = internal
     int32_t Bb = 0;
@@ -44,6 +45,7 @@ struct BlockSys {
     int64_t hblk_doubles = 0;
     // solver
     LdltMat A{};
+    double *d_bcr = nullptr; // workspace of the block cyclic reduction, when that is the solver
     double *d_A = nullptr, *d_work = nullptr, *d_dx = nullptr, *d_u = nullptr, *h_pin_u = nullptr;
     int *d_status = nullptr;
     hipGraph_t solve_graph = nullptr;

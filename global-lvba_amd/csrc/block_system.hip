@@ -446,6 +446,11 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
     }
     bs.A.a = bs.d_A;
     TRY(bs_dmalloc(bs, &bs.d_work, ldlt_workspace_doubles(n, bs.A.bw)));
+    {
+        const char *e = getenv("LVBA_BCR");
+        if (bs.spd && bs.use_band && bcr_applicable(N, bs.Bb) && !(e && !strcmp(e, "0")))
+            TRY(bs_dmalloc(bs, &bs.d_bcr, bcr_workspace_doubles(N, bs.Bb)));
+    }
     HIPCHK(hipMemset(bs.d_hg, 0, (size_t)bs.hg_doubles() * sizeof(double)));
     BS_MARK("solver");
     bs.built = true;
@@ -456,7 +461,8 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
 // is captured once into a hipGraph and replayed; u is read from device memory.
 static void solve_launches(BlockSys &bs)
 {
-    ldlt_solve(bs.A, bs.Hblk(), bs.Bb, bs.N, bs.g(), bs.d_u, bs.d_dx, bs.d_work, bs.d_status, bs.stream);
+    if (bs.d_bcr) bcr_solve(bs.Hblk(), bs.Bb, bs.N, bs.g(), bs.d_u, bs.d_dx, bs.d_bcr, bs.d_status, bs.stream);
+    else ldlt_solve(bs.A, bs.Hblk(), bs.Bb, bs.N, bs.g(), bs.d_u, bs.d_dx, bs.d_work, bs.d_status, bs.stream);
 }
 
 int32_t bs_enqueue_solve(BlockSys &bs, double u)
@@ -499,7 +505,7 @@ void bs_destroy(BlockSys &bs)
     if (bs.solve_exec) hipGraphExecDestroy(bs.solve_exec);
     if (bs.solve_graph) hipGraphDestroy(bs.solve_graph);
     void *ptrs[] = {bs.d_ar_slot, bs.d_arbuf, bs.d_multi_off, bs.d_multi_slot, bs.d_multi_idx, bs.d_partial, bs.d_perm, bs.d_csc_off, bs.d_blk_off, bs.d_blk_slot, bs.d_group_of_pos, bs.d_csc_f, bs.d_pos_of,
-                    bs.d_pairs, bs.d_Y, bs.d_hg, bs.d_A, bs.d_work, bs.d_dx, bs.d_u, bs.d_status};
+                    bs.d_pairs, bs.d_Y, bs.d_hg, bs.d_A, bs.d_work, bs.d_bcr, bs.d_dx, bs.d_u, bs.d_status};
     for (void *p : ptrs)
         if (p) DevicePool::get().free(p);
     if (bs.h_pin_u) hipHostFree(bs.h_pin_u);

@@ -138,6 +138,12 @@ int64_t ldlt_num_panels(int64_t n);
 void ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_poses, const double *g,
                 const double *u_dev, double *x, double *work, int *status, hipStream_t s);
 
+// bcr.hip: block cyclic reduction for narrow-band SPD systems (the visual stage's reduced camera system)
+bool bcr_applicable(int n_poses, int band_blocks);
+int64_t bcr_workspace_doubles(int n_poses, int band_blocks);
+void bcr_solve(const double *Hblk, int band_blocks, int n_poses, const double *g, const double *u_dev, double *x, double *work,
+               int *status, hipStream_t s);
+
 } // namespace lvba
 
 // lvba_balm_create with the clusters [F][10] already on `device` (the voxel front-end hands them over without a host

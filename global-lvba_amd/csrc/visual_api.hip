@@ -162,6 +162,7 @@ static int32_t finalize(lvba_visual_s *h)
     if (h->finalized) return LVBA_OK;
     BlockSys &bs = h->bs;
     HIPCHK(hipSetDevice(bs.device));
+    bs.spd = true; // S = sum Jc^T Jc + D^2 - sum Y Y^T is the Schur complement of a positive definite matrix
     TRY(bs_build(bs, h->M, h->Ta, h->h_off.data(), h->h_cam.data()));
     {
         std::vector<int32_t> cam((size_t)h->O);

@@ -55,9 +55,11 @@ __global__ __launch_bounds__(256) void vis_residual_kernel(VisDev d, const doubl
 #pragma unroll
         for (int e = 0; e < 3; ++e) { t[e] = tc[3 * (int64_t)cam + e]; X[e] = Xp[3 * i + e]; }
         reproj_eval<JAC>(q, t, X, d.uv[2 * gid], d.uv[2 * gid + 1], d.intr, d.inv_sig_px, r, Jc, Jp);
-        d.r[2 * gid] = r[0];
-        d.r[2 * gid + 1] = r[1];
         if (JAC) {
+            // r, Jc, Jp describe the linearisation point: a cost-only evaluation (a trial point, which may be rejected) must not
+            // touch them -- the next iteration linearises at the SAME point with a smaller radius
+            d.r[2 * gid] = r[0];
+            d.r[2 * gid + 1] = r[1];
             const bool fixed = cam == d.fixed_cam;
 #pragma unroll
             for (int e = 0; e < 12; ++e) d.Jc[12 * gid + e] = fixed ? 0.0 : Jc[e];
@@ -73,8 +75,8 @@ __global__ __launch_bounds__(256) void vis_residual_kernel(VisDev d, const doubl
 #pragma unroll
         for (int e = 0; e < 4; ++e) pl[e] = d.plane[4 * i + e];
         const double rp = plane_eval(X, pl, d.inv_sig_pl, JAC ? J : nullptr);
-        d.rpl[i] = rp;
         if (JAC) {
+            d.rpl[i] = rp;
 #pragma unroll
             for (int e = 0; e < 3; ++e) d.Jpl[3 * i + e] = J[e];
         }

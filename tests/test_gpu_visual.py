@@ -77,6 +77,25 @@ def test_refine_matches_oracle(pkg, synth, case):
     assert np.array_equal(t[0], d["t"][0])
 
 
+def test_refine_with_rejected_steps_matches_oracle(pkg, synth):
+    """A start far enough from the optimum that trust-region steps are REJECTED in the middle of the run (iterations 4-7 of
+    12): after a rejection the next system is linearised at the same point with a smaller radius, so the residuals of the
+    rejected trial point must not have replaced the ones of the linearisation point (they did until round 2: every later step
+    was garbage and the run ended on the radius test).  Row by row against the oracle."""
+    case = dict(n_cams=8, n_tracks=60, seed=3, rot_sigma_deg=1.5, trans_sigma=0.3, point_sigma=0.6)
+    d, prob, orc = _mk(pkg, synth, case)
+    (q, t, X), trace, term, rc = prob.refine(d["q"], d["t"], d["X"])
+    (qr, tr, Xr), trace_ref, term_ref = orc.solve()
+    acc = [b["accepted"] for b in trace_ref]
+    assert 0 in acc[1:-1] and acc[-2:] != [0, 0]                     # rejections followed by accepted steps
+    assert rc == 0 and term == term_ref and len(trace) == len(trace_ref)
+    for a, b in zip(trace, trace_ref):
+        assert a["accepted"] == b["accepted"]
+        assert abs(a["cost"] - b["cost"]) <= 1e-6 * abs(b["cost"])
+        assert abs(a["radius"] - b["radius"]) <= 1e-6 * b["radius"]
+    assert np.abs(q - qr).max() <= 1e-7 and np.abs(t - tr).max() <= 1e-6 and np.abs(X - Xr).max() <= 1e-6
+
+
 def test_reference_entry_mirror_and_edges(pkg, synth):
     d = synth.make_visual_problem(8, 60, seed=3)
     n = d["plane"][:, :3].copy()
@@ -201,3 +220,28 @@ def test_matches_to_landmarks_pipeline(pkg, synth):
         if key in first_obs:
             dists.append(np.linalg.norm(X[t] - d["X_gt"][first_obs[key]]))
     assert len(dists) > 50 and np.median(dists) < 0.5
+
+
+@pytest.mark.parametrize("n_cams,n_tracks,track_len", [(300, 6000, 4), (160, 4000, 9), (1000, 30000, 4)])
+def test_block_cyclic_reduction_equals_band_ldlt(pkg, synth, monkeypatch, n_cams, n_tracks, track_len):
+    """Narrow reduced camera systems are solved by block cyclic reduction (csrc/bcr.hip: camera half-bandwidth <= 10; block rows
+    of 32 scalars for track_len 4, of 64 for track_len 9) instead of the blocked band LDL^T.  Both are direct solvers of the
+    same positive definite system: the whole LM trace and the refined cameras must agree to rounding."""
+    d = synth.make_visual_problem(n_cams, n_tracks, track_len=track_len, seed=21)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LVBA_BCR", mode)
+        vp = pkg.VisualProblem(n_cams, d["obs_off"], d["obs_cam"], d["obs_uv"], d["plane"], d["valid"], d["intr"])
+        info = vp.info()
+        assert info["use_band"] == 1 and info["band_blocks"] == track_len - 1
+        out[mode] = vp.refine(d["q"], d["t"], d["X"])
+        vp.close()
+    (q1, t1, X1), tr1, term1, rc1 = out["1"]
+    (q0, t0, X0), tr0, term0, rc0 = out["0"]
+    assert rc1 == rc0 == 0 and term1 == term0 and len(tr1) == len(tr0) and len(tr1) >= 4
+    for a, b in zip(tr1, tr0):
+        assert a["accepted"] == b["accepted"] and abs(a["cost"] - b["cost"]) <= 1e-8 * b["cost"]
+    # the system is ill-conditioned (the constant camera's block carries only the 1e-10 LM diagonal: cond ~ 3e10), so two
+    # direct solvers agree to ~1e-10 in the costs and correspondingly less in the variables
+    assert np.abs(q1 - q0).max() <= 1e-7 and np.abs(t1 - t0).max() <= 1e-6 and np.abs(X1 - X0).max() <= 1e-5
+    assert tr1[-1]["cost"] < 0.1 * tr1[0]["cost"]
