@@ -459,10 +459,16 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
 
 // The launch sequence of one solve is static per BlockSys (3 kernels per 64-column panel + 1 for the backward pass), so it
 // is captured once into a hipGraph and replayed; u is read from device memory.
-static void solve_launches(BlockSys &bs)
+static int32_t dist_sum_cb(void *ctx, double *dbuf, size_t count) { return bs_comm_allreduce(*static_cast<BlockSys *>(ctx), dbuf, count, ncclDouble, ncclSum); }
+static int32_t dist_max_cb(void *ctx, int *dbuf) { return bs_comm_allreduce(*static_cast<BlockSys *>(ctx), dbuf, 1, ncclInt32, ncclMax); }
+static int32_t solve_launches(BlockSys &bs)
 {
-    if (bs.d_bcr) bcr_solve(bs.Hblk(), bs.Bb, bs.N, bs.g(), bs.d_u, bs.d_dx, bs.d_bcr, bs.d_status, bs.stream);
-    else ldlt_solve(bs.A, bs.Hblk(), bs.Bb, bs.N, bs.g(), bs.d_u, bs.d_dx, bs.d_work, bs.d_status, bs.stream);
+    if (bs.d_bcr) { bcr_solve(bs.Hblk(), bs.Bb, bs.N, bs.g(), bs.d_u, bs.d_dx, bs.d_bcr, bs.d_status, bs.stream); return LVBA_OK; }
+    // multi-rank: the two ends of the band factorisation on ranks 0 and 1 (LVBA_DIST_SOLVE=0: every rank solves alone)
+    static const bool dist_solve = [] { const char *e = getenv("LVBA_DIST_SOLVE"); return !(e && !strcmp(e, "0")); }();
+    LdltDist dd{bs.rank, bs.n_ranks, &bs, dist_sum_cb, dist_max_cb};
+    return ldlt_solve(bs.A, bs.Hblk(), bs.Bb, bs.N, bs.g(), bs.d_u, bs.d_dx, bs.d_work, bs.d_status, bs.stream,
+                      bs.distributed() && bs.n_ranks >= 2 && dist_solve ? &dd : nullptr);
 }
 
 int32_t bs_enqueue_solve(BlockSys &bs, double u)
@@ -473,12 +479,13 @@ int32_t bs_enqueue_solve(BlockSys &bs, double u)
     // handles that live for one short refinement (window BA) never pay for it
     // no capture while several host threads drive the device (bs_graph_inhibit): with HIP 7.0 a capture in one thread is
     // invalidated by allocations / synchronous copies in another even in hipStreamCaptureModeThreadLocal
+    if (bs.distributed() && bs.n_ranks >= 2) bs.graph_tried = true; // the solve has exchanges between the ranks in it
     if (!bs.graph_tried && g_graph_inhibit.load() == 0 && ++bs.solve_calls >= 3) {
         bs.graph_tried = true;
         if (!getenv("LVBA_NO_GRAPH")) {
             (void)hipGetLastError();
             if (hipStreamBeginCapture(bs.stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                solve_launches(bs);
+                (void)solve_launches(bs);
                 hipGraph_t gph = nullptr;
                 if (hipStreamEndCapture(bs.stream, &gph) == hipSuccess && gph &&
                     hipGraphInstantiate(&bs.solve_exec, gph, nullptr, nullptr, 0) == hipSuccess) {
@@ -492,7 +499,7 @@ int32_t bs_enqueue_solve(BlockSys &bs, double u)
         }
     }
     if (bs.solve_exec) HIPCHK(hipGraphLaunch(bs.solve_exec, bs.stream));
-    else solve_launches(bs);
+    else TRY(solve_launches(bs));
     HIPCHK(hipGetLastError());
     return LVBA_OK;
 }

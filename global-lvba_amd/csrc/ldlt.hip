@@ -28,6 +28,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "lvba_internal.h"
+#include "../../include/lvba_hip.h" // status codes
 
 namespace lvba {
 
@@ -104,6 +105,52 @@ __global__ void ldlt_twist_xb_kernel(LdltTwist tw, int64_t n, double *__restrict
 {
     const int64_t a = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (a < tw.m) x[n - 1 - a] = __longlong_as_double((long long)tw.x2[a]);
+}
+
+// Multi-rank form: rank 0 eliminates T, rank 1 eliminates B, each on its own GPU.  What they exchange is the S block of the
+// band storage and the S part of the right-hand side: E = [S x (bw + 1) entries | |S| entries].  side 0 packs matrix 1's
+// (original entries + T's Schur complement), side 1 matrix 2's reversed (B's Schur complement), side 2 zeros; after the
+// all-reduce (a sum of two non-zero operands: the same a + b the merge kernel forms) every rank unpacks E into matrix 1.
+__global__ void ldlt_twist_pack_kernel(LdltMat M, LdltTwist tw, const double *__restrict__ b, int side, double *__restrict__ E)
+{
+    const int64_t n = M.n, s0 = tw.m, s1 = tw.n1, ns = s1 - s0, bw1 = M.bw + 1;
+    const int64_t total = ns * bw1;
+    const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = gid; e < total + ns; e += gsz) {
+        double v = 0.0;
+        if (e < total) {
+            const int64_t cc = e / bw1, d = e - cc * bw1;
+            const int64_t C = s0 + cc, R = C + d;
+            if (R < s1) v = side == 0 ? M.a[R + C * M.ld] : side == 1 ? M.a[tw.sA + (n - 1 - C) + (n - 1 - R) * M.ld] : 0.0;
+        } else {
+            const int64_t a = s0 + (e - total);
+            v = side == 0 ? b[a] : side == 1 ? b[tw.sW + (n - 1 - a)] : 0.0;
+        }
+        E[e] = v;
+    }
+}
+__global__ void ldlt_twist_unpack_kernel(LdltMat M, LdltTwist tw, double *__restrict__ b, const double *__restrict__ E)
+{
+    const int64_t s0 = tw.m, s1 = tw.n1, ns = s1 - s0, bw1 = M.bw + 1;
+    const int64_t total = ns * bw1;
+    const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = gid; e < total + ns; e += gsz) {
+        if (e < total) {
+            const int64_t cc = e / bw1, d = e - cc * bw1;
+            const int64_t C = s0 + cc, R = C + d;
+            if (R < s1) M.a[R + C * M.ld] = E[e];
+        } else
+            b[s0 + (e - total)] = E[e];
+    }
+}
+// x parts that this rank did not compute are zeroed before the ranks' solutions are summed (side 0 keeps [0, n1), side 1
+// keeps [n1, n), side 2 nothing)
+__global__ void ldlt_twist_xmask_kernel(LdltTwist tw, int64_t n, int side, double *__restrict__ x)
+{
+    const int64_t a = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (a >= n) return;
+    const bool keep = side == 0 ? a < tw.n1 : side == 1 ? a >= tw.n1 : false;
+    if (!keep) x[a] = 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------- K1
@@ -740,7 +787,9 @@ static inline int64_t ldlt_ws_one(int64_t n, int64_t bw)
     return nsteps * 4096 /*G*/ + 3 * n /*d, b, bacc*/ + 2 * ldz_for(n, bw) * LVBA_NB /*Z, double-buffered*/ + 64;
 }
 // two problems' workspaces + matrix 2's solution vector (twisted factorisation)
-int64_t ldlt_workspace_doubles(int64_t n, int64_t bw) { return 2 * ldlt_ws_one(n, bw) + n + 64; }
+// + the exchange buffer of the multi-rank form: |S| <= bw + 2 * 64 columns of bw + 1 entries, and the S part of the rhs
+static inline int64_t ldlt_exchange_doubles(int64_t n, int64_t bw) { return std::min<int64_t>(n, bw + 2 * LVBA_NB) * (bw + 2) + 64; }
+int64_t ldlt_workspace_doubles(int64_t n, int64_t bw) { return 2 * ldlt_ws_one(n, bw) + n + 64 + ldlt_exchange_doubles(n, bw); }
 
 int64_t ldlt_num_panels(int64_t n) { return (n + LVBA_NB - 1) / LVBA_NB; }
 
@@ -761,8 +810,12 @@ int64_t ldlt_twist_panels(int64_t n, int64_t ld, int64_t bw)
 // overlap form gets the same concurrency from one heterogeneous launch.
 // Band systems are factorised from BOTH ENDS at once (LdltTwist above; LVBA_TWIST=0 turns it off): the serial chain of
 // panels -- the latency that bounds this solver -- is P + |S| / 64 long instead of n / 64, with the same flops and no fill.
-void ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_poses, const double *g,
-                const double *u_dev, double *x, double *work, int *status, hipStream_t s)
+// With `dist` (>= 2 ranks) the two ends run on two GPUs: rank 0 eliminates T, rank 1 eliminates B (as the second problem,
+// alone in its launches), the S block + right-hand side are all-reduced (ranks >= 2 contribute zeros), every rank factorises S,
+// rank 0 back-substitutes T and rank 1 B, and the solution is all-reduced.  Per rank the end phase is as long as the
+// single-GPU one but moves one window per launch instead of two; what is replicated is the S phase only.
+int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_poses, const double *g,
+                   const double *u_dev, double *x, double *work, int *status, hipStream_t s, const LdltDist *dist)
 {
     static const bool overlap = [] { const char *e = getenv("LVBA_SCHEDULE"); return !(e && !strcmp(e, "serial")); }();
     const int64_t n = A.n, bw = A.bw;
@@ -771,6 +824,9 @@ void ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_pos
     tw.m = P1 * LVBA_NB; tw.n1 = n - tw.m;
     tw.sA = (A.ld + 1) * (n + 1); tw.sW = ldlt_ws_one(n, bw);
     tw.x2 = reinterpret_cast<unsigned long long *>(work + 2 * tw.sW);
+    double *Ebuf = work + 2 * tw.sW + n + 64;
+    // side: -1 = both ends here (one rank); 0 / 1 = this rank eliminates T / B; 2 = neither (it only takes part in the exchanges)
+    const int side = (dist && dist->n_ranks >= 2 && P1 > 0) ? (dist->rank < 2 ? dist->rank : 2) : -1;
     const int64_t nf = tw.n1; // columns the top-down problem factorises (all of them without the twist)
     const int64_t nsteps = (nf + LVBA_NB - 1) / LVBA_NB;
     double *Gall = work;
@@ -798,25 +854,34 @@ void ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_pos
         q.T = q.w0 < q.rend ? (q.rend - q.w0 + 63) / 64 : 0;
         return q;
     };
-    auto factor_panel = [&](int64_t st, const Geo &q, unsigned ny) { // diag (+ panel) of one panel as a launch of its own
-        double *G = Gall + st * 4096, *Zws = Zbuf[st & 1];
+    // ny = 2: both problems in one launch (blockIdx.y); ny = 1 with second = true: the second problem alone (its pointers are
+    // passed as the launch's base pointers) -- what rank 1 of a multi-rank job runs
+    LdltMat M2 = M;
+    M2.a += tw.sA;
+    auto factor_panel = [&](int64_t st, const Geo &q, unsigned ny, bool second = false) { // diag (+ panel) of one panel
+        const int64_t wo = second ? tw.sW : 0;
+        double *G = Gall + wo + st * 4096, *Zws = Zbuf[st & 1] + wo;
         if (q.T > 0)
-            hipLaunchKernelGGL(ldlt_diagpanel_kernel, dim3((unsigned)q.T, ny), dim3(256), 0, s, M, q.k, q.nbe, q.w0, q.rend, G, dvec, Zws, ldz, b, status, tw.sA, tw.sW);
+            hipLaunchKernelGGL(ldlt_diagpanel_kernel, dim3((unsigned)q.T, ny), dim3(256), 0, s, second ? M2 : M, q.k, q.nbe, q.w0, q.rend, G,
+                               dvec + wo, Zws, ldz, b + wo, status, tw.sA, tw.sW);
         else
-            hipLaunchKernelGGL(ldlt_diag_blocked_kernel, dim3(1), dim3(256), 0, s, M, q.k, q.nbe, G, dvec, status);
+            hipLaunchKernelGGL(ldlt_diag_blocked_kernel, dim3(1), dim3(256), 0, s, second ? M2 : M, q.k, q.nbe, G, dvec + wo, status);
     };
-    auto first_column = [&](int64_t st, const Geo &q, unsigned ny) {
+    auto first_column = [&](int64_t st, const Geo &q, unsigned ny, bool second = false) {
+        const int64_t wo = second ? tw.sW : 0;
         if (q.T > 0)
-            hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)(4 * q.T), ny), dim3(256), 0, s, M, q.k, q.nbe, q.w0, q.rend, Zbuf[st & 1], ldz, 1, tw.sA, tw.sW);
+            hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)(4 * q.T), ny), dim3(256), 0, s, second ? M2 : M, q.k, q.nbe, q.w0, q.rend,
+                               Zbuf[st & 1] + wo, ldz, 1, tw.sA, tw.sW);
     };
     // [factorise panel st+1 || bulk update of panel st]; fac = false: the bulk update alone
-    auto step = [&](int64_t st, const Geo &q, const Geo &q2, bool fac, unsigned ny) {
+    auto step = [&](int64_t st, const Geo &q, const Geo &q2, bool fac, unsigned ny, bool second = false) {
+        const int64_t wo = second ? tw.sW : 0;
         const int64_t nb3 = q.T > 1 ? (q.T - 1) * q.T / 2 : 0; // bulk tiles of panel st
         const int64_t T2 = fac ? q2.T : 0;
         if (T2 + nb3 > 0)
-            hipLaunchKernelGGL(ldlt_step_kernel, dim3((unsigned)(T2 + nb3), ny), dim3(256), 0, s, M, q2.k, q2.nbe, q2.w0, q2.rend, (int)T2,
-                               Gall + (st + 1) * 4096, dvec, Zbuf[(st + 1) & 1], b, status, q.k, q.nbe, q.w0, q.rend,
-                               (const double *)Zbuf[st & 1], ldz, tw.sA, tw.sW);
+            hipLaunchKernelGGL(ldlt_step_kernel, dim3((unsigned)(T2 + nb3), ny), dim3(256), 0, s, second ? M2 : M, q2.k, q2.nbe, q2.w0, q2.rend,
+                               (int)T2, Gall + wo + (st + 1) * 4096, dvec + wo, Zbuf[(st + 1) & 1] + wo, b + wo, status, q.k, q.nbe, q.w0,
+                               q.rend, (const double *)(Zbuf[st & 1] + wo), ldz, tw.sA, tw.sW);
     };
     if (!overlap) {
         for (int64_t st = 0; st < nsteps; ++st) {
@@ -827,18 +892,29 @@ void ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_pos
         }
     } else {
         int64_t st0 = 0;
-        if (P1 > 0) { // both ends, panels 0 .. P1-1 of the two problems in the same launches
-            Geo q = geom(0);
-            factor_panel(0, q, 2);
-            first_column(0, q, 2);
-            for (int64_t st = 0; st + 1 < P1; ++st) {
-                const Geo q2 = geom(st + 1);
-                step(st, q, q2, true, 2);
-                first_column(st + 1, q2, 2);
-                q = q2;
+        if (P1 > 0) { // both ends, panels 0 .. P1-1 of the two problems in the same launches (or this rank's end alone)
+            if (side != 2) {
+                const unsigned ny = side < 0 ? 2 : 1;
+                const bool second = side == 1;
+                Geo q = geom(0);
+                factor_panel(0, q, ny, second);
+                first_column(0, q, ny, second);
+                for (int64_t st = 0; st + 1 < P1; ++st) {
+                    const Geo q2 = geom(st + 1);
+                    step(st, q, q2, true, ny, second);
+                    first_column(st + 1, q2, ny, second);
+                    q = q2;
+                }
+                step(P1 - 1, q, geom(P1), false, ny, second); // the bulk update of the last end panel
             }
-            step(P1 - 1, q, geom(P1), false, 2); // the bulk update of the last end panel
-            hipLaunchKernelGGL(ldlt_twist_merge_kernel, dim3(1024), dim3(256), 0, s, A, tw, b); // A: the reversal needs the full n
+            if (side < 0) {
+                hipLaunchKernelGGL(ldlt_twist_merge_kernel, dim3(1024), dim3(256), 0, s, A, tw, b); // A: the reversal needs the full n
+            } else { // exchange the S block and the S part of the right-hand side
+                const int64_t ne = (tw.n1 - tw.m) * (bw + 2);
+                hipLaunchKernelGGL(ldlt_twist_pack_kernel, dim3(1024), dim3(256), 0, s, A, tw, (const double *)b, side, Ebuf);
+                if (dist->allreduce_sum(dist->ctx, Ebuf, (size_t)ne)) return LVBA_ERR_DIST;
+                hipLaunchKernelGGL(ldlt_twist_unpack_kernel, dim3(1024), dim3(256), 0, s, A, tw, b, (const double *)Ebuf);
+            }
             st0 = P1;
         }
         Geo q = geom(st0);
@@ -862,13 +938,13 @@ void ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_pos
     if (!back_panel || P1 > 0) {
         // at most 256 panels per launch: one workgroup per CU is then resident whatever else shares the device, so the
         // chain cannot starve even if workgroups were not dispatched in index order; later launches only read finished x
-        for (int64_t top = nsteps - 1; top >= 0; top -= 256) {
-            const int64_t cnt = std::min<int64_t>(256, top + 1);
+        // (a multi-rank job stops matrix 1's chain after the S panels unless this rank owns T)
+        const int64_t low = side >= 1 ? P1 : 0;
+        for (int64_t top = nsteps - 1; top >= low; top -= 256) {
+            const int64_t cnt = std::min<int64_t>(256, top - low + 1);
             hipLaunchKernelGGL(ldlt_back_chain_kernel, dim3((unsigned)cnt), dim3(256), 0, s, M, (int)top, Gall, dvec, b, x);
         }
-        if (P1 > 0) { // matrix 2's B part: its chain starts from x of S (reversed)
-            LdltMat M2 = M;
-            M2.a += tw.sA;
+        if (P1 > 0 && (side < 0 || side == 1)) { // matrix 2's B part: its chain starts from x of S (reversed)
             const int64_t ns = tw.n1 - tw.m;
             hipLaunchKernelGGL(ldlt_twist_xs_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, s, tw, n, (const double *)x);
             for (int64_t top = P1 - 1; top >= 0; top -= 256) {
@@ -878,7 +954,12 @@ void ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_pos
             }
             hipLaunchKernelGGL(ldlt_twist_xb_kernel, dim3((unsigned)((tw.m + 255) / 256)), dim3(256), 0, s, tw, n, x);
         }
-        return;
+        if (side >= 0) { // everybody gets the whole solution and the worst status
+            hipLaunchKernelGGL(ldlt_twist_xmask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, tw, n, side, x);
+            if (dist->allreduce_sum(dist->ctx, x, (size_t)n)) return LVBA_ERR_DIST;
+            if (dist->allreduce_max_i32(dist->ctx, status)) return LVBA_ERR_DIST;
+        }
+        return LVBA_OK;
     }
     for (int64_t st = nsteps - 1; st >= 0; --st) {
         const int64_t k = st * LVBA_NB;
@@ -889,6 +970,7 @@ void ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_pos
         const unsigned nwg = (unsigned)(ncols > 0 ? (ncols + 255) / 256 : 1);
         hipLaunchKernelGGL(ldlt_back_kernel, dim3(nwg), dim3(256), 0, s, A, k, nbe, Gall + st * 4096, dvec, b, bacc, x, cmin);
     }
+    return LVBA_OK;
 }
 
 } // namespace lvba

@@ -331,6 +331,11 @@ extern "C" int32_t lvba_balm_info(lvba_balm_t h, lvba_balm_info_t *info)
     info->n_factors = h->F; info->n_pairs = h->Q; info->n_chunks = h->n_chunks; info->n_blocks = h->bs.nnzb;
     info->band_blocks = h->bs.Bb; info->use_band = h->bs.use_band ? 1 : 0; info->hess_bytes = h->bs.hblk_doubles * 8;
     info->device_bytes = h->bs.device_bytes;
+    info->twist_panels = h->bs.d_bcr ? 0 : (int32_t)ldlt_twist_panels(h->bs.A.n, h->bs.A.ld, h->bs.A.bw);
+    {
+        const char *e = getenv("LVBA_DIST_SOLVE");
+        info->solve_ranks = (h->bs.distributed() && h->bs.n_ranks >= 2 && info->twist_panels > 0 && !(e && !strcmp(e, "0"))) ? 2 : 1;
+    }
     info->allreduce_bytes = !h->bs.distributed() ? 0 : 8 * ((h->bs.d_ar_slot ? 36 * h->bs.n_ar : h->bs.hblk_doubles) + 6 * (int64_t)h->N + 1);
     return LVBA_OK;
 }

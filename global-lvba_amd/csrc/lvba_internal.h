@@ -131,12 +131,22 @@ void vis_launch_apply(const VisDev &d, const double *step_c, const double *qc, c
 // Workspace doubles needed by ldlt_solve for an n x n system.
 int64_t ldlt_workspace_doubles(int64_t n, int64_t bw);
 int64_t ldlt_num_panels(int64_t n);
+// panels each end of the two-ended ("twisted") band factorisation eliminates; 0: plain top-down
+int64_t ldlt_twist_panels(int64_t n, int64_t ld, int64_t bw);
 // A <- H + u*diag(H) from the block-band store, b <- -g; then unpivoted blocked LDL^T of the lower
 // triangle and the two triangular solves.  x (length n) receives the solution; status[0] != 0 on a
 // zero / non-finite pivot.  u is read from device memory (u_dev) so the launch sequence is static and
 // can be captured into a hipGraph.
-void ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_poses, const double *g,
-                const double *u_dev, double *x, double *work, int *status, hipStream_t s);
+// dist (may be NULL): a multi-rank job -- the two ends of the twisted factorisation are eliminated by rank 0 and rank 1 (the
+// callbacks all-reduce device buffers in place over the ranks; they return 0 on success).
+struct LdltDist {
+    int rank, n_ranks;
+    void *ctx;
+    int32_t (*allreduce_sum)(void *ctx, double *dbuf, size_t count);
+    int32_t (*allreduce_max_i32)(void *ctx, int *dbuf);
+};
+int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_poses, const double *g,
+                   const double *u_dev, double *x, double *work, int *status, hipStream_t s, const LdltDist *dist = nullptr);
 
 // bcr.hip: block cyclic reduction for narrow-band SPD systems (the visual stage's reduced camera system)
 bool bcr_applicable(int n_poses, int band_blocks);

@@ -89,6 +89,8 @@ typedef struct {
     int64_t hess_bytes;      /* block-band Hessian storage */
     int64_t device_bytes;    /* total device memory held by the handle */
     int64_t allreduce_bytes; /* bytes all-reduced per evaluation (0 without a communicator): the union-pattern blocks + g + cost */
+    int32_t twist_panels;    /* band solver: 64-column panels each END eliminates (0: plain top-down factorisation) */
+    int32_t solve_ranks;     /* ranks the factorisation is spread over: 2 when ranks 0 and 1 take one end each, else 1 */
 } lvba_balm_info_t;
 
 /* Accumulated device times (HIP events on the handle's stream) since the last reset, ms. */

@@ -57,7 +57,10 @@ def _run_ranks(pkg, d, world, packed=True):
 
 @pytest.mark.parametrize("world,case", [(2, dict(n_poses=200, n_voxels=6000, band=10, seed=7)),     # packed all-reduce, band solver
                                         (3, dict(n_poses=40, n_voxels=3000, band=10, seed=2)),      # dense store, ragged shards
-                                        (2, dict(n_poses=150, n_voxels=8000, band=12, seed=4))])
+                                        (2, dict(n_poses=150, n_voxels=8000, band=12, seed=4)),
+                                        # no loop closures -> a narrow band: ranks 0 and 1 eliminate one end of it each
+                                        (2, dict(n_poses=200, n_voxels=6000, band=10, seed=7, loop_frac=0.0)),
+                                        (3, dict(n_poses=300, n_voxels=9000, band=8, seed=9, loop_frac=0.0))])
 def test_ranks_agree_with_single_rank_and_oracle(pkg, oracle_mod, world, case, monkeypatch):
     d = make_problem(**case)
     N = d["n_poses"]
@@ -69,8 +72,10 @@ def test_ranks_agree_with_single_rank_and_oracle(pkg, oracle_mod, world, case, m
     r0 = out[0]
     assert r0["info"]["n_ranks"] == world and r0["info"]["n_voxels_global"] == len(d["voxel_off"]) - 1
     assert sum(o["info"]["n_voxels"] for o in out) == len(d["voxel_off"]) - 1
-    if N >= 200:
+    if N >= 200 and "loop_frac" not in case:   # band + sparse far blocks: only the union pattern's blocks travel
         assert 0 < r0["info"]["allreduce_bytes"] < 0.75 * r0["info"]["hess_bytes"]     # the packed form was used
+    if case.get("loop_frac") == 0.0:   # band systems: ranks 0 and 1 eliminate one end each, the middle block is exchanged (csrc/ldlt.hip)
+        assert r0["info"]["use_band"] == 1 and r0["info"]["twist_panels"] >= 4 and r0["info"]["solve_ranks"] == 2
     for o in out[1:]:                                                                    # replicas: bitwise
         assert np.array_equal(o["perm"], r0["perm"])
         assert np.array_equal(o["H"], r0["H"]) and np.array_equal(o["g"], r0["g"]) and o["c"] == r0["c"] and o["c_gt"] == r0["c_gt"]
