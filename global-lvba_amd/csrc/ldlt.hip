@@ -448,6 +448,20 @@ __device__ __forceinline__ void tri_decode(int64_t bidx, int64_t &ti, int64_t &t
     while ((ti + 1) * (ti + 2) / 2 <= bidx) ++ti;
     tj = bidx - ti * (ti + 1) / 2;
 }
+// column-major enumeration of the lower tiles of a Tb x Tb triangle: column tj holds the Tb - tj tiles ti = tj .. Tb-1, columns
+// one after the other (bidx -> (ti >= tj)).  A launch can then take a RANGE of tile columns -- the ones the next
+// factorisations need first.
+__host__ __device__ __forceinline__ int64_t col_start(int64_t tj, int64_t Tb) { return tj * Tb - tj * (tj - 1) / 2; }
+__device__ __forceinline__ void col_decode(int64_t bidx, int64_t Tb, int64_t &ti, int64_t &tj)
+{
+    const double bq = (double)(2 * Tb + 1);
+    tj = (int64_t)((bq - sqrt(bq * bq - 8.0 * (double)bidx)) * 0.5);
+    if (tj < 0) tj = 0;
+    if (tj > Tb - 1) tj = Tb - 1;
+    while (tj > 0 && col_start(tj, Tb) > bidx) --tj;
+    while (tj + 1 < Tb && col_start(tj + 1, Tb) <= bidx) ++tj;
+    ti = tj + (bidx - col_start(tj, Tb));
+}
 __device__ __forceinline__ void update_tile(double *lds, LdltMat M, int64_t k, int nbe, int64_t w0, int64_t rend,
                                             const double *__restrict__ Zws, int64_t ldz, int64_t ti, int64_t tj)
 {
@@ -496,6 +510,73 @@ __device__ __forceinline__ void update_tile(double *lds, LdltMat M, int64_t k, i
         }
     }
     // acc[t][reg] = sum_m Z[c = 16w+kk+4reg][m] * L[r = 16t+i][m]
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int64_t c = c0 + 16 * w + kk + 4 * reg, r = r0 + 16 * t + i;
+            if (r < rend && c < rend && r >= c) M.a[r + c * M.ld] = cv[4 * t + reg] - acc[t][reg];
+        }
+}
+// The same tile with the contributions of TWO consecutive panels (e, then o = e + 1) in one pass: C is read and written once
+// per 128 columns instead of once per 64 (rank-128 update; the end phase of the two-ended factorisation is bound by exactly that
+// traffic).  (ti, tj) are tile coordinates in panel o's window; panel e's window starts one tile earlier and ends one tile
+// earlier, so its rows / columns >= rend_e contribute nothing.  L and Z of panel o are prefetched while panel e's products run.
+__device__ __forceinline__ void update_tile2(double *lds, LdltMat M, int64_t k, int nbe, int64_t w0, int64_t rend,
+                                             const double *__restrict__ Zws, int64_t ke, int nbe_e, int64_t w0e, int64_t rend_e,
+                                             const double *__restrict__ Zwe, int64_t ldz, int64_t ti, int64_t tj)
+{
+    double *Ls = lds;                // [m][row of tile ti]
+    double *Zs = lds + 64 * LVBA_TS; // [m][row of tile tj] (= column of the updated tile)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t r0 = w0 + 64 * ti, c0 = w0 + 64 * tj;
+    const int row = tid & 63;
+    const int i = lane & 15, kk = lane >> 4;
+    const int64_t rr = r0 + row, cc = c0 + row;
+    double lv[16], zv[16], lv2[16], zv2[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) { // panel e first
+        const int m = w + 4 * it;
+        lv[it] = (rr < rend_e && m < nbe_e) ? M.a[rr + (ke + m) * M.ld] : 0.0;
+        zv[it] = (cc < rend_e && m < nbe_e) ? Zwe[(cc - w0e) + m * ldz] : 0.0;
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int m = w + 4 * it;
+        lv2[it] = (rr < rend && m < nbe) ? M.a[rr + (k + m) * M.ld] : 0.0;
+        zv2[it] = (cc < rend && m < nbe) ? Zws[(cc - w0) + m * ldz] : 0.0;
+    }
+    double cv[16];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int64_t c = c0 + 16 * w + kk + 4 * reg, r = r0 + 16 * t + i;
+            cv[4 * t + reg] = (r < rend && c < rend && r >= c) ? M.a[r + c * M.ld] : 0.0;
+        }
+    d4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass) __syncthreads(); // everybody is done reading panel e's tiles
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int m = w + 4 * it;
+            Ls[m * LVBA_TS + row] = pass ? lv2[it] : lv[it];
+            Zs[m * LVBA_TS + row] = pass ? zv2[it] : zv[it];
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int k0 = 0; k0 < 64; k0 += 4) {
+            const double a = Zs[(k0 + kk) * LVBA_TS + 16 * w + i];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const double bv = Ls[(k0 + kk) * LVBA_TS + 16 * t + i];
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc[t], 0, 0, 0);
+            }
+        }
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -563,8 +644,11 @@ __global__ __launch_bounds__(256) void ldlt_update_kernel(LdltMat M, int64_t k, 
     __shared__ double lds[LVBA_K3_LDS];
     if (blockIdx.y) { M.a += sA; Zws += sW; }
     int64_t ti, tj;
-    if (mode == 1) {
-        update_tile_quarter(lds, M, k, nbe, w0, rend, Zws, ldz, blockIdx.x >> 2, 0, blockIdx.x & 3);
+    if (mode == 1 || mode == 2) { // mode 2: the first TWO tile columns (a panel whose bulk update is deferred to its partner's)
+        const int64_t T = (rend - w0 + 63) / 64;
+        int64_t b = blockIdx.x;
+        if (b < 4 * T) update_tile_quarter(lds, M, k, nbe, w0, rend, Zws, ldz, b >> 2, 0, (int)(b & 3));
+        else { b -= 4 * T; update_tile_quarter(lds, M, k, nbe, w0, rend, Zws, ldz, 1 + (b >> 2), 1, (int)(b & 3)); }
         return;
     }
     tri_decode(blockIdx.x, ti, tj);
@@ -580,17 +664,20 @@ __global__ __launch_bounds__(256) void ldlt_step_kernel(LdltMat M, int64_t k2, i
                                                         double *__restrict__ G2, double *__restrict__ dvec,
                                                         double *__restrict__ Zws2, double *__restrict__ b,
                                                         int *__restrict__ status, int64_t k, int nbe, int64_t w0, int64_t rend,
-                                                        const double *__restrict__ Zws, int64_t ldz, int64_t sA, int64_t sW)
+                                                        const double *__restrict__ Zws, int64_t ldz, int64_t sA, int64_t sW,
+                                                        int64_t ke, int nbe_e, int64_t w0e, int64_t rend_e,
+                                                        const double *__restrict__ Zwe, int64_t tile0)
 {
     __shared__ double lds[LVBA_K3_LDS];
     static_assert(LVBA_K12_LDS <= LVBA_K3_LDS, "factorisation tables must fit the update's LDS");
-    if (blockIdx.y) { M.a += sA; G2 += sW; dvec += sW; Zws2 += sW; b += sW; Zws += sW; }
+    if (blockIdx.y) { M.a += sA; G2 += sW; dvec += sW; Zws2 += sW; b += sW; Zws += sW; if (Zwe) Zwe += sW; }
     if ((int)blockIdx.x < T2) {
         diagpanel_tile(lds, M, k2, nbe2, w02, rend2, G2, dvec, Zws2, ldz, b, status, blockIdx.x);
     } else {
-        int64_t ti, tj;
-        tri_decode((int64_t)blockIdx.x - T2, ti, tj);
-        update_tile(lds, M, k, nbe, w0, rend, Zws, ldz, ti + 1, tj + 1);
+        int64_t ti, tj; // bulk tiles (ti >= tj >= 1 of the window) in column-major order, from tile0 on
+        col_decode(tile0 + (int64_t)blockIdx.x - T2, (rend - w0 + 63) / 64 - 1, ti, tj);
+        if (Zwe) update_tile2(lds, M, k, nbe, w0, rend, Zws, ke, nbe_e, w0e, rend_e, Zwe, ldz, ti + 1, tj + 1); // with the partner panel
+        else update_tile(lds, M, k, nbe, w0, rend, Zws, ldz, ti + 1, tj + 1);
     }
 }
 
@@ -784,7 +871,7 @@ static inline int64_t ldz_for(int64_t n, int64_t bw)
 static inline int64_t ldlt_ws_one(int64_t n, int64_t bw)
 {
     const int64_t nsteps = (n + LVBA_NB - 1) / LVBA_NB;
-    return nsteps * 4096 /*G*/ + 3 * n /*d, b, bacc*/ + 2 * ldz_for(n, bw) * LVBA_NB /*Z, double-buffered*/ + 64;
+    return nsteps * 4096 /*G*/ + 3 * n /*d, b, bacc*/ + 4 * ldz_for(n, bw) * LVBA_NB /*Z, four buffers (st % 4)*/ + 64;
 }
 // two problems' workspaces + matrix 2's solution vector (twisted factorisation)
 // + the exchange buffer of the multi-rank form: |S| <= bw + 2 * 64 columns of bw + 1 entries, and the S part of the rhs
@@ -834,7 +921,7 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
     double *b = dvec + n;
     double *bacc = b + n;
     const int64_t ldz = ldz_for(n, bw);
-    double *Zbuf[2] = {bacc + n, bacc + n + ldz * LVBA_NB};
+    double *Zbuf[4] = {bacc + n, bacc + n + ldz * LVBA_NB, bacc + n + 2 * ldz * LVBA_NB, bacc + n + 3 * ldz * LVBA_NB};
     LdltMat M = A; // the problem the launches see: matrix 1 (and matrix 2 through blockIdx.y)
     M.n = nf;
     const size_t abytes = (size_t)((A.ld == n) ? n * n : (A.ld + 1) * n) * sizeof(double);
@@ -860,53 +947,100 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
     M2.a += tw.sA;
     auto factor_panel = [&](int64_t st, const Geo &q, unsigned ny, bool second = false) { // diag (+ panel) of one panel
         const int64_t wo = second ? tw.sW : 0;
-        double *G = Gall + wo + st * 4096, *Zws = Zbuf[st & 1] + wo;
+        double *G = Gall + wo + st * 4096, *Zws = Zbuf[st % 4] + wo;
         if (q.T > 0)
             hipLaunchKernelGGL(ldlt_diagpanel_kernel, dim3((unsigned)q.T, ny), dim3(256), 0, s, second ? M2 : M, q.k, q.nbe, q.w0, q.rend, G,
                                dvec + wo, Zws, ldz, b + wo, status, tw.sA, tw.sW);
         else
             hipLaunchKernelGGL(ldlt_diag_blocked_kernel, dim3(1), dim3(256), 0, s, second ? M2 : M, q.k, q.nbe, G, dvec + wo, status);
     };
-    auto first_column = [&](int64_t st, const Geo &q, unsigned ny, bool second = false) {
+    // ncols = 2: a panel whose bulk update is deferred to its partner's launch applies itself to the first TWO tile columns
+    auto first_column = [&](int64_t st, const Geo &q, unsigned ny, bool second, int ncols) {
         const int64_t wo = second ? tw.sW : 0;
         if (q.T > 0)
-            hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)(4 * q.T), ny), dim3(256), 0, s, second ? M2 : M, q.k, q.nbe, q.w0, q.rend,
-                               Zbuf[st & 1] + wo, ldz, 1, tw.sA, tw.sW);
+            hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)(ncols == 2 ? 4 * q.T + 4 * (q.T - 1) : 4 * q.T), ny), dim3(256), 0, s,
+                               second ? M2 : M, q.k, q.nbe, q.w0, q.rend, Zbuf[st % 4] + wo, ldz, ncols == 2 ? 2 : 1, tw.sA, tw.sW);
     };
-    // [factorise panel st+1 || bulk update of panel st]; fac = false: the bulk update alone
-    auto step = [&](int64_t st, const Geo &q, const Geo &q2, bool fac, unsigned ny, bool second = false) {
+    // One launch: [factorise panel st+1 (fac) || bulk tiles [t0, t1) of panel sb's trailing update], the tiles in column-major
+    // order.  qe != NULL: panel sb together with its partner sb-1 (rank 128: one pass over C for both).
+    auto step = [&](int64_t st, const Geo &q2, bool fac, unsigned ny, bool second, int64_t sb_, const Geo *qb, const Geo *qe,
+                    int64_t t0, int64_t t1) {
         const int64_t wo = second ? tw.sW : 0;
-        const int64_t nb3 = q.T > 1 ? (q.T - 1) * q.T / 2 : 0; // bulk tiles of panel st
+        const int64_t nb3 = qb ? t1 - t0 : 0;
         const int64_t T2 = fac ? q2.T : 0;
+        const Geo z{0, 0, 0, 0, 0};
+        const Geo &B = qb ? *qb : z;
         if (T2 + nb3 > 0)
             hipLaunchKernelGGL(ldlt_step_kernel, dim3((unsigned)(T2 + nb3), ny), dim3(256), 0, s, second ? M2 : M, q2.k, q2.nbe, q2.w0, q2.rend,
-                               (int)T2, Gall + wo + (st + 1) * 4096, dvec + wo, Zbuf[(st + 1) & 1] + wo, b + wo, status, q.k, q.nbe, q.w0,
-                               q.rend, (const double *)(Zbuf[st & 1] + wo), ldz, tw.sA, tw.sW);
+                               (int)T2, Gall + wo + (st + 1) * 4096, dvec + wo, Zbuf[(st + 1) % 4] + wo, b + wo, status, B.k, B.nbe, B.w0,
+                               B.rend, (const double *)(Zbuf[(sb_ % 4 + 4) % 4] + wo), ldz, tw.sA, tw.sW, qe ? qe->k : 0, qe ? qe->nbe : 0,
+                               qe ? qe->w0 : 0, qe ? qe->rend : 0,
+                               qe ? (const double *)(Zbuf[((sb_ - 1) % 4 + 4) % 4] + wo) : (const double *)nullptr, t0);
+    };
+    // LVBA_RANK128=0: every panel applies its own bulk update (A/B)
+    static const bool rank128 = [] { const char *e = getenv("LVBA_RANK128"); return !(e && !strcmp(e, "0")); }();
+    // Panels [sa, sb) of one problem (or of both, ny = 2).  Consecutive panels are PAIRED (e, o = e + 1): e applies itself to
+    // the two tile columns the next two factorisations need (first_column, ncols = 2) and leaves the rest of its trailing update
+    // to its partner's, where every C tile is read and written once for both.  That rank-128 update is spread over the two
+    // launches that follow o's factorisation -- the tile columns in order, the first half beside the factorisation of e + 2,
+    // the second beside that of e + 3 --, so every launch carries about the same share.  close: also finish the last panel's
+    // update (end phase).
+    auto run_phase = [&](int64_t sa, int64_t sb, unsigned ny, bool second, bool close) {
+        auto pe = [&](int64_t st) { return rank128 && ((st - sa) % 2 == 0) && st + 1 < sb && geom(st).T >= 3 && geom(st + 1).T >= 2; };
+        auto po = [&](int64_t st) { return st > sa && pe(st - 1); };
+        struct Pending { bool on; int64_t o; Geo qo, qe; int64_t t0, t1; } pend{false, 0, {}, {}, 0, 0};
+        auto flush = [&]() { // the deferred second half as a launch of its own
+            if (pend.on) step(pend.o, pend.qo, false, ny, second, pend.o, &pend.qo, &pend.qe, pend.t0, pend.t1);
+            pend.on = false;
+        };
+        auto launch = [&](int64_t st, const Geo &q, const Geo &q2, bool fac, bool all) {
+            const int64_t Tb = q.T - 1, total = Tb > 0 ? Tb * (Tb + 1) / 2 : 0;
+            if (pe(st)) { // its own update waits for the partner; this slot carries the previous pair's second half
+                if (pend.on) step(st, q2, fac, ny, second, pend.o, &pend.qo, &pend.qe, pend.t0, pend.t1);
+                else step(st, q2, fac, ny, second, st, nullptr, nullptr, 0, 0);
+                pend.on = false;
+                return;
+            }
+            flush();
+            if (po(st)) {
+                const Geo qe = geom(st - 1);
+                int64_t cs = 1; // first tile column of the second half: about half of the tiles each
+                while (cs < Tb && 2 * col_start(cs, Tb) < total) ++cs;
+                const int64_t t_half = all ? total : col_start(cs, Tb);
+                step(st, q2, fac, ny, second, st, &q, &qe, 0, t_half);
+                if (t_half < total) pend = Pending{true, st, q, qe, t_half, total};
+            } else
+                step(st, q2, fac, ny, second, st, total > 0 ? &q : nullptr, nullptr, 0, total);
+        };
+        Geo q = geom(sa);
+        factor_panel(sa, q, ny, second);
+        first_column(sa, q, ny, second, pe(sa) ? 2 : 1);
+        for (int64_t st = sa; st + 1 < sb; ++st) {
+            const Geo q2 = geom(st + 1);
+            if (q2.T > 0) {
+                launch(st, q, q2, true, false);
+                first_column(st + 1, q2, ny, second, pe(st + 1) ? 2 : 1);
+            } else { // the last panel has no rows below it: nothing to overlap with
+                launch(st, q, q2, false, true);
+                flush();
+                factor_panel(st + 1, q2, ny, second);
+            }
+            q = q2;
+        }
+        if (close) launch(sb - 1, q, geom(sb), false, true);
+        flush();
     };
     if (!overlap) {
         for (int64_t st = 0; st < nsteps; ++st) {
             const Geo q = geom(st);
             factor_panel(st, q, 1);
             if (q.T > 0)
-                hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)(q.T * (q.T + 1) / 2)), dim3(256), 0, s, M, q.k, q.nbe, q.w0, q.rend, Zbuf[st & 1], ldz, 0, tw.sA, tw.sW);
+                hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)(q.T * (q.T + 1) / 2)), dim3(256), 0, s, M, q.k, q.nbe, q.w0, q.rend, Zbuf[st % 4], ldz, 0, tw.sA, tw.sW);
         }
     } else {
         int64_t st0 = 0;
         if (P1 > 0) { // both ends, panels 0 .. P1-1 of the two problems in the same launches (or this rank's end alone)
-            if (side != 2) {
-                const unsigned ny = side < 0 ? 2 : 1;
-                const bool second = side == 1;
-                Geo q = geom(0);
-                factor_panel(0, q, ny, second);
-                first_column(0, q, ny, second);
-                for (int64_t st = 0; st + 1 < P1; ++st) {
-                    const Geo q2 = geom(st + 1);
-                    step(st, q, q2, true, ny, second);
-                    first_column(st + 1, q2, ny, second);
-                    q = q2;
-                }
-                step(P1 - 1, q, geom(P1), false, ny, second); // the bulk update of the last end panel
-            }
+            if (side != 2) run_phase(0, P1, side < 0 ? 2 : 1, side == 1, true);
             if (side < 0) {
                 hipLaunchKernelGGL(ldlt_twist_merge_kernel, dim3(1024), dim3(256), 0, s, A, tw, b); // A: the reversal needs the full n
             } else { // exchange the S block and the S part of the right-hand side
@@ -917,20 +1051,7 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
             }
             st0 = P1;
         }
-        Geo q = geom(st0);
-        factor_panel(st0, q, 1);
-        first_column(st0, q, 1);
-        for (int64_t st = st0; st + 1 < nsteps; ++st) {
-            const Geo q2 = geom(st + 1);
-            if (q2.T > 0) {
-                step(st, q, q2, true, 1);
-                first_column(st + 1, q2, 1);
-            } else { // the last panel has no rows below it: nothing to overlap with
-                step(st, q, q2, false, 1);
-                factor_panel(st + 1, q2, 1);
-            }
-            q = q2;
-        }
+        run_phase(st0, nsteps, 1, false, false);
     }
     // backward.  Default: the whole substitution as one chained launch (ldlt_back_chain_kernel).  LVBA_BACK=panel keeps
     // the former one-launch-per-panel form for A/B (1.7 ms of a C3 solve, ~9 us per kernel boundary).
