@@ -11,8 +11,9 @@ the same perturbed poses, so the timed steps are the iteration mix a real refine
   python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3|C2|NxV]
 N > 1 is launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`:
 one rank per GPU, voxels sharded by contiguous range (bavoxel.hpp:621-624 with thread -> GPU), the
-pose-block Hessian / gradient / cost all-reduced over RCCL inside liblvba_hip.so; the damped solve is
-replicated.  Total work is fixed as N grows -> "scaling": "strong".
+pose-block Hessian / gradient / cost all-reduced over RCCL inside liblvba_hip.so; the two ends of the band
+factorisation run on ranks 0 and 1 (the middle block is exchanged), the rest of the solve is replicated.  Total work is
+fixed as N grows -> "scaling": "strong".
 
 Rank 0 prints ONE JSON line.  `roofline` is the H/g/cost evaluation ("Jacobian") pass against HBM, from
 HIP-event durations recorded on the library's stream around its kernels during the timed steps and the

@@ -14,3 +14,8 @@ bash $R/tools/gpu_pmc2.sh > $O/pmc.log 2>&1
 cp $R/gpurun_out/pmc/pmc_FETCH_SIZE.csv $R/gpurun_out/pmc/pmc_WRITE_SIZE.csv $R/gpurun_out/pmc/traffic.json $O/ 2>/dev/null
 head -30 $O/headline_kernel_stats.csv | cut -c1-150
 cat $O/traffic.json | head -5
+# other configurations (headline leg only)
+cd $R
+python bench.py --config C2 --no-visual --no-front-end --no-reference-baseline > $O/bench_c2.json 2> $O/bench_c2.err
+python bench.py --config C4 --steps 10 --warmup 2 --no-visual --no-front-end --no-cpu-baseline > $O/bench_c4_1gpu.json 2> $O/bench_c4.err
+tail -c 600 $O/bench_c2.json; tail -c 400 $O/bench_c4_1gpu.json; tail -3 $O/bench_c4.err
