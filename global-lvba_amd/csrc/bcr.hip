@@ -9,7 +9,7 @@
 // independently: ceil(log2(M / k)) levels of small dense work instead of n / 64 dependent steps.
 //
 //   level l, stride s = 2^l, active rows = multiples of s; odd ones i = (2m+1) s are eliminated:
-//     A  (one workgroup per odd row)   Dinv_i by Gauss-Jordan in LDS (SPD: no pivoting; a pivot <= 0 raises `status`),
+//     A  (one workgroup per odd row)   Dinv_i by Gauss-Jordan in registers (SPD: no pivoting; a pivot <= 0 raises `status`),
 //                                      T1_i = Dinv_i L_i, T2_i = Dinv_i L_{i+s}^T, t_i = Dinv_i rhs_i      (L_r = S[r, r - s])
 //     B  (one workgroup per even row)  D_r  -= L_r T2_{r-s} + L_{r+s}^T T1_{r+s}
 //                                      rhs_r -= L_r t_{r-s}  + L_{r+s}^T t_{r+s}
@@ -114,33 +114,52 @@ template <int BP>
 __global__ __launch_bounds__(256) void bcr_A_kernel(BcrDev p, int s, int *__restrict__ status)
 {
     constexpr int LD = BP + 1, PER = BP * BP / 256;
-    __shared__ double A[BP * LD], Inv[BP * LD], X[BP * LD];
-    __shared__ double col[BP], v[BP];
+    __shared__ double Inv[BP * LD], X[BP * LD];
+    __shared__ double v[BP];
     const int tid = threadIdx.x;
     const int i = s > 0 ? (2 * (int)blockIdx.x + 1) * s : 0;
     const int q = s > 0 ? i + s : p.nb; // right neighbour, if any
-    load_tile<BP>(A, p.D + (int64_t)i * BP * BP, true);
-    for (int e = tid; e < BP * BP; e += 256) Inv[(e / BP) * LD + (e % BP)] = (e / BP == e % BP) ? 1.0 : 0.0;
+    // Gauss-Jordan on [A | Inv] with the entries in REGISTERS: thread t owns column c = t % BP of rows r_j = t / BP + (256 / BP) j
+    // of both halves.  Per pivot only the pivot row and the pivot column travel through LDS (double-buffered: one barrier per
+    // pivot); A is symmetric positive definite, so the pivots are taken in order.
+    constexpr int RPT = BP * BP / 256, RS = 256 / BP; // rows per thread and their stride
+    __shared__ double colb[2][BP], rowa[2][BP], rowi[2][BP];
+    const int c = tid % BP, rb = tid / BP;
+    double a[RPT], v_[RPT];
+    {
+        const double *Dg = p.D + (int64_t)i * BP * BP;
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            const int r = rb + RS * j;
+            a[j] = Dg[r * BP + c];
+            v_[j] = (r == c) ? 1.0 : 0.0;
+        }
+    }
     if (tid < BP) v[tid] = p.rhs[(int64_t)i * BP + tid];
-    __syncthreads();
-    // Gauss-Jordan on [A | Inv]; A is symmetric positive definite, so the pivots are taken in order
+#pragma unroll 1
     for (int kk = 0; kk < BP; ++kk) {
-        if (tid < BP) col[tid] = A[tid * LD + kk];
-        __syncthreads();
-        const double piv = col[kk];
-        if (tid == 0 && !(piv > 0.0)) status[0] = 1;
-        const double rp = 1.0 / piv;
-        if (tid < BP) A[kk * LD + tid] *= rp;
-        else if (tid < 2 * BP) Inv[kk * LD + (tid - BP)] *= rp;
-        __syncthreads();
-        for (int e = tid; e < 2 * BP * BP; e += 256) {
-            const int half = e / (BP * BP), f = e - half * BP * BP, r = f / BP, c = f % BP;
-            if (r == kk) continue;
-            double *Mx = half ? Inv : A;
-            Mx[r * LD + c] -= col[r] * Mx[kk * LD + c];
+        const int pb = kk & 1;
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            const int r = rb + RS * j;
+            if (c == kk) colb[pb][r] = a[j];
+            if (r == kk) { rowa[pb][c] = a[j]; rowi[pb][c] = v_[j]; }
         }
         __syncthreads();
+        const double piv = colb[pb][kk];
+        if (tid == 0 && !(piv > 0.0)) status[0] = 1;
+        const double rp = 1.0 / piv;
+        const double ra = rowa[pb][c] * rp, ri = rowi[pb][c] * rp;
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            const int r = rb + RS * j;
+            if (r == kk) { a[j] = ra; v_[j] = ri; }
+            else { const double f = colb[pb][r]; a[j] -= f * ra; v_[j] -= f * ri; }
+        }
     }
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) Inv[(rb + RS * j) * LD + c] = v_[j];
+    __syncthreads();
     // T1 = Inv L_i, T2 = Inv L_q^T, t = Inv rhs_i
     double C[PER];
     load_tile<BP>(X, p.L + (int64_t)i * BP * BP, s > 0);
