@@ -439,10 +439,10 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
     if (bs.use_band) {
         const int64_t ldab = bw + LVBA_NB + 64;
         bs.A.ld = ldab - 1; bs.A.bw = bw;
-        TRY(bs_dmalloc(bs, &bs.d_A, 2 * (ldab * (n + 1)) + ldab)); // room for the second matrix of the twisted factorisation
+        TRY(bs_dmalloc(bs, &bs.d_A, 2 * (ldab * (n + 1)) + 65 * ldab)); // room for the second matrix of the twisted factorisation (+ slack: edge tiles read past the window, ldlt.hip)
     } else {
         bs.A.ld = n; bs.A.bw = n - 1;
-        TRY(bs_dmalloc(bs, &bs.d_A, n * n));
+        TRY(bs_dmalloc(bs, &bs.d_A, n * n + 64 * n + 128)); // (+ slack: edge tiles read past the window, ldlt.hip)
     }
     bs.A.a = bs.d_A;
     TRY(bs_dmalloc(bs, &bs.d_work, ldlt_workspace_doubles(n, bs.A.bw)));

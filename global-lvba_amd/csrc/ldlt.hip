@@ -655,27 +655,223 @@ __global__ __launch_bounds__(256) void ldlt_update_kernel(LdltMat M, int64_t k, 
     update_tile(lds, M, k, nbe, w0, rend, Zws, ldz, ti, tj);
 }
 
-// One launch for two independent pieces of work: the factorisation of panel p+1 (diag + panel tiles, blocks [0, T2)) and the
-// bulk of the trailing update of panel p (tiles ti >= tj >= 1, the remaining blocks).  The former touches block column
-// p+1 only, the latter block columns >= p+2, and neither waits for the other inside the launch -- the only ordering is
-// between launches: update(first column of p) -> this -> update(first column of p+1).  The 20 us serial factorisation is
-// thereby hidden behind the HBM-bound update instead of preceding it.
-__global__ __launch_bounds__(256) void ldlt_step_kernel(LdltMat M, int64_t k2, int nbe2, int64_t w02, int64_t rend2, int T2,
-                                                        double *__restrict__ G2, double *__restrict__ dvec,
-                                                        double *__restrict__ Zws2, double *__restrict__ b,
-                                                        int *__restrict__ status, int64_t k, int nbe, int64_t w0, int64_t rend,
-                                                        const double *__restrict__ Zws, int64_t ldz, int64_t sA, int64_t sW,
-                                                        int64_t ke, int nbe_e, int64_t w0e, int64_t rend_e,
-                                                        const double *__restrict__ Zwe, int64_t tile0)
+// ------------------------------------------------------------------------------------ K3, 128 x 64 tiles
+// The bulk of the trailing update as 128 x 64 tiles (two tile rows of one tile column), K in chunks of 32 columns, for one
+// panel (K = 64) or a pair of panels (K = 128, panel e's columns first).  Measured on the 64 x 64 form (2 problems x 414 tiles
+// of a paired update, tools/step_microbench): L / Z operand loads 6 us (L2-bound), C load + store 8 us (HBM-bound), MFMA + LDS
+// 15 us -- and 34 us in total, because every workgroup did them one after the other and the two workgroups of a CU in step.  Here
+//   * while the products of a chunk run from LDS, the next chunk's operands are on their way into registers, and the C entries
+//     are fetched beside the last chunk's products;
+//   * a wavefront owns 32 rows x 64 columns: 6 LDS operand reads per 8 MFMAs (5 per 4 before), and the Z rows are fetched once
+//     per 128 rows of L;
+//   * operands move 16 bytes per lane (two rows of a column), C entries as the MFMA layout has them;
+//   * a paired update of both problems is ~410 workgroups: one round of the 2 x 256 slots the factorisation's LDS leaves.
+struct PanelRef { int64_t k, w0, rend; int nbe; const double *Z; };
+typedef __attribute__((address_space(1))) double gdouble;
+typedef __attribute__((address_space(1))) char gchar;
+#define LVBA_TL 144 // LDS stride of an L chunk column (128 rows), 16 mod 32 like LVBA_TS
+#define LVBA_K3B_LDS (32 * LVBA_TL + 32 * LVBA_TS) // doubles
+// column-major enumeration of the 128 x 64 tiles of tile columns [ca, cb) of a Tb x Tb lower triangle: column tj holds the row
+// pairs (tj + 2u, tj + 2u + 1), u < (Tb - tj + 1) / 2 (the last pair of a column may be a single tile row)
+__host__ __device__ __forceinline__ int64_t pair_col_items(int64_t tj, int64_t Tb) { return (Tb - tj + 1) / 2; }
+__device__ __forceinline__ bool pair_decode(int64_t j, int64_t ca, int64_t cb, int64_t Tb, int64_t &R0, int64_t &tj)
+{
+    for (int64_t c = ca; c < cb; ++c) {
+        const int64_t n = pair_col_items(c, Tb);
+        if (j < n) { tj = c; R0 = c + 2 * j; return true; }
+        j -= n;
+    }
+    return false;
+}
+// Buffer addressing (resource + 32-bit lane offset + 32-bit scalar offset): the 60 loads / 32 stores of a tile then need three
+// lane-offset registers between them; as flat 64-bit pointers their addresses alone filled > 100 VGPRs and spilled.
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+#define LVBA_BUF_WORD3 0x00020000 // raw buffer, 32-bit data format (gfx90a / gfx94x / gfx950)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_of(const double *p)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p), 0, 0xFFFFFFF0u, LVBA_BUF_WORD3); // no range to check against
+}
+__device__ __forceinline__ double buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    const v2u a = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return __hiloint2double(a.y, a.x);
+}
+__device__ __forceinline__ double2 buf_ld2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    const v4u a = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_double2(__hiloint2double(a.y, a.x), __hiloint2double(a.w, a.z));
+}
+__device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, double v, unsigned voff, unsigned soff)
+{
+    const v2u a = {(unsigned)__double2loint(v), (unsigned)__double2hiint(v)};
+    __builtin_amdgcn_raw_buffer_store_b64(a, r, voff, soff, 0);
+}
+__device__ __forceinline__ void bulk_tile_128(double *lds, LdltMat M, const PanelRef po, const PanelRef pe, int64_t ldz64, int64_t R0,
+                                              int64_t tj)
+{
+    double *Ls = lds, *Zs = lds + 32 * LVBA_TL; // Ls[m][row 0..127], Zs[m][row 0..63], m = column of the chunk
+    const int tid = threadIdx.x, lane = tid & 63;
+    const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, kk = lane >> 4;
+    const int64_t r0 = po.w0 + 64 * (R0 + 1), c0 = po.w0 + 64 * (tj + 1);
+    const int nch = pe.Z ? 4 : 2;
+    const bool two = r0 + 64 < po.rend; // the second tile row exists (else wavefronts 2, 3 have nothing to multiply)
+    // all offsets below are BYTES in 32 bits: one problem's band storage is < 2^32 bytes (ld * n * 8 = 256 MB at C3)
+    const unsigned ld = (unsigned)M.ld, ldz = (unsigned)ldz64;
+    const __amdgpu_buffer_rsrc_t rA = buf_of(M.a), rZo = buf_of(po.Z), rZe = buf_of(pe.Z ? pe.Z : po.Z);
+    // operand fetch: L chunk = 128 rows x 32 columns, lane -> rows 2 lane, 2 lane + 1 of column w + 4 it (it < 8);
+    //                Z chunk =  64 rows x 32 columns, lane -> rows 2 (lane & 31), + 1 of column 2 (w + 4 it) + (lane >> 5) (it < 4)
+    // one register array for the chunk in flight (L: xs[0..15], Z: xs[16..23]) and, after the last chunk, the C entries (xs[0..31]):
+    // as separate arrays the compiler gives them registers of their own and spills
+    double xs[32];
+    const int lrow = 2 * lane, zrow = 2 * (lane & 31), zc = lane >> 5;
+    const unsigned lvoff = 8u * (unsigned)lrow, zvoff = 8u * ((unsigned)zrow + (unsigned)zc * ldz);
+    auto fetch = [&](int ch) {
+        const bool use_e = nch == 4 && ch < 2;
+        const unsigned qk = (unsigned)(use_e ? pe.k : po.k), zr = (unsigned)(c0 - (use_e ? pe.w0 : po.w0));
+        const unsigned m0 = 32u * (unsigned)(ch & 1);
+        const unsigned lsoff = 8u * ((unsigned)r0 + (qk + m0 + w) * ld), zsoff = 8u * (zr + (m0 + 2u * w) * ldz);
+        // unconditional: what lies outside the window is masked when it is stored to LDS (the band storage's columns overlap
+        // their neighbours', and block_system.hip leaves slack behind the last one)
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const double2 v = buf_ld2(rA, lvoff, lsoff + (unsigned)it * (32u * ld));
+            xs[2 * it] = v.x; xs[2 * it + 1] = v.y;
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const double2 v = buf_ld2(use_e ? rZe : rZo, zvoff, zsoff + (unsigned)it * (64u * ldz));
+            xs[16 + 2 * it] = v.x; xs[17 + 2 * it] = v.y;
+        }
+    };
+    auto stage = [&](int ch) { // registers -> LDS, masking rows / columns outside the panel's window
+        const bool use_e = nch == 4 && ch < 2;
+        const int64_t qrend = use_e ? pe.rend : po.rend;
+        const int qnbe = use_e ? pe.nbe : po.nbe;
+        const int m0 = 32 * (ch & 1);
+        if (!(r0 + 128 <= qrend && c0 + 64 <= qrend && qnbe == 64)) { // edge tiles only (wave-uniform)
+            const bool l0 = r0 + lrow < qrend, l1 = r0 + lrow + 1 < qrend;
+            const bool z0 = c0 + zrow < qrend, z1 = c0 + zrow + 1 < qrend;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const bool mok = m0 + (int)w + 4 * it < qnbe;
+                xs[2 * it] = (l0 && mok) ? xs[2 * it] : 0.0;
+                xs[2 * it + 1] = (l1 && mok) ? xs[2 * it + 1] : 0.0;
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const bool mok = m0 + 2 * ((int)w + 4 * it) + zc < qnbe;
+                xs[16 + 2 * it] = (z0 && mok) ? xs[16 + 2 * it] : 0.0;
+                xs[17 + 2 * it] = (z1 && mok) ? xs[17 + 2 * it] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) *reinterpret_cast<double2 *>(Ls + (w + 4 * it) * LVBA_TL + lrow) = make_double2(xs[2 * it], xs[2 * it + 1]);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) *reinterpret_cast<double2 *>(Zs + (2 * (w + 4 * it) + zc) * LVBA_TS + zrow) = make_double2(xs[16 + 2 * it], xs[17 + 2 * it]);
+    };
+    // wavefront w: rows 32 w .. 32 w + 31 (two 16-row blocks tl) x 64 columns (four 16-column blocks cq);
+    // acc[tl][cq][reg] <-> row r0 + 32 w + 16 tl + i, column c0 + 16 cq + kk + 4 reg
+    d4 acc[2][4];
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+        for (int cq = 0; cq < 4; ++cq) acc[tl][cq] = (d4){0.0, 0.0, 0.0, 0.0};
+    const bool busy = two || w < 2;
+    const unsigned cvoff = 8u * ((unsigned)i + (unsigned)kk * ld);                 // lane part of a C entry's offset
+    const unsigned csoff = 8u * ((unsigned)r0 + 32u * w + (unsigned)c0 * ld);      // + 128 tl, + 8 (16 cq + 4 reg) ld
+    // iteration ch: chunk ch's operands set off for the registers (after the last chunk: the C entries instead), the products of
+    // chunk ch - 1 run from LDS, then chunk ch is staged.  One site per piece of code: unrolled, the four fetches and the C
+    // entries are all held in registers at once and spill.
+#pragma unroll 1
+    for (int ch = 0; ch <= nch; ++ch) {
+        if (ch < nch) fetch(ch);
+        else if (busy) { // needed after the last chunk's products, which run below.  Unmasked: entries outside the window or above
+                         // the diagonal are read (inside the allocation, see block_system.hip) but never stored
+#pragma unroll
+            for (int cq = 0; cq < 4; ++cq)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const unsigned so = csoff + 8u * (unsigned)(16 * cq + 4 * reg) * ld;
+#pragma unroll
+                    for (int tl = 0; tl < 2; ++tl) xs[16 * tl + 4 * cq + reg] = buf_ld(rA, cvoff + 128u * tl, so);
+                }
+        }
+        if (ch > 0 && busy) {
+#pragma unroll 2
+            for (int k0 = 0; k0 < 32; k0 += 4) {
+                double a[4], bv[2];
+#pragma unroll
+                for (int cq = 0; cq < 4; ++cq) a[cq] = Zs[(k0 + kk) * LVBA_TS + 16 * cq + i];
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl) bv[tl] = Ls[(k0 + kk) * LVBA_TL + 32 * w + 16 * tl + i];
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+                    for (int cq = 0; cq < 4; ++cq) acc[tl][cq] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cq], bv[tl], acc[tl][cq], 0, 0, 0);
+            }
+        }
+        if (ch < nch) {
+            if (ch > 0) __syncthreads(); // everybody is done with chunk ch - 1 in LDS
+            stage(ch);
+            __syncthreads();
+        }
+    }
+    if (busy) {
+        const bool inner = r0 + 128 <= po.rend && r0 > c0; // whole tile inside the window and below the diagonal
+#pragma unroll
+        for (int cq = 0; cq < 4; ++cq)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const unsigned so = csoff + 8u * (unsigned)(16 * cq + 4 * reg) * ld;
+                const int64_t c = c0 + 16 * cq + kk + 4 * reg;
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl) {
+                    const int64_t r = r0 + 32 * w + 16 * tl + i;
+                    if (inner || (r < po.rend && c < po.rend && r >= c))
+                        buf_st(rA, xs[16 * tl + 4 * cq + reg] - acc[tl][cq][reg], cvoff + 128u * tl, so);
+                }
+            }
+    }
+}
+
+// One launch for two independent pieces of work: the factorisation of panel p+1 (diag + panel tiles) and the bulk of the
+// trailing update of panel p (tiles ti >= tj >= 1).  The former touches block column p+1 only, the latter block columns >= p+2,
+// and neither waits for the other inside the launch -- the only ordering is between launches: update(first column of p) -> this
+// -> update(first column of p+1).  The 20 us serial factorisation is thereby hidden behind the update instead of preceding it.
+// Block order: the factorisation workgroups of ALL problems first (nprob = 2: both ends of a twisted factorisation; a
+// blockIdx.y per problem put the second problem's factorisation behind the first problem's ~800 update tiles in dispatch order
+// and made the launch ~10 us longer than its critical path), then the update workgroups, alternating between the problems.
+// big = true: 128 x 64 update tiles (bulk_tile_128) of the tile columns [ca, cb); false: the 64 x 64 tiles [ca, cb) of the
+// column-major enumeration (update_tile / update_tile2; LVBA_BULK=64, A/B).
+template <bool big>
+__global__ __launch_bounds__(256, 2) void ldlt_step_kernel(LdltMat M, int64_t k2, int nbe2, int64_t w02, int64_t rend2, int T2,
+                                                           double *__restrict__ G2, double *__restrict__ dvec,
+                                                           double *__restrict__ Zws2, double *__restrict__ b,
+                                                           int *__restrict__ status, int64_t k, int nbe, int64_t w0, int64_t rend,
+                                                           const double *__restrict__ Zws, int64_t ldz, int64_t sA, int64_t sW,
+                                                           int64_t ke, int nbe_e, int64_t w0e, int64_t rend_e,
+                                                           const double *__restrict__ Zwe, int64_t ca, int64_t cb, int nprob)
 {
     __shared__ double lds[LVBA_K3_LDS];
-    static_assert(LVBA_K12_LDS <= LVBA_K3_LDS, "factorisation tables must fit the update's LDS");
-    if (blockIdx.y) { M.a += sA; G2 += sW; dvec += sW; Zws2 += sW; b += sW; Zws += sW; if (Zwe) Zwe += sW; }
-    if ((int)blockIdx.x < T2) {
-        diagpanel_tile(lds, M, k2, nbe2, w02, rend2, G2, dvec, Zws2, ldz, b, status, blockIdx.x);
+    static_assert(LVBA_K12_LDS <= LVBA_K3_LDS && LVBA_K3B_LDS <= LVBA_K3_LDS, "factorisation tables / 128 x 64 chunks must fit the update's LDS");
+    const int64_t nfac = (int64_t)T2 * nprob;
+    int prob;
+    int64_t bx;
+    if ((int64_t)blockIdx.x < nfac) { prob = (int)(blockIdx.x / T2); bx = blockIdx.x - (int64_t)prob * T2; }
+    else { const int64_t bb = blockIdx.x - nfac; prob = (int)(bb % nprob); bx = bb / nprob; }
+    if (prob) { M.a += sA; G2 += sW; dvec += sW; Zws2 += sW; b += sW; Zws += sW; if (Zwe) Zwe += sW; }
+    if ((int64_t)blockIdx.x < nfac) {
+        diagpanel_tile(lds, M, k2, nbe2, w02, rend2, G2, dvec, Zws2, ldz, b, status, bx);
+    } else if constexpr (big) {
+        int64_t R0, tj;
+        if (!pair_decode(bx, ca, cb, (rend - w0 + 63) / 64 - 1, R0, tj)) return;
+        const PanelRef po{k, w0, rend, nbe, Zws}, pe{ke, w0e, rend_e, nbe_e, Zwe};
+        bulk_tile_128(lds, M, po, pe, ldz, R0, tj);
     } else {
-        int64_t ti, tj; // bulk tiles (ti >= tj >= 1 of the window) in column-major order, from tile0 on
-        col_decode(tile0 + (int64_t)blockIdx.x - T2, (rend - w0 + 63) / 64 - 1, ti, tj);
+        int64_t ti, tj; // bulk tiles (ti >= tj >= 1 of the window) in column-major order
+        col_decode(ca + bx, (rend - w0 + 63) / 64 - 1, ti, tj);
         if (Zwe) update_tile2(lds, M, k, nbe, w0, rend, Zws, ke, nbe_e, w0e, rend_e, Zwe, ldz, ti + 1, tj + 1); // with the partner panel
         else update_tile(lds, M, k, nbe, w0, rend, Zws, ldz, ti + 1, tj + 1);
     }
@@ -970,12 +1166,23 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
         const int64_t T2 = fac ? q2.T : 0;
         const Geo z{0, 0, 0, 0, 0};
         const Geo &B = qb ? *qb : z;
-        if (T2 + nb3 > 0)
-            hipLaunchKernelGGL(ldlt_step_kernel, dim3((unsigned)(T2 + nb3), ny), dim3(256), 0, s, second ? M2 : M, q2.k, q2.nbe, q2.w0, q2.rend,
+        // LVBA_BULK = 128 (default: 128 x 64 update tiles) | 64 (one 64 x 64 tile per workgroup; A/B)
+        static const bool big = [] { const char *e = getenv("LVBA_BULK"); return !(e && !strcmp(e, "64")); }();
+        int64_t ca = t0, cb = t1, nbu = nb3; // 64 x 64: the tile range itself
+        if (big && nb3 > 0) { // t0, t1 are column starts: tile columns [ca, cb), 128 x 64 tiles
+            const int64_t Tb = B.T - 1;
+            ca = 0; cb = Tb;
+            while (ca < Tb && col_start(ca, Tb) < t0) ++ca;
+            while (cb > ca && col_start(cb, Tb) > t1) --cb;
+            nbu = 0;
+            for (int64_t c = ca; c < cb; ++c) nbu += pair_col_items(c, Tb);
+        }
+        if (T2 + nbu > 0)
+            hipLaunchKernelGGL(big ? ldlt_step_kernel<true> : ldlt_step_kernel<false>, dim3((unsigned)((T2 + nbu) * ny)), dim3(256), 0, s, second ? M2 : M, q2.k, q2.nbe, q2.w0, q2.rend,
                                (int)T2, Gall + wo + (st + 1) * 4096, dvec + wo, Zbuf[(st + 1) % 4] + wo, b + wo, status, B.k, B.nbe, B.w0,
                                B.rend, (const double *)(Zbuf[(sb_ % 4 + 4) % 4] + wo), ldz, tw.sA, tw.sW, qe ? qe->k : 0, qe ? qe->nbe : 0,
                                qe ? qe->w0 : 0, qe ? qe->rend : 0,
-                               qe ? (const double *)(Zbuf[((sb_ - 1) % 4 + 4) % 4] + wo) : (const double *)nullptr, t0);
+                               qe ? (const double *)(Zbuf[((sb_ - 1) % 4 + 4) % 4] + wo) : (const double *)nullptr, ca, cb, (int)ny);
     };
     // LVBA_RANK128=0: every panel applies its own bulk update (A/B)
     static const bool rank128 = [] { const char *e = getenv("LVBA_RANK128"); return !(e && !strcmp(e, "0")); }();

@@ -2,7 +2,7 @@
 # quick check: BALM parity tests + stage times of the headline leg (optionally under several env settings given as args)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/quick; mkdir -p $O
 cd $R
-python -m pytest tests/test_gpu_balm.py tests/test_gpu_multirank.py -q -x -p no:cacheprovider 2>&1 | tail -2
+python -m pytest tests/test_gpu_balm.py tests/test_gpu_multirank.py -q -x -p no:cacheprovider 2>&1 | tail -15
 i=0
 for e in "${@:-LVBA_X=0}"; do
   i=$((i+1))
