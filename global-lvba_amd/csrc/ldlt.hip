@@ -707,6 +707,7 @@ __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, double v, unsig
     const v2u a = {(unsigned)__double2loint(v), (unsigned)__double2hiint(v)};
     __builtin_amdgcn_raw_buffer_store_b64(a, r, voff, soff, 0);
 }
+template <int nch> // K chunks of 32: 2 = one panel, 4 = a pair (pe, then po)
 __device__ __forceinline__ void bulk_tile_128(double *lds, LdltMat M, const PanelRef po, const PanelRef pe, int64_t ldz64, int64_t R0,
                                               int64_t tj)
 {
@@ -715,19 +716,19 @@ __device__ __forceinline__ void bulk_tile_128(double *lds, LdltMat M, const Pane
     const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, kk = lane >> 4;
     const int64_t r0 = po.w0 + 64 * (R0 + 1), c0 = po.w0 + 64 * (tj + 1);
-    const int nch = pe.Z ? 4 : 2;
     const bool two = r0 + 64 < po.rend; // the second tile row exists (else wavefronts 2, 3 have nothing to multiply)
     // all offsets below are BYTES in 32 bits: one problem's band storage is < 2^32 bytes (ld * n * 8 = 256 MB at C3)
     const unsigned ld = (unsigned)M.ld, ldz = (unsigned)ldz64;
-    const __amdgpu_buffer_rsrc_t rA = buf_of(M.a), rZo = buf_of(po.Z), rZe = buf_of(pe.Z ? pe.Z : po.Z);
+    const __amdgpu_buffer_rsrc_t rA = buf_of(M.a), rZo = buf_of(po.Z), rZe = buf_of(nch == 4 ? pe.Z : po.Z);
     // operand fetch: L chunk = 128 rows x 32 columns, lane -> rows 2 lane, 2 lane + 1 of column w + 4 it (it < 8);
     //                Z chunk =  64 rows x 32 columns, lane -> rows 2 (lane & 31), + 1 of column 2 (w + 4 it) + (lane >> 5) (it < 4)
-    // one register array for the chunk in flight (L: xs[0..15], Z: xs[16..23]) and, after the last chunk, the C entries (xs[0..31]):
-    // as separate arrays the compiler gives them registers of their own and spills
-    double xs[32];
+    // Two register sets: the chunk being staged and the next one in flight (L: [0..15], Z: [16..23]); set A also takes the C
+    // entries ([0..31]) once the last even chunk has left it -- as arrays of their own the compiler gives them registers of
+    // their own and spills.
+    double xa[32], xb[24];
     const int lrow = 2 * lane, zrow = 2 * (lane & 31), zc = lane >> 5;
     const unsigned lvoff = 8u * (unsigned)lrow, zvoff = 8u * ((unsigned)zrow + (unsigned)zc * ldz);
-    auto fetch = [&](int ch) {
+    auto fetch = [&](int ch, double *xs) {
         const bool use_e = nch == 4 && ch < 2;
         const unsigned qk = (unsigned)(use_e ? pe.k : po.k), zr = (unsigned)(c0 - (use_e ? pe.w0 : po.w0));
         const unsigned m0 = 32u * (unsigned)(ch & 1);
@@ -745,7 +746,7 @@ __device__ __forceinline__ void bulk_tile_128(double *lds, LdltMat M, const Pane
             xs[16 + 2 * it] = v.x; xs[17 + 2 * it] = v.y;
         }
     };
-    auto stage = [&](int ch) { // registers -> LDS, masking rows / columns outside the panel's window
+    auto stage = [&](int ch, double *xs) { // registers -> LDS, masking rows / columns outside the panel's window
         const bool use_e = nch == 4 && ch < 2;
         const int64_t qrend = use_e ? pe.rend : po.rend;
         const int qnbe = use_e ? pe.nbe : po.nbe;
@@ -779,44 +780,57 @@ __device__ __forceinline__ void bulk_tile_128(double *lds, LdltMat M, const Pane
 #pragma unroll
         for (int cq = 0; cq < 4; ++cq) acc[tl][cq] = (d4){0.0, 0.0, 0.0, 0.0};
     const bool busy = two || w < 2;
+    auto products = [&]() { // the chunk in LDS.  The operands of step k0 + 4 are read before the MFMAs of step k0 are issued: a
+                            // wavefront issues in order, and reads placed after them only start when the matrix pipe is draining
+        if (!busy) return;
+        double a[2][4], bv[2][2];
+        auto rd = [&](int k0, int q) {
+#pragma unroll
+            for (int cq = 0; cq < 4; ++cq) a[q][cq] = Zs[(k0 + kk) * LVBA_TS + 16 * cq + i];
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl) bv[q][tl] = Ls[(k0 + kk) * LVBA_TL + 32 * w + 16 * tl + i];
+        };
+        rd(0, 0);
+#pragma unroll
+        for (int k0 = 0; k0 < 32; k0 += 4) {
+            const int q = (k0 >> 2) & 1;
+            if (k0 + 4 < 32) rd(k0 + 4, q ^ 1);
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+                for (int cq = 0; cq < 4; ++cq) acc[tl][cq] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][cq], bv[q][tl], acc[tl][cq], 0, 0, 0);
+        }
+    };
     const unsigned cvoff = 8u * ((unsigned)i + (unsigned)kk * ld);                 // lane part of a C entry's offset
     const unsigned csoff = 8u * ((unsigned)r0 + 32u * w + (unsigned)c0 * ld);      // + 128 tl, + 8 (16 cq + 4 reg) ld
-    // iteration ch: chunk ch's operands set off for the registers (after the last chunk: the C entries instead), the products of
-    // chunk ch - 1 run from LDS, then chunk ch is staged.  One site per piece of code: unrolled, the four fetches and the C
-    // entries are all held in registers at once and spill.
-#pragma unroll 1
-    for (int ch = 0; ch <= nch; ++ch) {
-        if (ch < nch) fetch(ch);
-        else if (busy) { // needed after the last chunk's products, which run below.  Unmasked: entries outside the window or above
-                         // the diagonal are read (inside the allocation, see block_system.hip) but never stored
+    // Chunk c is staged from its register set (even chunks: A, odd: B) and the set is refilled at once with chunk c + 2, which
+    // then has the products of two chunks to arrive in.  After the last even chunk, set A takes the C entries instead.
+    // (fully unrolled: inside a loop the compiler's wait counts at the back edge drain every load in flight)
+    fetch(0, xa);
+    fetch(1, xb);
+#pragma unroll
+    for (int ch = 0; ch < nch; ch += 2) {
+        if (ch > 0) __syncthreads(); // everybody is done with chunk ch - 1 in LDS
+        stage(ch, xa);
+        __syncthreads();
+        if (ch + 2 < nch) fetch(ch + 2, xa);
+        else if (busy) { // Unmasked: entries outside the window or above the diagonal are read (inside the allocation, see
+                         // block_system.hip) but never stored
 #pragma unroll
             for (int cq = 0; cq < 4; ++cq)
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const unsigned so = csoff + 8u * (unsigned)(16 * cq + 4 * reg) * ld;
 #pragma unroll
-                    for (int tl = 0; tl < 2; ++tl) xs[16 * tl + 4 * cq + reg] = buf_ld(rA, cvoff + 128u * tl, so);
+                    for (int tl = 0; tl < 2; ++tl) xa[16 * tl + 4 * cq + reg] = buf_ld(rA, cvoff + 128u * tl, so);
                 }
         }
-        if (ch > 0 && busy) {
-#pragma unroll 2
-            for (int k0 = 0; k0 < 32; k0 += 4) {
-                double a[4], bv[2];
-#pragma unroll
-                for (int cq = 0; cq < 4; ++cq) a[cq] = Zs[(k0 + kk) * LVBA_TS + 16 * cq + i];
-#pragma unroll
-                for (int tl = 0; tl < 2; ++tl) bv[tl] = Ls[(k0 + kk) * LVBA_TL + 32 * w + 16 * tl + i];
-#pragma unroll
-                for (int tl = 0; tl < 2; ++tl)
-#pragma unroll
-                    for (int cq = 0; cq < 4; ++cq) acc[tl][cq] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cq], bv[tl], acc[tl][cq], 0, 0, 0);
-            }
-        }
-        if (ch < nch) {
-            if (ch > 0) __syncthreads(); // everybody is done with chunk ch - 1 in LDS
-            stage(ch);
-            __syncthreads();
-        }
+        products();
+        __syncthreads();
+        stage(ch + 1, xb);
+        __syncthreads();
+        if (ch + 3 < nch) fetch(ch + 3, xb);
+        products();
     }
     if (busy) {
         const bool inner = r0 + 128 <= po.rend && r0 > c0; // whole tile inside the window and below the diagonal
@@ -830,7 +844,7 @@ __device__ __forceinline__ void bulk_tile_128(double *lds, LdltMat M, const Pane
                 for (int tl = 0; tl < 2; ++tl) {
                     const int64_t r = r0 + 32 * w + 16 * tl + i;
                     if (inner || (r < po.rend && c < po.rend && r >= c))
-                        buf_st(rA, xs[16 * tl + 4 * cq + reg] - acc[tl][cq][reg], cvoff + 128u * tl, so);
+                        buf_st(rA, xa[16 * tl + 4 * cq + reg] - acc[tl][cq][reg], cvoff + 128u * tl, so);
                 }
             }
     }
@@ -868,7 +882,8 @@ __global__ __launch_bounds__(256, 2) void ldlt_step_kernel(LdltMat M, int64_t k2
         int64_t R0, tj;
         if (!pair_decode(bx, ca, cb, (rend - w0 + 63) / 64 - 1, R0, tj)) return;
         const PanelRef po{k, w0, rend, nbe, Zws}, pe{ke, w0e, rend_e, nbe_e, Zwe};
-        bulk_tile_128(lds, M, po, pe, ldz, R0, tj);
+        if (Zwe) bulk_tile_128<4>(lds, M, po, pe, ldz, R0, tj);
+        else bulk_tile_128<2>(lds, M, po, pe, ldz, R0, tj);
     } else {
         int64_t ti, tj; // bulk tiles (ti >= tj >= 1 of the window) in column-major order
         col_decode(ca + bx, (rend - w0 + 63) / 64 - 1, ti, tj);
