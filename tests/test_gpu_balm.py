@@ -4,6 +4,8 @@ Tolerances: the path is fp64; lambda_min (~1e-4) is a cancellation of second mom
 correct fp64 implementations agree to ~1e-9 relative per voxel.  north_star's bar is 1e-5 relative on
 per-iteration cost and final poses; these tests hold 1e-7 or tighter.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -420,3 +422,44 @@ def test_voxel_order_unrelated_to_the_poses(pkg):
     xa, ta, _ = a.refine(d["poses_init"])
     xb, tb, _ = b.refine(d["poses_init"])
     assert len(ta) == len(tb) and np.abs(xa - xb).max() <= 1e-8
+
+
+_SCHEDULE_SCRIPT = r"""
+import importlib, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+pkg = importlib.import_module("global-lvba_amd")
+synth = importlib.import_module("global-lvba_amd.synth")
+d = synth.make_balm_problem(700, 30000, band=12, loop_frac=0.0, seed=5)
+prob = pkg.BalmProblem(700, d["voxel_off"], d["pose_idx"], d["clusters"])
+prob.eval(d["poses_init"], want_H=False, want_g=False)
+info = prob.info()
+dx = prob.solve(0.01)
+np.save(sys.argv[2], np.concatenate([dx.ravel(), [info["use_band"], info["twist_panels"]]]))
+"""
+
+
+def test_solver_schedules(tmp_path):
+    """The launch schedule of the band LDL^T has several forms behind environment switches (read once per process): the
+    default (both ends at once, paired panels, 128 x 64 update tiles), and for A/B the former ones.  Every form must give
+    the same solution of the same damped system (they differ in summation order only): 4200 unknowns, half-bandwidth ~150,
+    enough panels for the two-ended form and the pairing to be active."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "run.py"
+    script.write_text(_SCHEDULE_SCRIPT)
+    variants = [{}, {"LVBA_FUSE": "1"}, {"LVBA_BULK": "64"}, {"LVBA_RANK128": "0"}, {"LVBA_TWIST": "0"},
+                {"LVBA_SCHEDULE": "serial"}, {"LVBA_FUSE": "1", "LVBA_RANK128": "0"}, {"LVBA_FUSE": "1", "LVBA_TWIST": "0"}]
+    out = []
+    for i, v in enumerate(variants):
+        f = tmp_path / f"dx_{i}.npy"
+        env = dict(os.environ, **v)
+        r = subprocess.run([sys.executable, str(script), root, str(f)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (v, r.stderr[-2000:])
+        out.append(np.load(f))
+    ref = out[0]
+    assert ref[-2] == 1 and ref[-1] >= 4, ref[-2:]          # band storage, factorised from both ends
+    assert np.isfinite(ref).all()
+    for v, o in zip(variants[1:], out[1:]):
+        assert np.abs(o[:-2] - ref[:-2]).max() <= 1e-9 * np.abs(ref[:-2]).max(), v
