@@ -221,7 +221,14 @@ def main():
             {"kernel": "damped LDL^T solve (ldlt_diagpanel/step/update/back kernels)", "bound": "mfma",
              "achieved": flops_solve / sv_ms / 1e9, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
              "frac": flops_solve / sv_ms / 1e9 / FP64_PEAK_TFLOPS, "traffic": None,
-             "algorithmic_flops": flops_solve, "avg_ms": sv_ms},
+             "algorithmic_flops": flops_solve, "avg_ms": sv_ms,
+             # the second bound: every C tile of a panel's window is read and written once per PAIR of 64-column panels
+             # (rank-128 update: 2 * 128 flops per 16 bytes moved), so HBM caps the trailing updates at 16 flop/B
+             "hbm_bound": {"flop_per_byte": 16.0, "peak": 16.0 * HBM_PEAK_GBS / 1e3, "unit": "TFLOP/s",
+                           "frac": flops_solve / sv_ms / 1e9 / (16.0 * HBM_PEAK_GBS / 1e3),
+                           "note": "above the MFMA peak since the panels are paired (8 flop/B -> 64 TFLOP/s with "
+                                   "single panels): the matrix pipe and the serial chain of panel factorisations "
+                                   "(~19 us each, 115 of them) bound the solve, not HBM"}},
         ]
         out = {
             "metric": "LM iterations/sec, 2k poses x 10M LiDAR factors (BALM damping_iter)",
