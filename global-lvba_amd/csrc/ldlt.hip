@@ -1061,10 +1061,14 @@ __global__ __launch_bounds__(256) void ldlt_back_kernel(LdltMat M, int64_t k, in
 // earlier launch, and a launch holds at most 256 workgroups (one per CU), so the chain cannot starve.  Critical path per panel: poll round trip + one 64x64 tile-vector
 // product + two 64x64 mat-vecs out of LDS, ~3 us, against ~9 us for a kernel boundary per panel.
 #define LVBA_X_SENTINEL 0x7ff4dead5eed0001ULL
+// gridDim.y = 2: two independent chains of the same geometry in one launch -- matrix 1's T part and matrix 2's B part of a
+// twisted factorisation both start from x of S (blockIdx.y = 1: matrix 2 at a + sA / workspace + sW, solution vector x2).
 __global__ __launch_bounds__(256) void ldlt_back_chain_kernel(LdltMat M, int j_top, const double *__restrict__ Gall,
                                                               const double *__restrict__ dvec, const double *__restrict__ b,
-                                                              double *__restrict__ x)
+                                                              double *__restrict__ x, int64_t sA, int64_t sW,
+                                                              double *__restrict__ x2)
 {
+    if (blockIdx.y) { M.a += sA; Gall += sW; dvec += sW; b += sW; x = x2; }
     constexpr int LS = 65;
     __shared__ double Gs[64 * LS]; // [c][m] = G[m][c]
     __shared__ double bs[64], sd[64], red[4 * 64];
@@ -1386,18 +1390,34 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
         // at most 256 panels per launch: one workgroup per CU is then resident whatever else shares the device, so the
         // chain cannot starve even if workgroups were not dispatched in index order; later launches only read finished x
         // (a multi-rank job stops matrix 1's chain after the S panels unless this rank owns T)
+        if (side < 0 && P1 > 0) {
+            // one rank, both ends: S on matrix 1, then T (matrix 1) and B (matrix 2, from x of S reversed) side by side
+            for (int64_t top = nsteps - 1; top >= P1; top -= 256) {
+                const int64_t cnt = std::min<int64_t>(256, top - P1 + 1);
+                hipLaunchKernelGGL(ldlt_back_chain_kernel, dim3((unsigned)cnt), dim3(256), 0, s, M, (int)top, Gall, dvec, b, x, (int64_t)0, (int64_t)0, (double *)nullptr);
+            }
+            const int64_t ns = tw.n1 - tw.m;
+            hipLaunchKernelGGL(ldlt_twist_xs_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, s, tw, n, (const double *)x);
+            for (int64_t top = P1 - 1; top >= 0; top -= 128) { // 2 x 128 workgroups: one per CU, the chains cannot starve
+                const int64_t cnt = std::min<int64_t>(128, top + 1);
+                hipLaunchKernelGGL(ldlt_back_chain_kernel, dim3((unsigned)cnt, 2), dim3(256), 0, s, M, (int)top, Gall, dvec, b, x, tw.sA, tw.sW,
+                                   reinterpret_cast<double *>(tw.x2));
+            }
+            hipLaunchKernelGGL(ldlt_twist_xb_kernel, dim3((unsigned)((tw.m + 255) / 256)), dim3(256), 0, s, tw, n, x);
+            return LVBA_OK;
+        }
         const int64_t low = side >= 1 ? P1 : 0;
         for (int64_t top = nsteps - 1; top >= low; top -= 256) {
             const int64_t cnt = std::min<int64_t>(256, top - low + 1);
-            hipLaunchKernelGGL(ldlt_back_chain_kernel, dim3((unsigned)cnt), dim3(256), 0, s, M, (int)top, Gall, dvec, b, x);
+            hipLaunchKernelGGL(ldlt_back_chain_kernel, dim3((unsigned)cnt), dim3(256), 0, s, M, (int)top, Gall, dvec, b, x, (int64_t)0, (int64_t)0, (double *)nullptr);
         }
-        if (P1 > 0 && (side < 0 || side == 1)) { // matrix 2's B part: its chain starts from x of S (reversed)
+        if (P1 > 0 && side == 1) { // matrix 2's B part: its chain starts from x of S (reversed)
             const int64_t ns = tw.n1 - tw.m;
             hipLaunchKernelGGL(ldlt_twist_xs_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, s, tw, n, (const double *)x);
             for (int64_t top = P1 - 1; top >= 0; top -= 256) {
                 const int64_t cnt = std::min<int64_t>(256, top + 1);
                 hipLaunchKernelGGL(ldlt_back_chain_kernel, dim3((unsigned)cnt), dim3(256), 0, s, M2, (int)top, Gall + tw.sW, dvec + tw.sW,
-                                   b + tw.sW, reinterpret_cast<double *>(tw.x2));
+                                   b + tw.sW, reinterpret_cast<double *>(tw.x2), (int64_t)0, (int64_t)0, (double *)nullptr);
             }
             hipLaunchKernelGGL(ldlt_twist_xb_kernel, dim3((unsigned)((tw.m + 255) / 256)), dim3(256), 0, s, tw, n, x);
         }
