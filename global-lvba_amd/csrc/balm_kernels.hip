@@ -767,13 +767,15 @@ __global__ void gather_csc_kernel(const double *__restrict__ clu, const int32_t 
 }
 
 // caller layout [F][10] -> device layout [10][F]
-__global__ void aos_to_soa_kernel(const double *__restrict__ aos, int64_t F, double *__restrict__ soa)
+// fmap != nullptr: factor f of the device layout is factor fmap[f] of the caller's (voxels reordered at create time)
+__global__ void aos_to_soa_kernel(const double *__restrict__ aos, const int32_t *__restrict__ fmap, int64_t F,
+                                  double *__restrict__ soa)
 {
     const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (t >= 10 * F) return;
     const int64_t f = t / 10;
     const int e = (int)(t - 10 * f);
-    soa[(int64_t)e * F + f] = aos[t];
+    soa[(int64_t)e * F + f] = fmap ? aos[10 * (int64_t)fmap[f] + e] : aos[t];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -926,9 +928,9 @@ void launch_eval_fused(const BalmDev &d, const FusedDev &fd, const PairDev &pd, 
     hipLaunchKernelGGL(reduce_chunks_kernel, dim3(1), dim3(1024), 0, s, chunk_cost, d.n_chunks, out);
 }
 
-void launch_aos_to_soa(const double *aos, int64_t F, double *soa, hipStream_t s)
+void launch_aos_to_soa(const double *aos, const int32_t *fmap, int64_t F, double *soa, hipStream_t s)
 {
-    hipLaunchKernelGGL(aos_to_soa_kernel, dim3((unsigned)((10 * F + 255) / 256)), dim3(256), 0, s, aos, F, soa);
+    hipLaunchKernelGGL(aos_to_soa_kernel, dim3((unsigned)((10 * F + 255) / 256)), dim3(256), 0, s, aos, fmap, F, soa);
 }
 
 void launch_gather_csc(const double *clu, const int32_t *csc_f, int64_t F, double *clu_csc, hipStream_t s)

@@ -30,6 +30,7 @@ struct lvba_balm_s {
     bool finalized = false;
     // fused voxel-major evaluation (balm_fused_kernel): tables built at finalize
     bool fused = false;
+    bool voxels_sorted = false; // the voxels were re-laid in the order of the first pose that sees them (balm_create_impl)
     int64_t n_super = 0;
     int64_t *d_super_c0 = nullptr, *d_pp_off = nullptr, *d_pp_idx = nullptr;
     int32_t *d_n_slots = nullptr;
@@ -129,14 +130,70 @@ static int32_t balm_create_impl(int32_t n_poses, int64_t n_voxels, const int64_t
         return fail(LVBA_ERR_DEVICE, "no HIP device available (liblvba_hip has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(LVBA_ERR_ARG, "device %d out of range [0,%d)", device, ndev);
 
+    for (int64_t f = 0; f < F; ++f)
+        if (pose_idx[f] < 0 || pose_idx[f] >= n_poses) return fail(LVBA_ERR_ARG, "pose_idx[%lld] = %d out of range", (long long)f, pose_idx[f]);
+    for (int64_t a = 0; a < n_voxels; ++a)
+        if (voxel_off[a + 1] - voxel_off[a] < 2)
+            return fail(LVBA_ERR_ARG, "voxel %lld has %lld factors (< 2)", (long long)a, (long long)(voxel_off[a + 1] - voxel_off[a]));
+
+    // Voxel order.  Every pass over the voxels is laid out for voxels that come roughly in the order of the poses that see
+    // them (a voxel map built along a trajectory does; the synthetic problems do): the pose gather of the voxel pass, the
+    // voxel records the factor pass gathers and above all the windows of the pair lists draw on a compact slice of memory then.
+    // The reference hands its voxels over in the iteration order of an unordered_map (src/lvba_system.cpp:254-262 -> tras_opt),
+    // i.e. in no order at all: at C3 that costs 30 % of the evaluation (3.0 vs 2.3 ms, tools/gpu_shuffled.sh).  So a large
+    // problem whose voxels jump about is re-laid internally, voxels sorted (stably) by the first pose that sees them.  Nothing
+    // the caller gets back is indexed by voxel; sums over voxels change in the last bits only.  LVBA_VOXEL_SORT=0: off.
+    std::vector<int64_t> voff_s;
+    std::vector<int32_t> pidx_s, fmap;
+    {
+        static const bool allow = [] { const char *e = getenv("LVBA_VOXEL_SORT"); return !(e && !strcmp(e, "0")); }();
+        bool sort_voxels = false;
+        std::vector<int32_t> key;
+        if (allow && 18 * 8 * F > ((int64_t)24 << 20) && n_voxels > 1) { // the size from which the pair lists are windowed
+            key.resize((size_t)n_voxels);
+            double jump = 0.0;
+            for (int64_t a = 0; a < n_voxels; ++a) {
+                int32_t m = 0x7fffffff;
+                for (int64_t f = voxel_off[a] - base; f < voxel_off[a + 1] - base; ++f) m = std::min(m, pose_idx[f]);
+                key[(size_t)a] = m;
+                if (a > 0) jump += std::abs((double)m - (double)key[(size_t)a - 1]);
+            }
+            sort_voxels = jump / (double)(n_voxels - 1) > std::max(64.0, 0.125 * n_poses);
+        }
+        if (sort_voxels) { // stable counting sort by the first pose
+            std::vector<int64_t> start((size_t)n_poses + 1, 0);
+            for (int64_t a = 0; a < n_voxels; ++a) ++start[(size_t)key[(size_t)a] + 1];
+            for (int32_t i = 0; i < n_poses; ++i) start[(size_t)i + 1] += start[(size_t)i];
+            std::vector<int64_t> order((size_t)n_voxels); // order[new] = old
+            for (int64_t a = 0; a < n_voxels; ++a) order[(size_t)start[(size_t)key[(size_t)a]]++] = a;
+            voff_s.resize((size_t)n_voxels + 1);
+            pidx_s.resize((size_t)F);
+            fmap.resize((size_t)F);
+            voff_s[0] = 0;
+            int64_t w = 0;
+            for (int64_t a = 0; a < n_voxels; ++a) {
+                const int64_t o = order[(size_t)a];
+                for (int64_t f = voxel_off[o] - base; f < voxel_off[o + 1] - base; ++f, ++w) {
+                    pidx_s[(size_t)w] = pose_idx[f];
+                    fmap[(size_t)w] = (int32_t)f;
+                }
+                voff_s[(size_t)a + 1] = w;
+            }
+            voxel_off = voff_s.data();
+            pose_idx = pidx_s.data();
+        }
+    }
+    const int64_t base2 = voxel_off[0]; // 0 after a re-layout
+
     lvba_balm_s *h = new (std::nothrow) lvba_balm_s();
     if (!h) return fail(LVBA_ERR_NOMEM, "host allocation failed");
     h->N = n_poses; h->V = n_voxels; h->F = F; h->Vglobal = n_voxels;
+    h->voxels_sorted = !fmap.empty();
     // validate + chunk
     h->h_voff.resize(n_voxels + 1);
     std::vector<int64_t> chunk_v0;
     int64_t Q = 0;
-    for (int64_t a = 0; a <= n_voxels; ++a) h->h_voff[a] = voxel_off[a] - base;
+    for (int64_t a = 0; a <= n_voxels; ++a) h->h_voff[a] = voxel_off[a] - base2;
     {
         const int64_t bad = lvba::chunk_voxels(n_voxels, voxel_off, LVBA_CF, LVBA_CV, chunk_v0, Q); // host_tables.h
         if (bad >= 0) {
@@ -156,8 +213,6 @@ static int32_t balm_create_impl(int32_t n_poses, int64_t n_voxels, const int64_t
         h->h_chunk_v0 = chunk_v0;
     }
     h->h_pidx.assign(pose_idx, pose_idx + F);
-    for (int64_t f = 0; f < F; ++f)
-        if (pose_idx[f] < 0 || pose_idx[f] >= n_poses) { delete h; return fail(LVBA_ERR_ARG, "pose_idx[%lld] = %d out of range", (long long)f, pose_idx[f]); }
 
     auto bail = [&](int32_t rc) { lvba_balm_destroy(h); return rc; };
 #define CTRY(expr) do { int32_t rc_ = (expr); if (rc_ != LVBA_OK) return bail(rc_); } while (0)
@@ -171,18 +226,25 @@ static int32_t balm_create_impl(int32_t n_poses, int64_t n_voxels, const int64_t
     CTRY(bs_dmalloc(bs, &h->d_chunk_cost, h->n_chunks));
     CHIP(hipMemcpy(h->d_voff, h->h_voff.data(), (size_t)(n_voxels + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
     CHIP(hipMemcpy(h->d_chunk_v0, chunk_v0.data(), (size_t)(h->n_chunks + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
-    { // AoS [F][10] -> SoA [10][F] on the device (a host array is staged in a temporary device buffer)
+    { // AoS [F][10] -> SoA [10][F] on the device (a host array is staged in a temporary device buffer), through the factor map of
+      // a re-layout
         const double *src = d_clusters; // like the host array: indexed relative to voxel_off[0]
         double *d_stage = nullptr;
+        int32_t *d_fmap = nullptr;
         if (!d_clusters) {
             CTRY(bs_dmalloc(bs, &d_stage, 10 * F));
             CHIP(hipMemcpy(d_stage, clusters, (size_t)(10 * F) * sizeof(double), hipMemcpyHostToDevice));
             src = d_stage;
         }
-        launch_aos_to_soa(src, F, h->d_clu, bs.stream);
+        if (!fmap.empty()) {
+            CTRY(bs_dmalloc(bs, &d_fmap, F));
+            CHIP(hipMemcpy(d_fmap, fmap.data(), (size_t)F * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+        launch_aos_to_soa(src, d_fmap, F, h->d_clu, bs.stream);
         CHIP(hipGetLastError());
         CHIP(hipStreamSynchronize(bs.stream));
         if (d_stage) { lvba::DevicePool::get().free(d_stage); bs.device_bytes -= (int64_t)(10 * F) * (int64_t)sizeof(double); }
+        if (d_fmap) { lvba::DevicePool::get().free(d_fmap); bs.device_bytes -= (int64_t)F * (int64_t)sizeof(int32_t); }
     }
     CHIP(hipHostMalloc((void **)&h->h_pin, 16 * sizeof(double), hipHostMallocDefault));
     for (int e = 0; e < EV_N; ++e)

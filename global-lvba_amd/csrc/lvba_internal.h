@@ -103,7 +103,7 @@ void launch_pairs(const PairDev &pd, double *Hblk, hipStream_t s);
 // the same evaluation with voxel + factor pass fused (Y at voxel-major positions)
 void launch_eval_fused(const BalmDev &d, const FusedDev &fd, const PairDev &pd, const double *poses, double *Hblk, int64_t hblk_doubles,
                        double *g, double *chunk_cost, double *out, bool zero_first, hipStream_t s, hipEvent_t k0, hipEvent_t k1);
-void launch_aos_to_soa(const double *aos, int64_t F, double *soa, hipStream_t s);
+void launch_aos_to_soa(const double *aos, const int32_t *fmap, int64_t F, double *soa, hipStream_t s);
 void launch_gather_csc(const double *clu, const int32_t *csc_f, int64_t F, double *clu_csc, hipStream_t s);
 void launch_retract(const double *poses, const double *dx, double *out, int n_poses, hipStream_t s);
 void launch_predicted_decrease(const double *Hblk, int band_blocks, const double *g, const double *dx, double u,

@@ -403,10 +403,12 @@ def test_voxels_with_more_observers_than_lanes(pkg, oracle_mod):
 
 
 def test_voxel_order_unrelated_to_the_poses(pkg):
-    """The pair lists of large problems are grouped by windows of consecutive voxels, which only pays when consecutive voxels are
-    seen from neighbouring poses (the synthetic problems and the voxel maps are ordered like that).  With the voxels in RANDOM
-    order every window touches every block; the library then falls back to the plain block-major lists.  Either way the result is
-    the sum over the same voxels: H, g and the cost must not depend on the order beyond rounding, and LM runs agree."""
+    """The passes over the voxels (and above all the voxel windows of the pair lists) are laid out for voxels that come roughly
+    in the order of the poses that see them; the synthetic problems and the voxel maps do.  The reference hands its voxels over
+    in the iteration order of an unordered_map, i.e. in RANDOM order: lvba_balm_create then re-lays a large problem internally
+    (voxels sorted by the first pose that sees them; below the size threshold, or with LVBA_VOXEL_SORT=0, the pair lists fall
+    back to the plain block-major form).  Either way the result is the sum over the same voxels: H, g and the cost must not
+    depend on the order beyond rounding, and LM runs agree.  (250 k factors: above the threshold.)"""
     d = make_problem(500, 50000, seed=11)
     off, idx, clu = d["voxel_off"], d["pose_idx"], d["clusters"]
     V = len(off) - 1
