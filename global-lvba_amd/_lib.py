@@ -14,7 +14,7 @@ SYMBOLS = [
     "lvba_version", "lvba_last_error", "lvba_device_count", "lvba_balm_default_opts", "lvba_shard_range",
     "lvba_balm_create", "lvba_balm_destroy", "lvba_balm_configure", "lvba_balm_info", "lvba_balm_cost",
     "lvba_balm_eval", "lvba_balm_solve", "lvba_balm_refine", "lvba_balm_lm_begin", "lvba_balm_lm_step",
-    "lvba_balm_lm_end", "lvba_balm_set_profiling", "lvba_balm_get_profile", "lvba_balm_get_ordering",
+    "lvba_balm_lm_end", "lvba_balm_set_groups", "lvba_balm_refine_groups", "lvba_balm_set_profiling", "lvba_balm_get_profile", "lvba_balm_get_ordering",
     "lvba_dist_unique_id", "lvba_balm_dist_init", "lvba_dist_host_unique_id",
     "lvba_visual_default_opts", "lvba_visual_create", "lvba_visual_destroy", "lvba_visual_cost", "lvba_visual_linearize", "lvba_visual_info", "lvba_visual_dist_init",
     "lvba_visual_refine",
@@ -93,7 +93,7 @@ class VoxmapInfo(C.Structure):
 
 class WindowOpts(C.Structure):
     _fields_ = [("window_size", C.c_int32), ("use_rel", C.c_int32), ("anchor_leaf", C.c_double), ("voxel", VoxelOpts),
-                ("lm", BalmOpts), ("merge_only", C.c_int32), ("reserved", C.c_int32)]
+                ("lm", BalmOpts), ("merge_only", C.c_int32), ("lm_mode", C.c_int32)]
 
 
 class WindowInfo(C.Structure):
@@ -170,6 +170,8 @@ def load():
     lib.lvba_balm_lm_begin.argtypes = [H, f64p, C.POINTER(BalmOpts)]
     lib.lvba_balm_lm_step.argtypes = [H, C.POINTER(LmTrace), C.POINTER(C.c_int32)]
     lib.lvba_balm_lm_end.argtypes = [H, C.c_void_p]
+    lib.lvba_balm_set_groups.argtypes = [H, C.c_int32, i32p, i64p]
+    lib.lvba_balm_refine_groups.argtypes = [H, f64p, C.POINTER(BalmOpts), i32p, i32p, f64p, f64p]
     lib.lvba_balm_set_profiling.argtypes = [H, C.c_int32]
     lib.lvba_balm_get_profile.argtypes = [H, C.POINTER(Prof), C.c_int32]
     lib.lvba_balm_get_ordering.argtypes = [H, i32p]

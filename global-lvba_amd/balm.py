@@ -150,6 +150,25 @@ class BalmProblem:
         rc = L.check(self.lib.lvba_balm_refine(self._h, x, C.byref(o), trace, C.byref(nt)), allow_numeric=True)
         return x.reshape(-1, 12), [trace[i].as_dict() for i in range(nt.value)], rc
 
+    def set_groups(self, pose_off, voxel_off):
+        """Independent groups of poses / voxels (lvba_balm_set_groups); before the first cost / eval / refine call."""
+        po = np.ascontiguousarray(pose_off, dtype=np.int32)
+        vo = np.ascontiguousarray(voxel_off, dtype=np.int64)
+        if len(po) != len(vo) or len(po) < 2:
+            raise ValueError("pose_off and voxel_off need n_groups + 1 entries each")
+        L.check(self.lib.lvba_balm_set_groups(self._h, len(po) - 1, po, vo))
+        self.n_groups = len(po) - 1
+
+    def refine_groups(self, poses, **opts):
+        """All groups through one LM loop in lock-step; returns (poses, per-group dict of arrays, rc)."""
+        o = self.default_opts(**opts)
+        x = self._poses(poses).copy()
+        G = self.n_groups
+        n_iter, status = np.zeros(G, np.int32), np.zeros(G, np.int32)
+        first, last = np.zeros(G), np.zeros(G)
+        rc = L.check(self.lib.lvba_balm_refine_groups(self._h, x, C.byref(o), n_iter, status, first, last), allow_numeric=True)
+        return x.reshape(-1, 12), dict(n_iter=n_iter, status=status, cost_first=first, cost_last=last), rc
+
     def lm_begin(self, poses, **opts):
         o = self.default_opts(**opts)
         L.check(self.lib.lvba_balm_lm_begin(self._h, self._poses(poses), C.byref(o)))

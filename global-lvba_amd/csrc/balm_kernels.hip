@@ -822,6 +822,46 @@ __global__ __launch_bounds__(1024) void predicted_decrease_kernel(const double *
     }
 }
 
+// ---- grouped refinement (lvba_balm_refine_groups): independent pose / voxel groups advance through one LM loop in lock-step,
+// each with its own cost, damping and accept / reject decision.  One workgroup per group, fixed summation order.
+__global__ __launch_bounds__(256) void reduce_chunks_groups_kernel(const double *__restrict__ part, const int64_t *__restrict__ gco,
+                                                                  double *__restrict__ out)
+{
+    __shared__ double red[4];
+    const int64_t c0 = gco[blockIdx.x], c1 = gco[blockIdx.x + 1];
+    double s = 0.0;
+    for (int64_t i = c0 + threadIdx.x; i < c1; i += 256) s += part[i];
+    const double t = block_sum_256(s, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = t;
+}
+// per group: 0.5 * dx . (u_g * diag(H) .* dx - g) over the group's poses (bavoxel.hpp:729)
+__global__ __launch_bounds__(256) void predicted_decrease_groups_kernel(const double *__restrict__ Hblk, int band_blocks,
+                                                                       const double *__restrict__ g, const double *__restrict__ dx,
+                                                                       const double *__restrict__ u, const int32_t *__restrict__ gpo,
+                                                                       double *__restrict__ out)
+{
+    __shared__ double red[4];
+    const int64_t Bb1 = band_blocks + 1;
+    const int64_t a0 = 6 * (int64_t)gpo[blockIdx.x], a1 = 6 * (int64_t)gpo[blockIdx.x + 1];
+    const double ug = u[blockIdx.x];
+    double s = 0.0;
+    for (int64_t a = a0 + threadIdx.x; a < a1; a += 256) {
+        const int64_t blk = a / 6, r = a - blk * 6;
+        const double dgl = Hblk[blk * Bb1 * 36 + r * 6 + r];
+        s += dx[a] * (ug * dgl * dx[a] - g[a]);
+    }
+    const double t = block_sum_256(s, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = 0.5 * t;
+}
+// cur[j] <- trial[j] for the poses of groups whose step was accepted
+__global__ void select_poses_kernel(double *__restrict__ cur, const double *__restrict__ trial, const int32_t *__restrict__ accept,
+                                    const int32_t *__restrict__ grp_of_pose, int n_poses)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 12 * n_poses) return;
+    if (accept[grp_of_pose[t / 12]]) cur[t] = trial[t];
+}
+
 // Export the block-band Hessian (solver pose order) as a full symmetric dense matrix in the CALLER's
 // pose order: Hd[(6*pi+r) + (6*pj+c)*n].  One thread per scalar of the lower block-band.
 __global__ void export_dense_kernel(const double *__restrict__ Hblk, int band_blocks, int n_poses,
@@ -969,6 +1009,27 @@ void launch_import_poses(const double *in, const int *perm, int n_poses, double 
 void launch_export_poses(const double *in, const int *perm, int n_poses, double *out, hipStream_t s)
 {
     hipLaunchKernelGGL(export_poses_kernel, dim3((12 * n_poses + 255) / 256), dim3(256), 0, s, in, perm, n_poses, out);
+}
+
+void launch_reduce_chunks_groups(const double *chunk_cost, const int64_t *gco, int n_groups, double *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(reduce_chunks_groups_kernel, dim3((unsigned)n_groups), dim3(256), 0, s, chunk_cost, gco, out);
+}
+
+void launch_cost_chunks(const BalmDev &d, const double *poses, double *chunk_cost, hipStream_t s)
+{
+    hipLaunchKernelGGL(balm_cost_kernel, dim3((unsigned)d.n_chunks), dim3(LVBA_CF), 0, s, d, poses, chunk_cost);
+}
+
+void launch_predicted_decrease_groups(const double *Hblk, int band_blocks, const double *g, const double *dx, const double *u,
+                                      const int32_t *gpo, int n_groups, double *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(predicted_decrease_groups_kernel, dim3((unsigned)n_groups), dim3(256), 0, s, Hblk, band_blocks, g, dx, u, gpo, out);
+}
+
+void launch_select_poses(double *cur, const double *trial, const int32_t *accept, const int32_t *grp_of_pose, int n_poses, hipStream_t s)
+{
+    hipLaunchKernelGGL(select_poses_kernel, dim3((unsigned)((12 * n_poses + 255) / 256)), dim3(256), 0, s, cur, trial, accept, grp_of_pose, n_poses);
 }
 
 } // namespace lvba

@@ -47,6 +47,9 @@ struct BlockSys {
     LdltMat A{};
     double *d_bcr = nullptr; // workspace of the block cyclic reduction, when that is the solver
     double *d_A = nullptr, *d_work = nullptr, *d_dx = nullptr, *d_u = nullptr, *h_pin_u = nullptr;
+    // grouped refinement: d_u holds one damping value per group, d_grp_of_pose [N] (owned by the caller) maps pose blocks to them
+    int32_t n_groups = 0;
+    const int32_t *d_grp_of_pose = nullptr;
     int *d_status = nullptr;
     hipGraph_t solve_graph = nullptr;
     hipGraphExec_t solve_exec = nullptr;
@@ -90,6 +93,8 @@ int32_t bs_init(BlockSys &bs, int device);
 int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const int32_t *pidx);
 // enqueue: dx = -(H + u diag H)^-1 g on bs.stream (u = 0: H is used as assembled)
 int32_t bs_enqueue_solve(BlockSys &bs, double u);
+// grouped form: u [bs.n_groups] (host); bs.n_groups / bs.d_grp_of_pose are set before the system is built
+int32_t bs_enqueue_solve_groups(BlockSys &bs, const double *u);
 // all-reduce `count` doubles in place over the ranks (no-op without a communicator)
 int32_t bs_allreduce(BlockSys &bs, double *buf, size_t count);
 // all-reduce [Hblk | g | cost] over the ranks: only the blocks of the union sparsity pattern travel when that is known

@@ -2,6 +2,7 @@
 // binding, block ordering (RCM + barycenter refinement), pose-major factor order and per-block pair lists of the
 // atomic-free assembly, block-band store, LDL^T solve (captured into a hipGraph), all-reduce.
 #include <dlfcn.h>
+#include <malloc.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -147,12 +148,32 @@ int32_t bs_comm_allreduce(BlockSys &bs, void *dbuf, size_t count, ncclDataType_t
     return LVBA_OK;
 }
 
+// Host memory that goes back to the operating system stalls the GPU.  Measured on the window stage's joint problem: freeing the
+// set-up's host tables (std::vectors of 2-9 MB, which glibc serves with mmap and returns with munmap) was followed by 14-25 ms in
+// which NO stream of the process got anything done -- the unmapping runs the kernel driver's MMU notifier, which evicts the
+// process's queues and restores them a moment later -- i.e. six times the three LM iterations the set-up was for; with the frees
+// skipped the stall was gone (47 -> 19 ms for 16 windows).  So, once per process: allocations up to 32 MB (the most mallopt
+// accepts) come from the heap, and the heap is not trimmed below 1 GB of free space; the pages stay with the process and are
+// reused by the next set-up.  Larger blocks still use mmap -- a problem with tables that big does not notice 20 ms.
+// LVBA_MALLOC_TUNE=0 leaves the allocator alone.
+static void tune_host_allocator()
+{
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *e = getenv("LVBA_MALLOC_TUNE");
+        if (e && !strcmp(e, "0")) return;
+        (void)mallopt(M_MMAP_THRESHOLD, 32 << 20);
+        (void)mallopt(M_TRIM_THRESHOLD, 1 << 30);
+    });
+}
+
 int32_t bs_init(BlockSys &bs, int device)
 {
+    tune_host_allocator();
     bs.device = device;
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamCreateWithFlags(&bs.stream, hipStreamNonBlocking));
-    HIPCHK(hipHostMalloc((void **)&bs.h_pin_u, 2 * sizeof(double), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&bs.h_pin_u, 2 * sizeof(double), hipHostMallocDefault)); // (re-made larger by a grouped problem, bs_build)
     return LVBA_OK;
 }
 
@@ -188,11 +209,11 @@ int32_t bs_dist_init(BlockSys &bs, int32_t n_ranks, int32_t rank, const char uid
     if (group_count_inout) { // global group count (the AVG_THR averages of the BALM stage)
         int64_t *dv = nullptr;
         HIPCHK(hipMalloc((void **)&dv, sizeof(int64_t)));
-        HIPCHK(hipMemcpy(dv, group_count_inout, sizeof(int64_t), hipMemcpyHostToDevice));
+        HIPCHK(lvba::copy_h2d(dv, group_count_inout, sizeof(int64_t)));
         const int32_t rc = bs_comm_allreduce(bs, dv, 1, ncclInt64, ncclSum);
         if (rc == LVBA_OK) {
             HIPCHK(hipStreamSynchronize(bs.stream));
-            HIPCHK(hipMemcpy(group_count_inout, dv, sizeof(int64_t), hipMemcpyDeviceToHost));
+            HIPCHK(lvba::copy_d2h(group_count_inout, dv, sizeof(int64_t)));
         }
         hipFree(dv);
         TRY(rc);
@@ -280,10 +301,10 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
     if (bs.distributed()) { // the store layout must agree on every rank: reduce over the global problem
         int32_t *dtmp = nullptr;
         HIPCHK(hipMalloc((void **)&dtmp, sizeof(int32_t)));
-        HIPCHK(hipMemcpy(dtmp, &Bb_nat, sizeof(int32_t), hipMemcpyHostToDevice));
+        HIPCHK(lvba::copy_h2d(dtmp, &Bb_nat, sizeof(int32_t)));
         TRY(bs_comm_allreduce(bs, dtmp, 1, ncclInt32, ncclMax));
         HIPCHK(hipStreamSynchronize(bs.stream));
-        HIPCHK(hipMemcpy(&Bb_nat, dtmp, sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIPCHK(lvba::copy_d2h(&Bb_nat, dtmp, sizeof(int32_t)));
         hipFree(dtmp);
     }
     bs.Bb = Bb_nat;
@@ -300,10 +321,10 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
         if (bs.distributed()) {
             uint8_t *dadj = nullptr;
             HIPCHK(hipMalloc((void **)&dadj, adj.size()));
-            HIPCHK(hipMemcpy(dadj, adj.data(), adj.size(), hipMemcpyHostToDevice));
+            HIPCHK(lvba::copy_h2d(dadj, adj.data(), adj.size()));
             TRY(bs_comm_allreduce(bs, dadj, adj.size(), ncclUint8, ncclMax));
             HIPCHK(hipStreamSynchronize(bs.stream));
-            HIPCHK(hipMemcpy(adj.data(), dadj, adj.size(), hipMemcpyDeviceToHost));
+            HIPCHK(lvba::copy_d2h(adj.data(), dadj, adj.size()));
             hipFree(dadj);
         }
         std::vector<int32_t> perm, iperm(N);
@@ -340,7 +361,7 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
                 bs.n_ar = (int64_t)slots.size();
                 TRY(bs_dmalloc(bs, &bs.d_ar_slot, bs.n_ar));
                 TRY(bs_dmalloc(bs, &bs.d_arbuf, 36 * bs.n_ar + 6 * (int64_t)N + 8));
-                HIPCHK(hipMemcpy(bs.d_ar_slot, slots.data(), (size_t)bs.n_ar * sizeof(int64_t), hipMemcpyHostToDevice));
+                HIPCHK(lvba::copy_h2d(bs.d_ar_slot, slots.data(), (size_t)bs.n_ar * sizeof(int64_t)));
             }
         }
     }
@@ -415,9 +436,9 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
                 TRY(bs_dmalloc(bs, &bs.d_multi_off, bs.n_multi + 1));
                 TRY(bs_dmalloc(bs, &bs.d_multi_slot, bs.n_multi));
                 TRY(bs_dmalloc(bs, &bs.d_multi_idx, (int64_t)multi_idx.size()));
-                HIPCHK(hipMemcpy(bs.d_multi_idx, multi_idx.data(), multi_idx.size() * sizeof(int64_t), hipMemcpyHostToDevice));
-                HIPCHK(hipMemcpy(bs.d_multi_off, multi_off.data(), (size_t)(bs.n_multi + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
-                HIPCHK(hipMemcpy(bs.d_multi_slot, multi_slot.data(), (size_t)bs.n_multi * sizeof(int64_t), hipMemcpyHostToDevice));
+                HIPCHK(lvba::copy_h2d(bs.d_multi_idx, multi_idx.data(), multi_idx.size() * sizeof(int64_t)));
+                HIPCHK(lvba::copy_h2d(bs.d_multi_off, multi_off.data(), (size_t)(bs.n_multi + 1) * sizeof(int64_t)));
+                HIPCHK(lvba::copy_h2d(bs.d_multi_slot, multi_slot.data(), (size_t)bs.n_multi * sizeof(int64_t)));
             }
         }
         // slices per block: enough workgroups to fill the chip, but >= ~256 factors per slice
@@ -428,15 +449,20 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
         TRY(bs_dmalloc(bs, &bs.d_Y, 18 * F));
         TRY(bs_dmalloc(bs, &bs.d_blk_off, bs.n_items + 1));
         TRY(bs_dmalloc(bs, &bs.d_blk_slot, bs.n_items));
-        HIPCHK(hipMemcpy(bs.d_blk_off, item_off.data(), (size_t)(bs.n_items + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
-        if (bs.n_items) HIPCHK(hipMemcpy(bs.d_blk_slot, item_dst.data(), (size_t)bs.n_items * sizeof(int64_t), hipMemcpyHostToDevice));
+        HIPCHK(lvba::copy_h2d(bs.d_blk_off, item_off.data(), (size_t)(bs.n_items + 1) * sizeof(int64_t)));
+        if (bs.n_items) HIPCHK(lvba::copy_h2d(bs.d_blk_slot, item_dst.data(), (size_t)bs.n_items * sizeof(int64_t)));
     }
     BS_MARK("upload");
     TRY(bs_dmalloc(bs, &bs.d_perm, N));
-    HIPCHK(hipMemcpy(bs.d_perm, bs.perm.data(), (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPCHK(lvba::copy_h2d(bs.d_perm, bs.perm.data(), (size_t)N * sizeof(int32_t)));
     TRY(bs_dmalloc(bs, &bs.d_hg, bs.hg_doubles()));
     TRY(bs_dmalloc(bs, &bs.d_dx, n));
-    TRY(bs_dmalloc(bs, &bs.d_u, 8));
+    TRY(bs_dmalloc(bs, &bs.d_u, std::max<int64_t>(1, bs.n_groups)));
+    if (bs.n_groups > 2) {
+        if (bs.h_pin_u) hipHostFree(bs.h_pin_u);
+        bs.h_pin_u = nullptr;
+        HIPCHK(hipHostMalloc((void **)&bs.h_pin_u, (size_t)bs.n_groups * sizeof(double), hipHostMallocDefault));
+    }
     TRY(bs_dmalloc(bs, &bs.d_status, 4));
     bs.A.n = n;
     if (bs.use_band) {
@@ -471,13 +497,33 @@ static int32_t solve_launches(BlockSys &bs)
     static const bool dist_solve = [] { const char *e = getenv("LVBA_DIST_SOLVE"); return !(e && !strcmp(e, "0")); }();
     LdltDist dd{bs.rank, bs.n_ranks, &bs, dist_sum_cb, dist_max_cb};
     return ldlt_solve(bs.A, bs.Hblk(), bs.Bb, bs.N, bs.g(), bs.d_u, bs.d_dx, bs.d_work, bs.d_status, bs.stream,
-                      bs.distributed() && bs.n_ranks >= 2 && dist_solve ? &dd : nullptr);
+                      bs.distributed() && bs.n_ranks >= 2 && dist_solve ? &dd : nullptr, bs.n_groups > 0 ? bs.d_grp_of_pose : nullptr);
 }
 
+static int32_t enqueue_solve_launches(BlockSys &bs);
 int32_t bs_enqueue_solve(BlockSys &bs, double u)
 {
+    if (bs.n_groups > 0) { // a grouped problem solved with one damping value for all groups
+        for (int32_t k = 0; k < bs.n_groups; ++k) bs.h_pin_u[k] = u;
+        HIPCHK(hipMemcpyAsync(bs.d_u, bs.h_pin_u, (size_t)bs.n_groups * sizeof(double), hipMemcpyHostToDevice, bs.stream));
+        return enqueue_solve_launches(bs);
+    }
     bs.h_pin_u[0] = u;
     HIPCHK(hipMemcpyAsync(bs.d_u, bs.h_pin_u, sizeof(double), hipMemcpyHostToDevice, bs.stream));
+    return enqueue_solve_launches(bs);
+}
+
+int32_t bs_enqueue_solve_groups(BlockSys &bs, const double *u)
+{
+    if (bs.n_groups <= 0 || bs.d_bcr) return LVBA_ERR_STATE;
+    HIPCHK(hipStreamSynchronize(bs.stream)); // the pinned staging buffer may still be read by the previous copy
+    for (int32_t k = 0; k < bs.n_groups; ++k) bs.h_pin_u[k] = u[k];
+    HIPCHK(hipMemcpyAsync(bs.d_u, bs.h_pin_u, (size_t)bs.n_groups * sizeof(double), hipMemcpyHostToDevice, bs.stream));
+    return enqueue_solve_launches(bs);
+}
+
+static int32_t enqueue_solve_launches(BlockSys &bs)
+{
     // capture + instantiate costs about as much as a few eager solves of a small system: wait for the third solve, so
     // handles that live for one short refinement (window BA) never pay for it
     // no capture while several host threads drive the device (bs_graph_inhibit): with HIP 7.0 a capture in one thread is

@@ -11,16 +11,20 @@ namespace lvba {
 // workgroup each: lane = factor, then lane = voxel).  A voxel with more than max_factors observers sits alone in its chunk
 // and is merged in tiles by the kernels.  voxel_off [n_voxels + 1]; chunk_v0 receives the first voxel of every chunk plus
 // n_voxels; Q = sum k (k - 1) / 2.  Returns -1, or the index of the first voxel with fewer than two factors.
+// breaks (optional, ascending voxel indices, n_breaks of them): a chunk never straddles one -- the voxel groups of a grouped
+// refinement (lvba_balm_set_groups) sum their chunks' costs separately.
 inline int64_t chunk_voxels(int64_t n_voxels, const int64_t *voxel_off, int max_factors, int max_voxels,
-                            std::vector<int64_t> &chunk_v0, int64_t &Q)
+                            std::vector<int64_t> &chunk_v0, int64_t &Q, const int64_t *breaks = nullptr, int64_t n_breaks = 0)
 {
     chunk_v0.assign(1, 0);
-    int64_t nf = 0, nv = 0;
+    int64_t nf = 0, nv = 0, nb = 0;
     Q = 0;
     for (int64_t a = 0; a < n_voxels; ++a) {
         const int64_t k = voxel_off[a + 1] - voxel_off[a];
         if (k < 2) return a;
         Q += k * (k - 1) / 2;
+        while (nb < n_breaks && breaks[nb] < a) ++nb;
+        if (nb < n_breaks && breaks[nb] == a && nv > 0) { chunk_v0.push_back(a); nf = 0; nv = 0; }
         if (k > max_factors) {
             if (nv > 0) chunk_v0.push_back(a);
             chunk_v0.push_back(a + 1);

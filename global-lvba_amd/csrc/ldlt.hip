@@ -47,9 +47,10 @@ struct LdltTwist {
 __global__ void ldlt_prepare_kernel(LdltMat M, const double *__restrict__ Hblk, int band_blocks, int n_poses,
                                     const double *__restrict__ g, const double *__restrict__ u_dev,
                                     double *__restrict__ b, unsigned long long *__restrict__ x, unsigned long long x_fill,
-                                    LdltTwist tw)
+                                    LdltTwist tw, const int32_t *__restrict__ grp)
 {
-    const double u = u_dev[0];
+    // grp != nullptr: the damping of pose block J is u_dev[grp[J]] (independent groups of poses, each with its own LM state)
+    const double u0 = u_dev[0];
     const int64_t Bb1 = band_blocks + 1;
     const int64_t total = (int64_t)n_poses * Bb1 * 36;
     const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
@@ -62,7 +63,7 @@ __global__ void ldlt_prepare_kernel(LdltMat M, const double *__restrict__ Hblk, 
         const int c = el / 6, r = el - c * 6;
         if (dI == 0 && r < c) continue;
         double v = Hblk[e];
-        if (dI == 0 && r == c) v += u * v;
+        if (dI == 0 && r == c) v += (grp ? u_dev[grp[J]] : u0) * v;
         const int64_t R = 6 * I + r, C = 6 * J + c;
         if (R < n1) M.a[R + C * M.ld] = v;
         else M.a[tw.sA + (n - 1 - C) + (n - 1 - R) * M.ld] = v; // row in B: reversed and transposed into the lower triangle
@@ -1201,7 +1202,7 @@ int64_t ldlt_twist_panels(int64_t n, int64_t ld, int64_t bw)
 // rank 0 back-substitutes T and rank 1 B, and the solution is all-reduced.  Per rank the end phase is as long as the
 // single-GPU one but moves one window per launch instead of two; what is replicated is the S phase only.
 int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_poses, const double *g,
-                   const double *u_dev, double *x, double *work, int *status, hipStream_t s, const LdltDist *dist)
+                   const double *u_dev, double *x, double *work, int *status, hipStream_t s, const LdltDist *dist, const int32_t *grp)
 {
     static const bool overlap = [] { const char *e = getenv("LVBA_SCHEDULE"); return !(e && !strcmp(e, "serial")); }();
     const int64_t n = A.n, bw = A.bw;
@@ -1228,7 +1229,7 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
     hipMemsetAsync(status, 0, sizeof(int), s);
     hipMemsetAsync(bacc, 0, (size_t)n * sizeof(double), s);
     hipLaunchKernelGGL(ldlt_prepare_kernel, dim3(2048), dim3(256), 0, s, A, Hblk, band_blocks, n_poses, g, u_dev, b,
-                       reinterpret_cast<unsigned long long *>(x), (unsigned long long)LVBA_X_SENTINEL, tw);
+                       reinterpret_cast<unsigned long long *>(x), (unsigned long long)LVBA_X_SENTINEL, tw, grp);
     struct Geo { int64_t k, w0, rend, T; int nbe; };
     auto geom = [&](int64_t st) {
         Geo q;

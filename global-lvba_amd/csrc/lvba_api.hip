@@ -45,6 +45,15 @@ struct lvba_balm_s {
     double *d_pose_in = nullptr, *d_pose_cur = nullptr, *d_pose_trial = nullptr, *d_out = nullptr;
     double *d_scal2 = nullptr; // [0]=trial cost sum, [1]=q1 numerator
     double *h_pin = nullptr;   // pinned host staging, 16 doubles
+    // grouped refinement (lvba_balm_set_groups): independent pose / voxel groups, one LM state each
+    int32_t n_groups = 0;
+    std::vector<int32_t> g_pose_off;   // [n_groups + 1]
+    std::vector<int64_t> g_vox_off;    // [n_groups + 1]
+    int32_t *d_grp_of_pose = nullptr, *d_gpo = nullptr, *d_gaccept = nullptr;
+    int64_t *d_gco = nullptr;          // chunk range of every group
+    double *d_gscal = nullptr;         // [3][n_groups]: cost at the current poses, cost at the trial poses, q1 numerator
+    double *h_gpin = nullptr;          // pinned, [3][n_groups]
+    int32_t *h_gacc = nullptr;         // pinned, [n_groups]
     // LM state (bavoxel.hpp:664-671)
     bool lm_active = false, lm_done = false, is_calc_hess = true;
     lvba_balm_opts lm_opts{};
@@ -224,8 +233,8 @@ static int32_t balm_create_impl(int32_t n_poses, int64_t n_voxels, const int64_t
     CTRY(bs_dmalloc(bs, &h->d_pidx, F));
     CTRY(bs_dmalloc(bs, &h->d_clu, 10 * F));
     CTRY(bs_dmalloc(bs, &h->d_chunk_cost, h->n_chunks));
-    CHIP(hipMemcpy(h->d_voff, h->h_voff.data(), (size_t)(n_voxels + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
-    CHIP(hipMemcpy(h->d_chunk_v0, chunk_v0.data(), (size_t)(h->n_chunks + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    CHIP(lvba::copy_h2d(h->d_voff, h->h_voff.data(), (size_t)(n_voxels + 1) * sizeof(int64_t)));
+    CHIP(lvba::copy_h2d(h->d_chunk_v0, chunk_v0.data(), (size_t)(h->n_chunks + 1) * sizeof(int64_t)));
     { // AoS [F][10] -> SoA [10][F] on the device (a host array is staged in a temporary device buffer), through the factor map of
       // a re-layout
         const double *src = d_clusters; // like the host array: indexed relative to voxel_off[0]
@@ -233,12 +242,12 @@ static int32_t balm_create_impl(int32_t n_poses, int64_t n_voxels, const int64_t
         int32_t *d_fmap = nullptr;
         if (!d_clusters) {
             CTRY(bs_dmalloc(bs, &d_stage, 10 * F));
-            CHIP(hipMemcpy(d_stage, clusters, (size_t)(10 * F) * sizeof(double), hipMemcpyHostToDevice));
+            CHIP(lvba::copy_h2d(d_stage, clusters, (size_t)(10 * F) * sizeof(double)));
             src = d_stage;
         }
         if (!fmap.empty()) {
             CTRY(bs_dmalloc(bs, &d_fmap, F));
-            CHIP(hipMemcpy(d_fmap, fmap.data(), (size_t)F * sizeof(int32_t), hipMemcpyHostToDevice));
+            CHIP(lvba::copy_h2d(d_fmap, fmap.data(), (size_t)F * sizeof(int32_t)));
         }
         launch_aos_to_soa(src, d_fmap, F, h->d_clu, bs.stream);
         CHIP(hipGetLastError());
@@ -262,10 +271,13 @@ extern "C" int32_t lvba_balm_destroy(lvba_balm_t h)
     if (h->bs.stream) hipStreamSynchronize(h->bs.stream);
     void *ptrs[] = {h->d_voff, h->d_chunk_v0, h->d_pidx, h->d_clu, h->d_chunk_cost, h->d_clu_csc, h->d_vrec, h->d_part,
                     h->d_pose_in, h->d_pose_cur, h->d_pose_trial, h->d_out, h->d_scal2, h->d_super_c0, h->d_pp_off, h->d_pp_idx,
-                    h->d_n_slots, h->d_slot, h->d_round, h->d_n_rounds, h->d_fpart};
+                    h->d_n_slots, h->d_slot, h->d_round, h->d_n_rounds, h->d_fpart, h->d_grp_of_pose, h->d_gpo, h->d_gaccept, h->d_gco,
+                    h->d_gscal};
     for (void *p : ptrs)
         if (p) lvba::DevicePool::get().free(p);
     if (h->h_pin) hipHostFree(h->h_pin);
+    if (h->h_gpin) hipHostFree(h->h_gpin);
+    if (h->h_gacc) hipHostFree(h->h_gacc);
     for (int e = 0; e < EV_N; ++e)
         for (int s = 0; s < 2; ++s)
             if (h->ev[e][s]) hipEventDestroy(h->ev[e][s]);
@@ -343,13 +355,13 @@ static int32_t build_fused_tables(lvba_balm_s *h, const std::vector<int32_t> &p)
     TRY(bs_dmalloc(bs, &h->d_fpart, h->n_super * 256 * 32));
     TRY(bs_dmalloc(bs, &h->d_pp_off, (int64_t)N + 1));
     TRY(bs_dmalloc(bs, &h->d_pp_idx, (int64_t)pp_idx.size()));
-    HIPCHK(hipMemcpy(h->d_super_c0, super_c0.data(), super_c0.size() * sizeof(int64_t), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->d_n_slots, n_slots.data(), n_slots.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->d_slot, slot.data(), (size_t)F, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->d_round, round.data(), (size_t)F, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->d_n_rounds, n_rounds.data(), (size_t)nch, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->d_pp_off, pp_cnt.data(), pp_cnt.size() * sizeof(int64_t), hipMemcpyHostToDevice));
-    if (!pp_idx.empty()) HIPCHK(hipMemcpy(h->d_pp_idx, pp_idx.data(), pp_idx.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    HIPCHK(lvba::copy_h2d(h->d_super_c0, super_c0.data(), super_c0.size() * sizeof(int64_t)));
+    HIPCHK(lvba::copy_h2d(h->d_n_slots, n_slots.data(), n_slots.size() * sizeof(int32_t)));
+    HIPCHK(lvba::copy_h2d(h->d_slot, slot.data(), (size_t)F));
+    HIPCHK(lvba::copy_h2d(h->d_round, round.data(), (size_t)F));
+    HIPCHK(lvba::copy_h2d(h->d_n_rounds, n_rounds.data(), (size_t)nch));
+    HIPCHK(lvba::copy_h2d(h->d_pp_off, pp_cnt.data(), pp_cnt.size() * sizeof(int64_t)));
+    if (!pp_idx.empty()) HIPCHK(lvba::copy_h2d(h->d_pp_idx, pp_idx.data(), pp_idx.size() * sizeof(int64_t)));
     return LVBA_OK;
 }
 
@@ -363,7 +375,7 @@ static int32_t finalize(lvba_balm_s *h)
     TRY(bs_build(bs, N, h->V, h->h_voff.data(), h->h_pidx.data()));
     std::vector<int32_t> p((size_t)h->F); // pose indices of the factors in solver order
     for (int64_t f = 0; f < h->F; ++f) p[f] = bs.iperm[h->h_pidx[f]];
-    HIPCHK(hipMemcpy(h->d_pidx, p.data(), (size_t)h->F * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPCHK(lvba::copy_h2d(h->d_pidx, p.data(), (size_t)h->F * sizeof(int32_t)));
     if (h->fused) {
         TRY(build_fused_tables(h, p));
     } else {
@@ -500,9 +512,42 @@ static int32_t enqueue_solve(lvba_balm_s *h, double u)
     return LVBA_OK;
 }
 
+// poses of the solver's order on the device -> caller's order on the host
+static int32_t download_poses(lvba_balm_s *h, const double *d_src, double *poses_out)
+{
+    const size_t bytes = (size_t)12 * h->N * sizeof(double);
+    if (bytes <= lvba::HostStage::kBytes) { // zero-copy, like upload_poses
+        if (void *st = lvba::HostStage::get().lock()) {
+            launch_export_poses(d_src, h->bs.d_perm, h->N, static_cast<double *>(st), h->stream());
+            const hipError_t e = hipStreamSynchronize(h->stream());
+            if (e == hipSuccess) memcpy(poses_out, st, bytes);
+            lvba::HostStage::get().unlock();
+            HIPCHK(e);
+            return LVBA_OK;
+        }
+    }
+    launch_export_poses(d_src, h->bs.d_perm, h->N, h->d_out, h->stream());
+    HIPCHK(hipStreamSynchronize(h->stream()));
+    HIPCHK(lvba::copy_d2h(poses_out, h->d_out, bytes));
+    return LVBA_OK;
+}
+
 static int32_t upload_poses(lvba_balm_s *h, const double *poses, double *d_dst)
 {
-    HIPCHK(hipMemcpyAsync(h->d_pose_in, poses, (size_t)12 * h->N * sizeof(double), hipMemcpyHostToDevice, h->stream()));
+    const size_t bytes = (size_t)12 * h->N * sizeof(double);
+    if (bytes <= lvba::HostStage::kBytes) { // zero-copy through the process-wide pinned stage (mempool.h: a copy costs ~20 ms here)
+        if (void *st = lvba::HostStage::get().lock()) {
+            memcpy(st, poses, bytes);
+            launch_import_poses(static_cast<const double *>(st), h->bs.d_perm, h->N, d_dst, h->stream());
+            const hipError_t e = hipStreamSynchronize(h->stream()); // the kernel has read the stage
+
+            lvba::HostStage::get().unlock();
+            HIPCHK(e);
+            return LVBA_OK;
+        }
+    }
+    HIPCHK(hipStreamSynchronize(h->stream())); // d_pose_in may still be read by an earlier import
+    HIPCHK(lvba::copy_h2d(h->d_pose_in, poses, bytes));
     launch_import_poses(h->d_pose_in, h->bs.d_perm, h->N, d_dst, h->stream());
     return LVBA_OK;
 }
@@ -648,9 +693,7 @@ extern "C" int32_t lvba_balm_lm_end(lvba_balm_t h, double *poses_out)
     if (!h->lm_active) return fail(LVBA_ERR_STATE, "lm_end without lm_begin");
     HIPCHK(hipSetDevice(h->bs.device));
     if (poses_out) {
-        launch_export_poses(h->d_pose_cur, h->bs.d_perm, h->N, h->d_out, h->stream());
-        HIPCHK(hipMemcpyAsync(poses_out, h->d_out, (size_t)12 * h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream()));
-        HIPCHK(hipStreamSynchronize(h->stream()));
+        TRY(download_poses(h, h->d_pose_cur, poses_out));
     }
     h->lm_active = false;
     return LVBA_OK;
@@ -680,6 +723,163 @@ extern "C" int32_t lvba_balm_refine(lvba_balm_t h, double *poses_inout, const lv
     if (rc < 0) return rc;
     if (rc2 != LVBA_OK) return rc2;
     if (worst != LVBA_OK) return fail(worst, "%s", worst_msg);
+    return LVBA_OK;
+}
+
+// ------------------------------------------------------------------------------------------ grouped LM
+// Several INDEPENDENT problems in one handle: group k owns the poses [pose_off[k], pose_off[k+1]) and the voxels
+// [voxel_off[k], voxel_off[k+1]), and every factor of its voxels is seen from one of its poses -- the windows of
+// LvbaSystem::runWindowBA (src/lvba_system.cpp:232-302), which the reference optimises one after the other.  The Hessian is
+// block diagonal, so ONE evaluation, ONE band factorisation (damping per group) and ONE cost pass serve all groups per LM
+// iteration; every group keeps the LM state of BALM2::damping_iter (bavoxel.hpp:662-767) for itself.
+extern "C" int32_t lvba_balm_set_groups(lvba_balm_t h, int32_t n_groups, const int32_t *pose_off, const int64_t *voxel_off)
+{
+    if (!h || !pose_off || !voxel_off) return fail(LVBA_ERR_ARG, "NULL argument");
+    if (h->finalized) return fail(LVBA_ERR_STATE, "set_groups must precede the first cost/eval/refine call");
+    if (h->bs.distributed()) return fail(LVBA_ERR_UNSUPPORTED, "groups and voxel shards do not combine");
+    if (n_groups < 1) return fail(LVBA_ERR_ARG, "n_groups must be >= 1");
+    if (pose_off[0] != 0 || pose_off[n_groups] != h->N || voxel_off[0] != 0 || voxel_off[n_groups] != h->V)
+        return fail(LVBA_ERR_ARG, "the groups must cover all poses and all voxels");
+    for (int32_t k = 0; k < n_groups; ++k) {
+        if (pose_off[k + 1] <= pose_off[k] || voxel_off[k + 1] <= voxel_off[k]) return fail(LVBA_ERR_ARG, "group %d is empty", k);
+        for (int64_t f = h->h_voff[voxel_off[k]]; f < h->h_voff[voxel_off[k + 1]]; ++f)
+            if (h->h_pidx[f] < pose_off[k] || h->h_pidx[f] >= pose_off[k + 1])
+                return fail(LVBA_ERR_ARG, "a voxel of group %d is seen from pose %d, which belongs to another group", k, h->h_pidx[f]);
+    }
+    HIPCHK(hipSetDevice(h->bs.device));
+    BlockSys &bs = h->bs;
+    // chunks must not straddle groups: the chunk table is made again with breaks at the group boundaries
+    std::vector<int64_t> chunk_v0;
+    int64_t Q = 0;
+    if (lvba::chunk_voxels(h->V, h->h_voff.data(), LVBA_CF, LVBA_CV, chunk_v0, Q, voxel_off + 1, n_groups - 1) >= 0)
+        return fail(LVBA_ERR_STATE, "chunk table");
+    lvba::DevicePool::get().free(h->d_chunk_v0); bs.device_bytes -= (h->n_chunks + 1) * (int64_t)sizeof(int64_t); h->d_chunk_v0 = nullptr;
+    lvba::DevicePool::get().free(h->d_chunk_cost); bs.device_bytes -= h->n_chunks * (int64_t)sizeof(double); h->d_chunk_cost = nullptr;
+    h->n_chunks = (int64_t)chunk_v0.size() - 1;
+    h->h_chunk_v0 = chunk_v0;
+    TRY(bs_dmalloc(bs, &h->d_chunk_v0, h->n_chunks + 1));
+    TRY(bs_dmalloc(bs, &h->d_chunk_cost, h->n_chunks));
+    HIPCHK(lvba::copy_h2d(h->d_chunk_v0, chunk_v0.data(), (size_t)(h->n_chunks + 1) * sizeof(int64_t)));
+    std::vector<int64_t> gco((size_t)n_groups + 1, 0);
+    {
+        int64_t c = 0;
+        for (int32_t k = 0; k <= n_groups; ++k) {
+            while (c < h->n_chunks && chunk_v0[(size_t)c] < voxel_off[k]) ++c;
+            if (chunk_v0[(size_t)c] != voxel_off[k]) return fail(LVBA_ERR_STATE, "group %d does not start on a chunk", k);
+            gco[(size_t)k] = c;
+        }
+    }
+    std::vector<int32_t> gof((size_t)h->N);
+    for (int32_t k = 0; k < n_groups; ++k)
+        for (int32_t j = pose_off[k]; j < pose_off[k + 1]; ++j) gof[(size_t)j] = k;
+    h->n_groups = n_groups;
+    h->g_pose_off.assign(pose_off, pose_off + n_groups + 1);
+    h->g_vox_off.assign(voxel_off, voxel_off + n_groups + 1);
+    TRY(bs_dmalloc(bs, &h->d_grp_of_pose, h->N));
+    TRY(bs_dmalloc(bs, &h->d_gpo, n_groups + 1));
+    TRY(bs_dmalloc(bs, &h->d_gaccept, n_groups));
+    TRY(bs_dmalloc(bs, &h->d_gco, n_groups + 1));
+    TRY(bs_dmalloc(bs, &h->d_gscal, 3 * (int64_t)n_groups));
+    HIPCHK(lvba::copy_h2d(h->d_grp_of_pose, gof.data(), (size_t)h->N * sizeof(int32_t)));
+    HIPCHK(lvba::copy_h2d(h->d_gpo, pose_off, (size_t)(n_groups + 1) * sizeof(int32_t)));
+    HIPCHK(lvba::copy_h2d(h->d_gco, gco.data(), (size_t)(n_groups + 1) * sizeof(int64_t)));
+    HIPCHK(hipHostMalloc((void **)&h->h_gpin, 3 * (size_t)n_groups * sizeof(double), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&h->h_gacc, (size_t)n_groups * sizeof(int32_t), hipHostMallocDefault));
+    // the caller's pose order is the solver's: the block-diagonal structure stays, and pose -> group is a plain table
+    bs.ordering = 0;
+    bs.n_groups = n_groups;
+    bs.d_grp_of_pose = h->d_grp_of_pose;
+    return LVBA_OK;
+}
+
+extern "C" int32_t lvba_balm_refine_groups(lvba_balm_t h, double *poses_inout, const lvba_balm_opts *opts, int32_t *n_iter,
+                                           int32_t *status, double *cost_first, double *cost_last)
+{
+    if (!h || !poses_inout) return fail(LVBA_ERR_ARG, "NULL argument");
+    if (h->n_groups < 1) return fail(LVBA_ERR_STATE, "refine_groups without set_groups");
+    TRY(finalize(h));
+    if (h->bs.d_bcr || h->fused) return fail(LVBA_ERR_UNSUPPORTED, "grouped refinement needs the LDL^T solver and the two-pass evaluation");
+    HIPCHK(hipSetDevice(h->bs.device));
+    lvba_balm_opts o;
+    if (opts) o = *opts; else lvba_balm_default_opts(&o);
+    if (o.max_iter < 0) return fail(LVBA_ERR_ARG, "max_iter < 0");
+    const int32_t G = h->n_groups;
+    const int64_t n = 6 * (int64_t)h->N;
+    (void)n;
+    BlockSys &bs = h->bs;
+    hipStream_t s = h->stream();
+    TRY(upload_poses(h, poses_inout, h->d_pose_cur));
+    struct St { double u, v, r1; bool calc, done; int iter; int32_t status; double first, last; };
+    std::vector<St> st((size_t)G);
+    for (auto &q : st) q = St{o.u0, o.v0, 0.0, true, o.max_iter == 0, 0, LVBA_OK, 0.0, 0.0};
+    std::vector<double> u((size_t)G);
+    double *c1 = h->d_gscal, *c2 = h->d_gscal + G, *q1d = h->d_gscal + 2 * (int64_t)G;
+    int32_t worst = LVBA_OK;
+    for (;;) {
+        bool any = false, need_eval = false;
+        for (const auto &q : st) { any = any || !q.done; need_eval = need_eval || (!q.done && q.calc); }
+        if (!any) break;
+        if (need_eval) { // :688-689 (groups whose last step was rejected get the same H, g, cost again: the kernels are deterministic)
+            TRY(enqueue_eval(h, h->d_pose_cur));
+
+            launch_reduce_chunks_groups(h->d_chunk_cost, h->d_gco, G, c1, s);
+        }
+        for (int32_t k = 0; k < G; ++k) u[(size_t)k] = st[(size_t)k].u;
+        ev_begin(h, EV_SOLVE);
+        TRY(bs_enqueue_solve_groups(bs, u.data()));                                            // :692-710
+        ev_end(h, EV_SOLVE);
+        launch_retract(h->d_pose_cur, bs.d_dx, h->d_pose_trial, h->N, s);                      // :722-727
+        launch_predicted_decrease_groups(bs.Hblk(), bs.Bb, bs.g(), bs.d_dx, bs.d_u, h->d_gpo, G, q1d, s); // :729
+        launch_cost_chunks(h->dev(), h->d_pose_trial, h->d_chunk_cost, s);                     // :731
+        launch_reduce_chunks_groups(h->d_chunk_cost, h->d_gco, G, c2, s);
+        HIPCHK(hipMemcpyAsync(h->h_gpin, h->d_gscal, 3 * (size_t)G * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(h->h_pin + 4, bs.d_status, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        ev_collect(h);
+        int pivot = 0;
+        memcpy(&pivot, h->h_pin + 4, sizeof(int));
+        // a zero pivot in one group's block poisons the band below it: the groups are not independent any more
+        if (pivot) return fail(LVBA_NUM_FACTORIZATION, "zero or non-finite pivot in LDL^T of the grouped system");
+        for (int32_t k = 0; k < G; ++k) {
+            St &q = st[(size_t)k];
+            h->h_gacc[k] = 0;
+            if (q.done) continue;
+            const double Vg = (double)(h->g_vox_off[(size_t)k + 1] - h->g_vox_off[(size_t)k]);
+            if (need_eval && q.calc) q.r1 = h->h_gpin[k] / Vg;                                 // AVG_THR :634-635
+            const double r1 = q.r1, r2 = h->h_gpin[G + k] / Vg, q1 = h->h_gpin[2 * G + k] / Vg; // :732
+            double dq = r1 - r2;                                                               // :736
+            if (!isfinite(r1) || !isfinite(r2)) q.status = LVBA_NUM_NONFINITE;
+            if (q.iter == 0) q.first = r1;
+            q.last = dq > 0 ? r2 : r1;
+            if (dq > 0) {                                                                      // :744-752
+                h->h_gacc[k] = 1;
+                dq = dq / q1;
+                q.v = 2.0;
+                dq = 1.0 - pow(2.0 * dq - 1.0, 3.0);
+                q.u *= (dq < (1.0 / 3.0) ? (1.0 / 3.0) : dq);
+                q.calc = true;
+            } else {                                                                           // :753-758
+                q.u = q.u * q.v;
+                q.v = 2.0 * q.v;
+                q.calc = false;
+            }
+            q.iter += 1;
+            if (fabs(r1 - r2) / r1 < o.rel_tol) q.done = true;                                 // :760
+            if (q.iter >= o.max_iter) q.done = true;                                           // :686
+            if (q.status > worst) worst = q.status;
+        }
+        HIPCHK(hipMemcpyAsync(h->d_gaccept, h->h_gacc, (size_t)G * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        launch_select_poses(h->d_pose_cur, h->d_pose_trial, h->d_gaccept, h->d_grp_of_pose, h->N, s);
+        HIPCHK(hipStreamSynchronize(s)); // h_gacc is rewritten in the next iteration
+    }
+    TRY(download_poses(h, h->d_pose_cur, poses_inout));
+    for (int32_t k = 0; k < G; ++k) {
+        if (n_iter) n_iter[k] = st[(size_t)k].iter;
+        if (status) status[k] = st[(size_t)k].status;
+        if (cost_first) cost_first[k] = st[(size_t)k].first;
+        if (cost_last) cost_last[k] = st[(size_t)k].last;
+    }
+    if (worst != LVBA_OK) return fail(worst, "non-finite cost in a group");
     return LVBA_OK;
 }
 

@@ -104,6 +104,12 @@ void launch_pairs(const PairDev &pd, double *Hblk, hipStream_t s);
 void launch_eval_fused(const BalmDev &d, const FusedDev &fd, const PairDev &pd, const double *poses, double *Hblk, int64_t hblk_doubles,
                        double *g, double *chunk_cost, double *out, bool zero_first, hipStream_t s, hipEvent_t k0, hipEvent_t k1);
 void launch_aos_to_soa(const double *aos, const int32_t *fmap, int64_t F, double *soa, hipStream_t s);
+// grouped refinement (lvba_balm_refine_groups)
+void launch_reduce_chunks_groups(const double *chunk_cost, const int64_t *gco, int n_groups, double *out, hipStream_t s);
+void launch_cost_chunks(const BalmDev &d, const double *poses, double *chunk_cost, hipStream_t s);
+void launch_predicted_decrease_groups(const double *Hblk, int band_blocks, const double *g, const double *dx, const double *u,
+                                      const int32_t *gpo, int n_groups, double *out, hipStream_t s);
+void launch_select_poses(double *cur, const double *trial, const int32_t *accept, const int32_t *grp_of_pose, int n_poses, hipStream_t s);
 void launch_gather_csc(const double *clu, const int32_t *csc_f, int64_t F, double *clu_csc, hipStream_t s);
 void launch_retract(const double *poses, const double *dx, double *out, int n_poses, hipStream_t s);
 void launch_predicted_decrease(const double *Hblk, int band_blocks, const double *g, const double *dx, double u,
@@ -146,7 +152,8 @@ struct LdltDist {
     int32_t (*allreduce_max_i32)(void *ctx, int *dbuf);
 };
 int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_poses, const double *g,
-                   const double *u_dev, double *x, double *work, int *status, hipStream_t s, const LdltDist *dist = nullptr);
+                   const double *u_dev, double *x, double *work, int *status, hipStream_t s, const LdltDist *dist = nullptr,
+                   const int32_t *grp = nullptr); // grp: pose block -> entry of u_dev (grouped refinement)
 
 // bcr.hip: block cyclic reduction for narrow-band SPD systems (the visual stage's reduced camera system)
 bool bcr_applicable(int n_poses, int band_blocks);

@@ -134,9 +134,9 @@ int32_t adjacency_build(hipStream_t s, int64_t G, const int64_t *h_voff, int64_t
         }
         if (poff[G] != Q) return LVBA_ERR_STATE;
         HIPCHK(d_voff.alloc(8 * ((size_t)G + 1))); HIPCHK(d_poff.alloc(8 * ((size_t)G + 1))); HIPCHK(d_pidx.alloc(4 * (size_t)F));
-        HIPCHK(hipMemcpyAsync(d_voff.p, h_voff, 8 * ((size_t)G + 1), hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(d_poff.p, poff.data(), 8 * ((size_t)G + 1), hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(d_pidx.p, h_pidx, 4 * (size_t)F, hipMemcpyHostToDevice, s));
+        HIPCHK(lvba::copy_h2d(d_voff.p, h_voff, 8 * ((size_t)G + 1)));
+        HIPCHK(lvba::copy_h2d(d_poff.p, poff.data(), 8 * ((size_t)G + 1)));
+        HIPCHK(lvba::copy_h2d(d_pidx.p, h_pidx, 4 * (size_t)F)); // (pieces below the pinning threshold: mempool.h)
         adj_kernel<<<(unsigned)((Q + 255) / 256), 256, 0, s>>>((const int64_t *)d_voff.p, (const int64_t *)d_poff.p,
                                                                (const int32_t *)d_pidx.p, G, Q, N, (uint8_t *)d_adj.p);
         HIPCHK(hipGetLastError());
@@ -161,8 +161,8 @@ int32_t csc_build(hipStream_t s, int64_t G, const int64_t *h_voff, int64_t F, co
     if (F > 0) {
         HIPCHK(d_pidx.alloc(4 * (size_t)F)); HIPCHK(d_voff.alloc(8 * ((size_t)G + 1)));
         HIPCHK(key.alloc(4 * (size_t)F)); HIPCHK(val.alloc(4 * (size_t)F)); HIPCHK(key_s.alloc(4 * (size_t)F)); HIPCHK(val_s.alloc(4 * (size_t)F));
-        HIPCHK(hipMemcpyAsync(d_pidx.p, h_pidx, 4 * (size_t)F, hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(d_voff.p, h_voff, 8 * ((size_t)G + 1), hipMemcpyHostToDevice, s));
+        HIPCHK(lvba::copy_h2d(d_pidx.p, h_pidx, 4 * (size_t)F)); // (pieces below the pinning threshold: mempool.h)
+        HIPCHK(lvba::copy_h2d(d_voff.p, h_voff, 8 * ((size_t)G + 1)));
         csc_key_kernel<<<(unsigned)((F + 255) / 256), 256, 0, s>>>(F, (const int32_t *)d_pidx.p, (const int32_t *)d_iperm.p,
                                                                    (uint32_t *)key.p, (uint32_t *)val.p, d_blk_of);
         HIPCHK(hipGetLastError());
@@ -217,8 +217,8 @@ int32_t pair_lists_build(hipStream_t s, int64_t G, const int64_t *h_voff, int64_
     HIPCHK(k_in.alloc((size_t)Q * 8));
     HIPCHK(k_out.alloc((size_t)Q * 8));
     HIPCHK(v_in.alloc((size_t)Q * 8));
-    HIPCHK(hipMemcpyAsync(d_voff.p, h_voff, (size_t)(G + 1) * 8, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(d_poff.p, poff.data(), (size_t)(G + 1) * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(lvba::copy_h2d(d_voff.p, h_voff, (size_t)(G + 1) * 8));
+    HIPCHK(lvba::copy_h2d(d_poff.p, poff.data(), (size_t)(G + 1) * 8));
     pair_gen_kernel<<<(unsigned)((Q + 255) / 256), 256, 0, s>>>((const int64_t *)d_voff.p, (const int64_t *)d_poff.p,
                                                                 d_blk_of, d_pos_of, G, Q, tiles_per_row, window_groups,
                                                                 block_bits, (uint64_t *)k_in.p, (uint64_t *)v_in.p);
@@ -247,12 +247,12 @@ int32_t pair_lists_build(hipStream_t s, int64_t G, const int64_t *h_voff, int64_
         HIPCHK(hipStreamSynchronize(s));
     }
     uint64_t n_runs = 0;
-    HIPCHK(hipMemcpy(&n_runs, nruns.p, 8, hipMemcpyDeviceToHost));
+    HIPCHK(lvba::copy_d2h(&n_runs, nruns.p, 8));
     std::vector<uint64_t> h_uniq((size_t)n_runs);
     std::vector<uint32_t> h_cnt((size_t)n_runs);
     if (n_runs) {
-        HIPCHK(hipMemcpy(h_uniq.data(), uniq.p, (size_t)n_runs * 8, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(h_cnt.data(), cnt.p, (size_t)n_runs * 4, hipMemcpyDeviceToHost));
+        HIPCHK(lvba::copy_d2h(h_uniq.data(), uniq.p, (size_t)n_runs * 8));
+        HIPCHK(lvba::copy_d2h(h_cnt.data(), cnt.p, (size_t)n_runs * 4));
     }
     blk_slot.resize((size_t)n_runs);
     blk_off.resize((size_t)n_runs + 1);

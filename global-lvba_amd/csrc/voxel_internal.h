@@ -17,6 +17,10 @@ struct lvba_scans_s {
     int64_t *d_frame_off = nullptr;
 };
 
+struct lvba_voxmap_s;
+// the admitted voxels' clusters of a map, [n_factors][10] on the device (voxelize.hip; for the window driver's joint problem)
+const double *lvba_voxmap_clusters(const lvba_voxmap_s *h);
+
 namespace lvba {
 
 inline double now_ms()

@@ -574,6 +574,8 @@ struct lvba_voxmap_s {
     double *d_clusters = nullptr;
 };
 
+const double *lvba_voxmap_clusters(const lvba_voxmap_s *h) { return h ? h->d_clusters : nullptr; }
+
 extern "C" int64_t lvba_release_cached_memory(void) { return (int64_t)DevicePool::get().release(); }
 
 extern "C" void lvba_voxel_default_opts(lvba_voxel_opts *o)
@@ -634,12 +636,12 @@ extern "C" int32_t lvba_scans_create(int32_t device, int32_t n_frames, const voi
         if (frame_count[f] > 0) {
             float *dst = sc->d_pts + 3 * sc->frame_off[f];
             e = point_stride_bytes == 12
-                    ? hipMemcpy(dst, frame_points[f], 12 * (size_t)frame_count[f], hipMemcpyHostToDevice)
+                    ? lvba::copy_h2d(dst, frame_points[f], 12 * (size_t)frame_count[f])
                     : hipMemcpy2D(dst, 12, frame_points[f], (size_t)point_stride_bytes, 12, (size_t)frame_count[f],
                                   hipMemcpyHostToDevice);
             if (e != hipSuccess) return fail(e, "hipMemcpy(points)");
         }
-    if ((e = hipMemcpy(sc->d_frame_off, sc->frame_off.data(), 8 * ((size_t)n_frames + 1), hipMemcpyHostToDevice)) != hipSuccess)
+    if ((e = lvba::copy_h2d(sc->d_frame_off, sc->frame_off.data(), 8 * ((size_t)n_frames + 1))) != hipSuccess)
         return fail(e, "hipMemcpy(frame_off)");
     *out = sc;
     return LVBA_OK;
@@ -674,7 +676,9 @@ int32_t voxmap_build_impl(lvba_voxmap_s *h, const lvba_scans_s *sc, int frame_be
 
     DevBuf d_poses(s);
     HIPCHK(d_poses.alloc(96 * (size_t)nfr));
-    HIPCHK(hipMemcpyAsync(d_poses.p, poses, 96 * (size_t)nfr, hipMemcpyHostToDevice, s));
+    // (small transfers to / from the caller's PAGEABLE memory go through the synchronous copy: the asynchronous one pins the
+    // pages on the fly, which was measured at up to 24 ms for 30 KB)
+    HIPCHK(lvba::copy_h2d(d_poses.p, poses, 96 * (size_t)nfr));
 
     // -- 1./2. keys + records, root sort (stable: inside a root the records stay frame-major, cloud order inside a frame),
     //          root table and (root, frame) segment table
@@ -690,8 +694,8 @@ int32_t voxmap_build_impl(lvba_voxmap_s *h, const lvba_scans_s *sc, int frame_be
                                                         idx.as<uint32_t>(), d_err.as<int>());
         HIPCHK(hipGetLastError());
         int err = 0;
-        HIPCHK(hipMemcpyAsync(&err, d_err.p, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(lvba::copy_d2h(&err, d_err.p, 4));
         if (err) return lvba_fail(LVBA_ERR_ARG, "a point is non-finite or its voxel key exceeds +-2^20 after the pose transform");
         h->info.key_ms = now_ms() - t0; t0 = now_ms();
         TRY(sort_pairs(s, key.as<uint64_t>(), key_s.as<uint64_t>(), idx.as<uint32_t>(), idx0.as<uint32_t>(), (size_t)P, 63));
@@ -706,8 +710,8 @@ int32_t voxmap_build_impl(lvba_voxmap_s *h, const lvba_scans_s *sc, int frame_be
         TRY(scan_incl<uint32_t>(s, head_root.as<uint32_t>(), incl_root.as<uint32_t>(), (size_t)P));
         TRY(scan_incl<uint32_t>(s, head_seg.as<uint32_t>(), incl_seg.as<uint32_t>(), (size_t)P));
         uint32_t last[2] = {0, 0};
-        HIPCHK(hipMemcpy(&last[0], incl_root.as<uint32_t>() + (P - 1), 4, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(&last[1], incl_seg.as<uint32_t>() + (P - 1), 4, hipMemcpyDeviceToHost));
+        HIPCHK(lvba::copy_d2h(&last[0], incl_root.as<uint32_t>() + (P - 1), 4));
+        HIPCHK(lvba::copy_d2h(&last[1], incl_seg.as<uint32_t>() + (P - 1), 4));
         R = last[0]; NS = last[1];
         HIPCHK(root_key.alloc(8 * (size_t)R)); HIPCHK(root_seg.alloc(4 * ((size_t)R + 1)));
         HIPCHK(seg_start.alloc(4 * ((size_t)NS + 1))); HIPCHK(seg_root.alloc(4 * (size_t)NS)); HIPCHK(seg_frame.alloc(4 * (size_t)NS));
@@ -754,8 +758,8 @@ int32_t voxmap_build_impl(lvba_voxmap_s *h, const lvba_scans_s *sc, int frame_be
     TRY(scan_excl<uint32_t>(s, is_split.as<uint32_t>(), split_excl.as<uint32_t>(), (size_t)R + 1));
     TRY(scan_excl<uint32_t>(s, seg_split.as<uint32_t>(), seg_excl.as<uint32_t>(), (size_t)NS + 1));
     uint32_t NRS = 0, NSS = 0;
-    HIPCHK(hipMemcpy(&NRS, split_excl.as<uint32_t>() + R, 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&NSS, seg_excl.as<uint32_t>() + NS, 4, hipMemcpyDeviceToHost));
+    HIPCHK(lvba::copy_d2h(&NRS, split_excl.as<uint32_t>() + R, 4));
+    HIPCHK(lvba::copy_d2h(&NSS, seg_excl.as<uint32_t>() + NS, 4));
 
     DevBuf split_roots(s), split_segs(s), m1(s), m2(s), cnt(s), base(s), nodecl(s), tmp_count(s), tmp_base(s), tmp_plane(s), tmp_nf(s);
     SplitArgs sa{};
@@ -771,7 +775,7 @@ int32_t voxmap_build_impl(lvba_voxmap_s *h, const lvba_scans_s *sc, int frame_be
         HIPCHK(hipGetLastError());
         TRY(scan_excl<uint32_t>(s, cnt.as<uint32_t>(), base.as<uint32_t>(), (size_t)NSS + 1));
         uint32_t NN = 0;
-        HIPCHK(hipMemcpy(&NN, base.as<uint32_t>() + NSS, 4, hipMemcpyDeviceToHost));
+        HIPCHK(lvba::copy_d2h(&NN, base.as<uint32_t>() + NSS, 4));
         HIPCHK(nodecl.alloc(80 * (size_t)NN));
         vox_split_cluster_kernel<<<NSS, 64, 0, s>>>(split_segs.as<uint32_t>(), seg_start.as<uint32_t>(), rec_s.as<float4>(),
                                                     m1.as<uint32_t>(), m2.as<uint64_t>(), base.as<uint32_t>(), nodecl.as<double>());
@@ -799,9 +803,9 @@ int32_t voxmap_build_impl(lvba_voxmap_s *h, const lvba_scans_s *sc, int frame_be
     TRY(scan_excl<int64_t>(s, n_fac.as<int64_t>(), fac_first.as<int64_t>(), (size_t)R + 1));
     int32_t n_planes = 0, V = 0;
     int64_t F = 0;
-    HIPCHK(hipMemcpy(&n_planes, plane_first.as<int32_t>() + R, 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&V, vox_first.as<int32_t>() + R, 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&F, fac_first.as<int64_t>() + R, 8, hipMemcpyDeviceToHost));
+    HIPCHK(lvba::copy_d2h(&n_planes, plane_first.as<int32_t>() + R, 4));
+    HIPCHK(lvba::copy_d2h(&V, vox_first.as<int32_t>() + R, 4));
+    HIPCHK(lvba::copy_d2h(&F, fac_first.as<int64_t>() + R, 8));
     h->info.n_planes = n_planes; h->info.n_voxels = V; h->info.n_factors = F;
     h->info.count_ms = now_ms() - t0; t0 = now_ms();
 
@@ -822,8 +826,8 @@ int32_t voxmap_build_impl(lvba_voxmap_s *h, const lvba_scans_s *sc, int frame_be
         vox_split_emit_kernel<<<NRS, 64, 0, s>>>(sa);
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipMemcpyAsync(vox_off.as<int64_t>() + V, &F, 8, hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(lvba::copy_h2d(vox_off.as<int64_t>() + V, &F, 8));
     h->info.write_ms = now_ms() - t0;
 
     h->d_root_key = (uint64_t *)root_key.release();
@@ -901,16 +905,16 @@ extern "C" int32_t lvba_voxmap_export(lvba_voxmap_t h, int64_t *voxel_off, int32
     HIPCHK(hipSetDevice(h->device));
     const int64_t V = h->info.n_voxels, F = h->info.n_factors;
     if (voxel_off) {
-        if (V > 0) HIPCHK(hipMemcpy(voxel_off, h->d_vox_off, 8 * (V + 1), hipMemcpyDeviceToHost));
+        if (V > 0) HIPCHK(lvba::copy_d2h(voxel_off, h->d_vox_off, 8 * (V + 1)));
         else voxel_off[0] = 0;
     }
-    if (pose_idx && F > 0) HIPCHK(hipMemcpy(pose_idx, h->d_pose_idx, 4 * F, hipMemcpyDeviceToHost));
-    if (clusters && F > 0) HIPCHK(hipMemcpy(clusters, h->d_clusters, 80 * F, hipMemcpyDeviceToHost));
+    if (pose_idx && F > 0) HIPCHK(lvba::copy_d2h(pose_idx, h->d_pose_idx, 4 * F));
+    if (clusters && F > 0) HIPCHK(lvba::copy_d2h(clusters, h->d_clusters, 80 * F));
     if (voxel_key && V > 0) {
         std::vector<int32_t> label(2 * V);
         std::vector<uint64_t> rk(h->info.n_roots);
-        HIPCHK(hipMemcpy(label.data(), h->d_vox_label, 8 * V, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(rk.data(), h->d_root_key, 8 * h->info.n_roots, hipMemcpyDeviceToHost));
+        HIPCHK(lvba::copy_d2h(label.data(), h->d_vox_label, 8 * V));
+        HIPCHK(lvba::copy_d2h(rk.data(), h->d_root_key, 8 * h->info.n_roots));
         for (int64_t v = 0; v < V; ++v) {
             const uint64_t k = rk[label[2 * v]];
             voxel_key[4 * v + 0] = (int64_t)(k >> 42) - KEY_BIAS;

@@ -12,6 +12,7 @@
 // global stages' lvba_voxmap_build_scans directly.
 // down_sampling_voxel2 emits survivors in unordered_map order (unspecified); here: sorted by voxel key (x, y, z).
 #include <atomic>
+#include <functional>
 #include <string>
 #include <thread>
 #include "voxel_internal.h"
@@ -117,7 +118,7 @@ extern "C" void lvba_window_default_opts(lvba_window_opts *o)
     o->window_size = 10;     // include/dataset_io.h:71
     o->use_rel = 1;          // config.yaml window_ba.use_window_ba_rel
     o->merge_only = 0;
-    o->reserved = 0;
+    o->lm_mode = 0;
     o->anchor_leaf = 0.1;    // include/dataset_io.h:72
     lvba_voxel_default_opts(&o->voxel);
     o->voxel.voxel_size = 0.5; // stage1_root_voxel_size_, include/dataset_io.h:76
@@ -139,7 +140,7 @@ extern "C" int32_t lvba_scans_download(lvba_scans_t sc, int32_t frame, float *xy
     if (frame < 0 || frame >= sc->n_frames) return lvba_fail(LVBA_ERR_ARG, "frame %d out of range [0,%d)", frame, sc->n_frames);
     HIPCHK(hipSetDevice(sc->device));
     const int64_t n = sc->frame_off[frame + 1] - sc->frame_off[frame];
-    if (n > 0) HIPCHK(hipMemcpy(xyz, sc->d_pts + 3 * sc->frame_off[frame], 12 * (size_t)n, hipMemcpyDeviceToHost));
+    if (n > 0) HIPCHK(lvba::copy_d2h(xyz, sc->d_pts + 3 * sc->frame_off[frame], 12 * (size_t)n));
     return LVBA_OK;
 }
 
@@ -171,57 +172,142 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
     std::vector<AnchorCloud> clouds;
     auto free_clouds = [&]() { for (auto &c : clouds) DevicePool::get().free(c.d); clouds.clear(); };
     // One window = map -> problem -> LM -> anchor cloud; windows are independent (src/lvba_system.cpp:232-302 runs them one
-    // after the other), and a single window leaves the GPU idle most of the time (its 5.6 ms are mostly host-side set-up and
-    // launch / synchronisation latency), so a few host threads, each with its own stream and handles, work through them
-    // concurrently (LVBA_WINDOW_THREADS, default 4; 1 = in the calling thread).  Results are assembled in window order below.
-    struct WinResult { int32_t rc = LVBA_OK; std::string err; lvba_window_info info{}; std::vector<double> x, rel; float *d_out = nullptr; int64_t n_out = 0; };
+    // after the other).  Three stages:
+    //   1. voxel map of every window (a few host threads, each with its own stream: a single map build leaves the GPU idle
+    //      most of the time -- launch and synchronisation latency);
+    //   2. the LM refinements of ALL windows in lock-step as one grouped problem (lvba_balm_set_groups /
+    //      lvba_balm_refine_groups: one evaluation, one band factorisation with a damping value per window, one cost pass per
+    //      iteration for all windows; every window keeps its own LM state).  lm_mode = 1 (or LVBA_WINDOW_BATCH=0), a single
+    //      window, or a broken pivot in the joint factorisation: one window at a time, as before;
+    //   3. alignment, relative poses, anchor merge + down-sampling per window (host threads again).
+    // Results are assembled in window order below.
+    struct WinResult { int32_t rc = LVBA_OK; std::string err; lvba_window_info info{}; std::vector<double> x, rel; float *d_out = nullptr; int64_t n_out = 0;
+                       lvba_voxmap_t map = nullptr; bool refined = false; };
     const int n_win = (n + w - 1) / w;
     std::vector<WinResult> results((size_t)n_win);
-    auto process = [&](int wi, hipStream_t s, WinResult &R) -> int32_t {
-        const int start = wi * w;
-        const int cw = std::min(w, n - start);
+    auto win_range = [&](int wi, int &start, int &cw) { start = wi * w; cw = std::min(w, n - start); };
+    // ---- stage 1: the voxel map at the odometry poses (:247-257) and the skip rule (:258-262)
+    auto stage_map = [&](int wi, hipStream_t, WinResult &R) -> int32_t {
+        int start, cw;
+        win_range(wi, start, cw);
         lvba_window_info &info = R.info;
         info = lvba_window_info{};
         info.start = start; info.n_frames = cw; info.anchor = -1;
         const double *x_odom = poses + 12 * (int64_t)start;
-        std::vector<double> &x = R.x;
-        x.assign(x_odom, x_odom + 12 * (size_t)cw);
-        double tw = now_ms();
-        if (!o.merge_only) {
-        lvba_voxmap_t map = nullptr;
-        int32_t rc = lvba_voxmap_build_scans(sc, start, cw, x_odom, &o.voxel, &map);
+        R.x.assign(x_odom, x_odom + 12 * (size_t)cw);
+        if (o.merge_only) return LVBA_OK;
+        const double tw = now_ms();
+        int32_t rc = lvba_voxmap_build_scans(sc, start, cw, x_odom, &o.voxel, &R.map);
         if (rc != LVBA_OK) return rc;
         lvba_voxmap_info_t mi;
-        lvba_voxmap_info(map, &mi);
+        lvba_voxmap_info(R.map, &mi);
         info.n_voxels = mi.n_voxels; info.n_factors = mi.n_factors;
-        info.map_ms = now_ms() - tw; tw = now_ms();
+        info.map_ms = now_ms() - tw;
         if (mi.n_voxels < 3 * (int64_t)cw) { // :258-262
             info.skipped = 1;
-            lvba_voxmap_destroy(map);
-            return LVBA_OK;
+            lvba_voxmap_destroy(R.map);
+            R.map = nullptr;
         }
-        {
-            lvba_balm_t b = nullptr;
-            rc = lvba_voxmap_to_balm(map, &b);
-            lvba_voxmap_destroy(map);
-            if (rc != LVBA_OK) return rc;
-            std::vector<lvba_lm_trace> trace((size_t)std::max(1, o.lm.max_iter));
-            int32_t nt = 0;
-            lvba_balm_info_t bi;
-            lvba_balm_info(b, &bi); // forces the one-off problem set-up (ordering, pair lists) so that it is timed apart
-            info.setup_ms = now_ms() - tw;
-            rc = lvba_balm_refine(b, x.data(), &o.lm, trace.data(), &nt);
-            lvba_balm_destroy(b);
-            if (rc < 0) return rc;
-            info.lm_status = rc; info.n_iter = nt;
-            if (nt > 0) {
-                info.cost_first = trace[0].residual1;
-                info.cost_last = trace[nt - 1].accepted ? trace[nt - 1].residual2 : trace[nt - 1].residual1;
-            }
+        return LVBA_OK;
+    };
+    // ---- stage 2, one window at a time: damping_iter on the window's own problem (:264)
+    auto stage_lm_single = [&](int wi, hipStream_t, WinResult &R) -> int32_t {
+        if (!R.map || R.refined) return LVBA_OK;
+        lvba_window_info &info = R.info;
+        double tw = now_ms();
+        lvba_balm_t b = nullptr;
+        int32_t rc = lvba_voxmap_to_balm(R.map, &b);
+        lvba_voxmap_destroy(R.map);
+        R.map = nullptr;
+        if (rc != LVBA_OK) return rc;
+        std::vector<lvba_lm_trace> trace((size_t)std::max(1, o.lm.max_iter));
+        int32_t nt = 0;
+        lvba_balm_info_t bi;
+        lvba_balm_info(b, &bi); // forces the one-off problem set-up (ordering, pair lists) so that it is timed apart
+        info.setup_ms = now_ms() - tw;
+        rc = lvba_balm_refine(b, R.x.data(), &o.lm, trace.data(), &nt);
+        lvba_balm_destroy(b);
+        if (rc < 0) return rc;
+        info.lm_status = rc; info.n_iter = nt;
+        if (nt > 0) {
+            info.cost_first = trace[0].residual1;
+            info.cost_last = trace[nt - 1].accepted ? trace[nt - 1].residual2 : trace[nt - 1].residual1;
         }
-        } // !merge_only
-        info.solve_ms = now_ms() - tw; tw = now_ms();
-        // alignment (:268-279) and relative poses (:284-299)
+        info.solve_ms = now_ms() - tw;
+        R.refined = true;
+        (void)wi;
+        return LVBA_OK;
+    };
+    // ---- stage 2, all windows at once.  Returns LVBA_OK with `done` = false when the windows have to go one by one.
+    auto stage_lm_batched = [&](bool &done) -> int32_t {
+        done = false;
+        std::vector<int> live;
+        for (int wi = 0; wi < n_win; ++wi)
+            if (results[(size_t)wi].map) live.push_back(wi);
+        if (live.size() < 2) return LVBA_OK;
+        const double t0 = now_ms();
+        const int G = (int)live.size();
+        std::vector<int32_t> pose_off((size_t)G + 1, 0);
+        std::vector<int64_t> vox_off((size_t)G + 1, 0), fac_off((size_t)G + 1, 0);
+        for (int k = 0; k < G; ++k) {
+            const WinResult &R = results[(size_t)live[(size_t)k]];
+            pose_off[(size_t)k + 1] = pose_off[(size_t)k] + R.info.n_frames;
+            vox_off[(size_t)k + 1] = vox_off[(size_t)k] + R.info.n_voxels;
+            fac_off[(size_t)k + 1] = fac_off[(size_t)k] + R.info.n_factors;
+        }
+        const int64_t V = vox_off[(size_t)G], F = fac_off[(size_t)G];
+        if (F >= ((int64_t)1 << 31)) return LVBA_OK; // too large for one handle: one by one
+        std::vector<int64_t> off((size_t)V + 1, 0);
+        std::vector<int32_t> idx((size_t)F);
+        std::vector<double> x(12 * (size_t)pose_off[(size_t)G]);
+        DevBuf d_clu(s);
+        HIPCHK(d_clu.alloc(80 * (size_t)F));
+        for (int k = 0; k < G; ++k) {
+            const WinResult &R = results[(size_t)live[(size_t)k]];
+            const int64_t v0 = vox_off[(size_t)k], f0 = fac_off[(size_t)k], nv = R.info.n_voxels, nf = R.info.n_factors;
+            std::vector<int64_t> o1((size_t)nv + 1);
+            TRY(lvba_voxmap_export(R.map, o1.data(), idx.data() + f0, nullptr, nullptr)); // CSR structure to the host, clusters stay in HBM
+            for (int64_t a = 0; a <= nv; ++a) off[(size_t)(v0 + a)] = f0 + (o1[(size_t)a] - o1[0]);
+            for (int64_t f = f0; f < f0 + nf; ++f) idx[(size_t)f] += pose_off[(size_t)k];
+            HIPCHK(hipMemcpyAsync(d_clu.as<double>() + 10 * f0, lvba_voxmap_clusters(R.map), 80 * (size_t)nf, hipMemcpyDeviceToDevice, s));
+            memcpy(x.data() + 12 * (size_t)pose_off[(size_t)k], R.x.data(), 96 * (size_t)R.info.n_frames);
+        }
+        HIPCHK(hipStreamSynchronize(s));
+        lvba_balm_t b = nullptr;
+        TRY(lvba_balm_create_dev(pose_off[(size_t)G], V, off.data(), idx.data(), d_clu.as<double>(), sc->device, &b));
+        struct Guard { lvba_balm_t b; ~Guard() { if (b) lvba_balm_destroy(b); } } guard{b};
+        TRY(lvba_balm_set_groups(b, G, pose_off.data(), vox_off.data()));
+        lvba_balm_info_t bi;
+        TRY(lvba_balm_info(b, &bi)); // the one-off set-up, timed apart
+        const double t1 = now_ms();
+        std::vector<int32_t> n_iter((size_t)G), status((size_t)G);
+        std::vector<double> first((size_t)G), last((size_t)G);
+        const int32_t rc = lvba_balm_refine_groups(b, x.data(), &o.lm, n_iter.data(), status.data(), first.data(), last.data());
+        if (rc == LVBA_NUM_FACTORIZATION) return LVBA_OK; // the windows are not independent in a broken factorisation: one by one
+        if (rc < 0) return rc;
+        const double t2 = now_ms();
+        for (int k = 0; k < G; ++k) {
+            WinResult &R = results[(size_t)live[(size_t)k]];
+            memcpy(R.x.data(), x.data() + 12 * (size_t)pose_off[(size_t)k], 96 * (size_t)R.info.n_frames);
+            R.info.n_iter = n_iter[(size_t)k]; R.info.lm_status = status[(size_t)k];
+            R.info.cost_first = first[(size_t)k]; R.info.cost_last = last[(size_t)k];
+            R.info.setup_ms = (t1 - t0) / G; R.info.solve_ms = (t2 - t0) / G; // the joint problem's times, shared out evenly
+            R.refined = true;
+            lvba_voxmap_destroy(R.map);
+            R.map = nullptr;
+        }
+        done = true;
+        return LVBA_OK;
+    };
+    // ---- stage 3: alignment (:268-279), relative poses (:284-299), merge + down_sampling_voxel2 on the device
+    auto stage_finish = [&](int wi, hipStream_t s, WinResult &R) -> int32_t {
+        int start, cw;
+        win_range(wi, start, cw);
+        lvba_window_info &info = R.info;
+        if (info.skipped) return LVBA_OK;
+        const double *x_odom = poses + 12 * (int64_t)start;
+        std::vector<double> &x = R.x;
+        double tw = now_ms();
         std::vector<double> &rel = R.rel;
         rel.assign(12 * (size_t)cw, 0.0);
         const double *Ro0 = x_odom, *po0 = x_odom + 9;
@@ -255,7 +341,7 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
         if (P > 0) {
             DevBuf d_rel(s), merged(s), key(s), d2(s), idx(s), d_err(s);
             HIPCHK(d_rel.alloc(96 * (size_t)cw)); HIPCHK(merged.alloc(12 * (size_t)P)); HIPCHK(d_err.alloc(4));
-            HIPCHK(hipMemcpyAsync(d_rel.p, rel.data(), 96 * (size_t)cw, hipMemcpyHostToDevice, s));
+            HIPCHK(lvba::copy_h2d(d_rel.p, rel.data(), 96 * (size_t)cw)); // (pageable source: synchronous copy, voxelize.hip)
             HIPCHK(hipMemsetAsync(d_err.p, 0, 4, s));
             if (down) { HIPCHK(key.alloc(8 * (size_t)P)); HIPCHK(d2.alloc(8 * (size_t)P)); HIPCHK(idx.alloc(4 * (size_t)P)); }
             wba_merge_kernel<<<grid_for(P, 256), 256, 0, s>>>(P, sc->d_pts + 3 * p_begin, sc->d_frame_off + start, cw, d_rel.as<double>(),
@@ -267,8 +353,8 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
                 d_out = (float *)merged.release();
             } else {
                 int err = 0;
-                HIPCHK(hipMemcpyAsync(&err, d_err.p, 4, hipMemcpyDeviceToHost, s));
                 HIPCHK(hipStreamSynchronize(s));
+                HIPCHK(lvba::copy_d2h(&err, d_err.p, 4));
                 if (err) { return lvba_fail(LVBA_ERR_ARG, "window %d: a merged point is non-finite or outside +-2^20 anchor leaves", wi); }
                 DevBuf key_s(s), order(s), flag(s), excl(s), pick(s);
                 HIPCHK(key_s.alloc(8 * (size_t)P)); HIPCHK(order.alloc(4 * (size_t)P)); HIPCHK(flag.alloc(4 * ((size_t)P + 1)));
@@ -280,7 +366,7 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
                 HIPCHK(hipMemsetAsync(flag.as<uint32_t>() + P, 0, 4, s));
                 TRY(scan_excl<uint32_t>(s, flag.as<uint32_t>(), excl.as<uint32_t>(), (size_t)P + 1));
                 uint32_t cnt = 0;
-                HIPCHK(hipMemcpy(&cnt, excl.as<uint32_t>() + P, 4, hipMemcpyDeviceToHost));
+                HIPCHK(lvba::copy_d2h(&cnt, excl.as<uint32_t>() + P, 4));
                 n_out = cnt;
                 void *raw = nullptr;
                 HIPCHK(DevicePool::get().alloc(&raw, 12 * (size_t)std::max<int64_t>(n_out, 1)));
@@ -296,42 +382,74 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
         R.d_out = d_out; R.n_out = n_out;
         return LVBA_OK;
     };
-    {
+    // a stage over all windows, on a small pool of host threads (LVBA_WINDOW_THREADS, default 4; 1 = in the calling thread)
+    auto run_stage = [&](const std::function<int32_t(int, hipStream_t, WinResult &)> &stage) {
         int n_thr = 4;
         if (const char *e = getenv("LVBA_WINDOW_THREADS")) n_thr = atoi(e);
         n_thr = std::max(1, std::min(n_thr, n_win));
         std::atomic<int> next{0};
+        std::vector<char> visited((size_t)n_win, 0);
         auto worker = [&](hipStream_t ws) {
             for (int wi = next.fetch_add(1); wi < n_win; wi = next.fetch_add(1)) {
                 WinResult &R = results[(size_t)wi];
-                R.rc = process(wi, ws, R);
+                visited[(size_t)wi] = 1;
+                if (R.rc < 0) continue;
+                R.rc = stage(wi, ws, R);
                 if (R.rc < 0) R.err = lvba_last_error();
             }
         };
         if (n_thr == 1) {
             worker(s);
-        } else {
-            struct Inhibit { Inhibit() { bs_graph_inhibit(+1); } ~Inhibit() { bs_graph_inhibit(-1); } } inhibit;
-            std::vector<std::thread> pool;
-            for (int t = 0; t < n_thr; ++t)
-                pool.emplace_back([&, t]() {
-                    (void)t;
-                    if (hipSetDevice(sc->device) != hipSuccess) return;
-                    hipStream_t ws = nullptr;
-                    if (hipStreamCreateWithFlags(&ws, hipStreamNonBlocking) != hipSuccess) return;
-                    worker(ws);
-                    (void)hipStreamSynchronize(ws);
-                    (void)hipStreamDestroy(ws);
-                });
-            for (auto &th : pool) th.join();
-            for (int wi = 0; wi < n_win; ++wi) // a thread that could not get a stream leaves its windows untouched
-                if (results[(size_t)wi].rc == LVBA_OK && results[(size_t)wi].info.n_frames == 0) {
-                    WinResult &R = results[(size_t)wi];
-                    R.rc = process(wi, s, R);
-                    if (R.rc < 0) R.err = lvba_last_error();
-                }
+            return;
         }
+        struct Inhibit { Inhibit() { bs_graph_inhibit(+1); } ~Inhibit() { bs_graph_inhibit(-1); } } inhibit;
+        std::vector<std::thread> pool;
+        for (int t = 0; t < n_thr; ++t)
+            pool.emplace_back([&, t]() {
+                (void)t;
+                if (hipSetDevice(sc->device) != hipSuccess) return;
+                hipStream_t ws = nullptr;
+                if (hipStreamCreateWithFlags(&ws, hipStreamNonBlocking) != hipSuccess) return;
+                worker(ws);
+                (void)hipStreamSynchronize(ws);
+                (void)hipStreamDestroy(ws);
+            });
+        for (auto &th : pool) th.join();
+        for (int wi = 0; wi < n_win; ++wi) // a thread that could not get a stream leaves its windows untouched
+            if (!visited[(size_t)wi] && results[(size_t)wi].rc >= 0) {
+                WinResult &R = results[(size_t)wi];
+                R.rc = stage(wi, s, R);
+                if (R.rc < 0) R.err = lvba_last_error();
+            }
+    };
+    auto free_maps = [&]() { for (auto &q : results) if (q.map) { lvba_voxmap_destroy(q.map); q.map = nullptr; } };
+    const bool timing = getenv("LVBA_TIMING") != nullptr; // stage times of the whole call to stderr
+    double tmark = now_ms();
+    auto mark = [&](const char *what) {
+        if (!timing) return;
+        const double t = now_ms();
+        fprintf(stderr, "[window_ba] %-18s %.3f ms\n", what, t - tmark);
+        tmark = t;
+    };
+    run_stage(stage_map);
+    mark("voxel maps");
+    bool any_failed = false;
+    for (auto &q : results) any_failed = any_failed || q.rc < 0;
+    if (!any_failed && !o.merge_only) {
+        bool batch = o.lm_mode == 0;
+        if (const char *e = getenv("LVBA_WINDOW_BATCH")) batch = strcmp(e, "0") != 0;
+        bool done = false;
+        if (batch) {
+            const int32_t rc = stage_lm_batched(done);
+            if (rc < 0) { free_maps(); return rc; }
+        }
+        if (!done) run_stage(stage_lm_single);
+        for (auto &q : results) any_failed = any_failed || q.rc < 0;
+        mark(done ? "LM, all windows" : "LM, one by one");
     }
+    if (!any_failed) run_stage(stage_finish);
+    free_maps();
+    mark("align + merge");
     for (int wi = 0; wi < n_win; ++wi) { // assemble in window order
         WinResult &R = results[(size_t)wi];
         if (R.rc < 0) {
@@ -367,7 +485,7 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
         if (clouds[a].n > 0)
             e = hipMemcpy(out->d_pts + 3 * out->frame_off[a], clouds[a].d, 12 * (size_t)clouds[a].n, hipMemcpyDeviceToDevice);
     if (e == hipSuccess)
-        e = hipMemcpy(out->d_frame_off, out->frame_off.data(), 8 * (clouds.size() + 1), hipMemcpyHostToDevice);
+        e = lvba::copy_h2d(out->d_frame_off, out->frame_off.data(), 8 * (clouds.size() + 1));
     free_clouds();
     if (e != hipSuccess) {
         lvba_scans_destroy(out);
@@ -375,6 +493,7 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
     }
     *n_anchors = out->n_frames;
     *anchor_scans = out;
+    mark("anchor scan set");
     return LVBA_OK;
 }
 

@@ -105,7 +105,7 @@ class Scans:
         return out
 
     def window_ba(self, poses, window_size=10, voxel_size=0.5, eigen_ratio_array=None, anchor_leaf=0.1, use_rel=True,
-                  min_points=None, merge_only=False, **lm):
+                  min_points=None, merge_only=False, lm_mode=0, **lm):
         """LvbaSystem::runWindowBA (src/lvba_system.cpp:204-310) on the resident scans.  Returns dict(anchor_poses,
         anchor_scans (a Scans), anchor_index, rel_poses, window_poses, windows)."""
         n = self.n_frames
@@ -117,6 +117,7 @@ class Scans:
         o.window_size, o.use_rel, o.anchor_leaf = int(window_size), 1 if use_rel else 0, float(anchor_leaf)
         o.voxel = _opts(voxel_size, eigen_ratio_array, min_points)
         o.merge_only = 1 if merge_only else 0
+        o.lm_mode = int(lm_mode)   # 0: all windows' LM in lock-step as one grouped problem, 1: one window at a time
         for k, v in lm.items():
             setattr(o.lm, k, v)
         nw = (n + o.window_size - 1) // o.window_size

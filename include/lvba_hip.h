@@ -151,6 +151,20 @@ int32_t lvba_balm_lm_begin(lvba_balm_t h, const double *poses, const lvba_balm_o
 int32_t lvba_balm_lm_step(lvba_balm_t h, lvba_lm_trace *row, int32_t *done);
 int32_t lvba_balm_lm_end(lvba_balm_t h, double *poses_out);
 
+/* Several INDEPENDENT refinements in one handle, advanced in lock-step -- the windows of LvbaSystem::runWindowBA
+ * (src/lvba_system.cpp:232-302: one damping_iter per window, one after the other).  Group k owns the poses
+ * [pose_off[k], pose_off[k+1]) and the voxels [voxel_off[k], voxel_off[k+1]); every factor of its voxels must be seen from
+ * one of its poses.  The Hessian is block diagonal, so ONE evaluation, ONE band factorisation (damping per group) and ONE
+ * cost pass per LM iteration serve all groups, while each group keeps the LM state of damping_iter (u, v, accept / reject,
+ * the bavoxel.hpp:760 exit) for itself: group k's poses are what lvba_balm_refine gives for group k alone, up to rounding.
+ *   lvba_balm_set_groups     after lvba_balm_create, before the first cost / eval / refine call (single rank only)
+ *   lvba_balm_refine_groups  n_iter / status / cost_first / cost_last [n_groups] may be NULL; status[k] = LVBA_OK or
+ *                            LVBA_NUM_NONFINITE.  Returns LVBA_NUM_FACTORIZATION (poses untouched) if a pivot of the joint
+ *                            factorisation broke down: the groups are not independent then, refine them one by one. */
+int32_t lvba_balm_set_groups(lvba_balm_t h, int32_t n_groups, const int32_t *pose_off, const int64_t *voxel_off);
+int32_t lvba_balm_refine_groups(lvba_balm_t h, double *poses_inout, const lvba_balm_opts *opts, int32_t *n_iter,
+                                int32_t *status, double *cost_first, double *cost_last);
+
 /* Profiling (HIP events around the stages, on the stream the kernels are launched on). */
 int32_t lvba_balm_set_profiling(lvba_balm_t h, int32_t enable);
 int32_t lvba_balm_get_profile(lvba_balm_t h, lvba_prof_t *out, int32_t reset);
@@ -391,14 +405,17 @@ typedef struct {
     lvba_balm_opts lm;
     int32_t merge_only;     /* 1: no map, no LM, no skip rule -- every window is merged at the given poses (rel = anchor^-1 o pose) and
                                down-sampled: the anchor clouds optimizeCameraPoses rebuilds from the refined poses (:1464-1487) */
-    int32_t reserved;
+    int32_t lm_mode;        /* 0: the damping_iter of all windows in lock-step as one grouped problem (lvba_balm_refine_groups;
+                               default), 1: one window at a time.  The windows are independent either way; results agree to
+                               rounding */
 } lvba_window_opts;
 typedef struct {
     int32_t start, n_frames, skipped, anchor; /* anchor = index into anchor_poses / anchor_scans, -1 if skipped */
     int32_t n_iter, lm_status;
     int64_t n_voxels, n_factors, n_anchor_points;
     double cost_first, cost_last;             /* averaged LiDAR cost before / after the window's damping_iter */
-    double map_ms, solve_ms, merge_ms;        /* host wall clock: voxel map, problem set-up + LM, anchor merge + down-sampling */
+    double map_ms, solve_ms, merge_ms;        /* host wall clock: voxel map, problem set-up + LM (lm_mode 0: the joint problem's
+                                                 time shared out evenly over its windows), anchor merge + down-sampling */
     double setup_ms;                          /* the part of solve_ms before the first LM iteration */
 } lvba_window_info;
 void lvba_window_default_opts(lvba_window_opts *opts);

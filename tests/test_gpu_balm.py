@@ -465,3 +465,54 @@ def test_solver_schedules(tmp_path):
     assert np.isfinite(ref).all()
     for v, o in zip(variants[1:], out[1:]):
         assert np.abs(o[:-2] - ref[:-2]).max() <= 1e-9 * np.abs(ref[:-2]).max(), v
+
+
+def test_grouped_refinement_equals_one_by_one(pkg):
+    """Several independent problems in one handle (lvba_balm_set_groups / lvba_balm_refine_groups: the windows of
+    LvbaSystem::runWindowBA, src/lvba_system.cpp:232-302) advance through ONE LM loop in lock-step -- one evaluation, one band
+    factorisation with a damping value per group, one cost pass per iteration -- while every group keeps its own u, v,
+    accept / reject and exit test.  Each group must end where lvba_balm_refine puts it when it is refined alone (the arithmetic
+    differs in summation order only), after the same number of iterations; the groups here differ in size, in how far they are
+    from the optimum and (max_iter small) in whether they run into the iteration cap."""
+    specs = [(20, 3000, 3), (12, 1500, 4), (20, 2500, 5), (8, 900, 6)]
+    parts = [make_problem(n, v, seed=s, band=50, loop_frac=0.0) for n, v, s in specs]
+    # scale the initial error differently per group so that the LM paths differ
+    inits = []
+    for i, d in enumerate(parts):
+        x0, xg = d["poses_init"].copy(), d["poses_gt"]
+        inits.append(xg + (x0 - xg) * (0.3 + 0.9 * i))
+    pose_off = np.cumsum([0] + [d["n_poses"] for d in parts]).astype(np.int32)
+    vox_off = np.cumsum([0] + [len(d["voxel_off"]) - 1 for d in parts]).astype(np.int64)
+    off = [np.zeros(1, np.int64)]
+    idx, clu = [], []
+    for k, d in enumerate(parts):
+        off.append(d["voxel_off"][1:] + off[-1][-1])
+        idx.append(d["pose_idx"] + pose_off[k])
+        clu.append(d["clusters"])
+    off, idx, clu = np.concatenate(off), np.concatenate(idx).astype(np.int32), np.concatenate(clu)
+    x0 = np.concatenate(inits)
+    for max_iter in (10, 3):
+        u = pkg.BalmProblem(int(pose_off[-1]), off, idx, clu)
+        u.set_groups(pose_off, vox_off)
+        xu, per, rc = u.refine_groups(x0, max_iter=max_iter)
+        assert rc == 0
+        its = []
+        for k, d in enumerate(parts):
+            p = pkg.BalmProblem(d["n_poses"], d["voxel_off"], d["pose_idx"], d["clusters"])
+            xs, tr, rck = p.refine(inits[k], max_iter=max_iter)
+            assert rck == 0
+            its.append(len(tr))
+            assert per["n_iter"][k] == len(tr), (k, per["n_iter"][k], len(tr))
+            assert abs(per["cost_first"][k] - tr[0]["residual1"]) <= 1e-9 * tr[0]["residual1"]
+            last = tr[-1]["residual2"] if tr[-1]["accepted"] else tr[-1]["residual1"]
+            assert abs(per["cost_last"][k] - last) <= 1e-8 * last
+            assert np.abs(xu[pose_off[k]:pose_off[k + 1]] - xs).max() <= 1e-8, k
+            p.close()
+        if max_iter == 10:
+            assert len(set(its)) > 1          # the groups really leave the loop at different iterations
+        u.close()
+    # a voxel seen from another group's pose is refused
+    bad = pkg.BalmProblem(int(pose_off[-1]), off, idx, clu)
+    with pytest.raises(Exception):
+        bad.set_groups(np.array([0, 10, pose_off[-1]], np.int32), np.array([0, 100, vox_off[-1]], np.int64))
+    bad.close()

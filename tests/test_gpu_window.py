@@ -130,6 +130,40 @@ def test_window_threads_give_identical_results(pkg, synth, monkeypatch):
         np.testing.assert_array_equal(p, q)
 
 
+def test_windows_in_lock_step_equal_one_at_a_time(pkg, synth):
+    """lm_mode 0 (default): the damping_iter of all windows advances in lock-step on ONE grouped problem (one evaluation, one band
+    factorisation with a damping value per window, one cost pass per LM iteration for all windows -- lvba_balm_refine_groups);
+    lm_mode 1: one window at a time, as the reference does (src/lvba_system.cpp:232-302).  The windows are independent either
+    way: same skipped windows, same iteration counts, poses to 1e-9, and anchor clouds that are the same point sets up to the
+    fp32 write-back of points moved by 1e-9."""
+    s = synth.make_scans(22, 6000, room=(10, 8, 4), origin=(2.0, -1.0, 0.4), n_panels=8, seed=43, rot_sigma_deg=0.1,
+                         trans_sigma=0.03)
+    clouds = [c.copy() for c in s["clouds"]]
+    for f in range(8, 12):
+        clouds[f] = clouds[f][:40]                                          # window 2 (frames 8..11) is skipped
+    outs = []
+    for mode in (0, 1):
+        with pkg.Scans(clouds) as scans:
+            got = scans.window_ba(s["poses"], window_size=4, voxel_size=1.0, anchor_leaf=0.05, lm_mode=mode)
+        pts = [got["anchor_scans"].download(a) for a in range(len(got["anchor_poses"]))]
+        got["anchor_scans"].close()
+        outs.append((got, pts))
+    (a, pa), (b, pb) = outs
+    assert [w["skipped"] for w in a["windows"]] == [w["skipped"] for w in b["windows"]] == [0, 0, 1, 0, 0, 0]
+    assert [w["n_iter"] for w in a["windows"]] == [w["n_iter"] for w in b["windows"]]
+    assert max(w["n_iter"] for w in a["windows"]) >= 2
+    for wa, wb in zip(a["windows"], b["windows"]):
+        if not wa["skipped"]:
+            assert abs(wa["cost_first"] - wb["cost_first"]) <= 1e-9 * wb["cost_first"]
+            assert abs(wa["cost_last"] - wb["cost_last"]) <= 1e-8 * wb["cost_last"]
+    assert np.abs(a["window_poses"] - b["window_poses"]).max() <= 1e-9
+    assert np.abs(a["rel_poses"] - b["rel_poses"]).max() <= 1e-9
+    np.testing.assert_array_equal(a["anchor_index"], b["anchor_index"])
+    np.testing.assert_array_equal(a["anchor_poses"], b["anchor_poses"])
+    for p, q in zip(pa, pb):
+        assert abs(len(p) - len(q)) <= 0.002 * len(q)
+
+
 def test_merge_only_matches_the_anchor_merge_of_the_visual_stage(pkg, synth):
     """lvba_window_opts.merge_only = the anchor clouds optimizeCameraPoses rebuilds from the refined poses
     (src/lvba_system.cpp:1466-1489: no window BA, every scan moved into the frame of its window's first scan with the poses
