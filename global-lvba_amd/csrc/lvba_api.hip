@@ -535,7 +535,7 @@ static int32_t download_poses(lvba_balm_s *h, const double *d_src, double *poses
 static int32_t upload_poses(lvba_balm_s *h, const double *poses, double *d_dst)
 {
     const size_t bytes = (size_t)12 * h->N * sizeof(double);
-    if (bytes <= lvba::HostStage::kBytes) { // zero-copy through the process-wide pinned stage (mempool.h: a copy costs ~20 ms here)
+    if (bytes <= lvba::HostStage::kBytes) { // zero-copy through the process-wide pinned stage (mempool.h)
         if (void *st = lvba::HostStage::get().lock()) {
             memcpy(st, poses, bytes);
             launch_import_poses(static_cast<const double *>(st), h->bs.d_perm, h->N, d_dst, h->stream());

@@ -98,12 +98,11 @@ class DevicePool {
 };
 
 // Host <-> device copies of set-up tables from / to the caller's or the library's PAGEABLE memory.  The runtime moves small
-// transfers through its own staging buffers, but pins the user pages for transfers from 4 MB up (GPU_PINNED_MIN_XFER_SIZE); when
-// such a host buffer is freed afterwards -- every set-up table is a temporary std::vector -- the kernel driver's MMU notifier
-// evicts ALL queues of the process and restores them 10-25 ms later.  Measured on the window stage's joint problem (9 MB of pose
-// indices uploaded, the vector freed at the end of the set-up): the first launch after the set-up waited 14-25 ms, six times the
-// three LM iterations that followed.  Medium-sized copies therefore go in pieces below the pinning threshold; huge ones (the
-// set-up of a 10 M-factor problem takes 0.3 s anyway) are left to the runtime.
+// transfers through its own staging buffers, but pins the user pages for transfers from 4 MB up (GPU_PINNED_MIN_XFER_SIZE) and
+// unpins them afterwards; every set-up table is a temporary std::vector that is freed right after.  Unmapping host memory the
+// driver knows about is what stalls the GPU (block_system.hip, tune_host_allocator: 14-25 ms with no stream making progress), so
+// medium-sized copies go in pieces below the pinning threshold and never register the vector at all; huge ones (the set-up of a
+// 10 M-factor problem takes 0.3 s anyway) are left to the runtime.
 inline hipError_t copy_chunked(void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
 {
     const size_t kPin = (size_t)4 << 20, kPiece = (size_t)2 << 20, kHuge = (size_t)256 << 20;
@@ -118,10 +117,9 @@ inline hipError_t copy_h2d(void *dst, const void *src, size_t bytes) { return co
 inline hipError_t copy_d2h(void *dst, const void *src, size_t bytes) { return copy_chunked(dst, src, bytes, hipMemcpyDeviceToHost); }
 
 // One process-wide piece of pinned, device-visible host memory for SMALL transfers, read / written by kernels directly
-// (zero-copy) instead of by a copy.  Measured on the window stage: a 30 KB pose array moved with hipMemcpy / hipMemcpyAsync
-// costs 14-24 ms per call on a handle that has just been created (from pageable memory: the runtime pins the caller's pages on
-// the fly; from freshly pinned memory: the mapping is set up on first use), i.e. 20 ms up and 20 ms down for a refinement whose
-// three LM iterations take 4 ms.  This buffer is pinned and mapped once; a kernel reads 30 KB over the host link in microseconds.
+// (zero-copy) instead of by a copy: the pose array of a refinement (30 KB for a window stage) goes up once and comes down once
+// per call, on handles that live for a few milliseconds; through this stage that is a memcpy and a kernel reading over the host
+// link -- no copy-engine submission, no pinning of the caller's pages, nothing to unpin.  Pinned and mapped once per process.
 // lock() ... unlock() bracket one use (several host threads drive windows concurrently).
 class HostStage {
   public:
