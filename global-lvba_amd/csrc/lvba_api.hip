@@ -139,6 +139,15 @@ static int32_t balm_create_impl(int32_t n_poses, int64_t n_voxels, const int64_t
         return fail(LVBA_ERR_DEVICE, "no HIP device available (liblvba_hip has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(LVBA_ERR_ARG, "device %d out of range [0,%d)", device, ndev);
 
+    const bool timing = getenv("LVBA_TIMING") != nullptr;
+    auto nowc = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tmark = nowc();
+    auto mark = [&](const char *what) {
+        if (!timing) return;
+        const double t = nowc();
+        fprintf(stderr, "[balm_create] %-14s %.3f ms\n", what, t - tmark);
+        tmark = t;
+    };
     for (int64_t f = 0; f < F; ++f)
         if (pose_idx[f] < 0 || pose_idx[f] >= n_poses) return fail(LVBA_ERR_ARG, "pose_idx[%lld] = %d out of range", (long long)f, pose_idx[f]);
     for (int64_t a = 0; a < n_voxels; ++a)
@@ -193,6 +202,7 @@ static int32_t balm_create_impl(int32_t n_poses, int64_t n_voxels, const int64_t
         }
     }
     const int64_t base2 = voxel_off[0]; // 0 after a re-layout
+    mark("checks + order");
 
     lvba_balm_s *h = new (std::nothrow) lvba_balm_s();
     if (!h) return fail(LVBA_ERR_NOMEM, "host allocation failed");
@@ -222,6 +232,7 @@ static int32_t balm_create_impl(int32_t n_poses, int64_t n_voxels, const int64_t
         h->h_chunk_v0 = chunk_v0;
     }
     h->h_pidx.assign(pose_idx, pose_idx + F);
+    mark("chunks + copies");
 
     auto bail = [&](int32_t rc) { lvba_balm_destroy(h); return rc; };
 #define CTRY(expr) do { int32_t rc_ = (expr); if (rc_ != LVBA_OK) return bail(rc_); } while (0)
@@ -255,9 +266,11 @@ static int32_t balm_create_impl(int32_t n_poses, int64_t n_voxels, const int64_t
         if (d_stage) { lvba::DevicePool::get().free(d_stage); bs.device_bytes -= (int64_t)(10 * F) * (int64_t)sizeof(double); }
         if (d_fmap) { lvba::DevicePool::get().free(d_fmap); bs.device_bytes -= (int64_t)F * (int64_t)sizeof(int32_t); }
     }
+    mark("device arrays");
     CHIP(hipHostMalloc((void **)&h->h_pin, 16 * sizeof(double), hipHostMallocDefault));
     for (int e = 0; e < EV_N; ++e)
         for (int s = 0; s < 2; ++s) CHIP(hipEventCreate(&h->ev[e][s]));
+    mark("pinned + events");
 #undef CTRY
 #undef CHIP
     *out = h;
@@ -372,10 +385,21 @@ static int32_t finalize(lvba_balm_s *h)
     HIPCHK(hipSetDevice(bs.device));
     const int N = h->N;
     bs.y_voxel_major = h->fused;
+    const bool timing = getenv("LVBA_TIMING") != nullptr;
+    auto nowc = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tmark = nowc();
+    auto mark = [&](const char *what) {
+        if (!timing) return;
+        const double t = nowc();
+        fprintf(stderr, "[finalize] %-14s %.3f ms\n", what, t - tmark);
+        tmark = t;
+    };
     TRY(bs_build(bs, N, h->V, h->h_voff.data(), h->h_pidx.data()));
+    mark("bs_build");
     std::vector<int32_t> p((size_t)h->F); // pose indices of the factors in solver order
     for (int64_t f = 0; f < h->F; ++f) p[f] = bs.iperm[h->h_pidx[f]];
     HIPCHK(lvba::copy_h2d(h->d_pidx, p.data(), (size_t)h->F * sizeof(int32_t)));
+    mark("pose indices");
     if (h->fused) {
         TRY(build_fused_tables(h, p));
     } else {
@@ -390,6 +414,7 @@ static int32_t finalize(lvba_balm_s *h)
     TRY(bs_dmalloc(bs, &h->d_out, 12 * (int64_t)N));
     TRY(bs_dmalloc(bs, &h->d_scal2, 8));
     HIPCHK(hipStreamSynchronize(bs.stream));
+    mark("pose-major copy");
     std::vector<int64_t>().swap(h->h_voff);
     std::vector<int64_t>().swap(h->h_chunk_v0);
     std::vector<int32_t>().swap(h->h_pidx);

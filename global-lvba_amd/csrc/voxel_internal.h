@@ -20,6 +20,10 @@ struct lvba_scans_s {
 struct lvba_voxmap_s;
 // the admitted voxels' clusters of a map, [n_factors][10] on the device (voxelize.hip; for the window driver's joint problem)
 const double *lvba_voxmap_clusters(const lvba_voxmap_s *h);
+// lvba_voxmap_build_scans on the caller's stream (the map does not own it)
+struct lvba_scans_s;
+int32_t lvba_voxmap_build_scans_on(lvba_scans_s *sc, int32_t frame_begin, int32_t n_frames, const double *poses,
+                                   const lvba_voxel_opts *opts, hipStream_t stream, lvba_voxmap_s **out);
 
 namespace lvba {
 

@@ -560,6 +560,7 @@ __global__ void vox_lookup_kernel(int64_t n, const double *__restrict__ X, doubl
 struct lvba_voxmap_s {
     int device = 0;
     hipStream_t stream = nullptr;
+    bool owns_stream = true; // false: the caller's stream (the window driver's worker streams; a stream costs ~0.6 ms to destroy)
     int n_frames = 0;
     lvba_voxel_opts opts{};
     lvba_voxmap_info_t info{};
@@ -654,7 +655,7 @@ extern "C" int32_t lvba_voxmap_destroy(lvba_voxmap_t h)
     void *ptrs[] = {h->d_root_key, h->d_mask, h->d_rootinfo, h->d_plane_first, h->d_plane,
                     h->d_vox_off, h->d_pose_idx, h->d_vox_label, h->d_clusters};
     for (void *p : ptrs) DevicePool::get().free(p);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->stream && h->owns_stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return LVBA_OK;
 }
@@ -844,8 +845,9 @@ int32_t voxmap_build_impl(lvba_voxmap_s *h, const lvba_scans_s *sc, int frame_be
 
 } // namespace
 
-extern "C" int32_t lvba_voxmap_build_scans(lvba_scans_t sc, int32_t frame_begin, int32_t n_frames, const double *poses,
-                                           const lvba_voxel_opts *opts, lvba_voxmap_t *out)
+// stream != nullptr: the map works on the caller's stream and does not own it (the caller keeps it alive as long as the map)
+int32_t lvba_voxmap_build_scans_on(lvba_scans_t sc, int32_t frame_begin, int32_t n_frames, const double *poses,
+                                   const lvba_voxel_opts *opts, hipStream_t stream, lvba_voxmap_t *out)
 {
     if (!out) return lvba_fail(LVBA_ERR_ARG, "out is null");
     *out = nullptr;
@@ -864,7 +866,10 @@ extern "C" int32_t lvba_voxmap_build_scans(lvba_scans_t sc, int32_t frame_begin,
     h->device = sc->device;
     h->n_frames = n_frames;
     h->opts = o;
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (stream) {
+        h->stream = stream;
+        h->owns_stream = false;
+    } else if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
         return lvba_fail(LVBA_ERR_DEVICE, "hipStreamCreate failed");
     }
@@ -872,6 +877,12 @@ extern "C" int32_t lvba_voxmap_build_scans(lvba_scans_t sc, int32_t frame_begin,
     if (rc != LVBA_OK) { lvba_voxmap_destroy(h); return rc; }
     *out = h;
     return LVBA_OK;
+}
+
+extern "C" int32_t lvba_voxmap_build_scans(lvba_scans_t sc, int32_t frame_begin, int32_t n_frames, const double *poses,
+                                           const lvba_voxel_opts *opts, lvba_voxmap_t *out)
+{
+    return lvba_voxmap_build_scans_on(sc, frame_begin, n_frames, poses, opts, nullptr, out);
 }
 
 extern "C" int32_t lvba_voxmap_build(int32_t device, int32_t n_frames, const void *const *frame_points,

@@ -187,7 +187,7 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
     std::vector<WinResult> results((size_t)n_win);
     auto win_range = [&](int wi, int &start, int &cw) { start = wi * w; cw = std::min(w, n - start); };
     // ---- stage 1: the voxel map at the odometry poses (:247-257) and the skip rule (:258-262)
-    auto stage_map = [&](int wi, hipStream_t, WinResult &R) -> int32_t {
+    auto stage_map = [&](int wi, hipStream_t ws, WinResult &R) -> int32_t {
         int start, cw;
         win_range(wi, start, cw);
         lvba_window_info &info = R.info;
@@ -197,7 +197,7 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
         R.x.assign(x_odom, x_odom + 12 * (size_t)cw);
         if (o.merge_only) return LVBA_OK;
         const double tw = now_ms();
-        int32_t rc = lvba_voxmap_build_scans(sc, start, cw, x_odom, &o.voxel, &R.map);
+        int32_t rc = lvba_voxmap_build_scans_on(sc, start, cw, x_odom, &o.voxel, ws, &R.map); // on the worker's stream, which outlives the map
         if (rc != LVBA_OK) return rc;
         lvba_voxmap_info_t mi;
         lvba_voxmap_info(R.map, &mi);
@@ -273,12 +273,19 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
             memcpy(x.data() + 12 * (size_t)pose_off[(size_t)k], R.x.data(), 96 * (size_t)R.info.n_frames);
         }
         HIPCHK(hipStreamSynchronize(s));
+        const bool tm = getenv("LVBA_TIMING") != nullptr;
+        double tk = now_ms();
+        auto mk = [&](const char *what) { if (tm) { const double t = now_ms(); fprintf(stderr, "[window_ba LM] %-16s %.3f ms\n", what, t - tk); tk = t; } };
+        if (tm) fprintf(stderr, "[window_ba LM] %-16s %.3f ms\n", "export + concat", tk - t0);
         lvba_balm_t b = nullptr;
         TRY(lvba_balm_create_dev(pose_off[(size_t)G], V, off.data(), idx.data(), d_clu.as<double>(), sc->device, &b));
         struct Guard { lvba_balm_t b; ~Guard() { if (b) lvba_balm_destroy(b); } } guard{b};
+        mk("create");
         TRY(lvba_balm_set_groups(b, G, pose_off.data(), vox_off.data()));
+        mk("set_groups");
         lvba_balm_info_t bi;
         TRY(lvba_balm_info(b, &bi)); // the one-off set-up, timed apart
+        mk("set-up");
         const double t1 = now_ms();
         std::vector<int32_t> n_iter((size_t)G), status((size_t)G);
         std::vector<double> first((size_t)G), last((size_t)G);
@@ -286,6 +293,7 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
         if (rc == LVBA_NUM_FACTORIZATION) return LVBA_OK; // the windows are not independent in a broken factorisation: one by one
         if (rc < 0) return rc;
         const double t2 = now_ms();
+        mk("refine_groups");
         for (int k = 0; k < G; ++k) {
             WinResult &R = results[(size_t)live[(size_t)k]];
             memcpy(R.x.data(), x.data() + 12 * (size_t)pose_off[(size_t)k], 96 * (size_t)R.info.n_frames);
@@ -296,6 +304,10 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
             lvba_voxmap_destroy(R.map);
             R.map = nullptr;
         }
+        mk("results, maps freed");
+        lvba_balm_destroy(guard.b);
+        guard.b = nullptr;
+        mk("handle destroyed");
         done = true;
         return LVBA_OK;
     };
@@ -382,11 +394,19 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
         R.d_out = d_out; R.n_out = n_out;
         return LVBA_OK;
     };
-    // a stage over all windows, on a small pool of host threads (LVBA_WINDOW_THREADS, default 4; 1 = in the calling thread)
+    // a stage over all windows, on a small pool of host threads (LVBA_WINDOW_THREADS, default 4; 1 = in the calling thread), each
+    // with a stream of its own; the streams live until the call returns (the maps of stage 1 work on them)
+    int n_thr = 4;
+    if (const char *e = getenv("LVBA_WINDOW_THREADS")) n_thr = atoi(e);
+    n_thr = std::max(1, std::min(n_thr, n_win));
+    std::vector<hipStream_t> wstreams;
+    struct StreamsGuard { std::vector<hipStream_t> &v; ~StreamsGuard() { for (hipStream_t q : v) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); } } } wguard{wstreams};
+    if (n_thr > 1) {
+        wstreams.assign((size_t)n_thr, nullptr);
+        for (auto &q : wstreams)
+            if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); q = nullptr; }
+    }
     auto run_stage = [&](const std::function<int32_t(int, hipStream_t, WinResult &)> &stage) {
-        int n_thr = 4;
-        if (const char *e = getenv("LVBA_WINDOW_THREADS")) n_thr = atoi(e);
-        n_thr = std::max(1, std::min(n_thr, n_win));
         std::atomic<int> next{0};
         std::vector<char> visited((size_t)n_win, 0);
         auto worker = [&](hipStream_t ws) {
@@ -406,13 +426,9 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
         std::vector<std::thread> pool;
         for (int t = 0; t < n_thr; ++t)
             pool.emplace_back([&, t]() {
-                (void)t;
-                if (hipSetDevice(sc->device) != hipSuccess) return;
-                hipStream_t ws = nullptr;
-                if (hipStreamCreateWithFlags(&ws, hipStreamNonBlocking) != hipSuccess) return;
-                worker(ws);
-                (void)hipStreamSynchronize(ws);
-                (void)hipStreamDestroy(ws);
+                if (!wstreams[(size_t)t] || hipSetDevice(sc->device) != hipSuccess) return;
+                worker(wstreams[(size_t)t]);
+                (void)hipStreamSynchronize(wstreams[(size_t)t]);
             });
         for (auto &th : pool) th.join();
         for (int wi = 0; wi < n_win; ++wi) // a thread that could not get a stream leaves its windows untouched
