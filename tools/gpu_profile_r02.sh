@@ -19,3 +19,5 @@ cd $R
 python bench.py --config C2 --no-visual --no-front-end --no-reference-baseline > $O/bench_c2.json 2> $O/bench_c2.err
 python bench.py --config C4 --steps 10 --warmup 2 --no-visual --no-front-end --no-cpu-baseline > $O/bench_c4_1gpu.json 2> $O/bench_c4.err
 tail -c 600 $O/bench_c2.json; tail -c 400 $O/bench_c4_1gpu.json; tail -3 $O/bench_c4.err
+# window stage (16 windows of 20 x 100 k points): batched LM (default) and one window at a time
+for m in 1 0; do LVBA_WINDOW_BATCH=$m python tools/window_bench.py 320 100000 20 1 > $O/window_bench_batch$m.json 2> $O/window_bench_batch$m.err; tail -c 300 $O/window_bench_batch$m.json; echo; done
