@@ -1277,7 +1277,10 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
         const Geo z{0, 0, 0, 0, 0};
         const Geo &B = qb ? *qb : z;
         // LVBA_BULK = 128 (default: 128 x 64 update tiles) | 64 (one 64 x 64 tile per workgroup; A/B)
-        static const bool big = [] { const char *e = getenv("LVBA_BULK"); return !(e && !strcmp(e, "64")); }();
+        static const bool big_env = [] { const char *e = getenv("LVBA_BULK"); return !(e && !strcmp(e, "64")); }();
+        // the 128 x 64 tiles address one problem's storage with 32-bit byte offsets (buffer instructions): a matrix of 4 GB or
+        // more (dense n >= 23 170, or a very long band) keeps the 64 x 64 tiles and their 64-bit pointers
+        const bool big = big_env && ((uint64_t)A.ld * (uint64_t)(n + 128) + (uint64_t)n + 256) * 8 < 0xFFFF0000ull;
         int64_t ca = t0, cb = t1, nbu = nb3; // 64 x 64: the tile range itself
         if (big && nb3 > 0) { // t0, t1 are column starts: tile columns [ca, cb), 128 x 64 tiles
             const int64_t Tb = B.T - 1;
