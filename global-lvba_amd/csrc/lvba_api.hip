@@ -148,36 +148,39 @@ static int32_t balm_create_impl(int32_t n_poses, int64_t n_voxels, const int64_t
         fprintf(stderr, "[balm_create] %-14s %.3f ms\n", what, t - tmark);
         tmark = t;
     };
-    for (int64_t f = 0; f < F; ++f)
-        if (pose_idx[f] < 0 || pose_idx[f] >= n_poses) return fail(LVBA_ERR_ARG, "pose_idx[%lld] = %d out of range", (long long)f, pose_idx[f]);
-    for (int64_t a = 0; a < n_voxels; ++a)
-        if (voxel_off[a + 1] - voxel_off[a] < 2)
-            return fail(LVBA_ERR_ARG, "voxel %lld has %lld factors (< 2)", (long long)a, (long long)(voxel_off[a + 1] - voxel_off[a]));
+    // one pass over the voxels: >= 2 factors each, pose indices in range, and the first pose that sees each voxel (for the
+    // re-layout decision below; only needed from the size on from which the pair lists are windowed)
+    static const bool allow_sort = [] { const char *e = getenv("LVBA_VOXEL_SORT"); return !(e && !strcmp(e, "0")); }();
+    const bool want_key = allow_sort && 18 * 8 * F > ((int64_t)24 << 20) && n_voxels > 1;
+    std::vector<int32_t> key;
+    if (want_key) key.resize((size_t)n_voxels);
+    double jump = 0.0;
+    for (int64_t a = 0; a < n_voxels; ++a) {
+        const int64_t f0 = voxel_off[a] - base, f1 = voxel_off[a + 1] - base;
+        if (f1 - f0 < 2) return fail(LVBA_ERR_ARG, "voxel %lld has %lld factors (< 2)", (long long)a, (long long)(f1 - f0));
+        int32_t lo = 0x7fffffff, hi = -1;
+        for (int64_t f = f0; f < f1; ++f) { lo = std::min(lo, pose_idx[f]); hi = std::max(hi, pose_idx[f]); }
+        if (lo < 0 || hi >= n_poses) {
+            for (int64_t f = f0; f < f1; ++f)
+                if (pose_idx[f] < 0 || pose_idx[f] >= n_poses) return fail(LVBA_ERR_ARG, "pose_idx[%lld] = %d out of range", (long long)f, pose_idx[f]);
+        }
+        if (want_key) {
+            key[(size_t)a] = lo;
+            if (a > 0) jump += std::abs((double)lo - (double)key[(size_t)a - 1]);
+        }
+    }
 
     // Voxel order.  Every pass over the voxels is laid out for voxels that come roughly in the order of the poses that see
     // them (a voxel map built along a trajectory does; the synthetic problems do): the pose gather of the voxel pass, the
     // voxel records the factor pass gathers and above all the windows of the pair lists draw on a compact slice of memory then.
     // The reference hands its voxels over in the iteration order of an unordered_map (src/lvba_system.cpp:254-262 -> tras_opt),
-    // i.e. in no order at all: at C3 that costs 30 % of the evaluation (3.0 vs 2.3 ms, tools/gpu_shuffled.sh).  So a large
+    // i.e. in no order at all: at C3 that costs 17 % of the evaluation (2.71 vs 2.32 ms, tools/gpu_shuffled.sh).  So a large
     // problem whose voxels jump about is re-laid internally, voxels sorted (stably) by the first pose that sees them.  Nothing
     // the caller gets back is indexed by voxel; sums over voxels change in the last bits only.  LVBA_VOXEL_SORT=0: off.
     std::vector<int64_t> voff_s;
     std::vector<int32_t> pidx_s, fmap;
     {
-        static const bool allow = [] { const char *e = getenv("LVBA_VOXEL_SORT"); return !(e && !strcmp(e, "0")); }();
-        bool sort_voxels = false;
-        std::vector<int32_t> key;
-        if (allow && 18 * 8 * F > ((int64_t)24 << 20) && n_voxels > 1) { // the size from which the pair lists are windowed
-            key.resize((size_t)n_voxels);
-            double jump = 0.0;
-            for (int64_t a = 0; a < n_voxels; ++a) {
-                int32_t m = 0x7fffffff;
-                for (int64_t f = voxel_off[a] - base; f < voxel_off[a + 1] - base; ++f) m = std::min(m, pose_idx[f]);
-                key[(size_t)a] = m;
-                if (a > 0) jump += std::abs((double)m - (double)key[(size_t)a - 1]);
-            }
-            sort_voxels = jump / (double)(n_voxels - 1) > std::max(64.0, 0.125 * n_poses);
-        }
+        const bool sort_voxels = want_key && jump / (double)(n_voxels - 1) > std::max(64.0, 0.125 * n_poses);
         if (sort_voxels) { // stable counting sort by the first pose
             std::vector<int64_t> start((size_t)n_poses + 1, 0);
             for (int64_t a = 0; a < n_voxels; ++a) ++start[(size_t)key[(size_t)a] + 1];
