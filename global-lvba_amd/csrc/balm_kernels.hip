@@ -915,11 +915,15 @@ __global__ void export_poses_kernel(const double *__restrict__ in, const int *__
 // ------------------------------------------------------------------------------------------------
 // launchers (called from lvba_api.hip)
 // ------------------------------------------------------------------------------------------------
+// with_records: the voxel pass of the full evaluation instead of the cost-only kernel -- the same per-chunk cost sums, plus the
+// voxel records at `poses`.  The LM loop costs its trial point like that: if the step is accepted, the next evaluation is AT that
+// point and starts from the records already there (launch_eval, skip_voxel_pass) instead of reading every cluster again.
 void launch_cost(const BalmDev &d, const double *poses, double *chunk_cost, double *out, hipStream_t s,
-                 hipEvent_t k0, hipEvent_t k1)
+                 hipEvent_t k0, hipEvent_t k1, bool with_records)
 {
     if (k0) hipEventRecord(k0, s);
-    hipLaunchKernelGGL(balm_cost_kernel, dim3((unsigned)d.n_chunks), dim3(LVBA_CF), 0, s, d, poses, chunk_cost);
+    if (with_records) hipLaunchKernelGGL(balm_voxel_kernel, dim3((unsigned)d.n_chunks), dim3(LVBA_CF), 0, s, d, poses, chunk_cost);
+    else hipLaunchKernelGGL(balm_cost_kernel, dim3((unsigned)d.n_chunks), dim3(LVBA_CF), 0, s, d, poses, chunk_cost);
     if (k1) hipEventRecord(k1, s);
     hipLaunchKernelGGL(reduce_chunks_kernel, dim3(1), dim3(1024), 0, s, chunk_cost, d.n_chunks, out);
 }
@@ -943,12 +947,13 @@ void launch_pairs(const PairDev &pd, double *Hblk, hipStream_t s)
         hipLaunchKernelGGL(balm_pair_reduce_kernel, dim3((unsigned)((pd.n_multi * 18 + 255) / 256)), dim3(256), 0, s, pd, Hblk);
 }
 
+// skip_voxel_pass: the voxel records and chunk costs at `poses` are already in place (launch_cost with_records at the same poses)
 void launch_eval(const BalmDev &d, const PairDev &pd, const double *poses, double *Hblk, int64_t hblk_doubles, double *g,
-                 double *chunk_cost, double *out, bool zero_first, hipStream_t s, hipEvent_t k0, hipEvent_t k1)
+                 double *chunk_cost, double *out, bool zero_first, hipStream_t s, hipEvent_t k0, hipEvent_t k1, bool skip_voxel_pass)
 {
     if (zero_first) hipMemsetAsync(Hblk, 0, (size_t)hblk_doubles * sizeof(double), s);
     if (k0) hipEventRecord(k0, s);
-    hipLaunchKernelGGL(balm_voxel_kernel, dim3((unsigned)d.n_chunks), dim3(LVBA_CF), 0, s, d, poses, chunk_cost);
+    if (!skip_voxel_pass) hipLaunchKernelGGL(balm_voxel_kernel, dim3((unsigned)d.n_chunks), dim3(LVBA_CF), 0, s, d, poses, chunk_cost);
     hipLaunchKernelGGL(balm_factor_kernel, dim3((unsigned)(d.n_poses * d.S)), dim3(256), 0, s, d, poses);
     hipLaunchKernelGGL(balm_diag_reduce_kernel, dim3((unsigned)((32 * (int64_t)d.n_poses + 255) / 256)), dim3(256), 0, s, d, Hblk, g);
     launch_pairs(pd, Hblk, s);

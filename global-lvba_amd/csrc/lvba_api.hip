@@ -60,6 +60,9 @@ struct lvba_balm_s {
     double u = 0.01, v = 2.0, residual1 = 0.0;
     int iter = 0;
     bool have_eval = false;
+    // the voxel records (d_vrec) and chunk costs belong to the poses in d_pose_cur: the LM loop costs its trial point with the
+    // voxel pass of the evaluation, and an accepted trial point is where the next evaluation happens
+    bool vrec_at_cur = false;
     // profiling
     bool prof_on = false;
     hipEvent_t ev[EV_N][2] = {};
@@ -491,11 +494,11 @@ extern "C" int32_t lvba_balm_get_profile(lvba_balm_t h, lvba_prof_t *out, int32_
 
 // ------------------------------------------------------------------------------------------ stages
 // enqueue: cost at device poses (solver order) -> dst[0] = (global) sum of lambda_min
-static int32_t enqueue_cost(lvba_balm_s *h, const double *d_poses, double *dst)
+static int32_t enqueue_cost(lvba_balm_s *h, const double *d_poses, double *dst, bool with_records = false)
 {
     ev_begin(h, EV_COST);
     launch_cost(h->dev(), d_poses, h->d_chunk_cost, dst, h->stream(), h->prof_on ? h->ev[EV_COSTK][0] : nullptr,
-                h->prof_on ? h->ev[EV_COSTK][1] : nullptr);
+                h->prof_on ? h->ev[EV_COSTK][1] : nullptr, with_records);
     if (h->prof_on) h->ev_used[EV_COSTK] = true;
     ev_end(h, EV_COST);
     if (h->bs.distributed()) {
@@ -508,7 +511,7 @@ static int32_t enqueue_cost(lvba_balm_s *h, const double *d_poses, double *dst)
 }
 
 // enqueue: H, g, cost at device poses -> bs.d_hg (all-reduced over ranks)
-static int32_t enqueue_eval(lvba_balm_s *h, const double *d_poses)
+static int32_t enqueue_eval(lvba_balm_s *h, const double *d_poses, bool records_in_place = false)
 {
     BlockSys &bs = h->bs;
     ev_begin(h, EV_EVAL);
@@ -519,7 +522,7 @@ static int32_t enqueue_eval(lvba_balm_s *h, const double *d_poses)
     else
         launch_eval(h->dev(), bs.pair_dev(), d_poses, bs.Hblk(), bs.hblk_doubles, bs.g(), h->d_chunk_cost, bs.scal(),
                     bs.distributed(), bs.stream, h->prof_on ? h->ev[EV_EVALK][0] : nullptr,
-                    h->prof_on ? h->ev[EV_EVALK][1] : nullptr);
+                    h->prof_on ? h->ev[EV_EVALK][1] : nullptr, records_in_place);
     if (h->prof_on) h->ev_used[EV_EVALK] = true;
     ev_end(h, EV_EVAL);
     if (bs.distributed()) {
@@ -587,6 +590,7 @@ extern "C" int32_t lvba_balm_cost(lvba_balm_t h, const double *poses, int32_t is
     TRY(finalize(h));
     HIPCHK(hipSetDevice(h->bs.device));
     TRY(upload_poses(h, poses, h->d_pose_trial));
+    h->vrec_at_cur = false; // the chunk costs are overwritten
     TRY(enqueue_cost(h, h->d_pose_trial, h->d_scal2));
     HIPCHK(hipMemcpyAsync(h->h_pin, h->d_scal2, sizeof(double), hipMemcpyDeviceToHost, h->stream()));
     HIPCHK(hipStreamSynchronize(h->stream()));
@@ -603,6 +607,7 @@ extern "C" int32_t lvba_balm_eval(lvba_balm_t h, const double *poses, double *H,
     BlockSys &bs = h->bs;
     HIPCHK(hipSetDevice(bs.device));
     TRY(upload_poses(h, poses, h->d_pose_cur));
+    h->vrec_at_cur = false; // (a full evaluation; an LM loop in progress starts its next evaluation from scratch too)
     TRY(enqueue_eval(h, h->d_pose_cur));
     HIPCHK(hipMemcpyAsync(h->h_pin, bs.scal(), sizeof(double), hipMemcpyDeviceToHost, bs.stream));
     const int64_t n = 6 * (int64_t)h->N;
@@ -650,6 +655,7 @@ extern "C" int32_t lvba_balm_lm_begin(lvba_balm_t h, const double *poses, const 
     TRY(upload_poses(h, poses, h->d_pose_cur));
     h->u = h->lm_opts.u0; h->v = h->lm_opts.v0;
     h->is_calc_hess = true; h->iter = 0; h->residual1 = 0.0;
+    h->vrec_at_cur = false;
     h->lm_active = true;
     h->lm_done = h->lm_opts.max_iter == 0;
     return LVBA_OK;
@@ -664,11 +670,15 @@ extern "C" int32_t lvba_balm_lm_step(lvba_balm_t h, lvba_lm_trace *row, int32_t 
     HIPCHK(hipSetDevice(h->bs.device));
     const bool evaluated = h->is_calc_hess;
     const int64_t n = 6 * (int64_t)h->N;
-    if (evaluated) TRY(enqueue_eval(h, h->d_pose_cur));                                    // :688-689
+    // LVBA_COST_RECORDS=0: the trial point is costed by the cost-only kernel and every evaluation runs its own voxel pass (A/B)
+    static const bool cost_records = [] { const char *e = getenv("LVBA_COST_RECORDS"); return !(e && !strcmp(e, "0")); }();
+    const bool with_records = cost_records && !h->fused && !h->bs.distributed();
+    if (evaluated) TRY(enqueue_eval(h, h->d_pose_cur, with_records && h->vrec_at_cur));    // :688-689
     TRY(enqueue_solve(h, h->u));                                                           // :692-710
     launch_retract(h->d_pose_cur, h->bs.d_dx, h->d_pose_trial, h->N, h->stream());              // :722-727
     launch_predicted_decrease(h->bs.Hblk(), h->bs.Bb, h->bs.g(), h->bs.d_dx, h->u, n, h->d_scal2 + 1, h->stream()); // :729
-    TRY(enqueue_cost(h, h->d_pose_trial, h->d_scal2));                                     // :731
+    TRY(enqueue_cost(h, h->d_pose_trial, h->d_scal2, with_records));                       // :731 (+ the voxel records at the trial point)
+    h->vrec_at_cur = false; // they belong to the trial point now
     HIPCHK(hipMemcpyAsync(h->h_pin, h->d_scal2, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream()));
     HIPCHK(hipMemcpyAsync(h->h_pin + 2, h->bs.scal(), sizeof(double), hipMemcpyDeviceToHost, h->stream()));
     HIPCHK(hipMemcpyAsync(h->h_pin + 4, h->bs.d_status, sizeof(int), hipMemcpyDeviceToHost, h->stream()));
@@ -695,6 +705,7 @@ extern "C" int32_t lvba_balm_lm_step(lvba_balm_t h, lvba_lm_trace *row, int32_t 
     }
     if (q > 0) {                                                                           // :744-752
         std::swap(h->d_pose_cur, h->d_pose_trial);
+        h->vrec_at_cur = with_records; // the trial point is the current point now
         q = q / q1;
         h->v = 2.0;
         q = 1.0 - pow(2.0 * q - 1.0, 3.0);

@@ -95,10 +95,11 @@ struct LdltMat {
 
 // balm_kernels.hip
 void launch_cost(const BalmDev &d, const double *poses, double *chunk_cost, double *out, hipStream_t s,
-                 hipEvent_t k0, hipEvent_t k1);
+                 hipEvent_t k0, hipEvent_t k1, bool with_records = false);
 // zero_first: clear the whole store first (needed when other ranks' blocks were reduced into it)
 void launch_eval(const BalmDev &d, const PairDev &pd, const double *poses, double *Hblk, int64_t hblk_doubles, double *g,
-                 double *chunk_cost, double *out, bool zero_first, hipStream_t s, hipEvent_t k0, hipEvent_t k1);
+                 double *chunk_cost, double *out, bool zero_first, hipStream_t s, hipEvent_t k0, hipEvent_t k1,
+                 bool skip_voxel_pass = false);
 void launch_pairs(const PairDev &pd, double *Hblk, hipStream_t s);
 // the same evaluation with voxel + factor pass fused (Y at voxel-major positions)
 void launch_eval_fused(const BalmDev &d, const FusedDev &fd, const PairDev &pd, const double *poses, double *Hblk, int64_t hblk_doubles,

@@ -5,6 +5,11 @@ import sys
 import numpy as np
 import pytest
 
+try:  # torch first: its bundled HIP runtime must be the one in the process.  Collecting tests/test_gpu_dropin.py dlopens
+    import torch  # noqa: F401  (oracle/_ref/*.so -> liblvba_hip.so -> the SYSTEM libamdhip64; if that loads before torch's own copy,
+except Exception:  # a later torch.cuda call and the library disagree about the device (seen as "no HIP device available"))
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -13,7 +13,7 @@ import json
 import sys
 
 EVAL_KERNELS = ["balm_voxel_kernel", "balm_factor_kernel", "balm_diag_reduce_kernel", "balm_pair_col_kernel", "balm_pair_reduce_kernel"]
-COST_KERNELS = ["balm_cost_kernel"]
+COST_KERNELS = ["balm_voxel_kernel"]   # the LM loop costs its trial point with the voxel pass (cost + voxel records)
 
 
 def read(path):
@@ -28,7 +28,7 @@ def read(path):
 def main():
     fetch, write = read(sys.argv[1]), read(sys.argv[2])
     per = {}
-    for k in EVAL_KERNELS + COST_KERNELS:
+    for k in dict.fromkeys(EVAL_KERNELS + COST_KERNELS):
         if k not in fetch or k not in write:
             raise SystemExit(f"kernel {k} is not in the PMC passes: were they taken from another build?")
         per[k] = {"fetch": 2.0 * 1024.0 * fetch[k]["kib"], "write": 1024.0 * write[k]["kib"], "raw_fetch_kib": fetch[k]["kib"],
