@@ -45,6 +45,35 @@ int main()
         std::vector<int64_t> off{0, 3, 4, 8}, chunk; int64_t Q;
         CHECK(lvba::chunk_voxels(3, off.data(), 256, 128, chunk, Q) == 1);
     }
+    for (int rep = 0; rep < 200; ++rep) { // group boundaries (lvba_balm_set_groups): no chunk straddles a break, every break starts a chunk
+        std::vector<int64_t> k(20 + next() % 600);
+        for (auto &v : k) v = 2 + next() % 9;
+        if (rep % 4 == 0) k[next() % k.size()] = 300 + next() % 500;
+        std::vector<int64_t> off(k.size() + 1, 0), chunk, brk;
+        for (size_t a = 0; a < k.size(); ++a) off[a + 1] = off[a] + k[a];
+        for (int64_t v = 1 + next() % 40; v < (int64_t)k.size(); v += 1 + next() % 90) brk.push_back(v);
+        int64_t Q = -1, Qw = 0;
+        for (auto v : k) Qw += v * (v - 1) / 2;
+        CHECK(lvba::chunk_voxels((int64_t)k.size(), off.data(), 256, 128, chunk, Q, brk.data(), (int64_t)brk.size()) == -1);
+        CHECK(Q == Qw && chunk.front() == 0 && chunk.back() == (int64_t)k.size());
+        for (size_t c = 0; c + 1 < chunk.size(); ++c) {
+            CHECK(chunk[c + 1] > chunk[c]);
+            const int64_t nf = off[chunk[c + 1]] - off[chunk[c]];
+            CHECK((chunk[c + 1] - chunk[c] == 1 && k[chunk[c]] > 256) || (nf <= 256 && chunk[c + 1] - chunk[c] <= 128));
+            for (int64_t b : brk) CHECK(!(chunk[c] < b && b < chunk[c + 1]));       // no chunk straddles a break
+        }
+        for (int64_t b : brk) { // every break is a chunk start
+            bool found = false;
+            for (int64_t c : chunk) found = found || c == b;
+            CHECK(found);
+        }
+        // without breaks the table is the plain one
+        std::vector<int64_t> plain, none;
+        int64_t Q2;
+        CHECK(lvba::chunk_voxels((int64_t)k.size(), off.data(), 256, 128, plain, Q2) == -1);
+        CHECK(lvba::chunk_voxels((int64_t)k.size(), off.data(), 256, 128, none, Q2, brk.data(), 0) == -1);
+        CHECK(plain == none);
+    }
     for (int rep = 0; rep < 200; ++rep) { // pair work items
         const int nb = 1 + next() % 300;
         std::vector<int64_t> slot(nb), off(nb + 1, 0);
