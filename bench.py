@@ -36,6 +36,7 @@ import numpy as np
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured achievable)
 FP64_PEAK_TFLOPS = 78.6    # MI355X fp64 vector == fp64 MFMA peak (256 CU x 128 flop/clk x 2.4 GHz)
+L2_PEAK_TBS = 34.5         # MI355X_MICROARCH.md: aggregate L2 -> CU bandwidth, 8 XCDs
 
 
 def parse_config(name, synth):
@@ -61,13 +62,13 @@ def cpu_baseline_and_parity(prob, d, info):
     solve_threads = min(32, os.cpu_count() or 1)
     # --- HIP path
     xg, trace, rc = prob.refine(x0, max_iter=1)
-    H, g, c = prob.eval(x0)
+    gi, gj, gblocks, g, c = prob.eval_blocks(x0)      # (sparse form: the dense Hessian is 28.8 GB at C4)
     # --- oracle: evaluation with the block list (two passes inside: count, fill)
     t = time.perf_counter()
     bi, bj, blocks, gc, cc = co.eval_sparse(x0, nthreads=cores)
     t_eval_list = 0.5 * (time.perf_counter() - t)
-    h_block_rel, h_outside = oracle.block_parity(H, bi, bj, blocks)
-    del H, blocks
+    h_block_rel, h_outside = oracle.block_parity_sparse(gi, gj, gblocks, bi, bj, blocks, N)
+    del gblocks, blocks
     g_rel = float(np.abs(g - gc).max() / np.abs(gc).max())
     cost_rel = abs(c - cc) / abs(cc)
     # --- oracle: one LM iteration, timed per stage
@@ -170,7 +171,7 @@ def main():
         state["evals"] += row["evaluated"]
         state["accepts"] += row["accepted"]
         # an evaluation after an accepted step starts from the voxel records the trial-point cost pass left (lvba_api.hip)
-        state["evals_on_records"] += int(bool(row["evaluated"]) and row["iter"] > 0 and RECORDS_REUSED)
+        state["evals_on_records"] += int(bool(row["evaluated"]) and row["iter"] > 0 and bool(info["trial_linearised"]))
         if done or rc != 0:
             prob.lm_end(want_poses=False)
             state["active"] = False
@@ -208,10 +209,12 @@ def main():
         bytes_cost = 84 * Fl + 4 * (Vl + 1) + 96 * N + 8
         ev_ms = p["eval_kernel_ms"] / max(1, p["eval_calls"])
         ck_ms = p["cost_kernel_ms"] / max(1, p["cost_calls"])
-        # The trial point of a step is costed by the evaluation's own voxel pass (cost + voxel records); when the step is accepted
-        # the next evaluation starts from those records.  For the roofline the evaluation is still charged with a voxel pass: the
-        # kernel time the library reports for such an evaluation + one cost-stage kernel.  (What the iteration saves is the
-        # cost-only pass it used to run on top.)
+        # The trial point of a step is costed by the FIRST HALF of the evaluation (fused: balm_fused_kernel -- costs, Y, per-pose
+        # sums; three-pass: the voxel pass); when the step is accepted the next evaluation starts from that linearisation and only
+        # assembles H and g.  For the roofline every evaluation is still charged with its first half: the kernel time the library
+        # reports for such an evaluation + one cost-stage kernel.
+        eval_kernels, cost_kernels = kernel_sets(info)
+        lin = bool(info["trial_linearised"])
         reuse = state["evals_on_records"] / max(1, p["eval_calls"])
         ev_ms_measured = ev_ms
         ev_ms = ev_ms + reuse * ck_ms
@@ -219,19 +222,40 @@ def main():
         n = 6 * N
         bw = 6 * info["band_blocks"] + 5
         flops_solve = (n * bw * bw if info["use_band"] else n ** 3 / 3.0)
-        roof = {"bound": "hbm", "kernel": "H/g/cost evaluation: " + " + ".join(EVAL_KERNELS),
+        roof = {"bound": "hbm", "kernel": "H/g/cost evaluation: " + " + ".join(eval_kernels),
                 "achieved": bytes_eval / ev_ms / 1e6 if ev_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (bytes_eval / ev_ms / 1e6) / HBM_PEAK_GBS if ev_ms > 0 else None,
-                "traffic": read_traffic("eval"), "traffic_source": TRAFFIC_FILE, "algorithmic_bytes": bytes_eval, "avg_ms": ev_ms,
-                "avg_ms_without_voxel_pass_of_reused_records": ev_ms_measured, "evaluations_on_trial_point_records": reuse,
-                "note": "avg_ms charges every evaluation with a voxel pass: evaluations that start from the records of the "
-                        "trial-point cost pass (same kernel, same poses) are counted as their own kernels + one such pass"}
+                "traffic": read_traffic("eval", args.config, world, eval_kernels), "traffic_source": TRAFFIC_FILE,
+                "algorithmic_bytes": bytes_eval, "avg_ms": ev_ms,
+                "avg_ms_of_evaluations_as_run": ev_ms_measured, "evaluations_on_trial_point_linearisation": reuse,
+                "note": "avg_ms charges every evaluation with its first half: evaluations that start from the linearisation the "
+                        "trial-point cost pass left (same kernel, same poses) are counted as their own kernels + one such pass"}
+        asm_ms = max(ev_ms - ck_ms, 1e-9) if lin else None
+        Ql = info["n_pairs"]
         others = [
-            {"kernel": COST_KERNELS[0] + (" (trial-point cost pass = voxel pass of the evaluation: cost + voxel records)"
-                                          if RECORDS_REUSED else " (cost-only pass)"),
+            {"kernel": cost_kernels[0] + ((" (first half of the evaluation, also the trial-point cost pass: costs + Y + per-pose "
+                                           "sums; its 144 B/factor of Y are not algorithmic bytes)") if info["eval_mode"] and lin else
+                                          " (trial-point cost pass = voxel pass of the evaluation: cost + voxel records)" if lin
+                                          else " (cost-only pass)"),
              "bound": "hbm", "achieved": bytes_cost / ck_ms / 1e6,
              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_cost / ck_ms / 1e6 / HBM_PEAK_GBS,
-             "traffic": read_traffic("cost"), "algorithmic_bytes": bytes_cost, "avg_ms": ck_ms},
+             "traffic": read_traffic("cost", args.config, world, cost_kernels), "algorithmic_bytes": bytes_cost, "avg_ms": ck_ms},
+        ]
+        if asm_ms:
+            # second half: per-pose sums + pair pass + partial-block sum.  Against HBM on what it must write (the pose blocks, once)
+            # and read (Y, once), and against the two bounds SURVEY.md 8(d) names for the pair pass: the L2 -> CU path of the two
+            # gathered 144-byte records per pair, and the fp64 vector rate of its 108 FMAs per pair.
+            bytes_asm = 8 * (36 * nnzb + 6 * N) + 144 * Fl
+            others.append({"kernel": "assembly: " + " + ".join(k for k in eval_kernels if k not in cost_kernels),
+                           "bound": "hbm", "achieved": bytes_asm / asm_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": bytes_asm / asm_ms / 1e6 / HBM_PEAK_GBS, "traffic": None, "avg_ms": asm_ms,
+                           "algorithmic_bytes": bytes_asm,
+                           "note_bytes": "the pose blocks written once + the Y records (144 B/factor) read once",
+                           "l2_bound": {"bytes": 288 * Ql, "achieved": 288 * Ql / asm_ms / 1e9, "peak": L2_PEAK_TBS, "unit": "TB/s",
+                                        "frac": 288 * Ql / asm_ms / 1e9 / L2_PEAK_TBS},
+                           "valu_bound": {"flops": 216 * Ql, "achieved": 216 * Ql / asm_ms / 1e9, "peak": FP64_PEAK_TFLOPS,
+                                          "unit": "TFLOP/s", "frac": 216 * Ql / asm_ms / 1e9 / FP64_PEAK_TFLOPS}})
+        others.append(
             {"kernel": "damped LDL^T solve (ldlt_diagpanel/step/update/back kernels)", "bound": "mfma",
              "achieved": flops_solve / sv_ms / 1e9, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
              "frac": flops_solve / sv_ms / 1e9 / FP64_PEAK_TFLOPS, "traffic": None,
@@ -242,8 +266,7 @@ def main():
                            "frac": flops_solve / sv_ms / 1e9 / (16.0 * HBM_PEAK_GBS / 1e3),
                            "note": "above the MFMA peak since the panels are paired (8 flop/B -> 64 TFLOP/s with "
                                    "single panels): the matrix pipe and the serial chain of panel factorisations "
-                                   "(~19 us each, 115 of them) bound the solve, not HBM"}},
-        ]
+                                   "bound the solve, not HBM"}})
         out = {
             "metric": "LM iterations/sec, 2k poses x 10M LiDAR factors (BALM damping_iter)",
             "value": args.steps / elapsed, "unit": "iterations/s", "n_gpus": world, "steps": args.steps,
@@ -511,21 +534,46 @@ def prob_nnzb(prob, info):
 
 
 # the kernels the `roofline` entries cover; a committed PMC summary is only quoted when it was taken from these very kernels
-RECORDS_REUSED = os.environ.get("LVBA_COST_RECORDS", "1") != "0"   # lvba_api.hip: lm_step costs the trial point with the voxel pass
-EVAL_KERNELS = ["balm_voxel_kernel", "balm_factor_kernel", "balm_diag_reduce_kernel", "balm_pair_col_kernel", "balm_pair_reduce_kernel"]
-COST_KERNELS = ["balm_voxel_kernel"] if RECORDS_REUSED else ["balm_cost_kernel"]
-TRAFFIC_FILE = os.path.join("profiles", "traffic_r02.json")
+def kernel_sets(info):
+    """(kernels of one H/g/cost evaluation, kernels of the LM loop's trial-point cost pass) as the library ran them
+    (lvba_balm_info: eval_mode, trial_linearised)."""
+    pair = ["balm_pair_col_kernel", "balm_pair_reduce_kernel"]
+    if info["eval_mode"]:
+        ev = ["balm_fused_kernel", "balm_fused_reduce_kernel"] + pair
+        first = ["balm_fused_kernel"]
+    else:
+        ev = ["balm_voxel_kernel", "balm_factor_kernel", "balm_diag_reduce_kernel"] + pair
+        first = ["balm_voxel_kernel"]
+    return ev, (first if info["trial_linearised"] else ["balm_cost_kernel"])
 
 
-def read_traffic(which):
+TRAFFIC_FILE = os.path.join("profiles", "traffic_r03.json")
+KERNEL_SOURCES = ["balm_kernels.hip", "balm_math.h", "lvba_internal.h", "lvba_api.hip", "block_system.hip", "pair_lists.hip",
+                  "host_tables.h"]
+
+
+def kernel_source_sha16():
+    """hash of the sources that decide what the evaluation kernels do and how they are launched: a committed PMC summary is
+    bound to it (a `git` hash would never match: the summary is committed AFTER the run it came from)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "global-lvba_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def read_traffic(which, config, world, kernels):
     """HBM bytes per launch from the committed PMC passes (tools/gpu_pmc2.sh -> tools/make_traffic.py -> profiles/), or null.
     PMC counters cannot be collected inside a timed run (rocprofv3 wraps the process), so the figure comes from a separate
-    profiled run of the same command; it is REFUSED (null) when that run profiled other kernels than the ones timed here."""
+    profiled run of the same command; it is REFUSED (null) unless that run was of THIS configuration on one GPU, profiled the
+    kernels timed here, and was built from the kernel sources that are in the tree now."""
     try:
         with open(os.path.join(ROOT, TRAFFIC_FILE)) as f:
             t = json.load(f)
-        want = EVAL_KERNELS if which == "eval" else COST_KERNELS
-        if t.get(which + "_kernels") != want:
+        if t.get("config") != config or world != 1 or t.get(which + "_kernels") != kernels:
+            return None
+        if t.get("kernel_source_sha16") != kernel_source_sha16():
             return None
         return t.get(which)
     except Exception:

@@ -13,9 +13,9 @@ LIB_PATH = os.environ.get("LVBA_HIP_LIB") or os.path.join(HERE, "liblvba_hip.so"
 SYMBOLS = [
     "lvba_version", "lvba_last_error", "lvba_device_count", "lvba_balm_default_opts", "lvba_shard_range",
     "lvba_balm_create", "lvba_balm_destroy", "lvba_balm_configure", "lvba_balm_info", "lvba_balm_cost",
-    "lvba_balm_eval", "lvba_balm_solve", "lvba_balm_refine", "lvba_balm_lm_begin", "lvba_balm_lm_step",
+    "lvba_balm_eval", "lvba_balm_eval_blocks", "lvba_balm_solve", "lvba_balm_refine", "lvba_balm_lm_begin", "lvba_balm_lm_step",
     "lvba_balm_lm_end", "lvba_balm_set_groups", "lvba_balm_refine_groups", "lvba_balm_set_profiling", "lvba_balm_get_profile", "lvba_balm_get_ordering",
-    "lvba_dist_unique_id", "lvba_balm_dist_init", "lvba_dist_host_unique_id",
+    "lvba_dist_unique_id", "lvba_balm_dist_init", "lvba_balm_dist_init_external", "lvba_visual_dist_init_external",
     "lvba_visual_default_opts", "lvba_visual_create", "lvba_visual_destroy", "lvba_visual_cost", "lvba_visual_linearize", "lvba_visual_info", "lvba_visual_dist_init",
     "lvba_visual_refine",
     "lvba_voxel_default_opts", "lvba_voxmap_build", "lvba_voxmap_destroy", "lvba_voxmap_info", "lvba_voxmap_export",
@@ -49,7 +49,7 @@ class BalmInfo(C.Structure):
                 ("n_voxels_global", C.c_int64), ("n_factors", C.c_int64), ("n_pairs", C.c_int64),
                 ("n_chunks", C.c_int64), ("n_blocks", C.c_int64), ("band_blocks", C.c_int32), ("use_band", C.c_int32),
                 ("hess_bytes", C.c_int64), ("device_bytes", C.c_int64), ("allreduce_bytes", C.c_int64),
-                ("twist_panels", C.c_int32), ("solve_ranks", C.c_int32)]
+                ("twist_panels", C.c_int32), ("solve_ranks", C.c_int32), ("eval_mode", C.c_int32), ("trial_linearised", C.c_int32)]
 
 
 class Prof(C.Structure):
@@ -165,6 +165,8 @@ def load():
     lib.lvba_balm_info.argtypes = [H, C.POINTER(BalmInfo)]
     lib.lvba_balm_cost.argtypes = [H, f64p, C.c_int32, C.POINTER(C.c_double)]
     lib.lvba_balm_eval.argtypes = [H, f64p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+    lib.lvba_balm_eval_blocks.argtypes = [H, f64p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p,
+                                          C.POINTER(C.c_double)]
     lib.lvba_balm_solve.argtypes = [H, C.c_double, f64p]
     lib.lvba_balm_refine.argtypes = [H, f64p, C.POINTER(BalmOpts), C.POINTER(LmTrace), C.POINTER(C.c_int32)]
     lib.lvba_balm_lm_begin.argtypes = [H, f64p, C.POINTER(BalmOpts)]
@@ -176,7 +178,8 @@ def load():
     lib.lvba_balm_get_profile.argtypes = [H, C.POINTER(Prof), C.c_int32]
     lib.lvba_balm_get_ordering.argtypes = [H, i32p]
     lib.lvba_dist_unique_id.argtypes = [C.c_char_p]
-    lib.lvba_dist_host_unique_id.argtypes = [C.c_char_p]
+    lib.lvba_balm_dist_init_external.argtypes = [H, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.lvba_visual_dist_init_external.argtypes = [H, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.lvba_balm_dist_init.argtypes = [H, C.c_int32, C.c_int32, C.c_char_p]
     u8p = np.ctypeslib.ndpointer(np.uint8, flags="C")
     lib.lvba_visual_default_opts.argtypes = [C.POINTER(VisualOpts)]

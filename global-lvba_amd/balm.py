@@ -85,15 +85,13 @@ class BalmProblem:
         L.check(L.load().lvba_dist_unique_id(buf))
         return buf.raw
 
-    @staticmethod
-    def host_unique_id():
-        """Id of the single-box test transport (ranks = host threads of this process; lvba_dist_host_unique_id)."""
-        buf = C.create_string_buffer(128)
-        L.check(L.load().lvba_dist_host_unique_id(buf))
-        return buf.raw
-
     def dist_init(self, n_ranks, rank, uid):
         L.check(self.lib.lvba_balm_dist_init(self._h, int(n_ranks), int(rank), bytes(uid)))
+
+    def dist_init_external(self, n_ranks, rank, fn, ctx):
+        """The caller's all-reduce instead of RCCL (lvba_balm_dist_init_external): fn = address of an lvba_allreduce_fn,
+        ctx = its context pointer."""
+        L.check(self.lib.lvba_balm_dist_init_external(self._h, int(n_ranks), int(rank), C.c_void_p(fn), C.c_void_p(ctx)))
 
     # -- queries ------------------------------------------------------------------------------------
     def info(self):
@@ -128,6 +126,21 @@ class BalmProblem:
         L.check(self.lib.lvba_balm_eval(self._h, self._poses(poses), H.ctypes.data if want_H else None,
                                         g.ctypes.data if want_g else None, C.byref(c)))
         return H, g, c.value
+
+    def eval_blocks(self, poses):
+        """H in sparse form (lvba_balm_eval_blocks): (bi, bj, blocks [nb, 6, 6], g, cost) with bi >= bj in the caller's pose
+        order, every unordered pair once, blocks[k, r, c] = H[6 bi + r, 6 bj + c]."""
+        x = self._poses(poses)
+        nb = C.c_int64()
+        c = C.c_double()
+        L.check(self.lib.lvba_balm_eval_blocks(self._h, x, 0, None, None, None, C.byref(nb), None, None))
+        cap = int(nb.value)
+        bi, bj = np.empty(cap, np.int32), np.empty(cap, np.int32)
+        blocks = np.empty((cap, 6, 6))
+        g = np.empty(6 * self.n_poses)
+        L.check(self.lib.lvba_balm_eval_blocks(self._h, x, cap, bi.ctypes.data, bj.ctypes.data, blocks.ctypes.data, C.byref(nb),
+                                               g.ctypes.data, C.byref(c)))
+        return bi, bj, blocks, g, c.value
 
     def solve(self, u):
         dx = np.empty(6 * self.n_poses)

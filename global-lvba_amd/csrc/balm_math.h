@@ -59,17 +59,62 @@ LVBA_HD void transform_cluster(const double *c, const double *R, const double *p
     T[9] = n;
 }
 
+// Reciprocal and reciprocal square root for the eigen-solver.  On the device: the hardware estimate (v_rcp_f64 / v_rsq_f64,
+// ~2^-23 relative) + two Newton steps -- 5 / 9 instructions instead of the ~28 / ~22 of an IEEE division / square root, which
+// were two thirds of the voxel pass's instruction count.  The results are accurate to an ulp or two, not correctly rounded;
+// Jacobi does not care (any rotation that is orthogonal to rounding error preserves the spectrum, and the rotated
+// off-diagonal is set to zero explicitly).  On the host (tests/host_emul.cpp): plain IEEE arithmetic.
+LVBA_HD double lvba_rcp(double d)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(r, fma(-d, r, 1.0), r);
+    r = fma(r, fma(-d, r, 1.0), r);
+    return r;
+#else
+    return 1.0 / d;
+#endif
+}
+LVBA_HD double lvba_rsq(double d)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rsq(d);
+    y = fma(0.5 * y, fma(-(d * y), y, 1.0), y);
+    y = fma(0.5 * y, fma(-(d * y), y, 1.0), y);
+    return y;
+#else
+    return 1.0 / sqrt(d);
+#endif
+}
+
 // One Jacobi rotation in the (p,q) plane of a symmetric 3x3; r is the third index.
 // Names: app,aqq,apq diagonal/off-diagonal; arp,arq the other two off-diagonals; v?p,v?q columns of V.
+// FAST (the LM kernels): with d = aqq - app, h = 2 apq the classical t = sgn(theta) / (|theta| + sqrt(theta^2 + 1)),
+// theta = d / h, is t = s |h| / (|d| + sqrt(d^2 + h^2)), s = sgn(d) sgn(h) (s = +1 for d = 0): one reciprocal square root and
+// one reciprocal instead of two divisions and a square root; c = rsqrt(t^2 + 1).  Off-diagonals below 1e-150 (d^2 + h^2 could
+// underflow) are negligible against any diagonal this code sees and are dropped.  !FAST (the voxel front-end, whose plane test
+// lam0 / lam2 > ratio is a discrete decision held bit-for-bit against the C++ restatement): IEEE divisions and square roots.
 #define LVBA_JROT(app, aqq, apq, arp, arq, v0p, v0q, v1p, v1q, v2p, v2q)                              \
     do {                                                                                               \
         double g_ = 100.0 * fabs(apq);                                                                 \
-        if (sweep > 3 && fabs(app) + g_ == fabs(app) && fabs(aqq) + g_ == fabs(aqq)) {                 \
+        if ((sweep > 3 && fabs(app) + g_ == fabs(app) && fabs(aqq) + g_ == fabs(aqq)) ||               \
+            (FAST ? !(fabs(apq) > 1e-150) : false)) {                                                  \
             apq = 0.0;                                                                                 \
         } else if (apq != 0.0) {                                                                       \
-            double th_ = (aqq - app) / (2.0 * apq);                                                    \
-            double t_ = (th_ >= 0.0 ? 1.0 : -1.0) / (fabs(th_) + sqrt(th_ * th_ + 1.0));               \
-            double c_ = 1.0 / sqrt(t_ * t_ + 1.0), s_ = t_ * c_;                                       \
+            double t_, c_;                                                                             \
+            if (FAST) {                                                                                \
+                const double d_ = aqq - app, h_ = 2.0 * apq;                                           \
+                const double x_0 = fma(d_, d_, h_ * h_);                                               \
+                const double den_ = fabs(d_) + x_0 * lvba_rsq(x_0);                                    \
+                const double sg_ = (d_ == 0.0 || (d_ > 0.0) == (h_ > 0.0)) ? 1.0 : -1.0;               \
+                t_ = sg_ * fabs(h_) * lvba_rcp(den_);                                                  \
+                c_ = lvba_rsq(fma(t_, t_, 1.0));                                                       \
+            } else {                                                                                   \
+                const double th_ = (aqq - app) / (2.0 * apq);                                          \
+                t_ = (th_ >= 0.0 ? 1.0 : -1.0) / (fabs(th_) + sqrt(th_ * th_ + 1.0));                  \
+                c_ = 1.0 / sqrt(t_ * t_ + 1.0);                                                        \
+            }                                                                                          \
+            const double s_ = t_ * c_;                                                                 \
             app -= t_ * apq;                                                                           \
             aqq += t_ * apq;                                                                           \
             apq = 0.0;                                                                                 \
@@ -90,7 +135,7 @@ LVBA_HD void transform_cluster(const double *c, const double *R, const double *p
 // bavoxel.hpp:98).  Input C = [c00 c01 c02 c11 c12 c22].  lam ascending; U[3*r+m] = component r of
 // eigenvector m (only if WANT_VEC).  Jacobi gives small eigenvalues of a PSD matrix to high relative
 // accuracy, which is what lambda_min (~1e-4 of ~1e-1) needs.
-template <bool WANT_VEC>
+template <bool WANT_VEC, bool FAST = false>
 LVBA_HD void eig3(const double *C, double *lam, double *U)
 {
     double a00 = C[0], a01 = C[1], a02 = C[2], a11 = C[3], a12 = C[4], a22 = C[5];
@@ -114,9 +159,10 @@ LVBA_HD void eig3(const double *C, double *lam, double *U)
 }
 
 // Merged-voxel covariance from the summed world-frame statistics S[10] (bavoxel.hpp:97-98).
+template <bool FAST = false>
 LVBA_HD void voxel_cov(const double *S, double *C, double *vbar)
 {
-    const double inv = 1.0 / S[9];
+    const double inv = FAST ? lvba_rcp(S[9]) : 1.0 / S[9];
     vbar[0] = S[6] * inv; vbar[1] = S[7] * inv; vbar[2] = S[8] * inv;
     C[0] = S[0] * inv - vbar[0] * vbar[0];
     C[1] = S[1] * inv - vbar[0] * vbar[1];
@@ -140,10 +186,10 @@ struct VoxRec {
 LVBA_HD double voxel_finish(const double *S, VoxRec &vr)
 {
     double C[6], lam[3], U[9];
-    voxel_cov(S, C, vr.vb);
-    eig3<true>(C, lam, U);
+    voxel_cov<true>(S, C, vr.vb);
+    eig3<true, true>(C, lam, U);
     vr.NN = S[9];
-    const double k1 = sqrt(2.0 / (lam[1] - lam[0])), k2 = sqrt(2.0 / (lam[2] - lam[0]));
+    const double k1 = lvba_rsq(0.5 * (lam[1] - lam[0])), k2 = lvba_rsq(0.5 * (lam[2] - lam[0])); // sqrt(2 / (lam_m - lam_0))
     vr.u0[0] = U[0]; vr.u0[1] = U[3]; vr.u0[2] = U[6];
     vr.s1[0] = k1 * U[1]; vr.s1[1] = k1 * U[4]; vr.s1[2] = k1 * U[7];
     vr.s2[0] = k2 * U[2]; vr.s2[1] = k2 * U[5]; vr.s2[2] = k2 * U[8];
@@ -153,8 +199,8 @@ LVBA_HD double voxel_finish(const double *S, VoxRec &vr)
 LVBA_HD double voxel_lambda_min(const double *S)
 {
     double C[6], lam[3], vb[3];
-    voxel_cov(S, C, vb);
-    eig3<false>(C, lam, nullptr);
+    voxel_cov<true>(S, C, vb);
+    eig3<false, true>(C, lam, nullptr);
     return lam[0];
 }
 
@@ -177,7 +223,7 @@ LVBA_HD void factor_derivs(const double *c, const double *R, const double *p, co
     const double P00 = c[0], P01 = c[1], P02 = c[2], P11 = c[3], P12 = c[4], P22 = c[5];
     const double v[3] = {c[6], c[7], c[8]};
     const double n = c[9];
-    const double invN = 1.0 / vr.NN;
+    const double invN = lvba_rcp(vr.NN);
     const double *u0 = vr.u0;
     // a = R^T u0
     const double a[3] = {R[0] * u0[0] + R[3] * u0[1] + R[6] * u0[2], R[1] * u0[0] + R[4] * u0[1] + R[7] * u0[2],

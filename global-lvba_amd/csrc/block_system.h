@@ -5,6 +5,7 @@
 // of the atomic-free assembly, the block-band store [H | g | scalars], the LDL^T workspace + captured hipGraph,
 // and the RCCL communicator.  The factor payload (clusters, observations) stays with the caller.
 #pragma once
+#include "host_arena.h"
 #include <memory>
 #include <vector>
 #include "lvba_common.h"
@@ -24,7 +25,7 @@ struct BlockSys {
     double band_frac = 0.6;
     bool spd = false; // the caller promises a symmetric POSITIVE DEFINITE system (visual stage): narrow bands go to bcr.hip
     // ordering / layout
-    std::vector<int32_t> perm, iperm; // perm[internal] = caller, iperm[caller] = internal
+    lvba::hvec<int32_t> perm, iperm; // perm[internal] = caller, iperm[caller] = internal
     int32_t Bb = 0;
     bool use_band = false, built = false;
     int32_t *d_perm = nullptr;
@@ -57,8 +58,9 @@ struct BlockSys {
     // distributed
     int n_ranks = 1, rank = 0;
     ncclComm_t comm = nullptr;
-    std::shared_ptr<struct HostComm> hostcomm; // single-box test transport (see bs_dist_init): ranks = host threads
-    bool distributed() const { return comm != nullptr || hostcomm != nullptr; }
+    lvba_allreduce_fn ext_allreduce = nullptr; // the caller's transport instead of RCCL (bs_dist_init_external)
+    void *ext_ctx = nullptr;
+    bool distributed() const { return comm != nullptr || ext_allreduce != nullptr; }
     // packed all-reduce: slots of the blocks that are non-zero on ANY rank (+ the diagonal), and the staging buffer
     int64_t n_ar = 0, *d_ar_slot = nullptr;
     double *d_arbuf = nullptr;
@@ -102,6 +104,7 @@ int32_t bs_allreduce_hg(BlockSys &bs);
 // all-reduce `count` elements of a device buffer in place (sum or max; double / int64 / int32 / uint8) over the ranks
 int32_t bs_comm_allreduce(BlockSys &bs, void *dbuf, size_t count, ncclDataType_t dt, ncclRedOp_t op);
 int32_t bs_dist_init(BlockSys &bs, int32_t n_ranks, int32_t rank, const char uid[128], int64_t *group_count_inout);
+int32_t bs_dist_init_external(BlockSys &bs, int32_t n_ranks, int32_t rank, lvba_allreduce_fn fn, void *ctx, int64_t *group_count_inout);
 void bs_destroy(BlockSys &bs);
 // +1 / -1 around sections in which several host threads use the library concurrently: solve graphs are not captured then
 void bs_graph_inhibit(int delta);

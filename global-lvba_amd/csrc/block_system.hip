@@ -2,7 +2,6 @@
 // binding, block ordering (RCM + barycenter refinement), pose-major factor order and per-block pair lists of the
 // atomic-free assembly, block-band store, LDL^T solve (captured into a hipGraph), all-reduce.
 #include <dlfcn.h>
-#include <malloc.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -17,6 +16,7 @@
 #include <queue>
 #include <string>
 #include <vector>
+#include "host_arena.h"
 #include "block_system.h"
 #include "pair_lists.h"
 #include "ordering.h"
@@ -67,57 +67,6 @@ extern "C" int32_t lvba_dist_unique_id(char uid[128])
     return LVBA_OK;
 }
 
-// ------------------------------------------------------------------------------------------ host-staged transport
-// A second transport behind the same all-reduce calls, for ONE purpose: running the multi-rank code paths (the max-reduced
-// band width, the all-reduced adjacency and the common pose order it yields, the packed [H | g | cost] all-reduce, the
-// global voxel count) with N > 1 ranks on a box with ONE GPU, where RCCL refuses two ranks on the same device.  Ranks are
-// host threads of one process, each with its own handle and stream on the same device; an all-reduce copies every rank's
-// buffer to the host, meets the others at a barrier, sums in RANK ORDER (so every rank computes bitwise the same result, as
-// RCCL guarantees for its own reductions) and copies the result back.  Selected by a unique id that starts with
-// "LVBAHOST:" (lvba_dist_host_unique_id); never used when a real multi-GPU job passes an RCCL id.  It moves data only:
-// every arithmetic operation on problem data still runs in the kernels.
-namespace lvba {
-struct HostComm {
-    int n = 0;
-    std::mutex mu;
-    std::condition_variable cv;
-    int arrived = 0;
-    uint64_t gen = 0;
-    std::vector<std::vector<unsigned char>> stage;
-    void barrier()
-    {
-        std::unique_lock<std::mutex> lk(mu);
-        const uint64_t g = gen;
-        if (++arrived == n) { arrived = 0; ++gen; cv.notify_all(); }
-        else cv.wait(lk, [&] { return gen != g; });
-    }
-};
-} // namespace lvba
-static std::mutex g_hostcomm_mu;
-static std::map<std::string, std::weak_ptr<lvba::HostComm>> g_hostcomms;
-static std::atomic<uint64_t> g_hostcomm_serial{0};
-
-extern "C" int32_t lvba_dist_host_unique_id(char uid[128])
-{
-    if (!uid) return lvba_fail(LVBA_ERR_ARG, "uid is NULL");
-    memset(uid, 0, 128);
-    snprintf(uid, 128, "LVBAHOST:%llu:%p", (unsigned long long)g_hostcomm_serial.fetch_add(1), (void *)&g_hostcomms);
-    return LVBA_OK;
-}
-
-template <typename T>
-static void host_reduce(std::vector<std::vector<unsigned char>> &stage, size_t count, bool is_max, T *out)
-{
-    const int n = (int)stage.size();
-    const T *r0 = reinterpret_cast<const T *>(stage[0].data());
-    for (size_t e = 0; e < count; ++e) out[e] = r0[e];
-    for (int r = 1; r < n; ++r) {
-        const T *p = reinterpret_cast<const T *>(stage[(size_t)r].data());
-        if (is_max) { for (size_t e = 0; e < count; ++e) out[e] = p[e] > out[e] ? p[e] : out[e]; }
-        else { for (size_t e = 0; e < count; ++e) out[e] = (T)(out[e] + p[e]); }
-    }
-}
-
 namespace lvba {
 
 int32_t bs_comm_allreduce(BlockSys &bs, void *dbuf, size_t count, ncclDataType_t dt, ncclRedOp_t op)
@@ -126,55 +75,39 @@ int32_t bs_comm_allreduce(BlockSys &bs, void *dbuf, size_t count, ncclDataType_t
         NCCLCHK(g_rccl.AllReduce(dbuf, dbuf, count, dt, op, bs.comm, bs.stream));
         return LVBA_OK;
     }
-    if (!bs.hostcomm) return LVBA_OK;
-    HostComm &hc = *bs.hostcomm;
-    const size_t esz = dt == ncclDouble || dt == ncclInt64 ? 8 : dt == ncclInt32 ? 4 : 1;
-    if (!(op == ncclSum || op == ncclMax) || !(dt == ncclDouble || dt == ncclInt64 || dt == ncclInt32 || dt == ncclUint8))
-        return lvba_fail(LVBA_ERR_UNSUPPORTED, "host transport: unsupported all-reduce type");
-    std::vector<unsigned char> &mine = hc.stage[(size_t)bs.rank];
-    mine.resize(count * esz);
-    HIPCHK(hipMemcpyAsync(mine.data(), dbuf, count * esz, hipMemcpyDeviceToHost, bs.stream));
-    HIPCHK(hipStreamSynchronize(bs.stream));
-    hc.barrier();
-    std::vector<unsigned char> res(count * esz);
-    const bool is_max = op == ncclMax;
-    if (dt == ncclDouble) host_reduce<double>(hc.stage, count, is_max, reinterpret_cast<double *>(res.data()));
-    else if (dt == ncclInt64) host_reduce<int64_t>(hc.stage, count, is_max, reinterpret_cast<int64_t *>(res.data()));
-    else if (dt == ncclInt32) host_reduce<int32_t>(hc.stage, count, is_max, reinterpret_cast<int32_t *>(res.data()));
-    else host_reduce<uint8_t>(hc.stage, count, is_max, res.data());
-    hc.barrier(); // nobody refills its stage before everybody has read it
-    HIPCHK(hipMemcpyAsync(dbuf, res.data(), count * esz, hipMemcpyHostToDevice, bs.stream));
-    HIPCHK(hipStreamSynchronize(bs.stream)); // res is a local
+    if (!bs.ext_allreduce) return LVBA_OK;
+    // the caller's transport (lvba_*_dist_init_external): same contract as ncclAllReduce in place on bs.stream, except that it
+    // may return before or after the data has moved -- it is handed the stream and orders itself against it
+    const int32_t edt = dt == ncclDouble ? LVBA_DT_F64 : dt == ncclInt64 ? LVBA_DT_I64 : dt == ncclInt32 ? LVBA_DT_I32 : dt == ncclUint8 ? LVBA_DT_U8 : -1;
+    const int32_t eop = op == ncclSum ? LVBA_OP_SUM : op == ncclMax ? LVBA_OP_MAX : -1;
+    if (edt < 0 || eop < 0) return lvba_fail(LVBA_ERR_UNSUPPORTED, "external transport: unsupported all-reduce type");
+    const int32_t rc = bs.ext_allreduce(bs.ext_ctx, dbuf, count, edt, eop, (void *)bs.stream);
+    if (rc != 0) return lvba_fail(LVBA_ERR_DIST, "external all-reduce failed with %d", rc);
     return LVBA_OK;
-}
-
-// Host memory that goes back to the operating system stalls the GPU.  Measured on the window stage's joint problem: freeing the
-// set-up's host tables (std::vectors of 2-9 MB, which glibc serves with mmap and returns with munmap) was followed by 14-25 ms in
-// which NO stream of the process got anything done -- the unmapping runs the kernel driver's MMU notifier, which evicts the
-// process's queues and restores them a moment later -- i.e. six times the three LM iterations the set-up was for; with the frees
-// skipped the stall was gone (47 -> 19 ms for 16 windows).  So, once per process: allocations up to 32 MB (the most mallopt
-// accepts) come from the heap, and the heap is not trimmed below 1 GB of free space; the pages stay with the process and are
-// reused by the next set-up.  Larger blocks still use mmap -- a problem with tables that big does not notice 20 ms.
-// LVBA_MALLOC_TUNE=0 leaves the allocator alone.
-static void tune_host_allocator()
-{
-    static std::once_flag once;
-    std::call_once(once, [] {
-        const char *e = getenv("LVBA_MALLOC_TUNE");
-        if (e && !strcmp(e, "0")) return;
-        (void)mallopt(M_MMAP_THRESHOLD, 32 << 20);
-        (void)mallopt(M_TRIM_THRESHOLD, 1 << 30);
-    });
 }
 
 int32_t bs_init(BlockSys &bs, int device)
 {
-    tune_host_allocator();
     bs.device = device;
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamCreateWithFlags(&bs.stream, hipStreamNonBlocking));
     HIPCHK(hipHostMalloc((void **)&bs.h_pin_u, 2 * sizeof(double), hipHostMallocDefault)); // (re-made larger by a grouped problem, bs_build)
     return LVBA_OK;
+}
+
+static int32_t dist_global_count(BlockSys &bs, int64_t *group_count_inout)
+{
+    if (!group_count_inout) return LVBA_OK; // global group count (the AVG_THR averages of the BALM stage)
+    int64_t *dv = nullptr;
+    HIPCHK(hipMalloc((void **)&dv, sizeof(int64_t)));
+    HIPCHK(lvba::copy_h2d(dv, group_count_inout, sizeof(int64_t)));
+    const int32_t rc = bs_comm_allreduce(bs, dv, 1, ncclInt64, ncclSum);
+    if (rc == LVBA_OK) {
+        HIPCHK(hipStreamSynchronize(bs.stream));
+        HIPCHK(lvba::copy_d2h(group_count_inout, dv, sizeof(int64_t)));
+    }
+    hipFree(dv);
+    return rc;
 }
 
 int32_t bs_dist_init(BlockSys &bs, int32_t n_ranks, int32_t rank, const char uid[128], int64_t *group_count_inout)
@@ -185,40 +118,26 @@ int32_t bs_dist_init(BlockSys &bs, int32_t n_ranks, int32_t rank, const char uid
     // a 1-rank job needs no communicator; LVBA_SINGLE_RANK_COMM=1 builds one anyway so that the whole
     // RCCL path (dlopen, communicator, all-reduces) can be exercised on a 1-GPU box
     HIPCHK(hipSetDevice(bs.device));
-    if (!strncmp(uid, "LVBAHOST:", 9)) { // the single-box test transport: ranks are host threads of this process
-        const std::string key(uid, strnlen(uid, 127));
-        std::lock_guard<std::mutex> g(g_hostcomm_mu);
-        std::shared_ptr<HostComm> hc = g_hostcomms[key].lock();
-        if (!hc) {
-            hc = std::make_shared<HostComm>();
-            hc->n = n_ranks;
-            hc->stage.resize((size_t)n_ranks);
-            g_hostcomms[key] = hc;
-        }
-        if (hc->n != n_ranks) return lvba_fail(LVBA_ERR_DIST, "host transport: rank counts disagree (%d vs %d)", hc->n, n_ranks);
-        bs.hostcomm = hc;
-        bs.graph_tried = true; // several host threads drive the device: no stream capture (see bs_enqueue_solve)
-    } else {
-        if (n_ranks == 1 && !getenv("LVBA_SINGLE_RANK_COMM")) return LVBA_OK;
-        TRY(rccl_load());
-        ncclUniqueId id;
-        memcpy(&id, uid, 128);
-        NCCLCHK(g_rccl.CommInitRank(&bs.comm, n_ranks, id, rank));
-    }
+    if (n_ranks == 1 && !getenv("LVBA_SINGLE_RANK_COMM")) return LVBA_OK;
+    TRY(rccl_load());
+    ncclUniqueId id;
+    memcpy(&id, uid, 128);
+    NCCLCHK(g_rccl.CommInitRank(&bs.comm, n_ranks, id, rank));
     bs.n_ranks = n_ranks; bs.rank = rank;
-    if (group_count_inout) { // global group count (the AVG_THR averages of the BALM stage)
-        int64_t *dv = nullptr;
-        HIPCHK(hipMalloc((void **)&dv, sizeof(int64_t)));
-        HIPCHK(lvba::copy_h2d(dv, group_count_inout, sizeof(int64_t)));
-        const int32_t rc = bs_comm_allreduce(bs, dv, 1, ncclInt64, ncclSum);
-        if (rc == LVBA_OK) {
-            HIPCHK(hipStreamSynchronize(bs.stream));
-            HIPCHK(lvba::copy_d2h(group_count_inout, dv, sizeof(int64_t)));
-        }
-        hipFree(dv);
-        TRY(rc);
-    }
-    return LVBA_OK;
+    return dist_global_count(bs, group_count_inout);
+}
+
+// The same with the caller's all-reduce instead of RCCL (include/lvba_hip.h: lvba_allreduce_fn).
+int32_t bs_dist_init_external(BlockSys &bs, int32_t n_ranks, int32_t rank, lvba_allreduce_fn fn, void *ctx, int64_t *group_count_inout)
+{
+    if (!fn) return lvba_fail(LVBA_ERR_ARG, "all-reduce callback is NULL");
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return lvba_fail(LVBA_ERR_ARG, "bad rank %d of %d", rank, n_ranks);
+    if (bs.built) return lvba_fail(LVBA_ERR_STATE, "dist_init must precede the first cost/eval/refine call");
+    HIPCHK(hipSetDevice(bs.device));
+    bs.ext_allreduce = fn; bs.ext_ctx = ctx;
+    bs.graph_tried = true; // a callback cannot be captured into the solve graph (and may drive the device from several threads)
+    bs.n_ranks = n_ranks; bs.rank = rank;
+    return dist_global_count(bs, group_count_inout);
 }
 
 int32_t bs_allreduce(BlockSys &bs, double *buf, size_t count)
@@ -285,7 +204,7 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
     bs.perm.resize(N);
     bs.iperm.resize(N);
     for (int i = 0; i < N; ++i) bs.perm[i] = bs.iperm[i] = i;
-    auto band_of = [&](const std::vector<int32_t> &iperm) {
+    auto band_of = [&](const lvba::hvec<int32_t> &iperm) {
         int32_t Bb = 0;
         for (int64_t a = 0; a < G; ++a) {
             int32_t lo = INT32_MAX, hi = -1;
@@ -313,7 +232,7 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
     bs.Q = Q;
     const bool small = (int64_t)N * N <= ((int64_t)1 << 29); // byte adjacency <= 512 MiB
     // systems of <= 1024 unknowns (window BA: 20 poses) are solved dense whatever the order: skip the graph work
-    std::vector<uint8_t> adj; // co-visibility of the GLOBAL problem (all-reduced), when it is computed at all
+    lvba::hvec<uint8_t> adj; // co-visibility of the GLOBAL problem (all-reduced), when it is computed at all
     if (bs.ordering == 1 && N > 2 && small && n > 1024) {
         adj.assign((size_t)N * N, 0);
         TRY(adjacency_build(bs.stream, G, voff, F, pidx, N, Q, adj.data())); // one thread per observer pair (pair_lists.hip)
@@ -327,7 +246,7 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
             HIPCHK(lvba::copy_d2h(adj.data(), dadj, adj.size()));
             hipFree(dadj);
         }
-        std::vector<int32_t> perm, iperm(N);
+        lvba::hvec<int32_t> perm, iperm(N);
         rcm_order(adj, N, perm);
         for (int i = 0; i < N; ++i) iperm[perm[i]] = i;
         int32_t Bb_rcm = 0; // from the (global) adjacency so that all ranks agree
@@ -347,7 +266,7 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
     {
         const char *e = getenv("LVBA_PACKED_ALLREDUCE");
         if (bs.distributed() && !adj.empty() && !(e && !strcmp(e, "0"))) {
-            std::vector<int64_t> slots;
+            lvba::hvec<int64_t> slots;
             for (int32_t J = 0; J < N; ++J) slots.push_back((int64_t)J * Bb1);
             for (int32_t i = 0; i < N; ++i)
                 for (int32_t j = 0; j < i; ++j)
@@ -381,7 +300,7 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
         // 8 + 8 poses' Y segments (factors are sorted by voxel inside a segment), which stays L2-resident, whereas a
         // column-by-column sweep re-fetches every Y record ~k-1 times from HBM (measured 5.5 GB per pass at C3).
         // The Q-sized grouping itself is a device sort (pair_lists.hip).
-        std::vector<int64_t> blk_slot, blk_off;
+        lvba::hvec<int64_t> blk_slot, blk_off;
         // Voxel windows of the pair lists: the pairs processed at about the same time should draw on a slice of Y that the
         // L2s can hold (8 x 4 MB; XCD x sweeps its own eighth of the windows).  A window of w consecutive voxels holds
         // w * F / G records of 144 bytes.  Measured at C3 (PMC, profiles/): 6 MB windows cut the L2 misses of the pair pass from
@@ -391,8 +310,11 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
         int64_t window_groups = 0;
         if (18 * 8 * F > ((int64_t)24 << 20)) window_groups = std::max<int64_t>(256, (((int64_t)6 << 20) / 144) * G / std::max<int64_t>(F, 1));
         if (const char *e = getenv("LVBA_PAIR_WINDOW")) window_groups = atoll(e);
-        TRY(pair_lists_build(bs.stream, G, voff, F, d_blk_of.as<int32_t>(), bs.y_voxel_major ? nullptr : bs.d_pos_of, N, (int32_t)Bb1, Q, window_groups, bs.d_pairs,
-                             blk_slot, blk_off));
+        // LVBA_PAIR_SORT=0: the windows' items in (tile, block) order instead of by length (A/B)
+        static const bool len_sort = [] { const char *e = getenv("LVBA_PAIR_SORT"); return !(e && !strcmp(e, "0")); }();
+        const bool want_col = [&] { const char *e = getenv("LVBA_PAIR"); return e ? !strcmp(e, "col") : true; }();
+        TRY(pair_lists_build(bs.stream, G, voff, F, d_blk_of.as<int32_t>(), bs.y_voxel_major ? nullptr : bs.d_pos_of, N, (int32_t)Bb1, Q, window_groups,
+                             len_sort && want_col ? LVBA_PAIR_CUT : 0, bs.d_pairs, blk_slot, blk_off));
         BS_MARK("pairs");
         bs.nnzb = (int64_t)blk_slot.size();
         if (window_groups > 0) {
@@ -402,24 +324,24 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
             // come in no order by the first pose that sees them, so this is the fall-back for problems without such structure.
             // Forming the windows from voxel RANKS instead of re-laying the voxels was tried: 3.0 ms per C3 evaluation against 2.7 ms
             // for this fall-back and 2.5 ms after a re-layout -- a window's Y records have to be neighbours in memory, not just few.)
-            std::vector<int64_t> u(blk_slot);
+            lvba::hvec<int64_t> u(blk_slot);
             std::sort(u.begin(), u.end());
             const int64_t distinct = (int64_t)(std::unique(u.begin(), u.end()) - u.begin());
             if ((int64_t)blk_slot.size() > 24 * std::max<int64_t>(distinct, 1)) {
                 window_groups = 0;
-                TRY(pair_lists_build(bs.stream, G, voff, F, d_blk_of.as<int32_t>(), bs.y_voxel_major ? nullptr : bs.d_pos_of, N, (int32_t)Bb1, Q, 0,
+                TRY(pair_lists_build(bs.stream, G, voff, F, d_blk_of.as<int32_t>(), bs.y_voxel_major ? nullptr : bs.d_pos_of, N, (int32_t)Bb1, Q, 0, 0,
                                      bs.d_pairs, blk_slot, blk_off));
             }
         }
         { // distinct blocks, not runs
-            std::vector<int64_t> u(blk_slot);
+            lvba::hvec<int64_t> u(blk_slot);
             std::sort(u.begin(), u.end());
             bs.nnzb = (int64_t)(std::unique(u.begin(), u.end()) - u.begin());
         }
         // work items of the pair pass.  One 16-lane group per block is right when there are many blocks (C3: 4e5 blocks of
         // ~60 pairs); with few blocks and long lists (window BA: 190 blocks x 2000 pairs) it leaves the chip empty, so lists
         // longer than `cut` pairs become several items whose partial blocks are summed afterwards.
-        std::vector<int64_t> item_off, item_dst, multi_off, multi_slot, multi_idx;
+        lvba::hvec<int64_t> item_off, item_dst, multi_off, multi_slot, multi_idx;
         {
             int64_t n_partial = 0;
             // windowed lists (large problems: many short (window, block) items) go to the column-per-lane kernel, cut at

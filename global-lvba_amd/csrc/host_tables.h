@@ -1,6 +1,7 @@
 // host_tables.h -- host-side work partitioning of the evaluation kernels (header-only, no HIP: unit-tested on the CPU by
 // tests/host_tables_check.cpp).
 #pragma once
+#include "host_arena.h"
 #include <algorithm>
 #include <cstdint>
 #include <vector>
@@ -13,26 +14,48 @@ namespace lvba {
 // n_voxels; Q = sum k (k - 1) / 2.  Returns -1, or the index of the first voxel with fewer than two factors.
 // breaks (optional, ascending voxel indices, n_breaks of them): a chunk never straddles one -- the voxel groups of a grouped
 // refinement (lvba_balm_set_groups) sum their chunks' costs separately.
+// pose_idx (optional; pose of factor f at pose_idx[f - voxel_off[0]], values in [0, n_poses)): a chunk's factors touch at most
+// max_poses DISTINCT poses (the pose slots of the fused evaluation); *over is set when a single voxel alone exceeds that.
 inline int64_t chunk_voxels(int64_t n_voxels, const int64_t *voxel_off, int max_factors, int max_voxels,
-                            std::vector<int64_t> &chunk_v0, int64_t &Q, const int64_t *breaks = nullptr, int64_t n_breaks = 0)
+                            lvba::hvec<int64_t> &chunk_v0, int64_t &Q, const int64_t *breaks = nullptr, int64_t n_breaks = 0,
+                            const int32_t *pose_idx = nullptr, int max_poses = 0, int32_t n_poses = 0, bool *over = nullptr)
 {
     chunk_v0.assign(1, 0);
-    int64_t nf = 0, nv = 0, nb = 0;
+    int64_t nf = 0, nv = 0, nb = 0, np = 0, epoch = 1;
     Q = 0;
+    if (over) *over = false;
+    lvba::hvec<int64_t> stamp, vstamp; // last chunk epoch / last voxel that saw each pose
+    if (pose_idx) { stamp.assign((size_t)n_poses, 0); vstamp.assign((size_t)n_poses, -1); }
+    const int64_t base = n_voxels > 0 ? voxel_off[0] : 0;
     for (int64_t a = 0; a < n_voxels; ++a) {
         const int64_t k = voxel_off[a + 1] - voxel_off[a];
         if (k < 2) return a;
         Q += k * (k - 1) / 2;
         while (nb < n_breaks && breaks[nb] < a) ++nb;
-        if (nb < n_breaks && breaks[nb] == a && nv > 0) { chunk_v0.push_back(a); nf = 0; nv = 0; }
-        if (k > max_factors) {
+        if (nb < n_breaks && breaks[nb] == a && nv > 0) { chunk_v0.push_back(a); nf = 0; nv = 0; np = 0; ++epoch; }
+        int64_t fresh = 0, own = 0; // poses of this voxel the open chunk has not seen / distinct poses of the voxel itself
+        if (pose_idx)
+            for (int64_t f = voxel_off[a] - base; f < voxel_off[a + 1] - base; ++f) {
+                const size_t P = (size_t)pose_idx[f];
+                if (vstamp[P] == a) continue;
+                vstamp[P] = a;
+                ++own;
+                if (stamp[P] != epoch) ++fresh;
+            }
+        if (k > max_factors || (pose_idx && own > max_poses)) {
+            if (over && pose_idx && own > max_poses) *over = true;
             if (nv > 0) chunk_v0.push_back(a);
             chunk_v0.push_back(a + 1);
-            nf = 0; nv = 0;
+            nf = 0; nv = 0; np = 0; ++epoch;
             continue;
         }
-        if (nf + k > max_factors || nv == max_voxels) { chunk_v0.push_back(a); nf = 0; nv = 0; }
-        nf += k; nv += 1;
+        if (nf + k > max_factors || nv == max_voxels || (pose_idx && np + fresh > max_poses)) {
+            chunk_v0.push_back(a); nf = 0; nv = 0; np = 0; ++epoch;
+            fresh = own;
+        }
+        if (pose_idx)
+            for (int64_t f = voxel_off[a] - base; f < voxel_off[a + 1] - base; ++f) stamp[(size_t)pose_idx[f]] = epoch;
+        nf += k; nv += 1; np += fresh;
     }
     if (chunk_v0.back() != n_voxels || chunk_v0.size() == 1) chunk_v0.push_back(n_voxels); // (an empty problem keeps one empty chunk)
     return -1;
@@ -49,9 +72,9 @@ inline int64_t pair_cut_length(int64_t Q)
     const int64_t cut = (Q / 4096 + 15) / 16 * 16;
     return std::max<int64_t>(64, std::min<int64_t>(cut, 512));
 }
-inline void cut_pair_items(const std::vector<int64_t> &blk_slot, const std::vector<int64_t> &blk_off, int64_t Q,
-                           std::vector<int64_t> &item_off, std::vector<int64_t> &item_dst, std::vector<int64_t> &multi_off,
-                           std::vector<int64_t> &multi_slot, int64_t &n_partial)
+inline void cut_pair_items(const lvba::hvec<int64_t> &blk_slot, const lvba::hvec<int64_t> &blk_off, int64_t Q,
+                           lvba::hvec<int64_t> &item_off, lvba::hvec<int64_t> &item_dst, lvba::hvec<int64_t> &multi_off,
+                           lvba::hvec<int64_t> &multi_slot, int64_t &n_partial)
 {
     item_off.assign(1, 0);
     item_dst.clear();
@@ -81,9 +104,9 @@ inline void cut_pair_items(const std::vector<int64_t> &blk_slot, const std::vect
 // blocks in item order (= voxel window order: deterministic).  Partial indices follow the ITEM order, so that consecutive
 // items store to consecutive partial blocks; the lists of a summed block's partials are multi_idx[multi_off[m] ..
 // multi_off[m+1]).  run_slot [R], run_off [R+1]; n_slots bounds the slot values.
-inline void group_pair_items(const std::vector<int64_t> &run_slot, const std::vector<int64_t> &run_off, int64_t cut, int64_t n_slots,
-                             std::vector<int64_t> &item_off, std::vector<int64_t> &item_dst, std::vector<int64_t> &multi_off,
-                             std::vector<int64_t> &multi_slot, std::vector<int64_t> &multi_idx, int64_t &n_partial)
+inline void group_pair_items(const lvba::hvec<int64_t> &run_slot, const lvba::hvec<int64_t> &run_off, int64_t cut, int64_t n_slots,
+                             lvba::hvec<int64_t> &item_off, lvba::hvec<int64_t> &item_dst, lvba::hvec<int64_t> &multi_off,
+                             lvba::hvec<int64_t> &multi_slot, lvba::hvec<int64_t> &multi_idx, int64_t &n_partial)
 {
     item_off.assign(1, 0);
     item_dst.clear();
@@ -92,15 +115,15 @@ inline void group_pair_items(const std::vector<int64_t> &run_slot, const std::ve
     multi_idx.clear();
     n_partial = 0;
     if (cut < 1) cut = 1;
-    std::vector<int32_t> cnt((size_t)n_slots, 0);
-    std::vector<int64_t> item_slot;
+    lvba::hvec<int32_t> cnt((size_t)n_slots, 0);
+    lvba::hvec<int64_t> item_slot;
     for (size_t r = 0; r < run_slot.size(); ++r)
         for (int64_t q = run_off[r]; q < run_off[r + 1]; q += cut) {
             item_off.push_back(std::min(q + cut, run_off[r + 1]));
             item_slot.push_back(run_slot[r]);
             cnt[(size_t)run_slot[r]]++;
         }
-    std::vector<int64_t> base((size_t)n_slots, -1);
+    lvba::hvec<int64_t> base((size_t)n_slots, -1);
     int64_t tot = 0;
     for (int64_t sl = 0; sl < n_slots; ++sl)
         if (cnt[(size_t)sl] > 1) {

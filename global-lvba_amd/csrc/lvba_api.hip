@@ -10,6 +10,7 @@
 #include <new>
 #include <vector>
 
+#include "host_arena.h"
 #include "block_system.h"
 #include "host_tables.h"
 
@@ -25,16 +26,17 @@ struct lvba_balm_s {
     int32_t N = 0;
     int64_t V = 0, F = 0, Q = 0, n_chunks = 0, Vglobal = 0;
     // host copies kept until finalize()
-    std::vector<int64_t> h_voff, h_chunk_v0;
-    std::vector<int32_t> h_pidx;
+    lvba::hvec<int64_t> h_voff, h_chunk_v0;
+    lvba::hvec<int32_t> h_pidx;
     bool finalized = false;
-    // fused voxel-major evaluation (balm_fused_kernel): tables built at finalize
-    bool fused = false;
+    // fused voxel-major evaluation (balm_fused_kernel, the default): tables built at finalize.  Not for problems with a voxel
+    // seen from more than LVBA_FS poses (`wide_voxel`): those keep the three-pass evaluation.
+    bool fused = false, wide_voxel = false;
     bool voxels_sorted = false; // the voxels were re-laid in the order of the first pose that sees them (balm_create_impl)
     int64_t n_super = 0;
     int64_t *d_super_c0 = nullptr, *d_pp_off = nullptr, *d_pp_idx = nullptr;
-    int32_t *d_n_slots = nullptr;
-    uint8_t *d_slot = nullptr, *d_round = nullptr, *d_n_rounds = nullptr;
+    int32_t *d_n_slots = nullptr, *d_cdesc = nullptr;
+    uint8_t *d_srt = nullptr, *d_run_start = nullptr, *d_run_len = nullptr, *d_run_slot = nullptr;
     double *d_fpart = nullptr;
     // device data (voxel-major)
     int64_t *d_voff = nullptr, *d_chunk_v0 = nullptr;
@@ -47,8 +49,8 @@ struct lvba_balm_s {
     double *h_pin = nullptr;   // pinned host staging, 16 doubles
     // grouped refinement (lvba_balm_set_groups): independent pose / voxel groups, one LM state each
     int32_t n_groups = 0;
-    std::vector<int32_t> g_pose_off;   // [n_groups + 1]
-    std::vector<int64_t> g_vox_off;    // [n_groups + 1]
+    lvba::hvec<int32_t> g_pose_off;   // [n_groups + 1]
+    lvba::hvec<int64_t> g_vox_off;    // [n_groups + 1]
     int32_t *d_grp_of_pose = nullptr, *d_gpo = nullptr, *d_gaccept = nullptr;
     int64_t *d_gco = nullptr;          // chunk range of every group
     double *d_gscal = nullptr;         // [3][n_groups]: cost at the current poses, cost at the trial poses, q1 numerator
@@ -60,9 +62,10 @@ struct lvba_balm_s {
     double u = 0.01, v = 2.0, residual1 = 0.0;
     int iter = 0;
     bool have_eval = false;
-    // the voxel records (d_vrec) and chunk costs belong to the poses in d_pose_cur: the LM loop costs its trial point with the
-    // voxel pass of the evaluation, and an accepted trial point is where the next evaluation happens
-    bool vrec_at_cur = false;
+    // the linearisation (fused evaluation: Y + per-pose partial sums; three-pass evaluation: the voxel records) and the chunk
+    // costs belong to the poses in d_pose_cur: the LM loop costs its trial point with the first half of the evaluation, and an
+    // accepted trial point is where the next evaluation happens
+    bool lin_at_cur = false;
     // profiling
     bool prof_on = false;
     hipEvent_t ev[EV_N][2] = {};
@@ -82,8 +85,8 @@ struct lvba_balm_s {
     FusedDev fdev() const
     {
         FusedDev f;
-        f.n_super = n_super; f.super_c0 = d_super_c0; f.n_slots = d_n_slots; f.slot = d_slot; f.round = d_round;
-        f.n_rounds = d_n_rounds; f.part = d_fpart; f.pp_off = d_pp_off; f.pp_idx = d_pp_idx;
+        f.n_super = n_super; f.super_c0 = d_super_c0; f.n_slots = d_n_slots; f.srt = d_srt; f.cdesc = reinterpret_cast<const int4 *>(d_cdesc);
+        f.run_start = d_run_start; f.run_len = d_run_len; f.run_slot = d_run_slot; f.part = d_fpart; f.pp_off = d_pp_off; f.pp_idx = d_pp_idx;
         return f;
     }
 };
@@ -155,7 +158,7 @@ static int32_t balm_create_impl(int32_t n_poses, int64_t n_voxels, const int64_t
     // re-layout decision below; only needed from the size on from which the pair lists are windowed)
     static const bool allow_sort = [] { const char *e = getenv("LVBA_VOXEL_SORT"); return !(e && !strcmp(e, "0")); }();
     const bool want_key = allow_sort && 18 * 8 * F > ((int64_t)24 << 20) && n_voxels > 1;
-    std::vector<int32_t> key;
+    lvba::hvec<int32_t> key;
     if (want_key) key.resize((size_t)n_voxels);
     double jump = 0.0;
     for (int64_t a = 0; a < n_voxels; ++a) {
@@ -180,15 +183,15 @@ static int32_t balm_create_impl(int32_t n_poses, int64_t n_voxels, const int64_t
     // i.e. in no order at all: at C3 that costs 17 % of the evaluation (2.71 vs 2.32 ms, tools/gpu_shuffled.sh).  So a large
     // problem whose voxels jump about is re-laid internally, voxels sorted (stably) by the first pose that sees them.  Nothing
     // the caller gets back is indexed by voxel; sums over voxels change in the last bits only.  LVBA_VOXEL_SORT=0: off.
-    std::vector<int64_t> voff_s;
-    std::vector<int32_t> pidx_s, fmap;
+    lvba::hvec<int64_t> voff_s;
+    lvba::hvec<int32_t> pidx_s, fmap;
     {
         const bool sort_voxels = want_key && jump / (double)(n_voxels - 1) > std::max(64.0, 0.125 * n_poses);
         if (sort_voxels) { // stable counting sort by the first pose
-            std::vector<int64_t> start((size_t)n_poses + 1, 0);
+            lvba::hvec<int64_t> start((size_t)n_poses + 1, 0);
             for (int64_t a = 0; a < n_voxels; ++a) ++start[(size_t)key[(size_t)a] + 1];
             for (int32_t i = 0; i < n_poses; ++i) start[(size_t)i + 1] += start[(size_t)i];
-            std::vector<int64_t> order((size_t)n_voxels); // order[new] = old
+            lvba::hvec<int64_t> order((size_t)n_voxels); // order[new] = old
             for (int64_t a = 0; a < n_voxels; ++a) order[(size_t)start[(size_t)key[(size_t)a]]++] = a;
             voff_s.resize((size_t)n_voxels + 1);
             pidx_s.resize((size_t)F);
@@ -216,11 +219,12 @@ static int32_t balm_create_impl(int32_t n_poses, int64_t n_voxels, const int64_t
     h->voxels_sorted = !fmap.empty();
     // validate + chunk
     h->h_voff.resize(n_voxels + 1);
-    std::vector<int64_t> chunk_v0;
+    lvba::hvec<int64_t> chunk_v0;
     int64_t Q = 0;
     for (int64_t a = 0; a <= n_voxels; ++a) h->h_voff[a] = voxel_off[a] - base2;
     {
-        const int64_t bad = lvba::chunk_voxels(n_voxels, voxel_off, LVBA_CF, LVBA_CV, chunk_v0, Q); // host_tables.h
+        const int64_t bad = lvba::chunk_voxels(n_voxels, voxel_off, LVBA_CF, LVBA_CV, chunk_v0, Q, nullptr, 0, pose_idx, LVBA_FS, n_poses,
+                                               &h->wide_voxel); // host_tables.h
         if (bad >= 0) {
             const long long k = (long long)(voxel_off[bad + 1] - voxel_off[bad]);
             delete h;
@@ -229,14 +233,7 @@ static int32_t balm_create_impl(int32_t n_poses, int64_t n_voxels, const int64_t
     }
     h->n_chunks = (int64_t)chunk_v0.size() - 1;
     h->Q = Q;
-    { // the fused evaluation (opt-in, LVBA_FUSED=1: measured slower than the two passes) needs every chunk to
-      // fit a workgroup's lanes (no voxel with more than LVBA_CF observers)
-        const char *e = getenv("LVBA_FUSED");
-        bool ok = e && !strcmp(e, "1");
-        for (int64_t a = 0; a < n_voxels && ok; ++a) ok = voxel_off[a + 1] - voxel_off[a] <= LVBA_CF;
-        h->fused = ok;
-        h->h_chunk_v0 = chunk_v0;
-    }
+    h->h_chunk_v0 = chunk_v0;
     h->h_pidx.assign(pose_idx, pose_idx + F);
     mark("chunks + copies");
 
@@ -290,7 +287,7 @@ extern "C" int32_t lvba_balm_destroy(lvba_balm_t h)
     if (h->bs.stream) hipStreamSynchronize(h->bs.stream);
     void *ptrs[] = {h->d_voff, h->d_chunk_v0, h->d_pidx, h->d_clu, h->d_chunk_cost, h->d_clu_csc, h->d_vrec, h->d_part,
                     h->d_pose_in, h->d_pose_cur, h->d_pose_trial, h->d_out, h->d_scal2, h->d_super_c0, h->d_pp_off, h->d_pp_idx,
-                    h->d_n_slots, h->d_slot, h->d_round, h->d_n_rounds, h->d_fpart, h->d_grp_of_pose, h->d_gpo, h->d_gaccept, h->d_gco,
+                    h->d_n_slots, h->d_cdesc, h->d_srt, h->d_run_start, h->d_run_len, h->d_run_slot, h->d_fpart, h->d_grp_of_pose, h->d_gpo, h->d_gaccept, h->d_gco,
                     h->d_gscal};
     for (void *p : ptrs)
         if (p) lvba::DevicePool::get().free(p);
@@ -311,74 +308,97 @@ extern "C" int32_t lvba_balm_configure(lvba_balm_t h, int32_t ordering, double b
     if (h->finalized) return fail(LVBA_ERR_STATE, "configure must precede the first cost/eval/refine call");
     if (ordering != 0 && ordering != 1) return fail(LVBA_ERR_ARG, "ordering must be 0 or 1");
     if (!(band_frac >= 0.0)) return fail(LVBA_ERR_ARG, "band_frac must be >= 0");
+    // a grouped problem keeps the caller's pose order: the per-group tables (damping, q1, accept / select) are indexed by it
+    if (h->n_groups > 0 && ordering != 0) return fail(LVBA_ERR_STATE, "a grouped problem (lvba_balm_set_groups) keeps ordering 0");
     h->bs.ordering = ordering;
     h->bs.band_frac = band_frac;
     return LVBA_OK;
 }
 
-// Super-chunks, pose slots and add rounds of the fused evaluation (balm_fused_kernel).  p [F]: solver-order pose per factor.
-static int32_t build_fused_tables(lvba_balm_s *h, const std::vector<int32_t> &p)
+// Super-chunks, pose slots, pose-sorted positions and runs of the fused evaluation (balm_fused_kernel).  p [F]: solver-order
+// pose per factor.
+static int32_t build_fused_tables(lvba_balm_s *h, const lvba::hvec<int32_t> &p)
 {
     BlockSys &bs = h->bs;
     const int32_t N = h->N;
     const int64_t F = h->F, nch = h->n_chunks;
-    const std::vector<int64_t> &cv = h->h_chunk_v0, &voff = h->h_voff;
-    // enough super-chunks to fill the chip a few times over (one workgroup per CU is resident), few enough to amortise the flush
-    const int64_t cap = std::max<int64_t>(1, (nch + 1023) / 1024);
-    std::vector<int64_t> super_c0(1, 0), pp_cnt((size_t)N + 1, 0);
-    std::vector<int32_t> n_slots, stamp((size_t)N, -1), slot_of((size_t)N, 0), seen((size_t)N, -1);
-    std::vector<uint8_t> slot((size_t)F), round((size_t)F), n_rounds((size_t)nch);
-    std::vector<std::pair<int32_t, int64_t>> rows; // (pose, row of `part`)
+    const lvba::hvec<int64_t> &cv = h->h_chunk_v0, &voff = h->h_voff;
+    // enough super-chunks to fill the chip several times over (two workgroups per CU are resident), few enough to amortise the
+    // accumulator flush (<= 27 KB per super-chunk against ~57 KB of clusters and Y per chunk)
+    const int64_t cap = std::max<int64_t>(4, (nch + 2047) / 2048);
+    lvba::hvec<int64_t> super_c0(1, 0), pp_cnt((size_t)N + 1, 0);
+    lvba::hvec<int32_t> n_slots, stamp((size_t)N, -1), slot_of((size_t)N, 0), cdesc(8 * (size_t)nch + 8, 0);
+    lvba::hvec<uint8_t> srt((size_t)F), run_start, run_len, run_slot;
+    run_start.reserve((size_t)F / 2); run_len.reserve((size_t)F / 2); run_slot.reserve((size_t)F / 2);
+    lvba::hvec<std::pair<int32_t, int64_t>> rows; // (pose, row of `part`)
+    lvba::hvec<uint64_t> keys;
     int32_t cur_slots = 0;
     int64_t cur_chunks = 0, epoch = 0;
     for (int64_t ch = 0; ch < nch; ++ch) {
         const int64_t f0 = voff[cv[ch]], f1 = voff[cv[ch + 1]];
-        int32_t fresh = 0; // poses of this chunk the open super-chunk has not seen
-        for (int64_t f = f0; f < f1; ++f)
-            if (stamp[p[f]] != (int32_t)epoch && seen[p[f]] != (int32_t)ch) { seen[p[f]] = (int32_t)ch; ++fresh; }
-        if (cur_chunks > 0 && (cur_slots + fresh > 256 || cur_chunks == cap)) { // close the open super-chunk
+        const int nf = (int)(f1 - f0);
+        if (nf > LVBA_CF) return lvba_fail(LVBA_ERR_STATE, "fused tables: a chunk has more than %d factors", LVBA_CF);
+        keys.resize((size_t)nf);
+        for (int i = 0; i < nf; ++i) keys[(size_t)i] = (uint64_t)(uint32_t)p[(size_t)(f0 + i)] << 16 | (uint64_t)i; // (pose, voxel order)
+        std::sort(keys.begin(), keys.end());
+        int32_t fresh = 0, npc = 0; // poses of this chunk the open super-chunk has not seen; distinct poses of the chunk
+        for (int i = 0; i < nf; ++i)
+            if (i == 0 || (keys[(size_t)i] >> 16) != (keys[(size_t)i - 1] >> 16)) { ++npc; if (stamp[(size_t)(keys[(size_t)i] >> 16)] != (int32_t)epoch) ++fresh; }
+        if (npc > LVBA_FS) return lvba_fail(LVBA_ERR_STATE, "fused tables: a chunk touches more than %d poses", LVBA_FS);
+        if (cur_chunks > 0 && (cur_slots + fresh > LVBA_FS || cur_chunks == cap)) { // close the open super-chunk
             super_c0.push_back(ch);
             n_slots.push_back(cur_slots);
             ++epoch; cur_slots = 0; cur_chunks = 0;
         }
-        uint8_t cnt[256] = {0};
-        int maxr = 0;
-        for (int64_t f = f0; f < f1; ++f) {
-            const int32_t P = p[f];
-            if (stamp[P] != (int32_t)epoch) {
-                stamp[P] = (int32_t)epoch;
-                slot_of[P] = cur_slots++;
-                rows.push_back({P, epoch * 256 + slot_of[P]});
-                pp_cnt[(size_t)P + 1]++;
-            }
-            const int sl = slot_of[P];
-            slot[f] = (uint8_t)sl;
-            round[f] = cnt[sl]++;
-            maxr = std::max(maxr, (int)round[f] + 1);
+        for (int i = 0; i < nf; ++i) {
+            const int32_t P = (int32_t)(keys[(size_t)i] >> 16);
+            srt[(size_t)(f0 + (int64_t)(keys[(size_t)i] & 0xffff))] = (uint8_t)i;
+            if (i == 0 || P != (int32_t)(keys[(size_t)i - 1] >> 16)) {
+                if (stamp[(size_t)P] != (int32_t)epoch) {
+                    stamp[(size_t)P] = (int32_t)epoch;
+                    slot_of[(size_t)P] = cur_slots++;
+                    rows.push_back({P, epoch * LVBA_FS + slot_of[(size_t)P]});
+                    pp_cnt[(size_t)P + 1]++;
+                }
+                run_start.push_back((uint8_t)i);
+                run_len.push_back(0);
+                run_slot.push_back((uint8_t)slot_of[(size_t)P]);
+            } else
+                ++run_len.back(); // (length - 1)
         }
-        if (cur_slots > 256) return lvba_fail(LVBA_ERR_STATE, "fused tables: a chunk touches more than 256 poses");
-        n_rounds[ch] = (uint8_t)maxr;
+        {
+            int32_t *q = cdesc.data() + 8 * (size_t)ch;
+            q[0] = (int32_t)f0; q[1] = nf; q[2] = (int32_t)cv[ch]; q[3] = (int32_t)(cv[ch + 1] - cv[ch]);
+            q[4] = (int32_t)run_start.size() - npc; q[5] = npc;
+        }
         ++cur_chunks;
     }
     super_c0.push_back(nch);
     n_slots.push_back(cur_slots);
     h->n_super = (int64_t)n_slots.size();
     for (int32_t i = 0; i < N; ++i) pp_cnt[(size_t)i + 1] += pp_cnt[i];
-    std::vector<int64_t> pp_idx(rows.size()), fill(pp_cnt.begin(), pp_cnt.end() - 1);
+    lvba::hvec<int64_t> pp_idx(rows.size()), fill(pp_cnt.begin(), pp_cnt.end() - 1);
     for (const auto &r : rows) pp_idx[(size_t)fill[r.first]++] = r.second; // rows arrive in super-chunk order: so do the sums
+    const int64_t nruns = (int64_t)run_start.size();
     TRY(bs_dmalloc(bs, &h->d_super_c0, h->n_super + 1));
     TRY(bs_dmalloc(bs, &h->d_n_slots, h->n_super));
-    TRY(bs_dmalloc(bs, &h->d_slot, F));
-    TRY(bs_dmalloc(bs, &h->d_round, F));
-    TRY(bs_dmalloc(bs, &h->d_n_rounds, nch));
-    TRY(bs_dmalloc(bs, &h->d_fpart, h->n_super * 256 * 32));
+    TRY(bs_dmalloc(bs, &h->d_srt, F));
+    TRY(bs_dmalloc(bs, &h->d_cdesc, 8 * nch + 8));
+    TRY(bs_dmalloc(bs, &h->d_run_start, nruns));
+    TRY(bs_dmalloc(bs, &h->d_run_len, nruns));
+    TRY(bs_dmalloc(bs, &h->d_run_slot, nruns));
+    TRY(bs_dmalloc(bs, &h->d_fpart, h->n_super * LVBA_FS * 32));
     TRY(bs_dmalloc(bs, &h->d_pp_off, (int64_t)N + 1));
     TRY(bs_dmalloc(bs, &h->d_pp_idx, (int64_t)pp_idx.size()));
     HIPCHK(lvba::copy_h2d(h->d_super_c0, super_c0.data(), super_c0.size() * sizeof(int64_t)));
     HIPCHK(lvba::copy_h2d(h->d_n_slots, n_slots.data(), n_slots.size() * sizeof(int32_t)));
-    HIPCHK(lvba::copy_h2d(h->d_slot, slot.data(), (size_t)F));
-    HIPCHK(lvba::copy_h2d(h->d_round, round.data(), (size_t)F));
-    HIPCHK(lvba::copy_h2d(h->d_n_rounds, n_rounds.data(), (size_t)nch));
+    HIPCHK(lvba::copy_h2d(h->d_srt, srt.data(), (size_t)F));
+    HIPCHK(lvba::copy_h2d(h->d_cdesc, cdesc.data(), cdesc.size() * sizeof(int32_t)));
+    if (nruns) {
+        HIPCHK(lvba::copy_h2d(h->d_run_start, run_start.data(), (size_t)nruns));
+        HIPCHK(lvba::copy_h2d(h->d_run_len, run_len.data(), (size_t)nruns));
+        HIPCHK(lvba::copy_h2d(h->d_run_slot, run_slot.data(), (size_t)nruns));
+    }
     HIPCHK(lvba::copy_h2d(h->d_pp_off, pp_cnt.data(), pp_cnt.size() * sizeof(int64_t)));
     if (!pp_idx.empty()) HIPCHK(lvba::copy_h2d(h->d_pp_idx, pp_idx.data(), pp_idx.size() * sizeof(int64_t)));
     return LVBA_OK;
@@ -390,7 +410,13 @@ static int32_t finalize(lvba_balm_s *h)
     BlockSys &bs = h->bs;
     HIPCHK(hipSetDevice(bs.device));
     const int N = h->N;
+    { // LVBA_FUSED=0: the three-pass evaluation (voxel-major, pose-major, pairs) also where the fused one applies (A/B)
+        const char *e = getenv("LVBA_FUSED");
+        // (the kernel addresses the cluster rows with 32-bit byte offsets: 80 F < 2^32, i.e. shards below 53 M factors)
+        h->fused = !h->wide_voxel && (uint64_t)h->F * 80u < 0xFFFFFFF0ull && !(e && !strcmp(e, "0"));
+    }
     bs.y_voxel_major = h->fused;
+    if (h->n_groups > 0) bs.ordering = 0; // (lvba_balm_configure / dist_init refuse to undo it; kept here as the single point of truth)
     const bool timing = getenv("LVBA_TIMING") != nullptr;
     auto nowc = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tmark = nowc();
@@ -402,7 +428,7 @@ static int32_t finalize(lvba_balm_s *h)
     };
     TRY(bs_build(bs, N, h->V, h->h_voff.data(), h->h_pidx.data()));
     mark("bs_build");
-    std::vector<int32_t> p((size_t)h->F); // pose indices of the factors in solver order
+    lvba::hvec<int32_t> p((size_t)h->F); // pose indices of the factors in solver order
     for (int64_t f = 0; f < h->F; ++f) p[f] = bs.iperm[h->h_pidx[f]];
     HIPCHK(lvba::copy_h2d(h->d_pidx, p.data(), (size_t)h->F * sizeof(int32_t)));
     mark("pose indices");
@@ -421,9 +447,9 @@ static int32_t finalize(lvba_balm_s *h)
     TRY(bs_dmalloc(bs, &h->d_scal2, 8));
     HIPCHK(hipStreamSynchronize(bs.stream));
     mark("pose-major copy");
-    std::vector<int64_t>().swap(h->h_voff);
-    std::vector<int64_t>().swap(h->h_chunk_v0);
-    std::vector<int32_t>().swap(h->h_pidx);
+    lvba::hvec<int64_t>().swap(h->h_voff);
+    lvba::hvec<int64_t>().swap(h->h_chunk_v0);
+    lvba::hvec<int32_t>().swap(h->h_pidx);
     h->finalized = true;
     return LVBA_OK;
 }
@@ -440,6 +466,11 @@ extern "C" int32_t lvba_balm_info(lvba_balm_t h, lvba_balm_info_t *info)
     {
         const char *e = getenv("LVBA_DIST_SOLVE");
         info->solve_ranks = (h->bs.distributed() && h->bs.n_ranks >= 2 && info->twist_panels > 0 && !(e && !strcmp(e, "0"))) ? 2 : 1;
+    }
+    info->eval_mode = h->fused ? 1 : 0;
+    {
+        const char *e = getenv("LVBA_COST_RECORDS");
+        info->trial_linearised = (!(e && !strcmp(e, "0")) && (h->fused || !h->bs.distributed())) ? 1 : 0;
     }
     info->allreduce_bytes = !h->bs.distributed() ? 0 : 8 * ((h->bs.d_ar_slot ? 36 * h->bs.n_ar : h->bs.hblk_doubles) + 6 * (int64_t)h->N + 1);
     return LVBA_OK;
@@ -494,11 +525,14 @@ extern "C" int32_t lvba_balm_get_profile(lvba_balm_t h, lvba_prof_t *out, int32_
 
 // ------------------------------------------------------------------------------------------ stages
 // enqueue: cost at device poses (solver order) -> dst[0] = (global) sum of lambda_min
-static int32_t enqueue_cost(lvba_balm_s *h, const double *d_poses, double *dst, bool with_records = false)
+// with_lin: by the first half of the evaluation instead of the cost-only kernel -- the same chunk costs, plus the linearisation
+// at `poses` (fused: Y and the per-pose partial sums; three-pass: the voxel records), which enqueue_eval can start from
+static int32_t enqueue_cost(lvba_balm_s *h, const double *d_poses, double *dst, bool with_lin = false)
 {
     ev_begin(h, EV_COST);
-    launch_cost(h->dev(), d_poses, h->d_chunk_cost, dst, h->stream(), h->prof_on ? h->ev[EV_COSTK][0] : nullptr,
-                h->prof_on ? h->ev[EV_COSTK][1] : nullptr, with_records);
+    hipEvent_t k0 = h->prof_on ? h->ev[EV_COSTK][0] : nullptr, k1 = h->prof_on ? h->ev[EV_COSTK][1] : nullptr;
+    if (with_lin && h->fused) launch_fused(h->dev(), h->fdev(), d_poses, h->d_chunk_cost, dst, h->stream(), k0, k1);
+    else launch_cost(h->dev(), d_poses, h->d_chunk_cost, dst, h->stream(), k0, k1, with_lin);
     if (h->prof_on) h->ev_used[EV_COSTK] = true;
     ev_end(h, EV_COST);
     if (h->bs.distributed()) {
@@ -511,18 +545,19 @@ static int32_t enqueue_cost(lvba_balm_s *h, const double *d_poses, double *dst, 
 }
 
 // enqueue: H, g, cost at device poses -> bs.d_hg (all-reduced over ranks)
-static int32_t enqueue_eval(lvba_balm_s *h, const double *d_poses, bool records_in_place = false)
+// lin_in_place: the linearisation at d_poses is already there (enqueue_cost with_lin at the same poses)
+static int32_t enqueue_eval(lvba_balm_s *h, const double *d_poses, bool lin_in_place = false)
 {
     BlockSys &bs = h->bs;
     ev_begin(h, EV_EVAL);
-    if (h->fused)
-        launch_eval_fused(h->dev(), h->fdev(), bs.pair_dev(), d_poses, bs.Hblk(), bs.hblk_doubles, bs.g(), h->d_chunk_cost, bs.scal(),
-                          bs.distributed(), bs.stream, h->prof_on ? h->ev[EV_EVALK][0] : nullptr,
-                          h->prof_on ? h->ev[EV_EVALK][1] : nullptr);
-    else
+    hipEvent_t k0 = h->prof_on ? h->ev[EV_EVALK][0] : nullptr, k1 = h->prof_on ? h->ev[EV_EVALK][1] : nullptr;
+    if (h->fused) {
+        if (!lin_in_place) launch_fused(h->dev(), h->fdev(), d_poses, h->d_chunk_cost, bs.scal(), bs.stream, k0, nullptr);
+        launch_fused_assemble(h->dev(), h->fdev(), bs.pair_dev(), bs.Hblk(), bs.hblk_doubles, bs.g(), h->d_chunk_cost, bs.scal(),
+                              bs.distributed(), bs.stream, lin_in_place ? k0 : nullptr, k1);
+    } else
         launch_eval(h->dev(), bs.pair_dev(), d_poses, bs.Hblk(), bs.hblk_doubles, bs.g(), h->d_chunk_cost, bs.scal(),
-                    bs.distributed(), bs.stream, h->prof_on ? h->ev[EV_EVALK][0] : nullptr,
-                    h->prof_on ? h->ev[EV_EVALK][1] : nullptr, records_in_place);
+                    bs.distributed(), bs.stream, k0, k1, lin_in_place);
     if (h->prof_on) h->ev_used[EV_EVALK] = true;
     ev_end(h, EV_EVAL);
     if (bs.distributed()) {
@@ -590,7 +625,7 @@ extern "C" int32_t lvba_balm_cost(lvba_balm_t h, const double *poses, int32_t is
     TRY(finalize(h));
     HIPCHK(hipSetDevice(h->bs.device));
     TRY(upload_poses(h, poses, h->d_pose_trial));
-    h->vrec_at_cur = false; // the chunk costs are overwritten
+    h->lin_at_cur = false; // the chunk costs are overwritten
     TRY(enqueue_cost(h, h->d_pose_trial, h->d_scal2));
     HIPCHK(hipMemcpyAsync(h->h_pin, h->d_scal2, sizeof(double), hipMemcpyDeviceToHost, h->stream()));
     HIPCHK(hipStreamSynchronize(h->stream()));
@@ -607,7 +642,7 @@ extern "C" int32_t lvba_balm_eval(lvba_balm_t h, const double *poses, double *H,
     BlockSys &bs = h->bs;
     HIPCHK(hipSetDevice(bs.device));
     TRY(upload_poses(h, poses, h->d_pose_cur));
-    h->vrec_at_cur = false; // (a full evaluation; an LM loop in progress starts its next evaluation from scratch too)
+    h->lin_at_cur = false; // (a full evaluation; an LM loop in progress starts its next evaluation from scratch too)
     TRY(enqueue_eval(h, h->d_pose_cur));
     HIPCHK(hipMemcpyAsync(h->h_pin, bs.scal(), sizeof(double), hipMemcpyDeviceToHost, bs.stream));
     const int64_t n = 6 * (int64_t)h->N;
@@ -624,6 +659,63 @@ extern "C" int32_t lvba_balm_eval(lvba_balm_t h, const double *poses, double *H,
     HIPCHK(hipStreamSynchronize(bs.stream));
     ev_collect(h);
     if (cost_avg) *cost_avg = h->h_pin[0] / (double)h->Vglobal;
+    return LVBA_OK;
+}
+
+// H of an evaluation in sparse form (the dense matrix of lvba_balm_eval is 28.8 GB at 10 000 poses): see include/lvba_hip.h
+extern "C" int32_t lvba_balm_eval_blocks(lvba_balm_t h, const double *poses, int64_t capacity, int32_t *bi, int32_t *bj,
+                                         double *blocks, int64_t *n_blocks, double *g, double *cost_avg)
+{
+    if (!h || !poses || !n_blocks) return fail(LVBA_ERR_ARG, "NULL argument");
+    if (capacity > 0 && (!bi || !bj || !blocks)) return fail(LVBA_ERR_ARG, "NULL block arrays");
+    TRY(finalize(h));
+    BlockSys &bs = h->bs;
+    HIPCHK(hipSetDevice(bs.device));
+    TRY(upload_poses(h, poses, h->d_pose_cur));
+    h->lin_at_cur = false;
+    TRY(enqueue_eval(h, h->d_pose_cur));
+    HIPCHK(hipMemcpyAsync(h->h_pin, bs.scal(), sizeof(double), hipMemcpyDeviceToHost, bs.stream));
+    if (g) {
+        launch_export_vec(bs.g(), bs.d_perm, h->N, h->d_out, bs.stream);
+        HIPCHK(hipMemcpyAsync(g, h->d_out, (size_t)6 * h->N * sizeof(double), hipMemcpyDeviceToHost, bs.stream));
+    }
+    HIPCHK(hipStreamSynchronize(bs.stream));
+    ev_collect(h);
+    if (cost_avg) *cost_avg = h->h_pin[0] / (double)h->Vglobal;
+    // the block-band store (solver order), one block column at a time
+    const int64_t Bb1 = (int64_t)bs.Bb + 1, N = h->N;
+    lvba::hvec<double> col((size_t)Bb1 * 36);
+    int64_t nb = 0;
+    for (int64_t J = 0; J < N; ++J) {
+        const int64_t rows = std::min<int64_t>(Bb1, N - J);
+        HIPCHK(hipMemcpy(col.data(), bs.Hblk() + J * Bb1 * 36, (size_t)rows * 36 * sizeof(double), hipMemcpyDeviceToHost));
+        for (int64_t dI = 0; dI < rows; ++dI) {
+            const double *b = col.data() + dI * 36; // column-major: b[c * 6 + r] = H(6 I + r, 6 J + c), I = J + dI (diagonal: r >= c only)
+            bool nz = dI == 0;
+            for (int e = 0; e < 36 && !nz; ++e) nz = b[e] != 0.0;
+            if (!nz) continue;
+            if (nb < capacity) {
+                const int32_t pi = bs.perm[(size_t)(J + dI)], pj = bs.perm[(size_t)J];
+                double *o = blocks + nb * 36;
+                if (dI == 0) {
+                    bi[nb] = pi; bj[nb] = pj;
+                    for (int r = 0; r < 6; ++r)
+                        for (int c = 0; c < 6; ++c) o[6 * r + c] = r >= c ? b[c * 6 + r] : b[r * 6 + c];
+                } else if (pi >= pj) {
+                    bi[nb] = pi; bj[nb] = pj;
+                    for (int r = 0; r < 6; ++r)
+                        for (int c = 0; c < 6; ++c) o[6 * r + c] = b[c * 6 + r];
+                } else { // the caller's order flips the pair: the transposed block
+                    bi[nb] = pj; bj[nb] = pi;
+                    for (int r = 0; r < 6; ++r)
+                        for (int c = 0; c < 6; ++c) o[6 * r + c] = b[r * 6 + c];
+                }
+            }
+            ++nb;
+        }
+    }
+    *n_blocks = nb;
+    if (capacity > 0 && nb > capacity) return fail(LVBA_ERR_ARG, "capacity %lld < %lld blocks", (long long)capacity, (long long)nb);
     return LVBA_OK;
 }
 
@@ -655,7 +747,7 @@ extern "C" int32_t lvba_balm_lm_begin(lvba_balm_t h, const double *poses, const 
     TRY(upload_poses(h, poses, h->d_pose_cur));
     h->u = h->lm_opts.u0; h->v = h->lm_opts.v0;
     h->is_calc_hess = true; h->iter = 0; h->residual1 = 0.0;
-    h->vrec_at_cur = false;
+    h->lin_at_cur = false;
     h->lm_active = true;
     h->lm_done = h->lm_opts.max_iter == 0;
     return LVBA_OK;
@@ -670,15 +762,18 @@ extern "C" int32_t lvba_balm_lm_step(lvba_balm_t h, lvba_lm_trace *row, int32_t 
     HIPCHK(hipSetDevice(h->bs.device));
     const bool evaluated = h->is_calc_hess;
     const int64_t n = 6 * (int64_t)h->N;
-    // LVBA_COST_RECORDS=0: the trial point is costed by the cost-only kernel and every evaluation runs its own voxel pass (A/B)
+    // The trial point is costed by the FIRST HALF of the evaluation (fused: the whole linearisation -- costs, Y, per-pose sums;
+    // three-pass: the voxel pass with its records): an accepted trial point is where the next evaluation happens, and that
+    // evaluation then only assembles H and g (per-pose sums + pair pass).  A rejected step wastes the difference to the
+    // cost-only kernel (C3: 0.2 ms).  LVBA_COST_RECORDS=0: cost-only kernel at the trial point, every evaluation from scratch (A/B).
     static const bool cost_records = [] { const char *e = getenv("LVBA_COST_RECORDS"); return !(e && !strcmp(e, "0")); }();
-    const bool with_records = cost_records && !h->fused && !h->bs.distributed();
-    if (evaluated) TRY(enqueue_eval(h, h->d_pose_cur, with_records && h->vrec_at_cur));    // :688-689
+    const bool with_lin = cost_records && (h->fused || !h->bs.distributed());
+    if (evaluated) TRY(enqueue_eval(h, h->d_pose_cur, with_lin && h->lin_at_cur));         // :688-689
     TRY(enqueue_solve(h, h->u));                                                           // :692-710
     launch_retract(h->d_pose_cur, h->bs.d_dx, h->d_pose_trial, h->N, h->stream());              // :722-727
     launch_predicted_decrease(h->bs.Hblk(), h->bs.Bb, h->bs.g(), h->bs.d_dx, h->u, n, h->d_scal2 + 1, h->stream()); // :729
-    TRY(enqueue_cost(h, h->d_pose_trial, h->d_scal2, with_records));                       // :731 (+ the voxel records at the trial point)
-    h->vrec_at_cur = false; // they belong to the trial point now
+    TRY(enqueue_cost(h, h->d_pose_trial, h->d_scal2, with_lin));                           // :731 (+ the linearisation at the trial point)
+    h->lin_at_cur = false; // it belongs to the trial point now
     HIPCHK(hipMemcpyAsync(h->h_pin, h->d_scal2, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream()));
     HIPCHK(hipMemcpyAsync(h->h_pin + 2, h->bs.scal(), sizeof(double), hipMemcpyDeviceToHost, h->stream()));
     HIPCHK(hipMemcpyAsync(h->h_pin + 4, h->bs.d_status, sizeof(int), hipMemcpyDeviceToHost, h->stream()));
@@ -705,7 +800,7 @@ extern "C" int32_t lvba_balm_lm_step(lvba_balm_t h, lvba_lm_trace *row, int32_t 
     }
     if (q > 0) {                                                                           // :744-752
         std::swap(h->d_pose_cur, h->d_pose_trial);
-        h->vrec_at_cur = with_records; // the trial point is the current point now
+        h->lin_at_cur = with_lin; // the trial point is the current point now
         q = q / q1;
         h->v = 2.0;
         q = 1.0 - pow(2.0 * q - 1.0, 3.0);
@@ -788,9 +883,10 @@ extern "C" int32_t lvba_balm_set_groups(lvba_balm_t h, int32_t n_groups, const i
     HIPCHK(hipSetDevice(h->bs.device));
     BlockSys &bs = h->bs;
     // chunks must not straddle groups: the chunk table is made again with breaks at the group boundaries
-    std::vector<int64_t> chunk_v0;
+    lvba::hvec<int64_t> chunk_v0;
     int64_t Q = 0;
-    if (lvba::chunk_voxels(h->V, h->h_voff.data(), LVBA_CF, LVBA_CV, chunk_v0, Q, voxel_off + 1, n_groups - 1) >= 0)
+    if (lvba::chunk_voxels(h->V, h->h_voff.data(), LVBA_CF, LVBA_CV, chunk_v0, Q, voxel_off + 1, n_groups - 1, h->h_pidx.data(), LVBA_FS, h->N,
+                           &h->wide_voxel) >= 0)
         return fail(LVBA_ERR_STATE, "chunk table");
     lvba::DevicePool::get().free(h->d_chunk_v0); bs.device_bytes -= (h->n_chunks + 1) * (int64_t)sizeof(int64_t); h->d_chunk_v0 = nullptr;
     lvba::DevicePool::get().free(h->d_chunk_cost); bs.device_bytes -= h->n_chunks * (int64_t)sizeof(double); h->d_chunk_cost = nullptr;
@@ -799,7 +895,7 @@ extern "C" int32_t lvba_balm_set_groups(lvba_balm_t h, int32_t n_groups, const i
     TRY(bs_dmalloc(bs, &h->d_chunk_v0, h->n_chunks + 1));
     TRY(bs_dmalloc(bs, &h->d_chunk_cost, h->n_chunks));
     HIPCHK(lvba::copy_h2d(h->d_chunk_v0, chunk_v0.data(), (size_t)(h->n_chunks + 1) * sizeof(int64_t)));
-    std::vector<int64_t> gco((size_t)n_groups + 1, 0);
+    lvba::hvec<int64_t> gco((size_t)n_groups + 1, 0);
     {
         int64_t c = 0;
         for (int32_t k = 0; k <= n_groups; ++k) {
@@ -808,7 +904,7 @@ extern "C" int32_t lvba_balm_set_groups(lvba_balm_t h, int32_t n_groups, const i
             gco[(size_t)k] = c;
         }
     }
-    std::vector<int32_t> gof((size_t)h->N);
+    lvba::hvec<int32_t> gof((size_t)h->N);
     for (int32_t k = 0; k < n_groups; ++k)
         for (int32_t j = pose_off[k]; j < pose_off[k + 1]; ++j) gof[(size_t)j] = k;
     h->n_groups = n_groups;
@@ -837,7 +933,7 @@ extern "C" int32_t lvba_balm_refine_groups(lvba_balm_t h, double *poses_inout, c
     if (!h || !poses_inout) return fail(LVBA_ERR_ARG, "NULL argument");
     if (h->n_groups < 1) return fail(LVBA_ERR_STATE, "refine_groups without set_groups");
     TRY(finalize(h));
-    if (h->bs.d_bcr || h->fused) return fail(LVBA_ERR_UNSUPPORTED, "grouped refinement needs the LDL^T solver and the two-pass evaluation");
+    if (h->bs.d_bcr) return fail(LVBA_ERR_UNSUPPORTED, "grouped refinement needs the LDL^T solver");
     HIPCHK(hipSetDevice(h->bs.device));
     lvba_balm_opts o;
     if (opts) o = *opts; else lvba_balm_default_opts(&o);
@@ -849,9 +945,9 @@ extern "C" int32_t lvba_balm_refine_groups(lvba_balm_t h, double *poses_inout, c
     hipStream_t s = h->stream();
     TRY(upload_poses(h, poses_inout, h->d_pose_cur));
     struct St { double u, v, r1; bool calc, done; int iter; int32_t status; double first, last; };
-    std::vector<St> st((size_t)G);
+    lvba::hvec<St> st((size_t)G);
     for (auto &q : st) q = St{o.u0, o.v0, 0.0, true, o.max_iter == 0, 0, LVBA_OK, 0.0, 0.0};
-    std::vector<double> u((size_t)G);
+    lvba::hvec<double> u((size_t)G);
     double *c1 = h->d_gscal, *c2 = h->d_gscal + G, *q1d = h->d_gscal + 2 * (int64_t)G;
     int32_t worst = LVBA_OK;
     for (;;) {
@@ -927,8 +1023,20 @@ extern "C" int32_t lvba_balm_dist_init(lvba_balm_t h, int32_t n_ranks, int32_t r
 {
     if (!h || !uid) return fail(LVBA_ERR_ARG, "NULL argument");
     if (h->finalized) return fail(LVBA_ERR_STATE, "dist_init must precede the first cost/eval/refine call");
+    if (h->n_groups > 0) return fail(LVBA_ERR_UNSUPPORTED, "groups and voxel shards do not combine");
     int64_t Vg = h->V;
     TRY(bs_dist_init(h->bs, n_ranks, rank, uid, &Vg));
+    h->Vglobal = Vg;
+    return LVBA_OK;
+}
+
+extern "C" int32_t lvba_balm_dist_init_external(lvba_balm_t h, int32_t n_ranks, int32_t rank, lvba_allreduce_fn fn, void *ctx)
+{
+    if (!h || !fn) return fail(LVBA_ERR_ARG, "NULL argument");
+    if (h->finalized) return fail(LVBA_ERR_STATE, "dist_init must precede the first cost/eval/refine call");
+    if (h->n_groups > 0) return fail(LVBA_ERR_UNSUPPORTED, "groups and voxel shards do not combine");
+    int64_t Vg = h->V;
+    TRY(bs_dist_init_external(h->bs, n_ranks, rank, fn, ctx, &Vg));
     h->Vglobal = Vg;
     return LVBA_OK;
 }

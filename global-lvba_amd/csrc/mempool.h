@@ -100,7 +100,7 @@ class DevicePool {
 // Host <-> device copies of set-up tables from / to the caller's or the library's PAGEABLE memory.  The runtime moves small
 // transfers through its own staging buffers, but pins the user pages for transfers from 4 MB up (GPU_PINNED_MIN_XFER_SIZE) and
 // unpins them afterwards; every set-up table is a temporary std::vector that is freed right after.  Unmapping host memory the
-// driver knows about is what stalls the GPU (block_system.hip, tune_host_allocator: 14-25 ms with no stream making progress), so
+// driver knows about is what stalls the GPU (host_arena.h: 14-25 ms with no stream making progress), so
 // medium-sized copies go in pieces below the pinning threshold and never register the vector at all; huge ones (the set-up of a
 // 10 M-factor problem takes 0.3 s anyway) are left to the runtime.
 inline hipError_t copy_chunked(void *dst, const void *src, size_t bytes, hipMemcpyKind kind)

@@ -1,6 +1,7 @@
 // ordering.h -- pose ordering for the band solver (host code, header-only, no HIP: unit-tested on the CPU by
 // tests/ordering_check.cpp).
 #pragma once
+#include "host_arena.h"
 #include <algorithm>
 #include <climits>
 #include <cstdint>
@@ -17,10 +18,10 @@ namespace lvba {
 // refinement: positions are repeatedly replaced by the mean position of the neighbours and re-ranked, which
 // interleaves the two sides of ring-like trajectories (loop closures).  The candidate with the smallest
 // pose-block bandwidth wins.  One-off host work at finalize().
-inline int32_t bandwidth_of(const std::vector<std::vector<int32_t>> &nb, const std::vector<int32_t> &perm)
+inline int32_t bandwidth_of(const lvba::hvec<lvba::hvec<int32_t>> &nb, const lvba::hvec<int32_t> &perm)
 {
     const int N = (int)perm.size();
-    std::vector<int32_t> ip(N);
+    lvba::hvec<int32_t> ip(N);
     for (int i = 0; i < N; ++i) ip[perm[i]] = i;
     int32_t bw = 0;
     for (int i = 0; i < N; ++i)
@@ -28,16 +29,16 @@ inline int32_t bandwidth_of(const std::vector<std::vector<int32_t>> &nb, const s
     return bw;
 }
 
-inline void rcm_from(const std::vector<std::vector<int32_t>> &nb, const std::vector<int32_t> &deg, bool peripheral,
-                     std::vector<int32_t> &perm)
+inline void rcm_from(const lvba::hvec<lvba::hvec<int32_t>> &nb, const lvba::hvec<int32_t> &deg, bool peripheral,
+                     lvba::hvec<int32_t> &perm)
 {
     const int N = (int)nb.size();
-    std::vector<char> seen(N, 0), mark(N, 0);
-    std::vector<int32_t> order, level(N);
+    lvba::hvec<char> seen(N, 0), mark(N, 0);
+    lvba::hvec<int32_t> order, level(N);
     order.reserve(N);
     auto bfs_far = [&](int start) { // farthest node (minimal degree among the last level) from start
         std::queue<int> q;
-        std::vector<int> touched;
+        lvba::hvec<int> touched;
         q.push(start); mark[start] = 1; touched.push_back(start); level[start] = 0;
         int last = start;
         while (!q.empty()) {
@@ -49,7 +50,7 @@ inline void rcm_from(const std::vector<std::vector<int32_t>> &nb, const std::vec
         for (int t : touched) mark[t] = 0;
         return last;
     };
-    std::vector<int32_t> by_deg(N);
+    lvba::hvec<int32_t> by_deg(N);
     for (int i = 0; i < N; ++i) by_deg[i] = i;
     std::stable_sort(by_deg.begin(), by_deg.end(), [&](int a, int b) { return deg[a] < deg[b]; });
     for (int root : by_deg) {
@@ -76,13 +77,13 @@ inline void rcm_from(const std::vector<std::vector<int32_t>> &nb, const std::vec
 // trajectory, +-50 pose band, antipodal loop closures) 10 N moves take the half-bandwidth from ~470 to ~435 pose blocks
 // (~15 % fewer factorisation flops) for ~0.1 s of one-off host time; 8x more moves reach ~420 but cost 2.5 s, more than
 // a whole refinement saves.
-inline void hill_climb(const std::vector<std::vector<int32_t>> &nb, std::vector<int32_t> &perm, int32_t &bw_io)
+inline void hill_climb(const lvba::hvec<lvba::hvec<int32_t>> &nb, lvba::hvec<int32_t> &perm, int32_t &bw_io)
 {
     const int N = (int)perm.size();
     if (N < 64) return;
-    std::vector<int32_t> pos(N), order(perm);
+    lvba::hvec<int32_t> pos(N), order(perm);
     for (int i = 0; i < N; ++i) pos[order[i]] = i;
-    std::vector<int64_t> hist((size_t)N + 1, 0);
+    lvba::hvec<int64_t> hist((size_t)N + 1, 0);
     for (int i = 0; i < N; ++i)
         for (int j : nb[i])
             if (j > i) hist[std::abs(pos[i] - pos[j])]++;
@@ -93,7 +94,7 @@ inline void hill_climb(const std::vector<std::vector<int32_t>> &nb, std::vector<
     uint64_t rng = 0x9e3779b97f4a7c15ull;
     auto next = [&]() { rng = rng * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(rng >> 33); };
     // candidate list of long edges, rebuilt lazily
-    std::vector<std::pair<int32_t, int32_t>> longe;
+    lvba::hvec<std::pair<int32_t, int32_t>> longe;
     auto rebuild = [&]() {
         longe.clear();
         for (int i = 0; i < N; ++i)
@@ -102,7 +103,7 @@ inline void hill_climb(const std::vector<std::vector<int32_t>> &nb, std::vector<
     };
     rebuild();
     const int64_t iters = std::min<int64_t>(100000, 10 * (int64_t)N); // fixed budget: every rank must derive the same order
-    std::vector<int32_t> seg, old;
+    lvba::hvec<int32_t> seg, old;
     int64_t since_rebuild = 0;
     int64_t stale = 0;
     for (int64_t it = 0; it < iters && cur > 1 && stale < 5000; ++it, ++stale) {
@@ -155,10 +156,10 @@ inline void hill_climb(const std::vector<std::vector<int32_t>> &nb, std::vector<
     if (cur < bw_io) { perm = order; bw_io = cur; }
 }
 
-inline void rcm_order(const std::vector<uint8_t> &adj, int N, std::vector<int32_t> &perm)
+inline void rcm_order(const lvba::hvec<uint8_t> &adj, int N, lvba::hvec<int32_t> &perm)
 {
-    std::vector<std::vector<int32_t>> nb(N);
-    std::vector<int32_t> deg(N, 0);
+    lvba::hvec<lvba::hvec<int32_t>> nb(N);
+    lvba::hvec<int32_t> deg(N, 0);
     for (int i = 0; i < N; ++i) { // the matrix is sparse (C3: 13 % non-zero): skip it eight bytes at a time
         const uint8_t *row = adj.data() + (size_t)i * N;
         int j = 0;
@@ -175,7 +176,7 @@ inline void rcm_order(const std::vector<uint8_t> &adj, int N, std::vector<int32_
     }
     for (int i = 0; i < N; ++i)
         std::sort(nb[i].begin(), nb[i].end(), [&](int a, int b) { return deg[a] != deg[b] ? deg[a] < deg[b] : a < b; });
-    std::vector<int32_t> best, cand;
+    lvba::hvec<int32_t> best, cand;
     int32_t best_bw = INT32_MAX;
     for (int variant = 0; variant < 2; ++variant) {
         rcm_from(nb, deg, variant == 0, cand);
@@ -183,9 +184,9 @@ inline void rcm_order(const std::vector<uint8_t> &adj, int N, std::vector<int32_
         if (bw < best_bw) { best_bw = bw; best = cand; }
     }
     // barycenter refinement of the best candidate
-    std::vector<double> x(N), y(N);
+    lvba::hvec<double> x(N), y(N);
     for (int i = 0; i < N; ++i) x[best[i]] = i;
-    std::vector<int32_t> idx(N);
+    lvba::hvec<int32_t> idx(N);
     for (int it = 1; it <= 40; ++it) {
         for (int i = 0; i < N; ++i) {
             if (nb[i].empty()) { y[i] = x[i]; continue; }

@@ -9,9 +9,11 @@
 //
 // key   = tile(J/8, I/8) << 6 | (J%8) << 3 | (I%8)   -- ascending key == (tile, block slot) order of the former host sort
 // value = (pos_x, pos_y) of the two factors in the pose-major Y array, swapped so that x belongs to the larger block index
+#include <algorithm>
 #include <cstring>
 #include <cstdint>
 #include <rocprim/rocprim.hpp>
+#include "host_arena.h"
 #include "lvba_common.h"
 #include "mempool.h"
 #include "pair_lists.h"
@@ -115,6 +117,20 @@ __global__ void adj_kernel(const int64_t *__restrict__ voff, const int64_t *__re
     adj[(size_t)j * N + i] = 1;
 }
 
+// pairs of piece r move from old_off[r] .. to new_off[r] .. (new_off ascending): one thread per pair
+__global__ void pair_permute_kernel(int64_t Q, int64_t n_pieces, const int64_t *__restrict__ new_off, const int64_t *__restrict__ old_off,
+                                    const uint64_t *__restrict__ src, uint64_t *__restrict__ dst)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    int64_t lo = 0, hi = n_pieces; // last piece with new_off <= q
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (new_off[mid] <= q) lo = mid; else hi = mid;
+    }
+    dst[q] = src[old_off[lo] + (q - new_off[lo])];
+}
+
 } // namespace
 
 // Co-visibility (byte adjacency, N x N, caller pose indices) of the local factors: one thread per pair of observers of a
@@ -127,7 +143,7 @@ int32_t adjacency_build(hipStream_t s, int64_t G, const int64_t *h_voff, int64_t
     HIPCHK(d_adj.alloc(nn));
     HIPCHK(hipMemsetAsync(d_adj.p, 0, nn, s));
     if (Q > 0) {
-        std::vector<int64_t> poff((size_t)G + 1, 0);
+        lvba::hvec<int64_t> poff((size_t)G + 1, 0);
         for (int64_t a = 0; a < G; ++a) {
             const int64_t k = h_voff[a + 1] - h_voff[a];
             poff[a + 1] = poff[a] + k * (k - 1) / 2;
@@ -185,13 +201,13 @@ int32_t csc_build(hipStream_t s, int64_t G, const int64_t *h_voff, int64_t F, co
 }
 
 int32_t pair_lists_build(hipStream_t s, int64_t G, const int64_t *h_voff, int64_t F, const int32_t *d_blk_of,
-                         const int32_t *d_pos_of, int32_t N, int32_t Bb1, int64_t Q, int64_t window_groups, int2 *d_pairs,
-                         std::vector<int64_t> &blk_slot, std::vector<int64_t> &blk_off)
+                         const int32_t *d_pos_of, int32_t N, int32_t Bb1, int64_t Q, int64_t window_groups, int64_t cut, int2 *d_pairs,
+                         lvba::hvec<int64_t> &blk_slot, lvba::hvec<int64_t> &blk_off)
 {
     blk_slot.clear();
     blk_off.assign(1, 0);
     if (Q <= 0) return LVBA_OK;
-    std::vector<int64_t> poff((size_t)G + 1, 0);
+    lvba::hvec<int64_t> poff((size_t)G + 1, 0);
     for (int64_t a = 0; a < G; ++a) {
         const int64_t k = h_voff[a + 1] - h_voff[a];
         poff[a + 1] = poff[a] + k * (k - 1) / 2;
@@ -248,19 +264,63 @@ int32_t pair_lists_build(hipStream_t s, int64_t G, const int64_t *h_voff, int64_
     }
     uint64_t n_runs = 0;
     HIPCHK(lvba::copy_d2h(&n_runs, nruns.p, 8));
-    std::vector<uint64_t> h_uniq((size_t)n_runs);
-    std::vector<uint32_t> h_cnt((size_t)n_runs);
+    lvba::hvec<uint64_t> h_uniq((size_t)n_runs);
+    lvba::hvec<uint32_t> h_cnt((size_t)n_runs);
     if (n_runs) {
         HIPCHK(lvba::copy_d2h(h_uniq.data(), uniq.p, (size_t)n_runs * 8));
         HIPCHK(lvba::copy_d2h(h_cnt.data(), cnt.p, (size_t)n_runs * 4));
     }
+    auto slot_of_key = [&](uint64_t k64) {
+        const uint64_t key = k64 & block_mask, tile = key >> 6;
+        const int64_t J = (int64_t)(tile / (uint64_t)tiles_per_row) * 8 + (int64_t)((key >> 3) & 7);
+        const int64_t I = (int64_t)(tile % (uint64_t)tiles_per_row) * 8 + (int64_t)(key & 7);
+        return J * Bb1 + (I - J);
+    };
+    if (window_groups > 0 && cut > 0) {
+        // Work items of the column-per-lane pair kernel: a wavefront walks ten consecutive items in lock-step and runs as long
+        // as the longest of them.  So the runs are cut into pieces of <= cut pairs HERE and the pieces of a window are laid out
+        // by length, longest first (stable: equal lengths stay in (tile, block) order): the ten items of a wavefront then have
+        // about the same length (C3: ~11 pairs on average against ~25 for the longest of ten in (tile, block) order).  The pairs
+        // move with their pieces (one gather of the sorted array).
+        struct Piece { int64_t win, old_off, slot; int32_t len; };
+        lvba::hvec<Piece> pc;
+        pc.reserve((size_t)n_runs + (size_t)(Q / cut) + 1);
+        int64_t o = 0;
+        for (size_t r = 0; r < (size_t)n_runs; ++r) {
+            const int64_t win = (int64_t)(h_uniq[r] >> block_bits), slot = slot_of_key(h_uniq[r]);
+            for (int64_t q = 0; q < (int64_t)h_cnt[r]; q += cut)
+                pc.push_back(Piece{win, o + q, slot, (int32_t)std::min<int64_t>(cut, (int64_t)h_cnt[r] - q)});
+            o += (int64_t)h_cnt[r];
+        }
+        if (o != Q) return LVBA_ERR_STATE;
+        std::stable_sort(pc.begin(), pc.end(), [](const Piece &a, const Piece &b) { return a.win != b.win ? a.win < b.win : a.len > b.len; });
+        const size_t np = pc.size();
+        lvba::hvec<int64_t> new_off(np + 1), old_off(np);
+        blk_slot.resize(np);
+        new_off[0] = 0;
+        for (size_t i = 0; i < np; ++i) {
+            blk_slot[i] = pc[i].slot;
+            old_off[i] = pc[i].old_off;
+            new_off[i + 1] = new_off[i] + pc[i].len;
+        }
+        blk_off = new_off;
+        DevBuf d_new(s), d_old(s);
+        HIPCHK(d_new.alloc((np + 1) * 8));
+        HIPCHK(d_old.alloc(np * 8));
+        HIPCHK(lvba::copy_h2d(d_new.p, new_off.data(), (np + 1) * 8));
+        HIPCHK(lvba::copy_h2d(d_old.p, old_off.data(), np * 8));
+        // v_in (the unsorted values) is free: gather into it, then back into the caller's array
+        pair_permute_kernel<<<(unsigned)((Q + 255) / 256), 256, 0, s>>>(Q, (int64_t)np, (const int64_t *)d_new.p, (const int64_t *)d_old.p,
+                                                                        (const uint64_t *)d_pairs, (uint64_t *)v_in.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(d_pairs, v_in.p, (size_t)Q * 8, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+        return LVBA_OK;
+    }
     blk_slot.resize((size_t)n_runs);
     blk_off.resize((size_t)n_runs + 1);
     for (size_t r = 0; r < (size_t)n_runs; ++r) {
-        const uint64_t key = h_uniq[r] & block_mask, tile = key >> 6;
-        const int64_t J = (int64_t)(tile / (uint64_t)tiles_per_row) * 8 + (int64_t)((key >> 3) & 7);
-        const int64_t I = (int64_t)(tile % (uint64_t)tiles_per_row) * 8 + (int64_t)(key & 7);
-        blk_slot[r] = J * Bb1 + (I - J);
+        blk_slot[r] = slot_of_key(h_uniq[r]);
         blk_off[r + 1] = blk_off[r] + (int64_t)h_cnt[r];
     }
     if (blk_off[n_runs] != Q) return LVBA_ERR_STATE;

@@ -12,6 +12,7 @@
 #include <new>
 #include <vector>
 
+#include "host_arena.h"
 #include "block_system.h"
 
 using namespace lvba;
@@ -21,9 +22,9 @@ struct lvba_visual_s {
     BlockSys bs;
     int32_t M = 0;
     int64_t T = 0, Ta = 0, O = 0;
-    std::vector<int64_t> act;      // active landmark -> caller track index
-    std::vector<int64_t> h_off;    // CSR of the active landmarks (host, kept until finalize)
-    std::vector<int32_t> h_cam;    // caller camera index per kept observation
+    lvba::hvec<int64_t> act;      // active landmark -> caller track index
+    lvba::hvec<int64_t> h_off;    // CSR of the active landmarks (host, kept until finalize)
+    lvba::hvec<int32_t> h_cam;    // caller camera index per kept observation
     bool finalized = false;
     double intr[8] = {}, sig_px = 0.5, sig_pl = 0.01;
     // device
@@ -39,7 +40,7 @@ struct lvba_visual_s {
     double *d_camsum = nullptr, *d_colsum = nullptr; // sharded runs: per-camera sums awaiting the other ranks' tracks
     double *d_out = nullptr;       // export staging
     double *h_pin = nullptr;
-    std::vector<double> hq, ht, hX; // host staging in solver order
+    lvba::hvec<double> hq, ht, hX; // host staging in solver order
 
     VisDev dev() const
     {
@@ -101,7 +102,7 @@ extern "C" int32_t lvba_visual_create(int32_t n_cams, int64_t n_tracks, const in
     h->M = n_cams; h->T = n_tracks; h->sig_px = sigma_px; h->sig_pl = sigma_plane;
     memcpy(h->intr, intr, 8 * sizeof(double));
     // keep only landmarks with a valid plane, together with their observations (src/lvba_system.cpp:1598-1603)
-    std::vector<double> uv, pl;
+    lvba::hvec<double> uv, pl;
     h->h_off.push_back(0);
     for (int64_t i = 0; i < n_tracks; ++i) {
         if (obs_off[i + 1] < obs_off[i]) { delete h; return fail(LVBA_ERR_ARG, "obs_off is not monotone at %lld", (long long)i); }
@@ -133,7 +134,7 @@ extern "C" int32_t lvba_visual_create(int32_t n_cams, int64_t n_tracks, const in
     if (O) CHIP(hipMemcpy(h->d_uv, uv.data(), (size_t)(2 * O) * sizeof(double), hipMemcpyHostToDevice));
     if (Ta) CHIP(hipMemcpy(h->d_plane, pl.data(), (size_t)(4 * Ta) * sizeof(double), hipMemcpyHostToDevice));
     {
-        std::vector<int32_t> too((size_t)O);
+        lvba::hvec<int32_t> too((size_t)O);
         for (int64_t i = 0; i < Ta; ++i)
             for (int64_t o = h->h_off[i]; o < h->h_off[i + 1]; ++o) too[o] = (int32_t)i;
         if (O) CHIP(hipMemcpy(h->d_track_of_obs, too.data(), (size_t)O * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -165,12 +166,12 @@ static int32_t finalize(lvba_visual_s *h)
     bs.spd = true; // S = sum Jc^T Jc + D^2 - sum Y Y^T is the Schur complement of a positive definite matrix
     TRY(bs_build(bs, h->M, h->Ta, h->h_off.data(), h->h_cam.data()));
     {
-        std::vector<int32_t> cam((size_t)h->O);
+        lvba::hvec<int32_t> cam((size_t)h->O);
         for (int64_t o = 0; o < h->O; ++o) cam[o] = bs.iperm[h->h_cam[o]];
         if (h->O) HIPCHK(hipMemcpy(h->d_cam, cam.data(), (size_t)h->O * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     TRY(bs_dmalloc(bs, &h->d_part, (int64_t)h->M * bs.S * 40));
-    std::vector<int32_t>().swap(h->h_cam);
+    lvba::hvec<int32_t>().swap(h->h_cam);
     h->finalized = true;
     return LVBA_OK;
 }
@@ -248,6 +249,13 @@ extern "C" int32_t lvba_visual_dist_init(lvba_visual_t h, int32_t n_ranks, int32
     if (!h || !uid) return fail(LVBA_ERR_ARG, "NULL argument");
     if (h->finalized) return fail(LVBA_ERR_STATE, "dist_init must precede the first cost/linearize/refine call");
     return bs_dist_init(h->bs, n_ranks, rank, uid, nullptr);
+}
+
+extern "C" int32_t lvba_visual_dist_init_external(lvba_visual_t h, int32_t n_ranks, int32_t rank, lvba_allreduce_fn fn, void *ctx)
+{
+    if (!h || !fn) return fail(LVBA_ERR_ARG, "NULL argument");
+    if (h->finalized) return fail(LVBA_ERR_STATE, "dist_init must precede the first cost/linearize/refine call");
+    return bs_dist_init_external(h->bs, n_ranks, rank, fn, ctx, nullptr);
 }
 
 extern "C" int32_t lvba_visual_cost(lvba_visual_t h, const double *q, const double *t, const double *X, double *cost)

@@ -1,6 +1,7 @@
 // voxel_internal.h -- pieces shared by the voxel front-end (voxelize.hip) and the window-BA driver (window_ba.hip):
 // the device-resident scan set, rocPRIM wrappers on the caching pool, small utilities.
 #pragma once
+#include "host_arena.h"
 #include <cstring>
 #include <cstdint>
 #include <rocprim/rocprim.hpp>
@@ -12,7 +13,7 @@
 struct lvba_scans_s {
     int device = 0;
     int n_frames = 0;
-    std::vector<int64_t> frame_off; // [n_frames+1]
+    lvba::hvec<int64_t> frame_off; // [n_frames+1]
     float *d_pts = nullptr;         // [P][3]
     int64_t *d_frame_off = nullptr;
 };

@@ -28,6 +28,7 @@
 #include <vector>
 #include <new>
 #include <chrono>
+#include "host_arena.h"
 #include "lvba_common.h"
 #include "balm_math.h"
 #include "mempool.h"
@@ -577,7 +578,7 @@ struct lvba_voxmap_s {
 
 const double *lvba_voxmap_clusters(const lvba_voxmap_s *h) { return h ? h->d_clusters : nullptr; }
 
-extern "C" int64_t lvba_release_cached_memory(void) { return (int64_t)DevicePool::get().release(); }
+extern "C" int64_t lvba_release_cached_memory(void) { return (int64_t)DevicePool::get().release() + (int64_t)lvba::HostArena::get().release(); }
 
 extern "C" void lvba_voxel_default_opts(lvba_voxel_opts *o)
 {
@@ -922,8 +923,8 @@ extern "C" int32_t lvba_voxmap_export(lvba_voxmap_t h, int64_t *voxel_off, int32
     if (pose_idx && F > 0) HIPCHK(lvba::copy_d2h(pose_idx, h->d_pose_idx, 4 * F));
     if (clusters && F > 0) HIPCHK(lvba::copy_d2h(clusters, h->d_clusters, 80 * F));
     if (voxel_key && V > 0) {
-        std::vector<int32_t> label(2 * V);
-        std::vector<uint64_t> rk(h->info.n_roots);
+        lvba::hvec<int32_t> label(2 * V);
+        lvba::hvec<uint64_t> rk(h->info.n_roots);
         HIPCHK(lvba::copy_d2h(label.data(), h->d_vox_label, 8 * V));
         HIPCHK(lvba::copy_d2h(rk.data(), h->d_root_key, 8 * h->info.n_roots));
         for (int64_t v = 0; v < V; ++v) {
@@ -943,8 +944,8 @@ extern "C" int32_t lvba_voxmap_to_balm(lvba_voxmap_t h, lvba_balm_t *out)
     *out = nullptr;
     const int64_t V = h->info.n_voxels, F = h->info.n_factors;
     if (V == 0) return lvba_fail(LVBA_ERR_ARG, "the map holds no admitted plane voxel (nothing to optimise)");
-    std::vector<int64_t> off(V + 1);
-    std::vector<int32_t> idx(F);
+    lvba::hvec<int64_t> off(V + 1);
+    lvba::hvec<int32_t> idx(F);
     TRY(lvba_voxmap_export(h, off.data(), idx.data(), nullptr, nullptr)); // CSR structure to the host, clusters stay in HBM
     return lvba_balm_create_dev(h->n_frames, V, off.data(), idx.data(), h->d_clusters, h->device, out);
 }

@@ -15,6 +15,7 @@
 #include <functional>
 #include <string>
 #include <thread>
+#include "host_arena.h"
 #include "voxel_internal.h"
 #include "lvba_internal.h"
 #include "block_system.h"
@@ -169,7 +170,7 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
     if (window_poses) memcpy(window_poses, poses, 96 * (size_t)n);
 
     struct AnchorCloud { float *d; int64_t n; };
-    std::vector<AnchorCloud> clouds;
+    lvba::hvec<AnchorCloud> clouds;
     auto free_clouds = [&]() { for (auto &c : clouds) DevicePool::get().free(c.d); clouds.clear(); };
     // One window = map -> problem -> LM -> anchor cloud; windows are independent (src/lvba_system.cpp:232-302 runs them one
     // after the other).  Three stages:
@@ -181,10 +182,10 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
     //      window, or a broken pivot in the joint factorisation: one window at a time, as before;
     //   3. alignment, relative poses, anchor merge + down-sampling per window (host threads again).
     // Results are assembled in window order below.
-    struct WinResult { int32_t rc = LVBA_OK; std::string err; lvba_window_info info{}; std::vector<double> x, rel; float *d_out = nullptr; int64_t n_out = 0;
+    struct WinResult { int32_t rc = LVBA_OK; std::string err; lvba_window_info info{}; lvba::hvec<double> x, rel; float *d_out = nullptr; int64_t n_out = 0;
                        lvba_voxmap_t map = nullptr; bool refined = false; };
     const int n_win = (n + w - 1) / w;
-    std::vector<WinResult> results((size_t)n_win);
+    lvba::hvec<WinResult> results((size_t)n_win);
     auto win_range = [&](int wi, int &start, int &cw) { start = wi * w; cw = std::min(w, n - start); };
     // ---- stage 1: the voxel map at the odometry poses (:247-257) and the skip rule (:258-262)
     auto stage_map = [&](int wi, hipStream_t ws, WinResult &R) -> int32_t {
@@ -220,7 +221,7 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
         lvba_voxmap_destroy(R.map);
         R.map = nullptr;
         if (rc != LVBA_OK) return rc;
-        std::vector<lvba_lm_trace> trace((size_t)std::max(1, o.lm.max_iter));
+        lvba::hvec<lvba_lm_trace> trace((size_t)std::max(1, o.lm.max_iter));
         int32_t nt = 0;
         lvba_balm_info_t bi;
         lvba_balm_info(b, &bi); // forces the one-off problem set-up (ordering, pair lists) so that it is timed apart
@@ -241,14 +242,14 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
     // ---- stage 2, all windows at once.  Returns LVBA_OK with `done` = false when the windows have to go one by one.
     auto stage_lm_batched = [&](bool &done) -> int32_t {
         done = false;
-        std::vector<int> live;
+        lvba::hvec<int> live;
         for (int wi = 0; wi < n_win; ++wi)
             if (results[(size_t)wi].map) live.push_back(wi);
         if (live.size() < 2) return LVBA_OK;
         const double t0 = now_ms();
         const int G = (int)live.size();
-        std::vector<int32_t> pose_off((size_t)G + 1, 0);
-        std::vector<int64_t> vox_off((size_t)G + 1, 0), fac_off((size_t)G + 1, 0);
+        lvba::hvec<int32_t> pose_off((size_t)G + 1, 0);
+        lvba::hvec<int64_t> vox_off((size_t)G + 1, 0), fac_off((size_t)G + 1, 0);
         for (int k = 0; k < G; ++k) {
             const WinResult &R = results[(size_t)live[(size_t)k]];
             pose_off[(size_t)k + 1] = pose_off[(size_t)k] + R.info.n_frames;
@@ -257,15 +258,15 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
         }
         const int64_t V = vox_off[(size_t)G], F = fac_off[(size_t)G];
         if (F >= ((int64_t)1 << 31)) return LVBA_OK; // too large for one handle: one by one
-        std::vector<int64_t> off((size_t)V + 1, 0);
-        std::vector<int32_t> idx((size_t)F);
-        std::vector<double> x(12 * (size_t)pose_off[(size_t)G]);
+        lvba::hvec<int64_t> off((size_t)V + 1, 0);
+        lvba::hvec<int32_t> idx((size_t)F);
+        lvba::hvec<double> x(12 * (size_t)pose_off[(size_t)G]);
         DevBuf d_clu(s);
         HIPCHK(d_clu.alloc(80 * (size_t)F));
         for (int k = 0; k < G; ++k) {
             const WinResult &R = results[(size_t)live[(size_t)k]];
             const int64_t v0 = vox_off[(size_t)k], f0 = fac_off[(size_t)k], nv = R.info.n_voxels, nf = R.info.n_factors;
-            std::vector<int64_t> o1((size_t)nv + 1);
+            lvba::hvec<int64_t> o1((size_t)nv + 1);
             TRY(lvba_voxmap_export(R.map, o1.data(), idx.data() + f0, nullptr, nullptr)); // CSR structure to the host, clusters stay in HBM
             for (int64_t a = 0; a <= nv; ++a) off[(size_t)(v0 + a)] = f0 + (o1[(size_t)a] - o1[0]);
             for (int64_t f = f0; f < f0 + nf; ++f) idx[(size_t)f] += pose_off[(size_t)k];
@@ -287,8 +288,8 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
         TRY(lvba_balm_info(b, &bi)); // the one-off set-up, timed apart
         mk("set-up");
         const double t1 = now_ms();
-        std::vector<int32_t> n_iter((size_t)G), status((size_t)G);
-        std::vector<double> first((size_t)G), last((size_t)G);
+        lvba::hvec<int32_t> n_iter((size_t)G), status((size_t)G);
+        lvba::hvec<double> first((size_t)G), last((size_t)G);
         const int32_t rc = lvba_balm_refine_groups(b, x.data(), &o.lm, n_iter.data(), status.data(), first.data(), last.data());
         if (rc == LVBA_NUM_FACTORIZATION) return LVBA_OK; // the windows are not independent in a broken factorisation: one by one
         if (rc < 0) return rc;
@@ -318,9 +319,9 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
         lvba_window_info &info = R.info;
         if (info.skipped) return LVBA_OK;
         const double *x_odom = poses + 12 * (int64_t)start;
-        std::vector<double> &x = R.x;
+        lvba::hvec<double> &x = R.x;
         double tw = now_ms();
-        std::vector<double> &rel = R.rel;
+        lvba::hvec<double> &rel = R.rel;
         rel.assign(12 * (size_t)cw, 0.0);
         const double *Ro0 = x_odom, *po0 = x_odom + 9;
         double R_align[9], p_align[3] = {0, 0, 0};
@@ -399,8 +400,8 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
     int n_thr = 4;
     if (const char *e = getenv("LVBA_WINDOW_THREADS")) n_thr = atoi(e);
     n_thr = std::max(1, std::min(n_thr, n_win));
-    std::vector<hipStream_t> wstreams;
-    struct StreamsGuard { std::vector<hipStream_t> &v; ~StreamsGuard() { for (hipStream_t q : v) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); } } } wguard{wstreams};
+    lvba::hvec<hipStream_t> wstreams;
+    struct StreamsGuard { lvba::hvec<hipStream_t> &v; ~StreamsGuard() { for (hipStream_t q : v) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); } } } wguard{wstreams};
     if (n_thr > 1) {
         wstreams.assign((size_t)n_thr, nullptr);
         for (auto &q : wstreams)
@@ -408,7 +409,7 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
     }
     auto run_stage = [&](const std::function<int32_t(int, hipStream_t, WinResult &)> &stage) {
         std::atomic<int> next{0};
-        std::vector<char> visited((size_t)n_win, 0);
+        lvba::hvec<char> visited((size_t)n_win, 0);
         auto worker = [&](hipStream_t ws) {
             for (int wi = next.fetch_add(1); wi < n_win; wi = next.fetch_add(1)) {
                 WinResult &R = results[(size_t)wi];
@@ -423,7 +424,7 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
             return;
         }
         struct Inhibit { Inhibit() { bs_graph_inhibit(+1); } ~Inhibit() { bs_graph_inhibit(-1); } } inhibit;
-        std::vector<std::thread> pool;
+        lvba::hvec<std::thread> pool;
         for (int t = 0; t < n_thr; ++t)
             pool.emplace_back([&, t]() {
                 if (!wstreams[(size_t)t] || hipSetDevice(sc->device) != hipSuccess) return;
@@ -539,15 +540,15 @@ extern "C" int32_t lvba_lidar_ba(lvba_scans_t sc, const double *poses_in, const 
     const int n = sc->n_frames;
     lvba_lidar_ba_report r{};
     r.n_frames = n;
-    std::vector<double> rel(12 * (size_t)n), anchor_poses;
-    std::vector<int32_t> aidx((size_t)n);
+    lvba::hvec<double> rel(12 * (size_t)n), anchor_poses;
+    lvba::hvec<int32_t> aidx((size_t)n);
     lvba_scans_t anchors = nullptr;
     int32_t na = 0;
     double t0 = now_ms();
     if (o.window_enable) {
         const int nw = (n + o.window.window_size - 1) / std::max(1, o.window.window_size);
         anchor_poses.resize(12 * (size_t)std::max(nw, 1));
-        std::vector<lvba_window_info> wi((size_t)std::max(nw, 1));
+        lvba::hvec<lvba_window_info> wi((size_t)std::max(nw, 1));
         TRY(lvba_window_ba(sc, poses_in, &o.window, nullptr, rel.data(), aidx.data(), anchor_poses.data(), &na, &anchors, wi.data()));
         r.n_windows = nw;
         for (int k = 0; k < nw; ++k) r.n_windows_skipped += wi[k].skipped;
@@ -585,7 +586,7 @@ extern "C" int32_t lvba_lidar_ba(lvba_scans_t sc, const double *poses_in, const 
             int32_t rc = lvba_voxmap_to_balm(map, &b);
             lvba_voxmap_destroy(map);
             if (rc != LVBA_OK) return rc;
-            std::vector<lvba_lm_trace> trace((size_t)std::max(1, o.lm.max_iter));
+            lvba::hvec<lvba_lm_trace> trace((size_t)std::max(1, o.lm.max_iter));
             int32_t nt = 0;
             rc = lvba_balm_refine(b, anchor_poses.data(), &o.lm, trace.data(), &nt);
             lvba_balm_destroy(b);

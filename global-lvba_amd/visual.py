@@ -69,6 +69,10 @@ class VisualProblem:
         """Track shards over several ranks (lvba_visual_dist_init): this handle holds the rank's own tracks."""
         L.check(self.lib.lvba_visual_dist_init(self._h, int(n_ranks), int(rank), bytes(uid)))
 
+    def dist_init_external(self, n_ranks, rank, fn, ctx):
+        """The caller's all-reduce instead of RCCL (lvba_visual_dist_init_external)."""
+        L.check(self.lib.lvba_visual_dist_init_external(self._h, int(n_ranks), int(rank), C.c_void_p(fn), C.c_void_p(ctx)))
+
     def linearize_only(self, q, t, X, radius=1e4):
         """The factor kernels of one linearisation (residuals, Jacobians, column norms, Schur products -> reduced system on
         the device) without exporting S / rhs; returns the cost."""

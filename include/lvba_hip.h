@@ -35,6 +35,7 @@
 #ifndef LVBA_HIP_H
 #define LVBA_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -91,6 +92,10 @@ typedef struct {
     int64_t allreduce_bytes; /* bytes all-reduced per evaluation (0 without a communicator): the union-pattern blocks + g + cost */
     int32_t twist_panels;    /* band solver: 64-column panels each END eliminates (0: plain top-down factorisation) */
     int32_t solve_ranks;     /* ranks the factorisation is spread over: 2 when ranks 0 and 1 take one end each, else 1 */
+    int32_t eval_mode;       /* 1: fused voxel-major evaluation (balm_fused_kernel + assembly); 0: three passes (a voxel is seen
+                              * from more poses than a chunk has pose slots, or LVBA_FUSED=0) */
+    int32_t trial_linearised; /* 1: the LM loop costs its trial point with the first half of the evaluation, and an accepted
+                               * step's next evaluation only assembles H and g from it */
 } lvba_balm_info_t;
 
 /* Accumulated device times (HIP events on the handle's stream) since the last reset, ms. */
@@ -138,6 +143,13 @@ int32_t lvba_balm_cost(lvba_balm_t h, const double *poses, int32_t is_avg, doubl
  * H and g may be NULL (kept on the device for lvba_balm_solve). */
 int32_t lvba_balm_eval(lvba_balm_t h, const double *poses, double *H, double *g, double *cost_avg);
 
+/* The same evaluation with H in SPARSE form, for problems whose dense matrix does not fit (10 000 poses: 28.8 GB): the non-zero
+ * 6x6 pose blocks of the lower triangle in the CALLER's pose order -- bi[k] >= bj[k], every unordered pose pair once, the
+ * diagonal blocks in full --, blocks[k][6 r + c] = H[6 bi[k] + r][6 bj[k] + c].  *n_blocks receives the number of blocks; call
+ * with capacity 0 (arrays may be NULL) to size the arrays.  g [6 n_poses] and cost_avg may be NULL. */
+int32_t lvba_balm_eval_blocks(lvba_balm_t h, const double *poses, int64_t capacity, int32_t *bi, int32_t *bj, double *blocks,
+                              int64_t *n_blocks, double *g, double *cost_avg);
+
 /* Solve (H + u*diag(H)) dx = -g with the H, g of the last lvba_balm_eval (bavoxel.hpp:692-710). */
 int32_t lvba_balm_solve(lvba_balm_t h, double u, double *dx);
 
@@ -177,11 +189,20 @@ int32_t lvba_balm_get_ordering(lvba_balm_t h, int32_t *perm);
  * uid is an ncclUniqueId (128 bytes) created on rank 0 and distributed by the caller. */
 int32_t lvba_dist_unique_id(char uid[128]);
 int32_t lvba_balm_dist_init(lvba_balm_t h, int32_t n_ranks, int32_t rank, const char uid[128]);
-/* A second transport behind the same entry points, for testing the multi-rank code on a box with ONE GPU (RCCL refuses two
- * ranks on one device): an id made by lvba_dist_host_unique_id selects ranks that are HOST THREADS of one process, each with
- * its own handle on the same device; every all-reduce is staged through the host and summed in rank order.  It moves data
- * only -- all arithmetic on problem data stays in the kernels -- and is not meant for production runs. */
-int32_t lvba_dist_host_unique_id(char uid[128]);
+/* The same with the CALLER'S transport instead of RCCL (an MPI job that already owns a communicator; a test harness that runs
+ * several ranks as host threads on one device, where RCCL refuses a duplicate GPU -- tests/host_transport.cpp).  `fn` must
+ * all-reduce `count` elements of type `dtype` of the DEVICE buffer `device_buf` in place over the n_ranks ranks with `op`,
+ * ordered after the work already enqueued on `hip_stream` (a hipStream_t) and visible to work enqueued on it afterwards;
+ * every rank must obtain bitwise the same result (sum in a fixed rank order), as RCCL guarantees for its own.  It returns 0
+ * on success.  The library calls it from the thread that calls the library, never concurrently for one handle. */
+#define LVBA_DT_F64 0
+#define LVBA_DT_I64 1
+#define LVBA_DT_I32 2
+#define LVBA_DT_U8 3
+#define LVBA_OP_SUM 0
+#define LVBA_OP_MAX 1
+typedef int32_t (*lvba_allreduce_fn)(void *ctx, void *device_buf, size_t count, int32_t dtype, int32_t op, void *hip_stream);
+int32_t lvba_balm_dist_init_external(lvba_balm_t h, int32_t n_ranks, int32_t rank, lvba_allreduce_fn fn, void *ctx);
 
 /* ===================================================================================================
  * Visual stage: replaces the ceres::Problem ... ceres::Solve region of LvbaSystem::optimizeCameraPoses
@@ -256,6 +277,7 @@ int32_t lvba_visual_info(lvba_visual_t h, lvba_balm_info_t *info);
  * whole diag(Jc^T Jc), Jc^T r) and five scalars; the reduced system is solved on every rank.  All ranks return bitwise the same
  * cameras and trace; X holds the rank's own landmarks.  uid as for lvba_balm_dist_init. */
 int32_t lvba_visual_dist_init(lvba_visual_t h, int32_t n_ranks, int32_t rank, const char uid[128]);
+int32_t lvba_visual_dist_init_external(lvba_visual_t h, int32_t n_ranks, int32_t rank, lvba_allreduce_fn fn, void *ctx);
 
 /* 1/2 sum r^2 over the residuals of the active landmarks at (q [M][4], t [M][3], X [n_tracks][3]). */
 int32_t lvba_visual_cost(lvba_visual_t h, const double *q, const double *t, const double *X, double *cost);

@@ -198,6 +198,33 @@ def block_parity(H, bi, bj, blocks):
     return worst, abs(total - listed) / total
 
 
+def block_parity_sparse(gi, gj, gblocks, bi, bj, blocks, n_poses):
+    """The same check for a path under test that hands out its Hessian as a block list (gi >= gj, gblocks[k, r, c] =
+    H[6 gi + r, 6 gj + c], each unordered pair once -- lvba_balm_eval_blocks) against COracle.eval_sparse's (bi <= bj).
+    Returns (worst per-block relative error over the oracle's blocks, relative weight of the blocks the path under test has
+    and the oracle has not)."""
+    N = int(n_poses)
+    gkey = gi.astype(np.int64) * N + gj.astype(np.int64)                  # lower: (larger, smaller)
+    okey = bj.astype(np.int64) * N + bi.astype(np.int64)                  # upper (bi <= bj) -> the same key
+    go, oo = np.argsort(gkey, kind="stable"), np.argsort(okey, kind="stable")
+    gk, ok = gkey[go], okey[oo]
+    pos = np.searchsorted(gk, ok)
+    found = (pos < len(gk)) & (gk[np.minimum(pos, len(gk) - 1)] == ok)
+    want = np.transpose(blocks[oo], (0, 2, 1))                            # H[6 bj + r, 6 bi + c]: the lower-oriented block
+    got = np.zeros_like(want)
+    got[found] = gblocks[go][pos[found]]
+    scale = np.abs(want).reshape(len(ok), -1).max(1)
+    err = np.abs(got - want).reshape(len(ok), -1).max(1)
+    floor = 1e-6 * np.abs(blocks).max()
+    worst = float((err / np.maximum(scale, floor)).max())
+    w = np.where(gi == gj, 1.0, 2.0)
+    tot = w * (gblocks.reshape(len(gi), -1) ** 2).sum(1)
+    matched = np.zeros(len(gk), bool)
+    matched[pos[found]] = True
+    extra = float(tot[go][~matched].sum())
+    return worst, extra / float(tot.sum())
+
+
 def ldlt_solve_dense(A, b, nthreads=8):
     """Unpivoted LDL^T solve; A symmetric (its C-order memory read col-major is A^T = A)."""
     lib = load_c()

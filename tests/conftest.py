@@ -51,3 +51,74 @@ def make_problem(n_poses, n_voxels, **kw):
 def rel(a, b):
     a, b = np.asarray(a), np.asarray(b)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+class HostTransport:
+    """tests/host_transport.cpp: ranks = host threads of this process on one GPU, all-reduces staged through the host and
+    reduced in rank order.  TEST INFRASTRUCTURE (the product only sees an lvba_allreduce_fn callback).  Built by
+    __graft_entry__.build() into tests/_build/libhost_transport.so."""
+    _lib = None
+
+    @classmethod
+    def lib(cls):
+        import ctypes as C
+        if cls._lib is None:
+            path = os.path.join(ROOT, "tests", "_build", "libhost_transport.so")
+            if not os.path.exists(path):
+                import __graft_entry__ as g
+                g.build_test_transport()
+            lib = C.CDLL(path)
+            lib.ht_create.restype = C.c_void_p
+            lib.ht_create.argtypes = [C.c_int]
+            lib.ht_rank.restype = C.c_void_p
+            lib.ht_rank.argtypes = [C.c_void_p, C.c_int]
+            lib.ht_rank_free.argtypes = [C.c_void_p]
+            lib.ht_destroy.argtypes = [C.c_void_p]
+            lib.ht_poison.argtypes = [C.c_void_p]
+            lib.ht_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+            cls._lib = lib
+        return cls._lib
+
+    def __init__(self, world):
+        import ctypes as C
+        self.world = world
+        self.comm = self.lib().ht_create(world)
+        self.fn = C.cast(self.lib().ht_allreduce, C.c_void_p).value
+        self.ctx = [self.lib().ht_rank(self.comm, r) for r in range(world)]
+
+    def attach(self, prob, rank):
+        prob.dist_init_external(self.world, rank, self.fn, self.ctx[rank])
+
+    def poison(self):
+        self.lib().ht_poison(self.comm)
+
+    def stats(self):
+        import ctypes as C
+        c, b = C.c_uint64(), C.c_uint64()
+        self.lib().ht_stats(self.comm, C.byref(c), C.byref(b))
+        return int(c.value), int(b.value)
+
+    def run(self, rank_main, timeout=600):
+        """rank_main(r) in one thread per rank; a rank that raises poisons the communicator so the others return instead of
+        hanging in a barrier.  Returns the list of results; re-raises the first error."""
+        import threading
+        out, err = [None] * self.world, [None] * self.world
+
+        def wrap(r):
+            try:
+                out[r] = rank_main(r)
+            except BaseException as e:
+                err[r] = e
+                self.poison()
+
+        th = [threading.Thread(target=wrap, args=(r,), daemon=True) for r in range(self.world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=timeout)
+        first = next((e for e in err if e is not None and "external all-reduce failed" not in str(e)), None) or \
+            next((e for e in err if e is not None), None)
+        if first is not None:
+            raise first
+        assert all(o is not None for o in out), "a rank did not finish (collective mismatch?)"
+        return out

@@ -11,7 +11,7 @@ int main(int argc, char **argv)
     const int N = argc > 1 ? atoi(argv[1]) : 2000, W = argc > 2 ? atoi(argv[2]) : 50, loop = argc > 3 ? atoi(argv[3]) : 50;
     // co-visibility of a closed trajectory: every voxel is seen by ~5 poses within +-W of a home pose (ring distance), and a
     // share of the voxels additionally by poses around the antipodal point (loop closures) -- the structure of bench config C3
-    std::vector<uint8_t> adj((size_t)N * N, 0);
+    lvba::hvec<uint8_t> adj((size_t)N * N, 0);
     uint64_t rng = 12345;
     auto next = [&]() { rng = rng * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(rng >> 33); };
     const int V = 200 * N;
@@ -27,24 +27,24 @@ int main(int argc, char **argv)
             for (int j = 0; j < i; ++j)
                 if (obs[i] != obs[j]) { adj[(size_t)obs[i] * N + obs[j]] = 1; adj[(size_t)obs[j] * N + obs[i]] = 1; }
     }
-    std::vector<std::vector<int32_t>> nb(N);
+    lvba::hvec<lvba::hvec<int32_t>> nb(N);
     for (int i = 0; i < N; ++i)
         for (int j = 0; j < N; ++j)
             if (adj[(size_t)i * N + j] && i != j) nb[i].push_back(j);
-    std::vector<int32_t> nat(N);
+    lvba::hvec<int32_t> nat(N);
     std::iota(nat.begin(), nat.end(), 0);
     const int32_t bw_nat = lvba::bandwidth_of(nb, nat);
-    std::vector<int32_t> p1, p2;
+    lvba::hvec<int32_t> p1, p2;
     const auto t0 = std::chrono::steady_clock::now();
     lvba::rcm_order(adj, N, p1);
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     lvba::rcm_order(adj, N, p2);
-    std::vector<char> seen(N, 0);
+    lvba::hvec<char> seen(N, 0);
     for (int v : p1) { if (v < 0 || v >= N || seen[v]) { std::printf("not a permutation\n"); return 1; } seen[v] = 1; }
     if (p1 != p2) { std::printf("not deterministic\n"); return 2; }
     const int32_t bw = lvba::bandwidth_of(nb, p1);
     // plain RCM for comparison
-    std::vector<int32_t> deg(N), rcm;
+    lvba::hvec<int32_t> deg(N), rcm;
     for (int i = 0; i < N; ++i) deg[i] = (int32_t)nb[i].size();
     lvba::rcm_from(nb, deg, true, rcm);
     const int32_t bw_rcm = lvba::bandwidth_of(nb, rcm);

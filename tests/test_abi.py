@@ -29,7 +29,7 @@ def test_header_symbols_are_exported(lib, pkg):
 def test_struct_layouts_match_header(pkg):
     L = pkg._lib
     assert ctypes.sizeof(L.BalmOpts) == 32 and ctypes.sizeof(L.LmTrace) == 64
-    assert ctypes.sizeof(L.BalmInfo) == 96 and ctypes.sizeof(L.Prof) == 80
+    assert ctypes.sizeof(L.BalmInfo) == 104 and ctypes.sizeof(L.Prof) == 80
     o = pkg.BalmProblem.default_opts()
     assert (o.max_iter, o.u0, o.v0, o.rel_tol) == (10, 0.01, 2.0, 1e-6)      # bavoxel.hpp:664,686,760
 

@@ -91,3 +91,45 @@ def test_c3_shard_cost_and_lm_trace(pkg, synth, oracle_mod):
     assert prob.info()["use_band"] == 1                       # the band path of the solver is what ran
     _compare_traces(trace, tr, xg, xr)
     prob.close()
+
+
+def test_c4_cost_and_one_lm_iteration(pkg, synth, oracle_mod):
+    """C4 (10 000 poses x 10 M voxels x 50 M factors -- the configuration BASELINE.json assigns to 8 GPUs) on ONE GPU: cost at
+    two points and the gradient of the full problem, every pose block of one 400k-voxel shard (slice 12 of 25 by the formula of
+    bavoxel.hpp:621-624), every pose block of the FULL problem through the sparse export (the dense Hessian would be 28.8 GB),
+    and the first LM iteration -- evaluation, damped band solve (n = 60 000), retraction, cost at the trial point -- against
+    the oracle's band twin."""
+    N, V, d = _gen(synth, "C4")
+    off, idx, clu = d["voxel_off"], d["pose_idx"], d["clusters"]
+    x = d["poses_init"]
+    a, b = pkg.shard_range(V, 12, 25)
+    assert b - a == 400_000
+    sh = pkg.BalmProblem(N, off[a:b + 1], idx[off[a]:off[b]], clu[off[a]:off[b]])
+    cs = oracle_mod.COracle(N, off[a:b + 1] - off[a], idx[off[a]:off[b]], clu[off[a]:off[b]])
+    gi, gj, gblocks, g, c = sh.eval_blocks(x)
+    bi, bj, blocks, gc, cc = cs.eval_sparse(x, nthreads=_threads())
+    assert abs(c - cc) <= 1e-8 * cc
+    assert np.abs(g - gc).max() <= 1e-8 * np.abs(gc).max()
+    worst, extra = oracle_mod.block_parity_sparse(gi, gj, gblocks, bi, bj, blocks, N)
+    assert worst <= 1e-8 and extra <= 1e-12, (worst, extra)
+    del gblocks, blocks
+    sh.close()
+    prob = pkg.BalmProblem(N, off, idx, clu)
+    co = oracle_mod.COracle(N, off, idx, clu)
+    c_ref = co.cost(d["poses_gt"], nthreads=_threads())
+    assert abs(prob.cost(d["poses_gt"]) - c_ref) <= 1e-8 * c_ref
+    gi, gj, gblocks, g, c = prob.eval_blocks(x)
+    bi, bj, blocks, gc, cc = co.eval_sparse(x, nthreads=_threads())
+    assert abs(c - cc) <= 1e-8 * cc and abs(prob.cost(x) - cc) <= 1e-8 * cc
+    assert np.abs(g - gc).max() <= 1e-8 * np.abs(gc).max()
+    worst, extra = oracle_mod.block_parity_sparse(gi, gj, gblocks, bi, bj, blocks, N)
+    assert worst <= 1e-8 and extra <= 1e-12, (worst, extra)
+    assert len(gi) == len(bi)
+    del gblocks, blocks
+    info = prob.info()
+    assert info["use_band"] == 1 and info["n_factors"] == int(off[-1])
+    xg, trace, rc = prob.refine(x, max_iter=1)
+    xr, tr, rcr, sec = co.damping_iter_band(x, perm=prob.ordering(), max_iter=1, eval_threads=_threads(), solve_threads=min(32, os.cpu_count() or 1))
+    assert rc == 0 and rcr == 0 and len(trace) == 1 and len(tr) == 1
+    _compare_traces(trace, tr, xg, xr)
+    prob.close()

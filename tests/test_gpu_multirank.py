@@ -1,19 +1,18 @@
 """The product's MULTI-RANK code with N = 2 and 3 ranks on a one-GPU box.
 
 RCCL refuses two ranks on one device, so the ranks are host threads of this process, each with its own handle (its own
-voxel shard, its own stream) on the same GPU, joined by the library's host-staged test transport
-(lvba_dist_host_unique_id: every all-reduce goes device -> host -> sum in rank order -> device).  Everything above the
+voxel shard, its own stream) on the same GPU, joined through the library's external-transport entry point
+(lvba_balm_dist_init_external) by a host-staged all-reduce that lives with the tests (tests/host_transport.cpp: device ->
+host -> sum in rank order -> device).  Everything above the
 transport is the code a real multi-GPU job runs (csrc/block_system.hip): the global voxel count, the max-reduced band
 width, the all-reduced co-visibility matrix and the common pose order computed from it, the packed [H | g | cost]
 all-reduce over the union sparsity pattern, the all-reduced cost scalar of the trial poses, the replicated damped solve.
 Required: every rank ends with bitwise the same answer, and that answer equals the single-rank one to rounding
 (partial sums are grouped differently) and the C oracle to 1e-8.  bavoxel.hpp:614-633 with thread -> rank."""
-import threading
-
 import numpy as np
 import pytest
 
-from conftest import make_problem, rel
+from conftest import HostTransport, make_problem, rel
 
 pytestmark = pytest.mark.gpu
 
@@ -27,32 +26,21 @@ def synth():
 def _run_ranks(pkg, d, world, packed=True):
     N, off, idx, clu = d["n_poses"], d["voxel_off"], d["pose_idx"], d["clusters"]
     V = len(off) - 1
-    uid = pkg.BalmProblem.host_unique_id()
-    out, err = [None] * world, [None] * world
+    ht = HostTransport(world)
 
     def rank_main(r):
-        try:
-            a, b = pkg.shard_range(V, r, world)
-            prob = pkg.BalmProblem(N, off[a:b + 1], idx[off[a]:off[b]], clu[off[a]:off[b]])
-            prob.dist_init(world, r, uid)
-            info = prob.info()
-            H, g, c = prob.eval(d["poses_init"])
-            c_gt = prob.cost(d["poses_gt"])
-            x, trace, rc = prob.refine(d["poses_init"])
-            out[r] = dict(info=info, H=H, g=g, c=c, c_gt=c_gt, x=x, trace=trace, rc=rc, perm=prob.ordering())
-            prob.close()
-        except Exception as e:   # a rank that dies would leave the others in the barrier: report, do not hang silently
-            err[r] = e
-            raise
+        a, b = pkg.shard_range(V, r, world)
+        prob = pkg.BalmProblem(N, off[a:b + 1], idx[off[a]:off[b]], clu[off[a]:off[b]])
+        ht.attach(prob, r)
+        info = prob.info()
+        H, g, c = prob.eval(d["poses_init"])
+        c_gt = prob.cost(d["poses_gt"])
+        x, trace, rc = prob.refine(d["poses_init"])
+        res = dict(info=info, H=H, g=g, c=c, c_gt=c_gt, x=x, trace=trace, rc=rc, perm=prob.ordering())
+        prob.close()
+        return res
 
-    th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join(timeout=300)
-    assert all(e is None for e in err), err
-    assert all(o is not None for o in out), "a rank did not finish (collective mismatch?)"
-    return out
+    return ht.run(rank_main)
 
 
 @pytest.mark.parametrize("world,case", [(2, dict(n_poses=200, n_voxels=6000, band=10, seed=7)),     # packed all-reduce, band solver
@@ -130,30 +118,20 @@ def test_visual_track_shards_agree_with_single_rank(pkg, synth, world, n_cams, n
     S1, rhs1, _ = one.linearize(d["q"], d["t"], d["X"], radius=3.0)
     (q1, t1, X1), tr1, term1, rc1 = one.refine(d["q"], d["t"], d["X"])
     one.close()
-    uid = pkg.BalmProblem.host_unique_id()
-    out, err = [None] * world, [None] * world
+    ht = HostTransport(world)
 
     def rank_main(r):
-        try:
-            a, b = pkg.shard_range(n_tracks, r, world)
-            vp = pkg.VisualProblem(n_cams, off[a:b + 1], cam[off[a]:off[b]], uv[off[a]:off[b]], d["plane"][a:b], d["valid"][a:b], d["intr"])
-            vp.dist_init(world, r, uid)
-            c = vp.cost(d["q"], d["t"], d["X"][a:b])
-            S, rhs, _ = vp.linearize(d["q"], d["t"], d["X"][a:b], radius=3.0)
-            (q, t, X), tr, term, rc = vp.refine(d["q"], d["t"], d["X"][a:b])
-            out[r] = dict(c=c, S=S, rhs=rhs, q=q, t=t, X=X, tr=tr, term=term, rc=rc, a=a, b=b)
-            vp.close()
-        except Exception as e:
-            err[r] = e
-            raise
+        a, b = pkg.shard_range(n_tracks, r, world)
+        vp = pkg.VisualProblem(n_cams, off[a:b + 1], cam[off[a]:off[b]], uv[off[a]:off[b]], d["plane"][a:b], d["valid"][a:b], d["intr"])
+        ht.attach(vp, r)
+        c = vp.cost(d["q"], d["t"], d["X"][a:b])
+        S, rhs, _ = vp.linearize(d["q"], d["t"], d["X"][a:b], radius=3.0)
+        (q, t, X), tr, term, rc = vp.refine(d["q"], d["t"], d["X"][a:b])
+        res = dict(c=c, S=S, rhs=rhs, q=q, t=t, X=X, tr=tr, term=term, rc=rc, a=a, b=b)
+        vp.close()
+        return res
 
-    th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
-    for t_ in th:
-        t_.start()
-    for t_ in th:
-        t_.join(timeout=300)
-    assert all(e is None for e in err), err
-    assert all(o is not None for o in out), "a rank did not finish (collective mismatch?)"
+    out = ht.run(rank_main)
     r0 = out[0]
     for o in out[1:]:
         assert o["c"] == r0["c"] and np.array_equal(o["S"], r0["S"]) and np.array_equal(o["rhs"], r0["rhs"])

@@ -278,3 +278,30 @@ def test_block_parity_checker(oracle_mod):
     Hbad = np.ascontiguousarray(H).copy()
     Hbad[0, 6 * 39 + 3] = Hbad[6 * 39 + 3, 0] = 1e-3 * np.abs(H).max()     # an entry outside the pattern is seen
     assert oracle_mod.block_parity(Hbad, bi, bj, blocks)[1] > 1e-12
+
+
+def test_block_parity_checker_sparse(oracle_mod):
+    """The block-list form of the checker (what bench.py and the C4 parity test use: the dense Hessian is 28.8 GB there)."""
+    d = make_problem(40, 3000, band=10, seed=2)
+    N = d["n_poses"]
+    co = oracle_mod.COracle(N, d["voxel_off"], d["pose_idx"], d["clusters"])
+    H, g, c = co.eval_dense(d["poses_init"])
+    bi, bj, blocks, g2, c2 = co.eval_sparse(d["poses_init"])
+    # a path under test that hands out lower blocks (gi >= gj) in another order
+    Hv = np.ascontiguousarray(H).reshape(N, 6, N, 6)
+    rng = np.random.default_rng(0)
+    order = rng.permutation(len(bi))
+    gi, gj = bj[order].copy(), bi[order].copy()
+    gblocks = np.ascontiguousarray(Hv[gi, :, gj, :])
+    worst, extra = oracle_mod.block_parity_sparse(gi, gj, gblocks, bi, bj, blocks, N)
+    assert worst <= 1e-12 and extra == 0.0
+    bad = gblocks.copy()
+    bad[7, 1, 2] *= 1.0 + 1e-6
+    assert oracle_mod.block_parity_sparse(gi, gj, bad, bi, bj, blocks, N)[0] > 1e-8
+    # a block the oracle does not have is seen, a block the path lacks is an error of 100 %
+    k = int(np.argmax(gi != gj))
+    assert oracle_mod.block_parity_sparse(np.delete(gi, k), np.delete(gj, k), np.delete(gblocks, k, 0), bi, bj, blocks, N)[0] >= 0.99
+    gi2, gj2 = np.append(gi, N - 1).astype(np.int32), np.append(gj, 0).astype(np.int32)
+    if not ((gi == N - 1) & (gj == 0)).any():
+        extra_blk = np.full((1, 6, 6), 1e-3 * np.abs(H).max())
+        assert oracle_mod.block_parity_sparse(gi2, gj2, np.concatenate([gblocks, extra_blk]), bi, bj, blocks, N)[1] > 1e-12
