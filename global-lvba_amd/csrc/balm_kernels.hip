@@ -313,242 +313,6 @@ __global__ __launch_bounds__(256) void balm_factor_kernel(BalmDev d, const doubl
     if (tid < 27) d.part[(int64_t)blockIdx.x * 32 + tid] = red[tid] + red[27 + tid] + red[54 + tid] + red[81 + tid];
 }
 
-// ------------------------------------------------------------------------------------------------
-// Fused form of passes 1 + 2: ONE voxel-major pass (the default whenever every voxel fits a chunk).  The workgroup that has
-// just merged a chunk's clusters and eigen-decomposed its voxels holds everything factor_derivs needs -- the factors' clusters
-// and poses in registers, the voxel records in LDS -- so the clusters are read ONCE per evaluation (not once voxel-major and
-// once from a pose-major copy), the voxel records never leave LDS (the pose-major pass gathered one 128-byte line per factor)
-// and Y is written at the factors' voxel-major positions as contiguous 36-KB runs (the pair lists only need positions).
-// What needed the pose-major pass was the sum over a pose's factors without atomics.  Here a workgroup walks a run of
-// consecutive chunks ("super-chunk") whose factors touch <= LVBA_FS poses and keeps a 27-double accumulator per pose slot in
-// LDS.  Per chunk the host has sorted the factors by pose: a factor parks its values at its sorted position (`srt`), the
-// factors of one pose then form a contiguous RUN, and one lane per (run, component) adds the run up and into the slot --
-// every slot is touched by exactly one lane per chunk: no atomics, no conflict rounds, a fixed summation order (sorted order
-// inside the chunk, chunk order inside the super-chunk, super-chunk order in balm_fused_reduce_kernel).
-// The 3 x 3 eigen-decompositions of a chunk (<= 128 voxels, typically ~50) are a serial stretch of ONE or two wavefronts;
-// the wavefront that takes it rotates with the chunk index so that the two workgroups a CU holds do not pile it on one SIMD.
-// LDS 74 KB (U = T [10][256] / (D, g) staging [9][256] 20 KB, voxel records [128][13] 13 KB, Y staging 12.5 KB, accumulators
-// [27][128] 27 KB) -> two workgroups, eight wavefronts per CU: nothing hides a memory latency but the kernel itself.  So every
-// table of chunk c + 1 is requested while chunk c is worked on -- descriptor (one 32-byte record per chunk, two chunks ahead,
-// instead of the chunk_v0 -> voff -> ... chain), clusters, pose indices, sorted positions, voxel offsets and run table at the
-// top of chunk c, the pose gather (it needs the pose indices) behind chunk c's factor_derivs -- and no register is held
-// longer than needed (Y leaves first, (D, g) nine components at a time): a spilled register's reload waits on vmcnt(0), i.e.
-// for every load in flight.
-// ------------------------------------------------------------------------------------------------
-#define LVBA_FNC 9 // (D, g) components staged per pass: 27 = 3 x 9
-__global__ __launch_bounds__(256, 2) void balm_fused_kernel(BalmDev d, FusedDev fd, const double *__restrict__ poses,
-                                                            double *__restrict__ chunk_cost)
-{
-    __shared__ double U[10 * LVBA_CF];
-    __shared__ double V[13 * LVBA_CV];
-    __shared__ double YS[4 * 6 * 65];
-    __shared__ double acc[27 * LVBA_FS];
-    __shared__ int lvoff[LVBA_CV + 1];
-    __shared__ unsigned char lvox[LVBA_CF];
-    __shared__ double red[4];
-    static_assert(LVBA_FNC * LVBA_CF <= 10 * LVBA_CF, "the (D, g) staging shares the transformed-cluster area");
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int64_t sc = blockIdx.x;
-    const int64_t c0 = fd.super_c0[sc], c1 = fd.super_c0[sc + 1];
-    for (int e = tid; e < 27 * LVBA_FS; e += 256) acc[e] = 0.0;
-    // chunk descriptors: {first factor, factors, first voxel, voxels, first run, runs, -, -}.  Uniform, so they end up in scalar
-    // registers -- but only when they are needed (to_desc): a v_readfirstlane right behind the load would wait for it, and
-    // with it for every load requested before it
-    struct Desc { int f0, nf, v0, nv, r0, npc; };
-    typedef unsigned v2u_ __attribute__((ext_vector_type(2)));
-    typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
-    struct RawDesc { v4u_ a; v2u_ b; };
-    // Every table through buffer addressing (resource in scalar registers + one 32-bit lane offset): as flat 64-bit addresses
-    // the tables of a chunk cost ~40 address registers of a kernel that has none to spare (spilled ones come back behind a
-    // vmcnt(0)).  The launcher only takes the fused path when every offset fits 32 bits (cluster rows: 72 F < 2^32).
-    auto rsrc = [](const void *p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, 0xFFFFFFF0u, 0x00020000); };
-    const __amdgpu_buffer_rsrc_t r_clu = rsrc(d.clu), r_pidx = rsrc(d.pidx), r_srt = rsrc(fd.srt), r_voff = rsrc(d.voff),
-                                 r_rs = rsrc(fd.run_start), r_rl = rsrc(fd.run_len), r_rt = rsrc(fd.run_slot), r_cd = rsrc(fd.cdesc);
-    auto load_desc = [&](int64_t ch) {
-        RawDesc q;
-        q.a = __builtin_amdgcn_raw_buffer_load_b128(r_cd, 0, 32u * (unsigned)ch, 0);
-        q.b = __builtin_amdgcn_raw_buffer_load_b64(r_cd, 0, 32u * (unsigned)ch + 16u, 0);
-        return q;
-    };
-    auto to_desc = [](const RawDesc &r) {
-        Desc q;
-        q.f0 = __builtin_amdgcn_readfirstlane((int)r.a.x); q.nf = __builtin_amdgcn_readfirstlane((int)r.a.y);
-        q.v0 = __builtin_amdgcn_readfirstlane((int)r.a.z); q.nv = __builtin_amdgcn_readfirstlane((int)r.a.w);
-        q.r0 = __builtin_amdgcn_readfirstlane((int)r.b.x); q.npc = __builtin_amdgcn_readfirstlane((int)r.b.y);
-        return q;
-    };
-    // per-lane state of a chunk: cluster, pose index, sorted position, voxel offset (lane <= nv; the low word of the global
-    // offset, the chunk's first factor is subtracted when it is used), run (lane j of its group).  No arithmetic on a loaded
-    // value here: it would wait for the load, and with it for every load requested before it.
-    struct Lane { v2u_ c[10]; int pid, lvo; unsigned char srt, r_start, r_len, r_slot; };
-    const unsigned rowb = (unsigned)(8 * d.F);
-    auto load_lane = [&](const Desc &q, Lane &L) { // everything of a chunk that does not depend on another load
-        const int gsh = q.npc <= 64 ? 6 : 7, jr = tid & ((1 << gsh) - 1);
-        if (tid < q.nf) {
-            const unsigned f = (unsigned)q.f0 + (unsigned)tid;
-            L.pid = (int)__builtin_amdgcn_raw_buffer_load_b32(r_pidx, 4u * f, 0, 0); // first: the pose gather waits for this one only
-#pragma unroll
-            for (int e = 0; e < 10; ++e) L.c[e] = __builtin_amdgcn_raw_buffer_load_b64(r_clu, 8u * f, (unsigned)e * rowb, 0);
-            L.srt = __builtin_amdgcn_raw_buffer_load_b8(r_srt, f, 0, 0);
-        }
-        if (tid <= q.nv) L.lvo = (int)__builtin_amdgcn_raw_buffer_load_b32(r_voff, 8u * ((unsigned)q.v0 + (unsigned)tid), 0, 0);
-        if (jr < q.npc) {
-            const unsigned o = (unsigned)q.r0 + (unsigned)jr;
-            L.r_start = __builtin_amdgcn_raw_buffer_load_b8(r_rs, o, 0, 0);
-            L.r_len = __builtin_amdgcn_raw_buffer_load_b8(r_rl, o, 0, 0);
-            L.r_slot = __builtin_amdgcn_raw_buffer_load_b8(r_rt, o, 0, 0);
-        }
-    };
-    auto load_pose = [&](const Desc &q, int pid, double (&xx)[12]) {
-        if (tid < q.nf) {
-            const double2 *xp = reinterpret_cast<const double2 *>(poses + 12 * (int64_t)pid);
-#pragma unroll
-            for (int e = 0; e < 6; ++e) {
-                const double2 v2 = xp[e];
-                xx[2 * e] = v2.x; xx[2 * e + 1] = v2.y;
-            }
-        }
-    };
-    Desc cur = to_desc(load_desc(c0)), nxt = to_desc(load_desc(c0 + 1 < c1 ? c0 + 1 : c0));
-    Lane L;
-    double x[12];
-    load_lane(cur, L);
-    load_pose(cur, L.pid, x);
-    for (int64_t ch = c0; ch < c1; ++ch) {
-        const int64_t f0 = cur.f0;
-        const int nf = cur.nf, nv = cur.nv, npc = cur.npc;
-        const int gsh = npc <= 64 ? 6 : 7, jr = tid & ((1 << gsh) - 1), grp = tid >> gsh, ng = 256 >> gsh;
-        const int my_srt = L.srt, r_start = L.r_start, r_len = L.r_len, r_slot = L.r_slot;
-        if (tid <= nv) lvoff[tid] = L.lvo - (int)f0;
-        double c[10];
-#pragma unroll
-        for (int e = 0; e < 10; ++e) c[e] = __hiloint2double((int)L.c[e].y, (int)L.c[e].x);
-        if (tid < nf) {
-            double t[10];
-            transform_cluster(c, x, x + 9, t);
-#pragma unroll
-            for (int e = 0; e < 10; ++e) U[e * LVBA_CF + tid] = t[e];
-        }
-        // the next chunk's tables are requested now; the chunk after that sends its descriptor
-        const bool more = ch + 1 < c1;
-        RawDesc nn;
-        if (more) {
-            load_lane(nxt, L);
-            nn = load_desc(ch + 2 < c1 ? ch + 2 : ch + 1);
-        }
-        __syncthreads();
-        double lam0 = 0.0;
-        {
-            const int vt = (tid + 256 - 64 * (int)(ch & 3)) & 255; // voxel of this thread: the eigen wavefront rotates with the chunk
-            if (vt < nv) {
-                double S[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                for (int f = lvoff[vt]; f < lvoff[vt + 1]; ++f) {
-                    lvox[f] = (unsigned char)vt;
-#pragma unroll
-                    for (int e = 0; e < 10; ++e) S[e] += U[e * LVBA_CF + f];
-                }
-                VoxRec vr;
-                lam0 = voxel_finish(S, vr);
-                double *o = V + 13 * vt;
-                o[0] = vr.NN;
-#pragma unroll
-                for (int e = 0; e < 3; ++e) {
-                    o[1 + e] = vr.vb[e];
-                    o[4 + e] = vr.u0[e];
-                    o[7 + e] = vr.s1[e];
-                    o[10 + e] = vr.s2[e];
-                }
-            }
-        }
-        __syncthreads();
-        double Y[18], Dg[27];
-        if (tid < nf) {
-            const double *o = V + 13 * (int)lvox[tid];
-            VoxRec vr;
-            vr.NN = o[0];
-#pragma unroll
-            for (int e = 0; e < 3; ++e) {
-                vr.vb[e] = o[1 + e];
-                vr.u0[e] = o[4 + e];
-                vr.s1[e] = o[7 + e];
-                vr.s2[e] = o[10 + e];
-            }
-            factor_derivs(c, x, x + 9, vr, Y, Dg, Dg + 21);
-        }
-        // the next chunk's pose gather (its pose indices were requested a chunk's arithmetic ago)
-        if (more) load_pose(nxt, L.pid, x);
-        // Y leaves first, through a wave-private staging area, one 6-double column at a time: a wavefront's 64 records go out
-        // as 16-byte pieces of consecutive lanes -- 48 contiguous bytes per record and pass; the three passes fill the cache
-        // lines in L2
-        {
-            double *ys = YS + wv * (6 * 65);
-            const int nrec = nf - 64 * wv < 64 ? nf - 64 * wv : 64; // may be <= 0
-            double2 *yo = reinterpret_cast<double2 *>(d.Y + 18 * (f0 + 64 * wv));
-#pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                if (tid < nf) {
-#pragma unroll
-                    for (int e = 0; e < 6; ++e) ys[e * 65 + lane] = Y[6 * m + e];
-                }
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    const int fl = lane + 64 * r, rec = fl / 3, pc = fl - 3 * rec;
-                    if (rec < nrec) yo[9 * rec + 3 * m + pc] = make_double2(ys[(2 * pc) * 65 + rec], ys[(2 * pc + 1) * 65 + rec]);
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        // per-pose sums in three passes over the staging area (T is dead): park at the sorted position, add the runs up
-#pragma unroll
-        for (int pass = 0; pass < 3; ++pass) {
-            if (pass) __syncthreads(); // the previous pass's sums have been read
-            if (tid < nf) {
-#pragma unroll
-                for (int e = 0; e < LVBA_FNC; ++e) U[e * LVBA_CF + my_srt] = Dg[LVBA_FNC * pass + e];
-            }
-            __syncthreads();
-            if (jr < npc) {
-                for (int e = grp; e < LVBA_FNC; e += ng) {
-                    const double *u = U + e * LVBA_CF + r_start;
-                    double s = u[0];
-                    for (int i = 1; i <= r_len; ++i) s += u[i];
-                    acc[(LVBA_FNC * pass + e) * LVBA_FS + r_slot] += s;
-                }
-            }
-        }
-        const double tot = block_sum_256(lam0, red); // (its barrier also ends the chunk: U, V, lvoff, lvox are free again)
-        if (tid == 0) chunk_cost[ch] = tot; // (red is rewritten after the next chunk's barriers)
-        cur = nxt;
-        if (more) nxt = to_desc(nn);
-    }
-    // flush: rows of 32 doubles (27 used), eight slots per sweep of the workgroup
-    const int ns = fd.n_slots[sc];
-    for (int s0 = 0; s0 < ns; s0 += 8) {
-        const int sl = s0 + (tid >> 5), e = tid & 31;
-        if (sl < ns && e < 27) fd.part[((int64_t)sc * LVBA_FS + sl) * 32 + e] = acc[e * LVBA_FS + sl];
-    }
-}
-
-// per pose: the super-chunks' partial sums in super-chunk order -> diagonal block (lower triangle) and gradient
-__global__ void balm_fused_reduce_kernel(BalmDev d, FusedDev fd, double *__restrict__ Hblk, double *__restrict__ g)
-{
-    const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    const int64_t I = gid >> 5;
-    const int e = (int)(gid & 31);
-    if (I >= d.n_poses || e >= 27) return;
-    double s = 0.0;
-    for (int64_t q = fd.pp_off[I]; q < fd.pp_off[I + 1]; ++q) s += fd.part[fd.pp_idx[q] * 32 + e];
-    if (e >= 21) {
-        g[6 * I + (e - 21)] = s;
-    } else {
-        int c = 0, base = 0;
-        while (e >= base + (6 - c)) { base += 6 - c; ++c; }
-        const int r = c + (e - base);
-        Hblk[I * (int64_t)(d.band_blocks + 1) * 36 + c * 6 + r] = s;
-    }
-}
-
 // sum the S slice partials of every pose -> diagonal block (lower triangle) and gradient
 __global__ void balm_diag_reduce_kernel(BalmDev d, double *__restrict__ Hblk, double *__restrict__ g)
 {
@@ -1040,30 +804,6 @@ void launch_eval(const BalmDev &d, const PairDev &pd, const double *poses, doubl
     if (!skip_voxel_pass) hipLaunchKernelGGL(balm_voxel_kernel, dim3((unsigned)d.n_chunks), dim3(LVBA_CF), 0, s, d, poses, chunk_cost);
     hipLaunchKernelGGL(balm_factor_kernel, dim3((unsigned)(d.n_poses * d.S)), dim3(256), 0, s, d, poses);
     hipLaunchKernelGGL(balm_diag_reduce_kernel, dim3((unsigned)((32 * (int64_t)d.n_poses + 255) / 256)), dim3(256), 0, s, d, Hblk, g);
-    launch_pairs(pd, Hblk, s);
-    if (k1) hipEventRecord(k1, s);
-    hipLaunchKernelGGL(reduce_chunks_kernel, dim3(1), dim3(1024), 0, s, chunk_cost, d.n_chunks, out);
-}
-
-// The fused evaluation in two halves.  launch_fused: the linearisation at `poses` -- chunk costs (summed into cost_out[0]), Y
-// and the per-super-chunk (D, g) sums; nothing of H or g is touched.  launch_fused_assemble: H and g from the linearisation in
-// place (per-pose sums + pair pass) and out[0] = the cost of that point again.  The LM loop costs its trial point with the
-// first half; if the step is accepted the next evaluation is AT that point and only needs the second.
-void launch_fused(const BalmDev &d, const FusedDev &fd, const double *poses, double *chunk_cost, double *cost_out, hipStream_t s,
-                  hipEvent_t k0, hipEvent_t k1)
-{
-    if (k0) hipEventRecord(k0, s);
-    hipLaunchKernelGGL(balm_fused_kernel, dim3((unsigned)fd.n_super), dim3(256), 0, s, d, fd, poses, chunk_cost);
-    if (k1) hipEventRecord(k1, s);
-    hipLaunchKernelGGL(reduce_chunks_kernel, dim3(1), dim3(1024), 0, s, chunk_cost, d.n_chunks, cost_out);
-}
-
-void launch_fused_assemble(const BalmDev &d, const FusedDev &fd, const PairDev &pd, double *Hblk, int64_t hblk_doubles, double *g,
-                           double *chunk_cost, double *out, bool zero_first, hipStream_t s, hipEvent_t k0, hipEvent_t k1)
-{
-    if (zero_first) hipMemsetAsync(Hblk, 0, (size_t)hblk_doubles * sizeof(double), s);
-    if (k0) hipEventRecord(k0, s);
-    hipLaunchKernelGGL(balm_fused_reduce_kernel, dim3((unsigned)((32 * (int64_t)d.n_poses + 255) / 256)), dim3(256), 0, s, d, fd, Hblk, g);
     launch_pairs(pd, Hblk, s);
     if (k1) hipEventRecord(k1, s);
     hipLaunchKernelGGL(reduce_chunks_kernel, dim3(1), dim3(1024), 0, s, chunk_cost, d.n_chunks, out);

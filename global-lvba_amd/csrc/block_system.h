@@ -33,7 +33,6 @@ struct BlockSys {
     int32_t S = 1;        // slices per block for the per-factor reduction
     int64_t nnzb = 0;
     int64_t *d_csc_off = nullptr, *d_blk_off = nullptr, *d_blk_slot = nullptr;
-    bool y_voxel_major = false;       // Y is indexed by the factors' own order (fused BALM evaluation), not by pose-major position
     bool pair_col = false;            // which pair kernel the item lists were cut for
     int64_t n_items = 0, n_multi = 0; // work items of the pair pass (>= nnzb), blocks cut into several items
     int64_t *d_multi_off = nullptr, *d_multi_slot = nullptr, *d_multi_idx = nullptr;

@@ -313,7 +313,7 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
         // LVBA_PAIR_SORT=0: the windows' items in (tile, block) order instead of by length (A/B)
         static const bool len_sort = [] { const char *e = getenv("LVBA_PAIR_SORT"); return !(e && !strcmp(e, "0")); }();
         const bool want_col = [&] { const char *e = getenv("LVBA_PAIR"); return e ? !strcmp(e, "col") : true; }();
-        TRY(pair_lists_build(bs.stream, G, voff, F, d_blk_of.as<int32_t>(), bs.y_voxel_major ? nullptr : bs.d_pos_of, N, (int32_t)Bb1, Q, window_groups,
+        TRY(pair_lists_build(bs.stream, G, voff, F, d_blk_of.as<int32_t>(), bs.d_pos_of, N, (int32_t)Bb1, Q, window_groups,
                              len_sort && want_col ? LVBA_PAIR_CUT : 0, bs.d_pairs, blk_slot, blk_off));
         BS_MARK("pairs");
         bs.nnzb = (int64_t)blk_slot.size();
@@ -329,7 +329,7 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
             const int64_t distinct = (int64_t)(std::unique(u.begin(), u.end()) - u.begin());
             if ((int64_t)blk_slot.size() > 24 * std::max<int64_t>(distinct, 1)) {
                 window_groups = 0;
-                TRY(pair_lists_build(bs.stream, G, voff, F, d_blk_of.as<int32_t>(), bs.y_voxel_major ? nullptr : bs.d_pos_of, N, (int32_t)Bb1, Q, 0, 0,
+                TRY(pair_lists_build(bs.stream, G, voff, F, d_blk_of.as<int32_t>(), bs.d_pos_of, N, (int32_t)Bb1, Q, 0, 0,
                                      bs.d_pairs, blk_slot, blk_off));
             }
         }

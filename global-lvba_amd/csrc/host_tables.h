@@ -14,48 +14,26 @@ namespace lvba {
 // n_voxels; Q = sum k (k - 1) / 2.  Returns -1, or the index of the first voxel with fewer than two factors.
 // breaks (optional, ascending voxel indices, n_breaks of them): a chunk never straddles one -- the voxel groups of a grouped
 // refinement (lvba_balm_set_groups) sum their chunks' costs separately.
-// pose_idx (optional; pose of factor f at pose_idx[f - voxel_off[0]], values in [0, n_poses)): a chunk's factors touch at most
-// max_poses DISTINCT poses (the pose slots of the fused evaluation); *over is set when a single voxel alone exceeds that.
 inline int64_t chunk_voxels(int64_t n_voxels, const int64_t *voxel_off, int max_factors, int max_voxels,
-                            lvba::hvec<int64_t> &chunk_v0, int64_t &Q, const int64_t *breaks = nullptr, int64_t n_breaks = 0,
-                            const int32_t *pose_idx = nullptr, int max_poses = 0, int32_t n_poses = 0, bool *over = nullptr)
+                            lvba::hvec<int64_t> &chunk_v0, int64_t &Q, const int64_t *breaks = nullptr, int64_t n_breaks = 0)
 {
     chunk_v0.assign(1, 0);
-    int64_t nf = 0, nv = 0, nb = 0, np = 0, epoch = 1;
+    int64_t nf = 0, nv = 0, nb = 0;
     Q = 0;
-    if (over) *over = false;
-    lvba::hvec<int64_t> stamp, vstamp; // last chunk epoch / last voxel that saw each pose
-    if (pose_idx) { stamp.assign((size_t)n_poses, 0); vstamp.assign((size_t)n_poses, -1); }
-    const int64_t base = n_voxels > 0 ? voxel_off[0] : 0;
     for (int64_t a = 0; a < n_voxels; ++a) {
         const int64_t k = voxel_off[a + 1] - voxel_off[a];
         if (k < 2) return a;
         Q += k * (k - 1) / 2;
         while (nb < n_breaks && breaks[nb] < a) ++nb;
-        if (nb < n_breaks && breaks[nb] == a && nv > 0) { chunk_v0.push_back(a); nf = 0; nv = 0; np = 0; ++epoch; }
-        int64_t fresh = 0, own = 0; // poses of this voxel the open chunk has not seen / distinct poses of the voxel itself
-        if (pose_idx)
-            for (int64_t f = voxel_off[a] - base; f < voxel_off[a + 1] - base; ++f) {
-                const size_t P = (size_t)pose_idx[f];
-                if (vstamp[P] == a) continue;
-                vstamp[P] = a;
-                ++own;
-                if (stamp[P] != epoch) ++fresh;
-            }
-        if (k > max_factors || (pose_idx && own > max_poses)) {
-            if (over && pose_idx && own > max_poses) *over = true;
+        if (nb < n_breaks && breaks[nb] == a && nv > 0) { chunk_v0.push_back(a); nf = 0; nv = 0; }
+        if (k > max_factors) {
             if (nv > 0) chunk_v0.push_back(a);
             chunk_v0.push_back(a + 1);
-            nf = 0; nv = 0; np = 0; ++epoch;
+            nf = 0; nv = 0;
             continue;
         }
-        if (nf + k > max_factors || nv == max_voxels || (pose_idx && np + fresh > max_poses)) {
-            chunk_v0.push_back(a); nf = 0; nv = 0; np = 0; ++epoch;
-            fresh = own;
-        }
-        if (pose_idx)
-            for (int64_t f = voxel_off[a] - base; f < voxel_off[a + 1] - base; ++f) stamp[(size_t)pose_idx[f]] = epoch;
-        nf += k; nv += 1; np += fresh;
+        if (nf + k > max_factors || nv == max_voxels) { chunk_v0.push_back(a); nf = 0; nv = 0; }
+        nf += k; nv += 1;
     }
     if (chunk_v0.back() != n_voxels || chunk_v0.size() == 1) chunk_v0.push_back(n_voxels); // (an empty problem keeps one empty chunk)
     return -1;

@@ -185,6 +185,10 @@ __device__ unsigned long long g_k1b_clk[16];
 //   update 4 waves: trailing 64 x (48 - 16 s) block -= X (X D)^T, fp64 MFMA.
 // 64 pivots still follow one another, but each costs ~(16 - j) readlane+FMA pairs instead of an LDS publish / flag /
 // read-back of a 64-entry column.
+// (Round 3 tried the opposite extreme -- the whole block by the symmetric sweep operator, every thread 16 entries of its column
+// in registers, ONE barrier and one 64-double pivot row per pivot, which also yields A11^-1 and turns the panel into a block
+// LDL^T step.  Measured with tools/solver_microbench: 22.0 us against 13.3 us for this form -- a workgroup barrier + LDS round
+// trip per pivot is ~700 cycles, the in-wavefront chain here ~290 per pivot.  Withdrawn.)
 #define LVBA_W1S 130 // column stride of W (doubles)
 #define LVBA_Z1S 50  // column stride of the Z^T tile (doubles)
 __device__ __forceinline__ double readlane_f64(double v, int lane)
@@ -225,9 +229,7 @@ __device__ __forceinline__ void k1b_steps(std::integer_sequence<int, Js...>, dou
 
 #define LVBA_K1B_LDS (64 * LVBA_W1S + 256 + 16 * LVBA_Z1S + 64) // doubles
 // Leaves d in dvs[64] and G[m][c] in W[c * LVBA_W1S + 64 + m]; ends on a __syncthreads().
-// ud != nullptr: a pending update of the block, subtracted as it is loaded (ud[it] <-> row tid & 63, column (tid >> 6) + 4 it)
-__device__ __forceinline__ void diag_blocked_body(double *lds, LdltMat M, int64_t k, int nbe, int *__restrict__ status,
-                                                  const double *ud = nullptr)
+__device__ __forceinline__ void diag_blocked_body(double *lds, LdltMat M, int64_t k, int nbe, int *__restrict__ status)
 {
     double *W = lds;                      // (row, col) at col * LVBA_W1S + row; rows 64..127 = the appended identity
     double *G11s = W + 64 * LVBA_W1S;     // [m][c]
@@ -245,10 +247,7 @@ __device__ __forceinline__ void diag_blocked_body(double *lds, LdltMat M, int64_
             const int col = (tid >> 6) + 4 * it;
             double v = 0.0;
             if (row < nbe) {
-                if (col <= row) {
-                    v = M.a[(k + row) + (k + col) * M.ld];
-                    if (ud) v -= ud[it];
-                }
+                if (col <= row) v = M.a[(k + row) + (k + col) * M.ld];
             } else if (col == row)
                 v = 1.0;
             vv[it] = v;
@@ -354,17 +353,9 @@ __global__ __launch_bounds__(256) void ldlt_diag_blocked_kernel(LdltMat M, int64
 // panel, and the workgroup's A21 tile is already in registers when the factorisation ends.  Workgroup 0 also writes G and d
 // (the backward pass needs them).
 #define LVBA_K12_LDS (LVBA_K1B_LDS + 128 + 256) // doubles: the blocked factorisation's tables + b_k, y_k + partial sums
-// pend.Z != nullptr: the panel before this one (columns pend.k .., Z = L D in pend.Z, its window starting at this panel's
-// first column) has not been applied to this panel's block column yet; the workgroup applies it to what it reads -- its own
-// 64-row tile and (every workgroup for itself, like the factorisation) the diagonal block -- before it factorises:
-//   tile -= L_p[tile rows] Z_p[diagonal rows]^T,  diag -= L_p[diagonal rows] Z_p[diagonal rows]^T   (two 64 x 64 x 64 MFMA products).
-// The separate launch that did this between two factorisations (6.8 us + a kernel boundary on the critical path) is gone.
-struct PendRef { int64_t k; int nbe; const double *Z; };
-#define LVBA_FUSE_LDS (2 * 64 * LVBA_TS) // doubles: the two operand tiles of the pending products
 __device__ __forceinline__ void diagpanel_tile(double *lds, LdltMat M, int64_t k, int nbe, int64_t w0, int64_t rend,
                                                double *__restrict__ G, double *__restrict__ dvec, double *__restrict__ Zws,
-                                               int64_t ldz, double *__restrict__ b, int *__restrict__ status, int64_t tile,
-                                               const PendRef pend = PendRef{0, 0, nullptr})
+                                               int64_t ldz, double *__restrict__ b, int *__restrict__ status, int64_t tile)
 {
     double *bks = lds + LVBA_K1B_LDS, *ys = bks + 64;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -378,67 +369,7 @@ __device__ __forceinline__ void diagpanel_tile(double *lds, LdltMat M, int64_t k
         av[it] = (r < rend && m < nbe) ? M.a[r + (k + m) * M.ld] : 0.0;
     }
     const double bk = (tid < nbe) ? b[k + tid] : 0.0;
-    if (pend.Z) {
-        double ud[16];
-        {
-            double *Ls = lds, *Zs = lds + 64 * LVBA_TS; // [m][row]
-            const int i = lane & 15, kk = lane >> 4;
-            double lt[16], ldg[16], zd[16];
-#pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const int m = w + 4 * it;
-                const bool mok = m < pend.nbe;
-                lt[it] = (r < rend && mok) ? M.a[r + (pend.k + m) * M.ld] : 0.0;              // L_p, this tile's rows
-                ldg[it] = (row < nbe && mok) ? M.a[(k + row) + (pend.k + m) * M.ld] : 0.0;    // L_p, the diagonal block's rows
-                zd[it] = (row < nbe && mok) ? pend.Z[row + m * ldz] : 0.0;                    // Z_p, the diagonal block's rows (= this panel's columns)
-            }
-#pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const int m = w + 4 * it;
-                Ls[m * LVBA_TS + row] = ldg[it];
-                Zs[m * LVBA_TS + row] = zd[it];
-            }
-            __syncthreads();
-            d4 accd[4], acct[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) { accd[t] = (d4){0.0, 0.0, 0.0, 0.0}; acct[t] = (d4){0.0, 0.0, 0.0, 0.0}; }
-#pragma unroll 4
-            for (int k0 = 0; k0 < 64; k0 += 4) {
-                const double a = Zs[(k0 + kk) * LVBA_TS + 16 * w + i];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) accd[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Ls[(k0 + kk) * LVBA_TS + 16 * t + i], accd[t], 0, 0, 0);
-            }
-            __syncthreads();
-#pragma unroll
-            for (int it = 0; it < 16; ++it) Ls[(w + 4 * it) * LVBA_TS + row] = lt[it];
-            __syncthreads();
-#pragma unroll 4
-            for (int k0 = 0; k0 < 64; k0 += 4) {
-                const double a = Zs[(k0 + kk) * LVBA_TS + 16 * w + i];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) acct[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Ls[(k0 + kk) * LVBA_TS + 16 * t + i], acct[t], 0, 0, 0);
-            }
-            __syncthreads();
-            // acc[t][reg] = product at (row 16 t + i, column 16 w + kk + 4 reg): through LDS into the (row = tid & 63, column
-            // w + 4 it) layout of av / of the diagonal block's loads
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    Ls[(16 * w + kk + 4 * reg) * LVBA_TS + 16 * t + i] = acct[t][reg];
-                    Zs[(16 * w + kk + 4 * reg) * LVBA_TS + 16 * t + i] = accd[t][reg];
-                }
-            __syncthreads();
-#pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                av[it] -= Ls[(w + 4 * it) * LVBA_TS + row];
-                ud[it] = Zs[(w + 4 * it) * LVBA_TS + row];
-            }
-            __syncthreads();
-        }
-        diag_blocked_body(lds, M, k, nbe, status, ud);
-    } else
-        diag_blocked_body(lds, M, k, nbe, status);
+    diag_blocked_body(lds, M, k, nbe, status);
     double *W = lds;
     const double *dvs = lds + 64 * LVBA_W1S + 256 + 16 * LVBA_Z1S;
     if (tile == 0) {
@@ -506,7 +437,7 @@ __global__ __launch_bounds__(256) void ldlt_diagpanel_kernel(LdltMat M, int64_t 
                                                              double *__restrict__ Zws, int64_t ldz, double *__restrict__ b,
                                                              int *__restrict__ status, int64_t sA, int64_t sW)
 {
-    __shared__ double lds[LVBA_K12_LDS > LVBA_FUSE_LDS ? LVBA_K12_LDS : LVBA_FUSE_LDS];
+    __shared__ double lds[LVBA_K12_LDS];
     if (blockIdx.y) { M.a += sA; G += sW; dvec += sW; Zws += sW; b += sW; }
     diagpanel_tile(lds, M, k, nbe, w0, rend, G, dvec, Zws, ldz, b, status, blockIdx.x);
 }
@@ -933,10 +864,6 @@ __device__ __forceinline__ void bulk_tile_128(double *lds, LdltMat M, const Pane
 // and made the launch ~10 us longer than its critical path), then the update workgroups, alternating between the problems.
 // big = true: 128 x 64 update tiles (bulk_tile_128) of the tile columns [ca, cb); false: the 64 x 64 tiles [ca, cb) of the
 // column-major enumeration (update_tile / update_tile2; LVBA_BULK=64, A/B).
-// Zq != nullptr: panel p (columns kq .., window [k2, rendq), Z in Zq) has not been applied to block column p+1 yet: the
-// factorisation workgroups do it themselves (diagpanel_tile, PendRef); nx > 0: nx more workgroups per problem apply panel p to
-// the SECOND tile column of its window (tiles (1 .. nx, 1)), which a panel whose bulk update waits for its partner owes to the
-// factorisation after next.
 template <bool big>
 __global__ __launch_bounds__(256, 2) void ldlt_step_kernel(LdltMat M, int64_t k2, int nbe2, int64_t w02, int64_t rend2, int T2,
                                                            double *__restrict__ G2, double *__restrict__ dvec,
@@ -944,25 +871,22 @@ __global__ __launch_bounds__(256, 2) void ldlt_step_kernel(LdltMat M, int64_t k2
                                                            int *__restrict__ status, int64_t k, int nbe, int64_t w0, int64_t rend,
                                                            const double *__restrict__ Zws, int64_t ldz, int64_t sA, int64_t sW,
                                                            int64_t ke, int nbe_e, int64_t w0e, int64_t rend_e,
-                                                           const double *__restrict__ Zwe, int64_t ca, int64_t cb, int nprob,
-                                                           int64_t kq, int nbeq, int64_t rendq, const double *__restrict__ Zq, int nx)
+                                                           const double *__restrict__ Zwe, int64_t ca, int64_t cb, int nprob)
 {
     __shared__ double lds[LVBA_K3_LDS];
-    static_assert(LVBA_K12_LDS <= LVBA_K3_LDS && LVBA_K3B_LDS <= LVBA_K3_LDS && LVBA_FUSE_LDS <= LVBA_K3_LDS,
-                  "factorisation tables / 128 x 64 chunks / pending products must fit the update's LDS");
-    const int64_t nfac = (int64_t)T2 * nprob, nxt = (int64_t)nx * nprob;
+    static_assert(LVBA_K12_LDS <= LVBA_K3_LDS && LVBA_K3B_LDS <= LVBA_K3_LDS,
+                  "factorisation tables / 128 x 64 chunks must fit the update's LDS");
+    const int64_t nfac = (int64_t)T2 * nprob;
     int prob;
     int64_t bx;
     if ((int64_t)blockIdx.x < nfac) { prob = (int)(blockIdx.x / T2); bx = blockIdx.x - (int64_t)prob * T2; }
     else {
-        const int64_t bb = blockIdx.x - ((int64_t)blockIdx.x < nfac + nxt ? nfac : nfac + nxt);
+        const int64_t bb = blockIdx.x - nfac;
         prob = (int)(bb % nprob); bx = bb / nprob;
     }
-    if (prob) { M.a += sA; G2 += sW; dvec += sW; Zws2 += sW; b += sW; Zws += sW; if (Zwe) Zwe += sW; if (Zq) Zq += sW; }
+    if (prob) { M.a += sA; G2 += sW; dvec += sW; Zws2 += sW; b += sW; Zws += sW; if (Zwe) Zwe += sW; }
     if ((int64_t)blockIdx.x < nfac) {
-        diagpanel_tile(lds, M, k2, nbe2, w02, rend2, G2, dvec, Zws2, ldz, b, status, bx, PendRef{kq, nbeq, Zq});
-    } else if ((int64_t)blockIdx.x < nfac + nxt) {
-        update_tile(lds, M, kq, nbeq, k2, rendq, Zq, ldz, bx + 1, 1);
+        diagpanel_tile(lds, M, k2, nbe2, w02, rend2, G2, dvec, Zws2, ldz, b, status, bx);
     } else if constexpr (big) {
         int64_t R0, tj;
         if (!pair_decode(bx, ca, cb, (rend - w0 + 63) / 64 - 1, R0, tj)) return;
@@ -1263,15 +1187,9 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
     };
     // One launch: [factorise panel st+1 (fac) || bulk tiles [t0, t1) of panel sb's trailing update], the tiles in column-major
     // order.  qe != NULL: panel sb together with its partner sb-1 (rank 128: one pass over C for both).
-    // fuse_q / fuse_extra (set by run_phase for the launch that factorises panel st+1): panel st has not been applied to block
-    // column st+1 -- the factorisation workgroups do it (PendRef) --, and, if fuse_extra, owes its second tile column too
-    const Geo *fuse_q = nullptr;
-    bool fuse_extra = false;
     auto step = [&](int64_t st, const Geo &q2, bool fac, unsigned ny, bool second, int64_t sb_, const Geo *qb, const Geo *qe,
                     int64_t t0, int64_t t1) {
         const int64_t wo = second ? tw.sW : 0;
-        const Geo *qp = fac ? fuse_q : nullptr;
-        const int64_t nx = (qp && fuse_extra) ? qp->T - 1 : 0;
         const int64_t nb3 = qb ? t1 - t0 : 0;
         const int64_t T2 = fac ? q2.T : 0;
         const Geo z{0, 0, 0, 0, 0};
@@ -1290,14 +1208,12 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
             nbu = 0;
             for (int64_t c = ca; c < cb; ++c) nbu += pair_col_items(c, Tb);
         }
-        if (T2 + nx + nbu > 0)
-            hipLaunchKernelGGL(big ? ldlt_step_kernel<true> : ldlt_step_kernel<false>, dim3((unsigned)((T2 + nx + nbu) * ny)), dim3(256), 0, s, second ? M2 : M, q2.k, q2.nbe, q2.w0, q2.rend,
+        if (T2 + nbu > 0)
+            hipLaunchKernelGGL(big ? ldlt_step_kernel<true> : ldlt_step_kernel<false>, dim3((unsigned)((T2 + nbu) * ny)), dim3(256), 0, s, second ? M2 : M, q2.k, q2.nbe, q2.w0, q2.rend,
                                (int)T2, Gall + wo + (st + 1) * 4096, dvec + wo, Zbuf[(st + 1) % 4] + wo, b + wo, status, B.k, B.nbe, B.w0,
                                B.rend, (const double *)(Zbuf[(sb_ % 4 + 4) % 4] + wo), ldz, tw.sA, tw.sW, qe ? qe->k : 0, qe ? qe->nbe : 0,
                                qe ? qe->w0 : 0, qe ? qe->rend : 0,
-                               qe ? (const double *)(Zbuf[((sb_ - 1) % 4 + 4) % 4] + wo) : (const double *)nullptr, ca, cb, (int)ny,
-                               qp ? qp->k : 0, qp ? qp->nbe : 0, qp ? qp->rend : 0,
-                               qp ? (const double *)(Zbuf[st % 4] + wo) : (const double *)nullptr, (int)nx);
+                               qe ? (const double *)(Zbuf[((sb_ - 1) % 4 + 4) % 4] + wo) : (const double *)nullptr, ca, cb, (int)ny);
     };
     // LVBA_RANK128=0: every panel applies its own bulk update (A/B)
     static const bool rank128 = [] { const char *e = getenv("LVBA_RANK128"); return !(e && !strcmp(e, "0")); }();
@@ -1334,24 +1250,18 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
             } else
                 step(st, q2, fac, ny, second, st, total > 0 ? &q : nullptr, nullptr, 0, total);
         };
-        // Default: a panel's first tile column(s) as a launch of its own between two factorisations.  LVBA_FUSE=1: the
-        // factorisation of panel st+1 applies panel st to its own block column as it reads it (PendRef), and a panel whose bulk
-        // waits for its partner sends its second tile column along in the same launch (fuse_extra).  Measured (C3): no gain -- the
-        // two 64 x 64 x 64 products and their LDS round trips add 10 us to the 19 us factorisation, as much as the launch
-        // they replace (6.8 us + a kernel boundary); kept for experiments, covered by tests/test_gpu_balm.py::test_solver_schedules.
-        static const bool fuse = [] { const char *e = getenv("LVBA_FUSE"); return e && !strcmp(e, "1"); }();
+        // A panel's first tile column(s) are a launch of their own between two factorisations.  (Folding them into the
+        // factorisation of the next panel -- two 64 x 64 x 64 products in front of it -- was measured in round 2: the products
+        // and their LDS round trips cost as much as the launch they replace.)
         Geo q = geom(sa);
         factor_panel(sa, q, ny, second);
-        if (!fuse) first_column(sa, q, ny, second, pe(sa) ? 2 : 1);
+        first_column(sa, q, ny, second, pe(sa) ? 2 : 1);
         for (int64_t st = sa; st + 1 < sb; ++st) {
             const Geo q2 = geom(st + 1);
             if (q2.T > 0) {
-                if (fuse) { fuse_q = &q; fuse_extra = pe(st); }
                 launch(st, q, q2, true, false);
-                fuse_q = nullptr; fuse_extra = false;
-                if (!fuse) first_column(st + 1, q2, ny, second, pe(st + 1) ? 2 : 1);
+                first_column(st + 1, q2, ny, second, pe(st + 1) ? 2 : 1);
             } else { // the last panel has no rows below it: nothing to overlap with
-                if (fuse) first_column(st, q, ny, second, 1); // its diagonal block gets panel st the former way
                 launch(st, q, q2, false, true);
                 flush();
                 factor_panel(st + 1, q2, ny, second);
@@ -1359,7 +1269,6 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
             q = q2;
         }
         if (close) {
-            if (fuse) first_column(sb - 1, q, ny, second, 1);
             launch(sb - 1, q, geom(sb), false, true);
         }
         flush();

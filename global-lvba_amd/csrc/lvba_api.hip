@@ -26,18 +26,10 @@ struct lvba_balm_s {
     int32_t N = 0;
     int64_t V = 0, F = 0, Q = 0, n_chunks = 0, Vglobal = 0;
     // host copies kept until finalize()
-    lvba::hvec<int64_t> h_voff, h_chunk_v0;
+    lvba::hvec<int64_t> h_voff;
     lvba::hvec<int32_t> h_pidx;
     bool finalized = false;
-    // fused voxel-major evaluation (balm_fused_kernel, the default): tables built at finalize.  Not for problems with a voxel
-    // seen from more than LVBA_FS poses (`wide_voxel`): those keep the three-pass evaluation.
-    bool fused = false, wide_voxel = false;
     bool voxels_sorted = false; // the voxels were re-laid in the order of the first pose that sees them (balm_create_impl)
-    int64_t n_super = 0;
-    int64_t *d_super_c0 = nullptr, *d_pp_off = nullptr, *d_pp_idx = nullptr;
-    int32_t *d_n_slots = nullptr, *d_cdesc = nullptr;
-    uint8_t *d_srt = nullptr, *d_run_start = nullptr, *d_run_len = nullptr, *d_run_slot = nullptr;
-    double *d_fpart = nullptr;
     // device data (voxel-major)
     int64_t *d_voff = nullptr, *d_chunk_v0 = nullptr;
     int32_t *d_pidx = nullptr;
@@ -62,9 +54,8 @@ struct lvba_balm_s {
     double u = 0.01, v = 2.0, residual1 = 0.0;
     int iter = 0;
     bool have_eval = false;
-    // the linearisation (fused evaluation: Y + per-pose partial sums; three-pass evaluation: the voxel records) and the chunk
-    // costs belong to the poses in d_pose_cur: the LM loop costs its trial point with the first half of the evaluation, and an
-    // accepted trial point is where the next evaluation happens
+    // the voxel records (d_vrec) and chunk costs belong to the poses in d_pose_cur: the LM loop costs its trial point with the
+    // voxel pass of the evaluation, and an accepted trial point is where the next evaluation happens
     bool lin_at_cur = false;
     // profiling
     bool prof_on = false;
@@ -81,13 +72,6 @@ struct lvba_balm_s {
         d.S = bs.S; d.csc_off = bs.d_csc_off; d.clu_csc = d_clu_csc; d.vox_of_pos = bs.d_group_of_pos; d.vrec = d_vrec;
         d.Y = bs.d_Y; d.part = d_part;
         return d;
-    }
-    FusedDev fdev() const
-    {
-        FusedDev f;
-        f.n_super = n_super; f.super_c0 = d_super_c0; f.n_slots = d_n_slots; f.srt = d_srt; f.cdesc = reinterpret_cast<const int4 *>(d_cdesc);
-        f.run_start = d_run_start; f.run_len = d_run_len; f.run_slot = d_run_slot; f.part = d_fpart; f.pp_off = d_pp_off; f.pp_idx = d_pp_idx;
-        return f;
     }
 };
 
@@ -223,8 +207,7 @@ static int32_t balm_create_impl(int32_t n_poses, int64_t n_voxels, const int64_t
     int64_t Q = 0;
     for (int64_t a = 0; a <= n_voxels; ++a) h->h_voff[a] = voxel_off[a] - base2;
     {
-        const int64_t bad = lvba::chunk_voxels(n_voxels, voxel_off, LVBA_CF, LVBA_CV, chunk_v0, Q, nullptr, 0, pose_idx, LVBA_FS, n_poses,
-                                               &h->wide_voxel); // host_tables.h
+        const int64_t bad = lvba::chunk_voxels(n_voxels, voxel_off, LVBA_CF, LVBA_CV, chunk_v0, Q); // host_tables.h
         if (bad >= 0) {
             const long long k = (long long)(voxel_off[bad + 1] - voxel_off[bad]);
             delete h;
@@ -233,7 +216,6 @@ static int32_t balm_create_impl(int32_t n_poses, int64_t n_voxels, const int64_t
     }
     h->n_chunks = (int64_t)chunk_v0.size() - 1;
     h->Q = Q;
-    h->h_chunk_v0 = chunk_v0;
     h->h_pidx.assign(pose_idx, pose_idx + F);
     mark("chunks + copies");
 
@@ -286,8 +268,7 @@ extern "C" int32_t lvba_balm_destroy(lvba_balm_t h)
     hipSetDevice(h->bs.device);
     if (h->bs.stream) hipStreamSynchronize(h->bs.stream);
     void *ptrs[] = {h->d_voff, h->d_chunk_v0, h->d_pidx, h->d_clu, h->d_chunk_cost, h->d_clu_csc, h->d_vrec, h->d_part,
-                    h->d_pose_in, h->d_pose_cur, h->d_pose_trial, h->d_out, h->d_scal2, h->d_super_c0, h->d_pp_off, h->d_pp_idx,
-                    h->d_n_slots, h->d_cdesc, h->d_srt, h->d_run_start, h->d_run_len, h->d_run_slot, h->d_fpart, h->d_grp_of_pose, h->d_gpo, h->d_gaccept, h->d_gco,
+                    h->d_pose_in, h->d_pose_cur, h->d_pose_trial, h->d_out, h->d_scal2, h->d_grp_of_pose, h->d_gpo, h->d_gaccept, h->d_gco,
                     h->d_gscal};
     for (void *p : ptrs)
         if (p) lvba::DevicePool::get().free(p);
@@ -315,107 +296,12 @@ extern "C" int32_t lvba_balm_configure(lvba_balm_t h, int32_t ordering, double b
     return LVBA_OK;
 }
 
-// Super-chunks, pose slots, pose-sorted positions and runs of the fused evaluation (balm_fused_kernel).  p [F]: solver-order
-// pose per factor.
-static int32_t build_fused_tables(lvba_balm_s *h, const lvba::hvec<int32_t> &p)
-{
-    BlockSys &bs = h->bs;
-    const int32_t N = h->N;
-    const int64_t F = h->F, nch = h->n_chunks;
-    const lvba::hvec<int64_t> &cv = h->h_chunk_v0, &voff = h->h_voff;
-    // enough super-chunks to fill the chip several times over (two workgroups per CU are resident), few enough to amortise the
-    // accumulator flush (<= 27 KB per super-chunk against ~57 KB of clusters and Y per chunk)
-    const int64_t cap = std::max<int64_t>(4, (nch + 2047) / 2048);
-    lvba::hvec<int64_t> super_c0(1, 0), pp_cnt((size_t)N + 1, 0);
-    lvba::hvec<int32_t> n_slots, stamp((size_t)N, -1), slot_of((size_t)N, 0), cdesc(8 * (size_t)nch + 8, 0);
-    lvba::hvec<uint8_t> srt((size_t)F), run_start, run_len, run_slot;
-    run_start.reserve((size_t)F / 2); run_len.reserve((size_t)F / 2); run_slot.reserve((size_t)F / 2);
-    lvba::hvec<std::pair<int32_t, int64_t>> rows; // (pose, row of `part`)
-    lvba::hvec<uint64_t> keys;
-    int32_t cur_slots = 0;
-    int64_t cur_chunks = 0, epoch = 0;
-    for (int64_t ch = 0; ch < nch; ++ch) {
-        const int64_t f0 = voff[cv[ch]], f1 = voff[cv[ch + 1]];
-        const int nf = (int)(f1 - f0);
-        if (nf > LVBA_CF) return lvba_fail(LVBA_ERR_STATE, "fused tables: a chunk has more than %d factors", LVBA_CF);
-        keys.resize((size_t)nf);
-        for (int i = 0; i < nf; ++i) keys[(size_t)i] = (uint64_t)(uint32_t)p[(size_t)(f0 + i)] << 16 | (uint64_t)i; // (pose, voxel order)
-        std::sort(keys.begin(), keys.end());
-        int32_t fresh = 0, npc = 0; // poses of this chunk the open super-chunk has not seen; distinct poses of the chunk
-        for (int i = 0; i < nf; ++i)
-            if (i == 0 || (keys[(size_t)i] >> 16) != (keys[(size_t)i - 1] >> 16)) { ++npc; if (stamp[(size_t)(keys[(size_t)i] >> 16)] != (int32_t)epoch) ++fresh; }
-        if (npc > LVBA_FS) return lvba_fail(LVBA_ERR_STATE, "fused tables: a chunk touches more than %d poses", LVBA_FS);
-        if (cur_chunks > 0 && (cur_slots + fresh > LVBA_FS || cur_chunks == cap)) { // close the open super-chunk
-            super_c0.push_back(ch);
-            n_slots.push_back(cur_slots);
-            ++epoch; cur_slots = 0; cur_chunks = 0;
-        }
-        for (int i = 0; i < nf; ++i) {
-            const int32_t P = (int32_t)(keys[(size_t)i] >> 16);
-            srt[(size_t)(f0 + (int64_t)(keys[(size_t)i] & 0xffff))] = (uint8_t)i;
-            if (i == 0 || P != (int32_t)(keys[(size_t)i - 1] >> 16)) {
-                if (stamp[(size_t)P] != (int32_t)epoch) {
-                    stamp[(size_t)P] = (int32_t)epoch;
-                    slot_of[(size_t)P] = cur_slots++;
-                    rows.push_back({P, epoch * LVBA_FS + slot_of[(size_t)P]});
-                    pp_cnt[(size_t)P + 1]++;
-                }
-                run_start.push_back((uint8_t)i);
-                run_len.push_back(0);
-                run_slot.push_back((uint8_t)slot_of[(size_t)P]);
-            } else
-                ++run_len.back(); // (length - 1)
-        }
-        {
-            int32_t *q = cdesc.data() + 8 * (size_t)ch;
-            q[0] = (int32_t)f0; q[1] = nf; q[2] = (int32_t)cv[ch]; q[3] = (int32_t)(cv[ch + 1] - cv[ch]);
-            q[4] = (int32_t)run_start.size() - npc; q[5] = npc;
-        }
-        ++cur_chunks;
-    }
-    super_c0.push_back(nch);
-    n_slots.push_back(cur_slots);
-    h->n_super = (int64_t)n_slots.size();
-    for (int32_t i = 0; i < N; ++i) pp_cnt[(size_t)i + 1] += pp_cnt[i];
-    lvba::hvec<int64_t> pp_idx(rows.size()), fill(pp_cnt.begin(), pp_cnt.end() - 1);
-    for (const auto &r : rows) pp_idx[(size_t)fill[r.first]++] = r.second; // rows arrive in super-chunk order: so do the sums
-    const int64_t nruns = (int64_t)run_start.size();
-    TRY(bs_dmalloc(bs, &h->d_super_c0, h->n_super + 1));
-    TRY(bs_dmalloc(bs, &h->d_n_slots, h->n_super));
-    TRY(bs_dmalloc(bs, &h->d_srt, F));
-    TRY(bs_dmalloc(bs, &h->d_cdesc, 8 * nch + 8));
-    TRY(bs_dmalloc(bs, &h->d_run_start, nruns));
-    TRY(bs_dmalloc(bs, &h->d_run_len, nruns));
-    TRY(bs_dmalloc(bs, &h->d_run_slot, nruns));
-    TRY(bs_dmalloc(bs, &h->d_fpart, h->n_super * LVBA_FS * 32));
-    TRY(bs_dmalloc(bs, &h->d_pp_off, (int64_t)N + 1));
-    TRY(bs_dmalloc(bs, &h->d_pp_idx, (int64_t)pp_idx.size()));
-    HIPCHK(lvba::copy_h2d(h->d_super_c0, super_c0.data(), super_c0.size() * sizeof(int64_t)));
-    HIPCHK(lvba::copy_h2d(h->d_n_slots, n_slots.data(), n_slots.size() * sizeof(int32_t)));
-    HIPCHK(lvba::copy_h2d(h->d_srt, srt.data(), (size_t)F));
-    HIPCHK(lvba::copy_h2d(h->d_cdesc, cdesc.data(), cdesc.size() * sizeof(int32_t)));
-    if (nruns) {
-        HIPCHK(lvba::copy_h2d(h->d_run_start, run_start.data(), (size_t)nruns));
-        HIPCHK(lvba::copy_h2d(h->d_run_len, run_len.data(), (size_t)nruns));
-        HIPCHK(lvba::copy_h2d(h->d_run_slot, run_slot.data(), (size_t)nruns));
-    }
-    HIPCHK(lvba::copy_h2d(h->d_pp_off, pp_cnt.data(), pp_cnt.size() * sizeof(int64_t)));
-    if (!pp_idx.empty()) HIPCHK(lvba::copy_h2d(h->d_pp_idx, pp_idx.data(), pp_idx.size() * sizeof(int64_t)));
-    return LVBA_OK;
-}
-
 static int32_t finalize(lvba_balm_s *h)
 {
     if (h->finalized) return LVBA_OK;
     BlockSys &bs = h->bs;
     HIPCHK(hipSetDevice(bs.device));
     const int N = h->N;
-    { // LVBA_FUSED=0: the three-pass evaluation (voxel-major, pose-major, pairs) also where the fused one applies (A/B)
-        const char *e = getenv("LVBA_FUSED");
-        // (the kernel addresses the cluster rows with 32-bit byte offsets: 80 F < 2^32, i.e. shards below 53 M factors)
-        h->fused = !h->wide_voxel && (uint64_t)h->F * 80u < 0xFFFFFFF0ull && !(e && !strcmp(e, "0"));
-    }
-    bs.y_voxel_major = h->fused;
     if (h->n_groups > 0) bs.ordering = 0; // (lvba_balm_configure / dist_init refuse to undo it; kept here as the single point of truth)
     const bool timing = getenv("LVBA_TIMING") != nullptr;
     auto nowc = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -432,14 +318,10 @@ static int32_t finalize(lvba_balm_s *h)
     for (int64_t f = 0; f < h->F; ++f) p[f] = bs.iperm[h->h_pidx[f]];
     HIPCHK(lvba::copy_h2d(h->d_pidx, p.data(), (size_t)h->F * sizeof(int32_t)));
     mark("pose indices");
-    if (h->fused) {
-        TRY(build_fused_tables(h, p));
-    } else {
-        TRY(bs_dmalloc(bs, &h->d_clu_csc, 10 * h->F));
-        TRY(bs_dmalloc(bs, &h->d_vrec, 16 * h->V));
-        TRY(bs_dmalloc(bs, &h->d_part, (int64_t)N * bs.S * 32));
-        launch_gather_csc(h->d_clu, bs.d_csc_f, h->F, h->d_clu_csc, bs.stream);
-    }
+    TRY(bs_dmalloc(bs, &h->d_clu_csc, 10 * h->F));
+    TRY(bs_dmalloc(bs, &h->d_vrec, 16 * h->V));
+    TRY(bs_dmalloc(bs, &h->d_part, (int64_t)N * bs.S * 32));
+    launch_gather_csc(h->d_clu, bs.d_csc_f, h->F, h->d_clu_csc, bs.stream);
     TRY(bs_dmalloc(bs, &h->d_pose_in, 12 * (int64_t)N));
     TRY(bs_dmalloc(bs, &h->d_pose_cur, 12 * (int64_t)N));
     TRY(bs_dmalloc(bs, &h->d_pose_trial, 12 * (int64_t)N));
@@ -448,7 +330,6 @@ static int32_t finalize(lvba_balm_s *h)
     HIPCHK(hipStreamSynchronize(bs.stream));
     mark("pose-major copy");
     lvba::hvec<int64_t>().swap(h->h_voff);
-    lvba::hvec<int64_t>().swap(h->h_chunk_v0);
     lvba::hvec<int32_t>().swap(h->h_pidx);
     h->finalized = true;
     return LVBA_OK;
@@ -467,11 +348,11 @@ extern "C" int32_t lvba_balm_info(lvba_balm_t h, lvba_balm_info_t *info)
         const char *e = getenv("LVBA_DIST_SOLVE");
         info->solve_ranks = (h->bs.distributed() && h->bs.n_ranks >= 2 && info->twist_panels > 0 && !(e && !strcmp(e, "0"))) ? 2 : 1;
     }
-    info->eval_mode = h->fused ? 1 : 0;
     {
         const char *e = getenv("LVBA_COST_RECORDS");
-        info->trial_linearised = (!(e && !strcmp(e, "0")) && (h->fused || !h->bs.distributed())) ? 1 : 0;
+        info->trial_linearised = !(e && !strcmp(e, "0")) ? 1 : 0;
     }
+    info->reserved = 0;
     info->allreduce_bytes = !h->bs.distributed() ? 0 : 8 * ((h->bs.d_ar_slot ? 36 * h->bs.n_ar : h->bs.hblk_doubles) + 6 * (int64_t)h->N + 1);
     return LVBA_OK;
 }
@@ -525,14 +406,13 @@ extern "C" int32_t lvba_balm_get_profile(lvba_balm_t h, lvba_prof_t *out, int32_
 
 // ------------------------------------------------------------------------------------------ stages
 // enqueue: cost at device poses (solver order) -> dst[0] = (global) sum of lambda_min
-// with_lin: by the first half of the evaluation instead of the cost-only kernel -- the same chunk costs, plus the linearisation
-// at `poses` (fused: Y and the per-pose partial sums; three-pass: the voxel records), which enqueue_eval can start from
+// with_lin: by the voxel pass of the evaluation instead of the cost-only kernel -- the same chunk costs, plus the voxel records
+// at `poses`, which enqueue_eval can start from
 static int32_t enqueue_cost(lvba_balm_s *h, const double *d_poses, double *dst, bool with_lin = false)
 {
     ev_begin(h, EV_COST);
-    hipEvent_t k0 = h->prof_on ? h->ev[EV_COSTK][0] : nullptr, k1 = h->prof_on ? h->ev[EV_COSTK][1] : nullptr;
-    if (with_lin && h->fused) launch_fused(h->dev(), h->fdev(), d_poses, h->d_chunk_cost, dst, h->stream(), k0, k1);
-    else launch_cost(h->dev(), d_poses, h->d_chunk_cost, dst, h->stream(), k0, k1, with_lin);
+    launch_cost(h->dev(), d_poses, h->d_chunk_cost, dst, h->stream(), h->prof_on ? h->ev[EV_COSTK][0] : nullptr,
+                h->prof_on ? h->ev[EV_COSTK][1] : nullptr, with_lin);
     if (h->prof_on) h->ev_used[EV_COSTK] = true;
     ev_end(h, EV_COST);
     if (h->bs.distributed()) {
@@ -545,19 +425,14 @@ static int32_t enqueue_cost(lvba_balm_s *h, const double *d_poses, double *dst, 
 }
 
 // enqueue: H, g, cost at device poses -> bs.d_hg (all-reduced over ranks)
-// lin_in_place: the linearisation at d_poses is already there (enqueue_cost with_lin at the same poses)
+// lin_in_place: the voxel records and chunk costs at d_poses are already there (enqueue_cost with_lin at the same poses)
 static int32_t enqueue_eval(lvba_balm_s *h, const double *d_poses, bool lin_in_place = false)
 {
     BlockSys &bs = h->bs;
     ev_begin(h, EV_EVAL);
-    hipEvent_t k0 = h->prof_on ? h->ev[EV_EVALK][0] : nullptr, k1 = h->prof_on ? h->ev[EV_EVALK][1] : nullptr;
-    if (h->fused) {
-        if (!lin_in_place) launch_fused(h->dev(), h->fdev(), d_poses, h->d_chunk_cost, bs.scal(), bs.stream, k0, nullptr);
-        launch_fused_assemble(h->dev(), h->fdev(), bs.pair_dev(), bs.Hblk(), bs.hblk_doubles, bs.g(), h->d_chunk_cost, bs.scal(),
-                              bs.distributed(), bs.stream, lin_in_place ? k0 : nullptr, k1);
-    } else
-        launch_eval(h->dev(), bs.pair_dev(), d_poses, bs.Hblk(), bs.hblk_doubles, bs.g(), h->d_chunk_cost, bs.scal(),
-                    bs.distributed(), bs.stream, k0, k1, lin_in_place);
+    launch_eval(h->dev(), bs.pair_dev(), d_poses, bs.Hblk(), bs.hblk_doubles, bs.g(), h->d_chunk_cost, bs.scal(),
+                bs.distributed(), bs.stream, h->prof_on ? h->ev[EV_EVALK][0] : nullptr,
+                h->prof_on ? h->ev[EV_EVALK][1] : nullptr, lin_in_place);
     if (h->prof_on) h->ev_used[EV_EVALK] = true;
     ev_end(h, EV_EVAL);
     if (bs.distributed()) {
@@ -762,12 +637,12 @@ extern "C" int32_t lvba_balm_lm_step(lvba_balm_t h, lvba_lm_trace *row, int32_t 
     HIPCHK(hipSetDevice(h->bs.device));
     const bool evaluated = h->is_calc_hess;
     const int64_t n = 6 * (int64_t)h->N;
-    // The trial point is costed by the FIRST HALF of the evaluation (fused: the whole linearisation -- costs, Y, per-pose sums;
-    // three-pass: the voxel pass with its records): an accepted trial point is where the next evaluation happens, and that
-    // evaluation then only assembles H and g (per-pose sums + pair pass).  A rejected step wastes the difference to the
-    // cost-only kernel (C3: 0.2 ms).  LVBA_COST_RECORDS=0: cost-only kernel at the trial point, every evaluation from scratch (A/B).
+    // The trial point is costed by the VOXEL PASS of the evaluation (cost + voxel records): an accepted trial point is where the
+    // next evaluation happens, and that evaluation then starts from the records (factor pass, pair pass) instead of reading
+    // and eigen-decomposing every voxel again.  A rejected step wastes the difference to the cost-only kernel (C3: 0.04 ms).
+    // Also on voxel shards (the records are local).  LVBA_COST_RECORDS=0: cost-only kernel, every evaluation from scratch (A/B).
     static const bool cost_records = [] { const char *e = getenv("LVBA_COST_RECORDS"); return !(e && !strcmp(e, "0")); }();
-    const bool with_lin = cost_records && (h->fused || !h->bs.distributed());
+    const bool with_lin = cost_records;
     if (evaluated) TRY(enqueue_eval(h, h->d_pose_cur, with_lin && h->lin_at_cur));         // :688-689
     TRY(enqueue_solve(h, h->u));                                                           // :692-710
     launch_retract(h->d_pose_cur, h->bs.d_dx, h->d_pose_trial, h->N, h->stream());              // :722-727
@@ -885,13 +760,11 @@ extern "C" int32_t lvba_balm_set_groups(lvba_balm_t h, int32_t n_groups, const i
     // chunks must not straddle groups: the chunk table is made again with breaks at the group boundaries
     lvba::hvec<int64_t> chunk_v0;
     int64_t Q = 0;
-    if (lvba::chunk_voxels(h->V, h->h_voff.data(), LVBA_CF, LVBA_CV, chunk_v0, Q, voxel_off + 1, n_groups - 1, h->h_pidx.data(), LVBA_FS, h->N,
-                           &h->wide_voxel) >= 0)
+    if (lvba::chunk_voxels(h->V, h->h_voff.data(), LVBA_CF, LVBA_CV, chunk_v0, Q, voxel_off + 1, n_groups - 1) >= 0)
         return fail(LVBA_ERR_STATE, "chunk table");
     lvba::DevicePool::get().free(h->d_chunk_v0); bs.device_bytes -= (h->n_chunks + 1) * (int64_t)sizeof(int64_t); h->d_chunk_v0 = nullptr;
     lvba::DevicePool::get().free(h->d_chunk_cost); bs.device_bytes -= h->n_chunks * (int64_t)sizeof(double); h->d_chunk_cost = nullptr;
     h->n_chunks = (int64_t)chunk_v0.size() - 1;
-    h->h_chunk_v0 = chunk_v0;
     TRY(bs_dmalloc(bs, &h->d_chunk_v0, h->n_chunks + 1));
     TRY(bs_dmalloc(bs, &h->d_chunk_cost, h->n_chunks));
     HIPCHK(lvba::copy_h2d(h->d_chunk_v0, chunk_v0.data(), (size_t)(h->n_chunks + 1) * sizeof(int64_t)));

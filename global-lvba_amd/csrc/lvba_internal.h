@@ -29,26 +29,6 @@ struct BalmDev {
     double *part;              // [N*S][32] per-workgroup partial sums of (D[21], g[6])
 };
 
-// Tables of the fused voxel-major evaluation (balm_fused_kernel): a workgroup owns a run of consecutive chunks ("super-chunk")
-// whose factors touch at most LVBA_FS distinct poses and keeps one 27-double accumulator (diagonal block + gradient) per pose
-// slot in LDS.  Inside a chunk the factors of one pose form a RUN of the chunk's pose-sorted order: every factor parks its
-// 27 values at its sorted position, and one lane per (run, component) adds the run up and into the slot -- no atomics, no
-// conflicts, a fixed order.
-#define LVBA_FS 128  // pose slots of a super-chunk (= the most distinct poses a chunk of the fused evaluation may touch)
-struct FusedDev {
-    int64_t n_super;
-    const int64_t *super_c0;   // [n_super+1] first chunk of each super-chunk
-    const int32_t *n_slots;    // [n_super] distinct poses of the super-chunk
-    const int4 *cdesc;         // [n_chunks][2] per chunk {first factor, factors, first voxel, voxels | first run, runs, -, -}
-    const uint8_t *srt;        // [F] position of every factor in its chunk's pose-sorted order
-    const uint8_t *run_start;  // [n_runs] first sorted position of the run
-    const uint8_t *run_len;    // [n_runs] its length - 1
-    const uint8_t *run_slot;   // [n_runs] pose slot inside the super-chunk
-    double *part;              // [n_super*LVBA_FS][32] per-super-chunk sums (27 used)
-    const int64_t *pp_off;     // [N+1] per pose: its (super-chunk, slot) rows in `part`
-    const int64_t *pp_idx;     // rows of `part`, in super-chunk order
-};
-
 // Per-block contributor lists of the atomic-free assembly of  -sum Y_I Y_J^T  (shared by both stages).
 struct PairDev {
     int64_t nnzb;              // work items of the pair pass: off-diagonal blocks, long pair lists cut into several items
@@ -107,11 +87,6 @@ void launch_eval(const BalmDev &d, const PairDev &pd, const double *poses, doubl
                  double *chunk_cost, double *out, bool zero_first, hipStream_t s, hipEvent_t k0, hipEvent_t k1,
                  bool skip_voxel_pass = false);
 void launch_pairs(const PairDev &pd, double *Hblk, hipStream_t s);
-// the fused voxel-major evaluation in two halves: linearisation (costs, Y, per-pose partial sums), then assembly of H and g
-void launch_fused(const BalmDev &d, const FusedDev &fd, const double *poses, double *chunk_cost, double *cost_out, hipStream_t s,
-                  hipEvent_t k0, hipEvent_t k1);
-void launch_fused_assemble(const BalmDev &d, const FusedDev &fd, const PairDev &pd, double *Hblk, int64_t hblk_doubles, double *g,
-                           double *chunk_cost, double *out, bool zero_first, hipStream_t s, hipEvent_t k0, hipEvent_t k1);
 void launch_aos_to_soa(const double *aos, const int32_t *fmap, int64_t F, double *soa, hipStream_t s);
 // grouped refinement (lvba_balm_refine_groups)
 void launch_reduce_chunks_groups(const double *chunk_cost, const int64_t *gco, int n_groups, double *out, hipStream_t s);

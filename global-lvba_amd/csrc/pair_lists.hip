@@ -45,8 +45,7 @@ __global__ __launch_bounds__(256) void pair_gen_kernel(const int64_t *__restrict
     while ((x + 1) * (2 * k - x - 2) / 2 <= t) ++x;
     const int64_t y = x + 1 + (t - x * (2 * k - x - 1) / 2);
     int32_t I = blk_of[f0 + x], J = blk_of[f0 + y];
-    // pos_of == nullptr: Y lives at the factors' own (voxel-major) positions
-    uint32_t px = pos_of ? (uint32_t)pos_of[f0 + x] : (uint32_t)(f0 + x), py = pos_of ? (uint32_t)pos_of[f0 + y] : (uint32_t)(f0 + y);
+    uint32_t px = (uint32_t)pos_of[f0 + x], py = (uint32_t)pos_of[f0 + y];
     if (I < J) {
         const int32_t ti = I; I = J; J = ti;
         const uint32_t tp = px; px = py; py = tp;

@@ -92,10 +92,9 @@ typedef struct {
     int64_t allreduce_bytes; /* bytes all-reduced per evaluation (0 without a communicator): the union-pattern blocks + g + cost */
     int32_t twist_panels;    /* band solver: 64-column panels each END eliminates (0: plain top-down factorisation) */
     int32_t solve_ranks;     /* ranks the factorisation is spread over: 2 when ranks 0 and 1 take one end each, else 1 */
-    int32_t eval_mode;       /* 1: fused voxel-major evaluation (balm_fused_kernel + assembly); 0: three passes (a voxel is seen
-                              * from more poses than a chunk has pose slots, or LVBA_FUSED=0) */
-    int32_t trial_linearised; /* 1: the LM loop costs its trial point with the first half of the evaluation, and an accepted
-                               * step's next evaluation only assembles H and g from it */
+    int32_t trial_linearised; /* 1: the LM loop costs its trial point with the voxel pass of the evaluation (cost + voxel records),
+                               * and an accepted step's next evaluation starts from those records */
+    int32_t reserved;
 } lvba_balm_info_t;
 
 /* Accumulated device times (HIP events on the handle's stream) since the last reset, ms. */

@@ -145,3 +145,54 @@ def test_visual_track_shards_agree_with_single_rank(pkg, synth, world, n_cams, n
     assert np.abs(r0["q"] - q1).max() <= 1e-8 and np.abs(r0["t"] - t1).max() <= 1e-8
     X = np.concatenate([o["X"] for o in out])
     assert np.abs(X - X1).max() <= 1e-7
+
+
+def test_c3_two_ranks_full_lm_trace(pkg, synth):
+    """The multi-rank path AT THE SIZE THE DRIVER LAUNCHES IT: config C3 (2 000 poses x 2 M voxels x 10 M factors) on two
+    ranks.  What only happens at this size: the packed all-reduce over ~4e5 union-pattern blocks (115 MB), the two-rank split
+    of the band factorisation with its 55 MB exchange of the middle block, windowed pair lists per shard, no solve graph.
+    Required: both ranks bitwise equal; H blocks, g, cost and the whole LM trace equal to the single-rank run (1e-7 on the
+    per-iteration costs, the bar of tests/test_gpu_config_parity.py, which holds the single-rank C3 run against the oracle)."""
+    import torch
+    N, V = synth.CONFIGS["C3"]
+    d = synth.make_balm_problem(N, V, device="cuda")
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    off, idx, clu = d["voxel_off"], d["pose_idx"], d["clusters"]
+    x0 = d["poses_init"]
+    single = pkg.BalmProblem(N, off, idx, clu)
+    gi1, gj1, B1, g1, c1 = single.eval_blocks(x0)
+    x1, tr1, rc1 = single.refine(x0)
+    single.close()
+    world = 2
+    ht = HostTransport(world)
+
+    def rank_main(r):
+        a, b = pkg.shard_range(V, r, world)
+        prob = pkg.BalmProblem(N, off[a:b + 1], idx[off[a]:off[b]], clu[off[a]:off[b]])
+        ht.attach(prob, r)
+        info = prob.info()
+        gi, gj, B, g, c = prob.eval_blocks(x0)
+        x, trace, rc = prob.refine(x0)
+        prob.close()
+        return dict(info=info, gi=gi, gj=gj, B=B, g=g, c=c, x=x, trace=trace, rc=rc)
+
+    out = ht.run(rank_main, timeout=900)
+    r0, r1 = out
+    calls, nbytes = ht.stats()
+    assert r0["info"]["n_ranks"] == 2 and r0["info"]["n_voxels_global"] == V and r0["info"]["solve_ranks"] == 2
+    assert 50e6 < r0["info"]["allreduce_bytes"] < 0.75 * r0["info"]["hess_bytes"]       # the packed form, at size
+    assert nbytes > 10 * r0["info"]["allreduce_bytes"]                                   # ... and it did travel, every evaluation
+    assert np.array_equal(r0["B"], r1["B"]) and np.array_equal(r0["g"], r1["g"]) and r0["c"] == r1["c"]
+    assert np.array_equal(r0["x"], r1["x"]) and r0["trace"] == r1["trace"]
+    # against the single-rank run: the union pattern may carry blocks that are zero on both shards' sum? no: the same blocks
+    k1 = gi1.astype(np.int64) * N + gj1
+    k0 = r0["gi"].astype(np.int64) * N + r0["gj"]
+    o1, o0 = np.argsort(k1), np.argsort(k0)
+    assert np.array_equal(k1[o1], k0[o0])
+    assert rel(r0["B"][o0], B1[o1]) <= 1e-11 and rel(r0["g"], g1) <= 1e-11 and abs(r0["c"] - c1) <= 1e-12 * c1
+    assert r0["rc"] == rc1 == 0 and len(r0["trace"]) == len(tr1)
+    for a_, b_ in zip(r0["trace"], tr1):
+        assert a_["accepted"] == b_["accepted"] and a_["evaluated"] == b_["evaluated"]
+        assert abs(a_["residual1"] - b_["residual1"]) <= 1e-7 * b_["residual1"] and abs(a_["residual2"] - b_["residual2"]) <= 1e-7 * b_["residual2"]
+    assert np.abs(r0["x"] - x1).max() <= 1e-7

@@ -55,10 +55,8 @@ int main(int argc, char **argv)
     const int64_t Tb = qo.T - 1, total = Tb * (Tb + 1) / 2;
     printf("n=%lld bw=%lld T=%lld bulk tiles of one panel=%lld (x2 problems)\n", (long long)n, (long long)bw, (long long)qo.T, (long long)total);
     // big: 128 x 64 update tiles of the tile columns holding tiles [t0, t1); else one 64 x 64 tile per workgroup
-    bool fused = false; // the factorisation workgroups also apply panel 11 to their block column, + panel 11's second tile column
     auto launch = [&](bool big, int T2, int64_t t0, int64_t t1, bool pair, int ny) {
-        const bool fz = fused && T2 > 0;
-        const int nx = fz ? (int)(qo.T - 1) : 0;
+        const int nx = 0;
         int64_t ca = t0, cb = t1, nbu = t1 - t0;
         if (big && t1 > t0) {
             ca = 0; cb = Tb;
@@ -70,13 +68,11 @@ int main(int argc, char **argv)
         if (big)
             hipLaunchKernelGGL(ldlt_step_kernel<true>, dim3((unsigned)((T2 + nx + nbu) * ny)), dim3(256), 0, s, M, q2.k, q2.nbe, q2.w0, q2.rend, T2, Gall + 12 * 4096,
                                dvec, Zbuf[0], b, status, qo.k, qo.nbe, qo.w0, qo.rend, (const double *)Zbuf[3], ldz, sA, sW, qe.k, qe.nbe, qe.w0, qe.rend,
-                               pair ? (const double *)Zbuf[2] : (const double *)nullptr, ca, cb, ny, fz ? qo.k : 0, fz ? qo.nbe : 0, fz ? qo.rend : 0,
-                               fz ? (const double *)Zbuf[3] : (const double *)nullptr, nx);
+                               pair ? (const double *)Zbuf[2] : (const double *)nullptr, ca, cb, ny);
         else
             hipLaunchKernelGGL(ldlt_step_kernel<false>, dim3((unsigned)((T2 + nx + nbu) * ny)), dim3(256), 0, s, M, q2.k, q2.nbe, q2.w0, q2.rend, T2, Gall + 12 * 4096,
                                dvec, Zbuf[0], b, status, qo.k, qo.nbe, qo.w0, qo.rend, (const double *)Zbuf[3], ldz, sA, sW, qe.k, qe.nbe, qe.w0, qe.rend,
-                               pair ? (const double *)Zbuf[2] : (const double *)nullptr, ca, cb, ny, fz ? qo.k : 0, fz ? qo.nbe : 0, fz ? qo.rend : 0,
-                               fz ? (const double *)Zbuf[3] : (const double *)nullptr, nx);
+                               pair ? (const double *)Zbuf[2] : (const double *)nullptr, ca, cb, ny);
     };
     const int T2 = (int)q2.T;
     int64_t cs = 1;
@@ -91,10 +87,6 @@ int main(int argc, char **argv)
     for (int ny = 1; ny <= 2; ++ny) {
         printf("---- %d problem(s) per launch\n", ny);
         printf("factorisation workgroups alone (%d)                     %7.2f us\n", T2 * ny, time_us(s, 200, [&] { launch(false, T2, 0, 0, false, ny); }));
-        fused = true;
-        printf("factorisation + pending panel + second column (%d)      %7.2f us\n", T2 * ny, time_us(s, 200, [&] { launch(false, T2, 0, 0, false, ny); }));
-        printf("   + rank-128a 128 x 64 tiles                           %7.2f us\n", time_us(s, 200, [&] { launch(true, T2, 0, t_half, true, ny); }));
-        fused = false;
         for (int pair = 0; pair < 3; ++pair) { // 0: rank 64, all tiles; 1 / 2: rank 128, first / second half of the tile columns
             const int64_t t0 = pair == 2 ? t_half : 0, t1 = pair == 1 ? t_half : total;
             const double gf = (double)(t1 - t0) * ny * (pair ? 2 : 1) * 2.0 * 64 * 64 * 64 * 1e-9;
