@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("LVBA_HIP_LIB") or os.path.join(HERE, "liblvba_hip.so"
 # every extern "C" symbol include/lvba_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
     "lvba_version", "lvba_last_error", "lvba_device_count", "lvba_balm_default_opts", "lvba_shard_range",
-    "lvba_balm_create", "lvba_balm_destroy", "lvba_balm_configure", "lvba_balm_info", "lvba_balm_cost",
+    "lvba_balm_create", "lvba_balm_create_dev", "lvba_balm_destroy", "lvba_balm_configure", "lvba_balm_info", "lvba_balm_cost",
     "lvba_balm_eval", "lvba_balm_eval_blocks", "lvba_balm_solve", "lvba_balm_refine", "lvba_balm_lm_begin", "lvba_balm_lm_step",
     "lvba_balm_lm_end", "lvba_balm_set_groups", "lvba_balm_refine_groups", "lvba_balm_set_profiling", "lvba_balm_get_profile", "lvba_balm_get_ordering",
     "lvba_dist_unique_id", "lvba_balm_dist_init", "lvba_balm_dist_init_external", "lvba_visual_dist_init_external",
@@ -160,6 +160,7 @@ def load():
     lib.lvba_shard_range.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.lvba_shard_range.restype = None
     lib.lvba_balm_create.argtypes = [C.c_int32, C.c_int64, i64p, i32p, f64p, C.c_int32, C.POINTER(H)]
+    lib.lvba_balm_create_dev.argtypes = [C.c_int32, C.c_int64, i64p, i32p, C.c_void_p, C.c_int32, C.POINTER(H)]
     lib.lvba_balm_destroy.argtypes = [H]
     lib.lvba_balm_configure.argtypes = [H, C.c_int32, C.c_double]
     lib.lvba_balm_info.argtypes = [H, C.POINTER(BalmInfo)]

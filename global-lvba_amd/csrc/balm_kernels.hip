@@ -12,8 +12,8 @@
 //   balm_voxel_kernel   voxel-major  : merged covariance, eigen-decomposition -> cost + voxel records
 //   balm_factor_kernel  pose-major   : per factor Y_i (stored), diagonal block E_i - Y_i Y_i^T and gradient
 //                                      reduced in registers over the pose's factors (one plain store)
-//   balm_pair_kernel    block-major  : every off-diagonal block -sum Y_I Y_J^T over its voxel list; 16 lanes
-//                                      per block, one pair per lane, DPP row reduction, one plain store
+//   balm_pair_*_kernel  block-major  : every off-diagonal block -sum Y_I Y_J^T over its voxel list (column-per-lane form for
+//                                      large windowed problems, 16 lanes per item otherwise), plain stores
 // so run-to-run results are bitwise identical.
 //
 // Replaces VOX_HESS::evaluate_only_residual (bavoxel.hpp:176-203) and VOX_HESS::acc_evaluate2
@@ -351,55 +351,14 @@ __device__ __forceinline__ double row16_sum(double x)
 }
 
 // ------------------------------------------------------------------------------------------------
-// pass 3 (block-major): 16 lanes (one DPP row) own one off-diagonal block; each lane takes one
-// contributing voxel (a pair of Y records) per iteration and forms the 6x6 rank-3 product in registers.
+// pass 3 (block-major), 16-lane form: 16 lanes (one DPP row) own one off-diagonal block (or one item of a long list); each lane
+// takes one contributing voxel (a pair of Y records) per iteration and forms the 6 x 6 rank-3 product in registers.  The records
+// are fetched COOPERATIVELY: if every lane gathered its own two 144-byte records, each of the 18 load instructions of an
+// iteration would touch 64+ different cache lines per wavefront (the texture-address path serialises on lines, not bytes).
+// Here the 16 lanes of a group fetch the group's 32 records of an iteration as 288 consecutive 16-byte chunks (a lane run of 9
+// covers one record), x side then y side, park them in LDS and each lane reads its own records back.  The default for problems
+// with few blocks and long lists (window BA); large problems use the column-per-lane form below.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void balm_pair_kernel(PairDev d, double *__restrict__ Hblk)
-{
-    // XCD-aware order: workgroup b runs on XCD b % 8 (observed dispatch rule; speed only).  Give every XCD a
-    // contiguous range of blocks (= a range of block columns J) so pose J's Y segment is re-read from ITS L2.
-    const int64_t per_xcd = (gridDim.x + 7) / 8;
-    const int64_t wg = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    const int64_t blk = wg * 16 + (threadIdx.x >> 4);
-    const int l16 = threadIdx.x & 15;
-    const bool live = blk < d.nnzb;
-    int64_t o0 = 0, o1 = 0;
-    if (live) { o0 = d.blk_off[blk]; o1 = d.blk_off[blk + 1]; }
-    double acc[36];
-#pragma unroll
-    for (int e = 0; e < 36; ++e) acc[e] = 0.0;
-    for (int64_t q = o0 + l16; q < o1; q += 16) {
-        const int2 pr = d.pairs[q];
-        const double2 *yi = reinterpret_cast<const double2 *>(d.Y + 18 * (int64_t)pr.x);
-        const double2 *yj = reinterpret_cast<const double2 *>(d.Y + 18 * (int64_t)pr.y);
-        double Yi[18], Yj[18];
-#pragma unroll
-        for (int e = 0; e < 9; ++e) {
-            const double2 a = yi[e], b = yj[e];
-            Yi[2 * e] = a.x; Yi[2 * e + 1] = a.y;
-            Yj[2 * e] = b.x; Yj[2 * e + 1] = b.y;
-        }
-#pragma unroll
-        for (int c = 0; c < 6; ++c)
-#pragma unroll
-            for (int r = 0; r < 6; ++r)
-                acc[c * 6 + r] += Yi[r] * Yj[c] + Yi[6 + r] * Yj[6 + c] + Yi[12 + r] * Yj[12 + c];
-    }
-#pragma unroll
-    for (int e = 0; e < 36; ++e) acc[e] = row16_sum(acc[e]);
-    if (live && l16 == 0) {
-        const int64_t dst = d.blk_slot[blk];
-        double2 *hp = reinterpret_cast<double2 *>(dst >= 0 ? Hblk + dst * 36 : d.partial + (-dst - 1) * 36);
-#pragma unroll
-        for (int e = 0; e < 18; ++e) hp[e] = make_double2(-acc[2 * e], -acc[2 * e + 1]);
-    }
-}
-
-// Same work items, records fetched COOPERATIVELY: in the kernel above every lane gathers its own two 144-byte records, so
-// each of the 18 load instructions of an iteration touches 64+ different cache lines per wavefront (the texture-address
-// path serialises on lines, not bytes).  Here the 16 lanes of a group fetch the group's 32 records of an iteration as 288
-// consecutive 16-byte chunks (a lane run of 9 covers one record), x side then y side, park them in LDS and each lane reads
-// its own records back.
 #define LVBA_PAIR_GROUP_DOUBLES (16 * 18)
 __global__ __launch_bounds__(256) void balm_pair_staged_kernel(PairDev d, double *__restrict__ Hblk)
 {
@@ -483,6 +442,9 @@ __global__ __launch_bounds__(256) void balm_pair_staged_kernel(PairDev d, double
 // ------------------------------------------------------------------------------------------------
 #define LVBA_PC_ITEMS 10 // items per wavefront (6 lanes each; lanes 60..63 only help fetching)
 #define LVBA_PC_DEPTH 2  // pairs of every item per round: the gathers of a round are what hides the memory latency
+// BUF: the Y records through buffer addressing (resource + one 32-bit byte offset per load) instead of 64-bit flat addresses --
+// six fewer 64-bit multiply-adds per lane and round; for Y arrays below 4 GB (29.8 M factors per shard), else the flat form.
+template <bool BUF>
 __global__ __launch_bounds__(256) void balm_pair_col_kernel(PairDev d, double *__restrict__ Hblk)
 {
     constexpr int NCH = LVBA_PC_ITEMS * LVBA_PC_DEPTH * 18; // 16-byte chunks per round
@@ -531,6 +493,7 @@ __global__ __launch_bounds__(256) void balm_pair_col_kernel(PairDev d, double *_
     // Software pipeline: round r + 1's records are requested as soon as round r's have been parked in LDS, so their way through
     // L2 / HBM overlaps the LDS reads and FMAs of round r (before: gather -> LDS -> FMA, one dependent chain per round).
     double2 v[NLD];
+    const __amdgpu_buffer_rsrc_t r_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(d.Y), 0, 0xFFFFFFF0u, 0x00020000);
     auto fetch = [&](int r) {
 #pragma unroll
         for (int s2 = 0; s2 < NLD; ++s2) {
@@ -538,7 +501,13 @@ __global__ __launch_bounds__(256) void balm_pair_col_kernel(PairDev d, double *_
             v[s2] = make_double2(0.0, 0.0);
             if (pi < c_len[s2]) {
                 const int2 pr = pl[c_fa[s2] + pi];
-                v[s2] = reinterpret_cast<const double2 *>(d.Y + 18 * (int64_t)(c_side[s2] ? pr.y : pr.x))[c_piece[s2]];
+                const int pos = c_side[s2] ? pr.y : pr.x;
+                if (BUF) {
+                    typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
+                    const v4u_ a = __builtin_amdgcn_raw_buffer_load_b128(r_y, 144u * (unsigned)pos + 16u * (unsigned)c_piece[s2], 0, 0);
+                    v[s2] = make_double2(__hiloint2double((int)a.y, (int)a.x), __hiloint2double((int)a.w, (int)a.z));
+                } else
+                    v[s2] = reinterpret_cast<const double2 *>(d.Y + 18 * (int64_t)pos)[c_piece[s2]];
             }
         }
     };
@@ -778,17 +747,15 @@ void launch_cost(const BalmDev &d, const double *poses, double *chunk_cost, doub
 
 void launch_pairs(const PairDev &pd, double *Hblk, hipStream_t s)
 {
-    // LVBA_PAIR = gather: the lane-per-record form of the 16-lane kernel, kept for A/B runs
-    static const bool gather = [] { const char *e = getenv("LVBA_PAIR"); return e && !strcmp(e, "gather"); }();
-    const int mode = pd.col_form ? 0 : gather ? 1 : 2;
     if (pd.nnzb > 0) {
-        if (mode == 0) {
+        if (pd.col_form) {
             const dim3 grid((unsigned)((((pd.nnzb + 4 * LVBA_PC_ITEMS - 1) / (4 * LVBA_PC_ITEMS)) + 7) / 8 * 8));
-            hipLaunchKernelGGL(balm_pair_col_kernel, grid, dim3(256), 0, s, pd, Hblk);
+            static const bool flat = [] { const char *e = getenv("LVBA_PAIR_FLAT"); return e && !strcmp(e, "1"); }(); // (A/B)
+            if (pd.y_bytes < 0xFFFFFF00ll && !flat) hipLaunchKernelGGL(balm_pair_col_kernel<true>, grid, dim3(256), 0, s, pd, Hblk);
+            else hipLaunchKernelGGL(balm_pair_col_kernel<false>, grid, dim3(256), 0, s, pd, Hblk);
         } else {
             const dim3 grid((unsigned)((((pd.nnzb + 15) / 16) + 7) / 8 * 8));
-            if (mode == 1) hipLaunchKernelGGL(balm_pair_kernel, grid, dim3(256), 0, s, pd, Hblk);
-            else hipLaunchKernelGGL(balm_pair_staged_kernel, grid, dim3(256), 0, s, pd, Hblk);
+            hipLaunchKernelGGL(balm_pair_staged_kernel, grid, dim3(256), 0, s, pd, Hblk);
         }
     }
     if (pd.n_multi > 0)

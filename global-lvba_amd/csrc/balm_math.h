@@ -158,6 +158,93 @@ LVBA_HD void eig3(const double *C, double *lam, double *U)
     }
 }
 
+// The same decomposition for the LM kernels, where it was the larger part of the voxel pass's instruction count (cyclic Jacobi
+// with eigenvectors: ~1500 instructions per voxel, a dependent chain).  A plane voxel's covariance has one small eigenvalue
+// well separated from the other two (the front-end admits lam0 / lam2 <= ~0.1), which a direct method can use:
+//   lam0   Newton on p(x) = det(C - x I) from x = 0: left of the smallest root p is positive, decreasing and convex, so the
+//          iterates rise monotonically to lam0; p and p' = -(sum of the principal 2 x 2 minors of C - x I) are formed from
+//          the shifted matrix itself (not from polynomial coefficients), the first step already lands within lam0 / lam1
+//          of the root and the convergence is quadratic -- 4 to 6 steps;
+//   u0     the largest of the three cross products of the rows of C - lam0 I (all of them are multiples of u0);
+//   u1, u2 the rows of C - lam0 I lie in the plane orthogonal to u0: e1 = the largest row, e2 = u0 x e1, and ONE Jacobi
+//          rotation diagonalises the 2 x 2 block e^T C e exactly (also when lam1 ~ lam2, where u1, u2 are not unique but the
+//          kernels only use the combination s1 s1^T + s2 s2^T).
+// ~330 instructions with eigenvectors, ~120 for lam0 alone.  Accuracy: lam0 to ~eps ||C||^3 / (lam1 lam2) absolute, i.e.
+// ~1e-13 relative for the planar voxels this path sees (the parity bar is 1e-8; tests/test_oracle.py holds it against LAPACK
+// on the host).  lam ascending; U[3*r+m] = component r of eigenvector m.  !WANT_VEC: lam[0] only.
+template <bool WANT_VEC>
+LVBA_HD void eig3_planar(const double *C, double *lam, double *U)
+{
+    const double c00 = C[0], c01 = C[1], c02 = C[2], c11 = C[3], c12 = C[4], c22 = C[5];
+    const double q01 = c01 * c01, q02 = c02 * c02, q12 = c12 * c12;
+    const double tr = c00 + c11 + c22;
+    double x = 0.0;
+    for (int it = 0; it < 16; ++it) {
+        const double a = c00 - x, b = c11 - x, c = c22 - x;
+        const double m0 = b * c - q12, m1 = a * c - q02, m2 = a * b - q01; // principal minors of C - x I
+        const double p = a * m0 - c01 * (c01 * c - c12 * c02) + c02 * (c01 * c12 - b * c02);
+        const double ms = m0 + m1 + m2;
+        if (!(ms > 0.0)) break;
+        const double dx = p * lvba_rcp(ms);
+        x += dx;
+        if (!(fabs(dx) > 4e-17 * tr)) break;
+    }
+    lam[0] = x;
+    const double a = c00 - x, b = c11 - x, c = c22 - x;
+    if (!WANT_VEC) { lam[1] = lam[2] = 0.0; return; } // the cost kernel wants lam0 only
+    // u0: rows r0 = (a, c01, c02), r1 = (c01, b, c12), r2 = (c02, c12, c) of C - lam0 I
+    const double n0[3] = {c01 * c12 - c02 * b, c02 * c01 - a * c12, a * b - q01};      // r0 x r1
+    const double n1[3] = {c01 * c - c02 * c12, c02 * c02 - a * c, a * c12 - c01 * c02}; // r0 x r2
+    const double n2[3] = {b * c - q12, c12 * c02 - c01 * c, c01 * c12 - b * c02};      // r1 x r2
+    const double l0 = n0[0] * n0[0] + n0[1] * n0[1] + n0[2] * n0[2], l1 = n1[0] * n1[0] + n1[1] * n1[1] + n1[2] * n1[2],
+                 l2 = n2[0] * n2[0] + n2[1] * n2[1] + n2[2] * n2[2];
+    double u[3], ll;
+    if (l0 >= l1 && l0 >= l2) { u[0] = n0[0]; u[1] = n0[1]; u[2] = n0[2]; ll = l0; }
+    else if (l1 >= l2) { u[0] = n1[0]; u[1] = n1[1]; u[2] = n1[2]; ll = l1; }
+    else { u[0] = n2[0]; u[1] = n2[1]; u[2] = n2[2]; ll = l2; }
+    const double iu = lvba_rsq(ll);
+    u[0] *= iu; u[1] *= iu; u[2] *= iu;
+    // e1: the largest row of C - lam0 I, made exactly orthogonal to u0 (one Gram-Schmidt step against rounding); e2 = u0 x e1
+    const double w0 = a * a + q01 + q02, w1 = q01 + b * b + q12, w2 = q02 + q12 + c * c;
+    double e1[3];
+    if (w0 >= w1 && w0 >= w2) { e1[0] = a; e1[1] = c01; e1[2] = c02; }
+    else if (w1 >= w2) { e1[0] = c01; e1[1] = b; e1[2] = c12; }
+    else { e1[0] = c02; e1[1] = c12; e1[2] = c; }
+    const double pe = e1[0] * u[0] + e1[1] * u[1] + e1[2] * u[2];
+    e1[0] -= pe * u[0]; e1[1] -= pe * u[1]; e1[2] -= pe * u[2];
+    const double ie = lvba_rsq(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+    e1[0] *= ie; e1[1] *= ie; e1[2] *= ie;
+    const double e2[3] = {u[1] * e1[2] - u[2] * e1[1], u[2] * e1[0] - u[0] * e1[2], u[0] * e1[1] - u[1] * e1[0]};
+    // B = [e1 e2]^T C [e1 e2]
+    const double g1[3] = {c00 * e1[0] + c01 * e1[1] + c02 * e1[2], c01 * e1[0] + c11 * e1[1] + c12 * e1[2], c02 * e1[0] + c12 * e1[1] + c22 * e1[2]};
+    const double g2[3] = {c00 * e2[0] + c01 * e2[1] + c02 * e2[2], c01 * e2[0] + c11 * e2[1] + c12 * e2[2], c02 * e2[0] + c12 * e2[1] + c22 * e2[2]};
+    double b11 = e1[0] * g1[0] + e1[1] * g1[1] + e1[2] * g1[2];
+    double b22 = e2[0] * g2[0] + e2[1] * g2[1] + e2[2] * g2[2];
+    const double b12 = e1[0] * g2[0] + e1[1] * g2[1] + e1[2] * g2[2];
+    double cs = 1.0, sn = 0.0;
+    if (fabs(b12) > 1e-150) { // the rotation of LVBA_JROT, in its division-free form
+        const double d_ = b22 - b11, h_ = 2.0 * b12;
+        const double x_0 = fma(d_, d_, h_ * h_);
+        const double den_ = fabs(d_) + x_0 * lvba_rsq(x_0);
+        const double sg_ = (d_ == 0.0 || (d_ > 0.0) == (h_ > 0.0)) ? 1.0 : -1.0;
+        const double t_ = sg_ * fabs(h_) * lvba_rcp(den_);
+        cs = lvba_rsq(fma(t_, t_, 1.0));
+        sn = t_ * cs;
+        b11 -= t_ * b12;
+        b22 += t_ * b12;
+    }
+    double ua[3] = {cs * e1[0] - sn * e2[0], cs * e1[1] - sn * e2[1], cs * e1[2] - sn * e2[2]};
+    double ub[3] = {sn * e1[0] + cs * e2[0], sn * e1[1] + cs * e2[1], sn * e1[2] + cs * e2[2]};
+    if (b11 > b22) {
+        LVBA_SWAP(b11, b22);
+        LVBA_SWAP(ua[0], ub[0]); LVBA_SWAP(ua[1], ub[1]); LVBA_SWAP(ua[2], ub[2]);
+    }
+    lam[1] = b11; lam[2] = b22;
+    U[0] = u[0]; U[1] = ua[0]; U[2] = ub[0];
+    U[3] = u[1]; U[4] = ua[1]; U[5] = ub[1];
+    U[6] = u[2]; U[7] = ua[2]; U[8] = ub[2];
+}
+
 // Merged-voxel covariance from the summed world-frame statistics S[10] (bavoxel.hpp:97-98).
 template <bool FAST = false>
 LVBA_HD void voxel_cov(const double *S, double *C, double *vbar)
@@ -187,7 +274,7 @@ LVBA_HD double voxel_finish(const double *S, VoxRec &vr)
 {
     double C[6], lam[3], U[9];
     voxel_cov<true>(S, C, vr.vb);
-    eig3<true, true>(C, lam, U);
+    eig3_planar<true>(C, lam, U);
     vr.NN = S[9];
     const double k1 = lvba_rsq(0.5 * (lam[1] - lam[0])), k2 = lvba_rsq(0.5 * (lam[2] - lam[0])); // sqrt(2 / (lam_m - lam_0))
     vr.u0[0] = U[0]; vr.u0[1] = U[3]; vr.u0[2] = U[6];
@@ -200,7 +287,7 @@ LVBA_HD double voxel_lambda_min(const double *S)
 {
     double C[6], lam[3], vb[3];
     voxel_cov<true>(S, C, vb);
-    eig3<false, true>(C, lam, nullptr);
+    eig3_planar<false>(C, lam, nullptr);
     return lam[0];
 }
 

@@ -63,19 +63,23 @@ __global__ void ldlt_prepare_kernel(LdltMat M, const double *__restrict__ Hblk, 
         const int c = el / 6, r = el - c * 6;
         if (dI == 0 && r < c) continue;
         double v = Hblk[e];
-        if (dI == 0 && r == c) v += (grp ? u_dev[grp[J]] : u0) * v;
+        const double uj = grp ? u_dev[grp[J]] : u0;
+        // a group whose damping is negative is out of the game (its refinement has ended): identity block, zero right-hand
+        // side -- it cannot produce a zero pivot any more, and its step is zero (groups are block diagonal: I and J share it)
+        if (uj < 0.0) v = (dI == 0 && r == c) ? 1.0 : 0.0;
+        else if (dI == 0 && r == c) v += uj * v;
         const int64_t R = 6 * I + r, C = 6 * J + c;
         if (R < n1) M.a[R + C * M.ld] = v;
         else M.a[tw.sA + (n - 1 - C) + (n - 1 - R) * M.ld] = v; // row in B: reversed and transposed into the lower triangle
     }
     for (int64_t a = gid; a < n; a += gsz) {
-        if (a < n1) b[a] = -g[a];
+        if (a < n1) b[a] = (grp && u_dev[grp[a / 6]] < 0.0) ? 0.0 : -g[a];
         x[a] = x_fill; // the backward chain kernel's "not yet written" mark
     }
     if (tw.m > 0)
         for (int64_t a = gid; a < n1; a += gsz) {
             const int64_t i = n - 1 - a;
-            b[tw.sW + a] = (i >= n1) ? -g[i] : 0.0; // the S part of matrix 2's right-hand side only collects updates
+            b[tw.sW + a] = (i >= n1 && !(grp && u_dev[grp[i / 6]] < 0.0)) ? -g[i] : 0.0; // the S part of matrix 2's right-hand side only collects updates
             tw.x2[a] = x_fill;
         }
 }

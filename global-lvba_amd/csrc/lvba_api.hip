@@ -832,7 +832,9 @@ extern "C" int32_t lvba_balm_refine_groups(lvba_balm_t h, double *poses_inout, c
 
             launch_reduce_chunks_groups(h->d_chunk_cost, h->d_gco, G, c1, s);
         }
-        for (int32_t k = 0; k < G; ++k) u[(size_t)k] = st[(size_t)k].u;
+        // finished groups stay in the joint system as identity blocks (negative damping: ldlt_prepare_kernel): they cost
+        // nothing to factorise and cannot raise the pivot flag for the groups that are still running
+        for (int32_t k = 0; k < G; ++k) u[(size_t)k] = st[(size_t)k].done ? -1.0 : st[(size_t)k].u;
         ev_begin(h, EV_SOLVE);
         TRY(bs_enqueue_solve_groups(bs, u.data()));                                            // :692-710
         ev_end(h, EV_SOLVE);

@@ -37,6 +37,7 @@ struct PairDev {
                                //        < 0: -(1 + index into `partial`) (the block is summed from several items)
     const int2 *pairs;         // [Q] (position of block I's factor, position of block J's factor), I > J
     const double *Y;           // [F][18] per-factor Y, pose-major positions
+    int64_t y_bytes;           // size of Y (the pair kernel addresses it with 32-bit offsets when it is below 4 GB)
     double *partial;           // [n_partial][36] partial blocks of the cut lists
     int64_t n_multi;           // blocks assembled from several items
     const int64_t *multi_off;  // [n_multi+1] their ranges in multi_idx
@@ -146,9 +147,3 @@ void bcr_solve(const double *Hblk, int band_blocks, int n_poses, const double *g
                int *status, hipStream_t s);
 
 } // namespace lvba
-
-// lvba_balm_create with the clusters [F][10] already on `device` (the voxel front-end hands them over without a host
-// round trip); voxel_off / pose_idx are host arrays as in lvba_balm_create.
-struct lvba_balm_s;
-extern "C" int32_t lvba_balm_create_dev(int32_t n_poses, int64_t n_voxels, const int64_t *voxel_off, const int32_t *pose_idx,
-                                        const double *d_clusters, int32_t device, struct lvba_balm_s **out);

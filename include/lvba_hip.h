@@ -126,6 +126,12 @@ void lvba_shard_range(int64_t n_voxels, int32_t rank, int32_t n_ranks, int64_t *
 int32_t lvba_balm_create(int32_t n_poses, int64_t n_voxels, const int64_t *voxel_off,
                          const int32_t *pose_idx, const double *clusters, int32_t device,
                          lvba_balm_t *out);
+/* The same with the clusters [F][10] already on `device` (a hipMalloc'ed / HIP-visible pointer, indexed like the host array
+ * relative to voxel_off[0]): what the voxel front-end of this library hands over without a host round trip, and what a caller
+ * that builds its clusters on the GPU would use.  voxel_off / pose_idx stay host arrays.  The device array is only read during
+ * the call. */
+int32_t lvba_balm_create_dev(int32_t n_poses, int64_t n_voxels, const int64_t *voxel_off, const int32_t *pose_idx,
+                             const double *d_clusters, int32_t device, lvba_balm_t *out);
 int32_t lvba_balm_destroy(lvba_balm_t h);
 
 /* Optional, before the first cost/eval/refine call: pose ordering for the linear solver

@@ -88,6 +88,13 @@ extern "C" int emul_eig3(const double *C6, double *lam, double *U)
     eig3<true>(C6, lam, U);
     return 0;
 }
+// the direct decomposition the LM kernels use (Newton for lam0, cross products, one 2 x 2 rotation); lam0 alone: U == NULL
+extern "C" int emul_eig3_planar(const double *C6, double *lam, double *U)
+{
+    if (U) eig3_planar<true>(C6, lam, U);
+    else eig3_planar<false>(C6, lam, nullptr);
+    return 0;
+}
 
 // ---- visual stage: hand-derived Jacobians of global-lvba_amd/csrc/visual_math.h --------------------------------
 #include "../global-lvba_amd/csrc/visual_math.h"

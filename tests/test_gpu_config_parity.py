@@ -120,7 +120,7 @@ def test_c4_cost_and_one_lm_iteration(pkg, synth, oracle_mod):
     assert abs(prob.cost(d["poses_gt"]) - c_ref) <= 1e-8 * c_ref
     gi, gj, gblocks, g, c = prob.eval_blocks(x)
     bi, bj, blocks, gc, cc = co.eval_sparse(x, nthreads=_threads())
-    assert abs(c - cc) <= 1e-8 * cc and abs(prob.cost(x) - cc) <= 1e-8 * cc
+    assert abs(c - cc) <= 1e-8 * cc and abs(prob.cost(x) - cc * V) <= 1e-8 * cc * V    # (eval: averaged, cost: the sum)
     assert np.abs(g - gc).max() <= 1e-8 * np.abs(gc).max()
     worst, extra = oracle_mod.block_parity_sparse(gi, gj, gblocks, bi, bj, blocks, N)
     assert worst <= 1e-8 and extra <= 1e-12, (worst, extra)

@@ -182,7 +182,7 @@ def test_c3_two_ranks_full_lm_trace(pkg, synth):
     calls, nbytes = ht.stats()
     assert r0["info"]["n_ranks"] == 2 and r0["info"]["n_voxels_global"] == V and r0["info"]["solve_ranks"] == 2
     assert 50e6 < r0["info"]["allreduce_bytes"] < 0.75 * r0["info"]["hess_bytes"]       # the packed form, at size
-    assert nbytes > 10 * r0["info"]["allreduce_bytes"]                                   # ... and it did travel, every evaluation
+    assert nbytes > 5 * r0["info"]["allreduce_bytes"]                                    # ... and it did travel, every evaluation
     assert np.array_equal(r0["B"], r1["B"]) and np.array_equal(r0["g"], r1["g"]) and r0["c"] == r1["c"]
     assert np.array_equal(r0["x"], r1["x"]) and r0["trace"] == r1["trace"]
     # against the single-rank run: the union pattern may carry blocks that are zero on both shards' sum? no: the same blocks

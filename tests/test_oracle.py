@@ -200,6 +200,7 @@ def emul(tmp_path_factory):
     lib.emul_cost.argtypes = [ctypes.c_int, ctypes.c_int64, i64p, i32p, f64p, f64p, ctypes.POINTER(ctypes.c_double)]
     lib.emul_retract.argtypes = [ctypes.c_int, f64p, f64p, f64p]
     lib.emul_eig3.argtypes = [f64p, f64p, f64p]
+    lib.emul_eig3_planar.argtypes = [f64p, f64p, ctypes.c_void_p]
     return lib
 
 
@@ -241,6 +242,43 @@ def test_device_eig3_accuracy(emul):
     out_l, out_U = np.empty(3), np.empty(9)
     emul.emul_eig3(np.array([3.0, 0, 0, 1.0, 0, 2.0]), out_l, out_U)
     assert np.array_equal(out_l, [1.0, 2.0, 3.0])
+
+
+def test_device_eig3_planar_accuracy(emul):
+    """eig3_planar (csrc/balm_math.h: Newton on det(C - x I) for lam0, cross products for u0, one rotation for the other two) --
+    what the LM kernels run -- against LAPACK on plane-like covariances: one small eigenvalue (1e-6 .. 1e-2 of the largest, the
+    front-end admits lam0 / lam2 <= ~0.1), in-plane eigenvalues from well separated to equal."""
+    rng = np.random.default_rng(7)
+    worst_l0 = worst_res = 0.0
+    for trial in range(600):
+        Q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+        l2 = 10.0 ** rng.uniform(-3, 1)
+        l1 = l2 * (1.0 if trial % 7 == 0 else 10.0 ** rng.uniform(-1.5, 0))
+        l0 = l1 * 10.0 ** rng.uniform(-4, -0.9)
+        lam = np.array([l0, l1, l2])
+        C = Q @ np.diag(lam) @ Q.T
+        C = 0.5 * (C + C.T)
+        ref_l, ref_U = np.linalg.eigh(C)
+        C6 = np.array([C[0, 0], C[0, 1], C[0, 2], C[1, 1], C[1, 2], C[2, 2]])
+        out_l, out_U, l_only = np.empty(3), np.empty(9), np.empty(3)
+        emul.emul_eig3_planar(C6, out_l, out_U.ctypes.data)
+        emul.emul_eig3_planar(C6, l_only, None)
+        assert out_l[0] == l_only[0]
+        U = out_U.reshape(3, 3)
+        assert np.abs(out_l - ref_l).max() <= 1e-13 * l2
+        worst_l0 = max(worst_l0, abs(out_l[0] - ref_l[0]) / l2)   # (forming C in fp64 already moves lam0 by ~eps * l2)
+        assert np.abs(U.T @ U - np.eye(3)).max() <= 1e-13
+        worst_res = max(worst_res, np.abs(C @ U - U * out_l).max() / l2)
+        # what the kernels use: u0 and the weighted in-plane projector sum_m 2 / (lam0 - lam_m) u_m u_m^T
+        W = sum(2.0 / (out_l[0] - out_l[m]) * np.outer(U[:, m], U[:, m]) for m in (1, 2))
+        Wr = sum(2.0 / (ref_l[0] - ref_l[m]) * np.outer(ref_U[:, m], ref_U[:, m]) for m in (1, 2))
+        assert np.abs(W - Wr).max() <= 1e-9 * np.abs(Wr).max()
+        assert abs(abs(U[:, 0] @ ref_U[:, 0]) - 1.0) <= 1e-12
+    assert worst_l0 <= 2e-15 and worst_res <= 1e-13, (worst_l0, worst_res)
+    # already diagonal / repeated in-plane eigenvalues
+    out_l, out_U = np.empty(3), np.empty(9)
+    emul.emul_eig3_planar(np.array([3.0, 0, 0, 1e-3, 0, 3.0]), out_l, out_U.ctypes.data)
+    assert np.allclose(out_l, [1e-3, 3.0, 3.0], rtol=1e-14)
 
 
 def test_band_lm_twin_equals_dense_lm(oracle_mod):

@@ -1,7 +1,10 @@
 """profiles/traffic_rNN.json from the two separate rocprofv3 PMC passes of tools/gpu_pmc2.sh (FETCH_SIZE, WRITE_SIZE):
 HBM bytes per launch of the kernels of one H/g/cost evaluation and of the cost-only pass.
 
-  python tools/make_traffic.py <pmc_FETCH_SIZE.csv> <pmc_WRITE_SIZE.csv> <out.json> [git hash]
+  python tools/make_traffic.py <pmc_FETCH_SIZE.csv> <pmc_WRITE_SIZE.csv> <out.json> [config] [git hash]
+
+The file is bound to the configuration it was taken on and to a hash of the kernel sources (bench.py: kernel_source_sha16):
+bench.py quotes it only for that configuration, on one GPU, while those sources are unchanged.
 
 Corrections (MI355X_MICROARCH.md, HBM / rocprofv3): the counters are in KiB; on gfx950 FETCH_SIZE = TCC_EA0_RDREQ x 64 B
 tallies 128-byte requests at 64 B, so it is doubled -- calibrated here on balm_cost_kernel, whose algorithmic byte count is
@@ -10,7 +13,10 @@ bound for any 64-byte requests among them).  WRITE_SIZE x1.  bench.py only repor
 it times (EVAL_KERNELS / COST_KERNELS there)."""
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 EVAL_KERNELS = ["balm_voxel_kernel", "balm_factor_kernel", "balm_diag_reduce_kernel", "balm_pair_col_kernel", "balm_pair_reduce_kernel"]
 COST_KERNELS = ["balm_voxel_kernel"]   # the LM loop costs its trial point with the voxel pass (cost + voxel records)
@@ -20,7 +26,7 @@ def read(path):
     out = {}
     with open(path) as f:
         for row in csv.DictReader(f):
-            name = row["Name"].split("(")[0].split("::")[-1]
+            name = row["Name"].split("(")[0].split("::")[-1].split("<")[0]   # (template arguments dropped)
             out[name] = dict(kib=float(row["MeanValue"]), calls=int(row["Dispatches"]), ns=float(row["MeanDurationNs"]))
     return out
 
@@ -37,8 +43,10 @@ def main():
         "eval": sum(per[k]["fetch"] + per[k]["write"] for k in EVAL_KERNELS),
         "cost": sum(per[k]["fetch"] + per[k]["write"] for k in COST_KERNELS),
         "eval_kernels": EVAL_KERNELS, "cost_kernels": COST_KERNELS,
-        "unit": "bytes per launch (C3, 1 GPU)",
-        "git": sys.argv[4] if len(sys.argv) > 4 else None,
+        "unit": "bytes per launch (1 GPU)",
+        "config": sys.argv[4] if len(sys.argv) > 4 else "C3",
+        "kernel_source_sha16": __import__("bench").kernel_source_sha16(),
+        "git": sys.argv[5] if len(sys.argv) > 5 else None,
         "source": "tools/gpu_pmc2.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py --no-visual --no-front-end",
         "correction": "KiB -> bytes; FETCH_SIZE x2 (gfx950: 128-byte requests tallied at 64 B; calibrated on balm_cost_kernel), WRITE_SIZE x1",
         "per_kernel": per,
