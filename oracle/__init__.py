@@ -345,6 +345,10 @@ def load_ref():
             lib.ref_visual_jacobian_pass.restype = c_dbl
             lib.ref_visual_jacobian_pass.argtypes = [c_i64, i64p, i32p, f64p, f64p, f64p, f64p, f64p, u8p, f64p, c_dbl, c_dbl, c_int,
                                                      ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl)]
+        if hasattr(lib, "ref_visual_reduced_system"):
+            lib.ref_visual_reduced_system.restype = c_int
+            lib.ref_visual_reduced_system.argtypes = [c_int, c_i64, i64p, i32p, f64p, f64p, f64p, f64p, f64p, u8p, f64p, c_dbl, c_dbl,
+                                                      c_dbl, c_dbl, c_dbl, c_int, c_int, f64p, f64p, ctypes.POINTER(c_dbl), f64p]
         lib.ref_plane.argtypes = [f64p, c_dbl, c_dbl, f64p, f64p, f64p]
         for fn in (lib.ref_distort, lib.ref_undistort):
             fn.restype, fn.argtypes = c_int, [f64p, c_dbl, c_dbl, f64p]
@@ -436,6 +440,26 @@ class Reference:
                                                 self._c(intr), float(sigma_px), float(max(1e-9, sigma_plane)), int(nthreads),
                                                 ctypes.byref(c), ctypes.byref(js))
         return float(sec), c.value
+
+    def visual_reduced_system(self, q, t, X, obs_off, obs_cam, obs_uv, plane, valid, intr, radius=1e4, sigma_px=0.5,
+                              sigma_plane=0.01, kb=3, min_diag=1e-6, max_diag=1e32, nthreads=None):
+        """The reduced camera system of one LM step from the reference's own functors + Jets (ref_glue_visual.cpp:
+        ref_visual_reduced_system; the Ceres-internal steps between functors and solver are restated there).  Returns
+        (Sband [M, kb+1, 6, 6] lower blocks S[a, a-d], rhs [6M], cost, widest camera pair, Jacobi scales of the camera columns)."""
+        if nthreads is None:
+            nthreads = min(64, os.cpu_count() or 1)
+        M = len(q)
+        Sb = np.zeros((M, kb + 1, 6, 6))
+        rhs = np.zeros(6 * M)
+        scale = np.zeros(6 * M)
+        c = ctypes.c_double()
+        far = self.lib.ref_visual_reduced_system(M, len(obs_off) - 1, self._c(obs_off, np.int64), self._c(obs_cam, np.int32),
+                                                 self._c(obs_uv).reshape(-1), self._c(q).reshape(-1), self._c(t).reshape(-1),
+                                                 self._c(X).reshape(-1), self._c(plane).reshape(-1), self._c(valid, np.uint8),
+                                                 self._c(intr), float(sigma_px), float(max(1e-9, sigma_plane)), float(radius),
+                                                 float(min_diag), float(max_diag), int(kb), int(nthreads), Sb.reshape(-1), rhs,
+                                                 ctypes.byref(c), scale)
+        return Sb, rhs, c.value, int(far), scale
 
     def map_build(self, clouds, poses, voxel_size, eigen_ratio=(0.3, 0.1, 0.06, 0.03)):
         """cut_voxel + recut + tras_opt as the reference's call sites run them.  Returns dict(keys [P,4] (x, y, z,

@@ -7,6 +7,9 @@
 // oracle/track_oracle.py's camera model and global-lvba_amd/dataset.py's timestamp parser.
 #include "utils.hpp"
 #include <omp.h>
+#include <vector>
+#include <algorithm>
+#include <cmath>
 
 extern "C" {
 
@@ -52,6 +55,193 @@ double ref_visual_jacobian_pass(int64_t n_tracks, const int64_t *obs_off, const 
     *cost = 0.5 * c;
     *jac_sum = js;
     return dt;
+}
+
+// The reduced camera system of one Levenberg-Marquardt step at (q, t, X), built from the reference's own functors differentiated
+// with Jets (the residuals and ambient Jacobians are the reference's arithmetic), for problems of any size (OpenMP over the
+// landmarks): what tests/test_gpu_visual.py holds the HIP path's S and rhs against at the BASELINE.json scale.  What is
+// RESTATED here is what Ceres does between the cost functors and the linear solver (from memory of Ceres 2.1, like
+// oracle/visual_oracle.py: the iterations inside ceres::Solve stay "parity unpinned"):
+//   tangent Jacobian  J_q (2 x 4) . PlusJacobian(q) (4 x 3) of EigenQuaternionManifold applied to the [w,x,y,z] memory as the
+//                     reference does (src/lvba_system.cpp:1579); camera 0 is constant (:1582-1583): no columns;
+//   Jacobi scaling    column k scaled by 1 / (1 + ||column k||), norms at this point;
+//   LM diagonal       D_k^2 = clamp(||scaled column k||^2, min_diag, max_diag) / radius;
+//   Schur complement  S = B + D_c^2 - E (C + D_p^2)^-1 E^T,  rhs = Jc^T r - E (C + D_p^2)^-1 Jp^T r   (DENSE_SCHUR).
+// Output: the lower blocks of S inside a camera half-bandwidth kb, Sband[(a * (kb + 1) + (a - b)) * 36 + 6 r + c] =
+// S[6 a + r][6 b + c] for 0 <= a - b <= kb (camera 0's rows and columns are zero), rhs [6 M], *cost = 1/2 sum r^2; returns the
+// largest |a - b| of a coupled camera pair (the caller checks it against kb); scale_c (optional) receives the Jacobi scales of
+// the camera columns (a solution x of S x = rhs is the camera step -scale_c . x in the tangent space).
+int ref_visual_reduced_system(int n_cams, int64_t n_tracks, const int64_t *obs_off, const int32_t *obs_cam, const double *obs_uv,
+                              const double *q, const double *t, const double *X, const double *plane, const uint8_t *valid,
+                              const double *intr, double sigma_px, double sigma_plane, double radius, double min_diag, double max_diag,
+                              int kb, int nthreads, double *Sband, double *rhs, double *cost, double *scale_c /* [6 M] or NULL */)
+{
+    typedef ceres::Jet<double, 10> J10;
+    typedef ceres::Jet<double, 3> J3;
+    const int M = n_cams;
+    const size_t nS = (size_t)M * (kb + 1) * 36;
+    struct Obs { double r[2], Jc[2][6], Jp[2][3]; int cam; };
+    auto eval_obs = [&](int64_t o, const double *Xa, Obs &ob) {
+        const int m = obs_cam[o];
+        lvba::ReprojErrorWhitenedDistorted f(obs_uv[2 * o], obs_uv[2 * o + 1], intr[0], intr[1], intr[2], intr[3], intr[4], intr[5],
+                                             intr[6], intr[7], sigma_px, sigma_px);
+        J10 jq[4], jt[3], jX[3], jr[2];
+        for (int i = 0; i < 4; ++i) jq[i] = J10(q[4 * m + i], i);
+        for (int i = 0; i < 3; ++i) jt[i] = J10(t[3 * m + i], 4 + i);
+        for (int i = 0; i < 3; ++i) jX[i] = J10(Xa[i], 7 + i);
+        f(jq, jt, jX, jr);
+        const double x0 = q[4 * m], x1 = q[4 * m + 1], x2 = q[4 * m + 2], x3 = q[4 * m + 3];
+        const double P[4][3] = {{x3, x2, -x1}, {-x2, x3, x0}, {x1, -x0, x3}, {-x0, -x1, -x2}}; // PlusJacobian on the memory as given
+        ob.cam = m;
+        for (int a = 0; a < 2; ++a) {
+            ob.r[a] = jr[a].a;
+            for (int k = 0; k < 3; ++k) {
+                double s = 0.0;
+                for (int i = 0; i < 4; ++i) s += jr[a].v[i] * P[i][k];
+                ob.Jc[a][k] = s;
+                ob.Jc[a][3 + k] = jr[a].v[4 + k];
+                ob.Jp[a][k] = jr[a].v[7 + k];
+            }
+        }
+    };
+    auto eval_plane = [&](int64_t a, double &r, double (&J)[3]) {
+        lvba::PointPlaneErrorWhitened fp(Eigen::Vector3d(plane[4 * a], plane[4 * a + 1], plane[4 * a + 2]), plane[4 * a + 3], sigma_plane);
+        J3 jX[3], jr[1];
+        for (int i = 0; i < 3; ++i) jX[i] = J3(X[3 * a + i], i);
+        fp(jX, jr);
+        r = jr[0].a;
+        for (int i = 0; i < 3; ++i) J[i] = jr[0].v[i];
+    };
+    // pass 1: squared column norms of the (unscaled) tangent Jacobian -- per camera (6), per landmark (3) -- and the cost
+    std::vector<double> cn((size_t)6 * M, 0.0), pn((size_t)3 * n_tracks, 0.0);
+    double c = 0.0;
+    int far = 0;
+#pragma omp parallel num_threads(nthreads)
+    {
+        std::vector<double> my((size_t)6 * M, 0.0);
+        double myc = 0.0;
+        int myfar = 0;
+#pragma omp for schedule(dynamic, 256)
+        for (int64_t a = 0; a < n_tracks; ++a) {
+            if (!valid[a]) continue;
+            int lo = M, hi = -1;
+            for (int64_t o = obs_off[a]; o < obs_off[a + 1]; ++o) {
+                Obs ob;
+                eval_obs(o, X + 3 * a, ob);
+                lo = ob.cam < lo ? ob.cam : lo; hi = ob.cam > hi ? ob.cam : hi;
+                for (int r2 = 0; r2 < 2; ++r2) {
+                    myc += ob.r[r2] * ob.r[r2];
+                    for (int k = 0; k < 6; ++k) my[(size_t)6 * ob.cam + k] += ob.Jc[r2][k] * ob.Jc[r2][k];
+                    for (int k = 0; k < 3; ++k) pn[(size_t)3 * a + k] += ob.Jp[r2][k] * ob.Jp[r2][k];
+                }
+            }
+            double rp, Jpl[3];
+            eval_plane(a, rp, Jpl);
+            myc += rp * rp;
+            for (int k = 0; k < 3; ++k) pn[(size_t)3 * a + k] += Jpl[k] * Jpl[k];
+            if (hi >= 0 && hi - lo > myfar) myfar = hi - lo;
+        }
+#pragma omp critical
+        {
+            for (size_t i = 0; i < my.size(); ++i) cn[i] += my[i];
+            c += myc;
+            if (myfar > far) far = myfar;
+        }
+    }
+    *cost = 0.5 * c;
+    std::vector<double> sc((size_t)6 * M), d2c((size_t)6 * M);
+    for (size_t i = 0; i < sc.size(); ++i) {
+        sc[i] = 1.0 / (1.0 + std::sqrt(cn[i]));
+        const double v = sc[i] * sc[i] * cn[i];
+        d2c[i] = (v < min_diag ? min_diag : v > max_diag ? max_diag : v) / radius;
+        if (scale_c) scale_c[i] = sc[i];
+    }
+    // pass 2: Schur products into per-thread band accumulators
+    std::fill(Sband, Sband + nS, 0.0);
+    std::fill(rhs, rhs + (size_t)6 * M, 0.0);
+#pragma omp parallel num_threads(nthreads)
+    {
+        std::vector<double> S(nS, 0.0), g((size_t)6 * M, 0.0);
+        std::vector<Obs> obs;
+#pragma omp for schedule(dynamic, 256)
+        for (int64_t a = 0; a < n_tracks; ++a) {
+            if (!valid[a]) continue;
+            double sp[3], Cm[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, gp[3] = {0, 0, 0};
+            for (int k = 0; k < 3; ++k) sp[k] = 1.0 / (1.0 + std::sqrt(pn[(size_t)3 * a + k]));
+            obs.clear();
+            for (int64_t o = obs_off[a]; o < obs_off[a + 1]; ++o) {
+                Obs ob;
+                eval_obs(o, X + 3 * a, ob);
+                for (int r2 = 0; r2 < 2; ++r2) {
+                    for (int k = 0; k < 6; ++k) ob.Jc[r2][k] *= sc[(size_t)6 * ob.cam + k];
+                    for (int k = 0; k < 3; ++k) ob.Jp[r2][k] *= sp[k];
+                }
+                for (int r2 = 0; r2 < 2; ++r2)
+                    for (int i = 0; i < 3; ++i) {
+                        gp[i] += ob.Jp[r2][i] * ob.r[r2];
+                        for (int j = 0; j < 3; ++j) Cm[i][j] += ob.Jp[r2][i] * ob.Jp[r2][j];
+                    }
+                obs.push_back(ob);
+            }
+            double rp, Jpl[3];
+            eval_plane(a, rp, Jpl);
+            for (int i = 0; i < 3; ++i) {
+                Jpl[i] *= sp[i];
+                gp[i] += Jpl[i] * rp;
+            }
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) Cm[i][j] += Jpl[i] * Jpl[j];
+            for (int k = 0; k < 3; ++k) {
+                const double v = sp[k] * sp[k] * pn[(size_t)3 * a + k];
+                Cm[k][k] += (v < min_diag ? min_diag : v > max_diag ? max_diag : v) / radius;
+            }
+            // C^-1 (3 x 3 symmetric positive definite) by cofactors
+            const double c00 = Cm[1][1] * Cm[2][2] - Cm[1][2] * Cm[2][1], c01 = Cm[0][2] * Cm[2][1] - Cm[0][1] * Cm[2][2],
+                         c02 = Cm[0][1] * Cm[1][2] - Cm[0][2] * Cm[1][1];
+            const double det = Cm[0][0] * c00 + Cm[1][0] * c01 + Cm[2][0] * c02;
+            double Ci[3][3];
+            Ci[0][0] = c00 / det; Ci[0][1] = c01 / det; Ci[0][2] = c02 / det;
+            Ci[1][0] = Ci[0][1]; Ci[1][1] = (Cm[0][0] * Cm[2][2] - Cm[0][2] * Cm[2][0]) / det; Ci[1][2] = (Cm[0][2] * Cm[1][0] - Cm[0][0] * Cm[1][2]) / det;
+            Ci[2][0] = Ci[0][2]; Ci[2][1] = Ci[1][2]; Ci[2][2] = (Cm[0][0] * Cm[1][1] - Cm[0][1] * Cm[1][0]) / det;
+            double Cig[3];
+            for (int i = 0; i < 3; ++i) Cig[i] = Ci[i][0] * gp[0] + Ci[i][1] * gp[1] + Ci[i][2] * gp[2];
+            const size_t no = obs.size();
+            std::vector<double> E(no * 18), EC(no * 18); // E_i = Jc_i^T Jp_i (6 x 3), EC_i = E_i C^-1
+            for (size_t i = 0; i < no; ++i)
+                for (int r = 0; r < 6; ++r)
+                    for (int k = 0; k < 3; ++k) E[i * 18 + 3 * r + k] = obs[i].Jc[0][r] * obs[i].Jp[0][k] + obs[i].Jc[1][r] * obs[i].Jp[1][k];
+            for (size_t i = 0; i < no; ++i)
+                for (int r = 0; r < 6; ++r)
+                    for (int k = 0; k < 3; ++k)
+                        EC[i * 18 + 3 * r + k] = E[i * 18 + 3 * r] * Ci[0][k] + E[i * 18 + 3 * r + 1] * Ci[1][k] + E[i * 18 + 3 * r + 2] * Ci[2][k];
+            for (size_t i = 0; i < no; ++i) {
+                const int ca = obs[i].cam;
+                if (ca == 0) continue; // constant
+                double *ga = g.data() + (size_t)6 * ca;
+                for (int r = 0; r < 6; ++r)
+                    ga[r] += obs[i].Jc[0][r] * obs[i].r[0] + obs[i].Jc[1][r] * obs[i].r[1] - (E[i * 18 + 3 * r] * Cig[0] + E[i * 18 + 3 * r + 1] * Cig[1] + E[i * 18 + 3 * r + 2] * Cig[2]);
+                double *Baa = S.data() + ((size_t)ca * (kb + 1)) * 36;
+                for (int r = 0; r < 6; ++r)
+                    for (int c2 = 0; c2 < 6; ++c2) Baa[6 * r + c2] += obs[i].Jc[0][r] * obs[i].Jc[0][c2] + obs[i].Jc[1][r] * obs[i].Jc[1][c2];
+                for (size_t j = 0; j < no; ++j) {
+                    const int cb = obs[j].cam;
+                    if (cb == 0 || cb > ca || ca - cb > kb) continue; // lower blocks inside the band
+                    double *Sab = S.data() + ((size_t)ca * (kb + 1) + (size_t)(ca - cb)) * 36;
+                    for (int r = 0; r < 6; ++r)
+                        for (int c2 = 0; c2 < 6; ++c2)
+                            Sab[6 * r + c2] -= EC[i * 18 + 3 * r] * E[j * 18 + 3 * c2] + EC[i * 18 + 3 * r + 1] * E[j * 18 + 3 * c2 + 1] + EC[i * 18 + 3 * r + 2] * E[j * 18 + 3 * c2 + 2];
+                }
+            }
+        }
+#pragma omp critical
+        {
+            for (size_t i = 0; i < nS; ++i) Sband[i] += S[i];
+            for (size_t i = 0; i < g.size(); ++i) rhs[i] += g[i];
+        }
+    }
+    for (int a = 1; a < M; ++a) // the LM diagonal of the camera part
+        for (int k = 0; k < 6; ++k) Sband[((size_t)a * (kb + 1)) * 36 + 7 * k] += d2c[(size_t)6 * a + k];
+    return far;
 }
 
 // ReprojErrorWhitenedDistorted (utils.hpp:51-127).  intr = fx fy cx cy k1 k2 p1 p2.  r[2]; J [2][10] = d r / d (q[4], t[3], X[3])

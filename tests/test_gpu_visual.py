@@ -245,3 +245,69 @@ def test_block_cyclic_reduction_equals_band_ldlt(pkg, synth, monkeypatch, n_cams
     # direct solvers agree to ~1e-10 in the costs and correspondingly less in the variables
     assert np.abs(q1 - q0).max() <= 1e-7 and np.abs(t1 - t0).max() <= 1e-6 and np.abs(X1 - X0).max() <= 1e-5
     assert tr1[-1]["cost"] < 0.1 * tr1[0]["cost"]
+
+
+def test_reduced_camera_system_at_c3_scale_matches_reference_functors(pkg, synth, monkeypatch):
+    """The visual stage AT THE BASELINE.json SCALE (2 000 cameras x 125 000 landmarks x 500 k observations) against the
+    reference's own cost functors differentiated with Jets (oracle/_ref, ref_visual_reduced_system: residuals and ambient
+    Jacobians are the reference's arithmetic; manifold, Jacobi scaling, LM diagonal and Schur complement restated in C++):
+    cost, every block of the reduced camera system S inside its band, nothing outside it, the reduced right-hand side -- and the
+    cameras after the FIRST LM iteration, with the reduced system solved by block cyclic reduction (default) and by the band
+    LDL^T (LVBA_BCR=0), against a LAPACK banded solve of the reference-functor system."""
+    import oracle
+    from scipy.linalg import solveh_banded
+    from oracle import visual_oracle as vo
+    if not oracle.Reference.available():
+        pytest.skip("oracle/_ref/libbalm_ref.so absent")
+    ref = oracle.Reference()
+    M, T = 2000, 125_000
+    d = synth.make_visual_problem(M, T, device="cuda")
+    args = (d["q"], d["t"], d["X"])
+    radius, kb = 1e4, 3
+    Sb, rhs_r, c_r, far, sc = ref.visual_reduced_system(*args, d["obs_off"], d["obs_cam"], d["obs_uv"], d["plane"], d["valid"], d["intr"],
+                                                       radius=radius, kb=kb)
+    assert far <= kb
+    # the first step of the reference-functor system: S x = rhs (cameras 1 .. M-1), step = -scale . x, manifold Plus
+    n = 6 * (M - 1)
+    bwid = 6 * kb + 5
+    ab = np.zeros((bwid + 1, n))                             # LAPACK lower band storage: ab[i - j, j] = S[i, j]
+    for a in range(1, M):
+        for dd in range(min(kb, a - 1) + 1):
+            blk = Sb[a, dd]
+            for r in range(6):
+                for c in range(6):
+                    i, j = 6 * (a - 1) + r, 6 * (a - 1 - dd) + c
+                    if i >= j:
+                        ab[i - j, j] = blk[r, c]
+    x = solveh_banded(ab, rhs_r[6:], lower=True)
+    step = -(sc[6:] * x).reshape(M - 1, 6)
+    q_ref, t_ref = d["q"].copy(), d["t"].copy()
+    for cidx in range(1, M):
+        q_ref[cidx] = vo.eigen_quat_plus(d["q"][cidx], step[cidx - 1, :3])
+        t_ref[cidx] = d["t"][cidx] + step[cidx - 1, 3:]
+    q_ref /= np.linalg.norm(q_ref, axis=1, keepdims=True)   # the write-back normalises (src/lvba_system.cpp:1653)
+    for bcr in ("1", "0"):
+        monkeypatch.setenv("LVBA_BCR", bcr)
+        prob = pkg.VisualProblem(M, d["obs_off"], d["obs_cam"], d["obs_uv"], d["plane"], d["valid"], d["intr"])
+        if bcr == "1":
+            S, rhs, c = prob.linearize(*args, radius)
+            assert abs(c - c_r) <= 1e-11 * c_r
+            assert np.array_equal(S, S.T)
+            worst = 0.0
+            Sv = S.reshape(M, 6, M, 6)
+            scale_S = np.abs(Sb).max()
+            for dd in range(kb + 1):
+                a = np.arange(max(1, dd + 1), M)
+                got = Sv[a, :, a - dd, :]                    # [len, 6, 6]
+                worst = max(worst, float(np.abs(got - Sb[a, dd]).max()) / scale_S)
+                Sv[a, :, a - dd, :] = 0.0
+                if dd:
+                    Sv[a - dd, :, a, :] = 0.0
+            assert worst <= 1e-9, worst
+            assert np.abs(S[6:, 6:]).max() == 0.0           # nothing outside the band
+            assert np.abs(rhs[6:] - rhs_r[6:]).max() <= 1e-9 * np.abs(rhs_r).max()
+            del S, Sv
+        (q1, t1, X1), trace, term, rc = prob.refine(*args, max_iter=1)
+        assert rc == 0 and len(trace) == 2 and trace[1]["accepted"] == 1
+        assert np.abs(t1 - t_ref).max() <= 1e-8 and np.abs(q1 - q_ref).max() <= 1e-9, (bcr, np.abs(t1 - t_ref).max())
+        prob.close()
