@@ -249,6 +249,9 @@ __global__ __launch_bounds__(256) void balm_factor_kernel(BalmDev d, const doubl
     __shared__ double red[4 * 27];
     __shared__ double Ys[4 * 64 * 19];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // (An XCD-aware order -- every XCD a contiguous eighth of the (pose, slice) list, so that neighbouring poses' gathers of
+    // the same voxel records meet in one L2 -- was measured in round 3: FETCH_SIZE unchanged at 2.1 GB, 0.63 vs 0.61 ms.  A
+    // voxel's ~5 observers are spread over ~100 poses; the ~16 poses an XCD has in flight rarely hold two of them.)
     const int I = blockIdx.x / d.S, s = blockIdx.x - I * d.S;
     const int64_t seg0 = d.csc_off[I], len = d.csc_off[I + 1] - seg0;
     const int64_t a = seg0 + (len * s) / d.S, b = seg0 + (len * (s + 1)) / d.S;
@@ -441,10 +444,14 @@ __global__ __launch_bounds__(256) void balm_pair_staged_kernel(PairDev d, double
 // with a single item goes straight into the store, the others into partial blocks in item order).
 // ------------------------------------------------------------------------------------------------
 #define LVBA_PC_ITEMS 10 // items per wavefront (6 lanes each; lanes 60..63 only help fetching)
-#define LVBA_PC_DEPTH 2  // pairs of every item per round: the gathers of a round are what hides the memory latency
-// BUF: the Y records through buffer addressing (resource + one 32-bit byte offset per load) instead of 64-bit flat addresses --
-// six fewer 64-bit multiply-adds per lane and round; for Y arrays below 4 GB (29.8 M factors per shard), else the flat form.
-template <bool BUF>
+#ifndef LVBA_PC_DEPTH
+#define LVBA_PC_DEPTH 1  // pairs of every item per round.  With the next round's gathers in flight during a round (below) one pair
+                         // per round is best: 90 VGPRs, five wavefronts per SIMD (C3, factor + pair passes: 1.69 ms; two pairs
+                         // 1.75, three 1.79, four 1.94)
+#endif
+#ifndef LVBA_PC_PF
+#define LVBA_PC_PF 1     // rounds whose gathers are in flight ahead of the one being multiplied (1 or 2)
+#endif
 __global__ __launch_bounds__(256) void balm_pair_col_kernel(PairDev d, double *__restrict__ Hblk)
 {
     constexpr int NCH = LVBA_PC_ITEMS * LVBA_PC_DEPTH * 18; // 16-byte chunks per round
@@ -490,36 +497,30 @@ __global__ __launch_bounds__(256) void balm_pair_col_kernel(PairDev d, double *_
     double acc[6];
 #pragma unroll
     for (int e = 0; e < 6; ++e) acc[e] = 0.0;
-    // Software pipeline: round r + 1's records are requested as soon as round r's have been parked in LDS, so their way through
-    // L2 / HBM overlaps the LDS reads and FMAs of round r (before: gather -> LDS -> FMA, one dependent chain per round).
-    double2 v[NLD];
-    const __amdgpu_buffer_rsrc_t r_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(d.Y), 0, 0xFFFFFFF0u, 0x00020000);
-    auto fetch = [&](int r) {
+    // Software pipeline: the records of round r + LVBA_PC_PF are requested as soon as round r's have been parked in LDS, so their
+    // way through L2 / HBM overlaps the LDS reads and FMAs of the rounds before (round 2: gather -> LDS -> FMA, one dependent
+    // chain per round).
+    double2 v[LVBA_PC_PF][NLD];
+    // (buffer addressing for these gathers -- 32-bit offsets instead of 64-bit flat addresses -- was measured in round 3: no change)
+    auto fetch = [&](int r, double2 (&vv)[NLD]) {
 #pragma unroll
         for (int s2 = 0; s2 < NLD; ++s2) {
             const int pi = LVBA_PC_DEPTH * r + c_dep[s2]; // this chunk's pair of its item
-            v[s2] = make_double2(0.0, 0.0);
+            vv[s2] = make_double2(0.0, 0.0);
             if (pi < c_len[s2]) {
                 const int2 pr = pl[c_fa[s2] + pi];
-                const int pos = c_side[s2] ? pr.y : pr.x;
-                if (BUF) {
-                    typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
-                    const v4u_ a = __builtin_amdgcn_raw_buffer_load_b128(r_y, 144u * (unsigned)pos + 16u * (unsigned)c_piece[s2], 0, 0);
-                    v[s2] = make_double2(__hiloint2double((int)a.y, (int)a.x), __hiloint2double((int)a.w, (int)a.z));
-                } else
-                    v[s2] = reinterpret_cast<const double2 *>(d.Y + 18 * (int64_t)pos)[c_piece[s2]];
+                vv[s2] = reinterpret_cast<const double2 *>(d.Y + 18 * (int64_t)(c_side[s2] ? pr.y : pr.x))[c_piece[s2]];
             }
         }
     };
-    if (rounds > 0) fetch(0);
-    for (int r = 0; r < rounds; ++r) {
+    auto round_body = [&](int r, double2 (&vv)[NLD]) { // vv holds round r; it is refilled with round r + LVBA_PC_PF
 #pragma unroll
         for (int s2 = 0; s2 < NLD; ++s2) {
             const int c = lane + 64 * s2;
-            if (c < NCH) rw[c] = v[s2];
+            if (c < NCH) rw[c] = vv[s2];
         }
         __builtin_amdgcn_wave_barrier();
-        if (r + 1 < rounds) fetch(r + 1);
+        if (r + LVBA_PC_PF < rounds) fetch(r + LVBA_PC_PF, vv);
 #pragma unroll
         for (int dep = 0; dep < LVBA_PC_DEPTH; ++dep) {
             if (owner && LVBA_PC_DEPTH * r + dep < mylen) {
@@ -537,6 +538,14 @@ __global__ __launch_bounds__(256) void balm_pair_col_kernel(PairDev d, double *_
             }
         }
         __builtin_amdgcn_wave_barrier();
+    };
+#pragma unroll
+    for (int k = 0; k < LVBA_PC_PF; ++k)
+        if (k < rounds) fetch(k, v[k]);
+    for (int r = 0; r < rounds; r += LVBA_PC_PF) {
+#pragma unroll
+        for (int k = 0; k < LVBA_PC_PF; ++k)
+            if (r + k < rounds) round_body(r + k, v[k]);
     }
     if (owner) {
         const int64_t dst = d.blk_slot[i0 + g];
@@ -750,9 +759,7 @@ void launch_pairs(const PairDev &pd, double *Hblk, hipStream_t s)
     if (pd.nnzb > 0) {
         if (pd.col_form) {
             const dim3 grid((unsigned)((((pd.nnzb + 4 * LVBA_PC_ITEMS - 1) / (4 * LVBA_PC_ITEMS)) + 7) / 8 * 8));
-            static const bool flat = [] { const char *e = getenv("LVBA_PAIR_FLAT"); return e && !strcmp(e, "1"); }(); // (A/B)
-            if (pd.y_bytes < 0xFFFFFF00ll && !flat) hipLaunchKernelGGL(balm_pair_col_kernel<true>, grid, dim3(256), 0, s, pd, Hblk);
-            else hipLaunchKernelGGL(balm_pair_col_kernel<false>, grid, dim3(256), 0, s, pd, Hblk);
+            hipLaunchKernelGGL(balm_pair_col_kernel, grid, dim3(256), 0, s, pd, Hblk);
         } else {
             const dim3 grid((unsigned)((((pd.nnzb + 15) / 16) + 7) / 8 * 8));
             hipLaunchKernelGGL(balm_pair_staged_kernel, grid, dim3(256), 0, s, pd, Hblk);

@@ -72,7 +72,7 @@ struct BlockSys {
     PairDev pair_dev() const
     {
         PairDev p;
-        p.nnzb = n_items; p.blk_off = d_blk_off; p.blk_slot = d_blk_slot; p.pairs = d_pairs; p.Y = d_Y; p.y_bytes = 144 * F;
+        p.nnzb = n_items; p.blk_off = d_blk_off; p.blk_slot = d_blk_slot; p.pairs = d_pairs; p.Y = d_Y;
         p.partial = d_partial; p.n_multi = n_multi; p.multi_off = d_multi_off; p.multi_slot = d_multi_slot; p.multi_idx = d_multi_idx; p.col_form = pair_col ? 1 : 0;
         return p;
     }

@@ -458,11 +458,11 @@ static int32_t download_poses(lvba_balm_s *h, const double *d_src, double *poses
 {
     const size_t bytes = (size_t)12 * h->N * sizeof(double);
     if (bytes <= lvba::HostStage::kBytes) { // zero-copy, like upload_poses
-        if (void *st = lvba::HostStage::get().lock()) {
+        if (void *st = lvba::HostStage::get().lock(bytes)) {
             launch_export_poses(d_src, h->bs.d_perm, h->N, static_cast<double *>(st), h->stream());
             const hipError_t e = hipStreamSynchronize(h->stream());
             if (e == hipSuccess) memcpy(poses_out, st, bytes);
-            lvba::HostStage::get().unlock();
+            lvba::HostStage::get().unlock(st);
             HIPCHK(e);
             return LVBA_OK;
         }
@@ -477,12 +477,11 @@ static int32_t upload_poses(lvba_balm_s *h, const double *poses, double *d_dst)
 {
     const size_t bytes = (size_t)12 * h->N * sizeof(double);
     if (bytes <= lvba::HostStage::kBytes) { // zero-copy through the process-wide pinned stage (mempool.h)
-        if (void *st = lvba::HostStage::get().lock()) {
+        if (void *st = lvba::HostStage::get().lock(bytes)) {
             memcpy(st, poses, bytes);
             launch_import_poses(static_cast<const double *>(st), h->bs.d_perm, h->N, d_dst, h->stream());
             const hipError_t e = hipStreamSynchronize(h->stream()); // the kernel has read the stage
-
-            lvba::HostStage::get().unlock();
+            lvba::HostStage::get().unlock(st);
             HIPCHK(e);
             return LVBA_OK;
         }

@@ -37,7 +37,6 @@ struct PairDev {
                                //        < 0: -(1 + index into `partial`) (the block is summed from several items)
     const int2 *pairs;         // [Q] (position of block I's factor, position of block J's factor), I > J
     const double *Y;           // [F][18] per-factor Y, pose-major positions
-    int64_t y_bytes;           // size of Y (the pair kernel addresses it with 32-bit offsets when it is below 4 GB)
     double *partial;           // [n_partial][36] partial blocks of the cut lists
     int64_t n_multi;           // blocks assembled from several items
     const int64_t *multi_off;  // [n_multi+1] their ranges in multi_idx

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <cstddef>
 #include <cstdint>
+#include <condition_variable>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -120,29 +121,45 @@ inline hipError_t copy_d2h(void *dst, const void *src, size_t bytes) { return co
 // (zero-copy) instead of by a copy: the pose array of a refinement (30 KB for a window stage) goes up once and comes down once
 // per call, on handles that live for a few milliseconds; through this stage that is a memcpy and a kernel reading over the host
 // link -- no copy-engine submission, no pinning of the caller's pages, nothing to unpin.  Pinned and mapped once per process.
-// lock() ... unlock() bracket one use (several host threads drive windows concurrently).
+// The stage is cut into kSlots slots: lock(bytes) hands out a free one (several host threads drive windows concurrently, each
+// holds its slot across its own stream synchronise without stopping the others; a caller waits only when all slots are taken),
+// unlock(p) gives it back.  Requests larger than a slot get nullptr (the caller takes the plain copy).
 class HostStage {
   public:
-    static constexpr size_t kBytes = (size_t)1 << 20;
+    static constexpr size_t kSlots = 8, kSlotBytes = (size_t)256 << 10, kBytes = kSlotBytes;
     static HostStage &get()
     {
         static HostStage s;
         return s;
     }
-    // nullptr: no staging memory (the caller takes the plain copy)
-    void *lock()
+    // nullptr: no staging memory for this request (the caller takes the plain copy)
+    void *lock(size_t bytes)
     {
-        mu_.lock();
+        if (bytes > kSlotBytes) return nullptr;
+        std::unique_lock<std::mutex> lk(mu_);
         if (!p_ && !failed_) {
-            if (hipHostMalloc(&p_, kBytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); p_ = nullptr; failed_ = true; }
+            if (hipHostMalloc(&p_, kSlots * kSlotBytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); p_ = nullptr; failed_ = true; }
         }
-        if (!p_) mu_.unlock();
-        return p_;
+        if (!p_) return nullptr;
+        cv_.wait(lk, [&] { return busy_ != (1u << kSlots) - 1u; });
+        unsigned k = 0;
+        while (busy_ & (1u << k)) ++k;
+        busy_ |= 1u << k;
+        return static_cast<char *>(p_) + k * kSlotBytes;
     }
-    void unlock() { mu_.unlock(); }
+    void unlock(void *slot)
+    {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            busy_ &= ~(1u << (unsigned)((static_cast<char *>(slot) - static_cast<char *>(p_)) / kSlotBytes));
+        }
+        cv_.notify_one();
+    }
 
   private:
     std::mutex mu_;
+    std::condition_variable cv_;
+    unsigned busy_ = 0;
     void *p_ = nullptr;
     bool failed_ = false;
 };
