@@ -648,6 +648,21 @@ __global__ __launch_bounds__(1024) void predicted_decrease_kernel(const double *
     }
 }
 
+// The five numbers the LM driver reads after an iteration, written straight into pinned host memory (zero-copy): trial cost,
+// q1 numerator, cost at the current poses, pivot status -- one tiny kernel instead of three device-to-host copies at the tail
+// of every iteration.
+__global__ void lm_report_kernel(const double *__restrict__ scal2, const double *__restrict__ cost_cur, const int *__restrict__ status,
+                                 double *__restrict__ host_pin)
+{
+    if (threadIdx.x == 0) {
+        host_pin[0] = scal2[0];
+        host_pin[1] = scal2[1];
+        host_pin[2] = cost_cur[0];
+        host_pin[4] = __longlong_as_double((long long)(unsigned)status[0]);
+        __threadfence_system();
+    }
+}
+
 // ---- grouped refinement (lvba_balm_refine_groups): independent pose / voxel groups advance through one LM loop in lock-step,
 // each with its own cost, damping and accept / reject decision.  One workgroup per group, fixed summation order.
 __global__ __launch_bounds__(256) void reduce_chunks_groups_kernel(const double *__restrict__ part, const int64_t *__restrict__ gco,
@@ -824,6 +839,11 @@ void launch_import_poses(const double *in, const int *perm, int n_poses, double 
 void launch_export_poses(const double *in, const int *perm, int n_poses, double *out, hipStream_t s)
 {
     hipLaunchKernelGGL(export_poses_kernel, dim3((12 * n_poses + 255) / 256), dim3(256), 0, s, in, perm, n_poses, out);
+}
+
+void launch_lm_report(const double *scal2, const double *cost_cur, const int *status, double *host_pin, hipStream_t s)
+{
+    hipLaunchKernelGGL(lm_report_kernel, dim3(1), dim3(64), 0, s, scal2, cost_cur, status, host_pin);
 }
 
 void launch_reduce_chunks_groups(const double *chunk_cost, const int64_t *gco, int n_groups, double *out, hipStream_t s)

@@ -648,9 +648,7 @@ extern "C" int32_t lvba_balm_lm_step(lvba_balm_t h, lvba_lm_trace *row, int32_t 
     launch_predicted_decrease(h->bs.Hblk(), h->bs.Bb, h->bs.g(), h->bs.d_dx, h->u, n, h->d_scal2 + 1, h->stream()); // :729
     TRY(enqueue_cost(h, h->d_pose_trial, h->d_scal2, with_lin));                           // :731 (+ the linearisation at the trial point)
     h->lin_at_cur = false; // it belongs to the trial point now
-    HIPCHK(hipMemcpyAsync(h->h_pin, h->d_scal2, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream()));
-    HIPCHK(hipMemcpyAsync(h->h_pin + 2, h->bs.scal(), sizeof(double), hipMemcpyDeviceToHost, h->stream()));
-    HIPCHK(hipMemcpyAsync(h->h_pin + 4, h->bs.d_status, sizeof(int), hipMemcpyDeviceToHost, h->stream()));
+    launch_lm_report(h->d_scal2, h->bs.scal(), h->bs.d_status, h->h_pin, h->stream()); // -> pinned host memory, zero-copy
     HIPCHK(hipStreamSynchronize(h->stream()));
     ev_collect(h);
     const double Vg = (double)h->Vglobal;
@@ -659,7 +657,7 @@ extern "C" int32_t lvba_balm_lm_step(lvba_balm_t h, lvba_lm_trace *row, int32_t 
     const double residual2 = h->h_pin[0] / Vg;
     const double q1 = h->h_pin[1] / Vg;                                                    // :732
     int st = 0;
-    memcpy(&st, h->h_pin + 4, sizeof(int));
+    { long long stl; memcpy(&stl, h->h_pin + 4, sizeof stl); st = (int)stl; }
     double q = residual1 - residual2;                                                      // :736
     int32_t status = LVBA_OK;
     if (st) status = LVBA_NUM_FACTORIZATION;
