@@ -47,12 +47,12 @@ struct LdltTwist {
 __global__ void ldlt_prepare_kernel(LdltMat M, const double *__restrict__ Hblk, int band_blocks, int n_poses,
                                     const double *__restrict__ g, const double *__restrict__ u_dev,
                                     double *__restrict__ b, unsigned long long *__restrict__ x, unsigned long long x_fill,
-                                    LdltTwist tw, const int32_t *__restrict__ grp)
+                                    LdltTwist tw, const int32_t *__restrict__ grp, int vectors_only)
 {
     // grp != nullptr: the damping of pose block J is u_dev[grp[J]] (independent groups of poses, each with its own LM state)
     const double u0 = u_dev[0];
     const int64_t Bb1 = band_blocks + 1;
-    const int64_t total = (int64_t)n_poses * Bb1 * 36;
+    const int64_t total = vectors_only ? 0 : (int64_t)n_poses * Bb1 * 36; // band storage: ldlt_prepare_band_kernel fills the matrix
     const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
     const int64_t n = M.n, n1 = tw.m > 0 ? tw.n1 : n;
     for (int64_t e = gid; e < total; e += gsz) {
@@ -82,6 +82,62 @@ __global__ void ldlt_prepare_kernel(LdltMat M, const double *__restrict__ Hblk, 
             b[tw.sW + a] = (i >= n1 && !(grp && u_dev[grp[i / 6]] < 0.0)) ? -g[i] : 0.0; // the S part of matrix 2's right-hand side only collects updates
             tw.x2[a] = x_fill;
         }
+}
+
+// Band storage, destination-major: one workgroup per block column of matrix 1 (blockIdx.y = 0) or block row of the B part
+// = six columns of the reversed matrix 2 (blockIdx.y = 1), one thread per stored entry INCLUDING the zeros (slack rows below
+// the band, the S x S block of matrix 2, columns that belong to the other matrix) -- every store is part of a contiguous
+// column, and no memset of the 0.5 GB store runs first.  The element-major kernel above scattered the B part's entries one
+// 8-byte store per column (they are transposed) on top of that memset: 0.064 + 0.164 ms at C3, this one 0.0xx ms.
+__global__ void __launch_bounds__(256)
+ldlt_prepare_band_kernel(LdltMat M, const double *__restrict__ Hblk, int band_blocks, int n_poses,
+                         const double *__restrict__ u_dev, LdltTwist tw, const int32_t *__restrict__ grp, int extra_col)
+{
+    // blockIdx.x: stored column (6 P + c of matrix 1; row 6 P + r of the B part = column of matrix 2), blockIdx.y: 1024
+    // entries of it, four per thread with their loads in flight together; blockIdx.z: which matrix
+    const int64_t Bb1 = band_blocks + 1, n = M.n, n1 = tw.m > 0 ? tw.n1 : n;
+    const int ldab = (int)(M.ld + 1);
+    const int64_t X = blockIdx.x;
+    const int d0 = blockIdx.y * 1024 + threadIdx.x;
+    if (X >= n) { // the one spare column after matrix 1 (tile reads may run into it)
+        if (extra_col && blockIdx.z == 0)
+            for (int k = 0; k < 4; ++k)
+                if (d0 + 256 * k < ldab) M.a[n * (int64_t)ldab + d0 + 256 * k] = 0.0;
+        return;
+    }
+    const int P = (int)(X / 6), e = (int)(X - 6 * (int64_t)P);
+    const double uj = grp ? u_dev[grp[P]] : u_dev[0];
+    const bool dead = uj < 0.0; // a finished group: identity block, see ldlt_prepare_kernel
+    double v[4];
+    double *__restrict__ dst;
+    if (blockIdx.z == 0) {
+        const double *__restrict__ src = Hblk + (int64_t)P * Bb1 * 36 + e * 6; // column c = e of block column P
+        dst = M.a + X * ldab;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int d = d0 + 256 * k, q = e + d, dI = q / 6, r = q - 6 * dI;
+            v[k] = (dI <= band_blocks && X + d < n1) ? src[dI * 36 + r] : 0.0;
+        }
+    } else {
+        dst = M.a + tw.sA + (n - 1 - X) * ldab; // row R = X, r = e of block row P
+        const bool inB = X >= n1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int d = d0 + 256 * k;
+            const int C = (int)X - d;
+            const int J = C >= 0 ? C / 6 : 0, c = C - 6 * J, dI = P - J;
+            v[k] = (inB && C >= 0 && dI <= band_blocks) ? Hblk[((int64_t)J * Bb1 + dI) * 36 + c * 6 + e] : 0.0;
+        }
+    }
+    if (d0 == 0) v[0] = dead ? ((blockIdx.z == 0 ? X < n1 : X >= n1) ? 1.0 : 0.0) : v[0] + uj * v[0];
+    if (dead) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (d0 + 256 * k != 0) v[k] = 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (d0 + 256 * k < ldab) dst[d0 + 256 * k] = v[k];
 }
 
 // After both ends have been eliminated: the Schur complement that matrix 2 (reversed) collected on S is added to matrix 1's
@@ -1153,11 +1209,17 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
     LdltMat M = A; // the problem the launches see: matrix 1 (and matrix 2 through blockIdx.y)
     M.n = nf;
     const size_t abytes = (size_t)((A.ld == n) ? n * n : (A.ld + 1) * n) * sizeof(double);
-    hipMemsetAsync(A.a, 0, P1 > 0 ? (size_t)tw.sA * sizeof(double) + abytes : abytes, s);
+    static const bool band_fill = [] { const char *e = getenv("LVBA_BAND_FILL"); return !(e && !strcmp(e, "0")); }();
+    const bool fill = band_fill && A.ld != n && n == 6 * (int64_t)n_poses;
+    if (fill)
+        hipLaunchKernelGGL(ldlt_prepare_band_kernel, dim3((unsigned)n + (P1 > 0 ? 1 : 0), (unsigned)((A.ld + 1 + 1023) / 1024), P1 > 0 ? 2 : 1),
+                           dim3(256), 0, s, A, Hblk, band_blocks, n_poses, u_dev, tw, grp, P1 > 0 ? 1 : 0);
+    else
+        hipMemsetAsync(A.a, 0, P1 > 0 ? (size_t)tw.sA * sizeof(double) + abytes : abytes, s);
     hipMemsetAsync(status, 0, sizeof(int), s);
     hipMemsetAsync(bacc, 0, (size_t)n * sizeof(double), s);
-    hipLaunchKernelGGL(ldlt_prepare_kernel, dim3(2048), dim3(256), 0, s, A, Hblk, band_blocks, n_poses, g, u_dev, b,
-                       reinterpret_cast<unsigned long long *>(x), (unsigned long long)LVBA_X_SENTINEL, tw, grp);
+    hipLaunchKernelGGL(ldlt_prepare_kernel, dim3(fill ? 64 : 2048), dim3(256), 0, s, A, Hblk, band_blocks, n_poses, g, u_dev, b,
+                       reinterpret_cast<unsigned long long *>(x), (unsigned long long)LVBA_X_SENTINEL, tw, grp, fill ? 1 : 0);
     struct Geo { int64_t k, w0, rend, T; int nbe; };
     auto geom = [&](int64_t st) {
         Geo q;
