@@ -19,6 +19,9 @@
 // with ldlt.hip.  Everything is deterministic (no atomics); every arithmetic operation runs here, on the device.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <utility>
 #include "lvba_internal.h"
 
 namespace lvba {
@@ -28,6 +31,7 @@ namespace {
 struct BcrDev {
     int nb, k, M, Bb;      // block rows, cameras per block row, cameras, camera half-bandwidth
     double *D, *L, *T1, *T2; // [nb][BP*BP] row-major
+    double *L2;              // second coupling-block array of the one-launch levels (bcr_level_kernel)
     double *rhs, *t, *x;   // [nb][BP]
 };
 
@@ -234,6 +238,227 @@ __global__ __launch_bounds__(256) void bcr_B_kernel(BcrDev p, int s)
     if (tid < BP) p.rhs[(int64_t)r * BP + tid] -= drhs;
 }
 
+// One level in ONE launch (block rows of 32 scalars): the workgroup of the even row r inverts BOTH odd neighbours itself (two
+// halves of a 512-thread workgroup, side by side), so no workgroup waits for another one inside a level -- the A / B pair above
+// costs two dependent launches per level, and at ~25 + 14 us each (single-workgroup latency, not work) the nine levels of a
+// 2 000-camera system were two thirds of the visual stage's LM iteration.  An odd row is inverted twice (by its left and its
+// right even neighbour); T1 / T2 / t of an odd row are stored by the LEFT one (every odd row has it), for the back substitution.
+// The new coupling blocks L_r go to the OTHER of two L arrays (Ldst): the right neighbour's workgroup still reads the old
+// L_{r} of this level (as its L_q) while this one finishes.  `last`: row 0 is the only row left after this level -- the
+// workgroup also solves x_0 = D_0^-1 rhs_0.
+typedef double bcr_d4 __attribute__((ext_vector_type(4)));
+
+// Two 32 x 32 inversions side by side, 128 threads (two wavefronts) each: thread lt owns column c = lt % 32 of the rows
+// rb + 4 j (rb = lt / 32, j < 8) of [A | Inv].  The pivot loop is unrolled in full, so which thread holds the pivot row is a
+// compile-time pattern; the pivot row and column travel through LDS (double-buffered: one barrier per pivot).  ~700 cycles per
+// pivot, bound by instruction issue of the single wavefront per SIMD, not by the trips through LDS: 2 x 2 block pivots (half
+// the barriers) measured 21.0 k cycles against 22.2 k and cost accuracy on the ill-conditioned systems of
+// test_block_cyclic_reduction_equals_band_ldlt (the determinant of a nearly singular 2 x 2 block), so pivots stay scalar.
+__device__ __forceinline__ void gauss_jordan_pair32(double (&a)[8], double (&v_)[8], double (*colb)[2][32], double (*rowa)[2][32],
+                                                    double (*rowi)[2][32], int gp, int lt, int *status)
+{
+    const int c = lt & 31, rb = lt >> 5;
+    bool bad = false;
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) {
+        const int pb = kk & 1, jk = kk >> 2;
+        if (c == kk) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) colb[gp][pb][rb + 4 * j] = a[j];
+        }
+        if (rb == (kk & 3)) { rowa[gp][pb][c] = a[jk]; rowi[gp][pb][c] = v_[jk]; }
+        __syncthreads();
+        const double piv = colb[gp][pb][kk];
+        bad |= !(piv > 0.0);
+        double rp = __builtin_amdgcn_rcp(piv); // v_rcp_f64 + two Newton steps (balm_math.h lvba_rcp)
+        rp = fma(rp, fma(-piv, rp, 1.0), rp);
+        rp = fma(rp, fma(-piv, rp, 1.0), rp);
+        const double ra = rowa[gp][pb][c] * rp, ri = rowi[gp][pb][c] * rp;
+        double f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = colb[gp][pb][rb + 4 * j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j == jk) {
+                const bool mine = rb == (kk & 3);
+                a[j] = mine ? ra : a[j] - f[j] * ra;
+                v_[j] = mine ? ri : v_[j] - f[j] * ri;
+            } else { a[j] -= f[j] * ra; v_[j] -= f[j] * ri; }
+        }
+    }
+    if (bad && lt == 0) status[0] = 1;
+}
+// one 16 x 16 tile (ti, tj) of opA * opB out of LDS on the matrix pipe (v_mfma_f64_16x16x4_f64: lane l supplies A[l & 15][l >> 4]
+// and B[l >> 4][l & 15]; register e of lane l is the result's [(l >> 4) + 4 e][l & 15]); tiles are row-major with stride 33
+template <bool TA, bool TB>
+__device__ __forceinline__ void mfma_tile32(const double *A, const double *B, int ti, int tj, bcr_d4 &acc)
+{
+    constexpr int LD = 33;
+    const int l = threadIdx.x & 63, lo = l & 15, hi = l >> 4;
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+        const int k = 4 * kb + hi;
+        const double av = TA ? A[k * LD + 16 * ti + lo] : A[(16 * ti + lo) * LD + k];
+        const double bv = TB ? B[(16 * tj + lo) * LD + k] : B[k * LD + 16 * tj + lo];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+}
+
+#ifdef LVBA_BCR_TIMING
+__device__ unsigned long long g_bcr_clk[8];
+#define BCR_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_bcr_clk[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define BCR_STAMP(k) do { } while (0)
+#endif
+// One level in ONE launch (block rows of 32 scalars): the workgroup of the even row r inverts BOTH odd neighbours itself (two
+// wavefronts each, side by side), so no workgroup waits for another one inside a level -- the A / B pair above costs two
+// dependent launches per level, and each is the latency of ONE workgroup (26 + 11 us measured: a 256-thread Gauss-Jordan at
+// ~1 500 cycles per pivot, LDS-bandwidth-bound scalar tile products), nine times over for 2 000 cameras.  Here the seven
+// 32 x 32 x 32 products of a level run on the matrix pipe (one wavefront per product).  An odd row is inverted twice (by its
+// left and its right even neighbour); T1 / T2 / t of an odd row are stored by the LEFT one (every odd row has it), for the back
+// substitution.  The new coupling blocks L_r go to the OTHER of two L arrays (Ldst): the right neighbour's workgroup still
+// reads the old L_r of this level (as its L_q) while this one finishes.  `last`: row 0 is the only row left after this
+// level -- the workgroup also solves x_0 = D_0^-1 rhs_0.
+__global__ __launch_bounds__(256) void bcr_level_kernel(BcrDev p, int s, const double *__restrict__ Lsrc, double *__restrict__ Ldst,
+                                                        int last, int *__restrict__ status)
+{
+    constexpr int BP = 32, LD = BP + 1, TS = BP * LD;
+    __shared__ double buf[6][TS]; // 0: Inv_il -> T1_il | 1: Inv_ir -> T1_ir | 2: L_il -> T2_il | 3: L_r | 4: L_ir | 5: L_q
+    __shared__ double colb[2][2][BP], rowa[2][2][BP], rowi[2][2][BP];
+    __shared__ double vrhs[2][BP], vt[2][BP];
+    const int tid = threadIdx.x, gp = tid >> 7, lt = tid & 127, wv = tid >> 6, l = tid & 63;
+    const int r = 2 * (int)blockIdx.x * s, il = r - s, ir = r + s, q = ir + s;
+    const bool hasl = il >= 0, hasr = ir < p.nb, hasq = hasr && q < p.nb;
+    const int64_t BB = BP * BP;
+    BCR_STAMP(0);
+    // every global read of the level up front: the two diagonal blocks (Gauss-Jordan layout, registers), four coupling blocks
+    const int io = gp == 0 ? il : ir;
+    const bool has = gp == 0 ? hasl : hasr;
+    const int c = lt & 31, rb = lt >> 5;
+    double a[8], v_[8];
+    {
+        const double *Dg = p.D + (int64_t)(has ? io : 0) * BB;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int rr = rb + 4 * j;
+            a[j] = has ? Dg[rr * BP + c] : (rr == c ? 1.0 : 0.0); // a missing neighbour: identity (its coupling blocks are zero)
+            v_[j] = (rr == c) ? 1.0 : 0.0;
+        }
+    }
+    {
+        const double *g2 = Lsrc + (int64_t)(hasl ? il : 0) * BB, *g3 = Lsrc + (int64_t)r * BB;
+        const double *g4 = Lsrc + (int64_t)(hasr ? ir : 0) * BB, *g5 = Lsrc + (int64_t)(hasq ? q : 0) * BB;
+#pragma unroll
+        for (int e0 = 0; e0 < BP * BP; e0 += 256) {
+            const int e = e0 + tid, o = (e / BP) * LD + (e % BP);
+            buf[2][o] = hasl ? g2[e] : 0.0;
+            buf[3][o] = hasl ? g3[e] : 0.0; // L_r couples r to r - s = il
+            buf[4][o] = hasr ? g4[e] : 0.0;
+            buf[5][o] = hasq ? g5[e] : 0.0;
+        }
+    }
+    if (lt < BP) vrhs[gp][lt] = has ? p.rhs[(int64_t)io * BP + lt] : 0.0;
+    // this row's own blocks: needed at the very end, asked for now
+    double dold[4], rold = 0.0;
+    const int ti = wv >> 1, tj = wv & 1, lo = l & 15, hi = l >> 4; // wavefront wv owns tile (ti, tj) of the results for row r
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dold[e] = p.D[(int64_t)r * BB + (16 * ti + hi + 4 * e) * BP + 16 * tj + lo];
+    if (tid < BP) rold = p.rhs[(int64_t)r * BP + tid];
+    BCR_STAMP(1);
+    gauss_jordan_pair32(a, v_, colb, rowa, rowi, gp, lt, status);
+    BCR_STAMP(2);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) buf[gp][(rb + 4 * j) * LD + c] = v_[j];
+    __syncthreads();
+    // wavefront 0: T1_il = Inv_il L_il | 1: T2_il = Inv_il L_r^T | 2: T1_ir = Inv_ir L_ir | 3: T2_ir = Inv_ir L_q^T ; t = Inv rhs
+    bcr_d4 P[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        P[t] = bcr_d4{0.0, 0.0, 0.0, 0.0};
+        if (wv == 0) mfma_tile32<false, false>(buf[0], buf[2], t >> 1, t & 1, P[t]);
+        else if (wv == 1) mfma_tile32<false, true>(buf[0], buf[3], t >> 1, t & 1, P[t]);
+        else if (wv == 2) mfma_tile32<false, false>(buf[1], buf[4], t >> 1, t & 1, P[t]);
+        else mfma_tile32<false, true>(buf[1], buf[5], t >> 1, t & 1, P[t]);
+    }
+    double tsave = 0.0;
+    if (lt < BP) {
+        double sacc = 0.0;
+#pragma unroll 8
+        for (int m = 0; m < BP; ++m) sacc += buf[gp][lt * LD + m] * vrhs[gp][m];
+        vt[gp][lt] = sacc;
+        tsave = sacc;
+    }
+    __syncthreads();
+    if (wv < 3) {
+        double *dstb = wv == 0 ? buf[0] : wv == 1 ? buf[2] : buf[1];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dstb[(16 * (t >> 1) + hi + 4 * e) * LD + 16 * (t & 1) + lo] = P[t][e];
+    }
+    __syncthreads();
+    BCR_STAMP(3);
+    // D_r -= L_r T2_il + L_ir^T T1_ir ; L_r <- -L_r T1_il ; rhs_r -= L_r t_il + L_ir^T t_ir : tile (ti, tj) per wavefront
+    bcr_d4 dD = bcr_d4{0.0, 0.0, 0.0, 0.0}, dL = bcr_d4{0.0, 0.0, 0.0, 0.0};
+    mfma_tile32<false, false>(buf[3], buf[2], ti, tj, dD);
+    mfma_tile32<true, false>(buf[4], buf[1], ti, tj, dD);
+    mfma_tile32<false, false>(buf[3], buf[0], ti, tj, dL);
+    double *D = p.D + (int64_t)r * BB, *Lo = Ldst + (int64_t)r * BB;
+    double dnew[4];
+    const bool keepl = hasl && r - 2 * s >= 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int o = (16 * ti + hi + 4 * e) * BP + 16 * tj + lo;
+        dnew[e] = dold[e] - dD[e];
+        D[o] = dnew[e];
+        Lo[o] = keepl ? -dL[e] : 0.0;
+    }
+    double rnew = 0.0;
+    if (tid < BP) {
+        double d1 = 0.0, d2 = 0.0;
+#pragma unroll 8
+        for (int m = 0; m < BP; ++m) { d1 += buf[3][tid * LD + m] * vt[0][m]; d2 += buf[4][m * LD + tid] * vt[1][m]; }
+        rnew = rold - (d1 + d2);
+        p.rhs[(int64_t)r * BP + tid] = rnew;
+    }
+    // T1 / T2 / t of the right neighbour, for the back substitution: global stores last (a barrier would wait for them)
+    if (hasr && gp == 1 && lt < BP) p.t[(int64_t)ir * BP + lt] = tsave;
+    if (hasr && wv >= 2) {
+        double *o = (wv == 2 ? p.T1 : p.T2) + (int64_t)ir * BB;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[(16 * (t >> 1) + hi + 4 * e) * BP + 16 * (t & 1) + lo] = P[t][e];
+    }
+    BCR_STAMP(4);
+    if (!last) return;
+    // row 0 alone is left: x_0 = D_0^-1 rhs_0 (the first half inverts, the second one keeps step with an identity)
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) buf[5][(16 * ti + hi + 4 * e) * LD + 16 * tj + lo] = dnew[e];
+    if (tid < BP) vrhs[0][tid] = rnew;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int rr = rb + 4 * j;
+        a[j] = gp == 0 ? buf[5][rr * LD + c] : (rr == c ? 1.0 : 0.0);
+        v_[j] = (rr == c) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    gauss_jordan_pair32(a, v_, colb, rowa, rowi, gp, lt, status);
+    if (gp == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) buf[0][(rb + 4 * j) * LD + c] = v_[j];
+    }
+    __syncthreads();
+    if (tid < BP) {
+        double sacc = 0.0;
+        for (int m = 0; m < BP; ++m) sacc += buf[0][tid * LD + m] * vrhs[0][m];
+        p.x[tid] = sacc;
+        p.t[tid] = sacc;
+    }
+}
+
 // back substitution of level s: x_i = t_i - T1_i x_{i-s} - T2_i x_{i+s} for the odd rows; s <= 0: x_0 = t_0
 template <int BP>
 __global__ __launch_bounds__(256) void bcr_back_kernel(BcrDev p, int s)
@@ -275,9 +500,28 @@ __global__ void bcr_scatter_kernel(BcrDev p, double *__restrict__ out)
 template <int BP>
 void bcr_run(const BcrDev &p, const double *Hblk, const double *g, const double *u_dev, double *x, int *status, hipStream_t s)
 {
+    static const bool one_launch = [] { const char *e = getenv("LVBA_BCR_LEVELS"); return !(e && !strcmp(e, "2")); }();
     hipMemsetAsync(status, 0, sizeof(int), s);
     hipLaunchKernelGGL(bcr_assemble_kernel<BP>, dim3((unsigned)p.nb), dim3(256), 0, s, p, Hblk, g, u_dev);
     int top = 0; // strides 1, 2, 4, ... while an odd row exists (stride < nb)
+    if constexpr (BP == 32) {
+        if (one_launch && p.nb > 1) {
+            double *Lbuf[2] = {p.L, p.L2};
+            int cur = 0;
+            for (int st = 1; st < p.nb; st *= 2) {
+                const int n_even = (p.nb + 2 * st - 1) / (2 * st); // r = 2 m st < nb
+                hipLaunchKernelGGL(bcr_level_kernel, dim3((unsigned)n_even), dim3(256), 0, s, p, st, Lbuf[cur], Lbuf[cur ^ 1], 2 * st >= p.nb ? 1 : 0, status);
+                cur ^= 1;
+                top = st;
+            }
+            for (int st = top; st >= 1; st /= 2) {
+                const int n_odd = (p.nb - st + 2 * st - 1) / (2 * st);
+                hipLaunchKernelGGL(bcr_back_kernel<BP>, dim3((unsigned)n_odd), dim3(256), 0, s, p, st);
+            }
+            hipLaunchKernelGGL(bcr_scatter_kernel<BP>, dim3((unsigned)((6 * (int64_t)p.M + 255) / 256)), dim3(256), 0, s, p, x);
+            return;
+        }
+    }
     for (int st = 1; st < p.nb; st *= 2) {
         const int n_odd = (p.nb - st + 2 * st - 1) / (2 * st);  // i = (2m+1) st < nb
         const int n_even = (p.nb + 2 * st - 1) / (2 * st);      // r = 2 m st < nb
@@ -311,7 +555,7 @@ int64_t bcr_workspace_doubles(int n_poses, int band_blocks)
     if (!bcr_applicable(n_poses, band_blocks)) return 0;
     const int k = bcr_block_cams(band_blocks), BP = bcr_pad(k);
     const int64_t nb = (n_poses + k - 1) / k;
-    return nb * (4 * (int64_t)BP * BP + 3 * BP) + 64;
+    return nb * (5 * (int64_t)BP * BP + 3 * BP) + 64;
 }
 
 // x = -(S + u diag S)^-1 g from the block-band store (u is read from device memory; the visual stage passes 0).
@@ -325,7 +569,8 @@ void bcr_solve(const double *Hblk, int band_blocks, int n_poses, const double *g
     p.M = n_poses; p.Bb = band_blocks;
     const int64_t m2 = (int64_t)p.nb * BP * BP, m1 = (int64_t)p.nb * BP;
     p.D = work; p.L = p.D + m2; p.T1 = p.L + m2; p.T2 = p.T1 + m2;
-    p.rhs = p.T2 + m2; p.t = p.rhs + m1; p.x = p.t + m1;
+    p.L2 = p.T2 + m2;
+    p.rhs = p.L2 + m2; p.t = p.rhs + m1; p.x = p.t + m1;
     if (BP == 32) bcr_run<32>(p, Hblk, g, u_dev, x, status, s);
     else bcr_run<64>(p, Hblk, g, u_dev, x, status, s);
 }

@@ -47,6 +47,9 @@ struct BlockSys {
     LdltMat A{};
     double *d_bcr = nullptr; // workspace of the block cyclic reduction, when that is the solver
     double *d_A = nullptr, *d_work = nullptr, *d_dx = nullptr, *d_u = nullptr, *h_pin_u = nullptr;
+    double u_on_device = 0.0;      // the damping value d_u[0] holds (u_known): an unchanged value is not uploaded again
+    bool u_known = false;
+    int u_slot = 0;
     // grouped refinement: d_u holds one damping value per group, d_grp_of_pose [N] (owned by the caller) maps pose blocks to them
     int32_t n_groups = 0;
     const int32_t *d_grp_of_pose = nullptr;

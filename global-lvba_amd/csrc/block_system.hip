@@ -428,10 +428,16 @@ int32_t bs_enqueue_solve(BlockSys &bs, double u)
     if (bs.n_groups > 0) { // a grouped problem solved with one damping value for all groups
         for (int32_t k = 0; k < bs.n_groups; ++k) bs.h_pin_u[k] = u;
         HIPCHK(hipMemcpyAsync(bs.d_u, bs.h_pin_u, (size_t)bs.n_groups * sizeof(double), hipMemcpyHostToDevice, bs.stream));
+        bs.u_known = false;
         return enqueue_solve_launches(bs);
     }
-    bs.h_pin_u[0] = u;
-    HIPCHK(hipMemcpyAsync(bs.d_u, bs.h_pin_u, sizeof(double), hipMemcpyHostToDevice, bs.stream));
+    if (!(bs.u_known && bs.u_on_device == u)) { // the visual stage solves with u = 0 every time (its damping is in the system)
+        bs.u_slot ^= 1; // two staging words: the previous copy may still be reading the other one
+        bs.h_pin_u[bs.u_slot] = u;
+        HIPCHK(hipMemcpyAsync(bs.d_u, bs.h_pin_u + bs.u_slot, sizeof(double), hipMemcpyHostToDevice, bs.stream));
+        bs.u_on_device = u;
+        bs.u_known = true;
+    }
     return enqueue_solve_launches(bs);
 }
 
@@ -441,6 +447,7 @@ int32_t bs_enqueue_solve_groups(BlockSys &bs, const double *u)
     HIPCHK(hipStreamSynchronize(bs.stream)); // the pinned staging buffer may still be read by the previous copy
     for (int32_t k = 0; k < bs.n_groups; ++k) bs.h_pin_u[k] = u[k];
     HIPCHK(hipMemcpyAsync(bs.d_u, bs.h_pin_u, (size_t)bs.n_groups * sizeof(double), hipMemcpyHostToDevice, bs.stream));
+    bs.u_known = false;
     return enqueue_solve_launches(bs);
 }
 

@@ -6,6 +6,7 @@
 // parameter/function tolerance checks before the accept test, radius /= max(1/3, 1-(2 rho-1)^3) on success and
 // /= 2,4,8.. on failure.  Host logic only; arithmetic runs in visual_kernels.hip, balm_pair_kernel and ldlt.hip.
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
@@ -145,7 +146,7 @@ extern "C" int32_t lvba_visual_create(int32_t n_cams, int64_t n_tracks, const in
     CTRY(bs_dmalloc(bs, &h->d_Lp, 6 * Ta)); CTRY(bs_dmalloc(bs, &h->d_zp, 3 * Ta)); CTRY(bs_dmalloc(bs, &h->d_step_p, 3 * Ta));
     CTRY(bs_dmalloc(bs, &h->d_q, 4 * M)); CTRY(bs_dmalloc(bs, &h->d_t, 3 * M)); CTRY(bs_dmalloc(bs, &h->d_X, 3 * Ta));
     CTRY(bs_dmalloc(bs, &h->d_q2, 4 * M)); CTRY(bs_dmalloc(bs, &h->d_t2, 3 * M)); CTRY(bs_dmalloc(bs, &h->d_X2, 3 * Ta));
-    CTRY(bs_dmalloc(bs, &h->d_blkpart, 2 * ((O + Ta + M) / 256 + 4)));
+    CTRY(bs_dmalloc(bs, &h->d_blkpart, 2 * ((O + 4 * Ta + M) / 256 + 4))); // vis_back_kernel: four lanes per landmark
     CTRY(bs_dmalloc(bs, &h->d_scal, 16));
     CTRY(bs_dmalloc(bs, &h->d_gmax, 2));
     CTRY(bs_dmalloc(bs, &h->d_out, 36 * (int64_t)M + 16));
@@ -351,17 +352,34 @@ extern "C" int32_t lvba_visual_refine(lvba_visual_t h, double *q, double *t, dou
     bool first = true;
     int invalid_run = 0;
     if (!isfinite(cost)) { term = LVBA_TERM_FAILURE; rc = fail(LVBA_NUM_NONFINITE, "non-finite initial cost"); }
+    // LVBA_VIS_PROFILE=1: HIP events between the phases of every iteration, averages on stderr at the end (tools/visual_bench.py)
+    static const bool prof = [] { const char *e = getenv("LVBA_VIS_PROFILE"); return e && !strcmp(e, "1"); }();
+    constexpr int NPH = 6, PCAP = 64;
+    std::vector<hipEvent_t> pev;
+    int pn = 0;
+    if (prof) {
+        pev.resize((size_t)NPH * PCAP);
+        for (auto &e : pev) hipEventCreate(&e);
+    }
+    auto mark = [&](int ph) { if (prof && pn < PCAP) hipEventRecord(pev[(size_t)pn * NPH + ph], bs.stream); };
     for (int it = 1; rc == LVBA_OK; ++it) {
         // linearised system at the current point (its gradient norm belongs to the row of the previous iteration)
+        mark(0);
         TRY(enqueue_reduced_system(h, radius, o));
+        mark(1);
         TRY(bs_enqueue_solve(bs, 0.0));
+        mark(2);
         vis_launch_back(d, bs.d_dx, h->d_blkpart, h->d_scal + 2, bs.stream);
+        mark(3);
         vis_launch_apply(d, bs.d_dx, h->d_q, h->d_t, h->d_X, h->d_q2, h->d_t2, h->d_X2, h->d_blkpart, h->d_scal + 3, bs.stream);
         vis_launch_residuals(d, false, h->d_q2, h->d_t2, h->d_X2, h->d_blkpart, h->d_scal + 1, bs.stream);
+        mark(4);
         TRY(allreduce_scalars(h, 1, 4)); // candidate cost, model cost change, |step|^2, |x|^2: sums over the track shards
         HIPCHK(hipMemcpyAsync(h->h_pin, h->d_scal, 5 * sizeof(double), hipMemcpyDeviceToHost, bs.stream));
         HIPCHK(hipMemcpyAsync(h->h_pin + 8, h->d_gmax, sizeof(unsigned long long), hipMemcpyDeviceToHost, bs.stream));
         HIPCHK(hipMemcpyAsync(h->h_pin + 9, bs.d_status, sizeof(int), hipMemcpyDeviceToHost, bs.stream));
+        mark(5);
+        if (prof && pn < PCAP) ++pn;
         HIPCHK(hipStreamSynchronize(bs.stream));
         HIPCHK(hipGetLastError());
         double gmax;
@@ -409,6 +427,26 @@ extern "C" int32_t lvba_visual_refine(lvba_visual_t h, double *q, double *t, dou
             push(it, 0, 1, cand, cost_change, step_norm, radius, rho, gmax);
             if (radius < o.min_radius) { term = LVBA_TERM_RADIUS; break; }
         }
+    }
+    if (prof) {
+        hipStreamSynchronize(bs.stream);
+        double acc[NPH] = {0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < pn; ++k)
+            for (int ph = 0; ph + 1 < NPH; ++ph) {
+                float ms = 0.f;
+                hipEventElapsedTime(&ms, pev[(size_t)k * NPH + ph], pev[(size_t)k * NPH + ph + 1]);
+                acc[ph] += ms;
+            }
+        for (int k = 0; k + 1 < pn; ++k) { // end of iteration k -> start of iteration k + 1: host turn-around + the accepted point's linearisation
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, pev[(size_t)k * NPH + NPH - 1], pev[(size_t)(k + 1) * NPH]);
+            acc[NPH - 1] += ms;
+        }
+        if (pn > 0)
+            fprintf(stderr, "[lvba visual profile] %d iterations, us each: reduced system %.1f | solve %.1f | back %.1f | step + trial cost %.1f | "
+                            "copies %.1f | between iterations %.1f\n", pn, 1e3 * acc[0] / pn, 1e3 * acc[1] / pn, 1e3 * acc[2] / pn,
+                    1e3 * acc[3] / pn, 1e3 * acc[4] / pn, pn > 1 ? 1e3 * acc[5] / (pn - 1) : 0.0);
+        for (auto &e : pev) hipEventDestroy(e);
     }
     if (n_trace) *n_trace = std::min(rows, trace_cap > 0 ? trace_cap : 0);
     if (termination) *termination = term;

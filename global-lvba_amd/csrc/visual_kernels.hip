@@ -38,6 +38,21 @@ __device__ __forceinline__ double v_block_sum(double x, double *red) // 256 thre
     return t;
 }
 
+// sum over the four lanes of a DPP quad; every lane of the quad gets the total (quad_perm [1,0,3,2], then [2,3,0,1])
+__device__ __forceinline__ double v_quad_sum(double x)
+{
+#define LVBA_QUAD_ADD(ctrl)                                                                          \
+    do {                                                                                             \
+        const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(x), (ctrl), 0xF, 0xF, false);  \
+        const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(x), (ctrl), 0xF, 0xF, false);  \
+        x += __hiloint2double(hi_, lo_);                                                             \
+    } while (0)
+    LVBA_QUAD_ADD(0xB1);
+    LVBA_QUAD_ADD(0x4E);
+#undef LVBA_QUAD_ADD
+    return x;
+}
+
 // residuals at (qc, tc, Xp); threads [0,O) observations, [O, O+Ta) plane priors.  part[blockIdx] = sum r^2.
 template <bool JAC>
 __global__ __launch_bounds__(256) void vis_residual_kernel(VisDev d, const double *__restrict__ qc, const double *__restrict__ tc,
@@ -134,41 +149,64 @@ __global__ void vis_colnorm_cam_finish_kernel(VisDev d)
     if (a < 6 * (int64_t)d.M) d.sc_cam[a] = 1.0 / (1.0 + sqrt(d.colsum[a]));
 }
 
-// lane = landmark: C = sum Jp^T Jp (+ plane) in the scaled variables, LM diagonal D^2 = clamp(diag C)/radius,
-// Cholesky of C + D^2, z = L^-1 g.  gmax: max |unscaled gradient entry| (bit pattern of a non-negative double).
-__global__ void vis_point_kernel(VisDev d, double radius, double min_diag, double max_diag, unsigned long long *gmax)
+// four lanes (one DPP quad) per landmark, lane `sub` takes the observations off[i] + sub, + 4, ...: C = sum Jp^T Jp (+ plane) in
+// the scaled variables, LM diagonal D^2 = clamp(diag C)/radius, Cholesky of C + D^2, z = L^-1 g.  gmax: max |unscaled gradient
+// entry| (bit pattern of a non-negative double).  (One lane per landmark left 125 k lanes walking four dependent gathers each:
+// 31 us of latency for 12 MB.)
+__global__ __launch_bounds__(256) void vis_point_kernel(VisDev d, double radius, double min_diag, double max_diag, unsigned long long *gmax)
 {
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= d.Ta) return;
-    const double sp[3] = {d.sc_pt[3 * i], d.sc_pt[3 * i + 1], d.sc_pt[3 * i + 2]};
-    double C[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
-    {
-        const double j[3] = {d.Jpl[3 * i] * sp[0], d.Jpl[3 * i + 1] * sp[1], d.Jpl[3 * i + 2] * sp[2]};
-        const double rp = d.rpl[i];
-        C[0] += j[0] * j[0]; C[1] += j[1] * j[0]; C[2] += j[1] * j[1]; C[3] += j[2] * j[0]; C[4] += j[2] * j[1]; C[5] += j[2] * j[2];
-        g[0] += j[0] * rp; g[1] += j[1] * rp; g[2] += j[2] * rp;
-    }
-    for (int64_t o = d.off[i]; o < d.off[i + 1]; ++o) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const double j[3] = {d.Jp[6 * o + 3 * k] * sp[0], d.Jp[6 * o + 3 * k + 1] * sp[1], d.Jp[6 * o + 3 * k + 2] * sp[2]};
-            const double rk = d.r[2 * o + k];
+    __shared__ double redm[4];
+    const int64_t gid = blockIdx.x * (int64_t)256 + threadIdx.x;
+    const int64_t i = gid >> 2;
+    const int sub = (int)(gid & 3);
+    double gm = 0.0;
+    if (i < d.Ta) { // whole quads
+        const double sp[3] = {d.sc_pt[3 * i], d.sc_pt[3 * i + 1], d.sc_pt[3 * i + 2]};
+        double C[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+        if (sub == 0) {
+            const double j[3] = {d.Jpl[3 * i] * sp[0], d.Jpl[3 * i + 1] * sp[1], d.Jpl[3 * i + 2] * sp[2]};
+            const double rp = d.rpl[i];
             C[0] += j[0] * j[0]; C[1] += j[1] * j[0]; C[2] += j[1] * j[1]; C[3] += j[2] * j[0]; C[4] += j[2] * j[1]; C[5] += j[2] * j[2];
-            g[0] += j[0] * rk; g[1] += j[1] * rk; g[2] += j[2] * rk;
+            g[0] += j[0] * rp; g[1] += j[1] * rp; g[2] += j[2] * rp;
+        }
+        const int64_t o1 = d.off[i + 1];
+        for (int64_t o = d.off[i] + sub; o < o1; o += 4) {
+            const double2 *jp = reinterpret_cast<const double2 *>(d.Jp + 6 * o);
+            const double2 p0 = jp[0], p1 = jp[1], p2 = jp[2], rr = *reinterpret_cast<const double2 *>(d.r + 2 * o);
+            const double P[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const double j[3] = {P[3 * k] * sp[0], P[3 * k + 1] * sp[1], P[3 * k + 2] * sp[2]};
+                const double rk = k == 0 ? rr.x : rr.y;
+                C[0] += j[0] * j[0]; C[1] += j[1] * j[0]; C[2] += j[1] * j[1]; C[3] += j[2] * j[0]; C[4] += j[2] * j[1]; C[5] += j[2] * j[2];
+                g[0] += j[0] * rk; g[1] += j[1] * rk; g[2] += j[2] * rk;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 6; ++e) C[e] = v_quad_sum(C[e]);
+#pragma unroll
+        for (int e = 0; e < 3; ++e) g[e] = v_quad_sum(g[e]);
+        if (sub == 0) {
+            gm = fmax(fabs(g[0] / sp[0]), fmax(fabs(g[1] / sp[1]), fabs(g[2] / sp[2])));
+            C[0] += fmin(fmax(C[0], min_diag), max_diag) / radius;
+            C[2] += fmin(fmax(C[2], min_diag), max_diag) / radius;
+            C[5] += fmin(fmax(C[5], min_diag), max_diag) / radius;
+            double L[6], z[3];
+            chol3(C, L);
+            chol3_fwd(L, g, z);
+#pragma unroll
+            for (int e = 0; e < 6; ++e) d.Lp[6 * i + e] = L[e];
+#pragma unroll
+            for (int e = 0; e < 3; ++e) d.zp[3 * i + e] = z[e];
         }
     }
-    double gm = fmax(fabs(g[0] / sp[0]), fmax(fabs(g[1] / sp[1]), fabs(g[2] / sp[2])));
-    atomicMax(gmax, (unsigned long long)__double_as_longlong(gm));
-    C[0] += fmin(fmax(C[0], min_diag), max_diag) / radius;
-    C[2] += fmin(fmax(C[2], min_diag), max_diag) / radius;
-    C[5] += fmin(fmax(C[5], min_diag), max_diag) / radius;
-    double L[6], z[3];
-    chol3(C, L);
-    chol3_fwd(L, g, z);
+    // one atomic per workgroup: atomics on ONE address are serialised (one per wavefront of 16 landmarks cost 60 us here)
 #pragma unroll
-    for (int e = 0; e < 6; ++e) d.Lp[6 * i + e] = L[e];
-#pragma unroll
-    for (int e = 0; e < 3; ++e) d.zp[3 * i + e] = z[e];
+    for (int off = 32; off > 0; off >>= 1) gm = fmax(gm, __shfl_down(gm, off, 64));
+    if ((threadIdx.x & 63) == 0) redm[threadIdx.x >> 6] = gm;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicMax(gmax, (unsigned long long)__double_as_longlong(fmax(fmax(redm[0], redm[1]), fmax(redm[2], redm[3]))));
 }
 
 // workgroup (I, s): slice s of camera I's observations in camera-major order.  Per observation Y = (Jc^T Jp) L^-T
@@ -177,7 +215,7 @@ __global__ void vis_point_kernel(VisDev d, double radius, double min_diag, doubl
 __global__ __launch_bounds__(256) void vis_cam_kernel(VisDev d)
 {
     __shared__ double red[4 * 39];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nth = (int)blockDim.x; // 64 or 256 threads (vis_launch_reduced_system)
     const int I = blockIdx.x / d.S, s = blockIdx.x - I * d.S;
     const int64_t seg0 = d.csc_off[I], len = d.csc_off[I + 1] - seg0;
     const int64_t a = seg0 + (len * s) / d.S, b = seg0 + (len * (s + 1)) / d.S;
@@ -187,18 +225,24 @@ __global__ __launch_bounds__(256) void vis_cam_kernel(VisDev d)
     double acc[39];
 #pragma unroll
     for (int e = 0; e < 39; ++e) acc[e] = 0.0;
-    for (int64_t t = a + tid; t < b; t += 256) {
+    for (int64_t t = a + tid; t < b; t += nth) {
         const int64_t o = d.csc_f[t], i = d.group_of_pos[t];
         double J[12], P[6], L[6], z[3];
+        {   // 16-byte loads: the records are 96 / 48 / 48 / 16 bytes at multiples of their size
+            const double2 *jc = reinterpret_cast<const double2 *>(d.Jc + 12 * o), *jp = reinterpret_cast<const double2 *>(d.Jp + 6 * o);
+            const double2 *lp = reinterpret_cast<const double2 *>(d.Lp + 6 * i);
 #pragma unroll
-        for (int e = 0; e < 12; ++e) J[e] = d.Jc[12 * o + e] * sc[e % 6];
+            for (int e = 0; e < 6; ++e) { const double2 v = jc[e]; J[2 * e] = v.x * sc[(2 * e) % 6]; J[2 * e + 1] = v.y * sc[(2 * e + 1) % 6]; }
+            const double sp[3] = {d.sc_pt[3 * i], d.sc_pt[3 * i + 1], d.sc_pt[3 * i + 2]};
 #pragma unroll
-        for (int e = 0; e < 6; ++e) P[e] = d.Jp[6 * o + e] * d.sc_pt[3 * i + (e % 3)];
+            for (int e = 0; e < 3; ++e) { const double2 v = jp[e]; P[2 * e] = v.x * sp[(2 * e) % 3]; P[2 * e + 1] = v.y * sp[(2 * e + 1) % 3]; }
 #pragma unroll
-        for (int e = 0; e < 6; ++e) L[e] = d.Lp[6 * i + e];
+            for (int e = 0; e < 3; ++e) { const double2 v = lp[e]; L[2 * e] = v.x; L[2 * e + 1] = v.y; }
+        }
 #pragma unroll
         for (int e = 0; e < 3; ++e) z[e] = d.zp[3 * i + e];
-        const double r0 = d.r[2 * o], r1 = d.r[2 * o + 1];
+        const double2 rr2 = *reinterpret_cast<const double2 *>(d.r + 2 * o);
+        const double r0 = rr2.x, r1 = rr2.y;
         double Y[18];
 #pragma unroll
         for (int e = 0; e < 6; ++e) {
@@ -209,9 +253,9 @@ __global__ __launch_bounds__(256) void vis_cam_kernel(VisDev d)
             const double y2 = (E2 - y0 * L[3] - y1 * L[4]) / L[5];
             Y[e] = y0; Y[6 + e] = y1; Y[12 + e] = y2;
         }
-        double *yo = d.Y + 18 * t;
+        double2 *yo = reinterpret_cast<double2 *>(d.Y + 18 * t);
 #pragma unroll
-        for (int e = 0; e < 18; ++e) yo[e] = Y[e];
+        for (int e = 0; e < 9; ++e) yo[e] = double2{Y[2 * e], Y[2 * e + 1]};
         int p = 0;
 #pragma unroll
         for (int c = 0; c < 6; ++c)
@@ -234,7 +278,11 @@ __global__ __launch_bounds__(256) void vis_cam_kernel(VisDev d)
         if (lane == 0) red[wv * 39 + e] = v;
     }
     __syncthreads();
-    if (tid < 39) d.part[(int64_t)blockIdx.x * 40 + tid] = red[tid] + red[39 + tid] + red[78 + tid] + red[117 + tid];
+    if (tid < 39) {
+        double v = red[tid];
+        for (int w = 1; w < (nth >> 6); ++w) v += red[w * 39 + tid];
+        d.part[(int64_t)blockIdx.x * 40 + tid] = v;
+    }
 }
 
 // one thread per camera: slice sums -> diagonal block (lower) + LM diagonal, reduced right-hand side, gradient max
@@ -294,48 +342,65 @@ __global__ void vis_cam_finish_kernel(VisDev d, double radius, double min_diag, 
     atomicMax(gmax, (unsigned long long)__double_as_longlong(gm));
 }
 
-// lane = landmark: step_p = -L^-T (z + sum_obs Y^T step_c), and the model cost change
-// -sum_rows m (r + m/2), m = J step (scaled variables).  part[blockIdx] = partial of the model cost change.
+// four lanes (one DPP quad) per landmark, as in vis_point_kernel: step_p = -L^-T (z + sum_obs Y^T step_c), and the model cost
+// change -sum_rows m (r + m/2), m = J step (scaled variables).  part[blockIdx] = partial of the model cost change.
 __global__ __launch_bounds__(256) void vis_back_kernel(VisDev d, const double *__restrict__ step_c, double *__restrict__ part)
 {
     __shared__ double red[4];
-    const int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x;
+    const int64_t gid = blockIdx.x * (int64_t)256 + threadIdx.x;
+    const int64_t i = gid >> 2;
+    const int sub = (int)(gid & 3);
     double mc = 0.0;
-    if (i < d.Ta) {
-        double s[3] = {d.zp[3 * i], d.zp[3 * i + 1], d.zp[3 * i + 2]};
-        for (int64_t o = d.off[i]; o < d.off[i + 1]; ++o) {
-            const double *y = d.Y + 18 * (int64_t)d.pos_of[o];
-            const double *sc = step_c + 6 * (int64_t)d.cam[o];
+    if (i < d.Ta) { // whole quads
+        const int64_t o0 = d.off[i] + sub, o1 = d.off[i + 1];
+        double s[3] = {0.0, 0.0, 0.0};
+        if (sub == 0) { s[0] = d.zp[3 * i]; s[1] = d.zp[3 * i + 1]; s[2] = d.zp[3 * i + 2]; }
+        for (int64_t o = o0; o < o1; o += 4) {
+            const double2 *y = reinterpret_cast<const double2 *>(d.Y + 18 * (int64_t)d.pos_of[o]);
+            const double2 *sc = reinterpret_cast<const double2 *>(step_c + 6 * (int64_t)d.cam[o]);
+            const double2 c0 = sc[0], c1 = sc[1], c2 = sc[2];
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
-                double v = 0.0;
-#pragma unroll
-                for (int e = 0; e < 6; ++e) v += y[6 * m + e] * sc[e];
-                s[m] += v;
+                const double2 y0 = y[3 * m], y1 = y[3 * m + 1], y2 = y[3 * m + 2];
+                s[m] += y0.x * c0.x + y0.y * c0.y + y1.x * c1.x + y1.y * c1.y + y2.x * c2.x + y2.y * c2.y;
             }
         }
+#pragma unroll
+        for (int e = 0; e < 3; ++e) s[e] = v_quad_sum(s[e]);
         double L[6], sp[3], st[3];
 #pragma unroll
         for (int e = 0; e < 6; ++e) L[e] = d.Lp[6 * i + e];
         chol3_bwd(L, s, st);
 #pragma unroll
-        for (int e = 0; e < 3; ++e) { st[e] = -st[e]; sp[e] = d.sc_pt[3 * i + e]; d.step_p[3 * i + e] = st[e]; }
-        {
+        for (int e = 0; e < 3; ++e) { st[e] = -st[e]; sp[e] = d.sc_pt[3 * i + e]; }
+        if (sub == 0) {
+#pragma unroll
+            for (int e = 0; e < 3; ++e) d.step_p[3 * i + e] = st[e];
             const double m = d.Jpl[3 * i] * sp[0] * st[0] + d.Jpl[3 * i + 1] * sp[1] * st[1] + d.Jpl[3 * i + 2] * sp[2] * st[2];
             mc -= m * (d.rpl[i] + 0.5 * m);
         }
-        for (int64_t o = d.off[i]; o < d.off[i + 1]; ++o) {
+        for (int64_t o = o0; o < o1; o += 4) {
             const int cam = d.cam[o];
             const double *sc = step_c + 6 * (int64_t)cam;
             const double *scl = d.sc_cam + 6 * (int64_t)cam;
+            double w[6];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) w[e] = scl[e] * sc[e];
+            const double2 *jc = reinterpret_cast<const double2 *>(d.Jc + 12 * o), *jp = reinterpret_cast<const double2 *>(d.Jp + 6 * o);
+            double J[12], P[6];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) { const double2 v = jc[e]; J[2 * e] = v.x; J[2 * e + 1] = v.y; }
+#pragma unroll
+            for (int e = 0; e < 3; ++e) { const double2 v = jp[e]; P[2 * e] = v.x; P[2 * e + 1] = v.y; }
+            const double2 rr = *reinterpret_cast<const double2 *>(d.r + 2 * o);
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 double m = 0.0;
 #pragma unroll
-                for (int e = 0; e < 6; ++e) m += d.Jc[12 * o + 6 * k + e] * scl[e] * sc[e];
+                for (int e = 0; e < 6; ++e) m += J[6 * k + e] * w[e];
 #pragma unroll
-                for (int e = 0; e < 3; ++e) m += d.Jp[6 * o + 3 * k + e] * sp[e] * st[e];
-                mc -= m * (d.r[2 * o + k] + 0.5 * m);
+                for (int e = 0; e < 3; ++e) m += P[3 * k + e] * sp[e] * st[e];
+                mc -= m * ((k == 0 ? rr.x : rr.y) + 0.5 * m);
             }
         }
     }
@@ -447,15 +512,18 @@ void vis_launch_reduced_system(const VisDev &d, const PairDev &pd, double radius
 {
     if (zero_first) hipMemsetAsync(Hblk, 0, (size_t)hblk_doubles * sizeof(double), s);
     hipMemsetAsync(gmax, 0, sizeof(unsigned long long), s);
-    hipLaunchKernelGGL(vis_point_kernel, dim3(nblk(d.Ta, 256)), dim3(256), 0, s, d, radius, min_diag, max_diag, gmax);
-    hipLaunchKernelGGL(vis_cam_kernel, dim3((unsigned)(d.M * d.S)), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(vis_point_kernel, dim3(nblk(4 * d.Ta, 256)), dim3(256), 0, s, d, radius, min_diag, max_diag, gmax);
+    // one wavefront per (camera, slice) while a slice is short: its 39 sums cost one 64-lane reduction per WAVEFRONT, which at ~250
+    // observations per camera was most of the kernel with four wavefronts of one observation per lane each
+    const int64_t per_slice = d.O / ((int64_t)d.M * d.S > 0 ? (int64_t)d.M * d.S : 1);
+    hipLaunchKernelGGL(vis_cam_kernel, dim3((unsigned)(d.M * d.S)), dim3(per_slice <= 1024 ? 64 : 256), 0, s, d);
     hipLaunchKernelGGL(vis_cam_reduce_kernel, dim3(nblk(d.M, 64)), dim3(64), 0, s, d, radius, min_diag, max_diag, Hblk, g, gmax);
     launch_pairs(pd, Hblk, s);
 }
 
 void vis_launch_back(const VisDev &d, const double *step_c, double *part, double *model_out, hipStream_t s)
 {
-    const unsigned nb = nblk(d.Ta, 256);
+    const unsigned nb = nblk(4 * d.Ta, 256);
     hipLaunchKernelGGL(vis_back_kernel, dim3(nb), dim3(256), 0, s, d, step_c, part);
     hipLaunchKernelGGL(vis_reduce_kernel, dim3(1), dim3(1024), 0, s, part, (int64_t)nb, 1, model_out);
 }
