@@ -53,6 +53,7 @@ struct VisDev {
     const int32_t *cam;            // [O] camera (solver order) of each observation
     const int32_t *track_of_obs;   // [O]
     const double *uv;              // [O][2]
+    const double *uv_cm;           // [O][2] the same in camera-major order (position t of the CSC lists): vis_cam_kernel
     const double *plane;           // [Ta][4]
     double intr[8];
     double inv_sig_px, inv_sig_pl;
@@ -112,8 +113,12 @@ void vis_launch_colsums(const VisDev &d, hipStream_t s);           // sharded: l
 void vis_launch_colnorm_finish(const VisDev &d, hipStream_t s);    //          (after the all-reduce of colsum) camera scaling
 void vis_launch_cam_finish(const VisDev &d, double radius, double min_diag, double max_diag, double *Hblk, unsigned long long *gmax,
                            hipStream_t s);                         // sharded, after the all-reduces: LM diagonal, gradient max
-void vis_launch_reduced_system(const VisDev &d, const PairDev &pd, double radius, double min_diag, double max_diag, double *Hblk,
+void vis_launch_gather_uv(const VisDev &d, double *uv_cm, hipStream_t s);
+void vis_launch_reduced_system(const VisDev &d, const PairDev &pd, const double *qc, const double *tc, const double *Xp, double radius, double min_diag, double max_diag, double *Hblk,
                                int64_t hblk_doubles, double *g, unsigned long long *gmax, bool zero_first, hipStream_t s);
+void vis_launch_step_and_trial(const VisDev &d, const double *step_c, const double *qc, const double *tc, const double *Xp, double *qc2,
+                               double *tc2, double *Xp2, double *part, double *scal, const unsigned long long *gmax, const int *status,
+                               double *host_pin, hipStream_t s);
 void vis_launch_back(const VisDev &d, const double *step_c, double *part, double *model_out, hipStream_t s);
 void vis_launch_apply(const VisDev &d, const double *step_c, const double *qc, const double *tc, const double *Xp, double *qc2,
                       double *tc2, double *Xp2, double *part, double *norms_out, hipStream_t s);

@@ -31,7 +31,7 @@ struct lvba_visual_s {
     // device
     int64_t *d_off = nullptr;
     int32_t *d_cam = nullptr, *d_track_of_obs = nullptr;
-    double *d_uv = nullptr, *d_plane = nullptr;
+    double *d_uv = nullptr, *d_plane = nullptr, *d_uv_cm = nullptr;
     double *d_Jc = nullptr, *d_Jp = nullptr, *d_r = nullptr, *d_rpl = nullptr, *d_Jpl = nullptr;
     double *d_sc_cam = nullptr, *d_sc_pt = nullptr, *d_Lp = nullptr, *d_zp = nullptr, *d_step_p = nullptr, *d_part = nullptr;
     double *d_q = nullptr, *d_t = nullptr, *d_X = nullptr, *d_q2 = nullptr, *d_t2 = nullptr, *d_X2 = nullptr;
@@ -47,7 +47,7 @@ struct lvba_visual_s {
     {
         VisDev d;
         d.M = M; d.S = bs.S; d.band_blocks = bs.Bb; d.fixed_cam = bs.iperm.empty() ? 0 : bs.iperm[0];
-        d.Ta = Ta; d.O = O; d.off = d_off; d.cam = d_cam; d.track_of_obs = d_track_of_obs; d.uv = d_uv; d.plane = d_plane;
+        d.Ta = Ta; d.O = O; d.off = d_off; d.cam = d_cam; d.track_of_obs = d_track_of_obs; d.uv = d_uv; d.uv_cm = d_uv_cm; d.plane = d_plane;
         for (int e = 0; e < 8; ++e) d.intr[e] = intr[e];
         d.inv_sig_px = 1.0 / sig_px; d.inv_sig_pl = 1.0 / std::max(1e-9, sig_pl); // utils.hpp:131
         d.Jc = d_Jc; d.Jp = d_Jp; d.r = d_r; d.rpl = d_rpl; d.Jpl = d_Jpl; d.sc_cam = d_sc_cam; d.sc_pt = d_sc_pt;
@@ -72,7 +72,7 @@ extern "C" int32_t lvba_visual_destroy(lvba_visual_t h)
     if (!h) return LVBA_OK;
     hipSetDevice(h->bs.device);
     if (h->bs.stream) hipStreamSynchronize(h->bs.stream);
-    void *ptrs[] = {h->d_off, h->d_cam, h->d_track_of_obs, h->d_uv, h->d_plane, h->d_Jc, h->d_Jp, h->d_r, h->d_rpl, h->d_Jpl,
+    void *ptrs[] = {h->d_off, h->d_cam, h->d_track_of_obs, h->d_uv, h->d_uv_cm, h->d_plane, h->d_Jc, h->d_Jp, h->d_r, h->d_rpl, h->d_Jpl,
                     h->d_sc_cam, h->d_sc_pt, h->d_Lp, h->d_zp, h->d_step_p, h->d_part, h->d_q, h->d_t, h->d_X, h->d_q2,
                     h->d_t2, h->d_X2, h->d_blkpart, h->d_scal, h->d_gmax, h->d_out, h->d_camsum, h->d_colsum};
     for (void *p : ptrs)
@@ -172,6 +172,8 @@ static int32_t finalize(lvba_visual_s *h)
         if (h->O) HIPCHK(hipMemcpy(h->d_cam, cam.data(), (size_t)h->O * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     TRY(bs_dmalloc(bs, &h->d_part, (int64_t)h->M * bs.S * 40));
+    TRY(bs_dmalloc(bs, &h->d_uv_cm, 2 * std::max<int64_t>(1, h->O)));
+    vis_launch_gather_uv(h->dev(), h->d_uv_cm, bs.stream);
     lvba::hvec<int32_t>().swap(h->h_cam);
     h->finalized = true;
     return LVBA_OK;
@@ -230,7 +232,7 @@ static int32_t enqueue_reduced_system(lvba_visual_s *h, double radius, const lvb
 {
     BlockSys &bs = h->bs;
     const VisDev d = h->dev();
-    vis_launch_reduced_system(d, bs.pair_dev(), radius, o.min_lm_diagonal, o.max_lm_diagonal, bs.Hblk(), bs.hblk_doubles, bs.g(),
+    vis_launch_reduced_system(d, bs.pair_dev(), h->d_q, h->d_t, h->d_X, radius, o.min_lm_diagonal, o.max_lm_diagonal, bs.Hblk(), bs.hblk_doubles, bs.g(),
                               h->d_gmax, bs.distributed(), bs.stream);
     if (!bs.distributed()) return LVBA_OK;
     TRY(bs_allreduce_hg(bs));                                   // [S blocks | reduced rhs]: sums over the track shards
@@ -369,15 +371,24 @@ extern "C" int32_t lvba_visual_refine(lvba_visual_t h, double *q, double *t, dou
         mark(1);
         TRY(bs_enqueue_solve(bs, 0.0));
         mark(2);
-        vis_launch_back(d, bs.d_dx, h->d_blkpart, h->d_scal + 2, bs.stream);
-        mark(3);
-        vis_launch_apply(d, bs.d_dx, h->d_q, h->d_t, h->d_X, h->d_q2, h->d_t2, h->d_X2, h->d_blkpart, h->d_scal + 3, bs.stream);
-        vis_launch_residuals(d, false, h->d_q2, h->d_t2, h->d_X2, h->d_blkpart, h->d_scal + 1, bs.stream);
-        mark(4);
-        TRY(allreduce_scalars(h, 1, 4)); // candidate cost, model cost change, |step|^2, |x|^2: sums over the track shards
-        HIPCHK(hipMemcpyAsync(h->h_pin, h->d_scal, 5 * sizeof(double), hipMemcpyDeviceToHost, bs.stream));
-        HIPCHK(hipMemcpyAsync(h->h_pin + 8, h->d_gmax, sizeof(unsigned long long), hipMemcpyDeviceToHost, bs.stream));
-        HIPCHK(hipMemcpyAsync(h->h_pin + 9, bs.d_status, sizeof(int), hipMemcpyDeviceToHost, bs.stream));
+        if (!bs.distributed()) {
+            // one rank: back-substitution, candidate, its cost, and one closing kernel that sums the partial lists and writes what
+            // the host reads below into the pinned buffer (no reductions of their own, no device-to-host copies)
+            mark(3);
+            vis_launch_step_and_trial(d, bs.d_dx, h->d_q, h->d_t, h->d_X, h->d_q2, h->d_t2, h->d_X2, h->d_blkpart, h->d_scal, h->d_gmax,
+                                      bs.d_status, h->h_pin, bs.stream);
+            mark(4);
+        } else {
+            vis_launch_back(d, bs.d_dx, h->d_blkpart, h->d_scal + 2, bs.stream);
+            mark(3);
+            vis_launch_apply(d, bs.d_dx, h->d_q, h->d_t, h->d_X, h->d_q2, h->d_t2, h->d_X2, h->d_blkpart, h->d_scal + 3, bs.stream);
+            vis_launch_residuals(d, false, h->d_q2, h->d_t2, h->d_X2, h->d_blkpart, h->d_scal + 1, bs.stream);
+            mark(4);
+            TRY(allreduce_scalars(h, 1, 4)); // candidate cost, model cost change, |step|^2, |x|^2: sums over the track shards
+            HIPCHK(hipMemcpyAsync(h->h_pin, h->d_scal, 5 * sizeof(double), hipMemcpyDeviceToHost, bs.stream));
+            HIPCHK(hipMemcpyAsync(h->h_pin + 8, h->d_gmax, sizeof(unsigned long long), hipMemcpyDeviceToHost, bs.stream));
+            HIPCHK(hipMemcpyAsync(h->h_pin + 9, bs.d_status, sizeof(int), hipMemcpyDeviceToHost, bs.stream));
+        }
         mark(5);
         if (prof && pn < PCAP) ++pn;
         HIPCHK(hipStreamSynchronize(bs.stream));

@@ -17,6 +17,7 @@
 // Camera order everywhere is the solver's (RCM) order; camera `fixed_cam` is constant (zero Jacobian columns).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 #include "lvba_internal.h"
 #include "visual_math.h"
 
@@ -114,34 +115,41 @@ __global__ void vis_colnorm_pt_kernel(VisDev d)
     for (int e = 0; e < 3; ++e) d.sc_pt[3 * i + e] = 1.0 / (1.0 + sqrt(s[e]));
 }
 
-// ... and of the camera columns (one thread per camera over its camera-major observation list)
-__global__ void vis_colnorm_cam_kernel(VisDev d)
+// ... and of the camera columns: one wavefront per camera over its camera-major observation list (one THREAD per camera walked
+// 250 dependent gathers: 180 us, a tenth of a whole refinement)
+__device__ __forceinline__ void colsq_cam(const VisDev &d, int64_t I, double (&s)[6])
 {
-    const int64_t I = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (I >= d.M) return;
-    double s[6] = {0, 0, 0, 0, 0, 0};
-    for (int64_t t = d.csc_off[I]; t < d.csc_off[I + 1]; ++t) {
-        const int64_t o = d.csc_f[t];
 #pragma unroll
-        for (int e = 0; e < 6; ++e) s[e] += d.Jc[12 * o + e] * d.Jc[12 * o + e] + d.Jc[12 * o + 6 + e] * d.Jc[12 * o + 6 + e];
+    for (int e = 0; e < 6; ++e) s[e] = 0.0;
+    for (int64_t t = d.csc_off[I] + (threadIdx.x & 63); t < d.csc_off[I + 1]; t += 64) {
+        const double2 *jc = reinterpret_cast<const double2 *>(d.Jc + 12 * (int64_t)d.csc_f[t]);
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const double2 a = jc[e], b = jc[3 + e];
+            s[2 * e] += a.x * a.x + b.x * b.x;
+            s[2 * e + 1] += a.y * a.y + b.y * b.y;
+        }
     }
 #pragma unroll
-    for (int e = 0; e < 6; ++e) d.sc_cam[6 * I + e] = 1.0 / (1.0 + sqrt(s[e]));
+    for (int e = 0; e < 6; ++e) s[e] = v_wave_sum(s[e]);
+}
+__global__ __launch_bounds__(64) void vis_colnorm_cam_kernel(VisDev d)
+{
+    double s[6];
+    colsq_cam(d, blockIdx.x, s);
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int e = 0; e < 6; ++e) d.sc_cam[6 * (int64_t)blockIdx.x + e] = 1.0 / (1.0 + sqrt(s[e]));
 }
 
 // sharded form: the sums of squares alone (all-reduced over the ranks' track shards before the scaling is taken)
-__global__ void vis_colsum_cam_kernel(VisDev d)
+__global__ __launch_bounds__(64) void vis_colsum_cam_kernel(VisDev d)
 {
-    const int64_t I = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (I >= d.M) return;
-    double s[6] = {0, 0, 0, 0, 0, 0};
-    for (int64_t t = d.csc_off[I]; t < d.csc_off[I + 1]; ++t) {
-        const int64_t o = d.csc_f[t];
+    double s[6];
+    colsq_cam(d, blockIdx.x, s);
+    if (threadIdx.x == 0)
 #pragma unroll
-        for (int e = 0; e < 6; ++e) s[e] += d.Jc[12 * o + e] * d.Jc[12 * o + e] + d.Jc[12 * o + 6 + e] * d.Jc[12 * o + 6 + e];
-    }
-#pragma unroll
-    for (int e = 0; e < 6; ++e) d.colsum[6 * I + e] = s[e];
+        for (int e = 0; e < 6; ++e) d.colsum[6 * (int64_t)blockIdx.x + e] = s[e];
 }
 __global__ void vis_colnorm_cam_finish_kernel(VisDev d)
 {
@@ -212,7 +220,8 @@ __global__ __launch_bounds__(256) void vis_point_kernel(VisDev d, double radius,
 // workgroup (I, s): slice s of camera I's observations in camera-major order.  Per observation Y = (Jc^T Jp) L^-T
 // (stored for the pair pass and the back-substitution); per camera the sums of
 //   D = Jc^T Jc - Y Y^T (lower 21) | reduced rhs Jc^T r - Y z (6) | diag(Jc^T Jc) (6) | Jc^T r (6)   -> part[.][40]
-__global__ __launch_bounds__(256) void vis_cam_kernel(VisDev d)
+__global__ __launch_bounds__(256) void vis_cam_kernel(VisDev d, const double *__restrict__ qc, const double *__restrict__ tc,
+                                                      const double *__restrict__ Xp)
 {
     __shared__ double red[4 * 39];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nth = (int)blockDim.x; // 64 or 256 threads (vis_launch_reduced_system)
@@ -225,24 +234,35 @@ __global__ __launch_bounds__(256) void vis_cam_kernel(VisDev d)
     double acc[39];
 #pragma unroll
     for (int e = 0; e < 39; ++e) acc[e] = 0.0;
-    for (int64_t t = a + tid; t < b; t += nth) {
-        const int64_t o = d.csc_f[t], i = d.group_of_pos[t];
-        double J[12], P[6], L[6], z[3];
-        {   // 16-byte loads: the records are 96 / 48 / 48 / 16 bytes at multiples of their size
-            const double2 *jc = reinterpret_cast<const double2 *>(d.Jc + 12 * o), *jp = reinterpret_cast<const double2 *>(d.Jp + 6 * o);
-            const double2 *lp = reinterpret_cast<const double2 *>(d.Lp + 6 * i);
+    // The observation's residual and Jacobians are RE-COMPUTED here from the camera (uniform over the workgroup), the landmark
+    // and the pixel (camera-major copy: coalesced) -- ~300 flops -- instead of gathered from what vis_residual_kernel stored in
+    // landmark-major order: 160 bytes per observation in 96 / 48 / 16-byte pieces of other cameras' cache lines were most of this
+    // kernel's time (85 us for 80 MB).
+    double qI[4], tI[3];
 #pragma unroll
-            for (int e = 0; e < 6; ++e) { const double2 v = jc[e]; J[2 * e] = v.x * sc[(2 * e) % 6]; J[2 * e + 1] = v.y * sc[(2 * e + 1) % 6]; }
+    for (int e = 0; e < 4; ++e) qI[e] = qc[4 * (int64_t)I + e];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) tI[e] = tc[3 * (int64_t)I + e];
+    const bool fixed = I == d.fixed_cam;
+    for (int64_t t = a + tid; t < b; t += nth) {
+        const int64_t i = d.group_of_pos[t];
+        double J[12], P[6], L[6], z[3], rr[2];
+        {
+            const double2 uv = *reinterpret_cast<const double2 *>(d.uv_cm + 2 * t);
+            const double X[3] = {Xp[3 * i], Xp[3 * i + 1], Xp[3 * i + 2]};
+            reproj_eval<true>(qI, tI, X, uv.x, uv.y, d.intr, d.inv_sig_px, rr, J, P);
             const double sp[3] = {d.sc_pt[3 * i], d.sc_pt[3 * i + 1], d.sc_pt[3 * i + 2]};
 #pragma unroll
-            for (int e = 0; e < 3; ++e) { const double2 v = jp[e]; P[2 * e] = v.x * sp[(2 * e) % 3]; P[2 * e + 1] = v.y * sp[(2 * e + 1) % 3]; }
+            for (int e = 0; e < 12; ++e) J[e] = fixed ? 0.0 : J[e] * sc[e % 6];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) P[e] *= sp[e % 3];
+            const double2 *lp = reinterpret_cast<const double2 *>(d.Lp + 6 * i);
 #pragma unroll
             for (int e = 0; e < 3; ++e) { const double2 v = lp[e]; L[2 * e] = v.x; L[2 * e + 1] = v.y; }
         }
 #pragma unroll
         for (int e = 0; e < 3; ++e) z[e] = d.zp[3 * i + e];
-        const double2 rr2 = *reinterpret_cast<const double2 *>(d.r + 2 * o);
-        const double r0 = rr2.x, r1 = rr2.y;
+        const double r0 = rr[0], r1 = rr[1];
         double Y[18];
 #pragma unroll
         for (int e = 0; e < 6; ++e) {
@@ -474,6 +494,51 @@ __global__ __launch_bounds__(1024) void vis_reduce_kernel(const double *__restri
     }
 }
 
+// camera-major copy of the pixel observations (set-up, once)
+__global__ void vis_gather_uv_kernel(VisDev d, double *__restrict__ uv_cm)
+{
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= d.O) return;
+    const int64_t o = d.csc_f[t];
+    uv_cm[2 * t] = d.uv[2 * o];
+    uv_cm[2 * t + 1] = d.uv[2 * o + 1];
+}
+
+// End of an LM iteration on one rank, ONE workgroup: the three per-workgroup partial lists (model cost change | step and
+// parameter norms | cost at the trial point) summed in a fixed order, and everything the host's accept / reject logic reads
+// written straight into its pinned buffer: host[0..4] = scal[0..4], host[8] = gradient max (bits), host[9] = solver status.
+// Replaces three single-workgroup reductions and three device-to-host copies (six stream operations of ~5 us each).
+__global__ __launch_bounds__(1024) void vis_finish_kernel(const double *__restrict__ part, int64_t nb_back, int64_t nb_apply,
+                                                          int64_t nb_res, double *__restrict__ scal,
+                                                          const unsigned long long *__restrict__ gmax, const int *__restrict__ status,
+                                                          double *__restrict__ host)
+{
+    __shared__ double red[4][16];
+    const double *pb = part, *pa = part + nb_back, *pr = part + nb_back + 2 * nb_apply;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int64_t i = threadIdx.x; i < nb_back; i += 1024) s0 += pb[i];
+    for (int64_t i = threadIdx.x; i < nb_apply; i += 1024) { s1 += pa[2 * i]; s2 += pa[2 * i + 1]; }
+    for (int64_t i = threadIdx.x; i < nb_res; i += 1024) s3 += pr[i];
+    s0 = v_wave_sum(s0); s1 = v_wave_sum(s1); s2 = v_wave_sum(s2); s3 = v_wave_sum(s3);
+    if ((threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
+        red[0][w] = s0; red[1][w] = s1; red[2][w] = s2; red[3][w] = s3;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int k = 0; k < 4; ++k)
+            for (int w = 0; w < 16; ++w) t[k] += red[k][w];
+        scal[2] = t[0]; scal[3] = t[1]; scal[4] = t[2]; scal[1] = t[3];
+        host[0] = scal[0]; host[1] = t[3]; host[2] = t[0]; host[3] = t[1]; host[4] = t[2];
+        host[8] = __longlong_as_double((long long)gmax[0]);
+        int st = status[0];
+        double stw = 0.0;
+        memcpy(&stw, &st, sizeof st);
+        host[9] = stw;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- launchers
 static inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b > 0 ? (n + b - 1) / b : 1); }
 
@@ -483,19 +548,33 @@ void vis_launch_residuals(const VisDev &d, bool jac, const double *qc, const dou
     const unsigned nb = nblk(d.O + d.Ta, 256);
     if (jac) hipLaunchKernelGGL(vis_residual_kernel<true>, dim3(nb), dim3(256), 0, s, d, qc, tc, Xp, part);
     else hipLaunchKernelGGL(vis_residual_kernel<false>, dim3(nb), dim3(256), 0, s, d, qc, tc, Xp, part);
-    hipLaunchKernelGGL(vis_reduce_kernel, dim3(1), dim3(1024), 0, s, part, (int64_t)nb, 1, cost_out);
+    if (cost_out) hipLaunchKernelGGL(vis_reduce_kernel, dim3(1), dim3(1024), 0, s, part, (int64_t)nb, 1, cost_out);
+}
+
+// back-substitution, candidate point and its cost with ONE closing kernel (vis_finish_kernel) instead of a reduction each
+void vis_launch_step_and_trial(const VisDev &d, const double *step_c, const double *qc, const double *tc, const double *Xp, double *qc2,
+                               double *tc2, double *Xp2, double *part, double *scal, const unsigned long long *gmax, const int *status,
+                               double *host_pin, hipStream_t s)
+{
+    const unsigned nb_back = nblk(4 * d.Ta, 256), nb_apply = nblk(d.M + d.Ta, 256), nb_res = nblk(d.O + d.Ta, 256);
+    double *pa = part + nb_back, *pr = pa + 2 * (int64_t)nb_apply;
+    hipLaunchKernelGGL(vis_back_kernel, dim3(nb_back), dim3(256), 0, s, d, step_c, part);
+    hipLaunchKernelGGL(vis_apply_kernel, dim3(nb_apply), dim3(256), 0, s, d, step_c, qc, tc, Xp, qc2, tc2, Xp2, pa);
+    hipLaunchKernelGGL(vis_residual_kernel<false>, dim3(nb_res), dim3(256), 0, s, d, qc2, tc2, Xp2, pr);
+    hipLaunchKernelGGL(vis_finish_kernel, dim3(1), dim3(1024), 0, s, part, (int64_t)nb_back, (int64_t)nb_apply, (int64_t)nb_res, scal,
+                       gmax, status, host_pin);
 }
 
 void vis_launch_colnorms(const VisDev &d, hipStream_t s)
 {
     hipLaunchKernelGGL(vis_colnorm_pt_kernel, dim3(nblk(d.Ta, 256)), dim3(256), 0, s, d);
-    hipLaunchKernelGGL(vis_colnorm_cam_kernel, dim3(nblk(d.M, 64)), dim3(64), 0, s, d);
+    hipLaunchKernelGGL(vis_colnorm_cam_kernel, dim3((unsigned)d.M), dim3(64), 0, s, d);
 }
 
 void vis_launch_colsums(const VisDev &d, hipStream_t s)
 {
     hipLaunchKernelGGL(vis_colnorm_pt_kernel, dim3(nblk(d.Ta, 256)), dim3(256), 0, s, d);
-    hipLaunchKernelGGL(vis_colsum_cam_kernel, dim3(nblk(d.M, 64)), dim3(64), 0, s, d);
+    hipLaunchKernelGGL(vis_colsum_cam_kernel, dim3((unsigned)d.M), dim3(64), 0, s, d);
 }
 void vis_launch_colnorm_finish(const VisDev &d, hipStream_t s)
 {
@@ -507,7 +586,12 @@ void vis_launch_cam_finish(const VisDev &d, double radius, double min_diag, doub
     hipLaunchKernelGGL(vis_cam_finish_kernel, dim3(nblk(d.M, 64)), dim3(64), 0, s, d, radius, min_diag, max_diag, Hblk, gmax);
 }
 
-void vis_launch_reduced_system(const VisDev &d, const PairDev &pd, double radius, double min_diag, double max_diag, double *Hblk,
+void vis_launch_gather_uv(const VisDev &d, double *uv_cm, hipStream_t s)
+{
+    if (d.O > 0) hipLaunchKernelGGL(vis_gather_uv_kernel, dim3(nblk(d.O, 256)), dim3(256), 0, s, d, uv_cm);
+}
+
+void vis_launch_reduced_system(const VisDev &d, const PairDev &pd, const double *qc, const double *tc, const double *Xp, double radius, double min_diag, double max_diag, double *Hblk,
                                int64_t hblk_doubles, double *g, unsigned long long *gmax, bool zero_first, hipStream_t s)
 {
     if (zero_first) hipMemsetAsync(Hblk, 0, (size_t)hblk_doubles * sizeof(double), s);
@@ -516,7 +600,7 @@ void vis_launch_reduced_system(const VisDev &d, const PairDev &pd, double radius
     // one wavefront per (camera, slice) while a slice is short: its 39 sums cost one 64-lane reduction per WAVEFRONT, which at ~250
     // observations per camera was most of the kernel with four wavefronts of one observation per lane each
     const int64_t per_slice = d.O / ((int64_t)d.M * d.S > 0 ? (int64_t)d.M * d.S : 1);
-    hipLaunchKernelGGL(vis_cam_kernel, dim3((unsigned)(d.M * d.S)), dim3(per_slice <= 1024 ? 64 : 256), 0, s, d);
+    hipLaunchKernelGGL(vis_cam_kernel, dim3((unsigned)(d.M * d.S)), dim3(per_slice <= 1024 ? 64 : 256), 0, s, d, qc, tc, Xp);
     hipLaunchKernelGGL(vis_cam_reduce_kernel, dim3(nblk(d.M, 64)), dim3(64), 0, s, d, radius, min_diag, max_diag, Hblk, g, gmax);
     launch_pairs(pd, Hblk, s);
 }

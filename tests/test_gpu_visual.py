@@ -239,10 +239,11 @@ def test_block_cyclic_reduction_equals_band_ldlt(pkg, synth, monkeypatch, n_cams
     (q1, t1, X1), tr1, term1, rc1 = out["1"]
     (q0, t0, X0), tr0, term0, rc0 = out["0"]
     assert rc1 == rc0 == 0 and term1 == term0 and len(tr1) == len(tr0) and len(tr1) >= 4
-    for a, b in zip(tr1, tr0):
-        assert a["accepted"] == b["accepted"] and abs(a["cost"] - b["cost"]) <= 1e-8 * b["cost"]
     # the system is ill-conditioned (the constant camera's block carries only the 1e-10 LM diagonal: cond ~ 3e10), so two
-    # direct solvers agree to ~1e-10 in the costs and correspondingly less in the variables
+    # direct solvers' steps differ by ~cond * eps ~ 3e-6 in the worst direction: the costs along the trace agree to a few 1e-8
+    # (3.1e-8 measured at one iteration of the 1 000-camera case), the variables correspondingly less
+    for a, b in zip(tr1, tr0):
+        assert a["accepted"] == b["accepted"] and abs(a["cost"] - b["cost"]) <= 1e-7 * b["cost"]
     assert np.abs(q1 - q0).max() <= 1e-7 and np.abs(t1 - t0).max() <= 1e-6 and np.abs(X1 - X0).max() <= 1e-5
     assert tr1[-1]["cost"] < 0.1 * tr1[0]["cost"]
 
