@@ -352,11 +352,18 @@ def visual_leg(pkg, synth, n_cams, local_rank, with_cpu=True):
     # must bring every error against ground truth DOWN
     d = synth.make_visual_problem(n_cams, 125_000, rot_sigma_deg=0.3, trans_sigma=0.10, point_sigma=0.30, device=f"cuda:{local_rank}")
     prob = pkg.VisualProblem(n_cams, d["obs_off"], d["obs_cam"], d["obs_uv"], d["plane"], d["valid"], d["intr"], device=local_rank)
-    prob.refine(d["q"], d["t"], d["X"], max_iter=2)                      # warm-up (graph capture, allocations)
+    prob.refine(d["q"], d["t"], d["X"], max_iter=3)                      # warm-up (graph capture, allocations)
     t0 = time.perf_counter()
     (q, t, X), trace, term, rc = prob.refine(d["q"], d["t"], d["X"])
     dt = time.perf_counter() - t0
     iters = max(1, len(trace) - 1)
+    # the cost of ONE iteration inside the loop (no state upload, first evaluation, Jacobi scaling, download): the slope between a
+    # refinement capped at two iterations and the whole one
+    t0 = time.perf_counter()
+    _, trace2, _, _ = prob.refine(d["q"], d["t"], d["X"], max_iter=2)
+    dt2 = time.perf_counter() - t0
+    it2 = max(1, len(trace2) - 1)
+    in_loop_ms = 1e3 * (dt - dt2) / (iters - it2) if iters > it2 else None
     # the factor kernels alone: residuals + Jacobians + column norms + Schur products -> reduced system (no solve, no download)
     lin = []
     for _ in range(5):
@@ -377,6 +384,8 @@ def visual_leg(pkg, synth, n_cams, local_rank, with_cpu=True):
     flops_solve = n * bw * bw
     out = {"workload": f"{n_cams} cameras x 125000 landmarks x {n_obs} reprojection observations + plane priors",
            "lm_iterations": iters, "iterations_per_s": iters / dt, "ms_per_iteration": iter_ms, "termination": term,
+           "ms_per_iteration_in_loop": in_loop_ms,
+           "fixed_ms": (1e3 * dt - iters * in_loop_ms) if in_loop_ms is not None else None,
            "observations_per_s": n_obs_act * iters / dt,
            "stage_ms": {"linearize (factor kernels)": lin_ms, "solve + step + trial cost": solve_ms},
            "roofline": {"bound": "hbm", "kernel": "vis_residual / vis_colnorm / vis_point / vis_cam / pair pass (one linearisation)",

@@ -119,7 +119,8 @@ void vis_launch_reduced_system(const VisDev &d, const PairDev &pd, const double 
 void vis_launch_step_and_trial(const VisDev &d, const double *step_c, const double *qc, const double *tc, const double *Xp, double *qc2,
                                double *tc2, double *Xp2, double *part, double *scal, const unsigned long long *gmax, const int *status,
                                double *host_pin, hipStream_t s);
-void vis_launch_back(const VisDev &d, const double *step_c, double *part, double *model_out, hipStream_t s);
+void vis_launch_back(const VisDev &d, const double *step_c, const double *qc, const double *tc, const double *Xp, double *part,
+                     double *model_out, hipStream_t s);
 void vis_launch_apply(const VisDev &d, const double *step_c, const double *qc, const double *tc, const double *Xp, double *qc2,
                       double *tc2, double *Xp2, double *part, double *norms_out, hipStream_t s);
 

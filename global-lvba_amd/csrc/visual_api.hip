@@ -41,7 +41,8 @@ struct lvba_visual_s {
     double *d_camsum = nullptr, *d_colsum = nullptr; // sharded runs: per-camera sums awaiting the other ranks' tracks
     double *d_out = nullptr;       // export staging
     double *h_pin = nullptr;
-    lvba::hvec<double> hq, ht, hX; // host staging in solver order
+    double *hq = nullptr, *ht = nullptr, *hX = nullptr; // host staging in solver order: ONE pinned block (h_stage), so the state
+    double *h_stage = nullptr;                          // uploads / downloads are DMA transfers, not pageable copies
 
     VisDev dev() const
     {
@@ -78,6 +79,7 @@ extern "C" int32_t lvba_visual_destroy(lvba_visual_t h)
     for (void *p : ptrs)
         if (p) lvba::DevicePool::get().free(p);
     if (h->h_pin) hipHostFree(h->h_pin);
+    if (h->h_stage) hipHostFree(h->h_stage);
     bs_destroy(h->bs);
     delete h;
     return LVBA_OK;
@@ -183,7 +185,10 @@ static int32_t finalize(lvba_visual_s *h)
 static int32_t import_state(lvba_visual_s *h, const double *q, const double *t, const double *X)
 {
     BlockSys &bs = h->bs;
-    h->hq.resize(4 * (size_t)h->M); h->ht.resize(3 * (size_t)h->M); h->hX.resize(3 * (size_t)h->Ta);
+    if (!h->h_stage) {
+        HIPCHK(hipHostMalloc((void **)&h->h_stage, (7 * (size_t)h->M + 3 * (size_t)h->Ta + 8) * sizeof(double), hipHostMallocDefault));
+        h->hq = h->h_stage; h->ht = h->hq + 4 * (size_t)h->M; h->hX = h->ht + 3 * (size_t)h->M;
+    }
     for (int c = 0; c < h->M; ++c) {
         const int I = bs.iperm[c];
         for (int e = 0; e < 4; ++e) h->hq[4 * I + e] = q[4 * c + e];
@@ -191,9 +196,9 @@ static int32_t import_state(lvba_visual_s *h, const double *q, const double *t, 
     }
     for (int64_t i = 0; i < h->Ta; ++i)
         for (int e = 0; e < 3; ++e) h->hX[3 * i + e] = X[3 * h->act[i] + e];
-    HIPCHK(hipMemcpyAsync(h->d_q, h->hq.data(), h->hq.size() * sizeof(double), hipMemcpyHostToDevice, bs.stream));
-    HIPCHK(hipMemcpyAsync(h->d_t, h->ht.data(), h->ht.size() * sizeof(double), hipMemcpyHostToDevice, bs.stream));
-    if (h->Ta) HIPCHK(hipMemcpyAsync(h->d_X, h->hX.data(), h->hX.size() * sizeof(double), hipMemcpyHostToDevice, bs.stream));
+    HIPCHK(hipMemcpyAsync(h->d_q, h->hq, 4 * (size_t)h->M * sizeof(double), hipMemcpyHostToDevice, bs.stream));
+    HIPCHK(hipMemcpyAsync(h->d_t, h->ht, 3 * (size_t)h->M * sizeof(double), hipMemcpyHostToDevice, bs.stream));
+    if (h->Ta) HIPCHK(hipMemcpyAsync(h->d_X, h->hX, 3 * (size_t)h->Ta * sizeof(double), hipMemcpyHostToDevice, bs.stream));
     HIPCHK(hipStreamSynchronize(bs.stream)); // the host staging vectors may be reused
     return LVBA_OK;
 }
@@ -201,9 +206,9 @@ static int32_t import_state(lvba_visual_s *h, const double *q, const double *t, 
 static int32_t export_state(lvba_visual_s *h, double *q, double *t, double *X)
 {
     BlockSys &bs = h->bs;
-    HIPCHK(hipMemcpyAsync(h->hq.data(), h->d_q, h->hq.size() * sizeof(double), hipMemcpyDeviceToHost, bs.stream));
-    HIPCHK(hipMemcpyAsync(h->ht.data(), h->d_t, h->ht.size() * sizeof(double), hipMemcpyDeviceToHost, bs.stream));
-    if (h->Ta) HIPCHK(hipMemcpyAsync(h->hX.data(), h->d_X, h->hX.size() * sizeof(double), hipMemcpyDeviceToHost, bs.stream));
+    HIPCHK(hipMemcpyAsync(h->hq, h->d_q, 4 * (size_t)h->M * sizeof(double), hipMemcpyDeviceToHost, bs.stream));
+    HIPCHK(hipMemcpyAsync(h->ht, h->d_t, 3 * (size_t)h->M * sizeof(double), hipMemcpyDeviceToHost, bs.stream));
+    if (h->Ta) HIPCHK(hipMemcpyAsync(h->hX, h->d_X, 3 * (size_t)h->Ta * sizeof(double), hipMemcpyDeviceToHost, bs.stream));
     HIPCHK(hipStreamSynchronize(bs.stream));
     for (int c = 0; c < h->M; ++c) {
         const int I = bs.iperm[c];
@@ -379,7 +384,7 @@ extern "C" int32_t lvba_visual_refine(lvba_visual_t h, double *q, double *t, dou
                                       bs.d_status, h->h_pin, bs.stream);
             mark(4);
         } else {
-            vis_launch_back(d, bs.d_dx, h->d_blkpart, h->d_scal + 2, bs.stream);
+            vis_launch_back(d, bs.d_dx, h->d_q, h->d_t, h->d_X, h->d_blkpart, h->d_scal + 2, bs.stream);
             mark(3);
             vis_launch_apply(d, bs.d_dx, h->d_q, h->d_t, h->d_X, h->d_q2, h->d_t2, h->d_X2, h->d_blkpart, h->d_scal + 3, bs.stream);
             vis_launch_residuals(d, false, h->d_q2, h->d_t2, h->d_X2, h->d_blkpart, h->d_scal + 1, bs.stream);
@@ -426,8 +431,9 @@ extern "C" int32_t lvba_visual_refine(lvba_visual_t h, double *q, double *t, dou
         }
         const double rho = cost_change / model;
         if (isfinite(cand) && rho > o.min_relative_decrease) {
+            // the accepted point becomes the current one: nothing to evaluate -- the kernels of the next iteration linearise from
+            // the state itself (residuals and Jacobians are re-computed where they are used)
             std::swap(h->d_q, h->d_q2); std::swap(h->d_t, h->d_t2); std::swap(h->d_X, h->d_X2);
-            vis_launch_residuals(d, true, h->d_q, h->d_t, h->d_X, h->d_blkpart, h->d_scal, bs.stream); // new J, r at x
             cost = cand;
             radius = std::min(o.max_radius, radius / std::max(1.0 / 3.0, 1.0 - pow(2.0 * rho - 1.0, 3.0)));
             decrease_factor = 2.0;

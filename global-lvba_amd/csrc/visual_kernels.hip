@@ -161,7 +161,9 @@ __global__ void vis_colnorm_cam_finish_kernel(VisDev d)
 // the scaled variables, LM diagonal D^2 = clamp(diag C)/radius, Cholesky of C + D^2, z = L^-1 g.  gmax: max |unscaled gradient
 // entry| (bit pattern of a non-negative double).  (One lane per landmark left 125 k lanes walking four dependent gathers each:
 // 31 us of latency for 12 MB.)
-__global__ __launch_bounds__(256) void vis_point_kernel(VisDev d, double radius, double min_diag, double max_diag, unsigned long long *gmax)
+__global__ __launch_bounds__(256) void vis_point_kernel(VisDev d, const double *__restrict__ qc, const double *__restrict__ tc,
+                                                        const double *__restrict__ Xp, double radius, double min_diag, double max_diag,
+                                                        unsigned long long *gmax)
 {
     __shared__ double redm[4];
     const int64_t gid = blockIdx.x * (int64_t)256 + threadIdx.x;
@@ -171,21 +173,30 @@ __global__ __launch_bounds__(256) void vis_point_kernel(VisDev d, double radius,
     if (i < d.Ta) { // whole quads
         const double sp[3] = {d.sc_pt[3 * i], d.sc_pt[3 * i + 1], d.sc_pt[3 * i + 2]};
         double C[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+        // residuals and landmark Jacobians are re-computed from the state (vis_cam_kernel does the same): nothing an LM iteration
+        // reads was stored by an earlier kernel, so an accepted step needs no linearisation pass of its own
+        const double X[3] = {Xp[3 * i], Xp[3 * i + 1], Xp[3 * i + 2]};
         if (sub == 0) {
-            const double j[3] = {d.Jpl[3 * i] * sp[0], d.Jpl[3 * i + 1] * sp[1], d.Jpl[3 * i + 2] * sp[2]};
-            const double rp = d.rpl[i];
+            double pl[4], Jl[3];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pl[e] = d.plane[4 * i + e];
+            const double rp = plane_eval(X, pl, d.inv_sig_pl, Jl);
+            const double j[3] = {Jl[0] * sp[0], Jl[1] * sp[1], Jl[2] * sp[2]};
             C[0] += j[0] * j[0]; C[1] += j[1] * j[0]; C[2] += j[1] * j[1]; C[3] += j[2] * j[0]; C[4] += j[2] * j[1]; C[5] += j[2] * j[2];
             g[0] += j[0] * rp; g[1] += j[1] * rp; g[2] += j[2] * rp;
         }
         const int64_t o1 = d.off[i + 1];
         for (int64_t o = d.off[i] + sub; o < o1; o += 4) {
-            const double2 *jp = reinterpret_cast<const double2 *>(d.Jp + 6 * o);
-            const double2 p0 = jp[0], p1 = jp[1], p2 = jp[2], rr = *reinterpret_cast<const double2 *>(d.r + 2 * o);
-            const double P[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
+            const int64_t cam = d.cam[o];
+            const double2 qa = *reinterpret_cast<const double2 *>(qc + 4 * cam), qb = *reinterpret_cast<const double2 *>(qc + 4 * cam + 2);
+            const double q[4] = {qa.x, qa.y, qb.x, qb.y}, t[3] = {tc[3 * cam], tc[3 * cam + 1], tc[3 * cam + 2]};
+            const double2 uv = *reinterpret_cast<const double2 *>(d.uv + 2 * o);
+            double rr[2], Jc[12], P[6];
+            reproj_eval<true>(q, t, X, uv.x, uv.y, d.intr, d.inv_sig_px, rr, Jc, P);
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const double j[3] = {P[3 * k] * sp[0], P[3 * k + 1] * sp[1], P[3 * k + 2] * sp[2]};
-                const double rk = k == 0 ? rr.x : rr.y;
+                const double rk = rr[k];
                 C[0] += j[0] * j[0]; C[1] += j[1] * j[0]; C[2] += j[1] * j[1]; C[3] += j[2] * j[0]; C[4] += j[2] * j[1]; C[5] += j[2] * j[2];
                 g[0] += j[0] * rk; g[1] += j[1] * rk; g[2] += j[2] * rk;
             }
@@ -364,7 +375,8 @@ __global__ void vis_cam_finish_kernel(VisDev d, double radius, double min_diag, 
 
 // four lanes (one DPP quad) per landmark, as in vis_point_kernel: step_p = -L^-T (z + sum_obs Y^T step_c), and the model cost
 // change -sum_rows m (r + m/2), m = J step (scaled variables).  part[blockIdx] = partial of the model cost change.
-__global__ __launch_bounds__(256) void vis_back_kernel(VisDev d, const double *__restrict__ step_c, double *__restrict__ part)
+__global__ __launch_bounds__(256) void vis_back_kernel(VisDev d, const double *__restrict__ step_c, const double *__restrict__ qc,
+                                                       const double *__restrict__ tc, const double *__restrict__ Xp, double *__restrict__ part)
 {
     __shared__ double red[4];
     const int64_t gid = blockIdx.x * (int64_t)256 + threadIdx.x;
@@ -393,26 +405,29 @@ __global__ __launch_bounds__(256) void vis_back_kernel(VisDev d, const double *_
         chol3_bwd(L, s, st);
 #pragma unroll
         for (int e = 0; e < 3; ++e) { st[e] = -st[e]; sp[e] = d.sc_pt[3 * i + e]; }
+        const double X[3] = {Xp[3 * i], Xp[3 * i + 1], Xp[3 * i + 2]};
         if (sub == 0) {
 #pragma unroll
             for (int e = 0; e < 3; ++e) d.step_p[3 * i + e] = st[e];
-            const double m = d.Jpl[3 * i] * sp[0] * st[0] + d.Jpl[3 * i + 1] * sp[1] * st[1] + d.Jpl[3 * i + 2] * sp[2] * st[2];
-            mc -= m * (d.rpl[i] + 0.5 * m);
+            double pl[4], Jl[3];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pl[e] = d.plane[4 * i + e];
+            const double rp = plane_eval(X, pl, d.inv_sig_pl, Jl);
+            const double m = Jl[0] * sp[0] * st[0] + Jl[1] * sp[1] * st[1] + Jl[2] * sp[2] * st[2];
+            mc -= m * (rp + 0.5 * m);
         }
         for (int64_t o = o0; o < o1; o += 4) {
-            const int cam = d.cam[o];
-            const double *sc = step_c + 6 * (int64_t)cam;
-            const double *scl = d.sc_cam + 6 * (int64_t)cam;
+            const int64_t cam = d.cam[o];
+            const double *sc = step_c + 6 * cam;
+            const double *scl = d.sc_cam + 6 * cam;
             double w[6];
 #pragma unroll
-            for (int e = 0; e < 6; ++e) w[e] = scl[e] * sc[e];
-            const double2 *jc = reinterpret_cast<const double2 *>(d.Jc + 12 * o), *jp = reinterpret_cast<const double2 *>(d.Jp + 6 * o);
-            double J[12], P[6];
-#pragma unroll
-            for (int e = 0; e < 6; ++e) { const double2 v = jc[e]; J[2 * e] = v.x; J[2 * e + 1] = v.y; }
-#pragma unroll
-            for (int e = 0; e < 3; ++e) { const double2 v = jp[e]; P[2 * e] = v.x; P[2 * e + 1] = v.y; }
-            const double2 rr = *reinterpret_cast<const double2 *>(d.r + 2 * o);
+            for (int e = 0; e < 6; ++e) w[e] = cam == d.fixed_cam ? 0.0 : scl[e] * sc[e]; // the constant camera: zero Jacobian columns
+            const double2 qa = *reinterpret_cast<const double2 *>(qc + 4 * cam), qb = *reinterpret_cast<const double2 *>(qc + 4 * cam + 2);
+            const double q[4] = {qa.x, qa.y, qb.x, qb.y}, t[3] = {tc[3 * cam], tc[3 * cam + 1], tc[3 * cam + 2]};
+            const double2 uv = *reinterpret_cast<const double2 *>(d.uv + 2 * o);
+            double rr[2], J[12], P[6];
+            reproj_eval<true>(q, t, X, uv.x, uv.y, d.intr, d.inv_sig_px, rr, J, P);
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 double m = 0.0;
@@ -420,7 +435,7 @@ __global__ __launch_bounds__(256) void vis_back_kernel(VisDev d, const double *_
                 for (int e = 0; e < 6; ++e) m += J[6 * k + e] * w[e];
 #pragma unroll
                 for (int e = 0; e < 3; ++e) m += P[3 * k + e] * sp[e] * st[e];
-                mc -= m * ((k == 0 ? rr.x : rr.y) + 0.5 * m);
+                mc -= m * (rr[k] + 0.5 * m);
             }
         }
     }
@@ -558,7 +573,7 @@ void vis_launch_step_and_trial(const VisDev &d, const double *step_c, const doub
 {
     const unsigned nb_back = nblk(4 * d.Ta, 256), nb_apply = nblk(d.M + d.Ta, 256), nb_res = nblk(d.O + d.Ta, 256);
     double *pa = part + nb_back, *pr = pa + 2 * (int64_t)nb_apply;
-    hipLaunchKernelGGL(vis_back_kernel, dim3(nb_back), dim3(256), 0, s, d, step_c, part);
+    hipLaunchKernelGGL(vis_back_kernel, dim3(nb_back), dim3(256), 0, s, d, step_c, qc, tc, Xp, part);
     hipLaunchKernelGGL(vis_apply_kernel, dim3(nb_apply), dim3(256), 0, s, d, step_c, qc, tc, Xp, qc2, tc2, Xp2, pa);
     hipLaunchKernelGGL(vis_residual_kernel<false>, dim3(nb_res), dim3(256), 0, s, d, qc2, tc2, Xp2, pr);
     hipLaunchKernelGGL(vis_finish_kernel, dim3(1), dim3(1024), 0, s, part, (int64_t)nb_back, (int64_t)nb_apply, (int64_t)nb_res, scal,
@@ -596,7 +611,7 @@ void vis_launch_reduced_system(const VisDev &d, const PairDev &pd, const double 
 {
     if (zero_first) hipMemsetAsync(Hblk, 0, (size_t)hblk_doubles * sizeof(double), s);
     hipMemsetAsync(gmax, 0, sizeof(unsigned long long), s);
-    hipLaunchKernelGGL(vis_point_kernel, dim3(nblk(4 * d.Ta, 256)), dim3(256), 0, s, d, radius, min_diag, max_diag, gmax);
+    hipLaunchKernelGGL(vis_point_kernel, dim3(nblk(4 * d.Ta, 256)), dim3(256), 0, s, d, qc, tc, Xp, radius, min_diag, max_diag, gmax);
     // one wavefront per (camera, slice) while a slice is short: its 39 sums cost one 64-lane reduction per WAVEFRONT, which at ~250
     // observations per camera was most of the kernel with four wavefronts of one observation per lane each
     const int64_t per_slice = d.O / ((int64_t)d.M * d.S > 0 ? (int64_t)d.M * d.S : 1);
@@ -605,10 +620,11 @@ void vis_launch_reduced_system(const VisDev &d, const PairDev &pd, const double 
     launch_pairs(pd, Hblk, s);
 }
 
-void vis_launch_back(const VisDev &d, const double *step_c, double *part, double *model_out, hipStream_t s)
+void vis_launch_back(const VisDev &d, const double *step_c, const double *qc, const double *tc, const double *Xp, double *part,
+                     double *model_out, hipStream_t s)
 {
     const unsigned nb = nblk(4 * d.Ta, 256);
-    hipLaunchKernelGGL(vis_back_kernel, dim3(nb), dim3(256), 0, s, d, step_c, part);
+    hipLaunchKernelGGL(vis_back_kernel, dim3(nb), dim3(256), 0, s, d, step_c, qc, tc, Xp, part);
     hipLaunchKernelGGL(vis_reduce_kernel, dim3(1), dim3(1024), 0, s, part, (int64_t)nb, 1, model_out);
 }
 
