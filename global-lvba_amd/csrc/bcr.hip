@@ -500,12 +500,11 @@ __global__ void bcr_scatter_kernel(BcrDev p, double *__restrict__ out)
 template <int BP>
 void bcr_run(const BcrDev &p, const double *Hblk, const double *g, const double *u_dev, double *x, int *status, hipStream_t s)
 {
-    static const bool one_launch = [] { const char *e = getenv("LVBA_BCR_LEVELS"); return !(e && !strcmp(e, "2")); }();
     hipMemsetAsync(status, 0, sizeof(int), s);
     hipLaunchKernelGGL(bcr_assemble_kernel<BP>, dim3((unsigned)p.nb), dim3(256), 0, s, p, Hblk, g, u_dev);
     int top = 0; // strides 1, 2, 4, ... while an odd row exists (stride < nb)
     if constexpr (BP == 32) {
-        if (one_launch && p.nb > 1) {
+        if (p.nb > 1) {
             double *Lbuf[2] = {p.L, p.L2};
             int cur = 0;
             for (int st = 1; st < p.nb; st *= 2) {

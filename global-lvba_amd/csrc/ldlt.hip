@@ -84,11 +84,11 @@ __global__ void ldlt_prepare_kernel(LdltMat M, const double *__restrict__ Hblk, 
         }
 }
 
-// Band storage, destination-major: one workgroup per block column of matrix 1 (blockIdx.y = 0) or block row of the B part
-// = six columns of the reversed matrix 2 (blockIdx.y = 1), one thread per stored entry INCLUDING the zeros (slack rows below
-// the band, the S x S block of matrix 2, columns that belong to the other matrix) -- every store is part of a contiguous
-// column, and no memset of the 0.5 GB store runs first.  The element-major kernel above scattered the B part's entries one
-// 8-byte store per column (they are transposed) on top of that memset: 0.064 + 0.164 ms at C3, this one 0.0xx ms.
+// Band storage, destination-major: one thread per STORED entry of both matrices, the zeros included (slack rows below the
+// band, the S x S block of matrix 2, columns that belong to the other matrix) -- every store is part of a contiguous column,
+// and no memset of the 0.5 GB store runs first.  The element-major kernel above scatters the B part's entries one 8-byte store
+// per column (they are transposed) on top of that memset (0.064 + 0.164 ms at C3; measured per kernel in
+// profiles/r03_bench_c3_kernel_stats.csv).
 __global__ void __launch_bounds__(256)
 ldlt_prepare_band_kernel(LdltMat M, const double *__restrict__ Hblk, int band_blocks, int n_poses,
                          const double *__restrict__ u_dev, LdltTwist tw, const int32_t *__restrict__ grp, int extra_col)
@@ -1209,8 +1209,7 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
     LdltMat M = A; // the problem the launches see: matrix 1 (and matrix 2 through blockIdx.y)
     M.n = nf;
     const size_t abytes = (size_t)((A.ld == n) ? n * n : (A.ld + 1) * n) * sizeof(double);
-    static const bool band_fill = [] { const char *e = getenv("LVBA_BAND_FILL"); return !(e && !strcmp(e, "0")); }();
-    const bool fill = band_fill && A.ld != n && n == 6 * (int64_t)n_poses;
+    const bool fill = A.ld != n && n == 6 * (int64_t)n_poses; // band storage: destination-major fill, no memset
     if (fill)
         hipLaunchKernelGGL(ldlt_prepare_band_kernel, dim3((unsigned)n + (P1 > 0 ? 1 : 0), (unsigned)((A.ld + 1 + 1023) / 1024), P1 > 0 ? 2 : 1),
                            dim3(256), 0, s, A, Hblk, band_blocks, n_poses, u_dev, tw, grp, P1 > 0 ? 1 : 0);
