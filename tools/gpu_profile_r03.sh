@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round-3 evidence run: (1) default bench.py, (2) rocprofv3 --kernel-trace --stats of the headline leg, (3) PMC passes of the
 # headline leg: FETCH_SIZE / WRITE_SIZE (-> traffic json) and the matrix-pipe counters of the solver kernels, (4) C2 and C4
-# with their parity legs, (5) the window stage.  Only summaries return (gpurun_out/prof_r03).
+# with their parity legs, (5) the visual stage's in-loop iteration time and phase profile (LVBA_WINDOW_BENCH=1: + the window
+# stage; LVBA_PMC_EXTRA=1: + the matrix-pipe counters).  Only summaries return (gpurun_out/prof_r03).
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_r03; rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
 cd $R
@@ -11,7 +12,7 @@ cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/pb1 -o stats -- python $R/bench.py --no-cpu-baseline --no-visual --no-front-end > $O/bench_headline_under_rocprof.json 2>&1
 python $R/tools/rocpd_stats.py /tmp/pb1/stats_results.db $O/headline_kernel_stats.csv > /dev/null
 head -16 $O/headline_kernel_stats.csv | cut -c1-150
-for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_WAVE_CYCLES"; do
+for c in FETCH_SIZE WRITE_SIZE ${LVBA_PMC_EXTRA:+"SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_WAVE_CYCLES"}; do
   t=$(echo $c | cut -d' ' -f1); rm -rf /tmp/pmc_$t
   timeout 600 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$t -o p -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-visual --no-front-end > $O/bench_pmc_$t.log 2>&1
   python $R/tools/rocpd_pmc.py /tmp/pmc_$t/p_results.db /tmp/pmc_$t.csv > /dev/null
@@ -19,8 +20,9 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS
 done
 cd $R
 python tools/make_traffic.py $O/pmc_FETCH_SIZE.csv $O/pmc_WRITE_SIZE.csv $O/traffic.json C3 ${1:-unknown}
-grep -E "ldlt_step|ldlt_update|ldlt_diag" $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES.csv | sed 's/(.*)"/"/' | cut -c1-130
+[ -f $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES.csv ] && grep -E "ldlt_step|ldlt_update|ldlt_diag" $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES.csv | sed 's/(.*)"/"/' | cut -c1-130
 timeout 600 python bench.py --config C2 --no-visual --no-front-end --no-reference-baseline > $O/bench_c2.json 2> $O/bench_c2.err
 timeout 900 python bench.py --config C4 --steps 10 --warmup 2 --no-visual --no-front-end --no-reference-baseline > $O/bench_c4_1gpu.json 2> $O/bench_c4.err
 tail -c 700 $O/bench_c2.json; echo; tail -c 900 $O/bench_c4_1gpu.json; echo; tail -3 $O/bench_c4.err
-LVBA_WINDOW_BATCH=1 timeout 300 python tools/window_bench.py 320 100000 20 1 > $O/window_bench.json 2> $O/window_bench.err; tail -c 300 $O/window_bench.json; echo
+LVBA_VIS_PROFILE=1 timeout 300 python tools/visual_bench.py 2000 5 > $O/visual_bench.json 2> $O/visual_bench.err; tail -c 400 $O/visual_bench.json; grep "visual profile" $O/visual_bench.err | tail -1
+[ -n "$LVBA_WINDOW_BENCH" ] && { LVBA_WINDOW_BATCH=1 timeout 300 python tools/window_bench.py 320 100000 20 1 > $O/window_bench.json 2> $O/window_bench.err; tail -c 300 $O/window_bench.json; echo; }
