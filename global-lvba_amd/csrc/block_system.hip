@@ -391,6 +391,8 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
         const int64_t ldab = bw + LVBA_NB + 64;
         bs.A.ld = ldab - 1; bs.A.bw = bw;
         TRY(bs_dmalloc(bs, &bs.d_A, 2 * (ldab * (n + 1)) + 65 * ldab)); // room for the second matrix of the twisted factorisation (+ slack: edge tiles read past the window, ldlt.hip)
+        // zero ONCE: every solve rewrites the columns its two matrices use (ldlt_prepare_band_kernel); the rest must read as zero
+        HIPCHK(hipMemsetAsync(bs.d_A, 0, (size_t)(2 * (ldab * (n + 1)) + 65 * ldab) * sizeof(double), bs.stream));
     } else {
         bs.A.ld = n; bs.A.bw = n - 1;
         TRY(bs_dmalloc(bs, &bs.d_A, n * n + 64 * n + 128)); // (+ slack: edge tiles read past the window, ldlt.hip)

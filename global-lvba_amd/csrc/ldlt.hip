@@ -91,20 +91,16 @@ __global__ void ldlt_prepare_kernel(LdltMat M, const double *__restrict__ Hblk, 
 // profiles/r03_bench_c3_kernel_stats.csv).
 __global__ void __launch_bounds__(256)
 ldlt_prepare_band_kernel(LdltMat M, const double *__restrict__ Hblk, int band_blocks, int n_poses,
-                         const double *__restrict__ u_dev, LdltTwist tw, const int32_t *__restrict__ grp, int extra_col)
+                         const double *__restrict__ u_dev, LdltTwist tw, const int32_t *__restrict__ grp)
 {
     // blockIdx.x: stored column (6 P + c of matrix 1; row 6 P + r of the B part = column of matrix 2), blockIdx.y: 1024
     // entries of it, four per thread with their loads in flight together; blockIdx.z: which matrix
     const int64_t Bb1 = band_blocks + 1, n = M.n, n1 = tw.m > 0 ? tw.n1 : n;
     const int ldab = (int)(M.ld + 1);
-    const int64_t X = blockIdx.x;
+    // matrix 1 uses its columns [0, n1), matrix 2 the rows [m, n) of the original (its columns n - 1 - X < n1): the rest of the
+    // store (the other matrix's columns, the spare column) is zeroed once when it is allocated and never written by anybody
+    const int64_t X = blockIdx.z == 0 ? (int64_t)blockIdx.x : tw.m + (int64_t)blockIdx.x;
     const int d0 = blockIdx.y * 1024 + threadIdx.x;
-    if (X >= n) { // the one spare column after matrix 1 (tile reads may run into it)
-        if (extra_col && blockIdx.z == 0)
-            for (int k = 0; k < 4; ++k)
-                if (d0 + 256 * k < ldab) M.a[n * (int64_t)ldab + d0 + 256 * k] = 0.0;
-        return;
-    }
     const int P = (int)(X / 6), e = (int)(X - 6 * (int64_t)P);
     const double uj = grp ? u_dev[grp[P]] : u_dev[0];
     const bool dead = uj < 0.0; // a finished group: identity block, see ldlt_prepare_kernel
@@ -1211,8 +1207,8 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
     const size_t abytes = (size_t)((A.ld == n) ? n * n : (A.ld + 1) * n) * sizeof(double);
     const bool fill = A.ld != n && n == 6 * (int64_t)n_poses; // band storage: destination-major fill, no memset
     if (fill)
-        hipLaunchKernelGGL(ldlt_prepare_band_kernel, dim3((unsigned)n + (P1 > 0 ? 1 : 0), (unsigned)((A.ld + 1 + 1023) / 1024), P1 > 0 ? 2 : 1),
-                           dim3(256), 0, s, A, Hblk, band_blocks, n_poses, u_dev, tw, grp, P1 > 0 ? 1 : 0);
+        hipLaunchKernelGGL(ldlt_prepare_band_kernel, dim3((unsigned)tw.n1, (unsigned)((A.ld + 1 + 1023) / 1024), P1 > 0 ? 2 : 1),
+                           dim3(256), 0, s, A, Hblk, band_blocks, n_poses, u_dev, tw, grp);
     else
         hipMemsetAsync(A.a, 0, P1 > 0 ? (size_t)tw.sA * sizeof(double) + abytes : abytes, s);
     hipMemsetAsync(status, 0, sizeof(int), s);
