@@ -117,12 +117,19 @@ def main():
     ap.add_argument("--no-reference-baseline", action="store_true", help="skip the reference's own divide_thread on C2 (16 GB of host memory)")
     ap.add_argument("--no-visual", action="store_true", help="skip the (untimed-for-the-metric) visual-stage leg")
     ap.add_argument("--no-front-end", action="store_true", help="skip the (untimed-for-the-metric) voxel front-end / window-BA leg")
+    ap.add_argument("--transport", choices=["rccl", "gloo"], default="rccl",
+                    help="N > 1: the all-reduce of the pose blocks.  rccl = the product path (one GPU per rank).  gloo = the caller-supplied "
+                         "transport entry point with a host-staged torch.distributed all-reduce: a REHEARSAL of the torchrun path on "
+                         "a box with fewer GPUs than ranks (with --same-device); its rate is not a result")
+    ap.add_argument("--same-device", action="store_true", help="all ranks on GPU 0 (rehearsal with --transport gloo)")
     args = ap.parse_args()
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
+    if args.same_device and args.transport != "gloo" and world > 1:
+        raise SystemExit("--same-device needs --transport gloo (RCCL refuses two ranks on one device)")
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
@@ -146,7 +153,11 @@ def main():
     head, end = pkg.shard_range(V, rank, world)
     prob = pkg.BalmProblem(N, off[head:end + 1], d["pose_idx"][off[head]:off[end]], d["clusters"][off[head]:off[end]],
                            device=local_rank)
-    if world > 1:
+    keep_alive = None
+    if world > 1 and args.transport == "gloo":
+        keep_alive = gloo_allreduce_callback(dist, torch)
+        prob.dist_init_external(world, rank, keep_alive[1], None)
+    elif world > 1:
         uid = [pkg.BalmProblem.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         prob.dist_init(world, rank, uid[0])
@@ -274,7 +285,7 @@ def main():
             "config": {"workload": f"{args.config}: BALM LiDAR BA, {N} poses x {V} voxels x {F_total} LiDAR factors "
                                    f"(plane-eigenvalue factors, exact Hessian, Nielsen LM)",
                        "n_poses": N, "n_voxels": V, "n_factors": F_total, "n_pairs_local": info["n_pairs"],
-                       "sharding": (f"voxel ranges over {world} rank(s), RCCL all-reduce of pose-block H/g/cost, "
+                       "sharding": (f"voxel ranges over {world} rank(s), {'RCCL' if args.transport == 'rccl' else 'HOST-STAGED gloo (rehearsal)'} all-reduce of pose-block H/g/cost, "
                                     f"{info['allreduce_bytes'] / 1e6:.0f} MB per evaluation") if world > 1 else "single GPU",
                        "solver": ("band" if info["use_band"] else "dense") + f" LDL^T, half-bandwidth {bw} of n={n}",
                        "lm_runs": state["runs"], "evals_in_timed_steps": state["evals"],
@@ -313,6 +324,35 @@ def main():
         dist.destroy_process_group()
     if not parity_ok:
         raise SystemExit("bench.py: the HIP path disagrees with the oracle beyond 1e-7 at the benchmark size (see \"parity\")")
+
+
+def gloo_allreduce_callback(dist, torch):
+    """An lvba_allreduce_fn (include/lvba_hip.h) in Python: device buffer -> host, torch.distributed (gloo) all-reduce, host ->
+    device.  For rehearsing the torchrun path of this script with more ranks than GPUs; returns (callback object, its address)."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    kinds = {0: (8, torch.float64), 1: (8, torch.int64), 2: (4, torch.int32), 3: (1, torch.uint8)}
+    FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.c_void_p)
+
+    def cb(ctx, buf, count, dtype, op, stream):
+        try:
+            nb, td = kinds[dtype]
+            host = torch.empty(int(count), dtype=td)
+            if hip.hipStreamSynchronize(stream) or hip.hipMemcpy(host.data_ptr(), buf, int(count) * nb, 2):   # device -> host
+                return 1
+            # every rank sums the ranks' buffers in rank order: bitwise the same result everywhere (what the header asks for)
+            parts = [torch.empty_like(host) for _ in range(dist.get_world_size())]
+            dist.all_gather(parts, host)
+            acc = parts[0]
+            for q in parts[1:]:
+                acc = torch.maximum(acc, q) if op == 1 else acc + q
+            return 1 if hip.hipMemcpy(buf, acc.data_ptr(), int(count) * nb, 1) else 0                         # host -> device
+        except Exception:
+            return 1
+    fn = FN(cb)
+    return fn, C.cast(fn, C.c_void_p).value
 
 
 def rms(v):
