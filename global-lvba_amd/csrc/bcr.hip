@@ -248,46 +248,135 @@ __global__ __launch_bounds__(256) void bcr_B_kernel(BcrDev p, int s)
 // workgroup also solves x_0 = D_0^-1 rhs_0.
 typedef double bcr_d4 __attribute__((ext_vector_type(4)));
 
-// Two 32 x 32 inversions side by side, 128 threads (two wavefronts) each: thread lt owns column c = lt % 32 of the rows
-// rb + 4 j (rb = lt / 32, j < 8) of [A | Inv].  The pivot loop is unrolled in full, so which thread holds the pivot row is a
-// compile-time pattern; the pivot row and column travel through LDS (double-buffered: one barrier per pivot).  ~700 cycles per
-// pivot, bound by instruction issue of the single wavefront per SIMD, not by the trips through LDS: 2 x 2 block pivots (half
-// the barriers) measured 21.0 k cycles against 22.2 k and cost accuracy on the ill-conditioned systems of
-// test_block_cyclic_reduction_equals_band_ldlt (the determinant of a nearly singular 2 x 2 block), so pivots stay scalar.
-__device__ __forceinline__ void gauss_jordan_pair32(double (&a)[8], double (&v_)[8], double (*colb)[2][32], double (*rowa)[2][32],
-                                                    double (*rowi)[2][32], int gp, int lt, int *status)
+#ifdef LVBA_BCR_TIMING
+__device__ unsigned long long g_bcr_clk[16];
+#define BCR_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_bcr_clk[k] = __builtin_readcyclecounter(); } while (0)
+#define BCR_PH(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); ph[k] += t_ - tph; tph = t_; } while (0)
+#else
+#define BCR_STAMP(k) do { } while (0)
+#define BCR_PH(k) do { } while (0)
+#endif
+// ---- 32 x 32 inverse by ONE wavefront, on the matrix pipe ---------------------------------------------------------------
+// [A | I] (32 x 64) lives in the accumulators of eight 16 x 16 MFMA tiles (register e of lane l of tile (ti, tj) is the entry
+// [16 ti + (l >> 4) + 4 e][16 tj + (l & 15)]).  Gauss-Jordan with 4 x 4 BLOCK pivots: per pivot block k the four pivot rows and
+// the four pivot columns go through LDS once (no workgroup barrier: one wavefront), every lane inverts the 4 x 4 pivot block for
+// itself (LDL^T with scalar pivots: positive definite, no pivoting -- the same elimination order as scalar Gauss-Jordan), forms
+// its component of P^-1 * (pivot rows), and the rank-4 update of all other rows is ONE MFMA per tile (K = 4); the pivot rows
+// themselves are the B operand the lane already holds.  Measured (tools/bcr_microbench.hip): 8 block steps of ~2 400 cycles -- ~1 400 of
+// them the 4 x 4 inverse and the operands, dependent fp64 chains of one wavefront at 4 cycles per instruction -- = 19-20 k cycles
+// against 22 k for the 128-thread scalar-pivot form it replaces (32 steps of ~700 through LDS and a workgroup barrier each).
+#define BCR_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#define BCR_ROWS 68 // stride of the pivot-row buffer [4][64]
+#define BCR_COLS 5  // stride of the pivot-column buffer [32][4]
+#define BCR_XCH (4 * BCR_ROWS + 32 * BCR_COLS)
+// inverse of a symmetric positive definite 4 x 4 block (lower part of P read), all in registers; false if a pivot is <= 0
+__device__ __forceinline__ bool inv4_spd(const double (&P)[4][4], double (&Pi)[4][4])
 {
-    const int c = lt & 31, rb = lt >> 5;
-    bool bad = false;
+    double L[4][4], d[4], rd[4];
+    bool ok = true;
 #pragma unroll
-    for (int kk = 0; kk < 32; ++kk) {
-        const int pb = kk & 1, jk = kk >> 2;
-        if (c == kk) {
+    for (int j = 0; j < 4; ++j) {
+        double dj = P[j][j];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) colb[gp][pb][rb + 4 * j] = a[j];
-        }
-        if (rb == (kk & 3)) { rowa[gp][pb][c] = a[jk]; rowi[gp][pb][c] = v_[jk]; }
-        __syncthreads();
-        const double piv = colb[gp][pb][kk];
-        bad |= !(piv > 0.0);
-        double rp = __builtin_amdgcn_rcp(piv); // v_rcp_f64 + two Newton steps (balm_math.h lvba_rcp)
-        rp = fma(rp, fma(-piv, rp, 1.0), rp);
-        rp = fma(rp, fma(-piv, rp, 1.0), rp);
-        const double ra = rowa[gp][pb][c] * rp, ri = rowi[gp][pb][c] * rp;
-        double f[8];
+        for (int k = 0; k < j; ++k) dj -= L[j][k] * L[j][k] * d[k];
+        d[j] = dj;
+        ok = ok && (dj > 0.0);
+        double r = __builtin_amdgcn_rcp(dj);
+        r = fma(r, fma(-dj, r, 1.0), r);
+        r = fma(r, fma(-dj, r, 1.0), r);
+        rd[j] = r;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = colb[gp][pb][rb + 4 * j];
+        for (int i = j + 1; i < 4; ++i) {
+            double v = P[i][j];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (j == jk) {
-                const bool mine = rb == (kk & 3);
-                a[j] = mine ? ra : a[j] - f[j] * ra;
-                v_[j] = mine ? ri : v_[j] - f[j] * ri;
-            } else { a[j] -= f[j] * ra; v_[j] -= f[j] * ri; }
+            for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k] * d[k];
+            L[i][j] = v * r;
         }
     }
-    if (bad && lt == 0) status[0] = 1;
+    double M[4][4]; // M = L^-1 (unit lower)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < i; ++j) {
+            double v = -L[i][j];
+#pragma unroll
+            for (int k = j + 1; k < i; ++k) v -= L[i][k] * M[k][j];
+            M[i][j] = v;
+        }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b <= a; ++b) { // P^-1 = M^T D^-1 M
+            double v = 0.0;
+#pragma unroll
+            for (int c = a; c < 4; ++c) v += (c == a ? 1.0 : M[c][a]) * rd[c] * (c == b ? 1.0 : M[c][b]);
+            Pi[a][b] = v;
+            Pi[b][a] = v;
+        }
+    return ok;
 }
+__device__ __forceinline__ bool gj32_wave(bcr_d4 (&acc)[2][4], double *xch)
+{
+    double *rowbuf = xch, *colbuf = xch + 4 * BCR_ROWS;
+    const int l = threadIdx.x & 63, lo = l & 15, hi = l >> 4;
+    bool ok = true;
+#ifdef LVBA_BCR_TIMING
+    unsigned long long ph[4] = {0, 0, 0, 0}, tph = __builtin_readcyclecounter();
+#endif
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int tip = k >> 2, rk = k & 3; // the pivot rows 4k .. 4k+3 are register rk of tile row tip; the pivot columns lie in tile column tip
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) rowbuf[hi * BCR_ROWS + 16 * tj + lo] = acc[tip][tj][rk];
+        if ((lo >> 2) == rk) {
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) colbuf[(16 * ti + hi + 4 * e) * BCR_COLS + (lo & 3)] = acc[ti][tip][e];
+        }
+        BCR_WAVE_SYNC();
+        BCR_PH(0);
+        double P[4][4], Pi[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b <= a; ++b) P[a][b] = rowbuf[a * BCR_ROWS + 4 * k + b];
+        ok = inv4_spd(P, Pi) && ok;
+        BCR_PH(1);
+        double pin[4]; // row `hi` of P^-1
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pin[q] = hi == 0 ? Pi[0][q] : hi == 1 ? Pi[1][q] : hi == 2 ? Pi[2][q] : Pi[3][q];
+        double rowp[4]; // (P^-1 * pivot rows)[hi][16 tj + lo]: the B operand of the update AND the new pivot rows
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) {
+            double v = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v += pin[q] * rowbuf[q * BCR_ROWS + 16 * tj + lo];
+            rowp[tj] = v;
+        }
+        double av[2]; // -A[16 ti + lo][4 k + hi], zero on the pivot rows (they are overwritten below)
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            const int R = 16 * ti + lo;
+            av[ti] = (R >> 2) == k ? 0.0 : -colbuf[R * BCR_COLS + hi];
+        }
+        BCR_WAVE_SYNC();
+        BCR_PH(2);
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ti], rowp[tj], acc[ti][tj], 0, 0, 0);
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) acc[tip][tj][rk] = rowp[tj];
+        BCR_PH(3);
+    }
+#ifdef LVBA_BCR_TIMING
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int q = 0; q < 4; ++q) g_bcr_clk[8 + q] = ph[q];
+#endif
+    return ok;
+}
+
 // one 16 x 16 tile (ti, tj) of opA * opB out of LDS on the matrix pipe (v_mfma_f64_16x16x4_f64: lane l supplies A[l & 15][l >> 4]
 // and B[l >> 4][l & 15]; register e of lane l is the result's [(l >> 4) + 4 e][l & 15]); tiles are row-major with stride 33
 template <bool TA, bool TB>
@@ -304,14 +393,8 @@ __device__ __forceinline__ void mfma_tile32(const double *A, const double *B, in
     }
 }
 
-#ifdef LVBA_BCR_TIMING
-__device__ unsigned long long g_bcr_clk[8];
-#define BCR_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_bcr_clk[k] = __builtin_readcyclecounter(); } while (0)
-#else
-#define BCR_STAMP(k) do { } while (0)
-#endif
 // One level in ONE launch (block rows of 32 scalars): the workgroup of the even row r inverts BOTH odd neighbours itself (two
-// wavefronts each, side by side), so no workgroup waits for another one inside a level -- the A / B pair above costs two
+// wavefronts, one each, side by side), so no workgroup waits for another one inside a level -- the A / B pair above costs two
 // dependent launches per level, and each is the latency of ONE workgroup (26 + 11 us measured: a 256-thread Gauss-Jordan at
 // ~1 500 cycles per pivot, LDS-bandwidth-bound scalar tile products), nine times over for 2 000 cameras.  Here the seven
 // 32 x 32 x 32 products of a level run on the matrix pipe (one wavefront per product).  An odd row is inverted twice (by its
@@ -324,7 +407,7 @@ __global__ __launch_bounds__(256) void bcr_level_kernel(BcrDev p, int s, const d
 {
     constexpr int BP = 32, LD = BP + 1, TS = BP * LD;
     __shared__ double buf[6][TS]; // 0: Inv_il -> T1_il | 1: Inv_ir -> T1_ir | 2: L_il -> T2_il | 3: L_r | 4: L_ir | 5: L_q
-    __shared__ double colb[2][2][BP], rowa[2][2][BP], rowi[2][2][BP];
+    __shared__ double xch[2][BCR_XCH]; // pivot rows / columns of the two inversions (gj32_wave)
     __shared__ double vrhs[2][BP], vt[2][BP];
     const int tid = threadIdx.x, gp = tid >> 7, lt = tid & 127, wv = tid >> 6, l = tid & 63;
     const int r = 2 * (int)blockIdx.x * s, il = r - s, ir = r + s, q = ir + s;
@@ -334,16 +417,21 @@ __global__ __launch_bounds__(256) void bcr_level_kernel(BcrDev p, int s, const d
     // every global read of the level up front: the two diagonal blocks (Gauss-Jordan layout, registers), four coupling blocks
     const int io = gp == 0 ? il : ir;
     const bool has = gp == 0 ? hasl : hasr;
-    const int c = lt & 31, rb = lt >> 5;
-    double a[8], v_[8];
-    {
+    const int lo = l & 15, hi = l >> 4;
+    const bool gjw = (wv & 1) == 0; // wavefronts 0 and 2 invert the left / right neighbour's diagonal block
+    bcr_d4 acc[2][4];
+    if (gjw) {
         const double *Dg = p.D + (int64_t)(has ? io : 0) * BB;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int rr = rb + 4 * j;
-            a[j] = has ? Dg[rr * BP + c] : (rr == c ? 1.0 : 0.0); // a missing neighbour: identity (its coupling blocks are zero)
-            v_[j] = (rr == c) ? 1.0 : 0.0;
-        }
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int R = 16 * ti + hi + 4 * e, C = 16 * tj + lo;
+                    acc[ti][tj][e] = has ? Dg[R * BP + C] : (R == C ? 1.0 : 0.0); // a missing neighbour: identity (its coupling blocks are zero)
+                    acc[ti][2 + tj][e] = (R == C) ? 1.0 : 0.0;
+                }
     }
     {
         const double *g2 = Lsrc + (int64_t)(hasl ? il : 0) * BB, *g3 = Lsrc + (int64_t)r * BB;
@@ -360,15 +448,21 @@ __global__ __launch_bounds__(256) void bcr_level_kernel(BcrDev p, int s, const d
     if (lt < BP) vrhs[gp][lt] = has ? p.rhs[(int64_t)io * BP + lt] : 0.0;
     // this row's own blocks: needed at the very end, asked for now
     double dold[4], rold = 0.0;
-    const int ti = wv >> 1, tj = wv & 1, lo = l & 15, hi = l >> 4; // wavefront wv owns tile (ti, tj) of the results for row r
+    const int ti = wv >> 1, tj = wv & 1; // wavefront wv owns tile (ti, tj) of the results for row r
 #pragma unroll
     for (int e = 0; e < 4; ++e) dold[e] = p.D[(int64_t)r * BB + (16 * ti + hi + 4 * e) * BP + 16 * tj + lo];
     if (tid < BP) rold = p.rhs[(int64_t)r * BP + tid];
     BCR_STAMP(1);
-    gauss_jordan_pair32(a, v_, colb, rowa, rowi, gp, lt, status);
-    BCR_STAMP(2);
+    if (gjw) {
+        if (!gj32_wave(acc, xch[gp]) && l == 0) status[0] = 1;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) buf[gp][(rb + 4 * j) * LD + c] = v_[j];
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int u2 = 0; u2 < 2; ++u2)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) buf[gp][(16 * t2 + hi + 4 * e) * LD + 16 * u2 + lo] = acc[t2][2 + u2][e];
+    }
+    BCR_STAMP(2);
     __syncthreads();
     // wavefront 0: T1_il = Inv_il L_il | 1: T2_il = Inv_il L_r^T | 2: T1_ir = Inv_ir L_ir | 3: T2_ir = Inv_ir L_q^T ; t = Inv rhs
     bcr_d4 P[4];
@@ -438,17 +532,24 @@ __global__ __launch_bounds__(256) void bcr_level_kernel(BcrDev p, int s, const d
     for (int e = 0; e < 4; ++e) buf[5][(16 * ti + hi + 4 * e) * LD + 16 * tj + lo] = dnew[e];
     if (tid < BP) vrhs[0][tid] = rnew;
     __syncthreads();
+    if (wv == 0) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int rr = rb + 4 * j;
-        a[j] = gp == 0 ? buf[5][rr * LD + c] : (rr == c ? 1.0 : 0.0);
-        v_[j] = (rr == c) ? 1.0 : 0.0;
-    }
-    __syncthreads();
-    gauss_jordan_pair32(a, v_, colb, rowa, rowi, gp, lt, status);
-    if (gp == 0) {
+        for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) buf[0][(rb + 4 * j) * LD + c] = v_[j];
+            for (int u2 = 0; u2 < 2; ++u2)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int R = 16 * t2 + hi + 4 * e, C = 16 * u2 + lo;
+                    acc[t2][u2][e] = buf[5][R * LD + C];
+                    acc[t2][2 + u2][e] = (R == C) ? 1.0 : 0.0;
+                }
+        if (!gj32_wave(acc, xch[0]) && l == 0) status[0] = 1;
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int u2 = 0; u2 < 2; ++u2)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) buf[0][(16 * t2 + hi + 4 * e) * LD + 16 * u2 + lo] = acc[t2][2 + u2][e];
     }
     __syncthreads();
     if (tid < BP) {
