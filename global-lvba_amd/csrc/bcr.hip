@@ -28,6 +28,8 @@ namespace lvba {
 
 namespace {
 
+#define BCR_X_SENTINEL 0x7ff4dead5eed0002ULL // a NaN payload no arithmetic produces
+
 struct BcrDev {
     int nb, k, M, Bb;      // block rows, cameras per block row, cameras, camera half-bandwidth
     double *D, *L, *T1, *T2; // [nb][BP*BP] row-major
@@ -110,6 +112,8 @@ __global__ __launch_bounds__(256) void bcr_assemble_kernel(BcrDev p, const doubl
     if (threadIdx.x < BP) {
         const int64_t g1 = gidx(R, threadIdx.x);
         p.rhs[(int64_t)R * BP + threadIdx.x] = g1 >= 0 ? -g[g1] : 0.0;
+        // "not yet written" for the one-launch back substitution (bcr_back_all_kernel)
+        reinterpret_cast<unsigned long long *>(p.x)[(int64_t)R * BP + threadIdx.x] = BCR_X_SENTINEL;
     }
 }
 
@@ -403,7 +407,7 @@ __device__ __forceinline__ void mfma_tile32(const double *A, const double *B, in
 // reads the old L_r of this level (as its L_q) while this one finishes.  `last`: row 0 is the only row left after this
 // level -- the workgroup also solves x_0 = D_0^-1 rhs_0.
 __global__ __launch_bounds__(256) void bcr_level_kernel(BcrDev p, int s, const double *__restrict__ Lsrc, double *__restrict__ Ldst,
-                                                        int last, int *__restrict__ status)
+                                                        int last, int *__restrict__ status, double *__restrict__ out)
 {
     constexpr int BP = 32, LD = BP + 1, TS = BP * LD;
     __shared__ double buf[6][TS]; // 0: Inv_il -> T1_il | 1: Inv_ir -> T1_ir | 2: L_il -> T2_il | 3: L_r | 4: L_ir | 5: L_q
@@ -555,8 +559,10 @@ __global__ __launch_bounds__(256) void bcr_level_kernel(BcrDev p, int s, const d
     if (tid < BP) {
         double sacc = 0.0;
         for (int m = 0; m < BP; ++m) sacc += buf[0][tid * LD + m] * vrhs[0][m];
-        p.x[tid] = sacc;
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(p.x) + tid, (unsigned long long)__double_as_longlong(sacc),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // what the back substitution's workgroups poll for
         p.t[tid] = sacc;
+        if (tid < 6 * p.k && tid / 6 < p.M) out[tid] = sacc;
     }
 }
 
@@ -588,6 +594,56 @@ __global__ __launch_bounds__(256) void bcr_back_kernel(BcrDev p, int s)
     if (tid < BP) p.x[(int64_t)i * BP + tid] = acc;
 }
 
+// The whole back substitution of the 32-scalar form as ONE launch (nine launches of ~4 us each before): workgroup b owns one
+// odd row of one level, the levels from the top (largest stride) down, so a workgroup only ever waits for workgroups with a
+// smaller blockIdx (dispatched earlier) or for x_0 of the last level kernel.  x is the only channel between workgroups:
+// pre-filled with a NaN sentinel (bcr_assemble_kernel), written with agent-scope atomic stores, polled with agent-scope atomic
+// loads -- 8 bytes carry data and flag at once (the scheme of ldlt_back_chain_kernel).  T1 / T2 / t of the row are fetched before
+// the wait.  Every workgroup also writes its cameras' part of the solution in the caller's layout (30 consecutive scalars: no
+// scatter kernel).  At most nb - 1 <= ~400 small workgroups: all resident at once on any device this library runs on.
+__global__ __launch_bounds__(256) void bcr_back_all_kernel(BcrDev p, int top, double *__restrict__ out)
+{
+    constexpr int BP = 32, LD = BP + 1;
+    __shared__ double X1[BP * LD], X2[BP * LD];
+    __shared__ double v1[BP], v2[BP];
+    const int tid = threadIdx.x;
+    int b = (int)blockIdx.x, s = top;
+    for (;; s >>= 1) { // level of this workgroup
+        const int n_odd = (p.nb - s + 2 * s - 1) / (2 * s);
+        if (b < n_odd || s == 1) break;
+        b -= n_odd;
+    }
+    const int i = (2 * b + 1) * s, q = i + s, left = i - s;
+    if (i >= p.nb) return;
+    const bool hasq = q < p.nb;
+    load_tile<BP>(X1, p.T1 + (int64_t)i * BP * BP, true);
+    load_tile<BP>(X2, p.T2 + (int64_t)(hasq ? i : 0) * BP * BP, hasq);
+    double acc = tid < BP ? p.t[(int64_t)i * BP + tid] : 0.0;
+    if (tid < 2 * BP) {
+        const int m = tid & (BP - 1);
+        const bool second = tid >= BP;
+        double xv = 0.0;
+        if (!second || hasq) {
+            const unsigned long long *px = reinterpret_cast<const unsigned long long *>(p.x) + (int64_t)(second ? q : left) * BP + m;
+            unsigned long long v;
+            while ((v = __hip_atomic_load(px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == BCR_X_SENTINEL) __builtin_amdgcn_s_sleep(1);
+            xv = __longlong_as_double((long long)v);
+        }
+        (second ? v2 : v1)[m] = xv;
+    }
+    __syncthreads();
+    if (tid < BP) {
+        double a1 = 0.0, a2 = 0.0;
+#pragma unroll 8
+        for (int m = 0; m < BP; ++m) { a1 += X1[tid * LD + m] * v1[m]; a2 += X2[tid * LD + m] * v2[m]; }
+        acc -= a1 + a2;
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(p.x) + (int64_t)i * BP + tid, (unsigned long long)__double_as_longlong(acc),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int64_t cam = (int64_t)i * p.k + tid / 6;
+        if (tid < 6 * p.k && cam < p.M) out[6 * (int64_t)i * p.k + tid] = acc;
+    }
+}
+
 template <int BP>
 __global__ void bcr_scatter_kernel(BcrDev p, double *__restrict__ out)
 {
@@ -610,15 +666,11 @@ void bcr_run(const BcrDev &p, const double *Hblk, const double *g, const double 
             int cur = 0;
             for (int st = 1; st < p.nb; st *= 2) {
                 const int n_even = (p.nb + 2 * st - 1) / (2 * st); // r = 2 m st < nb
-                hipLaunchKernelGGL(bcr_level_kernel, dim3((unsigned)n_even), dim3(256), 0, s, p, st, Lbuf[cur], Lbuf[cur ^ 1], 2 * st >= p.nb ? 1 : 0, status);
+                hipLaunchKernelGGL(bcr_level_kernel, dim3((unsigned)n_even), dim3(256), 0, s, p, st, Lbuf[cur], Lbuf[cur ^ 1], 2 * st >= p.nb ? 1 : 0, status, x);
                 cur ^= 1;
                 top = st;
             }
-            for (int st = top; st >= 1; st /= 2) {
-                const int n_odd = (p.nb - st + 2 * st - 1) / (2 * st);
-                hipLaunchKernelGGL(bcr_back_kernel<BP>, dim3((unsigned)n_odd), dim3(256), 0, s, p, st);
-            }
-            hipLaunchKernelGGL(bcr_scatter_kernel<BP>, dim3((unsigned)((6 * (int64_t)p.M + 255) / 256)), dim3(256), 0, s, p, x);
+            hipLaunchKernelGGL(bcr_back_all_kernel, dim3((unsigned)(p.nb - 1)), dim3(256), 0, s, p, top, x);
             return;
         }
     }

@@ -58,7 +58,7 @@ int main(int argc, char **argv)
     const int64_t m2 = (int64_t)p.nb * 1024, m1 = (int64_t)p.nb * 32;
     p.D = work; p.L = p.D + m2; p.T1 = p.L + m2; p.T2 = p.T1 + m2; p.L2 = p.T2 + m2; p.rhs = p.L2 + m2; p.t = p.rhs + m1; p.x = p.t + m1;
     for (int grid : {200, 50, 1}) {
-        t = time_us(s, 200, [&] { hipLaunchKernelGGL(bcr_level_kernel, dim3(grid), dim3(256), 0, s, p, 1, p.L, p.L2, 0, status); });
+        t = time_us(s, 200, [&] { hipLaunchKernelGGL(bcr_level_kernel, dim3(grid), dim3(256), 0, s, p, 1, p.L, p.L2, 0, status, dx); });
         unsigned long long c[16]; CK(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_bcr_clk), sizeof c));
         printf("level kernel x%-4d %7.2f us   cycles: loads %llu | gauss-jordan %llu (rows/cols to LDS %llu, 4x4 inverse %llu, operands %llu, MFMA + rows %llu) | products 1 %llu | products 2 + stores %llu | total %llu\n", grid, t,
                c[1] - c[0], c[2] - c[1], c[8], c[9], c[10], c[11], c[3] - c[2], c[4] - c[3], c[4] - c[0]);
