@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 #include <new>
 #include <vector>
 
@@ -337,7 +338,10 @@ extern "C" int32_t lvba_visual_refine(lvba_visual_t h, double *q, double *t, dou
     HIPCHK(hipSetDevice(bs.device));
     lvba_visual_opts o;
     if (opts) o = *opts; else lvba_visual_default_opts(&o);
+    auto wall_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tw0 = wall_us();
     TRY(import_state(h, q, t, X));
+    const double tw1 = wall_us();
     int32_t rows = 0, term = LVBA_TERM_NO_CONVERGENCE, rc = LVBA_OK;
     auto push = [&](int it, int acc, int valid, double cost, double dc, double sn, double rad, double rho, double gm) {
         if (trace && rows < trace_cap) {
@@ -355,6 +359,7 @@ extern "C" int32_t lvba_visual_refine(lvba_visual_t h, double *q, double *t, dou
     HIPCHK(hipMemcpyAsync(h->h_pin, h->d_scal, sizeof(double), hipMemcpyDeviceToHost, bs.stream));
     HIPCHK(hipStreamSynchronize(bs.stream));
     double cost = 0.5 * h->h_pin[0];
+    const double tw2 = wall_us();
     double radius = o.initial_radius, decrease_factor = 2.0;
     bool first = true;
     int invalid_run = 0;
@@ -467,6 +472,10 @@ extern "C" int32_t lvba_visual_refine(lvba_visual_t h, double *q, double *t, dou
     }
     if (n_trace) *n_trace = std::min(rows, trace_cap > 0 ? trace_cap : 0);
     if (termination) *termination = term;
+    const double tw3 = wall_us();
     const int32_t rc2 = export_state(h, q, t, X);
+    if (prof)
+        fprintf(stderr, "[lvba visual profile] host clock, us: state upload %.0f | first evaluation + Jacobi scaling %.0f | iterations %.0f | state download %.0f\n",
+                tw1 - tw0, tw2 - tw1, tw3 - tw2, wall_us() - tw3);
     return rc != LVBA_OK ? rc : rc2;
 }

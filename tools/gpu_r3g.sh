@@ -6,6 +6,6 @@ timeout 900 python -m pytest tests/test_gpu_visual.py -q -x -p no:cacheprovider 
 for e in "${@:-LVBA_X=0}"; do
   timeout 600 env $e python tools/visual_bench.py 2000 5 > /tmp/vb.log 2>&1
   echo "$e: $(tail -1 /tmp/vb.log | grep -o '"cap_50.*')"
-  grep "visual profile" /tmp/vb.log | tail -1
+  grep "visual profile" /tmp/vb.log | tail -2
 done
 exit 0
