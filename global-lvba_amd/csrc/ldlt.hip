@@ -84,71 +84,93 @@ __global__ void ldlt_prepare_kernel(LdltMat M, const double *__restrict__ Hblk, 
         }
 }
 
-// Band storage, destination-major: one thread per STORED entry of both matrices, the zeros included (slack rows below the
-// band, the S x S block of matrix 2, columns that belong to the other matrix) -- every store is part of a contiguous column,
-// and no memset of the 0.5 GB store runs first.  The element-major kernel above scatters the B part's entries one 8-byte store
-// per column (they are transposed) on top of that memset (0.064 + 0.164 ms at C3; measured per kernel in
-// profiles/r03_bench_c3_kernel_stats.csv).
+// Band storage, destination-major: one thread per STORED entry of the columns the two matrices use, the zeros included (slack
+// rows below the band, the S x S block of matrix 2) -- every store is part of a contiguous column segment, and no memset of the
+// 0.5 GB store runs first (the columns nobody uses are zeroed once, at allocation).  A workgroup stages 28 blocks of ONE block
+// column (matrix 1) or block row (matrix 2: its columns are the original's rows, reversed) through LDS and writes the six
+// columns they belong to: every block of the Hessian store is read once per matrix.  (One workgroup per column read every block
+// six times, from six XCDs; the element-major kernel above scatters the B part's entries one 8-byte store per column on top of a
+// memset: 0.064 + 0.164 ms at C3.)
+#define LVBA_PB_BLOCKS 28
+#define LVBA_PB_ROWS (6 * LVBA_PB_BLOCKS)
 __global__ void __launch_bounds__(256)
 ldlt_prepare_band_kernel(LdltMat M, const double *__restrict__ Hblk, int band_blocks, int n_poses,
                          const double *__restrict__ u_dev, LdltTwist tw, const int32_t *__restrict__ grp)
 {
-    // blockIdx.x: stored column (6 P + c of matrix 1; row 6 P + r of the B part = column of matrix 2), blockIdx.y: 1024
-    // entries of it, four per thread with their loads in flight together; blockIdx.z: which matrix
+    __shared__ double blk[LVBA_PB_BLOCKS * 36];
     const int64_t Bb1 = band_blocks + 1, n = M.n, n1 = tw.m > 0 ? tw.n1 : n;
     const int ldab = (int)(M.ld + 1);
-    // matrix 1 uses its columns [0, n1), matrix 2 the rows [m, n) of the original (its columns n - 1 - X < n1): the rest of the
-    // store (the other matrix's columns, the spare column) is zeroed once when it is allocated and never written by anybody
-    const int64_t X = blockIdx.z == 0 ? (int64_t)blockIdx.x : tw.m + (int64_t)blockIdx.x;
-    const int d0 = blockIdx.y * 1024 + threadIdx.x;
-    const int P = (int)(X / 6), e = (int)(X - 6 * (int64_t)P);
+    const bool second = blockIdx.z != 0;
+    const int64_t P = second ? tw.m / 6 + (int64_t)blockIdx.x : (int64_t)blockIdx.x; // block column J (matrix 1) / block row I (matrix 2)
+    if (P >= n_poses || (!second && 6 * P >= n1)) return;
+    const int d0 = (int)blockIdx.y * LVBA_PB_BLOCKS; // first block offset dI (matrix 1: I = P + dI) / dJ (matrix 2: J = P - dJ)
+    for (int i = threadIdx.x; i < LVBA_PB_BLOCKS * 36; i += 256) {
+        const int bq = i / 36, el = i - 36 * bq;
+        const int64_t dd = d0 + bq;
+        double v = 0.0;
+        if (dd <= band_blocks) {
+            if (!second) { if (P + dd < n_poses) v = Hblk[(P * Bb1 + dd) * 36 + el]; }
+            else if (P - dd >= 0) v = Hblk[((P - dd) * Bb1 + dd) * 36 + el];
+        }
+        blk[i] = v;
+    }
+    __syncthreads();
     const double uj = grp ? u_dev[grp[P]] : u_dev[0];
     const bool dead = uj < 0.0; // a finished group: identity block, see ldlt_prepare_kernel
-    double v[4];
-    double *__restrict__ dst;
-    if (blockIdx.z == 0) {
-        const double *__restrict__ src = Hblk + (int64_t)P * Bb1 * 36 + e * 6; // column c = e of block column P
-        dst = M.a + X * ldab;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int d = d0 + 256 * k, q = e + d, dI = q / 6, r = q - 6 * dI;
-            v[k] = (dI <= band_blocks && X + d < n1) ? src[dI * 36 + r] : 0.0;
+    for (int idx = threadIdx.x; idx < 6 * LVBA_PB_ROWS; idx += 256) {
+        const int e = idx / LVBA_PB_ROWS, t = idx - e * LVBA_PB_ROWS, bq = t / 6, w = t - 6 * bq;
+        const int64_t X = 6 * P + e; // the column of matrix 1 / the ORIGINAL row whose entries form a column of matrix 2
+        int d;
+        double v;
+        if (!second) { // element (r = w, c = e) of block (P + dI, P): offset d = 6 dI + r - c
+            d = 6 * d0 + t - e;
+            if (X >= n1 || d < 0 || d >= ldab) continue;
+            v = X + d < n1 ? blk[bq * 36 + e * 6 + w] : 0.0; // rows of the B part belong to matrix 2
+        } else {       // element (r = e, c = 5 - w) of block (P, P - dJ): offset d = 6 dJ + r - c, ascending in t
+            d = 6 * d0 + t + e - 5;
+            if (X < tw.m || X >= n || d < 0 || d >= ldab) continue;
+            v = X >= n1 ? blk[bq * 36 + (5 - w) * 6 + e] : 0.0; // the S x S block of matrix 2 starts from zero
         }
-    } else {
-        dst = M.a + tw.sA + (n - 1 - X) * ldab; // row R = X, r = e of block row P
-        const bool inB = X >= n1;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int d = d0 + 256 * k;
-            const int C = (int)X - d;
-            const int J = C >= 0 ? C / 6 : 0, c = C - 6 * J, dI = P - J;
-            v[k] = (inB && C >= 0 && dI <= band_blocks) ? Hblk[((int64_t)J * Bb1 + dI) * 36 + c * 6 + e] : 0.0;
-        }
+        if (dead) v = d == 0 && (second ? X >= n1 : true) ? 1.0 : 0.0;
+        else if (d == 0) v += uj * v;
+        if (!second) M.a[X * (int64_t)ldab + d] = v;
+        else M.a[tw.sA + (n - 1 - X) * (int64_t)ldab + d] = v;
     }
-    if (d0 == 0) v[0] = dead ? ((blockIdx.z == 0 ? X < n1 : X >= n1) ? 1.0 : 0.0) : v[0] + uj * v[0];
-    if (dead) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (d0 + 256 * k != 0) v[k] = 0.0;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (d0 + 256 * k < ldab) dst[d0 + 256 * k] = v[k];
 }
 
 // After both ends have been eliminated: the Schur complement that matrix 2 (reversed) collected on S is added to matrix 1's
 // S block, likewise the right-hand side.
-__global__ void ldlt_twist_merge_kernel(LdltMat M, LdltTwist tw, double *__restrict__ b)
+// (32 x 32 tiles through LDS: matrix 2 holds the block transposed and reversed, so reading it in matrix 1's order is one 8-byte
+// load per column -- 47 us for 3.5 M entries; a tile is read along ITS columns and added along matrix 1's)
+__global__ __launch_bounds__(256) void ldlt_twist_merge_kernel(LdltMat M, LdltTwist tw, double *__restrict__ b)
 {
-    const int64_t n = M.n, s0 = tw.m, s1 = tw.n1, ns = s1 - s0, bw1 = M.bw + 1;
-    const int64_t total = ns * bw1;
-    const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t e = gid; e < total; e += gsz) {
-        const int64_t cc = e / bw1, d = e - cc * bw1;
-        const int64_t C = s0 + cc, R = C + d;
-        if (R >= s1) continue;
-        M.a[R + C * M.ld] += M.a[tw.sA + (n - 1 - C) + (n - 1 - R) * M.ld];
+    __shared__ double tile[32][33];
+    const int64_t n = M.n, s0 = tw.m, s1 = tw.n1, ns = s1 - s0;
+    const int64_t T = (ns + 31) / 32, ntiles = T * (T + 1) / 2;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        // lower tile (tr >= tc) number t of the column-major enumeration
+        int64_t tc = 0, rem = t;
+        while (rem >= T - tc) { rem -= T - tc; ++tc; }
+        const int64_t tr = tc + rem;
+        const int64_t R0 = s0 + 32 * tr, C0 = s0 + 32 * tc;
+        if (R0 - (C0 + 31) > M.bw) continue; // wholly below the band (uniform over the workgroup)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { // matrix 2: entry (R, C) at (n-1-C) + (n-1-R) ld -- C fastest
+            const int64_t R = R0 + ty + 8 * k, C = C0 + tx;
+            double v = 0.0;
+            if (R < s1 && C < s1 && R >= C && R - C <= M.bw) v = M.a[tw.sA + (n - 1 - C) + (n - 1 - R) * M.ld];
+            tile[ty + 8 * k][tx] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { // matrix 1: R fastest
+            const int64_t R = R0 + tx, C = C0 + ty + 8 * k;
+            if (R < s1 && C < s1 && R >= C && R - C <= M.bw) M.a[R + C * M.ld] += tile[tx][ty + 8 * k];
+        }
+        __syncthreads();
     }
+    const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
     for (int64_t a = s0 + gid; a < s1; a += gsz) b[a] += b[tw.sW + (n - 1 - a)];
 }
 // x of the S part, reversed, into matrix 2's solution vector (its backward chain starts from there)
@@ -1207,8 +1229,11 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
     const size_t abytes = (size_t)((A.ld == n) ? n * n : (A.ld + 1) * n) * sizeof(double);
     const bool fill = A.ld != n && n == 6 * (int64_t)n_poses; // band storage: destination-major fill, no memset
     if (fill)
-        hipLaunchKernelGGL(ldlt_prepare_band_kernel, dim3((unsigned)tw.n1, (unsigned)((A.ld + 1 + 1023) / 1024), P1 > 0 ? 2 : 1),
+    {
+        const int64_t cols1 = (tw.n1 + 5) / 6, rows2 = P1 > 0 ? n_poses - tw.m / 6 : 0;
+        hipLaunchKernelGGL(ldlt_prepare_band_kernel, dim3((unsigned)std::max(cols1, rows2), (unsigned)((A.ld + 1 + 5 + LVBA_PB_ROWS - 1) / LVBA_PB_ROWS), P1 > 0 ? 2 : 1),
                            dim3(256), 0, s, A, Hblk, band_blocks, n_poses, u_dev, tw, grp);
+    }
     else
         hipMemsetAsync(A.a, 0, P1 > 0 ? (size_t)tw.sA * sizeof(double) + abytes : abytes, s);
     hipMemsetAsync(status, 0, sizeof(int), s);
