@@ -47,8 +47,9 @@ struct LdltTwist {
 __global__ void ldlt_prepare_kernel(LdltMat M, const double *__restrict__ Hblk, int band_blocks, int n_poses,
                                     const double *__restrict__ g, const double *__restrict__ u_dev,
                                     double *__restrict__ b, unsigned long long *__restrict__ x, unsigned long long x_fill,
-                                    LdltTwist tw, const int32_t *__restrict__ grp, int vectors_only)
+                                    LdltTwist tw, const int32_t *__restrict__ grp, int vectors_only, int *__restrict__ status)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) status[0] = 0; // (no memset node of its own in the solve's graph)
     // grp != nullptr: the damping of pose block J is u_dev[grp[J]] (independent groups of poses, each with its own LM state)
     const double u0 = u_dev[0];
     const int64_t Bb1 = band_blocks + 1;
@@ -1236,10 +1237,10 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
     }
     else
         hipMemsetAsync(A.a, 0, P1 > 0 ? (size_t)tw.sA * sizeof(double) + abytes : abytes, s);
-    hipMemsetAsync(status, 0, sizeof(int), s);
-    hipMemsetAsync(bacc, 0, (size_t)n * sizeof(double), s);
+    static const bool back_panel_env = [] { const char *e = getenv("LVBA_BACK"); return e && !strcmp(e, "panel"); }();
+    if (back_panel_env && P1 == 0) hipMemsetAsync(bacc, 0, (size_t)n * sizeof(double), s); // only ldlt_back_kernel accumulates there
     hipLaunchKernelGGL(ldlt_prepare_kernel, dim3(fill ? 64 : 2048), dim3(256), 0, s, A, Hblk, band_blocks, n_poses, g, u_dev, b,
-                       reinterpret_cast<unsigned long long *>(x), (unsigned long long)LVBA_X_SENTINEL, tw, grp, fill ? 1 : 0);
+                       reinterpret_cast<unsigned long long *>(x), (unsigned long long)LVBA_X_SENTINEL, tw, grp, fill ? 1 : 0, status);
     struct Geo { int64_t k, w0, rend, T; int nbe; };
     auto geom = [&](int64_t st) {
         Geo q;

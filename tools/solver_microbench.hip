@@ -59,7 +59,7 @@ int main(int argc, char **argv)
                               hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)(T * (T + 1) / 2)), dim3(256), 0, s, A, k, 64, w0, rend, Zws, ldz, 0, 0, 0); });
     printf("diag+panel, update chain %8.2f us\n", t * 1e3);
     // empty-kernel launch chain for reference
-    t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_prepare_kernel, dim3(1), dim3(64), 0, s, A, work, 0, 0, work, work, work, (unsigned long long *)x, 0ULL, LdltTwist{0, 0, 0, 0, nullptr}, (const int32_t *)nullptr, 0); });
+    t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_prepare_kernel, dim3(1), dim3(64), 0, s, A, work, 0, 0, work, work, work, (unsigned long long *)x, 0ULL, LdltTwist{0, 0, 0, 0, nullptr}, (const int32_t *)nullptr, 0, status); });
     printf("tiny kernel back-to-back %8.2f us\n", t * 1e3);
     return 0;
 }
