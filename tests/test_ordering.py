@@ -37,3 +37,13 @@ def test_host_tables(tmp_path):
     subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(ROOT, "tests", "host_tables_check.cpp"), "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and "host tables ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_host_arena(tmp_path):
+    """global-lvba_amd/csrc/host_arena.h: the library-owned host blocks the set-up tables live in (size classes with <= 12.5 %
+    slack, reuse from the class's free list, small blocks left to malloc, release, use from several threads), through
+    tests/host_arena_check.cpp."""
+    exe = str(tmp_path / "host_arena_check")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", os.path.join(ROOT, "tests", "host_arena_check.cpp"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "host arena ok" in r.stdout, r.stdout + r.stderr
