@@ -17,6 +17,7 @@
 // Camera order everywhere is the solver's (RCM) order; camera `fixed_cam` is constant (zero Jacobian columns).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include "lvba_internal.h"
 #include "visual_math.h"
@@ -167,10 +168,11 @@ __global__ __launch_bounds__(256) void vis_point_kernel(VisDev d, const double *
 {
     __shared__ double redm[4];
     const int64_t gid = blockIdx.x * (int64_t)256 + threadIdx.x;
-    const int64_t i = gid >> 2;
     const int sub = (int)(gid & 3);
     double gm = 0.0;
-    if (i < d.Ta) { // whole quads
+    // a workgroup walks several groups of 64 landmarks (vis_quad_grid): with one group each, the launch of ~1 900 workgroups that
+    // live for 2 us took longer than their work
+    for (int64_t i = gid >> 2; i < d.Ta; i += (int64_t)gridDim.x * 64) { // whole quads
         const double sp[3] = {d.sc_pt[3 * i], d.sc_pt[3 * i + 1], d.sc_pt[3 * i + 2]};
         double C[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
         // residuals and landmark Jacobians are re-computed from the state (vis_cam_kernel does the same): nothing an LM iteration
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(256) void vis_point_kernel(VisDev d, const double *
 #pragma unroll
         for (int e = 0; e < 3; ++e) g[e] = v_quad_sum(g[e]);
         if (sub == 0) {
-            gm = fmax(fabs(g[0] / sp[0]), fmax(fabs(g[1] / sp[1]), fabs(g[2] / sp[2])));
+            gm = fmax(gm, fmax(fabs(g[0] / sp[0]), fmax(fabs(g[1] / sp[1]), fabs(g[2] / sp[2]))));
             C[0] += fmin(fmax(C[0], min_diag), max_diag) / radius;
             C[2] += fmin(fmax(C[2], min_diag), max_diag) / radius;
             C[5] += fmin(fmax(C[5], min_diag), max_diag) / radius;
@@ -380,10 +382,9 @@ __global__ __launch_bounds__(256) void vis_back_kernel(VisDev d, const double *_
 {
     __shared__ double red[4];
     const int64_t gid = blockIdx.x * (int64_t)256 + threadIdx.x;
-    const int64_t i = gid >> 2;
     const int sub = (int)(gid & 3);
     double mc = 0.0;
-    if (i < d.Ta) { // whole quads
+    for (int64_t i = gid >> 2; i < d.Ta; i += (int64_t)gridDim.x * 64) { // whole quads; several groups of 64 landmarks per workgroup
         const int64_t o0 = d.off[i] + sub, o1 = d.off[i + 1];
         double s[3] = {0.0, 0.0, 0.0};
         if (sub == 0) { s[0] = d.zp[3 * i]; s[1] = d.zp[3 * i + 1]; s[2] = d.zp[3 * i + 2]; }
@@ -556,6 +557,13 @@ __global__ __launch_bounds__(1024) void vis_finish_kernel(const double *__restri
 
 // ---------------------------------------------------------------------------------------------- launchers
 static inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b > 0 ? (n + b - 1) / b : 1); }
+// workgroups of the quad-per-landmark kernels: four groups of 64 landmarks each (measured at 125 k landmarks: 1 / 4 / 8 / 16 groups
+// per workgroup -> 0.334 / 0.323 / 0.335 / 0.378 ms per LM iteration; vis_point_kernel 29 -> 19 us with four)
+static inline unsigned vis_quad_grid(int64_t Ta)
+{
+    const unsigned n = nblk(4 * Ta, 256);
+    return (n + 3) / 4;
+}
 
 void vis_launch_residuals(const VisDev &d, bool jac, const double *qc, const double *tc, const double *Xp, double *part,
                           double *cost_out, hipStream_t s)
@@ -571,7 +579,7 @@ void vis_launch_step_and_trial(const VisDev &d, const double *step_c, const doub
                                double *tc2, double *Xp2, double *part, double *scal, const unsigned long long *gmax, const int *status,
                                double *host_pin, hipStream_t s)
 {
-    const unsigned nb_back = nblk(4 * d.Ta, 256), nb_apply = nblk(d.M + d.Ta, 256), nb_res = nblk(d.O + d.Ta, 256);
+    const unsigned nb_back = vis_quad_grid(d.Ta), nb_apply = nblk(d.M + d.Ta, 256), nb_res = nblk(d.O + d.Ta, 256);
     double *pa = part + nb_back, *pr = pa + 2 * (int64_t)nb_apply;
     hipLaunchKernelGGL(vis_back_kernel, dim3(nb_back), dim3(256), 0, s, d, step_c, qc, tc, Xp, part);
     hipLaunchKernelGGL(vis_apply_kernel, dim3(nb_apply), dim3(256), 0, s, d, step_c, qc, tc, Xp, qc2, tc2, Xp2, pa);
@@ -611,7 +619,7 @@ void vis_launch_reduced_system(const VisDev &d, const PairDev &pd, const double 
 {
     if (zero_first) hipMemsetAsync(Hblk, 0, (size_t)hblk_doubles * sizeof(double), s);
     hipMemsetAsync(gmax, 0, sizeof(unsigned long long), s);
-    hipLaunchKernelGGL(vis_point_kernel, dim3(nblk(4 * d.Ta, 256)), dim3(256), 0, s, d, qc, tc, Xp, radius, min_diag, max_diag, gmax);
+    hipLaunchKernelGGL(vis_point_kernel, dim3(vis_quad_grid(d.Ta)), dim3(256), 0, s, d, qc, tc, Xp, radius, min_diag, max_diag, gmax);
     // one wavefront per (camera, slice) while a slice is short: its 39 sums cost one 64-lane reduction per WAVEFRONT, which at ~250
     // observations per camera was most of the kernel with four wavefronts of one observation per lane each
     const int64_t per_slice = d.O / ((int64_t)d.M * d.S > 0 ? (int64_t)d.M * d.S : 1);
@@ -623,7 +631,7 @@ void vis_launch_reduced_system(const VisDev &d, const PairDev &pd, const double 
 void vis_launch_back(const VisDev &d, const double *step_c, const double *qc, const double *tc, const double *Xp, double *part,
                      double *model_out, hipStream_t s)
 {
-    const unsigned nb = nblk(4 * d.Ta, 256);
+    const unsigned nb = vis_quad_grid(d.Ta);
     hipLaunchKernelGGL(vis_back_kernel, dim3(nb), dim3(256), 0, s, d, step_c, qc, tc, Xp, part);
     hipLaunchKernelGGL(vis_reduce_kernel, dim3(1), dim3(1024), 0, s, part, (int64_t)nb, 1, model_out);
 }
