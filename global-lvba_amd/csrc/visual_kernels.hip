@@ -234,11 +234,16 @@ __global__ __launch_bounds__(256) void vis_point_kernel(VisDev d, const double *
 // (stored for the pair pass and the back-substitution); per camera the sums of
 //   D = Jc^T Jc - Y Y^T (lower 21) | reduced rhs Jc^T r - Y z (6) | diag(Jc^T Jc) (6) | Jc^T r (6)   -> part[.][40]
 __global__ __launch_bounds__(256) void vis_cam_kernel(VisDev d, const double *__restrict__ qc, const double *__restrict__ tc,
-                                                      const double *__restrict__ Xp)
+                                                      const double *__restrict__ Xp, int wave_units)
 {
     __shared__ double red[4 * 39];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nth = (int)blockDim.x; // 64 or 256 threads (vis_launch_reduced_system)
-    const int I = blockIdx.x / d.S, s = blockIdx.x - I * d.S;
+    // wave_units = 1: every WAVEFRONT of the workgroup owns a (camera, slice) unit of its own (short slices: four units per
+    // workgroup -- a quarter of the workgroups to dispatch); 0: the workgroup's four wavefronts share one unit
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nth = wave_units ? 64 : (int)blockDim.x, tid = wave_units ? lane : (int)threadIdx.x;
+    const int unit = wave_units ? (int)blockIdx.x * 4 + wv : (int)blockIdx.x;
+    if (unit >= d.M * d.S) return; // (wave_units only; no workgroup barrier below in that mode)
+    const int I = unit / d.S, s = unit - I * d.S;
     const int64_t seg0 = d.csc_off[I], len = d.csc_off[I + 1] - seg0;
     const int64_t a = seg0 + (len * s) / d.S, b = seg0 + (len * (s + 1)) / d.S;
     double sc[6];
@@ -310,11 +315,17 @@ __global__ __launch_bounds__(256) void vis_cam_kernel(VisDev d, const double *__
         const double v = v_wave_sum(acc[e]);
         if (lane == 0) red[wv * 39 + e] = v;
     }
+    if (wave_units) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 39) d.part[(int64_t)unit * 40 + lane] = red[wv * 39 + lane];
+        return;
+    }
     __syncthreads();
     if (tid < 39) {
         double v = red[tid];
         for (int w = 1; w < (nth >> 6); ++w) v += red[w * 39 + tid];
-        d.part[(int64_t)blockIdx.x * 40 + tid] = v;
+        d.part[(int64_t)unit * 40 + tid] = v;
     }
 }
 
@@ -623,7 +634,8 @@ void vis_launch_reduced_system(const VisDev &d, const PairDev &pd, const double 
     // one wavefront per (camera, slice) while a slice is short: its 39 sums cost one 64-lane reduction per WAVEFRONT, which at ~250
     // observations per camera was most of the kernel with four wavefronts of one observation per lane each
     const int64_t per_slice = d.O / ((int64_t)d.M * d.S > 0 ? (int64_t)d.M * d.S : 1);
-    hipLaunchKernelGGL(vis_cam_kernel, dim3((unsigned)(d.M * d.S)), dim3(per_slice <= 1024 ? 64 : 256), 0, s, d, qc, tc, Xp);
+    if (per_slice <= 1024) hipLaunchKernelGGL(vis_cam_kernel, dim3((unsigned)((d.M * d.S + 3) / 4)), dim3(256), 0, s, d, qc, tc, Xp, 1);
+    else hipLaunchKernelGGL(vis_cam_kernel, dim3((unsigned)(d.M * d.S)), dim3(256), 0, s, d, qc, tc, Xp, 0);
     hipLaunchKernelGGL(vis_cam_reduce_kernel, dim3(nblk(d.M, 64)), dim3(64), 0, s, d, radius, min_diag, max_diag, Hblk, g, gmax);
     launch_pairs(pd, Hblk, s);
 }
