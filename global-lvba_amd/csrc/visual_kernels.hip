@@ -568,6 +568,9 @@ __global__ __launch_bounds__(1024) void vis_finish_kernel(const double *__restri
 
 // ---------------------------------------------------------------------------------------------- launchers
 static inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b > 0 ? (n + b - 1) / b : 1); }
+// vis_back_kernel keeps one group of 64 landmarks per workgroup (1 / 2 / 4 groups: 0.315 / 0.326 / 0.320 ms per LM iteration: its two
+// rounds of gathers are what it waits for, and a loop puts them one after the other)
+static inline unsigned vis_back_grid(int64_t Ta) { return nblk(4 * Ta, 256); }
 // workgroups of the quad-per-landmark kernels: four groups of 64 landmarks each (measured at 125 k landmarks: 1 / 4 / 8 / 16 groups
 // per workgroup -> 0.334 / 0.323 / 0.335 / 0.378 ms per LM iteration; vis_point_kernel 29 -> 19 us with four)
 static inline unsigned vis_quad_grid(int64_t Ta)
@@ -590,7 +593,7 @@ void vis_launch_step_and_trial(const VisDev &d, const double *step_c, const doub
                                double *tc2, double *Xp2, double *part, double *scal, const unsigned long long *gmax, const int *status,
                                double *host_pin, hipStream_t s)
 {
-    const unsigned nb_back = vis_quad_grid(d.Ta), nb_apply = nblk(d.M + d.Ta, 256), nb_res = nblk(d.O + d.Ta, 256);
+    const unsigned nb_back = vis_back_grid(d.Ta), nb_apply = nblk(d.M + d.Ta, 256), nb_res = nblk(d.O + d.Ta, 256);
     double *pa = part + nb_back, *pr = pa + 2 * (int64_t)nb_apply;
     hipLaunchKernelGGL(vis_back_kernel, dim3(nb_back), dim3(256), 0, s, d, step_c, qc, tc, Xp, part);
     hipLaunchKernelGGL(vis_apply_kernel, dim3(nb_apply), dim3(256), 0, s, d, step_c, qc, tc, Xp, qc2, tc2, Xp2, pa);
@@ -643,7 +646,7 @@ void vis_launch_reduced_system(const VisDev &d, const PairDev &pd, const double 
 void vis_launch_back(const VisDev &d, const double *step_c, const double *qc, const double *tc, const double *Xp, double *part,
                      double *model_out, hipStream_t s)
 {
-    const unsigned nb = vis_quad_grid(d.Ta);
+    const unsigned nb = vis_back_grid(d.Ta);
     hipLaunchKernelGGL(vis_back_kernel, dim3(nb), dim3(256), 0, s, d, step_c, qc, tc, Xp, part);
     hipLaunchKernelGGL(vis_reduce_kernel, dim3(1), dim3(1024), 0, s, part, (int64_t)nb, 1, model_out);
 }
