@@ -124,6 +124,10 @@ def main():
     ap.add_argument("--same-device", action="store_true", help="all ranks on GPU 0 (rehearsal with --transport gloo)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the ranks ourselves, exactly as the documented command does
+        # (one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1), and become that job
+        relaunch_under_torchrun(args.gpus)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -131,8 +135,7 @@ def main():
     if args.same_device and args.transport != "gloo" and world > 1:
         raise SystemExit("--same-device needs --transport gloo (RCCL refuses two ranks on one device)")
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node and --gpus must agree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -190,9 +193,9 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # ---- the timed region: K steps, the library's event profiling OFF (it costs ~1 % of a step)
     state.update(evals=0, accepts=0, evals_on_records=0)
-    prob.set_profiling(True)
-    prob.profile(reset=True)
+    prob.set_profiling(False)
     barrier()
     t0 = time.perf_counter()
     last = None
@@ -204,9 +207,26 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt[0])
-    p = prob.profile()
     if state["active"]:
         prob.lm_end(want_poses=False)
+        state["active"] = False
+    timed = dict(state)
+    # ---- a second, UNTIMED pass over the same K steps with HIP events on the library's stream around its kernels: the stage
+    # times and the kernel durations of the `roofline` objects come from here (same problem, same start, same iteration mix)
+    state.update(runs=0, evals=0, accepts=0, evals_on_records=0)
+    prob.set_profiling(True)
+    prob.profile(reset=True)
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed_profiled = time.perf_counter() - t1
+    p = prob.profile()
+    prob.set_profiling(False)
+    if state["active"]:
+        prob.lm_end(want_poses=False)
+        state["active"] = False
 
     parity_ok = True
     if rank == 0:
@@ -220,10 +240,10 @@ def main():
         bytes_cost = 84 * Fl + 4 * (Vl + 1) + 96 * N + 8
         ev_ms = p["eval_kernel_ms"] / max(1, p["eval_calls"])
         ck_ms = p["cost_kernel_ms"] / max(1, p["cost_calls"])
-        # The trial point of a step is costed by the FIRST HALF of the evaluation (fused: balm_fused_kernel -- costs, Y, per-pose
-        # sums; three-pass: the voxel pass); when the step is accepted the next evaluation starts from that linearisation and only
-        # assembles H and g.  For the roofline every evaluation is still charged with its first half: the kernel time the library
-        # reports for such an evaluation + one cost-stage kernel.
+        # The trial point of a step is costed by the evaluation's own voxel pass (balm_voxel_kernel: per-chunk cost sums + the
+        # voxel records); when the step is accepted the next evaluation is AT that point, starts from those records and only runs
+        # the factor and pair passes.  For the roofline every evaluation is still charged with a voxel pass: the kernel time the
+        # library reports for such an evaluation + one cost-stage kernel.
         eval_kernels, cost_kernels = kernel_sets(info)
         lin = bool(info["trial_linearised"])
         reuse = state["evals_on_records"] / max(1, p["eval_calls"])
@@ -288,11 +308,14 @@ def main():
                        "sharding": (f"voxel ranges over {world} rank(s), {'RCCL' if args.transport == 'rccl' else 'HOST-STAGED gloo (rehearsal)'} all-reduce of pose-block H/g/cost, "
                                     f"{info['allreduce_bytes'] / 1e6:.0f} MB per evaluation") if world > 1 else "single GPU",
                        "solver": ("band" if info["use_band"] else "dense") + f" LDL^T, half-bandwidth {bw} of n={n}",
-                       "lm_runs": state["runs"], "evals_in_timed_steps": state["evals"],
-                       "accepted_in_timed_steps": state["accepts"], "last_cost": last["residual2"] if last else None},
+                       "lm_runs": timed["runs"], "evals_in_timed_steps": timed["evals"],
+                       "accepted_in_timed_steps": timed["accepts"], "last_cost": last["residual2"] if last else None},
             "stage_ms": {"eval": p["eval_ms"] / max(1, p["eval_calls"]), "solve": sv_ms,
                          "cost": p["cost_ms"] / max(1, p["cost_calls"]),
                          "allreduce": p["reduce_ms"] / max(1, p["reduce_calls"]) if p["reduce_calls"] else 0.0},
+            "stage_ms_source": {"pass": "second, untimed pass over the same K steps with the library's HIP-event profiling on "
+                                        "(the timed region runs with it off)", "ms_per_step": 1e3 * elapsed_profiled / args.steps,
+                                "evals": state["evals"], "accepted": state["accepts"]},
             "roofline": roof, "roofline_other_kernels": others,
         }
         if world == 1 and not args.no_visual:
@@ -324,6 +347,22 @@ def main():
         dist.destroy_process_group()
     if not parity_ok:
         raise SystemExit("bench.py: the HIP path disagrees with the oracle beyond 1e-7 at the benchmark size (see \"parity\")")
+
+
+def relaunch_under_torchrun(n):
+    """Replace this process by `python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same arguments>`
+    (never returns).  The port is one the kernel has just handed out as free."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs across processes on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execve(sys.executable, cmd, env)
 
 
 def gloo_allreduce_callback(dist, torch):

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(1024) void reduce_chunks_kernel(const double *__res
 // ------------------------------------------------------------------------------------------------
 // full evaluation, pass 1 (voxel-major): cost + per-voxel records.  Same loads as balm_cost_kernel.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(LVBA_CF) void balm_voxel_kernel(BalmDev d, const double *__restrict__ poses,
+__global__ __launch_bounds__(LVBA_CF, 6) void balm_voxel_kernel(BalmDev d, const double *__restrict__ poses,
                                                             double *__restrict__ chunk_cost)
 {
     __shared__ double T[10 * LVBA_CF];

@@ -179,7 +179,16 @@ LVBA_HD void eig3_planar(const double *C, double *lam, double *U)
     const double q01 = c01 * c01, q02 = c02 * c02, q12 = c12 * c12;
     const double tr = c00 + c11 + c22;
     double x = 0.0;
-    for (int it = 0; it < 16; ++it) {
+    // The direct method needs lam0 SEPARATED from lam1: the reference admits a voxel on lam0 / lam2 alone (bavoxel.hpp:351), so
+    // an edge- or line-like voxel with lam0 ~ lam1 << lam2 is valid input.  There Newton converges only linearly (a nearly
+    // double root) and the cross products that give u0 all vanish like (lam1 - lam0)(lam2 - lam0).  Both are DETECTED and sent
+    // to cyclic Jacobi (eig3 with the fast reciprocals), which has no such restriction: (i) Newton that needs more than
+    // LVBA_EIG3_NEWTON_OK steps or leaves without meeting its step test -- a plane voxel takes 4 to 6 --, (ii) a largest cross
+    // product below 1e-4 tr^2, i.e. (lam1 - lam0)(lam2 - lam0) small against ||C||^2 (also the all-zero case, where rsq(0)
+    // would give NaN).  tests/test_oracle.py::test_device_eig3_planar_near_double_root holds lam1 / lam0 in [1, 1.01].
+    bool newton_ok = false;
+#define LVBA_EIG3_NEWTON_OK 9
+    for (int it = 0; it < LVBA_EIG3_NEWTON_OK; ++it) {
         const double a = c00 - x, b = c11 - x, c = c22 - x;
         const double m0 = b * c - q12, m1 = a * c - q02, m2 = a * b - q01; // principal minors of C - x I
         const double p = a * m0 - c01 * (c01 * c - c12 * c02) + c02 * (c01 * c12 - b * c02);
@@ -187,11 +196,14 @@ LVBA_HD void eig3_planar(const double *C, double *lam, double *U)
         if (!(ms > 0.0)) break;
         const double dx = p * lvba_rcp(ms);
         x += dx;
-        if (!(fabs(dx) > 4e-17 * tr)) break;
+        if (!(fabs(dx) > 4e-17 * tr)) { newton_ok = true; break; }
     }
-    lam[0] = x;
+    if (!WANT_VEC) { // the cost kernel wants lam0 only
+        if (__builtin_expect(!newton_ok, 0)) { eig3<false, true>(C, lam, nullptr); return; }
+        lam[0] = x; lam[1] = lam[2] = 0.0;
+        return;
+    }
     const double a = c00 - x, b = c11 - x, c = c22 - x;
-    if (!WANT_VEC) { lam[1] = lam[2] = 0.0; return; } // the cost kernel wants lam0 only
     // u0: rows r0 = (a, c01, c02), r1 = (c01, b, c12), r2 = (c02, c12, c) of C - lam0 I
     const double n0[3] = {c01 * c12 - c02 * b, c02 * c01 - a * c12, a * b - q01};      // r0 x r1
     const double n1[3] = {c01 * c - c02 * c12, c02 * c02 - a * c, a * c12 - c01 * c02}; // r0 x r2
@@ -202,6 +214,11 @@ LVBA_HD void eig3_planar(const double *C, double *lam, double *U)
     if (l0 >= l1 && l0 >= l2) { u[0] = n0[0]; u[1] = n0[1]; u[2] = n0[2]; ll = l0; }
     else if (l1 >= l2) { u[0] = n1[0]; u[1] = n1[1]; u[2] = n1[2]; ll = l1; }
     else { u[0] = n2[0]; u[1] = n2[1]; u[2] = n2[2]; ll = l2; }
+    if (__builtin_expect(!newton_ok || !(ll > 1e-8 * (tr * tr) * (tr * tr)), 0)) { // (i) or (ii): ONE exit to Jacobi
+        eig3<true, true>(C, lam, U);
+        return;
+    }
+    lam[0] = x;
     const double iu = lvba_rsq(ll);
     u[0] *= iu; u[1] *= iu; u[2] *= iu;
     // e1: the largest row of C - lam0 I, made exactly orthogonal to u0 (one Gram-Schmidt step against rounding); e2 = u0 x e1

@@ -105,6 +105,9 @@ int32_t bs_allreduce(BlockSys &bs, double *buf, size_t count);
 int32_t bs_allreduce_hg(BlockSys &bs);
 // all-reduce `count` elements of a device buffer in place (sum or max; double / int64 / int32 / uint8) over the ranks
 int32_t bs_comm_allreduce(BlockSys &bs, void *dbuf, size_t count, ncclDataType_t dt, ncclRedOp_t op);
+// slots of the structurally non-zero blocks of the block-band store (ascending, diagonal included); their download [n][36]
+int32_t bs_pattern_slots(BlockSys &bs, lvba::hvec<int64_t> &slots);
+int32_t bs_download_blocks(BlockSys &bs, const int64_t *slots, int64_t n, double *out);
 int32_t bs_dist_init(BlockSys &bs, int32_t n_ranks, int32_t rank, const char uid[128], int64_t *group_count_inout);
 int32_t bs_dist_init_external(BlockSys &bs, int32_t n_ranks, int32_t rank, lvba_allreduce_fn fn, void *ctx, int64_t *group_count_inout);
 void bs_destroy(BlockSys &bs);

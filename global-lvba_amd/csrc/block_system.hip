@@ -184,6 +184,63 @@ int32_t bs_allreduce_hg(BlockSys &bs)
     return LVBA_OK;
 }
 
+// Slots (J * (Bb + 1) + dI) of the STRUCTURALLY non-zero blocks of the block-band store, ascending, diagonal blocks included:
+// the union pattern of the packed all-reduce when there is one (multi-rank), else this rank's pair-list destinations.  Known
+// from the set-up alone -- no evaluation is needed to size a sparse download of H.
+int32_t bs_pattern_slots(BlockSys &bs, lvba::hvec<int64_t> &slots)
+{
+    const int64_t Bb1 = (int64_t)bs.Bb + 1;
+    slots.clear();
+    if (bs.d_ar_slot) {
+        slots.resize((size_t)bs.n_ar);
+        HIPCHK(hipMemcpy(slots.data(), bs.d_ar_slot, (size_t)bs.n_ar * sizeof(int64_t), hipMemcpyDeviceToHost));
+        return LVBA_OK; // sorted, diagonal included (bs_build)
+    }
+    if (bs.distributed()) { // no union pattern known: every slot inside the matrix
+        for (int64_t J = 0; J < bs.N; ++J)
+            for (int64_t dI = 0; dI < Bb1 && J + dI < bs.N; ++dI) slots.push_back(J * Bb1 + dI);
+        return LVBA_OK;
+    }
+    // item destinations: a slot (>= 0) or a partial block (< 0) that balm_pair_reduce_kernel sums into multi_slot[m]
+    slots.resize((size_t)(bs.n_items + bs.n_multi));
+    if (bs.n_items) HIPCHK(hipMemcpy(slots.data(), bs.d_blk_slot, (size_t)bs.n_items * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (bs.n_multi) HIPCHK(hipMemcpy(slots.data() + bs.n_items, bs.d_multi_slot, (size_t)bs.n_multi * sizeof(int64_t), hipMemcpyDeviceToHost));
+    slots.erase(std::remove_if(slots.begin(), slots.end(), [](int64_t v) { return v < 0; }), slots.end());
+    for (int64_t J = 0; J < bs.N; ++J) slots.push_back(J * Bb1);
+    std::sort(slots.begin(), slots.end());
+    slots.erase(std::unique(slots.begin(), slots.end()), slots.end());
+    return LVBA_OK;
+}
+
+// The blocks of `slots` (host, n of them) gathered on the device and brought to `out` [n][36] (pageable host memory) in slabs of
+// <= 64 MB through a pinned buffer on bs.stream: one gather kernel + a handful of copies instead of one blocking copy per
+// block column (10 000 of them at the C4 size).
+int32_t bs_download_blocks(BlockSys &bs, const int64_t *slots, int64_t n, double *out)
+{
+    if (n <= 0) return LVBA_OK;
+    DevBuf d_slots(bs.stream), d_buf(bs.stream);
+    HIPCHK(d_slots.alloc((size_t)n * sizeof(int64_t)));
+    HIPCHK(d_buf.alloc((size_t)n * 36 * sizeof(double)));
+    HIPCHK(lvba::copy_h2d(d_slots.as<int64_t>(), slots, (size_t)n * sizeof(int64_t)));
+    hipLaunchKernelGGL(hg_pack_kernel, dim3((unsigned)((36 * n + 255) / 256)), dim3(256), 0, bs.stream, bs.d_hg, d_slots.as<int64_t>(), n,
+                       bs.hblk_doubles, (int64_t)0, d_buf.as<double>());
+    HIPCHK(hipGetLastError());
+    const size_t total = (size_t)n * 36 * sizeof(double), slab = std::min<size_t>(total, (size_t)64 << 20);
+    void *pin = nullptr;
+    HIPCHK(hipHostMalloc(&pin, slab, hipHostMallocDefault));
+    int32_t rc = LVBA_OK;
+    for (size_t o = 0; o < total && rc == LVBA_OK; o += slab) {
+        const size_t nb = std::min(slab, total - o);
+        if (hipMemcpyAsync(pin, reinterpret_cast<const char *>(d_buf.as<double>()) + o, nb, hipMemcpyDeviceToHost, bs.stream) != hipSuccess ||
+            hipStreamSynchronize(bs.stream) != hipSuccess)
+            rc = LVBA_ERR_DEVICE;
+        else
+            memcpy(reinterpret_cast<char *>(out) + o, pin, nb);
+    }
+    hipHostFree(pin);
+    return rc;
+}
+
 static double bs_now_ms()
 {
     struct timespec ts;

@@ -25,9 +25,12 @@
 #include <algorithm>
 #include <math.h>
 #include <utility>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <vector>
 #include "lvba_internal.h"
+#include "ldlt_schedule.h"
 #include "../../include/lvba_hip.h" // status codes
 
 namespace lvba {
@@ -137,6 +140,25 @@ ldlt_prepare_band_kernel(LdltMat M, const double *__restrict__ Hblk, int band_bl
         if (!second) M.a[X * (int64_t)ldab + d] = v;
         else M.a[tw.sA + (n - 1 - X) * (int64_t)ldab + d] = v;
     }
+}
+
+// LVBA_CHECK_BAND=1 (debugging; use with LVBA_NO_GRAPH=1): the band store is zeroed ONCE, at allocation (block_system.hip), and
+// every solve rewrites only the columns its two matrices use -- [0, n1) of each.  That holds as long as no factorisation or
+// update kernel ever stores outside those columns: this kernel counts the non-zero entries of the rest (columns [n1, n] of both
+// matrices and the slack behind them) before a solve starts; ldlt_solve reports a non-zero count as LVBA_ERR_STATE.
+__global__ void ldlt_check_untouched_kernel(const double *__restrict__ a, int64_t ldab, int64_t n, int64_t n1, int64_t sA,
+                                            int64_t total, int two, unsigned long long *__restrict__ cnt)
+{
+    const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
+    unsigned long long bad = 0;
+    for (int64_t e = gid; e < total; e += gsz) {
+        bool untouched;
+        if (e < sA) untouched = e / ldab >= n1;                       // matrix 1: columns n1 .. n
+        else if (two && e < 2 * sA) untouched = (e - sA) / ldab >= n1; // matrix 2: columns n1 .. n
+        else untouched = true;                                        // slack (and matrix 2's room when it is not used)
+        if (untouched && a[e] != 0.0) ++bad;
+    }
+    if (bad) atomicAdd(cnt, bad);
 }
 
 // After both ends have been eliminated: the Schur complement that matrix 2 (reversed) collected on S is added to matrix 1's
@@ -307,14 +329,13 @@ __device__ __forceinline__ void k1b_steps(std::integer_sequence<int, Js...>, dou
 }
 
 #define LVBA_K1B_LDS (64 * LVBA_W1S + 256 + 16 * LVBA_Z1S + 64) // doubles
-// Leaves d in dvs[64] and G[m][c] in W[c * LVBA_W1S + 64 + m]; ends on a __syncthreads().
-__device__ __forceinline__ void diag_blocked_body(double *lds, LdltMat M, int64_t k, int nbe, int *__restrict__ status)
+// diag_blocked_load: the 64x64 block at (k, k) into W (lower triangle; identity below row nbe) with the identity appended.
+// diag_blocked_factor: the factorisation of what W holds (the look-ahead kernel fills W itself, from the registers its updates
+// of the block end in).  Leaves d in dvs[64] and G[m][c] in W[c * LVBA_W1S + 64 + m]; ends on a __syncthreads().
+__device__ __forceinline__ void diag_blocked_load(double *lds, LdltMat M, int64_t k, int nbe)
 {
     double *W = lds;                      // (row, col) at col * LVBA_W1S + row; rows 64..127 = the appended identity
-    double *G11s = W + 64 * LVBA_W1S;     // [m][c]
-    double *Zt = G11s + 256;              // [j][block row relative to c0 + 16] = X * d
-    double *dvs = Zt + 16 * LVBA_Z1S;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x;
     LVBA_K1B_STAMP(0);
     {
         // all 16 loads of a lane are issued before the first one is waited for (one memory latency instead of a chain of
@@ -339,6 +360,14 @@ __device__ __forceinline__ void diag_blocked_body(double *lds, LdltMat M, int64_
         }
     }
     __syncthreads();
+}
+__device__ __forceinline__ void diag_blocked_factor(double *lds, int nbe, int *__restrict__ status)
+{
+    double *W = lds;
+    double *G11s = W + 64 * LVBA_W1S;     // [m][c]
+    double *Zt = G11s + 256;              // [j][block row relative to c0 + 16] = X * d
+    double *dvs = Zt + 16 * LVBA_Z1S;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     LVBA_K1B_STAMP(1);
     const int i15 = lane & 15, kk = lane >> 4;
     // ---- diag step of the 16 columns at c0: wavefront 0 only, no barrier inside
@@ -410,11 +439,30 @@ __device__ __forceinline__ void diag_blocked_body(double *lds, LdltMat M, int64_
         LVBA_K1B_STAMP(4 + 3 * s);
     }
 }
+__device__ __forceinline__ void diag_blocked_body(double *lds, LdltMat M, int64_t k, int nbe, int *__restrict__ status)
+{
+    diag_blocked_load(lds, M, k, nbe);
+    diag_blocked_factor(lds, nbe, status);
+}
 
+// blockIdx.y: the problem of a two-ended factorisation.  blockIdx.x = 1 (look-ahead schedule, first launch of a phase): the
+// side copy of the tile below the diagonal block, A(rows w0 .., columns k ..) as [m][row], masked like load_panel_tile.
 __global__ __launch_bounds__(256) void ldlt_diag_blocked_kernel(LdltMat M, int64_t k, int nbe, double *__restrict__ G,
-                                                               double *__restrict__ dvec, int *__restrict__ status)
+                                                               double *__restrict__ dvec, int *__restrict__ status,
+                                                               int64_t sA, int64_t sW, double *__restrict__ side, int64_t rend)
 {
     __shared__ double lds[LVBA_K1B_LDS];
+    if (blockIdx.y) { M.a += sA; G += sW; dvec += sW; if (side) side += sW; } // the second problem of a two-ended factorisation
+    if (blockIdx.x == 1) {
+        const int row = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const int64_t r = k + nbe + row;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int m = w + 4 * it;
+            side[m * 64 + row] = (r < rend && m < nbe) ? M.a[r + (k + m) * M.ld] : 0.0;
+        }
+        return;
+    }
     diag_blocked_body(lds, M, k, nbe, status);
     const double *W = lds, *dvs = lds + 64 * LVBA_W1S + 256 + 16 * LVBA_Z1S;
     const int tid = threadIdx.x;
@@ -980,6 +1028,8 @@ __global__ __launch_bounds__(256, 2) void ldlt_step_kernel(LdltMat M, int64_t k2
     }
 }
 
+#include "ldlt_lookahead.h"
+
 // ---------------------------------------------------------------------------------------- backward
 // x_k = L11^-T (z_k - sum_{i>k} L_ik^T x_i),  z_k = D^-1 L11^-1 b_k = G^T b_k,  L11^-T = G D.
 // bacc accumulates sum_{i>k} L_ik^T x_i (right-looking: after x_k is known every column c left of the panel
@@ -1174,12 +1224,13 @@ static inline int64_t ldz_for(int64_t n, int64_t bw)
 static inline int64_t ldlt_ws_one(int64_t n, int64_t bw)
 {
     const int64_t nsteps = (n + LVBA_NB - 1) / LVBA_NB;
-    return nsteps * 4096 /*G*/ + 3 * n /*d, b, bacc*/ + 4 * ldz_for(n, bw) * LVBA_NB /*Z, four buffers (st % 4)*/ + 64;
+    return nsteps * 4096 /*G*/ + 3 * n /*d, b, bacc*/ + 4 * ldz_for(n, bw) * LVBA_NB /*Z, four buffers (st % 4)*/ + 64 +
+           2 * 4096 /*side copies of A(p+1, p), look-ahead schedule*/;
 }
 // two problems' workspaces + matrix 2's solution vector (twisted factorisation)
 // + the exchange buffer of the multi-rank form: |S| <= bw + 2 * 64 columns of bw + 1 entries, and the S part of the rhs
 static inline int64_t ldlt_exchange_doubles(int64_t n, int64_t bw) { return std::min<int64_t>(n, bw + 2 * LVBA_NB) * (bw + 2) + 64; }
-int64_t ldlt_workspace_doubles(int64_t n, int64_t bw) { return 2 * ldlt_ws_one(n, bw) + n + 64 + ldlt_exchange_doubles(n, bw); }
+int64_t ldlt_workspace_doubles(int64_t n, int64_t bw) { return 2 * ldlt_ws_one(n, bw) + n + 64 + ldlt_exchange_doubles(n, bw) + 8 /* LVBA_CHECK_BAND's counter */; }
 
 int64_t ldlt_num_panels(int64_t n) { return (n + LVBA_NB - 1) / LVBA_NB; }
 
@@ -1229,6 +1280,29 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
     M.n = nf;
     const size_t abytes = (size_t)((A.ld == n) ? n * n : (A.ld + 1) * n) * sizeof(double);
     const bool fill = A.ld != n && n == 6 * (int64_t)n_poses; // band storage: destination-major fill, no memset
+    // grid y of the fill: block offsets d0 = 28 y must cover every stored offset d in [0, ldab) of a column, for every element
+    // row / column e in [0, 6): d = 6 d0 + t - e (matrix 1) or 6 d0 + t + e - 5 (matrix 2), t in [0, 168) -- i.e. up to ldab + 5
+    static_assert(LVBA_PB_ROWS == 6 * LVBA_PB_BLOCKS, "a workgroup of the band fill covers LVBA_PB_BLOCKS block offsets");
+    if (fill) {
+        static const bool check_band = [] { const char *e = getenv("LVBA_CHECK_BAND"); return e && !strcmp(e, "1"); }();
+        static const bool band_memset = [] { const char *e = getenv("LVBA_BAND_MEMSET"); return e && !strcmp(e, "1"); }();
+        const int64_t ldab = A.ld + 1, total = 2 * (ldab * (n + 1)) + 65 * ldab; // = block_system.hip's allocation
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(s, &cap);
+        if (check_band && cap == hipStreamCaptureStatusNone) {
+            unsigned long long *cnt = reinterpret_cast<unsigned long long *>(work + ldlt_workspace_doubles(n, bw) - 8), hc = 0;
+            hipMemsetAsync(cnt, 0, sizeof hc, s);
+            hipLaunchKernelGGL(ldlt_check_untouched_kernel, dim3(2048), dim3(256), 0, s, (const double *)A.a, ldab, n, tw.n1, tw.sA, total,
+                               P1 > 0 ? 1 : 0, cnt);
+            hipMemcpyAsync(&hc, cnt, sizeof hc, hipMemcpyDeviceToHost, s);
+            hipStreamSynchronize(s);
+            if (hc) {
+                fprintf(stderr, "lvba: LVBA_CHECK_BAND: %llu non-zero entries in the never-rewritten part of the band store\n", hc);
+                return LVBA_ERR_STATE;
+            }
+        }
+        if (band_memset) hipMemsetAsync(A.a, 0, (size_t)total * sizeof(double), s); // A/B: the former per-solve memset
+    }
     if (fill)
     {
         const int64_t cols1 = (tw.n1 + 5) / 6, rows2 = P1 > 0 ? n_poses - tw.m / 6 : 0;
@@ -1263,7 +1337,8 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
             hipLaunchKernelGGL(ldlt_diagpanel_kernel, dim3((unsigned)q.T, ny), dim3(256), 0, s, second ? M2 : M, q.k, q.nbe, q.w0, q.rend, G,
                                dvec + wo, Zws, ldz, b + wo, status, tw.sA, tw.sW);
         else
-            hipLaunchKernelGGL(ldlt_diag_blocked_kernel, dim3(1), dim3(256), 0, s, second ? M2 : M, q.k, q.nbe, G, dvec + wo, status);
+            hipLaunchKernelGGL(ldlt_diag_blocked_kernel, dim3(1), dim3(256), 0, s, second ? M2 : M, q.k, q.nbe, G, dvec + wo, status,
+                               (int64_t)0, (int64_t)0, (double *)nullptr, (int64_t)0);
     };
     // ncols = 2: a panel whose bulk update is deferred to its partner's launch applies itself to the first TWO tile columns
     auto first_column = [&](int64_t st, const Geo &q, unsigned ny, bool second, int ncols) {
@@ -1360,7 +1435,76 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
         }
         flush();
     };
-    if (!overlap) {
+    // ---- the look-ahead schedule (default; LVBA_SOLVER=r3 keeps the two-launches-per-panel form above for A/B): one launch per
+    // panel, ldlt_lookahead.h; which launch carries which bulk job is decided by ldlt_schedule.h (checked on the CPU against a
+    // tile-level model of the factorisation, tests/ldlt_schedule_check.cpp)
+    static const bool lookahead = [] { const char *e = getenv("LVBA_SOLVER"); return !(e && !strcmp(e, "r3")); }();
+    double *side_buf[2] = {Zbuf[3] + ldz * LVBA_NB + 64, Zbuf[3] + ldz * LVBA_NB + 64 + 4096};
+    auto run_phase2 = [&](int64_t sa, int64_t sb, unsigned ny, bool second, bool close) {
+        static const bool big_env = [] { const char *e = getenv("LVBA_BULK"); return !(e && !strcmp(e, "64")); }();
+        const bool big = big_env && ((uint64_t)A.ld * (uint64_t)(n + 128) + (uint64_t)n + 256) * 8 < 0xFFFF0000ull;
+        const int64_t wo = second ? tw.sW : 0;
+        std::vector<SchedLaunch> sched;
+        ldlt_schedule_phase(sa, sb, close, rank128, [&](int64_t st) { return st < nsteps ? geom(st).T : (int64_t)0; }, sched);
+        auto pg = [&](int64_t st) { const Geo g = geom(st); return PanelGeo{g.k, g.w0, g.rend, g.nbe, (int)g.T}; };
+        for (const SchedLaunch &L : sched) {
+            if (L.kind == 0) {
+                const Geo g = geom(L.p);
+                hipLaunchKernelGGL(ldlt_diag_blocked_kernel, dim3(g.T > 0 ? 2 : 1, ny), dim3(256), 0, s, second ? M2 : M, g.k, g.nbe,
+                                   Gall + wo + L.p * 4096, dvec + wo, status, tw.sA, tw.sW, side_buf[L.p % 2] + wo, g.rend);
+                continue;
+            }
+            Step2Args a{};
+            a.M = second ? M2 : M; a.sA = tw.sA; a.sW = tw.sW; a.ldz = ldz; a.nprob = (int)ny;
+            a.roles = L.roles; a.has_q = L.has_q; a.do_diag = L.do_diag; a.status = status;
+            a.dvec = dvec + wo; a.b = b + wo;
+            int64_t nwg = 0;
+            if (L.roles) {
+                a.p = pg(L.p);
+                if (L.has_q) a.q = pg(L.p - 1);
+                const Geo gn = geom(L.p + 1);
+                a.nbe_next = gn.nbe; a.rend_next = gn.rend;
+                a.Gp = Gall + wo + L.p * 4096; a.Gn = Gall + wo + (L.p + 1) * 4096;
+                a.Zp = Zbuf[L.p % 4] + wo; a.Zq = L.has_q ? Zbuf[(L.p - 1) % 4] + wo : nullptr;
+                a.side_r = side_buf[L.p % 2] + wo; a.side_w = side_buf[(L.p + 1) % 2] + wo;
+                nwg += a.p.T;
+            }
+            for (int j = 0; j < L.njobs; ++j) {
+                BulkJob &J = a.job[a.njobs];
+                const SchedJob &sj = L.job[j];
+                J.o = pg(sj.o); J.Zo = Zbuf[sj.o % 4] + wo; J.pair = sj.pair;
+                if (sj.pair) { J.e = pg(sj.o - 1); J.Ze = Zbuf[(sj.o - 1) % 4] + wo; }
+                const int64_t Tb = J.o.T - 1;
+                if (big) {
+                    J.ca = sj.ca; J.cb = sj.cb; J.nwg = 0;
+                    for (int64_t c = sj.ca; c < sj.cb; ++c) J.nwg += pair_col_items(c, Tb);
+                } else {
+                    J.ca = col_start(sj.ca, Tb); J.cb = col_start(sj.cb, Tb); J.nwg = J.cb - J.ca;
+                }
+                if (J.nwg <= 0) continue;
+                nwg += J.nwg;
+                ++a.njobs;
+            }
+            if (nwg > 0)
+                hipLaunchKernelGGL(big ? ldlt_step2_kernel<true> : ldlt_step2_kernel<false>, dim3((unsigned)(nwg * ny)), dim3(256), 0, s, a);
+        }
+    };
+    if (overlap && lookahead) {
+        int64_t st0 = 0;
+        if (P1 > 0) {
+            if (side != 2) run_phase2(0, P1, side < 0 ? 2 : 1, side == 1, true);
+            if (side < 0) {
+                hipLaunchKernelGGL(ldlt_twist_merge_kernel, dim3(1024), dim3(256), 0, s, A, tw, b);
+            } else {
+                const int64_t ne = (tw.n1 - tw.m) * (bw + 2);
+                hipLaunchKernelGGL(ldlt_twist_pack_kernel, dim3(1024), dim3(256), 0, s, A, tw, (const double *)b, side, Ebuf);
+                if (dist->allreduce_sum(dist->ctx, Ebuf, (size_t)ne)) return LVBA_ERR_DIST;
+                hipLaunchKernelGGL(ldlt_twist_unpack_kernel, dim3(1024), dim3(256), 0, s, A, tw, b, (const double *)Ebuf);
+            }
+            st0 = P1;
+        }
+        run_phase2(st0, nsteps, 1, false, false);
+    } else if (!overlap) {
         for (int64_t st = 0; st < nsteps; ++st) {
             const Geo q = geom(st);
             factor_panel(st, q, 1);

@@ -1,0 +1,372 @@
+// ldlt_lookahead.h -- the look-ahead form of the band LDL^T's panel loop: ONE launch per 64-column panel (included by ldlt.hip,
+// after the tile kernels it builds on; no other file includes it).
+//
+// Until round 3 every panel cost two launches on the critical path: [factorise panel p: every tile-row workgroup repeats the
+// 64x64 diagonal factorisation, then forms its tile of L21] -> [apply panel p to block column p+1: "first column"] -> [factorise
+// p+1] ...  = 22 us + 7 us per panel, for a chain whose real dependency is only
+//      diag(p) -> L(p+1,p) -> A(p+1,p+1) -= L(p+1,p) D L(p+1,p)^T -> diag(p+1).
+// Here that chain is the work of ONE workgroup per problem (the "chain" role), which ends launch X_p with the factorisation of
+// the NEXT diagonal block; everything else is off the chain and runs beside it in the same launch:
+//
+//   launch X_p (G_p = L_pp^-T D_p^-1 and d_p come from launch X_{p-1}; q = p - 1):
+//     chain  (1 workgroup)        L(p+1,p) = A(p+1,p) G_p, Z = L D;  A(p+1,p+1) -= L(p+1,q) Z(p+1,q)^T + L(p+1,p) Z(p+1,p)^T;
+//                                 LDL^T of that block -> G_{p+1}, d_{p+1}   (3 products + the 64-pivot chain)
+//     row i  (T_p - 1 workgroups) L(i,p) = A(i,p) G_p, Z(i,p); the tile of block column p+1 in its row:
+//                                 A(i,p+1) -= L(i,q) Z(p+1,q)^T + L(i,p) Z(p+1,p)^T, with Z(p+1,p) recomputed from A(p+1,p) and G_p
+//                                 (one product more, nothing exchanged inside the launch)          (4 products)
+//                                 A(p+1,p) is read from a SIDE COPY: the chain workgroup turns that tile into L(p+1,p) in place
+//                                 during this very launch.  The copy is written by whoever finished the tile -- row p+1 of
+//                                 X_{p-1} (its block-column-p tile), or the phase's first launch -- into one of two buffers.
+//     bulk                        the trailing update of panel q on block columns >= p+2 (128 x 64 tiles, bulk_tile_128)
+//   Every tile has exactly one writer per launch: block column p is turned into L by the roles, block column p+1 receives the
+//   last two panels' contributions from the roles (panel q's could not come earlier: L(.,q) is made in X_q), block columns
+//   >= p+2 belong to the bulk.  No workgroup waits for another inside a launch; the only ordering is between launches.
+//
+// The forward substitution rides along as before: every role workgroup forms y_p = D G^T b_p itself and updates its rows of b.
+#pragma once
+
+struct PanelGeo { int64_t k, w0, rend; int nbe, T; };
+
+// one trailing-update job of a launch: panel o alone (rank 64) or together with its partner e = o - 1 (rank 128), the 128 x 64
+// tiles of the tile columns [ca, cb) in bulk coordinates (tile column tj' <-> block column o + 2 + tj'); 64 x 64 form: the tiles
+// [ca, cb) of the column-major enumeration
+struct BulkJob {
+    PanelGeo o, e;
+    const double *Zo, *Ze;
+    int pair;
+    int64_t ca, cb, nwg;
+};
+struct Step2Args {
+    LdltMat M;
+    int64_t sA, sW, ldz;
+    int nprob, roles, has_q, do_diag, nbe_next, njobs;
+    int64_t rend_next;   // row limit of panel p + 1's window
+    PanelGeo p, q;
+    const double *side_r; // A(p+1, p) as [m][row] (64 x 64, masked like load_panel_tile), read by the row roles
+    double *side_w;       // A(p+2, p+1) for the next launch, written by row 1
+    const double *Gp; // G of panel p
+    double *Gn;       // G of panel p + 1 (written by the chain role)
+    double *dvec, *b, *Zp;
+    const double *Zq;
+    int *status;
+    BulkJob job[2];
+};
+
+// Scratch doubles in the PAD of the first [m][row] tile (LVBA_TS = 80 doubles per column of 64 rows: 16 spare behind each of the
+// 64 columns, which stage_tile / put_acc never touch): b_k, y_k, d_p and the partial sums of the role workgroups.
+__device__ __forceinline__ double &pad_at(double *lds, int idx) { return lds[(idx >> 4) * LVBA_TS + 64 + (idx & 15)]; }
+#define LVBA_PAD_BK 0
+#define LVBA_PAD_YS 64
+#define LVBA_PAD_DP 128
+#define LVBA_PAD_RED 192 // [4][64]
+
+// acc[t][reg] += sum_m Zs[m][16 w + kk + 4 reg] * Ls[m][16 t + i]   (one 64 x 64 x 64 product out of LDS, 16 MFMAs per wave and
+// tile row block; the same operand pattern serves  C -= L Z^T  (Ls = L, Zs = Z)  and  L = A G  (Ls = A, Zs = G[m][j]))
+__device__ __forceinline__ void tile_product(const double *Ls, const double *Zs, int w, int i, int kk, d4 (&acc)[4])
+{
+#pragma unroll 4
+    for (int k0 = 0; k0 < 64; k0 += 4) {
+        const double a = Zs[(k0 + kk) * LVBA_TS + 16 * w + i];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const double bv = Ls[(k0 + kk) * LVBA_TS + 16 * t + i];
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc[t], 0, 0, 0);
+        }
+    }
+}
+// registers (thread (row, m = w + 4 it)) -> T[m][row]
+__device__ __forceinline__ void stage_tile(double *T, const double (&v)[16], int w, int row)
+{
+#pragma unroll
+    for (int it = 0; it < 16; ++it) T[(w + 4 * it) * LVBA_TS + row] = v[it];
+}
+// a product's result (acc[t][reg] <-> row 16 t + i of the Ls operand, row 16 w + kk + 4 reg of the Zs operand) as an operand
+// tile T[col = Zs row][row = Ls row], every column scaled by sc[col] (nullptr: unscaled)
+__device__ __forceinline__ void put_acc(double *T, const d4 (&acc)[4], int w, int i, int kk, double *lds_scale)
+{
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int c = 16 * w + kk + 4 * reg;
+        const double sc = lds_scale ? pad_at(lds_scale, LVBA_PAD_DP + c) : 1.0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) T[c * LVBA_TS + 16 * t + i] = acc[t][reg] * sc;
+    }
+}
+// tile rows [r0, r0 + 64) x the 64 columns of a panel (column kc + m), rows >= rlim and columns >= nbe read as zero
+__device__ __forceinline__ void load_panel_tile(const LdltMat &M, int64_t r0, int64_t kc, int64_t rlim, int nbe, int w, int row,
+                                                double (&v)[16])
+{
+    const int64_t r = r0 + row;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int m = w + 4 * it;
+        v[it] = (r < rlim && m < nbe) ? M.a[r + (kc + m) * M.ld] : 0.0;
+    }
+}
+// the same rows of a panel's Z buffer (row r at r - w0)
+__device__ __forceinline__ void load_z_tile(const double *__restrict__ Z, int64_t ldz, int64_t r0, int64_t w0, int64_t rlim, int nbe,
+                                            int w, int row, double (&v)[16])
+{
+    const int64_t r = r0 + row;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int m = w + 4 * it;
+        v[it] = (r < rlim && m < nbe) ? Z[(r - w0) + m * ldz] : 0.0;
+    }
+}
+// y_k and the rows' share of the forward substitution, common to both roles.  Before: Zs = G[m][j], pad BK = b_k, DP = d_p.
+__device__ __forceinline__ void fwd_partial_y(double *lds, const double *Zs, int w, int row)
+{
+    double z = 0.0; // z_j = sum_m G[m][j] b_m : thread (j = row, w) sums m in [16 w, 16 w + 16)
+#pragma unroll
+    for (int m = 0; m < 16; ++m) z += Zs[(16 * w + m) * LVBA_TS + row] * pad_at(lds, LVBA_PAD_BK + 16 * w + m);
+    pad_at(lds, LVBA_PAD_RED + 64 * w + row) = z;
+}
+__device__ __forceinline__ double red4(double *lds, int j)
+{
+    return pad_at(lds, LVBA_PAD_RED + j) + pad_at(lds, LVBA_PAD_RED + 64 + j) + pad_at(lds, LVBA_PAD_RED + 128 + j) +
+           pad_at(lds, LVBA_PAD_RED + 192 + j);
+}
+
+// ---------------------------------------------------------------------------------------------- the chain role
+__device__ __forceinline__ void chain_role(double *lds, const LdltMat &M, const Step2Args &A, const double *__restrict__ Gp,
+                                           double *__restrict__ Gn, double *__restrict__ dvec, double *__restrict__ b,
+                                           double *__restrict__ Zp, const double *__restrict__ Zq)
+{
+    double *Ls = lds, *Zs = lds + 64 * LVBA_TS;
+    const PanelGeo &p = A.p, &q = A.q;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, row = tid & 63, i = lane & 15, kk = lane >> 4;
+    const int64_t r0 = p.w0, r = r0 + row; // rows of tile p + 1 = columns of panel p + 1
+    __builtin_amdgcn_s_setprio(3);        // the launch is as long as this workgroup: first call on the issue slots it shares
+    const bool use_q = A.has_q && r0 < q.rend; // (a band narrower than two tiles: panel q does not reach tile row p + 1)
+    double va[16], vb[16], a1[16], gp[16];
+    if (use_q) {
+        load_panel_tile(M, r0, q.k, q.rend, q.nbe, w, row, va);    // L(p+1, q)
+        load_z_tile(Zq, A.ldz, r0, q.w0, q.rend, q.nbe, w, row, vb); // Z(p+1, q)
+    }
+    load_panel_tile(M, r0, p.k, p.rend, p.nbe, w, row, a1);        // A(p+1, p)
+#pragma unroll
+    for (int it = 0; it < 16; ++it) gp[it] = Gp[tid + 256 * it];   // G[m][c], row-major: thread (c = row, m = w + 4 it)
+    const double bk = (tid < p.nbe) ? b[p.k + tid] : 0.0;
+    const double dk = (tid < p.nbe) ? dvec[p.k + tid] : 0.0;
+    d4 acc[4], accL[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = accL[t] = (d4){0.0, 0.0, 0.0, 0.0};
+    if (use_q) { // block-uniform
+        stage_tile(Ls, va, w, row);
+        stage_tile(Zs, vb, w, row);
+        __syncthreads();
+        tile_product(Ls, Zs, w, i, kk, acc);
+        __syncthreads();
+    }
+    // the block itself, as the products' result layout has it: cv[4 t + reg] <-> (r0 + 16 t + i, r0 + 16 w + kk + 4 reg)
+    double cv[16];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int64_t c = r0 + 16 * w + kk + 4 * reg, rr = r0 + 16 * t + i;
+            cv[4 * t + reg] = (rr < p.rend && c < p.rend && rr >= c) ? M.a[rr + c * M.ld] : 0.0;
+        }
+    stage_tile(Ls, a1, w, row);
+    stage_tile(Zs, gp, w, row);
+    if (tid < 64) {
+        pad_at(lds, LVBA_PAD_BK + tid) = bk;
+        pad_at(lds, LVBA_PAD_DP + tid) = dk;
+    }
+    __syncthreads();
+    fwd_partial_y(lds, Zs, w, row);
+    tile_product(Ls, Zs, w, i, kk, accL); // accL[t][reg] = L[row 16 t + i][column 16 w + kk + 4 reg]
+    __syncthreads();
+    put_acc(Ls, accL, w, i, kk, nullptr); // L(p+1,p) as [m][row]
+    put_acc(Zs, accL, w, i, kk, lds);     // Z = L D
+    if (tid < 64) pad_at(lds, LVBA_PAD_YS + tid) = (tid < p.nbe) ? red4(lds, tid) * dk : 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int j = w + 4 * it;
+        if (r < p.rend && j < p.nbe) {
+            M.a[r + (p.k + j) * M.ld] = Ls[j * LVBA_TS + row];
+            Zp[(r - p.w0) + j * A.ldz] = Zs[j * LVBA_TS + row];
+        }
+    }
+    { // b[r] -= L[row] . y_p, four lanes per row
+        double sacc = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sacc += Ls[(16 * w + j) * LVBA_TS + row] * pad_at(lds, LVBA_PAD_YS + 16 * w + j);
+        pad_at(lds, LVBA_PAD_RED + 64 * w + row) = sacc;
+    }
+    tile_product(Ls, Zs, w, i, kk, acc);
+    __syncthreads();
+    if (tid < 64 && r < p.rend) b[r] -= red4(lds, tid);
+    if (!A.do_diag) { // the phase ends here: the updated block goes back to the matrix
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int64_t c = r0 + 16 * w + kk + 4 * reg, rr = r0 + 16 * t + i;
+                if (rr < p.rend && c < p.rend && rr >= c) M.a[rr + c * M.ld] = cv[4 * t + reg] - acc[t][reg];
+            }
+        return;
+    }
+    __syncthreads(); // (the red4 reads above: W overwrites the pads)
+    // W of the blocked factorisation, straight from the registers: lower triangle of the block, identity below its last row
+    // (a short last panel), the identity appended as rows 64..127
+    double *W = lds;
+    const int nbn = A.nbe_next;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int c = 16 * w + kk + 4 * reg, rr = 16 * t + i;
+            double v;
+            if (rr < nbn) v = (c <= rr) ? cv[4 * t + reg] - acc[t][reg] : 0.0;
+            else v = (c == rr) ? 1.0 : 0.0;
+            W[c * LVBA_W1S + rr] = v;
+            W[c * LVBA_W1S + 64 + rr] = (c == rr) ? 1.0 : 0.0;
+        }
+    __syncthreads();
+    diag_blocked_factor(lds, nbn, A.status);
+    const double *dvs = lds + 64 * LVBA_W1S + 256 + 16 * LVBA_Z1S;
+    if (tid < nbn) dvec[p.w0 + tid] = dvs[tid];
+    for (int e = tid; e < 4096; e += 256) Gn[e] = W[(e & 63) * LVBA_W1S + 64 + (e >> 6)];
+}
+
+// ---------------------------------------------------------------------------------------------- the row role
+// tile row t >= 1 of panel p's window (global tile row i = p + 1 + t)
+__device__ __forceinline__ void row_role(double *lds, const LdltMat &M, const Step2Args &A, int64_t t_row, const double *__restrict__ Gp,
+                                         const double *__restrict__ dvec, double *__restrict__ b, double *__restrict__ Zp,
+                                         const double *__restrict__ Zq, const double *__restrict__ side_r, double *__restrict__ side_w)
+{
+    double *Ls = lds, *Zs = lds + 64 * LVBA_TS;
+    const PanelGeo &p = A.p, &q = A.q;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, row = tid & 63, i = lane & 15, kk = lane >> 4;
+    const int64_t r0 = p.w0 + 64 * t_row, r = r0 + row; // this tile row
+    const int64_t s0 = p.w0;                             // rows of tile p + 1 = columns of the updated tile
+    const bool use_q = A.has_q && r0 < q.rend;           // the row lies inside panel q's window (block-uniform)
+    double va[16], vb[16], ai[16], gp[16];
+    if (use_q) {
+        load_panel_tile(M, r0, q.k, q.rend, q.nbe, w, row, va);      // L(i, q)
+        load_z_tile(Zq, A.ldz, s0, q.w0, q.rend, q.nbe, w, row, vb); // Z(p+1, q)
+    }
+    load_panel_tile(M, r0, p.k, p.rend, p.nbe, w, row, ai);          // A(i, p)
+#pragma unroll
+    for (int it = 0; it < 16; ++it) gp[it] = Gp[tid + 256 * it];
+    const double bk = (tid < p.nbe) ? b[p.k + tid] : 0.0;
+    const double dk = (tid < p.nbe) ? dvec[p.k + tid] : 0.0;
+    d4 acc[4], accI[4], acc0[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = accI[t] = acc0[t] = (d4){0.0, 0.0, 0.0, 0.0};
+    if (use_q) {
+        stage_tile(Ls, va, w, row);
+        stage_tile(Zs, vb, w, row);
+        __syncthreads();
+        tile_product(Ls, Zs, w, i, kk, acc);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) va[it] = side_r[(w + 4 * it) * 64 + row]; // A(p+1, p), for Z(p+1, p): the side copy
+    stage_tile(Ls, ai, w, row);
+    stage_tile(Zs, gp, w, row);
+    if (tid < 64) {
+        pad_at(lds, LVBA_PAD_BK + tid) = bk;
+        pad_at(lds, LVBA_PAD_DP + tid) = dk;
+    }
+    __syncthreads();
+    fwd_partial_y(lds, Zs, w, row);
+    tile_product(Ls, Zs, w, i, kk, accI); // L(i, p)
+    __syncthreads();
+    stage_tile(Ls, va, w, row);           // G stays in Zs
+    if (tid < 64) pad_at(lds, LVBA_PAD_YS + tid) = (tid < p.nbe) ? red4(lds, tid) * dk : 0.0;
+    __syncthreads();
+    // the tile of block column p + 1 in this row: cv[4 t + reg] <-> (r0 + 16 t + i, s0 + 16 w + kk + 4 reg).  Row 1 reads it
+    // as far as the NEXT panel's window reaches (rows the band gains there still hold their original entries): its result is
+    // also the side copy of A(p+2, p+1).
+    const bool mk_side = t_row == 1; // block-uniform
+    const int64_t rlim = mk_side ? A.rend_next : p.rend;
+    double cv[16];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int64_t c = s0 + 16 * w + kk + 4 * reg, rr = r0 + 16 * t + i;
+            cv[4 * t + reg] = (rr < rlim && c < rlim) ? M.a[rr + c * M.ld] : 0.0;
+        }
+    tile_product(Ls, Zs, w, i, kk, acc0); // L(p+1, p)
+    __syncthreads();
+    put_acc(Ls, accI, w, i, kk, nullptr); // L(i, p) as [m][row]
+    put_acc(Zs, acc0, w, i, kk, lds);     // Z(p+1, p) = L(p+1, p) D
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int j = w + 4 * it;
+        if (r < p.rend && j < p.nbe) {
+            const double v = Ls[j * LVBA_TS + row];
+            M.a[r + (p.k + j) * M.ld] = v;
+            Zp[(r - p.w0) + j * A.ldz] = v * pad_at(lds, LVBA_PAD_DP + j);
+        }
+    }
+    {
+        double sacc = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sacc += Ls[(16 * w + j) * LVBA_TS + row] * pad_at(lds, LVBA_PAD_YS + 16 * w + j);
+        pad_at(lds, LVBA_PAD_RED + 64 * w + row) = sacc;
+    }
+    tile_product(Ls, Zs, w, i, kk, acc);
+    __syncthreads();
+    if (tid < 64 && r < p.rend) b[r] -= red4(lds, tid);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int cl = 16 * w + kk + 4 * reg, rl = 16 * t + i;
+            const int64_t c = s0 + cl, rr = r0 + rl;
+            const double v = cv[4 * t + reg] - acc[t][reg];
+            if (rr < p.rend && c < p.rend) M.a[rr + c * M.ld] = v;
+            if (mk_side) side_w[cl * 64 + rl] = (rr < A.rend_next && cl < A.nbe_next) ? v : 0.0;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------- one launch
+// Block order: the chain workgroups of all problems first, then the row workgroups, then the bulk jobs' workgroups alternating
+// between the problems.  big: 128 x 64 bulk tiles (bulk_tile_128, 32-bit buffer offsets) / 64 x 64 tiles (update_tile[2]).
+template <bool big>
+__global__ __launch_bounds__(256, 2) void ldlt_step2_kernel(const Step2Args A)
+{
+    __shared__ double lds[LVBA_K3_LDS];
+    static_assert(LVBA_K1B_LDS <= LVBA_K3_LDS && LVBA_K3B_LDS <= LVBA_K3_LDS && LVBA_PAD_RED + 256 <= 1024, "LDS budget of the roles");
+    const int64_t nrole = A.roles ? A.p.T : 0, nfac = nrole * A.nprob;
+    LdltMat M = A.M;
+    int prob;
+    int64_t bx;
+    if ((int64_t)blockIdx.x < nfac) { prob = (int)(blockIdx.x % A.nprob); bx = blockIdx.x / A.nprob; }
+    else {
+        const int64_t bb = blockIdx.x - nfac;
+        prob = (int)(bb % A.nprob); bx = bb / A.nprob;
+    }
+    const int64_t wo = prob ? A.sW : 0;
+    if (prob) M.a += A.sA;
+    if ((int64_t)blockIdx.x < nfac) {
+        if (bx == 0) chain_role(lds, M, A, A.Gp + wo, A.Gn + wo, A.dvec + wo, A.b + wo, A.Zp + wo, A.Zq ? A.Zq + wo : nullptr);
+        else row_role(lds, M, A, bx, A.Gp + wo, A.dvec + wo, A.b + wo, A.Zp + wo, A.Zq ? A.Zq + wo : nullptr, A.side_r + wo, A.side_w + wo);
+        return;
+    }
+    for (int j = 0; j < A.njobs; ++j) {
+        const BulkJob &J = A.job[j];
+        if (bx >= J.nwg) { bx -= J.nwg; continue; }
+        const double *Zo = J.Zo + wo, *Ze = J.pair ? J.Ze + wo : nullptr;
+        if constexpr (big) {
+            int64_t R0, tj;
+            if (!pair_decode(bx, J.ca, J.cb, (int64_t)J.o.T - 1, R0, tj)) return;
+            const PanelRef po{J.o.k, J.o.w0, J.o.rend, J.o.nbe, Zo}, pe{J.e.k, J.e.w0, J.e.rend, J.e.nbe, Ze};
+            if (J.pair) bulk_tile_128<4>(lds, M, po, pe, A.ldz, R0, tj);
+            else bulk_tile_128<2>(lds, M, po, pe, A.ldz, R0, tj);
+        } else {
+            int64_t ti, tj;
+            col_decode(J.ca + bx, (int64_t)J.o.T - 1, ti, tj);
+            if (J.pair) update_tile2(lds, M, J.o.k, J.o.nbe, J.o.w0, J.o.rend, Zo, J.e.k, J.e.nbe, J.e.w0, J.e.rend, Ze, A.ldz, ti + 1, tj + 1);
+            else update_tile(lds, M, J.o.k, J.o.nbe, J.o.w0, J.o.rend, Zo, A.ldz, ti + 1, tj + 1);
+        }
+        return;
+    }
+}

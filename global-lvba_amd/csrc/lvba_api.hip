@@ -545,6 +545,14 @@ extern "C" int32_t lvba_balm_eval_blocks(lvba_balm_t h, const double *poses, int
     TRY(finalize(h));
     BlockSys &bs = h->bs;
     HIPCHK(hipSetDevice(bs.device));
+    // The block set is STRUCTURAL (the pair lists' destinations + the diagonal; the union pattern in a multi-rank job): it is
+    // known from the set-up, the same for every call, and a sizing call (capacity 0, no g, no cost) runs no evaluation.
+    lvba::hvec<int64_t> slots;
+    TRY(bs_pattern_slots(bs, slots));
+    const int64_t nb = (int64_t)slots.size();
+    *n_blocks = nb;
+    if (capacity <= 0 && !g && !cost_avg) return LVBA_OK;
+    if (capacity > 0 && nb > capacity) return fail(LVBA_ERR_ARG, "capacity %lld < %lld blocks", (long long)capacity, (long long)nb);
     TRY(upload_poses(h, poses, h->d_pose_cur));
     h->lin_at_cur = false;
     TRY(enqueue_eval(h, h->d_pose_cur));
@@ -556,40 +564,29 @@ extern "C" int32_t lvba_balm_eval_blocks(lvba_balm_t h, const double *poses, int
     HIPCHK(hipStreamSynchronize(bs.stream));
     ev_collect(h);
     if (cost_avg) *cost_avg = h->h_pin[0] / (double)h->Vglobal;
-    // the block-band store (solver order), one block column at a time
-    const int64_t Bb1 = (int64_t)bs.Bb + 1, N = h->N;
-    lvba::hvec<double> col((size_t)Bb1 * 36);
-    int64_t nb = 0;
-    for (int64_t J = 0; J < N; ++J) {
-        const int64_t rows = std::min<int64_t>(Bb1, N - J);
-        HIPCHK(hipMemcpy(col.data(), bs.Hblk() + J * Bb1 * 36, (size_t)rows * 36 * sizeof(double), hipMemcpyDeviceToHost));
-        for (int64_t dI = 0; dI < rows; ++dI) {
-            const double *b = col.data() + dI * 36; // column-major: b[c * 6 + r] = H(6 I + r, 6 J + c), I = J + dI (diagonal: r >= c only)
-            bool nz = dI == 0;
-            for (int e = 0; e < 36 && !nz; ++e) nz = b[e] != 0.0;
-            if (!nz) continue;
-            if (nb < capacity) {
-                const int32_t pi = bs.perm[(size_t)(J + dI)], pj = bs.perm[(size_t)J];
-                double *o = blocks + nb * 36;
-                if (dI == 0) {
-                    bi[nb] = pi; bj[nb] = pj;
-                    for (int r = 0; r < 6; ++r)
-                        for (int c = 0; c < 6; ++c) o[6 * r + c] = r >= c ? b[c * 6 + r] : b[r * 6 + c];
-                } else if (pi >= pj) {
-                    bi[nb] = pi; bj[nb] = pj;
-                    for (int r = 0; r < 6; ++r)
-                        for (int c = 0; c < 6; ++c) o[6 * r + c] = b[c * 6 + r];
-                } else { // the caller's order flips the pair: the transposed block
-                    bi[nb] = pj; bj[nb] = pi;
-                    for (int r = 0; r < 6; ++r)
-                        for (int c = 0; c < 6; ++c) o[6 * r + c] = b[r * 6 + c];
-                }
-            }
-            ++nb;
+    if (capacity <= 0) return LVBA_OK;
+    // one device-side gather of the pattern's blocks, downloaded in slabs; then into the caller's pose order, in place
+    TRY(bs_download_blocks(bs, slots.data(), nb, blocks));
+    const int64_t Bb1 = (int64_t)bs.Bb + 1;
+    for (int64_t q = 0; q < nb; ++q) {
+        const int64_t J = slots[(size_t)q] / Bb1, dI = slots[(size_t)q] - J * Bb1;
+        double *o = blocks + q * 36, b[36];
+        memcpy(b, o, sizeof b); // column-major: b[c * 6 + r] = H(6 I + r, 6 J + c), I = J + dI (diagonal: r >= c only)
+        const int32_t pi = bs.perm[(size_t)(J + dI)], pj = bs.perm[(size_t)J];
+        if (dI == 0) {
+            bi[q] = pi; bj[q] = pj;
+            for (int r = 0; r < 6; ++r)
+                for (int c = 0; c < 6; ++c) o[6 * r + c] = r >= c ? b[c * 6 + r] : b[r * 6 + c];
+        } else if (pi >= pj) {
+            bi[q] = pi; bj[q] = pj;
+            for (int r = 0; r < 6; ++r)
+                for (int c = 0; c < 6; ++c) o[6 * r + c] = b[c * 6 + r];
+        } else { // the caller's order flips the pair: the transposed block
+            bi[q] = pj; bj[q] = pi;
+            for (int r = 0; r < 6; ++r)
+                for (int c = 0; c < 6; ++c) o[6 * r + c] = b[r * 6 + c];
         }
     }
-    *n_blocks = nb;
-    if (capacity > 0 && nb > capacity) return fail(LVBA_ERR_ARG, "capacity %lld < %lld blocks", (long long)capacity, (long long)nb);
     return LVBA_OK;
 }
 

@@ -47,7 +47,7 @@ int main()
         lvba::hvec<lvba::hvec<int>> vv(4, lvba::hvec<int>(50000, 7));
         CHECK(vv[3][49999] == 7);
     }
-    CHECK(A.cached_bytes() > 0 && A.cached_bytes() <= HostArena::kCap);
+    CHECK(A.cached_bytes() > 0 && A.cached_bytes() <= A.cap());
     // concurrent use (the window stage's worker threads build tables at the same time)
     std::thread th[4];
     bool ok[4] = {false, false, false, false};
@@ -64,6 +64,38 @@ int main()
     CHECK(ok[0] && ok[1] && ok[2] && ok[3]);
     A.release();
     CHECK(A.cached_bytes() == 0);
+    // a miss in the request's own class takes the smallest cached block of up to twice the class, and the block goes back
+    // under ITS class whatever size its user frees it with
+    {
+        const size_t c3 = HostArena::size_class((size_t)3 << 20), c9 = HostArena::size_class((size_t)9 << 20);
+        void *a3 = A.alloc((size_t)3 << 20), *a9 = A.alloc((size_t)9 << 20);
+        A.free(a3, (size_t)3 << 20);
+        A.free(a9, (size_t)9 << 20);
+        CHECK(A.cached_bytes() == c3 + c9);
+        void *b = A.alloc((size_t)2 << 20);        // 2 MB class is empty: the 3 MB block (<= 2 x 2 MB), not the 9 MB one
+        CHECK(b == a3 && A.cached_bytes() == c9);
+        void *c = A.alloc((size_t)2 << 20);        // nothing within twice the class left: a fresh block
+        CHECK(c != a9 && A.cached_bytes() == c9);
+        A.free(b, (size_t)2 << 20);
+        CHECK(A.cached_bytes() == c9 + c3);
+        A.free(c, (size_t)2 << 20);
+        A.release();
+    }
+    // the cap: nothing above it is kept (LVBA_HOST_CACHE_MB; 0 turns the cache off)
+    {
+        CHECK(A.cap() == HostArena::kDefaultCap);
+        A.set_cap((size_t)4 << 20);
+        void *a = A.alloc((size_t)3 << 20), *b = A.alloc((size_t)3 << 20);
+        A.free(a, (size_t)3 << 20);
+        A.free(b, (size_t)3 << 20);               // would exceed 4 MB: goes to free()
+        CHECK(A.cached_bytes() == HostArena::size_class((size_t)3 << 20));
+        A.set_cap(0);
+        A.release();
+        void *z = A.alloc((size_t)1 << 20);
+        A.free(z, (size_t)1 << 20);
+        CHECK(A.cached_bytes() == 0);
+        A.set_cap(HostArena::kDefaultCap);
+    }
     printf("host arena ok\n");
     return 0;
 }

@@ -434,16 +434,20 @@ pkg = importlib.import_module("global-lvba_amd")
 synth = importlib.import_module("global-lvba_amd.synth")
 d = synth.make_balm_problem(700, 30000, band=12, loop_frac=0.0, seed=5)
 prob = pkg.BalmProblem(700, d["voxel_off"], d["pose_idx"], d["clusters"])
+import os
 prob.eval(d["poses_init"], want_H=False, want_g=False)
 info = prob.info()
 dx = prob.solve(0.01)
+if os.environ.get("LVBA_CHECK_BAND") == "1":      # the check runs at the START of a solve, on what the solves before it left
+    for _ in range(2):
+        assert np.array_equal(prob.solve(0.01), dx)
 np.save(sys.argv[2], np.concatenate([dx.ravel(), [info["use_band"], info["twist_panels"]]]))
 """
 
 
 def test_solver_schedules(tmp_path):
     """The launch schedule of the band LDL^T has several forms behind environment switches (read once per process): the
-    default (both ends at once, paired panels, 128 x 64 update tiles), and for A/B the former ones.  Every form must give
+    default (look-ahead: one launch per panel; both ends at once, paired panels, 128 x 64 update tiles), and for A/B the former ones.  Every form must give
     the same solution of the same damped system (they differ in summation order only): 4200 unknowns, half-bandwidth ~150,
     enough panels for the two-ended form and the pairing to be active."""
     import subprocess
@@ -452,7 +456,12 @@ def test_solver_schedules(tmp_path):
     script = tmp_path / "run.py"
     script.write_text(_SCHEDULE_SCRIPT)
     variants = [{}, {"LVBA_BULK": "64"}, {"LVBA_RANK128": "0"}, {"LVBA_TWIST": "0"}, {"LVBA_SCHEDULE": "serial"},
-                {"LVBA_BULK": "64", "LVBA_RANK128": "0"}, {"LVBA_RANK128": "0", "LVBA_TWIST": "0"}]
+                {"LVBA_BULK": "64", "LVBA_RANK128": "0"}, {"LVBA_RANK128": "0", "LVBA_TWIST": "0"},
+                # the round-3 schedule (two launches per panel) behind the look-ahead one (default since round 4)
+                {"LVBA_SOLVER": "r3"}, {"LVBA_SOLVER": "r3", "LVBA_RANK128": "0"}, {"LVBA_SOLVER": "r3", "LVBA_BULK": "64"},
+                {"LVBA_SOLVER": "r3", "LVBA_TWIST": "0"},
+                # debugging switches: the never-rewritten part of the band store stays zero over repeated solves (no graph)
+                {"LVBA_CHECK_BAND": "1", "LVBA_NO_GRAPH": "1"}, {"LVBA_BAND_MEMSET": "1"}]
     out = []
     for i, v in enumerate(variants):
         f = tmp_path / f"dx_{i}.npy"

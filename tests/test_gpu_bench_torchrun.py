@@ -48,3 +48,19 @@ def test_bench_two_ranks_through_torchrun_equals_one_rank():
         assert a["config"][k] == b["config"][k], k
     ca, cb = a["config"]["last_cost"], b["config"]["last_cost"]
     assert abs(ca - cb) <= 1e-9 * abs(ca), (ca, cb)
+
+
+@pytest.mark.gpu
+def test_bare_bench_with_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the shape of the driver's one-GPU command with another N) must
+    start the two ranks itself instead of exiting: same JSON line as the explicit torch.distributed.run form."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    common = ["--steps", "2", "--warmup", "1", "--config", "C2", "--no-cpu-baseline", "--no-visual", "--no-front-end"]
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--transport", "gloo", "--same-device"] + common, cwd=ROOT,
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    b = last_json(r.stdout)
+    assert b["n_gpus"] == 2 and b["steps"] == 2 and b["value"] > 0
+    assert "2 rank(s)" in b["config"]["sharding"] and b["stage_ms"]["allreduce"] > 0

@@ -281,6 +281,43 @@ def test_device_eig3_planar_accuracy(emul):
     assert np.allclose(out_l, [1e-3, 3.0, 3.0], rtol=1e-14)
 
 
+def test_device_eig3_planar_near_double_root(emul):
+    """Edge- / line-like voxels: lam0 ~ lam1 << lam2 is valid input (the reference admits a voxel on lam0 / lam2 alone,
+    bavoxel.hpp:351).  There eig3_planar's direct method breaks down (Newton on a nearly double root, vanishing cross products)
+    and must hand over to cyclic Jacobi: lam1 / lam0 from exactly 1 to 1.01, and a few ratios up to 2 that straddle the
+    hand-over, against LAPACK.  Eigenvectors are compared through what is unique: the residual C U - U diag(lam), orthonormality,
+    and the projector onto u2 (lam2 is well separated)."""
+    rng = np.random.default_rng(11)
+    ratios = [1.0, 1.0 + 1e-12, 1.0 + 1e-9, 1.0 + 1e-6, 1.0001, 1.001, 1.003, 1.01, 1.03, 1.1, 1.3, 2.0]
+    for trial in range(360):
+        Q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+        l2 = 10.0 ** rng.uniform(-3, 1)
+        l0 = l2 * 10.0 ** rng.uniform(-4, -1)
+        l1 = l0 * ratios[trial % len(ratios)]
+        C = Q @ np.diag([l0, l1, l2]) @ Q.T
+        C = 0.5 * (C + C.T)
+        ref_l, ref_U = np.linalg.eigh(C)
+        C6 = np.array([C[0, 0], C[0, 1], C[0, 2], C[1, 1], C[1, 2], C[2, 2]])
+        out_l, out_U, l_only = np.empty(3), np.empty(9), np.empty(3)
+        emul.emul_eig3_planar(C6, out_l, out_U.ctypes.data)
+        emul.emul_eig3_planar(C6, l_only, None)
+        U = out_U.reshape(3, 3)
+        assert np.isfinite(out_l).all() and np.isfinite(U).all()
+        assert np.abs(out_l - ref_l).max() <= 4e-15 * l2, (trial, out_l, ref_l)
+        assert abs(l_only[0] - ref_l[0]) <= 4e-15 * l2
+        assert out_l[0] <= out_l[1] <= out_l[2]
+        assert np.abs(U.T @ U - np.eye(3)).max() <= 1e-13
+        assert np.abs(C @ U - U * out_l).max() <= 1e-13 * l2
+        assert abs(abs(U[:, 2] @ ref_U[:, 2]) - 1.0) <= 1e-12
+    # all row cross products vanish (a multiple of the identity, a rank-one matrix): no NaN from rsq(0)
+    for C6 in ([2.0, 0, 0, 2.0, 0, 2.0], [1.0, 1.0, 1.0, 1.0, 1.0, 1.0], [0.0, 0, 0, 0.0, 0, 5.0]):
+        out_l, out_U = np.empty(3), np.empty(9)
+        emul.emul_eig3_planar(np.array(C6, dtype=float), out_l, out_U.ctypes.data)
+        C = np.array([[C6[0], C6[1], C6[2]], [C6[1], C6[3], C6[4]], [C6[2], C6[4], C6[5]]], dtype=float)
+        assert np.isfinite(out_l).all() and np.isfinite(out_U).all()
+        assert np.allclose(out_l, np.linalg.eigvalsh(C), atol=1e-14)
+
+
 def test_band_lm_twin_equals_dense_lm(oracle_mod):
     """bo_damping_iter_band (sparse block evaluation + band LDL^T; what the config-size GPU tests and bench.py compare
     against) == bo_damping_iter (dense, the pinned one): bitwise in the natural pose order, to rounding under a permutation."""

@@ -47,3 +47,15 @@ def test_host_arena(tmp_path):
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", os.path.join(ROOT, "tests", "host_arena_check.cpp"), "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and "host arena ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_ldlt_lookahead_schedule(tmp_path):
+    """global-lvba_amd/csrc/ldlt_schedule.h: the launch list of the look-ahead band LDL^T (one launch per panel, no
+    synchronisation inside a launch) replayed on a tile-level model of the factorisation -- one writer per tile and launch,
+    inputs from earlier launches only, every contribution exactly once, nothing missing at the end; both schedules (single
+    panels / paired rank-128 updates), both phase kinds (two-ended with an early close, top-down to the last panel), the
+    geometries of configs C3 and C4 and a set of edge cases (tests/ldlt_schedule_check.cpp)."""
+    exe = str(tmp_path / "ldlt_schedule_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "ldlt_schedule_check.cpp"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "ldlt schedule ok" in r.stdout, r.stdout[-3000:]

@@ -42,7 +42,7 @@ int main(int argc, char **argv)
     const int64_t k = 64 * 10, w0 = k + 64, rend = (k + 64 + bw < n) ? k + 64 + bw : n, T = (rend - w0 + 63) / 64;
     printf("n=%lld bw=%lld panels=%lld T=%lld\n", (long long)n, (long long)bw, (long long)nsteps, (long long)T);
     float t;
-    t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_diag_blocked_kernel, dim3(1), dim3(256), 0, s, A, k, 64, Gall, dvec, status); });
+    t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_diag_blocked_kernel, dim3(1), dim3(256), 0, s, A, k, 64, Gall, dvec, status, (int64_t)0, (int64_t)0, (double *)nullptr, (int64_t)0); });
     {
         unsigned long long c[16]; CK(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_k1b_clk), sizeof c));
         printf("K1 blocked %7.2f us   cycles: load %llu |", t * 1e3, c[1] - c[0]);
@@ -58,6 +58,47 @@ int main(int argc, char **argv)
     t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_diagpanel_kernel, dim3((unsigned)T), dim3(256), 0, s, A, k, 64, w0, rend, Gall, dvec, Zws, ldz, b, status, 0, 0);
                               hipLaunchKernelGGL(ldlt_update_kernel, dim3((unsigned)(T * (T + 1) / 2)), dim3(256), 0, s, A, k, 64, w0, rend, Zws, ldz, 0, 0, 0); });
     printf("diag+panel, update chain %8.2f us\n", t * 1e3);
+    // ---- the look-ahead launch (ldlt_lookahead.h) in pieces, at this geometry: panel p = 10 with its predecessor
+    {
+        auto geo = [&](int64_t st) {
+            PanelGeo g; g.k = 64 * st; g.nbe = 64; g.w0 = g.k + 64; g.rend = (g.w0 + bw < n) ? g.w0 + bw : n; g.T = (int)((g.rend - g.w0 + 63) / 64);
+            return g;
+        };
+        double *side; CK(hipMalloc((void **)&side, 4 * 4096 * 8)); CK(hipMemset(side, 0, 4 * 4096 * 8));
+        double *Z2; CK(hipMalloc((void **)&Z2, 4 * ldz * 64 * 8)); CK(hipMemset(Z2, 0, 4 * ldz * 64 * 8));
+        Step2Args a{};
+        a.M = A; a.sA = 0; a.sW = 0; a.ldz = ldz; a.nprob = 1; a.roles = 1; a.has_q = 1; a.do_diag = 1; a.nbe_next = 64;
+        a.p = geo(10); a.q = geo(9); a.rend_next = geo(11).rend;
+        a.side_r = side; a.side_w = side + 4096; a.Gp = Gall + 10 * 4096; a.Gn = Gall + 11 * 4096; a.dvec = dvec; a.b = b;
+        a.Zp = Z2; a.Zq = Z2 + ldz * 64; a.status = status;
+        const int Tfull = a.p.T;
+        a.p.T = 1; // the chain workgroup alone
+        t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_step2_kernel<true>, dim3(1), dim3(256), 0, s, a); });
+        printf("look-ahead: chain role alone            %7.2f us\n", t * 1e3);
+        a.has_q = 0;
+        t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_step2_kernel<true>, dim3(1), dim3(256), 0, s, a); });
+        printf("look-ahead: chain role, no predecessor  %7.2f us\n", t * 1e3);
+        a.has_q = 1; a.do_diag = 0;
+        t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_step2_kernel<true>, dim3(1), dim3(256), 0, s, a); });
+        printf("look-ahead: chain role without the diagonal factorisation %7.2f us\n", t * 1e3);
+        a.do_diag = 1; a.p.T = Tfull;
+        t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_step2_kernel<true>, dim3((unsigned)Tfull), dim3(256), 0, s, a); });
+        printf("look-ahead: chain + %d row roles         %7.2f us\n", Tfull - 1, t * 1e3);
+        // + the pair job of the steady state: panels (8, 9) as a rank-128 update, first half of the tile columns
+        a.njobs = 1;
+        BulkJob &J = a.job[0];
+        J.o = geo(9); J.e = geo(8); J.Zo = Z2 + ldz * 64; J.Ze = Z2 + 2 * ldz * 64; J.pair = 1;
+        const int64_t Tb = J.o.T - 1;
+        int64_t tot = 0, part = 0, cs = 1;
+        for (int64_t c = 1; c < Tb; ++c) tot += pair_col_items(c, Tb);
+        while (cs < Tb && (cs < 3 || 2 * part < tot)) part += pair_col_items(cs++, Tb);
+        J.ca = 1; J.cb = cs; J.nwg = part;
+        t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_step2_kernel<true>, dim3((unsigned)(Tfull + J.nwg)), dim3(256), 0, s, a); });
+        printf("look-ahead: roles + first half of a pair job (%lld tiles of 128 x 64) %7.2f us\n", (long long)J.nwg, t * 1e3);
+        a.roles = 0;
+        t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_step2_kernel<true>, dim3((unsigned)J.nwg), dim3(256), 0, s, a); });
+        printf("look-ahead: that job alone              %7.2f us\n", t * 1e3);
+    }
     // empty-kernel launch chain for reference
     t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_prepare_kernel, dim3(1), dim3(64), 0, s, A, work, 0, 0, work, work, work, (unsigned long long *)x, 0ULL, LdltTwist{0, 0, 0, 0, nullptr}, (const int32_t *)nullptr, 0, status); });
     printf("tiny kernel back-to-back %8.2f us\n", t * 1e3);
