@@ -254,6 +254,10 @@ __global__ __launch_bounds__(LVBA_CF, 6) void balm_voxel_kernel(BalmDev d, const
 // uniform per workgroup; cluster loads are coalesced (pose-major copy); the voxel record is one 128-byte
 // line per lane.  Y_i goes to global memory for pass 3; (D, g) are summed in registers.
 // ------------------------------------------------------------------------------------------------
+// Y32 (LVBA_Y32=1, an experiment of round 4): the Y records are stored as fp32, 20 floats = 80 bytes per factor (18 used) instead
+// of 144 -- half of the write traffic here and of the pair pass's gathers; the diagonal blocks and the gradient are formed from
+// the fp64 values in registers either way, the off-diagonal blocks then carry ~1e-7 relative rounding (fp64 accumulation).
+template <bool Y32>
 __global__ __launch_bounds__(256) void balm_factor_kernel(BalmDev d, const double *__restrict__ poses)
 {
     __shared__ double red[4 * 27];
@@ -309,12 +313,24 @@ __global__ __launch_bounds__(256) void balm_factor_kernel(BalmDev d, const doubl
             for (int e = 0; e < 18; ++e) ys[lane * 19 + e] = Y[e];
         }
         const int nrec = (int)((b - t0) < 64 ? (b - t0) : 64);
-        double2 *yo = reinterpret_cast<double2 *>(d.Y + 18 * t0);
+        if constexpr (Y32) { // 64 records x 5 chunks of four floats: five contiguous 1-KB stores
+            float4 *yo = reinterpret_cast<float4 *>(reinterpret_cast<float *>(d.Y) + 20 * t0);
 #pragma unroll
-        for (int r = 0; r < 9; ++r) {
-            const int f = 2 * (lane + 64 * r); // flat double index inside the batch
-            const int rec = f / 18, el = f - 18 * rec;
-            if (rec < nrec) yo[lane + 64 * r] = make_double2(ys[rec * 19 + el], ys[rec * 19 + el + 1]);
+            for (int r = 0; r < 5; ++r) {
+                const int ch = lane + 64 * r, rec = ch / 5, el = 4 * (ch - 5 * rec);
+                if (rec < nrec) {
+                    const double *yr = ys + rec * 19 + el;
+                    yo[ch] = make_float4((float)yr[0], (float)yr[1], el + 2 < 18 ? (float)yr[2] : 0.f, el + 3 < 18 ? (float)yr[3] : 0.f);
+                }
+            }
+        } else {
+            double2 *yo = reinterpret_cast<double2 *>(d.Y + 18 * t0);
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                const int f = 2 * (lane + 64 * r); // flat double index inside the batch
+                const int rec = f / 18, el = f - 18 * rec;
+                if (rec < nrec) yo[lane + 64 * r] = make_double2(ys[rec * 19 + el], ys[rec * 19 + el + 1]);
+            }
         }
     }
 #pragma unroll
@@ -462,9 +478,12 @@ __global__ __launch_bounds__(256) void balm_pair_staged_kernel(PairDev d, double
 #ifndef LVBA_PC_PF
 #define LVBA_PC_PF 1     // rounds whose gathers are in flight ahead of the one being multiplied (1 or 2)
 #endif
+// Y32: fp32 records of 80 bytes (balm_factor_kernel<true>): five 16-byte chunks per record instead of nine
+template <bool Y32>
 __global__ __launch_bounds__(256) void balm_pair_col_kernel(PairDev d, double *__restrict__ Hblk)
 {
-    constexpr int NCH = LVBA_PC_ITEMS * LVBA_PC_DEPTH * 18; // 16-byte chunks per round
+    constexpr int RCH = Y32 ? 5 : 9;                               // 16-byte chunks per record
+    constexpr int NCH = LVBA_PC_ITEMS * LVBA_PC_DEPTH * 2 * RCH;   // 16-byte chunks per round
     constexpr int NLD = (NCH + 63) / 64;                    // loads per lane per round
     __shared__ double2 recs[4][NCH]; // per wavefront: DEPTH x 10 pairs x (x record, y record) x 9 chunks of 16 bytes
     __shared__ int2 plist[4][LVBA_PC_ITEMS * LVBA_PAIR_CUT]; // the pair indices of the wavefront's items, fetched once
@@ -496,9 +515,9 @@ __global__ __launch_bounds__(256) void balm_pair_col_kernel(PairDev d, double *_
     int c_piece[NLD], c_side[NLD], c_dep[NLD], c_fa[NLD], c_len[NLD];
 #pragma unroll
     for (int s2 = 0; s2 < NLD; ++s2) {
-        const int c = lane + 64 * s2, rc = c / 9, slot = rc >> 1;
+        const int c = lane + 64 * s2, rc = c / RCH, slot = rc >> 1;
         const int dep = slot / LVBA_PC_ITEMS, gi = slot - dep * LVBA_PC_ITEMS;
-        c_piece[s2] = c - 9 * rc; c_side[s2] = rc & 1; c_dep[s2] = dep;
+        c_piece[s2] = c - RCH * rc; c_side[s2] = rc & 1; c_dep[s2] = dep;
         c_fa[s2] = __shfl(fa, gi, 64);
         c_len[s2] = (c < NCH) ? __shfl(flen, gi, 64) : 0;
     }
@@ -519,7 +538,7 @@ __global__ __launch_bounds__(256) void balm_pair_col_kernel(PairDev d, double *_
             vv[s2] = make_double2(0.0, 0.0);
             if (pi < c_len[s2]) {
                 const int2 pr = pl[c_fa[s2] + pi];
-                vv[s2] = reinterpret_cast<const double2 *>(d.Y + 18 * (int64_t)(c_side[s2] ? pr.y : pr.x))[c_piece[s2]];
+                vv[s2] = reinterpret_cast<const double2 *>(d.Y + (Y32 ? 10 : 18) * (int64_t)(c_side[s2] ? pr.y : pr.x))[c_piece[s2]];
             }
         }
     };
@@ -534,15 +553,27 @@ __global__ __launch_bounds__(256) void balm_pair_col_kernel(PairDev d, double *_
 #pragma unroll
         for (int dep = 0; dep < LVBA_PC_DEPTH; ++dep) {
             if (owner && LVBA_PC_DEPTH * r + dep < mylen) {
-                const double2 *ri = rw + 18 * (dep * LVBA_PC_ITEMS + g);
-                const double *yj = reinterpret_cast<const double *>(ri + 9);
-                double Yi[18];
+                const double2 *ri = rw + 2 * RCH * (dep * LVBA_PC_ITEMS + g);
+                double Yi[18], j0, j1, j2;
+                if constexpr (Y32) {
+                    const float4 *rf = reinterpret_cast<const float4 *>(ri);
+                    const float *yj = reinterpret_cast<const float *>(ri + RCH);
 #pragma unroll
-                for (int e = 0; e < 9; ++e) {
-                    const double2 x = ri[e];
-                    Yi[2 * e] = x.x; Yi[2 * e + 1] = x.y;
+                    for (int e = 0; e < 5; ++e) {
+                        const float4 x = rf[e];
+                        Yi[4 * e] = x.x; Yi[4 * e + 1] = x.y;
+                        if (4 * e + 2 < 18) { Yi[4 * e + 2] = x.z; Yi[4 * e + 3] = x.w; }
+                    }
+                    j0 = yj[cc]; j1 = yj[6 + cc]; j2 = yj[12 + cc];
+                } else {
+                    const double *yj = reinterpret_cast<const double *>(ri + RCH);
+#pragma unroll
+                    for (int e = 0; e < 9; ++e) {
+                        const double2 x = ri[e];
+                        Yi[2 * e] = x.x; Yi[2 * e + 1] = x.y;
+                    }
+                    j0 = yj[cc]; j1 = yj[6 + cc]; j2 = yj[12 + cc];
                 }
-                const double j0 = yj[cc], j1 = yj[6 + cc], j2 = yj[12 + cc];
 #pragma unroll
                 for (int e = 0; e < 6; ++e) acc[e] = fma(Yi[12 + e], j2, fma(Yi[6 + e], j1, fma(Yi[e], j0, acc[e])));
             }
@@ -785,7 +816,8 @@ void launch_pairs(const PairDev &pd, double *Hblk, hipStream_t s)
     if (pd.nnzb > 0) {
         if (pd.col_form) {
             const dim3 grid((unsigned)((((pd.nnzb + 4 * LVBA_PC_ITEMS - 1) / (4 * LVBA_PC_ITEMS)) + 7) / 8 * 8));
-            hipLaunchKernelGGL(balm_pair_col_kernel, grid, dim3(256), 0, s, pd, Hblk);
+            if (pd.col_form == 2) hipLaunchKernelGGL(balm_pair_col_kernel<true>, grid, dim3(256), 0, s, pd, Hblk);
+            else hipLaunchKernelGGL(balm_pair_col_kernel<false>, grid, dim3(256), 0, s, pd, Hblk);
         } else {
             const dim3 grid((unsigned)((((pd.nnzb + 15) / 16) + 7) / 8 * 8));
             hipLaunchKernelGGL(balm_pair_staged_kernel, grid, dim3(256), 0, s, pd, Hblk);
@@ -802,7 +834,8 @@ void launch_eval(const BalmDev &d, const PairDev &pd, const double *poses, doubl
     if (zero_first) hipMemsetAsync(Hblk, 0, (size_t)hblk_doubles * sizeof(double), s);
     if (k0) hipEventRecord(k0, s);
     if (!skip_voxel_pass) hipLaunchKernelGGL(balm_voxel_kernel, dim3((unsigned)d.n_chunks), dim3(LVBA_CF), 0, s, d, poses, chunk_cost);
-    hipLaunchKernelGGL(balm_factor_kernel, dim3((unsigned)(d.n_poses * d.S)), dim3(256), 0, s, d, poses);
+    if (pd.col_form == 2) hipLaunchKernelGGL(balm_factor_kernel<true>, dim3((unsigned)(d.n_poses * d.S)), dim3(256), 0, s, d, poses);
+    else hipLaunchKernelGGL(balm_factor_kernel<false>, dim3((unsigned)(d.n_poses * d.S)), dim3(256), 0, s, d, poses);
     hipLaunchKernelGGL(balm_diag_reduce_kernel, dim3((unsigned)((32 * (int64_t)d.n_poses + 255) / 256)), dim3(256), 0, s, d, Hblk, g);
     launch_pairs(pd, Hblk, s);
     if (k1) hipEventRecord(k1, s);

@@ -34,6 +34,7 @@ struct BlockSys {
     int64_t nnzb = 0;
     int64_t *d_csc_off = nullptr, *d_blk_off = nullptr, *d_blk_slot = nullptr;
     bool pair_col = false;            // which pair kernel the item lists were cut for
+    bool y32 = false;                 // LVBA_Y32=1 on a LiDAR handle whose lists use the column kernel: fp32 Y records (experiment)
     int64_t n_items = 0, n_multi = 0; // work items of the pair pass (>= nnzb), blocks cut into several items
     int64_t *d_multi_off = nullptr, *d_multi_slot = nullptr, *d_multi_idx = nullptr;
     double *d_partial = nullptr;
@@ -76,7 +77,7 @@ struct BlockSys {
     {
         PairDev p;
         p.nnzb = n_items; p.blk_off = d_blk_off; p.blk_slot = d_blk_slot; p.pairs = d_pairs; p.Y = d_Y;
-        p.partial = d_partial; p.n_multi = n_multi; p.multi_off = d_multi_off; p.multi_slot = d_multi_slot; p.multi_idx = d_multi_idx; p.col_form = pair_col ? 1 : 0;
+        p.partial = d_partial; p.n_multi = n_multi; p.multi_off = d_multi_off; p.multi_slot = d_multi_slot; p.multi_idx = d_multi_idx; p.col_form = pair_col ? (y32 ? 2 : 1) : 0;
         return p;
     }
 };

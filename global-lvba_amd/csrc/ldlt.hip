@@ -927,10 +927,16 @@ __device__ __forceinline__ void bulk_tile_128(double *lds, LdltMat M, const Pane
         for (int k0 = 0; k0 < 32; k0 += 4) {
             const int q = (k0 >> 2) & 1;
             if (k0 + 4 < 32) rd(k0 + 4, q ^ 1);
+#ifndef LVBA_BULK_NOSCHED
+            __builtin_amdgcn_sched_barrier(0); // keep the reads AHEAD of the MFMAs (LLVM's scheduler sinks them to their first use otherwise)
+#endif
 #pragma unroll
             for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
                 for (int cq = 0; cq < 4; ++cq) acc[tl][cq] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][cq], bv[q][tl], acc[tl][cq], 0, 0, 0);
+#ifndef LVBA_BULK_NOSCHED
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
     };
     const unsigned cvoff = 8u * ((unsigned)i + (unsigned)kk * ld);                 // lane part of a C entry's offset

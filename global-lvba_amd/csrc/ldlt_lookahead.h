@@ -50,6 +50,11 @@ struct Step2Args {
     const double *Zq;
     int *status;
     BulkJob job[2];
+    // experiments (tools/solver_microbench): bulk workgroups whose blockIdx is >= stagger_from start stagger_n x ~0.43 us late
+    // (two workgroups that share a CU otherwise run their load and MFMA phases in step); dbg != nullptr: the chain workgroup of
+    // problem 0 leaves its start / end clock there
+    int stagger_from, stagger_n;
+    unsigned long long *dbg;
 };
 
 // Scratch doubles in the PAD of the first [m][row] tile (LVBA_TS = 80 doubles per column of 64 rows: 16 spare behind each of the
@@ -62,8 +67,12 @@ __device__ __forceinline__ double &pad_at(double *lds, int idx) { return lds[(id
 
 // acc[t][reg] += sum_m Zs[m][16 w + kk + 4 reg] * Ls[m][16 t + i]   (one 64 x 64 x 64 product out of LDS, 16 MFMAs per wave and
 // tile row block; the same operand pattern serves  C -= L Z^T  (Ls = L, Zs = Z)  and  L = A G  (Ls = A, Zs = G[m][j]))
+// The operands of step k0 + 4 are read before the MFMAs of step k0 are issued (a role workgroup is ALONE on its SIMDs: a
+// wavefront issues in order, and an LDS read placed behind the MFMAs that need the previous one only starts when the matrix
+// pipe is draining -- measured with the loop in its plain form: 127 cycles per MFMA instead of 64).
 __device__ __forceinline__ void tile_product(const double *Ls, const double *Zs, int w, int i, int kk, d4 (&acc)[4])
 {
+#ifdef LVBA_TP_PLAIN
 #pragma unroll 4
     for (int k0 = 0; k0 < 64; k0 += 4) {
         const double a = Zs[(k0 + kk) * LVBA_TS + 16 * w + i];
@@ -73,6 +82,26 @@ __device__ __forceinline__ void tile_product(const double *Ls, const double *Zs,
             acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc[t], 0, 0, 0);
         }
     }
+#else
+    const double *zp = Zs + kk * LVBA_TS + 16 * w + i, *lp = Ls + kk * LVBA_TS + i;
+    double a[2], bv[2][4];
+    a[0] = zp[0];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bv[0][t] = lp[16 * t];
+#pragma unroll
+    for (int st = 0; st < 16; ++st) {
+        const int q = st & 1;
+        if (st + 1 < 16) {
+            a[q ^ 1] = zp[4 * (st + 1) * LVBA_TS];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bv[q ^ 1][t] = lp[4 * (st + 1) * LVBA_TS + 16 * t];
+        }
+        __builtin_amdgcn_sched_barrier(0); // (LLVM's scheduler otherwise sinks the reads to just before their first use)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], bv[q][t], acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
 }
 // registers (thread (row, m = w + 4 it)) -> T[m][row]
 __device__ __forceinline__ void stage_tile(double *T, const double (&v)[16], int w, int row)
@@ -159,14 +188,16 @@ __device__ __forceinline__ void chain_role(double *lds, const LdltMat &M, const 
         tile_product(Ls, Zs, w, i, kk, acc);
         __syncthreads();
     }
-    // the block itself, as the products' result layout has it: cv[4 t + reg] <-> (r0 + 16 t + i, r0 + 16 w + kk + 4 reg)
+    // the block itself, as the products' result layout has it: cv[4 t + reg] <-> (r0 + 16 t + i, r0 + 16 w + kk + 4 reg).  ALL of
+    // it (a band narrower than a tile leaves rows of the block outside panel p's window; they still belong to the block)
+    const int nbn = A.nbe_next;
     double cv[16];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            const int64_t c = r0 + 16 * w + kk + 4 * reg, rr = r0 + 16 * t + i;
-            cv[4 * t + reg] = (rr < p.rend && c < p.rend && rr >= c) ? M.a[rr + c * M.ld] : 0.0;
+            const int cl = 16 * w + kk + 4 * reg, rl = 16 * t + i;
+            cv[4 * t + reg] = (rl < nbn && cl <= rl) ? M.a[(r0 + rl) + (r0 + cl) * M.ld] : 0.0;
         }
     stage_tile(Ls, a1, w, row);
     stage_tile(Zs, gp, w, row);
@@ -204,8 +235,8 @@ __device__ __forceinline__ void chain_role(double *lds, const LdltMat &M, const 
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const int64_t c = r0 + 16 * w + kk + 4 * reg, rr = r0 + 16 * t + i;
-                if (rr < p.rend && c < p.rend && rr >= c) M.a[rr + c * M.ld] = cv[4 * t + reg] - acc[t][reg];
+                const int cl = 16 * w + kk + 4 * reg, rl = 16 * t + i;
+                if (rl < nbn && cl <= rl) M.a[(r0 + rl) + (r0 + cl) * M.ld] = cv[4 * t + reg] - acc[t][reg];
             }
         return;
     }
@@ -213,7 +244,6 @@ __device__ __forceinline__ void chain_role(double *lds, const LdltMat &M, const 
     // W of the blocked factorisation, straight from the registers: lower triangle of the block, identity below its last row
     // (a short last panel), the identity appended as rows 64..127
     double *W = lds;
-    const int nbn = A.nbe_next;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -347,10 +377,17 @@ __global__ __launch_bounds__(256, 2) void ldlt_step2_kernel(const Step2Args A)
     const int64_t wo = prob ? A.sW : 0;
     if (prob) M.a += A.sA;
     if ((int64_t)blockIdx.x < nfac) {
-        if (bx == 0) chain_role(lds, M, A, A.Gp + wo, A.Gn + wo, A.dvec + wo, A.b + wo, A.Zp + wo, A.Zq ? A.Zq + wo : nullptr);
+        if (bx == 0) {
+            const bool stamp = A.dbg && prob == 0 && threadIdx.x == 0;
+            if (stamp) A.dbg[0] = __builtin_readcyclecounter();
+            chain_role(lds, M, A, A.Gp + wo, A.Gn + wo, A.dvec + wo, A.b + wo, A.Zp + wo, A.Zq ? A.Zq + wo : nullptr);
+            if (stamp) A.dbg[1] = __builtin_readcyclecounter();
+        }
         else row_role(lds, M, A, bx, A.Gp + wo, A.dvec + wo, A.b + wo, A.Zp + wo, A.Zq ? A.Zq + wo : nullptr, A.side_r + wo, A.side_w + wo);
         return;
     }
+    if (A.stagger_n > 0 && (int)blockIdx.x >= A.stagger_from)
+        for (int q = 0; q < A.stagger_n; ++q) __builtin_amdgcn_s_sleep(16);
     for (int j = 0; j < A.njobs; ++j) {
         const BulkJob &J = A.job[j];
         if (bx >= J.nwg) { bx -= J.nwg; continue; }

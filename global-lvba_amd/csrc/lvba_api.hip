@@ -313,6 +313,10 @@ static int32_t finalize(lvba_balm_s *h)
         tmark = t;
     };
     TRY(bs_build(bs, N, h->V, h->h_voff.data(), h->h_pidx.data()));
+    { // experiment (round 4): fp32 Y records between the factor and the pair pass -- the column kernel's lists only
+        const char *e = getenv("LVBA_Y32");
+        bs.y32 = bs.pair_col && e && !strcmp(e, "1");
+    }
     mark("bs_build");
     lvba::hvec<int32_t> p((size_t)h->F); // pose indices of the factors in solver order
     for (int64_t f = 0; f < h->F; ++f) p[f] = bs.iperm[h->h_pidx[f]];
@@ -352,7 +356,7 @@ extern "C" int32_t lvba_balm_info(lvba_balm_t h, lvba_balm_info_t *info)
         const char *e = getenv("LVBA_COST_RECORDS");
         info->trial_linearised = !(e && !strcmp(e, "0")) ? 1 : 0;
     }
-    info->reserved = 0;
+    info->y_fp32 = h->bs.y32 ? 1 : 0;
     info->allreduce_bytes = !h->bs.distributed() ? 0 : 8 * ((h->bs.d_ar_slot ? 36 * h->bs.n_ar : h->bs.hblk_doubles) + 6 * (int64_t)h->N + 1);
     return LVBA_OK;
 }

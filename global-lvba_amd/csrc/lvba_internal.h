@@ -42,7 +42,8 @@ struct PairDev {
     const int64_t *multi_off;  // [n_multi+1] their ranges in multi_idx
     const int64_t *multi_slot; // [n_multi] their slots in the store
     const int64_t *multi_idx;  // indices into `partial`, in summation order
-    int32_t col_form;          // 1: balm_pair_col_kernel (short items of windowed lists), 0: balm_pair_staged_kernel
+    int32_t col_form;          // 1: balm_pair_col_kernel (short items of windowed lists), 0: balm_pair_staged_kernel,
+                               // 2: balm_pair_col_kernel on fp32 Y records of 80 bytes (LVBA_Y32=1; LiDAR handles only)
 };
 
 // Device view of one packed visual problem (cameras in solver order; only landmarks with a valid plane).

@@ -93,8 +93,10 @@ typedef struct {
     int32_t twist_panels;    /* band solver: 64-column panels each END eliminates (0: plain top-down factorisation) */
     int32_t solve_ranks;     /* ranks the factorisation is spread over: 2 when ranks 0 and 1 take one end each, else 1 */
     int32_t trial_linearised; /* 1: the LM loop costs its trial point with the voxel pass of the evaluation (cost + voxel records),
-                               * and an accepted step's next evaluation starts from those records */
-    int32_t reserved;
+                               * and an accepted step's next evaluation starts from those records (LiDAR handles only: 0 in
+                               * lvba_visual_info) */
+    int32_t y_fp32;           /* 1: LVBA_Y32=1 took effect -- the per-factor Y records travel as fp32 between the factor and the
+                               * pair pass (an experiment: off-diagonal pose blocks then carry ~1e-7 relative rounding) */
 } lvba_balm_info_t;
 
 /* Accumulated device times (HIP events on the handle's stream) since the last reset, ms. */

@@ -99,6 +99,60 @@ int main(int argc, char **argv)
         t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_step2_kernel<true>, dim3((unsigned)J.nwg), dim3(256), 0, s, a); });
         printf("look-ahead: that job alone              %7.2f us\n", t * 1e3);
     }
+    // ---- the steady state of config C3's two-ended phase: TWO problems per launch (2 chain + 2 x 40 row workgroups + the first
+    // half of a pair job for both: ~410 tiles of 128 x 64), with the chain workgroup's own clock, and the stagger experiment
+    {
+        const int64_t sA = ldab * (n + 1), sW = ldlt_workspace_doubles(n, bw) / 2 - 64;
+        LdltMat A2 = A;
+        CK(hipMalloc((void **)&A2.a, (2 * hA.size() + 65 * ldab) * 8));
+        CK(hipMemcpy(A2.a, hA.data(), hA.size() * 8, hipMemcpyHostToDevice));
+        CK(hipMemcpy(A2.a + sA, hA.data(), std::min<size_t>(hA.size(), (size_t)sA) * 8, hipMemcpyHostToDevice));
+        double *w2; CK(hipMalloc((void **)&w2, (2 * sW + 4 * 4096 + 8 * ldz * 64) * 8)); CK(hipMemset(w2, 0, (2 * sW + 4 * 4096 + 8 * ldz * 64) * 8));
+        unsigned long long *dbg; CK(hipMalloc((void **)&dbg, 64)); CK(hipMemset(dbg, 0, 64));
+        auto geo = [&](int64_t st) {
+            PanelGeo g; g.k = 64 * st; g.nbe = 64; g.w0 = g.k + 64; g.rend = (g.w0 + bw < n) ? g.w0 + bw : n; g.T = (int)((g.rend - g.w0 + 63) / 64);
+            return g;
+        };
+        // problem 0's arrays inside w2: G [16 panels] | d, b | Z x 4 | side x 2 ; problem 1 at + sW (sW only has to be larger)
+        double *G0 = w2, *d0 = G0 + 16 * 4096, *b0 = d0 + n, *Z0 = b0 + n, *side0 = Z0 + 4 * ldz * 64;
+        if (side0 + 2 * 4096 > w2 + sW) { printf("workspace layout too small\n"); return 1; }
+        Step2Args a{};
+        a.M = A2; a.sA = sA; a.sW = sW; a.ldz = ldz; a.nprob = 2; a.roles = 1; a.has_q = 1; a.do_diag = 1; a.nbe_next = 64;
+        a.p = geo(10); a.q = geo(9); a.rend_next = geo(11).rend;
+        a.side_r = side0; a.side_w = side0 + 4096; a.Gp = G0 + 10 * 4096; a.Gn = G0 + 11 * 4096; a.dvec = d0; a.b = b0;
+        a.Zp = Z0; a.Zq = Z0 + ldz * 64; a.status = status; a.dbg = dbg;
+        const int T = a.p.T;
+        auto chain_us = [&]() { unsigned long long c[2]; CK(hipMemcpy(c, dbg, 16, hipMemcpyDeviceToHost)); return (double)(c[1] - c[0]); };
+        t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_step2_kernel<true>, dim3((unsigned)(2 * T)), dim3(256), 0, s, a); });
+        printf("2 problems: roles alone (%d workgroups)        %7.2f us   chain workgroup %6.0f cycles\n", 2 * T, t * 1e3, chain_us());
+        a.njobs = 1;
+        BulkJob &J = a.job[0];
+        J.o = geo(9); J.e = geo(8); J.Zo = Z0 + ldz * 64; J.Ze = Z0 + 2 * ldz * 64; J.pair = 1;
+        const int64_t Tb = J.o.T - 1;
+        int64_t tot = 0, part = 0, cs = 1;
+        for (int64_t c = 1; c < Tb; ++c) tot += pair_col_items(c, Tb);
+        while (cs < Tb && (cs < 3 || 2 * part < tot)) part += pair_col_items(cs++, Tb);
+        J.ca = 1; J.cb = cs; J.nwg = part;
+        const unsigned nall = (unsigned)(2 * (T + J.nwg));
+        t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_step2_kernel<true>, dim3(nall), dim3(256), 0, s, a); });
+        printf("2 problems: roles + first half of the pair job (%u workgroups) %7.2f us   chain workgroup %6.0f cycles\n", nall, t * 1e3, chain_us());
+        for (int from : {256, 2 * T}) // the second dispatch round only / every bulk workgroup of problem 1 ... (blockIdx >= from)
+            for (int sn : {4, 8, 12, 16, 24}) {
+                a.stagger_from = from; a.stagger_n = sn;
+                t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_step2_kernel<true>, dim3(nall), dim3(256), 0, s, a); });
+                printf("   stagger: blockIdx >= %3d start %4.1f us late: %7.2f us   chain workgroup %6.0f cycles\n", from, sn * 0.43, t * 1e3, chain_us());
+            }
+        a.stagger_n = 0;
+        a.roles = 0;
+        t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_step2_kernel<true>, dim3((unsigned)(2 * J.nwg)), dim3(256), 0, s, a); });
+        printf("2 problems: that job alone (%lld tiles)          %7.2f us  (%.1f TFLOP/s)\n", (long long)(2 * J.nwg), t * 1e3,
+               2.0 * J.nwg * 2.0 * 128 * 64 * 128 / (t * 1e-3) / 1e12);
+        for (int sn : {8, 16}) {
+            a.stagger_from = 256; a.stagger_n = sn;
+            t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_step2_kernel<true>, dim3((unsigned)(2 * J.nwg)), dim3(256), 0, s, a); });
+            printf("   job alone, blockIdx >= 256 start %4.1f us late: %7.2f us\n", sn * 0.43, t * 1e3);
+        }
+    }
     // empty-kernel launch chain for reference
     t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_prepare_kernel, dim3(1), dim3(64), 0, s, A, work, 0, 0, work, work, work, (unsigned long long *)x, 0ULL, LdltTwist{0, 0, 0, 0, nullptr}, (const int32_t *)nullptr, 0, status); });
     printf("tiny kernel back-to-back %8.2f us\n", t * 1e3);
