@@ -298,6 +298,7 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
     return __hiloint2double(hi, lo);
 }
+#ifdef LVBA_K1B_V1
 template <int J>
 __device__ __forceinline__ void k1b_step(double (&a)[16], int lane, double &rd)
 {
@@ -327,6 +328,50 @@ __device__ __forceinline__ void k1b_steps(std::integer_sequence<int, Js...>, dou
 {
     (k1b_step<Js>(a, lane, rd), ...);
 }
+#else
+// Round 4: the column's broadcasts BATCHED.  Column J's update needs A[c][J] for every later column c in every lane: lane c holds
+// it (a[J] of lane c), so it travels through a v_readlane pair into scalar registers.  The form above read it where it was used
+// -- readlane, readlane, FMA per entry, all through ONE scalar register pair, i.e. a dependent triple whose readlane -> FMA latency
+// was paid 120 times per 16-column block (~22 cycles per entry: the larger part of the ~297 cycles a pivot cost).  Here the
+// broadcasts of column J + 1 are issued as soon as its entries are final -- each lane's a[J+1] after the FIRST FMA of column J --
+// into scalar registers of their own, back to back, while the rest of column J's FMAs and the next pivot's reciprocal run.
+template <int J>
+__device__ __forceinline__ void k1b_step(double (&a)[16], int lane, double &rd, double (&uc)[16])
+{
+    const bool done = lane < 16 && lane <= J; // finished block rows: l = 0 leaves them untouched
+    const double u = a[J];
+    const double l = done ? 0.0 : u * rd;
+    a[J] = done ? u : l;
+    if constexpr (J + 1 < 16) {
+        a[J + 1] = fma(-l, uc[J + 1], a[J + 1]);
+        const double pn = readlane_f64(a[J + 1], J + 1);
+        double r = __builtin_amdgcn_rcp(pn);
+        LVBA_PIN(r);
+        double un[16];
+#pragma unroll
+        for (int c = J + 2; c < 16; ++c) un[c] = readlane_f64(a[J + 1], c); // column J + 1's broadcasts
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = J + 2; c < 16; ++c) {
+            a[c] = fma(-l, uc[c], a[c]);
+            LVBA_PIN(a[c]);
+        }
+        r = fma(r, fma(-pn, r, 1.0), r);
+        r = fma(r, fma(-pn, r, 1.0), r);
+        rd = r;
+#pragma unroll
+        for (int c = J + 2; c < 16; ++c) uc[c] = un[c];
+    }
+}
+template <int... Js>
+__device__ __forceinline__ void k1b_steps(std::integer_sequence<int, Js...>, double (&a)[16], int lane, double rd)
+{
+    double uc[16];
+#pragma unroll
+    for (int c = 1; c < 16; ++c) uc[c] = readlane_f64(a[0], c);
+    (k1b_step<Js>(a, lane, rd, uc), ...);
+}
+#endif
 
 #define LVBA_K1B_LDS (64 * LVBA_W1S + 256 + 16 * LVBA_Z1S + 64) // doubles
 // diag_blocked_load: the 64x64 block at (k, k) into W (lower triangle; identity below row nbe) with the identity appended.
@@ -1446,6 +1491,13 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
     // tile-level model of the factorisation, tests/ldlt_schedule_check.cpp)
     static const bool lookahead = [] { const char *e = getenv("LVBA_SOLVER"); return !(e && !strcmp(e, "r3")); }();
     double *side_buf[2] = {Zbuf[3] + ldz * LVBA_NB + 64, Zbuf[3] + ldz * LVBA_NB + 64 + 4096};
+    static const bool chain_alone = [] { const char *e = getenv("LVBA_CHAIN_ALONE"); return !(e && !strcmp(e, "0")); }();
+    static const int n_cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        (void)hipGetLastError();
+        return n > 0 ? n : 256;
+    }();
     auto run_phase2 = [&](int64_t sa, int64_t sb, unsigned ny, bool second, bool close) {
         static const bool big_env = [] { const char *e = getenv("LVBA_BULK"); return !(e && !strcmp(e, "64")); }();
         const bool big = big_env && ((uint64_t)A.ld * (uint64_t)(n + 128) + (uint64_t)n + 256) * 8 < 0xFFFF0000ull;
@@ -1461,6 +1513,7 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
                 continue;
             }
             Step2Args a{};
+            a.skip_a = a.skip_b = -1;
             a.M = second ? M2 : M; a.sA = tw.sA; a.sW = tw.sW; a.ldz = ldz; a.nprob = (int)ny;
             a.roles = L.roles; a.has_q = L.has_q; a.do_diag = L.do_diag; a.status = status;
             a.dvec = dvec + wo; a.b = b + wo;
@@ -1491,8 +1544,13 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
                 nwg += J.nwg;
                 ++a.njobs;
             }
+            int64_t grid = nwg * ny;
+            if (chain_alone && L.roles && grid > n_cus) { // (ldlt_lookahead.h: resv_at)
+                a.resv_at = n_cus; a.resv_n = (int)ny;
+                grid += ny;
+            }
             if (nwg > 0)
-                hipLaunchKernelGGL(big ? ldlt_step2_kernel<true> : ldlt_step2_kernel<false>, dim3((unsigned)(nwg * ny)), dim3(256), 0, s, a);
+                hipLaunchKernelGGL(big ? ldlt_step2_kernel<true> : ldlt_step2_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, a);
         }
     };
     if (overlap && lookahead) {

@@ -54,6 +54,14 @@ struct Step2Args {
     // (two workgroups that share a CU otherwise run their load and MFMA phases in step); dbg != nullptr: the chain workgroup of
     // problem 0 leaves its start / end clock there
     int stagger_from, stagger_n;
+    int skip_a, skip_b;  // experiment: these two blocks return at once (-1: none)
+    // The chain workgroups ALONE on their CUs.  The step kernel's 80 KB of LDS admit two workgroups per CU, and the dispatcher
+    // fills the CUs in block order, round after round (observed, tools/solver_microbench: block b and block b + #CUs share a CU):
+    // the blocks [resv_at, resv_at + resv_n) -- the would-be partners of the chain workgroups, blocks 0 .. resv_n - 1 -- return
+    // at once and the later blocks count from resv_n less.  Measured on the two-problem launch of config C3: the chain workgroup
+    // 79 900 -> 59 600 cycles (what it takes alone), the launch 37.9 -> 29.6 us.  Placement is a matter of speed only: wherever
+    // the blocks land, every tile is still done exactly once.  resv_n = 0: off.
+    int resv_at, resv_n;
     unsigned long long *dbg;
 };
 
@@ -166,6 +174,8 @@ __device__ __forceinline__ void chain_role(double *lds, const LdltMat &M, const 
     const PanelGeo &p = A.p, &q = A.q;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, row = tid & 63, i = lane & 15, kk = lane >> 4;
     const int64_t r0 = p.w0, r = r0 + row; // rows of tile p + 1 = columns of panel p + 1
+#define LVBA_CH_STAMP(k) do { if (A.dbg && tid == 0 && Gp == A.Gp) A.dbg[520 + (k)] = __builtin_readcyclecounter(); } while (0)
+    LVBA_CH_STAMP(0);
     __builtin_amdgcn_s_setprio(3);        // the launch is as long as this workgroup: first call on the issue slots it shares
     const bool use_q = A.has_q && r0 < q.rend; // (a band narrower than two tiles: panel q does not reach tile row p + 1)
     double va[16], vb[16], a1[16], gp[16];
@@ -185,9 +195,11 @@ __device__ __forceinline__ void chain_role(double *lds, const LdltMat &M, const 
         stage_tile(Ls, va, w, row);
         stage_tile(Zs, vb, w, row);
         __syncthreads();
+        LVBA_CH_STAMP(1); // the first loads have arrived and are staged
         tile_product(Ls, Zs, w, i, kk, acc);
         __syncthreads();
     }
+    LVBA_CH_STAMP(2);
     // the block itself, as the products' result layout has it: cv[4 t + reg] <-> (r0 + 16 t + i, r0 + 16 w + kk + 4 reg).  ALL of
     // it (a band narrower than a tile leaves rows of the block outside panel p's window; they still belong to the block)
     const int nbn = A.nbe_next;
@@ -206,9 +218,11 @@ __device__ __forceinline__ void chain_role(double *lds, const LdltMat &M, const 
         pad_at(lds, LVBA_PAD_DP + tid) = dk;
     }
     __syncthreads();
+    LVBA_CH_STAMP(3);
     fwd_partial_y(lds, Zs, w, row);
     tile_product(Ls, Zs, w, i, kk, accL); // accL[t][reg] = L[row 16 t + i][column 16 w + kk + 4 reg]
     __syncthreads();
+    LVBA_CH_STAMP(4);
     put_acc(Ls, accL, w, i, kk, nullptr); // L(p+1,p) as [m][row]
     put_acc(Zs, accL, w, i, kk, lds);     // Z = L D
     if (tid < 64) pad_at(lds, LVBA_PAD_YS + tid) = (tid < p.nbe) ? red4(lds, tid) * dk : 0.0;
@@ -227,8 +241,10 @@ __device__ __forceinline__ void chain_role(double *lds, const LdltMat &M, const 
         for (int j = 0; j < 16; ++j) sacc += Ls[(16 * w + j) * LVBA_TS + row] * pad_at(lds, LVBA_PAD_YS + 16 * w + j);
         pad_at(lds, LVBA_PAD_RED + 64 * w + row) = sacc;
     }
+    LVBA_CH_STAMP(5);
     tile_product(Ls, Zs, w, i, kk, acc);
     __syncthreads();
+    LVBA_CH_STAMP(6);
     if (tid < 64 && r < p.rend) b[r] -= red4(lds, tid);
     if (!A.do_diag) { // the phase ends here: the updated block goes back to the matrix
 #pragma unroll
@@ -256,10 +272,13 @@ __device__ __forceinline__ void chain_role(double *lds, const LdltMat &M, const 
             W[c * LVBA_W1S + 64 + rr] = (c == rr) ? 1.0 : 0.0;
         }
     __syncthreads();
+    LVBA_CH_STAMP(7);
     diag_blocked_factor(lds, nbn, A.status);
+    LVBA_CH_STAMP(8);
     const double *dvs = lds + 64 * LVBA_W1S + 256 + 16 * LVBA_Z1S;
     if (tid < nbn) dvec[p.w0 + tid] = dvs[tid];
     for (int e = tid; e < 4096; e += 256) Gn[e] = W[(e & 63) * LVBA_W1S + 64 + (e >> 6)];
+    LVBA_CH_STAMP(9);
 }
 
 // ---------------------------------------------------------------------------------------------- the row role
@@ -369,14 +388,23 @@ __global__ __launch_bounds__(256, 2) void ldlt_step2_kernel(const Step2Args A)
     LdltMat M = A.M;
     int prob;
     int64_t bx;
-    if ((int64_t)blockIdx.x < nfac) { prob = (int)(blockIdx.x % A.nprob); bx = blockIdx.x / A.nprob; }
+    int64_t bid = blockIdx.x;
+    if (A.resv_n > 0 && bid >= A.resv_at) {
+        if (bid < A.resv_at + A.resv_n) return; // the seat next to a chain workgroup stays empty
+        bid -= A.resv_n;
+    }
+    if (bid < nfac) { prob = (int)(bid % A.nprob); bx = bid / A.nprob; }
     else {
-        const int64_t bb = blockIdx.x - nfac;
+        const int64_t bb = bid - nfac;
         prob = (int)(bb % A.nprob); bx = bb / A.nprob;
     }
     const int64_t wo = prob ? A.sW : 0;
     if (prob) M.a += A.sA;
-    if ((int64_t)blockIdx.x < nfac) {
+    if (A.dbg && threadIdx.x == 0) // where did the dispatcher put this workgroup?  (tools/solver_microbench: who shares a CU with the chain)
+        A.dbg[8 + blockIdx.x] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 /*XCC_ID*/) | (0 << 6) | (31 << 11)) << 32) |
+                                (unsigned)__builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (31 << 11));
+    if (A.skip_a >= 0 && ((int)blockIdx.x == A.skip_a || (int)blockIdx.x == A.skip_b)) return; // (experiment: leave the chain's CU alone)
+    if (bid < nfac) {
         if (bx == 0) {
             const bool stamp = A.dbg && prob == 0 && threadIdx.x == 0;
             if (stamp) A.dbg[0] = __builtin_readcyclecounter();

@@ -67,6 +67,7 @@ int main(int argc, char **argv)
         double *side; CK(hipMalloc((void **)&side, 4 * 4096 * 8)); CK(hipMemset(side, 0, 4 * 4096 * 8));
         double *Z2; CK(hipMalloc((void **)&Z2, 4 * ldz * 64 * 8)); CK(hipMemset(Z2, 0, 4 * ldz * 64 * 8));
         Step2Args a{};
+        a.skip_a = a.skip_b = -1;
         a.M = A; a.sA = 0; a.sW = 0; a.ldz = ldz; a.nprob = 1; a.roles = 1; a.has_q = 1; a.do_diag = 1; a.nbe_next = 64;
         a.p = geo(10); a.q = geo(9); a.rend_next = geo(11).rend;
         a.side_r = side; a.side_w = side + 4096; a.Gp = Gall + 10 * 4096; a.Gn = Gall + 11 * 4096; a.dvec = dvec; a.b = b;
@@ -108,7 +109,7 @@ int main(int argc, char **argv)
         CK(hipMemcpy(A2.a, hA.data(), hA.size() * 8, hipMemcpyHostToDevice));
         CK(hipMemcpy(A2.a + sA, hA.data(), std::min<size_t>(hA.size(), (size_t)sA) * 8, hipMemcpyHostToDevice));
         double *w2; CK(hipMalloc((void **)&w2, (2 * sW + 4 * 4096 + 8 * ldz * 64) * 8)); CK(hipMemset(w2, 0, (2 * sW + 4 * 4096 + 8 * ldz * 64) * 8));
-        unsigned long long *dbg; CK(hipMalloc((void **)&dbg, 64)); CK(hipMemset(dbg, 0, 64));
+        unsigned long long *dbg; CK(hipMalloc((void **)&dbg, 8 * 2048)); CK(hipMemset(dbg, 0, 8 * 2048));
         auto geo = [&](int64_t st) {
             PanelGeo g; g.k = 64 * st; g.nbe = 64; g.w0 = g.k + 64; g.rend = (g.w0 + bw < n) ? g.w0 + bw : n; g.T = (int)((g.rend - g.w0 + 63) / 64);
             return g;
@@ -117,6 +118,7 @@ int main(int argc, char **argv)
         double *G0 = w2, *d0 = G0 + 16 * 4096, *b0 = d0 + n, *Z0 = b0 + n, *side0 = Z0 + 4 * ldz * 64;
         if (side0 + 2 * 4096 > w2 + sW) { printf("workspace layout too small\n"); return 1; }
         Step2Args a{};
+        a.skip_a = a.skip_b = -1;
         a.M = A2; a.sA = sA; a.sW = sW; a.ldz = ldz; a.nprob = 2; a.roles = 1; a.has_q = 1; a.do_diag = 1; a.nbe_next = 64;
         a.p = geo(10); a.q = geo(9); a.rend_next = geo(11).rend;
         a.side_r = side0; a.side_w = side0 + 4096; a.Gp = G0 + 10 * 4096; a.Gn = G0 + 11 * 4096; a.dvec = d0; a.b = b0;
@@ -125,6 +127,14 @@ int main(int argc, char **argv)
         auto chain_us = [&]() { unsigned long long c[2]; CK(hipMemcpy(c, dbg, 16, hipMemcpyDeviceToHost)); return (double)(c[1] - c[0]); };
         t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_step2_kernel<true>, dim3((unsigned)(2 * T)), dim3(256), 0, s, a); });
         printf("2 problems: roles alone (%d workgroups)        %7.2f us   chain workgroup %6.0f cycles\n", 2 * T, t * 1e3, chain_us());
+        {
+            unsigned long long c[10]; CK(hipMemcpy(c, dbg + 520, sizeof c, hipMemcpyDeviceToHost));
+            const char *nm[9] = {"first loads + stage", "product q", "stage A, G (+ block load issue)", "product L", "put L, Z + stores", "product p",
+                                 "b, W build", "diagonal factorisation", "G store"};
+            printf("   chain role phases (cycles):");
+            for (int k = 0; k < 9; ++k) printf(" %s %llu |", nm[k], c[k + 1] - c[k]);
+            printf(" total %llu\n", c[9] - c[0]);
+        }
         a.njobs = 1;
         BulkJob &J = a.job[0];
         J.o = geo(9); J.e = geo(8); J.Zo = Z0 + ldz * 64; J.Ze = Z0 + 2 * ldz * 64; J.pair = 1;
@@ -136,8 +146,29 @@ int main(int argc, char **argv)
         const unsigned nall = (unsigned)(2 * (T + J.nwg));
         t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_step2_kernel<true>, dim3(nall), dim3(256), 0, s, a); });
         printf("2 problems: roles + first half of the pair job (%u workgroups) %7.2f us   chain workgroup %6.0f cycles\n", nall, t * 1e3, chain_us());
-        for (int from : {256, 2 * T}) // the second dispatch round only / every bulk workgroup of problem 1 ... (blockIdx >= from)
-            for (int sn : {4, 8, 12, 16, 24}) {
+        { // who shares a CU with the two chain workgroups (blocks 0 and 1)?  HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]; XCC_ID [3:0]
+            std::vector<unsigned long long> h(8 + nall);
+            CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+            auto cu_of = [&](unsigned b) { const unsigned long long v = h[8 + b]; return (unsigned)(((v >> 32) & 15) << 16 | (v & 0xFF00)); };
+            for (unsigned c = 0; c < 2; ++c) {
+                printf("   chain block %u on xcc %llu hw_id 0x%llx; same CU:", c, (h[8 + c] >> 32) & 15, h[8 + c] & 0xFFFF);
+                for (unsigned b = 0; b < nall; ++b) if (b != c && cu_of(b) == cu_of(c)) printf(" %u", b);
+                printf("\n");
+            }
+            std::vector<unsigned> seen;
+            for (unsigned b = 0; b < nall; ++b) { bool f = false; for (unsigned q : seen) f = f || q == cu_of(b); if (!f) seen.push_back(cu_of(b)); }
+            printf("   distinct CUs used by the %u workgroups: %zu; blocks 0..15 on xcc:", nall, seen.size());
+            for (unsigned b = 0; b < 16; ++b) printf(" %llu", (h[8 + b] >> 32) & 15);
+            printf("\n");
+            for (int pr : {256, 258, 264}) {
+                a.skip_a = pr; a.skip_b = pr + 1;
+                t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_step2_kernel<true>, dim3(nall), dim3(256), 0, s, a); });
+                printf("   blocks %d, %d return at once: %7.2f us   chain workgroup %6.0f cycles\n", pr, pr + 1, t * 1e3, chain_us());
+            }
+            a.skip_a = a.skip_b = -1;
+        }
+        for (int from : {256}) // the second dispatch round only / every bulk workgroup of problem 1 ... (blockIdx >= from)
+            for (int sn : {8, 24}) {
                 a.stagger_from = from; a.stagger_n = sn;
                 t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_step2_kernel<true>, dim3(nall), dim3(256), 0, s, a); });
                 printf("   stagger: blockIdx >= %3d start %4.1f us late: %7.2f us   chain workgroup %6.0f cycles\n", from, sn * 0.43, t * 1e3, chain_us());
