@@ -229,6 +229,26 @@ def main():
         prob.lm_end(want_poses=False)
         state["active"] = False
 
+    # ---- N > 1: what DOES scale over the GPUs of a node -- independent windows (the reference's window stage solves them one
+    # after the other, src/lvba_system.cpp:232): every rank runs lvba_window_ba on a sequence of its own, no data exchanged;
+    # reported beside the headline (whose single refinement is bound by the serial chain of its factorisation)
+    windows_multi = None
+    if world > 1 and not args.no_front_end:
+        try:
+            nw_local, dt_local = window_stage_weak(pkg, synth, rank)
+        except Exception as e:
+            nw_local, dt_local = 0, float("inf")
+            print(f"rank {rank}: window stage failed: {e!r}", file=sys.stderr)
+        tt = torch.tensor([dt_local, float(nw_local)], dtype=torch.float64)
+        tmax, tsum = tt.clone(), tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        windows_multi = {"workload": "every rank: 64 scans x 250 000 points, windows of 16 (its own sequence: weak scaling)",
+                         "windows": int(tsum[1]), "seconds_max_over_ranks": float(tmax[0]),
+                         "windows_per_s": float(tsum[1]) / float(tmax[0]) if float(tmax[0]) > 0 else None, "scaling": "weak",
+                         "note": "independent problems, no collective: lvba_window_ba per rank (one process per GPU); a single "
+                                 "process drives several GPUs through lvba_window_ba_multi"}
+
     parity_ok = True
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
@@ -318,7 +338,10 @@ def main():
                                         "(the timed region runs with it off)", "ms_per_step": 1e3 * elapsed_profiled / args.steps,
                                 "evals": state["evals"], "accepted": state["accepts"]},
             "roofline": roof, "roofline_other_kernels": others,
+            "scaling_model": scaling_model(p, sv_ms, info, world),
         }
+        if windows_multi is not None:
+            out["window_stage_all_ranks"] = windows_multi
         if world == 1 and not args.no_y32:
             try:
                 out["y32_mode"] = y32_leg(pkg, d, N, prob, local_rank, args.steps, args.warmup)
@@ -371,6 +394,48 @@ def relaunch_under_torchrun(n):
     os.execve(sys.executable, cmd, env)
 
 
+def scaling_model(p, sv_ms, info, world):
+    """What strong scaling of ONE refinement can give, from this run's own stage times: the evaluation and the cost pass shard by
+    voxel range (/ N), the pose blocks are all-reduced (bytes / an assumed 100 GB/s RCCL bus bandwidth over xGMI for N > 1), and the
+    damped solve is a serial chain of panel factorisations that two ranks split at best (the two ends of the band) -- with both
+    ends already sharing every launch on one GPU, the second rank buys almost nothing.  A projection, not a measurement."""
+    ev = p["eval_ms"] / max(1, p["eval_calls"])
+    ck = p["cost_ms"] / max(1, p["cost_calls"])
+    ar_mb = 8e-6 * (36 * (info.get("n_blocks", 0) + info["n_poses"]) + 6 * info["n_poses"] + 1)
+    proj = {}
+    for n in (1, 2, 4, 8):
+        ar = 0.0 if n == 1 else 2.0 * (n - 1) / n * ar_mb / 100.0   # ms at 100 GB/s bus bandwidth (MB / (GB/s) = ms)
+        t = (ev + ck) / n + ar + sv_ms
+        proj[str(n)] = {"ms_per_iteration": t, "speedup": (ev + ck + sv_ms) / t}
+    return {"kind": "strong scaling of one refinement: chain-bound", "stage_ms_1gpu": {"eval": ev, "cost": ck, "solve": sv_ms},
+            "allreduce_mb_per_evaluation": ar_mb, "assumed_bus_gb_s": 100.0, "projected": proj,
+            "note": "the solve (a chain of ~115 panel factorisations) does not shard; throughput across GPUs comes from independent "
+                    "work -- windows (window_stage_all_ranks, lvba_window_ba_multi), sequences -- not from one refinement",
+            "measured_ranks": world}
+
+
+def window_stage_weak(pkg, synth, rank):
+    """one rank's share of the weak-scaling window leg: (windows, seconds) of lvba_window_ba on its own 64-scan sequence"""
+    base = synth.make_scans(8, 250_000, room=(60, 40, 8), n_panels=16, n_blobs=40, origin=(120.0 + 7.0 * rank, -80.0, 2.0),
+                            rot_sigma_deg=0.1, trans_sigma=0.03, point_floats=12, seed=100 + rank)
+    clouds, poses = [], []
+    for r in range(8):
+        for c, T in zip(base["clouds"], base["poses"]):
+            T = T.copy(); T[9] += 100.0 * r
+            clouds.append(c); poses.append(T)
+    poses = np.asarray(poses)
+    import torch
+    scans = pkg.Scans(clouds, device=torch.cuda.current_device())
+    scans.window_ba(poses, window_size=16, voxel_size=0.5, anchor_leaf=0.05)["anchor_scans"].close()    # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    w = scans.window_ba(poses, window_size=16, voxel_size=0.5, anchor_leaf=0.05)
+    dt = time.perf_counter() - t0
+    w["anchor_scans"].close()
+    scans.close()
+    return len(w["windows"]), dt
+
+
 def y32_leg(pkg, d, N, prob_ref, local_rank, steps, warmup):
     """The same K timed steps with LVBA_Y32=1: the per-factor Y records travel as fp32 (80 instead of 144 bytes) between the
     factor pass and the pair pass -- off-diagonal Hessian blocks then carry ~6e-7 relative rounding, the cost and the gradient
@@ -382,12 +447,12 @@ def y32_leg(pkg, d, N, prob_ref, local_rank, steps, warmup):
     os.environ["LVBA_Y32"] = "1"
     try:
         prob = pkg.BalmProblem(N, d["voxel_off"], d["pose_idx"], d["clusters"], device=local_rank)
+        info = prob.info()       # (the switch is read when the handle is finalised: at its first use, i.e. here)
     finally:
         if old is None:
             os.environ.pop("LVBA_Y32", None)
         else:
             os.environ["LVBA_Y32"] = old
-    info = prob.info()
     x, tr, rc = prob.refine(x0)
     prob.refine(x0)   # (solve graph captured)
     active = [False]

@@ -271,6 +271,13 @@ __device__ unsigned long long g_k1b_clk[16];
 #else
 #define LVBA_K1B_STAMP(i)
 #endif
+#ifdef LVBA_K1_TIMING
+__device__ unsigned long long g_bulk_clk[16];
+__device__ int g_bulk_stamp_block = -1;
+#define LVBA_BULK_STAMP(i) do { if (threadIdx.x == 0 && (int)blockIdx.x == g_bulk_stamp_block) g_bulk_clk[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define LVBA_BULK_STAMP(i)
+#endif
 #define LVBA_PIN(x) asm volatile("" : "+v"(x)) // keep the value computed HERE (LLVM otherwise sinks it to its first use)
 
 // ------------------------------------------------------------------------------------------ K1, blocked
@@ -298,7 +305,7 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
     return __hiloint2double(hi, lo);
 }
-#ifdef LVBA_K1B_V1
+#ifndef LVBA_K1B_V2
 template <int J>
 __device__ __forceinline__ void k1b_step(double (&a)[16], int lane, double &rd)
 {
@@ -329,7 +336,9 @@ __device__ __forceinline__ void k1b_steps(std::integer_sequence<int, Js...>, dou
     (k1b_step<Js>(a, lane, rd), ...);
 }
 #else
-// Round 4: the column's broadcasts BATCHED.  Column J's update needs A[c][J] for every later column c in every lane: lane c holds
+// Round 4 experiment (LVBA_K1B_V2; measured: no gain, 4696 vs 4672 cycles per 16-column block, and ~70 more scalar registers --
+// the pivot chain is bound by the ISSUE of its ~34 instructions per column at ~8.5 cycles each, not by the readlane -> FMA latency):
+// the column's broadcasts BATCHED.  Column J's update needs A[c][J] for every later column c in every lane: lane c holds
 // it (a[J] of lane c), so it travels through a v_readlane pair into scalar registers.  The form above read it where it was used
 // -- readlane, readlane, FMA per entry, all through ONE scalar register pair, i.e. a dependent triple whose readlane -> FMA latency
 // was paid 120 times per 16-column block (~22 cycles per entry: the larger part of the ~297 cycles a pivot cost).  Here the
@@ -884,11 +893,18 @@ __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, double v, unsig
     const v2u a = {(unsigned)__double2loint(v), (unsigned)__double2hiint(v)};
     __builtin_amdgcn_raw_buffer_store_b64(a, r, voff, soff, 0);
 }
-template <int nch> // K chunks of 32: 2 = one panel, 4 = a pair (pe, then po)
+// DB (round 4, the look-ahead launch): TWO chunk buffers in LDS.  Stamps inside the single-buffer form (tools/solver_microbench,
+// a tile alone on its CU): 41 k cycles for 16 k of MFMA issue -- 12 k in the four "stage" steps (registers -> LDS between two
+// barriers, with the matrix pipe idle), 5.5 k waiting for C and storing it, 3.8 k before the first product.  With two buffers a
+// chunk is staged into the OTHER buffer in front of the products of the one before it and there is one barrier per chunk:
+//     stage(ch + 1) -> fetch(ch + 3) -> products(ch) -> barrier
+// 114 KB of LDS: one workgroup per CU -- which also leaves the chain workgroup of the look-ahead launch alone on its CU.
+#define LVBA_K3DB_LDS (2 * LVBA_K3B_LDS) // doubles
+template <int nch, bool DB = false> // K chunks of 32: 2 = one panel, 4 = a pair (pe, then po)
 __device__ __forceinline__ void bulk_tile_128(double *lds, LdltMat M, const PanelRef po, const PanelRef pe, int64_t ldz64, int64_t R0,
                                               int64_t tj)
 {
-    double *Ls = lds, *Zs = lds + 32 * LVBA_TL; // Ls[m][row 0..127], Zs[m][row 0..63], m = column of the chunk
+    // a chunk buffer: Ls[m][row 0..127] at its start, Zs[m][row 0..63] behind it (+ 32 * LVBA_TL), m = column of the chunk
     const int tid = threadIdx.x, lane = tid & 63;
     const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, kk = lane >> 4;
@@ -924,6 +940,7 @@ __device__ __forceinline__ void bulk_tile_128(double *lds, LdltMat M, const Pane
         }
     };
     auto stage = [&](int ch, double *xs) { // registers -> LDS, masking rows / columns outside the panel's window
+        double *Ls = lds + (DB ? (ch & 1) * LVBA_K3B_LDS : 0), *Zs = Ls + 32 * LVBA_TL;
         const bool use_e = nch == 4 && ch < 2;
         const int64_t qrend = use_e ? pe.rend : po.rend;
         const int qnbe = use_e ? pe.nbe : po.nbe;
@@ -957,9 +974,10 @@ __device__ __forceinline__ void bulk_tile_128(double *lds, LdltMat M, const Pane
 #pragma unroll
         for (int cq = 0; cq < 4; ++cq) acc[tl][cq] = (d4){0.0, 0.0, 0.0, 0.0};
     const bool busy = two || w < 2;
-    auto products = [&]() { // the chunk in LDS.  The operands of step k0 + 4 are read before the MFMAs of step k0 are issued: a
-                            // wavefront issues in order, and reads placed after them only start when the matrix pipe is draining
+    auto products = [&](int ch) { // the chunk in LDS.  The operands of step k0 + 4 are read before the MFMAs of step k0 are issued: a
+                                  // wavefront issues in order, and reads placed after them only start when the matrix pipe is draining
         if (!busy) return;
+        const double *Ls = lds + (DB ? (ch & 1) * LVBA_K3B_LDS : 0), *Zs = Ls + 32 * LVBA_TL;
         double a[2][4], bv[2][2];
         auto rd = [&](int k0, int q) {
 #pragma unroll
@@ -989,31 +1007,58 @@ __device__ __forceinline__ void bulk_tile_128(double *lds, LdltMat M, const Pane
     // Chunk c is staged from its register set (even chunks: A, odd: B) and the set is refilled at once with chunk c + 2, which
     // then has the products of two chunks to arrive in.  After the last even chunk, set A takes the C entries instead.
     // (fully unrolled: inside a loop the compiler's wait counts at the back edge drain every load in flight)
+    auto load_c = [&]() { // Unmasked: entries outside the window or above the diagonal are read (inside the allocation, see
+                          // block_system.hip) but never stored
+#pragma unroll
+        for (int cq = 0; cq < 4; ++cq)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const unsigned so = csoff + 8u * (unsigned)(16 * cq + 4 * reg) * ld;
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl) xa[16 * tl + 4 * cq + reg] = buf_ld(rA, cvoff + 128u * tl, so);
+            }
+    };
+    LVBA_BULK_STAMP(0);
     fetch(0, xa);
     fetch(1, xb);
+    if constexpr (DB) {
+        stage(0, xa);
+        if (nch > 2) fetch(2, xa);
+        else if (busy) load_c();
+        __syncthreads();
+        LVBA_BULK_STAMP(1);
+#pragma unroll
+        for (int ch = 0; ch < nch; ++ch) {
+            double *xs = ((ch + 1) & 1) ? xb : xa; // the register set of chunk ch + 1
+            if (ch + 1 < nch) {
+                stage(ch + 1, xs);                 // into the other buffer: everybody left it at the last barrier
+                if (ch + 3 < nch) fetch(ch + 3, xs);
+                else if (ch + 3 == nch && nch > 2 && busy) load_c(); // chunk nch - 2 has just left set A: C takes its place
+            }
+            products(ch);
+            LVBA_BULK_STAMP(2 + ch);
+            if (ch + 1 < nch) __syncthreads();
+        }
+        LVBA_BULK_STAMP(8);
+    } else {
 #pragma unroll
     for (int ch = 0; ch < nch; ch += 2) {
         if (ch > 0) __syncthreads(); // everybody is done with chunk ch - 1 in LDS
         stage(ch, xa);
         __syncthreads();
+        LVBA_BULK_STAMP(1 + 2 * ch);
         if (ch + 2 < nch) fetch(ch + 2, xa);
-        else if (busy) { // Unmasked: entries outside the window or above the diagonal are read (inside the allocation, see
-                         // block_system.hip) but never stored
-#pragma unroll
-            for (int cq = 0; cq < 4; ++cq)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const unsigned so = csoff + 8u * (unsigned)(16 * cq + 4 * reg) * ld;
-#pragma unroll
-                    for (int tl = 0; tl < 2; ++tl) xa[16 * tl + 4 * cq + reg] = buf_ld(rA, cvoff + 128u * tl, so);
-                }
-        }
-        products();
+        else if (busy) load_c();
+        products(ch);
+        LVBA_BULK_STAMP(2 + 2 * ch);
         __syncthreads();
         stage(ch + 1, xb);
         __syncthreads();
         if (ch + 3 < nch) fetch(ch + 3, xb);
-        products();
+        LVBA_BULK_STAMP(3 + 2 * ch);
+        products(ch + 1);
+        LVBA_BULK_STAMP(4 + 2 * ch);
+    }
     }
     if (busy) {
         const bool inner = r0 + 128 <= po.rend && r0 > c0; // whole tile inside the window and below the diagonal
@@ -1031,6 +1076,7 @@ __device__ __forceinline__ void bulk_tile_128(double *lds, LdltMat M, const Pane
                 }
             }
     }
+    LVBA_BULK_STAMP(10);
 }
 
 // One launch for two independent pieces of work: the factorisation of panel p+1 (diag + panel tiles) and the bulk of the
@@ -1491,6 +1537,7 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
     // tile-level model of the factorisation, tests/ldlt_schedule_check.cpp)
     static const bool lookahead = [] { const char *e = getenv("LVBA_SOLVER"); return !(e && !strcmp(e, "r3")); }();
     double *side_buf[2] = {Zbuf[3] + ldz * LVBA_NB + 64, Zbuf[3] + ldz * LVBA_NB + 64 + 4096};
+    static const bool bulk_db = [] { const char *e = getenv("LVBA_BULK_DB"); return !(e && !strcmp(e, "0")); }();
     static const bool chain_alone = [] { const char *e = getenv("LVBA_CHAIN_ALONE"); return !(e && !strcmp(e, "0")); }();
     static const int n_cus = [] {
         int dev = 0, n = 0;
@@ -1545,12 +1592,16 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
                 ++a.njobs;
             }
             int64_t grid = nwg * ny;
-            if (chain_alone && L.roles && grid > n_cus) { // (ldlt_lookahead.h: resv_at)
+            const bool db = big && bulk_db; // one workgroup per CU: nobody sits next to the chain workgroup anyway
+            if (chain_alone && !db && L.roles && grid > n_cus) { // (ldlt_lookahead.h: resv_at)
                 a.resv_at = n_cus; a.resv_n = (int)ny;
                 grid += ny;
             }
-            if (nwg > 0)
-                hipLaunchKernelGGL(big ? ldlt_step2_kernel<true> : ldlt_step2_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, a);
+            if (nwg > 0) {
+                if (db) hipLaunchKernelGGL((ldlt_step2_kernel<true, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
+                else if (big) hipLaunchKernelGGL((ldlt_step2_kernel<true, false>), dim3((unsigned)grid), dim3(256), 0, s, a);
+                else hipLaunchKernelGGL((ldlt_step2_kernel<false, false>), dim3((unsigned)grid), dim3(256), 0, s, a);
+            }
         }
     };
     if (overlap && lookahead) {

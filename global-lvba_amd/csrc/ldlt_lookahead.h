@@ -34,6 +34,7 @@ struct BulkJob {
     PanelGeo o, e;
     const double *Zo, *Ze;
     int pair;
+    int dbg_same; // experiment (tools/solver_microbench): every workgroup takes the job's FIRST tile -- operands from L2, no fabric traffic
     int64_t ca, cb, nwg;
 };
 struct Step2Args {
@@ -200,17 +201,7 @@ __device__ __forceinline__ void chain_role(double *lds, const LdltMat &M, const 
         __syncthreads();
     }
     LVBA_CH_STAMP(2);
-    // the block itself, as the products' result layout has it: cv[4 t + reg] <-> (r0 + 16 t + i, r0 + 16 w + kk + 4 reg).  ALL of
-    // it (a band narrower than a tile leaves rows of the block outside panel p's window; they still belong to the block)
     const int nbn = A.nbe_next;
-    double cv[16];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int cl = 16 * w + kk + 4 * reg, rl = 16 * t + i;
-            cv[4 * t + reg] = (rl < nbn && cl <= rl) ? M.a[(r0 + rl) + (r0 + cl) * M.ld] : 0.0;
-        }
     stage_tile(Ls, a1, w, row);
     stage_tile(Zs, gp, w, row);
     if (tid < 64) {
@@ -223,18 +214,35 @@ __device__ __forceinline__ void chain_role(double *lds, const LdltMat &M, const 
     tile_product(Ls, Zs, w, i, kk, accL); // accL[t][reg] = L[row 16 t + i][column 16 w + kk + 4 reg]
     __syncthreads();
     LVBA_CH_STAMP(4);
+    // the block itself, as the products' result layout has it: cv[4 t + reg] <-> (r0 + 16 t + i, r0 + 16 w + kk + 4 reg).  ALL of
+    // it (a band narrower than a tile leaves rows of the block outside panel p's window; they still belong to the block).
+    // Requested here: it is needed after the last product, whose 2 us cover the way from L2 / HBM.
+    double cv[16];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int cl = 16 * w + kk + 4 * reg, rl = 16 * t + i;
+            cv[4 * t + reg] = (rl < nbn && cl <= rl) ? M.a[(r0 + rl) + (r0 + cl) * M.ld] : 0.0;
+        }
     put_acc(Ls, accL, w, i, kk, nullptr); // L(p+1,p) as [m][row]
     put_acc(Zs, accL, w, i, kk, lds);     // Z = L D
     if (tid < 64) pad_at(lds, LVBA_PAD_YS + tid) = (tid < p.nbe) ? red4(lds, tid) * dk : 0.0;
-    __syncthreads();
+    // L and Z leave for global memory straight from the product's registers (16 lanes = 128 contiguous bytes of a column)
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        const int j = w + 4 * it;
-        if (r < p.rend && j < p.nbe) {
-            M.a[r + (p.k + j) * M.ld] = Ls[j * LVBA_TS + row];
-            Zp[(r - p.w0) + j * A.ldz] = Zs[j * LVBA_TS + row];
+    for (int reg = 0; reg < 4; ++reg) {
+        const int c = 16 * w + kk + 4 * reg;
+        const double dc = pad_at(lds, LVBA_PAD_DP + c);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int64_t rr = r0 + 16 * t + i;
+            if (rr < p.rend && c < p.nbe) {
+                M.a[rr + (p.k + c) * M.ld] = accL[t][reg];
+                Zp[(rr - p.w0) + c * A.ldz] = accL[t][reg] * dc;
+            }
         }
     }
+    __syncthreads();
     { // b[r] -= L[row] . y_p, four lanes per row
         double sacc = 0.0;
 #pragma unroll
@@ -345,16 +353,20 @@ __device__ __forceinline__ void row_role(double *lds, const LdltMat &M, const St
     __syncthreads();
     put_acc(Ls, accI, w, i, kk, nullptr); // L(i, p) as [m][row]
     put_acc(Zs, acc0, w, i, kk, lds);     // Z(p+1, p) = L(p+1, p) D
-    __syncthreads();
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        const int j = w + 4 * it;
-        if (r < p.rend && j < p.nbe) {
-            const double v = Ls[j * LVBA_TS + row];
-            M.a[r + (p.k + j) * M.ld] = v;
-            Zp[(r - p.w0) + j * A.ldz] = v * pad_at(lds, LVBA_PAD_DP + j);
+    for (int reg = 0; reg < 4; ++reg) {   // L(i, p) and Z(i, p) to global memory, from the product's registers
+        const int c = 16 * w + kk + 4 * reg;
+        const double dc = pad_at(lds, LVBA_PAD_DP + c);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int64_t rr = r0 + 16 * t + i;
+            if (rr < p.rend && c < p.nbe) {
+                M.a[rr + (p.k + c) * M.ld] = accI[t][reg];
+                Zp[(rr - p.w0) + c * A.ldz] = accI[t][reg] * dc;
+            }
         }
     }
+    __syncthreads();
     {
         double sacc = 0.0;
 #pragma unroll
@@ -379,11 +391,13 @@ __device__ __forceinline__ void row_role(double *lds, const LdltMat &M, const St
 // ---------------------------------------------------------------------------------------------- one launch
 // Block order: the chain workgroups of all problems first, then the row workgroups, then the bulk jobs' workgroups alternating
 // between the problems.  big: 128 x 64 bulk tiles (bulk_tile_128, 32-bit buffer offsets) / 64 x 64 tiles (update_tile[2]).
-template <bool big>
-__global__ __launch_bounds__(256, 2) void ldlt_step2_kernel(const Step2Args A)
+// DB: bulk tiles with two chunk buffers in LDS (bulk_tile_128<.., true>: 114 KB, one workgroup per CU) / one buffer (80 KB, two per CU)
+template <bool big, bool DB>
+__global__ __launch_bounds__(256, DB ? 1 : 2) void ldlt_step2_kernel(const Step2Args A)
 {
-    __shared__ double lds[LVBA_K3_LDS];
+    __shared__ double lds[DB ? (LVBA_K3DB_LDS > LVBA_K3_LDS ? LVBA_K3DB_LDS : LVBA_K3_LDS) : LVBA_K3_LDS];
     static_assert(LVBA_K1B_LDS <= LVBA_K3_LDS && LVBA_K3B_LDS <= LVBA_K3_LDS && LVBA_PAD_RED + 256 <= 1024, "LDS budget of the roles");
+    static_assert(!DB || big, "two chunk buffers exist for the 128 x 64 tiles only");
     const int64_t nrole = A.roles ? A.p.T : 0, nfac = nrole * A.nprob;
     LdltMat M = A.M;
     int prob;
@@ -422,10 +436,10 @@ __global__ __launch_bounds__(256, 2) void ldlt_step2_kernel(const Step2Args A)
         const double *Zo = J.Zo + wo, *Ze = J.pair ? J.Ze + wo : nullptr;
         if constexpr (big) {
             int64_t R0, tj;
-            if (!pair_decode(bx, J.ca, J.cb, (int64_t)J.o.T - 1, R0, tj)) return;
+            if (!pair_decode(J.dbg_same ? 0 : bx, J.ca, J.cb, (int64_t)J.o.T - 1, R0, tj)) return;
             const PanelRef po{J.o.k, J.o.w0, J.o.rend, J.o.nbe, Zo}, pe{J.e.k, J.e.w0, J.e.rend, J.e.nbe, Ze};
-            if (J.pair) bulk_tile_128<4>(lds, M, po, pe, A.ldz, R0, tj);
-            else bulk_tile_128<2>(lds, M, po, pe, A.ldz, R0, tj);
+            if (J.pair) bulk_tile_128<4, DB>(lds, M, po, pe, A.ldz, R0, tj);
+            else bulk_tile_128<2, DB>(lds, M, po, pe, A.ldz, R0, tj);
         } else {
             int64_t ti, tj;
             col_decode(J.ca + bx, (int64_t)J.o.T - 1, ti, tj);

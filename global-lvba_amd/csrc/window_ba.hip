@@ -515,6 +515,119 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The window stage over SEVERAL GPUs of one node.  The windows are independent problems (the reference solves them one after
+// the other, src/lvba_system.cpp:232-302), so this is where the GPUs of a node all have work: device k takes a contiguous run
+// of whole windows (lvba_window_split), a host thread per device runs lvba_window_ba on that device's scan set, the results are
+// put together in window order and the anchor clouds are gathered on the first device (one device-to-device copy per share).
+// A single LM refinement, by contrast, is bound by the serial chain of its band factorisation.
+extern "C" int32_t lvba_window_split(int32_t n_frames, int32_t window_size, int32_t n_shares, int32_t *frame_begin)
+{
+    if (n_frames < 0 || window_size < 1 || n_shares < 1 || !frame_begin) return lvba_fail(LVBA_ERR_ARG, "bad argument");
+    const int64_t n_win = ((int64_t)n_frames + window_size - 1) / window_size;
+    for (int k = 0; k <= n_shares; ++k) { // the thread split of bavoxel.hpp:621-624, on windows
+        const int64_t wb = n_win * k / n_shares;
+        frame_begin[k] = (int32_t)std::min<int64_t>(n_frames, wb * window_size);
+    }
+    return LVBA_OK;
+}
+
+extern "C" int32_t lvba_window_ba_multi(int32_t n_shares, const lvba_scans_t *scans, const double *poses, const lvba_window_opts *opts,
+                                        double *window_poses, double *rel_poses, int32_t *anchor_index, double *anchor_poses,
+                                        int32_t *n_anchors, lvba_scans_t *anchor_scans, lvba_window_info *win_info)
+{
+    if (anchor_scans) *anchor_scans = nullptr;
+    if (n_shares < 1 || !scans || !poses || !rel_poses || !anchor_index || !anchor_poses || !n_anchors || !anchor_scans)
+        return lvba_fail(LVBA_ERR_ARG, "null argument");
+    lvba_window_opts o;
+    lvba_window_default_opts(&o);
+    if (opts) o = *opts;
+    if (o.window_size < 1) return lvba_fail(LVBA_ERR_ARG, "window_size must be >= 1");
+    std::vector<int64_t> fb((size_t)n_shares + 1, 0), wb((size_t)n_shares + 1, 0);
+    for (int k = 0; k < n_shares; ++k) {
+        if (!scans[k]) return lvba_fail(LVBA_ERR_ARG, "share %d: null scan set", k);
+        if (k + 1 < n_shares && scans[k]->n_frames % o.window_size)
+            return lvba_fail(LVBA_ERR_ARG, "share %d holds %d frames: every share but the last must hold whole windows of %d (lvba_window_split)",
+                             k, scans[k]->n_frames, o.window_size);
+        fb[(size_t)k + 1] = fb[(size_t)k] + scans[k]->n_frames;
+        wb[(size_t)k + 1] = wb[(size_t)k] + (scans[k]->n_frames + o.window_size - 1) / o.window_size;
+    }
+    struct Share { int32_t rc = LVBA_OK, na = 0; std::string err; lvba_scans_t anchors = nullptr; std::vector<double> ap; };
+    std::vector<Share> sh((size_t)n_shares);
+    auto run = [&](int k) {
+        Share &S = sh[(size_t)k];
+        const int64_t nf = scans[k]->n_frames, nw = wb[(size_t)k + 1] - wb[(size_t)k];
+        S.ap.assign(12 * (size_t)std::max<int64_t>(nw, 1), 0.0);
+        S.rc = lvba_window_ba(scans[k], poses + 12 * fb[(size_t)k], &o, window_poses ? window_poses + 12 * fb[(size_t)k] : nullptr,
+                              rel_poses + 12 * fb[(size_t)k], anchor_index + fb[(size_t)k], S.ap.data(), &S.na, &S.anchors,
+                              win_info ? win_info + wb[(size_t)k] : nullptr);
+        if (S.rc < 0) S.err = lvba_last_error();
+        (void)nf;
+    };
+    {
+        std::vector<std::thread> th;
+        for (int k = 1; k < n_shares; ++k) th.emplace_back(run, k);
+        run(0);
+        for (auto &t : th) t.join();
+    }
+    auto drop = [&]() { for (auto &S : sh) if (S.anchors) { lvba_scans_destroy(S.anchors); S.anchors = nullptr; } };
+    for (int k = 0; k < n_shares; ++k)
+        if (sh[(size_t)k].rc < 0) {
+            const int32_t rc = sh[(size_t)k].rc;
+            const std::string msg = sh[(size_t)k].err;
+            drop();
+            return lvba_fail(rc, "share %d: %s", k, msg.c_str());
+        }
+    // window order: anchors of share k come after those of the shares before it
+    int32_t base = 0;
+    for (int k = 0; k < n_shares; ++k) {
+        const Share &S = sh[(size_t)k];
+        for (int64_t f = fb[(size_t)k]; f < fb[(size_t)k + 1]; ++f)
+            if (anchor_index[f] >= 0) anchor_index[f] += base;
+        if (win_info)
+            for (int64_t w = wb[(size_t)k]; w < wb[(size_t)k + 1]; ++w) {
+                win_info[w].start += (int32_t)fb[(size_t)k];
+                if (win_info[w].anchor >= 0) win_info[w].anchor += base;
+            }
+        memcpy(anchor_poses + 12 * (size_t)base, S.ap.data(), 96 * (size_t)S.na);
+        base += S.na;
+    }
+    // the anchor clouds as ONE scan set on the first share's device
+    lvba_scans_s *out = new (std::nothrow) lvba_scans_s();
+    if (!out) { drop(); return lvba_fail(LVBA_ERR_NOMEM, "host allocation failed"); }
+    out->device = scans[0]->device;
+    out->n_frames = base;
+    out->frame_off.assign((size_t)base + 1, 0);
+    {
+        size_t a = 0;
+        for (int k = 0; k < n_shares; ++k)
+            for (int f = 0; f < sh[(size_t)k].na; ++f, ++a)
+                out->frame_off[a + 1] = out->frame_off[a] + (sh[(size_t)k].anchors->frame_off[(size_t)f + 1] - sh[(size_t)k].anchors->frame_off[(size_t)f]);
+    }
+    hipError_t e = hipSetDevice(out->device);
+    const int64_t PT = out->frame_off.back();
+    if (e == hipSuccess) e = hipMalloc((void **)&out->d_pts, PT ? 12 * (size_t)PT : 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&out->d_frame_off, 8 * ((size_t)base + 1));
+    {
+        size_t a = 0;
+        for (int k = 0; k < n_shares && e == hipSuccess; ++k) {
+            const lvba_scans_s *A = sh[(size_t)k].anchors;
+            const int64_t np = A->frame_off[(size_t)sh[(size_t)k].na];
+            if (np > 0) e = hipMemcpy(out->d_pts + 3 * out->frame_off[a], A->d_pts, 12 * (size_t)np, hipMemcpyDefault); // (across devices: UVA)
+            a += (size_t)sh[(size_t)k].na;
+        }
+    }
+    if (e == hipSuccess) e = lvba::copy_h2d(out->d_frame_off, out->frame_off.data(), 8 * ((size_t)base + 1));
+    drop();
+    if (e != hipSuccess) {
+        lvba_scans_destroy(out);
+        return lvba_fail(e == hipErrorOutOfMemory ? LVBA_ERR_NOMEM : LVBA_ERR_DEVICE, "anchor scan set: %s", hipGetErrorString(e));
+    }
+    *n_anchors = base;
+    *anchor_scans = out;
+    return LVBA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // LvbaSystem::runLidarBA (src/lvba_system.cpp:312-410) without the ROS/visualisation calls: window BA -> anchors, then the
 // global stages (stage 1 optional, stage 2) each re-cutting the anchor clouds at the current anchor poses with that stage's
 // voxel size / eigen ratios and running damping_iter over all anchors, then every frame's pose = anchor o rel (:393-404).

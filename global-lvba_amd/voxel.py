@@ -133,6 +133,45 @@ class Scans:
         return dict(anchor_poses=aposes[:na.value].copy(), anchor_scans=Scans._from_handle(h), anchor_index=aidx,
                     rel_poses=rel, window_poses=window_poses, windows=[info[i].as_dict() for i in range(nw)])
 
+    @staticmethod
+    def window_ba_multi(clouds, poses, devices, window_size=10, voxel_size=0.5, eigen_ratio_array=None, anchor_leaf=0.1, use_rel=True,
+                        min_points=None, lm_mode=0, **lm):
+        """The window stage over several GPUs (lvba_window_ba_multi): `clouds` (host arrays, one per frame) are dealt out to
+        `devices` in contiguous runs of whole windows (lvba_window_split) -- a device id may repeat: several shares on one GPU --,
+        every share runs on its own host thread, results come back in window order as from `window_ba`; the anchor scans live on
+        devices[0]."""
+        lib = L.load()
+        n, D = len(clouds), len(devices)
+        poses = np.ascontiguousarray(poses, np.float64).reshape(-1)
+        if poses.size != 12 * n:
+            raise ValueError(f"poses must hold {n} x 12 doubles")
+        fb = np.zeros(D + 1, np.int32)
+        L.check(lib.lvba_window_split(n, int(window_size), D, fb))
+        shares = [Scans(clouds[fb[k]:fb[k + 1]], device=int(devices[k])) for k in range(D) if fb[k + 1] > fb[k]]
+        o = L.WindowOpts()
+        lib.lvba_window_default_opts(C.byref(o))
+        o.window_size, o.use_rel, o.anchor_leaf = int(window_size), 1 if use_rel else 0, float(anchor_leaf)
+        o.voxel = _opts(voxel_size, eigen_ratio_array, min_points)
+        o.lm_mode = int(lm_mode)
+        for k, v in lm.items():
+            setattr(o.lm, k, v)
+        nw = (n + o.window_size - 1) // o.window_size
+        window_poses, rel = np.zeros((n, 12)), np.zeros((n, 12))
+        aidx = np.zeros(n, np.int32)
+        aposes = np.zeros((max(nw, 1), 12))
+        na, h = C.c_int32(), C.c_void_p()
+        info = (L.WindowInfo * max(nw, 1))()
+        hs = (C.c_void_p * len(shares))(*[sc._h for sc in shares])
+        try:
+            L.check(lib.lvba_window_ba_multi(len(shares), hs, poses, C.byref(o), window_poses.ctypes.data, rel.reshape(-1), aidx,
+                                             aposes.reshape(-1), C.byref(na), C.byref(h), info))
+        finally:
+            for sc in shares:
+                sc.close()
+        return dict(anchor_poses=aposes[:na.value].copy(), anchor_scans=Scans._from_handle(h), anchor_index=aidx,
+                    rel_poses=rel, window_poses=window_poses, windows=[info[i].as_dict() for i in range(nw)],
+                    frame_begin=fb.copy())
+
     def lidar_ba(self, poses, window_enable=True, window_size=10, anchor_leaf=0.1, use_rel=True, stage1_enable=True,
                  stage_voxel_size=(0.5, 0.5), stage_eigen_ratio=((0.3, 0.1, 0.06, 0.03), (0.08, 0.08, 0.08, 0.08)),
                  window_eigen_ratio=None):

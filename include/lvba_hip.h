@@ -451,6 +451,16 @@ void lvba_window_default_opts(lvba_window_opts *opts);
 int32_t lvba_window_ba(lvba_scans_t scans, const double *poses, const lvba_window_opts *opts, double *window_poses,
                        double *rel_poses, int32_t *anchor_index, double *anchor_poses, int32_t *n_anchors,
                        lvba_scans_t *anchor_scans, lvba_window_info *win_info);
+/* The window stage over several GPUs of one node (or several shares on one GPU): the windows are independent problems
+ * (src/lvba_system.cpp:232 solves them one after the other), so share k -- scans[k], on whatever device it was created on --
+ * holds a contiguous run of whole windows of the sequence (every share but the last a multiple of window_size frames;
+ * lvba_window_split gives the frame ranges: frame_begin [n_shares + 1], the thread split of bavoxel.hpp:621-624 applied to
+ * windows).  One host thread per share runs lvba_window_ba on it; outputs are those of lvba_window_ba for the concatenated
+ * sequence, in window order (poses [n][12] covers all frames); the anchor scan set lives on scans[0]'s device. */
+int32_t lvba_window_split(int32_t n_frames, int32_t window_size, int32_t n_shares, int32_t *frame_begin);
+int32_t lvba_window_ba_multi(int32_t n_shares, const lvba_scans_t *scans, const double *poses, const lvba_window_opts *opts,
+                             double *window_poses, double *rel_poses, int32_t *anchor_index, double *anchor_poses, int32_t *n_anchors,
+                             lvba_scans_t *anchor_scans, lvba_window_info *win_info);
 /* ---- the whole LiDAR stage -------------------------------------------------------------------------------------------
  *   lvba_lidar_ba <- LvbaSystem::runLidarBA  src/lvba_system.cpp:312-410 (compute only): window BA (or, with
  *   window_enable = 0, every frame its own anchor, :221-229), then for stage 1 (optional) and stage 2 the voxel map of the

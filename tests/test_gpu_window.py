@@ -184,3 +184,46 @@ def test_merge_only_matches_the_anchor_merge_of_the_visual_stage(pkg, synth):
             _compare_clouds(asc.download(a), ac[a])
     finally:
         asc.close()
+
+
+@pytest.mark.parametrize("devices", [(0, 0), (0, 0, 0)])
+def test_window_stage_over_several_shares_equals_one_device(pkg, synth, devices):
+    """lvba_window_ba_multi: the windows of a sequence dealt out to several GPUs in contiguous runs of whole windows
+    (lvba_window_split = the thread split of bavoxel.hpp:621-624 on windows), one host thread per share, anchors gathered on the
+    first device.  On the one GPU of the test box the shares all sit on device 0 (as the multi-rank tests do): everything above
+    the device id -- the split, the concurrent host threads with their own handles and streams, the re-numbering of anchors with a
+    skipped window in a middle share, the gathered anchor scan set -- is the code a multi-GPU node runs.  With lm_mode 1 every
+    window is its own problem, so the result must be BITWISE the single-share one; with the lock-step grouped LM (default) the
+    groups a window shares a factorisation with change, and the results agree to rounding."""
+    s = synth.make_scans(26, 6000, room=(10, 8, 4), origin=(2.0, -1.0, 0.4), n_panels=8, seed=47, rot_sigma_deg=0.1,
+                         trans_sigma=0.03)
+    clouds = [c.copy() for c in s["clouds"]]
+    for f in range(12, 16):
+        clouds[f] = clouds[f][:40]                                          # window 3 (frames 12..15) is skipped
+    for mode in (1, 0):
+        with pkg.Scans(clouds) as scans:
+            one = scans.window_ba(s["poses"], window_size=4, voxel_size=1.0, anchor_leaf=0.05, lm_mode=mode)
+        p1 = [one["anchor_scans"].download(a) for a in range(len(one["anchor_poses"]))]
+        one["anchor_scans"].close()
+        got = pkg.Scans.window_ba_multi(clouds, s["poses"], devices, window_size=4, voxel_size=1.0, anchor_leaf=0.05, lm_mode=mode)
+        pm = [got["anchor_scans"].download(a) for a in range(len(got["anchor_poses"]))]
+        got["anchor_scans"].close()
+        nw = 7                                                              # 26 frames: six windows of 4 and one of 2
+        fb = got["frame_begin"]
+        assert fb[0] == 0 and fb[-1] == 26 and all(b % 4 == 0 for b in fb[:-1]) and len(set(fb)) == len(devices) + 1
+        assert [w["skipped"] for w in got["windows"]] == [w["skipped"] for w in one["windows"]] == [0, 0, 0, 1, 0, 0, 0]
+        assert [w["start"] for w in got["windows"]] == [4 * k for k in range(nw)]
+        assert [w["anchor"] for w in got["windows"]] == [w["anchor"] for w in one["windows"]] == [0, 1, 2, -1, 3, 4, 5]
+        np.testing.assert_array_equal(got["anchor_index"], one["anchor_index"])
+        np.testing.assert_array_equal(got["anchor_poses"], one["anchor_poses"])
+        assert len(pm) == len(p1) == 6
+        if mode == 1:
+            for k in ("window_poses", "rel_poses"):
+                np.testing.assert_array_equal(got[k], one[k])
+            for p, q in zip(pm, p1):
+                np.testing.assert_array_equal(p, q)
+        else:
+            assert np.abs(got["window_poses"] - one["window_poses"]).max() <= 1e-9
+            assert np.abs(got["rel_poses"] - one["rel_poses"]).max() <= 1e-9
+            for p, q in zip(pm, p1):
+                assert abs(len(p) - len(q)) <= 0.002 * len(q)

@@ -1,6 +1,9 @@
 // tools/solver_microbench.hip -- standalone timing of the LDL^T kernels (development tool, not product).
 // Includes ldlt.hip directly.  usage: solver_microbench [n=12000] [bw=2813]
 #define LVBA_K1_TIMING
+#ifndef LVBA_MB_DB
+#define LVBA_MB_DB true
+#endif
 #include "../global-lvba_amd/csrc/ldlt.hip"
 #include <cstdio>
 #include <cstdlib>
@@ -74,16 +77,16 @@ int main(int argc, char **argv)
         a.Zp = Z2; a.Zq = Z2 + ldz * 64; a.status = status;
         const int Tfull = a.p.T;
         a.p.T = 1; // the chain workgroup alone
-        t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_step2_kernel<true>, dim3(1), dim3(256), 0, s, a); });
+        t = time_ms(s, 200, [&] { hipLaunchKernelGGL((ldlt_step2_kernel<true, LVBA_MB_DB>), dim3(1), dim3(256), 0, s, a); });
         printf("look-ahead: chain role alone            %7.2f us\n", t * 1e3);
         a.has_q = 0;
-        t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_step2_kernel<true>, dim3(1), dim3(256), 0, s, a); });
+        t = time_ms(s, 200, [&] { hipLaunchKernelGGL((ldlt_step2_kernel<true, LVBA_MB_DB>), dim3(1), dim3(256), 0, s, a); });
         printf("look-ahead: chain role, no predecessor  %7.2f us\n", t * 1e3);
         a.has_q = 1; a.do_diag = 0;
-        t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_step2_kernel<true>, dim3(1), dim3(256), 0, s, a); });
+        t = time_ms(s, 200, [&] { hipLaunchKernelGGL((ldlt_step2_kernel<true, LVBA_MB_DB>), dim3(1), dim3(256), 0, s, a); });
         printf("look-ahead: chain role without the diagonal factorisation %7.2f us\n", t * 1e3);
         a.do_diag = 1; a.p.T = Tfull;
-        t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_step2_kernel<true>, dim3((unsigned)Tfull), dim3(256), 0, s, a); });
+        t = time_ms(s, 200, [&] { hipLaunchKernelGGL((ldlt_step2_kernel<true, LVBA_MB_DB>), dim3((unsigned)Tfull), dim3(256), 0, s, a); });
         printf("look-ahead: chain + %d row roles         %7.2f us\n", Tfull - 1, t * 1e3);
         // + the pair job of the steady state: panels (8, 9) as a rank-128 update, first half of the tile columns
         a.njobs = 1;
@@ -94,10 +97,10 @@ int main(int argc, char **argv)
         for (int64_t c = 1; c < Tb; ++c) tot += pair_col_items(c, Tb);
         while (cs < Tb && (cs < 3 || 2 * part < tot)) part += pair_col_items(cs++, Tb);
         J.ca = 1; J.cb = cs; J.nwg = part;
-        t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_step2_kernel<true>, dim3((unsigned)(Tfull + J.nwg)), dim3(256), 0, s, a); });
+        t = time_ms(s, 200, [&] { hipLaunchKernelGGL((ldlt_step2_kernel<true, LVBA_MB_DB>), dim3((unsigned)(Tfull + J.nwg)), dim3(256), 0, s, a); });
         printf("look-ahead: roles + first half of a pair job (%lld tiles of 128 x 64) %7.2f us\n", (long long)J.nwg, t * 1e3);
         a.roles = 0;
-        t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_step2_kernel<true>, dim3((unsigned)J.nwg), dim3(256), 0, s, a); });
+        t = time_ms(s, 200, [&] { hipLaunchKernelGGL((ldlt_step2_kernel<true, LVBA_MB_DB>), dim3((unsigned)J.nwg), dim3(256), 0, s, a); });
         printf("look-ahead: that job alone              %7.2f us\n", t * 1e3);
     }
     // ---- the steady state of config C3's two-ended phase: TWO problems per launch (2 chain + 2 x 40 row workgroups + the first
@@ -125,7 +128,7 @@ int main(int argc, char **argv)
         a.Zp = Z0; a.Zq = Z0 + ldz * 64; a.status = status; a.dbg = dbg;
         const int T = a.p.T;
         auto chain_us = [&]() { unsigned long long c[2]; CK(hipMemcpy(c, dbg, 16, hipMemcpyDeviceToHost)); return (double)(c[1] - c[0]); };
-        t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_step2_kernel<true>, dim3((unsigned)(2 * T)), dim3(256), 0, s, a); });
+        t = time_ms(s, 200, [&] { hipLaunchKernelGGL((ldlt_step2_kernel<true, LVBA_MB_DB>), dim3((unsigned)(2 * T)), dim3(256), 0, s, a); });
         printf("2 problems: roles alone (%d workgroups)        %7.2f us   chain workgroup %6.0f cycles\n", 2 * T, t * 1e3, chain_us());
         {
             unsigned long long c[10]; CK(hipMemcpy(c, dbg + 520, sizeof c, hipMemcpyDeviceToHost));
@@ -144,7 +147,7 @@ int main(int argc, char **argv)
         while (cs < Tb && (cs < 3 || 2 * part < tot)) part += pair_col_items(cs++, Tb);
         J.ca = 1; J.cb = cs; J.nwg = part;
         const unsigned nall = (unsigned)(2 * (T + J.nwg));
-        t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_step2_kernel<true>, dim3(nall), dim3(256), 0, s, a); });
+        t = time_ms(s, 200, [&] { hipLaunchKernelGGL((ldlt_step2_kernel<true, LVBA_MB_DB>), dim3(nall), dim3(256), 0, s, a); });
         printf("2 problems: roles + first half of the pair job (%u workgroups) %7.2f us   chain workgroup %6.0f cycles\n", nall, t * 1e3, chain_us());
         { // who shares a CU with the two chain workgroups (blocks 0 and 1)?  HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]; XCC_ID [3:0]
             std::vector<unsigned long long> h(8 + nall);
@@ -162,7 +165,7 @@ int main(int argc, char **argv)
             printf("\n");
             for (int pr : {256, 258, 264}) {
                 a.skip_a = pr; a.skip_b = pr + 1;
-                t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_step2_kernel<true>, dim3(nall), dim3(256), 0, s, a); });
+                t = time_ms(s, 200, [&] { hipLaunchKernelGGL((ldlt_step2_kernel<true, LVBA_MB_DB>), dim3(nall), dim3(256), 0, s, a); });
                 printf("   blocks %d, %d return at once: %7.2f us   chain workgroup %6.0f cycles\n", pr, pr + 1, t * 1e3, chain_us());
             }
             a.skip_a = a.skip_b = -1;
@@ -170,18 +173,36 @@ int main(int argc, char **argv)
         for (int from : {256}) // the second dispatch round only / every bulk workgroup of problem 1 ... (blockIdx >= from)
             for (int sn : {8, 24}) {
                 a.stagger_from = from; a.stagger_n = sn;
-                t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_step2_kernel<true>, dim3(nall), dim3(256), 0, s, a); });
+                t = time_ms(s, 200, [&] { hipLaunchKernelGGL((ldlt_step2_kernel<true, LVBA_MB_DB>), dim3(nall), dim3(256), 0, s, a); });
                 printf("   stagger: blockIdx >= %3d start %4.1f us late: %7.2f us   chain workgroup %6.0f cycles\n", from, sn * 0.43, t * 1e3, chain_us());
             }
         a.stagger_n = 0;
         a.roles = 0;
-        t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_step2_kernel<true>, dim3((unsigned)(2 * J.nwg)), dim3(256), 0, s, a); });
+        t = time_ms(s, 200, [&] { hipLaunchKernelGGL((ldlt_step2_kernel<true, LVBA_MB_DB>), dim3((unsigned)(2 * J.nwg)), dim3(256), 0, s, a); });
         printf("2 problems: that job alone (%lld tiles)          %7.2f us  (%.1f TFLOP/s)\n", (long long)(2 * J.nwg), t * 1e3,
                2.0 * J.nwg * 2.0 * 128 * 64 * 128 / (t * 1e-3) / 1e12);
-        for (int sn : {8, 16}) {
-            a.stagger_from = 256; a.stagger_n = sn;
-            t = time_ms(s, 200, [&] { hipLaunchKernelGGL(ldlt_step2_kernel<true>, dim3((unsigned)(2 * J.nwg)), dim3(256), 0, s, a); });
-            printf("   job alone, blockIdx >= 256 start %4.1f us late: %7.2f us\n", sn * 0.43, t * 1e3);
+        {   // where does a bulk tile's time go?  stamps of one workgroup (block 7: first round; block 300: second round, sharing its CU)
+            const char *nm[10] = {"first loads + stage", "products 0", "stage 1", "products 1", "stage 2 (+ C loads issued)", "products 2", "stage 3",
+                                  "products 3", "", "C wait + stores"};
+            for (int blk : {7, 300}) {
+                CK(hipMemcpyToSymbol(HIP_SYMBOL(g_bulk_stamp_block), &blk, sizeof blk));
+                hipLaunchKernelGGL((ldlt_step2_kernel<true, LVBA_MB_DB>), dim3((unsigned)(2 * J.nwg)), dim3(256), 0, s, a);
+                CK(hipStreamSynchronize(s));
+                unsigned long long c[16]; CK(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_bulk_clk), sizeof c));
+                printf("   bulk tile of block %3d (cycles from its start; two buffers: 1 prologue, 2..5 after products 0..3, 8 loop end, 10 end):", blk);
+                for (int k = 1; k <= 10; ++k) printf(" [%d] %lld", k, (long long)(c[k] - c[0]));
+                printf("\n");
+                (void)nm;
+            }
+            int off = -1; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_bulk_stamp_block), &off, sizeof off));
+        }
+        J.dbg_same = 1;
+        t = time_ms(s, 200, [&] { hipLaunchKernelGGL((ldlt_step2_kernel<true, LVBA_MB_DB>), dim3((unsigned)(2 * J.nwg)), dim3(256), 0, s, a); });
+        printf("2 problems: that job with every workgroup on the SAME tile (operands and C from L2): %7.2f us\n", t * 1e3);
+        J.dbg_same = 0;
+        for (unsigned nb : {128u, 256u, 384u, 512u}) { // fewer tiles: how does the launch scale?
+            t = time_ms(s, 200, [&] { hipLaunchKernelGGL((ldlt_step2_kernel<true, LVBA_MB_DB>), dim3(nb), dim3(256), 0, s, a); });
+            printf("   first %3u workgroups of the job only: %7.2f us\n", nb, t * 1e3);
         }
     }
     // empty-kernel launch chain for reference
