@@ -1079,6 +1079,161 @@ __device__ __forceinline__ void bulk_tile_128(double *lds, LdltMat M, const Pane
     LVBA_BULK_STAMP(10);
 }
 
+// ------------------------------------------------------------------------------------ K3, 128 x 64 tiles, K in chunks of 16
+// Round 4.  Stamps inside bulk_tile_128 (tools/solver_microbench; a tile alone on its CU): 41 k cycles for 16 k of MFMA issue --
+// 12 k of it in the four "stage" steps (registers -> LDS between two barriers with the matrix pipe idle), 5.5 k waiting for C and
+// storing it, 3.8 k before the first product; and the two workgroups of a CU run those phases in step (408 tiles on 2 x 256 seats:
+// 30 us against 21 us for one round).  Two chunk buffers of K = 32 take the stage steps off the path (33 k cycles per tile) but
+// need 114 KB of LDS, one workgroup per CU, and lose more than they gain (36 us).  This form keeps two workgroups per CU: chunks
+// of SIXTEEN columns, two chunk buffers (57 KB), a ring of three register sets -- per chunk
+//     stage(ch + 1) into the other buffer -> fetch(ch + 4) into the set just emptied -> products(ch) -> ONE barrier
+// so that a chunk has three products' time to arrive and the LDS writes sit in front of 32 MFMAs instead of between barriers.
+#define LVBA_KC 16
+#define LVBA_K16_BUF (LVBA_KC * LVBA_TL + LVBA_KC * LVBA_TS) // doubles per chunk buffer
+#define LVBA_K16_LDS (2 * LVBA_K16_BUF)
+template <int npan> // 1: panel o alone (K = 64); 2: panel e, then its partner o (K = 128)
+__device__ __forceinline__ void bulk_tile_k16(double *lds, LdltMat M, const PanelRef po, const PanelRef pe, int64_t ldz64, int64_t R0,
+                                              int64_t tj)
+{
+    constexpr int nch = 4 * npan;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, kk = lane >> 4;
+    const int64_t r0 = po.w0 + 64 * (R0 + 1), c0 = po.w0 + 64 * (tj + 1);
+    const bool two = r0 + 64 < po.rend; // the second tile row exists (else wavefronts 2, 3 have nothing to multiply)
+    const unsigned ld = (unsigned)M.ld, ldz = (unsigned)ldz64; // byte offsets in 32 bits (see bulk_tile_128)
+    const __amdgpu_buffer_rsrc_t rA = buf_of(M.a), rZo = buf_of(po.Z), rZe = buf_of(npan == 2 ? pe.Z : po.Z);
+    // L chunk = 128 rows x 16 columns: lane -> rows 2 lane, 2 lane + 1 of column w + 4 it (it < 4)
+    // Z chunk =  64 rows x 16 columns: lane -> rows 2 (lane & 31), + 1 of column 2 (w + 4 it) + (lane >> 5) (it < 2)
+    double xs[3][12]; // three register sets: L [0..7], Z [8..11]
+    double cv[32];
+    const int lrow = 2 * lane, zrow = 2 * (lane & 31), zc = lane >> 5;
+    const unsigned lvoff = 8u * (unsigned)lrow, zvoff = 8u * ((unsigned)zrow + (unsigned)zc * ldz);
+    auto fetch = [&](int ch, double *x) {
+        const bool use_e = npan == 2 && ch < 4;
+        const unsigned qk = (unsigned)(use_e ? pe.k : po.k), zr = (unsigned)(c0 - (use_e ? pe.w0 : po.w0));
+        const unsigned m0 = 16u * (unsigned)(ch & 3);
+        const unsigned lsoff = 8u * ((unsigned)r0 + (qk + m0 + w) * ld), zsoff = 8u * (zr + (m0 + 2u * w) * ldz);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const double2 v = buf_ld2(rA, lvoff, lsoff + (unsigned)it * (32u * ld));
+            x[2 * it] = v.x; x[2 * it + 1] = v.y;
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const double2 v = buf_ld2(use_e ? rZe : rZo, zvoff, zsoff + (unsigned)it * (64u * ldz));
+            x[8 + 2 * it] = v.x; x[9 + 2 * it] = v.y;
+        }
+    };
+    auto stage = [&](int ch, double *x) { // registers -> chunk buffer ch & 1, masking rows / columns outside the panel's window
+        double *Ls = lds + (ch & 1) * LVBA_K16_BUF, *Zs = Ls + LVBA_KC * LVBA_TL;
+        const bool use_e = npan == 2 && ch < 4;
+        const int64_t qrend = use_e ? pe.rend : po.rend;
+        const int qnbe = use_e ? pe.nbe : po.nbe;
+        const int m0 = 16 * (ch & 3);
+        if (!(r0 + 128 <= qrend && c0 + 64 <= qrend && qnbe == 64)) { // edge tiles only (wave-uniform)
+            const bool l0 = r0 + lrow < qrend, l1 = r0 + lrow + 1 < qrend;
+            const bool z0 = c0 + zrow < qrend, z1 = c0 + zrow + 1 < qrend;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const bool mok = m0 + (int)w + 4 * it < qnbe;
+                x[2 * it] = (l0 && mok) ? x[2 * it] : 0.0;
+                x[2 * it + 1] = (l1 && mok) ? x[2 * it + 1] : 0.0;
+            }
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const bool mok = m0 + 2 * ((int)w + 4 * it) + zc < qnbe;
+                x[8 + 2 * it] = (z0 && mok) ? x[8 + 2 * it] : 0.0;
+                x[9 + 2 * it] = (z1 && mok) ? x[9 + 2 * it] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) *reinterpret_cast<double2 *>(Ls + (w + 4 * it) * LVBA_TL + lrow) = make_double2(x[2 * it], x[2 * it + 1]);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) *reinterpret_cast<double2 *>(Zs + (2 * (w + 4 * it) + zc) * LVBA_TS + zrow) = make_double2(x[8 + 2 * it], x[9 + 2 * it]);
+    };
+    // wavefront w: rows 32 w .. 32 w + 31 (two 16-row blocks tl) x 64 columns (four 16-column blocks cq);
+    // acc[tl][cq][reg] <-> row r0 + 32 w + 16 tl + i, column c0 + 16 cq + kk + 4 reg
+    d4 acc[2][4];
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+        for (int cq = 0; cq < 4; ++cq) acc[tl][cq] = (d4){0.0, 0.0, 0.0, 0.0};
+    const bool busy = two || w < 2;
+    auto products = [&](int ch) {
+        if (!busy) return;
+        const double *Ls = lds + (ch & 1) * LVBA_K16_BUF, *Zs = Ls + LVBA_KC * LVBA_TL;
+        double a[2][4], bv[2][2];
+        auto rd = [&](int k0, int q) {
+#pragma unroll
+            for (int cq = 0; cq < 4; ++cq) a[q][cq] = Zs[(k0 + kk) * LVBA_TS + 16 * cq + i];
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl) bv[q][tl] = Ls[(k0 + kk) * LVBA_TL + 32 * w + 16 * tl + i];
+        };
+        rd(0, 0);
+#pragma unroll
+        for (int k0 = 0; k0 < LVBA_KC; k0 += 4) {
+            const int q = (k0 >> 2) & 1;
+            if (k0 + 4 < LVBA_KC) rd(k0 + 4, q ^ 1);
+            __builtin_amdgcn_sched_barrier(0); // the reads stay AHEAD of the MFMAs
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+                for (int cq = 0; cq < 4; ++cq) acc[tl][cq] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][cq], bv[q][tl], acc[tl][cq], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    const unsigned cvoff = 8u * ((unsigned)i + (unsigned)kk * ld);                 // lane part of a C entry's offset
+    const unsigned csoff = 8u * ((unsigned)r0 + 32u * w + (unsigned)c0 * ld);      // + 128 tl, + 8 (16 cq + 4 reg) ld
+    LVBA_BULK_STAMP(0);
+    fetch(0, xs[0]);
+    fetch(1, xs[1]);
+    fetch(2, xs[2]);
+    stage(0, xs[0]);
+    if (3 < nch) fetch(3, xs[0]);
+    __syncthreads();
+    LVBA_BULK_STAMP(1);
+#pragma unroll
+    for (int ch = 0; ch < nch; ++ch) {
+        if (ch + 1 < nch) {
+            stage(ch + 1, xs[(ch + 1) % 3]); // into the other buffer: everybody left it at the last barrier
+            if (ch + 4 < nch) fetch(ch + 4, xs[(ch + 1) % 3]);
+        }
+        if (ch == (nch > 3 ? nch - 3 : 0) && busy) { // the C entries: three chunks' products ahead of their use.  Unmasked: entries
+                                                     // outside the window or above the diagonal are read (inside the allocation,
+                                                     // block_system.hip) but never stored
+#pragma unroll
+            for (int cq = 0; cq < 4; ++cq)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const unsigned so = csoff + 8u * (unsigned)(16 * cq + 4 * reg) * ld;
+#pragma unroll
+                    for (int tl = 0; tl < 2; ++tl) cv[16 * tl + 4 * cq + reg] = buf_ld(rA, cvoff + 128u * tl, so);
+                }
+        }
+        products(ch);
+        if (ch + 1 < nch) __syncthreads();
+    }
+    LVBA_BULK_STAMP(8);
+    if (busy) {
+        const bool inner = r0 + 128 <= po.rend && r0 > c0; // whole tile inside the window and below the diagonal
+#pragma unroll
+        for (int cq = 0; cq < 4; ++cq)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const unsigned so = csoff + 8u * (unsigned)(16 * cq + 4 * reg) * ld;
+                const int64_t c = c0 + 16 * cq + kk + 4 * reg;
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl) {
+                    const int64_t r = r0 + 32 * w + 16 * tl + i;
+                    if (inner || (r < po.rend && c < po.rend && r >= c))
+                        buf_st(rA, cv[16 * tl + 4 * cq + reg] - acc[tl][cq][reg], cvoff + 128u * tl, so);
+                }
+            }
+    }
+    LVBA_BULK_STAMP(10);
+}
+
 // One launch for two independent pieces of work: the factorisation of panel p+1 (diag + panel tiles) and the bulk of the
 // trailing update of panel p (tiles ti >= tj >= 1).  The former touches block column p+1 only, the latter block columns >= p+2,
 // and neither waits for the other inside the launch -- the only ordering is between launches: update(first column of p) -> this
@@ -1537,7 +1692,11 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
     // tile-level model of the factorisation, tests/ldlt_schedule_check.cpp)
     static const bool lookahead = [] { const char *e = getenv("LVBA_SOLVER"); return !(e && !strcmp(e, "r3")); }();
     double *side_buf[2] = {Zbuf[3] + ldz * LVBA_NB + 64, Zbuf[3] + ldz * LVBA_NB + 64 + 4096};
-    static const bool bulk_db = [] { const char *e = getenv("LVBA_BULK_DB"); return !(e && !strcmp(e, "0")); }();
+    // LVBA_BULK_TILE = k16 (default) | k32 (round 2's tile) | k32db (two K = 32 chunk buffers: one workgroup per CU; measured slower)
+    static const int bulk_tile = [] {
+        const char *e = getenv("LVBA_BULK_TILE");
+        return !e ? 2 : !strcmp(e, "k32") ? 0 : !strcmp(e, "k32db") ? 1 : 2;
+    }();
     static const bool chain_alone = [] { const char *e = getenv("LVBA_CHAIN_ALONE"); return !(e && !strcmp(e, "0")); }();
     static const int n_cus = [] {
         int dev = 0, n = 0;
@@ -1562,7 +1721,7 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
             Step2Args a{};
             a.skip_a = a.skip_b = -1;
             a.M = second ? M2 : M; a.sA = tw.sA; a.sW = tw.sW; a.ldz = ldz; a.nprob = (int)ny;
-            a.roles = L.roles; a.has_q = L.has_q; a.do_diag = L.do_diag; a.status = status;
+            a.roles = L.roles; a.has_q = L.has_q; a.do_diag = L.do_diag; a.q_extra = L.q_extra; a.status = status;
             a.dvec = dvec + wo; a.b = b + wo;
             int64_t nwg = 0;
             if (L.roles) {
@@ -1592,15 +1751,16 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
                 ++a.njobs;
             }
             int64_t grid = nwg * ny;
-            const bool db = big && bulk_db; // one workgroup per CU: nobody sits next to the chain workgroup anyway
-            if (chain_alone && !db && L.roles && grid > n_cus) { // (ldlt_lookahead.h: resv_at)
+            const int bt = big ? bulk_tile : 0; // (ldlt_lookahead.h: BT)
+            if (chain_alone && bt != 1 && L.roles && grid > n_cus) { // (ldlt_lookahead.h: resv_at; bt 1 has one workgroup per CU anyway)
                 a.resv_at = n_cus; a.resv_n = (int)ny;
                 grid += ny;
             }
             if (nwg > 0) {
-                if (db) hipLaunchKernelGGL((ldlt_step2_kernel<true, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
-                else if (big) hipLaunchKernelGGL((ldlt_step2_kernel<true, false>), dim3((unsigned)grid), dim3(256), 0, s, a);
-                else hipLaunchKernelGGL((ldlt_step2_kernel<false, false>), dim3((unsigned)grid), dim3(256), 0, s, a);
+                if (bt == 2) hipLaunchKernelGGL((ldlt_step2_kernel<true, 2>), dim3((unsigned)grid), dim3(256), 0, s, a);
+                else if (bt == 1) hipLaunchKernelGGL((ldlt_step2_kernel<true, 1>), dim3((unsigned)grid), dim3(256), 0, s, a);
+                else if (big) hipLaunchKernelGGL((ldlt_step2_kernel<true, 0>), dim3((unsigned)grid), dim3(256), 0, s, a);
+                else hipLaunchKernelGGL((ldlt_step2_kernel<false, 0>), dim3((unsigned)grid), dim3(256), 0, s, a);
             }
         }
     };

@@ -41,6 +41,7 @@ struct Step2Args {
     LdltMat M;
     int64_t sA, sW, ldz;
     int nprob, roles, has_q, do_diag, nbe_next, njobs;
+    int q_extra;         // row roles: also A(i, p+2) -= L(i, q) Z(p+2, q)^T (ldlt_schedule.h)
     int64_t rend_next;   // row limit of panel p + 1's window
     PanelGeo p, q;
     const double *side_r; // A(p+1, p) as [m][row] (64 x 64, masked like load_panel_tile), read by the row roles
@@ -317,9 +318,34 @@ __device__ __forceinline__ void row_role(double *lds, const LdltMat &M, const St
     if (use_q) {
         stage_tile(Ls, va, w, row);
         stage_tile(Zs, vb, w, row);
+        if (A.q_extra) load_z_tile(Zq, A.ldz, s0 + 64, q.w0, q.rend, q.nbe, w, row, vb); // Z(p+2, q)
         __syncthreads();
         tile_product(Ls, Zs, w, i, kk, acc);
         __syncthreads();
+        if (A.q_extra) { // block column p + 2 from panel q alone: this row's tile, with L(i, q) still in LDS
+            stage_tile(Zs, vb, w, row);
+            double c2[16];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int64_t c = s0 + 64 + 16 * w + kk + 4 * reg, rr = r0 + 16 * t + i;
+                    c2[4 * t + reg] = (rr < q.rend && c < q.rend && rr >= c) ? M.a[rr + c * M.ld] : 0.0;
+                }
+            __syncthreads();
+            d4 accx[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) accx[t] = (d4){0.0, 0.0, 0.0, 0.0};
+            tile_product(Ls, Zs, w, i, kk, accx);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int64_t c = s0 + 64 + 16 * w + kk + 4 * reg, rr = r0 + 16 * t + i;
+                    if (rr < q.rend && c < q.rend && rr >= c) M.a[rr + c * M.ld] = c2[4 * t + reg] - accx[t][reg];
+                }
+            __syncthreads();
+        }
     }
 #pragma unroll
     for (int it = 0; it < 16; ++it) va[it] = side_r[(w + 4 * it) * 64 + row]; // A(p+1, p), for Z(p+1, p): the side copy
@@ -391,13 +417,16 @@ __device__ __forceinline__ void row_role(double *lds, const LdltMat &M, const St
 // ---------------------------------------------------------------------------------------------- one launch
 // Block order: the chain workgroups of all problems first, then the row workgroups, then the bulk jobs' workgroups alternating
 // between the problems.  big: 128 x 64 bulk tiles (bulk_tile_128, 32-bit buffer offsets) / 64 x 64 tiles (update_tile[2]).
-// DB: bulk tiles with two chunk buffers in LDS (bulk_tile_128<.., true>: 114 KB, one workgroup per CU) / one buffer (80 KB, two per CU)
-template <bool big, bool DB>
-__global__ __launch_bounds__(256, DB ? 1 : 2) void ldlt_step2_kernel(const Step2Args A)
+// BT, the bulk tile: 0 = bulk_tile_128 (K chunks of 32, one chunk buffer; 80 KB, two workgroups per CU)
+//                    1 = bulk_tile_128<.., true> (two chunk buffers of K = 32: 114 KB, one workgroup per CU)
+//                    2 = bulk_tile_k16 (K chunks of 16, two chunk buffers, three register sets; 80 KB with the roles, two per CU)
+template <bool big, int BT>
+__global__ __launch_bounds__(256, BT == 1 ? 1 : 2) void ldlt_step2_kernel(const Step2Args A)
 {
-    __shared__ double lds[DB ? (LVBA_K3DB_LDS > LVBA_K3_LDS ? LVBA_K3DB_LDS : LVBA_K3_LDS) : LVBA_K3_LDS];
-    static_assert(LVBA_K1B_LDS <= LVBA_K3_LDS && LVBA_K3B_LDS <= LVBA_K3_LDS && LVBA_PAD_RED + 256 <= 1024, "LDS budget of the roles");
-    static_assert(!DB || big, "two chunk buffers exist for the 128 x 64 tiles only");
+    __shared__ double lds[BT == 1 ? (LVBA_K3DB_LDS > LVBA_K3_LDS ? LVBA_K3DB_LDS : LVBA_K3_LDS) : LVBA_K3_LDS];
+    static_assert(LVBA_K1B_LDS <= LVBA_K3_LDS && LVBA_K3B_LDS <= LVBA_K3_LDS && LVBA_K16_LDS <= LVBA_K3_LDS && LVBA_PAD_RED + 256 <= 1024,
+                  "LDS budget of the roles");
+    static_assert(BT == 0 || big, "the other bulk tiles exist for the 128 x 64 form only");
     const int64_t nrole = A.roles ? A.p.T : 0, nfac = nrole * A.nprob;
     LdltMat M = A.M;
     int prob;
@@ -438,8 +467,13 @@ __global__ __launch_bounds__(256, DB ? 1 : 2) void ldlt_step2_kernel(const Step2
             int64_t R0, tj;
             if (!pair_decode(J.dbg_same ? 0 : bx, J.ca, J.cb, (int64_t)J.o.T - 1, R0, tj)) return;
             const PanelRef po{J.o.k, J.o.w0, J.o.rend, J.o.nbe, Zo}, pe{J.e.k, J.e.w0, J.e.rend, J.e.nbe, Ze};
-            if (J.pair) bulk_tile_128<4, DB>(lds, M, po, pe, A.ldz, R0, tj);
-            else bulk_tile_128<2, DB>(lds, M, po, pe, A.ldz, R0, tj);
+            if constexpr (BT == 2) {
+                if (J.pair) bulk_tile_k16<2>(lds, M, po, pe, A.ldz, R0, tj);
+                else bulk_tile_k16<1>(lds, M, po, pe, A.ldz, R0, tj);
+            } else {
+                if (J.pair) bulk_tile_128<4, BT == 1>(lds, M, po, pe, A.ldz, R0, tj);
+                else bulk_tile_128<2, BT == 1>(lds, M, po, pe, A.ldz, R0, tj);
+            }
         } else {
             int64_t ti, tj;
             col_decode(J.ca + bx, (int64_t)J.o.T - 1, ti, tj);

@@ -9,7 +9,10 @@
 //     block column q + 1   roles of X_q            block column q + 2   roles of X_{q+1}
 //     block columns >= q + 3 (tj' >= 1)            a job, in a launch X_r with q + 1 <= r <= (block column) - 2
 // Consecutive panels are PAIRED (e, o = e + 1) so that every C tile is read and written once for both (rank 128):
-//     X_o      single job  (e, tj' = 1)            = block column e + 3, which X_{o+1}'s roles need complete
+//     X_o      row roles   (q_extra)               = block column e + 3 from panel e alone, which X_{o+1}'s roles need complete:
+//                                                    the row workgroups of X_o hold L(i, e) anyway (their q is e), one product more
+//                                                    each -- as a bulk job of its own ("single job (e, tj' = 1)") it made the
+//                                                    second-half launches of config C3 534 workgroups on 512 seats
 //     X_{e+2}  pair job    (o + e, tj' in [1, cs)) = block columns e + 4 .. : the first half (at least tj' = 1, 2)
 //     X_{e+3}  pair job    (o + e, tj' >= cs)      the second half, beside the next pair's single job (block column e + 5 < e + 6)
 // Panels left over (an odd count, windows too short to pair) run their whole update as one single job in X_{q+1}.
@@ -24,6 +27,7 @@ struct SchedLaunch {
     int kind; // 0: the first diagonal block of a phase (ldlt_diag_blocked_kernel), 1: a step launch
     int64_t p;
     int roles, has_q, do_diag, njobs;
+    int q_extra; // the row roles also apply panel q = p - 1 to block column p + 2 (q is the first panel of a pair: see below)
     SchedJob job[2];
 };
 
@@ -72,9 +76,9 @@ void ldlt_schedule_phase(int64_t sa, int64_t sb, bool close, bool rank128, TF To
                 flush(); // (nothing is pending here in a regular sequence)
                 add(L, q, 1, 1, cs);
                 if (cs < Tb) { pend.on = true; pend.o = q; pend.ca = cs; }
-            } else if (is_e(q)) { // X_o: block column e + 3 from panel e alone, beside the previous pair's second half
+            } else if (is_e(q)) { // X_o: block column e + 3 from panel e alone (row roles), beside the previous pair's second half
                 if (pend.on) { add(L, pend.o, 1, pend.ca, INT64_MAX); pend.on = false; }
-                add(L, q, 0, 1, 2);
+                L.q_extra = 1;
             } else { // a panel without a partner: its whole update, alone in the launch
                 flush();
                 add(L, q, 0, 1, INT64_MAX);

@@ -102,6 +102,13 @@ struct Model {
                     apply(i, p + 1, p);
                     write(i, p + 1);
                     if (t == 1) { CHECK(complete(i, p + 1), "side copy taken of an incomplete tile"); side_copy[p + 1] = now; }
+                    if (L.q_extra && t >= 1 && i <= q + Tof(q)) { // block column p + 2 from panel q, by the row that holds L(i, q)
+                        CHECK(L.has_q, "q_extra without q");
+                        needL(i, q);
+                        needL(p + 2, q);
+                        apply(i, p + 2, q);
+                        write(i, p + 2);
+                    }
                 }
                 for (int64_t t = 0; t < Tof(p); ++t) isL[tk(p + 1 + t, p)] = now;
                 if (L.do_diag) {

@@ -464,8 +464,9 @@ def test_solver_schedules(tmp_path):
                 {"LVBA_CHECK_BAND": "1", "LVBA_NO_GRAPH": "1"}, {"LVBA_BAND_MEMSET": "1"},
                 # the seats next to the chain workgroups taken again (placement is a matter of speed only)
                 {"LVBA_CHAIN_ALONE": "0"},
-                # bulk tiles with one chunk buffer in LDS (two workgroups per CU) instead of two (one per CU)
-                {"LVBA_BULK_DB": "0"}, {"LVBA_BULK_DB": "0", "LVBA_CHAIN_ALONE": "0"}, {"LVBA_BULK_DB": "0", "LVBA_RANK128": "0"}]
+                # the other bulk tiles: K chunks of 32 with one / two chunk buffers in LDS (default: chunks of 16, two buffers)
+                {"LVBA_BULK_TILE": "k32"}, {"LVBA_BULK_TILE": "k32", "LVBA_CHAIN_ALONE": "0"}, {"LVBA_BULK_TILE": "k32", "LVBA_RANK128": "0"},
+                {"LVBA_BULK_TILE": "k32db"}]
     out = []
     for i, v in enumerate(variants):
         f = tmp_path / f"dx_{i}.npy"

@@ -2,7 +2,7 @@
 // Includes ldlt.hip directly.  usage: solver_microbench [n=12000] [bw=2813]
 #define LVBA_K1_TIMING
 #ifndef LVBA_MB_DB
-#define LVBA_MB_DB true
+#define LVBA_MB_DB 2
 #endif
 #include "../global-lvba_amd/csrc/ldlt.hip"
 #include <cstdio>
