@@ -1692,10 +1692,12 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
     // tile-level model of the factorisation, tests/ldlt_schedule_check.cpp)
     static const bool lookahead = [] { const char *e = getenv("LVBA_SOLVER"); return !(e && !strcmp(e, "r3")); }();
     double *side_buf[2] = {Zbuf[3] + ldz * LVBA_NB + 64, Zbuf[3] + ldz * LVBA_NB + 64 + 4096};
-    // LVBA_BULK_TILE = k16 (default) | k32 (round 2's tile) | k32db (two K = 32 chunk buffers: one workgroup per CU; measured slower)
+    // LVBA_BULK_TILE = k32 (default: round 2's tile, K chunks of 32, one chunk buffer) | k16 (chunks of 16, two buffers, three
+    // register sets: 28.9 against 30.3 us for 408 tiles alone, but the same solve time, 4.10 / 4.06 ms) | k32db (two K = 32
+    // buffers, one workgroup per CU: 4.87 ms)
     static const int bulk_tile = [] {
         const char *e = getenv("LVBA_BULK_TILE");
-        return !e ? 2 : !strcmp(e, "k32") ? 0 : !strcmp(e, "k32db") ? 1 : 2;
+        return !e ? 0 : !strcmp(e, "k16") ? 2 : !strcmp(e, "k32db") ? 1 : 0;
     }();
     static const bool chain_alone = [] { const char *e = getenv("LVBA_CHAIN_ALONE"); return !(e && !strcmp(e, "0")); }();
     static const int n_cus = [] {

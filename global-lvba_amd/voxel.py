@@ -161,7 +161,7 @@ class Scans:
         aposes = np.zeros((max(nw, 1), 12))
         na, h = C.c_int32(), C.c_void_p()
         info = (L.WindowInfo * max(nw, 1))()
-        hs = (C.c_void_p * len(shares))(*[sc._h for sc in shares])
+        hs = (C.c_void_p * len(shares))(*[sc._h.value for sc in shares])
         try:
             L.check(lib.lvba_window_ba_multi(len(shares), hs, poses, C.byref(o), window_poses.ctypes.data, rel.reshape(-1), aidx,
                                              aposes.reshape(-1), C.byref(na), C.byref(h), info))

@@ -198,7 +198,7 @@ def block_parity(H, bi, bj, blocks):
     return worst, abs(total - listed) / total
 
 
-def block_parity_sparse(gi, gj, gblocks, bi, bj, blocks, n_poses):
+def block_parity_sparse(gi, gj, gblocks, bi, bj, blocks, n_poses, details=False):
     """The same check for a path under test that hands out its Hessian as a block list (gi >= gj, gblocks[k, r, c] =
     H[6 gi + r, 6 gj + c], each unordered pair once -- lvba_balm_eval_blocks) against COracle.eval_sparse's (bi <= bj).
     Returns (worst per-block relative error over the oracle's blocks, relative weight of the blocks the path under test has
@@ -222,6 +222,11 @@ def block_parity_sparse(gi, gj, gblocks, bi, bj, blocks, n_poses):
     matched = np.zeros(len(gk), bool)
     matched[pos[found]] = True
     extra = float(tot[go][~matched].sum())
+    if details:  # which block is the worst one (tools/worst_block.py)
+        k = int(np.argmax(err / np.maximum(scale, floor)))
+        return worst, extra / float(tot.sum()), {"pose_i": int(ok[k] // N), "pose_j": int(ok[k] % N), "block_scale": float(scale[k]),
+                                                  "block_abs_err": float(err[k]), "largest_block_scale": float(np.abs(blocks).max()),
+                                                  "floor": float(floor)}
     return worst, extra / float(tot.sum())
 
 

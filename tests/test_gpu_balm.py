@@ -464,8 +464,8 @@ def test_solver_schedules(tmp_path):
                 {"LVBA_CHECK_BAND": "1", "LVBA_NO_GRAPH": "1"}, {"LVBA_BAND_MEMSET": "1"},
                 # the seats next to the chain workgroups taken again (placement is a matter of speed only)
                 {"LVBA_CHAIN_ALONE": "0"},
-                # the other bulk tiles: K chunks of 32 with one / two chunk buffers in LDS (default: chunks of 16, two buffers)
-                {"LVBA_BULK_TILE": "k32"}, {"LVBA_BULK_TILE": "k32", "LVBA_CHAIN_ALONE": "0"}, {"LVBA_BULK_TILE": "k32", "LVBA_RANK128": "0"},
+                # the other bulk tiles: K chunks of 16 with two chunk buffers, K chunks of 32 with two buffers (default: 32, one buffer)
+                {"LVBA_BULK_TILE": "k16"}, {"LVBA_BULK_TILE": "k16", "LVBA_CHAIN_ALONE": "0"}, {"LVBA_BULK_TILE": "k16", "LVBA_RANK128": "0"},
                 {"LVBA_BULK_TILE": "k32db"}]
     out = []
     for i, v in enumerate(variants):
