@@ -54,6 +54,8 @@ struct BlockSys {
     // grouped refinement: d_u holds one damping value per group, d_grp_of_pose [N] (owned by the caller) maps pose blocks to them
     int32_t n_groups = 0;
     const int32_t *d_grp_of_pose = nullptr;
+    int32_t bb_hint = -1; // >= 0: an upper bound of the block half-bandwidth in the caller's pose order (a grouped problem: the
+                          // largest group's pose count - 1; the voxels were checked against the groups) -- no host pass over the factors
     int *d_status = nullptr;
     hipGraph_t solve_graph = nullptr;
     hipGraphExec_t solve_exec = nullptr;

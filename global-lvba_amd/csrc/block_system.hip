@@ -273,7 +273,7 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
         }
         return Bb;
     };
-    int32_t Bb_nat = band_of(bs.iperm);
+    int32_t Bb_nat = (bs.bb_hint >= 0 && !bs.distributed()) ? std::min<int32_t>(bs.bb_hint, std::max(N - 1, 0)) : band_of(bs.iperm);
     if (bs.distributed()) { // the store layout must agree on every rank: reduce over the global problem
         int32_t *dtmp = nullptr;
         HIPCHK(hipMalloc((void **)&dtmp, sizeof(int32_t)));
@@ -366,6 +366,11 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
         // LVBA_PAIR_WINDOW overrides (voxels per window, 0 = none).
         int64_t window_groups = 0;
         if (18 * 8 * F > ((int64_t)24 << 20)) window_groups = std::max<int64_t>(256, (((int64_t)6 << 20) / 144) * G / std::max<int64_t>(F, 1));
+        // A grouped problem (the windows of the window stage as ONE handle) has few blocks with long lists and lives for a
+        // handful of iterations: the windowed, length-sorted lists cost it more set-up (pair lists 8.1 -> 1.0 ms, tables
+        // 4.1 -> 0.2 ms for 16 windows of 20 x 100 k points) than they can give back -- this was round 3's regression of the
+        // window stage (2.15 -> 2.9 ms per window), measured back to 2.13 with the plain lists.
+        if (bs.n_groups > 0) window_groups = 0;
         if (const char *e = getenv("LVBA_PAIR_WINDOW")) window_groups = atoll(e);
         // LVBA_PAIR_SORT=0: the windows' items in (tile, block) order instead of by length (A/B)
         static const bool len_sort = [] { const char *e = getenv("LVBA_PAIR_SORT"); return !(e && !strcmp(e, "0")); }();

@@ -779,6 +779,11 @@ extern "C" int32_t lvba_balm_set_groups(lvba_balm_t h, int32_t n_groups, const i
     for (int32_t k = 0; k < n_groups; ++k)
         for (int32_t j = pose_off[k]; j < pose_off[k + 1]; ++j) gof[(size_t)j] = k;
     h->n_groups = n_groups;
+    {
+        int32_t span = 0; // block half-bandwidth in the caller's pose order: no voxel leaves its group (checked above)
+        for (int32_t k = 0; k < n_groups; ++k) span = std::max(span, pose_off[k + 1] - pose_off[k] - 1);
+        bs.bb_hint = span;
+    }
     h->g_pose_off.assign(pose_off, pose_off + n_groups + 1);
     h->g_vox_off.assign(voxel_off, voxel_off + n_groups + 1);
     TRY(bs_dmalloc(bs, &h->d_grp_of_pose, h->N));

@@ -553,6 +553,9 @@ extern "C" int32_t lvba_window_ba_multi(int32_t n_shares, const lvba_scans_t *sc
     }
     struct Share { int32_t rc = LVBA_OK, na = 0; std::string err; lvba_scans_t anchors = nullptr; std::vector<double> ap; };
     std::vector<Share> sh((size_t)n_shares);
+    // several host threads drive the device(s) from here on: no solve graph is captured meanwhile (with HIP 7.0 a capture in one
+    // thread is invalidated by allocations and synchronous copies in another, block_system.hip)
+    struct Inhibit { Inhibit() { bs_graph_inhibit(+1); } ~Inhibit() { bs_graph_inhibit(-1); } } inhibit;
     auto run = [&](int k) {
         Share &S = sh[(size_t)k];
         const int64_t nf = scans[k]->n_frames, nw = wb[(size_t)k + 1] - wb[(size_t)k];
