@@ -396,7 +396,8 @@ def relaunch_under_torchrun(n):
 
 def scaling_model(p, sv_ms, info, world):
     """What strong scaling of ONE refinement can give, from this run's own stage times: the evaluation and the cost pass shard by
-    voxel range (/ N), the pose blocks are all-reduced (bytes / an assumed 100 GB/s RCCL bus bandwidth over xGMI for N > 1), and the
+    voxel range (/ N), the pose blocks are all-reduced (2 (N - 1) / N x bytes / an ASSUMED 250 GB/s RCCL bus bandwidth over xGMI -- 7
+    links x ~153 GB/s per GPU, full mesh; never measured here: no multi-GPU node was available to any round), and the
     damped solve is a serial chain of panel factorisations that two ranks split at best (the two ends of the band) -- with both
     ends already sharing every launch on one GPU, the second rank buys almost nothing.  A projection, not a measurement."""
     ev = p["eval_ms"] / max(1, p["eval_calls"])
@@ -404,11 +405,11 @@ def scaling_model(p, sv_ms, info, world):
     ar_mb = 8e-6 * (36 * (info.get("n_blocks", 0) + info["n_poses"]) + 6 * info["n_poses"] + 1)
     proj = {}
     for n in (1, 2, 4, 8):
-        ar = 0.0 if n == 1 else 2.0 * (n - 1) / n * ar_mb / 100.0   # ms at 100 GB/s bus bandwidth (MB / (GB/s) = ms)
+        ar = 0.0 if n == 1 else 2.0 * (n - 1) / n * ar_mb / 250.0   # ms at 250 GB/s bus bandwidth (MB / (GB/s) = ms)
         t = (ev + ck) / n + ar + sv_ms
         proj[str(n)] = {"ms_per_iteration": t, "speedup": (ev + ck + sv_ms) / t}
     return {"kind": "strong scaling of one refinement: chain-bound", "stage_ms_1gpu": {"eval": ev, "cost": ck, "solve": sv_ms},
-            "allreduce_mb_per_evaluation": ar_mb, "assumed_bus_gb_s": 100.0, "projected": proj,
+            "allreduce_mb_per_evaluation": ar_mb, "assumed_bus_gb_s": 250.0, "projected": proj,
             "note": "the solve (a chain of ~115 panel factorisations) does not shard; throughput across GPUs comes from independent "
                     "work -- windows (window_stage_all_ranks, lvba_window_ba_multi), sequences -- not from one refinement",
             "measured_ranks": world}
