@@ -102,3 +102,21 @@ def test_cpp_adapter_compiles_and_links(lib, tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "adapter_check.cpp"), "-o", exe,
                            "-L", libdir, "-llvba_hip", f"-Wl,-rpath,{libdir}"])
     assert subprocess.call([exe]) == 0
+
+
+def test_window_split_deals_out_whole_windows():
+    """lvba_window_split (host only, no device needed): contiguous runs of whole windows, every frame in exactly one share,
+    the thread split of bavoxel.hpp:621-624 applied to windows; shares may be empty when there are fewer windows than shares."""
+    import ctypes as C
+    import importlib
+    L = importlib.import_module("global-lvba_amd._lib")
+    lib = L.load()
+    for n, w, k in ((320, 20, 8), (26, 4, 3), (26, 4, 2), (5, 10, 4), (0, 10, 2), (64, 16, 1), (1000, 7, 8)):
+        fb = np.zeros(k + 1, np.int32)
+        assert lib.lvba_window_split(n, w, k, fb) == 0
+        assert fb[0] == 0 and fb[-1] == n and (np.diff(fb) >= 0).all()
+        assert all(int(b) % w == 0 for b in fb[:-1])
+        nw = (n + w - 1) // w
+        per = [(-(-int(fb[i + 1] - fb[i]) // w)) for i in range(k)]
+        assert sum(per) == nw and max(per) - min(per) <= 1
+    assert lib.lvba_window_split(10, 0, 2, np.zeros(3, np.int32)) != 0

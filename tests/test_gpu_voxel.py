@@ -259,3 +259,24 @@ def test_hip_matches_reference_voxel_golden(pkg):
     np.testing.assert_array_equal(valid.astype(bool), want_valid)
     sgn = np.sign(np.sum(plane[:, :3] * r["planes"][:, :3], axis=1))[:, None]
     assert np.abs(sgn * plane - r["planes"])[want_valid].max() < 1e-8
+
+
+def test_strided_scans_upload_packed_equals_memcpy2d(pkg, synth, monkeypatch):
+    """lvba_scans_create from a 48-byte point stride: the packed, pinned, multi-threaded upload (round 4) puts the same xyz on
+    the device as the former hipMemcpy2D path (LVBA_UPLOAD=memcpy2d) and as a 12-byte-stride upload of the coordinates alone --
+    frames longer and shorter than a 1 M-point chunk, an empty frame, one thread and many."""
+    rng = np.random.default_rng(5)
+    sizes = [3, 0, 70_000, 1_300_000, 1 << 20]
+    clouds = [rng.standard_normal((n, 12)).astype(np.float32) for n in sizes]
+    want = [np.ascontiguousarray(c[:, :3]) for c in clouds]
+    for env in ({}, {"LVBA_UPLOAD_THREADS": "1"}, {"LVBA_UPLOAD": "memcpy2d"}):
+        for k in ("LVBA_UPLOAD_THREADS", "LVBA_UPLOAD"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with pkg.Scans(clouds) as sc:
+            for f, w in enumerate(want):
+                np.testing.assert_array_equal(sc.download(f), w)
+    with pkg.Scans(want) as sc:
+        for f, w in enumerate(want):
+            np.testing.assert_array_equal(sc.download(f), w)
