@@ -21,7 +21,7 @@ SYMBOLS = [
     "lvba_voxel_default_opts", "lvba_voxmap_build", "lvba_voxmap_destroy", "lvba_voxmap_info", "lvba_voxmap_export",
     "lvba_voxmap_to_balm", "lvba_voxmap_find_planes", "lvba_scans_create", "lvba_scans_destroy", "lvba_voxmap_build_scans",
     "lvba_release_cached_memory", "lvba_window_default_opts", "lvba_window_ba", "lvba_window_split", "lvba_window_ba_multi", "lvba_scans_info", "lvba_scans_download",
-    "lvba_lidar_ba_default_opts", "lvba_lidar_ba", "lvba_triangulate_tracks",
+    "lvba_lidar_ba_default_opts", "lvba_lidar_ba", "lvba_lidar_ba_multi", "lvba_triangulate_tracks",
     "lvba_depth_render", "lvba_depth_upload", "lvba_depth_info", "lvba_depth_download", "lvba_depth_destroy",
     "lvba_fuse_default_opts", "lvba_fuse_tracks",
 ]
@@ -217,6 +217,7 @@ def load():
     lib.lvba_lidar_ba_default_opts.argtypes = [C.POINTER(LidarBaOpts)]
     lib.lvba_lidar_ba_default_opts.restype = None
     lib.lvba_lidar_ba.argtypes = [H, f64p, C.POINTER(LidarBaOpts), f64p, C.POINTER(LidarBaReport)]
+    lib.lvba_lidar_ba_multi.argtypes = [C.c_int32, C.POINTER(H), f64p, C.POINTER(LidarBaOpts), f64p, C.POINTER(LidarBaReport)]
     lib.lvba_triangulate_tracks.argtypes = [C.c_int32, C.c_int32, C.c_int64, i64p, C.c_void_p, C.c_void_p, f64p, f64p, f64p, f64p,
                                             f64p, i32p, u8p]
     lib.lvba_depth_render.argtypes = [C.c_void_p, f64p, f64p, C.c_int32, f64p, f64p, f64p, f64p, C.c_int32, C.c_int32, C.c_double,

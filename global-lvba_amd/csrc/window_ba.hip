@@ -646,14 +646,23 @@ extern "C" void lvba_lidar_ba_default_opts(lvba_lidar_ba_opts *o)
     lvba_balm_default_opts(&o->lm);
 }
 
-extern "C" int32_t lvba_lidar_ba(lvba_scans_t sc, const double *poses_in, const lvba_lidar_ba_opts *opts, double *poses_out,
-                                 lvba_lidar_ba_report *rep)
+// n_shares == 1: the whole sequence on scs[0]'s device; > 1: the window stage over the shares (lvba_window_ba_multi), the global
+// stages -- single problems over all anchors -- on the first share's device, where the anchor clouds are gathered
+static int32_t lidar_ba_impl(int32_t n_shares, const lvba_scans_t *scs, const double *poses_in, const lvba_lidar_ba_opts *opts,
+                             double *poses_out, lvba_lidar_ba_report *rep)
 {
-    if (!sc || !poses_in || !poses_out) return lvba_fail(LVBA_ERR_ARG, "null argument");
+    if (n_shares < 1 || !scs || !scs[0] || !poses_in || !poses_out) return lvba_fail(LVBA_ERR_ARG, "null argument");
     lvba_lidar_ba_opts o;
     lvba_lidar_ba_default_opts(&o);
     if (opts) o = *opts;
-    const int n = sc->n_frames;
+    lvba_scans_t sc = scs[0];
+    int n = 0;
+    for (int k = 0; k < n_shares; ++k) {
+        if (!scs[k]) return lvba_fail(LVBA_ERR_ARG, "share %d: null scan set", k);
+        n += scs[k]->n_frames;
+    }
+    if (n_shares > 1 && !o.window_enable)
+        return lvba_fail(LVBA_ERR_ARG, "several shares need the window stage (window_enable = 0 cuts the RAW scans in the global stages: one device)");
     lvba_lidar_ba_report r{};
     r.n_frames = n;
     lvba::hvec<double> rel(12 * (size_t)n), anchor_poses;
@@ -665,7 +674,8 @@ extern "C" int32_t lvba_lidar_ba(lvba_scans_t sc, const double *poses_in, const 
         const int nw = (n + o.window.window_size - 1) / std::max(1, o.window.window_size);
         anchor_poses.resize(12 * (size_t)std::max(nw, 1));
         lvba::hvec<lvba_window_info> wi((size_t)std::max(nw, 1));
-        TRY(lvba_window_ba(sc, poses_in, &o.window, nullptr, rel.data(), aidx.data(), anchor_poses.data(), &na, &anchors, wi.data()));
+        if (n_shares == 1) TRY(lvba_window_ba(sc, poses_in, &o.window, nullptr, rel.data(), aidx.data(), anchor_poses.data(), &na, &anchors, wi.data()));
+        else TRY(lvba_window_ba_multi(n_shares, scs, poses_in, &o.window, nullptr, rel.data(), aidx.data(), anchor_poses.data(), &na, &anchors, wi.data()));
         r.n_windows = nw;
         for (int k = 0; k < nw; ++k) r.n_windows_skipped += wi[k].skipped;
     } else { // :221-229: every frame is its own anchor
@@ -725,4 +735,16 @@ extern "C" int32_t lvba_lidar_ba(lvba_scans_t sc, const double *poses_in, const 
     }
     if (rep) *rep = r;
     return LVBA_OK;
+}
+
+extern "C" int32_t lvba_lidar_ba(lvba_scans_t sc, const double *poses_in, const lvba_lidar_ba_opts *opts, double *poses_out,
+                                 lvba_lidar_ba_report *rep)
+{
+    return lidar_ba_impl(1, &sc, poses_in, opts, poses_out, rep);
+}
+
+extern "C" int32_t lvba_lidar_ba_multi(int32_t n_shares, const lvba_scans_t *scans, const double *poses_in,
+                                       const lvba_lidar_ba_opts *opts, double *poses_out, lvba_lidar_ba_report *rep)
+{
+    return lidar_ba_impl(n_shares, scans, poses_in, opts, poses_out, rep);
 }

@@ -195,6 +195,38 @@ class Scans:
         L.check(self.lib.lvba_lidar_ba(self._h, poses, C.byref(o), out, C.byref(rep)))
         return out.reshape(n, 12), rep.as_dict()
 
+    @staticmethod
+    def lidar_ba_multi(clouds, poses, devices, window_size=10, anchor_leaf=0.1, use_rel=True, stage1_enable=True,
+                       stage_voxel_size=(0.5, 0.5), stage_eigen_ratio=((0.3, 0.1, 0.06, 0.03), (0.08, 0.08, 0.08, 0.08)),
+                       window_eigen_ratio=None):
+        """runLidarBA with the window stage over several GPUs (lvba_lidar_ba_multi): returns (poses [n,12], report dict)."""
+        lib = L.load()
+        n, D = len(clouds), len(devices)
+        poses = np.ascontiguousarray(poses, np.float64).reshape(-1)
+        if poses.size != 12 * n:
+            raise ValueError(f"poses must hold {n} x 12 doubles")
+        fb = np.zeros(D + 1, np.int32)
+        L.check(lib.lvba_window_split(n, int(window_size), D, fb))
+        shares = [Scans(clouds[fb[k]:fb[k + 1]], device=int(devices[k])) for k in range(D) if fb[k + 1] > fb[k]]
+        o = L.LidarBaOpts()
+        lib.lvba_lidar_ba_default_opts(C.byref(o))
+        o.window_enable, o.stage1_enable = 1, int(bool(stage1_enable))
+        o.window.window_size, o.window.use_rel, o.window.anchor_leaf = int(window_size), int(bool(use_rel)), float(anchor_leaf)
+        o.window.voxel = _opts(stage_voxel_size[0], window_eigen_ratio, None)
+        for i in range(2):
+            o.stage_voxel_size[i] = float(stage_voxel_size[i])
+            for k in range(4):
+                o.stage_eigen_ratio[i][k] = float(stage_eigen_ratio[i][k])
+        out = np.zeros(12 * n)
+        rep = L.LidarBaReport()
+        hs = (C.c_void_p * len(shares))(*[sc._h.value for sc in shares])
+        try:
+            L.check(lib.lvba_lidar_ba_multi(len(shares), hs, poses, C.byref(o), out, C.byref(rep)))
+        finally:
+            for sc in shares:
+                sc.close()
+        return out.reshape(n, 12), rep.as_dict()
+
     def voxel_map(self, poses, voxel_size=1.0, eigen_ratio_array=None, min_points=None, frame_begin=0, n_frames=None):
         """Map of frames [frame_begin, frame_begin + n_frames) at `poses` [n_frames, 12]."""
         n = self.n_frames - frame_begin if n_frames is None else int(n_frames)

@@ -484,6 +484,11 @@ typedef struct {
 void lvba_lidar_ba_default_opts(lvba_lidar_ba_opts *opts);
 int32_t lvba_lidar_ba(lvba_scans_t scans, const double *poses_in, const lvba_lidar_ba_opts *opts, double *poses_out,
                       lvba_lidar_ba_report *report);
+/* The same with the window stage over several GPUs (lvba_window_ba_multi: scans[k] = share k's frames, whole windows, in
+ * order; poses_in / poses_out cover all frames): the global stages are single problems over all anchors and run on scans[0]'s
+ * device, where the anchor clouds are gathered.  Needs window_enable = 1. */
+int32_t lvba_lidar_ba_multi(int32_t n_shares, const lvba_scans_t *scans, const double *poses_in, const lvba_lidar_ba_opts *opts,
+                            double *poses_out, lvba_lidar_ba_report *report);
 
 /* Frame count and per-frame point counts of a scan set; host copy of one frame's xyz [count][3]. */
 int32_t lvba_scans_info(lvba_scans_t scans, int32_t *n_frames, int64_t *frame_count);

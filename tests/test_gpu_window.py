@@ -227,3 +227,20 @@ def test_window_stage_over_several_shares_equals_one_device(pkg, synth, devices)
             assert np.abs(got["rel_poses"] - one["rel_poses"]).max() <= 1e-9
             for p, q in zip(pm, p1):
                 assert abs(len(p) - len(q)) <= 0.002 * len(q)
+
+
+def test_lidar_stage_with_the_windows_over_several_shares(pkg, synth):
+    """lvba_lidar_ba_multi: runLidarBA with its window stage dealt out to several shares (on the test box all on device 0), the
+    two global stages on the first share's device over the gathered anchors.  With one window per problem (the default batching
+    is per share, so the grouped LM sees other groups than in the one-share run) the anchors differ at rounding level only: same
+    anchors, same stage sizes to a fraction of a percent, final poses to the tolerance the one-device test holds against the oracle."""
+    s = synth.make_scans(16, 8000, room=(10, 8, 4), origin=(-3.3, 7.1, 0.4), n_panels=8, seed=43, rot_sigma_deg=0.1, trans_sigma=0.03)
+    kw = dict(window_size=4, anchor_leaf=0.05, stage_voxel_size=(1.0, 0.5))
+    with pkg.Scans(s["clouds"]) as scans:
+        one, rep1 = scans.lidar_ba(s["poses"], **kw)
+    got, rep = pkg.Scans.lidar_ba_multi(s["clouds"], s["poses"], (0, 0), **kw)
+    assert rep["n_frames"] == 16 and rep["n_windows"] == rep1["n_windows"] == 4 and rep["n_anchors"] == rep1["n_anchors"] == 4
+    for i in range(2):
+        assert rep["stage_ran"][i] == rep1["stage_ran"][i] == 1
+        assert abs(rep["stage_voxels"][i] - rep1["stage_voxels"][i]) <= max(3, 0.01 * rep1["stage_voxels"][i])
+    assert np.abs(got - one).max() < 2e-4
