@@ -210,6 +210,59 @@ lvba_lidar_ba_report lidar_ba(const CloudPtrVec &clouds, PoseVec &x_buf, const l
     return rep;
 }
 
+// The same over several GPUs of one node: the window stage's windows are dealt out to `devices` in contiguous runs of whole
+// windows (lvba_window_split), every device holds only its own frames, the global stages run on devices[0] over the gathered
+// anchors (lvba_lidar_ba_multi).  devices.size() == 1 is lidar_ba above.
+template <class CloudPtrVec, class PoseVec>
+lvba_lidar_ba_report lidar_ba(const CloudPtrVec &clouds, PoseVec &x_buf, const lvba_lidar_ba_opts &opts, const std::vector<int> &devices)
+{
+    if (devices.empty()) throw std::runtime_error("lvba::lidar_ba: empty device list");
+    if (devices.size() == 1 || !opts.window_enable) return lidar_ba(clouds, x_buf, opts, devices[0]);
+    const int32_t n = static_cast<int32_t>(x_buf.size()), D = static_cast<int32_t>(devices.size());
+    std::vector<int32_t> fb(static_cast<size_t>(D) + 1);
+    if (lvba_window_split(n, opts.window.window_size, D, fb.data()) != LVBA_OK)
+        throw std::runtime_error(std::string("lvba_window_split: ") + lvba_last_error());
+    std::vector<lvba_scans_t> shares;
+    auto drop = [&]() { for (lvba_scans_t q : shares) lvba_scans_destroy(q); shares.clear(); };
+    for (int32_t k = 0; k < D; ++k) {
+        const int32_t a = fb[k], b = fb[k + 1];
+        if (b <= a) continue;
+        std::vector<const void *> ptr(static_cast<size_t>(b - a));
+        std::vector<int64_t> cnt(static_cast<size_t>(b - a));
+        int32_t stride = 12;
+        for (int32_t j = a; j < b; ++j) {
+            const auto &pts = clouds[j]->points;
+            ptr[j - a] = pts.data();
+            cnt[j - a] = static_cast<int64_t>(pts.size());
+            stride = static_cast<int32_t>(sizeof(pts[0]));
+        }
+        lvba_scans_t sc = nullptr;
+        if (lvba_scans_create(devices[static_cast<size_t>(k)], b - a, ptr.data(), cnt.data(), stride, &sc) != LVBA_OK) {
+            const std::string msg = lvba_last_error();
+            drop();
+            throw std::runtime_error("lvba_scans_create: " + msg);
+        }
+        shares.push_back(sc);
+    }
+    std::vector<double> poses(12 * static_cast<size_t>(n));
+    for (int32_t j = 0; j < n; ++j) {
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) poses[12 * j + 3 * r + c] = x_buf[j].R(r, c);
+        for (int r = 0; r < 3; ++r) poses[12 * j + 9 + r] = x_buf[j].p[r];
+    }
+    lvba_lidar_ba_report rep;
+    const int32_t rc = lvba_lidar_ba_multi(static_cast<int32_t>(shares.size()), shares.data(), poses.data(), &opts, poses.data(), &rep);
+    const std::string msg = rc != LVBA_OK ? lvba_last_error() : "";
+    drop();
+    if (rc != LVBA_OK) throw std::runtime_error("lvba_lidar_ba_multi: " + msg);
+    for (int32_t j = 0; j < n; ++j) {
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) x_buf[j].R(r, c) = poses[12 * j + 3 * r + c];
+        for (int r = 0; r < 3; ++r) x_buf[j].p[r] = poses[12 * j + 9 + r];
+    }
+    return rep;
+}
+
 // ---- LvbaSystem::BuildTracksAndFuse3D (src/lvba_system.cpp:921-1263) ---------------------------------------------------------
 // One batch of components (observations = (image, key point) in BFS order) through lvba_fuse_tracks.  status[c] 0 = dropped,
 // 1 = triangulated, 2 = depth-fused; X [C][3]; kept: one flag per observation, components back to back.

@@ -78,6 +78,21 @@ int main()
         std::printf("refused: %s\n", e.what());
         if (!(lvba_device_count() == 0 && std::strstr(e.what(), "no CPU fallback"))) return 7;
     }
+    try { // the same over a device list (two shares; on a one-GPU box both on device 0): the windows dealt out, anchors gathered
+        std::vector<const Cloud *> four{&c0, &c1, &c0, &c1};
+        std::vector<IMUST> x4(4);
+        for (auto &s : x4) { std::memset(&s, 0, sizeof s); s.R(0, 0) = s.R(1, 1) = s.R(2, 2) = 1; }
+        lvba_lidar_ba_opts lo;
+        lvba_lidar_ba_default_opts(&lo);
+        lo.window.window_size = 2;
+        lo.window.voxel.voxel_size = 1.0; lo.stage_voxel_size[0] = lo.stage_voxel_size[1] = 1.0;
+        const auto rep = lvba::lidar_ba(four, x4, lo, std::vector<int>{0, 0});
+        std::printf("lidar_ba over two shares: %d windows, %d skipped, %d anchors\n", rep.n_windows, rep.n_windows_skipped, rep.n_anchors);
+        if (rep.n_windows != 2 || rep.n_frames != 4) return 16;
+    } catch (const std::exception &e) {
+        std::printf("refused: %s\n", e.what());
+        if (!(lvba_device_count() == 0 && std::strstr(e.what(), "no CPU fallback"))) return 17;
+    }
     try { // track fusion through the adapter: one landmark seen by five cameras on a line (triangulation candidate)
         struct Vec3 { double v[3]; double &operator[](int i) { return v[i]; } double operator[](int i) const { return v[i]; } };
         struct Kp { float x, y; };
