@@ -727,9 +727,16 @@ def front_end_leg(pkg, synth, with_cpu):
             clouds.append(c); poses.append(T)
     poses = np.asarray(poses)
     out = {"workload": f"{len(clouds)} scans x {len(clouds[0])} points (48-byte PCL stride on the host), 1.0 m root voxels"}
-    t0 = time.perf_counter()
-    scans = pkg.Scans(clouds)
-    out["upload_ms"] = 1e3 * (time.perf_counter() - t0)
+    ups = []
+    scans = None
+    for _ in range(2):     # (the first upload of a process also pays for the runtime's first pinned allocations: 17-20 ms became 85 on one box)
+        if scans is not None:
+            scans.close()
+        t0 = time.perf_counter()
+        scans = pkg.Scans(clouds)
+        ups.append(1e3 * (time.perf_counter() - t0))
+    out["upload_ms"] = min(ups)
+    out["upload_ms_first_call"] = ups[0]
     best, m = 1e9, None
     for _ in range(4):
         if m is not None:
