@@ -14,7 +14,7 @@
 //                                                    each -- as a bulk job of its own ("single job (e, tj' = 1)") it made the
 //                                                    second-half launches of config C3 534 workgroups on 512 seats
 //     X_{e+2}  pair job    (o + e, tj' in [1, cs)) = block columns e + 4 .. : the first half (at least tj' = 1, 2)
-//     X_{e+3}  pair job    (o + e, tj' >= cs)      the second half, beside the next pair's single job (block column e + 5 < e + 6)
+//     X_{e+3}  pair job    (o + e, tj' >= cs)      the second half, beside the next pair's q_extra products (block column e + 5 < e + 6)
 // Panels left over (an odd count, windows too short to pair) run their whole update as one single job in X_{q+1}.
 #pragma once
 #include <cstdint>
