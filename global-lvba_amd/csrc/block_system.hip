@@ -90,7 +90,7 @@ int32_t bs_init(BlockSys &bs, int device)
 {
     bs.device = device;
     HIPCHK(hipSetDevice(device));
-    HIPCHK(hipStreamCreateWithFlags(&bs.stream, hipStreamNonBlocking));
+    HIPCHK(lvba::StreamCache::get().acquire(&bs.stream));
     HIPCHK(hipHostMalloc((void **)&bs.h_pin_u, 2 * sizeof(double), hipHostMallocDefault)); // (re-made larger by a grouped problem, bs_build)
     return LVBA_OK;
 }
@@ -558,7 +558,7 @@ void bs_destroy(BlockSys &bs)
     for (void *p : ptrs)
         if (p) DevicePool::get().free(p);
     if (bs.h_pin_u) hipHostFree(bs.h_pin_u);
-    if (bs.stream) hipStreamDestroy(bs.stream);
+    if (bs.stream) lvba::StreamCache::get().release(bs.stream);
     bs = BlockSys();
 }
 

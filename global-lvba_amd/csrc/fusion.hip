@@ -174,8 +174,8 @@ extern "C" int32_t lvba_depth_render(lvba_scans_t sc, const double *scan_poses, 
     }
     struct Guard { lvba_depth_s *h; ~Guard() { if (h) { (void)hipFree(h->d_depth); delete h; } } } guard{h};
     hipStream_t s = nullptr;
-    HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    struct SG { hipStream_t s; ~SG() { (void)hipStreamDestroy(s); } } sg{s};
+    HIPCHK(lvba::StreamCache::get().acquire(&s));
+    struct SG { hipStream_t s; ~SG() { lvba::StreamCache::get().release(s); } } sg{s};
     if (n_images == 0) { *out = h; guard.h = nullptr; return LVBA_OK; }
     // every pixel starts at +inf
     HIPCHK(hipMemsetD32Async((hipDeviceptr_t)h->d_depth, 0x7f800000, (size_t)(n_images * npix), s));
@@ -317,8 +317,8 @@ extern "C" int32_t lvba_fuse_tracks(int32_t device, lvba_depth_t depth, int32_t 
     TRY(check_device(device));
     HIPCHK(hipSetDevice(device));
     hipStream_t s = nullptr;
-    HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    struct SG { hipStream_t s; ~SG() { (void)hipStreamDestroy(s); } } sg{s};
+    HIPCHK(lvba::StreamCache::get().acquire(&s));
+    struct SG { hipStream_t s; ~SG() { lvba::StreamCache::get().release(s); } } sg{s};
     DevBuf d_off(s), d_img(s), d_uv(s), d_R(s), d_t(s), d_pts(s), d_dirs(s), d_flag(s), d_idx(s), d_st(s), d_X(s), d_err(s), d_kept(s);
     const size_t O1 = (size_t)std::max<int64_t>(O, 1);
     HIPCHK(d_off.alloc(8 * ((size_t)n_tracks + 1))); HIPCHK(d_img.alloc(4 * O1)); HIPCHK(d_uv.alloc(8 * O1));

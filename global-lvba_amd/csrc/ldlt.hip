@@ -1234,6 +1234,199 @@ __device__ __forceinline__ void bulk_tile_k16(double *lds, LdltMat M, const Pane
     LVBA_BULK_STAMP(10);
 }
 
+// ------------------------------------------------------------------------------------ K3, 128 x 128 tiles, operands straight into LDS
+// Round 4 (late).  What the three forms above have in common: two workgroups per CU whose eight wavefronts share four matrix pipes
+// and run their phases in step, a register file half full of operands in flight, and prologue + epilogue once per 128 x 64 of C
+// (408 tiles of a two-problem launch alone: 28.9 - 30.3 us = 52 % of the issue rate).  This form is built the other way round:
+//   * 128 x 128 of C per workgroup, 64 x 64 per wavefront (wavefront w: rows 64 (w >> 1), columns 64 (w & 1)): 16 independent MFMAs
+//     per step of four columns behind 8 LDS reads, half the operand bytes per flop, half as many tiles -- ONE per CU and launch
+//     (204 + 82 role workgroups on 256 CUs), alone on its matrix pipes;
+//   * the operand chunks go from global memory STRAIGHT INTO LDS (buffer_load_dwordx4 ... lds: a wavefront's 64 x 16 bytes are one
+//     128-row column of a chunk, M0 = where it goes), no register sets, no stage step; a ring of LVBA_SQ_NBUF chunk buffers of
+//     LVBA_SQ_KC columns, chunk ch + NBUF - 1 is requested in front of the products of chunk ch, ONE barrier per chunk;
+//   * C is loaded into the accumulators (negated; the result is stored negated): no C registers besides them.
+// Loads into LDS cannot be masked on the way: an edge tile zeroes what lies outside the panel's window in LDS (one more barrier
+// per chunk, edge tiles only).
+#ifndef LVBA_SQ_KC
+#define LVBA_SQ_KC 16
+#endif
+#define LVBA_SQ_NBUF (32 / LVBA_SQ_KC)
+#define LVBA_SQ_BUF (2 * LVBA_SQ_KC * LVBA_TL)      // doubles: Ls[KC][TL] (rows of the tile), Zs[KC][TL] (its columns)
+#define LVBA_SQ_LDS (LVBA_SQ_NBUF * LVBA_SQ_BUF) // 64 * 144 doubles = 73.7 KB
+typedef __attribute__((address_space(3))) void lds_void_t;
+__device__ __forceinline__ void wait_vmcnt_le(int n) // s_waitcnt vmcnt(n) alone (n a constant after unrolling)
+{
+#define LVBA_VMCNT(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (7 << 4) | (15 << 8) | (((N) >> 4) << 14))
+    switch (n) {
+    case 0: LVBA_VMCNT(0); break;
+    case 2: LVBA_VMCNT(2); break;
+    case 4: LVBA_VMCNT(4); break;
+    case 6: LVBA_VMCNT(6); break;
+    case 8: LVBA_VMCNT(8); break;
+    case 12: LVBA_VMCNT(12); break;
+    case 16: LVBA_VMCNT(16); break;
+    case 24: LVBA_VMCNT(24); break;
+    default: LVBA_VMCNT(0); break;
+    }
+#undef LVBA_VMCNT
+}
+// A barrier that leaves the loads in flight alone (__syncthreads is a fence: it waits for vmcnt(0), i.e. for the chunks just
+// requested): this wavefront's LDS reads / writes are complete, then s_barrier.
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0) alone
+    __builtin_amdgcn_s_barrier();
+}
+// tile columns [ca, cb) in pairs (c, c + 1), c = ca, ca + 2, ...; a pair's tiles are the row pairs (c + 2u, c + 2u + 1) as in
+// pair_decode; ncol = 1 for the last column of an odd range
+__host__ __device__ __forceinline__ int64_t sq_job_items(int64_t ca, int64_t cb, int64_t Tb)
+{
+    int64_t n = 0;
+    for (int64_t c = ca; c < cb; c += 2) n += pair_col_items(c, Tb);
+    return n;
+}
+__device__ __forceinline__ bool sq_decode(int64_t j, int64_t ca, int64_t cb, int64_t Tb, int64_t &R0, int64_t &tj, int &ncol)
+{
+    for (int64_t c = ca; c < cb; c += 2) {
+        const int64_t n = pair_col_items(c, Tb);
+        if (j < n) { tj = c; R0 = c + 2 * j; ncol = c + 1 < cb ? 2 : 1; return true; }
+        j -= n;
+    }
+    return false;
+}
+template <int npan> // 1: panel o alone (K = 64); 2: panel e, then its partner o (K = 128)
+__device__ __forceinline__ void bulk_tile_sq(double *lds, LdltMat M, const PanelRef po, const PanelRef pe, int64_t ldz64, int64_t R0,
+                                             int64_t tj, int ncol)
+{
+    constexpr int KC = LVBA_SQ_KC, NBUF = LVBA_SQ_NBUF, CPP = 64 / KC, nch = CPP * npan, LPC = KC / 2; // LPC: loads per chunk and wavefront
+    const int tid = threadIdx.x, lane = tid & 63;
+    const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned wr = w >> 1, wc = w & 1;
+    const int i = lane & 15, kk = lane >> 4;
+    const int64_t r0 = po.w0 + 64 * (R0 + 1), c0 = po.w0 + 64 * (tj + 1);
+    const bool two = r0 + 64 < po.rend;
+    const bool busy = (wr == 0 || two) && (wc == 0 || ncol == 2) && !(R0 == tj && wr == 0 && wc == 1); // (0, 1) of a diagonal tile lies above the diagonal
+    const unsigned ld = (unsigned)M.ld, ldz = (unsigned)ldz64; // byte offsets in 32 bits (see bulk_tile_128)
+    const __amdgpu_buffer_rsrc_t rA = buf_of(M.a), rZo = buf_of(po.Z), rZe = buf_of(npan == 2 ? pe.Z : po.Z);
+    const unsigned lvoff = 16u * (unsigned)lane; // rows 2 lane, 2 lane + 1 of a chunk column: 16 bytes per lane, 1 KB per wavefront
+    auto fetch = [&](int ch) { // chunk ch -> buffer ch % NBUF; wavefront w: columns w + 4 it of the L part and of the Z part
+        const bool use_e = npan == 2 && ch < CPP;
+        const unsigned qk = (unsigned)(use_e ? pe.k : po.k), zr = (unsigned)(c0 - (use_e ? pe.w0 : po.w0));
+        const unsigned m0 = (unsigned)(KC * (ch % CPP));
+        double *Ls = lds + (ch % NBUF) * LVBA_SQ_BUF, *Zs = Ls + KC * LVBA_TL;
+        const unsigned lsoff = 8u * ((unsigned)r0 + (qk + m0 + w) * ld), zsoff = 8u * (zr + (m0 + w) * ldz);
+#pragma unroll
+        for (int it = 0; it < KC / 4; ++it)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t *)(Ls + (w + 4 * it) * LVBA_TL), 16, lvoff, lsoff + (unsigned)it * (32u * ld), 0, 0);
+#pragma unroll
+        for (int it = 0; it < KC / 4; ++it)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(use_e ? rZe : rZo, (lds_void_t *)(Zs + (w + 4 * it) * LVBA_TL), 16, lvoff,
+                                                     zsoff + (unsigned)it * (32u * ldz), 0, 0);
+    };
+    auto mask_edge = [&](int ch) { // (workgroup-uniform) zero what lies outside the panel's window: rows, columns of the chunk
+        const bool use_e = npan == 2 && ch < CPP;
+        const int64_t qrend = use_e ? pe.rend : po.rend;
+        const int qnbe = use_e ? pe.nbe : po.nbe;
+        if (r0 + 128 <= qrend && c0 + 128 <= qrend && qnbe == 64) return;
+        double *Ls = lds + (ch % NBUF) * LVBA_SQ_BUF, *Zs = Ls + KC * LVBA_TL;
+        const int m0 = KC * (ch % CPP);
+#pragma unroll
+        for (int idx = tid; idx < KC * 128; idx += 256) {
+            const int m = idx >> 7, row = idx & 127;
+            const bool mok = m0 + m < qnbe;
+            if (!(mok && r0 + row < qrend)) Ls[m * LVBA_TL + row] = 0.0;
+            if (!(mok && c0 + row < qrend)) Zs[m * LVBA_TL + row] = 0.0;
+        }
+        lds_barrier();
+    };
+    // acc[tr][tc][reg] <-> row r0 + 64 wr + 16 tr + i, column c0 + 64 wc + 16 tc + kk + 4 reg
+    d4 acc[4][4];
+    const unsigned cvoff = 8u * ((unsigned)i + (unsigned)kk * ld);
+    const unsigned csoff = 8u * ((unsigned)r0 + 64u * wr + ((unsigned)c0 + 64u * wc) * ld);
+    LVBA_BULK_STAMP(0);
+    if (busy) { // -C: unmasked -- entries outside the window or above the diagonal are read (inside the allocation) but never stored
+#pragma unroll
+        for (int tc = 0; tc < 4; ++tc)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const unsigned so = csoff + 8u * (unsigned)(16 * tc + 4 * reg) * ld;
+#pragma unroll
+                for (int tr = 0; tr < 4; ++tr) acc[tr][tc][reg] = buf_ld(rA, cvoff + 128u * tr, so);
+            }
+    } else {
+#pragma unroll
+        for (int tr = 0; tr < 4; ++tr)
+#pragma unroll
+            for (int tc = 0; tc < 4; ++tc) acc[tr][tc] = (d4){0.0, 0.0, 0.0, 0.0};
+    }
+#pragma unroll
+    for (int ch = 0; ch < NBUF - 1 && ch < nch; ++ch) fetch(ch);
+    wait_vmcnt_le(LPC * ((NBUF - 1 < nch ? NBUF - 1 : nch) - 1)); // chunk 0 (and C, requested before it) has arrived
+    lds_barrier();
+    if (busy) {
+#pragma unroll
+        for (int tr = 0; tr < 4; ++tr)
+#pragma unroll
+            for (int tc = 0; tc < 4; ++tc)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) acc[tr][tc][reg] = -acc[tr][tc][reg];
+    }
+    LVBA_BULK_STAMP(1);
+    auto products = [&](int ch) {
+        if (!busy) return;
+        const double *Ls = lds + (ch % NBUF) * LVBA_SQ_BUF, *Zs = Ls + KC * LVBA_TL;
+        double a[2][4], bv[2][4];
+        auto rd = [&](int k0, int q) {
+#pragma unroll
+            for (int tc = 0; tc < 4; ++tc) a[q][tc] = Zs[(k0 + kk) * LVBA_TL + 64 * wc + 16 * tc + i];
+#pragma unroll
+            for (int tr = 0; tr < 4; ++tr) bv[q][tr] = Ls[(k0 + kk) * LVBA_TL + 64 * wr + 16 * tr + i];
+        };
+        rd(0, 0);
+#pragma unroll
+        for (int k0 = 0; k0 < KC; k0 += 4) {
+            const int q = (k0 >> 2) & 1;
+            if (k0 + 4 < KC) rd(k0 + 4, q ^ 1);
+            __builtin_amdgcn_sched_barrier(0); // the reads stay AHEAD of the MFMAs
+#pragma unroll
+            for (int tr = 0; tr < 4; ++tr)
+#pragma unroll
+                for (int tc = 0; tc < 4; ++tc) acc[tr][tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][tc], bv[q][tr], acc[tr][tc], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+#pragma unroll
+    for (int ch = 0; ch < nch; ++ch) {
+        // here: chunk ch is in LDS and visible to everybody; buffer (ch - 1) % NBUF has been left by everybody
+        if (ch + NBUF - 1 < nch) fetch(ch + NBUF - 1);
+        mask_edge(ch);
+        products(ch);
+        if (ch < 5) LVBA_BULK_STAMP(2 + ch);
+        if (ch + 1 < nch) {
+            const int last = ch + NBUF - 1 < nch - 1 ? ch + NBUF - 1 : nch - 1; // last chunk requested so far
+            wait_vmcnt_le(LPC * (last - (ch + 1)));                             // chunk ch + 1 has arrived (requests complete in order)
+            lds_barrier();
+        }
+    }
+    LVBA_BULK_STAMP(8);
+    if (busy) {
+        const bool inner = r0 + 128 <= po.rend && r0 >= c0 + 128; // whole tile inside the window and below the diagonal
+#pragma unroll
+        for (int tc = 0; tc < 4; ++tc)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const unsigned so = csoff + 8u * (unsigned)(16 * tc + 4 * reg) * ld;
+                const int64_t c = c0 + 64 * wc + 16 * tc + kk + 4 * reg;
+#pragma unroll
+                for (int tr = 0; tr < 4; ++tr) {
+                    const int64_t r = r0 + 64 * wr + 16 * tr + i;
+                    if (inner || (r < po.rend && c < po.rend && r >= c)) buf_st(rA, -acc[tr][tc][reg], cvoff + 128u * tr, so);
+                }
+            }
+    }
+    LVBA_BULK_STAMP(10);
+}
+
 // One launch for two independent pieces of work: the factorisation of panel p+1 (diag + panel tiles) and the bulk of the
 // trailing update of panel p (tiles ti >= tj >= 1).  The former touches block column p+1 only, the latter block columns >= p+2,
 // and neither waits for the other inside the launch -- the only ordering is between launches: update(first column of p) -> this
@@ -1697,7 +1890,7 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
     // buffers, one workgroup per CU: 4.87 ms)
     static const int bulk_tile = [] {
         const char *e = getenv("LVBA_BULK_TILE");
-        return !e ? 0 : !strcmp(e, "k16") ? 2 : !strcmp(e, "k32db") ? 1 : 0;
+        return !e ? 0 : !strcmp(e, "k16") ? 2 : !strcmp(e, "k32db") ? 1 : !strcmp(e, "sq") ? 3 : 0;
     }();
     static const bool chain_alone = [] { const char *e = getenv("LVBA_CHAIN_ALONE"); return !(e && !strcmp(e, "0")); }();
     static const int n_cus = [] {
@@ -1742,7 +1935,9 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
                 J.o = pg(sj.o); J.Zo = Zbuf[sj.o % 4] + wo; J.pair = sj.pair;
                 if (sj.pair) { J.e = pg(sj.o - 1); J.Ze = Zbuf[(sj.o - 1) % 4] + wo; }
                 const int64_t Tb = J.o.T - 1;
-                if (big) {
+                if (big && bulk_tile == 3) {
+                    J.ca = sj.ca; J.cb = sj.cb; J.nwg = sq_job_items(sj.ca, sj.cb, Tb);
+                } else if (big) {
                     J.ca = sj.ca; J.cb = sj.cb; J.nwg = 0;
                     for (int64_t c = sj.ca; c < sj.cb; ++c) J.nwg += pair_col_items(c, Tb);
                 } else {
@@ -1759,7 +1954,8 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
                 grid += ny;
             }
             if (nwg > 0) {
-                if (bt == 2) hipLaunchKernelGGL((ldlt_step2_kernel<true, 2>), dim3((unsigned)grid), dim3(256), 0, s, a);
+                if (bt == 3) hipLaunchKernelGGL((ldlt_step2_kernel<true, 3>), dim3((unsigned)grid), dim3(256), 0, s, a);
+                else if (bt == 2) hipLaunchKernelGGL((ldlt_step2_kernel<true, 2>), dim3((unsigned)grid), dim3(256), 0, s, a);
                 else if (bt == 1) hipLaunchKernelGGL((ldlt_step2_kernel<true, 1>), dim3((unsigned)grid), dim3(256), 0, s, a);
                 else if (big) hipLaunchKernelGGL((ldlt_step2_kernel<true, 0>), dim3((unsigned)grid), dim3(256), 0, s, a);
                 else hipLaunchKernelGGL((ldlt_step2_kernel<false, 0>), dim3((unsigned)grid), dim3(256), 0, s, a);

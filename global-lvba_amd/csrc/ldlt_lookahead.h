@@ -420,11 +420,13 @@ __device__ __forceinline__ void row_role(double *lds, const LdltMat &M, const St
 // BT, the bulk tile: 0 = bulk_tile_128 (K chunks of 32, one chunk buffer; 80 KB, two workgroups per CU)
 //                    1 = bulk_tile_128<.., true> (two chunk buffers of K = 32: 114 KB, one workgroup per CU)
 //                    2 = bulk_tile_k16 (K chunks of 16, two chunk buffers, three register sets; 80 KB with the roles, two per CU)
+//                    3 = bulk_tile_sq (128 x 128 tiles, 64 x 64 per wavefront, operand chunks loaded straight into LDS)
 template <bool big, int BT>
 __global__ __launch_bounds__(256, BT == 1 ? 1 : 2) void ldlt_step2_kernel(const Step2Args A)
 {
     __shared__ double lds[BT == 1 ? (LVBA_K3DB_LDS > LVBA_K3_LDS ? LVBA_K3DB_LDS : LVBA_K3_LDS) : LVBA_K3_LDS];
-    static_assert(LVBA_K1B_LDS <= LVBA_K3_LDS && LVBA_K3B_LDS <= LVBA_K3_LDS && LVBA_K16_LDS <= LVBA_K3_LDS && LVBA_PAD_RED + 256 <= 1024,
+    static_assert(LVBA_K1B_LDS <= LVBA_K3_LDS && LVBA_K3B_LDS <= LVBA_K3_LDS && LVBA_K16_LDS <= LVBA_K3_LDS && LVBA_SQ_LDS <= LVBA_K3_LDS &&
+                      LVBA_PAD_RED + 256 <= 1024,
                   "LDS budget of the roles");
     static_assert(BT == 0 || big, "the other bulk tiles exist for the 128 x 64 form only");
     const int64_t nrole = A.roles ? A.p.T : 0, nfac = nrole * A.nprob;
@@ -465,8 +467,15 @@ __global__ __launch_bounds__(256, BT == 1 ? 1 : 2) void ldlt_step2_kernel(const 
         const double *Zo = J.Zo + wo, *Ze = J.pair ? J.Ze + wo : nullptr;
         if constexpr (big) {
             int64_t R0, tj;
-            if (!pair_decode(J.dbg_same ? 0 : bx, J.ca, J.cb, (int64_t)J.o.T - 1, R0, tj)) return;
             const PanelRef po{J.o.k, J.o.w0, J.o.rend, J.o.nbe, Zo}, pe{J.e.k, J.e.w0, J.e.rend, J.e.nbe, Ze};
+            if constexpr (BT == 3) {
+                int ncol;
+                if (!sq_decode(J.dbg_same ? 0 : bx, J.ca, J.cb, (int64_t)J.o.T - 1, R0, tj, ncol)) return;
+                if (J.pair) bulk_tile_sq<2>(lds, M, po, pe, A.ldz, R0, tj, ncol);
+                else bulk_tile_sq<1>(lds, M, po, pe, A.ldz, R0, tj, ncol);
+                return;
+            }
+            if (!pair_decode(J.dbg_same ? 0 : bx, J.ca, J.cb, (int64_t)J.o.T - 1, R0, tj)) return;
             if constexpr (BT == 2) {
                 if (J.pair) bulk_tile_k16<2>(lds, M, po, pe, A.ldz, R0, tj);
                 else bulk_tile_k16<1>(lds, M, po, pe, A.ldz, R0, tj);

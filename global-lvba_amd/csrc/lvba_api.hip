@@ -98,7 +98,7 @@ extern "C" void lvba_shard_range(int64_t V, int32_t rank, int32_t G, int64_t *he
 
 // ------------------------------------------------------------------------------------------ create
 static int32_t balm_create_impl(int32_t n_poses, int64_t n_voxels, const int64_t *voxel_off, const int32_t *pose_idx,
-                                const double *clusters, const double *d_clusters, int32_t device, lvba_balm_t *out);
+                                const double *clusters, const double *d_clusters, int32_t device, lvba_balm_t *out, bool trusted = false);
 
 extern "C" int32_t lvba_balm_create(int32_t n_poses, int64_t n_voxels, const int64_t *voxel_off,
                                     const int32_t *pose_idx, const double *clusters, int32_t device,
@@ -107,6 +107,17 @@ extern "C" int32_t lvba_balm_create(int32_t n_poses, int64_t n_voxels, const int
     return balm_create_impl(n_poses, n_voxels, voxel_off, pose_idx, clusters, nullptr, device, out);
 }
 
+// (internal, window_ba.hip) the caller vouches for its arrays -- they come out of this library's own voxel maps: no range checks,
+// no voxel re-layout pass (1.1 of the 7.3 ms the joint LM of bench.py's window leg took)
+namespace lvba {
+int32_t balm_create_dev_trusted(int32_t n_poses, int64_t n_voxels, const int64_t *voxel_off, const int32_t *pose_idx,
+                                const double *d_clusters, int32_t device, lvba_balm_t *out)
+{
+    if (!d_clusters) return fail(LVBA_ERR_ARG, "d_clusters is NULL");
+    return balm_create_impl(n_poses, n_voxels, voxel_off, pose_idx, nullptr, d_clusters, device, out, true);
+}
+} // namespace lvba
+
 extern "C" int32_t lvba_balm_create_dev(int32_t n_poses, int64_t n_voxels, const int64_t *voxel_off, const int32_t *pose_idx,
                                         const double *d_clusters, int32_t device, lvba_balm_t *out)
 {
@@ -114,7 +125,7 @@ extern "C" int32_t lvba_balm_create_dev(int32_t n_poses, int64_t n_voxels, const
 }
 
 static int32_t balm_create_impl(int32_t n_poses, int64_t n_voxels, const int64_t *voxel_off, const int32_t *pose_idx,
-                                const double *clusters, const double *d_clusters, int32_t device, lvba_balm_t *out)
+                                const double *clusters, const double *d_clusters, int32_t device, lvba_balm_t *out, bool trusted)
 {
     if (!out) return fail(LVBA_ERR_ARG, "out is NULL");
     *out = nullptr;
@@ -141,11 +152,11 @@ static int32_t balm_create_impl(int32_t n_poses, int64_t n_voxels, const int64_t
     // one pass over the voxels: >= 2 factors each, pose indices in range, and the first pose that sees each voxel (for the
     // re-layout decision below; only needed from the size on from which the pair lists are windowed)
     static const bool allow_sort = [] { const char *e = getenv("LVBA_VOXEL_SORT"); return !(e && !strcmp(e, "0")); }();
-    const bool want_key = allow_sort && 18 * 8 * F > ((int64_t)24 << 20) && n_voxels > 1;
+    const bool want_key = !trusted && allow_sort && 18 * 8 * F > ((int64_t)24 << 20) && n_voxels > 1;
     lvba::hvec<int32_t> key;
     if (want_key) key.resize((size_t)n_voxels);
     double jump = 0.0;
-    for (int64_t a = 0; a < n_voxels; ++a) {
+    for (int64_t a = 0; a < (trusted ? 0 : n_voxels); ++a) { // (trusted: the window driver's own voxel maps, window_ba.hip)
         const int64_t f0 = voxel_off[a] - base, f1 = voxel_off[a + 1] - base;
         if (f1 - f0 < 2) return fail(LVBA_ERR_ARG, "voxel %lld has %lld factors (< 2)", (long long)a, (long long)(f1 - f0));
         int32_t lo = 0x7fffffff, hi = -1;
@@ -252,7 +263,7 @@ static int32_t balm_create_impl(int32_t n_poses, int64_t n_voxels, const int64_t
         if (d_fmap) { lvba::DevicePool::get().free(d_fmap); bs.device_bytes -= (int64_t)F * (int64_t)sizeof(int32_t); }
     }
     mark("device arrays");
-    CHIP(hipHostMalloc((void **)&h->h_pin, 16 * sizeof(double), hipHostMallocDefault));
+    CHIP(lvba::PinnedCache::get().acquire((void **)&h->h_pin, 4096)); // (16 doubles; one size for the cache's sake)
     for (int e = 0; e < EV_N; ++e)
         for (int s = 0; s < 2; ++s) CHIP(hipEventCreate(&h->ev[e][s]));
     mark("pinned + events");
@@ -272,9 +283,9 @@ extern "C" int32_t lvba_balm_destroy(lvba_balm_t h)
                     h->d_gscal};
     for (void *p : ptrs)
         if (p) lvba::DevicePool::get().free(p);
-    if (h->h_pin) hipHostFree(h->h_pin);
-    if (h->h_gpin) hipHostFree(h->h_gpin);
-    if (h->h_gacc) hipHostFree(h->h_gacc);
+    lvba::PinnedCache::get().release(h->h_pin);
+    lvba::PinnedCache::get().release(h->h_gpin);
+    lvba::PinnedCache::get().release(h->h_gacc);
     for (int e = 0; e < EV_N; ++e)
         for (int s = 0; s < 2; ++s)
             if (h->ev[e][s]) hipEventDestroy(h->ev[e][s]);
@@ -794,8 +805,8 @@ extern "C" int32_t lvba_balm_set_groups(lvba_balm_t h, int32_t n_groups, const i
     HIPCHK(lvba::copy_h2d(h->d_grp_of_pose, gof.data(), (size_t)h->N * sizeof(int32_t)));
     HIPCHK(lvba::copy_h2d(h->d_gpo, pose_off, (size_t)(n_groups + 1) * sizeof(int32_t)));
     HIPCHK(lvba::copy_h2d(h->d_gco, gco.data(), (size_t)(n_groups + 1) * sizeof(int64_t)));
-    HIPCHK(hipHostMalloc((void **)&h->h_gpin, 3 * (size_t)n_groups * sizeof(double), hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void **)&h->h_gacc, (size_t)n_groups * sizeof(int32_t), hipHostMallocDefault));
+    HIPCHK(lvba::PinnedCache::get().acquire((void **)&h->h_gpin, std::max<size_t>(4096, 3 * (size_t)n_groups * sizeof(double))));
+    HIPCHK(lvba::PinnedCache::get().acquire((void **)&h->h_gacc, std::max<size_t>(4096, (size_t)n_groups * sizeof(int32_t))));
     // the caller's pose order is the solver's: the block-diagonal structure stays, and pose -> group is a plain table
     bs.ordering = 0;
     bs.n_groups = n_groups;

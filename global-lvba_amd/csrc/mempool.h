@@ -98,6 +98,122 @@ class DevicePool {
     size_t cached_ = 0;
 };
 
+// Streams are cached too: hipStreamCreate costs ~0.1 ms and hipStreamDestroy ~0.6 ms (measured, round 2: it waits for the
+// device's queues), and a window stage used to create and destroy seven of them per call (one per worker thread, one per handle):
+// 2.8 of the 16 ms of bench.py's window leg.  acquire() hands out an idle non-blocking stream of the current device, release()
+// takes it back (draining it first if the caller has not); lvba_release_cached_memory() destroys what is cached.
+class StreamCache {
+  public:
+    static StreamCache &get()
+    {
+        static StreamCache c;
+        return c;
+    }
+    hipError_t acquire(hipStream_t *s)
+    {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            auto &v = free_[dev];
+            if (!v.empty()) {
+                *s = v.back();
+                v.pop_back();
+                owner_[*s] = dev;
+                return hipSuccess;
+            }
+        }
+        const hipError_t e = hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+        if (e == hipSuccess) {
+            std::lock_guard<std::mutex> g(mu_);
+            owner_[*s] = dev;
+        }
+        return e;
+    }
+    void release(hipStream_t s)
+    {
+        if (!s) return;
+        if (hipStreamQuery(s) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(s); }
+        std::lock_guard<std::mutex> g(mu_);
+        auto it = owner_.find(s);
+        if (it == owner_.end()) { (void)hipStreamDestroy(s); return; }
+        auto &v = free_[it->second];
+        owner_.erase(it);
+        if (v.size() < kKeep) v.push_back(s);
+        else (void)hipStreamDestroy(s);
+    }
+    void release_all()
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        for (auto &kv : free_) {
+            for (hipStream_t q : kv.second) (void)hipStreamDestroy(q);
+            kv.second.clear();
+        }
+    }
+
+  private:
+    static constexpr size_t kKeep = 16; // per device
+    std::mutex mu_;
+    std::map<int, std::vector<hipStream_t>> free_;
+    std::map<hipStream_t, int> owner_;
+};
+
+// Pinned staging memory for the scan upload (voxelize.hip: 24 MB per call): hipHostMalloc / hipHostFree of that size cost
+// milliseconds and the unpinning stalls the device's queues (host_arena.h); a refinement handle's three small zero-copy blocks come
+// from here too.  At most kKeep blocks stay cached.
+class PinnedCache {
+  public:
+    static PinnedCache &get()
+    {
+        static PinnedCache c;
+        return c;
+    }
+    hipError_t acquire(void **p, size_t bytes)
+    {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            for (size_t i = 0; i < free_.size(); ++i)
+                if (free_[i].second >= bytes && free_[i].second <= 2 * bytes + ((size_t)1 << 20)) {
+                    *p = free_[i].first;
+                    owner_[*p] = free_[i].second;
+                    free_.erase(free_.begin() + (ptrdiff_t)i);
+                    return hipSuccess;
+                }
+        }
+        const hipError_t e = hipHostMalloc(p, bytes, hipHostMallocDefault);
+        if (e == hipSuccess) {
+            std::lock_guard<std::mutex> g(mu_);
+            owner_[*p] = bytes;
+        }
+        return e;
+    }
+    void release(void *p) // (no copy out of p is in flight any more)
+    {
+        if (!p) return;
+        std::lock_guard<std::mutex> g(mu_);
+        auto it = owner_.find(p);
+        if (it == owner_.end()) { (void)hipHostFree(p); return; }
+        const size_t bytes = it->second;
+        owner_.erase(it);
+        if (free_.size() < kKeep) free_.emplace_back(p, bytes);
+        else (void)hipHostFree(p);
+    }
+    size_t release_all()
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        size_t n = 0;
+        for (auto &b : free_) { n += b.second; (void)hipHostFree(b.first); }
+        free_.clear();
+        return n;
+    }
+
+  private:
+    static constexpr size_t kKeep = 8;
+    std::mutex mu_;
+    std::vector<std::pair<void *, size_t>> free_;
+    std::map<void *, size_t> owner_;
+};
+
 // Host <-> device copies of set-up tables from / to the caller's or the library's PAGEABLE memory.  The runtime moves small
 // transfers through its own staging buffers, but pins the user pages for transfers from 4 MB up (GPU_PINNED_MIN_XFER_SIZE) and
 // unpins them afterwards; every set-up table is a temporary std::vector that is freed right after.  Unmapping host memory the

@@ -60,8 +60,8 @@ extern "C" int32_t lvba_triangulate_tracks(int32_t device, int32_t n_cams, int64
     if (device < 0 || device >= ndev) return lvba_fail(LVBA_ERR_ARG, "device %d out of range [0,%d)", device, ndev);
     HIPCHK(hipSetDevice(device));
     hipStream_t s = nullptr;
-    HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    struct SG { hipStream_t s; ~SG() { (void)hipStreamDestroy(s); } } sg{s};
+    HIPCHK(lvba::StreamCache::get().acquire(&s));
+    struct SG { hipStream_t s; ~SG() { lvba::StreamCache::get().release(s); } } sg{s};
     DevBuf d_off(s), d_cam(s), d_uv(s), d_R(s), d_t(s), d_X(s), d_err(s), d_cnt(s), d_ok(s);
     HIPCHK(d_off.alloc(8 * ((size_t)n_tracks + 1))); HIPCHK(d_cam.alloc(4 * (size_t)O)); HIPCHK(d_uv.alloc(16 * (size_t)O));
     HIPCHK(d_R.alloc(72 * (size_t)n_cams)); HIPCHK(d_t.alloc(24 * (size_t)n_cams));

@@ -26,7 +26,11 @@ struct lvba_scans_s;
 int32_t lvba_voxmap_build_scans_on(lvba_scans_s *sc, int32_t frame_begin, int32_t n_frames, const double *poses,
                                    const lvba_voxel_opts *opts, hipStream_t stream, lvba_voxmap_s **out);
 
+struct lvba_balm_s;
 namespace lvba {
+// lvba_balm_create_dev without the argument checks and the voxel re-layout pass (lvba_api.hip; for arrays this library made itself)
+int32_t balm_create_dev_trusted(int32_t n_poses, int64_t n_voxels, const int64_t *voxel_off, const int32_t *pose_idx,
+                                const double *d_clusters, int32_t device, lvba_balm_s **out);
 
 inline double now_ms()
 {

@@ -580,7 +580,11 @@ struct lvba_voxmap_s {
 
 const double *lvba_voxmap_clusters(const lvba_voxmap_s *h) { return h ? h->d_clusters : nullptr; }
 
-extern "C" int64_t lvba_release_cached_memory(void) { return (int64_t)DevicePool::get().release() + (int64_t)lvba::HostArena::get().release(); }
+extern "C" int64_t lvba_release_cached_memory(void)
+{
+    lvba::StreamCache::get().release_all();
+    return (int64_t)DevicePool::get().release() + (int64_t)lvba::HostArena::get().release() + (int64_t)lvba::PinnedCache::get().release_all();
+}
 
 extern "C" void lvba_voxel_default_opts(lvba_voxel_opts *o)
 {
@@ -642,54 +646,70 @@ extern "C" int32_t lvba_scans_create(int32_t device, int32_t n_frames, const voi
     static const bool upload_2d = [] { const char *v = getenv("LVBA_UPLOAD"); return v && !strcmp(v, "memcpy2d"); }();
     bool packed_path = point_stride_bytes != 12 && !upload_2d && P > 0;
     if (packed_path) {
-        const int64_t kChunk = (int64_t)1 << 20;
-        void *pin[2] = {nullptr, nullptr};
-        hipEvent_t done[2] = {nullptr, nullptr};
-        hipStream_t us = nullptr;
-        if (hipHostMalloc(&pin[0], 12 * (size_t)kChunk, hipHostMallocDefault) != hipSuccess ||
-            hipHostMalloc(&pin[1], 12 * (size_t)kChunk, hipHostMallocDefault) != hipSuccess ||
-            hipEventCreateWithFlags(&done[0], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&done[1], hipEventDisableTiming) != hipSuccess ||
-            hipStreamCreateWithFlags(&us, hipStreamNonBlocking) != hipSuccess) {
+        // Every worker thread owns a contiguous run of the points (across frames), two pinned slots of kSub points and a stream:
+        // pack a slot, send it, pack the other one while it travels -- no thread waits for another.  (Round 3's form spawned its
+        // packing threads anew for every frame-sized chunk and allocated / freed its 24 MB of pinned memory per call: 17-20 ms
+        // for 16 M points at a 48-byte stride; this form 9-13 ms with 4-8 threads, 11 with two, 23 with one: the packing is the
+        // bound up to two threads, the link after that.)  The pinned block and the streams come from caches (mempool.h).
+        const int64_t kSub = (int64_t)1 << 17; // points per slot: 1.5 MB
+        unsigned nthr = std::thread::hardware_concurrency();
+        nthr = std::max(1u, std::min(nthr ? nthr : 1u, 8u));
+        if (const char *v = getenv("LVBA_UPLOAD_THREADS")) nthr = (unsigned)std::max(1, atoi(v));
+        nthr = (unsigned)std::max<int64_t>(1, std::min<int64_t>(nthr, P / 65536));
+        const size_t slot_bytes = 12 * (size_t)kSub;
+        void *pin = nullptr;
+        if (lvba::PinnedCache::get().acquire(&pin, 2 * slot_bytes * nthr) != hipSuccess) {
             (void)hipGetLastError();
             packed_path = false; // no pinned memory to be had: the plain path below
         }
         if (packed_path) {
-            unsigned nthr = std::thread::hardware_concurrency();
-            nthr = std::max(1u, std::min(nthr ? nthr : 1u, 8u));
-            if (const char *v = getenv("LVBA_UPLOAD_THREADS")) nthr = (unsigned)std::max(1, atoi(v));
-            int slot = 0;
-            bool used[2] = {false, false};
-            e = hipSuccess;
-            for (int f = 0; f < n_frames && e == hipSuccess; ++f)
-                for (int64_t c0 = 0; c0 < frame_count[f] && e == hipSuccess; c0 += kChunk) {
-                    const int64_t cn = std::min(kChunk, frame_count[f] - c0);
-                    if (used[slot] && (e = hipEventSynchronize(done[slot])) != hipSuccess) break; // its last copy has left the buffer
-                    const char *src = static_cast<const char *>(frame_points[f]) + (size_t)c0 * (size_t)point_stride_bytes;
-                    float *dstp = static_cast<float *>(pin[slot]);
-                    auto pack = [&](int64_t a, int64_t b) {
-                        for (int64_t i = a; i < b; ++i) memcpy(dstp + 3 * i, src + (size_t)i * (size_t)point_stride_bytes, 12);
-                    };
-                    const unsigned nt = (unsigned)std::min<int64_t>(nthr, std::max<int64_t>(1, cn / 65536));
-                    if (nt <= 1) pack(0, cn);
-                    else {
-                        std::vector<std::thread> th;
-                        for (unsigned t = 1; t < nt; ++t) th.emplace_back(pack, cn * t / nt, cn * (t + 1) / nt);
-                        pack(0, cn / nt);
-                        for (auto &q : th) q.join();
+            std::vector<hipError_t> errs(nthr, hipSuccess);
+            const int64_t *foff = sc->frame_off.data();
+            auto work = [&](unsigned t) {
+                hipError_t &er = errs[t];
+                hipStream_t us = nullptr;
+                hipEvent_t ev[2] = {nullptr, nullptr};
+                if ((er = hipSetDevice(device)) != hipSuccess) return;
+                if ((er = lvba::StreamCache::get().acquire(&us)) != hipSuccess) return;
+                for (int k = 0; k < 2 && er == hipSuccess; ++k) er = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
+                const int64_t g0 = P * (int64_t)t / nthr, g1 = P * (int64_t)(t + 1) / nthr;
+                int f = (int)(std::upper_bound(foff, foff + n_frames + 1, g0) - foff) - 1;
+                f = std::max(0, std::min(f, n_frames - 1));
+                bool used[2] = {false, false};
+                int k = 0;
+                for (int64_t g = g0; g < g1 && er == hipSuccess; g += kSub, k ^= 1) {
+                    const int64_t gend = std::min(g + kSub, g1);
+                    if (used[k] && (er = hipEventSynchronize(ev[k])) != hipSuccess) break; // its last copy has left the slot
+                    float *dst = reinterpret_cast<float *>(static_cast<char *>(pin) + (2 * (size_t)t + (size_t)k) * slot_bytes);
+                    for (int64_t i = g; i < gend;) {
+                        while (foff[f + 1] <= i) ++f; // (frames without points)
+                        const int64_t fe = std::min(gend, foff[f + 1]);
+                        const char *src = static_cast<const char *>(frame_points[f]) + (size_t)(i - foff[f]) * (size_t)point_stride_bytes;
+                        for (; i < fe; ++i, src += point_stride_bytes, dst += 3) memcpy(dst, src, 12);
                     }
-                    e = hipMemcpyAsync(sc->d_pts + 3 * (sc->frame_off[f] + c0), pin[slot], 12 * (size_t)cn, hipMemcpyHostToDevice, us);
-                    if (e == hipSuccess) e = hipEventRecord(done[slot], us);
-                    used[slot] = true;
-                    slot ^= 1;
+                    er = hipMemcpyAsync(sc->d_pts + 3 * g, static_cast<char *>(pin) + (2 * (size_t)t + (size_t)k) * slot_bytes,
+                                        12 * (size_t)(gend - g), hipMemcpyHostToDevice, us);
+                    if (er == hipSuccess) er = hipEventRecord(ev[k], us);
+                    used[k] = true;
                 }
-            if (e == hipSuccess) e = hipStreamSynchronize(us);
+                const hipError_t es = hipStreamSynchronize(us);
+                if (er == hipSuccess) er = es;
+                for (int q = 0; q < 2; ++q)
+                    if (ev[q]) (void)hipEventDestroy(ev[q]);
+                lvba::StreamCache::get().release(us);
+            };
+            {
+                std::vector<std::thread> th;
+                for (unsigned t = 1; t < nthr; ++t) th.emplace_back(work, t);
+                work(0);
+                for (auto &q : th) q.join();
+            }
+            e = hipSuccess;
+            for (hipError_t q : errs)
+                if (q != hipSuccess) e = q;
+            (void)hipSetDevice(device);
         }
-        if (us) (void)hipStreamDestroy(us);
-        for (int k = 0; k < 2; ++k) {
-            if (done[k]) (void)hipEventDestroy(done[k]);
-            if (pin[k]) (void)hipHostFree(pin[k]);
-        }
+        lvba::PinnedCache::get().release(pin);
         if (packed_path && e != hipSuccess) return fail(e, "packed upload (points)");
     }
     if (!packed_path)
@@ -715,7 +735,7 @@ extern "C" int32_t lvba_voxmap_destroy(lvba_voxmap_t h)
     void *ptrs[] = {h->d_root_key, h->d_mask, h->d_rootinfo, h->d_plane_first, h->d_plane,
                     h->d_vox_off, h->d_pose_idx, h->d_vox_label, h->d_clusters};
     for (void *p : ptrs) DevicePool::get().free(p);
-    if (h->stream && h->owns_stream) (void)hipStreamDestroy(h->stream);
+    if (h->stream && h->owns_stream) lvba::StreamCache::get().release(h->stream);
     delete h;
     return LVBA_OK;
 }
@@ -929,7 +949,7 @@ int32_t lvba_voxmap_build_scans_on(lvba_scans_t sc, int32_t frame_begin, int32_t
     if (stream) {
         h->stream = stream;
         h->owns_stream = false;
-    } else if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    } else if (lvba::StreamCache::get().acquire(&h->stream) != hipSuccess) {
         delete h;
         return lvba_fail(LVBA_ERR_DEVICE, "hipStreamCreate failed");
     }

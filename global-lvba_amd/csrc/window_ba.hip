@@ -159,8 +159,8 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
     HIPCHK(hipSetDevice(sc->device));
     const int n = sc->n_frames, w = o.window_size;
     hipStream_t s = nullptr;
-    HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sguard{s};
+    HIPCHK(lvba::StreamCache::get().acquire(&s));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { lvba::StreamCache::get().release(s); } } sguard{s};
 
     static const double I12[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
     for (int i = 0; i < n; ++i) { // rel_poses_to_anchor_.assign(total, IMUST()), anchor_index -1 (:338-339)
@@ -279,7 +279,7 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
         auto mk = [&](const char *what) { if (tm) { const double t = now_ms(); fprintf(stderr, "[window_ba LM] %-16s %.3f ms\n", what, t - tk); tk = t; } };
         if (tm) fprintf(stderr, "[window_ba LM] %-16s %.3f ms\n", "export + concat", tk - t0);
         lvba_balm_t b = nullptr;
-        TRY(lvba_balm_create_dev(pose_off[(size_t)G], V, off.data(), idx.data(), d_clu.as<double>(), sc->device, &b));
+        TRY(balm_create_dev_trusted(pose_off[(size_t)G], V, off.data(), idx.data(), d_clu.as<double>(), sc->device, &b));
         struct Guard { lvba_balm_t b; ~Guard() { if (b) lvba_balm_destroy(b); } } guard{b};
         mk("create");
         TRY(lvba_balm_set_groups(b, G, pose_off.data(), vox_off.data()));
@@ -401,11 +401,11 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
     if (const char *e = getenv("LVBA_WINDOW_THREADS")) n_thr = atoi(e);
     n_thr = std::max(1, std::min(n_thr, n_win));
     lvba::hvec<hipStream_t> wstreams;
-    struct StreamsGuard { lvba::hvec<hipStream_t> &v; ~StreamsGuard() { for (hipStream_t q : v) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); } } } wguard{wstreams};
+    struct StreamsGuard { lvba::hvec<hipStream_t> &v; ~StreamsGuard() { for (hipStream_t q : v) if (q) lvba::StreamCache::get().release(q); } } wguard{wstreams};
     if (n_thr > 1) {
         wstreams.assign((size_t)n_thr, nullptr);
         for (auto &q : wstreams)
-            if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); q = nullptr; }
+            if (lvba::StreamCache::get().acquire(&q) != hipSuccess) { (void)hipGetLastError(); q = nullptr; }
     }
     auto run_stage = [&](const std::function<int32_t(int, hipStream_t, WinResult &)> &stage) {
         std::atomic<int> next{0};

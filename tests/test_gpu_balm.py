@@ -466,7 +466,9 @@ def test_solver_schedules(tmp_path):
                 {"LVBA_CHAIN_ALONE": "0"},
                 # the other bulk tiles: K chunks of 16 with two chunk buffers, K chunks of 32 with two buffers (default: 32, one buffer)
                 {"LVBA_BULK_TILE": "k16"}, {"LVBA_BULK_TILE": "k16", "LVBA_CHAIN_ALONE": "0"}, {"LVBA_BULK_TILE": "k16", "LVBA_RANK128": "0"},
-                {"LVBA_BULK_TILE": "k32db"}]
+                {"LVBA_BULK_TILE": "k32db"},
+                # 128 x 128 tiles with the operand chunks loaded straight into LDS
+                {"LVBA_BULK_TILE": "sq"}, {"LVBA_BULK_TILE": "sq", "LVBA_RANK128": "0"}, {"LVBA_BULK_TILE": "sq", "LVBA_TWIST": "0"}]
     out = []
     for i, v in enumerate(variants):
         f = tmp_path / f"dx_{i}.npy"

@@ -96,7 +96,7 @@ int main(int argc, char **argv)
         int64_t tot = 0, part = 0, cs = 1;
         for (int64_t c = 1; c < Tb; ++c) tot += pair_col_items(c, Tb);
         while (cs < Tb && (cs < 3 || 2 * part < tot)) part += pair_col_items(cs++, Tb);
-        J.ca = 1; J.cb = cs; J.nwg = part;
+        J.ca = 1; J.cb = cs; J.nwg = LVBA_MB_DB == 3 ? sq_job_items(1, cs, Tb) : part;
         t = time_ms(s, 200, [&] { hipLaunchKernelGGL((ldlt_step2_kernel<true, LVBA_MB_DB>), dim3((unsigned)(Tfull + J.nwg)), dim3(256), 0, s, a); });
         printf("look-ahead: roles + first half of a pair job (%lld tiles of 128 x 64) %7.2f us\n", (long long)J.nwg, t * 1e3);
         a.roles = 0;
@@ -145,7 +145,8 @@ int main(int argc, char **argv)
         int64_t tot = 0, part = 0, cs = 1;
         for (int64_t c = 1; c < Tb; ++c) tot += pair_col_items(c, Tb);
         while (cs < Tb && (cs < 3 || 2 * part < tot)) part += pair_col_items(cs++, Tb);
-        J.ca = 1; J.cb = cs; J.nwg = part;
+        J.ca = 1; J.cb = cs; J.nwg = LVBA_MB_DB == 3 ? sq_job_items(1, cs, Tb) : part;
+        const double job_flops = 2.0 * part * 2.0 * 128 * 64 * 128; // (the 128 x 64 count: what lies above the diagonal is not work)
         const unsigned nall = (unsigned)(2 * (T + J.nwg));
         t = time_ms(s, 200, [&] { hipLaunchKernelGGL((ldlt_step2_kernel<true, LVBA_MB_DB>), dim3(nall), dim3(256), 0, s, a); });
         printf("2 problems: roles + first half of the pair job (%u workgroups) %7.2f us   chain workgroup %6.0f cycles\n", nall, t * 1e3, chain_us());
@@ -180,7 +181,7 @@ int main(int argc, char **argv)
         a.roles = 0;
         t = time_ms(s, 200, [&] { hipLaunchKernelGGL((ldlt_step2_kernel<true, LVBA_MB_DB>), dim3((unsigned)(2 * J.nwg)), dim3(256), 0, s, a); });
         printf("2 problems: that job alone (%lld tiles)          %7.2f us  (%.1f TFLOP/s)\n", (long long)(2 * J.nwg), t * 1e3,
-               2.0 * J.nwg * 2.0 * 128 * 64 * 128 / (t * 1e-3) / 1e12);
+               job_flops / (t * 1e-3) / 1e12);
         {   // where does a bulk tile's time go?  stamps of one workgroup (block 7: first round; block 300: second round, sharing its CU)
             const char *nm[10] = {"first loads + stage", "products 0", "stage 1", "products 1", "stage 2 (+ C loads issued)", "products 2", "stage 3",
                                   "products 3", "", "C wait + stores"};
