@@ -38,7 +38,8 @@ inline double now_ms()
 }
 inline unsigned grid_for(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
-inline int32_t sort_pairs(hipStream_t s, const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout, size_t n,
+template <class K>
+inline int32_t sort_pairs(hipStream_t s, const K *kin, K *kout, const uint32_t *vin, uint32_t *vout, size_t n,
                    unsigned end_bit)
 {
     size_t bytes = 0;
@@ -92,6 +93,101 @@ __device__ __forceinline__ bool root_key_of(const double pw[3], double vs, int64
 __device__ __forceinline__ uint64_t pack_key(const int64_t k[3])
 {
     return ((uint64_t)(k[0] + KEY_BIAS) << 42) | ((uint64_t)(k[1] + KEY_BIAS) << 21) | (uint64_t)(k[2] + KEY_BIAS);
+}
+
+// ---- sorting on the bits that vary --------------------------------------------------------------------------------
+// A packed key is 3 x 21 bits, but the points of a map span a few hundred voxels per axis: the radix sort by root key (and
+// by anchor leaf, window_ba.hip) spent eight passes over 64-bit keys on 20-30 bits of information (1.8 of the 3.3 ms of a 16 M
+// point map).  The kernel that makes the keys also reduces the RANGE of the three (biased) components -- per wavefront, and a
+// wavefront touches the global range only where it widens it: after the first few, none does --, the host reads it with the
+// error flag it waits for anyway, and the keys are re-packed as  (x - x0) << (by + bz) | (y - y0) << bz | (z - z0):
+// the same lexicographic order, hence the same stable sort, in 32 bits whenever bx + by + bz <= 32.
+// The range as six maxima, so that it starts from a plain memset to zero: rng[j] = max(KEY_MAXC - x_j), rng[3 + j] = max(x_j).
+constexpr int KEY_MAXC = (1 << 21) - 1;
+struct KeyPack {
+    int lo[3];  // biased minima
+    int b[3];   // bits per component
+    int total;  // >= 1
+};
+inline KeyPack key_pack_of(const int rng[6])
+{
+    KeyPack kp;
+    kp.total = 0;
+    for (int j = 0; j < 3; ++j) {
+        kp.lo[j] = KEY_MAXC - rng[j];
+        const unsigned span = rng[3 + j] >= kp.lo[j] ? (unsigned)(rng[3 + j] - kp.lo[j]) : 0u;
+        kp.b[j] = span ? 32 - __builtin_clz(span) : 0;
+        kp.total += kp.b[j];
+    }
+    if (kp.total == 0) kp.total = 1;
+    return kp;
+}
+// max over the 64 lanes of a wavefront, result in lane 63: four row shifts and two row broadcasts on the DPP path of the
+// vector ALU (as ds_bpermute shuffles the six reductions cost the key kernel 0.2 ms per 16 M points)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, false); }
+__device__ __forceinline__ int wave_max_to_lane63(int v) // v >= 0
+{
+    constexpr int id = 0; // what a lane without a source sees
+    auto op = [](int a, int b) { return max(a, b); };
+    v = op(v, dpp_i32<0x111, 0xf>(id, v)); // row_shr:1
+    v = op(v, dpp_i32<0x112, 0xf>(id, v)); // row_shr:2
+    v = op(v, dpp_i32<0x114, 0xf>(id, v)); // row_shr:4
+    v = op(v, dpp_i32<0x118, 0xf>(id, v)); // row_shr:8   -> lane 15 of every row of 16: the row
+    v = op(v, dpp_i32<0x142, 0xa>(id, v)); // row_bcast:15 -> rows 1 and 3 take in rows 0 and 2
+    v = op(v, dpp_i32<0x143, 0xc>(id, v)); // row_bcast:31 -> rows 2 and 3 take in rows 0 + 1
+    return v;
+}
+// every lane of the wavefront calls this (lanes without a point: valid = false); kb = biased components.  The wavefront's six
+// maxima go to its own slot of `partial` ([wavefronts of the launch][6]) -- no atomics, nothing read back: conditional atomics on
+// the global range cost 0.25 ms per 16 M points in the round trip of the read alone (and 16 ms unconditionally) --,
+// key_range_reduce_kernel folds the slots into rng[6] (zeroed by the caller).
+__device__ __forceinline__ void key_range_update(int *__restrict__ partial, const int kb[3], bool valid)
+{
+    int v[6];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        v[j] = wave_max_to_lane63(valid ? KEY_MAXC - kb[j] : 0);
+        v[3 + j] = wave_max_to_lane63(valid ? kb[j] : 0);
+    }
+    if ((threadIdx.x & 63) == 63) {
+        int *slot = partial + 6 * ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+#pragma unroll
+        for (int j = 0; j < 6; ++j) slot[j] = v[j];
+    }
+}
+inline int64_t key_range_slots(int64_t n_points, int block) { return (n_points + block - 1) / block * (block / 64); } // wavefronts
+static __global__ void key_range_reduce_kernel(int64_t n_slots, const int *__restrict__ partial, int *__restrict__ rng)
+{
+    int v[6] = {0, 0, 0, 0, 0, 0};
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_slots; w += (int64_t)gridDim.x * blockDim.x)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) v[j] = max(v[j], partial[6 * w + j]);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) v[j] = wave_max_to_lane63(v[j]);
+    if ((threadIdx.x & 63) == 63)
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            if (v[j] > 0) atomicMax(rng + j, v[j]);
+}
+template <class K> __device__ __forceinline__ K key_compress(uint64_t key, const KeyPack kp)
+{
+    const int x = (int)(key >> 42), y = (int)((key >> 21) & 0x1FFFFF), z = (int)(key & 0x1FFFFF);
+    return ((K)(x - kp.lo[0]) << (kp.b[1] + kp.b[2])) | ((K)(y - kp.lo[1]) << kp.b[2]) | (K)(z - kp.lo[2]);
+}
+template <class K> __device__ __forceinline__ uint64_t key_expand(K c, const KeyPack kp)
+{
+    const uint64_t v = (uint64_t)c;
+    const uint64_t x = (v >> (kp.b[1] + kp.b[2])) + (uint64_t)kp.lo[0];
+    const uint64_t y = ((v >> kp.b[2]) & (((uint64_t)1 << kp.b[1]) - 1)) + (uint64_t)kp.lo[1];
+    const uint64_t z = (v & (((uint64_t)1 << kp.b[2]) - 1)) + (uint64_t)kp.lo[2];
+    return (x << 42) | (y << 21) | z;
+}
+template <class K>
+__global__ void key_compress_kernel(int64_t n, const uint64_t *key, const KeyPack kp, K *out /* may be key */)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = key_compress<K>(key[i], kp);
 }
 
 } // namespace lvba

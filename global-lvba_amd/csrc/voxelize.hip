@@ -64,10 +64,11 @@ __device__ __forceinline__ void octants_of(const double pw[3], const int64_t k[3
 __global__ void vox_key_kernel(int64_t P, const float *__restrict__ pts, const int64_t *__restrict__ frame_off,
                                int n_frames, const double *__restrict__ poses, double vs,
                                uint64_t *__restrict__ key, float4 *__restrict__ rec, uint32_t *__restrict__ idx,
-                               int *__restrict__ err)
+                               int *__restrict__ err, int *__restrict__ range_partial /* voxel_internal.h: key_range_update */)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
+    int kb[3] = {0, 0, 0};
+    if (i < P) {
     const int64_t base = frame_off[0];
     int lo = 0, hi = n_frames; // frame f with frame_off[f] <= base + i < frame_off[f+1]
     while (hi - lo > 1) {
@@ -88,12 +89,20 @@ __global__ void vox_key_kernel(int64_t P, const float *__restrict__ pts, const i
     key[i] = pack_key(k);
     rec[i] = make_float4(fx, fy, fz, __int_as_float((int)(((uint32_t)lo << 6) | (uint32_t)(o1 << 3) | (uint32_t)o2)));
     idx[i] = (uint32_t)i;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) kb[j] = (int)(k[j] + KEY_BIAS);
+    }
+    key_range_update(range_partial, kb, i < P); // (the sort below runs on the bits that vary)
 }
+// records into sorted order; the sorted keys back in their 3 x 21-bit form (K = void: they are that already)
+template <class K>
 __global__ void vox_gather_kernel(int64_t n, const float4 *__restrict__ rec, const uint32_t *__restrict__ order,
-                                  float4 *__restrict__ out)
+                                  float4 *__restrict__ out, const K *ckey_s, const KeyPack kp, uint64_t *key_s /* may be ckey_s */)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = rec[order[i]];
+    if (i >= n) return;
+    out[i] = rec[order[i]];
+    if (ckey_s) key_s[i] = key_expand<K>(ckey_s[i], kp);
 }
 // head flags of the sorted records: bit 0 = first record of a root, bit 1 = first record of a (root, frame) segment
 __global__ void vox_heads_kernel(int64_t n, const uint64_t *__restrict__ key, const float4 *__restrict__ rec,
@@ -768,19 +777,42 @@ int32_t voxmap_build_impl(lvba_voxmap_s *h, const lvba_scans_s *sc, int frame_be
     {
         DevBuf key(s), rec(s), idx(s), key_s(s), idx0(s), d_err(s);
         HIPCHK(key.alloc(8 * P)); HIPCHK(rec.alloc(16 * P)); HIPCHK(idx.alloc(4 * P));
-        HIPCHK(key_s.alloc(8 * P)); HIPCHK(idx0.alloc(4 * P)); HIPCHK(rec_s.alloc(16 * P)); HIPCHK(d_err.alloc(4));
-        HIPCHK(hipMemsetAsync(d_err.p, 0, 4, s));
+        HIPCHK(key_s.alloc(8 * P)); HIPCHK(idx0.alloc(4 * P)); HIPCHK(rec_s.alloc(16 * P)); HIPCHK(d_err.alloc(28));
+        int h_err[7] = {0}; // [0] error flag, [1..6] range of the biased key components
+        DevBuf d_part(s);
+        const int64_t n_slots = key_range_slots(P, 256);
+        HIPCHK(d_part.alloc(24 * (size_t)n_slots));
+        HIPCHK(hipMemsetAsync(d_err.p, 0, 28, s));
         vox_key_kernel<<<grid_for(P, 256), 256, 0, s>>>(P, pts, sc->d_frame_off + frame_begin, nfr, d_poses.as<double>(),
                                                         h->opts.voxel_size, key.as<uint64_t>(), rec.as<float4>(),
-                                                        idx.as<uint32_t>(), d_err.as<int>());
+                                                        idx.as<uint32_t>(), d_err.as<int>(), d_part.as<int>());
         HIPCHK(hipGetLastError());
-        int err = 0;
+        key_range_reduce_kernel<<<(unsigned)std::min<int64_t>(256, (n_slots + 255) / 256), 256, 0, s>>>(n_slots, d_part.as<int>(), d_err.as<int>() + 1);
+        HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(s));
-        HIPCHK(lvba::copy_d2h(&err, d_err.p, 4));
-        if (err) return lvba_fail(LVBA_ERR_ARG, "a point is non-finite or its voxel key exceeds +-2^20 after the pose transform");
+        HIPCHK(lvba::copy_d2h(h_err, d_err.p, 28));
+        if (h_err[0]) return lvba_fail(LVBA_ERR_ARG, "a point is non-finite or its voxel key exceeds +-2^20 after the pose transform");
         h->info.key_ms = now_ms() - t0; t0 = now_ms();
-        TRY(sort_pairs(s, key.as<uint64_t>(), key_s.as<uint64_t>(), idx.as<uint32_t>(), idx0.as<uint32_t>(), (size_t)P, 63));
-        vox_gather_kernel<<<grid_for(P, 256), 256, 0, s>>>(P, rec.as<float4>(), idx0.as<uint32_t>(), rec_s.as<float4>());
+        static const bool full_sort = [] { const char *e = getenv("LVBA_SORT_BITS"); return e && !strcmp(e, "full"); }(); // A/B: all 63 bits
+        const KeyPack kp = key_pack_of(h_err + 1);
+        if (full_sort) {
+            TRY(sort_pairs(s, key.as<uint64_t>(), key_s.as<uint64_t>(), idx.as<uint32_t>(), idx0.as<uint32_t>(), (size_t)P, 63));
+            vox_gather_kernel<uint64_t><<<grid_for(P, 256), 256, 0, s>>>(P, rec.as<float4>(), idx0.as<uint32_t>(), rec_s.as<float4>(), nullptr, kp, nullptr);
+        } else if (kp.total <= 32) {
+            DevBuf k32(s), k32s(s);
+            HIPCHK(k32.alloc(4 * P)); HIPCHK(k32s.alloc(4 * P));
+            key_compress_kernel<uint32_t><<<grid_for(P, 256), 256, 0, s>>>(P, key.as<uint64_t>(), kp, k32.as<uint32_t>());
+            HIPCHK(hipGetLastError());
+            TRY(sort_pairs(s, k32.as<uint32_t>(), k32s.as<uint32_t>(), idx.as<uint32_t>(), idx0.as<uint32_t>(), (size_t)P, (unsigned)kp.total));
+            vox_gather_kernel<uint32_t><<<grid_for(P, 256), 256, 0, s>>>(P, rec.as<float4>(), idx0.as<uint32_t>(), rec_s.as<float4>(), k32s.as<uint32_t>(), kp,
+                                                                         key_s.as<uint64_t>());
+        } else { // wide maps: 64-bit keys, still only the bits that vary (compressed and expanded in place)
+            key_compress_kernel<uint64_t><<<grid_for(P, 256), 256, 0, s>>>(P, key.as<uint64_t>(), kp, key.as<uint64_t>());
+            HIPCHK(hipGetLastError());
+            TRY(sort_pairs(s, key.as<uint64_t>(), key_s.as<uint64_t>(), idx.as<uint32_t>(), idx0.as<uint32_t>(), (size_t)P, (unsigned)kp.total));
+            vox_gather_kernel<uint64_t><<<grid_for(P, 256), 256, 0, s>>>(P, rec.as<float4>(), idx0.as<uint32_t>(), rec_s.as<float4>(), key_s.as<uint64_t>(), kp,
+                                                                         key_s.as<uint64_t>());
+        }
         HIPCHK(hipGetLastError());
 
         DevBuf head_root(s), head_seg(s), incl_root(s), incl_seg(s);

@@ -31,10 +31,11 @@ constexpr int KEY_BIAS = 1 << 20;
 __global__ void wba_merge_kernel(int64_t P, const float *__restrict__ pts, const int64_t *__restrict__ frame_off, int n_frames,
                                  const double *__restrict__ rel, double leaf, float *__restrict__ out,
                                  uint64_t *__restrict__ key, double *__restrict__ d2, uint32_t *__restrict__ idx,
-                                 int *__restrict__ err)
+                                 int *__restrict__ err, int *__restrict__ range_partial /* voxel_internal.h: key_range_update */)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
+    int kb[3] = {0, 0, 0};
+    if (i < P) {
     const int64_t base = frame_off[0];
     int lo = 0, hi = n_frames;
     while (hi - lo > 1) {
@@ -46,7 +47,7 @@ __global__ void wba_merge_kernel(int64_t P, const float *__restrict__ pts, const
     const float q[3] = {(float)(T[0] * p0 + T[1] * p1 + T[2] * p2 + T[9]), (float)(T[3] * p0 + T[4] * p1 + T[5] * p2 + T[10]),
                         (float)(T[6] * p0 + T[7] * p1 + T[8] * p2 + T[11])};
     out[3 * i] = q[0]; out[3 * i + 1] = q[1]; out[3 * i + 2] = q[2];
-    if (!key) return;
+    if (key) {
     int64_t k[3];
     double dd = 0.0;
     bool ok = true;
@@ -64,9 +65,16 @@ __global__ void wba_merge_kernel(int64_t P, const float *__restrict__ pts, const
     key[i] = ((uint64_t)(k[0] + KEY_BIAS) << 42) | ((uint64_t)(k[1] + KEY_BIAS) << 21) | (uint64_t)(k[2] + KEY_BIAS);
     d2[i] = dd;
     idx[i] = (uint32_t)i;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) kb[j] = (int)(k[j] + KEY_BIAS);
+    }
+    }
+    if (key) key_range_update(range_partial, kb, i < P); // (the sort runs on the bits that vary)
 }
-// after the stable sort by key: the run leader picks the first minimum of d2 in merged order
-__global__ void wba_pick_kernel(int64_t P, const uint64_t *__restrict__ key_s, const uint32_t *__restrict__ order,
+// after the stable sort by key (K: the re-packed keys, equal exactly where the leaf keys are): the run leader picks the first
+// minimum of d2 in merged order
+template <class K>
+__global__ void wba_pick_kernel(int64_t P, const K *__restrict__ key_s, const uint32_t *__restrict__ order,
                                 const double *__restrict__ d2, uint32_t *__restrict__ flag, uint32_t *__restrict__ pick)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -74,7 +82,7 @@ __global__ void wba_pick_kernel(int64_t P, const uint64_t *__restrict__ key_s, c
     const bool head = i == 0 || key_s[i] != key_s[i - 1];
     flag[i] = head ? 1u : 0u;
     if (!head) return;
-    const uint64_t k = key_s[i];
+    const K k = key_s[i];
     uint32_t best = order[i];
     double bd = d2[best];
     for (int64_t j = i + 1; j < P && key_s[j] == k; ++j) {
@@ -353,28 +361,55 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
         int64_t n_out = P;
         if (P > 0) {
             DevBuf d_rel(s), merged(s), key(s), d2(s), idx(s), d_err(s);
-            HIPCHK(d_rel.alloc(96 * (size_t)cw)); HIPCHK(merged.alloc(12 * (size_t)P)); HIPCHK(d_err.alloc(4));
+            HIPCHK(d_rel.alloc(96 * (size_t)cw)); HIPCHK(merged.alloc(12 * (size_t)P)); HIPCHK(d_err.alloc(28));
             HIPCHK(lvba::copy_h2d(d_rel.p, rel.data(), 96 * (size_t)cw)); // (pageable source: synchronous copy, voxelize.hip)
-            HIPCHK(hipMemsetAsync(d_err.p, 0, 4, s));
+            int h_err[7] = {0}; // [0] error flag, [1..6] range of the biased key components
+            DevBuf d_part(s);
+            const int64_t n_slots = key_range_slots(P, 256);
+            if (down) HIPCHK(d_part.alloc(24 * (size_t)n_slots));
+            HIPCHK(hipMemsetAsync(d_err.p, 0, 28, s));
             if (down) { HIPCHK(key.alloc(8 * (size_t)P)); HIPCHK(d2.alloc(8 * (size_t)P)); HIPCHK(idx.alloc(4 * (size_t)P)); }
             wba_merge_kernel<<<grid_for(P, 256), 256, 0, s>>>(P, sc->d_pts + 3 * p_begin, sc->d_frame_off + start, cw, d_rel.as<double>(),
                                                               o.anchor_leaf, merged.as<float>(), down ? key.as<uint64_t>() : nullptr,
-                                                              d2.as<double>(), idx.as<uint32_t>(), d_err.as<int>());
+                                                              d2.as<double>(), idx.as<uint32_t>(), d_err.as<int>(), d_part.as<int>());
             HIPCHK(hipGetLastError());
+            if (down) {
+                key_range_reduce_kernel<<<(unsigned)std::min<int64_t>(256, (n_slots + 255) / 256), 256, 0, s>>>(n_slots, d_part.as<int>(), d_err.as<int>() + 1);
+                HIPCHK(hipGetLastError());
+            }
             if (!down) {
                 HIPCHK(hipStreamSynchronize(s));
                 d_out = (float *)merged.release();
             } else {
-                int err = 0;
                 HIPCHK(hipStreamSynchronize(s));
-                HIPCHK(lvba::copy_d2h(&err, d_err.p, 4));
-                if (err) { return lvba_fail(LVBA_ERR_ARG, "window %d: a merged point is non-finite or outside +-2^20 anchor leaves", wi); }
+                HIPCHK(lvba::copy_d2h(h_err, d_err.p, 28));
+                if (h_err[0]) { return lvba_fail(LVBA_ERR_ARG, "window %d: a merged point is non-finite or outside +-2^20 anchor leaves", wi); }
                 DevBuf key_s(s), order(s), flag(s), excl(s), pick(s);
                 HIPCHK(key_s.alloc(8 * (size_t)P)); HIPCHK(order.alloc(4 * (size_t)P)); HIPCHK(flag.alloc(4 * ((size_t)P + 1)));
                 HIPCHK(excl.alloc(4 * ((size_t)P + 1))); HIPCHK(pick.alloc(4 * (size_t)P));
-                TRY(sort_pairs(s, key.as<uint64_t>(), key_s.as<uint64_t>(), idx.as<uint32_t>(), order.as<uint32_t>(), (size_t)P, 63));
-                wba_pick_kernel<<<grid_for(P, 256), 256, 0, s>>>(P, key_s.as<uint64_t>(), order.as<uint32_t>(), d2.as<double>(),
-                                                                 flag.as<uint32_t>(), pick.as<uint32_t>());
+                // the sort runs on the bits of the leaf key that vary (voxel_internal.h; LVBA_SORT_BITS=full: all 63, A/B); run
+                // leaders only compare sorted keys for equality, so the re-packed ones serve as they are
+                static const bool full_sort = [] { const char *e = getenv("LVBA_SORT_BITS"); return e && !strcmp(e, "full"); }();
+                const KeyPack kp = key_pack_of(h_err + 1);
+                if (!full_sort && kp.total <= 32) {
+                    DevBuf k32(s);
+                    HIPCHK(k32.alloc(4 * (size_t)P));
+                    key_compress_kernel<uint32_t><<<grid_for(P, 256), 256, 0, s>>>(P, key.as<uint64_t>(), kp, k32.as<uint32_t>());
+                    HIPCHK(hipGetLastError());
+                    TRY(sort_pairs(s, k32.as<uint32_t>(), key_s.as<uint32_t>(), idx.as<uint32_t>(), order.as<uint32_t>(), (size_t)P, (unsigned)kp.total));
+                    wba_pick_kernel<uint32_t><<<grid_for(P, 256), 256, 0, s>>>(P, key_s.as<uint32_t>(), order.as<uint32_t>(), d2.as<double>(),
+                                                                               flag.as<uint32_t>(), pick.as<uint32_t>());
+                } else {
+                    unsigned bits = 63;
+                    if (!full_sort) {
+                        key_compress_kernel<uint64_t><<<grid_for(P, 256), 256, 0, s>>>(P, key.as<uint64_t>(), kp, key.as<uint64_t>());
+                        HIPCHK(hipGetLastError());
+                        bits = (unsigned)kp.total;
+                    }
+                    TRY(sort_pairs(s, key.as<uint64_t>(), key_s.as<uint64_t>(), idx.as<uint32_t>(), order.as<uint32_t>(), (size_t)P, bits));
+                    wba_pick_kernel<uint64_t><<<grid_for(P, 256), 256, 0, s>>>(P, key_s.as<uint64_t>(), order.as<uint32_t>(), d2.as<double>(),
+                                                                               flag.as<uint32_t>(), pick.as<uint32_t>());
+                }
                 HIPCHK(hipGetLastError());
                 HIPCHK(hipMemsetAsync(flag.as<uint32_t>() + P, 0, 4, s));
                 TRY(scan_excl<uint32_t>(s, flag.as<uint32_t>(), excl.as<uint32_t>(), (size_t)P + 1));

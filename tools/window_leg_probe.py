@@ -25,6 +25,16 @@ for k in range(3):
     print(f"upload {1e3 * (time.perf_counter() - t0):.2f} ms", file=sys.stderr)
     if k < 2:
         scans.close()
+best, m = 1e9, None
+for _ in range(4):
+    if m is not None:
+        m.close()
+    t0 = time.perf_counter()
+    m = scans.voxel_map(poses, 1.0)
+    best = min(best, time.perf_counter() - t0)
+print(f"voxel map (1.0 m, {m.info['n_points']} points): {1e3 * best:.3f} ms, phases "
+      f"{ {k: round(m.info[k], 3) for k in ('key_ms', 'sort_ms', 'count_ms', 'write_ms')} }, {m.info['n_voxels']} plane voxels", file=sys.stderr)
+m.close()
 for k in range(3):
     print(f"--- window_ba call {k}", file=sys.stderr)
     t0 = time.perf_counter()
