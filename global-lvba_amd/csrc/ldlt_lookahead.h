@@ -64,6 +64,9 @@ struct Step2Args {
     // 79 900 -> 59 600 cycles (what it takes alone), the launch 37.9 -> 29.6 us.  Placement is a matter of speed only: wherever
     // the blocks land, every tile is still done exactly once.  resv_n = 0: off.
     int resv_at, resv_n;
+    // experiment (tools/solver_microbench; needs dbg): every bulk workgroup does what a flag-driven, launch-free form would add to
+    // it -- one relaxed agent-scope poll + acquire fence before its tile, release fence + vmcnt(0) + one agent-scope atomic after
+    int fence_probe;
     unsigned long long *dbg;
 };
 
@@ -461,6 +464,23 @@ __global__ __launch_bounds__(256, BT == 1 ? 1 : 2) void ldlt_step2_kernel(const 
     }
     if (A.stagger_n > 0 && (int)blockIdx.x >= A.stagger_from)
         for (int q = 0; q < A.stagger_n; ++q) __builtin_amdgcn_s_sleep(16);
+    const bool probe = A.fence_probe && A.dbg;
+    if (probe) {
+        if (threadIdx.x == 0) {
+            (void)__hip_atomic_load(A.dbg + 600, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+    }
+    auto publish = [&]() {
+        if (!probe) return;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            (void)__hip_atomic_fetch_add(A.dbg + 601, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
     for (int j = 0; j < A.njobs; ++j) {
         const BulkJob &J = A.job[j];
         if (bx >= J.nwg) { bx -= J.nwg; continue; }
@@ -473,6 +493,7 @@ __global__ __launch_bounds__(256, BT == 1 ? 1 : 2) void ldlt_step2_kernel(const 
                 if (!sq_decode(J.dbg_same ? 0 : bx, J.ca, J.cb, (int64_t)J.o.T - 1, R0, tj, ncol)) return;
                 if (J.pair) bulk_tile_sq<2>(lds, M, po, pe, A.ldz, R0, tj, ncol);
                 else bulk_tile_sq<1>(lds, M, po, pe, A.ldz, R0, tj, ncol);
+                publish();
                 return;
             }
             if (!pair_decode(J.dbg_same ? 0 : bx, J.ca, J.cb, (int64_t)J.o.T - 1, R0, tj)) return;
@@ -489,6 +510,7 @@ __global__ __launch_bounds__(256, BT == 1 ? 1 : 2) void ldlt_step2_kernel(const 
             if (J.pair) update_tile2(lds, M, J.o.k, J.o.nbe, J.o.w0, J.o.rend, Zo, J.e.k, J.e.nbe, J.e.w0, J.e.rend, Ze, A.ldz, ti + 1, tj + 1);
             else update_tile(lds, M, J.o.k, J.o.nbe, J.o.w0, J.o.rend, Zo, A.ldz, ti + 1, tj + 1);
         }
+        publish();
         return;
     }
 }

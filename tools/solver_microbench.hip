@@ -197,6 +197,16 @@ int main(int argc, char **argv)
             }
             int off = -1; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_bulk_stamp_block), &off, sizeof off));
         }
+        a.fence_probe = 1; // what every bulk tile would pay in a flag-driven form without kernel boundaries
+        t = time_ms(s, 200, [&] { hipLaunchKernelGGL((ldlt_step2_kernel<true, LVBA_MB_DB>), dim3((unsigned)(2 * J.nwg)), dim3(256), 0, s, a); });
+        printf("2 problems: that job alone, every tile with poll + acquire fence before and release fence + atomic after: %7.2f us\n", t * 1e3);
+        a.roles = 1;
+        t = time_ms(s, 200, [&] { hipLaunchKernelGGL((ldlt_step2_kernel<true, LVBA_MB_DB>), dim3(nall), dim3(256), 0, s, a); });
+        printf("2 problems: roles + that job, bulk tiles fenced the same way: %7.2f us   chain workgroup %6.0f cycles\n", t * 1e3, chain_us());
+        a.fence_probe = 0;
+        t = time_ms(s, 200, [&] { hipLaunchKernelGGL((ldlt_step2_kernel<true, LVBA_MB_DB>), dim3(nall), dim3(256), 0, s, a); });
+        printf("2 problems: roles + that job, no fences:                      %7.2f us   chain workgroup %6.0f cycles\n", t * 1e3, chain_us());
+        a.roles = 0;
         J.dbg_same = 1;
         t = time_ms(s, 200, [&] { hipLaunchKernelGGL((ldlt_step2_kernel<true, LVBA_MB_DB>), dim3((unsigned)(2 * J.nwg)), dim3(256), 0, s, a); });
         printf("2 problems: that job with every workgroup on the SAME tile (operands and C from L2): %7.2f us\n", t * 1e3);
