@@ -9,6 +9,7 @@
 #include <vector>
 #include "lvba_common.h"
 #include "mempool.h"
+#include "key_pack.h"
 
 struct lvba_scans_s {
     int device = 0;
@@ -102,26 +103,7 @@ __device__ __forceinline__ uint64_t pack_key(const int64_t k[3])
 // wavefront touches the global range only where it widens it: after the first few, none does --, the host reads it with the
 // error flag it waits for anyway, and the keys are re-packed as  (x - x0) << (by + bz) | (y - y0) << bz | (z - z0):
 // the same lexicographic order, hence the same stable sort, in 32 bits whenever bx + by + bz <= 32.
-// The range as six maxima, so that it starts from a plain memset to zero: rng[j] = max(KEY_MAXC - x_j), rng[3 + j] = max(x_j).
-constexpr int KEY_MAXC = (1 << 21) - 1;
-struct KeyPack {
-    int lo[3];  // biased minima
-    int b[3];   // bits per component
-    int total;  // >= 1
-};
-inline KeyPack key_pack_of(const int rng[6])
-{
-    KeyPack kp;
-    kp.total = 0;
-    for (int j = 0; j < 3; ++j) {
-        kp.lo[j] = KEY_MAXC - rng[j];
-        const unsigned span = rng[3 + j] >= kp.lo[j] ? (unsigned)(rng[3 + j] - kp.lo[j]) : 0u;
-        kp.b[j] = span ? 32 - __builtin_clz(span) : 0;
-        kp.total += kp.b[j];
-    }
-    if (kp.total == 0) kp.total = 1;
-    return kp;
-}
+// (KeyPack, key_pack_of, key_compress, key_expand: key_pack.h -- plain arithmetic, also compiled by tests/key_pack_check.cpp)
 // max over the 64 lanes of a wavefront, result in lane 63: four row shifts and two row broadcasts on the DPP path of the
 // vector ALU (as ds_bpermute shuffles the six reductions cost the key kernel 0.2 ms per 16 M points)
 template <int CTRL, int ROW_MASK>
@@ -169,19 +151,6 @@ static __global__ void key_range_reduce_kernel(int64_t n_slots, const int *__res
 #pragma unroll
         for (int j = 0; j < 6; ++j)
             if (v[j] > 0) atomicMax(rng + j, v[j]);
-}
-template <class K> __device__ __forceinline__ K key_compress(uint64_t key, const KeyPack kp)
-{
-    const int x = (int)(key >> 42), y = (int)((key >> 21) & 0x1FFFFF), z = (int)(key & 0x1FFFFF);
-    return ((K)(x - kp.lo[0]) << (kp.b[1] + kp.b[2])) | ((K)(y - kp.lo[1]) << kp.b[2]) | (K)(z - kp.lo[2]);
-}
-template <class K> __device__ __forceinline__ uint64_t key_expand(K c, const KeyPack kp)
-{
-    const uint64_t v = (uint64_t)c;
-    const uint64_t x = (v >> (kp.b[1] + kp.b[2])) + (uint64_t)kp.lo[0];
-    const uint64_t y = ((v >> kp.b[2]) & (((uint64_t)1 << kp.b[1]) - 1)) + (uint64_t)kp.lo[1];
-    const uint64_t z = (v & (((uint64_t)1 << kp.b[2]) - 1)) + (uint64_t)kp.lo[2];
-    return (x << 42) | (y << 21) | z;
 }
 template <class K>
 __global__ void key_compress_kernel(int64_t n, const uint64_t *key, const KeyPack kp, K *out /* may be key */)

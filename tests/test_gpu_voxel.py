@@ -280,3 +280,67 @@ def test_strided_scans_upload_packed_equals_memcpy2d(pkg, synth, monkeypatch):
     with pkg.Scans(want) as sc:
         for f, w in enumerate(want):
             np.testing.assert_array_equal(sc.download(f), w)
+
+
+def test_wide_map_sorts_on_64_bit_repacked_keys(pkg, synth):
+    """The root sort runs on the key bits that vary (csrc/voxel_internal.h: KeyPack): 32-bit keys when the three components'
+    widths sum to <= 32 -- every other test here --, re-packed 64-bit keys otherwise.  Two rooms 150 km apart, on both sides of
+    the origin, at 0.25 m voxels need 20 + 19 + 12 bits: same roots in the same order, same voxels, bit-identical clusters."""
+    from oracle import voxel_oracle as vo
+    a = synth.make_scans(3, 6000, room=(6, 5, 3), origin=(-70000.3, 61000.7, -250.4), n_panels=5, seed=21)
+    b = synth.make_scans(3, 6000, room=(6, 5, 3), origin=(81000.2, -52000.9, 310.6), n_panels=5, seed=22)
+    clouds = a["clouds"] + b["clouds"]
+    poses = np.concatenate([a["poses"], b["poses"]])
+    surf_map, vox = vo.build([c[:, :3] for c in clouds], poses, 0.25, vo.DEFAULT_EIGEN_RATIO)
+    off_ref, idx_ref, cl_ref = vo.pack(vox)
+    keys = np.array([k for k in surf_map.keys()], np.int64)
+    widths = [int(np.ptp(keys[:, j])).bit_length() for j in range(3)]
+    assert sum(widths) > 32, widths
+    with pkg.VoxelMap(clouds, poses, 0.25, vo.DEFAULT_EIGEN_RATIO) as m:
+        assert m.info["n_roots"] == len(surf_map)
+        off, idx, cl, key = m.export()
+    key_ref = np.array([list(k) + [_path_code(p)] for k, p, _ in vox], np.int64)
+    assert len(vox) > 20
+    np.testing.assert_array_equal(key, key_ref)
+    np.testing.assert_array_equal(off, off_ref)
+    np.testing.assert_array_equal(idx, idx_ref)
+    np.testing.assert_array_equal(cl, cl_ref)
+
+
+_SORT_SCRIPT = r"""
+import importlib, sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+pkg = importlib.import_module("global-lvba_amd")
+synth = importlib.import_module("global-lvba_amd.synth")
+s = synth.make_scans(8, 20000, room=(20, 14, 5), origin=(-12.5, 33.1, 1.2), n_panels=8, seed=31)
+with pkg.Scans(s["clouds"]) as scans:
+    with scans.voxel_map(s["poses"], 0.5) as m:
+        off, idx, cl, key = m.export()
+    w = scans.window_ba(s["poses"], window_size=4, voxel_size=0.5, anchor_leaf=0.05)
+    anchors = [w["anchor_scans"].download(k) for k in range(w["anchor_scans"].n_frames)]
+    w["anchor_scans"].close()
+np.savez(sys.argv[2], off=off, idx=idx, cl=cl, key=key, wp=w["window_poses"], n=np.array([len(a) for a in anchors]),
+         pts=np.concatenate(anchors))
+"""
+
+
+def test_sorts_on_varying_bits_equal_full_key_sorts(tmp_path):
+    """LVBA_SORT_BITS=full sorts root keys and anchor-leaf keys on all 63 bits as rounds 1-3 did; the default re-packs them onto
+    the bits that vary.  Same order either way: the map and the whole window stage (anchor clouds point for point) are
+    identical byte for byte."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "run.py"
+    script.write_text(_SORT_SCRIPT)
+    out = []
+    for i, v in enumerate([{}, {"LVBA_SORT_BITS": "full"}]):
+        f = tmp_path / f"o_{i}.npz"
+        r = subprocess.run([sys.executable, str(script), root, str(f)], env=dict(os.environ, **v), capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, (v, r.stderr[-2000:])
+        out.append(np.load(f))
+    assert len(out[0]["off"]) > 100 and out[0]["n"].sum() > 1000
+    for k in out[0].files:
+        np.testing.assert_array_equal(out[0][k], out[1][k], err_msg=k)

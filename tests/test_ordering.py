@@ -59,3 +59,12 @@ def test_ldlt_lookahead_schedule(tmp_path):
     subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "ldlt_schedule_check.cpp"), "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and "ldlt schedule ok" in r.stdout, r.stdout[-3000:]
+
+
+def test_key_repacking_keeps_order_and_round_trips(tmp_path):
+    """csrc/key_pack.h: the voxel map's root sort and the anchor down-sampling sort run on keys re-packed onto the bits that
+    vary; the re-packed keys must order exactly like the 3 x 21-bit ones and expand back to them (tests/key_pack_check.cpp)."""
+    exe = str(tmp_path / "key_pack_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "key_pack_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "key pack ok" in out.stdout, out.stdout[-2000:]
