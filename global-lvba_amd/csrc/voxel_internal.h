@@ -27,6 +27,13 @@ struct lvba_scans_s;
 int32_t lvba_voxmap_build_scans_on(lvba_scans_s *sc, int32_t frame_begin, int32_t n_frames, const double *poses,
                                    const lvba_voxel_opts *opts, hipStream_t stream, lvba_voxmap_s **out);
 
+// ONE map for all windows of window_size frames in [frame_begin, frame_begin + n_frames) -- a root is (window, key) --, and the
+// per-window views into it: what lvba_voxmap_build_scans_on would give for that window (same voxels in the same order, bit for
+// bit), owning nothing; destroy the views before the joint map.  voxelize.hip.
+int32_t lvba_voxmap_build_scans_joint(lvba_scans_s *sc, int32_t frame_begin, int32_t n_frames, int32_t window_size, const double *poses,
+                                      const lvba_voxel_opts *opts, hipStream_t stream, lvba_voxmap_s **out);
+int32_t lvba_voxmap_window_view(lvba_voxmap_s *joint, int32_t w, lvba_voxmap_s **out);
+
 struct lvba_balm_s;
 namespace lvba {
 // lvba_balm_create_dev without the argument checks and the voxel re-layout pass (lvba_api.hip; for arrays this library made itself)

@@ -102,15 +102,46 @@ __global__ void vox_gather_kernel(int64_t n, const float4 *__restrict__ rec, con
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     out[i] = rec[order[i]];
-    if (ckey_s) key_s[i] = key_expand<K>(ckey_s[i], kp);
+    if (ckey_s) {
+        K c = ckey_s[i];
+        if (kp.total < (int)(8 * sizeof(K))) c &= (K)(((K)1 << kp.total) - 1); // (a joint map's window index sits above the key bits)
+        key_s[i] = key_expand<K>(c, kp);
+    }
 }
-// head flags of the sorted records: bit 0 = first record of a root, bit 1 = first record of a (root, frame) segment
-__global__ void vox_heads_kernel(int64_t n, const uint64_t *__restrict__ key, const float4 *__restrict__ rec,
-                                 uint32_t *__restrict__ head_root, uint32_t *__restrict__ head_seg)
+// joint map: (window << total) | re-packed key -- the records of a window stay together, inside it the order is the key's
+template <class K>
+__global__ void key_compress_win_kernel(int64_t n, const uint64_t *key, const float4 *__restrict__ rec, const KeyPack kp, int ws,
+                                        K *out /* may be key */)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const bool hr = i == 0 || key[i] != key[i - 1];
+    const K win = (K)((__float_as_int(rec[i].w) >> 6) / ws);
+    out[i] = (K)(win << kp.total) | key_compress<K>(key[i], kp);
+}
+// first admitted voxel / factor of every window that has roots (the others are filled in on the host)
+__global__ void vox_win_first_kernel(int64_t R, const uint32_t *__restrict__ root_seg, const int32_t *__restrict__ seg_frame, int ws,
+                                     const int32_t *__restrict__ vox_first, const int64_t *__restrict__ fac_first,
+                                     int64_t *__restrict__ win_v0, int64_t *__restrict__ win_f0)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const int w = seg_frame[root_seg[r]] / ws;
+    if (r == 0 || seg_frame[root_seg[r - 1]] / ws != w) { win_v0[w] = vox_first[r]; win_f0[w] = fac_first[r]; }
+}
+__global__ void vox_pose_rel_kernel(int64_t F, int32_t *__restrict__ pose_idx, int ws)
+{
+    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < F) pose_idx[f] %= ws;
+}
+// head flags of the sorted records: bit 0 = first record of a root, bit 1 = first record of a (root, frame) segment
+// (ws > 0, joint map of several windows: a root is (window, key), window = frame / ws)
+__global__ void vox_heads_kernel(int64_t n, const uint64_t *__restrict__ key, const float4 *__restrict__ rec,
+                                 uint32_t *__restrict__ head_root, uint32_t *__restrict__ head_seg, int ws)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bool hr = i == 0 || key[i] != key[i - 1];
+    if (ws > 0 && !hr) hr = (__float_as_int(rec[i].w) >> 6) / ws != (__float_as_int(rec[i - 1].w) >> 6) / ws;
     const bool hs = hr || (__float_as_int(rec[i].w) >> 6) != (__float_as_int(rec[i - 1].w) >> 6);
     head_root[i] = hr ? 1u : 0u;
     head_seg[i] = hs ? 1u : 0u;
@@ -585,6 +616,13 @@ struct lvba_voxmap_s {
     int64_t *d_vox_off = nullptr;
     int32_t *d_pose_idx = nullptr, *d_vox_label = nullptr;
     double *d_clusters = nullptr;
+    // A JOINT map of several windows (lvba_voxmap_build_scans_joint: roots are (window, key); the admitted voxels of window w are
+    // the range win_v0[w] .. win_v0[w + 1], its factors win_f0[w] .. win_f0[w + 1], pose indices relative to the window's first
+    // frame) and the per-window VIEWS into one (lvba_voxmap_window_view: they own nothing).  Neither has a key lookup: the root
+    // table of a joint map holds a key once per window.
+    int window_size = 0, n_windows = 1;
+    lvba::hvec<int64_t> win_v0, win_f0;
+    bool is_view = false;
 };
 
 const double *lvba_voxmap_clusters(const lvba_voxmap_s *h) { return h ? h->d_clusters : nullptr; }
@@ -740,6 +778,7 @@ extern "C" int32_t lvba_scans_create(int32_t device, int32_t n_frames, const voi
 extern "C" int32_t lvba_voxmap_destroy(lvba_voxmap_t h)
 {
     if (!h) return LVBA_OK;
+    if (h->is_view) { delete h; return LVBA_OK; } // a window view of a joint map: the arrays are the joint map's
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_root_key, h->d_mask, h->d_rootinfo, h->d_plane_first, h->d_plane,
                     h->d_vox_off, h->d_pose_idx, h->d_vox_label, h->d_clusters};
@@ -751,9 +790,15 @@ extern "C" int32_t lvba_voxmap_destroy(lvba_voxmap_t h)
 
 namespace {
 
-int32_t voxmap_build_impl(lvba_voxmap_s *h, const lvba_scans_s *sc, int frame_begin, const double *poses)
+// window_size > 0: a JOINT map of the windows [frame_begin + k ws, frame_begin + (k + 1) ws) -- one sort, one pass of every kernel
+// for all of them; every window's part is what its own map would be (same records in the same order, root by root).
+int32_t voxmap_build_impl(lvba_voxmap_s *h, const lvba_scans_s *sc, int frame_begin, const double *poses, int window_size = 0)
 {
     const int nfr = h->n_frames;
+    const int ws = window_size > 0 && window_size < nfr ? window_size : 0;
+    const int n_win = ws ? (nfr + ws - 1) / ws : 1;
+    const int wbits = n_win > 1 ? 32 - __builtin_clz((unsigned)(n_win - 1)) : 0;
+    h->window_size = ws; h->n_windows = n_win;
     hipStream_t s = h->stream;
     const int64_t p_begin = sc->frame_off[frame_begin];
     const int64_t P = sc->frame_off[frame_begin + nfr] - p_begin;
@@ -795,7 +840,24 @@ int32_t voxmap_build_impl(lvba_voxmap_s *h, const lvba_scans_s *sc, int frame_be
         h->info.key_ms = now_ms() - t0; t0 = now_ms();
         static const bool full_sort = [] { const char *e = getenv("LVBA_SORT_BITS"); return e && !strcmp(e, "full"); }(); // A/B: all 63 bits
         const KeyPack kp = key_pack_of(h_err + 1);
-        if (full_sort) {
+        if (ws) { // joint map: the window index above the re-packed key (LVBA_SORT_BITS does not apply)
+            if (kp.total + wbits > 64) return lvba_fail(LVBA_ERR_UNSUPPORTED, "joint map: %d key bits + %d window bits", kp.total, wbits);
+            if (kp.total + wbits <= 32) {
+                DevBuf k32(s), k32s(s);
+                HIPCHK(k32.alloc(4 * P)); HIPCHK(k32s.alloc(4 * P));
+                key_compress_win_kernel<uint32_t><<<grid_for(P, 256), 256, 0, s>>>(P, key.as<uint64_t>(), rec.as<float4>(), kp, ws, k32.as<uint32_t>());
+                HIPCHK(hipGetLastError());
+                TRY(sort_pairs(s, k32.as<uint32_t>(), k32s.as<uint32_t>(), idx.as<uint32_t>(), idx0.as<uint32_t>(), (size_t)P, (unsigned)(kp.total + wbits)));
+                vox_gather_kernel<uint32_t><<<grid_for(P, 256), 256, 0, s>>>(P, rec.as<float4>(), idx0.as<uint32_t>(), rec_s.as<float4>(), k32s.as<uint32_t>(), kp,
+                                                                             key_s.as<uint64_t>());
+            } else {
+                key_compress_win_kernel<uint64_t><<<grid_for(P, 256), 256, 0, s>>>(P, key.as<uint64_t>(), rec.as<float4>(), kp, ws, key.as<uint64_t>());
+                HIPCHK(hipGetLastError());
+                TRY(sort_pairs(s, key.as<uint64_t>(), key_s.as<uint64_t>(), idx.as<uint32_t>(), idx0.as<uint32_t>(), (size_t)P, (unsigned)(kp.total + wbits)));
+                vox_gather_kernel<uint64_t><<<grid_for(P, 256), 256, 0, s>>>(P, rec.as<float4>(), idx0.as<uint32_t>(), rec_s.as<float4>(), key_s.as<uint64_t>(), kp,
+                                                                             key_s.as<uint64_t>());
+            }
+        } else if (full_sort) {
             TRY(sort_pairs(s, key.as<uint64_t>(), key_s.as<uint64_t>(), idx.as<uint32_t>(), idx0.as<uint32_t>(), (size_t)P, 63));
             vox_gather_kernel<uint64_t><<<grid_for(P, 256), 256, 0, s>>>(P, rec.as<float4>(), idx0.as<uint32_t>(), rec_s.as<float4>(), nullptr, kp, nullptr);
         } else if (kp.total <= 32) {
@@ -818,7 +880,7 @@ int32_t voxmap_build_impl(lvba_voxmap_s *h, const lvba_scans_s *sc, int frame_be
         DevBuf head_root(s), head_seg(s), incl_root(s), incl_seg(s);
         HIPCHK(head_root.alloc(4 * P)); HIPCHK(head_seg.alloc(4 * P)); HIPCHK(incl_root.alloc(4 * P)); HIPCHK(incl_seg.alloc(4 * P));
         vox_heads_kernel<<<grid_for(P, 256), 256, 0, s>>>(P, key_s.as<uint64_t>(), rec_s.as<float4>(), head_root.as<uint32_t>(),
-                                                          head_seg.as<uint32_t>());
+                                                          head_seg.as<uint32_t>(), ws);
         HIPCHK(hipGetLastError());
         TRY(scan_incl<uint32_t>(s, head_root.as<uint32_t>(), incl_root.as<uint32_t>(), (size_t)P));
         TRY(scan_incl<uint32_t>(s, head_seg.as<uint32_t>(), incl_seg.as<uint32_t>(), (size_t)P));
@@ -920,6 +982,21 @@ int32_t voxmap_build_impl(lvba_voxmap_s *h, const lvba_scans_s *sc, int frame_be
     HIPCHK(lvba::copy_d2h(&V, vox_first.as<int32_t>() + R, 4));
     HIPCHK(lvba::copy_d2h(&F, fac_first.as<int64_t>() + R, 8));
     h->info.n_planes = n_planes; h->info.n_voxels = V; h->info.n_factors = F;
+    if (ws) { // where every window's voxels and factors begin
+        DevBuf wv(s), wf(s);
+        HIPCHK(wv.alloc(8 * (size_t)n_win)); HIPCHK(wf.alloc(8 * (size_t)n_win));
+        HIPCHK(hipMemsetAsync(wv.p, 0xFF, 8 * (size_t)n_win, s)); HIPCHK(hipMemsetAsync(wf.p, 0xFF, 8 * (size_t)n_win, s));
+        vox_win_first_kernel<<<grid_for(R, 256), 256, 0, s>>>(R, root_seg.as<uint32_t>(), seg_frame.as<int32_t>(), ws, vox_first.as<int32_t>(),
+                                                              fac_first.as<int64_t>(), wv.as<int64_t>(), wf.as<int64_t>());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s));
+        h->win_v0.assign((size_t)n_win + 1, 0); h->win_f0.assign((size_t)n_win + 1, 0);
+        HIPCHK(lvba::copy_d2h(h->win_v0.data(), wv.p, 8 * (size_t)n_win));
+        HIPCHK(lvba::copy_d2h(h->win_f0.data(), wf.p, 8 * (size_t)n_win));
+        h->win_v0[(size_t)n_win] = V; h->win_f0[(size_t)n_win] = F;
+        for (int k = n_win - 1; k >= 0; --k) // a window without roots begins (and ends) where the next one begins
+            if (h->win_v0[(size_t)k] < 0) { h->win_v0[(size_t)k] = h->win_v0[(size_t)k + 1]; h->win_f0[(size_t)k] = h->win_f0[(size_t)k + 1]; }
+    }
     h->info.count_ms = now_ms() - t0; t0 = now_ms();
 
     // -- emission
@@ -937,6 +1014,10 @@ int32_t voxmap_build_impl(lvba_voxmap_s *h, const lvba_scans_s *sc, int frame_be
         sa.plane = plane.as<double>(); sa.vox_off = vox_off.as<int64_t>(); sa.pose_idx = pose_idx.as<int32_t>();
         sa.clusters = clusters.as<double>(); sa.vox_label = vox_label.as<int32_t>();
         vox_split_emit_kernel<<<NRS, 64, 0, s>>>(sa);
+        HIPCHK(hipGetLastError());
+    }
+    if (ws && F > 0) { // pose indices relative to the window's first frame, as the window's own map would have them
+        vox_pose_rel_kernel<<<grid_for(F, 256), 256, 0, s>>>(F, pose_idx.as<int32_t>(), ws);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipStreamSynchronize(s));
@@ -958,8 +1039,47 @@ int32_t voxmap_build_impl(lvba_voxmap_s *h, const lvba_scans_s *sc, int frame_be
 } // namespace
 
 // stream != nullptr: the map works on the caller's stream and does not own it (the caller keeps it alive as long as the map)
+static int32_t build_scans_common(lvba_scans_t sc, int32_t frame_begin, int32_t n_frames, const double *poses,
+                                  const lvba_voxel_opts *opts, hipStream_t stream, int window_size, lvba_voxmap_t *out);
 int32_t lvba_voxmap_build_scans_on(lvba_scans_t sc, int32_t frame_begin, int32_t n_frames, const double *poses,
                                    const lvba_voxel_opts *opts, hipStream_t stream, lvba_voxmap_t *out)
+{
+    return build_scans_common(sc, frame_begin, n_frames, poses, opts, stream, 0, out);
+}
+// One map for the windows of window_size frames that make up [frame_begin, frame_begin + n_frames) (window_ba.hip); the windows'
+// own maps are views into it (lvba_voxmap_window_view).
+int32_t lvba_voxmap_build_scans_joint(lvba_scans_t sc, int32_t frame_begin, int32_t n_frames, int32_t window_size, const double *poses,
+                                      const lvba_voxel_opts *opts, hipStream_t stream, lvba_voxmap_t *out)
+{
+    if (window_size < 1) return lvba_fail(LVBA_ERR_ARG, "window_size must be >= 1");
+    return build_scans_common(sc, frame_begin, n_frames, poses, opts, stream, window_size, out);
+}
+int32_t lvba_voxmap_window_view(lvba_voxmap_t joint, int32_t w, lvba_voxmap_t *out)
+{
+    if (!joint || !out) return lvba_fail(LVBA_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (joint->is_view || w < 0 || w >= joint->n_windows) return lvba_fail(LVBA_ERR_ARG, "window %d of %d", w, joint->n_windows);
+    lvba_voxmap_s *v = new (std::nothrow) lvba_voxmap_s();
+    if (!v) return lvba_fail(LVBA_ERR_NOMEM, "host allocation failed");
+    v->device = joint->device; v->stream = joint->stream; v->owns_stream = false; v->opts = joint->opts; v->is_view = true;
+    v->info = joint->info;
+    if (joint->window_size == 0) { // a single window: the map itself
+        v->n_frames = joint->n_frames;
+        v->d_vox_off = joint->d_vox_off; v->d_pose_idx = joint->d_pose_idx; v->d_clusters = joint->d_clusters; v->d_vox_label = joint->d_vox_label;
+    } else {
+        const int64_t v0 = joint->win_v0[(size_t)w], v1 = joint->win_v0[(size_t)w + 1], f0 = joint->win_f0[(size_t)w], f1 = joint->win_f0[(size_t)w + 1];
+        v->n_frames = std::min(joint->window_size, joint->n_frames - w * joint->window_size);
+        v->info.n_voxels = v1 - v0; v->info.n_factors = f1 - f0;
+        v->d_vox_off = joint->d_vox_off + v0; v->d_pose_idx = joint->d_pose_idx + f0;
+        v->d_clusters = joint->d_clusters + 10 * f0; v->d_vox_label = joint->d_vox_label + 2 * v0;
+    }
+    v->d_root_key = joint->d_root_key; // (labels index the joint map's root table)
+    v->window_size = joint->window_size; v->n_windows = joint->n_windows;
+    *out = v;
+    return LVBA_OK;
+}
+static int32_t build_scans_common(lvba_scans_t sc, int32_t frame_begin, int32_t n_frames, const double *poses,
+                                  const lvba_voxel_opts *opts, hipStream_t stream, int window_size, lvba_voxmap_t *out)
 {
     if (!out) return lvba_fail(LVBA_ERR_ARG, "out is null");
     *out = nullptr;
@@ -985,7 +1105,7 @@ int32_t lvba_voxmap_build_scans_on(lvba_scans_t sc, int32_t frame_begin, int32_t
         delete h;
         return lvba_fail(LVBA_ERR_DEVICE, "hipStreamCreate failed");
     }
-    const int32_t rc = voxmap_build_impl(h, sc, frame_begin, poses);
+    const int32_t rc = voxmap_build_impl(h, sc, frame_begin, poses, window_size);
     if (rc != LVBA_OK) { lvba_voxmap_destroy(h); return rc; }
     *out = h;
     return LVBA_OK;
@@ -1065,6 +1185,8 @@ extern "C" int32_t lvba_voxmap_find_planes(lvba_voxmap_t h, int64_t n, const dou
 {
     if (!h || n < 0 || (n > 0 && (!X || !plane || !valid))) return lvba_fail(LVBA_ERR_ARG, "null argument");
     if (n == 0) return LVBA_OK;
+    if (h->is_view || h->window_size > 0)
+        return lvba_fail(LVBA_ERR_UNSUPPORTED, "a joint map of several windows (or a view into one) has no key lookup");
     if (h->info.n_roots == 0) {
         memset(plane, 0, 32 * (size_t)n);
         memset(valid, 0, (size_t)n);

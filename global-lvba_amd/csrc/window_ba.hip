@@ -474,7 +474,44 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
                 if (R.rc < 0) R.err = lvba_last_error();
             }
     };
-    auto free_maps = [&]() { for (auto &q : results) if (q.map) { lvba_voxmap_destroy(q.map); q.map = nullptr; } };
+    lvba_voxmap_t joint_map = nullptr; // stage 1 as ONE map of all windows; the windows' maps are views into it
+    auto free_maps = [&]() {
+        for (auto &q : results) if (q.map) { lvba_voxmap_destroy(q.map); q.map = nullptr; }
+        if (joint_map) { lvba_voxmap_destroy(joint_map); joint_map = nullptr; }
+    };
+    // ---- stage 1 for all windows at once: a root voxel is (window, key), so one sort and one pass of every kernel of the map build
+    // serve every window (the per-window builds are dozens of dependent launches and a dozen host round trips EACH); a window's
+    // part of the joint map is bit for bit what its own build gives (tests/test_gpu_window.py).  LVBA_WINDOW_JOINT_MAP=0: off.
+    auto stage_map_joint = [&]() -> bool {
+        static const bool on = [] { const char *e = getenv("LVBA_WINDOW_JOINT_MAP"); return !(e && !strcmp(e, "0")); }();
+        if (!on || o.merge_only || n_win < 2) return false;
+        const double tw = now_ms();
+        if (lvba_voxmap_build_scans_joint(sc, 0, n, w, poses, &o.voxel, s, &joint_map) != LVBA_OK) {
+            joint_map = nullptr; // (too many key + window bits, a bad point, ...: the per-window builds say what it is)
+            return false;
+        }
+        const double per = (now_ms() - tw) / n_win;
+        for (int wi = 0; wi < n_win; ++wi) {
+            WinResult &R = results[(size_t)wi];
+            int start, cw;
+            win_range(wi, start, cw);
+            R.info = lvba_window_info{};
+            R.info.start = start; R.info.n_frames = cw; R.info.anchor = -1;
+            R.x.assign(poses + 12 * (int64_t)start, poses + 12 * (int64_t)(start + cw));
+            R.rc = lvba_voxmap_window_view(joint_map, wi, &R.map);
+            if (R.rc != LVBA_OK) { R.err = lvba_last_error(); continue; }
+            lvba_voxmap_info_t mi;
+            lvba_voxmap_info(R.map, &mi);
+            R.info.n_voxels = mi.n_voxels; R.info.n_factors = mi.n_factors;
+            R.info.map_ms = per;
+            if (mi.n_voxels < 3 * (int64_t)cw) { // :258-262
+                R.info.skipped = 1;
+                lvba_voxmap_destroy(R.map);
+                R.map = nullptr;
+            }
+        }
+        return true;
+    };
     const bool timing = getenv("LVBA_TIMING") != nullptr; // stage times of the whole call to stderr
     double tmark = now_ms();
     auto mark = [&](const char *what) {
@@ -483,7 +520,7 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
         fprintf(stderr, "[window_ba] %-18s %.3f ms\n", what, t - tmark);
         tmark = t;
     };
-    run_stage(stage_map);
+    if (!stage_map_joint()) run_stage(stage_map);
     mark("voxel maps");
     bool any_failed = false;
     for (auto &q : results) any_failed = any_failed || q.rc < 0;

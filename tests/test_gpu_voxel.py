@@ -316,7 +316,7 @@ s = synth.make_scans(8, 20000, room=(20, 14, 5), origin=(-12.5, 33.1, 1.2), n_pa
 with pkg.Scans(s["clouds"]) as scans:
     with scans.voxel_map(s["poses"], 0.5) as m:
         off, idx, cl, key = m.export()
-    w = scans.window_ba(s["poses"], window_size=4, voxel_size=0.5, anchor_leaf=0.05)
+    w = scans.window_ba(s["poses"], window_size=3, voxel_size=0.5, anchor_leaf=0.05)       # 3 + 3 + 2 frames
     anchors = [w["anchor_scans"].download(k) for k in range(w["anchor_scans"].n_frames)]
     w["anchor_scans"].close()
 np.savez(sys.argv[2], off=off, idx=idx, cl=cl, key=key, wp=w["window_poses"], n=np.array([len(a) for a in anchors]),
@@ -324,10 +324,11 @@ np.savez(sys.argv[2], off=off, idx=idx, cl=cl, key=key, wp=w["window_poses"], n=
 """
 
 
-def test_sorts_on_varying_bits_equal_full_key_sorts(tmp_path):
+def test_sorts_on_varying_bits_and_joint_window_map_change_no_byte(tmp_path):
     """LVBA_SORT_BITS=full sorts root keys and anchor-leaf keys on all 63 bits as rounds 1-3 did; the default re-packs them onto
-    the bits that vary.  Same order either way: the map and the whole window stage (anchor clouds point for point) are
-    identical byte for byte."""
+    the bits that vary.  LVBA_WINDOW_JOINT_MAP=0 builds one voxel map per window as rounds 1-3 did; the default builds ONE map
+    whose roots are (window, key) and hands the windows views into it.  Same order, same sums either way: the map and the whole
+    window stage (refined window poses, anchor clouds point for point) are identical byte for byte."""
     import os
     import subprocess
     import sys
@@ -335,12 +336,14 @@ def test_sorts_on_varying_bits_equal_full_key_sorts(tmp_path):
     script = tmp_path / "run.py"
     script.write_text(_SORT_SCRIPT)
     out = []
-    for i, v in enumerate([{}, {"LVBA_SORT_BITS": "full"}]):
+    for i, v in enumerate([{}, {"LVBA_SORT_BITS": "full"}, {"LVBA_WINDOW_JOINT_MAP": "0"},
+                           {"LVBA_WINDOW_JOINT_MAP": "0", "LVBA_SORT_BITS": "full"}]):
         f = tmp_path / f"o_{i}.npz"
         r = subprocess.run([sys.executable, str(script), root, str(f)], env=dict(os.environ, **v), capture_output=True, text=True,
                            timeout=600)
         assert r.returncode == 0, (v, r.stderr[-2000:])
         out.append(np.load(f))
     assert len(out[0]["off"]) > 100 and out[0]["n"].sum() > 1000
-    for k in out[0].files:
-        np.testing.assert_array_equal(out[0][k], out[1][k], err_msg=k)
+    for o in out[1:]:
+        for k in out[0].files:
+            np.testing.assert_array_equal(out[0][k], o[k], err_msg=k)
