@@ -1670,7 +1670,7 @@ static inline int64_t ldlt_ws_one(int64_t n, int64_t bw)
 {
     const int64_t nsteps = (n + LVBA_NB - 1) / LVBA_NB;
     return nsteps * 4096 /*G*/ + 3 * n /*d, b, bacc*/ + 4 * ldz_for(n, bw) * LVBA_NB /*Z, four buffers (st % 4)*/ + 64 +
-           2 * 4096 /*side copies of A(p+1, p), look-ahead schedule*/;
+           2 * 4096 /*side copies of A(p+1, p), look-ahead schedule*/ + 2 * 4096 /*panel q's share of the next diagonal block, ditto*/;
 }
 // two problems' workspaces + matrix 2's solution vector (twisted factorisation)
 // + the exchange buffer of the multi-rank form: |S| <= bw + 2 * 64 columns of bw + 1 entries, and the S part of the rhs
@@ -1885,6 +1885,15 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
     // tile-level model of the factorisation, tests/ldlt_schedule_check.cpp)
     static const bool lookahead = [] { const char *e = getenv("LVBA_SOLVER"); return !(e && !strcmp(e, "r3")); }();
     double *side_buf[2] = {Zbuf[3] + ldz * LVBA_NB + 64, Zbuf[3] + ldz * LVBA_NB + 64 + 4096};
+    double *dq_buf[2] = {side_buf[1] + 4096, side_buf[1] + 2 * 4096};
+    // Panel q's share of the next diagonal block, L(p+1, q) Z(p+1, q)^T, is formed by row 1 of launch X_q (which holds L(p+1, q))
+    // and handed to X_p's chain workgroup ready-made: the chain role alone 26.1 -> 23.2 us.  Row 1 then does one product more
+    // than the other rows; in the launches where the rows also carry the q_extra product its q_extra tile goes to a role
+    // workgroup of its own (qx_helper), and the seat next to row 1 stays empty like the chain's (LVBA_ROW1_ALONE).  rocprof,
+    // S phase: launches 26.5 -> 23 us; C3 solve -0.08 .. -0.13 ms (ABAB on one box: 4.18, 4.12 against 4.05, 4.04).  Without
+    // the helper and the empty seat the S phase alternates 27 / 22.5 us and the two-ended launches grow: no gain at all (modes 1, 2).
+    // LVBA_CHAIN_DQ=0: the chain workgroup multiplies itself (A/B).
+    static const int chain_dq = [] { const char *e = getenv("LVBA_CHAIN_DQ"); return e ? atoi(e) : 3; }(); // 0: off, 1: always, 2: only from launches without q_extra, 3 (default): always + qx_helper
     // LVBA_BULK_TILE = k32 (default: round 2's tile, K chunks of 32, one chunk buffer) | k16 (chunks of 16, two buffers, three
     // register sets: 28.9 against 30.3 us for 408 tiles alone, but the same solve time, 4.10 / 4.06 ms) | k32db (two K = 32
     // buffers, one workgroup per CU: 4.87 ms)
@@ -1893,6 +1902,8 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
         return !e ? 0 : !strcmp(e, "k16") ? 2 : !strcmp(e, "k32db") ? 1 : !strcmp(e, "sq") ? 3 : 0;
     }();
     static const bool chain_alone = [] { const char *e = getenv("LVBA_CHAIN_ALONE"); return !(e && !strcmp(e, "0")); }();
+    static const int bulk_prio = [] { const char *e = getenv("LVBA_BULK_PRIO"); return e ? atoi(e) : 0; }();
+    static const bool row1_alone = [] { const char *e = getenv("LVBA_ROW1_ALONE"); return !(e && !strcmp(e, "0")); }();
     static const int n_cus = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
@@ -1906,6 +1917,7 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
         std::vector<SchedLaunch> sched;
         ldlt_schedule_phase(sa, sb, close, rank128, [&](int64_t st) { return st < nsteps ? geom(st).T : (int64_t)0; }, sched);
         auto pg = [&](int64_t st) { const Geo g = geom(st); return PanelGeo{g.k, g.w0, g.rend, g.nbe, (int)g.T}; };
+        bool dq_prev_written = false; // did the role launch before this one leave panel q's share of the diagonal block?
         for (const SchedLaunch &L : sched) {
             if (L.kind == 0) {
                 const Geo g = geom(L.p);
@@ -1927,7 +1939,14 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
                 a.Gp = Gall + wo + L.p * 4096; a.Gn = Gall + wo + (L.p + 1) * 4096;
                 a.Zp = Zbuf[L.p % 4] + wo; a.Zq = L.has_q ? Zbuf[(L.p - 1) % 4] + wo : nullptr;
                 a.side_r = side_buf[L.p % 2] + wo; a.side_w = side_buf[(L.p + 1) % 2] + wo;
-                nwg += a.p.T;
+                if (chain_dq) { // written by row 1 of this launch for the next one; read by the chain if the launch before had a row 1
+                    const bool wr = chain_dq == 1 || chain_dq == 3 || !L.q_extra;
+                    a.dq_w = wr ? dq_buf[L.p % 2] + wo : nullptr;
+                    a.dq_r = (L.has_q && geom(L.p - 1).T >= 2 && dq_prev_written) ? dq_buf[(L.p - 1) % 2] + wo : nullptr;
+                    dq_prev_written = wr;
+                    a.qx_helper = (wr && L.q_extra && a.p.T >= 2 && chain_dq == 3) ? 1 : 0; // (3: + row 1's q_extra tile on a workgroup of its own)
+                }
+                nwg += a.p.T + a.qx_helper;
             }
             for (int j = 0; j < L.njobs; ++j) {
                 BulkJob &J = a.job[a.njobs];
@@ -1947,11 +1966,14 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
                 nwg += J.nwg;
                 ++a.njobs;
             }
+            a.bulk_prio = bulk_prio;
             int64_t grid = nwg * ny;
             const int bt = big ? bulk_tile : 0; // (ldlt_lookahead.h: BT)
             if (chain_alone && bt != 1 && L.roles && grid > n_cus) { // (ldlt_lookahead.h: resv_at; bt 1 has one workgroup per CU anyway)
-                a.resv_at = n_cus; a.resv_n = (int)ny;
-                grid += ny;
+                // (row 1 -- the blocks ny .. 2 ny - 1 -- does one product more than the other rows when it forms panel p's share
+                // of the next diagonal block: LVBA_ROW1_ALONE=1 keeps the seats next to it empty as well)
+                a.resv_at = n_cus; a.resv_n = (int)ny * (row1_alone && a.p.T >= 2 ? 2 : 1);
+                grid += a.resv_n;
             }
             if (nwg > 0) {
                 if (bt == 3) hipLaunchKernelGGL((ldlt_step2_kernel<true, 3>), dim3((unsigned)grid), dim3(256), 0, s, a);

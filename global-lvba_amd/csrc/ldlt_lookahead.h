@@ -46,6 +46,14 @@ struct Step2Args {
     PanelGeo p, q;
     const double *side_r; // A(p+1, p) as [m][row] (64 x 64, masked like load_panel_tile), read by the row roles
     double *side_w;       // A(p+2, p+1) for the next launch, written by row 1
+    // Panel q's contribution to the diagonal block p + 1, L(p+1, q) Z(p+1, q)^T, formed OFF the chain: row 1 of launch X_q holds
+    // L(p+1, q) in its registers anyway and leaves the 64 x 64 product in dq_w ([column][row]); the chain workgroup of X_p starts
+    // its accumulators from dq_r instead of fetching L and Z and multiplying itself (22.7 instead of 26.1 us alone).  nullptr:
+    // the chain multiplies itself / row 1 leaves nothing.
+    const double *dq_r;
+    double *dq_w;
+    int qx_helper; // q_extra launches with dq_w: row 1's q_extra tile -- the diagonal tile (p+2, p+2) -- is done by one more role
+                   // workgroup (role index T), so that row 1 (which forms the dq product) does as many products as the other rows
     const double *Gp; // G of panel p
     double *Gn;       // G of panel p + 1 (written by the chain role)
     double *dvec, *b, *Zp;
@@ -64,6 +72,11 @@ struct Step2Args {
     // 79 900 -> 59 600 cycles (what it takes alone), the launch 37.9 -> 29.6 us.  Placement is a matter of speed only: wherever
     // the blocks land, every tile is still done exactly once.  resv_n = 0: off.
     int resv_at, resv_n;
+    // Issue priority of the bulk workgroups (s_setprio 0..3; the chain runs at 3).  A bulk tile that shares its CU with a row
+    // workgroup is what a two-ended launch waits for (rocprof, round 4: 32 - 36 us against 30 for two tiles sharing and 18 for a
+    // tile alone) although the two together have 18 us of matrix-pipe work: ahead of the row workgroup on the issue slots, the
+    // tile runs at its own pace and the row workgroup -- which has the whole launch to finish -- fills the gaps.
+    int bulk_prio;
     // experiment (tools/solver_microbench; needs dbg): every bulk workgroup does what a flag-driven, launch-free form would add to
     // it -- one relaxed agent-scope poll + acquire fence before its tile, release fence + vmcnt(0) + one agent-scope atomic after
     int fence_probe;
@@ -173,7 +186,7 @@ __device__ __forceinline__ double red4(double *lds, int j)
 // ---------------------------------------------------------------------------------------------- the chain role
 __device__ __forceinline__ void chain_role(double *lds, const LdltMat &M, const Step2Args &A, const double *__restrict__ Gp,
                                            double *__restrict__ Gn, double *__restrict__ dvec, double *__restrict__ b,
-                                           double *__restrict__ Zp, const double *__restrict__ Zq)
+                                           double *__restrict__ Zp, const double *__restrict__ Zq, const double *__restrict__ dq_r)
 {
     double *Ls = lds, *Zs = lds + 64 * LVBA_TS;
     const PanelGeo &p = A.p, &q = A.q;
@@ -182,7 +195,9 @@ __device__ __forceinline__ void chain_role(double *lds, const LdltMat &M, const 
 #define LVBA_CH_STAMP(k) do { if (A.dbg && tid == 0 && Gp == A.Gp) A.dbg[520 + (k)] = __builtin_readcyclecounter(); } while (0)
     LVBA_CH_STAMP(0);
     __builtin_amdgcn_s_setprio(3);        // the launch is as long as this workgroup: first call on the issue slots it shares
-    const bool use_q = A.has_q && r0 < q.rend; // (a band narrower than two tiles: panel q does not reach tile row p + 1)
+    const bool has_q = A.has_q && r0 < q.rend; // (a band narrower than two tiles: panel q does not reach tile row p + 1)
+    const bool use_dq = has_q && dq_r;         // panel q's contribution comes ready-made from row 1 of the launch before
+    const bool use_q = has_q && !use_dq;
     double va[16], vb[16], a1[16], gp[16];
     if (use_q) {
         load_panel_tile(M, r0, q.k, q.rend, q.nbe, w, row, va);    // L(p+1, q)
@@ -196,6 +211,12 @@ __device__ __forceinline__ void chain_role(double *lds, const LdltMat &M, const 
     d4 acc[4], accL[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = accL[t] = (d4){0.0, 0.0, 0.0, 0.0};
+    if (use_dq) { // requested behind the operands of the first product: needed only by the last one
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) acc[t][reg] = dq_r[(16 * w + kk + 4 * reg) * 64 + 16 * t + i];
+    }
     if (use_q) { // block-uniform
         stage_tile(Ls, va, w, row);
         stage_tile(Zs, vb, w, row);
@@ -297,7 +318,8 @@ __device__ __forceinline__ void chain_role(double *lds, const LdltMat &M, const 
 // tile row t >= 1 of panel p's window (global tile row i = p + 1 + t)
 __device__ __forceinline__ void row_role(double *lds, const LdltMat &M, const Step2Args &A, int64_t t_row, const double *__restrict__ Gp,
                                          const double *__restrict__ dvec, double *__restrict__ b, double *__restrict__ Zp,
-                                         const double *__restrict__ Zq, const double *__restrict__ side_r, double *__restrict__ side_w)
+                                         const double *__restrict__ Zq, const double *__restrict__ side_r, double *__restrict__ side_w,
+                                         double *__restrict__ dq_w)
 {
     double *Ls = lds, *Zs = lds + 64 * LVBA_TS;
     const PanelGeo &p = A.p, &q = A.q;
@@ -321,11 +343,12 @@ __device__ __forceinline__ void row_role(double *lds, const LdltMat &M, const St
     if (use_q) {
         stage_tile(Ls, va, w, row);
         stage_tile(Zs, vb, w, row);
-        if (A.q_extra) load_z_tile(Zq, A.ldz, s0 + 64, q.w0, q.rend, q.nbe, w, row, vb); // Z(p+2, q)
+        const bool qx = A.q_extra && !(A.qx_helper && t_row == 1); // (row 1's tile of block column p + 2: qx_diag_role, if there is one)
+        if (qx) load_z_tile(Zq, A.ldz, s0 + 64, q.w0, q.rend, q.nbe, w, row, vb); // Z(p+2, q)
         __syncthreads();
         tile_product(Ls, Zs, w, i, kk, acc);
         __syncthreads();
-        if (A.q_extra) { // block column p + 2 from panel q alone: this row's tile, with L(i, q) still in LDS
+        if (qx) { // block column p + 2 from panel q alone: this row's tile, with L(i, q) still in LDS
             stage_tile(Zs, vb, w, row);
             double c2[16];
 #pragma unroll
@@ -415,6 +438,55 @@ __device__ __forceinline__ void row_role(double *lds, const LdltMat &M, const St
             if (rr < p.rend && c < p.rend) M.a[rr + c * M.ld] = v;
             if (mk_side) side_w[cl * 64 + rl] = (rr < A.rend_next && cl < A.nbe_next) ? v : 0.0;
         }
+    if (mk_side && dq_w) { // this panel's contribution to the NEXT launch's diagonal block (p+2, p+2), off that launch's chain:
+                             // L(i, p) is in Ls; Z(i, p) = L(i, p) D takes Z(p+1, p)'s place
+        put_acc(Zs, accI, w, i, kk, lds);
+        __syncthreads();
+        d4 accP[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) accP[t] = (d4){0.0, 0.0, 0.0, 0.0};
+        tile_product(Ls, Zs, w, i, kk, accP);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) dq_w[(16 * w + kk + 4 * reg) * 64 + 16 * t + i] = accP[t][reg];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- row 1's q_extra tile, on its own
+// A(p+2, p+2) -= L(p+2, q) Z(p+2, q)^T (lower triangle): inputs of the launch before, nobody else in this launch touches the tile
+__device__ __forceinline__ void qx_diag_role(double *lds, const LdltMat &M, const Step2Args &A, const double *__restrict__ Zq)
+{
+    double *Ls = lds, *Zs = lds + 64 * LVBA_TS;
+    const PanelGeo &p = A.p, &q = A.q;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, row = tid & 63, i = lane & 15, kk = lane >> 4;
+    const int64_t r0 = p.w0 + 64; // tile row p + 2 = its tile column
+    if (!(A.has_q && r0 < q.rend)) return;
+    double va[16], vb[16];
+    load_panel_tile(M, r0, q.k, q.rend, q.nbe, w, row, va);      // L(p+2, q)
+    load_z_tile(Zq, A.ldz, r0, q.w0, q.rend, q.nbe, w, row, vb); // Z(p+2, q)
+    double c2[16];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int64_t c = r0 + 16 * w + kk + 4 * reg, rr = r0 + 16 * t + i;
+            c2[4 * t + reg] = (rr < q.rend && c < q.rend && rr >= c) ? M.a[rr + c * M.ld] : 0.0;
+        }
+    stage_tile(Ls, va, w, row);
+    stage_tile(Zs, vb, w, row);
+    __syncthreads();
+    d4 accx[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) accx[t] = (d4){0.0, 0.0, 0.0, 0.0};
+    tile_product(Ls, Zs, w, i, kk, accx);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int64_t c = r0 + 16 * w + kk + 4 * reg, rr = r0 + 16 * t + i;
+            if (rr < q.rend && c < q.rend && rr >= c) M.a[rr + c * M.ld] = c2[4 * t + reg] - accx[t][reg];
+        }
 }
 
 // ---------------------------------------------------------------------------------------------- one launch
@@ -432,7 +504,7 @@ __global__ __launch_bounds__(256, BT == 1 ? 1 : 2) void ldlt_step2_kernel(const 
                       LVBA_PAD_RED + 256 <= 1024,
                   "LDS budget of the roles");
     static_assert(BT == 0 || big, "the other bulk tiles exist for the 128 x 64 form only");
-    const int64_t nrole = A.roles ? A.p.T : 0, nfac = nrole * A.nprob;
+    const int64_t nrole = A.roles ? A.p.T + (A.qx_helper ? 1 : 0) : 0, nfac = nrole * A.nprob;
     LdltMat M = A.M;
     int prob;
     int64_t bx;
@@ -456,14 +528,23 @@ __global__ __launch_bounds__(256, BT == 1 ? 1 : 2) void ldlt_step2_kernel(const 
         if (bx == 0) {
             const bool stamp = A.dbg && prob == 0 && threadIdx.x == 0;
             if (stamp) A.dbg[0] = __builtin_readcyclecounter();
-            chain_role(lds, M, A, A.Gp + wo, A.Gn + wo, A.dvec + wo, A.b + wo, A.Zp + wo, A.Zq ? A.Zq + wo : nullptr);
+            chain_role(lds, M, A, A.Gp + wo, A.Gn + wo, A.dvec + wo, A.b + wo, A.Zp + wo, A.Zq ? A.Zq + wo : nullptr,
+                       A.dq_r ? A.dq_r + wo : nullptr);
             if (stamp) A.dbg[1] = __builtin_readcyclecounter();
         }
-        else row_role(lds, M, A, bx, A.Gp + wo, A.dvec + wo, A.b + wo, A.Zp + wo, A.Zq ? A.Zq + wo : nullptr, A.side_r + wo, A.side_w + wo);
+        else if (bx == A.p.T) qx_diag_role(lds, M, A, A.Zq ? A.Zq + wo : nullptr);
+        else row_role(lds, M, A, bx, A.Gp + wo, A.dvec + wo, A.b + wo, A.Zp + wo, A.Zq ? A.Zq + wo : nullptr, A.side_r + wo, A.side_w + wo,
+                      A.dq_w ? A.dq_w + wo : nullptr);
         return;
     }
     if (A.stagger_n > 0 && (int)blockIdx.x >= A.stagger_from)
         for (int q = 0; q < A.stagger_n; ++q) __builtin_amdgcn_s_sleep(16);
+    switch (A.bulk_prio) { // (s_setprio takes an immediate)
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    case 3: __builtin_amdgcn_s_setprio(3); break;
+    default: break;
+    }
     const bool probe = A.fence_probe && A.dbg;
     if (probe) {
         if (threadIdx.x == 0) {

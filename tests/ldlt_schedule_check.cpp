@@ -31,7 +31,7 @@ struct Model {
     std::vector<int64_t> T;
     std::map<std::pair<int64_t, int64_t>, std::set<int64_t>> applied;
     std::map<std::pair<int64_t, int64_t>, int> isL; // tile (i, k) -> launch that turned it into L
-    std::map<int64_t, int> diag_done, side_copy;
+    std::map<int64_t, int> diag_done, side_copy, dq_made; // dq_made[q]: row 1 of X_q left L(q+2, q) Z(q+2, q)^T for X_{q+1}'s chain
     std::set<std::pair<int64_t, int64_t>> written, readL;
     int now = 0;
 
@@ -97,11 +97,13 @@ struct Model {
                         needL(i, q);
                         needL(p + 1, q);
                         apply(i, p + 1, q);
+                        // the chain workgroup (t = 0) takes panel q's share of the diagonal block from what row 1 of X_q left
+                        if (t == 0) CHECK(dq_made.count(q) && dq_made[q] < now, "launch %d: no ready-made share of panel %lld for block %lld", now, (long long)q, (long long)(p + 1));
                     }
                     if (t >= 1) CHECK(side_copy.count(p) && side_copy[p] < now, "side copy of A(%lld,%lld) missing", (long long)(p + 1), (long long)p);
                     apply(i, p + 1, p);
                     write(i, p + 1);
-                    if (t == 1) { CHECK(complete(i, p + 1), "side copy taken of an incomplete tile"); side_copy[p + 1] = now; }
+                    if (t == 1) { CHECK(complete(i, p + 1), "side copy taken of an incomplete tile"); side_copy[p + 1] = now; dq_made[p] = now; }
                     if (L.q_extra && t >= 1 && i <= q + Tof(q)) { // block column p + 2 from panel q, by the row that holds L(i, q)
                         CHECK(L.has_q, "q_extra without q");
                         needL(i, q);

@@ -467,6 +467,12 @@ def test_solver_schedules(tmp_path):
                 # the other bulk tiles: K chunks of 16 with two chunk buffers, K chunks of 32 with two buffers (default: 32, one buffer)
                 {"LVBA_BULK_TILE": "k16"}, {"LVBA_BULK_TILE": "k16", "LVBA_CHAIN_ALONE": "0"}, {"LVBA_BULK_TILE": "k16", "LVBA_RANK128": "0"},
                 {"LVBA_BULK_TILE": "k32db"},
+                # panel q's share of the next diagonal block formed by row 1 of the launch before instead of by the chain workgroup
+                # (0: by the chain itself; 1: always, 2: only by launches without q_extra, 3 = default: always + row 1's q_extra tile on
+                # a workgroup of its own), the seats next to row 1 taken again, the bulk tiles ahead of the rows on the issue slots
+                {"LVBA_CHAIN_DQ": "1"}, {"LVBA_CHAIN_DQ": "1", "LVBA_RANK128": "0"}, {"LVBA_CHAIN_DQ": "2"},
+                {"LVBA_CHAIN_DQ": "3", "LVBA_ROW1_ALONE": "0"}, {"LVBA_CHAIN_DQ": "0", "LVBA_TWIST": "0"}, {"LVBA_CHAIN_DQ": "0"},
+                {"LVBA_CHAIN_DQ": "0", "LVBA_ROW1_ALONE": "0", "LVBA_RANK128": "0"}, {"LVBA_BULK_PRIO": "2"},
                 # 128 x 128 tiles with the operand chunks loaded straight into LDS
                 {"LVBA_BULK_TILE": "sq"}, {"LVBA_BULK_TILE": "sq", "LVBA_RANK128": "0"}, {"LVBA_BULK_TILE": "sq", "LVBA_TWIST": "0"}]
     out = []

@@ -74,6 +74,10 @@ int main(int argc, char **argv)
         a.M = A; a.sA = 0; a.sW = 0; a.ldz = ldz; a.nprob = 1; a.roles = 1; a.has_q = 1; a.do_diag = 1; a.nbe_next = 64;
         a.p = geo(10); a.q = geo(9); a.rend_next = geo(11).rend;
         a.side_r = side; a.side_w = side + 4096; a.Gp = Gall + 10 * 4096; a.Gn = Gall + 11 * 4096; a.dvec = dvec; a.b = b;
+        a.dq_r = side + 2 * 4096; a.dq_w = side + 3 * 4096; // (LVBA_MB_NODQ: the chain multiplies panel q's share itself, as before)
+#ifdef LVBA_MB_NODQ
+        a.dq_r = nullptr; a.dq_w = nullptr;
+#endif
         a.Zp = Z2; a.Zq = Z2 + ldz * 64; a.status = status;
         const int Tfull = a.p.T;
         a.p.T = 1; // the chain workgroup alone
@@ -119,12 +123,16 @@ int main(int argc, char **argv)
         };
         // problem 0's arrays inside w2: G [16 panels] | d, b | Z x 4 | side x 2 ; problem 1 at + sW (sW only has to be larger)
         double *G0 = w2, *d0 = G0 + 16 * 4096, *b0 = d0 + n, *Z0 = b0 + n, *side0 = Z0 + 4 * ldz * 64;
-        if (side0 + 2 * 4096 > w2 + sW) { printf("workspace layout too small\n"); return 1; }
+        if (side0 + 4 * 4096 > w2 + sW) { printf("workspace layout too small\n"); return 1; }
         Step2Args a{};
         a.skip_a = a.skip_b = -1;
         a.M = A2; a.sA = sA; a.sW = sW; a.ldz = ldz; a.nprob = 2; a.roles = 1; a.has_q = 1; a.do_diag = 1; a.nbe_next = 64;
         a.p = geo(10); a.q = geo(9); a.rend_next = geo(11).rend;
         a.side_r = side0; a.side_w = side0 + 4096; a.Gp = G0 + 10 * 4096; a.Gn = G0 + 11 * 4096; a.dvec = d0; a.b = b0;
+        a.dq_r = side0 + 2 * 4096; a.dq_w = side0 + 3 * 4096;
+#ifdef LVBA_MB_NODQ
+        a.dq_r = nullptr; a.dq_w = nullptr;
+#endif
         a.Zp = Z0; a.Zq = Z0 + ldz * 64; a.status = status; a.dbg = dbg;
         const int T = a.p.T;
         auto chain_us = [&]() { unsigned long long c[2]; CK(hipMemcpy(c, dbg, 16, hipMemcpyDeviceToHost)); return (double)(c[1] - c[0]); };
