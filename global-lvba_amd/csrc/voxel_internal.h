@@ -33,6 +33,7 @@ int32_t lvba_voxmap_build_scans_on(lvba_scans_s *sc, int32_t frame_begin, int32_
 int32_t lvba_voxmap_build_scans_joint(lvba_scans_s *sc, int32_t frame_begin, int32_t n_frames, int32_t window_size, const double *poses,
                                       const lvba_voxel_opts *opts, hipStream_t stream, lvba_voxmap_s **out);
 int32_t lvba_voxmap_window_view(lvba_voxmap_s *joint, int32_t w, lvba_voxmap_s **out);
+int32_t lvba_voxmap_window_range(lvba_voxmap_s *joint, int32_t w, int64_t *v0, int64_t *v1, int64_t *f0, int64_t *f1);
 
 struct lvba_balm_s;
 namespace lvba {

@@ -1054,6 +1054,15 @@ int32_t lvba_voxmap_build_scans_joint(lvba_scans_t sc, int32_t frame_begin, int3
     if (window_size < 1) return lvba_fail(LVBA_ERR_ARG, "window_size must be >= 1");
     return build_scans_common(sc, frame_begin, n_frames, poses, opts, stream, window_size, out);
 }
+// where window w's admitted voxels and factors sit in the joint map's arrays
+int32_t lvba_voxmap_window_range(lvba_voxmap_t joint, int32_t w, int64_t *v0, int64_t *v1, int64_t *f0, int64_t *f1)
+{
+    if (!joint || joint->is_view || w < 0 || w >= joint->n_windows || !v0 || !v1 || !f0 || !f1) return lvba_fail(LVBA_ERR_ARG, "bad argument");
+    if (joint->window_size == 0) { *v0 = 0; *v1 = joint->info.n_voxels; *f0 = 0; *f1 = joint->info.n_factors; return LVBA_OK; }
+    *v0 = joint->win_v0[(size_t)w]; *v1 = joint->win_v0[(size_t)w + 1];
+    *f0 = joint->win_f0[(size_t)w]; *f1 = joint->win_f0[(size_t)w + 1];
+    return LVBA_OK;
+}
 int32_t lvba_voxmap_window_view(lvba_voxmap_t joint, int32_t w, lvba_voxmap_t *out)
 {
     if (!joint || !out) return lvba_fail(LVBA_ERR_ARG, "null argument");

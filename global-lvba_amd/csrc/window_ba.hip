@@ -195,6 +195,7 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
     const int n_win = (n + w - 1) / w;
     lvba::hvec<WinResult> results((size_t)n_win);
     auto win_range = [&](int wi, int &start, int &cw) { start = wi * w; cw = std::min(w, n - start); };
+    lvba_voxmap_t joint_map = nullptr; // stage 1 as ONE map of all windows (stage_map_joint); the windows' maps are views into it
     // ---- stage 1: the voxel map at the odometry poses (:247-257) and the skip rule (:258-262)
     auto stage_map = [&](int wi, hipStream_t ws, WinResult &R) -> int32_t {
         int start, cw;
@@ -271,11 +272,25 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
         lvba::hvec<double> x(12 * (size_t)pose_off[(size_t)G]);
         DevBuf d_clu(s);
         HIPCHK(d_clu.alloc(80 * (size_t)F));
+        lvba::hvec<int64_t> joff; // with a joint map: its whole CSR structure in ONE pair of copies instead of two per window
+        lvba::hvec<int32_t> jidx;
+        if (joint_map) {
+            lvba_voxmap_info_t ji;
+            lvba_voxmap_info(joint_map, &ji);
+            joff.resize((size_t)ji.n_voxels + 1); jidx.resize((size_t)std::max<int64_t>(ji.n_factors, 1));
+            TRY(lvba_voxmap_export(joint_map, joff.data(), jidx.data(), nullptr, nullptr));
+        }
         for (int k = 0; k < G; ++k) {
             const WinResult &R = results[(size_t)live[(size_t)k]];
             const int64_t v0 = vox_off[(size_t)k], f0 = fac_off[(size_t)k], nv = R.info.n_voxels, nf = R.info.n_factors;
             lvba::hvec<int64_t> o1((size_t)nv + 1);
-            TRY(lvba_voxmap_export(R.map, o1.data(), idx.data() + f0, nullptr, nullptr)); // CSR structure to the host, clusters stay in HBM
+            if (joint_map) {
+                int64_t jv0, jv1, jf0, jf1;
+                TRY(lvba_voxmap_window_range(joint_map, live[(size_t)k], &jv0, &jv1, &jf0, &jf1));
+                memcpy(o1.data(), joff.data() + jv0, 8 * ((size_t)nv + 1));
+                memcpy(idx.data() + f0, jidx.data() + jf0, 4 * (size_t)nf);
+            } else
+                TRY(lvba_voxmap_export(R.map, o1.data(), idx.data() + f0, nullptr, nullptr)); // CSR structure to the host, clusters stay in HBM
             for (int64_t a = 0; a <= nv; ++a) off[(size_t)(v0 + a)] = f0 + (o1[(size_t)a] - o1[0]);
             for (int64_t f = f0; f < f0 + nf; ++f) idx[(size_t)f] += pose_off[(size_t)k];
             HIPCHK(hipMemcpyAsync(d_clu.as<double>() + 10 * f0, lvba_voxmap_clusters(R.map), 80 * (size_t)nf, hipMemcpyDeviceToDevice, s));
@@ -474,7 +489,6 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
                 if (R.rc < 0) R.err = lvba_last_error();
             }
     };
-    lvba_voxmap_t joint_map = nullptr; // stage 1 as ONE map of all windows; the windows' maps are views into it
     auto free_maps = [&]() {
         for (auto &q : results) if (q.map) { lvba_voxmap_destroy(q.map); q.map = nullptr; }
         if (joint_map) { lvba_voxmap_destroy(joint_map); joint_map = nullptr; }
