@@ -1903,6 +1903,7 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
     }();
     static const bool chain_alone = [] { const char *e = getenv("LVBA_CHAIN_ALONE"); return !(e && !strcmp(e, "0")); }();
     static const int bulk_prio = [] { const char *e = getenv("LVBA_BULK_PRIO"); return e ? atoi(e) : 0; }();
+    static const int row_prio = [] { const char *e = getenv("LVBA_ROW_PRIO"); return e ? atoi(e) : 0; }();
     static const bool row1_alone = [] { const char *e = getenv("LVBA_ROW1_ALONE"); return !(e && !strcmp(e, "0")); }();
     static const int n_cus = [] {
         int dev = 0, n = 0;
@@ -1966,7 +1967,7 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
                 nwg += J.nwg;
                 ++a.njobs;
             }
-            a.bulk_prio = bulk_prio;
+            a.bulk_prio = bulk_prio; a.row_prio = row_prio;
             int64_t grid = nwg * ny;
             const int bt = big ? bulk_tile : 0; // (ldlt_lookahead.h: BT)
             if (chain_alone && bt != 1 && L.roles && grid > n_cus) { // (ldlt_lookahead.h: resv_at; bt 1 has one workgroup per CU anyway)

@@ -77,6 +77,7 @@ struct Step2Args {
     // tile alone) although the two together have 18 us of matrix-pipe work: ahead of the row workgroup on the issue slots, the
     // tile runs at its own pace and the row workgroup -- which has the whole launch to finish -- fills the gaps.
     int bulk_prio;
+    int row_prio; // the same for the row workgroups (and row 1's helper)
     // experiment (tools/solver_microbench; needs dbg): every bulk workgroup does what a flag-driven, launch-free form would add to
     // it -- one relaxed agent-scope poll + acquire fence before its tile, release fence + vmcnt(0) + one agent-scope atomic after
     int fence_probe;
@@ -531,8 +532,15 @@ __global__ __launch_bounds__(256, BT == 1 ? 1 : 2) void ldlt_step2_kernel(const 
             chain_role(lds, M, A, A.Gp + wo, A.Gn + wo, A.dvec + wo, A.b + wo, A.Zp + wo, A.Zq ? A.Zq + wo : nullptr,
                        A.dq_r ? A.dq_r + wo : nullptr);
             if (stamp) A.dbg[1] = __builtin_readcyclecounter();
+            return;
         }
-        else if (bx == A.p.T) qx_diag_role(lds, M, A, A.Zq ? A.Zq + wo : nullptr);
+        switch (A.row_prio) { // (s_setprio takes an immediate)
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        case 3: __builtin_amdgcn_s_setprio(3); break;
+        default: break;
+        }
+        if (bx == A.p.T) qx_diag_role(lds, M, A, A.Zq ? A.Zq + wo : nullptr);
         else row_role(lds, M, A, bx, A.Gp + wo, A.dvec + wo, A.b + wo, A.Zp + wo, A.Zq ? A.Zq + wo : nullptr, A.side_r + wo, A.side_w + wo,
                       A.dq_w ? A.dq_w + wo : nullptr);
         return;

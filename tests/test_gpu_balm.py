@@ -472,7 +472,7 @@ def test_solver_schedules(tmp_path):
                 # a workgroup of its own), the seats next to row 1 taken again, the bulk tiles ahead of the rows on the issue slots
                 {"LVBA_CHAIN_DQ": "1"}, {"LVBA_CHAIN_DQ": "1", "LVBA_RANK128": "0"}, {"LVBA_CHAIN_DQ": "2"},
                 {"LVBA_CHAIN_DQ": "3", "LVBA_ROW1_ALONE": "0"}, {"LVBA_CHAIN_DQ": "0", "LVBA_TWIST": "0"}, {"LVBA_CHAIN_DQ": "0"},
-                {"LVBA_CHAIN_DQ": "0", "LVBA_ROW1_ALONE": "0", "LVBA_RANK128": "0"}, {"LVBA_BULK_PRIO": "2"},
+                {"LVBA_CHAIN_DQ": "0", "LVBA_ROW1_ALONE": "0", "LVBA_RANK128": "0"}, {"LVBA_BULK_PRIO": "2"}, {"LVBA_ROW_PRIO": "2"},
                 # 128 x 128 tiles with the operand chunks loaded straight into LDS
                 {"LVBA_BULK_TILE": "sq"}, {"LVBA_BULK_TILE": "sq", "LVBA_RANK128": "0"}, {"LVBA_BULK_TILE": "sq", "LVBA_TWIST": "0"}]
     out = []
