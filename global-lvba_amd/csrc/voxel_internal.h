@@ -147,8 +147,11 @@ __device__ __forceinline__ void key_range_update(int *__restrict__ partial, cons
     }
 }
 inline int64_t key_range_slots(int64_t n_points, int block) { return (n_points + block - 1) / block * (block / 64); } // wavefronts
-static __global__ void key_range_reduce_kernel(int64_t n_slots, const int *__restrict__ partial, int *__restrict__ rng)
+// (at most 64 workgroups, one atomic per workgroup and component: 1 024 wavefronts x 6 atomics on six addresses took 70 us --
+// same-address atomics retire one per ~11 ns)
+static __global__ __launch_bounds__(256) void key_range_reduce_kernel(int64_t n_slots, const int *__restrict__ partial, int *__restrict__ rng)
 {
+    __shared__ int part[4][6];
     int v[6] = {0, 0, 0, 0, 0, 0};
     for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_slots; w += (int64_t)gridDim.x * blockDim.x)
 #pragma unroll
@@ -157,9 +160,15 @@ static __global__ void key_range_reduce_kernel(int64_t n_slots, const int *__res
     for (int j = 0; j < 6; ++j) v[j] = wave_max_to_lane63(v[j]);
     if ((threadIdx.x & 63) == 63)
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
-            if (v[j] > 0) atomicMax(rng + j, v[j]);
+        for (int j = 0; j < 6; ++j) part[threadIdx.x >> 6][j] = v[j];
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int j = threadIdx.x;
+        const int m = max(max(part[0][j], part[1][j]), max(part[2][j], part[3][j]));
+        if (m > 0) atomicMax(rng + j, m);
+    }
 }
+inline unsigned key_range_reduce_grid(int64_t n_slots) { return (unsigned)std::min<int64_t>(64, (n_slots + 255) / 256); }
 template <class K>
 __global__ void key_compress_kernel(int64_t n, const uint64_t *key, const KeyPack kp, K *out /* may be key */)
 {

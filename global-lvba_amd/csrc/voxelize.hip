@@ -832,7 +832,7 @@ int32_t voxmap_build_impl(lvba_voxmap_s *h, const lvba_scans_s *sc, int frame_be
                                                         h->opts.voxel_size, key.as<uint64_t>(), rec.as<float4>(),
                                                         idx.as<uint32_t>(), d_err.as<int>(), d_part.as<int>());
         HIPCHK(hipGetLastError());
-        key_range_reduce_kernel<<<(unsigned)std::min<int64_t>(256, (n_slots + 255) / 256), 256, 0, s>>>(n_slots, d_part.as<int>(), d_err.as<int>() + 1);
+        key_range_reduce_kernel<<<key_range_reduce_grid(n_slots), 256, 0, s>>>(n_slots, d_part.as<int>(), d_err.as<int>() + 1);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(s));
         HIPCHK(lvba::copy_d2h(h_err, d_err.p, 28));

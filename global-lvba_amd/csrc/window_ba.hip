@@ -389,7 +389,7 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
                                                               d2.as<double>(), idx.as<uint32_t>(), d_err.as<int>(), d_part.as<int>());
             HIPCHK(hipGetLastError());
             if (down) {
-                key_range_reduce_kernel<<<(unsigned)std::min<int64_t>(256, (n_slots + 255) / 256), 256, 0, s>>>(n_slots, d_part.as<int>(), d_err.as<int>() + 1);
+                key_range_reduce_kernel<<<key_range_reduce_grid(n_slots), 256, 0, s>>>(n_slots, d_part.as<int>(), d_err.as<int>() + 1);
                 HIPCHK(hipGetLastError());
             }
             if (!down) {
