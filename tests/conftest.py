@@ -19,6 +19,36 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
 
 
+def ceres_probe():
+    """Is there a Ceres Solver (the one dependency whose iterations the visual path cannot pin by itself) on this
+    machine?  Cheap: the usual include / library directories and the loader cache, no walk of the file system."""
+    import glob
+    import subprocess
+    hits = []
+    for pat in ("/usr/include/ceres/ceres.h", "/usr/local/include/ceres/ceres.h", "/opt/*/include/ceres/ceres.h",
+                "/usr/lib/*/libceres*", "/usr/lib/libceres*", "/usr/local/lib/libceres*", "/opt/*/lib/libceres*",
+                "/usr/lib/cmake/Ceres*", "/usr/lib/*/cmake/Ceres*", "/usr/local/lib/cmake/Ceres*"):
+        hits += glob.glob(pat)
+    try:
+        out = subprocess.run(["ldconfig", "-p"], capture_output=True, text=True, timeout=10).stdout
+        hits += [ln.strip() for ln in out.splitlines() if "libceres" in ln]
+    except Exception:
+        pass
+    return hits
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """One line per run (also under -q): why tests/test_gpu_ceres_pin.py::test_visual_refine_matches_real_ceres ran or skipped."""
+    if "gpu" not in (config.getoption("-m") or "") or "not gpu" in (config.getoption("-m") or ""):
+        return
+    hits = ceres_probe()
+    driver = os.environ.get("LVBA_CERES_PIN_DRIVER", os.path.join(ROOT, "tools", "pin_ceres", "ceres_pin_driver"))
+    terminalreporter.write_line(
+        "ceres probe: " + (f"found {hits[:3]}" if hits else "no Ceres Solver on this machine (headers, libraries, loader cache)")
+        + f"; pin driver {'present' if os.path.exists(driver) else 'absent'} -> test_visual_refine_matches_real_ceres "
+        + ("runs" if os.path.exists(driver) else "SKIPPED: the iterations inside ceres::Solve stay unpinned (tools/pin_ceres/pin_ceres.sh builds the driver where Ceres 2.1 exists)"))
+
+
 @pytest.fixture(scope="session")
 def pkg():
     return importlib.import_module("global-lvba_amd")
