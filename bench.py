@@ -351,7 +351,12 @@ def main():
             "timing": {"regions": REGIONS, "steps_per_region": args.steps, "value_is": "median region",
                        "ms_per_step_by_region": [1e3 * t / args.steps for t in region_s],
                        "ms_per_step_min": 1e3 * min(region_s) / args.steps, "ms_per_step_max": 1e3 * max(region_s) / args.steps,
-                       "value_min": args.steps / max(region_s), "value_max": args.steps / min(region_s)},
+                       "value_min": args.steps / max(region_s), "value_max": args.steps / min(region_s),
+                       "median_region": mid,
+                       # (the regions continue one another's LM runs: their iteration mix differs, deterministically)
+                       "evals_by_region": [r["evals"] for r in region_state],
+                       "accepted_by_region": [r["accepts"] for r in region_state],
+                       "lm_runs_started_by_region": [r["runs"] for r in region_state]},
             "roofline": roof,
             # the kernel that dominates the step BY TIME (the evaluation above is the one north_star puts a number on)
             "roofline_solve": solve_roof,

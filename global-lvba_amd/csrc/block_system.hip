@@ -321,8 +321,7 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
     const int64_t Bb1 = (int64_t)bs.Bb + 1;
     bs.hblk_doubles = (int64_t)N * Bb1 * 36;
     {
-        const char *e = getenv("LVBA_PACKED_ALLREDUCE");
-        if (bs.distributed() && !adj.empty() && !(e && !strcmp(e, "0"))) {
+        if (bs.distributed() && !adj.empty()) {
             lvba::hvec<int64_t> slots;
             for (int32_t J = 0; J < N; ++J) slots.push_back((int64_t)J * Bb1);
             for (int32_t i = 0; i < N; ++i)
@@ -363,7 +362,8 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
         // w * F / G records of 144 bytes.  Measured at C3 (PMC, profiles/): 6 MB windows cut the L2 misses of the pair pass from
         // 88 M to 36 M per evaluation; smaller windows miss less still, but every (window, block) item costs a partial block
         // and the pass is latency-bound, not bandwidth-bound, by then.  Problems whose whole Y is small are not windowed.
-        // LVBA_PAIR_WINDOW overrides (voxels per window, 0 = none).
+        // LVBA_PAIR_WINDOW overrides (voxels per window; 0 = no windows, the plain block-major lists and the 16-lane kernel): the
+        // tests use it to reach either pair kernel at test sizes.
         int64_t window_groups = 0;
         if (18 * 8 * F > ((int64_t)24 << 20)) window_groups = std::max<int64_t>(256, (((int64_t)6 << 20) / 144) * G / std::max<int64_t>(F, 1));
         // A grouped problem (the windows of the window stage as ONE handle) has few blocks with long lists and lives for a
@@ -372,11 +372,9 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
         // window stage (2.15 -> 2.9 ms per window), measured back to 2.13 with the plain lists.
         if (bs.n_groups > 0) window_groups = 0;
         if (const char *e = getenv("LVBA_PAIR_WINDOW")) window_groups = atoll(e);
-        // LVBA_PAIR_SORT=0: the windows' items in (tile, block) order instead of by length (A/B)
-        static const bool len_sort = [] { const char *e = getenv("LVBA_PAIR_SORT"); return !(e && !strcmp(e, "0")); }();
-        const bool want_col = [&] { const char *e = getenv("LVBA_PAIR"); return e ? !strcmp(e, "col") : true; }();
+        // (the items of a window are laid out by length: a wavefront's ten items finish together)
         TRY(pair_lists_build(bs.stream, G, voff, F, d_blk_of.as<int32_t>(), bs.d_pos_of, N, (int32_t)Bb1, Q, window_groups,
-                             len_sort && want_col ? LVBA_PAIR_CUT : 0, bs.d_pairs, blk_slot, blk_off));
+                             LVBA_PAIR_CUT, bs.d_pairs, blk_slot, blk_off));
         BS_MARK("pairs");
         bs.nnzb = (int64_t)blk_slot.size();
         if (window_groups > 0) {
@@ -408,9 +406,8 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
             int64_t n_partial = 0;
             // windowed lists (large problems: many short (window, block) items) go to the column-per-lane kernel, cut at
             // LVBA_PAIR_CUT pairs; few blocks with long lists (window BA: 190 blocks x 2000 pairs) to the 16-lane kernel, cut so
-            // that the chip is filled.  LVBA_PAIR = col | staged | gather overrides the kernel.
+            // that the chip is filled.
             bs.pair_col = window_groups > 0;
-            if (const char *e = getenv("LVBA_PAIR")) bs.pair_col = !strcmp(e, "col");
             group_pair_items(blk_slot, blk_off, bs.pair_col ? LVBA_PAIR_CUT : pair_cut_length(Q), (int64_t)N * Bb1, item_off, item_dst,
                              multi_off, multi_slot, multi_idx, n_partial); // host_tables.h
             bs.n_items = (int64_t)item_dst.size();
@@ -479,11 +476,10 @@ static int32_t dist_max_cb(void *ctx, int *dbuf) { return bs_comm_allreduce(*sta
 static int32_t solve_launches(BlockSys &bs)
 {
     if (bs.d_bcr) { bcr_solve(bs.Hblk(), bs.Bb, bs.N, bs.g(), bs.d_u, bs.d_dx, bs.d_bcr, bs.d_status, bs.stream); return LVBA_OK; }
-    // multi-rank: the two ends of the band factorisation on ranks 0 and 1 (LVBA_DIST_SOLVE=0: every rank solves alone)
-    static const bool dist_solve = [] { const char *e = getenv("LVBA_DIST_SOLVE"); return !(e && !strcmp(e, "0")); }();
+    // multi-rank: the two ends of the band factorisation on ranks 0 and 1
     LdltDist dd{bs.rank, bs.n_ranks, &bs, dist_sum_cb, dist_max_cb};
     return ldlt_solve(bs.A, bs.Hblk(), bs.Bb, bs.N, bs.g(), bs.d_u, bs.d_dx, bs.d_work, bs.d_status, bs.stream,
-                      bs.distributed() && bs.n_ranks >= 2 && dist_solve ? &dd : nullptr, bs.n_groups > 0 ? bs.d_grp_of_pose : nullptr);
+                      bs.distributed() && bs.n_ranks >= 2 ? &dd : nullptr, bs.n_groups > 0 ? bs.d_grp_of_pose : nullptr);
 }
 
 static int32_t enqueue_solve_launches(BlockSys &bs);

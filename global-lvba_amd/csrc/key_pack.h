@@ -36,12 +36,15 @@ inline KeyPack key_pack_of(const int rng[6])
 template <class K> LVBA_KP_HD K key_compress(uint64_t key, const KeyPack kp)
 {
     const int x = (int)(key >> 42), y = (int)((key >> 21) & 0x1FFFFF), z = (int)(key & 0x1FFFFF);
-    return (K)((K)(x - kp.lo[0]) << (kp.b[1] + kp.b[2])) | (K)((K)(y - kp.lo[1]) << kp.b[2]) | (K)(z - kp.lo[2]);
+    // in 64 bits, narrowed afterwards: b[1] + b[2] may equal the width of K (b[0] = 0, 32 key bits on the uint32 path), and a
+    // shift by the full width of its type is undefined
+    const uint64_t v = ((uint64_t)(x - kp.lo[0]) << (kp.b[1] + kp.b[2])) | ((uint64_t)(y - kp.lo[1]) << kp.b[2]) | (uint64_t)(z - kp.lo[2]);
+    return (K)v;
 }
 template <class K> LVBA_KP_HD uint64_t key_expand(K c, const KeyPack kp)
 {
     const uint64_t v = (uint64_t)c;
-    const uint64_t x = (v >> (kp.b[1] + kp.b[2])) + (uint64_t)kp.lo[0];
+    const uint64_t x = (kp.b[1] + kp.b[2] < 64 ? v >> (kp.b[1] + kp.b[2]) : 0) + (uint64_t)kp.lo[0];
     const uint64_t y = ((v >> kp.b[2]) & (((uint64_t)1 << kp.b[1]) - 1)) + (uint64_t)kp.lo[1];
     const uint64_t z = (v & (((uint64_t)1 << kp.b[2]) - 1)) + (uint64_t)kp.lo[2];
     return (x << 42) | (y << 21) | z;

@@ -34,7 +34,6 @@ struct BulkJob {
     PanelGeo o, e;
     const double *Zo, *Ze;
     int pair;
-    int dbg_same; // experiment (tools/solver_microbench): every workgroup takes the job's FIRST tile -- operands from L2, no fabric traffic
     int64_t ca, cb, nwg;
 };
 struct Step2Args {
@@ -60,28 +59,13 @@ struct Step2Args {
     const double *Zq;
     int *status;
     BulkJob job[2];
-    // experiments (tools/solver_microbench): bulk workgroups whose blockIdx is >= stagger_from start stagger_n x ~0.43 us late
-    // (two workgroups that share a CU otherwise run their load and MFMA phases in step); dbg != nullptr: the chain workgroup of
-    // problem 0 leaves its start / end clock there
-    int stagger_from, stagger_n;
-    int skip_a, skip_b;  // experiment: these two blocks return at once (-1: none)
     // The chain workgroups ALONE on their CUs.  The step kernel's 80 KB of LDS admit two workgroups per CU, and the dispatcher
-    // fills the CUs in block order, round after round (observed, tools/solver_microbench: block b and block b + #CUs share a CU):
+    // fills the CUs in block order, round after round (observed, round 4: block b and block b + #CUs share a CU):
     // the blocks [resv_at, resv_at + resv_n) -- the would-be partners of the chain workgroups, blocks 0 .. resv_n - 1 -- return
     // at once and the later blocks count from resv_n less.  Measured on the two-problem launch of config C3: the chain workgroup
     // 79 900 -> 59 600 cycles (what it takes alone), the launch 37.9 -> 29.6 us.  Placement is a matter of speed only: wherever
     // the blocks land, every tile is still done exactly once.  resv_n = 0: off.
     int resv_at, resv_n;
-    // Issue priority of the bulk workgroups (s_setprio 0..3; the chain runs at 3).  A bulk tile that shares its CU with a row
-    // workgroup is what a two-ended launch waits for (rocprof, round 4: 32 - 36 us against 30 for two tiles sharing and 18 for a
-    // tile alone) although the two together have 18 us of matrix-pipe work: ahead of the row workgroup on the issue slots, the
-    // tile runs at its own pace and the row workgroup -- which has the whole launch to finish -- fills the gaps.
-    int bulk_prio;
-    int row_prio; // the same for the row workgroups (and row 1's helper)
-    // experiment (tools/solver_microbench; needs dbg): every bulk workgroup does what a flag-driven, launch-free form would add to
-    // it -- one relaxed agent-scope poll + acquire fence before its tile, release fence + vmcnt(0) + one agent-scope atomic after
-    int fence_probe;
-    unsigned long long *dbg;
 };
 
 // Scratch doubles in the PAD of the first [m][row] tile (LVBA_TS = 80 doubles per column of 64 rows: 16 spare behind each of the
@@ -99,17 +83,6 @@ __device__ __forceinline__ double &pad_at(double *lds, int idx) { return lds[(id
 // pipe is draining -- measured with the loop in its plain form: 127 cycles per MFMA instead of 64).
 __device__ __forceinline__ void tile_product(const double *Ls, const double *Zs, int w, int i, int kk, d4 (&acc)[4])
 {
-#ifdef LVBA_TP_PLAIN
-#pragma unroll 4
-    for (int k0 = 0; k0 < 64; k0 += 4) {
-        const double a = Zs[(k0 + kk) * LVBA_TS + 16 * w + i];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const double bv = Ls[(k0 + kk) * LVBA_TS + 16 * t + i];
-            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc[t], 0, 0, 0);
-        }
-    }
-#else
     const double *zp = Zs + kk * LVBA_TS + 16 * w + i, *lp = Ls + kk * LVBA_TS + i;
     double a[2], bv[2][4];
     a[0] = zp[0];
@@ -128,7 +101,6 @@ __device__ __forceinline__ void tile_product(const double *Ls, const double *Zs,
         for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], bv[q][t], acc[t], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
-#endif
 }
 // registers (thread (row, m = w + 4 it)) -> T[m][row]
 __device__ __forceinline__ void stage_tile(double *T, const double (&v)[16], int w, int row)
@@ -193,8 +165,6 @@ __device__ __forceinline__ void chain_role(double *lds, const LdltMat &M, const 
     const PanelGeo &p = A.p, &q = A.q;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, row = tid & 63, i = lane & 15, kk = lane >> 4;
     const int64_t r0 = p.w0, r = r0 + row; // rows of tile p + 1 = columns of panel p + 1
-#define LVBA_CH_STAMP(k) do { if (A.dbg && tid == 0 && Gp == A.Gp) A.dbg[520 + (k)] = __builtin_readcyclecounter(); } while (0)
-    LVBA_CH_STAMP(0);
     __builtin_amdgcn_s_setprio(3);        // the launch is as long as this workgroup: first call on the issue slots it shares
     const bool has_q = A.has_q && r0 < q.rend; // (a band narrower than two tiles: panel q does not reach tile row p + 1)
     const bool use_dq = has_q && dq_r;         // panel q's contribution comes ready-made from row 1 of the launch before
@@ -222,11 +192,9 @@ __device__ __forceinline__ void chain_role(double *lds, const LdltMat &M, const 
         stage_tile(Ls, va, w, row);
         stage_tile(Zs, vb, w, row);
         __syncthreads();
-        LVBA_CH_STAMP(1); // the first loads have arrived and are staged
         tile_product(Ls, Zs, w, i, kk, acc);
         __syncthreads();
     }
-    LVBA_CH_STAMP(2);
     const int nbn = A.nbe_next;
     stage_tile(Ls, a1, w, row);
     stage_tile(Zs, gp, w, row);
@@ -235,11 +203,9 @@ __device__ __forceinline__ void chain_role(double *lds, const LdltMat &M, const 
         pad_at(lds, LVBA_PAD_DP + tid) = dk;
     }
     __syncthreads();
-    LVBA_CH_STAMP(3);
     fwd_partial_y(lds, Zs, w, row);
     tile_product(Ls, Zs, w, i, kk, accL); // accL[t][reg] = L[row 16 t + i][column 16 w + kk + 4 reg]
     __syncthreads();
-    LVBA_CH_STAMP(4);
     // the block itself, as the products' result layout has it: cv[4 t + reg] <-> (r0 + 16 t + i, r0 + 16 w + kk + 4 reg).  ALL of
     // it (a band narrower than a tile leaves rows of the block outside panel p's window; they still belong to the block).
     // Requested here: it is needed after the last product, whose 2 us cover the way from L2 / HBM.
@@ -275,10 +241,8 @@ __device__ __forceinline__ void chain_role(double *lds, const LdltMat &M, const 
         for (int j = 0; j < 16; ++j) sacc += Ls[(16 * w + j) * LVBA_TS + row] * pad_at(lds, LVBA_PAD_YS + 16 * w + j);
         pad_at(lds, LVBA_PAD_RED + 64 * w + row) = sacc;
     }
-    LVBA_CH_STAMP(5);
     tile_product(Ls, Zs, w, i, kk, acc);
     __syncthreads();
-    LVBA_CH_STAMP(6);
     if (tid < 64 && r < p.rend) b[r] -= red4(lds, tid);
     if (!A.do_diag) { // the phase ends here: the updated block goes back to the matrix
 #pragma unroll
@@ -306,13 +270,10 @@ __device__ __forceinline__ void chain_role(double *lds, const LdltMat &M, const 
             W[c * LVBA_W1S + 64 + rr] = (c == rr) ? 1.0 : 0.0;
         }
     __syncthreads();
-    LVBA_CH_STAMP(7);
     diag_blocked_factor(lds, nbn, A.status);
-    LVBA_CH_STAMP(8);
     const double *dvs = lds + 64 * LVBA_W1S + 256 + 16 * LVBA_Z1S;
     if (tid < nbn) dvec[p.w0 + tid] = dvs[tid];
     for (int e = tid; e < 4096; e += 256) Gn[e] = W[(e & 63) * LVBA_W1S + 64 + (e >> 6)];
-    LVBA_CH_STAMP(9);
 }
 
 // ---------------------------------------------------------------------------------------------- the row role
@@ -492,19 +453,13 @@ __device__ __forceinline__ void qx_diag_role(double *lds, const LdltMat &M, cons
 
 // ---------------------------------------------------------------------------------------------- one launch
 // Block order: the chain workgroups of all problems first, then the row workgroups, then the bulk jobs' workgroups alternating
-// between the problems.  big: 128 x 64 bulk tiles (bulk_tile_128, 32-bit buffer offsets) / 64 x 64 tiles (update_tile[2]).
-// BT, the bulk tile: 0 = bulk_tile_128 (K chunks of 32, one chunk buffer; 80 KB, two workgroups per CU)
-//                    1 = bulk_tile_128<.., true> (two chunk buffers of K = 32: 114 KB, one workgroup per CU)
-//                    2 = bulk_tile_k16 (K chunks of 16, two chunk buffers, three register sets; 80 KB with the roles, two per CU)
-//                    3 = bulk_tile_sq (128 x 128 tiles, 64 x 64 per wavefront, operand chunks loaded straight into LDS)
-template <bool big, int BT>
-__global__ __launch_bounds__(256, BT == 1 ? 1 : 2) void ldlt_step2_kernel(const Step2Args A)
+// between the problems.  big: 128 x 64 bulk tiles (bulk_tile_128, 32-bit buffer offsets) / 64 x 64 tiles (update_tile[2], 64-bit
+// pointers: matrices of 4 GB and more).  80 KB of LDS: two workgroups per CU.
+template <bool big>
+__global__ __launch_bounds__(256, 2) void ldlt_step2_kernel(const Step2Args A)
 {
-    __shared__ double lds[BT == 1 ? (LVBA_K3DB_LDS > LVBA_K3_LDS ? LVBA_K3DB_LDS : LVBA_K3_LDS) : LVBA_K3_LDS];
-    static_assert(LVBA_K1B_LDS <= LVBA_K3_LDS && LVBA_K3B_LDS <= LVBA_K3_LDS && LVBA_K16_LDS <= LVBA_K3_LDS && LVBA_SQ_LDS <= LVBA_K3_LDS &&
-                      LVBA_PAD_RED + 256 <= 1024,
-                  "LDS budget of the roles");
-    static_assert(BT == 0 || big, "the other bulk tiles exist for the 128 x 64 form only");
+    __shared__ double lds[LVBA_K3_LDS];
+    static_assert(LVBA_K1B_LDS <= LVBA_K3_LDS && LVBA_K3B_LDS <= LVBA_K3_LDS && LVBA_PAD_RED + 256 <= 1024, "LDS budget of the roles");
     const int64_t nrole = A.roles ? A.p.T + (A.qx_helper ? 1 : 0) : 0, nfac = nrole * A.nprob;
     LdltMat M = A.M;
     int prob;
@@ -521,55 +476,15 @@ __global__ __launch_bounds__(256, BT == 1 ? 1 : 2) void ldlt_step2_kernel(const 
     }
     const int64_t wo = prob ? A.sW : 0;
     if (prob) M.a += A.sA;
-    if (A.dbg && threadIdx.x == 0) // where did the dispatcher put this workgroup?  (tools/solver_microbench: who shares a CU with the chain)
-        A.dbg[8 + blockIdx.x] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 /*XCC_ID*/) | (0 << 6) | (31 << 11)) << 32) |
-                                (unsigned)__builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (31 << 11));
-    if (A.skip_a >= 0 && ((int)blockIdx.x == A.skip_a || (int)blockIdx.x == A.skip_b)) return; // (experiment: leave the chain's CU alone)
     if (bid < nfac) {
-        if (bx == 0) {
-            const bool stamp = A.dbg && prob == 0 && threadIdx.x == 0;
-            if (stamp) A.dbg[0] = __builtin_readcyclecounter();
+        if (bx == 0)
             chain_role(lds, M, A, A.Gp + wo, A.Gn + wo, A.dvec + wo, A.b + wo, A.Zp + wo, A.Zq ? A.Zq + wo : nullptr,
                        A.dq_r ? A.dq_r + wo : nullptr);
-            if (stamp) A.dbg[1] = __builtin_readcyclecounter();
-            return;
-        }
-        switch (A.row_prio) { // (s_setprio takes an immediate)
-        case 1: __builtin_amdgcn_s_setprio(1); break;
-        case 2: __builtin_amdgcn_s_setprio(2); break;
-        case 3: __builtin_amdgcn_s_setprio(3); break;
-        default: break;
-        }
-        if (bx == A.p.T) qx_diag_role(lds, M, A, A.Zq ? A.Zq + wo : nullptr);
+        else if (bx == A.p.T) qx_diag_role(lds, M, A, A.Zq ? A.Zq + wo : nullptr);
         else row_role(lds, M, A, bx, A.Gp + wo, A.dvec + wo, A.b + wo, A.Zp + wo, A.Zq ? A.Zq + wo : nullptr, A.side_r + wo, A.side_w + wo,
                       A.dq_w ? A.dq_w + wo : nullptr);
         return;
     }
-    if (A.stagger_n > 0 && (int)blockIdx.x >= A.stagger_from)
-        for (int q = 0; q < A.stagger_n; ++q) __builtin_amdgcn_s_sleep(16);
-    switch (A.bulk_prio) { // (s_setprio takes an immediate)
-    case 1: __builtin_amdgcn_s_setprio(1); break;
-    case 2: __builtin_amdgcn_s_setprio(2); break;
-    case 3: __builtin_amdgcn_s_setprio(3); break;
-    default: break;
-    }
-    const bool probe = A.fence_probe && A.dbg;
-    if (probe) {
-        if (threadIdx.x == 0) {
-            (void)__hip_atomic_load(A.dbg + 600, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        __syncthreads();
-    }
-    auto publish = [&]() {
-        if (!probe) return;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            (void)__hip_atomic_fetch_add(A.dbg + 601, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    };
     for (int j = 0; j < A.njobs; ++j) {
         const BulkJob &J = A.job[j];
         if (bx >= J.nwg) { bx -= J.nwg; continue; }
@@ -577,29 +492,15 @@ __global__ __launch_bounds__(256, BT == 1 ? 1 : 2) void ldlt_step2_kernel(const 
         if constexpr (big) {
             int64_t R0, tj;
             const PanelRef po{J.o.k, J.o.w0, J.o.rend, J.o.nbe, Zo}, pe{J.e.k, J.e.w0, J.e.rend, J.e.nbe, Ze};
-            if constexpr (BT == 3) {
-                int ncol;
-                if (!sq_decode(J.dbg_same ? 0 : bx, J.ca, J.cb, (int64_t)J.o.T - 1, R0, tj, ncol)) return;
-                if (J.pair) bulk_tile_sq<2>(lds, M, po, pe, A.ldz, R0, tj, ncol);
-                else bulk_tile_sq<1>(lds, M, po, pe, A.ldz, R0, tj, ncol);
-                publish();
-                return;
-            }
-            if (!pair_decode(J.dbg_same ? 0 : bx, J.ca, J.cb, (int64_t)J.o.T - 1, R0, tj)) return;
-            if constexpr (BT == 2) {
-                if (J.pair) bulk_tile_k16<2>(lds, M, po, pe, A.ldz, R0, tj);
-                else bulk_tile_k16<1>(lds, M, po, pe, A.ldz, R0, tj);
-            } else {
-                if (J.pair) bulk_tile_128<4, BT == 1>(lds, M, po, pe, A.ldz, R0, tj);
-                else bulk_tile_128<2, BT == 1>(lds, M, po, pe, A.ldz, R0, tj);
-            }
+            if (!pair_decode(bx, J.ca, J.cb, (int64_t)J.o.T - 1, R0, tj)) return;
+            if (J.pair) bulk_tile_128<4>(lds, M, po, pe, A.ldz, R0, tj);
+            else bulk_tile_128<2>(lds, M, po, pe, A.ldz, R0, tj);
         } else {
             int64_t ti, tj;
             col_decode(J.ca + bx, (int64_t)J.o.T - 1, ti, tj);
             if (J.pair) update_tile2(lds, M, J.o.k, J.o.nbe, J.o.w0, J.o.rend, Zo, J.e.k, J.e.nbe, J.e.w0, J.e.rend, Ze, A.ldz, ti + 1, tj + 1);
             else update_tile(lds, M, J.o.k, J.o.nbe, J.o.w0, J.o.rend, Zo, A.ldz, ti + 1, tj + 1);
         }
-        publish();
         return;
     }
 }

@@ -151,8 +151,7 @@ static int32_t balm_create_impl(int32_t n_poses, int64_t n_voxels, const int64_t
     };
     // one pass over the voxels: >= 2 factors each, pose indices in range, and the first pose that sees each voxel (for the
     // re-layout decision below; only needed from the size on from which the pair lists are windowed)
-    static const bool allow_sort = [] { const char *e = getenv("LVBA_VOXEL_SORT"); return !(e && !strcmp(e, "0")); }();
-    const bool want_key = !trusted && allow_sort && 18 * 8 * F > ((int64_t)24 << 20) && n_voxels > 1;
+    const bool want_key = !trusted && 18 * 8 * F > ((int64_t)24 << 20) && n_voxels > 1;
     lvba::hvec<int32_t> key;
     if (want_key) key.resize((size_t)n_voxels);
     double jump = 0.0;
@@ -359,14 +358,8 @@ extern "C" int32_t lvba_balm_info(lvba_balm_t h, lvba_balm_info_t *info)
     info->band_blocks = h->bs.Bb; info->use_band = h->bs.use_band ? 1 : 0; info->hess_bytes = h->bs.hblk_doubles * 8;
     info->device_bytes = h->bs.device_bytes;
     info->twist_panels = h->bs.d_bcr ? 0 : (int32_t)ldlt_twist_panels(h->bs.A.n, h->bs.A.ld, h->bs.A.bw);
-    {
-        const char *e = getenv("LVBA_DIST_SOLVE");
-        info->solve_ranks = (h->bs.distributed() && h->bs.n_ranks >= 2 && info->twist_panels > 0 && !(e && !strcmp(e, "0"))) ? 2 : 1;
-    }
-    {
-        const char *e = getenv("LVBA_COST_RECORDS");
-        info->trial_linearised = !(e && !strcmp(e, "0")) ? 1 : 0;
-    }
+    info->solve_ranks = (h->bs.distributed() && h->bs.n_ranks >= 2 && info->twist_panels > 0) ? 2 : 1;
+    info->trial_linearised = 1;
     info->y_fp32 = h->bs.y32 ? 1 : 0;
     info->allreduce_bytes = !h->bs.distributed() ? 0 : 8 * ((h->bs.d_ar_slot ? 36 * h->bs.n_ar : h->bs.hblk_doubles) + 6 * (int64_t)h->N + 1);
     return LVBA_OK;
@@ -651,9 +644,8 @@ extern "C" int32_t lvba_balm_lm_step(lvba_balm_t h, lvba_lm_trace *row, int32_t 
     // The trial point is costed by the VOXEL PASS of the evaluation (cost + voxel records): an accepted trial point is where the
     // next evaluation happens, and that evaluation then starts from the records (factor pass, pair pass) instead of reading
     // and eigen-decomposing every voxel again.  A rejected step wastes the difference to the cost-only kernel (C3: 0.04 ms).
-    // Also on voxel shards (the records are local).  LVBA_COST_RECORDS=0: cost-only kernel, every evaluation from scratch (A/B).
-    static const bool cost_records = [] { const char *e = getenv("LVBA_COST_RECORDS"); return !(e && !strcmp(e, "0")); }();
-    const bool with_lin = cost_records;
+    // Also on voxel shards (the records are local).
+    const bool with_lin = true;
     if (evaluated) TRY(enqueue_eval(h, h->d_pose_cur, with_lin && h->lin_at_cur));         // :688-689
     TRY(enqueue_solve(h, h->u));                                                           // :692-710
     launch_retract(h->d_pose_cur, h->bs.d_dx, h->d_pose_trial, h->N, h->stream());              // :722-727

@@ -160,7 +160,10 @@ class StreamCache {
 
 // Pinned staging memory for the scan upload (voxelize.hip: 24 MB per call): hipHostMalloc / hipHostFree of that size cost
 // milliseconds and the unpinning stalls the device's queues (host_arena.h); a refinement handle's three small zero-copy blocks come
-// from here too.  At most kKeep blocks stay cached.
+// from here too.  Blocks are allocated portable + mapped: a block pinned under one device is reused as zero-copy / staging memory
+// by handles on another (lvba_window_ba_multi, lvba_lidar_ba_multi), which must not rest on what the default flags happen to
+// give.  Small (handle) blocks and large (upload) blocks are cached in lists of their own, so that a burst of 4 KB handle blocks
+// cannot evict the 24 MB upload block: at most kKeep of each stay cached.
 class PinnedCache {
   public:
     static PinnedCache &get()
@@ -172,15 +175,16 @@ class PinnedCache {
     {
         {
             std::lock_guard<std::mutex> g(mu_);
-            for (size_t i = 0; i < free_.size(); ++i)
-                if (free_[i].second >= bytes && free_[i].second <= 2 * bytes + ((size_t)1 << 20)) {
-                    *p = free_[i].first;
-                    owner_[*p] = free_[i].second;
-                    free_.erase(free_.begin() + (ptrdiff_t)i);
+            auto &fl = list_of(bytes);
+            for (size_t i = 0; i < fl.size(); ++i)
+                if (fl[i].second >= bytes && fl[i].second <= 2 * bytes + ((size_t)1 << 20)) {
+                    *p = fl[i].first;
+                    owner_[*p] = fl[i].second;
+                    fl.erase(fl.begin() + (ptrdiff_t)i);
                     return hipSuccess;
                 }
         }
-        const hipError_t e = hipHostMalloc(p, bytes, hipHostMallocDefault);
+        const hipError_t e = hipHostMalloc(p, bytes, hipHostMallocPortable | hipHostMallocMapped);
         if (e == hipSuccess) {
             std::lock_guard<std::mutex> g(mu_);
             owner_[*p] = bytes;
@@ -195,22 +199,26 @@ class PinnedCache {
         if (it == owner_.end()) { (void)hipHostFree(p); return; }
         const size_t bytes = it->second;
         owner_.erase(it);
-        if (free_.size() < kKeep) free_.emplace_back(p, bytes);
+        auto &fl = list_of(bytes);
+        if (fl.size() < kKeep) fl.emplace_back(p, bytes);
         else (void)hipHostFree(p);
     }
     size_t release_all()
     {
         std::lock_guard<std::mutex> g(mu_);
         size_t n = 0;
-        for (auto &b : free_) { n += b.second; (void)hipHostFree(b.first); }
-        free_.clear();
+        for (auto *fl : {&free_small_, &free_large_}) {
+            for (auto &b : *fl) { n += b.second; (void)hipHostFree(b.first); }
+            fl->clear();
+        }
         return n;
     }
 
   private:
-    static constexpr size_t kKeep = 8;
+    static constexpr size_t kKeep = 8, kSmall = (size_t)1 << 20;
+    std::vector<std::pair<void *, size_t>> &list_of(size_t bytes) { return bytes <= kSmall ? free_small_ : free_large_; }
     std::mutex mu_;
-    std::vector<std::pair<void *, size_t>> free_;
+    std::vector<std::pair<void *, size_t>> free_small_, free_large_;
     std::map<void *, size_t> owner_;
 };
 

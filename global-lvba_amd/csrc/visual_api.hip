@@ -364,8 +364,8 @@ extern "C" int32_t lvba_visual_refine(lvba_visual_t h, double *q, double *t, dou
     bool first = true;
     int invalid_run = 0;
     if (!isfinite(cost)) { term = LVBA_TERM_FAILURE; rc = fail(LVBA_NUM_NONFINITE, "non-finite initial cost"); }
-    // LVBA_VIS_PROFILE=1: HIP events between the phases of every iteration, averages on stderr at the end (tools/visual_bench.py)
-    static const bool prof = [] { const char *e = getenv("LVBA_VIS_PROFILE"); return e && !strcmp(e, "1"); }();
+    // LVBA_TIMING=vis: HIP events between the phases of every iteration, averages on stderr at the end (tools/visual_bench.py)
+    static const bool prof = [] { const char *e = getenv("LVBA_TIMING"); return e && !strcmp(e, "vis"); }();
     constexpr int NPH = 6, PCAP = 64;
     std::vector<hipEvent_t> pev;
     int pn = 0;

@@ -689,9 +689,9 @@ extern "C" int32_t lvba_scans_create(int32_t device, int32_t n_frames, const voi
     // xyz packed out of the caller's point stride (e.g. sizeof(pcl::PointXYZINormal) = 48).  hipMemcpy2D of 12-byte rows out of
     // pageable memory ran at 3.3 GB/s (57.8 ms for 16 M points: 18 x the map build it feeds).  Now the host packs the
     // coordinates itself -- a few threads, each a slice of a chunk of <= 1 M points -- into one of two pinned buffers, and the
-    // chunk travels as ONE contiguous asynchronous copy while the next is being packed (LVBA_UPLOAD=memcpy2d: the former path).
-    static const bool upload_2d = [] { const char *v = getenv("LVBA_UPLOAD"); return v && !strcmp(v, "memcpy2d"); }();
-    bool packed_path = point_stride_bytes != 12 && !upload_2d && P > 0;
+    // chunk travels as ONE contiguous asynchronous copy while the next is being packed (hipMemcpy2D remains the fall-back when no
+    // pinned memory is to be had).
+    bool packed_path = point_stride_bytes != 12 && P > 0;
     if (packed_path) {
         // Every worker thread owns a contiguous run of the points (across frames), two pinned slots of kSub points and a stream:
         // pack a slot, send it, pack the other one while it travels -- no thread waits for another.  (Round 3's form spawned its
@@ -701,7 +701,6 @@ extern "C" int32_t lvba_scans_create(int32_t device, int32_t n_frames, const voi
         const int64_t kSub = (int64_t)1 << 17; // points per slot: 1.5 MB
         unsigned nthr = std::thread::hardware_concurrency();
         nthr = std::max(1u, std::min(nthr ? nthr : 1u, 8u));
-        if (const char *v = getenv("LVBA_UPLOAD_THREADS")) nthr = (unsigned)std::max(1, atoi(v));
         nthr = (unsigned)std::max<int64_t>(1, std::min<int64_t>(nthr, P / 65536));
         const size_t slot_bytes = 12 * (size_t)kSub;
         void *pin = nullptr;
@@ -838,9 +837,8 @@ int32_t voxmap_build_impl(lvba_voxmap_s *h, const lvba_scans_s *sc, int frame_be
         HIPCHK(lvba::copy_d2h(h_err, d_err.p, 28));
         if (h_err[0]) return lvba_fail(LVBA_ERR_ARG, "a point is non-finite or its voxel key exceeds +-2^20 after the pose transform");
         h->info.key_ms = now_ms() - t0; t0 = now_ms();
-        static const bool full_sort = [] { const char *e = getenv("LVBA_SORT_BITS"); return e && !strcmp(e, "full"); }(); // A/B: all 63 bits
         const KeyPack kp = key_pack_of(h_err + 1);
-        if (ws) { // joint map: the window index above the re-packed key (LVBA_SORT_BITS does not apply)
+        if (ws) { // joint map: the window index above the re-packed key
             if (kp.total + wbits > 64) return lvba_fail(LVBA_ERR_UNSUPPORTED, "joint map: %d key bits + %d window bits", kp.total, wbits);
             if (kp.total + wbits <= 32) {
                 DevBuf k32(s), k32s(s);
@@ -857,9 +855,6 @@ int32_t voxmap_build_impl(lvba_voxmap_s *h, const lvba_scans_s *sc, int frame_be
                 vox_gather_kernel<uint64_t><<<grid_for(P, 256), 256, 0, s>>>(P, rec.as<float4>(), idx0.as<uint32_t>(), rec_s.as<float4>(), key_s.as<uint64_t>(), kp,
                                                                              key_s.as<uint64_t>());
             }
-        } else if (full_sort) {
-            TRY(sort_pairs(s, key.as<uint64_t>(), key_s.as<uint64_t>(), idx.as<uint32_t>(), idx0.as<uint32_t>(), (size_t)P, 63));
-            vox_gather_kernel<uint64_t><<<grid_for(P, 256), 256, 0, s>>>(P, rec.as<float4>(), idx0.as<uint32_t>(), rec_s.as<float4>(), nullptr, kp, nullptr);
         } else if (kp.total <= 32) {
             DevBuf k32(s), k32s(s);
             HIPCHK(k32.alloc(4 * P)); HIPCHK(k32s.alloc(4 * P));

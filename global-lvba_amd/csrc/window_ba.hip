@@ -402,11 +402,10 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
                 DevBuf key_s(s), order(s), flag(s), excl(s), pick(s);
                 HIPCHK(key_s.alloc(8 * (size_t)P)); HIPCHK(order.alloc(4 * (size_t)P)); HIPCHK(flag.alloc(4 * ((size_t)P + 1)));
                 HIPCHK(excl.alloc(4 * ((size_t)P + 1))); HIPCHK(pick.alloc(4 * (size_t)P));
-                // the sort runs on the bits of the leaf key that vary (voxel_internal.h; LVBA_SORT_BITS=full: all 63, A/B); run
-                // leaders only compare sorted keys for equality, so the re-packed ones serve as they are
-                static const bool full_sort = [] { const char *e = getenv("LVBA_SORT_BITS"); return e && !strcmp(e, "full"); }();
+                // the sort runs on the bits of the leaf key that vary (voxel_internal.h); run leaders only compare sorted keys for
+                // equality, so the re-packed ones serve as they are
                 const KeyPack kp = key_pack_of(h_err + 1);
-                if (!full_sort && kp.total <= 32) {
+                if (kp.total <= 32) {
                     DevBuf k32(s);
                     HIPCHK(k32.alloc(4 * (size_t)P));
                     key_compress_kernel<uint32_t><<<grid_for(P, 256), 256, 0, s>>>(P, key.as<uint64_t>(), kp, k32.as<uint32_t>());
@@ -415,12 +414,9 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
                     wba_pick_kernel<uint32_t><<<grid_for(P, 256), 256, 0, s>>>(P, key_s.as<uint32_t>(), order.as<uint32_t>(), d2.as<double>(),
                                                                                flag.as<uint32_t>(), pick.as<uint32_t>());
                 } else {
-                    unsigned bits = 63;
-                    if (!full_sort) {
-                        key_compress_kernel<uint64_t><<<grid_for(P, 256), 256, 0, s>>>(P, key.as<uint64_t>(), kp, key.as<uint64_t>());
-                        HIPCHK(hipGetLastError());
-                        bits = (unsigned)kp.total;
-                    }
+                    key_compress_kernel<uint64_t><<<grid_for(P, 256), 256, 0, s>>>(P, key.as<uint64_t>(), kp, key.as<uint64_t>());
+                    HIPCHK(hipGetLastError());
+                    const unsigned bits = (unsigned)kp.total;
                     TRY(sort_pairs(s, key.as<uint64_t>(), key_s.as<uint64_t>(), idx.as<uint32_t>(), order.as<uint32_t>(), (size_t)P, bits));
                     wba_pick_kernel<uint64_t><<<grid_for(P, 256), 256, 0, s>>>(P, key_s.as<uint64_t>(), order.as<uint32_t>(), d2.as<double>(),
                                                                                flag.as<uint32_t>(), pick.as<uint32_t>());
@@ -496,9 +492,23 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
     // ---- stage 1 for all windows at once: a root voxel is (window, key), so one sort and one pass of every kernel of the map build
     // serve every window (the per-window builds are dozens of dependent launches and a dozen host round trips EACH); a window's
     // part of the joint map is bit for bit what its own build gives (tests/test_gpu_window.py).  LVBA_WINDOW_JOINT_MAP=0: off.
+    // The joint build holds keys, records, indices and sort temporaries of ALL frames at once (~90 bytes per point, where a
+    // per-window build needs one window's worth): it is only tried when that fits the device's free memory with room to spare --
+    // a long sequence goes window by window instead of running into hipErrorOutOfMemory first.
     auto stage_map_joint = [&]() -> bool {
         static const bool on = [] { const char *e = getenv("LVBA_WINDOW_JOINT_MAP"); return !(e && !strcmp(e, "0")); }();
         if (!on || o.merge_only || n_win < 2) return false;
+        {
+            size_t free_b = 0, total_b = 0;
+            const int64_t P_all = sc->frame_off[(size_t)n] - sc->frame_off[0];
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return false; }
+            if ((double)P_all * 96.0 > 0.5 * (double)free_b) {
+                if (getenv("LVBA_TIMING"))
+                    fprintf(stderr, "[window_ba] joint voxel map skipped: %lld points x ~96 B against %.1f GB free -> one map per window\n",
+                            (long long)P_all, (double)free_b / 1e9);
+                return false;
+            }
+        }
         const double tw = now_ms();
         if (lvba_voxmap_build_scans_joint(sc, 0, n, w, poses, &o.voxel, s, &joint_map) != LVBA_OK) {
             joint_map = nullptr; // (too many key + window bits, a bad point, ...: the per-window builds say what it is)
@@ -539,8 +549,7 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
     bool any_failed = false;
     for (auto &q : results) any_failed = any_failed || q.rc < 0;
     if (!any_failed && !o.merge_only) {
-        bool batch = o.lm_mode == 0;
-        if (const char *e = getenv("LVBA_WINDOW_BATCH")) batch = strcmp(e, "0") != 0;
+        const bool batch = o.lm_mode == 0;
         bool done = false;
         if (batch) {
             const int32_t rc = stage_lm_batched(done);

@@ -150,10 +150,12 @@ int32_t lvba_balm_cost(lvba_balm_t h, const double *poses, int32_t is_avg, doubl
  * H and g may be NULL (kept on the device for lvba_balm_solve). */
 int32_t lvba_balm_eval(lvba_balm_t h, const double *poses, double *H, double *g, double *cost_avg);
 
-/* The same evaluation with H in SPARSE form, for problems whose dense matrix does not fit (10 000 poses: 28.8 GB): the non-zero
- * 6x6 pose blocks of the lower triangle in the CALLER's pose order -- bi[k] >= bj[k], every unordered pose pair once, the
- * diagonal blocks in full --, blocks[k][6 r + c] = H[6 bi[k] + r][6 bj[k] + c].  *n_blocks receives the number of blocks; call
- * with capacity 0 (arrays may be NULL) to size the arrays.  g [6 n_poses] and cost_avg may be NULL. */
+/* The same evaluation with H in SPARSE form, for problems whose dense matrix does not fit (10 000 poses: 28.8 GB): the
+ * STRUCTURALLY non-zero 6x6 pose blocks of the lower triangle in the CALLER's pose order -- bi[k] >= bj[k], every unordered pose
+ * pair that shares a voxel once (on a voxel shard without a union pattern: every slot of the band), the diagonal blocks in full
+ * --, blocks[k][6 r + c] = H[6 bi[k] + r][6 bj[k] + c].  The set does not depend on the poses: it is the same on every call (the
+ * sizing call and the filling call agree), and a block of it may be numerically zero.  *n_blocks receives the number of blocks;
+ * call with capacity 0 (arrays may be NULL) to size the arrays.  g [6 n_poses] and cost_avg may be NULL. */
 int32_t lvba_balm_eval_blocks(lvba_balm_t h, const double *poses, int64_t capacity, int32_t *bi, int32_t *bj, double *blocks,
                               int64_t *n_blocks, double *g, double *cost_avg);
 

@@ -76,6 +76,10 @@ int main()
         run_box<uint32_t>(rng, a1, a1, 5);
         const int b0[3] = {1 << 20, (1 << 20) - 7, 0}, b1[3] = {1 << 20, (1 << 20) + 9, M};
         run_box<uint32_t>(rng, b0, b1, 300);
+        // b[0] = 0 and b[1] + b[2] = 32: the x component's shift equals the width of the 32-bit key (computed in 64 bits)
+        const int c0[3] = {77, 5, 0}, c1[3] = {77, 5 + (1 << 11) - 1, M};
+        run_box<uint32_t>(rng, c0, c1, 300);
+        run_box<uint64_t>(rng, c0, c1, 300);
     }
     if (g_fail) { printf("%d check(s) failed\n", g_fail); return 1; }
     printf("key pack ok (%d boxes)\n", boxes);

@@ -261,22 +261,16 @@ def test_hip_matches_reference_voxel_golden(pkg):
     assert np.abs(sgn * plane - r["planes"])[want_valid].max() < 1e-8
 
 
-def test_strided_scans_upload_packed_equals_memcpy2d(pkg, synth, monkeypatch):
-    """lvba_scans_create from a 48-byte point stride: the packed, pinned, multi-threaded upload (round 4) puts the same xyz on
-    the device as the former hipMemcpy2D path (LVBA_UPLOAD=memcpy2d) and as a 12-byte-stride upload of the coordinates alone --
-    frames longer and shorter than a 1 M-point chunk, an empty frame, one thread and many."""
+def test_strided_scans_upload_packed(pkg, synth):
+    """lvba_scans_create from a 48-byte point stride: the packed, pinned, multi-threaded upload puts the same xyz on the device
+    as a 12-byte-stride upload of the coordinates alone -- frames longer and shorter than a 1 M-point chunk, an empty frame."""
     rng = np.random.default_rng(5)
     sizes = [3, 0, 70_000, 1_300_000, 1 << 20]
     clouds = [rng.standard_normal((n, 12)).astype(np.float32) for n in sizes]
     want = [np.ascontiguousarray(c[:, :3]) for c in clouds]
-    for env in ({}, {"LVBA_UPLOAD_THREADS": "1"}, {"LVBA_UPLOAD": "memcpy2d"}):
-        for k in ("LVBA_UPLOAD_THREADS", "LVBA_UPLOAD"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        with pkg.Scans(clouds) as sc:
-            for f, w in enumerate(want):
-                np.testing.assert_array_equal(sc.download(f), w)
+    with pkg.Scans(clouds) as sc:
+        for f, w in enumerate(want):
+            np.testing.assert_array_equal(sc.download(f), w)
     with pkg.Scans(want) as sc:
         for f, w in enumerate(want):
             np.testing.assert_array_equal(sc.download(f), w)
@@ -324,11 +318,10 @@ np.savez(sys.argv[2], off=off, idx=idx, cl=cl, key=key, wp=w["window_poses"], n=
 """
 
 
-def test_sorts_on_varying_bits_and_joint_window_map_change_no_byte(tmp_path):
-    """LVBA_SORT_BITS=full sorts root keys and anchor-leaf keys on all 63 bits as rounds 1-3 did; the default re-packs them onto
-    the bits that vary.  LVBA_WINDOW_JOINT_MAP=0 builds one voxel map per window as rounds 1-3 did; the default builds ONE map
-    whose roots are (window, key) and hands the windows views into it.  Same order, same sums either way: the map and the whole
-    window stage (refined window poses, anchor clouds point for point) are identical byte for byte."""
+def test_joint_window_map_changes_no_byte(tmp_path):
+    """LVBA_WINDOW_JOINT_MAP=0 builds one voxel map per window (what a scan set too large for one joint map falls back to); the
+    default builds ONE map whose roots are (window, key) and hands the windows views into it.  Same order, same sums either way:
+    the map and the whole window stage (refined window poses, anchor clouds point for point) are identical byte for byte."""
     import os
     import subprocess
     import sys
@@ -336,8 +329,7 @@ def test_sorts_on_varying_bits_and_joint_window_map_change_no_byte(tmp_path):
     script = tmp_path / "run.py"
     script.write_text(_SORT_SCRIPT)
     out = []
-    for i, v in enumerate([{}, {"LVBA_SORT_BITS": "full"}, {"LVBA_WINDOW_JOINT_MAP": "0"},
-                           {"LVBA_WINDOW_JOINT_MAP": "0", "LVBA_SORT_BITS": "full"}]):
+    for i, v in enumerate([{}, {"LVBA_WINDOW_JOINT_MAP": "0"}]):
         f = tmp_path / f"o_{i}.npz"
         r = subprocess.run([sys.executable, str(script), root, str(f)], env=dict(os.environ, **v), capture_output=True, text=True,
                            timeout=600)

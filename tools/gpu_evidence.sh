@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round-4 evidence run: (1) the whole GPU suite + smoke, (2) default bench.py, (3) rocprofv3 --kernel-trace --stats of the headline
+# The round's evidence run (gpurun -- 'bash tools/gpu_evidence.sh <git hash> [round tag, default r05]'): (1) the whole GPU suite + smoke, (2) default bench.py, (3) rocprofv3 --kernel-trace --stats of the headline
 # leg, (4) PMC passes of the headline leg: FETCH_SIZE / WRITE_SIZE (-> traffic json; also with LVBA_Y32=1) and the matrix-pipe
 # counters of the solver kernels, (5) C2 and C4 with their parity legs, (6) visual stage, window stage.  Only summaries return.
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_r04; rm -rf $O; mkdir -p $O
+TAG=${2:-r05}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG; rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
 cd $R
 timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -4 | tee $O/gpu_tests.txt
@@ -32,5 +32,5 @@ grep -E "ldlt_step|ldlt_diag" $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES.csv | sed 's/(.*)"
 timeout 600 python bench.py --config C2 --no-visual --no-front-end --no-reference-baseline > $O/bench_c2.json 2> $O/bench_c2.err
 timeout 900 python bench.py --config C4 --steps 10 --warmup 2 --no-visual --no-front-end --no-reference-baseline --no-y32 > $O/bench_c4_1gpu.json 2> $O/bench_c4.err
 tail -c 400 $O/bench_c2.json; echo; tail -c 400 $O/bench_c4_1gpu.json; echo; tail -3 $O/bench_c4.err
-LVBA_VIS_PROFILE=1 timeout 300 python tools/visual_bench.py 2000 5 > $O/visual_bench.json 2> $O/visual_bench.err; tail -c 300 $O/visual_bench.json
+LVBA_TIMING=vis timeout 300 python tools/visual_bench.py 2000 5 > $O/visual_bench.json 2> $O/visual_bench.err; tail -c 300 $O/visual_bench.json
 timeout 300 python tools/window_bench.py 320 100000 20 1 > $O/window_bench.json 2> $O/window_bench.err; tail -c 200 $O/window_bench.json; echo
