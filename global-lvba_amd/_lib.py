@@ -49,7 +49,9 @@ class BalmInfo(C.Structure):
                 ("n_voxels_global", C.c_int64), ("n_factors", C.c_int64), ("n_pairs", C.c_int64),
                 ("n_chunks", C.c_int64), ("n_blocks", C.c_int64), ("band_blocks", C.c_int32), ("use_band", C.c_int32),
                 ("hess_bytes", C.c_int64), ("device_bytes", C.c_int64), ("allreduce_bytes", C.c_int64),
-                ("twist_panels", C.c_int32), ("solve_ranks", C.c_int32), ("trial_linearised", C.c_int32), ("y_fp32", C.c_int32)]
+                ("twist_panels", C.c_int32), ("solve_ranks", C.c_int32), ("trial_linearised", C.c_int32), ("y_fp32", C.c_int32),
+                ("nd_kind", C.c_int32), ("nd_arcs", C.c_int32), ("nd_sep_poses", C.c_int32), ("nd_sep_band_blocks", C.c_int32),
+                ("nd_model_band_ms", C.c_double), ("nd_model_nd_ms", C.c_double)]
 
 
 class Prof(C.Structure):

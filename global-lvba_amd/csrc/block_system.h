@@ -46,6 +46,8 @@ struct BlockSys {
     int64_t hblk_doubles = 0;
     // solver
     LdltMat A{};
+    NdSys nd;                // one level of nested dissection, when that is the solver (nd_plan.h / ldlt_nd.h)
+    std::vector<void *> nd_allocs;
     double *d_bcr = nullptr; // workspace of the block cyclic reduction, when that is the solver
     double *d_A = nullptr, *d_work = nullptr, *d_dx = nullptr, *d_u = nullptr, *h_pin_u = nullptr;
     double u_on_device = 0.0;      // the damping value d_u[0] holds (u_known): an unchanged value is not uploaded again

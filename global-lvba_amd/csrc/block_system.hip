@@ -20,6 +20,7 @@
 #include "block_system.h"
 #include "pair_lists.h"
 #include "ordering.h"
+#include "nd_plan.h"
 #include "host_tables.h"
 
 static std::atomic<int> g_graph_inhibit{0};
@@ -249,6 +250,77 @@ static double bs_now_ms()
 }
 #define BS_MARK(tag) do { if (timing) { const double t_ = bs_now_ms(); fprintf(stderr, "[bs_build] %-12s %.3f ms\n", tag, t_ - tmark); tmark = t_; } } while (0)
 
+// band or dense storage of an n x n system for ldlt_solve (the allocation rules of the whole-system path)
+static int32_t nd_alloc_mat(BlockSys &bs, int64_t n, int64_t bw, LdltMat &A, double **d_A, double **work, bool no_twist)
+{
+    A = LdltMat{};
+    A.n = n;
+    A.no_twist = no_twist ? 1 : 0;
+    if ((double)(bw + LVBA_NB + 64) < bs.band_frac * (double)n) {
+        const int64_t ldab = bw + LVBA_NB + 64;
+        A.ld = ldab - 1; A.bw = bw;
+        const int64_t cnt = 2 * (ldab * (n + 1)) + 65 * ldab;
+        TRY(bs_dmalloc(bs, d_A, cnt));
+        HIPCHK(hipMemsetAsync(*d_A, 0, (size_t)cnt * sizeof(double), bs.stream)); // zeroed ONCE (ldlt_prepare_band_kernel)
+    } else {
+        A.ld = n; A.bw = n - 1;
+        TRY(bs_dmalloc(bs, d_A, n * n + 64 * n + 128));
+    }
+    A.a = *d_A;
+    TRY(bs_dmalloc(bs, work, ldlt_workspace_doubles(n, A.bw)));
+    bs.nd_allocs.push_back(*d_A);
+    bs.nd_allocs.push_back(*work);
+    return LVBA_OK;
+}
+// device side of a dissection plan: per arc its matrix, workspace, border blocks and stream; the separator system
+static int32_t nd_alloc(BlockSys &bs, const NdPlan &pl)
+{
+    NdSys &nd = bs.nd;
+    nd.ps = pl.ps; nd.Ns = pl.Ns; nd.BbS = pl.BbS; nd.kind = pl.kind; nd.t_band = pl.t_band; nd.t_nd = pl.t_nd;
+    const int P = (int)pl.arcs.size();
+    int *stat = nullptr;
+    TRY(bs_dmalloc(bs, &stat, P + 1));
+    bs.nd_allocs.push_back(stat);
+    HIPCHK(hipMemsetAsync(stat, 0, (size_t)(P + 1) * sizeof(int), bs.stream));
+    nd.d_stat = stat; nd.statusS = stat + P;
+    nd.arcs.resize((size_t)P);
+    auto dm = [&](double **p, int64_t cnt) -> int32_t {
+        TRY(bs_dmalloc(bs, p, cnt));
+        bs.nd_allocs.push_back(*p);
+        return LVBA_OK;
+    };
+    for (int a = 0; a < P; ++a) {
+        const NdPlanArc &pa = pl.arcs[(size_t)a];
+        NdArc &A = nd.arcs[(size_t)a];
+        A = NdArc{};
+        A.p0 = pa.p0; A.Na = pa.Na; A.nsep = (int32_t)pa.sep.size(); A.owner = pa.owner;
+        A.n = 6 * (int64_t)pa.Na; A.ldb = ((6 * (int64_t)A.nsep + 63) / 64) * 64;
+        A.status = stat + a;
+        if (bs.distributed() && bs.n_ranks >= 2 && A.owner != bs.rank) continue; // another rank's arc: only its ranges are needed here
+        if (!(bs.distributed() && bs.n_ranks >= 2)) A.owner = 0;
+        TRY(nd_alloc_mat(bs, A.n, 6 * (int64_t)pa.Bb + 5, A.A, &A.d_A, &A.work, true));
+        if (A.nsep > 0) {
+            TRY(dm(&A.B, A.n * A.ldb)); TRY(dm(&A.Y, A.n * A.ldb)); TRY(dm(&A.Sa, A.ldb * A.ldb));
+            TRY(dm(&A.wv, A.n)); TRY(dm(&A.gpart, ND_GS_SLICES * A.ldb));
+            HIPCHK(hipMemsetAsync(A.B, 0, (size_t)(A.n * A.ldb) * sizeof(double), bs.stream)); // (the pad columns stay zero)
+            HIPCHK(hipMemsetAsync(A.Y, 0, (size_t)(A.n * A.ldb) * sizeof(double), bs.stream));
+            TRY(bs_dmalloc(bs, &A.sep, A.nsep));
+            bs.nd_allocs.push_back(A.sep);
+            HIPCHK(lvba::copy_h2d(A.sep, pa.sep.data(), (size_t)A.nsep * sizeof(int32_t)));
+        }
+        HIPCHK(lvba::StreamCache::get().acquire(&A.stream));
+        HIPCHK(hipEventCreateWithFlags(&A.done, hipEventDisableTiming));
+    }
+    TRY(nd_alloc_mat(bs, 6 * (int64_t)nd.Ns, 6 * (int64_t)nd.BbS + 5, nd.AS, &nd.d_AS, &nd.workS, false));
+    TRY(dm(&nd.Sblk, (int64_t)nd.Ns * (nd.BbS + 1) * 36 + 6 * (int64_t)nd.Ns + 8));
+    TRY(dm(&nd.d_zero, 8));
+    HIPCHK(hipMemsetAsync(nd.d_zero, 0, 8 * sizeof(double), bs.stream));
+    HIPCHK(hipEventCreateWithFlags(&nd.start, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&nd.mid, hipEventDisableTiming));
+    nd.active = true;
+    return LVBA_OK;
+}
+
 int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const int32_t *pidx)
 {
     if (bs.built) return LVBA_OK;
@@ -290,6 +362,7 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
     const bool small = (int64_t)N * N <= ((int64_t)1 << 29); // byte adjacency <= 512 MiB
     // systems of <= 1024 unknowns (window BA: 20 poses) are solved dense whatever the order: skip the graph work
     lvba::hvec<uint8_t> adj; // co-visibility of the GLOBAL problem (all-reduced), when it is computed at all
+    NdPlan plan;
     if (bs.ordering == 1 && N > 2 && small && n > 1024) {
         adj.assign((size_t)N * N, 0);
         TRY(adjacency_build(bs.stream, G, voff, F, pidx, N, Q, adj.data())); // one thread per observer pair (pair_lists.hip)
@@ -313,10 +386,22 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
                 if (row[j]) Bb_rcm = std::max(Bb_rcm, std::abs(iperm[i] - iperm[j]));
         }
         if (Bb_rcm < Bb_nat) { bs.perm = perm; bs.iperm = iperm; bs.Bb = Bb_rcm; }
+        // A graph that is not a narrow band (a hub on the ring), or a long band on several ranks: one level of nested dissection
+        // (nd_plan.h: the cost model decides; every rank derives the same plan from the same all-reduced graph).  Not for grouped
+        // problems (their groups are independent already) nor for the visual stage's SPD systems (bcr.hip).
+        if (bs.n_groups == 0 && !bs.spd && !solver_form("nond")) {
+            NdPlan pl = nd_plan(adj.data(), N, bs.perm, bs.Bb, bs.distributed() ? bs.n_ranks : 1, solver_form("nd") ? 1e30 : 0.8);
+            if (pl.active) {
+                plan = pl;
+                bs.perm = plan.perm;
+                for (int i = 0; i < N; ++i) bs.iperm[bs.perm[i]] = i;
+                bs.Bb = N - 1;
+            }
+        }
     }
     BS_MARK("ordering");
     const int64_t bw = 6 * (int64_t)bs.Bb + 5;
-    bs.use_band = (double)(bw + LVBA_NB + 64) < bs.band_frac * (double)n;
+    bs.use_band = !plan.active && (double)(bw + LVBA_NB + 64) < bs.band_frac * (double)n;
     if (!bs.use_band) bs.Bb = N - 1; // full lower block triangle
     const int64_t Bb1 = (int64_t)bs.Bb + 1;
     bs.hblk_doubles = (int64_t)N * Bb1 * 36;
@@ -446,7 +531,9 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
     }
     TRY(bs_dmalloc(bs, &bs.d_status, 4));
     bs.A.n = n;
-    if (bs.use_band) {
+    if (plan.active) {
+        TRY(nd_alloc(bs, plan));
+    } else if (bs.use_band) {
         const int64_t ldab = bw + LVBA_NB + 64;
         bs.A.ld = ldab - 1; bs.A.bw = bw;
         TRY(bs_dmalloc(bs, &bs.d_A, 2 * (ldab * (n + 1)) + 65 * ldab)); // room for the second matrix of the twisted factorisation (+ slack: edge tiles read past the window, ldlt.hip)
@@ -457,7 +544,7 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
         TRY(bs_dmalloc(bs, &bs.d_A, n * n + 64 * n + 128)); // (+ slack: edge tiles read past the window, ldlt.hip)
     }
     bs.A.a = bs.d_A;
-    TRY(bs_dmalloc(bs, &bs.d_work, ldlt_workspace_doubles(n, bs.A.bw)));
+    if (!plan.active) TRY(bs_dmalloc(bs, &bs.d_work, ldlt_workspace_doubles(n, bs.A.bw)));
     {
         const char *e = getenv("LVBA_BCR");
         if (bs.spd && bs.use_band && bcr_applicable(N, bs.Bb) && !(e && !strcmp(e, "0")))
@@ -475,6 +562,10 @@ static int32_t dist_sum_cb(void *ctx, double *dbuf, size_t count) { return bs_co
 static int32_t dist_max_cb(void *ctx, int *dbuf) { return bs_comm_allreduce(*static_cast<BlockSys *>(ctx), dbuf, 1, ncclInt32, ncclMax); }
 static int32_t solve_launches(BlockSys &bs)
 {
+    if (bs.nd.active) {
+        LdltDist dd{bs.rank, bs.n_ranks, &bs, dist_sum_cb, dist_max_cb};
+        return nd_solve(bs.nd, bs.Hblk(), bs.N, bs.g(), bs.d_u, bs.d_dx, bs.d_status, bs.stream, bs.distributed() && bs.n_ranks >= 2 ? &dd : nullptr);
+    }
     if (bs.d_bcr) { bcr_solve(bs.Hblk(), bs.Bb, bs.N, bs.g(), bs.d_u, bs.d_dx, bs.d_bcr, bs.d_status, bs.stream); return LVBA_OK; }
     // multi-rank: the two ends of the band factorisation on ranks 0 and 1
     LdltDist dd{bs.rank, bs.n_ranks, &bs, dist_sum_cb, dist_max_cb};
@@ -518,6 +609,7 @@ static int32_t enqueue_solve_launches(BlockSys &bs)
     // no capture while several host threads drive the device (bs_graph_inhibit): with HIP 7.0 a capture in one thread is
     // invalidated by allocations / synchronous copies in another even in hipStreamCaptureModeThreadLocal
     if (bs.distributed() && bs.n_ranks >= 2) bs.graph_tried = true; // the solve has exchanges between the ranks in it
+    if (bs.nd.active) bs.graph_tried = true; // (a dissected solve forks onto one stream per arc: launched eagerly)
     if (!bs.graph_tried && g_graph_inhibit.load() == 0 && ++bs.solve_calls >= 3) {
         bs.graph_tried = true;
         if (!getenv("LVBA_NO_GRAPH")) {
@@ -553,6 +645,14 @@ void bs_destroy(BlockSys &bs)
                     bs.d_pairs, bs.d_Y, bs.d_hg, bs.d_A, bs.d_work, bs.d_bcr, bs.d_dx, bs.d_u, bs.d_status};
     for (void *p : ptrs)
         if (p) DevicePool::get().free(p);
+    for (void *p : bs.nd_allocs)
+        if (p) DevicePool::get().free(p);
+    for (NdArc &A : bs.nd.arcs) {
+        if (A.stream) lvba::StreamCache::get().release(A.stream);
+        if (A.done) hipEventDestroy(A.done);
+    }
+    if (bs.nd.start) hipEventDestroy(bs.nd.start);
+    if (bs.nd.mid) hipEventDestroy(bs.nd.mid);
     if (bs.h_pin_u) hipHostFree(bs.h_pin_u);
     if (bs.stream) lvba::StreamCache::get().release(bs.stream);
     bs = BlockSys();

@@ -13,6 +13,7 @@
 //   ldlt_lookahead.h  ONE launch per panel: chain role (the next diagonal block), row roles (L21, Z, the next block column),
 //                     bulk tiles of earlier panels' rank-128 updates; which launch carries what: ldlt_schedule.h (host)
 //   ldlt_back.h       the backward substitution as one chained launch
+//   ldlt_nd.h         graphs that are not a narrow band: one level of nested dissection over arcs solved by this very file
 //   this file         the launch sequence of one solve (captured once into a hipGraph by block_system.hip)
 //
 // MFMA operand layout used (v_mfma_f64_16x16x4_f64): lane l supplies A[i=l&15][k=l>>4] and
@@ -63,9 +64,10 @@ int64_t ldlt_num_panels(int64_t n) { return (n + LVBA_NB - 1) / LVBA_NB; }
 
 // Panels each end eliminates in the twisted form (0: plain top-down).  Both ends run the same number of panels, so the two
 // problems have identical geometry and share every launch (blockIdx.y); the middle block S = n - 128 P keeps >= bw columns.
+static int64_t twist_panels_of(const LdltMat &A) { return A.no_twist ? 0 : ldlt_twist_panels(A.n, A.ld, A.bw); }
 int64_t ldlt_twist_panels(int64_t n, int64_t ld, int64_t bw)
 {
-    static const bool off = [] { const char *e = getenv("LVBA_TWIST"); return e && !strcmp(e, "0"); }();
+    static const bool off = solver_form("notwist");
     if (off || ld == n) return 0; // dense storage: every column is coupled to every other
     const int64_t P = (n - bw) / (2 * LVBA_NB);
     return P >= 4 ? P : 0;
@@ -75,17 +77,19 @@ int64_t ldlt_twist_panels(int64_t n, int64_t ld, int64_t bw)
 // Launch sequence of one solve on one stream (captured once into a hipGraph by the caller): ONE launch per 64-column panel
 // (ldlt_lookahead.h), which launch carries which bulk job decided by ldlt_schedule.h (checked on the CPU against a tile-level
 // model of the factorisation, tests/ldlt_schedule_check.cpp).
-// Band systems are factorised from BOTH ENDS at once (LdltTwist, ldlt_prepare.h; LVBA_TWIST=0 turns it off): the serial chain of
+// Band systems are factorised from BOTH ENDS at once (LdltTwist, ldlt_prepare.h; LVBA_SOLVER=notwist turns it off): the serial chain of
 // panels -- the latency that bounds this solver -- is P + |S| / 64 long instead of n / 64, with the same flops and no fill.
 // With `dist` (>= 2 ranks) the two ends run on two GPUs: rank 0 eliminates T, rank 1 eliminates B (as the second problem,
 // alone in its launches), the S block + right-hand side are all-reduced (ranks >= 2 contribute zeros), every rank factorises S,
 // rank 0 back-substitutes T and rank 1 B, and the solution is all-reduced.  Per rank the end phase is as long as the
 // single-GPU one but moves one window per launch instead of two; what is replicated is the S phase only.
 int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_poses, const double *g,
-                   const double *u_dev, double *x, double *work, int *status, hipStream_t s, const LdltDist *dist, const int32_t *grp)
+                   const double *u_dev, double *x, double *work, int *status, hipStream_t s, const LdltDist *dist, const int32_t *grp,
+                   int phase)
 {
     const int64_t n = A.n, bw = A.bw;
-    const int64_t P1 = ldlt_twist_panels(n, A.ld, bw);
+    const int64_t P1 = twist_panels_of(A);
+    if (phase != LDLT_ALL && (P1 > 0 || dist)) return LVBA_ERR_STATE; // the halves exist for plain single-rank factorisations
     LdltTwist tw;
     tw.m = P1 * LVBA_NB; tw.n1 = n - tw.m;
     tw.sA = (A.ld + 1) * (n + 1); tw.sW = ldlt_ws_one(n, bw);
@@ -108,6 +112,9 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
     // grid y of the fill: block offsets d0 = 28 y must cover every stored offset d in [0, ldab) of a column, for every element
     // row / column e in [0, 6): d = 6 d0 + t - e (matrix 1) or 6 d0 + t + e - 5 (matrix 2), t in [0, 168) -- i.e. up to ldab + 5
     static_assert(LVBA_PB_ROWS == 6 * LVBA_PB_BLOCKS, "a workgroup of the band fill covers LVBA_PB_BLOCKS block offsets");
+    LdltMat M2 = M; // the second problem alone (its pointers are the launch's base pointers): what rank 1 of a multi-rank job runs
+    M2.a += tw.sA;
+    if (phase != LDLT_BACKWARD) { // ---- fill, factorisation, forward substitution
     if (fill) {
         static const bool check_band = [] { const char *e = getenv("LVBA_CHECK_BAND"); return e && !strcmp(e, "1"); }();
         const int64_t ldab = A.ld + 1, total = 2 * (ldab * (n + 1)) + 65 * ldab; // = block_system.hip's allocation
@@ -143,8 +150,6 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
         q.T = q.w0 < q.rend ? (q.rend - q.w0 + 63) / 64 : 0;
         return q;
     };
-    LdltMat M2 = M; // the second problem alone (its pointers are the launch's base pointers): what rank 1 of a multi-rank job runs
-    M2.a += tw.sA;
     double *side_buf[2] = {Zbuf[3] + ldz * LVBA_NB + 64, Zbuf[3] + ldz * LVBA_NB + 64 + 4096};
     double *dq_buf[2] = {side_buf[1] + 4096, side_buf[1] + 2 * 4096};
     static const int n_cus = [] {
@@ -153,9 +158,9 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
         (void)hipGetLastError();
         return n > 0 ? n : 256;
     }();
-    // LVBA_BULK=64 forces the 64 x 64 bulk tiles (64-bit pointers) that matrices of 4 GB and more take anyway -- the 128 x 64 tiles
-    // address one problem's storage with 32-bit byte offsets (buffer instructions) -- so that the tests reach that path at test sizes
-    static const bool big_env = [] { const char *e = getenv("LVBA_BULK"); return !(e && !strcmp(e, "64")); }();
+    // LVBA_SOLVER=bulk64 forces the 64 x 64 bulk tiles (64-bit pointers) that matrices of 4 GB and more take anyway -- the 128 x 64
+    // tiles address one problem's storage with 32-bit byte offsets (buffer instructions) -- so that the tests reach that path at test sizes
+    static const bool big_env = !solver_form("bulk64");
     const bool big = big_env && ((uint64_t)A.ld * (uint64_t)(n + 128) + (uint64_t)n + 256) * 8 < 0xFFFF0000ull;
     // Panels [sa, sb) of one problem (or of both, ny = 2).  Consecutive panels are PAIRED (e, o = e + 1): e leaves the bulk of its
     // trailing update to its partner's launches, where every C tile is read and written once for both (rank 128).
@@ -237,6 +242,8 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
         st0 = P1;
     }
     run_phase(st0, nsteps, 1, false, false);
+    }
+    if (phase == LDLT_FACTOR) return LVBA_OK;
     // backward: the whole substitution as chained launches (ldlt_back.h).  At most 256 panels per launch: one workgroup per CU is
     // then resident whatever else shares the device, so the chain cannot starve even if workgroups were not dispatched in index
     // order; later launches only read finished x (a multi-rank job stops matrix 1's chain after the S panels unless this rank owns T)
@@ -278,5 +285,7 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
     }
     return LVBA_OK;
 }
+
+#include "ldlt_nd.h"
 
 } // namespace lvba

@@ -357,7 +357,10 @@ extern "C" int32_t lvba_balm_info(lvba_balm_t h, lvba_balm_info_t *info)
     info->n_factors = h->F; info->n_pairs = h->Q; info->n_chunks = h->n_chunks; info->n_blocks = h->bs.nnzb;
     info->band_blocks = h->bs.Bb; info->use_band = h->bs.use_band ? 1 : 0; info->hess_bytes = h->bs.hblk_doubles * 8;
     info->device_bytes = h->bs.device_bytes;
-    info->twist_panels = h->bs.d_bcr ? 0 : (int32_t)ldlt_twist_panels(h->bs.A.n, h->bs.A.ld, h->bs.A.bw);
+    info->twist_panels = (h->bs.d_bcr || h->bs.nd.active) ? 0 : (int32_t)ldlt_twist_panels(h->bs.A.n, h->bs.A.ld, h->bs.A.bw);
+    info->nd_kind = !h->bs.nd.active ? 0 : !strcmp(h->bs.nd.kind, "hubs") ? 1 : 2;
+    info->nd_arcs = (int32_t)h->bs.nd.arcs.size(); info->nd_sep_poses = h->bs.nd.Ns; info->nd_sep_band_blocks = h->bs.nd.BbS;
+    info->nd_model_band_ms = 1e3 * h->bs.nd.t_band; info->nd_model_nd_ms = 1e3 * h->bs.nd.t_nd;
     info->solve_ranks = (h->bs.distributed() && h->bs.n_ranks >= 2 && info->twist_panels > 0) ? 2 : 1;
     info->trial_linearised = 1;
     info->y_fp32 = h->bs.y32 ? 1 : 0;

@@ -2,6 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
 
 #define LVBA_CF 256   // max factors per chunk == workgroup size of the BALM kernels
 #define LVBA_CV 128   // max voxels per chunk (every voxel has >= 2 factors)
@@ -73,13 +76,66 @@ struct VisDev {
     double *camsum, *colsum;
 };
 
+
 // Working matrix of the damped system, lower triangle, column-major with leading dimension ld:
 // A(r,c) = a[r + c*ld].  Dense: ld = n.  Band: LAPACK lower-band storage with ldab = ld+1, i.e.
 // A(r,c) = ab[(r-c) + c*ldab]; valid offsets 0 <= r-c <= ld.  bw = half bandwidth in scalars.
 struct LdltMat {
     double *a;
     int64_t n, ld, bw;
+    int32_t no_twist; // 1: plain top-down factorisation whatever the shape (the arcs of nd_solve.hip: their factors are reused)
 };
+
+// LVBA_SOLVER = comma-separated forms the damped solve is FORCED into (tests reach every form at test sizes that way):
+//   notwist  plain top-down band factorisation (what bands too short for two ends take)
+//   bulk64   64 x 64 update tiles with 64-bit pointers (what matrices of 4 GB and more take)
+//   nd       nested dissection (ldlt_nd.h) whenever a partition exists, whatever the cost model says;  nond: never
+inline bool solver_form(const char *name)
+{
+    const char *e = getenv("LVBA_SOLVER");
+    if (!e) return false;
+    const size_t n = strlen(name);
+    for (const char *p = e; *p;) {
+        const char *q = strchr(p, ',');
+        const size_t len = q ? (size_t)(q - p) : strlen(p);
+        if (len == n && !strncmp(p, name, n)) return true;
+        p += len + (q ? 1 : 0);
+    }
+    return false;
+}
+
+// One level of nested dissection (nd_plan.h decides, ldlt_nd.h solves): device-side pieces of an arc and of the whole system
+struct NdArc {
+    int32_t p0, Na;     // pose range [p0, p0 + Na) of the solver order
+    int32_t nsep;       // separator poses the arc touches
+    int32_t owner;      // rank that factorises it
+    int64_t n, ldb;     // 6 Na; row stride of B / Y: 6 nsep rounded up to 64
+    LdltMat A;          // its band (or dense) matrix, no_twist
+    double *d_A;        // (allocation behind A.a)
+    double *work;       // ldlt_solve's workspace: G, d, b
+    double *B, *Y;      // [n][ldb] row-major: E_a^T as the forward substitution leaves it / L^-1 E_a^T
+    double *Sa;         // [ldb][ldb], column j at Sa + j ldb: lower tiles of Y^T D^-1 Y
+    double *wv;         // [n]   G^T b, panel by panel (= D^-1 L^-1 b)
+    double *gpart;      // [ND_GS_SLICES][ldb] partial sums of Y^T wv
+    int32_t *sep;       // [nsep] separator-local pose indices, ascending (device)
+    int *status;
+    hipStream_t stream;
+    hipEvent_t done;
+};
+struct NdSys {
+    bool active = false;
+    int32_t ps = 0, Ns = 0, BbS = 0; // separator: solver positions [ps, ps + Ns), half-bandwidth of its system in pose blocks
+    std::vector<NdArc> arcs;
+    LdltMat AS{};                    // the separator system
+    double *d_AS = nullptr, *workS = nullptr;
+    double *Sblk = nullptr;          // [Ns (BbS + 1) 36 | 6 Ns]: its block store and gradient (one all-reduce covers both)
+    double *d_zero = nullptr;        // a zero on the device: the separator system is damped when it is built
+    int *d_stat = nullptr, *statusS = nullptr; // [arcs + 1]
+    hipEvent_t start = nullptr, mid = nullptr;
+    const char *kind = "band";
+    double t_band = 0.0, t_nd = 0.0;
+};
+#define ND_GS_SLICES 16
 
 // balm_kernels.hip
 void launch_cost(const BalmDev &d, const double *poses, double *chunk_cost, double *out, hipStream_t s,
@@ -131,6 +187,13 @@ int64_t ldlt_workspace_doubles(int64_t n, int64_t bw);
 int64_t ldlt_num_panels(int64_t n);
 // panels each end of the two-ended ("twisted") band factorisation eliminates; 0: plain top-down
 int64_t ldlt_twist_panels(int64_t n, int64_t ld, int64_t bw);
+// where ldlt_solve keeps the pieces of a (plain top-down) factorisation in its workspace: G [panels][64 x 64] (G = L11^-T D^-1 of
+// every diagonal block, [m][c] row-major), d [n], and the right-hand side b [n] -- after the forward substitution b holds, panel
+// by panel, the rows as the earlier panels' updates left them (L11^-1 not yet applied: c_k = D_k G_k^T b_k)
+inline double *ldlt_work_G(double *work) { return work; }
+inline double *ldlt_work_d(int64_t n, double *work) { return work + ((n + LVBA_NB - 1) / LVBA_NB) * 4096; }
+inline double *ldlt_work_b(int64_t n, double *work) { return ldlt_work_d(n, work) + n; }
+enum { LDLT_ALL = 0, LDLT_FACTOR = 1, LDLT_BACKWARD = 2 }; // ldlt_solve's `phase`: everything / fill + factorise + forward / backward only
 // A <- H + u*diag(H) from the block-band store, b <- -g; then unpivoted blocked LDL^T of the lower
 // triangle and the two triangular solves.  x (length n) receives the solution; status[0] != 0 on a
 // zero / non-finite pivot.  u is read from device memory (u_dev) so the launch sequence is static and
@@ -143,9 +206,13 @@ struct LdltDist {
     int32_t (*allreduce_sum)(void *ctx, double *dbuf, size_t count);
     int32_t (*allreduce_max_i32)(void *ctx, int *dbuf);
 };
+struct LdltDist;
+int32_t nd_solve(NdSys &nd, const double *Hblk, int32_t N, const double *g, const double *u_dev, double *x, int *status, hipStream_t s,
+                 const LdltDist *dist);
 int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_poses, const double *g,
                    const double *u_dev, double *x, double *work, int *status, hipStream_t s, const LdltDist *dist = nullptr,
-                   const int32_t *grp = nullptr); // grp: pose block -> entry of u_dev (grouped refinement)
+                   const int32_t *grp = nullptr, // grp: pose block -> entry of u_dev (grouped refinement)
+                   int phase = LDLT_ALL);        // LDLT_FACTOR / LDLT_BACKWARD: the two halves of a solve (single rank, A.no_twist)
 
 // bcr.hip: block cyclic reduction for narrow-band SPD systems (the visual stage's reduced camera system)
 bool bcr_applicable(int n_poses, int band_blocks);

@@ -55,11 +55,25 @@ def trajectory(n_poses, gen, device):
     return Rz @ Ry @ Rx, p
 
 
+REVISITS = ("antipodal", "figure8", "chords", "lot")
+
+
 def make_balm_problem(n_poses, n_voxels, *, seed=20250925, band=50, loop_frac=0.05,
                       k_extra_mean=3.0, k_max=16, npts=(15, 120), rot_sigma_deg=0.02,
-                      trans_sigma=0.01, thickness=0.01, device="cpu", chunk=None):
+                      trans_sigma=0.01, thickness=0.01, device="cpu", chunk=None, revisit="antipodal"):
     """Returns dict(poses_gt, poses_init [N,12], voxel_off [V+1] i64, pose_idx [F] i32,
-    clusters [F,10] f64, plane_n [V,3], plane_c [V,3])."""
+    clusters [F,10] f64, plane_n [V,3], plane_c [V,3]).
+
+    revisit: where the loop-closure voxels (loop_frac of them) find their far observers -- the SHAPE of the co-visibility graph
+    beyond the ring of reach `band`:
+      "antipodal" (SURVEY 8(d), the BASELINE configs): pose h sees what h + N/2 sees -- a regular pattern a band ordering folds;
+      "figure8":  h <-> N - h (a road driven back in the other direction): mirror chords, also foldable;
+      "chords":   six random places visited twice (segments of 2 band + 1 poses, a -> b): irregular chords;
+      "lot":      eight short stretches (band / 2 poses) spread irregularly over the trajectory, ALL at the same place (a parking
+                  lot crossed eight times): half of the voxels homed there are seen from other crossings -- a dense clique of
+                  8 x band / 2 poses hanging on the ring, which no band ordering keeps narrow."""
+    if revisit not in REVISITS:
+        raise ValueError(f"revisit must be one of {REVISITS}")
     dev = torch.device(device)
     f64 = torch.float64
     g_struct = torch.Generator(device=dev).manual_seed(seed)
@@ -78,16 +92,46 @@ def make_balm_problem(n_poses, n_voxels, *, seed=20250925, band=50, loop_frac=0.
     k = (2 + torch.poisson(lam, generator=g_struct)).clamp(2, k_max).long()
     loops_ok = N >= 4 * W + 4
     is_loop = (torch.rand(V, generator=g_struct, device=dev) < loop_frac) & loops_ok
-    n_far = torch.where(is_loop, (k // 2).clamp_min(1), torch.zeros_like(k))
 
-    def band_members(center):
-        c = center.clamp(W, N - 1 - W) if N > 2 * W else torch.full_like(center, W)
-        r = torch.rand(V, band_sz, generator=g_struct, device=dev)
-        off = r.topk(k_max, dim=1, largest=False).indices  # k_max distinct offsets
-        return (c[:, None] - W + off).clamp(0, N - 1)
+    def band_members(center, Wb=None):
+        Wb = W if Wb is None else Wb
+        bsz = min(2 * Wb + 1, N)
+        c = center.clamp(Wb, N - 1 - Wb) if N > 2 * Wb else torch.full_like(center, Wb)
+        r = torch.rand(V, bsz, generator=g_struct, device=dev)
+        off = r.topk(min(k_max, bsz), dim=1, largest=False).indices  # distinct offsets
+        if off.shape[1] < k_max:
+            off = torch.cat([off, off[:, :1].expand(V, k_max - off.shape[1])], 1)   # (duplicates are dropped below)
+        return (c[:, None] - Wb + off).clamp(0, N - 1)
 
     near = band_members(home)
-    far = band_members((home + N // 2) % N)
+    if revisit == "antipodal":
+        far = band_members((home + N // 2) % N)
+    elif revisit == "figure8":
+        far = band_members((N - home) % N)
+    else:
+        rs = np.random.default_rng(seed + 7)
+        if revisit == "chords":
+            n_ch, seg = 6, 2 * W + 1
+            a = np.sort(rs.choice(np.arange(seg, N - seg, seg), size=min(n_ch, max(1, (N - 2 * seg) // seg)), replace=False))
+            b = rs.permutation(a)                                   # every visited place is some other place's second visit
+            ta, tb = torch.as_tensor(a, device=dev), torch.as_tensor(b, device=dev)
+            d = (home[:, None] - ta[None, :]).abs()
+            near_a = d.min(1)
+            on = (near_a.values <= W) & (tb[near_a.indices] != ta[near_a.indices])
+            far = band_members(torch.where(on, tb[near_a.indices] + (home - ta[near_a.indices]), home))
+            is_loop = on & (torch.rand(V, generator=g_struct, device=dev) < min(1.0, loop_frac * N / max(1, len(a) * seg))) & loops_ok
+        else:   # "lot"
+            n_lot, Ls = 8, max(4, W // 2)
+            starts = np.sort(rs.choice(np.arange(Ls, N - 2 * Ls, 2 * Ls), size=min(n_lot, max(2, (N - 3 * Ls) // (2 * Ls))), replace=False))
+            ts = torch.as_tensor(starts, device=dev)
+            rel = home[:, None] - ts[None, :]
+            inside = (rel >= 0) & (rel < Ls)
+            on = inside.any(1)
+            mine = inside.float().argmax(1)
+            other = (mine + 1 + torch.randint(0, len(starts) - 1, (V,), generator=g_struct, device=dev)) % len(starts)
+            far = band_members(torch.where(on, ts[other] + Ls // 2, home), Ls // 2)
+            is_loop = on & (torch.rand(V, generator=g_struct, device=dev) < 0.5) & loops_ok
+    n_far = torch.where(is_loop, (k // 2).clamp_min(1), torch.zeros_like(k))
     j = torch.arange(k_max, device=dev)[None, :]
     n_near = (k - n_far)[:, None]
     obs = torch.where(j < n_near, near, far.gather(1, (j - n_near).clamp(0, k_max - 1)))
@@ -98,6 +142,11 @@ def make_balm_problem(n_poses, n_voxels, *, seed=20250925, band=50, loop_frac=0.
     dup[:, 1:] = obs[:, 1:] == obs[:, :-1]
     valid = (obs <= N - 1) & ~dup
     k = valid.sum(1)
+    if revisit != "antipodal" and int(k.min()) < 2:
+        # (a far observer that is also a near one -- revisited places closer than the band: the few voxels left with one observer go)
+        keep = k >= 2
+        home, obs, valid, k = home[keep], obs[keep], valid[keep], k[keep]
+        V = int(keep.sum())
     assert int(k.min()) >= 2, "generator produced a voxel with < 2 observers"
     voxel_off = torch.zeros(V + 1, dtype=torch.int64, device=dev)
     voxel_off[1:] = k.cumsum(0)

@@ -97,6 +97,13 @@ typedef struct {
                                * lvba_visual_info) */
     int32_t y_fp32;           /* 1: LVBA_Y32=1 took effect -- the per-factor Y records travel as fp32 between the factor and the
                                * pair pass (an experiment: off-diagonal pose blocks then carry ~1e-7 relative rounding) */
+    /* The damped solve by one level of nested dissection (csrc/nd_plan.h, csrc/ldlt_nd.h) instead of one band: a co-visibility
+     * graph with a hub (a place crossed many times), or a long band on several ranks.  nd_kind 0: no (band / dense as above). */
+    int32_t nd_kind;          /* 1: hub separator, 2: chunks of the band ordering */
+    int32_t nd_arcs;          /* independent band systems (over all ranks) */
+    int32_t nd_sep_poses;     /* poses of the separator system */
+    int32_t nd_sep_band_blocks; /* its pose-block half bandwidth */
+    double nd_model_band_ms, nd_model_nd_ms; /* the plan's cost model: seconds -> ms per solve, band against dissection */
 } lvba_balm_info_t;
 
 /* Accumulated device times (HIP events on the handle's stream) since the last reset, ms. */

@@ -1,0 +1,101 @@
+"""The damped solve by one level of nested dissection (csrc/nd_plan.h + csrc/ldlt_nd.h) -- the form the solver takes when the
+pose co-visibility graph is not a narrow band: a HUB on the ring (a place crossed many times: synth's revisit="lot"), or a long
+band shared by several ranks (chunks of the band ordering as separators).  The reference hands whatever pattern arrives to
+Eigen::SimplicialLDLT (include/BALM/bavoxel.hpp:696-710); the checks here are the ones the band solver has: the solution of the
+damped system against a dense solve of the SAME system on the host, whole LM runs against the C oracle, and -- multi-rank, as
+host threads through tests/host_transport.cpp -- bitwise agreement of the ranks.  LVBA_SOLVER=nd forces the dissection at test
+sizes (the cost model would keep two dozen panels in one band); nothing else is switched."""
+import numpy as np
+import pytest
+
+from conftest import HostTransport, make_problem, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def dense_solve(H, g, u):
+    A = H + u * np.diag(np.diag(H))
+    return np.linalg.solve(A, -g)
+
+
+@pytest.mark.parametrize("case", [dict(n_poses=320, n_voxels=16000, band=12, seed=3, revisit="lot"),
+                                  dict(n_poses=420, n_voxels=20000, band=10, seed=5, revisit="lot"),
+                                  dict(n_poses=400, n_voxels=20000, band=8, seed=8, revisit="chords")])
+def test_hub_graph_dissection_matches_dense_solve_and_oracle(pkg, oracle_mod, case, monkeypatch):
+    d = make_problem(**case)
+    N = d["n_poses"]
+    monkeypatch.setenv("LVBA_SOLVER", "nond")
+    band = pkg.BalmProblem(N, d["voxel_off"], d["pose_idx"], d["clusters"])
+    Hb, gb, cb = band.eval(d["poses_init"])
+    assert band.info()["nd_kind"] == 0
+    monkeypatch.setenv("LVBA_SOLVER", "nd")
+    prob = pkg.BalmProblem(N, d["voxel_off"], d["pose_idx"], d["clusters"])
+    info = prob.info()
+    if case["revisit"] == "chords" and info["nd_kind"] == 0:
+        pytest.skip("no hub in this graph: the plan kept the band")
+    assert info["nd_kind"] == 1 and info["nd_arcs"] >= 1 and 0 < info["nd_sep_poses"] < N // 2, info
+    H, g, c = prob.eval(d["poses_init"])
+    # the evaluation does not depend on the order the poses are stored in
+    assert rel(H, Hb) <= 1e-12 and rel(g, gb) <= 1e-12 and abs(c - cb) <= 1e-12 * cb
+    for u in (0.01, 1e-4, 3.0):
+        dx = prob.solve(u)
+        want = dense_solve(H, g, u)
+        assert np.isfinite(dx).all()
+        assert np.abs(dx - want).max() <= 1e-8 * np.abs(want).max(), (u, np.abs(dx - want).max() / np.abs(want).max())
+        assert np.abs(dx - band.solve(u)).max() <= 1e-8 * np.abs(want).max()
+        assert np.array_equal(prob.solve(u), dx)                     # the same launches, the same sums: bitwise
+    x, trace, rc = prob.refine(d["poses_init"])
+    xb, trb, rcb = band.refine(d["poses_init"])
+    co = oracle_mod.COracle(N, d["voxel_off"], d["pose_idx"], d["clusters"])
+    xr, tr, _ = co.damping_iter(d["poses_init"])
+    assert rc == 0 and rcb == 0 and len(trace) == len(tr) == len(trb)
+    assert [r["accepted"] for r in trace] == [r["accepted"] for r in trb]
+    assert np.abs(x - xr).max() <= 1e-7 and np.abs(x - xb).max() <= 1e-7
+    prob.close()
+    band.close()
+
+
+@pytest.mark.parametrize("world,case", [(4, dict(n_poses=640, n_voxels=24000, band=6, seed=11)),
+                                        (3, dict(n_poses=600, n_voxels=20000, band=6, seed=12, loop_frac=0.0))])
+def test_long_band_shared_by_ranks(pkg, oracle_mod, world, case, monkeypatch):
+    """Chunks of the band ordering as separators: every rank factorises its own arcs, the separator system is summed over the
+    ranks and solved, every rank substitutes back into its arcs, the solution is summed.  Ranks bitwise equal; equal to the
+    single-rank band solve to rounding; LM run equal to the oracle's."""
+    d = make_problem(**case)
+    N, off, idx, clu = d["n_poses"], d["voxel_off"], d["pose_idx"], d["clusters"]
+    V = len(off) - 1
+    monkeypatch.setenv("LVBA_SOLVER", "nond")
+    single = pkg.BalmProblem(N, off, idx, clu)
+    H1, g1, c1 = single.eval(d["poses_init"])
+    dx1 = single.solve(0.01)
+    x1, tr1, rc1 = single.refine(d["poses_init"])
+    single.close()
+    monkeypatch.setenv("LVBA_SOLVER", "nd")
+    ht = HostTransport(world)
+
+    def rank_main(r):
+        a, b = pkg.shard_range(V, r, world)
+        prob = pkg.BalmProblem(N, off[a:b + 1], idx[off[a]:off[b]], clu[off[a]:off[b]])
+        ht.attach(prob, r)
+        info = prob.info()
+        H, g, c = prob.eval(d["poses_init"])
+        dx = prob.solve(0.01)
+        x, trace, rc = prob.refine(d["poses_init"])
+        prob.close()
+        return dict(info=info, H=H, g=g, c=c, dx=dx, x=x, trace=trace, rc=rc)
+
+    out = ht.run(rank_main)
+    r0 = out[0]
+    assert r0["info"]["nd_kind"] == 2 and r0["info"]["nd_arcs"] >= world, r0["info"]
+    for o in out[1:]:
+        assert np.array_equal(o["H"], r0["H"]) and np.array_equal(o["dx"], r0["dx"]) and np.array_equal(o["x"], r0["x"])
+        assert o["trace"] == r0["trace"]
+    assert rel(r0["H"], H1) <= 1e-12 and rel(r0["g"], g1) <= 1e-12
+    want = dense_solve(r0["H"], r0["g"], 0.01)
+    assert np.abs(r0["dx"] - want).max() <= 1e-8 * np.abs(want).max()
+    assert np.abs(r0["dx"] - dx1).max() <= 1e-8 * np.abs(want).max()
+    assert r0["rc"] == rc1 == 0 and len(r0["trace"]) == len(tr1)
+    assert np.abs(r0["x"] - x1).max() <= 1e-7
+    co = oracle_mod.COracle(N, off, idx, clu)
+    xr, tr, _ = co.damping_iter(d["poses_init"])
+    assert np.abs(r0["x"] - xr).max() <= 1e-7

@@ -29,6 +29,22 @@ def test_ordering_properties(exe, n, band, loop):
         assert got <= 0.8 * rcm
 
 
+@pytest.mark.parametrize("shape,n,reach,ranks,kind", [("ring", 2000, 50, 1, "band"), ("lot", 2000, 50, 1, "hubs"),
+                                                     ("long", 4000, 30, 4, "chunks"), ("long", 3000, 20, 8, "chunks")])
+def test_nested_dissection_plan(tmp_path_factory, shape, n, reach, ranks, kind):
+    """global-lvba_amd/csrc/nd_plan.h through tests/nd_plan_check.cpp: the folded ring of config C3 keeps its band; a hub on the
+    ring (a place crossed eight times) is taken out as the separator; a long band on several ranks is cut into arcs by chunks
+    of its band ordering.  The check program verifies the partition itself (permutation, no edge between two arcs, every arc's
+    separator list complete, the bandwidths it reports, every rank owns an arc, determinism)."""
+    exe = str(tmp_path_factory.mktemp("nd") / "nd_plan_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "nd_plan_check.cpp"), "-o", exe])
+    r = subprocess.run([exe, shape, str(n), str(reach), str(ranks)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert f"kind={kind}" in r.stdout, r.stdout
+    if kind != "band":
+        assert "nd plan ok" in r.stdout
+
+
 def test_host_tables(tmp_path):
     """global-lvba_amd/csrc/host_tables.h: chunks of the voxel-major kernels (<= 256 factors, <= 128 voxels, big voxels alone,
     greedy) and work items of the pair pass (lists longer than the cut become partial-block items), through
