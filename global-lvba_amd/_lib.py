@@ -14,7 +14,7 @@ SYMBOLS = [
     "lvba_version", "lvba_last_error", "lvba_device_count", "lvba_balm_default_opts", "lvba_shard_range",
     "lvba_balm_create", "lvba_balm_create_dev", "lvba_balm_destroy", "lvba_balm_configure", "lvba_balm_info", "lvba_balm_cost",
     "lvba_balm_eval", "lvba_balm_eval_blocks", "lvba_balm_solve", "lvba_balm_refine", "lvba_balm_lm_begin", "lvba_balm_lm_step",
-    "lvba_balm_lm_end", "lvba_balm_set_groups", "lvba_balm_refine_groups", "lvba_balm_set_profiling", "lvba_balm_get_profile", "lvba_balm_get_ordering",
+    "lvba_balm_lm_end", "lvba_balm_set_groups", "lvba_balm_refine_groups", "lvba_balm_set_profiling", "lvba_balm_get_profile", "lvba_balm_get_ordering", "lvba_balm_nd_model",
     "lvba_dist_unique_id", "lvba_balm_dist_init", "lvba_balm_dist_init_external", "lvba_visual_dist_init_external",
     "lvba_visual_default_opts", "lvba_visual_create", "lvba_visual_destroy", "lvba_visual_cost", "lvba_visual_linearize", "lvba_visual_info", "lvba_visual_dist_init",
     "lvba_visual_refine",
@@ -52,6 +52,11 @@ class BalmInfo(C.Structure):
                 ("twist_panels", C.c_int32), ("solve_ranks", C.c_int32), ("trial_linearised", C.c_int32), ("y_fp32", C.c_int32),
                 ("nd_kind", C.c_int32), ("nd_arcs", C.c_int32), ("nd_sep_poses", C.c_int32), ("nd_sep_band_blocks", C.c_int32),
                 ("nd_model_band_ms", C.c_double), ("nd_model_nd_ms", C.c_double)]
+
+
+class NdModel(C.Structure):
+    _fields_ = [("n_ranks", C.c_int32), ("arcs", C.c_int32), ("sep_poses", C.c_int32), ("sep_band_blocks", C.c_int32),
+                ("max_arc_poses", C.c_int32), ("max_arc_band_blocks", C.c_int32), ("band_ms", C.c_double), ("nd_ms", C.c_double)]
 
 
 class Prof(C.Structure):
@@ -180,6 +185,7 @@ def load():
     lib.lvba_balm_set_profiling.argtypes = [H, C.c_int32]
     lib.lvba_balm_get_profile.argtypes = [H, C.POINTER(Prof), C.c_int32]
     lib.lvba_balm_get_ordering.argtypes = [H, i32p]
+    lib.lvba_balm_nd_model.argtypes = [H, C.c_int32, C.POINTER(NdModel)]
     lib.lvba_dist_unique_id.argtypes = [C.c_char_p]
     lib.lvba_balm_dist_init_external.argtypes = [H, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.lvba_visual_dist_init_external.argtypes = [H, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]

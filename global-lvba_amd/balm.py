@@ -99,6 +99,12 @@ class BalmProblem:
         L.check(self.lib.lvba_balm_info(self._h, C.byref(i)))
         return {f: getattr(i, f) for f, _ in i._fields_}
 
+    def nd_model(self, n_ranks):
+        """the nested-dissection plan of this problem's graph on n_ranks ranks and its cost model (lvba_balm_nd_model)"""
+        m = L.NdModel()
+        L.check(self.lib.lvba_balm_nd_model(self._h, int(n_ranks), C.byref(m)))
+        return {f: getattr(m, f) for f, _ in m._fields_}
+
     def ordering(self):
         perm = np.empty(self.n_poses, np.int32)
         L.check(self.lib.lvba_balm_get_ordering(self._h, perm))

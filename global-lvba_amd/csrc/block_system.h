@@ -48,6 +48,10 @@ struct BlockSys {
     LdltMat A{};
     NdSys nd;                // one level of nested dissection, when that is the solver (nd_plan.h / ldlt_nd.h)
     std::vector<void *> nd_allocs;
+    // what nd_plan.h was given (kept for lvba_balm_nd_model: "what would n ranks do with this graph"); empty for small systems
+    lvba::hvec<uint8_t> adj_keep;
+    lvba::hvec<int32_t> perm_band;
+    int32_t Bb_band = 0;
     double *d_bcr = nullptr; // workspace of the block cyclic reduction, when that is the solver
     double *d_A = nullptr, *d_work = nullptr, *d_dx = nullptr, *d_u = nullptr, *h_pin_u = nullptr;
     double u_on_device = 0.0;      // the damping value d_u[0] holds (u_known): an unchanged value is not uploaded again
@@ -115,6 +119,8 @@ int32_t bs_pattern_slots(BlockSys &bs, lvba::hvec<int64_t> &slots);
 int32_t bs_download_blocks(BlockSys &bs, const int64_t *slots, int64_t n, double *out);
 int32_t bs_dist_init(BlockSys &bs, int32_t n_ranks, int32_t rank, const char uid[128], int64_t *group_count_inout);
 int32_t bs_dist_init_external(BlockSys &bs, int32_t n_ranks, int32_t rank, lvba_allreduce_fn fn, void *ctx, int64_t *group_count_inout);
+int32_t bs_nd_model(BlockSys &bs, int32_t n_ranks, double *t_band, double *t_nd, int32_t *arcs, int32_t *sep_poses, int32_t *sep_bb,
+                    int32_t *max_arc_poses, int32_t *max_arc_bb);
 void bs_destroy(BlockSys &bs);
 // +1 / -1 around sections in which several host threads use the library concurrently: solve graphs are not captured then
 void bs_graph_inhibit(int delta);

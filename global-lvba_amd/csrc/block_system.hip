@@ -389,6 +389,7 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
         // A graph that is not a narrow band (a hub on the ring), or a long band on several ranks: one level of nested dissection
         // (nd_plan.h: the cost model decides; every rank derives the same plan from the same all-reduced graph).  Not for grouped
         // problems (their groups are independent already) nor for the visual stage's SPD systems (bcr.hip).
+        if (bs.n_groups == 0 && !bs.spd && N >= 256) { bs.perm_band = bs.perm; bs.Bb_band = bs.Bb; }
         if (bs.n_groups == 0 && !bs.spd && !solver_form("nond")) {
             NdPlan pl = nd_plan(adj.data(), N, bs.perm, bs.Bb, bs.distributed() ? bs.n_ranks : 1, solver_form("nd") ? 1e30 : 0.8);
             if (pl.active) {
@@ -400,6 +401,7 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
         }
     }
     BS_MARK("ordering");
+    if (!bs.perm_band.empty()) bs.adj_keep.swap(adj);
     const int64_t bw = 6 * (int64_t)bs.Bb + 5;
     bs.use_band = !plan.active && (double)(bw + LVBA_NB + 64) < bs.band_frac * (double)n;
     if (!bs.use_band) bs.Bb = N - 1; // full lower block triangle
@@ -631,6 +633,19 @@ static int32_t enqueue_solve_launches(BlockSys &bs)
     if (bs.solve_exec) HIPCHK(hipGraphLaunch(bs.solve_exec, bs.stream));
     else TRY(solve_launches(bs));
     HIPCHK(hipGetLastError());
+    return LVBA_OK;
+}
+
+// The dissection plan nd_plan.h would make of this system's graph on n_ranks ranks, and its cost model (seconds per solve)
+int32_t bs_nd_model(BlockSys &bs, int32_t n_ranks, double *t_band, double *t_nd, int32_t *arcs, int32_t *sep_poses, int32_t *sep_bb,
+                    int32_t *max_arc_poses, int32_t *max_arc_bb)
+{
+    if (bs.adj_keep.empty()) return LVBA_ERR_STATE;
+    const NdPlan pl = nd_plan(bs.adj_keep.data(), bs.N, bs.perm_band, bs.Bb_band, n_ranks, 1e30);
+    *t_band = pl.t_band; *t_nd = pl.active ? pl.t_nd : 0.0;
+    *arcs = (int32_t)pl.arcs.size(); *sep_poses = pl.Ns; *sep_bb = pl.BbS;
+    *max_arc_poses = *max_arc_bb = 0;
+    for (const NdPlanArc &a : pl.arcs) { *max_arc_poses = std::max(*max_arc_poses, a.Na); *max_arc_bb = std::max(*max_arc_bb, a.Bb); }
     return LVBA_OK;
 }
 

@@ -376,6 +376,20 @@ extern "C" int32_t lvba_balm_get_ordering(lvba_balm_t h, int32_t *perm)
     return LVBA_OK;
 }
 
+extern "C" int32_t lvba_balm_nd_model(lvba_balm_t h, int32_t n_ranks, lvba_nd_model_t *out)
+{
+    if (!h || !out || n_ranks < 1) return fail(LVBA_ERR_ARG, "bad argument");
+    TRY(finalize(h));
+    memset(out, 0, sizeof *out);
+    out->n_ranks = n_ranks;
+    double tb = 0.0, tn = 0.0;
+    const int32_t rc = bs_nd_model(h->bs, n_ranks, &tb, &tn, &out->arcs, &out->sep_poses, &out->sep_band_blocks, &out->max_arc_poses,
+                                   &out->max_arc_band_blocks);
+    if (rc != LVBA_OK) return fail(rc, "no co-visibility graph was kept for this problem (fewer than 256 poses, grouped, or solved dense without an ordering)");
+    out->band_ms = 1e3 * tb; out->nd_ms = 1e3 * tn;
+    return LVBA_OK;
+}
+
 // ------------------------------------------------------------------------------------------ profiling
 static void ev_begin(lvba_balm_s *h, int which)
 {

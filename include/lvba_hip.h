@@ -200,6 +200,16 @@ int32_t lvba_balm_get_profile(lvba_balm_t h, lvba_prof_t *out, int32_t reset);
 /* Pose ordering used internally: perm[internal] = caller pose index (n_poses entries). */
 int32_t lvba_balm_get_ordering(lvba_balm_t h, int32_t *perm);
 
+/* What the damped solve would look like on n_ranks ranks: the nested-dissection plan csrc/nd_plan.h makes of this problem's
+ * co-visibility graph (arcs dealt out over the ranks, separator system) and its cost model in ms per solve, next to the band
+ * factorisation's (two ranks at best).  A MODEL, in the solver's own measured units (launches on the serial chain x us per
+ * launch, flops / sustained rate); nd_ms = 0: no partition exists.  Needs >= 256 poses. */
+typedef struct {
+    int32_t n_ranks, arcs, sep_poses, sep_band_blocks, max_arc_poses, max_arc_band_blocks;
+    double band_ms, nd_ms;
+} lvba_nd_model_t;
+int32_t lvba_balm_nd_model(lvba_balm_t h, int32_t n_ranks, lvba_nd_model_t *out);
+
 /* Multi-GPU (one process per GPU): factors are sharded by voxel range across ranks; every eval
  * all-reduces {block-band H, g, cost} and every cost pass all-reduces one double, over RCCL.
  * uid is an ncclUniqueId (128 bytes) created on rank 0 and distributed by the caller. */

@@ -29,7 +29,7 @@ def test_header_symbols_are_exported(lib, pkg):
 def test_struct_layouts_match_header(pkg):
     L = pkg._lib
     assert ctypes.sizeof(L.BalmOpts) == 32 and ctypes.sizeof(L.LmTrace) == 64
-    assert ctypes.sizeof(L.BalmInfo) == 104 and ctypes.sizeof(L.Prof) == 80
+    assert ctypes.sizeof(L.BalmInfo) == 136 and ctypes.sizeof(L.Prof) == 80 and ctypes.sizeof(L.NdModel) == 40
     o = pkg.BalmProblem.default_opts()
     assert (o.max_iter, o.u0, o.v0, o.rel_tol) == (10, 0.01, 2.0, 1e-6)      # bavoxel.hpp:664,686,760
 
@@ -42,7 +42,7 @@ def test_every_struct_has_the_size_the_c_compiler_gives_it(pkg, tmp_path):
              ("lvba_prof_t", L.Prof), ("lvba_visual_opts", L.VisualOpts), ("lvba_visual_trace", L.VisualTrace),
              ("lvba_voxel_opts", L.VoxelOpts), ("lvba_voxmap_info_t", L.VoxmapInfo), ("lvba_window_opts", L.WindowOpts),
              ("lvba_window_info", L.WindowInfo), ("lvba_lidar_ba_opts", L.LidarBaOpts), ("lvba_lidar_ba_report", L.LidarBaReport),
-             ("lvba_fuse_opts", L.FuseOpts)]
+             ("lvba_fuse_opts", L.FuseOpts), ("lvba_nd_model_t", L.NdModel)]
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include "lvba_hip.h"\nint main(void){' +
                    "".join(f'printf("%zu\\n", sizeof({n}));' for n, _ in pairs) + "return 0;}\n")

@@ -56,7 +56,9 @@ def test_hub_graph_dissection_matches_dense_solve_and_oracle(pkg, oracle_mod, ca
 
 
 @pytest.mark.parametrize("world,case", [(4, dict(n_poses=640, n_voxels=24000, band=6, seed=11)),
-                                        (3, dict(n_poses=600, n_voxels=20000, band=6, seed=12, loop_frac=0.0))])
+                                        (3, dict(n_poses=600, n_voxels=20000, band=6, seed=12, loop_frac=0.0)),
+                                        # config C4's shape scaled down (n / bw > 20) on the eight ranks BASELINE.json gives it
+                                        (8, dict(n_poses=1600, n_voxels=48000, band=5, seed=13))])
 def test_long_band_shared_by_ranks(pkg, oracle_mod, world, case, monkeypatch):
     """Chunks of the band ordering as separators: every rank factorises its own arcs, the separator system is summed over the
     ranks and solved, every rank substitutes back into its arcs, the solution is summed.  Ranks bitwise equal; equal to the
@@ -87,6 +89,8 @@ def test_long_band_shared_by_ranks(pkg, oracle_mod, world, case, monkeypatch):
     out = ht.run(rank_main)
     r0 = out[0]
     assert r0["info"]["nd_kind"] == 2 and r0["info"]["nd_arcs"] >= world, r0["info"]
+    if world == 8:
+        assert N / max(1, r0["info"]["nd_sep_band_blocks"]) > 8
     for o in out[1:]:
         assert np.array_equal(o["H"], r0["H"]) and np.array_equal(o["dx"], r0["dx"]) and np.array_equal(o["x"], r0["x"])
         assert o["trace"] == r0["trace"]
