@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblvba_hip.so")
 SOURCES = ["lvba_api.hip", "block_system.hip", "balm_kernels.hip", "ldlt.hip", "visual_api.hip", "visual_kernels.hip",
            "voxelize.hip", "window_ba.hip", "tracks.hip", "pair_lists.hip", "fusion.hip", "bcr.hip"]
-HEADERS = ["balm_math.h", "lvba_internal.h", "lvba_common.h", "block_system.h", "visual_math.h", "mempool.h", "voxel_internal.h", "pair_lists.h", "tracks_device.h", "ordering.h", "host_tables.h", "host_arena.h", "fusion_device.h", "ldlt_lookahead.h", "ldlt_schedule.h", "ldlt_prepare.h", "ldlt_diag.h", "ldlt_tiles.h", "ldlt_back.h", "key_pack.h", os.path.join("..", "..", "include", "lvba_hip.h")]
+HEADERS = ["balm_math.h", "lvba_internal.h", "lvba_common.h", "block_system.h", "visual_math.h", "mempool.h", "voxel_internal.h", "pair_lists.h", "tracks_device.h", "ordering.h", "host_tables.h", "host_arena.h", "fusion_device.h", "ldlt_lookahead.h", "ldlt_schedule.h", "ldlt_prepare.h", "ldlt_diag.h", "ldlt_tiles.h", "ldlt_back.h", "ldlt_nd.h", "nd_plan.h", "key_pack.h", os.path.join("..", "..", "include", "lvba_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-result", "-Wno-unused-value"]
 # Kernels that take DISCRETE decisions on floating-point values (voxel keys, pixel indices, depth / angle / reprojection

@@ -309,7 +309,9 @@ static int32_t nd_alloc(BlockSys &bs, const NdPlan &pl)
             HIPCHK(lvba::copy_h2d(A.sep, pa.sep.data(), (size_t)A.nsep * sizeof(int32_t)));
         }
         HIPCHK(lvba::StreamCache::get().acquire(&A.stream));
+        HIPCHK(lvba::StreamCache::get().acquire(&A.fstream));
         HIPCHK(hipEventCreateWithFlags(&A.done, hipEventDisableTiming));
+        for (hipEvent_t &e : A.ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     TRY(nd_alloc_mat(bs, 6 * (int64_t)nd.Ns, 6 * (int64_t)nd.BbS + 5, nd.AS, &nd.d_AS, &nd.workS, false));
     TRY(dm(&nd.Sblk, (int64_t)nd.Ns * (nd.BbS + 1) * 36 + 6 * (int64_t)nd.Ns + 8));
@@ -664,7 +666,10 @@ void bs_destroy(BlockSys &bs)
         if (p) DevicePool::get().free(p);
     for (NdArc &A : bs.nd.arcs) {
         if (A.stream) lvba::StreamCache::get().release(A.stream);
+        if (A.fstream) lvba::StreamCache::get().release(A.fstream);
         if (A.done) hipEventDestroy(A.done);
+        for (hipEvent_t e : A.ev)
+            if (e) hipEventDestroy(e);
     }
     if (bs.nd.start) hipEventDestroy(bs.nd.start);
     if (bs.nd.mid) hipEventDestroy(bs.nd.mid);

@@ -85,7 +85,7 @@ int64_t ldlt_twist_panels(int64_t n, int64_t ld, int64_t bw)
 // single-GPU one but moves one window per launch instead of two; what is replicated is the S phase only.
 int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_poses, const double *g,
                    const double *u_dev, double *x, double *work, int *status, hipStream_t s, const LdltDist *dist, const int32_t *grp,
-                   int phase)
+                   int phase, const LdltHook *hook)
 {
     const int64_t n = A.n, bw = A.bw;
     const int64_t P1 = twist_panels_of(A);
@@ -226,6 +226,7 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
                 if (big) hipLaunchKernelGGL(ldlt_step2_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, a);
                 else hipLaunchKernelGGL(ldlt_step2_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, a);
             }
+            if (hook && L.roles && ny == 1) hook->panel_enqueued(hook->ctx, L.p);
         }
     };
     int64_t st0 = 0;
@@ -242,6 +243,9 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
         st0 = P1;
     }
     run_phase(st0, nsteps, 1, false, false);
+    if (hook && P1 == 0) // the panels without rows below them (the last one) have no launch of their own: complete by now
+        for (int64_t p = 0; p < nsteps; ++p)
+            if (geom(p).T == 0) hook->panel_enqueued(hook->ctx, p);
     }
     if (phase == LDLT_FACTOR) return LVBA_OK;
     // backward: the whole substitution as chained launches (ldlt_back.h).  At most 256 panels per launch: one workgroup per CU is

@@ -256,35 +256,53 @@ int32_t nd_solve(NdSys &nd, const double *Hblk, int32_t N, const double *g, cons
     const int P = (int)nd.arcs.size();
     const int64_t Bb1 = N; // the Hessian store of a dissected system is the full lower block triangle
     hipEventRecord(nd.start, s);
-    // ---- the arcs, each on its own stream
+    // ---- the arcs, each on its own pair of streams: the factorisation's launches, and -- a panel behind them -- the forward
+    // substitution of the border's columns (a factorisation launch is a few dozen workgroups on a serial chain, a forward
+    // launch a few hundred: they share the chip)
+    struct FwdCtx { NdArc *A; const double *Gall, *dvec; int n_ev; };
+    std::vector<FwdCtx> fctx((size_t)P);
     for (int a = 0; a < P; ++a) {
         NdArc &A = nd.arcs[(size_t)a];
         if (A.owner != rank) continue;
-        hipStream_t as = A.stream;
+        hipStream_t as = A.stream, fs = A.fstream;
         hipStreamWaitEvent(as, nd.start, 0);
-        const int32_t rc = ldlt_solve(A.A, Hblk + (int64_t)A.p0 * Bb1 * 36, (int)(Bb1 - 1), A.Na, g + 6 * (int64_t)A.p0, u_dev,
-                                      x + 6 * (int64_t)A.p0, A.work, A.status, as, nullptr, nullptr, LDLT_FACTOR);
-        if (rc != LVBA_OK) return rc;
+        hipStreamWaitEvent(fs, nd.start, 0);
+        FwdCtx &fc = fctx[(size_t)a];
+        fc = FwdCtx{&A, ldlt_work_G(A.work), ldlt_work_d(A.n, A.work), 0};
+        LdltHook hook{nullptr, &fc};
         if (A.nsep > 0) {
             const int64_t cnt = (int64_t)A.Na * A.nsep * 36;
-            hipLaunchKernelGGL(nd_border_fill_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, as, Hblk, (int64_t)N, A.p0, A.Na,
+            hipLaunchKernelGGL(nd_border_fill_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, fs, Hblk, (int64_t)N, A.p0, A.Na,
                                nd.ps, A.sep, A.nsep, A.B, A.ldb);
-            const double *Gall = ldlt_work_G(A.work), *dvec = ldlt_work_d(A.n, A.work);
-            const unsigned nct = (unsigned)(A.ldb / 64);
-            for (int64_t k = 0; k < A.n; k += LVBA_NB) {
+            hook.panel_enqueued = [](void *ctx, int64_t p) {
+                FwdCtx &f = *static_cast<FwdCtx *>(ctx);
+                NdArc &A = *f.A;
+                hipEvent_t ev = A.ev[f.n_ev++ & 7];
+                hipEventRecord(ev, A.stream);
+                hipStreamWaitEvent(A.fstream, ev, 0);
+                const int64_t k = p * LVBA_NB;
                 const int nbe = (int)((A.n - k) < LVBA_NB ? (A.n - k) : LVBA_NB);
                 const int64_t w0 = k + nbe, rend = std::min<int64_t>(A.n, k + nbe + A.A.bw);
                 const int64_t T = w0 < rend ? (rend - w0 + 63) / 64 : 0;
-                hipLaunchKernelGGL(nd_fwd_kernel, dim3((unsigned)(T + 1), nct), dim3(256), 0, as, A.A, Gall + (k / LVBA_NB) * 4096, dvec,
-                                   A.B, A.Y, A.ldb, k, nbe, w0, rend);
-            }
-            const unsigned np = (unsigned)((A.n + LVBA_NB - 1) / LVBA_NB);
-            hipLaunchKernelGGL(nd_w_kernel, dim3(np), dim3(256), 0, as, Gall, (const double *)ldlt_work_b(A.n, A.work), A.n, A.wv);
-            hipLaunchKernelGGL(nd_gs_kernel, dim3(nct, ND_GS_SLICES), dim3(256), 0, as, (const double *)A.Y, (const double *)A.wv, A.n,
-                               A.ldb, A.gpart);
-            hipLaunchKernelGGL(nd_schur_kernel, dim3(nct * (nct + 1) / 2), dim3(256), 0, as, (const double *)A.Y, dvec, A.n, A.ldb, A.Sa);
+                hipLaunchKernelGGL(nd_fwd_kernel, dim3((unsigned)(T + 1), (unsigned)(A.ldb / 64)), dim3(256), 0, A.fstream, A.A,
+                                   f.Gall + p * 4096, f.dvec, A.B, A.Y, A.ldb, k, nbe, w0, rend);
+            };
         }
+        const int32_t rc = ldlt_solve(A.A, Hblk + (int64_t)A.p0 * Bb1 * 36, (int)(Bb1 - 1), A.Na, g + 6 * (int64_t)A.p0, u_dev,
+                                      x + 6 * (int64_t)A.p0, A.work, A.status, as, nullptr, nullptr, LDLT_FACTOR,
+                                      A.nsep > 0 ? &hook : nullptr);
+        if (rc != LVBA_OK) return rc;
         hipEventRecord(A.done, as);
+        hipStreamWaitEvent(fs, A.done, 0); // (b is final: the factorisation has finished)
+        if (A.nsep > 0) {
+            const unsigned nct = (unsigned)(A.ldb / 64);
+            const unsigned np = (unsigned)((A.n + LVBA_NB - 1) / LVBA_NB);
+            hipLaunchKernelGGL(nd_w_kernel, dim3(np), dim3(256), 0, fs, fc.Gall, (const double *)ldlt_work_b(A.n, A.work), A.n, A.wv);
+            hipLaunchKernelGGL(nd_gs_kernel, dim3(nct, ND_GS_SLICES), dim3(256), 0, fs, (const double *)A.Y, (const double *)A.wv, A.n,
+                               A.ldb, A.gpart);
+            hipLaunchKernelGGL(nd_schur_kernel, dim3(nct * (nct + 1) / 2), dim3(256), 0, fs, (const double *)A.Y, fc.dvec, A.n, A.ldb, A.Sa);
+        }
+        hipEventRecord(A.done, fs);
     }
     // ---- the separator system: S + u diag(S) from the store, minus the arcs' Schur complements in arc order
     const int64_t sep_doubles = (int64_t)nd.Ns * (nd.BbS + 1) * 36;

@@ -36,24 +36,31 @@ struct NdPlan {
     double t_band = 0.0, t_nd = 0.0; // the model's estimates, seconds per solve
 };
 
-// ---- the cost model: seconds per solve (measured constants of round 4 / 5: a chain-bound look-ahead launch is ~27 us, the
-// trailing updates sustain ~25 TFLOP/s of fp64 MFMA, a forward-substitution launch of ldlt_nd.h ~12 us)
+// ---- the cost model: seconds per solve (measured constants of rounds 4 / 5: a chain-bound look-ahead launch is ~27 us with one
+// problem in it and ~32 with the two ends of a band, wide bands sustain ~36 TFLOP/s of fp64 MFMA (n bw^2 flops: 9.3 ms at
+// n = 12 000, bw = 5 243; 88 ms at n = 60 000, bw = 7 229), a forward-substitution launch of ldlt_nd.h ~12 us)
 inline double nd_fact_seconds(double n, double bw, bool may_twist)
 {
-    const double t_launch = 27e-6, rate = 25e12;
+    const double t_launch = may_twist ? 32e-6 : 27e-6, rate = 36e12; // (two problems per launch: 32 - 36 us; one: 23 - 27 us)
     if (bw + 128.0 >= 0.6 * n) return std::max(n * n * n / 3.0 / rate, n / 64.0 * t_launch); // dense
     double chain = n / 64.0;
     const double P = std::floor((n - bw) / 128.0);
     if (may_twist && P >= 4) chain = P + (n - 128.0 * P) / 64.0;
     return std::max(n * bw * bw / rate, chain * t_launch);
 }
-inline double nd_arc_seconds(double n, double bw, double s, double *flops_out)
+// one arc alone on the device: the factorisation's chain with the border's forward substitution beside it (a panel behind, on a
+// stream of its own), then Y^T D^-1 Y.  work_out: the same as pure throughput -- what several arcs of one rank, side by side, add up to.
+// (measured, round 5, n = 10 326, bw = 617, s = 1 674: 162 forward launches of 19 us = 16 TFLOP/s with Y recomputed per tile;
+// Y^T D^-1 Y 1.5 ms = 19 TFLOP/s)
+inline double nd_arc_seconds(double n, double bw, double s, double *work_out)
 {
-    const double t_launch = 27e-6, t_fwd = 12e-6, rate = 25e12;
+    const double t_launch = 27e-6, t_fwd = 12e-6, rate = 36e12, rate_fwd = 16e12, rate_schur = 19e12;
     const double w = std::min(bw, n);
-    const double flops = n * w * w + 4.0 * n * w * s + n * s * s; // factorisation, forward substitution (Y recomputed per tile), Y^T D^-1 Y
-    *flops_out = flops;
-    return std::max(flops / rate, n / 64.0 * (t_launch + (s > 0 ? t_fwd : 0.0)));
+    const double f_fact = n * w * w / rate, f_fwd = 4.0 * n * w * s / rate_fwd, f_schur = n * s * s / rate_schur;
+    *work_out = f_fact + f_fwd + f_schur;
+    const double t_fact = std::max(f_fact, n / 64.0 * t_launch);
+    const double t_f = s > 0 ? std::max(f_fwd, n / 64.0 * t_fwd) : 0.0;
+    return std::max(t_fact, t_f) + f_schur;
 }
 
 namespace nd_detail {
@@ -170,7 +177,7 @@ inline bool nd_build_candidate(const uint8_t *adj, int N, const lvba::hvec<lvba:
         for (int r = 1; r < (int)load.size(); ++r)
             if (load[(size_t)r] < load[(size_t)best]) best = r;
         arc.owner = best;
-        load[(size_t)best] += fl / 25e12;
+        load[(size_t)best] += fl;
         chain[(size_t)best] = std::max(chain[(size_t)best], t);
         out.arcs.push_back(arc);
     }
@@ -199,6 +206,38 @@ inline NdPlan nd_plan(const uint8_t *adj, int N, const lvba::hvec<int32_t> &perm
         if (!nd_build_candidate(adj, N, nb, in_sep, n_ranks, kind, cand)) return;
         cand.t_band = best.t_band;
         if (cand.t_nd < t_best) { t_best = cand.t_nd; best = cand; }
+        // Long arcs are serial chains of their own (an arc is factorised top-down: its factor is reused by the border's forward
+        // substitution): cut them further with chunks of THEIR band ordering -- the pieces are independent, run side by side on
+        // their streams, and the chunks join the separator.  Repeated while the model gains (a folded ring falls into its two
+        // sides at the first cut, each with half the bandwidth: the next cut's chunks are half as wide).
+        NdPlan base = cand;
+        for (int round = 0; round < 4; ++round) {
+            NdPlan round_best;
+            double t_round = base.t_nd;
+            for (int pieces : {2, 3, 5}) {
+                lvba::hvec<uint8_t> s2((size_t)N, 0);
+                for (int q = base.ps; q < N; ++q) s2[(size_t)base.perm[(size_t)q]] = 1;
+                bool any = false;
+                for (const NdPlanArc &a : base.arcs) {
+                    const int w = std::max(1, (int)a.Bb);
+                    const double piece = ((double)a.Na - (double)(pieces - 1) * w) / pieces;
+                    if (piece < 3.0 * w || piece < 22.0) continue;
+                    for (int c = 0; c < pieces - 1; ++c) {
+                        const int a0 = a.p0 + (int)((c + 1) * piece + c * w + 0.5);
+                        for (int q = a0; q < a0 + w && q < a.p0 + a.Na; ++q) s2[(size_t)base.perm[(size_t)q]] = 1;
+                    }
+                    any = true;
+                }
+                if (!any) break;
+                NdPlan c2;
+                if (!nd_build_candidate(adj, N, nb, s2, n_ranks, kind, c2)) continue;
+                c2.t_band = best.t_band;
+                if (c2.t_nd < t_round) { t_round = c2.t_nd; round_best = c2; }
+            }
+            if (!round_best.active) break;
+            base = round_best;
+            if (base.t_nd < t_best) { t_best = base.t_nd; best = base; }
+        }
     };
     // ---- hubs
     {

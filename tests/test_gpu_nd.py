@@ -99,7 +99,13 @@ def test_long_band_shared_by_ranks(pkg, oracle_mod, world, case, monkeypatch):
     assert np.abs(r0["dx"] - want).max() <= 1e-8 * np.abs(want).max()
     assert np.abs(r0["dx"] - dx1).max() <= 1e-8 * np.abs(want).max()
     assert r0["rc"] == rc1 == 0 and len(r0["trace"]) == len(tr1)
-    assert np.abs(r0["x"] - x1).max() <= 1e-7
+    # (rounding differences of the first evaluation -- eight shards' partial sums -- grow from iteration to iteration of an LM run)
+    # and the undamped gauge directions of 1 600 poses carry them into the poses: north_star's 1e-5 there, the LM costs at 1e-7)
+    tol = 1e-7 if world < 8 else 1e-5
+    assert np.abs(r0["x"] - x1).max() <= tol, np.abs(r0["x"] - x1).max()
+    for a, b in zip(r0["trace"], tr1):
+        assert a["accepted"] == b["accepted"]
+        assert abs(a["residual1"] - b["residual1"]) <= 1e-7 * b["residual1"] and abs(a["residual2"] - b["residual2"]) <= 1e-7 * b["residual2"]
     co = oracle_mod.COracle(N, off, idx, clu)
     xr, tr, _ = co.damping_iter(d["poses_init"])
-    assert np.abs(r0["x"] - xr).max() <= 1e-7
+    assert np.abs(r0["x"] - xr).max() <= tol, np.abs(r0["x"] - xr).max()
