@@ -309,9 +309,7 @@ static int32_t nd_alloc(BlockSys &bs, const NdPlan &pl)
             HIPCHK(lvba::copy_h2d(A.sep, pa.sep.data(), (size_t)A.nsep * sizeof(int32_t)));
         }
         HIPCHK(lvba::StreamCache::get().acquire(&A.stream));
-        HIPCHK(lvba::StreamCache::get().acquire(&A.fstream));
         HIPCHK(hipEventCreateWithFlags(&A.done, hipEventDisableTiming));
-        for (hipEvent_t &e : A.ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     TRY(nd_alloc_mat(bs, 6 * (int64_t)nd.Ns, 6 * (int64_t)nd.BbS + 5, nd.AS, &nd.d_AS, &nd.workS, false));
     TRY(dm(&nd.Sblk, (int64_t)nd.Ns * (nd.BbS + 1) * 36 + 6 * (int64_t)nd.Ns + 8));
@@ -613,7 +611,9 @@ static int32_t enqueue_solve_launches(BlockSys &bs)
     // no capture while several host threads drive the device (bs_graph_inhibit): with HIP 7.0 a capture in one thread is
     // invalidated by allocations / synchronous copies in another even in hipStreamCaptureModeThreadLocal
     if (bs.distributed() && bs.n_ranks >= 2) bs.graph_tried = true; // the solve has exchanges between the ranks in it
-    if (bs.nd.active) bs.graph_tried = true; // (a dissected solve forks onto one stream per arc: launched eagerly)
+    // a dissected solve forks onto one stream per arc: not captured -- the graph executor ran the arcs' branches one after the
+    // other (timeline, round 5: 9.6 ms as a graph against 8.3 ms eager for two arcs)
+    if (bs.nd.active) bs.graph_tried = true;
     if (!bs.graph_tried && g_graph_inhibit.load() == 0 && ++bs.solve_calls >= 3) {
         bs.graph_tried = true;
         if (!getenv("LVBA_NO_GRAPH")) {
@@ -666,10 +666,7 @@ void bs_destroy(BlockSys &bs)
         if (p) DevicePool::get().free(p);
     for (NdArc &A : bs.nd.arcs) {
         if (A.stream) lvba::StreamCache::get().release(A.stream);
-        if (A.fstream) lvba::StreamCache::get().release(A.fstream);
         if (A.done) hipEventDestroy(A.done);
-        for (hipEvent_t e : A.ev)
-            if (e) hipEventDestroy(e);
     }
     if (bs.nd.start) hipEventDestroy(bs.nd.start);
     if (bs.nd.mid) hipEventDestroy(bs.nd.mid);

@@ -27,6 +27,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <thread>
 #include "lvba_internal.h"
 #include "ldlt_schedule.h"
 #include "../../include/lvba_hip.h" // status codes
@@ -85,7 +86,7 @@ int64_t ldlt_twist_panels(int64_t n, int64_t ld, int64_t bw)
 // single-GPU one but moves one window per launch instead of two; what is replicated is the S phase only.
 int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_poses, const double *g,
                    const double *u_dev, double *x, double *work, int *status, hipStream_t s, const LdltDist *dist, const int32_t *grp,
-                   int phase, const LdltHook *hook)
+                   int phase, const LdltBorder *border)
 {
     const int64_t n = A.n, bw = A.bw;
     const int64_t P1 = twist_panels_of(A);
@@ -164,6 +165,12 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
     const bool big = big_env && ((uint64_t)A.ld * (uint64_t)(n + 128) + (uint64_t)n + 256) * 8 < 0xFFFF0000ull;
     // Panels [sa, sb) of one problem (or of both, ny = 2).  Consecutive panels are PAIRED (e, o = e + 1): e leaves the bulk of its
     // trailing update to its partner's launches, where every C tile is read and written once for both (rank 128).
+    // the border's forward substitution (LdltBorder): panel p rides in the launch AFTER the one that made its column block L
+    int64_t fwd_next = 0;
+    auto passenger = [&](int64_t p) {
+        const Geo g = geom(p);
+        return FwdPassenger{1, g.nbe, g.k, g.w0, g.rend, g.T, border->ldb, Gall + p * 4096, border->B, border->Y};
+    };
     auto run_phase = [&](int64_t sa, int64_t sb, unsigned ny, bool second, bool close) {
         const int64_t wo = second ? tw.sW : 0;
         std::vector<SchedLaunch> sched;
@@ -215,6 +222,10 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
                 nwg += J.nwg;
                 ++a.njobs;
             }
+            if (border && L.roles && ny == 1 && fwd_next < L.p) {
+                a.fwd = passenger(fwd_next++);
+                nwg += (a.fwd.T + 1) * (border->ldb / 64);
+            }
             int64_t grid = nwg * ny;
             if (L.roles && grid > n_cus) {
                 // the seats next to the chain workgroups and next to row 1 (one product more than the other rows) stay empty
@@ -226,7 +237,6 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
                 if (big) hipLaunchKernelGGL(ldlt_step2_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, a);
                 else hipLaunchKernelGGL(ldlt_step2_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, a);
             }
-            if (hook && L.roles && ny == 1) hook->panel_enqueued(hook->ctx, L.p);
         }
     };
     int64_t st0 = 0;
@@ -243,9 +253,11 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
         st0 = P1;
     }
     run_phase(st0, nsteps, 1, false, false);
-    if (hook && P1 == 0) // the panels without rows below them (the last one) have no launch of their own: complete by now
-        for (int64_t p = 0; p < nsteps; ++p)
-            if (geom(p).T == 0) hook->panel_enqueued(hook->ctx, p);
+    if (border) // the panels no step launch was left to carry
+        for (; fwd_next < nsteps; ++fwd_next) {
+            const FwdPassenger f = passenger(fwd_next);
+            hipLaunchKernelGGL(ldlt_fwd_kernel, dim3((unsigned)((f.T + 1) * (border->ldb / 64))), dim3(256), 0, s, M, f, (const double *)dvec);
+        }
     }
     if (phase == LDLT_FACTOR) return LVBA_OK;
     // backward: the whole substitution as chained launches (ldlt_back.h).  At most 256 panels per launch: one workgroup per CU is

@@ -36,6 +36,18 @@ struct BulkJob {
     int pair;
     int64_t ca, cb, nwg;
 };
+// A passenger of the launch: the forward substitution of a block of extra right-hand sides (the border columns of a dissected
+// system, ldlt_nd.h) for the panel BEFORE the one the roles work on -- its column block is L since the launch before, and its
+// rows of B were completed by that launch's passengers.  B, Y: [n][ldb] row-major.  (T + 1) x ldb / 64 workgroups:
+//   tile row 0      Y[k .. k + 64) = D G^T B[k .. k + 64)
+//   tile row t >= 1 B[tile t of the window] -= L(tile t, panel) Y_panel   (Y_panel recomputed: nothing exchanged inside a launch)
+struct FwdPassenger {
+    int on;
+    int nbe;
+    int64_t k, w0, rend, T, ldb;
+    const double *G; // the panel's G
+    double *B, *Y;
+};
 struct Step2Args {
     LdltMat M;
     int64_t sA, sW, ldz;
@@ -66,6 +78,7 @@ struct Step2Args {
     // 79 900 -> 59 600 cycles (what it takes alone), the launch 37.9 -> 29.6 us.  Placement is a matter of speed only: wherever
     // the blocks land, every tile is still done exactly once.  resv_n = 0: off.
     int resv_at, resv_n;
+    FwdPassenger fwd;
 };
 
 // Scratch doubles in the PAD of the first [m][row] tile (LVBA_TS = 80 doubles per column of 64 rows: 16 spare behind each of the
@@ -451,6 +464,71 @@ __device__ __forceinline__ void qx_diag_role(double *lds, const LdltMat &M, cons
         }
 }
 
+// ---------------------------------------------------------------------------------------------- the forward-substitution passenger
+__device__ __forceinline__ void fwd_passenger(double *lds, const LdltMat &M, const FwdPassenger &F, const double *__restrict__ dvec,
+                                              int64_t idx)
+{
+    double *Ls = lds, *Zs = lds + 64 * LVBA_TS;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, row = tid & 63, i = lane & 15, kk = lane >> 4;
+    const int64_t ti = idx % (F.T + 1), j0 = 64 * (idx / (F.T + 1));
+    if (j0 >= F.ldb) return;
+    const int64_t k = F.k, ldb = F.ldb;
+    const int nbe = F.nbe;
+    double *__restrict__ B = F.B;
+    double bp[16], gp[16], lv[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int m = w + 4 * it;
+        bp[it] = m < nbe ? B[(k + m) * ldb + j0 + row] : 0.0; // [m][jj]: thread (jj = row, m)
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) gp[it] = F.G[tid + 256 * it]; // G[m][c]: thread (c = row, m = w + 4 it)
+    const int64_t r0 = F.w0 + 64 * (ti - 1);
+    if (ti > 0) load_panel_tile(M, r0, k, F.rend, nbe, w, row, lv); // L(tile, panel) as [m = c][x = r]
+    const double dk = tid < nbe ? dvec[k + tid] : 0.0;
+    stage_tile(Ls, bp, w, row);
+    stage_tile(Zs, gp, w, row);
+    if (tid < 64) pad_at(lds, LVBA_PAD_DP + tid) = dk;
+    __syncthreads();
+    d4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+    tile_product(Ls, Zs, w, i, kk, acc); // acc[t][reg] <-> (jj = 16 t + i, c = 16 w + kk + 4 reg): (G^T B)[c][jj]
+    if (ti == 0) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int c = 16 * w + kk + 4 * reg;
+            const double dc = pad_at(lds, LVBA_PAD_DP + c);
+            if (c < nbe)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) F.Y[(k + c) * ldb + j0 + 16 * t + i] = acc[t][reg] * dc;
+        }
+        return;
+    }
+    __syncthreads();
+    put_acc(Ls, acc, w, i, kk, lds); // Ls[c][jj] = d_c (G^T B)[c][jj] = Y_panel
+    stage_tile(Zs, lv, w, row);      // Zs[c][r]
+    __syncthreads();
+    d4 acc2[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc2[t] = (d4){0.0, 0.0, 0.0, 0.0};
+    tile_product(Ls, Zs, w, i, kk, acc2); // (jj = 16 t + i, r = 16 w + kk + 4 reg): sum_c L[r][c] Y[c][jj]
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int64_t r = r0 + 16 * w + kk + 4 * reg;
+        if (r < F.rend)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) B[r * ldb + j0 + 16 * t + i] -= acc2[t][reg];
+    }
+}
+
+// the same on its own: the panels no step launch is left to carry (the last ones of a factorisation)
+__global__ __launch_bounds__(256, 2) void ldlt_fwd_kernel(LdltMat M, FwdPassenger F, const double *__restrict__ dvec)
+{
+    __shared__ double lds[LVBA_K3_LDS];
+    fwd_passenger(lds, M, F, dvec, blockIdx.x);
+}
+
 // ---------------------------------------------------------------------------------------------- one launch
 // Block order: the chain workgroups of all problems first, then the row workgroups, then the bulk jobs' workgroups alternating
 // between the problems.  big: 128 x 64 bulk tiles (bulk_tile_128, 32-bit buffer offsets) / 64 x 64 tiles (update_tile[2], 64-bit
@@ -503,4 +581,5 @@ __global__ __launch_bounds__(256, 2) void ldlt_step2_kernel(const Step2Args A)
         }
         return;
     }
+    if (A.fwd.on && prob == 0) fwd_passenger(lds, M, A.fwd, A.dvec, bx); // (bx: what the jobs left of the block index)
 }

@@ -14,7 +14,8 @@
 //
 //   per arc a (its own stream; on several ranks: its owner)
 //        A_a = L D L^T, c = L^-1 b_a          ldlt_solve(..., LDLT_FACTOR): the look-ahead band factorisation, unchanged
-//        Y   = L^-1 E_a^T                     nd_fwd_kernel: one launch per panel, fp64 MFMA (the s_a columns are right-hand sides)
+//        Y   = L^-1 E_a^T                     riding in the factorisation's launches one panel behind (ldlt_lookahead.h: FwdPassenger),
+//                                             fp64 MFMA: the s_a border columns are right-hand sides
 //        S_a = Y^T D^-1 Y,  g_a = Y^T D^-1 c  nd_schur_kernel / nd_gs_kernel
 //   separator   S' = S + u diag(S) - sum_a S_a,  g' = g_S + sum_a g_a  (summed in arc order: deterministic; all-reduced over
 //               the ranks), solved by ldlt_solve again (band or dense, both ends at once, two ranks) -> x_S
@@ -40,65 +41,6 @@ __global__ void nd_border_fill_kernel(const double *__restrict__ Hblk, int64_t N
     const int c = el / 6, r = el - 6 * c;
     const int64_t J = p0 + jj, I = (int64_t)ps + sep[q];
     B[(6 * (int64_t)jj + c) * ldb + 6 * q + r] = Hblk[(J * N + (I - J)) * 36 + el];
-}
-
-// One panel of the forward substitution with the ldb columns of B as right-hand sides (grid: (T + 1) x ldb / 64):
-//   block row 0      Y[k .. k + 64) = D G^T B[k .. k + 64)                 (the panel's rows are final: earlier launches updated them)
-//   block row t >= 1 B[tile t of the window] -= L(tile t, panel) Y_panel   (Y_panel recomputed: nothing exchanged inside a launch)
-__global__ __launch_bounds__(256, 2) void nd_fwd_kernel(LdltMat M, const double *__restrict__ G, const double *__restrict__ dvec,
-                                                        double *__restrict__ B, double *__restrict__ Y, int64_t ldb, int64_t k,
-                                                        int nbe, int64_t w0, int64_t rend)
-{
-    __shared__ double lds[LVBA_K3_LDS];
-    double *Ls = lds, *Zs = lds + 64 * LVBA_TS;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, row = tid & 63, i = lane & 15, kk = lane >> 4;
-    const int64_t j0 = 64 * (int64_t)blockIdx.y;
-    const int ti = (int)blockIdx.x;
-    double bp[16], gp[16], lv[16];
-#pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        const int m = w + 4 * it;
-        bp[it] = m < nbe ? B[(k + m) * ldb + j0 + row] : 0.0; // [m][jj]: thread (jj = row, m)
-    }
-#pragma unroll
-    for (int it = 0; it < 16; ++it) gp[it] = G[tid + 256 * it]; // G[m][c]: thread (c = row, m = w + 4 it)
-    const int64_t r0 = w0 + 64 * (int64_t)(ti - 1);
-    if (ti > 0) load_panel_tile(M, r0, k, rend, nbe, w, row, lv); // L(tile, panel) as [m = c][x = r]
-    const double dk = tid < nbe ? dvec[k + tid] : 0.0;
-    stage_tile(Ls, bp, w, row);
-    stage_tile(Zs, gp, w, row);
-    if (tid < 64) pad_at(lds, LVBA_PAD_DP + tid) = dk;
-    __syncthreads();
-    d4 acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
-    tile_product(Ls, Zs, w, i, kk, acc); // acc[t][reg] <-> (jj = 16 t + i, c = 16 w + kk + 4 reg): (G^T B)[c][jj]
-    if (ti == 0) {
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int c = 16 * w + kk + 4 * reg;
-            const double dc = pad_at(lds, LVBA_PAD_DP + c);
-            if (c < nbe)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) Y[(k + c) * ldb + j0 + 16 * t + i] = acc[t][reg] * dc;
-        }
-        return;
-    }
-    __syncthreads();
-    put_acc(Ls, acc, w, i, kk, lds); // Ls[c][jj] = d_c (G^T B)[c][jj] = Y_panel
-    stage_tile(Zs, lv, w, row);      // Zs[c][r]
-    __syncthreads();
-    d4 acc2[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc2[t] = (d4){0.0, 0.0, 0.0, 0.0};
-    tile_product(Ls, Zs, w, i, kk, acc2); // (jj = 16 t + i, r = 16 w + kk + 4 reg): sum_c L[r][c] Y[c][jj]
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-        const int64_t r = r0 + 16 * w + kk + 4 * reg;
-        if (r < rend)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) B[r * ldb + j0 + 16 * t + i] -= acc2[t][reg];
-    }
 }
 
 // wv[k + c] = sum_m G_p[m][c] b[k + m]  (one workgroup per panel): D^-1 L^-1 b, what the separator's right-hand side needs
@@ -256,53 +198,34 @@ int32_t nd_solve(NdSys &nd, const double *Hblk, int32_t N, const double *g, cons
     const int P = (int)nd.arcs.size();
     const int64_t Bb1 = N; // the Hessian store of a dissected system is the full lower block triangle
     hipEventRecord(nd.start, s);
-    // ---- the arcs, each on its own pair of streams: the factorisation's launches, and -- a panel behind them -- the forward
-    // substitution of the border's columns (a factorisation launch is a few dozen workgroups on a serial chain, a forward
-    // launch a few hundred: they share the chip)
-    struct FwdCtx { NdArc *A; const double *Gall, *dvec; int n_ev; };
-    std::vector<FwdCtx> fctx((size_t)P);
+    // ---- the arcs, each on a stream of its own: the factorisation, with the forward substitution of the border's columns riding in
+    // its launches one panel behind (ldlt_lookahead.h: FwdPassenger -- a step launch is a few dozen workgroups on a serial chain, the
+    // passengers a few hundred: they share the chip, and the host issues ONE launch per panel), then Y^T D^-1 Y
     for (int a = 0; a < P; ++a) {
         NdArc &A = nd.arcs[(size_t)a];
         if (A.owner != rank) continue;
-        hipStream_t as = A.stream, fs = A.fstream;
+        hipStream_t as = A.stream;
         hipStreamWaitEvent(as, nd.start, 0);
-        hipStreamWaitEvent(fs, nd.start, 0);
-        FwdCtx &fc = fctx[(size_t)a];
-        fc = FwdCtx{&A, ldlt_work_G(A.work), ldlt_work_d(A.n, A.work), 0};
-        LdltHook hook{nullptr, &fc};
+        LdltBorder border{A.B, A.Y, A.ldb};
         if (A.nsep > 0) {
             const int64_t cnt = (int64_t)A.Na * A.nsep * 36;
-            hipLaunchKernelGGL(nd_border_fill_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, fs, Hblk, (int64_t)N, A.p0, A.Na,
+            hipLaunchKernelGGL(nd_border_fill_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, as, Hblk, (int64_t)N, A.p0, A.Na,
                                nd.ps, A.sep, A.nsep, A.B, A.ldb);
-            hook.panel_enqueued = [](void *ctx, int64_t p) {
-                FwdCtx &f = *static_cast<FwdCtx *>(ctx);
-                NdArc &A = *f.A;
-                hipEvent_t ev = A.ev[f.n_ev++ & 7];
-                hipEventRecord(ev, A.stream);
-                hipStreamWaitEvent(A.fstream, ev, 0);
-                const int64_t k = p * LVBA_NB;
-                const int nbe = (int)((A.n - k) < LVBA_NB ? (A.n - k) : LVBA_NB);
-                const int64_t w0 = k + nbe, rend = std::min<int64_t>(A.n, k + nbe + A.A.bw);
-                const int64_t T = w0 < rend ? (rend - w0 + 63) / 64 : 0;
-                hipLaunchKernelGGL(nd_fwd_kernel, dim3((unsigned)(T + 1), (unsigned)(A.ldb / 64)), dim3(256), 0, A.fstream, A.A,
-                                   f.Gall + p * 4096, f.dvec, A.B, A.Y, A.ldb, k, nbe, w0, rend);
-            };
         }
         const int32_t rc = ldlt_solve(A.A, Hblk + (int64_t)A.p0 * Bb1 * 36, (int)(Bb1 - 1), A.Na, g + 6 * (int64_t)A.p0, u_dev,
                                       x + 6 * (int64_t)A.p0, A.work, A.status, as, nullptr, nullptr, LDLT_FACTOR,
-                                      A.nsep > 0 ? &hook : nullptr);
+                                      A.nsep > 0 ? &border : nullptr);
         if (rc != LVBA_OK) return rc;
-        hipEventRecord(A.done, as);
-        hipStreamWaitEvent(fs, A.done, 0); // (b is final: the factorisation has finished)
         if (A.nsep > 0) {
+            const double *Gall = ldlt_work_G(A.work), *dvec = ldlt_work_d(A.n, A.work);
             const unsigned nct = (unsigned)(A.ldb / 64);
             const unsigned np = (unsigned)((A.n + LVBA_NB - 1) / LVBA_NB);
-            hipLaunchKernelGGL(nd_w_kernel, dim3(np), dim3(256), 0, fs, fc.Gall, (const double *)ldlt_work_b(A.n, A.work), A.n, A.wv);
-            hipLaunchKernelGGL(nd_gs_kernel, dim3(nct, ND_GS_SLICES), dim3(256), 0, fs, (const double *)A.Y, (const double *)A.wv, A.n,
+            hipLaunchKernelGGL(nd_w_kernel, dim3(np), dim3(256), 0, as, Gall, (const double *)ldlt_work_b(A.n, A.work), A.n, A.wv);
+            hipLaunchKernelGGL(nd_gs_kernel, dim3(nct, ND_GS_SLICES), dim3(256), 0, as, (const double *)A.Y, (const double *)A.wv, A.n,
                                A.ldb, A.gpart);
-            hipLaunchKernelGGL(nd_schur_kernel, dim3(nct * (nct + 1) / 2), dim3(256), 0, fs, (const double *)A.Y, fc.dvec, A.n, A.ldb, A.Sa);
+            hipLaunchKernelGGL(nd_schur_kernel, dim3(nct * (nct + 1) / 2), dim3(256), 0, as, (const double *)A.Y, dvec, A.n, A.ldb, A.Sa);
         }
-        hipEventRecord(A.done, fs);
+        hipEventRecord(A.done, as);
     }
     // ---- the separator system: S + u diag(S) from the store, minus the arcs' Schur complements in arc order
     const int64_t sep_doubles = (int64_t)nd.Ns * (nd.BbS + 1) * 36;

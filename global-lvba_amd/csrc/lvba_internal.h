@@ -119,9 +119,8 @@ struct NdArc {
     double *gpart;      // [ND_GS_SLICES][ldb] partial sums of Y^T wv
     int32_t *sep;       // [nsep] separator-local pose indices, ascending (device)
     int *status;
-    hipStream_t stream;  // the factorisation's launches
-    hipStream_t fstream; // the border's forward substitution, a panel behind them
-    hipEvent_t done, ev[8];
+    hipStream_t stream;
+    hipEvent_t done;
 };
 struct NdSys {
     bool active = false;
@@ -201,11 +200,12 @@ enum { LDLT_ALL = 0, LDLT_FACTOR = 1, LDLT_BACKWARD = 2 }; // ldlt_solve's `phas
 // can be captured into a hipGraph.
 // dist (may be NULL): a multi-rank job -- the two ends of the twisted factorisation are eliminated by rank 0 and rank 1 (the
 // callbacks all-reduce device buffers in place over the ranks; they return 0 on success).
-// called (host side) right after the launch that completes panel p of a plain top-down factorisation has been enqueued: column
-// block p holds L, G_p and d_p are final once that launch has run (ldlt_nd.h hangs the border's forward substitution on it)
-struct LdltHook {
-    void (*panel_enqueued)(void *ctx, int64_t p);
-    void *ctx;
+// Extra right-hand sides carried through a plain top-down factorisation (the border columns of a dissected system, ldlt_nd.h):
+// B [n][ldb] row-major is forward-substituted in place (its rows end as the earlier panels' updates left them: L11^-1 not applied,
+// like ldlt_solve's own b), Y [n][ldb] receives L^-1 B.  The work rides in the factorisation's own launches, one panel behind.
+struct LdltBorder {
+    double *B, *Y;
+    int64_t ldb; // a multiple of 64
 };
 struct LdltDist {
     int rank, n_ranks;
@@ -220,7 +220,7 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
                    const double *u_dev, double *x, double *work, int *status, hipStream_t s, const LdltDist *dist = nullptr,
                    const int32_t *grp = nullptr, // grp: pose block -> entry of u_dev (grouped refinement)
                    int phase = LDLT_ALL,         // LDLT_FACTOR / LDLT_BACKWARD: the two halves of a solve (single rank, A.no_twist)
-                   const LdltHook *hook = nullptr);
+                   const LdltBorder *border = nullptr);
 
 // bcr.hip: block cyclic reduction for narrow-band SPD systems (the visual stage's reduced camera system)
 bool bcr_applicable(int n_poses, int band_blocks);

@@ -48,19 +48,17 @@ inline double nd_fact_seconds(double n, double bw, bool may_twist)
     if (may_twist && P >= 4) chain = P + (n - 128.0 * P) / 64.0;
     return std::max(n * bw * bw / rate, chain * t_launch);
 }
-// one arc alone on the device: the factorisation's chain with the border's forward substitution beside it (a panel behind, on a
-// stream of its own), then Y^T D^-1 Y.  work_out: the same as pure throughput -- what several arcs of one rank, side by side, add up to.
-// (measured, round 5, n = 10 326, bw = 617, s = 1 674: 162 forward launches of 19 us = 16 TFLOP/s with Y recomputed per tile;
+// one arc alone on the device: the factorisation's chain with the border's forward substitution riding in its launches (one
+// panel behind), then Y^T D^-1 Y.  work_out: the same as pure throughput -- what several arcs of one rank, side by side, add up to.
+// (measured, round 5, n = 10 326, bw = 617, s = 1 674: the forward substitution at 16 TFLOP/s with Y recomputed per tile;
 // Y^T D^-1 Y 1.5 ms = 19 TFLOP/s)
 inline double nd_arc_seconds(double n, double bw, double s, double *work_out)
 {
-    const double t_launch = 27e-6, t_fwd = 12e-6, rate = 36e12, rate_fwd = 16e12, rate_schur = 19e12;
+    const double t_launch = 30e-6, rate = 36e12, rate_fwd = 16e12, rate_schur = 19e12;
     const double w = std::min(bw, n);
     const double f_fact = n * w * w / rate, f_fwd = 4.0 * n * w * s / rate_fwd, f_schur = n * s * s / rate_schur;
     *work_out = f_fact + f_fwd + f_schur;
-    const double t_fact = std::max(f_fact, n / 64.0 * t_launch);
-    const double t_f = s > 0 ? std::max(f_fwd, n / 64.0 * t_fwd) : 0.0;
-    return std::max(t_fact, t_f) + f_schur;
+    return std::max(f_fact + f_fwd, n / 64.0 * t_launch) + f_schur;
 }
 
 namespace nd_detail {
