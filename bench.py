@@ -363,7 +363,7 @@ def main():
             # the LM loop's own cost pass (every iteration runs one at the trial point), as timed inside the loop
             "roofline_cost_pass_in_loop": others[0],
             "roofline_other_kernels": others,
-            "scaling_model": scaling_model(p, sv_ms, info, world),
+            "scaling_model": scaling_model(p, sv_ms, info, world, prob),
         }
         if windows_multi is not None:
             out["window_stage_all_ranks"] = windows_multi
@@ -419,7 +419,7 @@ def relaunch_under_torchrun(n):
     os.execve(sys.executable, cmd, env)
 
 
-def scaling_model(p, sv_ms, info, world):
+def scaling_model(p, sv_ms, info, world, prob=None):
     """What strong scaling of ONE refinement can give, from this run's own stage times: the evaluation and the cost pass shard by
     voxel range (/ N), the pose blocks are all-reduced (2 (N - 1) / N x bytes / an ASSUMED 250 GB/s RCCL bus bandwidth over xGMI -- 7
     links x ~153 GB/s per GPU, full mesh; never measured here: no multi-GPU node was available to any round), and the
@@ -432,12 +432,29 @@ def scaling_model(p, sv_ms, info, world):
     proj = {}
     for n in (1, 2, 4, 8):
         ar = 0.0 if n == 1 else 2.0 * (n - 1) / n * ar_mb / 250.0   # ms at 250 GB/s bus bandwidth (MB / (GB/s) = ms)
-        t = (ev + ck) / n + ar + sv_ms
-        proj[str(n)] = {"ms_per_iteration": t, "speedup": (ev + ck + sv_ms) / t}
-    return {"kind": "strong scaling of one refinement: chain-bound", "stage_ms_1gpu": {"eval": ev, "cost": ck, "solve": sv_ms}, "stage_ms_1gpu_from": f"this run's stage times on {world} rank(s), evaluation and cost pass scaled by the rank count",
+        sv, how = sv_ms, "band LDL^T as measured on this GPU (a second rank takes the other end: no gain over both ends in one launch)"
+        nd = None
+        if n > 1 and prob is not None:
+            # the solver's own plan for n ranks (lvba_balm_nd_model: csrc/nd_plan.h on this problem's co-visibility graph): arcs of the
+            # band dealt out over the ranks + a separator system, costed in the solver's measured units -- a MODEL (its band figure
+            # next to the measured solve says how far off it is); taken when it beats the band
+            try:
+                nd = prob.nd_model(n)
+            except Exception:
+                nd = None
+            if nd and nd["nd_ms"] > 0 and nd["nd_ms"] * (sv_ms / max(nd["band_ms"], 1e-9)) < sv_ms:
+                sv = nd["nd_ms"] * (sv_ms / nd["band_ms"])   # scaled by measured / modelled band time of this very problem
+                how = (f"nested dissection over {n} ranks (csrc/ldlt_nd.h): {nd['arcs']} arcs of <= {nd['max_arc_poses']} poses, separator "
+                       f"{nd['sep_poses']} poses; model {nd['nd_ms']:.2f} ms against {nd['band_ms']:.2f} ms for the band, scaled by this "
+                       f"run's measured / modelled band solve")
+        t = (ev + ck) / n + ar + sv
+        proj[str(n)] = {"ms_per_iteration": t, "speedup": (ev + ck + sv_ms) / t, "solve_ms": sv, "solve": how, "nd_model": nd}
+    return {"kind": "strong scaling of one refinement: evaluation / cost pass sharded by voxel range, pose blocks all-reduced, solve by the band (two ranks at best) or by nested dissection over the ranks -- whichever the solver's model prefers", "stage_ms_1gpu": {"eval": ev, "cost": ck, "solve": sv_ms}, "stage_ms_1gpu_from": f"this run's stage times on {world} rank(s), evaluation and cost pass scaled by the rank count",
             "allreduce_mb_per_evaluation": ar_mb, "assumed_bus_gb_s": 250.0, "projected": proj,
-            "note": "the solve (a chain of ~115 panel factorisations) does not shard; throughput across GPUs comes from independent "
-                    "work -- windows (window_stage_all_ranks, lvba_window_ba_multi), sequences -- not from one refinement",
+            "note": "a projection, not a measurement (no multi-GPU node was available to any round).  A band that is short compared "
+                    "with its width (C3: n / bw = 4.6) is a serial chain of panel factorisations that does not shard -- throughput "
+                    "across GPUs then comes from independent work: windows (window_stage_all_ranks, lvba_window_ba_multi), "
+                    "sequences; a long band (C4: n / bw = 24) is dissected into one arc per rank (csrc/nd_plan.h)",
             "measured_ranks": world}
 
 

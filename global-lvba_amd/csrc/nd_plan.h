@@ -71,35 +71,39 @@ inline void neighbours(const uint8_t *adj, int N, lvba::hvec<lvba::hvec<int32_t>
             if (row[j] && j != i) nb[(size_t)i].push_back(j);
     }
 }
-// band ordering of the sub-graph on `nodes` (caller indices): order_out = the nodes in solver order, returns its half-bandwidth
-inline int32_t sub_order(const uint8_t *adj, int N, const lvba::hvec<int32_t> &nodes, lvba::hvec<int32_t> &order_out,
-                         const lvba::hvec<uint8_t> *extra = nullptr /* [m*m] more edges, local indices */)
+// band ordering of the sub-graph on `nodes` (caller indices) from the neighbour lists (+ `extra` lists, local indices):
+// order_out = the nodes in solver order, returns its half-bandwidth.  local: scratch [N], -1 on entry and on exit.
+inline int32_t sub_order(const lvba::hvec<lvba::hvec<int32_t>> &nb, const lvba::hvec<int32_t> &nodes, lvba::hvec<int32_t> &local,
+                         lvba::hvec<int32_t> &order_out, bool quick, const lvba::hvec<lvba::hvec<int32_t>> *extra = nullptr)
 {
     const int m = (int)nodes.size();
     order_out.assign(nodes.begin(), nodes.end());
     if (m <= 2) return m - 1 > 0 ? m - 1 : 0;
-    lvba::hvec<uint8_t> sub((size_t)m * m, 0);
+    for (int a = 0; a < m; ++a) local[(size_t)nodes[(size_t)a]] = a;
+    lvba::hvec<lvba::hvec<int32_t>> sub((size_t)m);
     for (int a = 0; a < m; ++a) {
-        const uint8_t *row = adj + (size_t)nodes[(size_t)a] * N;
-        for (int b = 0; b < m; ++b) sub[(size_t)a * m + b] = (row[nodes[(size_t)b]] || (extra && (*extra)[(size_t)a * m + b])) ? 1 : 0;
+        for (int v : nb[(size_t)nodes[(size_t)a]])
+            if (local[(size_t)v] >= 0) sub[(size_t)a].push_back(local[(size_t)v]);
+        if (extra) {
+            for (int b : (*extra)[(size_t)a])
+                if (b != a) sub[(size_t)a].push_back(b);
+            std::sort(sub[(size_t)a].begin(), sub[(size_t)a].end());
+            sub[(size_t)a].erase(std::unique(sub[(size_t)a].begin(), sub[(size_t)a].end()), sub[(size_t)a].end());
+        }
     }
+    for (int a = 0; a < m; ++a) local[(size_t)nodes[(size_t)a]] = -1;
     lvba::hvec<int32_t> perm;
-    rcm_order(sub, m, perm);
-    lvba::hvec<int32_t> ip((size_t)m);
-    for (int a = 0; a < m; ++a) ip[(size_t)perm[(size_t)a]] = a;
-    int32_t bw = 0;
-    for (int a = 0; a < m; ++a)
-        for (int b = 0; b < m; ++b)
-            if (sub[(size_t)a * m + b]) bw = std::max(bw, std::abs(ip[(size_t)a] - ip[(size_t)b]));
+    const int32_t bw = rcm_order_nb(sub, perm, quick);
     for (int a = 0; a < m; ++a) order_out[(size_t)a] = nodes[(size_t)perm[(size_t)a]];
     return bw;
 }
 } // namespace nd_detail
 
 // One candidate: the separator set `in_sep` (by caller index).  Builds the whole plan and its cost; false if it degenerates.
-inline bool nd_build_candidate(const uint8_t *adj, int N, const lvba::hvec<lvba::hvec<int32_t>> &nb, lvba::hvec<uint8_t> in_sep,
-                               int n_ranks, const char *kind, NdPlan &out)
+inline bool nd_build_candidate(int N, const lvba::hvec<lvba::hvec<int32_t>> &nb, lvba::hvec<uint8_t> in_sep,
+                               int n_ranks, const char *kind, bool quick, NdPlan &out)
 {
+    lvba::hvec<int32_t> scratch((size_t)N, -1);
     // connected components of the rest; components too small to be worth a factorisation of their own join the separator
     lvba::hvec<int32_t> comp((size_t)N, -1);
     lvba::hvec<lvba::hvec<int32_t>> parts;
@@ -138,18 +142,18 @@ inline bool nd_build_candidate(const uint8_t *adj, int N, const lvba::hvec<lvba:
     lvba::hvec<int32_t> sep_local((size_t)N, -1);
     for (int q = 0; q < Ns; ++q) sep_local[(size_t)sep_nodes[(size_t)q]] = q;
     lvba::hvec<lvba::hvec<int32_t>> touch((size_t)P); // separator poses (local index in sep_nodes) each arc touches
-    lvba::hvec<uint8_t> fillg((size_t)Ns * Ns, 0);
+    lvba::hvec<lvba::hvec<int32_t>> fillg((size_t)Ns);
     for (int a = 0; a < P; ++a) {
         lvba::hvec<uint8_t> seen((size_t)Ns, 0);
         for (int v : parts[(size_t)a])
             for (int b : nb[(size_t)v])
                 if (in_sep[(size_t)b] && !seen[(size_t)sep_local[(size_t)b]]) { seen[(size_t)sep_local[(size_t)b]] = 1; touch[(size_t)a].push_back(sep_local[(size_t)b]); }
         for (int x : touch[(size_t)a])
-            for (int y : touch[(size_t)a]) fillg[(size_t)x * Ns + y] = 1;
+            for (int y : touch[(size_t)a]) fillg[(size_t)x].push_back(y);
     }
     lvba::hvec<int32_t> sep_order;
     out = NdPlan();
-    out.BbS = nd_detail::sub_order(adj, N, sep_nodes, sep_order, &fillg);
+    out.BbS = nd_detail::sub_order(nb, sep_nodes, scratch, sep_order, quick, &fillg);
     lvba::hvec<int32_t> sep_pos((size_t)N, -1); // caller index -> position in the separator's order
     for (int q = 0; q < Ns; ++q) sep_pos[(size_t)sep_order[(size_t)q]] = q;
     // the arcs, largest first (the owner assignment below deals them out in that order)
@@ -163,7 +167,7 @@ inline bool nd_build_candidate(const uint8_t *adj, int N, const lvba::hvec<lvba:
         const int a = by_size[(size_t)idx];
         NdPlanArc arc;
         lvba::hvec<int32_t> order;
-        arc.Bb = nd_detail::sub_order(adj, N, parts[(size_t)a], order);
+        arc.Bb = nd_detail::sub_order(nb, parts[(size_t)a], scratch, order, quick);
         arc.p0 = (int32_t)out.perm.size();
         arc.Na = (int32_t)order.size();
         for (int v : order) out.perm.push_back(v);
@@ -201,7 +205,7 @@ inline NdPlan nd_plan(const uint8_t *adj, int N, const lvba::hvec<int32_t> &perm
     double t_best = best.t_band * min_gain;
     auto consider = [&](const lvba::hvec<uint8_t> &in_sep, const char *kind) {
         NdPlan cand;
-        if (!nd_build_candidate(adj, N, nb, in_sep, n_ranks, kind, cand)) return;
+        if (!nd_build_candidate(N, nb, in_sep, n_ranks, kind, true, cand)) return;
         cand.t_band = best.t_band;
         if (cand.t_nd < t_best) { t_best = cand.t_nd; best = cand; }
         // Long arcs are serial chains of their own (an arc is factorised top-down: its factor is reused by the border's forward
@@ -209,10 +213,10 @@ inline NdPlan nd_plan(const uint8_t *adj, int N, const lvba::hvec<int32_t> &perm
         // their streams, and the chunks join the separator.  Repeated while the model gains (a folded ring falls into its two
         // sides at the first cut, each with half the bandwidth: the next cut's chunks are half as wide).
         NdPlan base = cand;
-        for (int round = 0; round < 4; ++round) {
+        for (int round = 0; round < 3; ++round) {
             NdPlan round_best;
             double t_round = base.t_nd;
-            for (int pieces : {2, 3, 5}) {
+            for (int pieces : {2, 4}) {
                 lvba::hvec<uint8_t> s2((size_t)N, 0);
                 for (int q = base.ps; q < N; ++q) s2[(size_t)base.perm[(size_t)q]] = 1;
                 bool any = false;
@@ -228,7 +232,7 @@ inline NdPlan nd_plan(const uint8_t *adj, int N, const lvba::hvec<int32_t> &perm
                 }
                 if (!any) break;
                 NdPlan c2;
-                if (!nd_build_candidate(adj, N, nb, s2, n_ranks, kind, c2)) continue;
+                if (!nd_build_candidate(N, nb, s2, n_ranks, kind, true, c2)) continue;
                 c2.t_band = best.t_band;
                 if (c2.t_nd < t_round) { t_round = c2.t_nd; round_best = c2; }
             }
@@ -274,6 +278,15 @@ inline NdPlan nd_plan(const uint8_t *adj, int N, const lvba::hvec<int32_t> &perm
                 }
                 consider(in_sep, "chunks");
             }
+        }
+    }
+    if (best.active) { // the partition that won, ordered in full (hill-climbing on every arc and on the separator's graph)
+        lvba::hvec<uint8_t> in_sep((size_t)N, 0);
+        for (int q = best.ps; q < N; ++q) in_sep[(size_t)best.perm[(size_t)q]] = 1;
+        NdPlan full;
+        if (nd_build_candidate(N, nb, in_sep, n_ranks, best.kind, false, full) && full.t_nd <= best.t_nd * 1.02) {
+            full.t_band = best.t_band;
+            best = full;
         }
     }
     return best;

@@ -156,24 +156,13 @@ inline void hill_climb(const lvba::hvec<lvba::hvec<int32_t>> &nb, lvba::hvec<int
     if (cur < bw_io) { perm = order; bw_io = cur; }
 }
 
-inline void rcm_order(const lvba::hvec<uint8_t> &adj, int N, lvba::hvec<int32_t> &perm)
+// the ordering from neighbour lists (nb is re-sorted by degree).  quick: RCM + barycenter sweeps only (nd_plan.h weighs many
+// candidate partitions; the one it keeps is ordered in full)
+inline int32_t rcm_order_nb(lvba::hvec<lvba::hvec<int32_t>> &nb, lvba::hvec<int32_t> &perm, bool quick = false)
 {
-    lvba::hvec<lvba::hvec<int32_t>> nb(N);
+    const int N = (int)nb.size();
     lvba::hvec<int32_t> deg(N, 0);
-    for (int i = 0; i < N; ++i) { // the matrix is sparse (C3: 13 % non-zero): skip it eight bytes at a time
-        const uint8_t *row = adj.data() + (size_t)i * N;
-        int j = 0;
-        for (; j + 8 <= N; j += 8) {
-            uint64_t w;
-            std::memcpy(&w, row + j, 8);
-            if (!w) continue;
-            for (int e = 0; e < 8; ++e)
-                if (row[j + e] && j + e != i) nb[i].push_back(j + e);
-        }
-        for (; j < N; ++j)
-            if (row[j] && j != i) nb[i].push_back(j);
-        deg[i] = (int32_t)nb[i].size();
-    }
+    for (int i = 0; i < N; ++i) deg[i] = (int32_t)nb[i].size();
     for (int i = 0; i < N; ++i)
         std::sort(nb[i].begin(), nb[i].end(), [&](int a, int b) { return deg[a] != deg[b] ? deg[a] < deg[b] : a < b; });
     lvba::hvec<int32_t> best, cand;
@@ -187,7 +176,7 @@ inline void rcm_order(const lvba::hvec<uint8_t> &adj, int N, lvba::hvec<int32_t>
     lvba::hvec<double> x(N), y(N);
     for (int i = 0; i < N; ++i) x[best[i]] = i;
     lvba::hvec<int32_t> idx(N);
-    for (int it = 1; it <= 40; ++it) {
+    for (int it = 1; it <= (quick ? 10 : 40); ++it) {
         for (int i = 0; i < N; ++i) {
             if (nb[i].empty()) { y[i] = x[i]; continue; }
             double s = 0.0;
@@ -204,7 +193,28 @@ inline void rcm_order(const lvba::hvec<uint8_t> &adj, int N, lvba::hvec<int32_t>
         }
     }
     perm = best;
-    hill_climb(nb, perm, best_bw);
+    if (!quick) hill_climb(nb, perm, best_bw);
+    return best_bw;
+}
+
+
+inline void rcm_order(const lvba::hvec<uint8_t> &adj, int N, lvba::hvec<int32_t> &perm)
+{
+    lvba::hvec<lvba::hvec<int32_t>> nb(N);
+    for (int i = 0; i < N; ++i) { // the matrix is sparse (C3: 13 % non-zero): skip it eight bytes at a time
+        const uint8_t *row = adj.data() + (size_t)i * N;
+        int j = 0;
+        for (; j + 8 <= N; j += 8) {
+            uint64_t w;
+            std::memcpy(&w, row + j, 8);
+            if (!w) continue;
+            for (int e = 0; e < 8; ++e)
+                if (row[j + e] && j + e != i) nb[i].push_back(j + e);
+        }
+        for (; j < N; ++j)
+            if (row[j] && j != i) nb[i].push_back(j);
+    }
+    rcm_order_nb(nb, perm);
 }
 
 } // namespace lvba
