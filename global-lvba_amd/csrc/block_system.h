@@ -112,6 +112,8 @@ int32_t bs_enqueue_solve_groups(BlockSys &bs, const double *u);
 int32_t bs_allreduce(BlockSys &bs, double *buf, size_t count);
 // all-reduce [Hblk | g | cost] over the ranks: only the blocks of the union sparsity pattern travel when that is known
 int32_t bs_allreduce_hg(BlockSys &bs);
+// clear what the last all-reduce left in the store of a multi-rank job (before the next evaluation writes this rank's blocks)
+int32_t bs_clear_reduced(BlockSys &bs);
 // all-reduce `count` elements of a device buffer in place (sum or max; double / int64 / int32 / uint8) over the ranks
 int32_t bs_comm_allreduce(BlockSys &bs, void *dbuf, size_t count, ncclDataType_t dt, ncclRedOp_t op);
 // slots of the structurally non-zero blocks of the block-band store (ascending, diagonal included); their download [n][36]

@@ -171,6 +171,25 @@ __global__ void hg_unpack_kernel(double *__restrict__ hg, const int64_t *__restr
 // The block-band store is mostly structural zeros (C3: 4e5 non-zero blocks of 8.7e5 slots, 270 MB): when the union sparsity
 // pattern is known (it is whenever the ordering was computed from the all-reduced adjacency) only its blocks travel --
 // xGMI all-reduce time is proportional to bytes, and slots outside the union are zero on every rank.
+__global__ void hg_zero_slots_kernel(double *__restrict__ hg, const int64_t *__restrict__ slot, int64_t n_ar)
+{
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t < 36 * n_ar) hg[slot[t / 36] * 36 + t % 36] = 0.0;
+}
+// Before an evaluation of a multi-rank job: the blocks other ranks reduced into the store must read as zero again (this rank's
+// kernels only write the blocks of its own shard).  With a union pattern only its slots are cleared -- a dissected system keeps the
+// full lower block triangle (N^2 blocks: 28.8 GB at 10 000 poses), of which the pattern is a few per cent.
+int32_t bs_clear_reduced(BlockSys &bs)
+{
+    if (!bs.distributed()) return LVBA_OK;
+    if (bs.d_ar_slot)
+        hipLaunchKernelGGL(hg_zero_slots_kernel, dim3((unsigned)((36 * bs.n_ar + 255) / 256)), dim3(256), 0, bs.stream, bs.d_hg, bs.d_ar_slot, bs.n_ar);
+    else
+        HIPCHK(hipMemsetAsync(bs.d_hg, 0, (size_t)bs.hblk_doubles * sizeof(double), bs.stream));
+    HIPCHK(hipGetLastError());
+    return LVBA_OK;
+}
+
 int32_t bs_allreduce_hg(BlockSys &bs)
 {
     if (!bs.distributed()) return LVBA_OK;
@@ -401,7 +420,6 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
         }
     }
     BS_MARK("ordering");
-    if (!bs.perm_band.empty()) bs.adj_keep.swap(adj);
     const int64_t bw = 6 * (int64_t)bs.Bb + 5;
     bs.use_band = !plan.active && (double)(bw + LVBA_NB + 64) < bs.band_frac * (double)n;
     if (!bs.use_band) bs.Bb = N - 1; // full lower block triangle
@@ -428,6 +446,7 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
         }
     }
 
+    if (!bs.perm_band.empty()) bs.adj_keep.swap(adj); // (kept for lvba_balm_nd_model)
     { // pose-major (CSC) view + per-block group lists for the atomic-free assembly: built on the device (pair_lists.hip)
         TRY(bs_dmalloc(bs, &bs.d_csc_off, N + 1));
         TRY(bs_dmalloc(bs, &bs.d_group_of_pos, F));

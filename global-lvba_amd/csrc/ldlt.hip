@@ -165,11 +165,25 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
     const bool big = big_env && ((uint64_t)A.ld * (uint64_t)(n + 128) + (uint64_t)n + 256) * 8 < 0xFFFF0000ull;
     // Panels [sa, sb) of one problem (or of both, ny = 2).  Consecutive panels are PAIRED (e, o = e + 1): e leaves the bulk of its
     // trailing update to its partner's launches, where every C tile is read and written once for both (rank 128).
-    // the border's forward substitution (LdltBorder): panel p rides in the launch AFTER the one that made its column block L
-    int64_t fwd_next = 0;
-    auto passenger = [&](int64_t p) {
-        const Geo g = geom(p);
-        return FwdPassenger{1, g.nbe, g.k, g.w0, g.rend, g.T, border->ldb, Gall + p * 4096, border->B, border->Y};
+    // the border's forward substitution (LdltBorder), two panels behind the roles: stage q = [Y role of panel q - 1, U role of panel
+    // q - 2] rides in launch X_q (ldlt_lookahead.h: FwdPassenger); the stages no launch is left for run on their own at the end
+    int64_t fwd_next = 1;
+    auto fwd_stage = [&](int64_t q, int64_t &nwg_out) {
+        FwdPassenger f{};
+        f.on = 1; f.ldb = border->ldb; f.B = border->B; f.Y = border->Y;
+        const int64_t nct = border->ldb / 64;
+        nwg_out = 0;
+        if (q - 1 < nsteps) {
+            const Geo ga = geom(q - 1);
+            f.y_on = 1; f.a_k = ga.k; f.a_nbe = ga.nbe; f.Ga = Gall + (q - 1) * 4096;
+            if (q - 2 >= 0) { const Geo gm = geom(q - 2); f.has_prev = 1; f.am_k = gm.k; f.am_nbe = gm.nbe; f.am_rend = gm.rend; }
+            nwg_out += nct;
+        }
+        if (q - 2 >= 0) {
+            const Geo gc = geom(q - 2);
+            if (gc.T >= 2) { f.u_on = 1; f.c_k = gc.k; f.c_nbe = gc.nbe; f.c_w0 = gc.w0; f.c_rend = gc.rend; f.c_T = gc.T; nwg_out += (gc.T - 1) * nct; }
+        }
+        return f;
     };
     auto run_phase = [&](int64_t sa, int64_t sb, unsigned ny, bool second, bool close) {
         const int64_t wo = second ? tw.sW : 0;
@@ -222,9 +236,10 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
                 nwg += J.nwg;
                 ++a.njobs;
             }
-            if (border && L.roles && ny == 1 && fwd_next < L.p) {
-                a.fwd = passenger(fwd_next++);
-                nwg += (a.fwd.T + 1) * (border->ldb / 64);
+            if (border && L.roles && ny == 1 && fwd_next == L.p) {
+                int64_t nf = 0;
+                a.fwd = fwd_stage(fwd_next++, nf);
+                nwg += nf;
             }
             int64_t grid = nwg * ny;
             if (L.roles && grid > n_cus) {
@@ -253,10 +268,11 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
         st0 = P1;
     }
     run_phase(st0, nsteps, 1, false, false);
-    if (border) // the panels no step launch was left to carry
-        for (; fwd_next < nsteps; ++fwd_next) {
-            const FwdPassenger f = passenger(fwd_next);
-            hipLaunchKernelGGL(ldlt_fwd_kernel, dim3((unsigned)((f.T + 1) * (border->ldb / 64))), dim3(256), 0, s, M, f, (const double *)dvec);
+    if (border) // the stages no step launch was left to carry
+        for (; fwd_next <= nsteps; ++fwd_next) {
+            int64_t nf = 0;
+            const FwdPassenger f = fwd_stage(fwd_next, nf);
+            if (nf > 0) hipLaunchKernelGGL(ldlt_fwd_kernel, dim3((unsigned)nf), dim3(256), 0, s, M, f, (const double *)dvec);
         }
     }
     if (phase == LDLT_FACTOR) return LVBA_OK;

@@ -36,16 +36,21 @@ struct BulkJob {
     int pair;
     int64_t ca, cb, nwg;
 };
-// A passenger of the launch: the forward substitution of a block of extra right-hand sides (the border columns of a dissected
-// system, ldlt_nd.h) for the panel BEFORE the one the roles work on -- its column block is L since the launch before, and its
-// rows of B were completed by that launch's passengers.  B, Y: [n][ldb] row-major.  (T + 1) x ldb / 64 workgroups:
-//   tile row 0      Y[k .. k + 64) = D G^T B[k .. k + 64)
-//   tile row t >= 1 B[tile t of the window] -= L(tile t, panel) Y_panel   (Y_panel recomputed: nothing exchanged inside a launch)
+// Passengers of the launch: the forward substitution of a block of extra right-hand sides (the border columns of a dissected
+// system, ldlt_nd.h), two panels behind the roles.  B, Y: [n][ldb] row-major.  Stage q (it rides in launch X_q) is
+//   Y role  (panel a = q - 1; ldb / 64 workgroups)  B_a -= L(a, a - 1) Y_{a-1}  -- the one update its rows still miss --, then
+//                                                   Y_a = D_a G_a^T B_a
+//   U role  (panel c = q - 2; (T_c - 1) ldb / 64)   B[tile t >= 2 of c's window] -= L(tile, c) Y_c
+// Y_{a-1} and Y_c come from the stages before (launches before): nothing is exchanged inside a launch, and no product is done
+// twice (a first form let every tile recompute its panel's Y: 16 TFLOP/s on twice the flops).
 struct FwdPassenger {
     int on;
-    int nbe;
-    int64_t k, w0, rend, T, ldb;
-    const double *G; // the panel's G
+    int y_on, a_nbe, am_nbe, has_prev; // Y role: panel a (and a - 1, if there is one)
+    int u_on, c_nbe;                   // U role: panel c
+    int64_t ldb;
+    int64_t a_k, am_k, am_rend;
+    int64_t c_k, c_w0, c_rend, c_T;
+    const double *Ga;
     double *B, *Y;
 };
 struct Step2Args {
@@ -464,61 +469,96 @@ __device__ __forceinline__ void qx_diag_role(double *lds, const LdltMat &M, cons
         }
 }
 
-// ---------------------------------------------------------------------------------------------- the forward-substitution passenger
+// ---------------------------------------------------------------------------------------------- the forward-substitution passengers
 __device__ __forceinline__ void fwd_passenger(double *lds, const LdltMat &M, const FwdPassenger &F, const double *__restrict__ dvec,
                                               int64_t idx)
 {
     double *Ls = lds, *Zs = lds + 64 * LVBA_TS;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, row = tid & 63, i = lane & 15, kk = lane >> 4;
-    const int64_t ti = idx % (F.T + 1), j0 = 64 * (idx / (F.T + 1));
-    if (j0 >= F.ldb) return;
-    const int64_t k = F.k, ldb = F.ldb;
-    const int nbe = F.nbe;
+    const int64_t nct = F.ldb / 64, ldb = F.ldb;
+    const int64_t ny = F.y_on ? nct : 0;
     double *__restrict__ B = F.B;
-    double bp[16], gp[16], lv[16];
-#pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        const int m = w + 4 * it;
-        bp[it] = m < nbe ? B[(k + m) * ldb + j0 + row] : 0.0; // [m][jj]: thread (jj = row, m)
-    }
-#pragma unroll
-    for (int it = 0; it < 16; ++it) gp[it] = F.G[tid + 256 * it]; // G[m][c]: thread (c = row, m = w + 4 it)
-    const int64_t r0 = F.w0 + 64 * (ti - 1);
-    if (ti > 0) load_panel_tile(M, r0, k, F.rend, nbe, w, row, lv); // L(tile, panel) as [m = c][x = r]
-    const double dk = tid < nbe ? dvec[k + tid] : 0.0;
-    stage_tile(Ls, bp, w, row);
-    stage_tile(Zs, gp, w, row);
-    if (tid < 64) pad_at(lds, LVBA_PAD_DP + tid) = dk;
-    __syncthreads();
+    double *__restrict__ Y = F.Y;
+    double va[16], vb[16];
     d4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
-    tile_product(Ls, Zs, w, i, kk, acc); // acc[t][reg] <-> (jj = 16 t + i, c = 16 w + kk + 4 reg): (G^T B)[c][jj]
-    if (ti == 0) {
+    if (idx < ny) { // ---- Y role, column block idx
+        const int64_t j0 = 64 * idx, k = F.a_k;
+        const int nbe = F.a_nbe;
+        if (F.has_prev) { // B_a -= L(a, a - 1) Y_{a-1}
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int m = w + 4 * it;
+                va[it] = m < F.am_nbe ? Y[(F.am_k + m) * ldb + j0 + row] : 0.0; // Y_{a-1} as [m = c][x = jj]
+            }
+            load_panel_tile(M, k, F.am_k, F.am_rend, F.am_nbe, w, row, vb);      // L(a, a - 1) as [m = c][x = r]
+            stage_tile(Ls, va, w, row);
+            stage_tile(Zs, vb, w, row);
+        }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) vb[it] = F.Ga[tid + 256 * it]; // G_a[m][c]: thread (c = row, m = w + 4 it)
+        const double dk = tid < nbe ? dvec[k + tid] : 0.0;
+        // B_a in the products' result layout: (jj = 16 t + i, r = 16 w + kk + 4 reg)
+        d4 bn[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int r = 16 * w + kk + 4 * reg;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bn[t][reg] = r < nbe ? B[(k + r) * ldb + j0 + 16 * t + i] : 0.0;
+        }
+        if (F.has_prev) {
+            __syncthreads();
+            tile_product(Ls, Zs, w, i, kk, acc); // (jj = 16 t + i, r = 16 w + kk + 4 reg): sum_c L[r][c] Y[c][jj]
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int r = 16 * w + kk + 4 * reg;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    bn[t][reg] -= acc[t][reg];
+                    if (r < nbe) B[(k + r) * ldb + j0 + 16 * t + i] = bn[t][reg];
+                    acc[t][reg] = 0.0;
+                }
+            }
+            __syncthreads();
+        }
+        put_acc(Ls, bn, w, i, kk, nullptr); // Ls[m = r][x = jj] = B_a
+        stage_tile(Zs, vb, w, row);         // Zs[m][c] = G_a
+        if (tid < 64) pad_at(lds, LVBA_PAD_DP + tid) = dk;
+        __syncthreads();
+        tile_product(Ls, Zs, w, i, kk, acc); // (jj = 16 t + i, c = 16 w + kk + 4 reg): (G^T B)[c][jj]
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int c = 16 * w + kk + 4 * reg;
             const double dc = pad_at(lds, LVBA_PAD_DP + c);
             if (c < nbe)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) F.Y[(k + c) * ldb + j0 + 16 * t + i] = acc[t][reg] * dc;
+                for (int t = 0; t < 4; ++t) Y[(k + c) * ldb + j0 + 16 * t + i] = acc[t][reg] * dc;
         }
         return;
     }
-    __syncthreads();
-    put_acc(Ls, acc, w, i, kk, lds); // Ls[c][jj] = d_c (G^T B)[c][jj] = Y_panel
-    stage_tile(Zs, lv, w, row);      // Zs[c][r]
-    __syncthreads();
-    d4 acc2[4];
+    // ---- U role: tile row ti >= 2 of panel c's window, column block
+    if (!F.u_on) return;
+    idx -= ny;
+    const int64_t ti = 2 + idx % (F.c_T - 1), j0 = 64 * (idx / (F.c_T - 1));
+    if (j0 >= ldb) return;
+    const int64_t r0 = F.c_w0 + 64 * (ti - 1);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc2[t] = (d4){0.0, 0.0, 0.0, 0.0};
-    tile_product(Ls, Zs, w, i, kk, acc2); // (jj = 16 t + i, r = 16 w + kk + 4 reg): sum_c L[r][c] Y[c][jj]
+    for (int it = 0; it < 16; ++it) {
+        const int m = w + 4 * it;
+        va[it] = m < F.c_nbe ? Y[(F.c_k + m) * ldb + j0 + row] : 0.0; // Y_c as [m = c][x = jj]
+    }
+    load_panel_tile(M, r0, F.c_k, F.c_rend, F.c_nbe, w, row, vb);       // L(tile, c) as [m = c][x = r]
+    stage_tile(Ls, va, w, row);
+    stage_tile(Zs, vb, w, row);
+    __syncthreads();
+    tile_product(Ls, Zs, w, i, kk, acc); // (jj = 16 t + i, r = 16 w + kk + 4 reg)
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const int64_t r = r0 + 16 * w + kk + 4 * reg;
-        if (r < F.rend)
+        if (r < F.c_rend)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) B[r * ldb + j0 + 16 * t + i] -= acc2[t][reg];
+            for (int t = 0; t < 4; ++t) B[r * ldb + j0 + 16 * t + i] -= acc[t][reg];
     }
 }
 

@@ -116,6 +116,9 @@ __global__ __launch_bounds__(256, 2) void nd_schur_kernel(const double *__restri
         for (int t = 0; t < 4; ++t) Sa[j * ldb + i0 + 16 * t + i] = acc[t][reg];
     }
 }
+// (A 128 x 128 tile per workgroup, 64 x 64 per wavefront -- twice the arithmetic per LDS read -- was measured in round 5 and is
+// SLOWER: 1.59 against 0.73 ms at n = 5 100, s = 1 818.  The border has a few dozen tile columns: 120 tiles of 128 leave half the
+// chip idle where 435 tiles of 64 fill it.)
 
 // The separator system's block store and gradient from the Hessian store: S(I, J) + u diag, as ldlt_solve's fill expects it
 // (the damping is applied HERE: the solve runs with u = 0, because the Schur complements must not be damped).  include = 0:

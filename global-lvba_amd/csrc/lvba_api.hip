@@ -455,8 +455,9 @@ static int32_t enqueue_eval(lvba_balm_s *h, const double *d_poses, bool lin_in_p
 {
     BlockSys &bs = h->bs;
     ev_begin(h, EV_EVAL);
+    TRY(bs_clear_reduced(bs));
     launch_eval(h->dev(), bs.pair_dev(), d_poses, bs.Hblk(), bs.hblk_doubles, bs.g(), h->d_chunk_cost, bs.scal(),
-                bs.distributed(), bs.stream, h->prof_on ? h->ev[EV_EVALK][0] : nullptr,
+                false, bs.stream, h->prof_on ? h->ev[EV_EVALK][0] : nullptr,
                 h->prof_on ? h->ev[EV_EVALK][1] : nullptr, lin_in_place);
     if (h->prof_on) h->ev_used[EV_EVALK] = true;
     ev_end(h, EV_EVAL);

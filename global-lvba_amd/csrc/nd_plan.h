@@ -48,15 +48,15 @@ inline double nd_fact_seconds(double n, double bw, bool may_twist)
     if (may_twist && P >= 4) chain = P + (n - 128.0 * P) / 64.0;
     return std::max(n * bw * bw / rate, chain * t_launch);
 }
-// one arc alone on the device: the factorisation's chain with the border's forward substitution riding in its launches (one
-// panel behind), then Y^T D^-1 Y.  work_out: the same as pure throughput -- what several arcs of one rank, side by side, add up to.
-// (measured, round 5, n = 10 326, bw = 617, s = 1 674: the forward substitution at 16 TFLOP/s with Y recomputed per tile;
-// Y^T D^-1 Y 1.5 ms = 19 TFLOP/s)
+// one arc alone on the device: the factorisation's chain with the border's forward substitution riding in its launches (two
+// panels behind: ldlt_lookahead.h, FwdPassenger), then Y^T D^-1 Y.  work_out: the same as pure throughput -- what several arcs of
+// one rank, side by side, add up to.  (measured, round 5: a step launch with its passengers 26 us; Y^T D^-1 Y 0.73 ms at
+// n = 5 100, s = 1 818 = 23 TFLOP/s; whole solves 5.0 ms / 24.2 ms at 2 000 / 10 000 poses against 4.2 / 19.8 from this model)
 inline double nd_arc_seconds(double n, double bw, double s, double *work_out)
 {
-    const double t_launch = 30e-6, rate = 36e12, rate_fwd = 16e12, rate_schur = 19e12;
+    const double t_launch = 28e-6, rate = 36e12, rate_fwd = 20e12, rate_schur = 23e12;
     const double w = std::min(bw, n);
-    const double f_fact = n * w * w / rate, f_fwd = 4.0 * n * w * s / rate_fwd, f_schur = n * s * s / rate_schur;
+    const double f_fact = n * w * w / rate, f_fwd = 2.0 * n * w * s / rate_fwd, f_schur = n * s * s / rate_schur;
     *work_out = f_fact + f_fwd + f_schur;
     return std::max(f_fact + f_fwd, n / 64.0 * t_launch) + f_schur;
 }
@@ -188,7 +188,7 @@ inline bool nd_build_candidate(int N, const lvba::hvec<lvba::hvec<int32_t>> &nb,
     for (int v : sep_order) out.perm.push_back(v);
     double t_arcs = 0.0;
     for (size_t r = 0; r < load.size(); ++r) t_arcs = std::max(t_arcs, std::max(load[r], chain[r])); // a rank's arcs run side by side
-    out.t_nd = t_arcs + nd_fact_seconds(6.0 * Ns, 6.0 * out.BbS + 5.0, true) + 0.2e-3;
+    out.t_nd = 1.15 * (t_arcs + nd_fact_seconds(6.0 * Ns, 6.0 * out.BbS + 5.0, true)) + 0.4e-3; // (+ fills, merges, back-substitution: measured)
     out.kind = kind;
     out.active = true;
     return true;
