@@ -94,19 +94,41 @@ __global__ void vox_key_kernel(int64_t P, const float *__restrict__ pts, const i
     }
     key_range_update(range_partial, kb, i < P); // (the sort below runs on the bits that vary)
 }
-// records into sorted order; the sorted keys back in their 3 x 21-bit form (K = void: they are that already)
+// records into sorted order, the sorted keys back in their 3 x 21-bit form, and the head flags of the sorted sequence in the same
+// pass: heads[i] = (first record of a root) << 32 | (first record of a (root, frame) segment) -- one 64-bit word, so that ONE
+// inclusive scan numbers roots and segments together.  The frame of a record is found from its index in the window's points (a
+// search over <= 2^25 frame offsets that sit in the scalar cache): the flags need no second gather.
+// (ws > 0, joint map of several windows: a root is (window, key), window = frame / ws -- the window index sits above the key bits
+// of the compressed key, so "the compressed key changed" covers it)
+__device__ __forceinline__ int frame_of_point(const int64_t *__restrict__ frame_off, int n_frames, int64_t i)
+{
+    const int64_t base = frame_off[0];
+    int lo = 0, hi = n_frames; // frame f with frame_off[f] <= base + i < frame_off[f+1]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (frame_off[mid] - base <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
 template <class K>
 __global__ void vox_gather_kernel(int64_t n, const float4 *__restrict__ rec, const uint32_t *__restrict__ order,
-                                  float4 *__restrict__ out, const K *ckey_s, const KeyPack kp, uint64_t *key_s /* may be ckey_s */)
+                                  float4 *__restrict__ out, const K *__restrict__ ckey_s, const KeyPack kp, uint64_t *__restrict__ key_s,
+                                  const int64_t *__restrict__ frame_off, int n_frames, uint64_t *__restrict__ heads)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    out[i] = rec[order[i]];
-    if (ckey_s) {
-        K c = ckey_s[i];
-        if (kp.total < (int)(8 * sizeof(K))) c &= (K)(((K)1 << kp.total) - 1); // (a joint map's window index sits above the key bits)
-        key_s[i] = key_expand<K>(c, kp);
+    const uint32_t oi = order[i];
+    out[i] = rec[oi];
+    const K c = ckey_s[i];
+    bool hr = i == 0, hs = i == 0;
+    if (i > 0) {
+        hr = c != ckey_s[i - 1]; // (key_s is a buffer of its own: the neighbour's compressed key is still there)
+        hs = hr || frame_of_point(frame_off, n_frames, oi) != frame_of_point(frame_off, n_frames, order[i - 1]);
     }
+    heads[i] = ((uint64_t)(hr ? 1u : 0u) << 32) | (uint64_t)(hs ? 1u : 0u);
+    K ck = c;
+    if (kp.total < (int)(8 * sizeof(K))) ck &= (K)(((K)1 << kp.total) - 1); // (a joint map's window index sits above the key bits)
+    key_s[i] = key_expand<K>(ck, kp);
 }
 // joint map: (window << total) | re-packed key -- the records of a window stay together, inside it the order is the key's
 template <class K>
@@ -133,42 +155,30 @@ __global__ void vox_pose_rel_kernel(int64_t F, int32_t *__restrict__ pose_idx, i
     const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (f < F) pose_idx[f] %= ws;
 }
-// head flags of the sorted records: bit 0 = first record of a root, bit 1 = first record of a (root, frame) segment
-// (ws > 0, joint map of several windows: a root is (window, key), window = frame / ws)
-__global__ void vox_heads_kernel(int64_t n, const uint64_t *__restrict__ key, const float4 *__restrict__ rec,
-                                 uint32_t *__restrict__ head_root, uint32_t *__restrict__ head_seg, int ws)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    bool hr = i == 0 || key[i] != key[i - 1];
-    if (ws > 0 && !hr) hr = (__float_as_int(rec[i].w) >> 6) / ws != (__float_as_int(rec[i - 1].w) >> 6) / ws;
-    const bool hs = hr || (__float_as_int(rec[i].w) >> 6) != (__float_as_int(rec[i - 1].w) >> 6);
-    head_root[i] = hr ? 1u : 0u;
-    head_seg[i] = hs ? 1u : 0u;
-}
-// root table and (root, frame) segment table from the heads and their inclusive scans
+// root table and (root, frame) segment table from the packed head flags (vox_gather_kernel) and their inclusive scan
 __global__ void vox_tables_kernel(int64_t n, const uint64_t *__restrict__ key, const float4 *__restrict__ rec,
-                                  const uint32_t *__restrict__ head_root, const uint32_t *__restrict__ incl_root,
-                                  const uint32_t *__restrict__ head_seg, const uint32_t *__restrict__ incl_seg,
+                                  const uint64_t *__restrict__ heads, const uint64_t *__restrict__ incl,
                                   uint64_t *__restrict__ root_key, uint32_t *__restrict__ root_seg,
                                   uint32_t *__restrict__ seg_start, uint32_t *__restrict__ seg_root,
                                   int32_t *__restrict__ seg_frame)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (head_seg[i]) {
-        const uint32_t sg = incl_seg[i] - 1;
+    const uint64_t hd = heads[i], in = incl[i];
+    const uint32_t in_root = (uint32_t)(in >> 32), in_seg = (uint32_t)in;
+    if (hd & 1u) {
+        const uint32_t sg = in_seg - 1;
         seg_start[sg] = (uint32_t)i;
-        seg_root[sg] = incl_root[i] - 1;
+        seg_root[sg] = in_root - 1;
         seg_frame[sg] = __float_as_int(rec[i].w) >> 6;
-        if (head_root[i]) {
-            root_key[incl_root[i] - 1] = key[i];
-            root_seg[incl_root[i] - 1] = sg;
+        if (hd >> 32) {
+            root_key[in_root - 1] = key[i];
+            root_seg[in_root - 1] = sg;
         }
     }
     if (i == n - 1) {
-        seg_start[incl_seg[i]] = (uint32_t)n;
-        root_seg[incl_root[i]] = incl_seg[i];
+        seg_start[in_seg] = (uint32_t)n;
+        root_seg[in_root] = in_seg;
     }
 }
 
@@ -247,11 +257,15 @@ __global__ void vox_seg_small_kernel(int64_t NS, const uint32_t *__restrict__ se
     segm1[sg] = a1;
     segm2[sg] = a2;
 }
-__global__ __launch_bounds__(64) void vox_seg_big_kernel(const uint32_t *__restrict__ seg_start, const float4 *__restrict__ rec,
+__global__ __launch_bounds__(64) void vox_seg_big_kernel(int64_t NS, const uint32_t *__restrict__ seg_start, const float4 *__restrict__ rec,
                                                          double *__restrict__ segcl, uint32_t *__restrict__ segm1,
                                                          uint64_t *__restrict__ segm2)
 {
+    // (one block per segment, most of which return at once.  A few thousand persistent blocks walking the segment table instead
+    // were measured in round 5: the octree phase 0.91 -> 1.27 ms -- the big segments are serial chains, and a block that walks fifty
+    // of them one after the other is what the launch then waits for.)
     const int64_t sg = blockIdx.x;
+    if (sg >= NS) return;
     const uint32_t b = seg_start[sg], e = seg_start[sg + 1];
     if (e - b < SEG_BIG) return;
     __shared__ double terms[64 * 9];
@@ -838,57 +852,43 @@ int32_t voxmap_build_impl(lvba_voxmap_s *h, const lvba_scans_s *sc, int frame_be
         if (h_err[0]) return lvba_fail(LVBA_ERR_ARG, "a point is non-finite or its voxel key exceeds +-2^20 after the pose transform");
         h->info.key_ms = now_ms() - t0; t0 = now_ms();
         const KeyPack kp = key_pack_of(h_err + 1);
-        if (ws) { // joint map: the window index above the re-packed key
-            if (kp.total + wbits > 64) return lvba_fail(LVBA_ERR_UNSUPPORTED, "joint map: %d key bits + %d window bits", kp.total, wbits);
-            if (kp.total + wbits <= 32) {
-                DevBuf k32(s), k32s(s);
-                HIPCHK(k32.alloc(4 * P)); HIPCHK(k32s.alloc(4 * P));
-                key_compress_win_kernel<uint32_t><<<grid_for(P, 256), 256, 0, s>>>(P, key.as<uint64_t>(), rec.as<float4>(), kp, ws, k32.as<uint32_t>());
-                HIPCHK(hipGetLastError());
-                TRY(sort_pairs(s, k32.as<uint32_t>(), k32s.as<uint32_t>(), idx.as<uint32_t>(), idx0.as<uint32_t>(), (size_t)P, (unsigned)(kp.total + wbits)));
-                vox_gather_kernel<uint32_t><<<grid_for(P, 256), 256, 0, s>>>(P, rec.as<float4>(), idx0.as<uint32_t>(), rec_s.as<float4>(), k32s.as<uint32_t>(), kp,
-                                                                             key_s.as<uint64_t>());
-            } else {
-                key_compress_win_kernel<uint64_t><<<grid_for(P, 256), 256, 0, s>>>(P, key.as<uint64_t>(), rec.as<float4>(), kp, ws, key.as<uint64_t>());
-                HIPCHK(hipGetLastError());
-                TRY(sort_pairs(s, key.as<uint64_t>(), key_s.as<uint64_t>(), idx.as<uint32_t>(), idx0.as<uint32_t>(), (size_t)P, (unsigned)(kp.total + wbits)));
-                vox_gather_kernel<uint64_t><<<grid_for(P, 256), 256, 0, s>>>(P, rec.as<float4>(), idx0.as<uint32_t>(), rec_s.as<float4>(), key_s.as<uint64_t>(), kp,
-                                                                             key_s.as<uint64_t>());
-            }
-        } else if (kp.total <= 32) {
+        // (the gather also writes the head flags of the sorted sequence: vox_gather_kernel)
+        DevBuf heads(s), incl(s);
+        HIPCHK(heads.alloc(8 * P)); HIPCHK(incl.alloc(8 * P));
+        const int64_t *foff = sc->d_frame_off + frame_begin;
+        uint64_t *keys_sorted = key_s.as<uint64_t>(); // the sorted keys in their 3 x 21-bit form
+        const unsigned sort_bits = (unsigned)(kp.total + (ws ? wbits : 0));
+        if (ws && sort_bits > 64) return lvba_fail(LVBA_ERR_UNSUPPORTED, "joint map: %d key bits + %d window bits", kp.total, wbits);
+        if (sort_bits <= 32) {
             DevBuf k32(s), k32s(s);
             HIPCHK(k32.alloc(4 * P)); HIPCHK(k32s.alloc(4 * P));
-            key_compress_kernel<uint32_t><<<grid_for(P, 256), 256, 0, s>>>(P, key.as<uint64_t>(), kp, k32.as<uint32_t>());
+            if (ws) key_compress_win_kernel<uint32_t><<<grid_for(P, 256), 256, 0, s>>>(P, key.as<uint64_t>(), rec.as<float4>(), kp, ws, k32.as<uint32_t>());
+            else key_compress_kernel<uint32_t><<<grid_for(P, 256), 256, 0, s>>>(P, key.as<uint64_t>(), kp, k32.as<uint32_t>());
             HIPCHK(hipGetLastError());
-            TRY(sort_pairs(s, k32.as<uint32_t>(), k32s.as<uint32_t>(), idx.as<uint32_t>(), idx0.as<uint32_t>(), (size_t)P, (unsigned)kp.total));
+            TRY(sort_pairs(s, k32.as<uint32_t>(), k32s.as<uint32_t>(), idx.as<uint32_t>(), idx0.as<uint32_t>(), (size_t)P, sort_bits));
             vox_gather_kernel<uint32_t><<<grid_for(P, 256), 256, 0, s>>>(P, rec.as<float4>(), idx0.as<uint32_t>(), rec_s.as<float4>(), k32s.as<uint32_t>(), kp,
-                                                                         key_s.as<uint64_t>());
-        } else { // wide maps: 64-bit keys, still only the bits that vary (compressed and expanded in place)
-            key_compress_kernel<uint64_t><<<grid_for(P, 256), 256, 0, s>>>(P, key.as<uint64_t>(), kp, key.as<uint64_t>());
+                                                                         keys_sorted, foff, nfr, heads.as<uint64_t>());
             HIPCHK(hipGetLastError());
-            TRY(sort_pairs(s, key.as<uint64_t>(), key_s.as<uint64_t>(), idx.as<uint32_t>(), idx0.as<uint32_t>(), (size_t)P, (unsigned)kp.total));
+            HIPCHK(hipStreamSynchronize(s)); // (k32 / k32s go back to the pool here)
+        } else { // wide maps: 64-bit keys, still only the bits that vary (compressed in place; expanded into the unsorted keys' buffer)
+            if (ws) key_compress_win_kernel<uint64_t><<<grid_for(P, 256), 256, 0, s>>>(P, key.as<uint64_t>(), rec.as<float4>(), kp, ws, key.as<uint64_t>());
+            else key_compress_kernel<uint64_t><<<grid_for(P, 256), 256, 0, s>>>(P, key.as<uint64_t>(), kp, key.as<uint64_t>());
+            HIPCHK(hipGetLastError());
+            TRY(sort_pairs(s, key.as<uint64_t>(), key_s.as<uint64_t>(), idx.as<uint32_t>(), idx0.as<uint32_t>(), (size_t)P, sort_bits));
+            keys_sorted = key.as<uint64_t>();
             vox_gather_kernel<uint64_t><<<grid_for(P, 256), 256, 0, s>>>(P, rec.as<float4>(), idx0.as<uint32_t>(), rec_s.as<float4>(), key_s.as<uint64_t>(), kp,
-                                                                         key_s.as<uint64_t>());
+                                                                         keys_sorted, foff, nfr, heads.as<uint64_t>());
+            HIPCHK(hipGetLastError());
         }
-        HIPCHK(hipGetLastError());
-
-        DevBuf head_root(s), head_seg(s), incl_root(s), incl_seg(s);
-        HIPCHK(head_root.alloc(4 * P)); HIPCHK(head_seg.alloc(4 * P)); HIPCHK(incl_root.alloc(4 * P)); HIPCHK(incl_seg.alloc(4 * P));
-        vox_heads_kernel<<<grid_for(P, 256), 256, 0, s>>>(P, key_s.as<uint64_t>(), rec_s.as<float4>(), head_root.as<uint32_t>(),
-                                                          head_seg.as<uint32_t>(), ws);
-        HIPCHK(hipGetLastError());
-        TRY(scan_incl<uint32_t>(s, head_root.as<uint32_t>(), incl_root.as<uint32_t>(), (size_t)P));
-        TRY(scan_incl<uint32_t>(s, head_seg.as<uint32_t>(), incl_seg.as<uint32_t>(), (size_t)P));
-        uint32_t last[2] = {0, 0};
-        HIPCHK(lvba::copy_d2h(&last[0], incl_root.as<uint32_t>() + (P - 1), 4));
-        HIPCHK(lvba::copy_d2h(&last[1], incl_seg.as<uint32_t>() + (P - 1), 4));
-        R = last[0]; NS = last[1];
+        // ONE inclusive scan numbers roots (high word) and (root, frame) segments (low word)
+        TRY(scan_incl<uint64_t>(s, heads.as<uint64_t>(), incl.as<uint64_t>(), (size_t)P));
+        uint64_t last = 0;
+        HIPCHK(lvba::copy_d2h(&last, incl.as<uint64_t>() + (P - 1), 8));
+        R = (int64_t)(last >> 32); NS = (int64_t)(last & 0xFFFFFFFFull);
         HIPCHK(root_key.alloc(8 * (size_t)R)); HIPCHK(root_seg.alloc(4 * ((size_t)R + 1)));
         HIPCHK(seg_start.alloc(4 * ((size_t)NS + 1))); HIPCHK(seg_root.alloc(4 * (size_t)NS)); HIPCHK(seg_frame.alloc(4 * (size_t)NS));
-        vox_tables_kernel<<<grid_for(P, 256), 256, 0, s>>>(P, key_s.as<uint64_t>(), rec_s.as<float4>(), head_root.as<uint32_t>(),
-                                                           incl_root.as<uint32_t>(), head_seg.as<uint32_t>(),
-                                                           incl_seg.as<uint32_t>(), root_key.as<uint64_t>(),
-                                                           root_seg.as<uint32_t>(), seg_start.as<uint32_t>(),
+        vox_tables_kernel<<<grid_for(P, 256), 256, 0, s>>>(P, keys_sorted, rec_s.as<float4>(), heads.as<uint64_t>(), incl.as<uint64_t>(),
+                                                           root_key.as<uint64_t>(), root_seg.as<uint32_t>(), seg_start.as<uint32_t>(),
                                                            seg_root.as<uint32_t>(), seg_frame.as<int32_t>());
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(s));
@@ -912,7 +912,7 @@ int32_t voxmap_build_impl(lvba_voxmap_s *h, const lvba_scans_s *sc, int frame_be
     HIPCHK(hipMemsetAsync(seg_split.as<uint32_t>() + NS, 0, 4, s));
     vox_seg_small_kernel<<<grid_for(NS, 64), 64, 0, s>>>(NS, seg_start.as<uint32_t>(), rec_s.as<float4>(), segcl.as<double>(),
                                                          segm1.as<uint32_t>(), segm2.as<uint64_t>());
-    vox_seg_big_kernel<<<(unsigned)NS, 64, 0, s>>>(seg_start.as<uint32_t>(), rec_s.as<float4>(), segcl.as<double>(),
+    vox_seg_big_kernel<<<(unsigned)NS, 64, 0, s>>>(NS, seg_start.as<uint32_t>(), rec_s.as<float4>(), segcl.as<double>(),
                                                    segm1.as<uint32_t>(), segm2.as<uint64_t>());
     HIPCHK(hipGetLastError());
     RootArgs ra{};
