@@ -261,9 +261,10 @@ __global__ __launch_bounds__(64) void vox_seg_big_kernel(int64_t NS, const uint3
                                                          double *__restrict__ segcl, uint32_t *__restrict__ segm1,
                                                          uint64_t *__restrict__ segm2)
 {
-    // (one block per segment, most of which return at once.  A few thousand persistent blocks walking the segment table instead
-    // were measured in round 5: the octree phase 0.91 -> 1.27 ms -- the big segments are serial chains, and a block that walks fifty
-    // of them one after the other is what the launch then waits for.)
+    // (one block per segment, most of which return at once.  Measured in round 5 and withdrawn: a few thousand persistent blocks
+    // walking the segment table -- the octree phase 0.91 -> 1.27 ms: the big segments are serial chains, and a block that walks
+    // fifty of them one after the other is what the launch then waits for --, and four segments per block, one wavefront each:
+    // 0.91 -> 1.01 ms.)
     const int64_t sg = blockIdx.x;
     if (sg >= NS) return;
     const uint32_t b = seg_start[sg], e = seg_start[sg + 1];
