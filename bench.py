@@ -869,7 +869,7 @@ def kernel_sets(info):
     return ev, (["balm_voxel_kernel"] if info["trial_linearised"] else ["balm_cost_kernel"])
 
 
-TRAFFIC_FILE = os.path.join("profiles", "traffic_r04.json")
+TRAFFIC_FILE = os.path.join("profiles", "traffic_r05.json")
 KERNEL_SOURCES = ["balm_kernels.hip", "balm_math.h", "lvba_internal.h", "lvba_api.hip", "block_system.hip", "pair_lists.hip",
                   "host_tables.h"]
 

@@ -34,3 +34,9 @@ timeout 900 python bench.py --config C4 --steps 10 --warmup 2 --no-visual --no-f
 tail -c 400 $O/bench_c2.json; echo; tail -c 400 $O/bench_c4_1gpu.json; echo; tail -3 $O/bench_c4.err
 LVBA_TIMING=vis timeout 300 python tools/visual_bench.py 2000 5 > $O/visual_bench.json 2> $O/visual_bench.err; tail -c 300 $O/visual_bench.json
 timeout 300 python tools/window_bench.py 320 100000 20 1 > $O/window_bench.json 2> $O/window_bench.err; tail -c 200 $O/window_bench.json; echo
+# the solver on graphs that are not the BASELINE ring (band / nested dissection), and a kernel trace of a dissected solve
+timeout 900 python tools/graph_bench.py > $O/graph_bench.json 2> $O/graph_bench.err; tail -c 300 $O/graph_bench.json; echo
+cd /tmp; rm -rf /tmp/ndp
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/ndp -o nd -- python $R/tools/nd_probe.py 10000 3 > $O/nd_probe_under_rocprof.json 2>&1
+python $R/tools/rocpd_stats.py /tmp/ndp/nd_results.db $O/nd_kernel_stats.csv > /dev/null; grep -E "step2|nd_|ldlt_fwd" $O/nd_kernel_stats.csv | cut -c1-70,120-190
+cd $R
