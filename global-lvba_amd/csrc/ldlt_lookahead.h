@@ -82,6 +82,8 @@ struct Step2Args {
     // at once and the later blocks count from resv_n less.  Measured on the two-problem launch of config C3: the chain workgroup
     // 79 900 -> 59 600 cycles (what it takes alone), the launch 37.9 -> 29.6 us.  Placement is a matter of speed only: wherever
     // the blocks land, every tile is still done exactly once.  resv_n = 0: off.
+    // (Round 5, measured and withdrawn: the second half of the ROW workgroups on the seats next to the first half -- rows next to
+    // rows, bulk tiles next to bulk tiles, where today every row shares its CU with a bulk tile: C3 solve 4.11 -> 4.17 ms.)
     int resv_at, resv_n;
     FwdPassenger fwd;
 };
