@@ -8,7 +8,11 @@
 //   * a block column is turned into L only when all its contributions are in; a diagonal block is factorised only then;
 //   * the roles of X_p find block column p + 1 holding exactly the panels <= p - 2; no contribution is applied twice;
 //   * every L / Z / G / side copy that is read was produced by an EARLIER launch;
-//   * at the end every contribution has been applied (Schur complement complete when the phase closes early).
+//   * at the end every contribution has been applied (Schur complement complete when the phase closes early);
+//   * BUFFER LIFETIMES of ldlt.hip's run_phase: Z of panel k lives in slot k % 4 of a ring that X_{k+4} overwrites -- every launch
+//     that reads Z_k (the roles as Z_q, the bulk jobs as Z_o / Z_e) must come before X_{k+4}, and not be X_{k+4} itself; the side
+//     copy of A(p+1, p) and panel q's ready-made share of the diagonal block alternate between two slots by panel parity -- a
+//     reader must find the panel it expects in its slot.
 // usage: ldlt_schedule_check   (runs a list of geometries incl. config C3's: n = 12000, half-bandwidth 2597)
 #include <cstdio>
 #include <cstdlib>
@@ -34,6 +38,16 @@ struct Model {
     std::map<int64_t, int> diag_done, side_copy, dq_made; // dq_made[q]: row 1 of X_q left L(q+2, q) Z(q+2, q)^T for X_{q+1}'s chain
     std::set<std::pair<int64_t, int64_t>> written, readL;
     int now = 0;
+    int64_t cur_p = -1;                    // panel of the last roles launch enqueued (the one that owns Z slot cur_p % 4 now)
+    int64_t side_slot[2] = {-1, -1}, dq_slot[2] = {-1, -1}; // which panel's side copy / diagonal share each of the two slots holds
+    void needZ(int64_t k)
+    {
+#ifndef LVBA_ZRING
+#define LVBA_ZRING 4 // (ldlt.hip: Zbuf[st % 4]; -DLVBA_ZRING=3 must FAIL: the schedule needs all four slots)
+#endif
+        CHECK(cur_p - k <= LVBA_ZRING - 1, "Z_%lld read in launch %d after X_%lld took its ring slot (current roles panel %lld)", (long long)k, now,
+              (long long)(k + 4), (long long)cur_p);
+    }
 
     Model(int64_t nf_, int64_t bw_) : nf(nf_), bw(bw_)
     {
@@ -79,11 +93,14 @@ struct Model {
             if (L.kind == 0) {
                 CHECK(complete(L.p, L.p), "first diagonal block %lld incomplete", (long long)L.p);
                 diag_done[L.p] = now;
-                if (Tof(L.p) > 0) { CHECK(complete(L.p + 1, L.p), "side tile incomplete"); side_copy[L.p] = now; }
+                if (Tof(L.p) > 0) { CHECK(complete(L.p + 1, L.p), "side tile incomplete"); side_copy[L.p] = now; side_slot[L.p % 2] = L.p; }
                 continue;
             }
             if (L.roles) {
                 const int64_t p = L.p, q = p - 1;
+                cur_p = p; // (this launch writes Z slot p % 4: a job of the same launch must not read Z_{p-4})
+                if (Tof(p) >= 2) CHECK(side_slot[p % 2] == p, "launch X_%lld finds the side copy of panel %lld in its slot", (long long)p, (long long)side_slot[p % 2]);
+                if (L.has_q) needZ(q);
                 CHECK(diag_done.count(p) && diag_done[p] < now, "G_%lld not there for launch %d", (long long)p, now);
                 CHECK(L.has_q == (p > sa), "has_q");
                 for (int64_t t = 0; t < Tof(p); ++t) {
@@ -98,12 +115,19 @@ struct Model {
                         needL(p + 1, q);
                         apply(i, p + 1, q);
                         // the chain workgroup (t = 0) takes panel q's share of the diagonal block from what row 1 of X_q left
-                        if (t == 0) CHECK(dq_made.count(q) && dq_made[q] < now, "launch %d: no ready-made share of panel %lld for block %lld", now, (long long)q, (long long)(p + 1));
+                        if (t == 0) {
+                            CHECK(dq_made.count(q) && dq_made[q] < now, "launch %d: no ready-made share of panel %lld for block %lld", now, (long long)q, (long long)(p + 1));
+                            CHECK(dq_slot[q % 2] == q, "X_%lld's chain finds panel %lld's share in the slot of panel %lld's", (long long)p, (long long)dq_slot[q % 2], (long long)q);
+                        }
                     }
                     if (t >= 1) CHECK(side_copy.count(p) && side_copy[p] < now, "side copy of A(%lld,%lld) missing", (long long)(p + 1), (long long)p);
                     apply(i, p + 1, p);
                     write(i, p + 1);
-                    if (t == 1) { CHECK(complete(i, p + 1), "side copy taken of an incomplete tile"); side_copy[p + 1] = now; dq_made[p] = now; }
+                    if (t == 1) {
+                        CHECK(complete(i, p + 1), "side copy taken of an incomplete tile");
+                        side_copy[p + 1] = now; dq_made[p] = now;
+                        side_slot[(p + 1) % 2] = p + 1; dq_slot[p % 2] = p; // (written at the END of the launch: the readers above have passed)
+                    }
                     if (L.q_extra && t >= 1 && i <= q + Tof(q)) { // block column p + 2 from panel q, by the row that holds L(i, q)
                         CHECK(L.has_q, "q_extra without q");
                         needL(i, q);
@@ -122,6 +146,9 @@ struct Model {
                 const SchedJob &J = L.job[jn];
                 const int64_t o = J.o, e = o - 1, Tb = Tof(o) - 1;
                 CHECK(J.ca >= 0 && J.cb <= Tb && J.ca < J.cb, "job columns [%lld,%lld) of %lld", (long long)J.ca, (long long)J.cb, (long long)Tb);
+                needZ(o);
+                CHECK(!(L.roles && o == L.p), "a job reads Z of the panel its own launch is writing");
+                if (J.pair) needZ(e);
                 for (int64_t tj = J.ca; tj < J.cb; ++tj) {
                     const int64_t j = o + 2 + tj;
                     for (int64_t i = j; i <= o + Tof(o); ++i) {

@@ -75,6 +75,12 @@ def test_ldlt_lookahead_schedule(tmp_path):
     subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "ldlt_schedule_check.cpp"), "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and "ldlt schedule ok" in r.stdout, r.stdout[-3000:]
+    # buffer lifetimes are part of the model (the ring of four Z buffers, the two side-copy / diagonal-share slots of ldlt.hip's
+    # run_phase): with one Z slot fewer the same schedule must be refused
+    exe3 = str(tmp_path / "ldlt_schedule_check_ring3")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DLVBA_ZRING=3", os.path.join(ROOT, "tests", "ldlt_schedule_check.cpp"), "-o", exe3])
+    r3 = subprocess.run([exe3], capture_output=True, text=True)
+    assert r3.returncode != 0 and "ring slot" in r3.stdout, r3.stdout[-2000:]
 
 
 def test_key_repacking_keeps_order_and_round_trips(tmp_path):
