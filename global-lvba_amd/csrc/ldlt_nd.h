@@ -118,7 +118,9 @@ __global__ __launch_bounds__(256, 2) void nd_schur_kernel(const double *__restri
 }
 // (A 128 x 128 tile per workgroup, 64 x 64 per wavefront -- twice the arithmetic per LDS read -- was measured in round 5 and is
 // SLOWER: 1.59 against 0.73 ms at n = 5 100, s = 1 818.  The border has a few dozen tile columns: 120 tiles of 128 leave half the
-// chip idle where 435 tiles of 64 fill it.)
+// chip idle where 435 tiles of 64 fill it.  Cutting the arc's rows into slices so that 128 x 128 tiles fill the chip again (partial
+// sums added in slice order) did not help either: 5.0 against 4.3 ms at n = 29 000 -- 312 registers, one wavefront per SIMD, and the
+// row chunks' loads are not hidden.  This kernel re-reads Y ~ 30 times (12.9 GB at that size: it is bound by those bytes).)
 
 // The separator system's block store and gradient from the Hessian store: S(I, J) + u diag, as ldlt_solve's fill expects it
 // (the damping is applied HERE: the solve runs with u = 0, because the Schur complements must not be damped).  include = 0:
