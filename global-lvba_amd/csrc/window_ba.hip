@@ -103,6 +103,31 @@ __global__ void wba_compact_kernel(int64_t P, const uint32_t *__restrict__ flag,
     out[3 * (int64_t)o + 2] = merged[3 * (int64_t)s + 2];
 }
 
+// joint form of the merge stage (all windows in one pass): (code of the point's window << total) | re-packed leaf key -- the
+// points of a window stay together, inside it the order is the leaf key's, as in the window's own sort.  code[window]: its rank
+// among the windows that produce an anchor cloud; the others' points get the code above all of those and sort to the end.
+template <class K>
+__global__ void wba_compress_win_kernel(int64_t P, const uint64_t *key, const int64_t *__restrict__ frame_off, int n_frames, int ws,
+                                        const uint32_t *__restrict__ code, const KeyPack kp, K *out /* may be key */)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const int64_t base = frame_off[0];
+    int lo = 0, hi = n_frames;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (frame_off[mid] - base <= i) lo = mid; else hi = mid;
+    }
+    const uint64_t c = code[lo / ws];
+    out[i] = (K)((c << kp.total) | key_compress<uint64_t>(key[i], kp)); // (in 64 bits, narrowed afterwards: key_pack.h)
+}
+// anchor points of every window: the scan of the leader flags read at the windows' bounds in the sorted sequence
+__global__ void wba_bounds_kernel(int n, const int64_t *__restrict__ at, const uint32_t *__restrict__ excl, uint32_t *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = excl[at[i]];
+}
+
 inline void mat3_mul(const double *A, const double *B, double *C)
 {
     for (int r = 0; r < 3; ++r)
@@ -186,9 +211,10 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
     //      most of the time -- launch and synchronisation latency);
     //   2. the LM refinements of ALL windows in lock-step as one grouped problem (lvba_balm_set_groups /
     //      lvba_balm_refine_groups: one evaluation, one band factorisation with a damping value per window, one cost pass per
-    //      iteration for all windows; every window keeps its own LM state).  lm_mode = 1 (or LVBA_WINDOW_BATCH=0), a single
+    //      iteration for all windows; every window keeps its own LM state).  lm_mode = 1, a single
     //      window, or a broken pivot in the joint factorisation: one window at a time, as before;
-    //   3. alignment, relative poses, anchor merge + down-sampling per window (host threads again).
+    //   3. alignment, relative poses, anchor merge + down-sampling: all windows in one pass (stage_finish_joint), or per window
+    //      on the host threads again.
     // Results are assembled in window order below.
     struct WinResult { int32_t rc = LVBA_OK; std::string err; lvba_window_info info{}; lvba::hvec<double> x, rel; float *d_out = nullptr; int64_t n_out = 0;
                        lvba_voxmap_t map = nullptr; bool refined = false; };
@@ -336,14 +362,11 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
         return LVBA_OK;
     };
     // ---- stage 3: alignment (:268-279), relative poses (:284-299), merge + down_sampling_voxel2 on the device
-    auto stage_finish = [&](int wi, hipStream_t s, WinResult &R) -> int32_t {
+    auto align_window = [&](int wi, WinResult &R) {
         int start, cw;
         win_range(wi, start, cw);
-        lvba_window_info &info = R.info;
-        if (info.skipped) return LVBA_OK;
         const double *x_odom = poses + 12 * (int64_t)start;
         lvba::hvec<double> &x = R.x;
-        double tw = now_ms();
         lvba::hvec<double> &rel = R.rel;
         rel.assign(12 * (size_t)cw, 0.0);
         const double *Ro0 = x_odom, *po0 = x_odom + 9;
@@ -369,6 +392,15 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
             const double d[3] = {pa[0] - po0[0], pa[1] - po0[1], pa[2] - po0[2]};
             for (int r = 0; r < 3; ++r) rj[9 + r] = Ro0[r] * d[0] + Ro0[3 + r] * d[1] + Ro0[6 + r] * d[2];
         }
+    };
+    auto stage_finish = [&](int wi, hipStream_t s, WinResult &R) -> int32_t {
+        int start, cw;
+        win_range(wi, start, cw);
+        lvba_window_info &info = R.info;
+        if (info.skipped) return LVBA_OK;
+        double tw = now_ms();
+        align_window(wi, R);
+        lvba::hvec<double> &rel = R.rel;
         // merge + down_sampling_voxel2 on the device
         const int64_t p_begin = sc->frame_off[start], P = sc->frame_off[start + cw] - p_begin;
         const bool down = o.anchor_leaf >= 0.001 && P > 0; // tools.hpp:303
@@ -536,6 +568,147 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
         }
         return true;
     };
+    // ---- stage 3 for all windows at once, as stage 1: the points of every window moved by their frames' relative poses in one
+    // launch, ONE sort by (window, leaf key), one pick / scan / compaction -- straight into the anchor scan set's point array, whose
+    // frames are the windows' runs of the compacted sequence (their bounds in the SORTED sequence are the windows' point counts:
+    // known on the host).  A window's anchor cloud is bit for bit what its own pass gives: the same fp32 points, the same leaf keys,
+    // the same order inside a leaf (the sort is stable and a window's points keep their order), the leaves in key order.  Per window
+    // the stage was seventeen launches and five waits on the host.  Same switch and the same memory rule as the joint map.
+    float *joint_pts = nullptr; // [anchor points of all windows][3], allocated like a scan set's d_pts
+    auto stage_finish_joint = [&]() -> bool {
+        static const bool on = [] { const char *e = getenv("LVBA_WINDOW_JOINT_MAP"); return !(e && !strcmp(e, "0")); }();
+        const int64_t p_begin = sc->frame_off[0], P = sc->frame_off[(size_t)n] - p_begin;
+        if (!on || n_win < 2 || !(o.anchor_leaf >= 0.001) || P <= 0 || P >= ((int64_t)1 << 32)) return false;
+        {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return false; }
+            if ((double)P * 96.0 > 0.5 * (double)free_b) return false;
+        }
+        const double tw = now_ms();
+        // codes, relative poses of all frames, the windows' bounds in the sorted sequence
+        lvba::hvec<uint32_t> code((size_t)n_win);
+        lvba::hvec<int64_t> at;
+        lvba::hvec<double> rel_all(12 * (size_t)n);
+        int G = 0;
+        for (int wi = 0; wi < n_win; ++wi)
+            if (!results[(size_t)wi].info.skipped) ++G;
+        if (G == 0) return false;
+        at.push_back(0);
+        for (int wi = 0, g = 0; wi < n_win; ++wi) {
+            WinResult &R = results[(size_t)wi];
+            int start, cw;
+            win_range(wi, start, cw);
+            if (R.info.skipped) {
+                code[(size_t)wi] = (uint32_t)G;
+                for (int j = 0; j < cw; ++j) memcpy(rel_all.data() + 12 * (size_t)(start + j), I12, sizeof I12);
+                continue;
+            }
+            code[(size_t)wi] = (uint32_t)g++;
+            align_window(wi, R);
+            memcpy(rel_all.data() + 12 * (size_t)start, R.rel.data(), 96 * (size_t)cw);
+            at.push_back(at.back() + (sc->frame_off[(size_t)(start + cw)] - sc->frame_off[(size_t)start]));
+        }
+        const int64_t P_live = at.back();
+        const int cbits = G < n_win ? 32 - __builtin_clz((unsigned)G) : (G > 1 ? 32 - __builtin_clz((unsigned)(G - 1)) : 0);
+        const bool jt = getenv("LVBA_TIMING") != nullptr;
+        double tj = now_ms();
+        auto jm = [&](const char *what) { // (LVBA_TIMING: waits for the stream at every mark)
+            if (!jt) return;
+            (void)hipStreamSynchronize(s);
+            const double t = now_ms();
+            fprintf(stderr, "[window_ba merge] %-18s %.3f ms\n", what, t - tj);
+            tj = t;
+        };
+        auto body = [&]() -> int32_t {
+            jm("align (host)");
+            DevBuf d_rel(s), d_code(s), d_at(s), d_cnt(s), merged(s), key(s), d2(s), idx(s), d_err(s), d_part(s);
+            HIPCHK(d_rel.alloc(96 * (size_t)n)); HIPCHK(d_code.alloc(4 * (size_t)n_win)); HIPCHK(d_at.alloc(8 * ((size_t)G + 1)));
+            HIPCHK(d_cnt.alloc(4 * ((size_t)G + 1))); HIPCHK(merged.alloc(12 * (size_t)P)); HIPCHK(d_err.alloc(28));
+            HIPCHK(key.alloc(8 * (size_t)P)); HIPCHK(d2.alloc(8 * (size_t)P)); HIPCHK(idx.alloc(4 * (size_t)P));
+            const int64_t n_slots = key_range_slots(P, 256);
+            HIPCHK(d_part.alloc(24 * (size_t)n_slots));
+            HIPCHK(lvba::copy_h2d(d_rel.p, rel_all.data(), 96 * (size_t)n)); // (pageable sources: synchronous copies)
+            HIPCHK(lvba::copy_h2d(d_code.p, code.data(), 4 * (size_t)n_win));
+            HIPCHK(lvba::copy_h2d(d_at.p, at.data(), 8 * ((size_t)G + 1)));
+            HIPCHK(hipMemsetAsync(d_err.p, 0, 28, s));
+            jm("alloc + tables");
+            wba_merge_kernel<<<grid_for(P, 256), 256, 0, s>>>(P, sc->d_pts + 3 * p_begin, sc->d_frame_off, n, d_rel.as<double>(), o.anchor_leaf,
+                                                              merged.as<float>(), key.as<uint64_t>(), d2.as<double>(), idx.as<uint32_t>(),
+                                                              d_err.as<int>(), d_part.as<int>());
+            HIPCHK(hipGetLastError());
+            key_range_reduce_kernel<<<key_range_reduce_grid(n_slots), 256, 0, s>>>(n_slots, d_part.as<int>(), d_err.as<int>() + 1);
+            HIPCHK(hipGetLastError());
+            int h_err[7] = {0};
+            HIPCHK(hipStreamSynchronize(s));
+            HIPCHK(lvba::copy_d2h(h_err, d_err.p, 28));
+            if (h_err[0]) return LVBA_ERR_ARG; // (the per-window passes name the window)
+            jm("merge + range");
+            const KeyPack kp = key_pack_of(h_err + 1);
+            const unsigned bits = (unsigned)(kp.total + cbits);
+            if (bits > 64) return LVBA_ERR_UNSUPPORTED;
+            DevBuf key_s(s), order(s), flag(s), excl(s), pick(s);
+            HIPCHK(key_s.alloc(8 * (size_t)P)); HIPCHK(order.alloc(4 * (size_t)P)); HIPCHK(flag.alloc(4 * ((size_t)P_live + 1)));
+            HIPCHK(excl.alloc(4 * ((size_t)P_live + 1))); HIPCHK(pick.alloc(4 * (size_t)std::max<int64_t>(P_live, 1)));
+            if (bits <= 32) {
+                DevBuf k32(s);
+                HIPCHK(k32.alloc(4 * (size_t)P));
+                wba_compress_win_kernel<uint32_t><<<grid_for(P, 256), 256, 0, s>>>(P, key.as<uint64_t>(), sc->d_frame_off, n, w, d_code.as<uint32_t>(),
+                                                                                   kp, k32.as<uint32_t>());
+                HIPCHK(hipGetLastError());
+                TRY(sort_pairs(s, k32.as<uint32_t>(), key_s.as<uint32_t>(), idx.as<uint32_t>(), order.as<uint32_t>(), (size_t)P, bits));
+                if (P_live > 0)
+                    wba_pick_kernel<uint32_t><<<grid_for(P_live, 256), 256, 0, s>>>(P_live, key_s.as<uint32_t>(), order.as<uint32_t>(), d2.as<double>(),
+                                                                                    flag.as<uint32_t>(), pick.as<uint32_t>());
+            } else {
+                wba_compress_win_kernel<uint64_t><<<grid_for(P, 256), 256, 0, s>>>(P, key.as<uint64_t>(), sc->d_frame_off, n, w, d_code.as<uint32_t>(),
+                                                                                   kp, key.as<uint64_t>());
+                HIPCHK(hipGetLastError());
+                TRY(sort_pairs(s, key.as<uint64_t>(), key_s.as<uint64_t>(), idx.as<uint32_t>(), order.as<uint32_t>(), (size_t)P, bits));
+                if (P_live > 0)
+                    wba_pick_kernel<uint64_t><<<grid_for(P_live, 256), 256, 0, s>>>(P_live, key_s.as<uint64_t>(), order.as<uint32_t>(), d2.as<double>(),
+                                                                                    flag.as<uint32_t>(), pick.as<uint32_t>());
+            }
+            HIPCHK(hipGetLastError());
+            jm("sort + pick");
+            HIPCHK(hipMemsetAsync(flag.as<uint32_t>() + P_live, 0, 4, s));
+            TRY(scan_excl<uint32_t>(s, flag.as<uint32_t>(), excl.as<uint32_t>(), (size_t)P_live + 1));
+            wba_bounds_kernel<<<grid_for(G + 1, 256), 256, 0, s>>>(G + 1, d_at.as<int64_t>(), excl.as<uint32_t>(), d_cnt.as<uint32_t>());
+            HIPCHK(hipGetLastError());
+            lvba::hvec<uint32_t> cnt((size_t)G + 1);
+            HIPCHK(hipStreamSynchronize(s));
+            HIPCHK(lvba::copy_d2h(cnt.data(), d_cnt.p, 4 * ((size_t)G + 1)));
+            const int64_t n_all = cnt[(size_t)G];
+            jm("scan + counts");
+            hipError_t e = hipMalloc((void **)&joint_pts, n_all ? 12 * (size_t)n_all : 8);
+            if (e != hipSuccess) { (void)hipGetLastError(); joint_pts = nullptr; return LVBA_ERR_NOMEM; }
+            jm("hipMalloc (cloud)");
+            if (P_live > 0) {
+                wba_compact_kernel<<<grid_for(P_live, 256), 256, 0, s>>>(P_live, flag.as<uint32_t>(), excl.as<uint32_t>(), pick.as<uint32_t>(),
+                                                                         merged.as<float>(), joint_pts);
+                HIPCHK(hipGetLastError());
+            }
+            HIPCHK(hipStreamSynchronize(s));
+            jm("compact");
+            const double per = (now_ms() - tw) / G;
+            for (int wi = 0; wi < n_win; ++wi) {
+                WinResult &R = results[(size_t)wi];
+                if (R.info.skipped) continue;
+                const uint32_t g = code[(size_t)wi];
+                R.d_out = nullptr;
+                R.n_out = (int64_t)cnt[(size_t)g + 1] - (int64_t)cnt[(size_t)g];
+                R.info.n_anchor_points = R.n_out;
+                R.info.merge_ms = per;
+            }
+            return LVBA_OK;
+        };
+        const int32_t rc = body();
+        if (rc != LVBA_OK) {
+            if (joint_pts) { (void)hipFree(joint_pts); joint_pts = nullptr; }
+            if (getenv("LVBA_TIMING")) fprintf(stderr, "[window_ba] joint merge not taken (rc %d): one pass per window\n", rc);
+            return false;
+        }
+        return true;
+    };
     const bool timing = getenv("LVBA_TIMING") != nullptr; // stage times of the whole call to stderr
     double tmark = now_ms();
     auto mark = [&](const char *what) {
@@ -559,7 +732,7 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
         for (auto &q : results) any_failed = any_failed || q.rc < 0;
         mark(done ? "LM, all windows" : "LM, one by one");
     }
-    if (!any_failed) run_stage(stage_finish);
+    if (!any_failed && !stage_finish_joint()) run_stage(stage_finish);
     free_maps();
     mark("align + merge");
     for (int wi = 0; wi < n_win; ++wi) { // assemble in window order
@@ -567,6 +740,7 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
         if (R.rc < 0) {
             for (auto &q : results) if (q.d_out) DevicePool::get().free(q.d_out);
             clouds.clear();
+            if (joint_pts) (void)hipFree(joint_pts);
             return lvba_fail(R.rc, "%s", R.err.c_str());
         }
     }
@@ -585,15 +759,17 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
     }
     // the anchor clouds as a scan set of their own
     lvba_scans_s *out = new (std::nothrow) lvba_scans_s();
-    if (!out) { free_clouds(); return lvba_fail(LVBA_ERR_NOMEM, "host allocation failed"); }
+    if (!out) { free_clouds(); if (joint_pts) (void)hipFree(joint_pts); return lvba_fail(LVBA_ERR_NOMEM, "host allocation failed"); }
     out->device = sc->device;
     out->n_frames = (int)clouds.size();
     out->frame_off.assign(clouds.size() + 1, 0);
     for (size_t a = 0; a < clouds.size(); ++a) out->frame_off[a + 1] = out->frame_off[a] + clouds[a].n;
     const int64_t PT = out->frame_off.back();
-    hipError_t e = hipMalloc((void **)&out->d_pts, PT ? 12 * (size_t)PT : 8);
+    hipError_t e = hipSuccess;
+    if (joint_pts) out->d_pts = joint_pts; // (stage_finish_joint: the windows' clouds already lie one after the other)
+    else e = hipMalloc((void **)&out->d_pts, PT ? 12 * (size_t)PT : 8);
     if (e == hipSuccess) e = hipMalloc((void **)&out->d_frame_off, 8 * (clouds.size() + 1));
-    for (size_t a = 0; a < clouds.size() && e == hipSuccess; ++a)
+    for (size_t a = 0; a < clouds.size() && e == hipSuccess && !joint_pts; ++a)
         if (clouds[a].n > 0)
             e = hipMemcpy(out->d_pts + 3 * out->frame_off[a], clouds[a].d, 12 * (size_t)clouds[a].n, hipMemcpyDeviceToDevice);
     if (e == hipSuccess)

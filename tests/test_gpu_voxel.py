@@ -320,7 +320,8 @@ np.savez(sys.argv[2], off=off, idx=idx, cl=cl, key=key, wp=w["window_poses"], n=
 
 def test_joint_window_map_changes_no_byte(tmp_path):
     """LVBA_WINDOW_JOINT_MAP=0 builds one voxel map per window (what a scan set too large for one joint map falls back to); the
-    default builds ONE map whose roots are (window, key) and hands the windows views into it.  Same order, same sums either way:
+    default builds ONE map whose roots are (window, key) and hands the windows views into it, and merges + down-samples the anchor
+    clouds of all windows in one pass sorted by (window, leaf key) (window_ba.hip: stage_finish_joint).  Same order, same sums either way:
     the map and the whole window stage (refined window poses, anchor clouds point for point) are identical byte for byte."""
     import os
     import subprocess
