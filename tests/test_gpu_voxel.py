@@ -307,18 +307,25 @@ sys.path.insert(0, sys.argv[1])
 pkg = importlib.import_module("global-lvba_amd")
 synth = importlib.import_module("global-lvba_amd.synth")
 s = synth.make_scans(8, 20000, room=(20, 14, 5), origin=(-12.5, 33.1, 1.2), n_panels=8, seed=31)
-with pkg.Scans(s["clouds"]) as scans:
+clouds = list(s["clouds"])
+if sys.argv[3] == "skip":                 # the middle window sees volume noise only: no plane voxels, no anchor
+    rng = np.random.default_rng(4)
+    for f in (3, 4, 5):
+        clouds[f] = (rng.uniform(-1, 1, (500, 3)) + np.array([-12.5, 33.1, 1.2])).astype(np.float32)
+with pkg.Scans(clouds) as scans:
     with scans.voxel_map(s["poses"], 0.5) as m:
         off, idx, cl, key = m.export()
     w = scans.window_ba(s["poses"], window_size=3, voxel_size=0.5, anchor_leaf=0.05)       # 3 + 3 + 2 frames
     anchors = [w["anchor_scans"].download(k) for k in range(w["anchor_scans"].n_frames)]
     w["anchor_scans"].close()
 np.savez(sys.argv[2], off=off, idx=idx, cl=cl, key=key, wp=w["window_poses"], n=np.array([len(a) for a in anchors]),
-         pts=np.concatenate(anchors))
+         pts=np.concatenate(anchors), rel=w["rel_poses"], ai=w["anchor_index"],
+         skipped=np.array([x["skipped"] for x in w["windows"]]))
 """
 
 
-def test_joint_window_map_changes_no_byte(tmp_path):
+@pytest.mark.parametrize("mode", ["plain", "skip"])
+def test_joint_window_map_changes_no_byte(tmp_path, mode):
     """LVBA_WINDOW_JOINT_MAP=0 builds one voxel map per window (what a scan set too large for one joint map falls back to); the
     default builds ONE map whose roots are (window, key) and hands the windows views into it, and merges + down-samples the anchor
     clouds of all windows in one pass sorted by (window, leaf key) (window_ba.hip: stage_finish_joint).  Same order, same sums either way:
@@ -332,11 +339,12 @@ def test_joint_window_map_changes_no_byte(tmp_path):
     out = []
     for i, v in enumerate([{}, {"LVBA_WINDOW_JOINT_MAP": "0"}]):
         f = tmp_path / f"o_{i}.npz"
-        r = subprocess.run([sys.executable, str(script), root, str(f)], env=dict(os.environ, **v), capture_output=True, text=True,
+        r = subprocess.run([sys.executable, str(script), root, str(f), mode], env=dict(os.environ, **v), capture_output=True, text=True,
                            timeout=600)
         assert r.returncode == 0, (v, r.stderr[-2000:])
         out.append(np.load(f))
     assert len(out[0]["off"]) > 100 and out[0]["n"].sum() > 1000
+    assert out[0]["skipped"].tolist() == ([0, 1, 0] if mode == "skip" else [0, 0, 0])   # (skipped windows' points sort behind the others')
     for o in out[1:]:
         for k in out[0].files:
             np.testing.assert_array_equal(out[0][k], o[k], err_msg=k)
