@@ -320,7 +320,7 @@ static int32_t nd_alloc(BlockSys &bs, const NdPlan &pl)
         TRY(nd_alloc_mat(bs, A.n, 6 * (int64_t)pa.Bb + 5, A.A, &A.d_A, &A.work, true));
         if (A.nsep > 0) {
             TRY(dm(&A.B, A.n * A.ldb)); TRY(dm(&A.Y, A.n * A.ldb)); TRY(dm(&A.Sa, A.ldb * A.ldb));
-            TRY(dm(&A.wv, A.n)); TRY(dm(&A.gpart, ND_GS_SLICES * A.ldb));
+            TRY(dm(&A.wv, 2 * A.n)); TRY(dm(&A.gpart, ND_GS_SLICES * A.ldb));
             HIPCHK(hipMemsetAsync(A.B, 0, (size_t)(A.n * A.ldb) * sizeof(double), bs.stream)); // (the pad columns stay zero)
             HIPCHK(hipMemsetAsync(A.Y, 0, (size_t)(A.n * A.ldb) * sizeof(double), bs.stream));
             TRY(bs_dmalloc(bs, &A.sep, A.nsep));

@@ -44,8 +44,9 @@ __global__ void nd_border_fill_kernel(const double *__restrict__ Hblk, int64_t N
 }
 
 // wv[k + c] = sum_m G_p[m][c] b[k + m]  (one workgroup per panel): D^-1 L^-1 b, what the separator's right-hand side needs
-__global__ __launch_bounds__(256) void nd_w_kernel(const double *__restrict__ Gall, const double *__restrict__ b, int64_t n,
-                                                   double *__restrict__ wv)
+// (and rd = 1 / d for nd_schur_kernel: with sixteen fp64 divisions per thread and row chunk it took 4.32 instead of 4.10 ms at n = 29 000)
+__global__ __launch_bounds__(256) void nd_w_kernel(const double *__restrict__ Gall, const double *__restrict__ b, const double *__restrict__ dvec,
+                                                   int64_t n, double *__restrict__ wv, double *__restrict__ rd)
 {
     __shared__ double red[4][64];
     const int64_t k = 64 * (int64_t)blockIdx.x;
@@ -57,7 +58,10 @@ __global__ __launch_bounds__(256) void nd_w_kernel(const double *__restrict__ Ga
     for (int m = 16 * q; m < 16 * q + 16; ++m) s += m < nbe ? G[m * 64 + c] * b[k + m] : 0.0;
     red[q][c] = s;
     __syncthreads();
-    if (threadIdx.x < nbe) wv[k + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (threadIdx.x < nbe) {
+        wv[k + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        rd[k + threadIdx.x] = 1.0 / dvec[k + threadIdx.x];
+    }
 }
 
 // gpart[slice][jj] = sum over the slice's rows of Y[r][jj] wv[r]   (grid: ldb / 64 x ND_GS_SLICES)
@@ -75,8 +79,8 @@ __global__ __launch_bounds__(256) void nd_gs_kernel(const double *__restrict__ Y
     if (threadIdx.x < 64) gpart[(int64_t)blockIdx.y * ldb + j] = red[0][jj] + red[1][jj] + red[2][jj] + red[3][jj];
 }
 
-// Sa(i, j) = sum_r Y[r][i] Y[r][j] / d_r for the lower 64 x 64 tiles (ti >= tj), column j at Sa + j ldb
-__global__ __launch_bounds__(256, 2) void nd_schur_kernel(const double *__restrict__ Y, const double *__restrict__ dvec, int64_t n,
+// Sa(i, j) = sum_r Y[r][i] Y[r][j] rd_r (rd = 1 / d: nd_w_kernel) for the lower 64 x 64 tiles (ti >= tj), column j at Sa + j ldb
+__global__ __launch_bounds__(256, 2) void nd_schur_kernel(const double *__restrict__ Y, const double *__restrict__ rd, int64_t n,
                                                           int64_t ldb, double *__restrict__ Sa)
 {
     __shared__ double lds[LVBA_K3_LDS];
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void nd_schur_kernel(const double *__restri
             const int64_t r = rc + w + 4 * it;
             const bool ok = r < n;
             yi[it] = ok ? Y[r * ldb + i0 + row] : 0.0;
-            yj[it] = ok ? Y[r * ldb + j0 + row] / dvec[r] : 0.0;
+            yj[it] = ok ? Y[r * ldb + j0 + row] * rd[r] : 0.0;
         }
     };
     fetch(0);
@@ -120,7 +124,9 @@ __global__ __launch_bounds__(256, 2) void nd_schur_kernel(const double *__restri
 // SLOWER: 1.59 against 0.73 ms at n = 5 100, s = 1 818.  The border has a few dozen tile columns: 120 tiles of 128 leave half the
 // chip idle where 435 tiles of 64 fill it.  Cutting the arc's rows into slices so that 128 x 128 tiles fill the chip again (partial
 // sums added in slice order) did not help either: 5.0 against 4.3 ms at n = 29 000 -- 312 registers, one wavefront per SIMD, and the
-// row chunks' loads are not hidden.  This kernel re-reads Y ~ 30 times (12.9 GB at that size: it is bound by those bytes).)
+// row chunks' loads are not hidden.  This kernel requests Y ~ 30 times (12.9 GB at that size, 3.1 TB/s); a blocked tile order that lets
+// an XCD's 55 tiles share 11 - 26 of the 29 column panels instead of all of them changed nothing (4.46 against 4.32 ms): the tiles march
+// through Y's rows together, a 64-row slab of Y is under 1 MB, and the panels come out of L2 either way.)
 
 // The separator system's block store and gradient from the Hessian store: S(I, J) + u diag, as ldlt_solve's fill expects it
 // (the damping is applied HERE: the solve runs with u = 0, because the Schur complements must not be damped).  include = 0:
@@ -225,10 +231,11 @@ int32_t nd_solve(NdSys &nd, const double *Hblk, int32_t N, const double *g, cons
             const double *Gall = ldlt_work_G(A.work), *dvec = ldlt_work_d(A.n, A.work);
             const unsigned nct = (unsigned)(A.ldb / 64);
             const unsigned np = (unsigned)((A.n + LVBA_NB - 1) / LVBA_NB);
-            hipLaunchKernelGGL(nd_w_kernel, dim3(np), dim3(256), 0, as, Gall, (const double *)ldlt_work_b(A.n, A.work), A.n, A.wv);
+            hipLaunchKernelGGL(nd_w_kernel, dim3(np), dim3(256), 0, as, Gall, (const double *)ldlt_work_b(A.n, A.work), dvec, A.n, A.wv, A.wv + A.n);
             hipLaunchKernelGGL(nd_gs_kernel, dim3(nct, ND_GS_SLICES), dim3(256), 0, as, (const double *)A.Y, (const double *)A.wv, A.n,
                                A.ldb, A.gpart);
-            hipLaunchKernelGGL(nd_schur_kernel, dim3(nct * (nct + 1) / 2), dim3(256), 0, as, (const double *)A.Y, dvec, A.n, A.ldb, A.Sa);
+            hipLaunchKernelGGL(nd_schur_kernel, dim3(nct * (nct + 1) / 2), dim3(256), 0, as, (const double *)A.Y, (const double *)(A.wv + A.n), A.n, A.ldb,
+                               A.Sa);
         }
         hipEventRecord(A.done, as);
     }

@@ -115,7 +115,7 @@ struct NdArc {
     double *work;       // ldlt_solve's workspace: G, d, b
     double *B, *Y;      // [n][ldb] row-major: E_a^T as the forward substitution leaves it / L^-1 E_a^T
     double *Sa;         // [ldb][ldb], column j at Sa + j ldb: lower tiles of Y^T D^-1 Y
-    double *wv;         // [n]   G^T b, panel by panel (= D^-1 L^-1 b)
+    double *wv;         // [2][n] G^T b, panel by panel (= D^-1 L^-1 b); 1 / d
     double *gpart;      // [ND_GS_SLICES][ldb] partial sums of Y^T wv
     int32_t *sep;       // [nsep] separator-local pose indices, ascending (device)
     int *status;
