@@ -94,19 +94,28 @@ __global__ __launch_bounds__(256, 2) void nd_schur_kernel(const double *__restri
     d4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
-    double yi[16], yj[16];
+    // fetch() only loads -- from a clamped row, unconditionally: rows past the end are masked and the 1 / d factor is applied when the
+    // chunk is staged, one product later.  (With the mask and the factor applied where the values were loaded, the compiler waited
+    // for every row's loads in turn: sixteen memory round trips per chunk, 4.10 instead of 3.30 ms at n = 29 000, s = 1 818.)
+    double yi[16], yj[16], rv[16];
     auto fetch = [&](int64_t rc) {
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
-            const int64_t r = rc + w + 4 * it;
-            const bool ok = r < n;
-            yi[it] = ok ? Y[r * ldb + i0 + row] : 0.0;
-            yj[it] = ok ? Y[r * ldb + j0 + row] * rd[r] : 0.0;
+            const int64_t r = rc + w + 4 * it, rr = r < n ? r : n - 1;
+            yi[it] = Y[rr * ldb + i0 + row];
+            yj[it] = Y[rr * ldb + j0 + row];
+            rv[it] = rd[rr];
         }
     };
     fetch(0);
     for (int64_t rc = 0; rc < n; rc += 64) {
         if (rc) __syncthreads(); // everybody has left the tiles of the chunk before
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const bool ok = rc + w + 4 * it < n;
+            yi[it] = ok ? yi[it] : 0.0;
+            yj[it] = ok ? yj[it] * rv[it] : 0.0;
+        }
         stage_tile(Ls, yi, w, row);
         stage_tile(Zs, yj, w, row);
         __syncthreads();
