@@ -273,7 +273,13 @@ __device__ __forceinline__ void bulk_tile_128(double *lds, LdltMat M, const Pane
     auto products = [&](int ch) { // the chunk in LDS.  The operands of step k0 + 4 are read before the MFMAs of step k0 are issued: a
                                   // wavefront issues in order, and reads placed after them only start when the matrix pipe is draining
         if (!busy) return;
-        const double *Ls = lds, *Zs = Ls + 32 * LVBA_TL;
+        // (an offset the compiler cannot see through: the sixteen LDS addresses of a chunk's k-steps are then formed per chunk instead of
+        // being kept in registers across the whole tile -- with them the kernel needed 258 registers, and the reload of a spilled one,
+        // placed behind the prefetch of the next chunk, made the first products of every tile wait for that prefetch to arrive:
+        // C3 solve 4.10 -> 4.03 ms on the same box)
+        int lo = 0;
+        asm volatile("" : "+v"(lo));
+        const double *Ls = lds + lo, *Zs = Ls + 32 * LVBA_TL;
         double a[2][4], bv[2][2];
         auto rd = [&](int k0, int q) {
 #pragma unroll
