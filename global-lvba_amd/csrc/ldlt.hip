@@ -202,6 +202,7 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
             a.M = second ? M2 : M; a.sA = tw.sA; a.sW = tw.sW; a.ldz = ldz; a.nprob = (int)ny;
             a.roles = L.roles; a.has_q = L.has_q; a.do_diag = L.do_diag; a.q_extra = L.q_extra; a.status = status;
             a.dvec = dvec + wo; a.b = b + wo;
+            a.stamp_id = L.roles ? (int)L.p : -1; a.stamp_prob = second ? 1 : 0;
             int64_t nwg = 0;
             if (L.roles) {
                 a.p = pg(L.p);
@@ -319,5 +320,20 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
 }
 
 #include "ldlt_nd.h"
+
+#ifdef LVBA_STAMPS
+} // namespace lvba
+// (debug builds only) the stamp arrays of ldlt_lookahead.h, roles then bulk, to host memory; returns the number of words
+extern "C" int64_t lvba_debug_stamps(unsigned long long *out, int64_t cap)
+{
+    const int64_t n1 = (int64_t)LVBA_ST_LAUNCHES * LVBA_ST_ROLES * LVBA_ST_MARKS, n2 = (int64_t)LVBA_ST_LAUNCHES * LVBA_ST_BULK * 2;
+    if (!out || cap < n1 + n2) return n1 + n2;
+    hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(lvba::g_lvba_stamps), (size_t)n1 * 8) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out + n1, HIP_SYMBOL(lvba::g_lvba_bulk_stamps), (size_t)n2 * 8) != hipSuccess) return -2;
+    return n1 + n2;
+}
+namespace lvba {
+#endif
 
 } // namespace lvba

@@ -27,6 +27,25 @@
 
 struct PanelGeo { int64_t k, w0, rend; int nbe, T; };
 
+// -DLVBA_STAMPS (tools/build_variant.py stamps -DLVBA_STAMPS; never in the shipped library): wall-clock marks (s_memrealtime) of
+// the role workgroups and the first / last instruction of every bulk workgroup, per launch, read back through
+// lvba_debug_stamps (ldlt.hip) by tools/step_stamps.py.
+#ifdef LVBA_STAMPS
+#define LVBA_ST_LAUNCHES 256
+#define LVBA_ST_ROLES 96   // problem * 48 + role index
+#define LVBA_ST_MARKS 12
+#define LVBA_ST_BULK 640
+__device__ unsigned long long g_lvba_stamps[LVBA_ST_LAUNCHES][LVBA_ST_ROLES][LVBA_ST_MARKS];
+__device__ unsigned long long g_lvba_bulk_stamps[LVBA_ST_LAUNCHES][LVBA_ST_BULK][2];
+#define LVBA_STAMP(A_, prob_, role_, m_)                                                                                          \
+    do {                                                                                                                          \
+        if (threadIdx.x == 0 && (A_).stamp_id >= 0 && (A_).stamp_id < LVBA_ST_LAUNCHES && (role_) < 48)                            \
+            g_lvba_stamps[(A_).stamp_id][(prob_) * 48 + (role_)][m_] = __builtin_amdgcn_s_memrealtime();                          \
+    } while (0)
+#else
+#define LVBA_STAMP(A_, prob_, role_, m_) do { } while (0)
+#endif
+
 // one trailing-update job of a launch: panel o alone (rank 64) or together with its partner e = o - 1 (rank 128), the 128 x 64
 // tiles of the tile columns [ca, cb) in bulk coordinates (tile column tj' <-> block column o + 2 + tj'); 64 x 64 form: the tiles
 // [ca, cb) of the column-major enumeration
@@ -85,6 +104,7 @@ struct Step2Args {
     // (Round 5, measured and withdrawn: the second half of the ROW workgroups on the seats next to the first half -- rows next to
     // rows, bulk tiles next to bulk tiles, where today every row shares its CU with a bulk tile: C3 solve 4.11 -> 4.17 ms.)
     int resv_at, resv_n;
+    int stamp_id, stamp_prob; // (LVBA_STAMPS builds: slot of this launch in the stamp arrays; problem of a one-problem launch)
     FwdPassenger fwd;
 };
 
@@ -140,27 +160,46 @@ __device__ __forceinline__ void put_acc(double *T, const d4 (&acc)[4], int w, in
         for (int t = 0; t < 4; ++t) T[c * LVBA_TS + 16 * t + i] = acc[t][reg] * sc;
     }
 }
-// tile rows [r0, r0 + 64) x the 64 columns of a panel (column kc + m), rows >= rlim and columns >= nbe read as zero
+// tile rows [r0, r0 + 64) x the 64 columns of a panel (column kc + m), rows >= rlim and columns >= nbe read as zero.
+// The loads are UNCONDITIONAL -- what lies past the window or the panel's last column is inside the allocation (block_system.hip
+// leaves the slack; ldlt.hip's workspace likewise) -- and edge tiles are masked afterwards: written as `cond ? load : 0` every one of
+// a role's 64 first loads sat behind its own exec-mask branch and 64-bit multiply, and a row workgroup spent 4.8 us REQUESTING them
+// (stamps, round 6: start 0.6 us, last request 5.4 us, data there 5.6 us).
+__device__ __forceinline__ void mask_tile(double (&v)[16], bool whole, bool rok, int nbe, int w)
+{
+    if (whole) return; // block-uniform
+#pragma unroll
+    for (int it = 0; it < 16; ++it) v[it] = (rok && w + 4 * it < nbe) ? v[it] : 0.0;
+}
 __device__ __forceinline__ void load_panel_tile(const LdltMat &M, int64_t r0, int64_t kc, int64_t rlim, int nbe, int w, int row,
                                                 double (&v)[16])
 {
-    const int64_t r = r0 + row;
+    const double *__restrict__ base = M.a + (r0 + row) + (kc + w) * M.ld;
+    const int64_t step = 4 * M.ld;
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        const int m = w + 4 * it;
-        v[it] = (r < rlim && m < nbe) ? M.a[r + (kc + m) * M.ld] : 0.0;
-    }
+    for (int it = 0; it < 16; ++it) v[it] = base[it * step];
+    mask_tile(v, r0 + 64 <= rlim && nbe == 64, r0 + row < rlim, nbe, w);
 }
 // the same rows of a panel's Z buffer (row r at r - w0)
 __device__ __forceinline__ void load_z_tile(const double *__restrict__ Z, int64_t ldz, int64_t r0, int64_t w0, int64_t rlim, int nbe,
                                             int w, int row, double (&v)[16])
 {
-    const int64_t r = r0 + row;
+    const double *__restrict__ base = Z + (r0 + row - w0) + w * ldz;
+    const int64_t step = 4 * ldz;
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        const int m = w + 4 * it;
-        v[it] = (r < rlim && m < nbe) ? Z[(r - w0) + m * ldz] : 0.0;
-    }
+    for (int it = 0; it < 16; ++it) v[it] = base[it * step];
+    mask_tile(v, r0 + 64 <= rlim && nbe == 64, r0 + row < rlim, nbe, w);
+}
+// a product's result layout (acc[t][reg] <-> row R0 + 16 t + i, column C0 + 16 w + kk + 4 reg) <-> global memory: the C tile's
+// entries, loaded unconditionally (the caller masks what it must), and the stores of an inner tile without a branch per entry
+__device__ __forceinline__ void load_c_tile(const LdltMat &M, int64_t R0, int64_t C0, int w, int i, int kk, double (&cv)[16])
+{
+    const double *__restrict__ base = M.a + (R0 + i) + (C0 + 16 * w + kk) * M.ld;
+    const int64_t step = 4 * M.ld;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) cv[4 * t + reg] = base[16 * t + reg * step];
 }
 // y_k and the rows' share of the forward substitution, common to both roles.  Before: Zs = G[m][j], pad BK = b_k, DP = d_p.
 __device__ __forceinline__ void fwd_partial_y(double *lds, const double *Zs, int w, int row)
@@ -176,11 +215,68 @@ __device__ __forceinline__ double red4(double *lds, int j)
            pad_at(lds, LVBA_PAD_RED + 192 + j);
 }
 
+// L(tile, p) and Z(tile, p) = L D to global memory straight from the product's registers (16 lanes = 128 contiguous bytes of a
+// column); a tile wholly inside the window without a branch per entry
+__device__ __forceinline__ void store_lz_tile(const LdltMat &M, const PanelGeo &p, int64_t R0, const d4 (&accL)[4], double *lds,
+                                              double *__restrict__ Zp, int64_t ldz, int w, int i, int kk)
+{
+    double *__restrict__ lb = M.a + (R0 + i) + (p.k + 16 * w + kk) * M.ld;
+    double *__restrict__ zb = Zp + (R0 + i - p.w0) + (16 * w + kk) * ldz;
+    const int64_t ls = 4 * M.ld, zs = 4 * ldz;
+    if (R0 + 64 <= p.rend && p.nbe == 64) { // block-uniform
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const double dc = pad_at(lds, LVBA_PAD_DP + 16 * w + kk + 4 * reg);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                lb[16 * t + reg * ls] = accL[t][reg];
+                zb[16 * t + reg * zs] = accL[t][reg] * dc;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int c = 16 * w + kk + 4 * reg;
+        const double dc = pad_at(lds, LVBA_PAD_DP + c);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (R0 + 16 * t + i < p.rend && c < p.nbe) {
+                lb[16 * t + reg * ls] = accL[t][reg];
+                zb[16 * t + reg * zs] = accL[t][reg] * dc;
+            }
+        }
+    }
+}
+// C tile (rows R0.., columns C0..) = cv - acc, entries with row < rlim, column < clim (and row >= column if `lower`); an inner
+// tile without a branch per entry
+__device__ __forceinline__ void store_c_tile(const LdltMat &M, int64_t R0, int64_t C0, int64_t rlim, int64_t clim, bool lower,
+                                             const double (&cv)[16], const d4 (&acc)[4], int w, int i, int kk)
+{
+    double *__restrict__ base = M.a + (R0 + i) + (C0 + 16 * w + kk) * M.ld;
+    const int64_t step = 4 * M.ld;
+    if (R0 + 64 <= rlim && C0 + 64 <= clim && (!lower || R0 >= C0 + 63)) { // block-uniform
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) base[16 * t + reg * step] = cv[4 * t + reg] - acc[t][reg];
+        return;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int64_t rr = R0 + 16 * t + i, c = C0 + 16 * w + kk + 4 * reg;
+            if (rr < rlim && c < clim && (!lower || rr >= c)) base[16 * t + reg * step] = cv[4 * t + reg] - acc[t][reg];
+        }
+}
+
 // ---------------------------------------------------------------------------------------------- the chain role
 __device__ __forceinline__ void chain_role(double *lds, const LdltMat &M, const Step2Args &A, const double *__restrict__ Gp,
                                            double *__restrict__ Gn, double *__restrict__ dvec, double *__restrict__ b,
-                                           double *__restrict__ Zp, const double *__restrict__ Zq, const double *__restrict__ dq_r)
+                                           double *__restrict__ Zp, const double *__restrict__ Zq, const double *__restrict__ dq_r, int st_prob)
 {
+    LVBA_STAMP(A, st_prob, 0, 0);
     double *Ls = lds, *Zs = lds + 64 * LVBA_TS;
     const PanelGeo &p = A.p, &q = A.q;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, row = tid & 63, i = lane & 15, kk = lane >> 4;
@@ -216,6 +312,7 @@ __device__ __forceinline__ void chain_role(double *lds, const LdltMat &M, const 
         __syncthreads();
     }
     const int nbn = A.nbe_next;
+    LVBA_STAMP(A, st_prob, 0, 8); // (loads requested)
     stage_tile(Ls, a1, w, row);
     stage_tile(Zs, gp, w, row);
     if (tid < 64) {
@@ -223,38 +320,29 @@ __device__ __forceinline__ void chain_role(double *lds, const LdltMat &M, const 
         pad_at(lds, LVBA_PAD_DP + tid) = dk;
     }
     __syncthreads();
+    LVBA_STAMP(A, st_prob, 0, 1);
     fwd_partial_y(lds, Zs, w, row);
     tile_product(Ls, Zs, w, i, kk, accL); // accL[t][reg] = L[row 16 t + i][column 16 w + kk + 4 reg]
     __syncthreads();
+    LVBA_STAMP(A, st_prob, 0, 2);
     // the block itself, as the products' result layout has it: cv[4 t + reg] <-> (r0 + 16 t + i, r0 + 16 w + kk + 4 reg).  ALL of
     // it (a band narrower than a tile leaves rows of the block outside panel p's window; they still belong to the block).
     // Requested here: it is needed after the last product, whose 2 us cover the way from L2 / HBM.
     double cv[16];
+    load_c_tile(M, r0, r0, w, i, kk, cv);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int cl = 16 * w + kk + 4 * reg, rl = 16 * t + i;
-            cv[4 * t + reg] = (rl < nbn && cl <= rl) ? M.a[(r0 + rl) + (r0 + cl) * M.ld] : 0.0;
+            cv[4 * t + reg] = (rl < nbn && cl <= rl) ? cv[4 * t + reg] : 0.0;
         }
     put_acc(Ls, accL, w, i, kk, nullptr); // L(p+1,p) as [m][row]
     put_acc(Zs, accL, w, i, kk, lds);     // Z = L D
     if (tid < 64) pad_at(lds, LVBA_PAD_YS + tid) = (tid < p.nbe) ? red4(lds, tid) * dk : 0.0;
-    // L and Z leave for global memory straight from the product's registers (16 lanes = 128 contiguous bytes of a column)
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-        const int c = 16 * w + kk + 4 * reg;
-        const double dc = pad_at(lds, LVBA_PAD_DP + c);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int64_t rr = r0 + 16 * t + i;
-            if (rr < p.rend && c < p.nbe) {
-                M.a[rr + (p.k + c) * M.ld] = accL[t][reg];
-                Zp[(rr - p.w0) + c * A.ldz] = accL[t][reg] * dc;
-            }
-        }
-    }
+    store_lz_tile(M, p, r0, accL, lds, Zp, A.ldz, w, i, kk); // L and Z leave for global memory
     __syncthreads();
+    LVBA_STAMP(A, st_prob, 0, 3);
     { // b[r] -= L[row] . y_p, four lanes per row
         double sacc = 0.0;
 #pragma unroll
@@ -263,6 +351,7 @@ __device__ __forceinline__ void chain_role(double *lds, const LdltMat &M, const 
     }
     tile_product(Ls, Zs, w, i, kk, acc);
     __syncthreads();
+    LVBA_STAMP(A, st_prob, 0, 4);
     if (tid < 64 && r < p.rend) b[r] -= red4(lds, tid);
     if (!A.do_diag) { // the phase ends here: the updated block goes back to the matrix
 #pragma unroll
@@ -290,10 +379,13 @@ __device__ __forceinline__ void chain_role(double *lds, const LdltMat &M, const 
             W[c * LVBA_W1S + 64 + rr] = (c == rr) ? 1.0 : 0.0;
         }
     __syncthreads();
+    LVBA_STAMP(A, st_prob, 0, 5);
     diag_blocked_factor(lds, nbn, A.status);
-    const double *dvs = lds + 64 * LVBA_W1S + 256 + 16 * LVBA_Z1S;
+    LVBA_STAMP(A, st_prob, 0, 6);
+    const double *dvs = lds + LVBA_K1B_DVS;
     if (tid < nbn) dvec[p.w0 + tid] = dvs[tid];
     for (int e = tid; e < 4096; e += 256) Gn[e] = W[(e & 63) * LVBA_W1S + 64 + (e >> 6)];
+    LVBA_STAMP(A, st_prob, 0, 7);
 }
 
 // ---------------------------------------------------------------------------------------------- the row role
@@ -301,8 +393,9 @@ __device__ __forceinline__ void chain_role(double *lds, const LdltMat &M, const 
 __device__ __forceinline__ void row_role(double *lds, const LdltMat &M, const Step2Args &A, int64_t t_row, const double *__restrict__ Gp,
                                          const double *__restrict__ dvec, double *__restrict__ b, double *__restrict__ Zp,
                                          const double *__restrict__ Zq, const double *__restrict__ side_r, double *__restrict__ side_w,
-                                         double *__restrict__ dq_w)
+                                         double *__restrict__ dq_w, int st_prob)
 {
+    LVBA_STAMP(A, st_prob, (int)t_row, 0);
     double *Ls = lds, *Zs = lds + 64 * LVBA_TS;
     const PanelGeo &p = A.p, &q = A.q;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, row = tid & 63, i = lane & 15, kk = lane >> 4;
@@ -310,51 +403,50 @@ __device__ __forceinline__ void row_role(double *lds, const LdltMat &M, const St
     const int64_t s0 = p.w0;                             // rows of tile p + 1 = columns of the updated tile
     const bool use_q = A.has_q && r0 < q.rend;           // the row lies inside panel q's window (block-uniform)
     double va[16], vb[16], ai[16], gp[16];
+    double bk = 0.0, dk = 0.0;
+    // panel p's operands: requested at once if there is no panel q to apply first, else behind the staging of panel q's tiles
+    // (they arrive under that product; requested together with them, 128 registers of operands were in flight at once and the
+    // C tile of the q_extra product was spilled as it arrived, one memory round trip after the other)
+    auto load_p = [&]() {
+        load_panel_tile(M, r0, p.k, p.rend, p.nbe, w, row, ai);      // A(i, p)
+#pragma unroll
+        for (int it = 0; it < 16; ++it) gp[it] = Gp[tid + 256 * it];
+        if (tid < p.nbe) { bk = b[p.k + tid]; dk = dvec[p.k + tid]; }
+    };
     if (use_q) {
         load_panel_tile(M, r0, q.k, q.rend, q.nbe, w, row, va);      // L(i, q)
         load_z_tile(Zq, A.ldz, s0, q.w0, q.rend, q.nbe, w, row, vb); // Z(p+1, q)
-    }
-    load_panel_tile(M, r0, p.k, p.rend, p.nbe, w, row, ai);          // A(i, p)
-#pragma unroll
-    for (int it = 0; it < 16; ++it) gp[it] = Gp[tid + 256 * it];
-    const double bk = (tid < p.nbe) ? b[p.k + tid] : 0.0;
-    const double dk = (tid < p.nbe) ? dvec[p.k + tid] : 0.0;
+    } else
+        load_p();
     d4 acc[4], accI[4], acc0[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = accI[t] = acc0[t] = (d4){0.0, 0.0, 0.0, 0.0};
+    LVBA_STAMP(A, st_prob, (int)t_row, 8); // (loads requested)
     if (use_q) {
         stage_tile(Ls, va, w, row);
         stage_tile(Zs, vb, w, row);
+        LVBA_STAMP(A, st_prob, (int)t_row, 9); // (first tiles there and staged)
         const bool qx = A.q_extra && !(A.qx_helper && t_row == 1); // (row 1's tile of block column p + 2: qx_diag_role, if there is one)
         if (qx) load_z_tile(Zq, A.ldz, s0 + 64, q.w0, q.rend, q.nbe, w, row, vb); // Z(p+2, q)
         __syncthreads();
+        if (!qx) load_p();
         tile_product(Ls, Zs, w, i, kk, acc);
         __syncthreads();
         if (qx) { // block column p + 2 from panel q alone: this row's tile, with L(i, q) still in LDS
             stage_tile(Zs, vb, w, row);
             double c2[16];
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int64_t c = s0 + 64 + 16 * w + kk + 4 * reg, rr = r0 + 16 * t + i;
-                    c2[4 * t + reg] = (rr < q.rend && c < q.rend && rr >= c) ? M.a[rr + c * M.ld] : 0.0;
-                }
+            load_c_tile(M, r0, s0 + 64, w, i, kk, c2); // (unmasked: what is not stored below is not used)
             __syncthreads();
             d4 accx[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) accx[t] = (d4){0.0, 0.0, 0.0, 0.0};
+            load_p();
             tile_product(Ls, Zs, w, i, kk, accx);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int64_t c = s0 + 64 + 16 * w + kk + 4 * reg, rr = r0 + 16 * t + i;
-                    if (rr < q.rend && c < q.rend && rr >= c) M.a[rr + c * M.ld] = c2[4 * t + reg] - accx[t][reg];
-                }
+            store_c_tile(M, r0, s0 + 64, q.rend, q.rend, true, c2, accx, w, i, kk);
             __syncthreads();
         }
     }
+    LVBA_STAMP(A, st_prob, (int)t_row, 1);
 #pragma unroll
     for (int it = 0; it < 16; ++it) va[it] = side_r[(w + 4 * it) * 64 + row]; // A(p+1, p), for Z(p+1, p): the side copy
     stage_tile(Ls, ai, w, row);
@@ -364,9 +456,11 @@ __device__ __forceinline__ void row_role(double *lds, const LdltMat &M, const St
         pad_at(lds, LVBA_PAD_DP + tid) = dk;
     }
     __syncthreads();
+    LVBA_STAMP(A, st_prob, (int)t_row, 2);
     fwd_partial_y(lds, Zs, w, row);
     tile_product(Ls, Zs, w, i, kk, accI); // L(i, p)
     __syncthreads();
+    LVBA_STAMP(A, st_prob, (int)t_row, 3);
     stage_tile(Ls, va, w, row);           // G stays in Zs
     if (tid < 64) pad_at(lds, LVBA_PAD_YS + tid) = (tid < p.nbe) ? red4(lds, tid) * dk : 0.0;
     __syncthreads();
@@ -376,31 +470,22 @@ __device__ __forceinline__ void row_role(double *lds, const LdltMat &M, const St
     const bool mk_side = t_row == 1; // block-uniform
     const int64_t rlim = mk_side ? A.rend_next : p.rend;
     double cv[16];
+    load_c_tile(M, r0, s0, w, i, kk, cv);
+    if (!(r0 + 64 <= rlim && s0 + 64 <= rlim)) { // block-uniform: edge tiles
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int64_t c = s0 + 16 * w + kk + 4 * reg, rr = r0 + 16 * t + i;
-            cv[4 * t + reg] = (rr < rlim && c < rlim) ? M.a[rr + c * M.ld] : 0.0;
-        }
+            for (int reg = 0; reg < 4; ++reg)
+                cv[4 * t + reg] = (r0 + 16 * t + i < rlim && s0 + 16 * w + kk + 4 * reg < rlim) ? cv[4 * t + reg] : 0.0;
+    }
     tile_product(Ls, Zs, w, i, kk, acc0); // L(p+1, p)
     __syncthreads();
+    LVBA_STAMP(A, st_prob, (int)t_row, 4);
     put_acc(Ls, accI, w, i, kk, nullptr); // L(i, p) as [m][row]
     put_acc(Zs, acc0, w, i, kk, lds);     // Z(p+1, p) = L(p+1, p) D
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {   // L(i, p) and Z(i, p) to global memory, from the product's registers
-        const int c = 16 * w + kk + 4 * reg;
-        const double dc = pad_at(lds, LVBA_PAD_DP + c);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int64_t rr = r0 + 16 * t + i;
-            if (rr < p.rend && c < p.nbe) {
-                M.a[rr + (p.k + c) * M.ld] = accI[t][reg];
-                Zp[(rr - p.w0) + c * A.ldz] = accI[t][reg] * dc;
-            }
-        }
-    }
+    store_lz_tile(M, p, r0, accI, lds, Zp, A.ldz, w, i, kk); // L(i, p) and Z(i, p) to global memory
     __syncthreads();
+    LVBA_STAMP(A, st_prob, (int)t_row, 5);
     {
         double sacc = 0.0;
 #pragma unroll
@@ -409,17 +494,18 @@ __device__ __forceinline__ void row_role(double *lds, const LdltMat &M, const St
     }
     tile_product(Ls, Zs, w, i, kk, acc);
     __syncthreads();
+    LVBA_STAMP(A, st_prob, (int)t_row, 6);
     if (tid < 64 && r < p.rend) b[r] -= red4(lds, tid);
+    store_c_tile(M, r0, s0, p.rend, p.rend, false, cv, acc, w, i, kk);
+    if (mk_side) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int cl = 16 * w + kk + 4 * reg, rl = 16 * t + i;
-            const int64_t c = s0 + cl, rr = r0 + rl;
-            const double v = cv[4 * t + reg] - acc[t][reg];
-            if (rr < p.rend && c < p.rend) M.a[rr + c * M.ld] = v;
-            if (mk_side) side_w[cl * 64 + rl] = (rr < A.rend_next && cl < A.nbe_next) ? v : 0.0;
-        }
+            for (int reg = 0; reg < 4; ++reg) {
+                const int cl = 16 * w + kk + 4 * reg, rl = 16 * t + i;
+                side_w[cl * 64 + rl] = (r0 + rl < A.rend_next && cl < A.nbe_next) ? cv[4 * t + reg] - acc[t][reg] : 0.0;
+            }
+    }
     if (mk_side && dq_w) { // this panel's contribution to the NEXT launch's diagonal block (p+2, p+2), off that launch's chain:
                              // L(i, p) is in Ls; Z(i, p) = L(i, p) D takes Z(p+1, p)'s place
         put_acc(Zs, accI, w, i, kk, lds);
@@ -433,6 +519,7 @@ __device__ __forceinline__ void row_role(double *lds, const LdltMat &M, const St
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) dq_w[(16 * w + kk + 4 * reg) * 64 + 16 * t + i] = accP[t][reg];
     }
+    LVBA_STAMP(A, st_prob, (int)t_row, 7);
 }
 
 // ---------------------------------------------------------------------------------------------- row 1's q_extra tile, on its own
@@ -448,13 +535,7 @@ __device__ __forceinline__ void qx_diag_role(double *lds, const LdltMat &M, cons
     load_panel_tile(M, r0, q.k, q.rend, q.nbe, w, row, va);      // L(p+2, q)
     load_z_tile(Zq, A.ldz, r0, q.w0, q.rend, q.nbe, w, row, vb); // Z(p+2, q)
     double c2[16];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int64_t c = r0 + 16 * w + kk + 4 * reg, rr = r0 + 16 * t + i;
-            c2[4 * t + reg] = (rr < q.rend && c < q.rend && rr >= c) ? M.a[rr + c * M.ld] : 0.0;
-        }
+    load_c_tile(M, r0, r0, w, i, kk, c2); // (unmasked: what is not stored below is not used)
     stage_tile(Ls, va, w, row);
     stage_tile(Zs, vb, w, row);
     __syncthreads();
@@ -462,13 +543,7 @@ __device__ __forceinline__ void qx_diag_role(double *lds, const LdltMat &M, cons
 #pragma unroll
     for (int t = 0; t < 4; ++t) accx[t] = (d4){0.0, 0.0, 0.0, 0.0};
     tile_product(Ls, Zs, w, i, kk, accx);
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int64_t c = r0 + 16 * w + kk + 4 * reg, rr = r0 + 16 * t + i;
-            if (rr < q.rend && c < q.rend && rr >= c) M.a[rr + c * M.ld] = c2[4 * t + reg] - accx[t][reg];
-        }
+    store_c_tile(M, r0, r0, q.rend, q.rend, true, c2, accx, w, i, kk);
 }
 
 // ---------------------------------------------------------------------------------------------- the forward-substitution passengers
@@ -599,12 +674,24 @@ __global__ __launch_bounds__(256, 2) void ldlt_step2_kernel(const Step2Args A)
     if (bid < nfac) {
         if (bx == 0)
             chain_role(lds, M, A, A.Gp + wo, A.Gn + wo, A.dvec + wo, A.b + wo, A.Zp + wo, A.Zq ? A.Zq + wo : nullptr,
-                       A.dq_r ? A.dq_r + wo : nullptr);
+                       A.dq_r ? A.dq_r + wo : nullptr, prob + A.stamp_prob);
         else if (bx == A.p.T) qx_diag_role(lds, M, A, A.Zq ? A.Zq + wo : nullptr);
         else row_role(lds, M, A, bx, A.Gp + wo, A.dvec + wo, A.b + wo, A.Zp + wo, A.Zq ? A.Zq + wo : nullptr, A.side_r + wo, A.side_w + wo,
-                      A.dq_w ? A.dq_w + wo : nullptr);
+                      A.dq_w ? A.dq_w + wo : nullptr, prob + A.stamp_prob);
         return;
     }
+#ifdef LVBA_STAMPS
+    const int64_t st_bulk = bid - nfac;
+    if (threadIdx.x == 0 && A.stamp_id >= 0 && A.stamp_id < LVBA_ST_LAUNCHES && st_bulk < LVBA_ST_BULK)
+        g_lvba_bulk_stamps[A.stamp_id][st_bulk][0] = __builtin_amdgcn_s_memrealtime();
+    struct StampEnd {
+        const Step2Args &A; int64_t b;
+        __device__ ~StampEnd() {
+            if (threadIdx.x == 0 && A.stamp_id >= 0 && A.stamp_id < LVBA_ST_LAUNCHES && b < LVBA_ST_BULK)
+                g_lvba_bulk_stamps[A.stamp_id][b][1] = __builtin_amdgcn_s_memrealtime();
+        }
+    } st_end{A, st_bulk};
+#endif
     for (int j = 0; j < A.njobs; ++j) {
         const BulkJob &J = A.job[j];
         if (bx >= J.nwg) { bx -= J.nwg; continue; }

@@ -334,18 +334,29 @@ __device__ __forceinline__ void bulk_tile_128(double *lds, LdltMat M, const Pane
     }
     if (busy) {
         const bool inner = r0 + 128 <= po.rend && r0 > c0; // whole tile inside the window and below the diagonal
+        if (inner) { // (a branch of its own: with the test inside the loops every store sat behind ~15 instructions of mask logic)
 #pragma unroll
-        for (int cq = 0; cq < 4; ++cq)
+            for (int cq = 0; cq < 4; ++cq)
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const unsigned so = csoff + 8u * (unsigned)(16 * cq + 4 * reg) * ld;
-                const int64_t c = c0 + 16 * cq + kk + 4 * reg;
+                for (int reg = 0; reg < 4; ++reg) {
+                    const unsigned so = csoff + 8u * (unsigned)(16 * cq + 4 * reg) * ld;
 #pragma unroll
-                for (int tl = 0; tl < 2; ++tl) {
-                    const int64_t r = r0 + 32 * w + 16 * tl + i;
-                    if (inner || (r < po.rend && c < po.rend && r >= c))
-                        buf_st(rA, xa[16 * tl + 4 * cq + reg] - acc[tl][cq][reg], cvoff + 128u * tl, so);
+                    for (int tl = 0; tl < 2; ++tl) buf_st(rA, xa[16 * tl + 4 * cq + reg] - acc[tl][cq][reg], cvoff + 128u * tl, so);
                 }
-            }
+        } else {
+#pragma unroll
+            for (int cq = 0; cq < 4; ++cq)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const unsigned so = csoff + 8u * (unsigned)(16 * cq + 4 * reg) * ld;
+                    const int64_t c = c0 + 16 * cq + kk + 4 * reg;
+#pragma unroll
+                    for (int tl = 0; tl < 2; ++tl) {
+                        const int64_t r = r0 + 32 * w + 16 * tl + i;
+                        if (r < po.rend && c < po.rend && r >= c)
+                            buf_st(rA, xa[16 * tl + 4 * cq + reg] - acc[tl][cq][reg], cvoff + 128u * tl, so);
+                    }
+                }
+        }
     }
 }
