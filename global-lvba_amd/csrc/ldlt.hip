@@ -333,6 +333,25 @@ extern "C" int64_t lvba_debug_stamps(unsigned long long *out, int64_t cap)
     if (hipMemcpyFromSymbol(out + n1, HIP_SYMBOL(lvba::g_lvba_bulk_stamps), (size_t)n2 * 8) != hipSuccess) return -2;
     return n1 + n2;
 }
+extern "C" int64_t lvba_debug_bulk_marks(unsigned long long *out, int64_t cap)
+{
+    const int64_t n = (int64_t)LVBA_ST_LAUNCHES * LVBA_ST_BTILES * 12;
+    if (!out || cap < n) return n;
+    hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(lvba::g_lvba_bulk_marks), (size_t)n * 8) != hipSuccess) return -1;
+    return n;
+}
+namespace lvba { __global__ void debug_tick_kernel(unsigned long long *o) { o[0] = __builtin_amdgcn_s_memrealtime(); } }
+// the s_memrealtime counter now (its rate differs from box to box: the reader calibrates it against the host's clock)
+extern "C" unsigned long long lvba_debug_tick(void)
+{
+    unsigned long long *d = nullptr, h = 0;
+    if (hipMalloc(&d, 8) != hipSuccess) return 0;
+    hipLaunchKernelGGL(lvba::debug_tick_kernel, dim3(1), dim3(1), 0, 0, d);
+    hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
+    hipFree(d);
+    return h;
+}
 namespace lvba {
 #endif
 

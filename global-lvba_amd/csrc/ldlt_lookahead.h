@@ -37,6 +37,8 @@ struct PanelGeo { int64_t k, w0, rend; int nbe, T; };
 #define LVBA_ST_BULK 640
 __device__ unsigned long long g_lvba_stamps[LVBA_ST_LAUNCHES][LVBA_ST_ROLES][LVBA_ST_MARKS];
 __device__ unsigned long long g_lvba_bulk_stamps[LVBA_ST_LAUNCHES][LVBA_ST_BULK][2];
+#define LVBA_ST_BTILES 640
+__device__ unsigned long long g_lvba_bulk_marks[LVBA_ST_LAUNCHES][LVBA_ST_BTILES][12]; // phases inside the first bulk tiles (ldlt_tiles.h)
 #define LVBA_STAMP(A_, prob_, role_, m_)                                                                                          \
     do {                                                                                                                          \
         if (threadIdx.x == 0 && (A_).stamp_id >= 0 && (A_).stamp_id < LVBA_ST_LAUNCHES && (role_) < 48)                            \
@@ -111,6 +113,7 @@ struct Step2Args {
 // Scratch doubles in the PAD of the first [m][row] tile (LVBA_TS = 80 doubles per column of 64 rows: 16 spare behind each of the
 // 64 columns, which stage_tile / put_acc never touch): b_k, y_k, d_p and the partial sums of the role workgroups.
 __device__ __forceinline__ double &pad_at(double *lds, int idx) { return lds[(idx >> 4) * LVBA_TS + 64 + (idx & 15)]; }
+#define LVBA_FETCH(...) asm volatile("" ::__VA_ARGS__) // the values in scalar registers HERE: their kernel-argument loads leave in one batch (ldlt_step2_kernel)
 #define LVBA_PAD_BK 0
 #define LVBA_PAD_YS 64
 #define LVBA_PAD_DP 128
@@ -235,13 +238,14 @@ __device__ __forceinline__ void store_lz_tile(const LdltMat &M, const PanelGeo &
         }
         return;
     }
+    const int rl_lim = (int)(p.rend - R0 < 64 ? p.rend - R0 : 64);
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const int c = 16 * w + kk + 4 * reg;
         const double dc = pad_at(lds, LVBA_PAD_DP + c);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            if (R0 + 16 * t + i < p.rend && c < p.nbe) {
+            if (16 * t + i < rl_lim && c < p.nbe) {
                 lb[16 * t + reg * ls] = accL[t][reg];
                 zb[16 * t + reg * zs] = accL[t][reg] * dc;
             }
@@ -262,12 +266,14 @@ __device__ __forceinline__ void store_c_tile(const LdltMat &M, int64_t R0, int64
             for (int reg = 0; reg < 4; ++reg) base[16 * t + reg * step] = cv[4 * t + reg] - acc[t][reg];
         return;
     }
+    const int rl_lim = (int)(rlim - R0 < 64 ? rlim - R0 : 64), cl_lim = (int)(clim - C0 < 64 ? clim - C0 : 64); // tile-local, 32 bits
+    const int dd = lower ? (int)(C0 - R0 < -64 ? -64 : C0 - R0) : -64; // lower triangle: local row >= local column + dd
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            const int64_t rr = R0 + 16 * t + i, c = C0 + 16 * w + kk + 4 * reg;
-            if (rr < rlim && c < clim && (!lower || rr >= c)) base[16 * t + reg * step] = cv[4 * t + reg] - acc[t][reg];
+            const int rl = 16 * t + i, cl = 16 * w + kk + 4 * reg;
+            if (rl < rl_lim && cl < cl_lim && rl >= cl + dd) base[16 * t + reg * step] = cv[4 * t + reg] - acc[t][reg];
         }
 }
 
@@ -276,6 +282,8 @@ __device__ __forceinline__ void chain_role(double *lds, const LdltMat &M, const 
                                            double *__restrict__ Gn, double *__restrict__ dvec, double *__restrict__ b,
                                            double *__restrict__ Zp, const double *__restrict__ Zq, const double *__restrict__ dq_r, int st_prob)
 {
+    LVBA_FETCH("s"(A.p.k), "s"(A.p.w0), "s"(A.p.rend), "s"(A.p.nbe), "s"(A.q.k), "s"(A.q.w0), "s"(A.q.rend), "s"(A.q.nbe), "s"(A.has_q), "s"(A.do_diag),
+               "s"(A.nbe_next), "s"(A.ldz), "s"(Gp), "s"(Gn), "s"(dvec), "s"(b), "s"(Zp), "s"(Zq), "s"(dq_r));
     LVBA_STAMP(A, st_prob, 0, 0);
     double *Ls = lds, *Zs = lds + 64 * LVBA_TS;
     const PanelGeo &p = A.p, &q = A.q;
@@ -395,6 +403,8 @@ __device__ __forceinline__ void row_role(double *lds, const LdltMat &M, const St
                                          const double *__restrict__ Zq, const double *__restrict__ side_r, double *__restrict__ side_w,
                                          double *__restrict__ dq_w, int st_prob)
 {
+    LVBA_FETCH("s"(A.p.k), "s"(A.p.w0), "s"(A.p.rend), "s"(A.p.nbe), "s"(A.q.k), "s"(A.q.w0), "s"(A.q.rend), "s"(A.q.nbe), "s"(A.has_q), "s"(A.q_extra),
+               "s"(A.qx_helper), "s"(A.nbe_next), "s"(A.rend_next), "s"(A.ldz), "s"(Gp), "s"(dvec), "s"(b), "s"(Zp), "s"(Zq), "s"(side_r), "s"(side_w), "s"(dq_w));
     LVBA_STAMP(A, st_prob, (int)t_row, 0);
     double *Ls = lds, *Zs = lds + 64 * LVBA_TS;
     const PanelGeo &p = A.p, &q = A.q;
@@ -655,60 +665,83 @@ __global__ __launch_bounds__(256, 2) void ldlt_step2_kernel(const Step2Args A)
 {
     __shared__ double lds[LVBA_K3_LDS];
     static_assert(LVBA_K1B_LDS <= LVBA_K3_LDS && LVBA_K3B_LDS <= LVBA_K3_LDS && LVBA_PAD_RED + 256 <= 1024, "LDS budget of the roles");
-    const int64_t nrole = A.roles ? A.p.T + (A.qx_helper ? 1 : 0) : 0, nfac = nrole * A.nprob;
+    // Kernel arguments are fetched where they are first used, one dependent scalar round trip after the other (the launch's
+    // arguments are cold in every XCD's caches): read as the source was until round 6, a bulk workgroup went through five of them
+    // and a 64-bit software division before its first load left (stamps: 2.2 us from its first instruction to "first fetches
+    // out").  The words every workgroup's dispatch needs are requested here in ONE batch (LVBA_FETCH pins the values in scalar
+    // registers at this point), the problem index is a bit of the block index (nprob is 1 or 2), and each branch below fetches
+    // what it needs the same way.
+    const int nprob = A.nprob, roles = A.roles, Tp = A.p.T, qxh = A.qx_helper, resv_at = A.resv_at, resv_n = A.resv_n, njobs = A.njobs;
+    const int nwg0 = (int)A.job[0].nwg;
+    const int64_t sW = A.sW, sA = A.sA, ldz = A.ldz;
     LdltMat M = A.M;
-    int prob;
-    int64_t bx;
-    int64_t bid = blockIdx.x;
-    if (A.resv_n > 0 && bid >= A.resv_at) {
-        if (bid < A.resv_at + A.resv_n) return; // the seat next to a chain workgroup stays empty
-        bid -= A.resv_n;
+    LVBA_FETCH("s"(nprob), "s"(roles), "s"(Tp), "s"(qxh), "s"(resv_at), "s"(resv_n), "s"(njobs), "s"(nwg0), "s"(sW), "s"(sA), "s"(ldz), "s"(M.a),
+               "s"(M.ld));
+    const int nrole = roles ? Tp + (qxh ? 1 : 0) : 0, nfac = nrole * nprob;
+    int bid = (int)blockIdx.x;
+    if (resv_n > 0 && bid >= resv_at) {
+        if (bid < resv_at + resv_n) return; // the seat next to a chain workgroup stays empty
+        bid -= resv_n;
     }
-    if (bid < nfac) { prob = (int)(bid % A.nprob); bx = bid / A.nprob; }
-    else {
-        const int64_t bb = bid - nfac;
-        prob = (int)(bb % A.nprob); bx = bb / A.nprob;
-    }
-    const int64_t wo = prob ? A.sW : 0;
-    if (prob) M.a += A.sA;
+    const int bb = bid < nfac ? bid : bid - nfac;
+    const int prob = nprob == 2 ? (bb & 1) : 0;
+    int bx = nprob == 2 ? (bb >> 1) : bb;
+    const int64_t wo = prob ? sW : 0;
+    if (prob) M.a += sA;
     if (bid < nfac) {
         if (bx == 0)
             chain_role(lds, M, A, A.Gp + wo, A.Gn + wo, A.dvec + wo, A.b + wo, A.Zp + wo, A.Zq ? A.Zq + wo : nullptr,
                        A.dq_r ? A.dq_r + wo : nullptr, prob + A.stamp_prob);
-        else if (bx == A.p.T) qx_diag_role(lds, M, A, A.Zq ? A.Zq + wo : nullptr);
+        else if (bx == Tp) qx_diag_role(lds, M, A, A.Zq ? A.Zq + wo : nullptr);
         else row_role(lds, M, A, bx, A.Gp + wo, A.dvec + wo, A.b + wo, A.Zp + wo, A.Zq ? A.Zq + wo : nullptr, A.side_r + wo, A.side_w + wo,
                       A.dq_w ? A.dq_w + wo : nullptr, prob + A.stamp_prob);
         return;
     }
 #ifdef LVBA_STAMPS
-    const int64_t st_bulk = bid - nfac;
+    const int st_bulk = bid - nfac;
     if (threadIdx.x == 0 && A.stamp_id >= 0 && A.stamp_id < LVBA_ST_LAUNCHES && st_bulk < LVBA_ST_BULK)
         g_lvba_bulk_stamps[A.stamp_id][st_bulk][0] = __builtin_amdgcn_s_memrealtime();
     struct StampEnd {
-        const Step2Args &A; int64_t b;
+        const Step2Args &A; int b;
         __device__ ~StampEnd() {
             if (threadIdx.x == 0 && A.stamp_id >= 0 && A.stamp_id < LVBA_ST_LAUNCHES && b < LVBA_ST_BULK)
                 g_lvba_bulk_stamps[A.stamp_id][b][1] = __builtin_amdgcn_s_memrealtime();
         }
     } st_end{A, st_bulk};
 #endif
-    for (int j = 0; j < A.njobs; ++j) {
-        const BulkJob &J = A.job[j];
-        if (bx >= J.nwg) { bx -= J.nwg; continue; }
-        const double *Zo = J.Zo + wo, *Ze = J.pair ? J.Ze + wo : nullptr;
-        if constexpr (big) {
-            int64_t R0, tj;
-            const PanelRef po{J.o.k, J.o.w0, J.o.rend, J.o.nbe, Zo}, pe{J.e.k, J.e.w0, J.e.rend, J.e.nbe, Ze};
-            if (!pair_decode(bx, J.ca, J.cb, (int64_t)J.o.T - 1, R0, tj)) return;
-            if (J.pair) bulk_tile_128<4>(lds, M, po, pe, A.ldz, R0, tj);
-            else bulk_tile_128<2>(lds, M, po, pe, A.ldz, R0, tj);
-        } else {
-            int64_t ti, tj;
-            col_decode(J.ca + bx, (int64_t)J.o.T - 1, ti, tj);
-            if (J.pair) update_tile2(lds, M, J.o.k, J.o.nbe, J.o.w0, J.o.rend, Zo, J.e.k, J.e.nbe, J.e.w0, J.e.rend, Ze, A.ldz, ti + 1, tj + 1);
-            else update_tile(lds, M, J.o.k, J.o.nbe, J.o.w0, J.o.rend, Zo, A.ldz, ti + 1, tj + 1);
+    int jsel = 0;
+    if (njobs > 0 && bx >= nwg0) { bx -= nwg0; jsel = 1; }
+    if (jsel < njobs) {
+        const BulkJob &J = A.job[jsel];
+        // this job's words, one batch
+        const int64_t ok_ = J.o.k, ow0 = J.o.w0, orend = J.o.rend, ek_ = J.e.k, ew0 = J.e.w0, erend = J.e.rend, ca = J.ca, cb = J.cb, nwg = J.nwg;
+        const int onbe = J.o.nbe, oT = J.o.T, enbe = J.e.nbe, pair = J.pair;
+        const double *Zo_ = J.Zo, *Ze_ = J.Ze;
+        LVBA_FETCH("s"(ok_), "s"(ow0), "s"(orend), "s"(ek_), "s"(ew0), "s"(erend), "s"(ca), "s"(cb), "s"(nwg), "s"(onbe), "s"(oT), "s"(enbe), "s"(pair),
+                   "s"(Zo_), "s"(Ze_));
+        if (bx < nwg) {
+            const double *Zo = Zo_ + wo, *Ze = pair ? Ze_ + wo : nullptr;
+            if constexpr (big) {
+                int64_t R0, tj;
+                const PanelRef po{ok_, ow0, orend, onbe, Zo}, pe{ek_, ew0, erend, enbe, Ze};
+                if (!pair_decode(bx, ca, cb, (int64_t)oT - 1, R0, tj)) return;
+#ifdef LVBA_STAMPS
+                unsigned long long *bst = (A.stamp_id >= 0 && A.stamp_id < LVBA_ST_LAUNCHES && st_bulk < LVBA_ST_BTILES) ? g_lvba_bulk_marks[A.stamp_id][st_bulk] : nullptr;
+                if (pair) bulk_tile_128<4>(lds, M, po, pe, ldz, R0, tj, bst);
+                else bulk_tile_128<2>(lds, M, po, pe, ldz, R0, tj, bst);
+#else
+                if (pair) bulk_tile_128<4>(lds, M, po, pe, ldz, R0, tj);
+                else bulk_tile_128<2>(lds, M, po, pe, ldz, R0, tj);
+#endif
+            } else {
+                int64_t ti, tj;
+                col_decode(ca + bx, (int64_t)oT - 1, ti, tj);
+                if (pair) update_tile2(lds, M, ok_, onbe, ow0, orend, Zo, ek_, enbe, ew0, erend, Ze, ldz, ti + 1, tj + 1);
+                else update_tile(lds, M, ok_, onbe, ow0, orend, Zo, ldz, ti + 1, tj + 1);
+            }
+            return;
         }
-        return;
+        bx -= (int)nwg;
     }
     if (A.fwd.on && prob == 0) fwd_passenger(lds, M, A.fwd, A.dvec, bx); // (bx: what the jobs left of the block index)
 }

@@ -196,10 +196,16 @@ __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, double v, unsig
     const v2u a = {(unsigned)__double2loint(v), (unsigned)__double2hiint(v)};
     __builtin_amdgcn_raw_buffer_store_b64(a, r, voff, soff, 0);
 }
+#ifdef LVBA_STAMPS
+#define LVBA_BSTAMP(m_) do { if (bst && threadIdx.x == 0) bst[m_] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define LVBA_BSTAMP(m_) do { } while (0)
+#endif
 template <int nch> // K chunks of 32: 2 = one panel, 4 = a pair (pe, then po)
 __device__ __forceinline__ void bulk_tile_128(double *lds, LdltMat M, const PanelRef po, const PanelRef pe, int64_t ldz64, int64_t R0,
-                                              int64_t tj)
+                                              int64_t tj, unsigned long long *bst = nullptr)
 {
+    LVBA_BSTAMP(0);
     // a chunk buffer: Ls[m][row 0..127] at its start, Zs[m][row 0..63] behind it (+ 32 * LVBA_TL), m = column of the chunk
     const int tid = threadIdx.x, lane = tid & 63;
     const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6);
@@ -318,19 +324,24 @@ __device__ __forceinline__ void bulk_tile_128(double *lds, LdltMat M, const Pane
     };
     fetch(0, xa);
     fetch(1, xb);
+    LVBA_BSTAMP(1);
 #pragma unroll
     for (int ch = 0; ch < nch; ch += 2) {
         if (ch > 0) __syncthreads(); // everybody is done with chunk ch - 1 in LDS
         stage(ch, xa);
         __syncthreads();
+        LVBA_BSTAMP(2 + 2 * ch);
         if (ch + 2 < nch) fetch(ch + 2, xa);
         else if (busy) load_c();
         products(ch);
         __syncthreads();
+        LVBA_BSTAMP(3 + 2 * ch);
         stage(ch + 1, xb);
         __syncthreads();
+        LVBA_BSTAMP(4 + 2 * ch);
         if (ch + 3 < nch) fetch(ch + 3, xb);
         products(ch + 1);
+        LVBA_BSTAMP(5 + 2 * ch);
     }
     if (busy) {
         const bool inner = r0 + 128 <= po.rend && r0 > c0; // whole tile inside the window and below the diagonal
@@ -343,20 +354,25 @@ __device__ __forceinline__ void bulk_tile_128(double *lds, LdltMat M, const Pane
 #pragma unroll
                     for (int tl = 0; tl < 2; ++tl) buf_st(rA, xa[16 * tl + 4 * cq + reg] - acc[tl][cq][reg], cvoff + 128u * tl, so);
                 }
-        } else {
+        } else { // edge tiles (the diagonal, the window's last rows): 32-bit tile-local limits -- with the 64-bit tests spelled out per
+                 // entry these were the slowest workgroups of every two-ended launch (27.5 us against a median of 21: stamps, round 6)
+            const int rlim = (int)(po.rend - r0 < 128 ? po.rend - r0 : 128), clim = (int)(po.rend - c0 < 64 ? po.rend - c0 : 64);
+            const int dd = (int)(c0 - r0); // <= 0; entry (rl, cl) lies in the lower triangle iff rl >= cl + dd
+            const int rl0 = 32 * (int)w + i;
 #pragma unroll
             for (int cq = 0; cq < 4; ++cq)
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const unsigned so = csoff + 8u * (unsigned)(16 * cq + 4 * reg) * ld;
-                    const int64_t c = c0 + 16 * cq + kk + 4 * reg;
+                    const int cl = 16 * cq + kk + 4 * reg;
 #pragma unroll
                     for (int tl = 0; tl < 2; ++tl) {
-                        const int64_t r = r0 + 32 * w + 16 * tl + i;
-                        if (r < po.rend && c < po.rend && r >= c)
+                        const int rl = rl0 + 16 * tl;
+                        if (rl < rlim && cl < clim && rl >= cl + dd)
                             buf_st(rA, xa[16 * tl + 4 * cq + reg] - acc[tl][cq][reg], cvoff + 128u * tl, so);
                     }
                 }
         }
     }
+    LVBA_BSTAMP(10);
 }
