@@ -493,17 +493,33 @@ __global__ __launch_bounds__(256) void balm_pair_col_kernel(PairDev d, double *_
     const int64_t i0 = (wg * 4 + wv) * LVBA_PC_ITEMS;
     if (i0 >= d.nnzb) return; // wavefront-uniform; no workgroup barrier below
     const int g = lane / 6, cc = lane - 6 * g; // item of the wavefront, column of its block (g = 10: idle lanes 60..63)
-    const int64_t iend = (i0 + LVBA_PC_ITEMS < d.nnzb) ? i0 + LVBA_PC_ITEMS : d.nnzb;
-    const int64_t q0 = d.blk_off[i0], q1 = d.blk_off[iend];
+    // A wavefront lives for ~ ten rounds: what happens before the first one counts.  The ranges of its items come in ONE load (lane l
+    // takes blk_off[i0 + l], the others learn what they need through shuffles), the pair lists in one batch of loads -- as a
+    // loop of load / wait / store per 64 pairs and with the ranges fetched twice, a wavefront spent four to five memory round trips
+    // one after the other before its first gather left (a quarter of its life).
+    const int nit = (int)((i0 + LVBA_PC_ITEMS < d.nnzb ? i0 + LVBA_PC_ITEMS : d.nnzb) - i0); // items of this wavefront, 1 .. 10
+    long long bo = 0;
+    if (lane <= LVBA_PC_ITEMS) bo = d.blk_off[i0 + (lane < nit ? lane : nit)];
+    const int64_t q0 = __shfl(bo, 0, 64), q1 = __shfl(bo, nit, 64);
+    const long long bo_next = __shfl_down(bo, 1, 64);
     // the items' pair lists are one contiguous range of the sorted pair array: coalesced copy into LDS
     int2 *pl = plist[wv];
-    for (int64_t q = q0 + lane; q < q1; q += 64) pl[q - q0] = d.pairs[q];
-    // lane l < 10 keeps the range of item l (relative to q0); everybody learns the ranges it needs through shuffles
-    int fa = 0, flen = 0;
-    if (lane < LVBA_PC_ITEMS && i0 + lane < d.nnzb) {
-        const int64_t a = d.blk_off[i0 + lane];
-        fa = (int)(a - q0); flen = (int)(d.blk_off[i0 + lane + 1] - a);
+    {
+        constexpr int NPL = (LVBA_PC_ITEMS * LVBA_PAIR_CUT + 63) / 64;
+        int2 pv[NPL];
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            const int64_t q = q0 + lane + 64 * k;
+            pv[k] = d.pairs[q < q1 ? q : q1 - 1]; // (unconditional: every list has a pair)
+        }
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            const int64_t q = q0 + lane + 64 * k;
+            if (q < q1) pl[q - q0] = pv[k];
+        }
     }
+    // lane l < 10 keeps the range of item l (relative to q0); everybody learns the ranges it needs through shuffles
+    const int fa = lane < nit ? (int)(bo - q0) : 0, flen = lane < nit ? (int)(bo_next - bo) : 0;
     int rounds = flen;
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) { const int t = __shfl_xor(rounds, o, 16); rounds = t > rounds ? t : rounds; }
@@ -532,14 +548,21 @@ __global__ __launch_bounds__(256) void balm_pair_col_kernel(PairDev d, double *_
     double2 v[LVBA_PC_PF][NLD];
     // (buffer addressing for these gathers -- 32-bit offsets instead of 64-bit flat addresses -- was measured in round 3: no change)
     auto fetch = [&](int r, double2 (&vv)[NLD]) {
+        // the pair indices of the round's chunks: unconditional LDS reads (a clamped pair of the same item), all of them ahead of the
+        // gathers -- read inside the condition, each gather waited for its own LDS read in turn
+        int2 pr[NLD];
 #pragma unroll
         for (int s2 = 0; s2 < NLD; ++s2) {
             const int pi = LVBA_PC_DEPTH * r + c_dep[s2]; // this chunk's pair of its item
+            const int lm1 = c_len[s2] > 0 ? c_len[s2] - 1 : 0;
+            pr[s2] = pl[c_fa[s2] + (pi < lm1 ? pi : lm1)];
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < NLD; ++s2) {
+            const int pi = LVBA_PC_DEPTH * r + c_dep[s2];
             vv[s2] = make_double2(0.0, 0.0);
-            if (pi < c_len[s2]) {
-                const int2 pr = pl[c_fa[s2] + pi];
-                vv[s2] = reinterpret_cast<const double2 *>(d.Y + (Y32 ? 10 : 18) * (int64_t)(c_side[s2] ? pr.y : pr.x))[c_piece[s2]];
-            }
+            if (pi < c_len[s2])
+                vv[s2] = reinterpret_cast<const double2 *>(d.Y + (Y32 ? 10 : 18) * (int64_t)(c_side[s2] ? pr[s2].y : pr[s2].x))[c_piece[s2]];
         }
     };
     auto round_body = [&](int r, double2 (&vv)[NLD]) { // vv holds round r; it is refilled with round r + LVBA_PC_PF
