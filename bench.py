@@ -641,7 +641,7 @@ def visual_leg(pkg, synth, n_cams, local_rank, with_cpu=True):
            "observations_per_s": n_obs_act * iters / dt,
            "stage_ms": {"linearize (stand-alone call: state upload + factor kernels)": lin_ms, "rest of an iteration": solve_ms},
            "stage_note": "a stand-alone linearisation re-uploads the state (~0.23 ms of its time); inside the LM loop the state stays on the "
-                         "device -- see ms_per_iteration_in_loop, and LVBA_VIS_PROFILE=1 (tools/visual_bench.py) for the phases of an iteration",
+                         "device -- see ms_per_iteration_in_loop, and LVBA_TIMING=vis (tools/visual_bench.py) for the phases of an iteration",
            "roofline": {"bound": "hbm", "kernel": "vis_residual / vis_colnorm / vis_point / vis_cam / pair pass (one linearisation)",
                         "achieved": bytes_factor / lin_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": bytes_factor / lin_ms / 1e6 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": bytes_factor,

@@ -343,7 +343,7 @@ static int32_t nd_alloc(BlockSys &bs, const NdPlan &pl)
 int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const int32_t *pidx)
 {
     if (bs.built) return LVBA_OK;
-    const bool timing = getenv("LVBA_TIMING") != nullptr;
+    const bool timing = timing_on("build");
     double tmark = bs_now_ms();
     HIPCHK(hipSetDevice(bs.device));
     bs.N = N; bs.G = G; bs.F = voff[G];
@@ -411,6 +411,29 @@ int32_t bs_build(BlockSys &bs, int32_t N, int64_t G, const int64_t *voff, const 
         if (bs.n_groups == 0 && !bs.spd && N >= 256) { bs.perm_band = bs.perm; bs.Bb_band = bs.Bb; }
         if (bs.n_groups == 0 && !bs.spd && !solver_form("nond")) {
             NdPlan pl = nd_plan(adj.data(), N, bs.perm, bs.Bb, bs.distributed() ? bs.n_ranks : 1, solver_form("nd") ? 1e30 : 0.8);
+            if (pl.active) {
+                // What the dissected layout allocates on a rank -- the full lower block triangle of H (N^2 blocks), per owned arc its
+                // matrix, the border columns B / Y and S_a, the separator's system: the cost model counts time only, and a graph with
+                // a hub that fit as a band (N (Bb + 1) blocks) can be far larger this way.  Keep the band when the most loaded rank
+                // would need more than half of the device's memory (LVBA_SOLVER=nd insists).  Every rank evaluates the same numbers
+                // (all arcs, the device's TOTAL memory), so every rank decides alike.
+                const int nr = bs.distributed() ? bs.n_ranks : 1;
+                std::vector<double> per_rank((size_t)nr, 0.0);
+                for (const NdPlanArc &a : pl.arcs) {
+                    const double na = 6.0 * a.Na, bwa = std::min(6.0 * a.Bb + 5.0, na), ldb = 64.0 * std::ceil(6.0 * (double)a.sep.size() / 64.0);
+                    per_rank[(size_t)std::min(std::max(a.owner, 0), nr - 1)] += 8.0 * (2.0 * (bwa + 128.0) * (na + 1.0) + 2.0 * na * ldb + ldb * ldb + 4.0 * na);
+                }
+                const double ns = 6.0 * pl.Ns, bws = std::min(6.0 * pl.BbS + 5.0, ns);
+                const double need = 288.0 * (double)N * (double)N + *std::max_element(per_rank.begin(), per_rank.end()) +
+                                    8.0 * 2.0 * (bws + 128.0) * (ns + 1.0) + 288.0 * pl.Ns * (double)(pl.BbS + 1);
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > 0.5 * (double)total_b && !solver_form("nd")) {
+                    if (timing_on("build"))
+                        fprintf(stderr, "[bs_build] dissection (%s, %zu arcs) would take %.1f GB of the device's %.1f GB: keeping the band\n", pl.kind,
+                                pl.arcs.size(), need / 1e9, (double)total_b / 1e9);
+                    pl.active = false;
+                }
+            }
             if (pl.active) {
                 plan = pl;
                 bs.perm = plan.perm;

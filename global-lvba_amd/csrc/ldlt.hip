@@ -237,7 +237,7 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
                 nwg += J.nwg;
                 ++a.njobs;
             }
-            if (border && L.roles && ny == 1 && fwd_next == L.p) {
+            if (border && L.roles && ny == 1 && fwd_next <= L.p) { // (<=: a stage no launch carried rides the next one that can)
                 int64_t nf = 0;
                 a.fwd = fwd_stage(fwd_next++, nf);
                 nwg += nf;

@@ -217,6 +217,18 @@ int32_t nd_solve(NdSys &nd, const double *Hblk, int32_t N, const double *g, cons
     const int rank = dist ? dist->rank : 0;
     const int P = (int)nd.arcs.size();
     const int64_t Bb1 = N; // the Hessian store of a dissected system is the full lower block triangle
+    // an error return must not leave arc streams running beside what the caller enqueues on s next (retract, the next evaluation):
+    // s waits for every owned arc's stream first
+    auto bail = [&](int32_t rc) {
+        for (int a = 0; a < P; ++a) {
+            NdArc &A = nd.arcs[(size_t)a];
+            if (A.owner != rank) continue;
+            hipEventRecord(A.done, A.stream);
+            hipStreamWaitEvent(s, A.done, 0);
+        }
+        (void)hipGetLastError();
+        return rc;
+    };
     hipEventRecord(nd.start, s);
     // ---- the arcs, each on a stream of its own: the factorisation, with the forward substitution of the border's columns riding in
     // its launches one panel behind (ldlt_lookahead.h: FwdPassenger -- a step launch is a few dozen workgroups on a serial chain, the
@@ -235,7 +247,7 @@ int32_t nd_solve(NdSys &nd, const double *Hblk, int32_t N, const double *g, cons
         const int32_t rc = ldlt_solve(A.A, Hblk + (int64_t)A.p0 * Bb1 * 36, (int)(Bb1 - 1), A.Na, g + 6 * (int64_t)A.p0, u_dev,
                                       x + 6 * (int64_t)A.p0, A.work, A.status, as, nullptr, nullptr, LDLT_FACTOR,
                                       A.nsep > 0 ? &border : nullptr);
-        if (rc != LVBA_OK) return rc;
+        if (rc != LVBA_OK) return bail(rc);
         if (A.nsep > 0) {
             const double *Gall = ldlt_work_G(A.work), *dvec = ldlt_work_d(A.n, A.work);
             const unsigned nct = (unsigned)(A.ldb / 64);
@@ -264,12 +276,12 @@ int32_t nd_solve(NdSys &nd, const double *Hblk, int32_t N, const double *g, cons
         hipLaunchKernelGGL(nd_sep_sub_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, (const double *)A.Sa,
                            (const double *)A.gpart, A.ldb, A.sep, A.nsep, nd.BbS, nd.Sblk, nd.Sblk + sep_doubles);
     }
-    if (dist && dist->n_ranks >= 2 && dist->allreduce_sum(dist->ctx, nd.Sblk, (size_t)(sep_doubles + 6 * (int64_t)nd.Ns))) return LVBA_ERR_DIST;
+    if (dist && dist->n_ranks >= 2 && dist->allreduce_sum(dist->ctx, nd.Sblk, (size_t)(sep_doubles + 6 * (int64_t)nd.Ns))) return bail(LVBA_ERR_DIST);
     double *xS = x + 6 * (int64_t)nd.ps;
     {
         const int32_t rc = ldlt_solve(nd.AS, nd.Sblk, nd.BbS, nd.Ns, nd.Sblk + sep_doubles, nd.d_zero, xS, nd.workS, nd.statusS, s, dist, nullptr,
                                       LDLT_ALL);
-        if (rc != LVBA_OK) return rc;
+        if (rc != LVBA_OK) return bail(rc);
     }
     // ---- back into the arcs
     hipEventRecord(nd.mid, s);
@@ -287,12 +299,13 @@ int32_t nd_solve(NdSys &nd, const double *Hblk, int32_t N, const double *g, cons
                                (const double *)xS, A.sep, A.nsep, ldlt_work_b(A.n, A.work));
         const int32_t rc = ldlt_solve(A.A, Hblk + (int64_t)A.p0 * Bb1 * 36, (int)(Bb1 - 1), A.Na, g + 6 * (int64_t)A.p0, u_dev, xa, A.work,
                                       A.status, as, nullptr, nullptr, LDLT_BACKWARD);
-        if (rc != LVBA_OK) return rc;
+        if (rc != LVBA_OK) return bail(rc);
         hipEventRecord(A.done, as);
     }
     for (int a = 0; a < P; ++a)
         if (nd.arcs[(size_t)a].owner == rank) hipStreamWaitEvent(s, nd.arcs[(size_t)a].done, 0);
     hipLaunchKernelGGL(nd_status_kernel, dim3(1), dim3(1), 0, s, (const int *)nd.d_stat, P + 1, status);
+    if (hipGetLastError() != hipSuccess) return LVBA_ERR_DEVICE; // (one check behind the whole launch sequence, as elsewhere in the library)
     if (dist && dist->n_ranks >= 2) {
         if (dist->allreduce_sum(dist->ctx, x, (size_t)(6 * (int64_t)nd.ps))) return LVBA_ERR_DIST; // (x_S is the same on every rank already)
         if (dist->allreduce_max_i32(dist->ctx, status)) return LVBA_ERR_DIST;

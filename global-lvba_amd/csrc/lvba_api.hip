@@ -140,7 +140,7 @@ static int32_t balm_create_impl(int32_t n_poses, int64_t n_voxels, const int64_t
         return fail(LVBA_ERR_DEVICE, "no HIP device available (liblvba_hip has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(LVBA_ERR_ARG, "device %d out of range [0,%d)", device, ndev);
 
-    const bool timing = getenv("LVBA_TIMING") != nullptr;
+    const bool timing = timing_on("build");
     auto nowc = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tmark = nowc();
     auto mark = [&](const char *what) {
@@ -176,7 +176,7 @@ static int32_t balm_create_impl(int32_t n_poses, int64_t n_voxels, const int64_t
     // The reference hands its voxels over in the iteration order of an unordered_map (src/lvba_system.cpp:254-262 -> tras_opt),
     // i.e. in no order at all: at C3 that costs 17 % of the evaluation (2.71 vs 2.32 ms, tools/gpu_shuffled.sh).  So a large
     // problem whose voxels jump about is re-laid internally, voxels sorted (stably) by the first pose that sees them.  Nothing
-    // the caller gets back is indexed by voxel; sums over voxels change in the last bits only.  LVBA_VOXEL_SORT=0: off.
+    // the caller gets back is indexed by voxel; sums over voxels change in the last bits only.
     lvba::hvec<int64_t> voff_s;
     lvba::hvec<int32_t> pidx_s, fmap;
     {
@@ -313,7 +313,7 @@ static int32_t finalize(lvba_balm_s *h)
     HIPCHK(hipSetDevice(bs.device));
     const int N = h->N;
     if (h->n_groups > 0) bs.ordering = 0; // (lvba_balm_configure / dist_init refuse to undo it; kept here as the single point of truth)
-    const bool timing = getenv("LVBA_TIMING") != nullptr;
+    const bool timing = timing_on("build");
     auto nowc = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tmark = nowc();
     auto mark = [&](const char *what) {
@@ -361,7 +361,7 @@ extern "C" int32_t lvba_balm_info(lvba_balm_t h, lvba_balm_info_t *info)
     info->nd_kind = !h->bs.nd.active ? 0 : !strcmp(h->bs.nd.kind, "hubs") ? 1 : 2;
     info->nd_arcs = (int32_t)h->bs.nd.arcs.size(); info->nd_sep_poses = h->bs.nd.Ns; info->nd_sep_band_blocks = h->bs.nd.BbS;
     info->nd_model_band_ms = 1e3 * h->bs.nd.t_band; info->nd_model_nd_ms = 1e3 * h->bs.nd.t_nd;
-    info->solve_ranks = (h->bs.distributed() && h->bs.n_ranks >= 2 && info->twist_panels > 0) ? 2 : 1;
+    info->solve_ranks = !(h->bs.distributed() && h->bs.n_ranks >= 2) ? 1 : h->bs.nd.active ? h->bs.n_ranks : info->twist_panels > 0 ? 2 : 1;
     info->trial_linearised = 1;
     info->y_fp32 = h->bs.y32 ? 1 : 0;
     info->allreduce_bytes = !h->bs.distributed() ? 0 : 8 * ((h->bs.d_ar_slot ? 36 * h->bs.n_ar : h->bs.hblk_doubles) + 6 * (int64_t)h->N + 1);

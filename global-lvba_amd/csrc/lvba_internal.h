@@ -104,6 +104,23 @@ inline bool solver_form(const char *name)
     return false;
 }
 
+// LVBA_TIMING = comma-separated parts whose stage times go to stderr: build (bs_build, finalize, create), window (window_ba.hip),
+// vis (the visual refinement's phases); "1" or "all": every part.
+inline bool timing_on(const char *part, bool named_only = false) // named_only: the part must be listed itself ("1" / "all" do not count)
+{
+    const char *e = getenv("LVBA_TIMING");
+    if (!e || !*e) return false;
+    const size_t n = strlen(part);
+    for (const char *p = e; *p;) {
+        const char *q = strchr(p, ',');
+        const size_t len = q ? (size_t)(q - p) : strlen(p);
+        if (len == n && !strncmp(p, part, n)) return true;
+        if (!named_only && ((len == 3 && !strncmp(p, "all", 3)) || (len == 1 && *p == '1'))) return true;
+        p += len + (q ? 1 : 0);
+    }
+    return false;
+}
+
 // One level of nested dissection (nd_plan.h decides, ldlt_nd.h solves): device-side pieces of an arc and of the whole system
 struct NdArc {
     int32_t p0, Na;     // pose range [p0, p0 + Na) of the solver order
@@ -168,7 +185,7 @@ void vis_launch_residuals(const VisDev &d, bool jac, const double *qc, const dou
 void vis_launch_colnorms(const VisDev &d, hipStream_t s);          // single rank: sums + scaling in one go
 void vis_launch_colsums(const VisDev &d, hipStream_t s);           // sharded: landmark scaling + per-camera column sums -> colsum
 void vis_launch_colnorm_finish(const VisDev &d, hipStream_t s);    //          (after the all-reduce of colsum) camera scaling
-void vis_launch_cam_finish(const VisDev &d, double radius, double min_diag, double max_diag, double *Hblk, unsigned long long *gmax,
+void vis_launch_cam_finish(const VisDev &d, double radius, double min_diag, double max_diag, double *Hblk, const double *qc, unsigned long long *gmax,
                            hipStream_t s);                         // sharded, after the all-reduces: LM diagonal, gradient max
 void vis_launch_gather_uv(const VisDev &d, double *uv_cm, hipStream_t s);
 void vis_launch_reduced_system(const VisDev &d, const PairDev &pd, const double *qc, const double *tc, const double *Xp, double radius, double min_diag, double max_diag, double *Hblk,

@@ -243,7 +243,7 @@ static int32_t enqueue_reduced_system(lvba_visual_s *h, double radius, const lvb
     if (!bs.distributed()) return LVBA_OK;
     TRY(bs_allreduce_hg(bs));                                   // [S blocks | reduced rhs]: sums over the track shards
     TRY(bs_allreduce(bs, h->d_camsum, 12 * (size_t)h->M));      // diag(Jc^T Jc), Jc^T r
-    vis_launch_cam_finish(d, radius, o.min_lm_diagonal, o.max_lm_diagonal, bs.Hblk(), h->d_gmax, bs.stream);
+    vis_launch_cam_finish(d, radius, o.min_lm_diagonal, o.max_lm_diagonal, bs.Hblk(), h->d_q, h->d_gmax, bs.stream);
     TRY(bs_comm_allreduce(bs, h->d_gmax, 1, ncclInt64, ncclMax)); // bit patterns of non-negative doubles order like integers
     return LVBA_OK;
 }
@@ -365,7 +365,7 @@ extern "C" int32_t lvba_visual_refine(lvba_visual_t h, double *q, double *t, dou
     int invalid_run = 0;
     if (!isfinite(cost)) { term = LVBA_TERM_FAILURE; rc = fail(LVBA_NUM_NONFINITE, "non-finite initial cost"); }
     // LVBA_TIMING=vis: HIP events between the phases of every iteration, averages on stderr at the end (tools/visual_bench.py)
-    static const bool prof = [] { const char *e = getenv("LVBA_TIMING"); return e && !strcmp(e, "vis"); }();
+    static const bool prof = timing_on("vis", true); // (a stream synchronisation per phase: only when asked for by name)
     constexpr int NPH = 6, PCAP = 64;
     std::vector<hipEvent_t> pev;
     int pn = 0;

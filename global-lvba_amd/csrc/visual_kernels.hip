@@ -329,9 +329,24 @@ __global__ __launch_bounds__(256) void vis_cam_kernel(VisDev d, const double *__
     }
 }
 
+// A camera's share of Ceres' gradient_max_norm = || x - Plus(x, -g) ||_inf over the ambient parameters (the max norm of the
+// PROJECTED gradient step: trust_region_minimizer.cc of 2.1): |g| itself on the Euclidean block (translation; likewise the
+// landmarks in vis_point_kernel), the four components of q - Plus(q, -g_rot) on the quaternion block.  gu: unscaled gradient.
+__device__ __forceinline__ double cam_projected_gmax(const double *__restrict__ qc, int64_t I, const double (&gu)[6])
+{
+    const double q[4] = {qc[4 * I], qc[4 * I + 1], qc[4 * I + 2], qc[4 * I + 3]}, ng[3] = {-gu[0], -gu[1], -gu[2]};
+    double q2[4], gm = 0.0;
+    quat_plus(q, ng, q2);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) gm = fmax(gm, fabs(q[e] - q2[e]));
+#pragma unroll
+    for (int c = 3; c < 6; ++c) gm = fmax(gm, fabs(gu[c]));
+    return gm;
+}
+
 // one thread per camera: slice sums -> diagonal block (lower) + LM diagonal, reduced right-hand side, gradient max
 __global__ void vis_cam_reduce_kernel(VisDev d, double radius, double min_diag, double max_diag, double *__restrict__ Hblk,
-                                      double *__restrict__ g, unsigned long long *gmax)
+                                      double *__restrict__ g, const double *__restrict__ qc, unsigned long long *gmax)
 {
     const int64_t I = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (I >= d.M) return;
@@ -343,7 +358,7 @@ __global__ void vis_cam_reduce_kernel(VisDev d, double radius, double min_diag, 
         for (int e = 0; e < 39; ++e) acc[e] += d.part[(I * d.S + q) * 40 + e];
     double *hp = Hblk + I * (int64_t)(d.band_blocks + 1) * 36;
     int p = 0;
-    double gm = 0.0;
+    double gu[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c)
 #pragma unroll
@@ -356,7 +371,7 @@ __global__ void vis_cam_reduce_kernel(VisDev d, double radius, double min_diag, 
 #pragma unroll
     for (int e = 0; e < 6; ++e) {
         g[6 * I + e] = acc[21 + e];
-        gm = fmax(gm, fabs(acc[33 + e] / d.sc_cam[6 * I + e]));
+        gu[e] = acc[33 + e] / d.sc_cam[6 * I + e];
     }
     if (d.dist) {
 #pragma unroll
@@ -366,24 +381,24 @@ __global__ void vis_cam_reduce_kernel(VisDev d, double radius, double min_diag, 
         }
         return;
     }
-    atomicMax(gmax, (unsigned long long)__double_as_longlong(gm));
+    atomicMax(gmax, (unsigned long long)__double_as_longlong(cam_projected_gmax(qc, I, gu)));
 }
 
 // sharded, after [H | g] and camsum have been all-reduced: the LM diagonal on the diagonal blocks and the cameras' part of
 // the gradient max (the landmarks' part is local to their rank; gmax itself is max-reduced afterwards)
 __global__ void vis_cam_finish_kernel(VisDev d, double radius, double min_diag, double max_diag, double *__restrict__ Hblk,
-                                      unsigned long long *gmax)
+                                      const double *__restrict__ qc, unsigned long long *gmax)
 {
     const int64_t I = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (I >= d.M) return;
     double *hp = Hblk + I * (int64_t)(d.band_blocks + 1) * 36;
-    double gm = 0.0;
+    double gu[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
         hp[c * 6 + c] += fmin(fmax(d.camsum[6 * I + c], min_diag), max_diag) / radius;
-        gm = fmax(gm, fabs(d.camsum[6 * (int64_t)d.M + 6 * I + c] / d.sc_cam[6 * I + c]));
+        gu[c] = d.camsum[6 * (int64_t)d.M + 6 * I + c] / d.sc_cam[6 * I + c];
     }
-    atomicMax(gmax, (unsigned long long)__double_as_longlong(gm));
+    atomicMax(gmax, (unsigned long long)__double_as_longlong(cam_projected_gmax(qc, I, gu)));
 }
 
 // four lanes (one DPP quad) per landmark, as in vis_point_kernel: step_p = -L^-T (z + sum_obs Y^T step_c), and the model cost
@@ -617,10 +632,10 @@ void vis_launch_colnorm_finish(const VisDev &d, hipStream_t s)
 {
     hipLaunchKernelGGL(vis_colnorm_cam_finish_kernel, dim3(nblk(6 * (int64_t)d.M, 256)), dim3(256), 0, s, d);
 }
-void vis_launch_cam_finish(const VisDev &d, double radius, double min_diag, double max_diag, double *Hblk, unsigned long long *gmax,
-                           hipStream_t s)
+void vis_launch_cam_finish(const VisDev &d, double radius, double min_diag, double max_diag, double *Hblk, const double *qc,
+                           unsigned long long *gmax, hipStream_t s)
 {
-    hipLaunchKernelGGL(vis_cam_finish_kernel, dim3(nblk(d.M, 64)), dim3(64), 0, s, d, radius, min_diag, max_diag, Hblk, gmax);
+    hipLaunchKernelGGL(vis_cam_finish_kernel, dim3(nblk(d.M, 64)), dim3(64), 0, s, d, radius, min_diag, max_diag, Hblk, qc, gmax);
 }
 
 void vis_launch_gather_uv(const VisDev &d, double *uv_cm, hipStream_t s)
@@ -639,7 +654,7 @@ void vis_launch_reduced_system(const VisDev &d, const PairDev &pd, const double 
     const int64_t per_slice = d.O / ((int64_t)d.M * d.S > 0 ? (int64_t)d.M * d.S : 1);
     if (per_slice <= 1024) hipLaunchKernelGGL(vis_cam_kernel, dim3((unsigned)((d.M * d.S + 3) / 4)), dim3(256), 0, s, d, qc, tc, Xp, 1);
     else hipLaunchKernelGGL(vis_cam_kernel, dim3((unsigned)(d.M * d.S)), dim3(256), 0, s, d, qc, tc, Xp, 0);
-    hipLaunchKernelGGL(vis_cam_reduce_kernel, dim3(nblk(d.M, 64)), dim3(64), 0, s, d, radius, min_diag, max_diag, Hblk, g, gmax);
+    hipLaunchKernelGGL(vis_cam_reduce_kernel, dim3(nblk(d.M, 64)), dim3(64), 0, s, d, radius, min_diag, max_diag, Hblk, g, qc, gmax);
     launch_pairs(pd, Hblk, s);
 }
 

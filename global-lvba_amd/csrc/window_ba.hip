@@ -323,7 +323,7 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
             memcpy(x.data() + 12 * (size_t)pose_off[(size_t)k], R.x.data(), 96 * (size_t)R.info.n_frames);
         }
         HIPCHK(hipStreamSynchronize(s));
-        const bool tm = getenv("LVBA_TIMING") != nullptr;
+        const bool tm = timing_on("window");
         double tk = now_ms();
         auto mk = [&](const char *what) { if (tm) { const double t = now_ms(); fprintf(stderr, "[window_ba LM] %-16s %.3f ms\n", what, t - tk); tk = t; } };
         if (tm) fprintf(stderr, "[window_ba LM] %-16s %.3f ms\n", "export + concat", tk - t0);
@@ -535,7 +535,7 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
             const int64_t P_all = sc->frame_off[(size_t)n] - sc->frame_off[0];
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return false; }
             if ((double)P_all * 96.0 > 0.5 * (double)free_b) {
-                if (getenv("LVBA_TIMING"))
+                if (timing_on("window"))
                     fprintf(stderr, "[window_ba] joint voxel map skipped: %lld points x ~96 B against %.1f GB free -> one map per window\n",
                             (long long)P_all, (double)free_b / 1e9);
                 return false;
@@ -610,7 +610,7 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
         }
         const int64_t P_live = at.back();
         const int cbits = G < n_win ? 32 - __builtin_clz((unsigned)G) : (G > 1 ? 32 - __builtin_clz((unsigned)(G - 1)) : 0);
-        const bool jt = getenv("LVBA_TIMING") != nullptr;
+        const bool jt = timing_on("window");
         double tj = now_ms();
         auto jm = [&](const char *what) { // (LVBA_TIMING: waits for the stream at every mark)
             if (!jt) return;
@@ -704,12 +704,12 @@ extern "C" int32_t lvba_window_ba(lvba_scans_t sc, const double *poses, const lv
         const int32_t rc = body();
         if (rc != LVBA_OK) {
             if (joint_pts) { (void)hipFree(joint_pts); joint_pts = nullptr; }
-            if (getenv("LVBA_TIMING")) fprintf(stderr, "[window_ba] joint merge not taken (rc %d): one pass per window\n", rc);
+            if (timing_on("window")) fprintf(stderr, "[window_ba] joint merge not taken (rc %d): one pass per window\n", rc);
             return false;
         }
         return true;
     };
-    const bool timing = getenv("LVBA_TIMING") != nullptr; // stage times of the whole call to stderr
+    const bool timing = timing_on("window"); // stage times of the whole call to stderr
     double tmark = now_ms();
     auto mark = [&](const char *what) {
         if (!timing) return;

@@ -205,6 +205,17 @@ class VisualOracle:
         xp = Cinv @ (g[nc:] - E.T @ xc)
         return np.concatenate([xc, xp])
 
+    def gradient_max_norm(self, q, g_unscaled):
+        """Ceres 2.1's gradient_max_norm: the max norm of the PROJECTED gradient step, || x - Plus(x, -g) ||_inf over the ambient
+        parameters (trust_region_minimizer.cc) -- |g| itself on the Euclidean blocks, the four components of q - Plus(q, -g_rot) on
+        a quaternion block.  g_unscaled: tangent gradient, cameras 1.. (6 each: rotation, translation), then the landmarks."""
+        nc = self.n_cam
+        gm = np.abs(g_unscaled[nc:]).max(initial=0.0)
+        for c in range(1, self.M):
+            gc = g_unscaled[6 * (c - 1):6 * c]
+            gm = max(gm, np.abs(q[c] - eigen_quat_plus(q[c], -gc[:3])).max(), np.abs(gc[3:]).max())
+        return float(gm)
+
     # Ceres 2.1 TrustRegionMinimizer + LevenbergMarquardtStrategy, as restated in the module docstring ---------
     def solve(self, max_iter=50, verbose=False):
         q, t, X = self.state()
@@ -220,7 +231,7 @@ class VisualOracle:
         # FinalizeIterationAndCheckIfMinimizerCanContinue checks iterations, then gradient, then radius
         if max_iter <= 0:
             return (q, t, X), trace, "NO_CONVERGENCE"
-        if np.abs(g / scale).max(initial=0.0) <= 1e-10:
+        if self.gradient_max_norm(q, g / scale) <= 1e-10:
             return (q, t, X), trace, "CONVERGENCE(gradient)"
         invalid_run = 0
         x_norm = float(np.sqrt((q[1:] ** 2).sum() + (t[1:] ** 2).sum() + (X[self.act] ** 2).sum()))
@@ -288,7 +299,7 @@ class VisualOracle:
                 g = J.T @ r
                 if it >= max_iter:                      # MaxSolverIterationsReached comes before GradientToleranceReached
                     break
-                if np.abs(g / scale).max(initial=0.0) <= 1e-10:
+                if self.gradient_max_norm(q, g / scale) <= 1e-10:
                     status = "CONVERGENCE(gradient)"
                     break
             else:

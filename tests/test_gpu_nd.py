@@ -55,6 +55,20 @@ def test_hub_graph_dissection_matches_dense_solve_and_oracle(pkg, oracle_mod, ca
     band.close()
 
 
+def align_to_pose0(x, ref):
+    """x with the rigid transform applied that maps its pose 0 onto ref's pose 0 (poses [N][12]: R row-major, then p): the BALM
+    cost does not see a common rigid motion of all poses, an LM run without a gauge fix may drift along it."""
+    x, ref = np.asarray(x, float).reshape(-1, 12), np.asarray(ref, float).reshape(-1, 12)
+    R0, p0 = x[0, :9].reshape(3, 3), x[0, 9:]
+    Rr, pr = ref[0, :9].reshape(3, 3), ref[0, 9:]
+    T = Rr @ R0.T                       # T R0 = Rr
+    t = pr - T @ p0                     # T p0 + t = pr
+    out = np.empty_like(x)
+    out[:, :9] = (T @ x[:, :9].reshape(-1, 3, 3)).reshape(-1, 9)
+    out[:, 9:] = x[:, 9:] @ T.T + t
+    return out.reshape(np.shape(ref))
+
+
 @pytest.mark.parametrize("world,case", [(4, dict(n_poses=640, n_voxels=24000, band=6, seed=11)),
                                         (3, dict(n_poses=600, n_voxels=20000, band=6, seed=12, loop_frac=0.0)),
                                         # config C4's shape scaled down (n / bw > 20) on the eight ranks BASELINE.json gives it
@@ -99,15 +113,20 @@ def test_long_band_shared_by_ranks(pkg, oracle_mod, world, case, monkeypatch):
     assert np.abs(r0["dx"] - want).max() <= 1e-8 * np.abs(want).max()
     assert np.abs(r0["dx"] - dx1).max() <= 1e-8 * np.abs(want).max()
     assert r0["rc"] == rc1 == 0 and len(r0["trace"]) == len(tr1)
-    # (rounding differences of the first evaluation -- eight shards' partial sums -- grow from iteration to iteration of an LM run)
-    # and the undamped gauge directions of 1 600 poses carry them into the poses: north_star's 1e-5 there, the LM costs at 1e-7)
-    tol = 1e-7 if world < 8 else 1e-5
-    assert np.abs(r0["x"] - x1).max() <= tol, np.abs(r0["x"] - x1).max()
+    # The LM costs are gauge-invariant: 1e-7 for every world size.  The poses are not -- the chain of 1 600 poses has next to no
+    # loop closures, its undamped gauge directions carry the rounding differences of eight shards' partial sums into the poses --
+    # so they are compared twice: after aligning both runs to their pose 0 at 1e-7, and raw at north_star's 1e-5.
+    tol_raw = 1e-7 if world < 8 else 1e-5
+    assert np.abs(r0["x"] - x1).max() <= tol_raw, np.abs(r0["x"] - x1).max()
+    assert np.abs(align_to_pose0(r0["x"], x1) - x1).max() <= 1e-7, np.abs(align_to_pose0(r0["x"], x1) - x1).max()
     for a, b in zip(r0["trace"], tr1):
         assert a["accepted"] == b["accepted"]
-        assert abs(a["residual1"] - b["residual1"]) <= 100 * tol * b["residual1"] and abs(a["residual2"] - b["residual2"]) <= 100 * tol * b["residual2"]
-    if world < 8:   # (the 1 600-pose chain has next to no loop closures: its gauge drifts 1e-4 between ANY two implementations' LM runs,
-                    # the single-rank band path and the oracle included -- the solve itself is held against the dense solve above)
-        co = oracle_mod.COracle(N, off, idx, clu)
-        xr, tr, _ = co.damping_iter(d["poses_init"])
-        assert np.abs(r0["x"] - xr).max() <= tol, np.abs(r0["x"] - xr).max()
+        assert abs(a["residual1"] - b["residual1"]) <= 1e-7 * b["residual1"] and abs(a["residual2"] - b["residual2"]) <= 1e-7 * b["residual2"]
+    co = oracle_mod.COracle(N, off, idx, clu)
+    xr, tr, _ = co.damping_iter(d["poses_init"])
+    assert len(tr) == len(r0["trace"])
+    for a, b in zip(r0["trace"], tr):   # (oracle trace row: iter, residual1, residual2, u, v, q, q1, accepted, evaluated)
+        assert a["accepted"] == int(b[7])
+        assert abs(a["residual1"] - b[1]) <= 1e-7 * b[1] and abs(a["residual2"] - b[2]) <= 1e-7 * b[2]
+    assert np.abs(r0["x"] - xr).max() <= tol_raw, np.abs(r0["x"] - xr).max()
+    assert np.abs(align_to_pose0(r0["x"], xr) - xr).max() <= 1e-7, np.abs(align_to_pose0(r0["x"], xr) - xr).max()
