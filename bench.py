@@ -97,6 +97,46 @@ def cpu_baseline_and_parity(prob, d, info):
     return base, parity
 
 
+def cpu_baseline_dense(d, base_s):
+    """BASELINE.md variant (D): the reference's OWN memory scheme on the problem the bench timed -- 16 thread-local dense (6N)^2
+    Hessians filled by 16 threads, summed serially in thread order, mirrored (bavoxel.hpp:603-633), then the dense D / HessuD
+    matrices and the scan of all (6N)^2 entries into a triplet list (:692-703) -- timed on the host; the damped solve and the
+    cost pass are the sparse port's (base_s: the reference hands the triplets to Eigen::SimplicialLDLT, which the oracle does not
+    restate).  Needs ~17 x 8 (6N)^2 bytes of host memory (21 GB at C3): skipped with a note when the host has less."""
+    import oracle
+    N = d["n_poses"]
+    n = 6 * N
+    need = (17 + 3) * 8 * n * n
+    avail = None
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable"):
+                    avail = int(line.split()[1]) * 1024
+    except Exception:
+        pass
+    if avail is not None and avail < 1.3 * need:
+        return {"value": None, "kind": "port", "sample": f"skipped: variant (D) needs {need / 1e9:.0f} GB of host memory, {avail / 1e9:.0f} GB available"}
+    co = oracle.COracle(N, d["voxel_off"], d["pose_idx"], d["clusters"])
+    t0 = time.perf_counter()
+    H, g, c = co.eval_dense(d["poses_init"])
+    t_eval = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ntrip = co.dense_to_triplets(H)
+    t_scan = time.perf_counter() - t0
+    del H
+    if ntrip < 0:
+        return {"value": None, "kind": "port", "sample": "variant (D): out of host memory in the triplet scan"}
+    t_iter = t_eval + t_scan + base_s["solve"] + base_s["cost"]
+    return {"value": 1.0 / t_iter, "unit": "iterations/s", "cores": min(16, os.cpu_count() or 1), "kind": "port",
+            "sample": (f"oracle/balm_oracle.c, variant (D) of BASELINE.md section 2 on the whole problem: 16 thread-local dense ({n} x {n}) Hessians, "
+                       f"serial sum + mirror {t_eval:.2f} s (bavoxel.hpp:603-633), dense D / HessuD + scan of {n * n / 1e6:.0f} M entries into "
+                       f"{ntrip / 1e6:.1f} M triplets {t_scan:.2f} s (:692-703); damped solve {base_s['solve']:.2f} s and cost pass "
+                       f"{base_s['cost']:.2f} s as in `cpu_baseline` (variant S)"),
+            "stage_s": {"eval_dense": t_eval, "dense_to_triplets": t_scan, "solve": base_s["solve"], "cost": base_s["cost"]},
+            "host_bytes": need}
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -116,6 +156,7 @@ def main():
     ap.add_argument("--config", default="C3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-baseline", action="store_true", help="skip the reference's own divide_thread on C2 (16 GB of host memory)")
+    ap.add_argument("--no-dense-baseline", action="store_true", help="skip the CPU baseline's variant (D) at C3 (21 GB of host memory, ~20 s)")
     ap.add_argument("--no-visual", action="store_true", help="skip the (untimed-for-the-metric) visual-stage leg")
     ap.add_argument("--no-y32", action="store_true", help="skip the leg that repeats the timed steps with LVBA_Y32=1 (fp32 Y records)")
     ap.add_argument("--no-front-end", action="store_true", help="skip the (untimed-for-the-metric) voxel front-end / window-BA leg")
@@ -390,6 +431,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(prob, d, info)
+                if args.config == "C3" and not args.no_dense_baseline:
+                    try:
+                        out["cpu_baseline_dense_c3"] = cpu_baseline_dense(d, out["cpu_baseline"]["stage_s"])
+                    except Exception as e:
+                        out["cpu_baseline_dense_c3"] = {"value": None, "kind": "port", "sample": f"failed: {e!r}"}
                 parity_ok = out["parity"]["ok"]
             except Exception as e:  # the baseline is a reported number, not part of the measured path
                 out["cpu_baseline"] = {"value": None, "unit": "iterations/s", "cores": 0, "kind": "port",
@@ -429,9 +475,16 @@ def scaling_model(p, sv_ms, info, world, prob=None):
     ev = world * p["eval_ms"] / max(1, p["eval_calls"])
     ck = world * p["cost_ms"] / max(1, p["cost_calls"])
     ar_mb = 8e-6 * (36 * (info.get("n_blocks", 0) + info["n_poses"]) + 6 * info["n_poses"] + 1)
+    bus, bus_src = 250.0, "assumed (no multi-GPU node was available to any round); tools/first_node.sh measures it"
+    try:   # the measured figure, once a node has been seen (tools/rccl_smoke.py writes it)
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "rccl_bus_bandwidth.json")) as f:
+            mb = json.load(f)
+        bus, bus_src = float(mb["bus_gb_s"]), f"measured by tools/rccl_smoke.py on {mb['n_gpus']} GPUs (profiles/rccl_bus_bandwidth.json)"
+    except Exception:
+        pass
     proj = {}
     for n in (1, 2, 4, 8):
-        ar = 0.0 if n == 1 else 2.0 * (n - 1) / n * ar_mb / 250.0   # ms at 250 GB/s bus bandwidth (MB / (GB/s) = ms)
+        ar = 0.0 if n == 1 else 2.0 * (n - 1) / n * ar_mb / bus   # ms at `bus` GB/s bus bandwidth (MB / (GB/s) = ms)
         sv, how = sv_ms, "band LDL^T as measured on this GPU (a second rank takes the other end: no gain over both ends in one launch)"
         nd = None
         if n > 1 and prob is not None:
@@ -450,7 +503,7 @@ def scaling_model(p, sv_ms, info, world, prob=None):
         t = (ev + ck) / n + ar + sv
         proj[str(n)] = {"ms_per_iteration": t, "speedup": (ev + ck + sv_ms) / t, "solve_ms": sv, "solve": how, "nd_model": nd}
     return {"kind": "strong scaling of one refinement: evaluation / cost pass sharded by voxel range, pose blocks all-reduced, solve by the band (two ranks at best) or by nested dissection over the ranks -- whichever the solver's model prefers", "stage_ms_1gpu": {"eval": ev, "cost": ck, "solve": sv_ms}, "stage_ms_1gpu_from": f"this run's stage times on {world} rank(s), evaluation and cost pass scaled by the rank count",
-            "allreduce_mb_per_evaluation": ar_mb, "assumed_bus_gb_s": 250.0, "projected": proj,
+            "allreduce_mb_per_evaluation": ar_mb, "bus_gb_s": bus, "bus_gb_s_source": bus_src, "projected": proj,
             "note": "a projection, not a measurement (no multi-GPU node was available to any round).  A band that is short compared "
                     "with its width (C3: n / bw = 4.6) is a serial chain of panel factorisations that does not shard -- throughput "
                     "across GPUs then comes from independent work: windows (window_stage_all_ranks, lvba_window_ba_multi), "

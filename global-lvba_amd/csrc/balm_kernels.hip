@@ -688,6 +688,35 @@ __global__ void retract_kernel(const double *__restrict__ poses, const double *_
     for (int e = 0; e < 12; ++e) out[12 * (int64_t)j + e] = o[e];
 }
 
+// The LM loop's form of the two kernels around this comment: the retraction and, from the same dx, each workgroup's share of the q1
+// numerator 0.5 dx . (u diag(H) .* dx - g) (bavoxel.hpp:722-729), summed in workgroup order by lm_report_kernel.  As a kernel of
+// its own (one workgroup of 1024 lanes walking 6 N entries) the numerator took 18 us between the solve and the cost pass.
+__global__ __launch_bounds__(128) void retract_q1_kernel(const double *__restrict__ poses, const double *__restrict__ dx, double *__restrict__ out,
+                                                         int n_poses, const double *__restrict__ Hblk, int band_blocks,
+                                                         const double *__restrict__ g, double u, double *__restrict__ q1_part)
+{
+    __shared__ double red[2];
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    double s = 0.0;
+    if (j < n_poses) {
+        double x[12], dd[6], o[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) x[e] = poses[12 * (int64_t)j + e];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) dd[e] = dx[6 * (int64_t)j + e];
+        retract_pose(x, dd, o);
+#pragma unroll
+        for (int e = 0; e < 12; ++e) out[12 * (int64_t)j + e] = o[e];
+        const double *hd = Hblk + (int64_t)j * (band_blocks + 1) * 36;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) s += dd[r] * (u * hd[r * 6 + r] * dd[r] - g[6 * (int64_t)j + r]);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) q1_part[blockIdx.x] = red[0] + red[1];
+}
+
 // q1 numerator: 0.5 * dx . (u * diag(H) .* dx - g)   (bavoxel.hpp:729); out[0] = value
 __global__ __launch_bounds__(1024) void predicted_decrease_kernel(const double *__restrict__ Hblk, int band_blocks,
                                                                   const double *__restrict__ g,
@@ -716,12 +745,14 @@ __global__ __launch_bounds__(1024) void predicted_decrease_kernel(const double *
 // The five numbers the LM driver reads after an iteration, written straight into pinned host memory (zero-copy): trial cost,
 // q1 numerator, cost at the current poses, pivot status -- one tiny kernel instead of three device-to-host copies at the tail
 // of every iteration.
-__global__ void lm_report_kernel(const double *__restrict__ scal2, const double *__restrict__ cost_cur, const int *__restrict__ status,
-                                 double *__restrict__ host_pin)
+__global__ void lm_report_kernel(const double *__restrict__ scal2, const double *__restrict__ q1_part, int n_q1,
+                                 const double *__restrict__ cost_cur, const int *__restrict__ status, double *__restrict__ host_pin)
 {
     if (threadIdx.x == 0) {
         host_pin[0] = scal2[0];
-        host_pin[1] = scal2[1];
+        double q1 = 0.0; // the q1 numerator from retract_q1_kernel's per-workgroup shares, in workgroup order
+        for (int e = 0; e < n_q1; ++e) q1 += q1_part[e];
+        host_pin[1] = 0.5 * q1;
         host_pin[2] = cost_cur[0];
         host_pin[4] = __longlong_as_double((long long)(unsigned)status[0]);
         __threadfence_system();
@@ -908,9 +939,18 @@ void launch_export_poses(const double *in, const int *perm, int n_poses, double 
     hipLaunchKernelGGL(export_poses_kernel, dim3((12 * n_poses + 255) / 256), dim3(256), 0, s, in, perm, n_poses, out);
 }
 
-void launch_lm_report(const double *scal2, const double *cost_cur, const int *status, double *host_pin, hipStream_t s)
+void launch_lm_report(const double *scal2, const double *q1_part, int n_q1, const double *cost_cur, const int *status, double *host_pin,
+                      hipStream_t s)
 {
-    hipLaunchKernelGGL(lm_report_kernel, dim3(1), dim3(64), 0, s, scal2, cost_cur, status, host_pin);
+    hipLaunchKernelGGL(lm_report_kernel, dim3(1), dim3(64), 0, s, scal2, q1_part, n_q1, cost_cur, status, host_pin);
+}
+
+int launch_retract_q1(const double *poses, const double *dx, double *out, int n_poses, const double *Hblk, int band_blocks, const double *g,
+                      double u, double *q1_part, hipStream_t s)
+{
+    const int nb = (n_poses + 127) / 128;
+    hipLaunchKernelGGL(retract_q1_kernel, dim3(nb), dim3(128), 0, s, poses, dx, out, n_poses, Hblk, band_blocks, g, u, q1_part);
+    return nb;
 }
 
 void launch_reduce_chunks_groups(const double *chunk_cost, const int64_t *gco, int n_groups, double *out, hipStream_t s)

@@ -134,7 +134,7 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
             }
         }
         const int64_t cols1 = (tw.n1 + 5) / 6, rows2 = P1 > 0 ? n_poses - tw.m / 6 : 0;
-        hipLaunchKernelGGL(ldlt_prepare_band_kernel, dim3((unsigned)std::max(cols1, rows2), (unsigned)((A.ld + 1 + 5 + LVBA_PB_ROWS - 1) / LVBA_PB_ROWS), P1 > 0 ? 2 : 1),
+        hipLaunchKernelGGL(ldlt_prepare_band_kernel, dim3((unsigned)std::max(cols1, rows2), (unsigned)((A.ld + 1 + 5 + LVBA_PB_CHUNKS * LVBA_PB_ROWS - 1) / (LVBA_PB_CHUNKS * LVBA_PB_ROWS)), P1 > 0 ? 2 : 1),
                            dim3(256), 0, s, A, Hblk, band_blocks, n_poses, u_dev, tw, grp);
     } else
         hipMemsetAsync(A.a, 0, P1 > 0 ? (size_t)tw.sA * sizeof(double) + abytes : abytes, s);

@@ -386,7 +386,9 @@ __device__ __forceinline__ void chain_role(double *lds, const LdltMat &M, const 
             W[c * LVBA_W1S + rr] = v;
             W[c * LVBA_W1S + 64 + rr] = (c == rr) ? 1.0 : 0.0;
         }
-    __syncthreads();
+    // (no barrier here: the first diag step reads columns 0 .. 15 only, and those are wavefront 0's own -- a product's result
+    // layout gives wavefront w the columns 16 w .. 16 w + 15 --, so it starts while the others are still writing theirs; the
+    // barrier behind that step inside diag_blocked_factor is the first one anybody needs)
     LVBA_STAMP(A, st_prob, 0, 5);
     diag_blocked_factor(lds, nbn, A.status);
     LVBA_STAMP(A, st_prob, 0, 6);

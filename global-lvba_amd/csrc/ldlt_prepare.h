@@ -61,6 +61,7 @@ __global__ void ldlt_prepare_kernel(LdltMat M, const double *__restrict__ Hblk, 
 // memset: 0.064 + 0.164 ms at C3.)
 #define LVBA_PB_BLOCKS 28
 #define LVBA_PB_ROWS (6 * LVBA_PB_BLOCKS)
+#define LVBA_PB_CHUNKS 4
 __global__ void __launch_bounds__(256)
 ldlt_prepare_band_kernel(LdltMat M, const double *__restrict__ Hblk, int band_blocks, int n_poses,
                          const double *__restrict__ u_dev, LdltTwist tw, const int32_t *__restrict__ grp)
@@ -71,7 +72,14 @@ ldlt_prepare_band_kernel(LdltMat M, const double *__restrict__ Hblk, int band_bl
     const bool second = blockIdx.z != 0;
     const int64_t P = second ? tw.m / 6 + (int64_t)blockIdx.x : (int64_t)blockIdx.x; // block column J (matrix 1) / block row I (matrix 2)
     if (P >= n_poses || (!second && 6 * P >= n1)) return;
-    const int d0 = (int)blockIdx.y * LVBA_PB_BLOCKS; // first block offset dI (matrix 1: I = P + dI) / dJ (matrix 2: J = P - dJ)
+    const double uj = grp ? u_dev[grp[P]] : u_dev[0];
+    const bool dead = uj < 0.0; // a finished group: identity block, see ldlt_prepare_kernel
+    // LVBA_PB_CHUNKS chunks of 28 block offsets per workgroup, one after the other: with one chunk each, C3 launched 41 k workgroups
+    // that wrote 8 KB apiece (0.13 ms for 320 MB: their set-up, not the stores, was the time)
+    for (int yc = 0; yc < LVBA_PB_CHUNKS; ++yc) {
+    const int d0 = ((int)blockIdx.y * LVBA_PB_CHUNKS + yc) * LVBA_PB_BLOCKS; // first block offset dI (matrix 1: I = P + dI) / dJ (matrix 2: J = P - dJ)
+    if (6 * d0 - 5 >= ldab) break; // (block-uniform: nothing of this chunk lies inside the stored offsets)
+    if (yc) __syncthreads();       // everybody is done with the chunk before in LDS
     for (int i = threadIdx.x; i < LVBA_PB_BLOCKS * 36; i += 256) {
         const int bq = i / 36, el = i - 36 * bq;
         const int64_t dd = d0 + bq;
@@ -83,8 +91,6 @@ ldlt_prepare_band_kernel(LdltMat M, const double *__restrict__ Hblk, int band_bl
         blk[i] = v;
     }
     __syncthreads();
-    const double uj = grp ? u_dev[grp[P]] : u_dev[0];
-    const bool dead = uj < 0.0; // a finished group: identity block, see ldlt_prepare_kernel
     for (int idx = threadIdx.x; idx < 6 * LVBA_PB_ROWS; idx += 256) {
         const int e = idx / LVBA_PB_ROWS, t = idx - e * LVBA_PB_ROWS, bq = t / 6, w = t - 6 * bq;
         const int64_t X = 6 * P + e; // the column of matrix 1 / the ORIGINAL row whose entries form a column of matrix 2
@@ -103,6 +109,7 @@ ldlt_prepare_band_kernel(LdltMat M, const double *__restrict__ Hblk, int band_bl
         else if (d == 0) v += uj * v;
         if (!second) M.a[X * (int64_t)ldab + d] = v;
         else M.a[tw.sA + (n - 1 - X) * (int64_t)ldab + d] = v;
+    }
     }
 }
 

@@ -37,7 +37,8 @@ struct lvba_balm_s {
     // pose-major payload
     double *d_clu_csc = nullptr, *d_vrec = nullptr, *d_part = nullptr;
     double *d_pose_in = nullptr, *d_pose_cur = nullptr, *d_pose_trial = nullptr, *d_out = nullptr;
-    double *d_scal2 = nullptr; // [0]=trial cost sum, [1]=q1 numerator
+    double *d_scal2 = nullptr; // [0]=trial cost sum
+    double *d_q1part = nullptr; // per-workgroup shares of the q1 numerator (retract_q1_kernel)
     double *h_pin = nullptr;   // pinned host staging, 16 doubles
     // grouped refinement (lvba_balm_set_groups): independent pose / voxel groups, one LM state each
     int32_t n_groups = 0;
@@ -278,7 +279,7 @@ extern "C" int32_t lvba_balm_destroy(lvba_balm_t h)
     hipSetDevice(h->bs.device);
     if (h->bs.stream) hipStreamSynchronize(h->bs.stream);
     void *ptrs[] = {h->d_voff, h->d_chunk_v0, h->d_pidx, h->d_clu, h->d_chunk_cost, h->d_clu_csc, h->d_vrec, h->d_part,
-                    h->d_pose_in, h->d_pose_cur, h->d_pose_trial, h->d_out, h->d_scal2, h->d_grp_of_pose, h->d_gpo, h->d_gaccept, h->d_gco,
+                    h->d_pose_in, h->d_pose_cur, h->d_pose_trial, h->d_out, h->d_scal2, h->d_q1part, h->d_grp_of_pose, h->d_gpo, h->d_gaccept, h->d_gco,
                     h->d_gscal};
     for (void *p : ptrs)
         if (p) lvba::DevicePool::get().free(p);
@@ -341,6 +342,7 @@ static int32_t finalize(lvba_balm_s *h)
     TRY(bs_dmalloc(bs, &h->d_pose_trial, 12 * (int64_t)N));
     TRY(bs_dmalloc(bs, &h->d_out, 12 * (int64_t)N));
     TRY(bs_dmalloc(bs, &h->d_scal2, 8));
+    TRY(bs_dmalloc(bs, &h->d_q1part, (N + 127) / 128 + 8));
     HIPCHK(hipStreamSynchronize(bs.stream));
     mark("pose-major copy");
     lvba::hvec<int64_t>().swap(h->h_voff);
@@ -658,7 +660,6 @@ extern "C" int32_t lvba_balm_lm_step(lvba_balm_t h, lvba_lm_trace *row, int32_t 
     if (h->lm_done) { if (done) *done = 1; return fail(LVBA_ERR_STATE, "LM loop already finished"); }
     HIPCHK(hipSetDevice(h->bs.device));
     const bool evaluated = h->is_calc_hess;
-    const int64_t n = 6 * (int64_t)h->N;
     // The trial point is costed by the VOXEL PASS of the evaluation (cost + voxel records): an accepted trial point is where the
     // next evaluation happens, and that evaluation then starts from the records (factor pass, pair pass) instead of reading
     // and eigen-decomposing every voxel again.  A rejected step wastes the difference to the cost-only kernel (C3: 0.04 ms).
@@ -666,11 +667,11 @@ extern "C" int32_t lvba_balm_lm_step(lvba_balm_t h, lvba_lm_trace *row, int32_t 
     const bool with_lin = true;
     if (evaluated) TRY(enqueue_eval(h, h->d_pose_cur, with_lin && h->lin_at_cur));         // :688-689
     TRY(enqueue_solve(h, h->u));                                                           // :692-710
-    launch_retract(h->d_pose_cur, h->bs.d_dx, h->d_pose_trial, h->N, h->stream());              // :722-727
-    launch_predicted_decrease(h->bs.Hblk(), h->bs.Bb, h->bs.g(), h->bs.d_dx, h->u, n, h->d_scal2 + 1, h->stream()); // :729
+    const int n_q1 = launch_retract_q1(h->d_pose_cur, h->bs.d_dx, h->d_pose_trial, h->N, h->bs.Hblk(), h->bs.Bb, h->bs.g(), h->u, h->d_q1part,
+                                       h->stream());                                       // :722-729 (retraction + the q1 numerator's shares)
     TRY(enqueue_cost(h, h->d_pose_trial, h->d_scal2, with_lin));                           // :731 (+ the linearisation at the trial point)
     h->lin_at_cur = false; // it belongs to the trial point now
-    launch_lm_report(h->d_scal2, h->bs.scal(), h->bs.d_status, h->h_pin, h->stream()); // -> pinned host memory, zero-copy
+    launch_lm_report(h->d_scal2, h->d_q1part, n_q1, h->bs.scal(), h->bs.d_status, h->h_pin, h->stream()); // -> pinned host memory, zero-copy
     HIPCHK(hipStreamSynchronize(h->stream()));
     ev_collect(h);
     const double Vg = (double)h->Vglobal;

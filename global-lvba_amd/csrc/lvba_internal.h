@@ -173,7 +173,10 @@ void launch_gather_csc(const double *clu, const int32_t *csc_f, int64_t F, doubl
 void launch_retract(const double *poses, const double *dx, double *out, int n_poses, hipStream_t s);
 void launch_predicted_decrease(const double *Hblk, int band_blocks, const double *g, const double *dx, double u,
                                int64_t n, double *out, hipStream_t s);
-void launch_lm_report(const double *scal2, const double *cost_cur, const int *status, double *host_pin, hipStream_t s);
+void launch_lm_report(const double *scal2, const double *q1_part, int n_q1, const double *cost_cur, const int *status, double *host_pin,
+                      hipStream_t s);
+int launch_retract_q1(const double *poses, const double *dx, double *out, int n_poses, const double *Hblk, int band_blocks, const double *g,
+                      double u, double *q1_part, hipStream_t s); // returns the number of q1 shares written
 void launch_export_dense(const double *Hblk, int band_blocks, int n_poses, const int *perm, double *Hd, hipStream_t s);
 void launch_export_vec(const double *v, const int *perm, int n_poses, double *out, hipStream_t s);
 void launch_import_poses(const double *in, const int *perm, int n_poses, double *out, hipStream_t s);

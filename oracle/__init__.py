@@ -122,6 +122,15 @@ class COracle:
                                ctypes.byref(c))
         return H.T, g, c.value
 
+    def dense_to_triplets(self, H, u=0.01):
+        """bavoxel.hpp:692-703 on the dense Hessian eval_dense returned (col-major == row-major: symmetric): the dense D and
+        HessuD = Hess + u D, then the scan of all (6N)^2 entries into a triplet list.  Returns the number of triplets."""
+        n = 6 * self.N
+        Hc = np.ascontiguousarray(H)
+        self.lib.bo_dense_to_triplets.restype = ctypes.c_int64
+        self.lib.bo_dense_to_triplets.argtypes = [ctypes.c_int64, np.ctypeslib.ndpointer(np.float64, flags="C"), ctypes.c_double]
+        return int(self.lib.bo_dense_to_triplets(n, Hc, u))
+
     def eval_sparse(self, poses, nthreads=16, want_blocks=True):
         n = 6 * self.N
         g = np.empty(n)

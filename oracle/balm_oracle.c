@@ -409,6 +409,39 @@ int bo_eval_dense(int n_poses, int64_t V, const int64_t *voff, const int32_t *pi
     return 0;
 }
 
+/* BASELINE.md variant (D), what the reference does with the dense Hessian between divide_thread and the solver
+ * (bavoxel.hpp:692-703): D = diag(Hess) as a dense matrix, HessuD = Hess + u D as a third one, then a scan of all
+ * (6N)^2 entries, row by row over the column-major matrix, pushing the non-zero ones onto a triplet list
+ * (Eigen::Triplet<double>: two ints and a double; std::vector growth by doubling).  H: col-major [n x n].
+ * Returns the number of triplets (-1: out of memory). */
+int64_t bo_dense_to_triplets(int64_t n, const double *H, double u)
+{
+    double *D = calloc((size_t)(n * n), sizeof(double));
+    double *HuD = malloc((size_t)(n * n) * sizeof(double));
+    if (!D || !HuD) { free(D); free(HuD); return -1; }
+    for (int64_t a = 0; a < n; a++) D[a + a * n] = H[a + a * n];          /* :692 */
+    for (int64_t e = 0; e < n * n; e++) HuD[e] = H[e] + u * D[e];          /* :693 */
+    typedef struct { int r, c; double v; } Trip;
+    int64_t cap = 1, cnt = 0;
+    Trip *tl = malloc(sizeof(Trip));
+    for (int64_t a = 0; a < n && tl; a++)                                  /* :697-703 */
+        for (int64_t b = 0; b < n; b++) {
+            const double v = HuD[a + b * n];
+            if (v != 0) {
+                if (cnt == cap) {
+                    Trip *t2 = realloc(tl, (size_t)(2 * cap) * sizeof(Trip));
+                    if (!t2) { free(tl); tl = NULL; break; }
+                    tl = t2; cap *= 2;
+                }
+                tl[cnt].r = (int)a; tl[cnt].c = (int)b; tl[cnt].v = v; cnt++;
+            }
+        }
+    free(D); free(HuD);
+    if (!tl) return -1;
+    free(tl);
+    return cnt;
+}
+
 /* a6, sparse-honest variant (BASELINE.md variant S): same math and slicing, thread-local
  * hash maps of upper 6x6 blocks merged in thread order.  Outputs the merged block list
  * (bi<=bj, 6x6 row-major) if blocks != NULL and cap is large enough; *nblocks always set. */
