@@ -329,10 +329,13 @@ def main():
                 "achieved": bytes_eval / ev_ms / 1e6 if ev_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (bytes_eval / ev_ms / 1e6) / HBM_PEAK_GBS if ev_ms > 0 else None,
                 "traffic": read_traffic("eval", args.config, world, eval_kernels), "traffic_source": TRAFFIC_FILE,
+                "frac_of_real_traffic": None,   # filled below: the bytes the counters saw / avg_ms / peak -- how close to copy speed the passes run on what they really move
                 "algorithmic_bytes": bytes_eval, "avg_ms": ev_ms,
                 "avg_ms_of_evaluations_as_run": ev_ms_measured, "evaluations_on_trial_point_linearisation": reuse,
                 "note": "avg_ms charges every evaluation with its first half: evaluations that start from the linearisation the "
                         "trial-point cost pass left (same kernel, same poses) are counted as their own kernels + one such pass"}
+        if roof["traffic"] and ev_ms > 0:
+            roof["frac_of_real_traffic"] = roof["traffic"] / ev_ms / 1e6 / HBM_PEAK_GBS
         asm_ms = max(ev_ms - ck_ms, 1e-9) if lin else None
         Ql = info["n_pairs"]
         others = [
@@ -342,6 +345,8 @@ def main():
              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_cost / ck_ms / 1e6 / HBM_PEAK_GBS,
              "traffic": read_traffic("cost", args.config, world, cost_kernels), "algorithmic_bytes": bytes_cost, "avg_ms": ck_ms},
         ]
+        if others[0]["traffic"]:
+            others[0]["frac_of_real_traffic"] = others[0]["traffic"] / ck_ms / 1e6 / HBM_PEAK_GBS
         if asm_ms:
             # the rest of an evaluation: factor pass (pose-major) + pair pass + partial-block sum.  Against HBM on what it must
             # read (the clusters) and write (the pose blocks, once), and against the two bounds SURVEY.md 8(d) names for the pair
@@ -922,7 +927,7 @@ def kernel_sets(info):
     return ev, (["balm_voxel_kernel"] if info["trial_linearised"] else ["balm_cost_kernel"])
 
 
-TRAFFIC_FILE = os.path.join("profiles", "traffic_r05.json")
+TRAFFIC_FILE = os.path.join("profiles", "traffic_r06.json")
 KERNEL_SOURCES = ["balm_kernels.hip", "balm_math.h", "lvba_internal.h", "lvba_api.hip", "block_system.hip", "pair_lists.hip",
                   "host_tables.h"]
 

@@ -2,12 +2,12 @@
 # The round's evidence run (gpurun -- 'bash tools/gpu_evidence.sh <git hash> [round tag, default r05]'): (1) the whole GPU suite + smoke, (2) default bench.py, (3) rocprofv3 --kernel-trace --stats of the headline
 # leg, (4) PMC passes of the headline leg: FETCH_SIZE / WRITE_SIZE (-> traffic json; also with LVBA_Y32=1) and the matrix-pipe
 # counters of the solver kernels, (5) C2 and C4 with their parity legs, (6) visual stage, window stage.  Only summaries return.
-TAG=${2:-r05}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG; rm -rf $O; mkdir -p $O
+TAG=${2:-r06}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG; rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
 cd $R
 timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -4 | tee $O/gpu_tests.txt
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 | tee -a $O/gpu_tests.txt
-timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err
+timeout 1200 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 tail -c 300 $O/bench_default.json; echo
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/pb1 -o stats -- python $R/bench.py --no-cpu-baseline --no-visual --no-front-end --no-y32 > $O/bench_headline_under_rocprof.json 2>&1
