@@ -732,13 +732,8 @@ __global__ __launch_bounds__(256, 2) void ldlt_step2_kernel(const Step2Args A)
                 if (pair) bulk_tile_128<4>(lds, M, po, pe, ldz, R0, tj, bst);
                 else bulk_tile_128<2>(lds, M, po, pe, ldz, R0, tj, bst);
 #else
-#ifdef LVBA_BULK_DMA
-                if (pair) { if (bulk_tile_inside<4>(po, pe, R0, tj)) bulk_tile_dma<4>(lds, M, po, pe, ldz, R0, tj); else bulk_tile_128<4>(lds, M, po, pe, ldz, R0, tj); }
-                else { if (bulk_tile_inside<2>(po, pe, R0, tj)) bulk_tile_dma<2>(lds, M, po, pe, ldz, R0, tj); else bulk_tile_128<2>(lds, M, po, pe, ldz, R0, tj); }
-#else
                 if (pair) bulk_tile_128<4>(lds, M, po, pe, ldz, R0, tj);
                 else bulk_tile_128<2>(lds, M, po, pe, ldz, R0, tj);
-#endif
 #endif
             } else {
                 int64_t ti, tj;

@@ -196,142 +196,6 @@ __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, double v, unsig
     const v2u a = {(unsigned)__double2loint(v), (unsigned)__double2hiint(v)};
     __builtin_amdgcn_raw_buffer_store_b64(a, r, voff, soff, 0);
 }
-// ------------------------------------------------------------------------------------ K3, 128 x 64 tiles fed by LDS-DMA (round 6)
-// The same tile, the operands travelling global memory -> LDS without passing through registers (buffer_load_dwordx4 ... lds:
-// one wave instruction moves 1 KB, lane l's 16 bytes landing at M0 + 16 l), K in chunks of 16 columns, TWO chunk buffers:
-//   [C tile -> registers] [DMA 0, DMA 1]  then per chunk c:  wait DMA c | barrier | 32 MFMAs per wave from buffer c & 1 | barrier |
-//   DMA c + 2 into the buffer just read
-// so the only thing between two chunks' products is a pair of barriers: the register form above spends 3.4 of its ~19 us per tile
-// in its four "stage" phases (wait for the fetch, 12 ds_write_b128 per lane, two barriers) with the matrix pipe idle in BOTH
-// workgroups of the CU (they run in lock-step: stamps, round 6).  Only tiles that lie wholly inside both panels' windows take this
-// path (nothing can be masked on the way); the others -- the last tile rows of a window -- keep the register form.
-// Chunk buffer: L as [m][row 0..127], column stride LVBA_TL; Z as eight PAIRS of columns (j, j + 8) -- one instruction fills a
-// pair, lanes 0..31 column j, lanes 32..63 column j + 8, 64 doubles apart -- pair stride LVBA_TL: columns m and m + 1, which one
-// MFMA operand read touches together, stay 16 banks apart.
-#define LVBA_KC 16
-#define LVBA_DL (LVBA_KC * LVBA_TL)
-#define LVBA_DZ (8 * LVBA_TL)
-#define LVBA_DBUF (LVBA_DL + LVBA_DZ)
-// one wave instruction: lane l loads the 16 bytes at (resource base + voff_l + soff) into LDS at lds_byte + 16 l
-__device__ __forceinline__ void dma16(v4u rsrc, unsigned lds_byte, unsigned voff, unsigned soff)
-{
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_byte), "v"(voff), "s"(rsrc), "s"(soff)
-                 : "memory", "m0");
-}
-__device__ __forceinline__ v4u rsrc_words(const double *p)
-{
-    const unsigned long long a = (unsigned long long)p;
-    return (v4u){(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu)),
-                 0xFFFFFFF0u, LVBA_BUF_WORD3};
-}
-template <int nch> // K chunks of 32 as the register form counts them: 2 = one panel, 4 = a pair (pe, then po)
-__device__ __forceinline__ void bulk_tile_dma(double *lds, LdltMat M, const PanelRef po, const PanelRef pe, int64_t ldz64, int64_t R0, int64_t tj)
-{
-    static_assert(2 * LVBA_DBUF <= LVBA_K3_LDS, "two chunk buffers in the step kernel's LDS");
-    constexpr int NC = 2 * nch;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i = lane & 15, kk = lane >> 4;
-    const int64_t r0 = po.w0 + 64 * (R0 + 1), c0 = po.w0 + 64 * (tj + 1);
-    const unsigned ld = (unsigned)M.ld, ldz = (unsigned)ldz64;
-    const __amdgpu_buffer_rsrc_t rA = buf_of(M.a);
-    const v4u wA = rsrc_words(M.a), wZo = rsrc_words(po.Z), wZe = rsrc_words(nch == 4 ? pe.Z : po.Z);
-    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)lds);
-    // the C entries first: they have the whole tile to arrive in
-    double xc[32];
-    const unsigned cvoff = 8u * ((unsigned)i + (unsigned)kk * ld);
-    const unsigned csoff = 8u * ((unsigned)r0 + 32u * w + (unsigned)c0 * ld);
-#pragma unroll
-    for (int cq = 0; cq < 4; ++cq)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const unsigned so = csoff + 8u * (unsigned)(16 * cq + 4 * reg) * ld;
-#pragma unroll
-            for (int tl = 0; tl < 2; ++tl) xc[16 * tl + 4 * cq + reg] = buf_ld(rA, cvoff + 128u * tl, so);
-        }
-    const unsigned lvoff = 16u * (unsigned)lane, zvoff = 16u * (unsigned)(lane & 31) + (unsigned)(lane >> 5) * (64u * ldz);
-    auto issue = [&](int c, int buf) { // chunk c (16 columns) into buffer buf: wavefront w takes L columns w, w + 4, w + 8, w + 12 and Z pairs w, w + 4
-        const bool use_e = nch == 4 && c < 4;
-        const unsigned qk = (unsigned)(use_e ? pe.k : po.k), zr = (unsigned)(c0 - (use_e ? pe.w0 : po.w0)), m0 = 16u * (unsigned)(c & 3);
-        const unsigned lb = lds0 + 8u * (unsigned)(buf * LVBA_DBUF);
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const unsigned m = w + 4u * it;
-            dma16(wA, lb + 8u * m * LVBA_TL, lvoff, 8u * ((unsigned)r0 + (qk + m0 + m) * ld));
-        }
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const unsigned j = w + 4u * it;
-            dma16(use_e ? wZe : wZo, lb + 8u * (LVBA_DL + j * LVBA_TL), zvoff, 8u * (zr + (m0 + j) * ldz));
-        }
-    };
-    d4 acc[2][4];
-#pragma unroll
-    for (int tl = 0; tl < 2; ++tl)
-#pragma unroll
-        for (int cq = 0; cq < 4; ++cq) acc[tl][cq] = (d4){0.0, 0.0, 0.0, 0.0};
-    auto products = [&](int buf) {
-        int lo = 0;
-        asm volatile("" : "+v"(lo)); // (as in the register form: the LDS addresses formed per chunk, not kept across the tile)
-        const double *Ls = lds + buf * LVBA_DBUF + lo, *Zs = Ls + LVBA_DL;
-        double a[2][4], bv[2][2];
-        auto rd = [&](int k0, int q) {
-            const int m = k0 + kk;
-#pragma unroll
-            for (int cq = 0; cq < 4; ++cq) a[q][cq] = Zs[(m & 7) * LVBA_TL + (m >> 3) * 64 + 16 * cq + i];
-#pragma unroll
-            for (int tl = 0; tl < 2; ++tl) bv[q][tl] = Ls[m * LVBA_TL + 32 * w + 16 * tl + i];
-        };
-        rd(0, 0);
-#pragma unroll
-        for (int k0 = 0; k0 < LVBA_KC; k0 += 4) {
-            const int q = (k0 >> 2) & 1;
-            if (k0 + 4 < LVBA_KC) rd(k0 + 4, q ^ 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int tl = 0; tl < 2; ++tl)
-#pragma unroll
-                for (int cq = 0; cq < 4; ++cq) acc[tl][cq] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][cq], bv[q][tl], acc[tl][cq], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    issue(0, 0);
-    issue(1, 1);
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        // chunk c has landed when at most the six instructions of chunk c + 1 are still in flight (the C loads are older than both)
-        if (c + 1 < NC) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        products(c & 1);
-        if (c + 2 < NC) {
-            __syncthreads(); // everybody is done with the buffer
-            issue(c + 2, c & 1);
-        }
-    }
-    const bool below = r0 > c0; // (diagonal tiles: the entries above the diagonal are not stored)
-    const int dd = (int)(c0 - r0), rl0 = 32 * (int)w + i;
-#pragma unroll
-    for (int cq = 0; cq < 4; ++cq)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const unsigned so = csoff + 8u * (unsigned)(16 * cq + 4 * reg) * ld;
-            const int cl = 16 * cq + kk + 4 * reg;
-#pragma unroll
-            for (int tl = 0; tl < 2; ++tl)
-                if (below || rl0 + 16 * tl >= cl + dd) buf_st(rA, xc[16 * tl + 4 * cq + reg] - acc[tl][cq][reg], cvoff + 128u * tl, so);
-        }
-}
-// does the tile lie wholly inside the windows of the panels it takes (block-uniform)?
-template <int nch>
-__device__ __forceinline__ bool bulk_tile_inside(const PanelRef &po, const PanelRef &pe, int64_t R0, int64_t tj)
-{
-    const int64_t r0 = po.w0 + 64 * (R0 + 1), c0 = po.w0 + 64 * (tj + 1);
-    bool in = r0 + 128 <= po.rend && c0 + 64 <= po.rend && po.nbe == 64;
-    if (nch == 4) in = in && r0 + 128 <= pe.rend && c0 + 64 <= pe.rend && pe.nbe == 64;
-    return in;
-}
-
 #ifdef LVBA_STAMPS
 #define LVBA_BSTAMP(m_) do { if (bst && threadIdx.x == 0) bst[m_] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
