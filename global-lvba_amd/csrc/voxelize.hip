@@ -150,6 +150,48 @@ __global__ void vox_win_first_kernel(int64_t R, const uint32_t *__restrict__ roo
     const int w = seg_frame[root_seg[r]] / ws;
     if (r == 0 || seg_frame[root_seg[r - 1]] / ws != w) { win_v0[w] = vox_first[r]; win_f0[w] = fac_first[r]; }
 }
+// The build sizes its next buffers and launches from counts the device has just formed.  Every such read used to be a
+// synchronous copy of its own (sixteen blocking calls per map); now one single-workgroup kernel writes the words of up to six
+// device locations into a slot of the process-wide pinned stage (mempool.h) and the host waits for the stream ONCE per decision
+// point.  No slot to be had: the plain copies.
+struct FetchArgs {
+    const uint32_t *src[6];
+    int words[6], n;
+    uint32_t *dst;
+};
+__global__ void vox_fetch_kernel(FetchArgs a)
+{
+    int base = 0;
+    for (int k = 0; k < a.n; ++k) {
+        for (int i = threadIdx.x; i < a.words[k]; i += blockDim.x) a.dst[base + i] = a.src[k][i];
+        base += a.words[k];
+    }
+}
+struct Fetch {
+    FetchArgs a{};
+    void *host[6];
+    void add(void *h, const void *d, size_t bytes) { host[a.n] = h; a.src[a.n] = (const uint32_t *)d; a.words[a.n] = (int)(bytes / 4); ++a.n; }
+    hipError_t run(hipStream_t s)
+    {
+        size_t total = 0;
+        for (int k = 0; k < a.n; ++k) total += 4 * (size_t)a.words[k];
+        void *slot = lvba::HostStage::get().lock(total);
+        if (!slot) {
+            hipError_t e = hipStreamSynchronize(s);
+            for (int k = 0; k < a.n && e == hipSuccess; ++k) e = lvba::copy_d2h(host[k], a.src[k], 4 * (size_t)a.words[k]);
+            return e;
+        }
+        a.dst = (uint32_t *)slot;
+        vox_fetch_kernel<<<1, 256, 0, s>>>(a);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        const char *q = (const char *)slot;
+        for (int k = 0; k < a.n && e == hipSuccess; ++k) { memcpy(host[k], q, 4 * (size_t)a.words[k]); q += 4 * (size_t)a.words[k]; }
+        lvba::HostStage::get().unlock(slot);
+        return e;
+    }
+};
+__global__ void vox_close_offsets_kernel(int64_t *__restrict__ vox_off_end, const int64_t *__restrict__ fac_total) { *vox_off_end = *fac_total; }
 __global__ void vox_pose_rel_kernel(int64_t F, int32_t *__restrict__ pose_idx, int ws)
 {
     const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -848,8 +890,7 @@ int32_t voxmap_build_impl(lvba_voxmap_s *h, const lvba_scans_s *sc, int frame_be
         HIPCHK(hipGetLastError());
         key_range_reduce_kernel<<<key_range_reduce_grid(n_slots), 256, 0, s>>>(n_slots, d_part.as<int>(), d_err.as<int>() + 1);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(s));
-        HIPCHK(lvba::copy_d2h(h_err, d_err.p, 28));
+        { Fetch f; f.add(h_err, d_err.p, 28); HIPCHK(f.run(s)); }
         if (h_err[0]) return lvba_fail(LVBA_ERR_ARG, "a point is non-finite or its voxel key exceeds +-2^20 after the pose transform");
         h->info.key_ms = now_ms() - t0; t0 = now_ms();
         const KeyPack kp = key_pack_of(h_err + 1);
@@ -860,8 +901,8 @@ int32_t voxmap_build_impl(lvba_voxmap_s *h, const lvba_scans_s *sc, int frame_be
         uint64_t *keys_sorted = key_s.as<uint64_t>(); // the sorted keys in their 3 x 21-bit form
         const unsigned sort_bits = (unsigned)(kp.total + (ws ? wbits : 0));
         if (ws && sort_bits > 64) return lvba_fail(LVBA_ERR_UNSUPPORTED, "joint map: %d key bits + %d window bits", kp.total, wbits);
+        DevBuf k32(s), k32s(s); // (live until the block ends: handing them back earlier would cost a stream round trip)
         if (sort_bits <= 32) {
-            DevBuf k32(s), k32s(s);
             HIPCHK(k32.alloc(4 * P)); HIPCHK(k32s.alloc(4 * P));
             if (ws) key_compress_win_kernel<uint32_t><<<grid_for(P, 256), 256, 0, s>>>(P, key.as<uint64_t>(), rec.as<float4>(), kp, ws, k32.as<uint32_t>());
             else key_compress_kernel<uint32_t><<<grid_for(P, 256), 256, 0, s>>>(P, key.as<uint64_t>(), kp, k32.as<uint32_t>());
@@ -870,7 +911,6 @@ int32_t voxmap_build_impl(lvba_voxmap_s *h, const lvba_scans_s *sc, int frame_be
             vox_gather_kernel<uint32_t><<<grid_for(P, 256), 256, 0, s>>>(P, rec.as<float4>(), idx0.as<uint32_t>(), rec_s.as<float4>(), k32s.as<uint32_t>(), kp,
                                                                          keys_sorted, foff, nfr, heads.as<uint64_t>());
             HIPCHK(hipGetLastError());
-            HIPCHK(hipStreamSynchronize(s)); // (k32 / k32s go back to the pool here)
         } else { // wide maps: 64-bit keys, still only the bits that vary (compressed in place; expanded into the unsorted keys' buffer)
             if (ws) key_compress_win_kernel<uint64_t><<<grid_for(P, 256), 256, 0, s>>>(P, key.as<uint64_t>(), rec.as<float4>(), kp, ws, key.as<uint64_t>());
             else key_compress_kernel<uint64_t><<<grid_for(P, 256), 256, 0, s>>>(P, key.as<uint64_t>(), kp, key.as<uint64_t>());
@@ -884,7 +924,7 @@ int32_t voxmap_build_impl(lvba_voxmap_s *h, const lvba_scans_s *sc, int frame_be
         // ONE inclusive scan numbers roots (high word) and (root, frame) segments (low word)
         TRY(scan_incl<uint64_t>(s, heads.as<uint64_t>(), incl.as<uint64_t>(), (size_t)P));
         uint64_t last = 0;
-        HIPCHK(lvba::copy_d2h(&last, incl.as<uint64_t>() + (P - 1), 8));
+        { Fetch f; f.add(&last, incl.as<uint64_t>() + (P - 1), 8); HIPCHK(f.run(s)); }
         R = (int64_t)(last >> 32); NS = (int64_t)(last & 0xFFFFFFFFull);
         HIPCHK(root_key.alloc(8 * (size_t)R)); HIPCHK(root_seg.alloc(4 * ((size_t)R + 1)));
         HIPCHK(seg_start.alloc(4 * ((size_t)NS + 1))); HIPCHK(seg_root.alloc(4 * (size_t)NS)); HIPCHK(seg_frame.alloc(4 * (size_t)NS));
@@ -892,8 +932,7 @@ int32_t voxmap_build_impl(lvba_voxmap_s *h, const lvba_scans_s *sc, int frame_be
                                                            root_key.as<uint64_t>(), root_seg.as<uint32_t>(), seg_start.as<uint32_t>(),
                                                            seg_root.as<uint32_t>(), seg_frame.as<int32_t>());
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(s));
-    }
+    } // (the work buffers' destructors wait for the stream before the pool takes them back)
     h->info.n_roots = R;
     h->info.sort_ms = now_ms() - t0; t0 = now_ms();
 
@@ -929,8 +968,7 @@ int32_t voxmap_build_impl(lvba_voxmap_s *h, const lvba_scans_s *sc, int frame_be
     TRY(scan_excl<uint32_t>(s, is_split.as<uint32_t>(), split_excl.as<uint32_t>(), (size_t)R + 1));
     TRY(scan_excl<uint32_t>(s, seg_split.as<uint32_t>(), seg_excl.as<uint32_t>(), (size_t)NS + 1));
     uint32_t NRS = 0, NSS = 0;
-    HIPCHK(lvba::copy_d2h(&NRS, split_excl.as<uint32_t>() + R, 4));
-    HIPCHK(lvba::copy_d2h(&NSS, seg_excl.as<uint32_t>() + NS, 4));
+    { Fetch f; f.add(&NRS, split_excl.as<uint32_t>() + R, 4); f.add(&NSS, seg_excl.as<uint32_t>() + NS, 4); HIPCHK(f.run(s)); }
 
     DevBuf split_roots(s), split_segs(s), m1(s), m2(s), cnt(s), base(s), nodecl(s), tmp_count(s), tmp_base(s), tmp_plane(s), tmp_nf(s);
     SplitArgs sa{};
@@ -946,7 +984,7 @@ int32_t voxmap_build_impl(lvba_voxmap_s *h, const lvba_scans_s *sc, int frame_be
         HIPCHK(hipGetLastError());
         TRY(scan_excl<uint32_t>(s, cnt.as<uint32_t>(), base.as<uint32_t>(), (size_t)NSS + 1));
         uint32_t NN = 0;
-        HIPCHK(lvba::copy_d2h(&NN, base.as<uint32_t>() + NSS, 4));
+        { Fetch f; f.add(&NN, base.as<uint32_t>() + NSS, 4); HIPCHK(f.run(s)); }
         HIPCHK(nodecl.alloc(80 * (size_t)NN));
         vox_split_cluster_kernel<<<NSS, 64, 0, s>>>(split_segs.as<uint32_t>(), seg_start.as<uint32_t>(), rec_s.as<float4>(),
                                                     m1.as<uint32_t>(), m2.as<uint64_t>(), base.as<uint32_t>(), nodecl.as<double>());
@@ -974,21 +1012,24 @@ int32_t voxmap_build_impl(lvba_voxmap_s *h, const lvba_scans_s *sc, int frame_be
     TRY(scan_excl<int64_t>(s, n_fac.as<int64_t>(), fac_first.as<int64_t>(), (size_t)R + 1));
     int32_t n_planes = 0, V = 0;
     int64_t F = 0;
-    HIPCHK(lvba::copy_d2h(&n_planes, plane_first.as<int32_t>() + R, 4));
-    HIPCHK(lvba::copy_d2h(&V, vox_first.as<int32_t>() + R, 4));
-    HIPCHK(lvba::copy_d2h(&F, fac_first.as<int64_t>() + R, 8));
-    h->info.n_planes = n_planes; h->info.n_voxels = V; h->info.n_factors = F;
+    Fetch fc;
+    fc.add(&n_planes, plane_first.as<int32_t>() + R, 4);
+    fc.add(&V, vox_first.as<int32_t>() + R, 4);
+    fc.add(&F, fac_first.as<int64_t>() + R, 8);
+    DevBuf wv(s), wf(s);
     if (ws) { // where every window's voxels and factors begin
-        DevBuf wv(s), wf(s);
         HIPCHK(wv.alloc(8 * (size_t)n_win)); HIPCHK(wf.alloc(8 * (size_t)n_win));
         HIPCHK(hipMemsetAsync(wv.p, 0xFF, 8 * (size_t)n_win, s)); HIPCHK(hipMemsetAsync(wf.p, 0xFF, 8 * (size_t)n_win, s));
         vox_win_first_kernel<<<grid_for(R, 256), 256, 0, s>>>(R, root_seg.as<uint32_t>(), seg_frame.as<int32_t>(), ws, vox_first.as<int32_t>(),
                                                               fac_first.as<int64_t>(), wv.as<int64_t>(), wf.as<int64_t>());
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(s));
         h->win_v0.assign((size_t)n_win + 1, 0); h->win_f0.assign((size_t)n_win + 1, 0);
-        HIPCHK(lvba::copy_d2h(h->win_v0.data(), wv.p, 8 * (size_t)n_win));
-        HIPCHK(lvba::copy_d2h(h->win_f0.data(), wf.p, 8 * (size_t)n_win));
+        fc.add(h->win_v0.data(), wv.p, 8 * (size_t)n_win);
+        fc.add(h->win_f0.data(), wf.p, 8 * (size_t)n_win);
+    }
+    HIPCHK(fc.run(s)); // the totals and the windows' first voxels / factors in one round trip
+    h->info.n_planes = n_planes; h->info.n_voxels = V; h->info.n_factors = F;
+    if (ws) {
         h->win_v0[(size_t)n_win] = V; h->win_f0[(size_t)n_win] = F;
         for (int k = n_win - 1; k >= 0; --k) // a window without roots begins (and ends) where the next one begins
             if (h->win_v0[(size_t)k] < 0) { h->win_v0[(size_t)k] = h->win_v0[(size_t)k + 1]; h->win_f0[(size_t)k] = h->win_f0[(size_t)k + 1]; }
@@ -1016,8 +1057,9 @@ int32_t voxmap_build_impl(lvba_voxmap_s *h, const lvba_scans_s *sc, int frame_be
         vox_pose_rel_kernel<<<grid_for(F, 256), 256, 0, s>>>(F, pose_idx.as<int32_t>(), ws);
         HIPCHK(hipGetLastError());
     }
+    vox_close_offsets_kernel<<<1, 1, 0, s>>>(vox_off.as<int64_t>() + V, fac_first.as<int64_t>() + R);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));
-    HIPCHK(lvba::copy_h2d(vox_off.as<int64_t>() + V, &F, 8));
     h->info.write_ms = now_ms() - t0;
 
     h->d_root_key = (uint64_t *)root_key.release();
