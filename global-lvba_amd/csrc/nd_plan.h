@@ -259,10 +259,13 @@ inline NdPlan nd_plan(const uint8_t *adj, int N, const lvba::hvec<int32_t> &perm
     // ---- chunks of the band ordering: what lets several RANKS share a long band (on one GPU the arcs would only share its
     // matrix pipes: nothing to gain over the two-ended band).  K chunks give K + 1 pieces of a path or 2 K arcs of a folded ring:
     // K = ranks / 2 and K = ranks - 1 are the two counts that can give every rank an arc.
-    if (n_ranks >= 2 && (int64_t)Bb_band * 6 <= N) {
+    // LVBA_ND_CHUNK_RANKS=r (measurement only, with LVBA_SOLVER=nd): cut as for r ranks although fewer -- or one -- run the arcs
+    int cr = n_ranks;
+    if (const char *e = getenv("LVBA_ND_CHUNK_RANKS")) cr = std::max(cr, atoi(e));
+    if (cr >= 2 && (int64_t)Bb_band * 6 <= N) {
         const int w = Bb_band; // a chunk of `Bb_band` consecutive positions cuts the band (edges reach at most Bb_band)
-        for (int K : {std::max(1, n_ranks / 2), n_ranks - 1}) {
-            if ((int64_t)K * w * 3 > N || (K == n_ranks - 1 && K == std::max(1, n_ranks / 2))) continue;
+        for (int K : {std::max(1, cr / 2), cr - 1}) {
+            if ((int64_t)K * w * 3 > N || (K == cr - 1 && K == std::max(1, cr / 2))) continue;
             for (int variant = 0; variant < 2; ++variant) {
                 // pieces between the chunks: K + 1 of them.  variant 0: equal pieces; variant 1: the two END pieces half as long
                 // (on a folded ring the inner pieces fall into two arcs each, the end pieces -- around the folds -- do not)
