@@ -185,10 +185,11 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
         }
         return f;
     };
+    static const bool defer_env = !solver_form("nodefer"); // (A / B and tests: the row roles' full form in every phase)
     auto run_phase = [&](int64_t sa, int64_t sb, unsigned ny, bool second, bool close) {
         const int64_t wo = second ? tw.sW : 0;
         std::vector<SchedLaunch> sched;
-        ldlt_schedule_phase(sa, sb, close, true, [&](int64_t st) { return st < nsteps ? geom(st).T : (int64_t)0; }, sched);
+        ldlt_schedule_phase(sa, sb, close, true, [&](int64_t st) { return st < nsteps ? geom(st).T : (int64_t)0; }, sched, close && defer_env);
         auto pg = [&](int64_t st) { const Geo g = geom(st); return PanelGeo{g.k, g.w0, g.rend, g.nbe, (int)g.T}; };
         bool dq_prev_written = false; // did the role launch before this one leave panel q's share of the diagonal block?
         for (const SchedLaunch &L : sched) {
@@ -200,7 +201,7 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
             }
             Step2Args a{};
             a.M = second ? M2 : M; a.sA = tw.sA; a.sW = tw.sW; a.ldz = ldz; a.nprob = (int)ny;
-            a.roles = L.roles; a.has_q = L.has_q; a.do_diag = L.do_diag; a.q_extra = L.q_extra; a.status = status;
+            a.roles = L.roles; a.has_q = L.has_q; a.do_diag = L.do_diag; a.q_extra = L.q_extra; a.defer = L.defer; a.status = status;
             a.dvec = dvec + wo; a.b = b + wo;
             a.stamp_id = L.roles ? (int)L.p : -1; a.stamp_prob = second ? 1 : 0;
             int64_t nwg = 0;
@@ -250,8 +251,13 @@ int32_t ldlt_solve(const LdltMat &A, const double *Hblk, int band_blocks, int n_
                 grid += a.resv_n;
             }
             if (nwg > 0) {
-                if (big) hipLaunchKernelGGL(ldlt_step2_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, a);
-                else hipLaunchKernelGGL(ldlt_step2_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, a);
+                if (a.defer) {
+                    if (big) hipLaunchKernelGGL((ldlt_step2_kernel<true, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
+                    else hipLaunchKernelGGL((ldlt_step2_kernel<false, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
+                } else {
+                    if (big) hipLaunchKernelGGL((ldlt_step2_kernel<true, false>), dim3((unsigned)grid), dim3(256), 0, s, a);
+                    else hipLaunchKernelGGL((ldlt_step2_kernel<false, false>), dim3((unsigned)grid), dim3(256), 0, s, a);
+                }
             }
         }
     };

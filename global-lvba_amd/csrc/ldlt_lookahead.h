@@ -79,6 +79,7 @@ struct Step2Args {
     int64_t sA, sW, ldz;
     int nprob, roles, has_q, do_diag, nbe_next, njobs;
     int q_extra;         // row roles: also A(i, p+2) -= L(i, q) Z(p+2, q)^T (ldlt_schedule.h)
+    int defer;           // the deferred form of the row roles (ldlt_schedule.h; row_role)
     int64_t rend_next;   // row limit of panel p + 1's window
     PanelGeo p, q;
     const double *side_r; // A(p+1, p) as [m][row] (64 x 64, masked like load_panel_tile), read by the row roles
@@ -399,14 +400,20 @@ __device__ __forceinline__ void chain_role(double *lds, const LdltMat &M, const 
 }
 
 // ---------------------------------------------------------------------------------------------- the row role
-// tile row t >= 1 of panel p's window (global tile row i = p + 1 + t)
+// tile row t >= 1 of panel p's window (global tile row i = p + 1 + t).
+// A.defer (ldlt_schedule.h, the two ends of a twisted factorisation): panel q's update of the row's OWN tile, A(i,p) -= L(i,q)
+// Z(p,q)^T, is still to come when the launch starts (`pre`); rows t >= 2 of a launch that is not the phase's last are `lean`: they
+// stop after L(i,p) and panel q's update of block column p + 1 -- panel p's follows at the start of the next launch -- and never
+// form L(p+1,p).
+template <bool dfr> // = A.defer, known when the kernel is compiled: either form alone fits the registers, both side by side spill
 __device__ __forceinline__ void row_role(double *lds, const LdltMat &M, const Step2Args &A, int64_t t_row, const double *__restrict__ Gp,
                                          const double *__restrict__ dvec, double *__restrict__ b, double *__restrict__ Zp,
                                          const double *__restrict__ Zq, const double *__restrict__ side_r, double *__restrict__ side_w,
                                          double *__restrict__ dq_w, int st_prob)
 {
     LVBA_FETCH("s"(A.p.k), "s"(A.p.w0), "s"(A.p.rend), "s"(A.p.nbe), "s"(A.q.k), "s"(A.q.w0), "s"(A.q.rend), "s"(A.q.nbe), "s"(A.has_q), "s"(A.q_extra),
-               "s"(A.qx_helper), "s"(A.nbe_next), "s"(A.rend_next), "s"(A.ldz), "s"(Gp), "s"(dvec), "s"(b), "s"(Zp), "s"(Zq), "s"(side_r), "s"(side_w), "s"(dq_w));
+               "s"(A.qx_helper), "s"(A.nbe_next), "s"(A.rend_next), "s"(A.ldz), "s"(A.do_diag), "s"(Gp), "s"(dvec), "s"(b), "s"(Zp), "s"(Zq),
+               "s"(side_r), "s"(side_w), "s"(dq_w));
     LVBA_STAMP(A, st_prob, (int)t_row, 0);
     double *Ls = lds, *Zs = lds + 64 * LVBA_TS;
     const PanelGeo &p = A.p, &q = A.q;
@@ -414,13 +421,14 @@ __device__ __forceinline__ void row_role(double *lds, const LdltMat &M, const St
     const int64_t r0 = p.w0 + 64 * t_row, r = r0 + row; // this tile row
     const int64_t s0 = p.w0;                             // rows of tile p + 1 = columns of the updated tile
     const bool use_q = A.has_q && r0 < q.rend;           // the row lies inside panel q's window (block-uniform)
+    const bool pre = dfr && use_q;                       // panel q's update of A(i, p) first
+    const bool lean = dfr && A.do_diag && t_row >= 2;
     double va[16], vb[16], ai[16], gp[16];
     double bk = 0.0, dk = 0.0;
     // panel p's operands: requested at once if there is no panel q to apply first, else behind the staging of panel q's tiles
-    // (they arrive under that product; requested together with them, 128 registers of operands were in flight at once and the
+    // (they arrive under a product; requested together with panel q's, 128 registers of operands were in flight at once and the
     // C tile of the q_extra product was spilled as it arrived, one memory round trip after the other)
-    auto load_p = [&]() {
-        load_panel_tile(M, r0, p.k, p.rend, p.nbe, w, row, ai);      // A(i, p)
+    auto load_g = [&]() {
 #pragma unroll
         for (int it = 0; it < 16; ++it) gp[it] = Gp[tid + 256 * it];
         if (tid < p.nbe) { bk = b[p.k + tid]; dk = dvec[p.k + tid]; }
@@ -428,22 +436,51 @@ __device__ __forceinline__ void row_role(double *lds, const LdltMat &M, const St
     if (use_q) {
         load_panel_tile(M, r0, q.k, q.rend, q.nbe, w, row, va);      // L(i, q)
         load_z_tile(Zq, A.ldz, s0, q.w0, q.rend, q.nbe, w, row, vb); // Z(p+1, q)
-    } else
-        load_p();
+    } else { // no panel q to apply first: A(i, p) as the operand it is
+        load_panel_tile(M, r0, p.k, p.rend, p.nbe, w, row, ai);
+        load_g();
+    }
     d4 acc[4], accI[4], acc0[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = accI[t] = acc0[t] = (d4){0.0, 0.0, 0.0, 0.0};
     LVBA_STAMP(A, st_prob, (int)t_row, 8); // (loads requested)
+    // the tile of block column p + 1 in this row: cv[4 t + reg] <-> (r0 + 16 t + i, s0 + 16 w + kk + 4 reg).  Row 1 reads it
+    // as far as the NEXT panel's window reaches (rows the band gains there still hold their original entries): its result is
+    // also the side copy of A(p+2, p+1).
+    const bool mk_side = t_row == 1; // block-uniform
+    const int64_t rlim = mk_side ? A.rend_next : p.rend;
+    double cv[16];
+    auto load_cv = [&]() {
+        load_c_tile(M, r0, s0, w, i, kk, cv);
+        if (!(r0 + 64 <= rlim && s0 + 64 <= rlim)) { // block-uniform: edge tiles
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    cv[4 * t + reg] = (r0 + 16 * t + i < rlim && s0 + 16 * w + kk + 4 * reg < rlim) ? cv[4 * t + reg] : 0.0;
+        }
+    };
     if (use_q) {
+        double ca[16]; // A(i, p) in the products' layout: (r0 + 16 t + i, p.k + 16 w + kk + 4 reg)
+        auto load_p = [&]() { // panel p's operands: requested so that they arrive under the last product before they are needed
+            if constexpr (dfr) load_c_tile(M, r0, p.k, w, i, kk, ca);
+            else load_panel_tile(M, r0, p.k, p.rend, p.nbe, w, row, ai); // (the full form: A(i, p) is complete, an operand as it is)
+            load_g();
+        };
         stage_tile(Ls, va, w, row);
         stage_tile(Zs, vb, w, row);
         LVBA_STAMP(A, st_prob, (int)t_row, 9); // (first tiles there and staged)
         const bool qx = A.q_extra && !(A.qx_helper && t_row == 1); // (row 1's tile of block column p + 2: qx_diag_role, if there is one)
         if (qx) load_z_tile(Zq, A.ldz, s0 + 64, q.w0, q.rend, q.nbe, w, row, vb); // Z(p+2, q)
+        if (pre) load_z_tile(Zq, A.ldz, q.w0, q.w0, q.rend, q.nbe, w, row, va);  // Z(p, q): rows of tile p = columns of panel p
         __syncthreads();
-        if (!qx) load_p();
+        if (!qx && !pre) load_p();
+        if (lean) load_cv();
         tile_product(Ls, Zs, w, i, kk, acc);
         __syncthreads();
+        if (lean) { // block column p + 1 is done for this launch: panel p's share follows at the start of the next one
+            store_c_tile(M, r0, s0, p.rend, p.rend, false, cv, acc, w, i, kk);
+        }
         if (qx) { // block column p + 2 from panel q alone: this row's tile, with L(i, q) still in LDS
             stage_tile(Zs, vb, w, row);
             double c2[16];
@@ -452,16 +489,38 @@ __device__ __forceinline__ void row_role(double *lds, const LdltMat &M, const St
             d4 accx[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) accx[t] = (d4){0.0, 0.0, 0.0, 0.0};
-            load_p();
+            if (!pre) load_p();
             tile_product(Ls, Zs, w, i, kk, accx);
             store_c_tile(M, r0, s0 + 64, q.rend, q.rend, true, c2, accx, w, i, kk);
             __syncthreads();
         }
-    }
-    LVBA_STAMP(A, st_prob, (int)t_row, 1);
+        if constexpr (dfr) { // A(i, p) -= L(i, q) Z(p, q)^T in the products' layout, then as the next product's operand
+            d4 accA[4];
 #pragma unroll
-    for (int it = 0; it < 16; ++it) va[it] = side_r[(w + 4 * it) * 64 + row]; // A(p+1, p), for Z(p+1, p): the side copy
-    stage_tile(Ls, ai, w, row);
+            for (int t = 0; t < 4; ++t) accA[t] = (d4){0.0, 0.0, 0.0, 0.0};
+            stage_tile(Zs, va, w, row);
+            load_p();
+            __syncthreads();
+            tile_product(Ls, Zs, w, i, kk, accA);
+            const bool whole = r0 + 64 <= p.rend && p.nbe == 64; // block-uniform
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const bool in = whole || (r0 + 16 * t + i < p.rend && 16 * w + kk + 4 * reg < p.nbe);
+                    accA[t][reg] = in ? ca[4 * t + reg] - accA[t][reg] : 0.0;
+                }
+            __syncthreads(); // everybody is done with L(i, q) in Ls
+            put_acc(Ls, accA, w, i, kk, nullptr); // A(i, p) as [m][row]
+        } else
+            stage_tile(Ls, ai, w, row);
+    } else
+        stage_tile(Ls, ai, w, row);
+    LVBA_STAMP(A, st_prob, (int)t_row, 1);
+    if (!lean) {
+#pragma unroll
+        for (int it = 0; it < 16; ++it) va[it] = side_r[(w + 4 * it) * 64 + row]; // A(p+1, p), for Z(p+1, p): the side copy
+    }
     stage_tile(Zs, gp, w, row);
     if (tid < 64) {
         pad_at(lds, LVBA_PAD_BK + tid) = bk;
@@ -473,23 +532,25 @@ __device__ __forceinline__ void row_role(double *lds, const LdltMat &M, const St
     tile_product(Ls, Zs, w, i, kk, accI); // L(i, p)
     __syncthreads();
     LVBA_STAMP(A, st_prob, (int)t_row, 3);
+    if (lean) {
+        if (tid < 64) pad_at(lds, LVBA_PAD_YS + tid) = (tid < p.nbe) ? red4(lds, tid) * dk : 0.0;
+        put_acc(Ls, accI, w, i, kk, nullptr); // L(i, p) as [m][row]
+        store_lz_tile(M, p, r0, accI, lds, Zp, A.ldz, w, i, kk); // L(i, p) and Z(i, p) to global memory
+        __syncthreads();
+        LVBA_STAMP(A, st_prob, (int)t_row, 5);
+        double sacc = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sacc += Ls[(16 * w + j) * LVBA_TS + row] * pad_at(lds, LVBA_PAD_YS + 16 * w + j);
+        pad_at(lds, LVBA_PAD_RED + 64 * w + row) = sacc; // (red4 above read these slots before the barrier)
+        __syncthreads();
+        if (tid < 64 && r < p.rend) b[r] -= red4(lds, tid);
+        LVBA_STAMP(A, st_prob, (int)t_row, 7);
+        return;
+    }
     stage_tile(Ls, va, w, row);           // G stays in Zs
     if (tid < 64) pad_at(lds, LVBA_PAD_YS + tid) = (tid < p.nbe) ? red4(lds, tid) * dk : 0.0;
     __syncthreads();
-    // the tile of block column p + 1 in this row: cv[4 t + reg] <-> (r0 + 16 t + i, s0 + 16 w + kk + 4 reg).  Row 1 reads it
-    // as far as the NEXT panel's window reaches (rows the band gains there still hold their original entries): its result is
-    // also the side copy of A(p+2, p+1).
-    const bool mk_side = t_row == 1; // block-uniform
-    const int64_t rlim = mk_side ? A.rend_next : p.rend;
-    double cv[16];
-    load_c_tile(M, r0, s0, w, i, kk, cv);
-    if (!(r0 + 64 <= rlim && s0 + 64 <= rlim)) { // block-uniform: edge tiles
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg)
-                cv[4 * t + reg] = (r0 + 16 * t + i < rlim && s0 + 16 * w + kk + 4 * reg < rlim) ? cv[4 * t + reg] : 0.0;
-    }
+    load_cv();
     tile_product(Ls, Zs, w, i, kk, acc0); // L(p+1, p)
     __syncthreads();
     LVBA_STAMP(A, st_prob, (int)t_row, 4);
@@ -662,7 +723,7 @@ __global__ __launch_bounds__(256, 2) void ldlt_fwd_kernel(LdltMat M, FwdPassenge
 // Block order: the chain workgroups of all problems first, then the row workgroups, then the bulk jobs' workgroups alternating
 // between the problems.  big: 128 x 64 bulk tiles (bulk_tile_128, 32-bit buffer offsets) / 64 x 64 tiles (update_tile[2], 64-bit
 // pointers: matrices of 4 GB and more).  80 KB of LDS: two workgroups per CU.
-template <bool big>
+template <bool big, bool dfr>
 __global__ __launch_bounds__(256, 2) void ldlt_step2_kernel(const Step2Args A)
 {
     __shared__ double lds[LVBA_K3_LDS];
@@ -695,7 +756,7 @@ __global__ __launch_bounds__(256, 2) void ldlt_step2_kernel(const Step2Args A)
             chain_role(lds, M, A, A.Gp + wo, A.Gn + wo, A.dvec + wo, A.b + wo, A.Zp + wo, A.Zq ? A.Zq + wo : nullptr,
                        A.dq_r ? A.dq_r + wo : nullptr, prob + A.stamp_prob);
         else if (bx == Tp) qx_diag_role(lds, M, A, A.Zq ? A.Zq + wo : nullptr);
-        else row_role(lds, M, A, bx, A.Gp + wo, A.dvec + wo, A.b + wo, A.Zp + wo, A.Zq ? A.Zq + wo : nullptr, A.side_r + wo, A.side_w + wo,
+        else row_role<dfr>(lds, M, A, bx, A.Gp + wo, A.dvec + wo, A.b + wo, A.Zp + wo, A.Zq ? A.Zq + wo : nullptr, A.side_r + wo, A.side_w + wo,
                       A.dq_w ? A.dq_w + wo : nullptr, prob + A.stamp_prob);
         return;
     }

@@ -16,6 +16,14 @@
 //     X_{e+2}  pair job    (o + e, tj' in [1, cs)) = block columns e + 4 .. : the first half (at least tj' = 1, 2)
 //     X_{e+3}  pair job    (o + e, tj' >= cs)      the second half, beside the next pair's q_extra products (block column e + 5 < e + 6)
 // Panels left over (an odd count, windows too short to pair) run their whole update as one single job in X_{q+1}.
+//
+// DEFERRED form (round 6; the phases that close early, i.e. the two ends of the twisted factorisation): panel q's update of block
+// column q + 1 moves from the END of X_q -- where every row workgroup had to recompute L(q+1, q), a product that 40 workgroups per
+// problem did alike -- to the START of X_{q+1}, where L(i, q) and Z(q+1, q) are stored operands:
+//     row t >= 2 of X_p ("lean")   A(i,p) -= L(i,q) Z(p,q)^T;  L(i,p) = A(i,p) G_p;  A(i,p+1) -= L(i,q) Z(p+1,q)^T     (3 products)
+//     row 1 of X_p, and every row of the phase's closing launch: the same first product, then the full form (the chain workgroup
+//     of X_{p+1} needs A(p+2, p+1) complete; the Schur complement must be complete when the phase ends)
+// The chain role and the bulk jobs are unchanged.
 #pragma once
 #include <cstdint>
 #include <vector>
@@ -28,6 +36,7 @@ struct SchedLaunch {
     int64_t p;
     int roles, has_q, do_diag, njobs;
     int q_extra; // the row roles also apply panel q = p - 1 to block column p + 2 (q is the first panel of a pair: see below)
+    int defer;   // the deferred form (above)
     SchedJob job[2];
 };
 
@@ -37,7 +46,7 @@ inline int64_t sched_pair_items(int64_t tj, int64_t Tb) { return (Tb - tj + 1) /
 // Schur complement complete on the block columns >= sb and the diagonal block sb NOT factorised (the two ends of the twisted
 // factorisation); else the phase runs to the last panel of the matrix.
 template <class TF>
-void ldlt_schedule_phase(int64_t sa, int64_t sb, bool close, bool rank128, TF Tof, std::vector<SchedLaunch> &out)
+void ldlt_schedule_phase(int64_t sa, int64_t sb, bool close, bool rank128, TF Tof, std::vector<SchedLaunch> &out, bool defer = false)
 {
     auto is_e = [&](int64_t st) { return rank128 && st >= sa && ((st - sa) % 2 == 0) && st + 1 < sb && Tof(st) >= 3 && Tof(st + 1) >= 2; };
     auto is_o = [&](int64_t st) { return st > sa && is_e(st - 1); };
@@ -65,7 +74,7 @@ void ldlt_schedule_phase(int64_t sa, int64_t sb, bool close, bool rank128, TF To
     for (int64_t p = sa; p < sb; ++p) {
         if (Tof(p) == 0) break;
         SchedLaunch L{};
-        L.kind = 1; L.p = p; L.roles = 1; L.has_q = p > sa; L.do_diag = !(close && p == sb - 1);
+        L.kind = 1; L.p = p; L.roles = 1; L.has_q = p > sa; L.do_diag = !(close && p == sb - 1); L.defer = defer ? 1 : 0;
         if (L.has_q) {
             const int64_t q = p - 1;
             if (is_o(q)) { // X_{e+2}: the first half of the pair's rank-128 update (at least its tile columns 1 and 2)

@@ -90,6 +90,7 @@ struct LdltMat {
 //   notwist  plain top-down band factorisation (what bands too short for two ends take)
 //   bulk64   64 x 64 update tiles with 64-bit pointers (what matrices of 4 GB and more take)
 //   nd       nested dissection (ldlt_nd.h) whenever a partition exists, whatever the cost model says;  nond: never
+//   nodefer  the row roles' full form in the two-ended phases as well (ldlt_schedule.h: the deferred form is their default)
 inline bool solver_form(const char *name)
 {
     const char *e = getenv("LVBA_SOLVER");

@@ -105,8 +105,15 @@ struct Model {
                 CHECK(L.has_q == (p > sa), "has_q");
                 for (int64_t t = 0; t < Tof(p); ++t) {
                     const int64_t i = p + 1 + t;
+                    if (L.defer && L.has_q && t >= 1 && i <= q + Tof(q)) { // deferred form: panel q's update of the row's own tile comes first
+                        CHECK(applied[tk(i, p)] == eligible(i, p, q), "tile (%lld,%lld) before its deferred update: wrong set", (long long)i, (long long)p);
+                        needL(i, q);
+                        needL(p, q);
+                        apply(i, p, q);
+                    }
                     CHECK(complete(i, p), "tile (%lld,%lld) becomes L before it is complete", (long long)i, (long long)p);
                     write(i, p);
+                    const bool lean = L.defer && L.do_diag && t >= 2;
                     // block column p + 1 in this row: exactly the panels <= p - 2 so far
                     CHECK(applied[tk(i, p + 1)] == eligible(i, p + 1, p - 1), "tile (%lld,%lld) before the roles of X_%lld: wrong set", (long long)i,
                           (long long)(p + 1), (long long)p);
@@ -120,9 +127,11 @@ struct Model {
                             CHECK(dq_slot[q % 2] == q, "X_%lld's chain finds panel %lld's share in the slot of panel %lld's", (long long)p, (long long)dq_slot[q % 2], (long long)q);
                         }
                     }
-                    if (t >= 1) CHECK(side_copy.count(p) && side_copy[p] < now, "side copy of A(%lld,%lld) missing", (long long)(p + 1), (long long)p);
-                    apply(i, p + 1, p);
-                    write(i, p + 1);
+                    if (!lean) {
+                        if (t >= 1) CHECK(side_copy.count(p) && side_copy[p] < now, "side copy of A(%lld,%lld) missing", (long long)(p + 1), (long long)p);
+                        apply(i, p + 1, p);
+                    }
+                    if (!lean || (L.has_q && i <= q + Tof(q))) write(i, p + 1);
                     if (t == 1) {
                         CHECK(complete(i, p + 1), "side copy taken of an incomplete tile");
                         side_copy[p + 1] = now; dq_made[p] = now;
@@ -184,7 +193,7 @@ struct Model {
 
 static int launches_of(const std::vector<SchedLaunch> &s) { return (int)s.size(); }
 
-static void run_case(int64_t n, int64_t bw, bool twist, bool rank128)
+static void run_case(int64_t n, int64_t bw, bool twist, bool rank128, bool defer)
 {
     // as ldlt_solve: the two ends eliminate P1 panels each when the band allows it, then the middle runs on matrix 1
     int64_t P1 = twist ? (n - bw) / 128 : 0;
@@ -195,7 +204,7 @@ static void run_case(int64_t n, int64_t bw, bool twist, bool rank128)
         Model m(nf, bw);
         m.sa = 0; m.sb = P1; m.close = true;
         std::vector<SchedLaunch> s;
-        lvba::ldlt_schedule_phase(m.sa, m.sb, true, rank128, [&](int64_t st) { return m.Tof(st); }, s);
+        lvba::ldlt_schedule_phase(m.sa, m.sb, true, rank128, [&](int64_t st) { return m.Tof(st); }, s, defer);
         m.run(s);
         total += launches_of(s);
     }
@@ -207,7 +216,7 @@ static void run_case(int64_t n, int64_t bw, bool twist, bool rank128)
         m.run(s);
         total += launches_of(s);
     }
-    printf("n=%lld bw=%lld twist=%d rank128=%d: %d launches, %s\n", (long long)n, (long long)bw, (int)twist, (int)rank128, total,
+    printf("n=%lld bw=%lld twist=%d rank128=%d defer=%d: %d launches, %s\n", (long long)n, (long long)bw, (int)twist, (int)rank128, (int)defer, total,
            g_fail ? "FAILED" : "ok");
 }
 
@@ -217,10 +226,11 @@ int main()
                                 {1000, 999}, {6000, 767}, {6000, 768}, {6000, 769}, {3001, 333}, {60000, 2549}};
     for (auto &c : cases)
         for (int tw = 0; tw < 2; ++tw)
-            for (int r = 0; r < 2; ++r) {
-                run_case(c[0], c[1], tw != 0, r != 0);
-                if (g_fail) { printf("%d check(s) failed\n", g_fail); return 1; }
-            }
+            for (int r = 0; r < 2; ++r)
+                for (int df = 0; df <= tw; ++df) { // (the deferred form exists for the phases that close early)
+                    run_case(c[0], c[1], tw != 0, r != 0, df != 0);
+                    if (g_fail) { printf("%d check(s) failed\n", g_fail); return 1; }
+                }
     printf("ldlt schedule ok\n");
     return 0;
 }

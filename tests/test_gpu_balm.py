@@ -448,7 +448,8 @@ np.save(sys.argv[2], np.concatenate([dx.ravel(), [info["use_band"], info["twist_
 def test_solver_schedules(tmp_path):
     """The band LDL^T (look-ahead schedule: one launch per panel; both ends at once, paired panels, 128 x 64 update tiles) has two
     forms a problem can end up in by its size and shape -- 64 x 64 update tiles with 64-bit addressing (matrices of 4 GB and
-    more; LVBA_SOLVER=bulk64 forces it) and the plain top-down factorisation (bands too short for two ends; LVBA_SOLVER=notwist).
+    more; LVBA_SOLVER=bulk64 forces it) and the plain top-down factorisation (bands too short for two ends; LVBA_SOLVER=notwist);
+    the two ends run the row roles' deferred form, everything else their full form (LVBA_SOLVER=nodefer: the full form everywhere).
     Every form must give the same solution of the same damped system (they differ in summation order only): 4200 unknowns,
     half-bandwidth ~150, enough panels for the two-ended form and the pairing to be active.  (Environment switches are read
     once per process: one subprocess per form.)"""
@@ -458,6 +459,8 @@ def test_solver_schedules(tmp_path):
     script = tmp_path / "run.py"
     script.write_text(_SCHEDULE_SCRIPT)
     variants = [{}, {"LVBA_SOLVER": "bulk64"}, {"LVBA_SOLVER": "notwist"}, {"LVBA_SOLVER": "bulk64,notwist"},
+                # the row roles' full form in the two-ended phases too (default there: the deferred form, ldlt_schedule.h)
+                {"LVBA_SOLVER": "nodefer"}, {"LVBA_SOLVER": "bulk64,nodefer"},
                 # debugging switch: the never-rewritten part of the band store stays zero over repeated solves (no graph)
                 {"LVBA_CHECK_BAND": "1", "LVBA_NO_GRAPH": "1"}]
     out = []
