@@ -14,6 +14,9 @@
 //     row i  (T_p - 1 workgroups) L(i,p) = A(i,p) G_p, Z(i,p); the tile of block column p+1 in its row:
 //                                 A(i,p+1) -= L(i,q) Z(p+1,q)^T + L(i,p) Z(p+1,p)^T, with Z(p+1,p) recomputed from A(p+1,p) and G_p
 //                                 (one product more, nothing exchanged inside the launch)          (4 products)
+//                                 -- the FULL form.  The two ends of a twisted factorisation run the DEFERRED form
+//                                 (ldlt_schedule.h; row_role<true>): panel p's update of block column p+1 waits for the start of
+//                                 X_{p+1}, where its operands are stored ones, and only row 1 recomputes Z(p+1,p) (3 products).
 //                                 A(p+1,p) is read from a SIDE COPY: the chain workgroup turns that tile into L(p+1,p) in place
 //                                 during this very launch.  The copy is written by whoever finished the tile -- row p+1 of
 //                                 X_{p-1} (its block-column-p tile), or the phase's first launch -- into one of two buffers.
@@ -787,7 +790,11 @@ __global__ __launch_bounds__(256, 2) void ldlt_step2_kernel(const Step2Args A)
             if constexpr (big) {
                 int64_t R0, tj;
                 const PanelRef po{ok_, ow0, orend, onbe, Zo}, pe{ek_, ew0, erend, enbe, Ze};
+#ifdef LVBA_BULK_REVERSE // (experiment: the job's tiles in reverse order)
+                if (!pair_decode(nwg - 1 - bx, ca, cb, (int64_t)oT - 1, R0, tj)) return;
+#else
                 if (!pair_decode(bx, ca, cb, (int64_t)oT - 1, R0, tj)) return;
+#endif
 #ifdef LVBA_STAMPS
                 unsigned long long *bst = (A.stamp_id >= 0 && A.stamp_id < LVBA_ST_LAUNCHES && st_bulk < LVBA_ST_BTILES) ? g_lvba_bulk_marks[A.stamp_id][st_bulk] : nullptr;
                 if (pair) bulk_tile_128<4>(lds, M, po, pe, ldz, R0, tj, bst);
