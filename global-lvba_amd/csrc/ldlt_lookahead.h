@@ -790,11 +790,7 @@ __global__ __launch_bounds__(256, 2) void ldlt_step2_kernel(const Step2Args A)
             if constexpr (big) {
                 int64_t R0, tj;
                 const PanelRef po{ok_, ow0, orend, onbe, Zo}, pe{ek_, ew0, erend, enbe, Ze};
-#ifdef LVBA_BULK_REVERSE // (experiment: the job's tiles in reverse order)
-                if (!pair_decode(nwg - 1 - bx, ca, cb, (int64_t)oT - 1, R0, tj)) return;
-#else
                 if (!pair_decode(bx, ca, cb, (int64_t)oT - 1, R0, tj)) return;
-#endif
 #ifdef LVBA_STAMPS
                 unsigned long long *bst = (A.stamp_id >= 0 && A.stamp_id < LVBA_ST_LAUNCHES && st_bulk < LVBA_ST_BTILES) ? g_lvba_bulk_marks[A.stamp_id][st_bulk] : nullptr;
                 if (pair) bulk_tile_128<4>(lds, M, po, pe, ldz, R0, tj, bst);
