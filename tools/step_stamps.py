@@ -54,6 +54,9 @@ def main():
     mbuf = np.zeros(nm, np.uint64)
     assert lib.lvba_debug_bulk_marks(mbuf.ctypes.data, nm) == nm
     marks = mbuf.reshape(NL, NB, 12).astype(np.int64)
+    dump = os.environ.get("LVBA_STAMPS_DUMP") # a .npz with the raw arrays (ticks) for offline analysis
+    if dump:
+        np.savez_compressed(dump, roles=roles, bulk=bulk, marks=marks, tick_mhz=TICK_MHZ)
     for L in picks:
         r, b = roles[L], bulk[L]
         live = r[:, 0] > 0
