@@ -306,7 +306,9 @@ __global__ __launch_bounds__(256) void balm_factor_kernel(BalmDev d, const doubl
             for (int e = 0; e < 6; ++e) acc[21 + e] += gi[e];
         }
         // Y records leave through LDS: a lane-per-record store puts 16 bytes into each of 72 cache lines per instruction
-        // (stride 144 B); transposed, the wavefront's 64 records go out as 9 contiguous 1-KB stores
+        // (stride 144 B); transposed, the wavefront's 64 records go out as 9 contiguous 1-KB stores -- NON-TEMPORAL ones: 1.44 GB
+        // written once and read again only by the next kernel do not belong in L2 (round 6, same box, A / B twice: factor + pair
+        // passes 1.481 / 1.492 -> 1.455 / 1.461 ms; most of it in the pair pass, which no longer starts behind the write-back)
         double *ys = Ys + wv * (64 * 19);
         if (t < b) {
 #pragma unroll
@@ -320,7 +322,9 @@ __global__ __launch_bounds__(256) void balm_factor_kernel(BalmDev d, const doubl
                 const int ch = lane + 64 * r, rec = ch / 5, el = 4 * (ch - 5 * rec);
                 if (rec < nrec) {
                     const double *yr = ys + rec * 19 + el;
-                    yo[ch] = make_float4((float)yr[0], (float)yr[1], el + 2 < 18 ? (float)yr[2] : 0.f, el + 3 < 18 ? (float)yr[3] : 0.f);
+                    typedef float f4v __attribute__((ext_vector_type(4)));
+                    const f4v vv = {(float)yr[0], (float)yr[1], el + 2 < 18 ? (float)yr[2] : 0.f, el + 3 < 18 ? (float)yr[3] : 0.f};
+                    __builtin_nontemporal_store(vv, reinterpret_cast<f4v *>(yo) + ch);
                 }
             }
         } else {
@@ -329,7 +333,11 @@ __global__ __launch_bounds__(256) void balm_factor_kernel(BalmDev d, const doubl
             for (int r = 0; r < 9; ++r) {
                 const int f = 2 * (lane + 64 * r); // flat double index inside the batch
                 const int rec = f / 18, el = f - 18 * rec;
-                if (rec < nrec) yo[lane + 64 * r] = make_double2(ys[rec * 19 + el], ys[rec * 19 + el + 1]);
+                if (rec < nrec) {
+                    typedef double d2v __attribute__((ext_vector_type(2)));
+                    const d2v vv = {ys[rec * 19 + el], ys[rec * 19 + el + 1]};
+                    __builtin_nontemporal_store(vv, reinterpret_cast<d2v *>(yo) + lane + 64 * r);
+                }
             }
         }
     }
